@@ -1,0 +1,231 @@
+"""TEST INFRASTRUCTURE -- ctypes binding of the CPU oracle (oracle/bz2_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product package (rust-compression_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ACTION_RUN, ACTION_FLUSH, ACTION_FINISH = 0, 1, 2
+
+
+class BlockStats(C.Structure):
+    _fields_ = [
+        ("nblock", C.c_uint32), ("block_crc", C.c_uint32), ("orig_ptr", C.c_uint32),
+        ("mtf_count", C.c_uint32), ("in_use_count", C.c_uint32), ("group_num", C.c_uint32),
+        ("n_selectors", C.c_uint32), ("max_len", C.c_uint32), ("lm_tables", C.c_uint32),
+        ("bits", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+PULL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+def build(force=False):
+    """Compile oracle/libbz2oracle.so with gcc (building the checker is not using it)."""
+    so = os.path.join(_HERE, "libbz2oracle.so")
+    src = [os.path.join(_HERE, f) for f in ("bz2_oracle.c", "sais_template.inc")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "libbz2oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        u8p, szp = C.POINTER(C.c_uint8), C.POINTER(C.c_size_t)
+        L.bzo_crc32_bzip2.restype = C.c_uint32
+        L.bzo_crc32_bzip2.argtypes = [C.c_char_p, C.c_size_t]
+        L.bzo_bwt.restype = None
+        L.bzo_bwt.argtypes = [C.c_char_p, C.c_size_t, szp]
+        L.bzo_bwt_shift.restype = C.c_size_t
+        L.bzo_bwt_shift.argtypes = [C.c_char_p, C.c_size_t]
+        L.bzo_ls_types.restype = None
+        L.bzo_ls_types.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, u8p, u8p]
+        L.bzo_make_tab_with_fn.restype = C.c_int
+        L.bzo_make_tab_with_fn.argtypes = [szp, C.c_size_t, C.c_size_t, C.c_int, u8p, szp]
+        L.bzo_canonical_codes.restype = None
+        L.bzo_canonical_codes.argtypes = [u8p, C.c_size_t, C.POINTER(C.c_uint32)]
+        L.bzo_bitwriter_pack.restype = C.c_size_t
+        L.bzo_bitwriter_pack.argtypes = [C.POINTER(C.c_uint32), u8p, C.c_size_t, u8p, C.c_size_t]
+        L.bzo_enc_new.restype = C.c_void_p
+        L.bzo_enc_new.argtypes = [C.c_int]
+        L.bzo_enc_free.restype = None
+        L.bzo_enc_free.argtypes = [C.c_void_p]
+        L.bzo_enc_set_huffman_mode.restype = None
+        L.bzo_enc_set_huffman_mode.argtypes = [C.c_void_p, C.c_int]
+        L.bzo_enc_enable_stats.restype = None
+        L.bzo_enc_enable_stats.argtypes = [C.c_void_p, C.c_int]
+        L.bzo_enc_stats.restype = C.c_size_t
+        L.bzo_enc_stats.argtypes = [C.c_void_p, C.POINTER(BlockStats), C.c_size_t]
+        L.bzo_enc_next.restype = C.c_int
+        L.bzo_enc_next.argtypes = [C.c_void_p, PULL_FN, C.c_void_p, C.c_int, u8p]
+        L.bzo_enc_encode_iter.restype = C.c_long
+        L.bzo_enc_encode_iter.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, u8p, C.c_size_t]
+        L.bzo_encode_buffer.restype = C.c_long
+        L.bzo_encode_buffer.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_size_t, u8p, C.c_size_t,
+                                        C.POINTER(BlockStats), C.c_size_t, szp]
+        L.bzo_encode_bound.restype = C.c_size_t
+        L.bzo_encode_bound.argtypes = [C.c_size_t]
+        L.bzo_rle1_blocks.restype = C.c_size_t
+        L.bzo_rle1_blocks.argtypes = [C.c_int, C.c_char_p, C.c_size_t, u8p, C.c_size_t,
+                                      C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                      C.POINTER(C.c_uint32), C.c_size_t]
+        L.bzo_mtf_zle.restype = C.c_size_t
+        L.bzo_mtf_zle.argtypes = [C.c_char_p, C.c_size_t, szp, C.POINTER(C.c_uint16),
+                                  C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        _LIB = L
+    return _LIB
+
+
+def crc32_bzip2(data: bytes) -> int:
+    return lib().bzo_crc32_bzip2(bytes(data), len(data))
+
+
+def bwt(data: bytes):
+    """Rotation start indices in sorted order (sais.rs:266 `bwt`)."""
+    n = len(data)
+    sa = (C.c_size_t * max(n, 1))()
+    lib().bzo_bwt(bytes(data), n, sa)
+    return list(sa[:n])
+
+
+def bwt_shift(data: bytes) -> int:
+    return lib().bzo_bwt_shift(bytes(data), len(data))
+
+
+def ls_types(data: bytes, shift: int = 0):
+    n = len(data)
+    t = (C.c_uint8 * n)()
+    l = (C.c_uint8 * n)()
+    lib().bzo_ls_types(bytes(data), n, shift, t, l)
+    return [bool(x) for x in t], [bool(x) for x in l]
+
+
+def make_tab_with_fn(freq, lim, mode):
+    """mode 0: plain x+y (`make_table`), mode 1: bzip2's depth-tagged combine.
+    Returns (lengths, took_length_limited_path)."""
+    n = len(freq)
+    f = (C.c_size_t * max(n, 1))(*freq)
+    out = (C.c_uint8 * max(n, 1))()
+    outn = C.c_size_t(0)
+    lm = lib().bzo_make_tab_with_fn(f, n, lim, mode, out, C.byref(outn))
+    return list(out[:outn.value]), bool(lm)
+
+
+def bzip2_code_lengths(freq, lim=17):
+    """`EncoderInner::create_huffman` (bzip2/encoder.rs:641-651)."""
+    w = [max(1, x) << 8 for x in freq]
+    return make_tab_with_fn(w, lim, 1)
+
+
+def canonical_codes(lengths):
+    n = len(lengths)
+    l = (C.c_uint8 * n)(*lengths)
+    code = (C.c_uint32 * n)()
+    lib().bzo_canonical_codes(l, n, code)
+    return [(code[i], lengths[i]) if lengths[i] else None for i in range(n)]
+
+
+def bitwriter_pack(pairs):
+    n = len(pairs)
+    v = (C.c_uint32 * max(n, 1))(*[p[0] for p in pairs])
+    l = (C.c_uint8 * max(n, 1))(*[p[1] for p in pairs])
+    out = (C.c_uint8 * (4 * n + 8))()
+    k = lib().bzo_bitwriter_pack(v, l, n, out, len(out))
+    return bytes(out[:k])
+
+
+def encode(data: bytes, level: int = 9, huffman_mode: int = 0, with_stats: bool = False):
+    """`data.iter().cloned().encode(&mut BZip2Encoder::new(level), Action::Finish).collect()`"""
+    data = bytes(data)
+    cap = lib().bzo_encode_bound(len(data))
+    out = (C.c_uint8 * cap)()
+    if with_stats:
+        scap = len(data) // 1000 + 16
+        st = (BlockStats * scap)()
+        ns = C.c_size_t(0)
+        r = lib().bzo_encode_buffer(level, huffman_mode, data, len(data), out, cap, st, scap, C.byref(ns))
+    else:
+        r = lib().bzo_encode_buffer(level, huffman_mode, data, len(data), out, cap, None, 0, None)
+    if r == -200:
+        raise ValueError("invalid level")  # the reference panics (encoder.rs:59-61)
+    if r < 0:
+        raise RuntimeError("oracle error %d" % r)
+    res = C.string_at(out, r)
+    if with_stats:
+        return res, [st[i].as_dict() for i in range(ns.value)]
+    return res
+
+
+class Encoder:
+    """Mirror of `BZip2Encoder` + `Encoder::next` for streaming/Action tests."""
+
+    def __init__(self, level=9, huffman_mode=0):
+        self._h = lib().bzo_enc_new(level)
+        if not self._h:
+            raise ValueError("invalid level")
+        lib().bzo_enc_set_huffman_mode(self._h, huffman_mode)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().bzo_enc_free(self._h)
+            self._h = None
+
+    def next(self, it, action):
+        """One `Encoder::next` call: returns an int byte or None."""
+        def pull(_ctx):
+            try:
+                return next(it)
+            except StopIteration:
+                return -1
+        b = C.c_uint8(0)
+        r = lib().bzo_enc_next(self._h, PULL_FN(pull), None, action, C.byref(b))
+        if r < 0:
+            raise RuntimeError("CompressionError::Unexpected")
+        return b.value if r == 1 else None
+
+    def encode_iter(self, data: bytes, action) -> bytes:
+        """`data.encode(&mut self, action).collect()` (drains until None)."""
+        data = bytes(data)
+        cap = lib().bzo_encode_bound(len(data)) + 64
+        out = (C.c_uint8 * cap)()
+        r = lib().bzo_enc_encode_iter(self._h, data, len(data), action, out, cap)
+        if r < 0:
+            raise RuntimeError("oracle error %d" % r)
+        return C.string_at(out, r)
+
+
+def rle1_blocks(data: bytes, level: int = 9):
+    data = bytes(data)
+    n = len(data)
+    cap = n + n // 4 + 64
+    rle = (C.c_uint8 * cap)()
+    maxb = n // 50000 + 8
+    be = (C.c_uint64 * maxb)()
+    ie = (C.c_uint64 * maxb)()
+    crcs = (C.c_uint32 * maxb)()
+    nb = lib().bzo_rle1_blocks(level, data, n, rle, cap, be, ie, crcs, maxb)
+    assert nb <= maxb
+    total = be[nb - 1] if nb else 0
+    return C.string_at(rle, total), list(be[:nb]), list(ie[:nb]), list(crcs[:nb])
+
+
+def mtf_zle(block: bytes, sa):
+    block = bytes(block)
+    n = len(block)
+    sa_c = (C.c_size_t * max(n, 1))(*sa)
+    out = (C.c_uint16 * (n + 2))()
+    freq = (C.c_uint32 * 258)()
+    op = C.c_uint32(0)
+    iu = C.c_uint32(0)
+    k = lib().bzo_mtf_zle(block, n, sa_c, out, freq, C.byref(op), C.byref(iu))
+    return list(out[:k]), list(freq), op.value, iu.value

@@ -1,0 +1,37 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def product():
+    """The product package (directory name has a hyphen, hence importlib)."""
+    return importlib.import_module("rust-compression_amd")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as o
+    o.lib()
+    return o
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return product()
+
+
+def sample(i):
+    with open(os.path.join(GOLDEN, "sample%d.ref" % i), "rb") as f:
+        return f.read()
