@@ -1,0 +1,199 @@
+/*
+ * bz2_mi355x.h -- C ABI of the MI355X-native BZip2 block-encode path.
+ *
+ * This is the drop-in boundary for ONE hot path of chalharu/rust-compression:
+ *   `iter.encode(&mut BZip2Encoder::new(level), action)`  (BZip2 encode).
+ * The reference is pure Rust and has no FFI of its own; each entry point below
+ * names the reference interface it replaces (paths relative to the reference
+ * repo).  A Rust shim re-implements `Encoder::next` on top
+ * of these calls; host/compression.hpp is the same shim in C++.
+ *
+ * Plain C types only: pointers, sizes, ints.  No torch / HIP types appear in
+ * any signature; device pointers are `void*`/`const void*` and a HIP stream is
+ * an opaque `void*` (0 = the engine's own stream).
+ *
+ * Results are bit-identical to the reference encoder (checked against the CPU
+ * oracle in oracle/).  There is NO CPU fallback: without a gfx950 device every
+ * compute entry point returns BZ_E_NOGPU.
+ */
+#ifndef BZ2_MI355X_H
+#define BZ2_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes -------------------------------------------------------
+ * 0 = ok.  -1..-3 mirror CompressionError::{DataError,UnexpectedEof,Unexpected}
+ * (src/error.rs:10-15); -4/-5 are BZip2Error::{DataErrorMagicFirst,DataErrorMagic}
+ * (src/bzip2/error.rs:5-11, reserved for the decoder rows).  The encoder can
+ * only fail with BZ_E_UNEXPECTED in the reference (src/bzip2/encoder.rs:623);
+ * HIP failures map to it too. */
+#define BZ_OK 0
+#define BZ_E_DATA (-1)
+#define BZ_E_EOF (-2)
+#define BZ_E_UNEXPECTED (-3)
+#define BZ_E_MAGIC_FIRST (-4)
+#define BZ_E_MAGIC (-5)
+#define BZ_E_PARAM (-6)  /* invalid level: BZip2Encoder::new panics (src/bzip2/encoder.rs:59-61) */
+#define BZ_E_NOGPU (-7)  /* no gfx950 device / HIP runtime unusable: the path fails loudly */
+#define BZ_E_NOMEM (-8)
+#define BZ_E_CAPACITY (-9) /* caller's output buffer too small */
+
+/* src/action.rs:8-13 */
+#define BZ_ACTION_RUN 0
+#define BZ_ACTION_FLUSH 1
+#define BZ_ACTION_FINISH 2
+
+const char *bz_strerror(int code);
+const char *bz_version(void);
+/* number of usable gfx950 devices (0 when none; never initialises a context) */
+int bz_device_count(void);
+
+/* ========================================================================
+ * 1. Streaming encoder context  ==  `BZip2Encoder`  (src/bzip2/encoder.rs:40-49)
+ * ======================================================================== */
+typedef struct bz_enc bz_enc;
+
+/* BZip2Encoder::new(level) (src/bzip2/encoder.rs:58-72).  level 1..=9 else
+ * BZ_E_PARAM (the shim turns that back into the reference's panic).
+ * `device` is the HIP device ordinal.  The GPU is first touched lazily, at the
+ * first call that has work for it. */
+int bz_enc_create(bz_enc **out, int level, int device);
+
+/* The input iterator yielded `n` more bytes (src/bzip2/encoder.rs:80-85,
+ * EncoderInner::next :671-697).  Bytes are copied; complete blocks may be
+ * encoded immediately. */
+int bz_enc_write(bz_enc *e, const uint8_t *in, size_t n);
+
+/* The input iterator returned None while the caller's Action is `action`
+ * (src/bzip2/encoder.rs:86-110 and :129-146): Run = nothing is flushed,
+ * Flush = current block without the pending run, then zero-pad to a byte,
+ * Finish = pending run, last block, trailer, pad.  Runs the reference's
+ * state machine up to the point where `Encoder::next` would return None. */
+int bz_enc_end(bz_enc *e, int action);
+
+/* Output bytes in stream order (the bytes `Encoder::next` hands out,
+ * src/bzip2/encoder.rs:149-157).  Returns the number of bytes copied (0 = none
+ * ready) or a negative status. */
+long bz_enc_read(bz_enc *e, uint8_t *out, size_t cap);
+/* bytes currently readable */
+size_t bz_enc_pending(const bz_enc *e);
+
+void bz_enc_destroy(bz_enc *e);
+
+/* One-shot over host buffers:
+ * `in.iter().cloned().encode(&mut BZip2Encoder::new(level), Action::Finish).collect()`.
+ * *out is malloc'ed by the library; release with bz_free. */
+int bz_encode_buffer(int level, int device, const uint8_t *in, size_t in_len,
+                     uint8_t **out, size_t *out_len);
+void bz_free(void *p);
+
+/* ========================================================================
+ * 2. Device-resident engine (what bz_enc drives; also the bench / multi-GPU
+ *    surface: input and output stay in HBM).
+ *    Stages == src/bzip2/encoder.rs: RLE1+split+CRC (:671-716), write_blockdata
+ *    (:300-639: BWT src/suffix_array/sais.rs:266, MTF src/bzip2/mtf.rs:16-39,
+ *    ZLE :653-669, table selection :370-509, code lengths
+ *    src/huffman/cano_huff_table.rs:198-225, canonical codes
+ *    src/huffman/mod.rs:22-67, emission :527-629) and stream framing
+ *    write_block (:224-291) + BitWriter<Left> (src/bitio/writer.rs:186-243).
+ * ======================================================================== */
+typedef struct bz_gpu_engine bz_gpu_engine;
+
+/* max_blocks_in_flight bounds the workspace (about 26 MB of HBM per 900 KB
+ * block); inputs with more blocks are processed in several batches. */
+int bz_gpu_engine_create(bz_gpu_engine **out, int device, size_t max_blocks_in_flight);
+void bz_gpu_engine_destroy(bz_gpu_engine *g);
+
+/* Upper bound of the .bz2 size for n input bytes (for sizing d_out). */
+size_t bz_encode_bound(size_t n);
+
+/* Whole stream on one GPU: d_in[n] (HBM, 16-byte aligned) -> d_out (HBM,
+ * 4-byte aligned, cap bytes).  *out_len receives the stream length.
+ * Equivalent to the one-shot above minus the PCIe copies. */
+int bz_gpu_encode_device(bz_gpu_engine *g, int level, const void *d_in, size_t n,
+                         void *d_out, size_t cap, size_t *out_len);
+
+/* ---- the same, split into the three steps a multi-GPU job needs ---------- */
+
+/* (a) RLE1 + block split over the whole input (every rank runs it: it is
+ * <2 % of the work and keeps block boundaries a pure function of the input).
+ * mode: BZ_ACTION_FINISH = all chunks, tail block emitted;
+ *       BZ_ACTION_FLUSH  = like FINISH over the bytes given (the caller has
+ *                          already removed the pending run);
+ *       BZ_ACTION_RUN    = only blocks closed by a cut; *consumed tells how
+ *                          many input bytes they cover.
+ * Returns the number of blocks in *n_blocks; *tail_block = 1 when the last of
+ * them is the unfinished tail rather than a block closed by a cut (the
+ * streaming context needs that to replay write_block's call sequence). */
+int bz_gpu_partition(bz_gpu_engine *g, int level, const void *d_in, size_t n, int mode,
+                     size_t *n_blocks, size_t *consumed, int *tail_block);
+
+/* (b) Encode blocks first, first+stride, ... (< n_blocks) of the last
+ * partition.  Each block's bit string (block magic .. last payload bit,
+ * MSB-first) is appended to d_packed as host-endian uint32 words whose bit 31
+ * is the earliest bit, zero padded to a whole word (cap_words words).  For the k-th local block:
+ * h_word_off[k] = first word in d_packed, h_bit_len[k] = length in bits,
+ * h_crc[k] = block CRC.  Arrays are HOST arrays with room for the local
+ * block count ceil((n_blocks-first)/stride). *words_used = words written. */
+int bz_gpu_encode_blocks(bz_gpu_engine *g, size_t first, size_t stride,
+                         void *d_packed, size_t cap_words,
+                         uint64_t *h_word_off, uint64_t *h_bit_len, uint32_t *h_crc,
+                         size_t *words_used);
+
+/* (c) Assemble a stream from block bit strings held in d_packed (in STREAM
+ * order k = 0..n_blocks-1, described by the three host arrays): optional
+ * "BZh<level>" header, blocks back to back at bit granularity, optional
+ * trailer (0x177245385090 + combined CRC) and zero padding to a byte.
+ * `carry_bits` (0..7) bits of `carry_byte` (left aligned) precede the
+ * output -- the BitWriter carry of a previous call; *out_carry_* return the
+ * new carry when no padding is requested.  combined_crc_in/out carry
+ * src/bzip2/encoder.rs:237-238 across calls. */
+int bz_gpu_assemble(bz_gpu_engine *g, int level, size_t n_blocks,
+                    const void *d_packed, const uint64_t *h_word_off,
+                    const uint64_t *h_bit_len, const uint32_t *h_crc,
+                    int write_header, int write_trailer, int pad_to_byte,
+                    unsigned carry_bits, unsigned carry_byte,
+                    uint32_t combined_crc_in, uint32_t *combined_crc_out,
+                    void *d_out, size_t cap, size_t *out_len,
+                    unsigned *out_carry_bits, unsigned *out_carry_byte);
+
+/* Seconds of GPU time spent in the kernels of the last bz_gpu_encode_device /
+ * bz_gpu_encode_blocks call, by stage (HIP events on the engine's stream):
+ * [0] rle1+crc+split [1] bwt [2] mtf+zle [3] huffman [4] emit+assemble [5] total. */
+int bz_gpu_last_timings(bz_gpu_engine *g, double out_seconds[6]);
+/* BWT rounds executed (prefix doubling) and total sorted elements, last call */
+int bz_gpu_last_bwt_stats(bz_gpu_engine *g, uint64_t out[4]);
+
+/* Per-kernel timing of the BWT kernels (HIP events around every launch, on the engine's
+ * stream).  Enable, run encodes, then read: kernel name (all template instances of one
+ * kernel are pooled), launches, summed duration, summed ALGORITHMIC bytes.
+ * bz_gpu_profile_enable also clears the counters. */
+int bz_gpu_profile_enable(bz_gpu_engine *g, int on);
+int bz_gpu_profile_kernels(bz_gpu_engine *g);
+int bz_gpu_profile_get(bz_gpu_engine *g, int idx, const char **name, uint64_t *launches,
+                       double *seconds, uint64_t *algorithmic_bytes);
+
+/* ---- stage probes for the parity tests (device results copied to host) ---- */
+
+/* Rotation order of ONE block (src/suffix_array/sais.rs:266 `bwt`). */
+int bz_gpu_debug_bwt(bz_gpu_engine *g, const uint8_t *h_block, size_t n, uint32_t *h_sa);
+/* Code lengths of one table (EncoderInner::create_huffman,
+ * src/bzip2/encoder.rs:641-651) through the device code. */
+int bz_gpu_debug_code_lengths(bz_gpu_engine *g, const uint32_t *h_freq, size_t alpha,
+                              uint8_t *h_len, int *took_length_limited_path);
+/* Per-block statistics of the last bz_gpu_encode_blocks / encode_device call,
+ * the numbers behind the reference's log::debug! lines
+ * (src/bzip2/encoder.rs:240-243, :360-365): 8 x uint32 per block:
+ * nblock, crc, origPtr, mtf_count, in_use_count, group_num, n_selectors, max_len */
+int bz_gpu_debug_block_stats(bz_gpu_engine *g, uint32_t *h_stats, size_t cap_blocks,
+                             size_t *n_blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BZ2_MI355X_H */

@@ -1,0 +1,346 @@
+"""rust-compression_amd -- MI355X-native BZip2 block-encode path.
+
+Host-side mirror (Python flavour) of the reference's encode interface for this one path:
+
+    reference (Rust)                                   here
+    ------------------------------------------------   ---------------------------------------
+    Action::{Run,Flush,Finish}   src/action.rs:8-13    Action.RUN / FLUSH / FINISH
+    CompressionError             src/error.rs:10-15    CompressionError(kind)
+    BZip2Encoder::new(level)     bzip2/encoder.rs:58   BZip2Encoder(level)   (ValueError = the panic)
+    Encoder::next(iter, action)  traits/encoder.rs:81  BZip2Encoder.next(iter, action) -> int | None
+    iter.encode(&mut enc, act)   traits/encoder.rs:12  encode(iterable, enc, action) -> iterator of ints
+
+Everything below the iterator plumbing happens in the HIP library (csrc/, C ABI in
+include/bz2_mi355x.h) loaded with ctypes.  There is no CPU implementation in this package: if the
+library or a gfx950 device is missing, calls raise.  PyTorch is used only by GpuEngine's callers
+for device memory (tensor.data_ptr()); nothing here imports torch.
+"""
+import ctypes as C
+import enum
+import os
+
+from . import _build
+
+__all__ = ["Action", "CompressionError", "BZip2Encoder", "encode", "compress", "GpuEngine",
+           "build", "lib", "device_count", "encode_bound"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+BZ_OK, BZ_E_DATA, BZ_E_EOF, BZ_E_UNEXPECTED = 0, -1, -2, -3
+BZ_E_PARAM, BZ_E_NOGPU, BZ_E_NOMEM, BZ_E_CAPACITY = -6, -7, -8, -9
+
+
+class Action(enum.IntEnum):
+    """src/action.rs:8-13"""
+    RUN = 0
+    FLUSH = 1
+    FINISH = 2
+
+
+class CompressionError(Exception):
+    """src/error.rs:10-15 (kinds DataError / UnexpectedEof / Unexpected) + this library's own."""
+    KINDS = {BZ_E_DATA: "DataError", BZ_E_EOF: "UnexpectedEof", BZ_E_UNEXPECTED: "Unexpected",
+             BZ_E_NOGPU: "NoGpu", BZ_E_NOMEM: "NoMemory", BZ_E_CAPACITY: "Capacity", BZ_E_PARAM: "Param"}
+
+    def __init__(self, code):
+        self.code = code
+        self.kind = self.KINDS.get(code, "Unexpected")
+        msg = lib().bz_strerror(code).decode() if _LIB is not None else str(code)
+        super().__init__("%s (%d): %s" % (self.kind, code, msg))
+
+
+def build(force=False):
+    """Compile csrc/*.hip for gfx950 into rust-compression_amd/libbz2_mi355x.so (in-tree)."""
+    return _build.build(force=force)
+
+
+EXPORTS = [
+    "bz_strerror", "bz_version", "bz_device_count",
+    "bz_enc_create", "bz_enc_write", "bz_enc_end", "bz_enc_read", "bz_enc_pending", "bz_enc_destroy",
+    "bz_encode_buffer", "bz_free",
+    "bz_gpu_engine_create", "bz_gpu_engine_destroy", "bz_encode_bound", "bz_gpu_encode_device",
+    "bz_gpu_partition", "bz_gpu_encode_blocks", "bz_gpu_assemble", "bz_gpu_last_timings",
+    "bz_gpu_last_bwt_stats", "bz_gpu_profile_enable", "bz_gpu_profile_kernels", "bz_gpu_profile_get",
+    "bz_gpu_debug_bwt", "bz_gpu_debug_code_lengths", "bz_gpu_debug_block_stats",
+]
+
+
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so.7.  Two HIP runtimes in one process do not
+    work (the second sees no GPU), so when torch is installed its copy is loaded first and this
+    library binds to it by soname.  torch itself is NOT imported."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def lib():
+    """Load the HIP library (never falls back to anything else)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = os.path.join(_HERE, "libbz2_mi355x.so")
+    if not os.path.exists(so):
+        so = build()
+    _share_hip_runtime_with_torch()
+    L = C.CDLL(so)
+    vp, sz, szp = C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)
+    u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    L.bz_strerror.restype = C.c_char_p
+    L.bz_strerror.argtypes = [C.c_int]
+    L.bz_version.restype = C.c_char_p
+    L.bz_device_count.restype = C.c_int
+    L.bz_enc_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+    L.bz_enc_write.argtypes = [vp, C.c_char_p, sz]
+    L.bz_enc_end.argtypes = [vp, C.c_int]
+    L.bz_enc_read.restype = C.c_long
+    L.bz_enc_read.argtypes = [vp, u8p, sz]
+    L.bz_enc_pending.restype = sz
+    L.bz_enc_pending.argtypes = [vp]
+    L.bz_enc_destroy.restype = None
+    L.bz_enc_destroy.argtypes = [vp]
+    L.bz_encode_buffer.argtypes = [C.c_int, C.c_int, C.c_char_p, sz, C.POINTER(u8p), szp]
+    L.bz_free.restype = None
+    L.bz_free.argtypes = [vp]
+    L.bz_gpu_engine_create.argtypes = [C.POINTER(vp), C.c_int, sz]
+    L.bz_gpu_engine_destroy.restype = None
+    L.bz_gpu_engine_destroy.argtypes = [vp]
+    L.bz_encode_bound.restype = sz
+    L.bz_encode_bound.argtypes = [sz]
+    L.bz_gpu_encode_device.argtypes = [vp, C.c_int, vp, sz, vp, sz, szp]
+    L.bz_gpu_partition.argtypes = [vp, C.c_int, vp, sz, C.c_int, szp, szp, C.POINTER(C.c_int)]
+    L.bz_gpu_encode_blocks.argtypes = [vp, sz, sz, vp, sz, u64p, u64p, u32p, szp]
+    L.bz_gpu_assemble.argtypes = [vp, C.c_int, sz, vp, u64p, u64p, u32p, C.c_int, C.c_int, C.c_int,
+                                  C.c_uint, C.c_uint, C.c_uint32, u32p, vp, sz, szp,
+                                  C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+    L.bz_gpu_last_timings.argtypes = [vp, C.POINTER(C.c_double)]
+    L.bz_gpu_last_bwt_stats.argtypes = [vp, u64p]
+    L.bz_gpu_profile_enable.argtypes = [vp, C.c_int]
+    L.bz_gpu_profile_kernels.argtypes = [vp]
+    L.bz_gpu_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), u64p, C.POINTER(C.c_double), u64p]
+    L.bz_gpu_debug_bwt.argtypes = [vp, C.c_char_p, sz, u32p]
+    L.bz_gpu_debug_code_lengths.argtypes = [vp, u32p, sz, u8p, C.POINTER(C.c_int)]
+    L.bz_gpu_debug_block_stats.argtypes = [vp, u32p, sz, szp]
+    _LIB = L
+    return L
+
+
+def _check(rc):
+    if rc != BZ_OK:
+        raise CompressionError(rc)
+
+
+def device_count():
+    return lib().bz_device_count()
+
+
+def encode_bound(n):
+    return lib().bz_encode_bound(n)
+
+
+class BZip2Encoder:
+    """`BZip2Encoder` (src/bzip2/encoder.rs:40-159) over the C ABI's streaming context."""
+
+    CHUNK = 1 << 20  # bytes pulled from the input iterator per refill
+
+    def __init__(self, level=9, device=0):
+        if level < 1 or level > 9:
+            raise ValueError("invalid level")  # the reference panics (encoder.rs:59-61)
+        self._h = C.c_void_p()
+        _check(lib().bz_enc_create(C.byref(self._h), level, device))
+        self._buf = (C.c_uint8 * 65536)()
+        self._ready = b""
+        self._pos = 0
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _LIB is not None:
+            _LIB.bz_enc_destroy(self._h)
+            self._h = None
+
+    def _refill(self):
+        k = lib().bz_enc_read(self._h, self._buf, len(self._buf))
+        if k < 0:
+            raise CompressionError(k)
+        self._ready = C.string_at(self._buf, k)
+        self._pos = 0
+        return k
+
+    def next(self, it, action):
+        """One `Encoder::next(iter, action)` call: an int byte, or None."""
+        if self._pos >= len(self._ready) and self._refill() == 0:
+            # pull the input (the reference pulls one byte per call; the bytes are the same)
+            while True:
+                chunk = bytearray()
+                for b in it:
+                    chunk.append(b)
+                    if len(chunk) >= self.CHUNK:
+                        break
+                if chunk:
+                    _check(lib().bz_enc_write(self._h, bytes(chunk), len(chunk)))
+                    if lib().bz_enc_pending(self._h):
+                        break
+                if len(chunk) < self.CHUNK:
+                    _check(lib().bz_enc_end(self._h, int(action)))
+                    break
+            if self._refill() == 0:
+                return None
+        b = self._ready[self._pos]
+        self._pos += 1
+        return b
+
+    # bulk helpers (same semantics, fewer Python-level calls)
+    def write(self, data):
+        _check(lib().bz_enc_write(self._h, bytes(data), len(data)))
+
+    def end(self, action):
+        _check(lib().bz_enc_end(self._h, int(action)))
+
+    def read_all(self):
+        out = bytearray(self._ready[self._pos:])
+        self._ready, self._pos = b"", 0
+        while self._refill():
+            out += self._ready
+        self._ready, self._pos = b"", 0
+        return bytes(out)
+
+    def encode_all(self, data, action=Action.FINISH):
+        """`data.encode(&mut self, action).collect()`"""
+        self.write(data)
+        self.end(action)
+        return self.read_all()
+
+
+def encode(iterable, encoder, action):
+    """`EncodeExt::encode` / `EncodeIterator` (src/traits/encoder.rs:12-79)."""
+    it = iter(iterable)
+    while True:
+        b = encoder.next(it, action)
+        if b is None:
+            return
+        yield b
+
+
+def compress(data, level=9, device=0):
+    """One-shot over host buffers (bz_encode_buffer)."""
+    if level < 1 or level > 9:
+        raise ValueError("invalid level")
+    data = bytes(data)
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t(0)
+    _check(lib().bz_encode_buffer(level, device, data, len(data), C.byref(out), C.byref(n)))
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        lib().bz_free(out)
+
+
+class GpuEngine:
+    """Device-resident engine (section 2 of the C ABI).  Pointers are plain ints
+    (e.g. torch.Tensor.data_ptr())."""
+
+    STAGES = ("rle1_crc_split", "bwt", "mtf_zle", "huffman", "emit_assemble", "total")
+
+    def __init__(self, device=0, max_blocks_in_flight=64):
+        self._h = C.c_void_p()
+        _check(lib().bz_gpu_engine_create(C.byref(self._h), device, max_blocks_in_flight))
+
+    def close(self):
+        if getattr(self, "_h", None) and _LIB is not None:
+            _LIB.bz_gpu_engine_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def encode_device(self, level, d_in, n, d_out, cap):
+        out_len = C.c_size_t(0)
+        _check(lib().bz_gpu_encode_device(self._h, level, d_in, n, d_out, cap, C.byref(out_len)))
+        return out_len.value
+
+    def partition(self, level, d_in, n, mode=Action.FINISH):
+        nb, cons, tail = C.c_size_t(0), C.c_size_t(0), C.c_int(0)
+        _check(lib().bz_gpu_partition(self._h, level, d_in, n, int(mode), C.byref(nb), C.byref(cons), C.byref(tail)))
+        return nb.value, cons.value, tail.value
+
+    def encode_blocks(self, first, stride, n_blocks, d_packed, cap_words):
+        k = max(0, (n_blocks - first + stride - 1) // stride) if n_blocks > first else 0
+        woff = (C.c_uint64 * max(k, 1))()
+        blen = (C.c_uint64 * max(k, 1))()
+        crc = (C.c_uint32 * max(k, 1))()
+        used = C.c_size_t(0)
+        _check(lib().bz_gpu_encode_blocks(self._h, first, stride, d_packed, cap_words, woff, blen, crc, C.byref(used)))
+        return list(woff[:k]), list(blen[:k]), list(crc[:k]), used.value
+
+    def assemble(self, level, d_packed, word_off, bit_len, crc, d_out, cap, header=True, trailer=True, pad=True,
+                 carry_bits=0, carry_byte=0, combined_crc=0):
+        k = len(word_off)
+        woff = (C.c_uint64 * max(k, 1))(*word_off)
+        blen = (C.c_uint64 * max(k, 1))(*bit_len)
+        crcs = (C.c_uint32 * max(k, 1))(*crc)
+        out_len, comb = C.c_size_t(0), C.c_uint32(0)
+        ocb, ocy = C.c_uint(0), C.c_uint(0)
+        _check(lib().bz_gpu_assemble(self._h, level, k, d_packed, woff, blen, crcs, int(header), int(trailer), int(pad),
+                                     carry_bits, carry_byte, combined_crc, C.byref(comb), d_out, cap,
+                                     C.byref(out_len), C.byref(ocb), C.byref(ocy)))
+        return out_len.value, comb.value, ocb.value, ocy.value
+
+    def timings(self):
+        t = (C.c_double * 6)()
+        _check(lib().bz_gpu_last_timings(self._h, t))
+        return dict(zip(self.STAGES, t))
+
+    def profile(self, on=True):
+        _check(lib().bz_gpu_profile_enable(self._h, int(on)))
+
+    def kernel_profile(self):
+        """{kernel: {launches, seconds, bytes}} accumulated since profile(True)."""
+        out = {}
+        for i in range(lib().bz_gpu_profile_kernels(self._h)):
+            name, n, s, b = C.c_char_p(), C.c_uint64(0), C.c_double(0), C.c_uint64(0)
+            _check(lib().bz_gpu_profile_get(self._h, i, C.byref(name), C.byref(n), C.byref(s), C.byref(b)))
+            out[name.value.decode()] = {"launches": n.value, "seconds": s.value, "bytes": b.value}
+        return out
+
+    def bwt_stats(self):
+        s = (C.c_uint64 * 4)()
+        _check(lib().bz_gpu_last_bwt_stats(self._h, s))
+        return {"rounds": s[0], "resorted_elements": s[1], "batches": s[2]}
+
+    def block_stats(self):
+        n = C.c_size_t(0)
+        _check(lib().bz_gpu_debug_block_stats(self._h, None, 0, C.byref(n)))
+        buf = (C.c_uint32 * (8 * max(n.value, 1)))()
+        _check(lib().bz_gpu_debug_block_stats(self._h, buf, n.value, C.byref(n)))
+        keys = ("nblock", "block_crc", "orig_ptr", "mtf_count", "in_use_count", "group_num", "n_selectors")
+        out = []
+        for i in range(n.value):
+            d = dict(zip(keys, buf[i * 8:i * 8 + 7]))
+            d["max_len"] = buf[i * 8 + 7] & 0xFFFF
+            d["lm_tables"] = buf[i * 8 + 7] >> 16
+            out.append(d)
+        return out
+
+    # stage probes
+    def debug_bwt(self, block):
+        block = bytes(block)
+        sa = (C.c_uint32 * len(block))()
+        _check(lib().bz_gpu_debug_bwt(self._h, block, len(block), sa))
+        return list(sa)
+
+    def debug_code_lengths(self, freq):
+        n = len(freq)
+        f = (C.c_uint32 * n)(*freq)
+        out = (C.c_uint8 * n)()
+        lm = C.c_int(0)
+        _check(lib().bz_gpu_debug_code_lengths(self._h, f, n, out, C.byref(lm)))
+        return list(out), bool(lm.value)

@@ -1,0 +1,54 @@
+"""Builds the HIP shared library (gfx950 only) in-tree: rust-compression_amd/libbz2_mi355x.so."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(HERE, "libbz2_mi355x.so")
+SOURCES = ["k_rle1.hip", "k_bwt.hip", "k_mtf.hip", "k_huff.hip", "k_emit.hip", "engine.hip", "capi.hip"]
+HEADERS = ["bzgpu.h", os.path.join("..", "..", "include", "bz2_mi355x.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-D__HIP_PLATFORM_AMD__"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    deps_h = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    procs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(HERE, "build", s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + deps_h):
+            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = False
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write("hipcc failed on %s:\n%s\n" % (s, out.decode(errors="replace")))
+        elif verbose and out:
+            sys.stderr.write(out.decode(errors="replace"))
+    if failed:
+        raise RuntimeError("HIP build failed")
+    if force or procs or _stale(SO, objs):
+        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", SO] + objs
+        subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,269 @@
+// bzgpu.h -- internal declarations shared by the HIP translation units.
+// gfx950 only: wave64, 160 KiB LDS/CU, 256 CUs in 8 XCDs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace bzgpu {
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int64_t i64;
+
+// ---- sizes (level 9 worst case; lower levels just use less of each slot) ----
+constexpr u32 kWave = 64;
+constexpr u32 kMaxBlockLen = 900000;        // 100000*level, >= n (n <= 100000*level - 19 + 4)
+constexpr u32 kSortTile = 16384;            // elements per radix tile: 16 waves x 16 rows x 64 lanes
+constexpr u32 kSortThreads = 1024;
+constexpr u32 kTilesPerBlock = 55;          // ceil(900000 / 16384)
+constexpr u32 kSlot = kTilesPerBlock * kSortTile; // 901120: per-block stride of the u32 work arrays
+constexpr u32 kMaxBins = 2048;              // 11-bit digits for the initial 32-bit key sort
+constexpr u32 kGSize = 50;                  // BZ_G_SIZE, src/bzip2/mod.rs:20
+constexpr u32 kMaxSelectors = 18002;        // BZ_MAX_SELECTORS, src/bzip2/encoder.rs:295
+constexpr u32 kMaxAlpha = 258;
+constexpr u32 kRleTile = 4096;              // input bytes per RLE1/CRC tile (256 threads x 16 B)
+constexpr u32 kMtfChunk = 256;              // symbols per serial MTF chunk (one lane each)
+constexpr u32 kMaxMtfChunks = (kMaxBlockLen + kMtfChunk - 1) / kMtfChunk; // 3516
+// words reserved per block bit string: header (<= ~27k bits) + 900001 symbols x 17 bits (+ slack)
+constexpr u32 kStreamWords = 480000;        // 1.92 MB
+
+constexpr u32 kFinalBit = 0x80000000u;      // rank word: rotation is alone in its group
+
+// per-block record produced by the partition step (device + host mirror)
+struct BlockDesc {
+    u64 rle_off;   // offset of the block's bytes in the RLE1 image
+    u64 in_off;    // offset of the first input byte the block covers
+    u64 in_end;    // one past the last input byte it covers
+    u32 n;         // post-RLE1 length
+    u32 pad;
+};
+
+// per-block results of the encode step
+struct BlockOut {
+    u32 crc;
+    u32 orig_ptr;
+    u32 in_use_count;
+    u32 mtf_count;
+    u32 group_num;
+    u32 n_selectors;
+    u32 max_len;
+    u32 lm_tables;
+    u32 header_bits;
+    u32 pad;
+    u64 total_bits;
+};
+
+// ---- wave64 primitives -------------------------------------------------------
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ u32 wave_incl_sum(u32 v)
+{
+    const u32 l = lane_id();
+#pragma unroll
+    for (u32 d = 1; d < 64; d <<= 1) {
+        u32 t = __shfl_up(v, d, 64);
+        if (l >= d) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ i64 wave_incl_max64(i64 v)
+{
+    const u32 l = lane_id();
+#pragma unroll
+    for (u32 d = 1; d < 64; d <<= 1) {
+        i64 t = __shfl_up(v, d, 64);
+        if (l >= d && t > v) v = t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int wave_incl_max32(int v)
+{
+    const u32 l = lane_id();
+#pragma unroll
+    for (u32 d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (l >= d && t > v) v = t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ u32 wave_sum(u32 v)
+{
+#pragma unroll
+    for (u32 d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ u32 wave_xor(u32 v)
+{
+#pragma unroll
+    for (u32 d = 32; d >= 1; d >>= 1) v ^= __shfl_xor(v, d, 64);
+    return v;
+}
+
+// XCD-aware remap of a 2-D (tile, block) launch.  Workgroups are dealt
+// round-robin over the 8 XCDs by linear id, so lid%8 names the XCD group.  We
+// hand each XCD group whole blocks (all tiles of a block land on one XCD and
+// its 4 MiB L2 keeps that block's rank array hot for the gathers).
+// Speed only: any placement gives the same result.
+__device__ __forceinline__ void xcd_remap(u32 tiles, u32 nblocks, u32 &tile, u32 &blk)
+{
+    const u32 lid = blockIdx.x + gridDim.x * blockIdx.y;
+    const u32 xcd = lid & 7u;
+    const u32 slot = lid >> 3;
+    const u32 b8 = slot / tiles;         // which group of 8 blocks
+    tile = slot - b8 * tiles;
+    blk = b8 * 8u + xcd;
+    if (blk >= nblocks) blk = 0xFFFFFFFFu;
+}
+// grid.y for such a launch: blocks rounded up to a multiple of 8
+inline u32 xcd_grid_y(u32 nblocks) { return (nblocks + 7u) & ~7u; }
+
+// ---- CRC-32/BZIP2 arithmetic in GF(2)[x] / 0x104C11DB7 ------------------------
+constexpr u32 kCrcPoly = 0x04C11DB7u;
+
+__host__ __device__ inline u32 gf_mulmod(u32 a, u32 b)
+{
+    u32 r = 0;
+#pragma unroll 4
+    for (int i = 31; i >= 0; --i) {
+        r = (r << 1) ^ ((r & 0x80000000u) ? kCrcPoly : 0u);
+        if ((b >> i) & 1u) r ^= a;
+    }
+    return r;
+}
+
+
+// ---- argument blocks shared by the kernels (k_*.hip) and the host code (engine.hip) ----------
+struct RleBuffers {
+    i64 *tile_last;   // [ntiles] last run start inside the tile, -1 if none
+    i64 *carry_in;    // [ntiles] last run start before the tile
+    u32 *tile_crc;    // [ntiles] raw CRC of the tile's bytes
+    u32 *tile_count;  // [ntiles] RLE1 bytes the tile emits
+    u64 *tile_off;    // [ntiles+1] exclusive sum of tile_count
+    u64 *total;       // [1]
+    u64 *cut_result;  // [3] number of blocks, input bytes consumed, tail-block flag
+};
+
+struct BwtArgs {
+    const u8 *rle;
+    const BlockDesc *blocks; // descriptors of the batch's blocks
+    u32 nb;
+    u32 *SA, *R, *KA, *VA, *KB, *VB; // [nb * kSlot]
+    u32 *tile_hist;                  // [nb][kTilesPerBlock][kMaxBins]
+    u32 *count;                      // [nb] length of the compacted pair list
+    u8 *flags;                       // [nb * kSlot]
+    int *tile_last_old;              // [nb][kTilesPerBlock]
+    int *tile_last_new;              // [nb][kTilesPerBlock]
+    u32 *nonfinal;                   // [nb]
+    unsigned long long *active;      // [64] per-round count of non-final rotations in unfinished blocks
+    u32 *per_k, *per_shift;          // [nb] periodic blocks: repetition count, least-rotation start
+};
+
+constexpr u32 kMtfStride = kSlot + 64;
+struct MtfArgs {
+    const BlockDesc *blocks;
+    u32 nb;
+    const u8 *L;             // [nb * kSlot] last column (raw bytes)
+    const u32 *inuse_bits;   // [nb][8]
+    u8 *summ;                // [nb][kMaxMtfChunks][256] recency lists
+    u16 *summ_len;           // [nb][kMaxMtfChunks]
+    u8 *init_state;          // [nb][kMaxMtfChunks][256]
+    u8 *rank8;               // [nb * kSlot]
+    int *ztile_last;         // [nb][kTilesPerBlock] last position with a non-zero rank
+    u32 *ztile_cnt;          // [nb][kTilesPerBlock]
+    u16 *mtf;                // [nb][kMtfStride] output symbols
+    u32 *mtf_freq;           // [nb][kMaxAlpha]
+    BlockOut *out;           // [nb]
+};
+
+constexpr u32 kLim = 17;                       // maxLen, src/bzip2/encoder.rs:504-507
+constexpr u32 kLmRow = 2 * kMaxAlpha + 4;      // >= max_elem[j] for every package-merge row
+constexpr u32 kLmWords = 2 * kLim * kLmRow + 5 * kMaxAlpha + 64; // last kMaxAlpha words: the weights
+constexpr u32 kSelStride = kMaxSelectors + 14;
+constexpr u32 kGboStride = kMaxSelectors + 2;
+struct HuffArgs {
+    const BlockDesc *blocks;
+    u32 nb;
+    const u16 *mtf;        // [nb][kMtfStride]
+    u32 mtf_stride;
+    const u32 *mtf_freq;   // [nb][kMaxAlpha]
+    const u32 *inuse_bits; // [nb][8]
+    const u32 *crc;        // [nb]
+    const u32 *orig_ptr;   // [nb]
+    u8 *selector;          // [nb][kSelStride]
+    u32 *code_len;         // [nb][6][kMaxAlpha]   code | len << 24
+    u32 *group_bitoff;     // [nb][kGboStride]  payload bit offset of each 50-symbol group
+    u32 *lm_scratch;       // [nb][6][kLmWords]
+    u32 *stream;           // [nb][kStreamWords]  block bit string, logical MSB-first words
+    BlockOut *out;         // [nb]
+    u32 *error_flag;       // [1]
+};
+
+struct AsmBlock {
+    u64 src_word;   // first word of the block's bit string in `packed`
+    u64 bit_len;    // bits
+    u64 dst_bit;    // position of its first bit in the output stream
+};
+struct PackBlock {
+    u64 src_word, dst_word, nwords;
+};
+
+// ---- per-kernel timing (HIP events on the launch stream) -------------------------------------------
+// Off by default.  When on, every launch of the listed kernels is bracketed by two events; the
+// records are resolved after the stream is synchronised.  `bytes` is the ALGORITHMIC traffic of the
+// launch ("Kernels and rooflines").
+enum KernelId {
+    KID_RADIX_HIST = 0,
+    KID_RADIX_SCAN,
+    KID_RADIX_SCATTER,
+    KID_GROUP_FLAGS,
+    KID_GROUP_APPLY,
+    KID_LAST_COLUMN,
+    KID_COUNT
+};
+struct KernelProf {
+    bool on = false;
+    struct Rec {
+        int id;
+        u64 bytes;
+        hipEvent_t a, b;
+    };
+    Rec *recs = nullptr;
+    u32 nrecs = 0, cap = 0;
+    // accumulated results
+    u64 launches[KID_COUNT] = {};
+    u64 bytes[KID_COUNT] = {};
+    double seconds[KID_COUNT] = {};
+    int begin(hipStream_t st, int id, u64 nbytes);
+    void end(hipStream_t st, int idx);
+    void collect(); // call after the stream has been synchronised
+    void reset();
+};
+
+// ---- launchers -----------------------------------------------------------------------------------
+void launch_rle1(hipStream_t st, const u8 *d_in, u64 n, const u32 *crc_tab, const u32 *xp16,
+                 const RleBuffers &rb, u8 *d_rle, u32 block_max_len, int emit_tail, BlockDesc *d_blocks,
+                 u32 max_blocks);
+void launch_block_crc(hipStream_t st, const u8 *d_in, const BlockDesc *d_blocks, u32 nblocks,
+                      const u32 *crc_tab, const u32 *xp2, const u32 *tile_crc, u32 *d_crc);
+int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned long long *h_active,
+            u64 *sorted_elems, KernelProf *prof);
+void launch_last_column(hipStream_t st, const BwtArgs &a, u8 *L, u32 *orig_ptr, u32 *inuse_bits, u64 total_n,
+                        KernelProf *prof);
+void launch_mtf(hipStream_t st, const MtfArgs &a);
+void launch_huffman(hipStream_t st, const HuffArgs &a);
+void launch_probe_code_lengths(hipStream_t st, const u32 *d_freq, u32 alpha, u8 *d_out, u32 *lm_scr,
+                               int *d_flag);
+void launch_assemble(hipStream_t st, const u32 *packed, const AsmBlock *d_blocks, u32 n_blocks, u64 max_words,
+                     u32 *out_words);
+void launch_frame(hipStream_t st, u32 *out_words, int write_header, u32 level, u32 carry_bits, u32 carry_byte,
+                  int write_trailer, u64 trailer_bit, u32 combined_crc);
+void launch_pack(hipStream_t st, const u32 *src, const PackBlock *d_pb, u32 n_blocks, u32 *dst);
+
+} // namespace bzgpu

@@ -1,0 +1,663 @@
+// engine.hip -- host orchestration of the device-resident BZip2 block-encode engine and the
+// device half of the C ABI (include/bz2_mi355x.h, section 2).
+//
+// One engine == one GPU == one HIP stream.  Multi-GPU jobs run one process (one engine) per
+// GPU and exchange block bit strings with RCCL outside this library (bench.py,
+// rust-compression_amd/__init__.py); nothing here needs a collective.
+#include "../../include/bz2_mi355x.h"
+#include "bzgpu.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+
+
+using namespace bzgpu;
+
+#define HIPCHK(x)                                                                                     \
+    do {                                                                                              \
+        hipError_t e_ = (x);                                                                          \
+        if (e_ != hipSuccess) {                                                                       \
+            fprintf(stderr, "bz2_mi355x: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__,   \
+                    __LINE__);                                                                        \
+            return BZ_E_UNEXPECTED;                                                                   \
+        }                                                                                             \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return BZ_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            if (hipMalloc(&p, bytes) != hipSuccess) return BZ_E_NOMEM;
+            want = bytes;
+        }
+        cap = want;
+        return BZ_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct bz_gpu_engine {
+    int device = 0;
+    hipStream_t st = nullptr;
+    size_t max_blocks = 0;
+
+    // constant tables
+    DevBuf crc_tab, xp16, xp2;
+    // partition state (sized by the input)
+    DevBuf tile_last, carry_in, tile_crc, tile_count, tile_off, scal, rle, blocks_all, crc_all;
+    std::vector<BlockDesc> h_blocks;
+    std::vector<u32> h_crc;
+    const u8 *d_in = nullptr;
+    u64 n_in = 0;
+    int level = 9;
+    // batch workspace (sized by max_blocks)
+    DevBuf lblocks, lcrc, SA, R, KA, VA, KB, VB, tile_hist, count, flags, tlo, tln, nonfinal, active, per_k,
+        per_shift, L, orig_ptr, inuse_bits, summ, summ_len, init_state, rank8, ztile_last, ztile_cnt, mtf,
+        mtf_freq, bout, selector, code_len, group_bitoff, lm_scratch, stream, error_flag, packlist;
+    bool ws_ready = false;
+    // own packed buffer / assemble list for the single-GPU convenience call
+    DevBuf packed, asmlist;
+    unsigned long long *h_active = nullptr; // pinned
+    // results of the last encode
+    std::vector<BlockOut> h_out;
+    std::vector<u32> h_out_nblock;
+    double t_stage[6] = {0, 0, 0, 0, 0, 0};
+    KernelProf prof;
+    u64 bwt_stats[4] = {0, 0, 0, 0};
+
+    struct Span {
+        int stage;
+        hipEvent_t a, b;
+    };
+    std::vector<Span> spans;
+};
+
+static int span_begin(bz_gpu_engine *g, int stage)
+{
+    bz_gpu_engine::Span s;
+    s.stage = stage;
+    if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return -1;
+    (void)hipEventRecord(s.a, g->st);
+    g->spans.push_back(s);
+    return (int)g->spans.size() - 1;
+}
+static void span_end(bz_gpu_engine *g, int idx)
+{
+    if (idx >= 0) (void)hipEventRecord(g->spans[idx].b, g->st);
+}
+static void spans_collect(bz_gpu_engine *g)
+{
+    (void)hipStreamSynchronize(g->st);
+    g->prof.collect();
+    for (auto &s : g->spans) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) g->t_stage[s.stage] += ms * 1e-3;
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    g->spans.clear();
+    g->t_stage[5] = g->t_stage[0] + g->t_stage[1] + g->t_stage[2] + g->t_stage[3] + g->t_stage[4];
+}
+
+static int ensure_workspace(bz_gpu_engine *g)
+{
+    if (g->ws_ready) return BZ_OK;
+    const size_t nb = g->max_blocks;
+    int rc = BZ_OK;
+#define ENS(buf, bytes)                         \
+    do {                                        \
+        rc = g->buf.ensure((size_t)(bytes));    \
+        if (rc != BZ_OK) return rc;             \
+    } while (0)
+    ENS(lblocks, nb * sizeof(BlockDesc));
+    ENS(lcrc, nb * 4);
+    ENS(SA, nb * (size_t)kSlot * 4);
+    ENS(R, nb * (size_t)kSlot * 4);
+    ENS(KA, nb * (size_t)kSlot * 4);
+    ENS(VA, nb * (size_t)kSlot * 4);
+    ENS(KB, nb * (size_t)kSlot * 4);
+    ENS(VB, nb * (size_t)kSlot * 4);
+    ENS(tile_hist, nb * (size_t)kTilesPerBlock * kMaxBins * 4);
+    ENS(count, nb * 4);
+    ENS(flags, nb * (size_t)kSlot);
+    ENS(tlo, nb * (size_t)kTilesPerBlock * 4);
+    ENS(tln, nb * (size_t)kTilesPerBlock * 4);
+    ENS(nonfinal, nb * 4);
+    ENS(active, 64 * 8);
+    ENS(per_k, nb * 4);
+    ENS(per_shift, nb * 4);
+    ENS(L, nb * (size_t)kSlot + 64);
+    ENS(orig_ptr, nb * 4);
+    ENS(inuse_bits, nb * 32);
+    ENS(summ, nb * (size_t)kMaxMtfChunks * 256);
+    ENS(summ_len, nb * (size_t)kMaxMtfChunks * 2);
+    ENS(init_state, nb * (size_t)kMaxMtfChunks * 256);
+    ENS(rank8, nb * (size_t)kSlot + 64);
+    ENS(ztile_last, nb * (size_t)kTilesPerBlock * 4);
+    ENS(ztile_cnt, nb * (size_t)kTilesPerBlock * 4);
+    ENS(mtf, nb * (size_t)kMtfStride * 2);
+    ENS(mtf_freq, nb * (size_t)kMaxAlpha * 4);
+    ENS(bout, nb * sizeof(BlockOut));
+    ENS(selector, nb * (size_t)kSelStride);
+    ENS(code_len, nb * (size_t)6 * kMaxAlpha * 4);
+    ENS(group_bitoff, nb * (size_t)kGboStride * 4);
+    ENS(lm_scratch, nb * (size_t)6 * kLmWords * 4);
+    ENS(stream, nb * (size_t)kStreamWords * 4);
+    ENS(error_flag, 4);
+    ENS(packlist, nb * sizeof(PackBlock));
+#undef ENS
+    g->ws_ready = true;
+    return BZ_OK;
+}
+
+extern "C" int bz_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" size_t bz_encode_bound(size_t n)
+{
+    // RLE1 expands by at most 5/4; a Huffman code over <= 258 symbols averages < 10 bits;
+    // per block: header + selectors + tables < 24 KiB.
+    return n + n / 2 + (n / 700000 + 2) * 24576 + 64;
+}
+
+extern "C" int bz_gpu_engine_create(bz_gpu_engine **out, int device, size_t max_blocks_in_flight)
+{
+    if (!out) return BZ_E_PARAM;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BZ_E_NOGPU;
+    if (device < 0 || device >= ndev) return BZ_E_PARAM;
+    HIPCHK(hipSetDevice(device));
+    bz_gpu_engine *g = new bz_gpu_engine();
+    g->device = device;
+    g->max_blocks = max_blocks_in_flight ? max_blocks_in_flight : 64;
+    HIPCHK(hipStreamCreateWithFlags(&g->st, hipStreamNonBlocking));
+    HIPCHK(hipHostMalloc((void **)&g->h_active, 64, hipHostMallocDefault));
+
+    // CRC byte table (src/crc32.rs:58-72) and powers of x
+    u32 tab[256], xp16[256], xp2[48];
+    for (u32 i = 0; i < 256; ++i) {
+        u32 v = i << 24;
+        for (int k = 0; k < 8; ++k) v = (v & 0x80000000u) ? ((v << 1) ^ kCrcPoly) : (v << 1);
+        tab[i] = v;
+    }
+    xp2[0] = 0x100u; // x^8
+    for (int k = 1; k < 48; ++k) xp2[k] = gf_mulmod(xp2[k - 1], xp2[k - 1]);
+    xp16[0] = 1u;
+    for (int k = 1; k < 256; ++k) xp16[k] = gf_mulmod(xp16[k - 1], xp2[4]); // * x^(8*16)
+    int rc;
+    if ((rc = g->crc_tab.ensure(sizeof(tab))) || (rc = g->xp16.ensure(sizeof(xp16))) ||
+        (rc = g->xp2.ensure(sizeof(xp2)))) {
+        delete g;
+        return rc;
+    }
+    HIPCHK(hipMemcpy(g->crc_tab.p, tab, sizeof(tab), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(g->xp16.p, xp16, sizeof(xp16), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(g->xp2.p, xp2, sizeof(xp2), hipMemcpyHostToDevice));
+    *out = g;
+    return BZ_OK;
+}
+
+extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
+{
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    (void)hipStreamSynchronize(g->st);
+    DevBuf *all[] = {&g->crc_tab, &g->xp16, &g->xp2, &g->tile_last, &g->carry_in, &g->tile_crc, &g->tile_count,
+                     &g->tile_off, &g->scal, &g->rle, &g->blocks_all, &g->crc_all, &g->lblocks, &g->lcrc, &g->SA,
+                     &g->R, &g->KA, &g->VA, &g->KB, &g->VB, &g->tile_hist, &g->count, &g->flags, &g->tlo, &g->tln,
+                     &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->L, &g->orig_ptr, &g->inuse_bits,
+                     &g->summ, &g->summ_len, &g->init_state, &g->rank8, &g->ztile_last, &g->ztile_cnt, &g->mtf,
+                     &g->mtf_freq, &g->bout, &g->selector, &g->code_len, &g->group_bitoff, &g->lm_scratch,
+                     &g->stream, &g->error_flag, &g->packlist, &g->packed, &g->asmlist};
+    for (DevBuf *b : all) b->release();
+    if (g->h_active) (void)hipHostFree(g->h_active);
+    if (g->st) (void)hipStreamDestroy(g->st);
+    delete g;
+}
+
+extern "C" int bz_gpu_partition(bz_gpu_engine *g, int level, const void *d_in, size_t n, int mode,
+                                size_t *n_blocks, size_t *consumed, int *tail_block)
+{
+    if (!g || level < 1 || level > 9) return BZ_E_PARAM;
+    if (n && ((uintptr_t)d_in & 15u)) return BZ_E_PARAM;
+    HIPCHK(hipSetDevice(g->device));
+    g->level = level;
+    g->d_in = (const u8 *)d_in;
+    g->n_in = n;
+    g->h_blocks.clear();
+    g->h_crc.clear();
+    for (double &t : g->t_stage) t = 0;
+    for (u64 &s : g->bwt_stats) s = 0;
+    if (n_blocks) *n_blocks = 0;
+    if (consumed) *consumed = 0;
+    if (tail_block) *tail_block = 0;
+    if (n == 0) return BZ_OK;
+
+    const u32 block_max_len = (u32)level * 100000u - 19u; // encoder.rs:186
+    const u64 ntiles = (n + kRleTile - 1) / kRleTile;
+    const size_t max_blocks = (size_t)((n + n / 4) / block_max_len + 2);
+    int rc;
+    if ((rc = g->tile_last.ensure(ntiles * 8)) || (rc = g->carry_in.ensure(ntiles * 8)) ||
+        (rc = g->tile_crc.ensure(ntiles * 4)) || (rc = g->tile_count.ensure(ntiles * 4)) ||
+        (rc = g->tile_off.ensure((ntiles + 1) * 8)) || (rc = g->scal.ensure(64)) ||
+        (rc = g->rle.ensure(n + n / 4 + 256)) || (rc = g->blocks_all.ensure(max_blocks * sizeof(BlockDesc))) ||
+        (rc = g->crc_all.ensure(max_blocks * 4)))
+        return rc;
+    RleBuffers rb;
+    rb.tile_last = g->tile_last.as<i64>();
+    rb.carry_in = g->carry_in.as<i64>();
+    rb.tile_crc = g->tile_crc.as<u32>();
+    rb.tile_count = g->tile_count.as<u32>();
+    rb.tile_off = g->tile_off.as<u64>();
+    rb.total = g->scal.as<u64>();
+    rb.cut_result = g->scal.as<u64>() + 2;
+    const int emit_tail = (mode == BZ_ACTION_RUN) ? 0 : 1;
+    const int sp = span_begin(g, 0);
+    launch_rle1(g->st, g->d_in, n, g->crc_tab.as<u32>(), g->xp16.as<u32>(), rb, g->rle.as<u8>(), block_max_len,
+                emit_tail, g->blocks_all.as<BlockDesc>(), (u32)max_blocks);
+    u64 res[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(res, rb.cut_result, sizeof(res), hipMemcpyDeviceToHost, g->st));
+    HIPCHK(hipStreamSynchronize(g->st));
+    const size_t nb = (size_t)res[0];
+    if (nb > max_blocks) return BZ_E_UNEXPECTED;
+    g->h_blocks.resize(nb);
+    g->h_crc.resize(nb);
+    if (nb) {
+        launch_block_crc(g->st, g->d_in, g->blocks_all.as<BlockDesc>(), (u32)nb, g->crc_tab.as<u32>(),
+                         g->xp2.as<u32>(), g->tile_crc.as<u32>(), g->crc_all.as<u32>());
+        HIPCHK(hipMemcpyAsync(g->h_blocks.data(), g->blocks_all.p, nb * sizeof(BlockDesc), hipMemcpyDeviceToHost,
+                              g->st));
+        HIPCHK(hipMemcpyAsync(g->h_crc.data(), g->crc_all.p, nb * 4, hipMemcpyDeviceToHost, g->st));
+    }
+    span_end(g, sp);
+    spans_collect(g);
+    HIPCHK(hipGetLastError());
+    if (n_blocks) *n_blocks = nb;
+    if (consumed) *consumed = (size_t)res[1];
+    if (tail_block) *tail_block = (int)res[2];
+    return BZ_OK;
+}
+
+// encode one batch of local blocks (descriptors already in g->lblocks / g->lcrc)
+static int encode_batch(bz_gpu_engine *g, u32 nb, u32 max_n, u64 total_n)
+{
+    BwtArgs ba;
+    ba.rle = g->rle.as<u8>();
+    ba.blocks = g->lblocks.as<BlockDesc>();
+    ba.nb = nb;
+    ba.SA = g->SA.as<u32>();
+    ba.R = g->R.as<u32>();
+    ba.KA = g->KA.as<u32>();
+    ba.VA = g->VA.as<u32>();
+    ba.KB = g->KB.as<u32>();
+    ba.VB = g->VB.as<u32>();
+    ba.tile_hist = g->tile_hist.as<u32>();
+    ba.count = g->count.as<u32>();
+    ba.flags = g->flags.as<u8>();
+    ba.tile_last_old = g->tlo.as<int>();
+    ba.tile_last_new = g->tln.as<int>();
+    ba.nonfinal = g->nonfinal.as<u32>();
+    ba.active = g->active.as<unsigned long long>();
+    ba.per_k = g->per_k.as<u32>();
+    ba.per_shift = g->per_shift.as<u32>();
+
+    int sp = span_begin(g, 1);
+    u64 sorted = 0;
+    const int rounds = run_bwt(g->st, ba, max_n, total_n, g->h_active, &sorted, &g->prof);
+    if (rounds < 0) return BZ_E_UNEXPECTED;
+    launch_last_column(g->st, ba, g->L.as<u8>(), g->orig_ptr.as<u32>(), g->inuse_bits.as<u32>(), total_n, &g->prof);
+    span_end(g, sp);
+    g->bwt_stats[0] += (u64)rounds;
+    g->bwt_stats[1] += sorted;
+    g->bwt_stats[2] += 1;
+
+    MtfArgs ma;
+    ma.blocks = ba.blocks;
+    ma.nb = nb;
+    ma.L = g->L.as<u8>();
+    ma.inuse_bits = g->inuse_bits.as<u32>();
+    ma.summ = g->summ.as<u8>();
+    ma.summ_len = g->summ_len.as<u16>();
+    ma.init_state = g->init_state.as<u8>();
+    ma.rank8 = g->rank8.as<u8>();
+    ma.ztile_last = g->ztile_last.as<int>();
+    ma.ztile_cnt = g->ztile_cnt.as<u32>();
+    ma.mtf = g->mtf.as<u16>();
+    ma.mtf_freq = g->mtf_freq.as<u32>();
+    ma.out = g->bout.as<BlockOut>();
+    sp = span_begin(g, 2);
+    launch_mtf(g->st, ma);
+    span_end(g, sp);
+
+    HuffArgs ha;
+    ha.blocks = ba.blocks;
+    ha.nb = nb;
+    ha.mtf = g->mtf.as<u16>();
+    ha.mtf_stride = kMtfStride;
+    ha.mtf_freq = g->mtf_freq.as<u32>();
+    ha.inuse_bits = g->inuse_bits.as<u32>();
+    ha.crc = g->lcrc.as<u32>();
+    ha.orig_ptr = g->orig_ptr.as<u32>();
+    ha.selector = g->selector.as<u8>();
+    ha.code_len = g->code_len.as<u32>();
+    ha.group_bitoff = g->group_bitoff.as<u32>();
+    ha.lm_scratch = g->lm_scratch.as<u32>();
+    ha.stream = g->stream.as<u32>();
+    ha.out = g->bout.as<BlockOut>();
+    ha.error_flag = g->error_flag.as<u32>();
+    sp = span_begin(g, 3);
+    launch_huffman(g->st, ha);
+    span_end(g, sp);
+    return BZ_OK;
+}
+
+extern "C" int bz_gpu_encode_blocks(bz_gpu_engine *g, size_t first, size_t stride, void *d_packed,
+                                    size_t cap_words, uint64_t *h_word_off, uint64_t *h_bit_len,
+                                    uint32_t *h_crc, size_t *words_used)
+{
+    if (!g || stride == 0) return BZ_E_PARAM;
+    HIPCHK(hipSetDevice(g->device));
+    if (words_used) *words_used = 0;
+    g->h_out.clear();
+    g->h_out_nblock.clear();
+    const size_t total = g->h_blocks.size();
+    std::vector<size_t> mine;
+    for (size_t b = first; b < total; b += stride) mine.push_back(b);
+    if (mine.empty()) return BZ_OK;
+    int rc = ensure_workspace(g);
+    if (rc != BZ_OK) return rc;
+    HIPCHK(hipMemsetAsync(g->error_flag.p, 0, 4, g->st));
+
+    u64 word_cursor = 0;
+    std::vector<BlockDesc> descs;
+    std::vector<u32> crcs;
+    std::vector<BlockOut> outs;
+    std::vector<PackBlock> pbs;
+    for (size_t k0 = 0; k0 < mine.size(); k0 += g->max_blocks) {
+        const u32 nb = (u32)std::min(g->max_blocks, mine.size() - k0);
+        descs.resize(nb);
+        crcs.resize(nb);
+        u32 max_n = 0;
+        u64 total_n = 0;
+        for (u32 i = 0; i < nb; ++i) {
+            descs[i] = g->h_blocks[mine[k0 + i]];
+            crcs[i] = g->h_crc[mine[k0 + i]];
+            max_n = std::max(max_n, descs[i].n);
+            total_n += descs[i].n;
+            if (descs[i].n > kMaxBlockLen) return BZ_E_UNEXPECTED;
+        }
+        HIPCHK(hipMemcpyAsync(g->lblocks.p, descs.data(), nb * sizeof(BlockDesc), hipMemcpyHostToDevice, g->st));
+        HIPCHK(hipMemcpyAsync(g->lcrc.p, crcs.data(), nb * 4, hipMemcpyHostToDevice, g->st));
+        HIPCHK(hipStreamSynchronize(g->st)); // descs/crcs are reused by the next batch
+        rc = encode_batch(g, nb, max_n, total_n);
+        if (rc != BZ_OK) return rc;
+        outs.resize(nb);
+        u32 err = 0;
+        HIPCHK(hipMemcpyAsync(outs.data(), g->bout.p, nb * sizeof(BlockOut), hipMemcpyDeviceToHost, g->st));
+        HIPCHK(hipMemcpyAsync(&err, g->error_flag.p, 4, hipMemcpyDeviceToHost, g->st));
+        HIPCHK(hipStreamSynchronize(g->st));
+        HIPCHK(hipGetLastError());
+        if (err) return BZ_E_UNEXPECTED;
+        pbs.resize(nb);
+        for (u32 i = 0; i < nb; ++i) {
+            const u64 nwords = (outs[i].total_bits + 31) / 32;
+            pbs[i].src_word = (u64)i * kStreamWords;
+            pbs[i].dst_word = word_cursor;
+            pbs[i].nwords = nwords;
+            h_word_off[k0 + i] = word_cursor;
+            h_bit_len[k0 + i] = outs[i].total_bits;
+            h_crc[k0 + i] = crcs[i];
+            word_cursor += nwords;
+            g->h_out.push_back(outs[i]);
+            g->h_out_nblock.push_back(descs[i].n);
+        }
+        if (word_cursor > cap_words) return BZ_E_CAPACITY;
+        const int sp = span_begin(g, 4);
+        HIPCHK(hipMemcpyAsync(g->packlist.p, pbs.data(), nb * sizeof(PackBlock), hipMemcpyHostToDevice, g->st));
+        launch_pack(g->st, g->stream.as<u32>(), g->packlist.as<PackBlock>(), nb, (u32 *)d_packed);
+        span_end(g, sp);
+        HIPCHK(hipStreamSynchronize(g->st)); // pbs reused
+    }
+    spans_collect(g);
+    HIPCHK(hipGetLastError());
+    if (words_used) *words_used = (size_t)word_cursor;
+    return BZ_OK;
+}
+
+extern "C" int bz_gpu_assemble(bz_gpu_engine *g, int level, size_t n_blocks, const void *d_packed,
+                               const uint64_t *h_word_off, const uint64_t *h_bit_len, const uint32_t *h_crc,
+                               int write_header, int write_trailer, int pad_to_byte, unsigned carry_bits,
+                               unsigned carry_byte, uint32_t combined_crc_in, uint32_t *combined_crc_out,
+                               void *d_out, size_t cap, size_t *out_len, unsigned *out_carry_bits,
+                               unsigned *out_carry_byte)
+{
+    if (!g || level < 1 || level > 9 || carry_bits > 7) return BZ_E_PARAM;
+    if ((uintptr_t)d_out & 3u) return BZ_E_PARAM;
+    HIPCHK(hipSetDevice(g->device));
+    std::vector<AsmBlock> ab(n_blocks);
+    u64 pos = carry_bits + (write_header ? 32u : 0u);
+    u32 comb = combined_crc_in;
+    u64 max_words = 0;
+    for (size_t k = 0; k < n_blocks; ++k) {
+        ab[k].src_word = h_word_off[k];
+        ab[k].bit_len = h_bit_len[k];
+        ab[k].dst_bit = pos;
+        pos += h_bit_len[k];
+        comb = ((comb << 1) | (comb >> 31)) ^ h_crc[k]; // encoder.rs:237-238
+        max_words = std::max<u64>(max_words, (h_bit_len[k] + 31) / 32 + 1);
+    }
+    const u64 trailer_bit = pos;
+    if (write_trailer) pos += 80;
+    const u64 total_bits = pos;
+    const u64 nwords = (total_bits + 31) / 32;
+    if (nwords * 4 > cap) return BZ_E_CAPACITY;
+    const int sp = span_begin(g, 4);
+    if (nwords) HIPCHK(hipMemsetAsync(d_out, 0, nwords * 4, g->st));
+    if (n_blocks) {
+        int rc = g->asmlist.ensure(n_blocks * sizeof(AsmBlock));
+        if (rc != BZ_OK) return rc;
+        HIPCHK(hipMemcpyAsync(g->asmlist.p, ab.data(), n_blocks * sizeof(AsmBlock), hipMemcpyHostToDevice, g->st));
+        launch_assemble(g->st, (const u32 *)d_packed, g->asmlist.as<AsmBlock>(), (u32)n_blocks, max_words,
+                        (u32 *)d_out);
+    }
+    if (nwords)
+        launch_frame(g->st, (u32 *)d_out, write_header, (u32)level, carry_bits, carry_byte, write_trailer,
+                     trailer_bit, comb);
+    span_end(g, sp);
+    size_t bytes;
+    unsigned ocb = 0, ocy = 0;
+    if (pad_to_byte) {
+        bytes = (size_t)((total_bits + 7) / 8);
+    } else {
+        bytes = (size_t)(total_bits / 8);
+        ocb = (unsigned)(total_bits & 7u);
+        if (ocb) {
+            u8 last = 0;
+            HIPCHK(hipMemcpyAsync(&last, (const u8 *)d_out + bytes, 1, hipMemcpyDeviceToHost, g->st));
+            HIPCHK(hipStreamSynchronize(g->st));
+            ocy = last & (0xFFu << (8 - ocb));
+        }
+    }
+    spans_collect(g);
+    HIPCHK(hipGetLastError());
+    if (combined_crc_out) *combined_crc_out = comb;
+    if (out_len) *out_len = bytes;
+    if (out_carry_bits) *out_carry_bits = ocb;
+    if (out_carry_byte) *out_carry_byte = ocy;
+    return BZ_OK;
+}
+
+extern "C" int bz_gpu_encode_device(bz_gpu_engine *g, int level, const void *d_in, size_t n, void *d_out,
+                                    size_t cap, size_t *out_len)
+{
+    if (!g) return BZ_E_PARAM;
+    size_t nblocks = 0, consumed = 0;
+    int rc = bz_gpu_partition(g, level, d_in, n, BZ_ACTION_FINISH, &nblocks, &consumed, nullptr);
+    if (rc != BZ_OK) return rc;
+    std::vector<uint64_t> woff(nblocks + 1), blen(nblocks + 1);
+    std::vector<uint32_t> crc(nblocks + 1);
+    size_t used = 0;
+    if (nblocks) {
+        const size_t cap_words = bz_encode_bound(n) / 4 + 2 * nblocks + 16;
+        rc = g->packed.ensure(cap_words * 4);
+        if (rc != BZ_OK) return rc;
+        rc = bz_gpu_encode_blocks(g, 0, 1, g->packed.p, cap_words, woff.data(), blen.data(), crc.data(), &used);
+        if (rc != BZ_OK) return rc;
+    }
+    return bz_gpu_assemble(g, level, nblocks, g->packed.p, woff.data(), blen.data(), crc.data(), 1, 1, 1, 0, 0, 0,
+                           nullptr, d_out, cap, out_len, nullptr, nullptr);
+}
+
+extern "C" int bz_gpu_last_timings(bz_gpu_engine *g, double out_seconds[6])
+{
+    if (!g) return BZ_E_PARAM;
+    for (int i = 0; i < 6; ++i) out_seconds[i] = g->t_stage[i];
+    return BZ_OK;
+}
+
+extern "C" int bz_gpu_last_bwt_stats(bz_gpu_engine *g, uint64_t out[4])
+{
+    if (!g) return BZ_E_PARAM;
+    for (int i = 0; i < 4; ++i) out[i] = g->bwt_stats[i];
+    return BZ_OK;
+}
+
+extern "C" int bz_gpu_debug_block_stats(bz_gpu_engine *g, uint32_t *h_stats, size_t cap_blocks, size_t *n_blocks)
+{
+    if (!g) return BZ_E_PARAM;
+    const size_t nb = g->h_out.size();
+    if (n_blocks) *n_blocks = nb;
+    for (size_t i = 0; i < nb && i < cap_blocks; ++i) {
+        const BlockOut &o = g->h_out[i];
+        uint32_t *s = h_stats + i * 8;
+        s[0] = g->h_out_nblock[i];
+        s[1] = o.crc;
+        s[2] = o.orig_ptr;
+        s[3] = o.mtf_count;
+        s[4] = o.in_use_count;
+        s[5] = o.group_num;
+        s[6] = o.n_selectors;
+        s[7] = o.max_len | (o.lm_tables << 16);
+    }
+    return BZ_OK;
+}
+
+extern "C" int bz_gpu_debug_bwt(bz_gpu_engine *g, const uint8_t *h_block, size_t n, uint32_t *h_sa)
+{
+    if (!g || n == 0 || n > kMaxBlockLen) return BZ_E_PARAM;
+    HIPCHK(hipSetDevice(g->device));
+    int rc = ensure_workspace(g);
+    if (rc != BZ_OK) return rc;
+    if ((rc = g->rle.ensure(n + 256)) != BZ_OK) return rc;
+    HIPCHK(hipMemcpyAsync(g->rle.p, h_block, n, hipMemcpyHostToDevice, g->st));
+    BlockDesc d;
+    d.rle_off = 0;
+    d.in_off = 0;
+    d.in_end = n;
+    d.n = (u32)n;
+    d.pad = 0;
+    HIPCHK(hipMemcpyAsync(g->lblocks.p, &d, sizeof(d), hipMemcpyHostToDevice, g->st));
+    BwtArgs ba;
+    ba.rle = g->rle.as<u8>();
+    ba.blocks = g->lblocks.as<BlockDesc>();
+    ba.nb = 1;
+    ba.SA = g->SA.as<u32>();
+    ba.R = g->R.as<u32>();
+    ba.KA = g->KA.as<u32>();
+    ba.VA = g->VA.as<u32>();
+    ba.KB = g->KB.as<u32>();
+    ba.VB = g->VB.as<u32>();
+    ba.tile_hist = g->tile_hist.as<u32>();
+    ba.count = g->count.as<u32>();
+    ba.flags = g->flags.as<u8>();
+    ba.tile_last_old = g->tlo.as<int>();
+    ba.tile_last_new = g->tln.as<int>();
+    ba.nonfinal = g->nonfinal.as<u32>();
+    ba.active = g->active.as<unsigned long long>();
+    ba.per_k = g->per_k.as<u32>();
+    ba.per_shift = g->per_shift.as<u32>();
+    u64 sorted = 0;
+    const int rounds = run_bwt(g->st, ba, (u32)n, (u64)n, g->h_active, &sorted, nullptr);
+    if (rounds < 0) return BZ_E_UNEXPECTED;
+    g->bwt_stats[0] = (u64)rounds;
+    g->bwt_stats[1] = sorted;
+    HIPCHK(hipMemcpyAsync(h_sa, g->SA.p, n * 4, hipMemcpyDeviceToHost, g->st));
+    HIPCHK(hipStreamSynchronize(g->st));
+    HIPCHK(hipGetLastError());
+    return BZ_OK;
+}
+
+extern "C" int bz_gpu_debug_code_lengths(bz_gpu_engine *g, const uint32_t *h_freq, size_t alpha, uint8_t *h_len,
+                                         int *took_length_limited_path)
+{
+    if (!g || alpha == 0 || alpha > kMaxAlpha) return BZ_E_PARAM;
+    HIPCHK(hipSetDevice(g->device));
+    DevBuf f, o, s, fl;
+    int rc;
+    if ((rc = f.ensure(alpha * 4)) || (rc = o.ensure(alpha + 8)) || (rc = s.ensure((size_t)kLmWords * 4)) ||
+        (rc = fl.ensure(4)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(f.p, h_freq, alpha * 4, hipMemcpyHostToDevice, g->st));
+    launch_probe_code_lengths(g->st, f.as<u32>(), (u32)alpha, o.as<u8>(), s.as<u32>(), fl.as<int>());
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(h_len, o.p, alpha, hipMemcpyDeviceToHost, g->st));
+    HIPCHK(hipMemcpyAsync(&flag, fl.p, 4, hipMemcpyDeviceToHost, g->st));
+    HIPCHK(hipStreamSynchronize(g->st));
+    HIPCHK(hipGetLastError());
+    if (took_length_limited_path) *took_length_limited_path = flag;
+    f.release();
+    o.release();
+    s.release();
+    fl.release();
+    return BZ_OK;
+}
+
+static const char *kKernelNames[KID_COUNT] = {"k_radix_hist", "k_radix_scan", "k_radix_scatter",
+                                              "k_group_flags", "k_group_apply", "k_last_column"};
+
+extern "C" int bz_gpu_profile_enable(bz_gpu_engine *g, int on)
+{
+    if (!g) return BZ_E_PARAM;
+    g->prof.reset();
+    g->prof.on = on != 0;
+    return BZ_OK;
+}
+
+extern "C" int bz_gpu_profile_kernels(bz_gpu_engine *g)
+{
+    (void)g;
+    return KID_COUNT;
+}
+
+extern "C" int bz_gpu_profile_get(bz_gpu_engine *g, int idx, const char **name, uint64_t *launches,
+                                  double *seconds, uint64_t *algorithmic_bytes)
+{
+    if (!g || idx < 0 || idx >= KID_COUNT) return BZ_E_PARAM;
+    if (name) *name = kKernelNames[idx];
+    if (launches) *launches = g->prof.launches[idx];
+    if (seconds) *seconds = g->prof.seconds[idx];
+    if (algorithmic_bytes) *algorithmic_bytes = g->prof.bytes[idx];
+    return BZ_OK;
+}

@@ -1,0 +1,647 @@
+// k_bwt.hip -- batched Burrows-Wheeler transform: order of all CYCLIC ROTATIONS of
+// every block of a batch.
+//
+// Reference being replaced: suffix_array::sais::bwt (src/suffix_array/sais.rs:266-272;
+// a cyclic SA-IS, :12-264).  Only its RESULT is reproduced: the exact rotation
+// order, including the tie rule for periodic blocks (equal rotations come out by
+// DESCENDING (i - shift) mod n, shift = smallest start of a least rotation;
+// SURVEY.md F4, pinned by tests/test_oracle_vectors.py::test_bwt_periodic_tie_rule).
+// A serial induced sort is the wrong shape for a GPU; this is a prefix-doubling
+// rotation sort built from LDS-tiled stable radix passes:
+//
+//   init   : 32-bit key = first 4 bytes of each rotation, LSD radix 11+11+10 bits
+//            -> groups of rotations equal on 4 bytes; rank R[j] = group head position,
+//            bit31 = "group is a singleton, rotation j is final".
+//   round h: (Manber-Myers step) walk SA in order, i -> j = SA[i]-h; the non-final j
+//            arrive ordered by the rank of rotation j+h.  A STABLE sort of that
+//            sequence by R[j] (20 bits = two 10-bit passes; pass A also compacts
+//            away final rotations) yields the 2h-order inside every old group.
+//            Then flags (old group start / new group start), a max-scan, and the
+//            scatter of SA and the refined ranks.  h doubles: 4,8,...
+//   stop   : no non-final rotation left (or h >= n: the block is periodic, finish
+//            with the closed-form tie rule).
+//
+// Everything is per-block independent; a launch covers (55 tiles) x (blocks of the
+// batch).  Tiles of one block are mapped to one XCD (bzgpu::xcd_remap) so the
+// block's 3.6 MB rank array stays in that XCD's L2 for the gathers.
+//
+// Integer path: no MFMA.  Bound: HBM (streamed u32 arrays) + L2 gathers.
+#include "bzgpu.h"
+#include <cstdlib>
+
+namespace bzgpu {
+
+enum { SRC_TEXT = 0, SRC_PAIRS = 1, SRC_MM = 2 };
+
+__device__ __forceinline__ u32 text_key4(const u8 *__restrict__ t, u32 n, u32 i)
+{
+    u32 k = 0;
+    if (i + 4 <= n) {
+        k = ((u32)t[i] << 24) | ((u32)t[i + 1] << 16) | ((u32)t[i + 2] << 8) | (u32)t[i + 3];
+    } else {
+        u32 p = i;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            k = (k << 8) | t[p];
+            p = (p + 1 == n) ? 0u : p + 1; // n >= 1
+        }
+    }
+    return k;
+}
+
+// fetch element idx of the pass's input sequence; returns false when it takes no part
+template <int SRC>
+__device__ __forceinline__ bool fetch(const BwtArgs &a, u32 lb, const u8 *__restrict__ text, u32 n, u32 hm,
+                                      const u32 *__restrict__ Kin, const u32 *__restrict__ Vin, u32 idx,
+                                      u32 &key, u32 &val)
+{
+    const size_t base = (size_t)lb * kSlot;
+    if (SRC == SRC_TEXT) {
+        key = text_key4(text, n, idx);
+        val = idx;
+        return true;
+    } else if (SRC == SRC_PAIRS) {
+        key = Kin[base + idx];
+        val = Vin[base + idx];
+        return true;
+    } else {
+        const u32 s = a.SA[base + idx];
+        const u32 j = (s >= hm) ? s - hm : s + n - hm;
+        const u32 r = a.R[base + j];
+        key = r;
+        val = j;
+        return (r & kFinalBit) == 0;
+    }
+}
+
+// ---- radix pass, part 1: per-tile digit histogram ---------------------------------
+template <int SRC, int BITS>
+__global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shift, u32 h,
+                                                              const u32 *__restrict__ Kin,
+                                                              const u32 *__restrict__ Vin)
+{
+    constexpr u32 NB = 1u << BITS;
+    __shared__ u32 s_hist[NB];
+    u32 tile, lb;
+    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    const BlockDesc d = a.blocks[lb];
+    const u32 n = d.n;
+    const u32 cnt = (SRC == SRC_PAIRS) ? a.count[lb] : n;
+    const u32 start = tile * kSortTile;
+    if (start >= cnt) return;
+    const u8 *text = a.rle + d.rle_off;
+    const u32 hm = (SRC == SRC_MM) ? h % n : 0u;
+
+    for (u32 i = threadIdx.x; i < NB; i += kSortThreads) s_hist[i] = 0;
+    __syncthreads();
+    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+#pragma unroll 4
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 idx = start + w * 1024u + r * 64u + l;
+        if (idx < cnt) {
+            u32 key, val;
+            if (fetch<SRC>(a, lb, text, n, hm, Kin, Vin, idx, key, val))
+                atomicAdd(&s_hist[(key >> shift) & (NB - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    u32 *out = a.tile_hist + ((size_t)lb * kTilesPerBlock + tile) * kMaxBins;
+    for (u32 i = threadIdx.x; i < NB; i += kSortThreads) out[i] = s_hist[i];
+}
+
+// ---- radix pass, part 2: per-block scan of the tile histograms ----------------------
+// After it, tile_hist[lb][tile][bin] = first output slot of that (bin, tile).
+template <int SRC, int BITS>
+__global__ __launch_bounds__(kSortThreads) void k_radix_scan(BwtArgs a)
+{
+    constexpr u32 NB = 1u << BITS;
+    constexpr u32 PER = (NB + kSortThreads - 1) / kSortThreads; // bins per thread (1 or 2)
+    __shared__ u32 s_wsum[kSortThreads / 64];
+    const u32 lb = blockIdx.x;
+    const u32 n = a.blocks[lb].n;
+    const u32 cnt = (SRC == SRC_PAIRS) ? a.count[lb] : n;
+    const u32 ntiles = (cnt + kSortTile - 1) / kSortTile;
+    u32 *hist = a.tile_hist + (size_t)lb * kTilesPerBlock * kMaxBins;
+
+    // bins d0..d0+PER-1 of this thread are consecutive -> block scan in thread order
+    const u32 d0 = threadIdx.x * PER;
+    u32 tot[PER];
+#pragma unroll
+    for (u32 q = 0; q < PER; ++q) {
+        const u32 dgt = d0 + q;
+        u32 run = 0;
+        if (dgt < NB) {
+            for (u32 t = 0; t < ntiles; ++t) {
+                const u32 v = hist[t * kMaxBins + dgt];
+                hist[t * kMaxBins + dgt] = run;
+                run += v;
+            }
+        }
+        tot[q] = run;
+    }
+    u32 mine = 0;
+#pragma unroll
+    for (u32 q = 0; q < PER; ++q) mine += tot[q];
+    const u32 inc = wave_incl_sum(mine);
+    if ((threadIdx.x & 63u) == 63u) s_wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    u32 carry = 0, total = 0;
+    for (u32 k = 0; k < kSortThreads / 64; ++k) {
+        if (k < (threadIdx.x >> 6)) carry += s_wsum[k];
+        total += s_wsum[k];
+    }
+    u32 base = carry + inc - mine;
+#pragma unroll
+    for (u32 q = 0; q < PER; ++q) {
+        const u32 dgt = d0 + q;
+        if (dgt < NB && base != 0) {
+            for (u32 t = 0; t < ntiles; ++t) hist[t * kMaxBins + dgt] += base;
+        }
+        base += tot[q];
+    }
+    if (SRC != SRC_PAIRS && threadIdx.x == 0) a.count[lb] = total; // list length for the next passes
+}
+
+// ---- radix pass, part 3: stable scatter -----------------------------------------------
+// Wave w owns the contiguous elements [w*1024, (w+1)*1024) of the tile and walks them in
+// 16 rows of 64, so (wave, row, lane) order == sequence order.  Ranking inside a row uses
+// ballot matching; counts per (wave, digit) live in LDS as u16.
+template <int SRC, int BITS>
+__global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 shift, u32 h,
+                                                                 const u32 *__restrict__ Kin,
+                                                                 const u32 *__restrict__ Vin,
+                                                                 u32 *__restrict__ Kout,
+                                                                 u32 *__restrict__ Vout)
+{
+    constexpr u32 NB = 1u << BITS;
+    constexpr u32 NW = kSortThreads / 64;
+    __shared__ u16 s_cnt[NW * NB];
+    __shared__ u32 s_base[NB];
+    u32 tile, lb;
+    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    const BlockDesc d = a.blocks[lb];
+    const u32 n = d.n;
+    const u32 cnt = (SRC == SRC_PAIRS) ? a.count[lb] : n;
+    const u32 start = tile * kSortTile;
+    if (start >= cnt) return;
+    const u8 *text = a.rle + d.rle_off;
+    const u32 hm = (SRC == SRC_MM) ? h % n : 0u;
+    const size_t base = (size_t)lb * kSlot;
+
+    {
+        u32 *z = reinterpret_cast<u32 *>(s_cnt);
+        for (u32 i = threadIdx.x; i < NW * NB / 2; i += kSortThreads) z[i] = 0;
+        const u32 *hist = a.tile_hist + ((size_t)lb * kTilesPerBlock + tile) * kMaxBins;
+        for (u32 i = threadIdx.x; i < NB; i += kSortThreads) s_base[i] = hist[i];
+    }
+    __syncthreads();
+
+    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const u64 lt_mask = (l == 0) ? 0ull : (~0ull >> (64 - l));
+    u16 *my_cnt = s_cnt + w * NB;
+
+    u32 key[16], val[16];
+    u32 rnk[16]; // 0xFFFFFFFF = takes no part
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 idx = start + w * 1024u + r * 64u + l;
+        bool ok = false;
+        key[r] = 0;
+        val[r] = 0;
+        if (idx < cnt) ok = fetch<SRC>(a, lb, text, n, hm, Kin, Vin, idx, key[r], val[r]);
+        const u32 dg = (key[r] >> shift) & (NB - 1);
+        u64 peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < BITS; ++b) {
+            const bool bit = (dg >> b) & 1u;
+            const u64 m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        rnk[r] = 0xFFFFFFFFu;
+        if (ok) {
+            const u32 before = __popcll(peers & lt_mask);
+            const u32 c0 = my_cnt[dg];
+            rnk[r] = c0 + before;
+            // the highest lane of the peer set publishes the new count
+            if ((peers >> l) == 1ull) my_cnt[dg] = (u16)(c0 + before + 1u);
+        }
+        // LDS ops of one wave retire in order: the next row's reads see this row's writes
+    }
+    __syncthreads();
+    // exclusive prefix over waves, per digit
+    for (u32 dg = threadIdx.x; dg < NB; dg += kSortThreads) {
+        u32 run = 0;
+#pragma unroll
+        for (u32 k = 0; k < NW; ++k) {
+            const u32 c = s_cnt[k * NB + dg];
+            s_cnt[k * NB + dg] = (u16)run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        if (rnk[r] != 0xFFFFFFFFu) {
+            const u32 dg = (key[r] >> shift) & (NB - 1);
+            const u32 dst = s_base[dg] + my_cnt[dg] + rnk[r];
+            Kout[base + dst] = key[r];
+            Vout[base + dst] = val[r];
+        }
+    }
+}
+
+// ---- group refinement, part 1: boundary flags over the sorted pair list ----------------
+// INIT: the list is all n rotations sorted by their 4-byte key (one old group).
+// else: list sorted by old group head g = K; secondary key = rank of rotation j+h.
+template <bool INIT>
+__global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 h, const u32 *__restrict__ K,
+                                                               const u32 *__restrict__ V)
+{
+    __shared__ int s_old, s_new;
+    u32 tile, lb;
+    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    const u32 n = a.blocks[lb].n;
+    const u32 cnt = a.count[lb];
+    const u32 start = tile * kSortTile;
+    if (start >= cnt) return;
+    const u32 hm = h % n;
+    const size_t base = (size_t)lb * kSlot;
+    if (threadIdx.x == 0) {
+        s_old = -1;
+        s_new = -1;
+    }
+    __syncthreads();
+    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    int last_old = -1, last_new = -1;
+#pragma unroll 2
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 idx = start + w * 1024u + r * 64u + l;
+        const bool ok = idx < cnt;
+        u32 g = 0, s = 0;
+        if (ok) {
+            const u32 kk = K[base + idx];
+            if (INIT) {
+                s = kk;
+            } else {
+                g = kk;
+                const u32 j = V[base + idx];
+                u32 jj = j + hm;
+                if (jj >= n) jj -= n;
+                s = a.R[base + jj];
+            }
+        }
+        u32 pg = __shfl_up(g, 1, 64), ps = __shfl_up(s, 1, 64);
+        if (l == 0 && ok && idx > 0) {
+            const u32 kk = K[base + idx - 1];
+            if (INIT) {
+                ps = kk;
+                pg = 0;
+            } else {
+                pg = kk;
+                const u32 j = V[base + idx - 1];
+                u32 jj = j + hm;
+                if (jj >= n) jj -= n;
+                ps = a.R[base + jj];
+            }
+        }
+        if (ok) {
+            const bool os = (idx == 0) || (g != pg);
+            const bool ns = os || (s != ps);
+            a.flags[base + idx] = (u8)((os ? 1u : 0u) | (ns ? 2u : 0u));
+            if (os) last_old = (int)idx;
+            if (ns) last_new = (int)idx;
+        }
+    }
+#pragma unroll
+    for (u32 dd = 32; dd >= 1; dd >>= 1) {
+        const int o1 = __shfl_xor(last_old, dd, 64), o2 = __shfl_xor(last_new, dd, 64);
+        last_old = o1 > last_old ? o1 : last_old;
+        last_new = o2 > last_new ? o2 : last_new;
+    }
+    if (l == 0) {
+        if (last_old >= 0) atomicMax(&s_old, last_old);
+        if (last_new >= 0) atomicMax(&s_new, last_new);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.tile_last_old[lb * kTilesPerBlock + tile] = s_old;
+        a.tile_last_new[lb * kTilesPerBlock + tile] = s_new;
+    }
+}
+
+// ---- group refinement, part 2: positions, new ranks, final bits ---------------------------
+template <bool INIT>
+__global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 h_next, u32 round,
+                                                               const u32 *__restrict__ K,
+                                                               const u32 *__restrict__ V)
+{
+    constexpr u32 NW = kSortThreads / 64;
+    __shared__ int s_carry_old, s_carry_new;
+    __shared__ int s_wold[NW], s_wnew[NW];
+    __shared__ u32 s_nonfinal;
+    u32 tile, lb;
+    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    const u32 n = a.blocks[lb].n;
+    const u32 cnt = a.count[lb];
+    const u32 start = tile * kSortTile;
+    if (start >= cnt) return;
+    const size_t base = (size_t)lb * kSlot;
+
+    if (threadIdx.x == 0) {
+        int co = -1, cn = -1;
+        for (int t = (int)tile - 1; t >= 0 && co < 0; --t) co = a.tile_last_old[lb * kTilesPerBlock + t];
+        for (int t = (int)tile - 1; t >= 0 && cn < 0; --t) cn = a.tile_last_new[lb * kTilesPerBlock + t];
+        s_carry_old = co;
+        s_carry_new = cn;
+        s_nonfinal = 0;
+    }
+    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const u32 wbase = start + w * 1024u;
+    u64 mo[16], mn[16];
+    int wl_old = -1, wl_new = -1;
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 idx = wbase + r * 64u + l;
+        const u32 f = (idx < cnt) ? a.flags[base + idx] : 0u;
+        mo[r] = __ballot(f & 1u);
+        mn[r] = __ballot(f & 2u);
+        if (mo[r]) wl_old = (int)(wbase + r * 64u + 63u - __clzll(mo[r]));
+        if (mn[r]) wl_new = (int)(wbase + r * 64u + 63u - __clzll(mn[r]));
+    }
+    if (l == 0) {
+        s_wold[w] = wl_old;
+        s_wnew[w] = wl_new;
+    }
+    __syncthreads();
+    int carry_old = s_carry_old, carry_new = s_carry_new;
+    for (u32 k = 0; k < w; ++k) {
+        carry_old = s_wold[k] > carry_old ? s_wold[k] : carry_old;
+        carry_new = s_wnew[k] > carry_new ? s_wnew[k] : carry_new;
+    }
+    const u64 le_mask = (l == 63) ? ~0ull : ((2ull << l) - 1ull);
+    u32 my_nonfinal = 0;
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 rowbase = wbase + r * 64u;
+        const u32 idx = rowbase + l;
+        if (idx < cnt) {
+            const u64 o = mo[r] & le_mask, q = mn[r] & le_mask;
+            const int rs = o ? (int)(rowbase + 63u - __clzll(o)) : carry_old;
+            const int ss = q ? (int)(rowbase + 63u - __clzll(q)) : carry_new;
+            // is the next list element the start of a new group?
+            bool next_new;
+            if (idx + 1 >= cnt) next_new = true;
+            else if (l < 63) next_new = (mn[r] >> (l + 1)) & 1ull;
+            else if (r < 15) next_new = mn[(r + 1) & 15] & 1ull;
+            else next_new = (a.flags[base + idx + 1] & 2u) != 0;
+            const bool is_new = (mn[r] >> l) & 1ull;
+            const bool fin = is_new && next_new;
+            const u32 g = INIT ? 0u : K[base + idx];
+            const u32 j = V[base + idx];
+            const u32 p = g + (idx - (u32)rs);
+            const u32 head = g + ((u32)ss - (u32)rs);
+            a.SA[base + p] = j;
+            a.R[base + j] = head | (fin ? kFinalBit : 0u);
+            my_nonfinal += fin ? 0u : 1u;
+        }
+        if (mo[r]) carry_old = (int)(rowbase + 63u - __clzll(mo[r]));
+        if (mn[r]) carry_new = (int)(rowbase + 63u - __clzll(mn[r]));
+    }
+    my_nonfinal = wave_sum(my_nonfinal);
+    if (l == 0 && my_nonfinal) atomicAdd(&s_nonfinal, my_nonfinal);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_nonfinal) {
+        atomicAdd(&a.nonfinal[lb], s_nonfinal);
+        if (h_next < n) atomicAdd(&a.active[round], (unsigned long long)s_nonfinal);
+    }
+}
+
+// ---- periodic blocks (block = u^k): closed-form tie rule -------------------------------------
+__global__ __launch_bounds__(kSortThreads) void k_periodic_stats(BwtArgs a)
+{
+    u32 tile, lb;
+    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    if (a.nonfinal[lb] == 0) return;
+    const u32 n = a.blocks[lb].n;
+    const size_t base = (size_t)lb * kSlot;
+    u32 c = 0, mj = 0xFFFFFFFFu;
+    for (u32 j = tile * kSortTile + threadIdx.x; j < n && j < (tile + 1) * kSortTile; j += kSortThreads) {
+        if (a.R[base + j] == 0u) { // non-final member of the group at position 0 (least rotation)
+            ++c;
+            mj = j < mj ? j : mj;
+        }
+    }
+    c = wave_sum(c);
+#pragma unroll
+    for (u32 dd = 32; dd >= 1; dd >>= 1) {
+        const u32 o = __shfl_xor(mj, dd, 64);
+        mj = o < mj ? o : mj;
+    }
+    if ((threadIdx.x & 63u) == 0 && c) {
+        atomicAdd(&a.per_k[lb], c);
+        atomicMin(&a.per_shift[lb], mj);
+    }
+}
+
+__global__ __launch_bounds__(kSortThreads) void k_periodic_place(BwtArgs a)
+{
+    u32 tile, lb;
+    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    if (a.nonfinal[lb] == 0) return;
+    const u32 n = a.blocks[lb].n;
+    const size_t base = (size_t)lb * kSlot;
+    const u32 k = a.per_k[lb], shift = a.per_shift[lb];
+    if (k == 0) return;
+    const u32 p = n / k; // the period
+    for (u32 j = tile * kSortTile + threadIdx.x; j < n && j < (tile + 1) * kSortTile; j += kSortThreads) {
+        const u32 r = a.R[base + j];
+        if (r & kFinalBit) continue;
+        const u32 i0 = j % p, t = j / p;
+        // members j = i0 + t*p of one group, DESCENDING (j - shift) mod n
+        const u32 pos = (i0 >= shift) ? (k - 1u - t) : (t == 0 ? 0u : k - t);
+        a.SA[base + r + pos] = j;
+    }
+}
+
+// ---- last column, origPtr, symbol map ------------------------------------------------------------
+// L[i] = block[(SA[i]-1) mod n]  (src/bzip2/encoder.rs:331-338); origPtr = i with SA[i]==0 (:332-334)
+__global__ __launch_bounds__(kSortThreads) void k_last_column(BwtArgs a, u8 *__restrict__ L,
+                                                               u32 *__restrict__ orig_ptr,
+                                                               u32 *__restrict__ inuse_bits /*[nb][8]*/)
+{
+    __shared__ u32 s_bits[8];
+    u32 tile, lb;
+    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    const BlockDesc d = a.blocks[lb];
+    const u32 n = d.n;
+    const u32 start = tile * kSortTile;
+    if (start >= n) return;
+    const u8 *text = a.rle + d.rle_off;
+    const size_t base = (size_t)lb * kSlot;
+    if (threadIdx.x < 8) s_bits[threadIdx.x] = 0;
+    __syncthreads();
+    u32 seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (u32 i = start + threadIdx.x; i < n && i < start + kSortTile; i += kSortThreads) {
+        const u32 s = a.SA[base + i];
+        if (s == 0) orig_ptr[lb] = i;
+        const u8 c = text[s == 0 ? n - 1 : s - 1];
+        L[base + i] = c;
+        seen[c >> 5] |= 1u << (c & 31u);
+    }
+#pragma unroll
+    for (u32 q = 0; q < 8; ++q) {
+        u32 v = seen[q];
+#pragma unroll
+        for (u32 dd = 32; dd >= 1; dd >>= 1) v |= __shfl_xor(v, dd, 64);
+        if ((threadIdx.x & 63u) == 0 && v) atomicOr(&s_bits[q], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && s_bits[threadIdx.x]) atomicOr(&inuse_bits[lb * 8 + threadIdx.x], s_bits[threadIdx.x]);
+}
+
+// ---- host side ------------------------------------------------------------------------------------
+int KernelProf::begin(hipStream_t st, int id, u64 nbytes)
+{
+    if (!on) return -1;
+    if (nrecs == cap) {
+        const u32 ncap = cap ? cap * 2 : 256;
+        Rec *nr = (Rec *)realloc(recs, ncap * sizeof(Rec));
+        if (!nr) return -1;
+        recs = nr;
+        cap = ncap;
+    }
+    Rec &r = recs[nrecs];
+    r.id = id;
+    r.bytes = nbytes;
+    if (hipEventCreate(&r.a) != hipSuccess) return -1;
+    if (hipEventCreate(&r.b) != hipSuccess) {
+        (void)hipEventDestroy(r.a);
+        return -1;
+    }
+    (void)hipEventRecord(r.a, st);
+    return (int)nrecs++;
+}
+void KernelProf::end(hipStream_t st, int idx)
+{
+    if (idx >= 0) (void)hipEventRecord(recs[idx].b, st);
+}
+void KernelProf::collect()
+{
+    for (u32 i = 0; i < nrecs; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, recs[i].a, recs[i].b) == hipSuccess) {
+            launches[recs[i].id] += 1;
+            bytes[recs[i].id] += recs[i].bytes;
+            seconds[recs[i].id] += ms * 1e-3;
+        }
+        (void)hipEventDestroy(recs[i].a);
+        (void)hipEventDestroy(recs[i].b);
+    }
+    nrecs = 0;
+}
+void KernelProf::reset()
+{
+    collect();
+    for (int i = 0; i < KID_COUNT; ++i) {
+        launches[i] = 0;
+        bytes[i] = 0;
+        seconds[i] = 0;
+    }
+}
+
+// Algorithmic bytes per element of each radix kernel, by source:
+//   hist   : TEXT 1 (block byte), PAIRS 4 (key), MM 8 (SA + rank)
+//   scatter: the same reads (+4 for the value of PAIRS) + 8 written (key, value)
+template <int SRC, int BITS>
+static void radix_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const u32 *Kin, const u32 *Vin,
+                       u32 *Kout, u32 *Vout, u64 elems, KernelProf *prof)
+{
+    const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
+    const u64 rd_hist = (SRC == SRC_TEXT) ? 1 : (SRC == SRC_PAIRS ? 4 : 8);
+    const u64 rd_scat = (SRC == SRC_TEXT) ? 1 : 8;
+    int p = prof ? prof->begin(st, KID_RADIX_HIST, elems * rd_hist) : -1;
+    hipLaunchKernelGGL((k_radix_hist<SRC, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Kin, Vin);
+    if (prof) prof->end(st, p);
+    p = prof ? prof->begin(st, KID_RADIX_SCAN, (u64)a.nb * kTilesPerBlock * (1u << BITS) * 8u) : -1;
+    hipLaunchKernelGGL((k_radix_scan<SRC, BITS>), dim3(a.nb), dim3(kSortThreads), 0, st, a);
+    if (prof) prof->end(st, p);
+    p = prof ? prof->begin(st, KID_RADIX_SCATTER, elems * (rd_scat + 8)) : -1;
+    hipLaunchKernelGGL((k_radix_scatter<SRC, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Kin, Vin,
+                       Kout, Vout);
+    if (prof) prof->end(st, p);
+}
+
+// Sorts the rotations of every block of the batch; leaves the order in a.SA.
+// h_active is a pinned host word used to poll the per-round counters.  total_n = sum of block
+// lengths (for the profiler's byte accounting).
+// Returns the number of doubling rounds executed, <0 on HIP error.
+int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned long long *h_active,
+            u64 *sorted_elems, KernelProf *prof)
+{
+    const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
+    (void)hipMemsetAsync(a.active, 0, 64 * sizeof(unsigned long long), st);
+    (void)hipMemsetAsync(a.nonfinal, 0, a.nb * sizeof(u32), st);
+
+    // init: 4-byte keys, LSD 11 + 11 + 10 bits
+    radix_pass<SRC_TEXT, 11>(st, a, 0, 0, nullptr, nullptr, a.KA, a.VA, total_n, prof);
+    radix_pass<SRC_PAIRS, 11>(st, a, 11, 0, a.KA, a.VA, a.KB, a.VB, total_n, prof);
+    radix_pass<SRC_PAIRS, 10>(st, a, 22, 0, a.KB, a.VB, a.KA, a.VA, total_n, prof);
+    int p = prof ? prof->begin(st, KID_GROUP_FLAGS, total_n * 5) : -1;
+    hipLaunchKernelGGL((k_group_flags<true>), grid, dim3(kSortThreads), 0, st, a, 0u, a.KA, a.VA);
+    if (prof) prof->end(st, p);
+    p = prof ? prof->begin(st, KID_GROUP_APPLY, total_n * 13) : -1;
+    hipLaunchKernelGGL((k_group_apply<true>), grid, dim3(kSortThreads), 0, st, a, 4u, 0u, a.KA, a.VA);
+    if (prof) prof->end(st, p);
+
+    u32 h = 4;
+    int rounds = 0;
+    u32 slot = 0;
+    while (true) {
+        if (hipMemcpyAsync(h_active, a.active + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, st) !=
+            hipSuccess)
+            return -1;
+        if (hipStreamSynchronize(st) != hipSuccess) return -1;
+        const u64 m = *h_active; // rotations still to be ordered (in unfinished blocks)
+        if (sorted_elems) *sorted_elems += m;
+        if (m == 0 || h >= max_n) break;
+        ++slot;
+        ++rounds;
+        (void)hipMemsetAsync(a.nonfinal, 0, a.nb * sizeof(u32), st);
+        // pass A walks all of SA (total_n), pass B and the refinement only the m survivors
+        radix_pass<SRC_MM, 10>(st, a, 0, h, nullptr, nullptr, a.KA, a.VA, total_n, prof);
+        radix_pass<SRC_PAIRS, 10>(st, a, 10, h, a.KA, a.VA, a.KB, a.VB, m, prof);
+        p = prof ? prof->begin(st, KID_GROUP_FLAGS, m * 13) : -1;
+        hipLaunchKernelGGL((k_group_flags<false>), grid, dim3(kSortThreads), 0, st, a, h, a.KB, a.VB);
+        if (prof) prof->end(st, p);
+        const u32 hn = (h > 0x40000000u) ? 0x80000000u : h * 2u;
+        p = prof ? prof->begin(st, KID_GROUP_APPLY, m * 17) : -1;
+        hipLaunchKernelGGL((k_group_apply<false>), grid, dim3(kSortThreads), 0, st, a, hn, slot, a.KB, a.VB);
+        if (prof) prof->end(st, p);
+        h = hn;
+    }
+    // periodic blocks: whatever is still non-final is a set of equal rotations
+    (void)hipMemsetAsync(a.per_k, 0, a.nb * sizeof(u32), st);
+    (void)hipMemsetAsync(a.per_shift, 0xFF, a.nb * sizeof(u32), st);
+    hipLaunchKernelGGL(k_periodic_stats, grid, dim3(kSortThreads), 0, st, a);
+    hipLaunchKernelGGL(k_periodic_place, grid, dim3(kSortThreads), 0, st, a);
+    return rounds;
+}
+
+void launch_last_column(hipStream_t st, const BwtArgs &a, u8 *L, u32 *orig_ptr, u32 *inuse_bits, u64 total_n,
+                        KernelProf *prof)
+{
+    const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
+    (void)hipMemsetAsync(inuse_bits, 0, (size_t)a.nb * 8 * sizeof(u32), st);
+    const int p = prof ? prof->begin(st, KID_LAST_COLUMN, total_n * 6) : -1;
+    hipLaunchKernelGGL(k_last_column, grid, dim3(kSortThreads), 0, st, a, L, orig_ptr, inuse_bits);
+    if (prof) prof->end(st, p);
+}
+
+} // namespace bzgpu

@@ -1,0 +1,525 @@
+// k_huff.hip -- Huffman stage of one block per workgroup: table count, initial tables,
+// four refinement passes, code lengths, canonical codes, selector MTF and the whole
+// block header; plus the payload emission kernel.
+//
+// Reference being replaced (src/bzip2/encoder.rs): table count :370-376, initial tables
+// :379-426, refinement :433-509, create_huffman :641-651, selector MTF :511-517, codes
+// :519-524, mapping table :527-554, selectors :567-574, coding tables :583-601, payload
+// :609-629; src/huffman/cano_huff_table.rs:14-225 (code lengths; the serial heap procedure
+// and the "reverse package merge" fallback are replayed step for step by ONE lane per
+// table -- SURVEY.md F3/F5: bit-exactness hinges on the heap's tie-breaks);
+// src/huffman/mod.rs:22-67 (canonical codes).
+//
+// Table order: the reference stores `len` reversed and always walks it with .rev()
+// (encoder.rs:452-454, 504-508, 520-524, 585); here tables are kept in selector order
+// t = 0..group_num-1, which is the order the stream carries them in.
+#include "bzgpu.h"
+
+namespace bzgpu {
+
+constexpr u32 kHuffThreads = 512;
+
+// encoder.rs:647-650
+__device__ __forceinline__ u32 weight_add(u32 x, u32 y)
+{
+    const u32 dx = x & 0xFFu, dy = y & 0xFFu;
+    return ((x & 0xFFFFFF00u) + (y & 0xFFFFFF00u)) | (1u + (dx > dy ? dx : dy));
+}
+
+// cano_huff_table.rs:14-31
+__device__ void down_heap(u32 *buf, u32 nn, u32 len)
+{
+    const u32 tmp = buf[nn];
+    u32 leaf = (nn << 1) + 1;
+    while (leaf < len) {
+        if (leaf + 1 < len && buf[buf[leaf]] > buf[buf[leaf + 1]]) leaf += 1;
+        if (buf[tmp] < buf[buf[leaf]]) break;
+        buf[nn] = buf[leaf];
+        nn = leaf;
+        leaf = (nn << 1) + 1;
+    }
+    buf[nn] = tmp;
+}
+
+// cano_huff_table.rs:58-151 ("reverse package merge"), scratch in global memory.
+// freq = the weights (all non-zero), n symbols, out = lengths in symbol order.
+__device__ void gen_code_lm(const u32 *freq, u32 n, u32 *scr, u8 *out)
+{
+    const u32 lim = kLim;
+    u32 *map = scr;                 // [n]
+    u32 *sfreq = map + kMaxAlpha;   // [n]
+    u32 *c = sfreq + kMaxAlpha;     // [n]
+    u32 *misc = c + kMaxAlpha;      // max_elem[17], b[17], cur[17]
+    u32 *max_elem = misc, *b = misc + 20, *cur = misc + 40;
+    u32 *val = misc + 64 + kMaxAlpha; // [lim][kLmRow]
+    u32 *ty = val + lim * kLmRow;     // [lim][kLmRow]
+
+    // stable sort by weight, descending (:64-70): insertion sort keeps equal keys in order
+    for (u32 i = 0; i < n; ++i) {
+        const u32 f = freq[i];
+        u32 p = i;
+        while (p > 0 && sfreq[p - 1] < f) {
+            sfreq[p] = sfreq[p - 1];
+            map[p] = map[p - 1];
+            --p;
+        }
+        sfreq[p] = f;
+        map[p] = i;
+    }
+    for (u32 j = 0; j < lim; ++j) { max_elem[j] = 0; b[j] = 0; cur[j] = 0; }
+    u32 excess = (1u << lim) - n;       // :75
+    const u32 half = 1u << (lim - 1);   // :76
+    max_elem[lim - 1] = n;              // :77
+    for (u32 j = 0; j < lim; ++j) {     // :79-88
+        if (excess >= half) {
+            b[j] = 1;
+            excess -= half;
+        }
+        excess <<= 1;
+        if (lim >= 2 + j) max_elem[lim - 2 - j] = max_elem[lim - 1 - j] / 2 + n;
+    }
+    max_elem[0] = b[0];                 // :90-95
+    for (u32 j = 1; j < lim; ++j)
+        if (max_elem[j] > 2 * max_elem[j - 1] + b[j]) max_elem[j] = 2 * max_elem[j - 1] + b[j];
+
+    for (u32 j = 0; j < lim; ++j)       // :97-98 (zero initialised vectors)
+        for (u32 t = 0; t < max_elem[j]; ++t) { val[j * kLmRow + t] = 0; ty[j * kLmRow + t] = 0; }
+    for (u32 i = 0; i < n; ++i) c[i] = lim; // :99
+    for (u32 t = 0; t < n && t < max_elem[lim - 1]; ++t) { // :101-104
+        val[(lim - 1) * kLmRow + t] = sfreq[t];
+        ty[(lim - 1) * kLmRow + t] = t;
+    }
+    if (b[lim - 1] == 1) {              // :107-110
+        c[0] -= 1;
+        cur[lim - 1] += 1;
+    }
+    u32 j = lim - 1;
+    while (j > 0) {                     // :112-142
+        u32 i = 0;
+        u32 next = cur[j];
+        for (u32 t = 0; t < max_elem[j - 1]; ++t) {
+            const u32 weight = (next + 1 < max_elem[j])
+                                   ? weight_add(val[j * kLmRow + next], val[j * kLmRow + next + 1])
+                                   : 0u;
+            if (weight > sfreq[i]) {
+                val[(j - 1) * kLmRow + t] = weight;
+                ty[(j - 1) * kLmRow + t] = n;
+                next += 2;
+            } else {
+                val[(j - 1) * kLmRow + t] = sfreq[i];
+                ty[(j - 1) * kLmRow + t] = i;
+                i += 1;
+                if (i >= n) break;
+            }
+        }
+        j -= 1;
+        cur[j] = 0;
+        if (b[j] == 1) {
+            // take_package(ty, c, cur, j) (:40-55) with an explicit stack
+            u32 lvl[20], ph[20];
+            int sp = 0;
+            lvl[0] = j;
+            ph[0] = 0;
+            while (sp >= 0) {
+                const u32 li = lvl[sp];
+                if (ph[sp] == 0) {
+                    const u32 x = ty[li * kLmRow + cur[li]];
+                    if (x == n) {
+                        ph[sp] = 1;
+                        ++sp;
+                        lvl[sp] = li + 1;
+                        ph[sp] = 0;
+                    } else {
+                        c[x] -= 1;
+                        cur[li] += 1;
+                        --sp;
+                    }
+                } else if (ph[sp] == 1) {
+                    ph[sp] = 2;
+                    ++sp;
+                    lvl[sp] = li + 1;
+                    ph[sp] = 0;
+                } else {
+                    cur[li] += 1;
+                    --sp;
+                }
+            }
+        }
+    }
+    for (u32 i = 0; i < n; ++i) out[map[i]] = (u8)c[i]; // :144-150
+}
+
+// cano_huff_table.rs:153-196 gen_code on the bzip2 weights (encoder.rs:641-651).
+// rfreq: symbol counts of this table; buf: 2*alpha words of LDS; returns 1 if the
+// length-limited path was taken.
+__device__ int make_code_lengths(const u32 *rfreq, u32 alpha, u32 *buf, u8 *out, u32 *lm_scr)
+{
+    const u32 n = alpha;
+    if (n == 1) { // cannot happen on this path (alpha >= 3), kept for the probe entry
+        out[0] = 1;
+        return 0;
+    }
+    for (u32 i = 0; i < n; ++i) {
+        buf[i] = n + i;
+        const u32 f = rfreq[i];
+        buf[n + i] = (f > 1u ? f : 1u) << 8; // encoder.rs:642-645
+    }
+    // create_heap, :33-38
+    for (u32 i = n >> 1; i-- > 0;) down_heap(buf, i, n);
+    for (u32 i = n - 1; i >= 1; --i) { // :168-178
+        const u32 m1 = buf[0];
+        buf[0] = buf[i];
+        down_heap(buf, 0, i);
+        const u32 m2 = buf[0];
+        buf[i] = weight_add(buf[m1], buf[m2]);
+        buf[0] = i;
+        buf[m1] = i;
+        buf[m2] = i;
+        down_heap(buf, 0, i);
+    }
+    buf[1] = 0; // :181-184
+    for (u32 i = 2; i < n; ++i) buf[i] = buf[buf[i]] + 1;
+    int too_long = 0;
+    for (u32 i = 0; i < n; ++i) { // :186-188
+        const u32 l = buf[buf[i + n]] + 1;
+        out[i] = (u8)l;
+        if (l > kLim) too_long = 1;
+    }
+    if (too_long) { // :190-194: redo from the weights
+        u32 *w = lm_scr + kLmWords - kMaxAlpha; // tail of the scratch holds the weights
+        for (u32 i = 0; i < n; ++i) {
+            const u32 f = rfreq[i];
+            w[i] = (f > 1u ? f : 1u) << 8;
+        }
+        gen_code_lm(w, n, lm_scr, out);
+        return 1;
+    }
+    return 0;
+}
+
+// MSB-first bit sink writing logical 32-bit words (single lane)
+struct BitSink {
+    u32 *w;
+    u64 acc;   // bits are left aligned in acc
+    u32 nacc;  // number of valid bits in acc (< 32 between calls)
+    u32 widx;
+    __device__ void put(u32 v, u32 nbits)
+    {
+        if (nbits == 0) return;
+        acc |= ((u64)v << (64 - nacc - nbits));
+        nacc += nbits;
+        if (nacc >= 32) {
+            w[widx++] = (u32)(acc >> 32);
+            acc <<= 32;
+            nacc -= 32;
+        }
+    }
+    __device__ void finish()
+    {
+        if (nacc) w[widx] = (u32)(acc >> 32); // zero padded partial word
+    }
+    __device__ u32 bits() const { return widx * 32 + nacc; }
+};
+
+__global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
+{
+    __shared__ u8 s_len[6][kMaxAlpha + 6];
+    __shared__ u32 s_rfreq[6][kMaxAlpha];
+    __shared__ unsigned long long s_pack[kMaxAlpha]; // 6 x 10-bit lengths per symbol
+    __shared__ u32 s_buf[6][2 * kMaxAlpha + 4];
+    __shared__ u32 s_lm[6];
+    __shared__ u32 s_scan[kHuffThreads / 64];
+    __shared__ u32 s_run;
+    __shared__ u32 s_first[6][24], s_lcount[6][24];
+
+    const u32 lb = blockIdx.x;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const u16 *mtf = a.mtf + (size_t)lb * a.mtf_stride;
+    const u32 *mtf_freq = a.mtf_freq + (size_t)lb * kMaxAlpha;
+    BlockOut &bo = a.out[lb];
+    const u32 mtf_count = bo.mtf_count;
+    const u32 in_use_count = bo.in_use_count;
+    const u32 alpha = in_use_count + 2; // encoder.rs:367
+    u8 *selector = a.selector + (size_t)lb * kSelStride;
+
+    u32 group_num; // encoder.rs:370-376
+    if (mtf_count < 200) group_num = 2;
+    else if (mtf_count < 600) group_num = 3;
+    else if (mtf_count < 1200) group_num = 4;
+    else if (mtf_count < 2400) group_num = 5;
+    else group_num = 6;
+    const u32 n_selectors = (mtf_count + kGSize - 1) / kGSize;
+
+    if (tid < 6) s_lm[tid] = 0;
+    // initial tables, encoder.rs:379-426.  The scan produces n_part = group_num..1; its
+    // k-th result is table (group_num-1-k) in selector order... which the reference then
+    // reverses, so scan result k IS the table with selector value (group_num-1-k).
+    if (tid == 0) {
+        u32 rem = mtf_count;
+        int gs = 0;
+        for (u32 k = 0; k < group_num; ++k) {
+            const u32 n_part = group_num - k;
+            const u32 t_freq = rem / n_part;
+            int ge = gs - 1;
+            u32 a_freq = 0;
+            while (a_freq < t_freq && ge < (int)alpha - 1) {
+                ge += 1;
+                a_freq += mtf_freq[ge];
+            }
+            if (ge > gs && n_part != group_num && n_part != 1 && (((group_num - n_part) & 1u) == 1u)) {
+                a_freq -= mtf_freq[ge];
+                ge -= 1;
+            }
+            u8 *l = s_len[group_num - 1 - k];
+            for (int i = 0; i < (int)alpha; ++i) l[i] = (i >= gs && i <= ge) ? 0 : 15; // :297-298
+            rem -= a_freq;
+            gs = ge + 1;
+        }
+    }
+    __syncthreads();
+
+    for (u32 iter = 0; iter < 4; ++iter) { // BZ_N_ITERS, encoder.rs:294,433
+        for (u32 i = tid; i < alpha; i += kHuffThreads) {
+            unsigned long long p = 0;
+            for (u32 t = 0; t < group_num; ++t) p |= (unsigned long long)s_len[t][i] << (10 * t);
+            s_pack[i] = p;
+        }
+        for (u32 i = tid; i < 6 * kMaxAlpha; i += kHuffThreads) (&s_rfreq[0][0])[i] = 0;
+        __syncthreads();
+        for (u32 g = tid; g < n_selectors; g += kHuffThreads) {
+            const u32 gs = g * kGSize;
+            const u32 ge = (gs + kGSize < mtf_count) ? gs + kGSize : mtf_count;
+            unsigned long long cost = 0;
+            for (u32 i = gs; i < ge; ++i) cost += s_pack[mtf[i]];
+            // first minimum wins (min_by, encoder.rs:466)
+            u32 bt = 0, bc = (u32)(cost & 1023u);
+            for (u32 t = 1; t < group_num; ++t) {
+                const u32 ct = (u32)((cost >> (10 * t)) & 1023u);
+                if (ct < bc) {
+                    bc = ct;
+                    bt = t;
+                }
+            }
+            selector[g] = (u8)bt;
+            for (u32 i = gs; i < ge; ++i) atomicAdd(&s_rfreq[bt][mtf[i]], 1u);
+        }
+        __syncthreads();
+        // one lane per table replays the serial heap procedure
+        if (lane == 0 && wave < group_num) {
+            const int lm = make_code_lengths(s_rfreq[wave], alpha, s_buf[wave], s_len[wave],
+                                             a.lm_scratch + ((size_t)lb * 6 + wave) * kLmWords);
+            if (lm) s_lm[wave] += 1;
+        }
+        __syncthreads();
+    }
+
+    // canonical codes, src/huffman/mod.rs:22-67 (stable by length, then symbol)
+    if (tid < 6 * 24) (&s_lcount[0][0])[tid] = 0;
+    __syncthreads();
+    for (u32 i = tid; i < group_num * alpha; i += kHuffThreads) {
+        const u32 t = i / alpha, s = i - t * alpha;
+        atomicAdd(&s_lcount[t][s_len[t][s]], 1u);
+    }
+    __syncthreads();
+    if (tid < group_num) {
+        u32 code = 0;
+        for (u32 l = 1; l < 24; ++l) {
+            code = (code + s_lcount[tid][l - 1]) << 1; // s_lcount[.][0] == 0: every symbol is coded
+            s_first[tid][l] = code;
+        }
+    }
+    __syncthreads();
+    u32 *code_len = a.code_len + (size_t)lb * 6 * kMaxAlpha;
+    u32 my_max = 0;
+    for (u32 i = tid; i < group_num * alpha; i += kHuffThreads) {
+        const u32 t = i / alpha, s = i - t * alpha;
+        const u32 l = s_len[t][s];
+        u32 r = 0;
+        for (u32 q = 0; q < s; ++q) r += (s_len[t][q] == l) ? 1u : 0u;
+        code_len[t * kMaxAlpha + s] = (s_first[t][l] + r) | (l << 24);
+        my_max = l > my_max ? l : my_max;
+    }
+#pragma unroll
+    for (u32 dd = 32; dd >= 1; dd >>= 1) {
+        const u32 o = __shfl_xor(my_max, dd, 64);
+        my_max = o > my_max ? o : my_max;
+    }
+    if (tid == 0) s_run = 0;
+    if (tid < kHuffThreads / 64) s_scan[tid] = 0;
+    __syncthreads();
+    if (lane == 0) atomicMax(&s_scan[0], my_max);
+    __syncthreads();
+    const u32 max_len = s_scan[0];
+    __syncthreads();
+
+    // payload bit offset of every group (exclusive scan over the groups)
+    u32 *gbo = a.group_bitoff + (size_t)lb * kGboStride;
+    for (u32 g0 = 0; g0 < n_selectors; g0 += kHuffThreads) {
+        const u32 g = g0 + tid;
+        u32 bits = 0;
+        if (g < n_selectors) {
+            const u32 gs = g * kGSize;
+            const u32 ge = (gs + kGSize < mtf_count) ? gs + kGSize : mtf_count;
+            const u8 *l = s_len[selector[g]];
+            for (u32 i = gs; i < ge; ++i) bits += l[mtf[i]];
+        }
+        const u32 inc = wave_incl_sum(bits);
+        if (lane == 63) s_scan[wave] = inc;
+        __syncthreads();
+        u32 carry = s_run, tot = 0;
+        for (u32 k = 0; k < kHuffThreads / 64; ++k) {
+            if (k < wave) carry += s_scan[k];
+            tot += s_scan[k];
+        }
+        if (g < n_selectors) gbo[g] = carry + inc - bits;
+        __syncthreads();
+        if (tid == 0) s_run += tot;
+        __syncthreads();
+    }
+    const u32 payload_bits = s_run;
+
+    // block header, written by one lane (it is a few hundred to ~25k bits)
+    u32 *stream = a.stream + (size_t)lb * kStreamWords;
+    if (tid == 0) {
+        BitSink bs{stream, 0ull, 0u, 0u};
+        bs.put(0x314159u, 24); // encoder.rs:254-259
+        bs.put(0x265359u, 24);
+        bs.put(a.crc[lb], 32); // :262
+        bs.put(0, 1);          // :273
+        bs.put(a.orig_ptr[lb], 24); // :333
+        // mapping table, :527-554
+        const u32 *bits = a.inuse_bits + lb * 8;
+        u32 in_use16 = 0;
+        for (u32 i = 0; i < 16; ++i) {
+            const u32 half = (bits[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
+            in_use16 = (in_use16 << 1) | (half ? 1u : 0u);
+        }
+        bs.put(in_use16, 16);
+        for (u32 i = 0; i < 16; ++i) {
+            const u32 half = (bits[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
+            if (half) bs.put(__brev(half) >> 16, 16); // byte value 16i+j is bit j: emit j = 0 first
+        }
+        // selectors, :567-574 with the MTF of :511-517
+        bs.put(group_num, 3);
+        bs.put(n_selectors, 15);
+        {
+            u32 lst = 0x543210u; // 4 bits per entry, entry 0 in the low nibble
+            for (u32 g = 0; g < n_selectors; ++g) {
+                const u32 v = selector[g];
+                u32 pos = 0;
+                while (((lst >> (4 * pos)) & 15u) != v) ++pos;
+                if (pos) {
+                    const u32 lowmask = (1u << (4 * pos)) - 1u;
+                    lst = (lst & ~((lowmask << 4) | 15u)) | ((lst & lowmask) << 4) | v;
+                }
+                bs.put((1u << (pos + 1)) - 2u, pos + 1);
+            }
+        }
+        // coding tables, :583-601
+        for (u32 t = 0; t < group_num; ++t) {
+            const u8 *l = s_len[t];
+            u32 curr = l[0];
+            bs.put(curr, 5);
+            for (u32 i = 0; i < alpha; ++i) {
+                const u32 li = l[i];
+                while (curr < li) { bs.put(2, 2); curr += 1; }
+                while (curr > li) { bs.put(3, 2); curr -= 1; }
+                bs.put(0, 1);
+            }
+        }
+        bs.finish();
+        const u32 hb = bs.bits();
+        bo.header_bits = hb;
+        bo.total_bits = (u64)hb + payload_bits;
+        bo.group_num = group_num;
+        bo.n_selectors = n_selectors;
+        bo.max_len = max_len;
+        bo.lm_tables = s_lm[0] + s_lm[1] + s_lm[2] + s_lm[3] + s_lm[4] + s_lm[5];
+        bo.crc = a.crc[lb];
+        bo.orig_ptr = a.orig_ptr[lb];
+        if ((u64)hb + payload_bits + 96u > (u64)kStreamWords * 32u) atomicExch(a.error_flag, 1u);
+        s_run = hb;
+    }
+    __syncthreads();
+    // zero the words the payload kernel will OR into
+    {
+        const u32 hb = s_run;
+        const u64 tb = (u64)hb + payload_bits;
+        u32 w0 = (hb + 31u) >> 5;
+        u32 w1 = (u32)(tb >> 5) + 2u;
+        if (w1 > kStreamWords) w1 = kStreamWords;
+        for (u32 w = w0 + tid; w < w1; w += kHuffThreads) stream[w] = 0;
+    }
+}
+
+// ---- payload: one lane per 50-symbol group (encoder.rs:609-629) ---------------------------
+__global__ __launch_bounds__(256) void k_emit_payload(HuffArgs a)
+{
+    __shared__ u32 s_code[6 * kMaxAlpha];
+    const u32 lb = blockIdx.y;
+    const BlockOut &bo = a.out[lb];
+    const u32 mtf_count = bo.mtf_count;
+    const u32 n_selectors = bo.n_selectors;
+    if (blockIdx.x * 256u >= n_selectors) return;
+    const u32 *code_len = a.code_len + (size_t)lb * 6 * kMaxAlpha;
+    for (u32 i = threadIdx.x; i < 6 * kMaxAlpha; i += 256u) s_code[i] = code_len[i];
+    __syncthreads();
+    const u32 g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= n_selectors) return;
+    const u16 *mtf = a.mtf + (size_t)lb * a.mtf_stride;
+    const u32 gs = g * kGSize;
+    const u32 ge = (gs + kGSize < mtf_count) ? gs + kGSize : mtf_count;
+    const u32 *tab = s_code + (u32)a.selector[(size_t)lb * kSelStride + g] * kMaxAlpha;
+    const u32 bitpos = bo.header_bits + a.group_bitoff[(size_t)lb * kGboStride + g];
+    u32 *stream = a.stream + (size_t)lb * kStreamWords;
+    u32 widx = bitpos >> 5;
+    u32 nacc = bitpos & 31u;
+    u64 acc = 0;
+    bool first = true;
+    for (u32 i = gs; i < ge; ++i) {
+        const u32 cl = tab[mtf[i]];
+        const u32 len = cl >> 24, code = cl & 0xFFFFFFu;
+        acc |= (u64)code << (64u - nacc - len);
+        nacc += len;
+        if (nacc >= 32u) {
+            const u32 word = (u32)(acc >> 32);
+            if (first) {
+                atomicOr(&stream[widx], word); // shared with the previous group / the header
+                first = false;
+            } else {
+                stream[widx] = word;           // all 32 bits are this group's
+            }
+            ++widx;
+            acc <<= 32;
+            nacc -= 32u;
+        }
+    }
+    if (nacc) atomicOr(&stream[widx], (u32)(acc >> 32)); // shared with the next group
+}
+
+void launch_huffman(hipStream_t st, const HuffArgs &a)
+{
+    hipLaunchKernelGGL(k_huffman, dim3(a.nb), dim3(kHuffThreads), 0, st, a);
+    hipLaunchKernelGGL(k_emit_payload, dim3((kMaxSelectors + 255) / 256, a.nb), dim3(256), 0, st, a);
+}
+
+// ---- probe: code lengths of one frequency table through the device code --------------------
+__global__ void k_probe_code_lengths(const u32 *freq, u32 alpha, u8 *out, u32 *lm_scr, int *lm_flag)
+{
+    __shared__ u32 s_buf[2 * kMaxAlpha + 4];
+    __shared__ u32 s_f[kMaxAlpha];
+    __shared__ u8 s_o[kMaxAlpha + 6];
+    if (threadIdx.x == 0) {
+        for (u32 i = 0; i < alpha; ++i) s_f[i] = freq[i];
+        *lm_flag = make_code_lengths(s_f, alpha, s_buf, s_o, lm_scr);
+        for (u32 i = 0; i < alpha; ++i) out[i] = s_o[i];
+    }
+}
+
+void launch_probe_code_lengths(hipStream_t st, const u32 *d_freq, u32 alpha, u8 *d_out, u32 *lm_scr,
+                               int *d_flag)
+{
+    hipLaunchKernelGGL(k_probe_code_lengths, dim3(1), dim3(64), 0, st, d_freq, alpha, d_out, lm_scr, d_flag);
+}
+
+} // namespace bzgpu

@@ -1,0 +1,397 @@
+// k_mtf.hip -- move-to-front + zero-run coding of the BWT last column.
+//
+// Reference being replaced: MtfPosition::pop (src/bzip2/mtf.rs:16-39), the symbol
+// loop and zle_write of write_blockdata (src/bzip2/encoder.rs:324-358, 653-669).
+//
+// MTF is a serial recurrence on a <=256-entry list, made parallel the classic way:
+//   M1  every 256-symbol chunk reports its "recency list" (distinct symbols, most
+//       recent first) -- that is exactly the head of the MTF list after the chunk;
+//   M2  one wave per block composes the chunk reports left to right and stores the
+//       list each chunk starts from (3516 chunks/block, 256 B each);
+//   M3  one lane per chunk replays its 256 symbols against its start list held in
+//       LDS (65-dword stride => bank = lane + entry/4), 4 list entries per LDS
+//       access, and writes the rank bytes.
+// The list works on raw byte values, initialised with the in-use bytes in
+// increasing order, which is the same thing as the reference's unseq2seq mapping
+// (encoder.rs:304-318) because that mapping is monotone.
+//   Z1-Z3  zero runs -> RUNA/RUNB digits (bijective base 2, LSB first), rank r>0 ->
+//       symbol r+1, EOB appended, symbol histogram (LDS atomics).
+#include "bzgpu.h"
+
+namespace bzgpu {
+
+constexpr u32 kChunkWGs = (kMaxMtfChunks + 255) / 256; // 14 workgroups of 256 chunks
+
+__device__ __forceinline__ u32 popc8(const u32 *b)
+{
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c += __popc(b[i]);
+    return c;
+}
+
+// ---- M1: recency list of each chunk ------------------------------------------------
+__global__ __launch_bounds__(256) void k_mtf_summaries(MtfArgs a)
+{
+    __shared__ u32 s_seen[8 * 256]; // [word][thread]: conflict-free
+    const u32 lb = blockIdx.y;
+    const u32 n = a.blocks[lb].n;
+    const u32 chunk = blockIdx.x * 256u + threadIdx.x;
+    const u32 beg = chunk * kMtfChunk;
+    if (beg >= n) return;
+    const u32 end = (beg + kMtfChunk < n) ? beg + kMtfChunk : n;
+    const u32 alpha = popc8(a.inuse_bits + lb * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s_seen[i * 256 + threadIdx.x] = 0;
+    const u8 *L = a.L + (size_t)lb * kSlot;
+    u8 *out = a.summ + ((size_t)lb * kMaxMtfChunks + chunk) * 256u;
+    u32 cnt = 0;
+    // walk backwards, 16 bytes at a time (chunk starts are 256-byte aligned)
+    for (int v = 15; v >= 0 && cnt < alpha; --v) {
+        const u32 p0 = beg + (u32)v * 16u;
+        if (p0 >= end) continue;
+        const uint4 q = *reinterpret_cast<const uint4 *>(L + p0);
+        const u32 wv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 15; k >= 0; --k) {
+            if (p0 + (u32)k < end) {
+                const u32 c = (wv[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+                const u32 bit = 1u << (c & 31u);
+                const u32 wd = s_seen[(c >> 5) * 256 + threadIdx.x];
+                if (!(wd & bit)) {
+                    s_seen[(c >> 5) * 256 + threadIdx.x] = wd | bit;
+                    out[cnt++] = (u8)c;
+                }
+            }
+        }
+    }
+    a.summ_len[(size_t)lb * kMaxMtfChunks + chunk] = (u16)cnt;
+}
+
+// ---- M2: compose the reports; one wave per block --------------------------------------
+__global__ __launch_bounds__(64) void k_mtf_compose(MtfArgs a)
+{
+    __shared__ u8 s_state[256];
+    __shared__ u8 s_new[256];
+    __shared__ u8 s_mark[256];
+    const u32 lb = blockIdx.x;
+    const u32 n = a.blocks[lb].n;
+    const u32 l = threadIdx.x;
+    const u32 nchunks = (n + kMtfChunk - 1) / kMtfChunk;
+    const u32 *bits = a.inuse_bits + lb * 8;
+    // identity list: in-use byte values ascending
+    {
+        u32 before = 0;
+        for (u32 q = 0; q < (l * 4u) / 32u; ++q) before += __popc(bits[q]);
+        // entries for byte values 4l..4l+3
+        const u32 wd = bits[(l * 4u) >> 5];
+        const u32 sh = (l * 4u) & 31u;
+        before += __popc(wd & ((1u << sh) - 1u));
+        for (u32 k = 0; k < 4; ++k) {
+            s_state[l * 4 + k] = 0;
+        }
+        __syncthreads();
+        u32 pos = before;
+        for (u32 k = 0; k < 4; ++k)
+            if ((wd >> (sh + k)) & 1u) s_state[pos++] = (u8)(l * 4u + k);
+    }
+    __syncthreads();
+    const u32 alpha = popc8(bits);
+    u32 *st32 = reinterpret_cast<u32 *>(s_state);
+    for (u32 c = 0; c < nchunks; ++c) {
+        // the list chunk c starts from
+        u32 *dst = reinterpret_cast<u32 *>(a.init_state + ((size_t)lb * kMaxMtfChunks + c) * 256u);
+        dst[l] = st32[l];
+        if (c + 1 == nchunks) break;
+        const u32 m = a.summ_len[(size_t)lb * kMaxMtfChunks + c];
+        const u8 *sm = a.summ + ((size_t)lb * kMaxMtfChunks + c) * 256u;
+        reinterpret_cast<u32 *>(s_mark)[l] = 0;
+        __syncthreads();
+        for (u32 i = l; i < m; i += 64) {
+            const u8 v = sm[i];
+            s_mark[v] = 1;
+            s_new[i] = v;
+        }
+        __syncthreads();
+        // stable compaction of the old entries that are not in the report
+        u32 keep[4], nk = 0;
+        u8 ev[4];
+#pragma unroll
+        for (u32 k = 0; k < 4; ++k) {
+            const u32 e = l * 4 + k;
+            ev[k] = s_state[e];
+            keep[k] = (e < alpha && !s_mark[ev[k]]) ? 1u : 0u;
+            nk += keep[k];
+        }
+        const u32 inc = wave_incl_sum(nk);
+        u32 pos = m + inc - nk;
+#pragma unroll
+        for (u32 k = 0; k < 4; ++k)
+            if (keep[k]) s_new[pos++] = ev[k];
+        __syncthreads();
+        st32[l] = reinterpret_cast<u32 *>(s_new)[l];
+        __syncthreads();
+    }
+}
+
+// ---- M3: one lane per chunk replays its symbols ------------------------------------------
+__global__ __launch_bounds__(256) void k_mtf_ranks(MtfArgs a)
+{
+    __shared__ u32 s_list[256 * 65];
+    const u32 lb = blockIdx.y;
+    const u32 n = a.blocks[lb].n;
+    const u32 chunk0 = blockIdx.x * 256u;
+    if (chunk0 * kMtfChunk >= n) return;
+    const u32 nchunks = (n + kMtfChunk - 1) / kMtfChunk;
+    // cooperative, coalesced load of up to 256 start lists (64 dwords each)
+    {
+        const u32 *src = reinterpret_cast<const u32 *>(a.init_state + ((size_t)lb * kMaxMtfChunks + chunk0) * 256u);
+        const u32 avail = (nchunks - chunk0 < 256u ? nchunks - chunk0 : 256u) * 64u;
+        for (u32 i = threadIdx.x; i < avail; i += 256u) s_list[(i >> 6) * 65u + (i & 63u)] = src[i];
+    }
+    __syncthreads();
+    const u32 chunk = chunk0 + threadIdx.x;
+    const u32 beg = chunk * kMtfChunk;
+    if (beg >= n) return;
+    const u32 end = (beg + kMtfChunk < n) ? beg + kMtfChunk : n;
+    u32 *list = s_list + threadIdx.x * 65u;
+    const u8 *L = a.L + (size_t)lb * kSlot;
+    u8 *R8 = a.rank8 + (size_t)lb * kSlot;
+    for (u32 v = 0; v < 16; ++v) {
+        const u32 p0 = beg + v * 16u;
+        if (p0 >= end) break;
+        const uint4 q = *reinterpret_cast<const uint4 *>(L + p0);
+        const u32 wv[4] = {q.x, q.y, q.z, q.w};
+        u32 ov[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (u32 k = 0; k < 16; ++k) {
+            u32 rank = 0;
+            if (p0 + k < end) {
+                const u32 c = (wv[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+                u32 w = list[0];
+                if ((w & 0xFFu) != c) {
+                    const u32 rep = c * 0x01010101u;
+                    u32 carry = c, d = 0;
+                    while (true) {
+                        const u32 x = w ^ rep;
+                        const u32 z = (x - 0x01010101u) & ~x & 0x80808080u;
+                        if (z == 0) {
+                            list[d] = (w << 8) | carry;
+                            carry = w >> 24;
+                            ++d;
+                            if (d == 64u) { // symbol not in the list: impossible for in-use bytes
+                                rank = 0xFFu;
+                                break;
+                            }
+                            w = list[d];
+                            continue;
+                        }
+                        const u32 b = (u32)__builtin_ctz(z) >> 3;
+                        const u32 upto = (b == 3u) ? 0xFFFFFFFFu : ((1u << (8u * (b + 1u))) - 1u);
+                        const u32 lowm = upto >> 8;
+                        list[d] = (w & ~upto) | ((((w & lowm) << 8) | carry) & upto);
+                        rank = 4u * d + b;
+                        break;
+                    }
+                }
+            }
+            ov[k >> 2] |= rank << ((k & 3) * 8);
+        }
+        *reinterpret_cast<uint4 *>(R8 + p0) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+    }
+}
+
+// ---- ZLE helpers ----------------------------------------------------------------------------
+struct ZSeg {
+    u8 r[16];
+    u32 valid;
+    u32 p0;
+    int next_nonzero; // 1 if the position after the segment holds a non-zero rank or is past the end
+};
+
+__device__ __forceinline__ void zload(const u8 *__restrict__ R8, u32 n, u32 tile, ZSeg &s)
+{
+    s.p0 = tile * kSortTile + threadIdx.x * 16u;
+    s.valid = s.p0 < n ? ((n - s.p0) < 16u ? (n - s.p0) : 16u) : 0u;
+    if (s.valid) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(R8 + s.p0);
+        const u32 wv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s.r[k] = (u8)(wv[k >> 2] >> ((k & 3) * 8));
+        const u32 nx = s.p0 + s.valid;
+        s.next_nonzero = (nx >= n) ? 1 : (R8[nx] != 0);
+    } else {
+        s.next_nonzero = 1;
+    }
+}
+
+__device__ __forceinline__ int block_excl_max_int(int v, int *sh /*[16]*/)
+{
+    const u32 l = lane_id(), w = threadIdx.x >> 6;
+    const int inc = wave_incl_max32(v);
+    if (l == 63) sh[w] = inc;
+    __syncthreads();
+    int carry = -1;
+    for (u32 k = 0; k < w; ++k) carry = sh[k] > carry ? sh[k] : carry;
+    const int prev = __shfl_up(inc, 1, 64);
+    const int ex = (l == 0) ? -1 : prev;
+    __syncthreads();
+    return ex > carry ? ex : carry;
+}
+
+__device__ __forceinline__ u32 block_excl_sum1024(u32 v, u32 *sh /*[16]*/, u32 &total)
+{
+    const u32 l = lane_id(), w = threadIdx.x >> 6;
+    const u32 inc = wave_incl_sum(v);
+    if (l == 63) sh[w] = inc;
+    __syncthreads();
+    u32 carry = 0, tot = 0;
+    for (u32 k = 0; k < kSortThreads / 64; ++k) {
+        if (k < w) carry += sh[k];
+        tot += sh[k];
+    }
+    total = tot;
+    __syncthreads();
+    return carry + inc - v;
+}
+
+// Z1: last non-zero rank position per tile
+__global__ __launch_bounds__(kSortThreads) void k_zle_last(MtfArgs a)
+{
+    __shared__ int s_last;
+    const u32 lb = blockIdx.y, tile = blockIdx.x;
+    const u32 n = a.blocks[lb].n;
+    if (tile * kSortTile >= n) return;
+    if (threadIdx.x == 0) s_last = -1;
+    __syncthreads();
+    ZSeg s;
+    zload(a.rank8 + (size_t)lb * kSlot, n, tile, s);
+    int last = -1;
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k)
+        if (k < s.valid && s.r[k]) last = (int)(s.p0 + k);
+#pragma unroll
+    for (u32 dd = 32; dd >= 1; dd >>= 1) {
+        const int o = __shfl_xor(last, dd, 64);
+        last = o > last ? o : last;
+    }
+    if (lane_id() == 0 && last >= 0) atomicMax(&s_last, last);
+    __syncthreads();
+    if (threadIdx.x == 0) a.ztile_last[lb * kTilesPerBlock + tile] = s_last;
+}
+
+// number of symbols a zero run of length z becomes: digits of z in bijective base 2
+__device__ __forceinline__ u32 run_digits(u32 z) { return 31u - (u32)__clz(z + 1u); }
+
+// Z2 (WRITE=false): count output symbols per tile.  Z3 (WRITE=true): write them.
+template <bool WRITE>
+__global__ __launch_bounds__(kSortThreads) void k_zle_emit(MtfArgs a)
+{
+    __shared__ int s_mi[16];
+    __shared__ u32 s_su[16];
+    __shared__ u32 s_freq[kMaxAlpha + 2];
+    __shared__ int s_carry;
+    __shared__ u32 s_base;
+    const u32 lb = blockIdx.y, tile = blockIdx.x;
+    const u32 n = a.blocks[lb].n;
+    if (tile * kSortTile >= n) return;
+    if (threadIdx.x == 0) {
+        int c = -1;
+        for (int t = (int)tile - 1; t >= 0 && c < 0; --t) c = a.ztile_last[lb * kTilesPerBlock + t];
+        s_carry = c;
+        if (WRITE) {
+            u32 b = 0;
+            for (u32 t = 0; t < tile; ++t) b += a.ztile_cnt[lb * kTilesPerBlock + t];
+            s_base = b;
+        }
+    }
+    if (WRITE)
+        for (u32 i = threadIdx.x; i < kMaxAlpha + 2; i += kSortThreads) s_freq[i] = 0;
+    __syncthreads();
+    ZSeg s;
+    zload(a.rank8 + (size_t)lb * kSlot, n, tile, s);
+    int last = -1;
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k)
+        if (k < s.valid && s.r[k]) last = (int)(s.p0 + k);
+    int lnz = block_excl_max_int(last, s_mi); // last non-zero position before this segment
+    lnz = lnz > s_carry ? lnz : s_carry;
+    // pass 1: count
+    u32 cnt = 0;
+    {
+        int ln = lnz;
+#pragma unroll
+        for (u32 k = 0; k < 16; ++k) {
+            if (k < s.valid) {
+                const u32 p = s.p0 + k;
+                if (s.r[k]) {
+                    ln = (int)p;
+                    cnt += 1;
+                } else {
+                    const bool run_end = (k + 1 < s.valid) ? (s.r[(k + 1) & 15] != 0) : (s.next_nonzero != 0);
+                    if (run_end) cnt += run_digits((u32)((int)p - ln));
+                }
+            }
+        }
+    }
+    u32 total;
+    u32 off = block_excl_sum1024(cnt, s_su, total);
+    if (!WRITE) {
+        if (threadIdx.x == 0) a.ztile_cnt[lb * kTilesPerBlock + tile] = total;
+        return;
+    }
+    u16 *out = a.mtf + (size_t)lb * kMtfStride + s_base + off;
+    {
+        int ln = lnz;
+#pragma unroll
+        for (u32 k = 0; k < 16; ++k) {
+            if (k < s.valid) {
+                const u32 p = s.p0 + k;
+                if (s.r[k]) {
+                    ln = (int)p;
+                    const u32 sym = (u32)s.r[k] + 1u; // encoder.rs:340,349
+                    *out++ = (u16)sym;
+                    atomicAdd(&s_freq[sym], 1u);
+                } else {
+                    const bool run_end = (k + 1 < s.valid) ? (s.r[(k + 1) & 15] != 0) : (s.next_nonzero != 0);
+                    if (run_end) {
+                        u32 zc = (u32)((int)p - ln) + 1u; // encoder.rs:659-667
+                        while (zc > 1u) {
+                            const u32 run = zc & 1u;
+                            *out++ = (u16)run;
+                            atomicAdd(&s_freq[run], 1u);
+                            zc >>= 1;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const bool last_tile = (tile + 1) * kSortTile >= n;
+    if (last_tile && threadIdx.x == 0) {
+        const u32 alpha_in = popc8(a.inuse_bits + lb * 8);
+        const u32 eob = alpha_in + 1u; // encoder.rs:316
+        a.mtf[(size_t)lb * kMtfStride + s_base + total] = (u16)eob;
+        atomicAdd(&s_freq[eob], 1u);
+        a.out[lb].mtf_count = s_base + total + 1u;
+        a.out[lb].in_use_count = alpha_in;
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < kMaxAlpha; i += kSortThreads)
+        if (s_freq[i]) atomicAdd(&a.mtf_freq[(size_t)lb * kMaxAlpha + i], s_freq[i]);
+}
+
+void launch_mtf(hipStream_t st, const MtfArgs &a)
+{
+    (void)hipMemsetAsync(a.mtf_freq, 0, (size_t)a.nb * kMaxAlpha * sizeof(u32), st);
+    hipLaunchKernelGGL(k_mtf_summaries, dim3(kChunkWGs, a.nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_mtf_compose, dim3(a.nb), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_mtf_ranks, dim3(kChunkWGs, a.nb), dim3(256), 0, st, a);
+    const dim3 grid(kTilesPerBlock, a.nb);
+    hipLaunchKernelGGL(k_zle_last, grid, dim3(kSortThreads), 0, st, a);
+    hipLaunchKernelGGL((k_zle_emit<false>), grid, dim3(kSortThreads), 0, st, a);
+    hipLaunchKernelGGL((k_zle_emit<true>), grid, dim3(kSortThreads), 0, st, a);
+}
+
+} // namespace bzgpu

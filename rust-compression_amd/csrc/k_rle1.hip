@@ -1,0 +1,541 @@
+// k_rle1.hip -- RLE1, block split and block CRC as data-parallel kernels.
+//
+// Reference being replaced: EncoderInner::next / write_rle
+// (src/bzip2/encoder.rs:671-716), the block cut at :692 and the CRC update at
+// :701-702 (src/crc32.rs:58-84, 128-149).
+//
+// Restatement that makes it parallel.  A "chunk" is a maximal same-byte run cut
+// every 255 bytes from the run's start (encoder.rs:682).  For input position p
+// with run start rs(p):  q = p - rs(p),  c = q mod 255 (position inside its
+// chunk).  Position p emits its byte iff c < 4, and a count byte (c-3) iff it
+// is the last byte of its chunk and c >= 3.  The RLE1 image of the whole input
+// is therefore one exclusive prefix sum away, and blocks are contiguous slices
+// of it: a block is cut right after the first chunk whose end brings the block
+// to >= 100000*level-19 bytes (encoder.rs:186,692).  Only the cut positions are
+// a serial chain (about 1200 per GiB).
+//
+// HBM traffic: the input is read 3x (tile scan+CRC, count, scatter) and the
+// image written once -- all coalesced 16 B/lane.
+#include "bzgpu.h"
+
+namespace bzgpu {
+
+constexpr u32 RT = 256; // threads per RLE tile
+
+__device__ __forceinline__ i64 block_excl_max64(i64 v, i64 *sh /*[RT/64 + 1]*/, i64 &total)
+{
+    // exclusive max-scan over the workgroup in thread order
+    const u32 l = lane_id(), w = threadIdx.x >> 6;
+    i64 inc = wave_incl_max64(v);
+    if (l == 63) sh[w] = inc;
+    __syncthreads();
+    i64 carry = -1;
+    for (u32 k = 0; k < w; ++k) carry = sh[k] > carry ? sh[k] : carry;
+    i64 tot = -1;
+    for (u32 k = 0; k < RT / 64; ++k) tot = sh[k] > tot ? sh[k] : tot;
+    total = tot;
+    i64 prev = __shfl_up(inc, 1, 64);
+    i64 ex = (l == 0) ? (i64)-1 : prev;
+    __syncthreads();
+    return ex > carry ? ex : carry;
+}
+
+__device__ __forceinline__ u32 block_excl_sum(u32 v, u32 *sh /*[RT/64]*/, u32 &total)
+{
+    const u32 l = lane_id(), w = threadIdx.x >> 6;
+    u32 inc = wave_incl_sum(v);
+    if (l == 63) sh[w] = inc;
+    __syncthreads();
+    u32 carry = 0, tot = 0;
+    for (u32 k = 0; k < RT / 64; ++k) {
+        if (k < w) carry += sh[k];
+        tot += sh[k];
+    }
+    total = tot;
+    __syncthreads();
+    return carry + inc - v;
+}
+
+// load the 16 bytes of this thread (tile t, thread tid) + the byte before and after
+struct Seg {
+    u8 b[16];
+    int prev;  // byte before p0 or -1
+    int next;  // byte after the segment or -1 (end of input)
+    u64 p0;
+    u32 valid; // number of valid bytes (0..16)
+};
+
+__device__ __forceinline__ void load_seg(const u8 *__restrict__ in, u64 n, u64 tile, Seg &s)
+{
+    s.p0 = tile * (u64)kRleTile + (u64)threadIdx.x * 16u;
+    if (s.p0 + 16 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(in + s.p0);
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s.b[k] = (u8)(w[k >> 2] >> ((k & 3) * 8));
+        s.valid = 16;
+    } else {
+        s.valid = s.p0 < n ? (u32)(n - s.p0) : 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s.b[k] = (u32)k < s.valid ? in[s.p0 + k] : (u8)0;
+    }
+    s.prev = (s.p0 > 0 && s.valid > 0) ? (int)in[s.p0 - 1] : -1;
+    s.next = (s.p0 + s.valid < n && s.valid > 0) ? (int)in[s.p0 + s.valid] : -1;
+}
+
+// ---- kernel A: per-tile last run start + per-tile raw CRC ---------------------
+// crc_tab: 256-entry byte table (src/crc32.rs:58-72); xp16: x^(8*16*k) mod P, k=0..255
+__global__ __launch_bounds__(RT) void k_rle_tile_scan(const u8 *__restrict__ in, u64 n,
+                                                       const u32 *__restrict__ crc_tab,
+                                                       const u32 *__restrict__ xp16,
+                                                       i64 *__restrict__ tile_last_start,
+                                                       u32 *__restrict__ tile_crc)
+{
+    __shared__ u32 s_tab[256];
+    __shared__ i64 s_max[RT / 64];
+    __shared__ u32 s_x[RT / 64];
+    s_tab[threadIdx.x] = crc_tab[threadIdx.x];
+    __syncthreads();
+
+    const u64 tile = blockIdx.x;
+    Seg s;
+    load_seg(in, n, tile, s);
+
+    i64 last = -1;
+    int pb = s.prev;
+    u32 crc = 0;
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k) {
+        if (k < s.valid) {
+            if ((int)s.b[k] != pb) last = (i64)(s.p0 + k);
+            pb = s.b[k];
+            crc = s_tab[(crc >> 24) ^ s.b[k]] ^ (crc << 8);
+        }
+    }
+    // shift this thread's CRC to the end of the tile: bytes after it inside the tile
+    const u64 tile_beg = tile * (u64)kRleTile;
+    const u32 tile_len = (u32)((n - tile_beg) < (u64)kRleTile ? (n - tile_beg) : (u64)kRleTile);
+    if (s.valid > 0) {
+        const u32 after = tile_len - (threadIdx.x * 16u + s.valid);
+        if ((after & 15u) == 0) {
+            crc = gf_mulmod(crc, xp16[after >> 4]);
+        } else { // only in the last, partial tile
+            u32 m = gf_mulmod(xp16[after >> 4], 1u);
+            for (u32 k = 0; k < (after & 15u); ++k) m = gf_mulmod(m, 0x100u); // * x^8
+            crc = gf_mulmod(crc, m);
+        }
+    } else {
+        crc = 0;
+    }
+    i64 wl = last;
+#pragma unroll
+    for (u32 d = 32; d >= 1; d >>= 1) {
+        i64 o = __shfl_xor(wl, d, 64);
+        wl = o > wl ? o : wl;
+    }
+    const u32 wx = wave_xor(crc);
+    if (lane_id() == 0) {
+        s_max[threadIdx.x >> 6] = wl;
+        s_x[threadIdx.x >> 6] = wx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        i64 m = -1;
+        u32 x = 0;
+        for (u32 k = 0; k < RT / 64; ++k) {
+            m = s_max[k] > m ? s_max[k] : m;
+            x ^= s_x[k];
+        }
+        tile_last_start[tile] = m;
+        tile_crc[tile] = x;
+    }
+}
+
+// ---- kernel B: exclusive max-scan over tiles (one workgroup) -------------------
+__global__ __launch_bounds__(1024) void k_rle_scan_tiles_max(const i64 *__restrict__ tile_last,
+                                                              i64 *__restrict__ carry_in, u64 ntiles)
+{
+    __shared__ i64 s_part[1024];
+    const u64 per = (ntiles + 1023) / 1024;
+    const u64 a = (u64)threadIdx.x * per;
+    const u64 b = (a + per < ntiles) ? a + per : ntiles;
+    i64 m = -1;
+    for (u64 t = a; t < b; ++t) m = tile_last[t] > m ? tile_last[t] : m;
+    s_part[threadIdx.x] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        i64 run = -1;
+        for (u32 k = 0; k < 1024; ++k) {
+            i64 v = s_part[k];
+            s_part[k] = run;
+            run = v > run ? v : run;
+        }
+    }
+    __syncthreads();
+    i64 run = s_part[threadIdx.x];
+    for (u64 t = a; t < b; ++t) {
+        carry_in[t] = run;
+        run = tile_last[t] > run ? tile_last[t] : run;
+    }
+}
+
+// Per-thread RLE1 evaluation of its 16 positions.
+//   rs_in : run start that is live when the segment begins (from earlier threads/tiles), -1 if p0==0
+// Produces the emitted-byte count, and (optionally) the bytes.
+struct SegEval {
+    u32 count;      // bytes this segment emits
+    u32 c_first;    // chunk phase of the first position
+};
+
+__device__ __forceinline__ u32 phase_of(u64 p, i64 rs)
+{
+    return (u32)((p - (u64)rs) % 255u);
+}
+
+// fills e[k] = number of bytes position k emits (0,1,2); returns sum
+__device__ __forceinline__ u32 eval_seg(const Seg &s, i64 rs_in, u8 e[16], u8 cph[16])
+{
+    u32 sum = 0;
+    i64 rs = rs_in;
+    int pb = s.prev;
+    u32 c = 0;
+    bool have_c = false;
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k) {
+        u32 ek = 0;
+        u32 ck = 0;
+        if (k < s.valid) {
+            const u64 p = s.p0 + k;
+            if ((int)s.b[k] != pb) {
+                rs = (i64)p;
+                c = 0;
+                have_c = true;
+            } else if (!have_c) {
+                c = phase_of(p, rs);
+                have_c = true;
+            } else {
+                c = (c == 254u) ? 0u : c + 1u;
+            }
+            pb = s.b[k];
+            const int nb = (k + 1 < s.valid) ? (int)s.b[k + 1 < 16 ? k + 1 : 15] : s.next;
+            const bool chunk_end = (nb != (int)s.b[k]) || (c == 254u);
+            ek = (c < 4u ? 1u : 0u) + ((chunk_end && c >= 3u) ? 1u : 0u);
+            ck = c;
+        }
+        e[k] = (u8)ek;
+        cph[k] = (u8)ck;
+        sum += ek;
+    }
+    return sum;
+}
+
+// run start live at the beginning of each thread's segment
+__device__ __forceinline__ i64 seg_run_start(const Seg &s, i64 tile_carry, i64 *sh)
+{
+    i64 last = -1;
+    int pb = s.prev;
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k) {
+        if (k < s.valid) {
+            if ((int)s.b[k] != pb) last = (i64)(s.p0 + k);
+            pb = s.b[k];
+        }
+    }
+    i64 tot;
+    i64 ex = block_excl_max64(last, sh, tot);
+    return ex > tile_carry ? ex : tile_carry;
+}
+
+// ---- kernel C: bytes emitted per tile -------------------------------------------
+__global__ __launch_bounds__(RT) void k_rle_count(const u8 *__restrict__ in, u64 n,
+                                                   const i64 *__restrict__ carry_in,
+                                                   u32 *__restrict__ tile_count)
+{
+    __shared__ i64 s_m[RT / 64 + 1];
+    __shared__ u32 s_s[RT / 64];
+    const u64 tile = blockIdx.x;
+    Seg s;
+    load_seg(in, n, tile, s);
+    const i64 rs = seg_run_start(s, carry_in[tile], s_m);
+    u8 e[16], cph[16];
+    const u32 cnt = eval_seg(s, rs, e, cph);
+    u32 tot;
+    (void)block_excl_sum(cnt, s_s, tot);
+    if (threadIdx.x == 0) tile_count[tile] = tot;
+}
+
+// ---- kernel D: exclusive sum over tiles (one workgroup), u64 offsets -------------
+__global__ __launch_bounds__(1024) void k_rle_scan_tiles_sum(const u32 *__restrict__ tile_count,
+                                                              u64 *__restrict__ tile_off, u64 ntiles,
+                                                              u64 *__restrict__ total)
+{
+    __shared__ u64 s_part[1024];
+    const u64 per = (ntiles + 1023) / 1024;
+    const u64 a = (u64)threadIdx.x * per;
+    const u64 b = (a + per < ntiles) ? a + per : ntiles;
+    u64 m = 0;
+    for (u64 t = a; t < b; ++t) m += tile_count[t];
+    s_part[threadIdx.x] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 run = 0;
+        for (u32 k = 0; k < 1024; ++k) {
+            u64 v = s_part[k];
+            s_part[k] = run;
+            run += v;
+        }
+        *total = run;
+        tile_off[ntiles] = run;
+    }
+    __syncthreads();
+    u64 run = s_part[threadIdx.x];
+    for (u64 t = a; t < b; ++t) {
+        tile_off[t] = run;
+        run += tile_count[t];
+    }
+}
+
+// ---- kernel E: scatter the RLE1 image -------------------------------------------
+__global__ __launch_bounds__(RT) void k_rle_scatter(const u8 *__restrict__ in, u64 n,
+                                                     const i64 *__restrict__ carry_in,
+                                                     const u64 *__restrict__ tile_off,
+                                                     u8 *__restrict__ rle)
+{
+    __shared__ i64 s_m[RT / 64 + 1];
+    __shared__ u32 s_s[RT / 64];
+    __shared__ u8 s_out[2 * kRleTile];
+    const u64 tile = blockIdx.x;
+    Seg s;
+    load_seg(in, n, tile, s);
+    const i64 rs = seg_run_start(s, carry_in[tile], s_m);
+    u8 e[16], cph[16];
+    const u32 cnt = eval_seg(s, rs, e, cph);
+    u32 tot;
+    u32 o = block_excl_sum(cnt, s_s, tot);
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k) {
+        if (e[k]) {
+            if (cph[k] < 4u) s_out[o++] = s.b[k];
+            if (e[k] == 2u || cph[k] >= 4u) s_out[o++] = (u8)(cph[k] - 3u);
+        }
+    }
+    __syncthreads();
+    u8 *dst = rle + tile_off[tile];
+    for (u32 i = threadIdx.x; i < tot; i += RT) dst[i] = s_out[i];
+}
+
+// ---- kernel F: the serial chain of block cuts (one workgroup) --------------------
+// Emits BlockDesc records.  emit_tail: also emit the remaining partial block.
+__global__ __launch_bounds__(RT) void k_rle_cuts(const u8 *__restrict__ in, u64 n,
+                                                  const i64 *__restrict__ carry_in,
+                                                  const u64 *__restrict__ tile_off, u64 ntiles,
+                                                  u32 block_max_len, int emit_tail,
+                                                  BlockDesc *__restrict__ blocks, u32 max_blocks,
+                                                  u64 *__restrict__ out_nblocks_consumed /*[3]*/)
+{
+    __shared__ i64 s_m[RT / 64 + 1];
+    __shared__ u32 s_s[RT / 64];
+    __shared__ u64 s_tile;
+    __shared__ u64 s_cut_rle, s_cut_in;
+    __shared__ int s_found;
+
+    const u64 M = tile_off[ntiles];
+    u64 s_rle = 0, s_in = 0;
+    u32 nb = 0;
+
+    while (true) {
+        const u64 target = s_rle + block_max_len;
+        if (M < target || M == s_rle) break; // no chunk end reaches the limit any more
+        // tile holding the first position whose inclusive prefix >= target:
+        // largest t with tile_off[t] < target
+        if (threadIdx.x == 0) {
+            u64 lo = 0, hi = ntiles - 1;
+            while (lo < hi) {
+                u64 mid = (lo + hi + 1) >> 1;
+                if (tile_off[mid] < target) lo = mid; else hi = mid - 1;
+            }
+            s_tile = lo;
+            s_found = 0;
+        }
+        __syncthreads();
+        const u64 tile = s_tile;
+        Seg s;
+        load_seg(in, n, tile, s);
+        const i64 rs = seg_run_start(s, carry_in[tile], s_m);
+        u8 e[16], cph[16];
+        const u32 cnt = eval_seg(s, rs, e, cph);
+        u32 tot;
+        const u32 ex = block_excl_sum(cnt, s_s, tot);
+        const u64 base = tile_off[tile] + ex;
+        if (base < target && base + cnt >= target) {
+            // this thread holds p0*: walk to it, then on to the end of its chunk
+            u64 acc = base;
+            u32 k = 0;
+            for (; k < 16; ++k) {
+                acc += e[k];
+                if (acc >= target) break;
+            }
+            u64 p = s.p0 + k;
+            u32 c = cph[k];
+            // advance to the chunk end (at most 254 steps)
+            while (true) {
+                const bool last = (p + 1 >= n);
+                const bool chunk_end = last || in[p + 1] != in[p] || c == 254u;
+                if (chunk_end) break;
+                ++p;
+                ++c;
+                acc += (c < 4u ? 1u : 0u);
+                const bool end2 = (p + 1 >= n) || in[p + 1] != in[p] || c == 254u;
+                if (end2 && c >= 3u) acc += 1u;
+            }
+            s_cut_rle = acc;
+            s_cut_in = p + 1;
+            s_found = 1;
+        }
+        __syncthreads();
+        if (!s_found) break; // cannot happen; guards against an endless loop
+        const u64 cut_rle = s_cut_rle, cut_in = s_cut_in;
+        if (threadIdx.x == 0 && nb < max_blocks) {
+            BlockDesc d;
+            d.rle_off = s_rle;
+            d.in_off = s_in;
+            d.in_end = cut_in;
+            d.n = (u32)(cut_rle - s_rle);
+            d.pad = 0;
+            blocks[nb] = d;
+        }
+        ++nb;
+        s_rle = cut_rle;
+        s_in = cut_in;
+        __syncthreads();
+    }
+    u32 tail = 0;
+    if (emit_tail && M > s_rle) {
+        tail = 1;
+        if (threadIdx.x == 0 && nb < max_blocks) {
+            BlockDesc d;
+            d.rle_off = s_rle;
+            d.in_off = s_in;
+            d.in_end = n;
+            d.n = (u32)(M - s_rle);
+            d.pad = 0;
+            blocks[nb] = d;
+        }
+        ++nb;
+        s_in = n;
+    }
+    if (threadIdx.x == 0) {
+        out_nblocks_consumed[0] = nb;
+        out_nblocks_consumed[1] = s_in;
+        out_nblocks_consumed[2] = tail; // 1: the last block is the unfinished tail, not one closed by a cut
+    }
+}
+
+// ---- kernel G: block CRC from tile CRCs -------------------------------------------
+// xp2[k] = x^(8 * 2^k) mod P, k = 0..47
+__device__ __forceinline__ u32 gf_xpow_bytes(u64 nbytes, const u32 *__restrict__ xp2)
+{
+    u32 r = 1u;
+    for (u32 k = 0; nbytes; ++k, nbytes >>= 1)
+        if (nbytes & 1u) r = gf_mulmod(r, xp2[k]);
+    return r;
+}
+
+__device__ __forceinline__ u32 crc_bytes_raw(const u8 *__restrict__ p, u64 len, const u32 *s_tab)
+{
+    u32 crc = 0;
+    for (u64 i = 0; i < len; ++i) crc = s_tab[(crc >> 24) ^ p[i]] ^ (crc << 8);
+    return crc;
+}
+
+__global__ __launch_bounds__(RT) void k_block_crc(const u8 *__restrict__ in,
+                                                   const BlockDesc *__restrict__ blocks,
+                                                   const u32 *__restrict__ crc_tab,
+                                                   const u32 *__restrict__ xp2,
+                                                   const u32 *__restrict__ tile_crc,
+                                                   u32 *__restrict__ out_crc)
+{
+    __shared__ u32 s_tab[256];
+    __shared__ u32 s_x[RT / 64];
+    s_tab[threadIdx.x] = crc_tab[threadIdx.x];
+    __syncthreads();
+    const BlockDesc d = blocks[blockIdx.x];
+    const u64 a = d.in_off, b = d.in_end;
+    const u64 ft = (a + kRleTile - 1) / kRleTile; // first full tile
+    const u64 lt = b / kRleTile;                  // one past the last full tile
+    u32 acc = 0;
+    if (ft >= lt) {
+        // short range: 16-byte pieces straight from the bytes
+        for (u64 p = a + (u64)threadIdx.x * 16u; p < b; p += (u64)RT * 16u) {
+            const u64 len = (b - p) < 16u ? (b - p) : 16u;
+            const u32 c = crc_bytes_raw(in + p, len, s_tab);
+            acc ^= gf_mulmod(c, gf_xpow_bytes(b - (p + len), xp2));
+        }
+    } else {
+        const u64 head_end = ft * kRleTile, tail_beg = lt * kRleTile;
+        // head and tail pieces
+        for (u64 p = a + (u64)threadIdx.x * 16u; p < head_end; p += (u64)RT * 16u) {
+            const u64 len = (head_end - p) < 16u ? (head_end - p) : 16u;
+            const u32 c = crc_bytes_raw(in + p, len, s_tab);
+            acc ^= gf_mulmod(c, gf_xpow_bytes(b - (p + len), xp2));
+        }
+        for (u64 p = tail_beg + (u64)threadIdx.x * 16u; p < b; p += (u64)RT * 16u) {
+            const u64 len = (b - p) < 16u ? (b - p) : 16u;
+            const u32 c = crc_bytes_raw(in + p, len, s_tab);
+            acc ^= gf_mulmod(c, gf_xpow_bytes(b - (p + len), xp2));
+        }
+        // full tiles: each thread folds a contiguous run of tiles
+        const u64 nt = lt - ft;
+        const u64 per = (nt + RT - 1) / RT;
+        const u64 t0 = ft + (u64)threadIdx.x * per;
+        const u64 t1 = (t0 + per < lt) ? t0 + per : lt;
+        if (t0 < t1) {
+            const u32 xt = xp2[12]; // x^(8*4096)
+            u32 c = 0;
+            for (u64 t = t0; t < t1; ++t) c = gf_mulmod(c, xt) ^ tile_crc[t];
+            acc ^= gf_mulmod(c, gf_xpow_bytes(b - t1 * kRleTile, xp2));
+        }
+    }
+    const u32 wx = wave_xor(acc);
+    if (lane_id() == 0) s_x[threadIdx.x >> 6] = wx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 x = 0;
+        for (u32 k = 0; k < RT / 64; ++k) x ^= s_x[k];
+        // init 0xFFFFFFFF rides through the whole message; final NOT (crc32.rs:128-131)
+        x ^= gf_mulmod(0xFFFFFFFFu, gf_xpow_bytes(b - a, xp2));
+        out_crc[blockIdx.x] = ~x;
+    }
+}
+
+// ---- host launchers -----------------------------------------------------------------
+void launch_rle1(hipStream_t st, const u8 *d_in, u64 n, const u32 *crc_tab, const u32 *xp16,
+                 const RleBuffers &rb, u8 *d_rle, u32 block_max_len, int emit_tail,
+                 BlockDesc *d_blocks, u32 max_blocks)
+{
+    const u64 ntiles = (n + kRleTile - 1) / kRleTile;
+    if (ntiles == 0) {
+        (void)hipMemsetAsync(rb.cut_result, 0, 3 * sizeof(u64), st);
+        return;
+    }
+    hipLaunchKernelGGL(k_rle_tile_scan, dim3((u32)ntiles), dim3(RT), 0, st, d_in, n, crc_tab, xp16,
+                       rb.tile_last, rb.tile_crc);
+    hipLaunchKernelGGL(k_rle_scan_tiles_max, dim3(1), dim3(1024), 0, st, rb.tile_last, rb.carry_in, ntiles);
+    hipLaunchKernelGGL(k_rle_count, dim3((u32)ntiles), dim3(RT), 0, st, d_in, n, rb.carry_in, rb.tile_count);
+    hipLaunchKernelGGL(k_rle_scan_tiles_sum, dim3(1), dim3(1024), 0, st, rb.tile_count, rb.tile_off, ntiles,
+                       rb.total);
+    hipLaunchKernelGGL(k_rle_scatter, dim3((u32)ntiles), dim3(RT), 0, st, d_in, n, rb.carry_in, rb.tile_off,
+                       d_rle);
+    hipLaunchKernelGGL(k_rle_cuts, dim3(1), dim3(RT), 0, st, d_in, n, rb.carry_in, rb.tile_off, ntiles,
+                       block_max_len, emit_tail, d_blocks, max_blocks, rb.cut_result);
+}
+
+void launch_block_crc(hipStream_t st, const u8 *d_in, const BlockDesc *d_blocks, u32 nblocks,
+                      const u32 *crc_tab, const u32 *xp2, const u32 *tile_crc, u32 *d_crc)
+{
+    if (nblocks == 0) return;
+    hipLaunchKernelGGL(k_block_crc, dim3(nblocks), dim3(RT), 0, st, d_in, d_blocks, crc_tab, xp2, tile_crc,
+                       d_crc);
+}
+
+} // namespace bzgpu

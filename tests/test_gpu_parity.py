@@ -1,0 +1,217 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same inputs -- bit-exact."""
+import bz2
+import hashlib
+import json
+import os
+import random
+
+import pytest
+
+from conftest import GOLDEN, product, sample
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(GOLDEN, "reference_vectors.json")) as f:
+    V = json.load(f)
+
+
+@pytest.fixture(scope="module")
+def eng(pkg):
+    e = pkg.GpuEngine(0, 16)
+    yield e
+    e.close()
+
+
+def test_library_loaded_and_device(pkg):
+    assert pkg.device_count() >= 1
+
+
+def test_known_answer_stream(pkg):
+    v = V["stream_a_nl_level9"]
+    assert pkg.compress(bytes.fromhex(v["input_hex"]), 9).hex() == v["output_hex"]
+
+
+@pytest.mark.parametrize("v", V["bwt_pos"], ids=lambda v: v["src_hex"][:16])
+def test_bwt_reference_vectors(eng, v):
+    assert eng.debug_bwt(bytes.fromhex(v["src_hex"])) == v["pos"]
+
+
+@pytest.mark.parametrize("v", V["bwt_L"], ids=lambda v: v["src"][:12])
+def test_bwt_L_vectors(eng, v):
+    src = v["src"].encode()
+    sa = eng.debug_bwt(src)
+    assert bytes(src[(s - 1) % len(src)] for s in sa) == v["L"].encode()
+
+
+def test_bwt_random_vs_oracle(eng, oracle):
+    rng = random.Random(11)
+    for _ in range(60):
+        n = rng.randint(1, 3000)
+        k = rng.choice([1, 2, 3, 4, 16, 256])
+        s = bytes(rng.randrange(k) for _ in range(n))
+        assert eng.debug_bwt(s) == oracle.bwt(s), (n, k)
+
+
+def test_bwt_periodic_tie_rule(eng, oracle):
+    rng = random.Random(12)
+    cases = [b"aaaa", b"abab", b"abcabcabc", b"cabcabcab", b"a", b"aa", b"ab" * 500, b"aaaa\xfb" * 200]
+    for _ in range(40):
+        p = rng.randint(1, 9)
+        u = bytes(rng.randrange(3) for _ in range(p))
+        cases.append(u * rng.randint(2, 300))
+    for s in cases:
+        assert eng.debug_bwt(s) == oracle.bwt(s), s[:20]
+
+
+def test_bwt_deep_lcp(eng, oracle):
+    para = bytes(random.Random(5).randrange(97, 123) for _ in range(997))
+    s = (para * 40)[:35000]
+    assert eng.debug_bwt(s) == oracle.bwt(s)
+
+
+def test_code_lengths_vs_oracle(eng, oracle):
+    rng = random.Random(3)
+    fib = [1, 1]
+    while len(fib) < 25:
+        fib.append(fib[-1] + fib[-2])
+    tables = [fib[:20], fib[:25], [5] * 7, [1, 1, 1, 1, 2], [0] * 6, [3, 3, 2, 2, 1, 1, 1], [0, 0, 0]]
+    for _ in range(60):
+        n = rng.randint(3, 258)
+        r = rng.uniform(0.35, 0.9)
+        f = [int(900000 * (1 - r) * r ** i * rng.uniform(0.7, 1.3)) for i in range(n)]
+        rng.shuffle(f)
+        tables.append(f)
+    fired = 0
+    for f in tables:
+        got, lm = eng.debug_code_lengths(f)
+        exp, elm = oracle.bzip2_code_lengths(f, 17)
+        assert (got, lm) == (exp, elm), f[:8]
+        fired += lm
+    assert fired >= 5  # the length-limited path (cano_huff_table.rs:58-151) is exercised
+
+
+SMALL = [b"", b"a", b"a\n", b"ab" * 500, b"a" * 1000, b"aabbaabbaabbaabb\n", b"a" * 255, b"a" * 256, b"a" * 259,
+         b"abc" * 7, bytes(range(256)), bytes(range(256)) * 3, b"\x00" * 70000, b"xy" * 40000]
+
+
+@pytest.mark.parametrize("i", range(len(SMALL)))
+def test_small_streams(pkg, oracle, i):
+    d = SMALL[i]
+    out = pkg.compress(d, 9)
+    assert out == oracle.encode(d, 9)
+    assert bz2.decompress(out) == d
+
+
+@pytest.mark.parametrize("i", [1, 2, 3, 4])
+def test_samples_level9(pkg, oracle, i):
+    d = sample(i)
+    out = pkg.compress(d, 9)
+    assert out == oracle.encode(d, 9)
+    assert bz2.decompress(out) == d
+
+
+@pytest.mark.parametrize("i,level", [(1, 1), (2, 2), (3, 3), (2, 1), (4, 1)])
+def test_samples_reference_levels(pkg, oracle, i, level):
+    """src/bzip2/mod.rs:84-139 uses levels 1/2/3 (several blocks per sample)."""
+    d = sample(i)
+    out = pkg.compress(d, level)
+    assert out == oracle.encode(d, level)
+    assert bz2.decompress(out) == d
+
+
+def _text(n, seed):
+    rng = random.Random(seed)
+    words = ["".join(rng.choice("etaoinshrdlucmfw") for _ in range(rng.randint(2, 9))) for _ in range(600)]
+    out = bytearray()
+    while len(out) < n:
+        out += rng.choice(words).encode() + (b" " if rng.random() > 0.1 else b".\n")
+    return bytes(out[:n])
+
+
+def test_multiblock_text_level9(pkg, oracle):
+    d = _text(2_100_000, 1)
+    out = pkg.compress(d, 9)
+    assert out == oracle.encode(d, 9)
+
+
+def test_multiblock_runs_level1(pkg, oracle):
+    rng = random.Random(5)
+    d = b"".join(bytes([rng.randrange(4)]) * rng.randint(1, 700) for _ in range(3000))
+    out = pkg.compress(d, 1)
+    assert out == oracle.encode(d, 1)
+    assert bz2.decompress(out) == d
+
+
+def test_block_stats_match_oracle(pkg, oracle):
+    import torch
+    d = sample(2)
+    eng = pkg.GpuEngine(0, 8)
+    t = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+    o = torch.empty(pkg.encode_bound(len(d)) + 16, dtype=torch.uint8, device="cuda")
+    n = eng.encode_device(1, t.data_ptr(), len(d), o.data_ptr(), o.numel())
+    got = eng.block_stats()
+    exp_stream, exp = oracle.encode(d, 1, with_stats=True)
+    assert bytes(o[:n].cpu().numpy()) == exp_stream
+    assert len(got) == len(exp)
+    for g, e in zip(got, exp):
+        for k in ("nblock", "block_crc", "orig_ptr", "mtf_count", "in_use_count", "group_num", "n_selectors", "max_len"):
+            assert g[k] == e[k], k
+    eng.close()
+
+
+# ---- Action semantics through the streaming context ---------------------------------------
+
+def test_streaming_run_then_finish(pkg, oracle):
+    d = sample(1)
+    enc = pkg.BZip2Encoder(1)
+    ora = oracle.Encoder(1)
+    a = enc.encode_all(d[:40000], pkg.Action.RUN)
+    b = enc.encode_all(d[40000:], pkg.Action.FINISH)
+    assert a == ora.encode_iter(d[:40000], oracle.ACTION_RUN)
+    assert b == ora.encode_iter(d[40000:], oracle.ACTION_FINISH)
+    assert a + b == oracle.encode(d, 1)
+
+
+def test_streaming_flush_sequences(pkg, oracle):
+    rng = random.Random(8)
+    d = sample(3)[:60000] + _text(150000, 3)
+    for trial in range(4):
+        enc = pkg.BZip2Encoder(1)
+        ora = oracle.Encoder(1)
+        pos = 0
+        while pos < len(d):
+            step = rng.randint(1, 90000)
+            act = rng.choice([pkg.Action.RUN, pkg.Action.FLUSH, pkg.Action.RUN])
+            piece = d[pos:pos + step]
+            pos += step
+            assert enc.encode_all(piece, act) == ora.encode_iter(piece, int(act)), (trial, pos, act)
+        assert enc.encode_all(b"", pkg.Action.FINISH) == ora.encode_iter(b"", oracle.ACTION_FINISH)
+
+
+def test_flush_on_fresh_encoder(pkg, oracle):
+    enc = pkg.BZip2Encoder(9)
+    ora = oracle.Encoder(9)
+    assert enc.encode_all(b"", pkg.Action.FLUSH) == ora.encode_iter(b"", oracle.ACTION_FLUSH)
+    assert enc.encode_all(b"hello world", pkg.Action.FLUSH) == ora.encode_iter(b"hello world", oracle.ACTION_FLUSH)
+    assert enc.encode_all(b"", pkg.Action.FINISH) == ora.encode_iter(b"", oracle.ACTION_FINISH)
+
+
+def test_encoder_iterator_api(pkg):
+    enc = pkg.BZip2Encoder(9)
+    out = bytes(pkg.encode(b"a\n", enc, pkg.Action.FINISH))
+    assert out.hex() == V["stream_a_nl_level9"]["output_hex"]
+
+
+def test_invalid_level(pkg):
+    for lv in (0, 10):
+        with pytest.raises(ValueError):
+            pkg.BZip2Encoder(lv)
+        with pytest.raises(ValueError):
+            pkg.compress(b"x", lv)
+
+
+def test_determinism(pkg):
+    d = _text(1_200_000, 9)
+    h = {hashlib.sha256(pkg.compress(d, 9)).hexdigest() for _ in range(3)}
+    assert len(h) == 1
