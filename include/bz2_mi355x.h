@@ -168,6 +168,9 @@ int bz_gpu_assemble(bz_gpu_engine *g, int level, size_t n_blocks,
 int bz_gpu_last_timings(bz_gpu_engine *g, double out_seconds[6]);
 /* BWT rounds executed (prefix doubling) and total sorted elements, last call */
 int bz_gpu_last_bwt_stats(bz_gpu_engine *g, uint64_t out[4]);
+/* rotations still unordered after the initial 4-byte sort (out[0]) and after each doubling
+ * round (out[1..]), summed over the blocks of the last encode */
+int bz_gpu_last_bwt_rounds(bz_gpu_engine *g, uint64_t out[64]);
 
 /* Per-kernel timing of the BWT kernels (HIP events around every launch, on the engine's
  * stream).  Enable, run encodes, then read: kernel name (all template instances of one

@@ -61,7 +61,7 @@ EXPORTS = [
     "bz_encode_buffer", "bz_free",
     "bz_gpu_engine_create", "bz_gpu_engine_destroy", "bz_encode_bound", "bz_gpu_encode_device",
     "bz_gpu_partition", "bz_gpu_encode_blocks", "bz_gpu_assemble", "bz_gpu_last_timings",
-    "bz_gpu_last_bwt_stats", "bz_gpu_profile_enable", "bz_gpu_profile_kernels", "bz_gpu_profile_get",
+    "bz_gpu_last_bwt_stats", "bz_gpu_last_bwt_rounds", "bz_gpu_profile_enable", "bz_gpu_profile_kernels", "bz_gpu_profile_get",
     "bz_gpu_debug_bwt", "bz_gpu_debug_code_lengths", "bz_gpu_debug_block_stats",
 ]
 
@@ -126,6 +126,7 @@ def lib():
                                   C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     L.bz_gpu_last_timings.argtypes = [vp, C.POINTER(C.c_double)]
     L.bz_gpu_last_bwt_stats.argtypes = [vp, u64p]
+    L.bz_gpu_last_bwt_rounds.argtypes = [vp, u64p]
     L.bz_gpu_profile_enable.argtypes = [vp, C.c_int]
     L.bz_gpu_profile_kernels.argtypes = [vp]
     L.bz_gpu_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), u64p, C.POINTER(C.c_double), u64p]
@@ -314,7 +315,12 @@ class GpuEngine:
     def bwt_stats(self):
         s = (C.c_uint64 * 4)()
         _check(lib().bz_gpu_last_bwt_stats(self._h, s))
-        return {"rounds": s[0], "resorted_elements": s[1], "batches": s[2]}
+        r = (C.c_uint64 * 64)()
+        _check(lib().bz_gpu_last_bwt_rounds(self._h, r))
+        unordered = [int(x) for x in r]
+        while unordered and unordered[-1] == 0:
+            unordered.pop()
+        return {"rounds": s[0], "resorted_elements": s[1], "batches": s[2], "unordered_after_round": unordered}
 
     def block_stats(self):
         n = C.c_size_t(0)

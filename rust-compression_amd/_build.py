@@ -10,7 +10,7 @@ SOURCES = ["k_rle1.hip", "k_bwt.hip", "k_mtf.hip", "k_huff.hip", "k_emit.hip", "
 HEADERS = ["bzgpu.h", os.path.join("..", "..", "include", "bz2_mi355x.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-D__HIP_PLATFORM_AMD__"]
+         "-D__HIP_PLATFORM_AMD__"] + os.environ.get("BZ_EXTRA_FLAGS", "").split()
 
 
 def _stale(target, deps):

@@ -56,6 +56,30 @@ struct BlockOut {
     u64 total_bits;
 };
 
+// ---- streaming access hints -----------------------------------------------------
+// Arrays that are swept once per kernel (sorted pair lists, SA as the walk source) are loaded
+// non-temporally so they do not push the block's rank array (3.6 MB, gathered at random) out of the
+// XCD's 4 MiB L2.  -DBZ_USE_NT=0 turns the hint off (A/B switch).
+#ifndef BZ_USE_NT
+#define BZ_USE_NT 1
+#endif
+template <class T> __device__ __forceinline__ T ld_stream(const T *p)
+{
+#if BZ_USE_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <class T> __device__ __forceinline__ void st_stream(T *p, T v)
+{
+#if BZ_USE_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // ---- wave64 primitives -------------------------------------------------------
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
 
@@ -253,7 +277,7 @@ void launch_rle1(hipStream_t st, const u8 *d_in, u64 n, const u32 *crc_tab, cons
 void launch_block_crc(hipStream_t st, const u8 *d_in, const BlockDesc *d_blocks, u32 nblocks,
                       const u32 *crc_tab, const u32 *xp2, const u32 *tile_crc, u32 *d_crc);
 int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned long long *h_active,
-            u64 *sorted_elems, KernelProf *prof);
+            u64 *sorted_elems, KernelProf *prof, u64 *round_active /*[64] or null*/);
 void launch_last_column(hipStream_t st, const BwtArgs &a, u8 *L, u32 *orig_ptr, u32 *inuse_bits, u64 total_n,
                         KernelProf *prof);
 void launch_mtf(hipStream_t st, const MtfArgs &a);

@@ -81,6 +81,7 @@ struct bz_gpu_engine {
     double t_stage[6] = {0, 0, 0, 0, 0, 0};
     KernelProf prof;
     u64 bwt_stats[4] = {0, 0, 0, 0};
+    u64 round_active[64] = {};
 
     struct Span {
         int stage;
@@ -250,6 +251,7 @@ extern "C" int bz_gpu_partition(bz_gpu_engine *g, int level, const void *d_in, s
     g->h_crc.clear();
     for (double &t : g->t_stage) t = 0;
     for (u64 &s : g->bwt_stats) s = 0;
+    for (u64 &s : g->round_active) s = 0;
     if (n_blocks) *n_blocks = 0;
     if (consumed) *consumed = 0;
     if (tail_block) *tail_block = 0;
@@ -325,7 +327,7 @@ static int encode_batch(bz_gpu_engine *g, u32 nb, u32 max_n, u64 total_n)
 
     int sp = span_begin(g, 1);
     u64 sorted = 0;
-    const int rounds = run_bwt(g->st, ba, max_n, total_n, g->h_active, &sorted, &g->prof);
+    const int rounds = run_bwt(g->st, ba, max_n, total_n, g->h_active, &sorted, &g->prof, g->round_active);
     if (rounds < 0) return BZ_E_UNEXPECTED;
     launch_last_column(g->st, ba, g->L.as<u8>(), g->orig_ptr.as<u32>(), g->inuse_bits.as<u32>(), total_n, &g->prof);
     span_end(g, sp);
@@ -544,6 +546,13 @@ extern "C" int bz_gpu_last_bwt_stats(bz_gpu_engine *g, uint64_t out[4])
     return BZ_OK;
 }
 
+extern "C" int bz_gpu_last_bwt_rounds(bz_gpu_engine *g, uint64_t out[64])
+{
+    if (!g) return BZ_E_PARAM;
+    for (int i = 0; i < 64; ++i) out[i] = g->round_active[i];
+    return BZ_OK;
+}
+
 extern "C" int bz_gpu_debug_block_stats(bz_gpu_engine *g, uint32_t *h_stats, size_t cap_blocks, size_t *n_blocks)
 {
     if (!g) return BZ_E_PARAM;
@@ -599,7 +608,7 @@ extern "C" int bz_gpu_debug_bwt(bz_gpu_engine *g, const uint8_t *h_block, size_t
     ba.per_k = g->per_k.as<u32>();
     ba.per_shift = g->per_shift.as<u32>();
     u64 sorted = 0;
-    const int rounds = run_bwt(g->st, ba, (u32)n, (u64)n, g->h_active, &sorted, nullptr);
+    const int rounds = run_bwt(g->st, ba, (u32)n, (u64)n, g->h_active, &sorted, nullptr, nullptr);
     if (rounds < 0) return BZ_E_UNEXPECTED;
     g->bwt_stats[0] = (u64)rounds;
     g->bwt_stats[1] = sorted;

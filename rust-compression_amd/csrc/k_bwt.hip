@@ -61,17 +61,65 @@ __device__ __forceinline__ bool fetch(const BwtArgs &a, u32 lb, const u8 *__rest
         val = idx;
         return true;
     } else if (SRC == SRC_PAIRS) {
-        key = Kin[base + idx];
-        val = Vin[base + idx];
+        key = ld_stream(Kin + base + idx);
+        val = ld_stream(Vin + base + idx);
         return true;
     } else {
-        const u32 s = a.SA[base + idx];
+        const u32 s = ld_stream(a.SA + base + idx);
         const u32 j = (s >= hm) ? s - hm : s + n - hm;
         const u32 r = a.R[base + j];
         key = r;
         val = j;
         return (r & kFinalBit) == 0;
     }
+}
+
+// Batched form: the 16 rows of one lane.  All primary loads are issued back to back (clamped
+// index instead of a branch), then all dependent gathers, so a wave keeps 16-32 memory
+// operations in flight instead of one -- these kernels are latency-bound otherwise.
+// first = index of the lane's row-0 element; rows are 64 apart.  Returns the participation mask.
+template <int SRC>
+__device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__restrict__ text, u32 n, u32 hm,
+                                          const u32 *__restrict__ Kin, const u32 *__restrict__ Vin, u32 first,
+                                          u32 cnt, u32 (&key)[16], u32 (&val)[16])
+{
+    const size_t base = (size_t)lb * kSlot;
+    u32 ok = 0;
+    if (SRC == SRC_TEXT) {
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) {
+            const u32 idx = first + r * 64u;
+            const u32 c = idx < cnt ? idx : cnt - 1u;
+            key[r] = text_key4(text, n, c);
+            val[r] = c;
+            ok |= (idx < cnt ? 1u : 0u) << r;
+        }
+    } else if (SRC == SRC_PAIRS) {
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) {
+            const u32 idx = first + r * 64u;
+            const u32 c = idx < cnt ? idx : cnt - 1u;
+            key[r] = ld_stream(Kin + base + c);
+            val[r] = ld_stream(Vin + base + c);
+            ok |= (idx < cnt ? 1u : 0u) << r;
+        }
+    } else {
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) {
+            const u32 idx = first + r * 64u;
+            const u32 c = idx < cnt ? idx : cnt - 1u;
+            const u32 s = ld_stream(a.SA + base + c);
+            val[r] = (s >= hm) ? s - hm : s + n - hm;
+        }
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) key[r] = a.R[base + val[r]];
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) {
+            const u32 idx = first + r * 64u;
+            ok |= ((idx < cnt && !(key[r] & kFinalBit)) ? 1u : 0u) << r;
+        }
+    }
+    return ok;
 }
 
 // ---- radix pass, part 1: per-tile digit histogram ---------------------------------
@@ -96,14 +144,12 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shif
     for (u32 i = threadIdx.x; i < NB; i += kSortThreads) s_hist[i] = 0;
     __syncthreads();
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
-#pragma unroll 4
-    for (u32 r = 0; r < 16; ++r) {
-        const u32 idx = start + w * 1024u + r * 64u + l;
-        if (idx < cnt) {
-            u32 key, val;
-            if (fetch<SRC>(a, lb, text, n, hm, Kin, Vin, idx, key, val))
-                atomicAdd(&s_hist[(key >> shift) & (NB - 1)], 1u);
-        }
+    {
+        u32 key[16], val[16];
+        const u32 ok = fetch_rows<SRC>(a, lb, text, n, hm, Kin, Vin, start + w * 1024u + l, cnt, key, val);
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r)
+            if ((ok >> r) & 1u) atomicAdd(&s_hist[(key[r] >> shift) & (NB - 1)], 1u);
     }
     __syncthreads();
     u32 *out = a.tile_hist + ((size_t)lb * kTilesPerBlock + tile) * kMaxBins;
@@ -176,8 +222,16 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
 {
     constexpr u32 NB = 1u << BITS;
     constexpr u32 NW = kSortThreads / 64;
-    __shared__ u16 s_cnt[NW * NB];
+    // One 64 KiB LDS buffer, used twice: first as the per-(wave, digit) counters, then as the
+    // staging area that puts the tile's elements in digit order so the global stores of
+    // consecutive lanes hit consecutive addresses (a lane-per-bin scatter costs one cache line
+    // per lane).
+    __shared__ u32 s_buf[kSortTile];
     __shared__ u32 s_base[NB];
+    __shared__ u16 s_tpre[NB];
+    __shared__ u32 s_wsum[NW];
+    __shared__ u32 s_total;
+    u16 *s_cnt = reinterpret_cast<u16 *>(s_buf); // [NW][NB] u16 <= 64 KiB
     u32 tile, lb;
     xcd_remap(kTilesPerBlock, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
@@ -191,8 +245,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
     const size_t base = (size_t)lb * kSlot;
 
     {
-        u32 *z = reinterpret_cast<u32 *>(s_cnt);
-        for (u32 i = threadIdx.x; i < NW * NB / 2; i += kSortThreads) z[i] = 0;
+        for (u32 i = threadIdx.x; i < NW * NB / 2; i += kSortThreads) s_buf[i] = 0;
         const u32 *hist = a.tile_hist + ((size_t)lb * kTilesPerBlock + tile) * kMaxBins;
         for (u32 i = threadIdx.x; i < NB; i += kSortThreads) s_base[i] = hist[i];
     }
@@ -204,13 +257,10 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
 
     u32 key[16], val[16];
     u32 rnk[16]; // 0xFFFFFFFF = takes no part
+    const u32 okmask = fetch_rows<SRC>(a, lb, text, n, hm, Kin, Vin, start + w * 1024u + l, cnt, key, val);
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
-        const u32 idx = start + w * 1024u + r * 64u + l;
-        bool ok = false;
-        key[r] = 0;
-        val[r] = 0;
-        if (idx < cnt) ok = fetch<SRC>(a, lb, text, n, hm, Kin, Vin, idx, key[r], val[r]);
+        const bool ok = (okmask >> r) & 1u;
         const u32 dg = (key[r] >> shift) & (NB - 1);
         u64 peers = __ballot(ok);
 #pragma unroll
@@ -230,8 +280,13 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
         // LDS ops of one wave retire in order: the next row's reads see this row's writes
     }
     __syncthreads();
-    // exclusive prefix over waves, per digit
-    for (u32 dg = threadIdx.x; dg < NB; dg += kSortThreads) {
+    // exclusive prefix over waves per digit, and the tile's total per digit
+    constexpr u32 PER = NB / kSortThreads; // digits per thread (1 or 2), consecutive
+    u32 tot[PER];
+    u32 mine = 0;
+#pragma unroll
+    for (u32 q = 0; q < PER; ++q) {
+        const u32 dg = threadIdx.x * PER + q;
         u32 run = 0;
 #pragma unroll
         for (u32 k = 0; k < NW; ++k) {
@@ -239,16 +294,62 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
             s_cnt[k * NB + dg] = (u16)run;
             run += c;
         }
+        tot[q] = run;
+        mine += run;
+    }
+    // exclusive scan of the totals over digits (digit order == thread order)
+    {
+        const u32 inc = wave_incl_sum(mine);
+        if (l == 63) s_wsum[w] = inc;
+        __syncthreads();
+        u32 carry = 0, total = 0;
+        for (u32 k = 0; k < NW; ++k) {
+            if (k < w) carry += s_wsum[k];
+            total += s_wsum[k];
+        }
+        u32 ex = carry + inc - mine;
+#pragma unroll
+        for (u32 q = 0; q < PER; ++q) {
+            s_tpre[threadIdx.x * PER + q] = (u16)ex;
+            ex += tot[q];
+        }
+        if (threadIdx.x == 0) s_total = total;
+    }
+    __syncthreads();
+    // position of every element in the tile's digit order
+    u32 lpos[16];
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 dg = (key[r] >> shift) & (NB - 1);
+        lpos[r] = (rnk[r] != 0xFFFFFFFFu) ? (u32)s_tpre[dg] + (u32)my_cnt[dg] + rnk[r] : 0xFFFFFFFFu;
+    }
+    const u32 total = s_total;
+    __syncthreads(); // counters are dead from here on: the buffer becomes the staging area
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r)
+        if (lpos[r] != 0xFFFFFFFFu) s_buf[lpos[r]] = key[r];
+    __syncthreads();
+    u32 dst[16];
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k) {
+        const u32 i = k * kSortThreads + threadIdx.x;
+        dst[k] = 0xFFFFFFFFu;
+        if (i < total) {
+            const u32 kk = s_buf[i];
+            const u32 dg = (kk >> shift) & (NB - 1);
+            dst[k] = s_base[dg] + (i - (u32)s_tpre[dg]);
+            Kout[base + dst[k]] = kk;
+        }
     }
     __syncthreads();
 #pragma unroll
-    for (u32 r = 0; r < 16; ++r) {
-        if (rnk[r] != 0xFFFFFFFFu) {
-            const u32 dg = (key[r] >> shift) & (NB - 1);
-            const u32 dst = s_base[dg] + my_cnt[dg] + rnk[r];
-            Kout[base + dst] = key[r];
-            Vout[base + dst] = val[r];
-        }
+    for (u32 r = 0; r < 16; ++r)
+        if (lpos[r] != 0xFFFFFFFFu) s_buf[lpos[r]] = val[r];
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k) {
+        const u32 i = k * kSortThreads + threadIdx.x;
+        if (i < total) Vout[base + dst[k]] = s_buf[i];
     }
 }
 
@@ -276,40 +377,59 @@ __global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 h, 
     __syncthreads();
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
     int last_old = -1, last_new = -1;
-#pragma unroll 2
+    const u32 first = start + w * 1024u + l;
+    u32 g[16], s[16];
+    // row 0 of lane 0 also needs the element just before the wave's range
+    u32 pg0 = 0, ps0 = 0;
+    {
+        u32 jj[16];
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) {
+            const u32 idx = first + r * 64u;
+            const u32 c = idx < cnt ? idx : cnt - 1u;
+            const u32 kk = ld_stream(K + base + c);
+            if (INIT) {
+                g[r] = 0;
+                s[r] = kk;
+            } else {
+                g[r] = kk;
+                u32 t = ld_stream(V + base + c) + hm;
+                jj[r] = t >= n ? t - n : t;
+            }
+        }
+        u32 pj = 0;
+        const bool need_prev = (l == 0) && (first > 0) && (first < cnt);
+        if (need_prev) {
+            const u32 kk = K[base + first - 1];
+            if (INIT) {
+                ps0 = kk;
+            } else {
+                pg0 = kk;
+                u32 t = V[base + first - 1] + hm;
+                pj = t >= n ? t - n : t;
+            }
+        }
+        if (!INIT) {
+#pragma unroll
+            for (u32 r = 0; r < 16; ++r) s[r] = a.R[base + jj[r]];
+            if (need_prev) ps0 = a.R[base + pj];
+        }
+    }
+#pragma unroll
     for (u32 r = 0; r < 16; ++r) {
-        const u32 idx = start + w * 1024u + r * 64u + l;
+        const u32 idx = first + r * 64u;
         const bool ok = idx < cnt;
-        u32 g = 0, s = 0;
-        if (ok) {
-            const u32 kk = K[base + idx];
-            if (INIT) {
-                s = kk;
-            } else {
-                g = kk;
-                const u32 j = V[base + idx];
-                u32 jj = j + hm;
-                if (jj >= n) jj -= n;
-                s = a.R[base + jj];
-            }
-        }
-        u32 pg = __shfl_up(g, 1, 64), ps = __shfl_up(s, 1, 64);
-        if (l == 0 && ok && idx > 0) {
-            const u32 kk = K[base + idx - 1];
-            if (INIT) {
-                ps = kk;
-                pg = 0;
-            } else {
-                pg = kk;
-                const u32 j = V[base + idx - 1];
-                u32 jj = j + hm;
-                if (jj >= n) jj -= n;
-                ps = a.R[base + jj];
-            }
+        u32 pg = __shfl_up(g[r], 1, 64), ps = __shfl_up(s[r], 1, 64);
+        // lane 0: the previous element is lane 63 of the previous row (or the pre-loaded one)
+        const u32 qg = (r == 0) ? pg0 : __shfl(g[(r + 15) & 15], 63, 64);
+        const u32 qs = (r == 0) ? ps0 : __shfl(s[(r + 15) & 15], 63, 64);
+        if (l == 0) {
+            pg = qg;
+            ps = qs;
         }
         if (ok) {
-            const bool os = (idx == 0) || (g != pg);
-            const bool ns = os || (s != ps);
+            const bool os = (idx == 0) || (g[r] != pg);
+            const bool ns = os || (s[r] != ps);
             a.flags[base + idx] = (u8)((os ? 1u : 0u) | (ns ? 2u : 0u));
             if (os) last_old = (int)idx;
             if (ns) last_new = (int)idx;
@@ -361,12 +481,21 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 h_n
     }
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
     const u32 wbase = start + w * 1024u;
+    // the pair list is loaded up front (16 rows in flight), the flag bytes likewise
+    u32 gk[16], jv[16];
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 idx = wbase + r * 64u + l;
+        const u32 c = idx < cnt ? idx : cnt - 1u;
+        gk[r] = INIT ? 0u : ld_stream(K + base + c);
+        jv[r] = ld_stream(V + base + c);
+    }
     u64 mo[16], mn[16];
     int wl_old = -1, wl_new = -1;
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
         const u32 idx = wbase + r * 64u + l;
-        const u32 f = (idx < cnt) ? a.flags[base + idx] : 0u;
+        const u32 f = (idx < cnt) ? ld_stream(a.flags + base + idx) : 0u;
         mo[r] = __ballot(f & 1u);
         mn[r] = __ballot(f & 2u);
         if (mo[r]) wl_old = (int)(wbase + r * 64u + 63u - __clzll(mo[r]));
@@ -400,11 +529,11 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 h_n
             else next_new = (a.flags[base + idx + 1] & 2u) != 0;
             const bool is_new = (mn[r] >> l) & 1ull;
             const bool fin = is_new && next_new;
-            const u32 g = INIT ? 0u : K[base + idx];
-            const u32 j = V[base + idx];
+            const u32 g = gk[r];
+            const u32 j = jv[r];
             const u32 p = g + (idx - (u32)rs);
             const u32 head = g + ((u32)ss - (u32)rs);
-            a.SA[base + p] = j;
+            st_stream(a.SA + base + p, j);
             a.R[base + j] = head | (fin ? kFinalBit : 0u);
             my_nonfinal += fin ? 0u : 1u;
         }
@@ -583,7 +712,7 @@ static void radix_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const
 // lengths (for the profiler's byte accounting).
 // Returns the number of doubling rounds executed, <0 on HIP error.
 int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned long long *h_active,
-            u64 *sorted_elems, KernelProf *prof)
+            u64 *sorted_elems, KernelProf *prof, u64 *round_active)
 {
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
     (void)hipMemsetAsync(a.active, 0, 64 * sizeof(unsigned long long), st);
@@ -610,6 +739,7 @@ int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned l
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
         const u64 m = *h_active; // rotations still to be ordered (in unfinished blocks)
         if (sorted_elems) *sorted_elems += m;
+        if (round_active && slot < 64) round_active[slot] += m;
         if (m == 0 || h >= max_n) break;
         ++slot;
         ++rounds;

@@ -221,6 +221,19 @@ struct BitSink {
     __device__ u32 bits() const { return widx * 32 + nacc; }
 };
 
+// Cooperative, coalesced load of the symbols of groups [g0, g0 + blockDim) into LDS (two u16 per
+// dword; a group starts on a 100-byte = dword boundary).
+__device__ __forceinline__ void stage_symbols(u32 *s_sym, const u16 *__restrict__ mtf, u32 g0, u32 mtf_count)
+{
+    const u32 first = g0 * kGSize;                       // symbol index, even
+    const u32 avail = mtf_count - first;                 // > 0
+    const u32 want = blockDim.x * kGSize;
+    const u32 nsym = avail < want ? avail : want;
+    const u32 ndw = (nsym + 1u) >> 1;
+    const u32 *src = reinterpret_cast<const u32 *>(mtf + first);
+    for (u32 i = threadIdx.x; i < ndw; i += blockDim.x) s_sym[i] = src[i];
+}
+
 __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
 {
     __shared__ u8 s_len[6][kMaxAlpha + 6];
@@ -231,6 +244,9 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
     __shared__ u32 s_scan[kHuffThreads / 64];
     __shared__ u32 s_run;
     __shared__ u32 s_first[6][24], s_lcount[6][24];
+    // 512 groups x 50 symbols staged per sweep step: coalesced global reads, and a lane's 50
+    // symbols are 25 dwords at a 25-dword stride (odd => no LDS bank conflicts)
+    __shared__ u32 s_sym[kHuffThreads * kGSize / 2];
 
     const u32 lb = blockIdx.x;
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -286,22 +302,30 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
         }
         for (u32 i = tid; i < 6 * kMaxAlpha; i += kHuffThreads) (&s_rfreq[0][0])[i] = 0;
         __syncthreads();
-        for (u32 g = tid; g < n_selectors; g += kHuffThreads) {
-            const u32 gs = g * kGSize;
-            const u32 ge = (gs + kGSize < mtf_count) ? gs + kGSize : mtf_count;
-            unsigned long long cost = 0;
-            for (u32 i = gs; i < ge; ++i) cost += s_pack[mtf[i]];
-            // first minimum wins (min_by, encoder.rs:466)
-            u32 bt = 0, bc = (u32)(cost & 1023u);
-            for (u32 t = 1; t < group_num; ++t) {
-                const u32 ct = (u32)((cost >> (10 * t)) & 1023u);
-                if (ct < bc) {
-                    bc = ct;
-                    bt = t;
+        for (u32 g0 = 0; g0 < n_selectors; g0 += kHuffThreads) {
+            stage_symbols(s_sym, mtf, g0, mtf_count);
+            __syncthreads();
+            const u32 g = g0 + tid;
+            if (g < n_selectors) {
+                const u32 gs = g * kGSize;
+                const u32 cnt = (gs + kGSize < mtf_count) ? kGSize : mtf_count - gs;
+                const u32 *my = s_sym + tid * (kGSize / 2);
+                unsigned long long cost = 0;
+                for (u32 i = 0; i < cnt; ++i) cost += s_pack[(my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu];
+                // first minimum wins (min_by, encoder.rs:466)
+                u32 bt = 0, bc = (u32)(cost & 1023u);
+                for (u32 t = 1; t < group_num; ++t) {
+                    const u32 ct = (u32)((cost >> (10 * t)) & 1023u);
+                    if (ct < bc) {
+                        bc = ct;
+                        bt = t;
+                    }
                 }
+                selector[g] = (u8)bt;
+                for (u32 i = 0; i < cnt; ++i)
+                    atomicAdd(&s_rfreq[bt][(my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu], 1u);
             }
-            selector[g] = (u8)bt;
-            for (u32 i = gs; i < ge; ++i) atomicAdd(&s_rfreq[bt][mtf[i]], 1u);
+            __syncthreads();
         }
         __syncthreads();
         // one lane per table replays the serial heap procedure
@@ -355,13 +379,16 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
     // payload bit offset of every group (exclusive scan over the groups)
     u32 *gbo = a.group_bitoff + (size_t)lb * kGboStride;
     for (u32 g0 = 0; g0 < n_selectors; g0 += kHuffThreads) {
+        stage_symbols(s_sym, mtf, g0, mtf_count);
+        __syncthreads();
         const u32 g = g0 + tid;
         u32 bits = 0;
         if (g < n_selectors) {
             const u32 gs = g * kGSize;
-            const u32 ge = (gs + kGSize < mtf_count) ? gs + kGSize : mtf_count;
+            const u32 cnt = (gs + kGSize < mtf_count) ? kGSize : mtf_count - gs;
+            const u32 *my = s_sym + tid * (kGSize / 2);
             const u8 *l = s_len[selector[g]];
-            for (u32 i = gs; i < ge; ++i) bits += l[mtf[i]];
+            for (u32 i = 0; i < cnt; ++i) bits += l[(my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu];
         }
         const u32 inc = wave_incl_sum(bits);
         if (lane == 63) s_scan[wave] = inc;
@@ -456,19 +483,23 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
 __global__ __launch_bounds__(256) void k_emit_payload(HuffArgs a)
 {
     __shared__ u32 s_code[6 * kMaxAlpha];
+    __shared__ u32 s_sym[256 * kGSize / 2];
     const u32 lb = blockIdx.y;
     const BlockOut &bo = a.out[lb];
     const u32 mtf_count = bo.mtf_count;
     const u32 n_selectors = bo.n_selectors;
-    if (blockIdx.x * 256u >= n_selectors) return;
+    const u32 g0 = blockIdx.x * 256u;
+    if (g0 >= n_selectors) return;
     const u32 *code_len = a.code_len + (size_t)lb * 6 * kMaxAlpha;
     for (u32 i = threadIdx.x; i < 6 * kMaxAlpha; i += 256u) s_code[i] = code_len[i];
-    __syncthreads();
-    const u32 g = blockIdx.x * 256u + threadIdx.x;
-    if (g >= n_selectors) return;
     const u16 *mtf = a.mtf + (size_t)lb * a.mtf_stride;
+    stage_symbols(s_sym, mtf, g0, mtf_count);
+    __syncthreads();
+    const u32 g = g0 + threadIdx.x;
+    if (g >= n_selectors) return;
     const u32 gs = g * kGSize;
-    const u32 ge = (gs + kGSize < mtf_count) ? gs + kGSize : mtf_count;
+    const u32 cnt = (gs + kGSize < mtf_count) ? kGSize : mtf_count - gs;
+    const u32 *my = s_sym + threadIdx.x * (kGSize / 2);
     const u32 *tab = s_code + (u32)a.selector[(size_t)lb * kSelStride + g] * kMaxAlpha;
     const u32 bitpos = bo.header_bits + a.group_bitoff[(size_t)lb * kGboStride + g];
     u32 *stream = a.stream + (size_t)lb * kStreamWords;
@@ -476,8 +507,8 @@ __global__ __launch_bounds__(256) void k_emit_payload(HuffArgs a)
     u32 nacc = bitpos & 31u;
     u64 acc = 0;
     bool first = true;
-    for (u32 i = gs; i < ge; ++i) {
-        const u32 cl = tab[mtf[i]];
+    for (u32 i = 0; i < cnt; ++i) {
+        const u32 cl = tab[(my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu];
         const u32 len = cl >> 24, code = cl & 0xFFFFFFu;
         acc |= (u64)code << (64u - nacc - len);
         nacc += len;

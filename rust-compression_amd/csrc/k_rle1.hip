@@ -336,26 +336,43 @@ __global__ __launch_bounds__(RT) void k_rle_cuts(const u8 *__restrict__ in, u64 
     __shared__ i64 s_m[RT / 64 + 1];
     __shared__ u32 s_s[RT / 64];
     __shared__ u64 s_tile;
+    __shared__ u32 s_w[RT / 64];
     __shared__ u64 s_cut_rle, s_cut_in;
     __shared__ int s_found;
 
     const u64 M = tile_off[ntiles];
     u64 s_rle = 0, s_in = 0;
+    u64 cur_tile = 0; // tile of the previous cut: tile_off[cur_tile] < every later target
     u32 nb = 0;
 
     while (true) {
         const u64 target = s_rle + block_max_len;
         if (M < target || M == s_rle) break; // no chunk end reaches the limit any more
-        // tile holding the first position whose inclusive prefix >= target:
-        // largest t with tile_off[t] < target
-        if (threadIdx.x == 0) {
-            u64 lo = 0, hi = ntiles - 1;
-            while (lo < hi) {
-                u64 mid = (lo + hi + 1) >> 1;
-                if (tile_off[mid] < target) lo = mid; else hi = mid - 1;
+        // tile holding the first position whose inclusive prefix >= target: the largest t with
+        // tile_off[t] < target.  Blocks are ~220 tiles apart on text, so probe windows of 256
+        // tiles forward from the previous cut (all lanes at once) instead of a dependent
+        // binary search; tile_off[ntiles] = M >= target bounds the walk.
+        {
+            u64 base_t = cur_tile;
+            while (true) {
+                const u64 t = base_t + threadIdx.x + 1; // candidate for "first t with off[t] >= target"
+                const bool hit = (t <= ntiles) && (tile_off[t] >= target);
+                const u64 bal = __ballot(hit);
+                if (lane_id() == 0) s_w[threadIdx.x >> 6] = bal ? (u32)(threadIdx.x + (u32)__builtin_ctzll(bal)) : 0xFFFFFFFFu;
+                __syncthreads();
+                u32 firsthit = 0xFFFFFFFFu;
+                for (u32 k = 0; k < RT / 64; ++k) firsthit = s_w[k] < firsthit ? s_w[k] : firsthit;
+                __syncthreads();
+                if (firsthit != 0xFFFFFFFFu) {
+                    cur_tile = base_t + firsthit; // = (first t with off[t] >= target) - 1
+                    break;
+                }
+                base_t += RT;
             }
-            s_tile = lo;
-            s_found = 0;
+            if (threadIdx.x == 0) {
+                s_tile = cur_tile;
+                s_found = 0;
+            }
         }
         __syncthreads();
         const u64 tile = s_tile;
