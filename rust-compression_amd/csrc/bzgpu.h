@@ -16,9 +16,9 @@ typedef int64_t i64;
 // ---- sizes (level 9 worst case; lower levels just use less of each slot) ----
 constexpr u32 kWave = 64;
 constexpr u32 kMaxBlockLen = 900000;        // 100000*level, >= n (n <= 100000*level - 19 + 4)
-constexpr u32 kSortTile = 16384;            // elements per radix tile: 16 waves x 16 rows x 64 lanes
-constexpr u32 kSortThreads = 1024;
-constexpr u32 kTilesPerBlock = 55;          // ceil(900000 / 16384)
+constexpr u32 kSortTile = 8192;             // elements per radix tile: 8 waves x 16 rows x 64 lanes
+constexpr u32 kSortThreads = 512;
+constexpr u32 kTilesPerBlock = 110;         // ceil(900000 / 8192)
 constexpr u32 kSlot = kTilesPerBlock * kSortTile; // 901120: per-block stride of the u32 work arrays
 constexpr u32 kMaxBins = 2048;              // 11-bit digits for the initial 32-bit key sort
 constexpr u32 kGSize = 50;                  // BZ_G_SIZE, src/bzip2/mod.rs:20
@@ -180,6 +180,7 @@ struct BwtArgs {
     u32 nb;
     u32 *SA, *R, *KA, *VA, *KB, *VB; // [nb * kSlot]
     u32 *tile_hist;                  // [nb][kTilesPerBlock][kMaxBins]
+    u32 *bin_base;                   // [nb][kMaxBins]
     u32 *count;                      // [nb] length of the compacted pair list
     u8 *flags;                       // [nb * kSlot]
     int *tile_last_old;              // [nb][kTilesPerBlock]

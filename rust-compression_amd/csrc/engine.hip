@@ -69,7 +69,7 @@ struct bz_gpu_engine {
     int level = 9;
     // batch workspace (sized by max_blocks)
     DevBuf lblocks, lcrc, SA, R, KA, VA, KB, VB, tile_hist, count, flags, tlo, tln, nonfinal, active, per_k,
-        per_shift, L, orig_ptr, inuse_bits, summ, summ_len, init_state, rank8, ztile_last, ztile_cnt, mtf,
+        per_shift, bin_base, L, orig_ptr, inuse_bits, summ, summ_len, init_state, rank8, ztile_last, ztile_cnt, mtf,
         mtf_freq, bout, selector, code_len, group_bitoff, lm_scratch, stream, error_flag, packlist;
     bool ws_ready = false;
     // own packed buffer / assemble list for the single-GPU convenience call
@@ -137,6 +137,7 @@ static int ensure_workspace(bz_gpu_engine *g)
     ENS(VB, nb * (size_t)kSlot * 4);
     ENS(tile_hist, nb * (size_t)kTilesPerBlock * kMaxBins * 4);
     ENS(count, nb * 4);
+    ENS(bin_base, nb * (size_t)kMaxBins * 4);
     ENS(flags, nb * (size_t)kSlot);
     ENS(tlo, nb * (size_t)kTilesPerBlock * 4);
     ENS(tln, nb * (size_t)kTilesPerBlock * 4);
@@ -228,7 +229,7 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
     DevBuf *all[] = {&g->crc_tab, &g->xp16, &g->xp2, &g->tile_last, &g->carry_in, &g->tile_crc, &g->tile_count,
                      &g->tile_off, &g->scal, &g->rle, &g->blocks_all, &g->crc_all, &g->lblocks, &g->lcrc, &g->SA,
                      &g->R, &g->KA, &g->VA, &g->KB, &g->VB, &g->tile_hist, &g->count, &g->flags, &g->tlo, &g->tln,
-                     &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->L, &g->orig_ptr, &g->inuse_bits,
+                     &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->bin_base, &g->L, &g->orig_ptr, &g->inuse_bits,
                      &g->summ, &g->summ_len, &g->init_state, &g->rank8, &g->ztile_last, &g->ztile_cnt, &g->mtf,
                      &g->mtf_freq, &g->bout, &g->selector, &g->code_len, &g->group_bitoff, &g->lm_scratch,
                      &g->stream, &g->error_flag, &g->packlist, &g->packed, &g->asmlist};
@@ -317,6 +318,7 @@ static int encode_batch(bz_gpu_engine *g, u32 nb, u32 max_n, u64 total_n)
     ba.VB = g->VB.as<u32>();
     ba.tile_hist = g->tile_hist.as<u32>();
     ba.count = g->count.as<u32>();
+    ba.bin_base = g->bin_base.as<u32>();
     ba.flags = g->flags.as<u8>();
     ba.tile_last_old = g->tlo.as<int>();
     ba.tile_last_new = g->tln.as<int>();
@@ -600,6 +602,7 @@ extern "C" int bz_gpu_debug_bwt(bz_gpu_engine *g, const uint8_t *h_block, size_t
     ba.VB = g->VB.as<u32>();
     ba.tile_hist = g->tile_hist.as<u32>();
     ba.count = g->count.as<u32>();
+    ba.bin_base = g->bin_base.as<u32>();
     ba.flags = g->flags.as<u8>();
     ba.tile_last_old = g->tlo.as<int>();
     ba.tile_last_new = g->tln.as<int>();

@@ -157,20 +157,24 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shif
 }
 
 // ---- radix pass, part 2: per-block scan of the tile histograms ----------------------
-// After it, tile_hist[lb][tile][bin] = first output slot of that (bin, tile).
+// After it, bin_base[lb][bin] + tile_hist[lb][tile][bin] = first output slot of that (bin, tile).
 template <int SRC, int BITS>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scan(BwtArgs a)
 {
     constexpr u32 NB = 1u << BITS;
-    constexpr u32 PER = (NB + kSortThreads - 1) / kSortThreads; // bins per thread (1 or 2)
+    constexpr u32 PER = (NB + kSortThreads - 1) / kSortThreads; // bins per thread, consecutive
+    constexpr u32 CH = 11;                                      // tiles per batch of loads (110 = 10 x 11)
     __shared__ u32 s_wsum[kSortThreads / 64];
     const u32 lb = blockIdx.x;
     const u32 n = a.blocks[lb].n;
     const u32 cnt = (SRC == SRC_PAIRS) ? a.count[lb] : n;
     const u32 ntiles = (cnt + kSortTile - 1) / kSortTile;
     u32 *hist = a.tile_hist + (size_t)lb * kTilesPerBlock * kMaxBins;
+    u32 *bin_base = a.bin_base + (size_t)lb * kMaxBins;
 
-    // bins d0..d0+PER-1 of this thread are consecutive -> block scan in thread order
+    // tile_hist[t][bin] becomes the count of that bin in tiles < t; bin_base[bin] the count of
+    // all smaller bins.  Loads of a batch are issued together (the running sum is the only
+    // dependency), the stores follow.
     const u32 d0 = threadIdx.x * PER;
     u32 tot[PER];
 #pragma unroll
@@ -178,10 +182,15 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scan(BwtArgs a)
         const u32 dgt = d0 + q;
         u32 run = 0;
         if (dgt < NB) {
-            for (u32 t = 0; t < ntiles; ++t) {
-                const u32 v = hist[t * kMaxBins + dgt];
-                hist[t * kMaxBins + dgt] = run;
-                run += v;
+            for (u32 t0 = 0; t0 < ntiles; t0 += CH) {
+                u32 v[CH];
+#pragma unroll
+                for (u32 k = 0; k < CH; ++k) v[k] = (t0 + k < ntiles) ? hist[(t0 + k) * kMaxBins + dgt] : 0u;
+#pragma unroll
+                for (u32 k = 0; k < CH; ++k) {
+                    if (t0 + k < ntiles) hist[(t0 + k) * kMaxBins + dgt] = run;
+                    run += v[k];
+                }
             }
         }
         tot[q] = run;
@@ -201,9 +210,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scan(BwtArgs a)
 #pragma unroll
     for (u32 q = 0; q < PER; ++q) {
         const u32 dgt = d0 + q;
-        if (dgt < NB && base != 0) {
-            for (u32 t = 0; t < ntiles; ++t) hist[t * kMaxBins + dgt] += base;
-        }
+        if (dgt < NB) bin_base[dgt] = base;
         base += tot[q];
     }
     if (SRC != SRC_PAIRS && threadIdx.x == 0) a.count[lb] = total; // list length for the next passes
@@ -247,7 +254,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
     {
         for (u32 i = threadIdx.x; i < NW * NB / 2; i += kSortThreads) s_buf[i] = 0;
         const u32 *hist = a.tile_hist + ((size_t)lb * kTilesPerBlock + tile) * kMaxBins;
-        for (u32 i = threadIdx.x; i < NB; i += kSortThreads) s_base[i] = hist[i];
+        const u32 *bin_base = a.bin_base + (size_t)lb * kMaxBins;
+        for (u32 i = threadIdx.x; i < NB; i += kSortThreads) s_base[i] = hist[i] + bin_base[i];
     }
     __syncthreads();
 
