@@ -541,8 +541,12 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 h_n
             const u32 j = jv[r];
             const u32 p = g + (idx - (u32)rs);
             const u32 head = g + ((u32)ss - (u32)rs);
+#ifndef BZ_EXP_NO_SAWRITE
             st_stream(a.SA + base + p, j);
+#endif
+#ifndef BZ_EXP_NO_RWRITE
             a.R[base + j] = head | (fin ? kFinalBit : 0u);
+#endif
             my_nonfinal += fin ? 0u : 1u;
         }
         if (mo[r]) carry_old = (int)(rowbase + 63u - __clzll(mo[r]));
@@ -749,6 +753,10 @@ int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned l
         if (sorted_elems) *sorted_elems += m;
         if (round_active && slot < 64) round_active[slot] += m;
         if (m == 0 || h >= max_n) break;
+        {
+            static const int max_rounds = getenv("BZ_MAX_ROUNDS") ? atoi(getenv("BZ_MAX_ROUNDS")) : 1000; // experiments only
+            if (rounds >= max_rounds) break;
+        }
         ++slot;
         ++rounds;
         (void)hipMemsetAsync(a.nonfinal, 0, a.nb * sizeof(u32), st);

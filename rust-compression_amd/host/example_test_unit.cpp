@@ -1,0 +1,42 @@
+// The reference's bzip2::tests::test_unit (src/bzip2/mod.rs:41-58) and test_long (:150-172) written
+// against the C++ mirror.  Build: g++ -std=c++17 example_test_unit.cpp -L.. -lbz2_mi355x -Wl,-rpath,..
+#include "compression.hpp"
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+using namespace compression;
+
+int main()
+{
+    const std::string src = "a\n";
+    BZip2Encoder enc(9);
+    auto ret = collect(encode(src, enc, Action::Finish));
+    if (!ret.ok) {
+        std::printf("error: %s\n", description(ret.error));
+        return 2;
+    }
+    const uint8_t expect[] = {0x42, 0x5A, 0x68, 0x39, 0x31, 0x41, 0x59, 0x26, 0x53, 0x59, 0x63, 0x3E, 0xD6,
+                              0xE2, 0x00, 0x00, 0x00, 0xC1, 0x00, 0x00, 0x10, 0x20, 0x00, 0x20, 0x00, 0x21,
+                              0x00, 0x82, 0xB1, 0x77, 0x24, 0x53, 0x85, 0x09, 0x06, 0x33, 0xED, 0x6E, 0x20};
+    if (ret.value.size() != sizeof(expect) || std::memcmp(ret.value.data(), expect, sizeof(expect)) != 0) {
+        std::printf("test_unit: MISMATCH (%zu bytes)\n", ret.value.size());
+        return 1;
+    }
+    BZip2Encoder enc2; // Default == level 9
+    const std::string longs(1000, 'a');
+    auto r2 = collect(encode(longs, enc2, Action::Finish));
+    if (!r2.ok || r2.value.size() != 45) {
+        std::printf("test_long: unexpected size %zu\n", r2.value.size());
+        return 1;
+    }
+    bool threw = false;
+    try {
+        BZip2Encoder bad(0);
+    } catch (const std::invalid_argument &) {
+        threw = true;
+    }
+    std::printf("test_unit ok, test_long ok (%zu bytes), invalid level %s\n", r2.value.size(),
+                threw ? "rejected" : "ACCEPTED");
+    return threw ? 0 : 1;
+}

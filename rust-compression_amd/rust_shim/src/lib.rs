@@ -1,0 +1,140 @@
+//! Rust shim: `BZip2Encoder` of the `compression` crate re-implemented over the MI355X C ABI
+//! (include/bz2_mi355x.h).  NOT compiled in this repository's image (no Rust toolchain); it is
+//! the binding a maintainer drops into the crate as `src/bzip2/encoder.rs` behind a
+//! `feature = "mi355x"` gate.  The trait, `Action`, `CompressionError` and `EncodeExt` stay the
+//! crate's own (src/traits/encoder.rs, src/action.rs, src/error.rs), so callers do not change:
+//!
+//!     let out = data.iter().cloned()
+//!         .encode(&mut BZip2Encoder::new(9), Action::Finish)
+//!         .collect::<Result<Vec<_>, _>>();
+use crate::action::Action;
+use crate::error::CompressionError;
+use crate::traits::encoder::Encoder;
+use core::ffi::c_void;
+
+#[allow(non_camel_case_types)]
+type bz_enc = c_void;
+
+#[link(name = "bz2_mi355x")]
+extern "C" {
+    fn bz_enc_create(out: *mut *mut bz_enc, level: i32, device: i32) -> i32;
+    fn bz_enc_write(e: *mut bz_enc, data: *const u8, n: usize) -> i32;
+    fn bz_enc_end(e: *mut bz_enc, action: i32) -> i32;
+    fn bz_enc_read(e: *mut bz_enc, out: *mut u8, cap: usize) -> isize;
+    fn bz_enc_pending(e: *const bz_enc) -> usize;
+    fn bz_enc_destroy(e: *mut bz_enc);
+}
+
+const CHUNK: usize = 1 << 20;
+
+pub struct BZip2Encoder {
+    h: *mut bz_enc,
+    ready: Vec<u8>,
+    pos: usize,
+    chunk: Vec<u8>,
+}
+
+impl Default for BZip2Encoder {
+    fn default() -> Self {
+        Self::new(9)
+    }
+}
+
+impl BZip2Encoder {
+    pub fn new(level: usize) -> Self {
+        let mut h = core::ptr::null_mut();
+        let rc = unsafe { bz_enc_create(&mut h, level as i32, 0) };
+        if rc != 0 {
+            panic!("invalid level"); // src/bzip2/encoder.rs:59-61
+        }
+        Self { h, ready: Vec::new(), pos: 0, chunk: Vec::with_capacity(CHUNK) }
+    }
+
+    fn refill(&mut self) -> Result<usize, CompressionError> {
+        self.ready.resize(1 << 16, 0);
+        let k = unsafe { bz_enc_read(self.h, self.ready.as_mut_ptr(), self.ready.len()) };
+        if k < 0 {
+            return Err(map_err(k as i32));
+        }
+        self.ready.truncate(k as usize);
+        self.pos = 0;
+        Ok(k as usize)
+    }
+}
+
+fn map_err(rc: i32) -> CompressionError {
+    match rc {
+        -1 => CompressionError::DataError,
+        -2 => CompressionError::UnexpectedEof,
+        _ => CompressionError::Unexpected,
+    }
+}
+
+fn action_code(a: Action) -> i32 {
+    match a {
+        Action::Run => 0,
+        Action::Flush => 1,
+        Action::Finish => 2,
+    }
+}
+
+impl Encoder for BZip2Encoder {
+    type Error = CompressionError;
+    type In = u8;
+    type Out = u8;
+
+    fn next<I: Iterator<Item = u8>>(
+        &mut self,
+        iter: &mut I,
+        action: Action,
+    ) -> Option<Result<u8, CompressionError>> {
+        if self.pos == self.ready.len() {
+            match self.refill() {
+                Err(e) => return Some(Err(e)),
+                Ok(0) => {
+                    loop {
+                        self.chunk.clear();
+                        while self.chunk.len() < CHUNK {
+                            match iter.next() {
+                                Some(b) => self.chunk.push(b),
+                                None => break,
+                            }
+                        }
+                        let exhausted = self.chunk.len() < CHUNK;
+                        if !self.chunk.is_empty() {
+                            let rc = unsafe { bz_enc_write(self.h, self.chunk.as_ptr(), self.chunk.len()) };
+                            if rc != 0 {
+                                return Some(Err(map_err(rc)));
+                            }
+                            if unsafe { bz_enc_pending(self.h) } > 0 {
+                                break;
+                            }
+                        }
+                        if exhausted {
+                            let rc = unsafe { bz_enc_end(self.h, action_code(action)) };
+                            if rc != 0 {
+                                return Some(Err(map_err(rc)));
+                            }
+                            break;
+                        }
+                    }
+                    match self.refill() {
+                        Err(e) => return Some(Err(e)),
+                        Ok(0) => return None,
+                        Ok(_) => {}
+                    }
+                }
+                Ok(_) => {}
+            }
+        }
+        let b = self.ready[self.pos];
+        self.pos += 1;
+        Some(Ok(b))
+    }
+}
+
+impl Drop for BZip2Encoder {
+    fn drop(&mut self) {
+        unsafe { bz_enc_destroy(self.h) }
+    }
+}
