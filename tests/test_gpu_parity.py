@@ -215,3 +215,25 @@ def test_determinism(pkg):
     d = _text(1_200_000, 9)
     h = {hashlib.sha256(pkg.compress(d, 9)).hexdigest() for _ in range(3)}
     assert len(h) == 1
+
+
+def test_cpp_host_mirror(pkg):
+    """host/compression.hpp: the reference's test_unit / test_long written against the C++ mirror."""
+    import subprocess
+    from conftest import ROOT
+    host = os.path.join(ROOT, "rust-compression_amd", "host")
+    exe = os.path.join(host, "example_test_unit")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(host, "example_test_unit.cpp"),
+                           "-L" + os.path.join(ROOT, "rust-compression_amd"), "-lbz2_mi355x",
+                           "-Wl,-rpath," + os.path.join(ROOT, "rust-compression_amd"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "test_unit ok" in r.stdout
+
+
+def test_host_buffer_roundtrip_large(pkg):
+    """bz_encode_buffer on 40 MB (PCIe-inclusive path): decodes to the input."""
+    import corpus
+    d = corpus.chapter(3, 16 << 20) + corpus.stress_t2(8 << 20) + corpus.chapter(4, 16 << 20)
+    out = pkg.compress(d, 9)
+    assert bz2.decompress(out) == d
