@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--cpu-sample-mib", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--corpus", default="text", choices=["text", "t2"])
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the partition / encode_blocks / exchange / assemble path even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -77,7 +79,7 @@ def main():
         state["out_len"] = eng.encode_device(args.level, d_in.data_ptr(), n, d_out.data_ptr(), cap)
 
     # multi-GPU buffers
-    if world > 1:
+    if world > 1 or args.force_sharded:
         cap_words = pkg.encode_bound(n // world + (2 << 20)) // 4 + 4 * local_blocks + 64
         d_packed = torch.empty(cap_words, dtype=torch.int32, device=dev)
         d_all = torch.empty((world, cap_words), dtype=torch.int32, device=dev) if rank == 0 else None
@@ -91,7 +93,7 @@ def main():
             out_len, _, _, _ = eng.assemble(args.level, buf.data_ptr(), w_off, b_len, crcs, d_out.data_ptr(), cap)
             state["out_len"] = out_len
 
-    step = step_single if world == 1 else step_multi
+    step = step_single if (world == 1 and not args.force_sharded) else step_multi
 
     def sync():
         torch.cuda.synchronize()

@@ -188,6 +188,8 @@ struct BwtArgs {
     u32 *nonfinal;                   // [nb]
     unsigned long long *active;      // [64] per-round count of non-final rotations in unfinished blocks
     u32 *per_k, *per_shift;          // [nb] periodic blocks: repetition count, least-rotation start
+    const u8 *sym_code;              // [nb][256] byte -> code (rank among the bytes in use)
+    const u8 *keyinfo;               // [nb] KeyInfo {bits per symbol, symbols per key}
 };
 
 constexpr u32 kMtfStride = kSlot + 64;
@@ -277,10 +279,11 @@ void launch_rle1(hipStream_t st, const u8 *d_in, u64 n, const u32 *crc_tab, cons
                  u32 max_blocks);
 void launch_block_crc(hipStream_t st, const u8 *d_in, const BlockDesc *d_blocks, u32 nblocks,
                       const u32 *crc_tab, const u32 *xp2, const u32 *tile_crc, u32 *d_crc);
+void launch_block_symbols(hipStream_t st, const BwtArgs &a, u32 *inuse_bits, u8 *sym_code, u8 *keyinfo);
 int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned long long *h_active,
-            u64 *sorted_elems, KernelProf *prof, u64 *round_active /*[64] or null*/);
-void launch_last_column(hipStream_t st, const BwtArgs &a, u8 *L, u32 *orig_ptr, u32 *inuse_bits, u64 total_n,
-                        KernelProf *prof);
+            u64 *sorted_elems, KernelProf *prof, u64 *round_active /*[64] or null*/, bool wide_keys,
+            u32 min_chars);
+void launch_last_column(hipStream_t st, const BwtArgs &a, u8 *L, u32 *orig_ptr, u64 total_n, KernelProf *prof);
 void launch_mtf(hipStream_t st, const MtfArgs &a);
 void launch_huffman(hipStream_t st, const HuffArgs &a);
 void launch_probe_code_lengths(hipStream_t st, const u32 *d_freq, u32 alpha, u8 *d_out, u32 *lm_scr,

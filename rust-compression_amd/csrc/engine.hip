@@ -69,7 +69,7 @@ struct bz_gpu_engine {
     int level = 9;
     // batch workspace (sized by max_blocks)
     DevBuf lblocks, lcrc, SA, R, KA, VA, KB, VB, tile_hist, count, flags, tlo, tln, nonfinal, active, per_k,
-        per_shift, bin_base, L, orig_ptr, inuse_bits, summ, summ_len, init_state, rank8, ztile_last, ztile_cnt, mtf,
+        per_shift, bin_base, sym_code, keyinfo, L, orig_ptr, inuse_bits, summ, summ_len, init_state, rank8, ztile_last, ztile_cnt, mtf,
         mtf_freq, bout, selector, code_len, group_bitoff, lm_scratch, stream, error_flag, packlist;
     bool ws_ready = false;
     // own packed buffer / assemble list for the single-GPU convenience call
@@ -138,6 +138,8 @@ static int ensure_workspace(bz_gpu_engine *g)
     ENS(tile_hist, nb * (size_t)kTilesPerBlock * kMaxBins * 4);
     ENS(count, nb * 4);
     ENS(bin_base, nb * (size_t)kMaxBins * 4);
+    ENS(sym_code, nb * (size_t)256);
+    ENS(keyinfo, nb * (size_t)4);
     ENS(flags, nb * (size_t)kSlot);
     ENS(tlo, nb * (size_t)kTilesPerBlock * 4);
     ENS(tln, nb * (size_t)kTilesPerBlock * 4);
@@ -229,7 +231,7 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
     DevBuf *all[] = {&g->crc_tab, &g->xp16, &g->xp2, &g->tile_last, &g->carry_in, &g->tile_crc, &g->tile_count,
                      &g->tile_off, &g->scal, &g->rle, &g->blocks_all, &g->crc_all, &g->lblocks, &g->lcrc, &g->SA,
                      &g->R, &g->KA, &g->VA, &g->KB, &g->VB, &g->tile_hist, &g->count, &g->flags, &g->tlo, &g->tln,
-                     &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->bin_base, &g->L, &g->orig_ptr, &g->inuse_bits,
+                     &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->bin_base, &g->sym_code, &g->keyinfo, &g->L, &g->orig_ptr, &g->inuse_bits,
                      &g->summ, &g->summ_len, &g->init_state, &g->rank8, &g->ztile_last, &g->ztile_cnt, &g->mtf,
                      &g->mtf_freq, &g->bout, &g->selector, &g->code_len, &g->group_bitoff, &g->lm_scratch,
                      &g->stream, &g->error_flag, &g->packlist, &g->packed, &g->asmlist};
@@ -303,35 +305,60 @@ extern "C" int bz_gpu_partition(bz_gpu_engine *g, int level, const void *d_in, s
     return BZ_OK;
 }
 
+static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb)
+{
+    BwtArgs x;
+    x.rle = g->rle.as<u8>();
+    x.blocks = g->lblocks.as<BlockDesc>();
+    x.nb = nb;
+    x.SA = g->SA.as<u32>();
+    x.R = g->R.as<u32>();
+    x.KA = g->KA.as<u32>();
+    x.VA = g->VA.as<u32>();
+    x.KB = g->KB.as<u32>();
+    x.VB = g->VB.as<u32>();
+    x.tile_hist = g->tile_hist.as<u32>();
+    x.count = g->count.as<u32>();
+    x.bin_base = g->bin_base.as<u32>();
+    x.flags = g->flags.as<u8>();
+    x.tile_last_old = g->tlo.as<int>();
+    x.tile_last_new = g->tln.as<int>();
+    x.nonfinal = g->nonfinal.as<u32>();
+    x.active = g->active.as<unsigned long long>();
+    x.per_k = g->per_k.as<u32>();
+    x.per_shift = g->per_shift.as<u32>();
+    x.sym_code = g->sym_code.as<u8>();
+    x.keyinfo = g->keyinfo.as<u8>();
+    return x;
+}
+
+// symbols in use -> key geometry -> rotation sort.  Returns rounds (<0: error).
+static int sort_batch(bz_gpu_engine *g, const BwtArgs &ba, u32 max_n, u64 total_n, u64 *sorted, KernelProf *prof,
+                      u64 *round_active)
+{
+    launch_block_symbols(g->st, ba, g->inuse_bits.as<u32>(), g->sym_code.as<u8>(), g->keyinfo.as<u8>());
+    std::vector<u8> ki((size_t)ba.nb * 4);
+    if (hipMemcpyAsync(ki.data(), g->keyinfo.p, ki.size(), hipMemcpyDeviceToHost, g->st) != hipSuccess) return -1;
+    if (hipStreamSynchronize(g->st) != hipSuccess) return -1;
+    bool wide = false;
+    u32 min_chars = 8;
+    for (u32 i = 0; i < ba.nb; ++i) {
+        if (ki[(size_t)i * 4] >= 8) wide = true;
+        if (ki[(size_t)i * 4 + 1] < min_chars) min_chars = ki[(size_t)i * 4 + 1];
+    }
+    return run_bwt(g->st, ba, max_n, total_n, g->h_active, sorted, prof, round_active, wide, min_chars);
+}
+
 // encode one batch of local blocks (descriptors already in g->lblocks / g->lcrc)
 static int encode_batch(bz_gpu_engine *g, u32 nb, u32 max_n, u64 total_n)
 {
-    BwtArgs ba;
-    ba.rle = g->rle.as<u8>();
-    ba.blocks = g->lblocks.as<BlockDesc>();
-    ba.nb = nb;
-    ba.SA = g->SA.as<u32>();
-    ba.R = g->R.as<u32>();
-    ba.KA = g->KA.as<u32>();
-    ba.VA = g->VA.as<u32>();
-    ba.KB = g->KB.as<u32>();
-    ba.VB = g->VB.as<u32>();
-    ba.tile_hist = g->tile_hist.as<u32>();
-    ba.count = g->count.as<u32>();
-    ba.bin_base = g->bin_base.as<u32>();
-    ba.flags = g->flags.as<u8>();
-    ba.tile_last_old = g->tlo.as<int>();
-    ba.tile_last_new = g->tln.as<int>();
-    ba.nonfinal = g->nonfinal.as<u32>();
-    ba.active = g->active.as<unsigned long long>();
-    ba.per_k = g->per_k.as<u32>();
-    ba.per_shift = g->per_shift.as<u32>();
+    const BwtArgs ba = make_bwt_args(g, nb);
 
     int sp = span_begin(g, 1);
     u64 sorted = 0;
-    const int rounds = run_bwt(g->st, ba, max_n, total_n, g->h_active, &sorted, &g->prof, g->round_active);
+    const int rounds = sort_batch(g, ba, max_n, total_n, &sorted, &g->prof, g->round_active);
     if (rounds < 0) return BZ_E_UNEXPECTED;
-    launch_last_column(g->st, ba, g->L.as<u8>(), g->orig_ptr.as<u32>(), g->inuse_bits.as<u32>(), total_n, &g->prof);
+    launch_last_column(g->st, ba, g->L.as<u8>(), g->orig_ptr.as<u32>(), total_n, &g->prof);
     span_end(g, sp);
     g->bwt_stats[0] += (u64)rounds;
     g->bwt_stats[1] += sorted;
@@ -590,28 +617,9 @@ extern "C" int bz_gpu_debug_bwt(bz_gpu_engine *g, const uint8_t *h_block, size_t
     d.n = (u32)n;
     d.pad = 0;
     HIPCHK(hipMemcpyAsync(g->lblocks.p, &d, sizeof(d), hipMemcpyHostToDevice, g->st));
-    BwtArgs ba;
-    ba.rle = g->rle.as<u8>();
-    ba.blocks = g->lblocks.as<BlockDesc>();
-    ba.nb = 1;
-    ba.SA = g->SA.as<u32>();
-    ba.R = g->R.as<u32>();
-    ba.KA = g->KA.as<u32>();
-    ba.VA = g->VA.as<u32>();
-    ba.KB = g->KB.as<u32>();
-    ba.VB = g->VB.as<u32>();
-    ba.tile_hist = g->tile_hist.as<u32>();
-    ba.count = g->count.as<u32>();
-    ba.bin_base = g->bin_base.as<u32>();
-    ba.flags = g->flags.as<u8>();
-    ba.tile_last_old = g->tlo.as<int>();
-    ba.tile_last_new = g->tln.as<int>();
-    ba.nonfinal = g->nonfinal.as<u32>();
-    ba.active = g->active.as<unsigned long long>();
-    ba.per_k = g->per_k.as<u32>();
-    ba.per_shift = g->per_shift.as<u32>();
+    const BwtArgs ba = make_bwt_args(g, 1);
     u64 sorted = 0;
-    const int rounds = run_bwt(g->st, ba, (u32)n, (u64)n, g->h_active, &sorted, nullptr, nullptr);
+    const int rounds = sort_batch(g, ba, (u32)n, (u64)n, &sorted, nullptr, nullptr);
     if (rounds < 0) return BZ_E_UNEXPECTED;
     g->bwt_stats[0] = (u64)rounds;
     g->bwt_stats[1] = sorted;

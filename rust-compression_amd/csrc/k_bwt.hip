@@ -9,15 +9,20 @@
 // A serial induced sort is the wrong shape for a GPU; this is a prefix-doubling
 // rotation sort built from LDS-tiled stable radix passes:
 //
-//   init   : 32-bit key = first 4 bytes of each rotation, LSD radix 11+11+10 bits
-//            -> groups of rotations equal on 4 bytes; rank R[j] = group head position,
+//   init   : the block's bytes are re-coded to b = ceil(log2(#symbols in use)) bits and c of them
+//            (c = 30/b, at most 8; 4 when b = 8) packed into one key.  Phase A sorts the rotations
+//            by key(j) (3 LSD radix passes); phase B walks that order, i -> j = V[i]-c, and sorts
+//            the sequence stably by key(j) again (3 more passes): the result is ordered by the
+//            first 2c symbols without ever holding more than 8 bytes per element.  Text of 36
+//            symbols gets c = 5, i.e. the first 10 bytes, from six 10-bit passes.
+//            Groups of equal 2c-prefixes get rank R[j] = group head position,
 //            bit31 = "group is a singleton, rotation j is final".
 //   round h: (Manber-Myers step) walk SA in order, i -> j = SA[i]-h; the non-final j
 //            arrive ordered by the rank of rotation j+h.  A STABLE sort of that
 //            sequence by R[j] (20 bits = two 10-bit passes; pass A also compacts
 //            away final rotations) yields the 2h-order inside every old group.
 //            Then flags (old group start / new group start), a max-scan, and the
-//            scatter of SA and the refined ranks.  h doubles: 4,8,...
+//            scatter of SA and the refined ranks.  h doubles: 2c, 4c, ...
 //   stop   : no non-final rotation left (or h >= n: the block is periodic, finish
 //            with the closed-form tie rule).
 //
@@ -31,47 +36,44 @@
 
 namespace bzgpu {
 
-enum { SRC_TEXT = 0, SRC_PAIRS = 1, SRC_MM = 2 };
+enum { SRC_TEXT = 0, SRC_PAIRS = 1, SRC_MM = 2, SRC_WALK = 3 };
 
-__device__ __forceinline__ u32 text_key4(const u8 *__restrict__ t, u32 n, u32 i)
+// per-block key geometry, produced by k_key_params
+struct KeyInfo {
+    u8 bits;   // bits per re-coded symbol
+    u8 chars;  // symbols per key
+    u8 pad[2];
+};
+
+// key(j): `chars` re-coded symbols of the rotation starting at j, first symbol most significant.
+// s_code: the block's 256-entry byte -> code table (in LDS).
+__device__ __forceinline__ u32 pack_key(const u8 *__restrict__ t, u32 n, u32 j, const u8 *s_code, u32 bits,
+                                        u32 chars)
 {
     u32 k = 0;
-    if (i + 4 <= n) {
-        k = ((u32)t[i] << 24) | ((u32)t[i + 1] << 16) | ((u32)t[i + 2] << 8) | (u32)t[i + 3];
-    } else {
-        u32 p = i;
+    if (j + 8u <= n) {
+        // 8 bytes from an arbitrary address out of three aligned dwords (the image is padded)
+        const uintptr_t p = reinterpret_cast<uintptr_t>(t + j);
+        const u32 *ap = reinterpret_cast<const u32 *>(p & ~(uintptr_t)3);
+        const u32 sh = (u32)(p & 3u) * 8u;
+        const u32 w0 = ap[0], w1 = ap[1], w2 = ap[2];
+        const u32 lo = sh ? ((w0 >> sh) | (w1 << (32u - sh))) : w0;
+        const u32 hi = sh ? ((w1 >> sh) | (w2 << (32u - sh))) : w1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            k = (k << 8) | t[p];
-            p = (p + 1 == n) ? 0u : p + 1; // n >= 1
+        for (u32 q = 0; q < 8; ++q) {
+            if (q < chars) {
+                const u32 byte = ((q < 4 ? lo >> (8u * q) : hi >> (8u * (q - 4u)))) & 0xFFu;
+                k = (k << bits) | s_code[byte];
+            }
+        }
+    } else {
+        u32 p = j;
+        for (u32 q = 0; q < chars; ++q) {
+            k = (k << bits) | s_code[t[p]];
+            p = (p + 1u == n) ? 0u : p + 1u; // rotations are cyclic
         }
     }
     return k;
-}
-
-// fetch element idx of the pass's input sequence; returns false when it takes no part
-template <int SRC>
-__device__ __forceinline__ bool fetch(const BwtArgs &a, u32 lb, const u8 *__restrict__ text, u32 n, u32 hm,
-                                      const u32 *__restrict__ Kin, const u32 *__restrict__ Vin, u32 idx,
-                                      u32 &key, u32 &val)
-{
-    const size_t base = (size_t)lb * kSlot;
-    if (SRC == SRC_TEXT) {
-        key = text_key4(text, n, idx);
-        val = idx;
-        return true;
-    } else if (SRC == SRC_PAIRS) {
-        key = ld_stream(Kin + base + idx);
-        val = ld_stream(Vin + base + idx);
-        return true;
-    } else {
-        const u32 s = ld_stream(a.SA + base + idx);
-        const u32 j = (s >= hm) ? s - hm : s + n - hm;
-        const u32 r = a.R[base + j];
-        key = r;
-        val = j;
-        return (r & kFinalBit) == 0;
-    }
 }
 
 // Batched form: the 16 rows of one lane.  All primary loads are issued back to back (clamped
@@ -81,7 +83,7 @@ __device__ __forceinline__ bool fetch(const BwtArgs &a, u32 lb, const u8 *__rest
 template <int SRC>
 __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__restrict__ text, u32 n, u32 hm,
                                           const u32 *__restrict__ Kin, const u32 *__restrict__ Vin, u32 first,
-                                          u32 cnt, u32 (&key)[16], u32 (&val)[16])
+                                          u32 cnt, const u8 *s_code, KeyInfo ki, u32 (&key)[16], u32 (&val)[16])
 {
     const size_t base = (size_t)lb * kSlot;
     u32 ok = 0;
@@ -90,10 +92,23 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
         for (u32 r = 0; r < 16; ++r) {
             const u32 idx = first + r * 64u;
             const u32 c = idx < cnt ? idx : cnt - 1u;
-            key[r] = text_key4(text, n, c);
+            key[r] = pack_key(text, n, c, s_code, ki.bits, ki.chars);
             val[r] = c;
             ok |= (idx < cnt ? 1u : 0u) << r;
         }
+    } else if (SRC == SRC_WALK) {
+        // phase B of the init: walk the key order of phase A, step back `chars` symbols
+        const u32 cm = ki.chars % n;
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) {
+            const u32 idx = first + r * 64u;
+            const u32 c = idx < cnt ? idx : cnt - 1u;
+            const u32 s = ld_stream(Vin + base + c);
+            val[r] = (s >= cm) ? s - cm : s + n - cm;
+            ok |= (idx < cnt ? 1u : 0u) << r;
+        }
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) key[r] = pack_key(text, n, val[r], s_code, ki.bits, ki.chars);
     } else if (SRC == SRC_PAIRS) {
 #pragma unroll
         for (u32 r = 0; r < 16; ++r) {
@@ -130,6 +145,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shif
 {
     constexpr u32 NB = 1u << BITS;
     __shared__ u32 s_hist[NB];
+    __shared__ u8 s_code[256];
     u32 tile, lb;
     xcd_remap(kTilesPerBlock, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
@@ -139,14 +155,18 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shif
     const u32 start = tile * kSortTile;
     if (start >= cnt) return;
     const u8 *text = a.rle + d.rle_off;
-    const u32 hm = (SRC == SRC_MM) ? h % n : 0u;
+    const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
+    const u32 hm = (SRC == SRC_MM) ? (((u32)ki.chars * 2u) << h) % n : 0u; // h = doubling step index
 
     for (u32 i = threadIdx.x; i < NB; i += kSortThreads) s_hist[i] = 0;
+    if (SRC == SRC_TEXT || SRC == SRC_WALK)
+        for (u32 i = threadIdx.x; i < 256; i += kSortThreads) s_code[i] = a.sym_code[(size_t)lb * 256 + i];
     __syncthreads();
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
     {
         u32 key[16], val[16];
-        const u32 ok = fetch_rows<SRC>(a, lb, text, n, hm, Kin, Vin, start + w * 1024u + l, cnt, key, val);
+        const u32 ok =
+            fetch_rows<SRC>(a, lb, text, n, hm, Kin, Vin, start + w * 1024u + l, cnt, s_code, ki, key, val);
 #pragma unroll
         for (u32 r = 0; r < 16; ++r)
             if ((ok >> r) & 1u) atomicAdd(&s_hist[(key[r] >> shift) & (NB - 1)], 1u);
@@ -238,6 +258,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
     __shared__ u16 s_tpre[NB];
     __shared__ u32 s_wsum[NW];
     __shared__ u32 s_total;
+    __shared__ u8 s_code[256];
     u16 *s_cnt = reinterpret_cast<u16 *>(s_buf); // [NW][NB] u16 <= 64 KiB
     u32 tile, lb;
     xcd_remap(kTilesPerBlock, a.nb, tile, lb);
@@ -248,10 +269,13 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
     const u32 start = tile * kSortTile;
     if (start >= cnt) return;
     const u8 *text = a.rle + d.rle_off;
-    const u32 hm = (SRC == SRC_MM) ? h % n : 0u;
+    const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
+    const u32 hm = (SRC == SRC_MM) ? (((u32)ki.chars * 2u) << h) % n : 0u; // h = doubling step index
     const size_t base = (size_t)lb * kSlot;
 
     {
+        if (SRC == SRC_TEXT || SRC == SRC_WALK)
+            for (u32 i = threadIdx.x; i < 256; i += kSortThreads) s_code[i] = a.sym_code[(size_t)lb * 256 + i];
         for (u32 i = threadIdx.x; i < NW * NB / 2; i += kSortThreads) s_buf[i] = 0;
         const u32 *hist = a.tile_hist + ((size_t)lb * kTilesPerBlock + tile) * kMaxBins;
         const u32 *bin_base = a.bin_base + (size_t)lb * kMaxBins;
@@ -265,7 +289,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
 
     u32 key[16], val[16];
     u32 rnk[16]; // 0xFFFFFFFF = takes no part
-    const u32 okmask = fetch_rows<SRC>(a, lb, text, n, hm, Kin, Vin, start + w * 1024u + l, cnt, key, val);
+    const u32 okmask =
+        fetch_rows<SRC>(a, lb, text, n, hm, Kin, Vin, start + w * 1024u + l, cnt, s_code, ki, key, val);
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
         const bool ok = (okmask >> r) & 1u;
@@ -362,33 +387,42 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
 }
 
 // ---- group refinement, part 1: boundary flags over the sorted pair list ----------------
-// INIT: the list is all n rotations sorted by their 4-byte key (one old group).
+// INIT: the list is all n rotations sorted by their first 2c symbols (one old group); K holds
+//       key(j) = symbols [0,c), the second half key(j+c) is re-read from the block (L2).
 // else: list sorted by old group head g = K; secondary key = rank of rotation j+h.
+// `step` is the doubling step: h = 2c << step.
 template <bool INIT>
-__global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 h, const u32 *__restrict__ K,
+__global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 step, const u32 *__restrict__ K,
                                                                const u32 *__restrict__ V)
 {
     __shared__ int s_old, s_new;
+    __shared__ u8 s_code[256];
     u32 tile, lb;
     xcd_remap(kTilesPerBlock, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
-    const u32 n = a.blocks[lb].n;
+    const BlockDesc d = a.blocks[lb];
+    const u32 n = d.n;
     const u32 cnt = a.count[lb];
     const u32 start = tile * kSortTile;
     if (start >= cnt) return;
-    const u32 hm = h % n;
+    const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
+    const u32 hm = INIT ? (u32)ki.chars % n : (((u32)ki.chars * 2u) << step) % n;
+    const u8 *text = a.rle + d.rle_off;
     const size_t base = (size_t)lb * kSlot;
     if (threadIdx.x == 0) {
         s_old = -1;
         s_new = -1;
     }
+    if (INIT)
+        for (u32 i = threadIdx.x; i < 256; i += kSortThreads) s_code[i] = a.sym_code[(size_t)lb * 256 + i];
     __syncthreads();
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
     int last_old = -1, last_new = -1;
     const u32 first = start + w * 1024u + l;
-    u32 g[16], s[16];
+    // per element: old-group key g, and the secondary key as one or two words (s1, s2)
+    u32 g[16], s1[16], s2[16];
     // row 0 of lane 0 also needs the element just before the wave's range
-    u32 pg0 = 0, ps0 = 0;
+    u32 pg0 = 0, ps10 = 0, ps20 = 0;
     {
         u32 jj[16];
 #pragma unroll
@@ -396,48 +430,48 @@ __global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 h, 
             const u32 idx = first + r * 64u;
             const u32 c = idx < cnt ? idx : cnt - 1u;
             const u32 kk = ld_stream(K + base + c);
-            if (INIT) {
-                g[r] = 0;
-                s[r] = kk;
-            } else {
-                g[r] = kk;
-                u32 t = ld_stream(V + base + c) + hm;
-                jj[r] = t >= n ? t - n : t;
-            }
+            const u32 t = ld_stream(V + base + c) + hm;
+            jj[r] = t >= n ? t - n : t;
+            g[r] = INIT ? 0u : kk;
+            s1[r] = kk;
+            s2[r] = 0;
         }
         u32 pj = 0;
         const bool need_prev = (l == 0) && (first > 0) && (first < cnt);
         if (need_prev) {
             const u32 kk = K[base + first - 1];
-            if (INIT) {
-                ps0 = kk;
-            } else {
-                pg0 = kk;
-                u32 t = V[base + first - 1] + hm;
-                pj = t >= n ? t - n : t;
-            }
+            pg0 = INIT ? 0u : kk;
+            ps10 = kk;
+            const u32 t = V[base + first - 1] + hm;
+            pj = t >= n ? t - n : t;
         }
-        if (!INIT) {
+        if (INIT) {
 #pragma unroll
-            for (u32 r = 0; r < 16; ++r) s[r] = a.R[base + jj[r]];
-            if (need_prev) ps0 = a.R[base + pj];
+            for (u32 r = 0; r < 16; ++r) s2[r] = pack_key(text, n, jj[r], s_code, ki.bits, ki.chars);
+            if (need_prev) ps20 = pack_key(text, n, pj, s_code, ki.bits, ki.chars);
+        } else {
+#pragma unroll
+            for (u32 r = 0; r < 16; ++r) s1[r] = a.R[base + jj[r]];
+            if (need_prev) ps10 = a.R[base + pj];
         }
     }
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
         const u32 idx = first + r * 64u;
         const bool ok = idx < cnt;
-        u32 pg = __shfl_up(g[r], 1, 64), ps = __shfl_up(s[r], 1, 64);
+        u32 pg = __shfl_up(g[r], 1, 64), p1 = __shfl_up(s1[r], 1, 64), p2 = __shfl_up(s2[r], 1, 64);
         // lane 0: the previous element is lane 63 of the previous row (or the pre-loaded one)
         const u32 qg = (r == 0) ? pg0 : __shfl(g[(r + 15) & 15], 63, 64);
-        const u32 qs = (r == 0) ? ps0 : __shfl(s[(r + 15) & 15], 63, 64);
+        const u32 q1 = (r == 0) ? ps10 : __shfl(s1[(r + 15) & 15], 63, 64);
+        const u32 q2 = (r == 0) ? ps20 : __shfl(s2[(r + 15) & 15], 63, 64);
         if (l == 0) {
             pg = qg;
-            ps = qs;
+            p1 = q1;
+            p2 = q2;
         }
         if (ok) {
             const bool os = (idx == 0) || (g[r] != pg);
-            const bool ns = os || (s[r] != ps);
+            const bool ns = os || (s1[r] != p1) || (s2[r] != p2);
             a.flags[base + idx] = (u8)((os ? 1u : 0u) | (ns ? 2u : 0u));
             if (os) last_old = (int)idx;
             if (ns) last_new = (int)idx;
@@ -462,7 +496,7 @@ __global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 h, 
 
 // ---- group refinement, part 2: positions, new ranks, final bits ---------------------------
 template <bool INIT>
-__global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 h_next, u32 round,
+__global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 next_step, u32 round,
                                                                const u32 *__restrict__ K,
                                                                const u32 *__restrict__ V)
 {
@@ -557,6 +591,9 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 h_n
     __syncthreads();
     if (threadIdx.x == 0 && s_nonfinal) {
         atomicAdd(&a.nonfinal[lb], s_nonfinal);
+        // the block still needs rounds only while the next comparison depth is below its length
+        const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
+        const u32 h_next = ((u32)ki.chars * 2u) << next_step;
         if (h_next < n) atomicAdd(&a.active[round], (unsigned long long)s_nonfinal);
     }
 }
@@ -610,11 +647,8 @@ __global__ __launch_bounds__(kSortThreads) void k_periodic_place(BwtArgs a)
     }
 }
 
-// ---- last column, origPtr, symbol map ------------------------------------------------------------
-// L[i] = block[(SA[i]-1) mod n]  (src/bzip2/encoder.rs:331-338); origPtr = i with SA[i]==0 (:332-334)
-__global__ __launch_bounds__(kSortThreads) void k_last_column(BwtArgs a, u8 *__restrict__ L,
-                                                               u32 *__restrict__ orig_ptr,
-                                                               u32 *__restrict__ inuse_bits /*[nb][8]*/)
+// ---- symbols in use and key geometry (before the sort) ----------------------------------------------
+__global__ __launch_bounds__(kSortThreads) void k_block_symbols(BwtArgs a, u32 *__restrict__ inuse_bits /*[nb][8]*/)
 {
     __shared__ u32 s_bits[8];
     u32 tile, lb;
@@ -625,15 +659,11 @@ __global__ __launch_bounds__(kSortThreads) void k_last_column(BwtArgs a, u8 *__r
     const u32 start = tile * kSortTile;
     if (start >= n) return;
     const u8 *text = a.rle + d.rle_off;
-    const size_t base = (size_t)lb * kSlot;
     if (threadIdx.x < 8) s_bits[threadIdx.x] = 0;
     __syncthreads();
     u32 seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (u32 i = start + threadIdx.x; i < n && i < start + kSortTile; i += kSortThreads) {
-        const u32 s = a.SA[base + i];
-        if (s == 0) orig_ptr[lb] = i;
-        const u8 c = text[s == 0 ? n - 1 : s - 1];
-        L[base + i] = c;
+        const u8 c = text[i];
         seen[c >> 5] |= 1u << (c & 31u);
     }
 #pragma unroll
@@ -645,6 +675,54 @@ __global__ __launch_bounds__(kSortThreads) void k_last_column(BwtArgs a, u8 *__r
     }
     __syncthreads();
     if (threadIdx.x < 8 && s_bits[threadIdx.x]) atomicOr(&inuse_bits[lb * 8 + threadIdx.x], s_bits[threadIdx.x]);
+}
+
+// one 256-thread workgroup per block: byte -> code table (rank among the bytes in use, the
+// reference's unseq2seq, src/bzip2/encoder.rs:304-314) and the key geometry
+__global__ __launch_bounds__(256) void k_key_params(const u32 *__restrict__ inuse_bits, u8 *__restrict__ sym_code,
+                                                     u8 *__restrict__ keyinfo)
+{
+    const u32 lb = blockIdx.x;
+    const u32 *bits = inuse_bits + lb * 8;
+    const u32 v = threadIdx.x;
+    u32 before = 0;
+    for (u32 q = 0; q < (v >> 5); ++q) before += __popc(bits[q]);
+    before += __popc(bits[v >> 5] & ((1u << (v & 31u)) - 1u));
+    sym_code[(size_t)lb * 256 + v] = (u8)before;
+    if (v == 0) {
+        u32 alpha = 0;
+        for (u32 q = 0; q < 8; ++q) alpha += __popc(bits[q]);
+        u32 nbits = 1;
+        while ((1u << nbits) < alpha) ++nbits;
+        u32 chars = (nbits >= 8) ? 4u : 30u / nbits;
+        if (chars > 8u) chars = 8u;
+        KeyInfo ki;
+        ki.bits = (u8)nbits;
+        ki.chars = (u8)chars;
+        ki.pad[0] = ki.pad[1] = 0;
+        reinterpret_cast<KeyInfo *>(keyinfo)[lb] = ki;
+    }
+}
+
+// ---- last column, origPtr ---------------------------------------------------------------------------
+// L[i] = block[(SA[i]-1) mod n]  (src/bzip2/encoder.rs:331-338); origPtr = i with SA[i]==0 (:332-334)
+__global__ __launch_bounds__(kSortThreads) void k_last_column(BwtArgs a, u8 *__restrict__ L,
+                                                               u32 *__restrict__ orig_ptr)
+{
+    u32 tile, lb;
+    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    const BlockDesc d = a.blocks[lb];
+    const u32 n = d.n;
+    const u32 start = tile * kSortTile;
+    if (start >= n) return;
+    const u8 *text = a.rle + d.rle_off;
+    const size_t base = (size_t)lb * kSlot;
+    for (u32 i = start + threadIdx.x; i < n && i < start + kSortTile; i += kSortThreads) {
+        const u32 s = ld_stream(a.SA + base + i);
+        if (s == 0) orig_ptr[lb] = i;
+        L[base + i] = text[s == 0 ? n - 1 : s - 1];
+    }
 }
 
 // ---- host side ------------------------------------------------------------------------------------
@@ -698,15 +776,15 @@ void KernelProf::reset()
 }
 
 // Algorithmic bytes per element of each radix kernel, by source:
-//   hist   : TEXT 1 (block byte), PAIRS 4 (key), MM 8 (SA + rank)
+//   hist   : TEXT 1 (block byte), PAIRS 4 (key), MM 8 (SA + rank), WALK 5 (order + block byte)
 //   scatter: the same reads (+4 for the value of PAIRS) + 8 written (key, value)
 template <int SRC, int BITS>
 static void radix_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const u32 *Kin, const u32 *Vin,
                        u32 *Kout, u32 *Vout, u64 elems, KernelProf *prof)
 {
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
-    const u64 rd_hist = (SRC == SRC_TEXT) ? 1 : (SRC == SRC_PAIRS ? 4 : 8);
-    const u64 rd_scat = (SRC == SRC_TEXT) ? 1 : 8;
+    const u64 rd_hist = (SRC == SRC_TEXT) ? 1 : (SRC == SRC_PAIRS ? 4 : (SRC == SRC_WALK ? 5 : 8));
+    const u64 rd_scat = (SRC == SRC_TEXT) ? 1 : (SRC == SRC_WALK ? 5 : 8);
     int p = prof ? prof->begin(st, KID_RADIX_HIST, elems * rd_hist) : -1;
     hipLaunchKernelGGL((k_radix_hist<SRC, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Kin, Vin);
     if (prof) prof->end(st, p);
@@ -719,29 +797,49 @@ static void radix_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const
     if (prof) prof->end(st, p);
 }
 
+void launch_block_symbols(hipStream_t st, const BwtArgs &a, u32 *inuse_bits, u8 *sym_code, u8 *keyinfo)
+{
+    const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
+    (void)hipMemsetAsync(inuse_bits, 0, (size_t)a.nb * 8 * sizeof(u32), st);
+    hipLaunchKernelGGL(k_block_symbols, grid, dim3(kSortThreads), 0, st, a, inuse_bits);
+    hipLaunchKernelGGL(k_key_params, dim3(a.nb), dim3(256), 0, st, inuse_bits, sym_code, keyinfo);
+}
+
+template <int B0, int B1, int B2>
+static void init_sort(hipStream_t st, const BwtArgs &a, u64 total_n, KernelProf *prof)
+{
+    // phase A: order by key(j); phase B: walk it, order by key(j - c) -> 2c symbols
+    radix_pass<SRC_TEXT, B0>(st, a, 0, 0, nullptr, nullptr, a.KA, a.VA, total_n, prof);
+    radix_pass<SRC_PAIRS, B1>(st, a, B0, 0, a.KA, a.VA, a.KB, a.VB, total_n, prof);
+    radix_pass<SRC_PAIRS, B2>(st, a, B0 + B1, 0, a.KB, a.VB, a.KA, a.VA, total_n, prof);
+    radix_pass<SRC_WALK, B0>(st, a, 0, 0, a.KA, a.VA, a.KB, a.VB, total_n, prof);
+    radix_pass<SRC_PAIRS, B1>(st, a, B0, 0, a.KB, a.VB, a.KA, a.VA, total_n, prof);
+    radix_pass<SRC_PAIRS, B2>(st, a, B0 + B1, 0, a.KA, a.VA, a.KB, a.VB, total_n, prof);
+}
+
 // Sorts the rotations of every block of the batch; leaves the order in a.SA.
 // h_active is a pinned host word used to poll the per-round counters.  total_n = sum of block
-// lengths (for the profiler's byte accounting).
+// lengths (for the profiler's byte accounting).  wide_keys: some block uses more than 128
+// symbols (32-bit keys, 11+11+10 bit digits; otherwise 30-bit keys, 10+10+10).  min_chars: the
+// smallest symbols-per-key of the batch.
 // Returns the number of doubling rounds executed, <0 on HIP error.
 int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned long long *h_active,
-            u64 *sorted_elems, KernelProf *prof, u64 *round_active)
+            u64 *sorted_elems, KernelProf *prof, u64 *round_active, bool wide_keys, u32 min_chars)
 {
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
     (void)hipMemsetAsync(a.active, 0, 64 * sizeof(unsigned long long), st);
     (void)hipMemsetAsync(a.nonfinal, 0, a.nb * sizeof(u32), st);
 
-    // init: 4-byte keys, LSD 11 + 11 + 10 bits
-    radix_pass<SRC_TEXT, 11>(st, a, 0, 0, nullptr, nullptr, a.KA, a.VA, total_n, prof);
-    radix_pass<SRC_PAIRS, 11>(st, a, 11, 0, a.KA, a.VA, a.KB, a.VB, total_n, prof);
-    radix_pass<SRC_PAIRS, 10>(st, a, 22, 0, a.KB, a.VB, a.KA, a.VA, total_n, prof);
-    int p = prof ? prof->begin(st, KID_GROUP_FLAGS, total_n * 5) : -1;
-    hipLaunchKernelGGL((k_group_flags<true>), grid, dim3(kSortThreads), 0, st, a, 0u, a.KA, a.VA);
+    if (wide_keys) init_sort<11, 11, 10>(st, a, total_n, prof);
+    else init_sort<10, 10, 10>(st, a, total_n, prof);
+    int p = prof ? prof->begin(st, KID_GROUP_FLAGS, total_n * 9) : -1;
+    hipLaunchKernelGGL((k_group_flags<true>), grid, dim3(kSortThreads), 0, st, a, 0u, a.KB, a.VB);
     if (prof) prof->end(st, p);
     p = prof ? prof->begin(st, KID_GROUP_APPLY, total_n * 13) : -1;
-    hipLaunchKernelGGL((k_group_apply<true>), grid, dim3(kSortThreads), 0, st, a, 4u, 0u, a.KA, a.VA);
+    hipLaunchKernelGGL((k_group_apply<true>), grid, dim3(kSortThreads), 0, st, a, 0u, 0u, a.KB, a.VB);
     if (prof) prof->end(st, p);
 
-    u32 h = 4;
+    u32 step = 0; // this round compares at depth h = 2c << step
     int rounds = 0;
     u32 slot = 0;
     while (true) {
@@ -752,25 +850,20 @@ int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned l
         const u64 m = *h_active; // rotations still to be ordered (in unfinished blocks)
         if (sorted_elems) *sorted_elems += m;
         if (round_active && slot < 64) round_active[slot] += m;
-        if (m == 0 || h >= max_n) break;
-        {
-            static const int max_rounds = getenv("BZ_MAX_ROUNDS") ? atoi(getenv("BZ_MAX_ROUNDS")) : 1000; // experiments only
-            if (rounds >= max_rounds) break;
-        }
+        if (m == 0 || step > 24 || ((u64)(2u * min_chars) << step) >= max_n) break;
         ++slot;
         ++rounds;
         (void)hipMemsetAsync(a.nonfinal, 0, a.nb * sizeof(u32), st);
         // pass A walks all of SA (total_n), pass B and the refinement only the m survivors
-        radix_pass<SRC_MM, 10>(st, a, 0, h, nullptr, nullptr, a.KA, a.VA, total_n, prof);
-        radix_pass<SRC_PAIRS, 10>(st, a, 10, h, a.KA, a.VA, a.KB, a.VB, m, prof);
+        radix_pass<SRC_MM, 10>(st, a, 0, step, nullptr, nullptr, a.KA, a.VA, total_n, prof);
+        radix_pass<SRC_PAIRS, 10>(st, a, 10, step, a.KA, a.VA, a.KB, a.VB, m, prof);
         p = prof ? prof->begin(st, KID_GROUP_FLAGS, m * 13) : -1;
-        hipLaunchKernelGGL((k_group_flags<false>), grid, dim3(kSortThreads), 0, st, a, h, a.KB, a.VB);
+        hipLaunchKernelGGL((k_group_flags<false>), grid, dim3(kSortThreads), 0, st, a, step, a.KB, a.VB);
         if (prof) prof->end(st, p);
-        const u32 hn = (h > 0x40000000u) ? 0x80000000u : h * 2u;
         p = prof ? prof->begin(st, KID_GROUP_APPLY, m * 17) : -1;
-        hipLaunchKernelGGL((k_group_apply<false>), grid, dim3(kSortThreads), 0, st, a, hn, slot, a.KB, a.VB);
+        hipLaunchKernelGGL((k_group_apply<false>), grid, dim3(kSortThreads), 0, st, a, step + 1, slot, a.KB, a.VB);
         if (prof) prof->end(st, p);
-        h = hn;
+        ++step;
     }
     // periodic blocks: whatever is still non-final is a set of equal rotations
     (void)hipMemsetAsync(a.per_k, 0, a.nb * sizeof(u32), st);
@@ -780,13 +873,11 @@ int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned l
     return rounds;
 }
 
-void launch_last_column(hipStream_t st, const BwtArgs &a, u8 *L, u32 *orig_ptr, u32 *inuse_bits, u64 total_n,
-                        KernelProf *prof)
+void launch_last_column(hipStream_t st, const BwtArgs &a, u8 *L, u32 *orig_ptr, u64 total_n, KernelProf *prof)
 {
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
-    (void)hipMemsetAsync(inuse_bits, 0, (size_t)a.nb * 8 * sizeof(u32), st);
     const int p = prof ? prof->begin(st, KID_LAST_COLUMN, total_n * 6) : -1;
-    hipLaunchKernelGGL(k_last_column, grid, dim3(kSortThreads), 0, st, a, L, orig_ptr, inuse_bits);
+    hipLaunchKernelGGL(k_last_column, grid, dim3(kSortThreads), 0, st, a, L, orig_ptr);
     if (prof) prof->end(st, p);
 }
 
