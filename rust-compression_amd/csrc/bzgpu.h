@@ -182,6 +182,8 @@ struct BwtArgs {
     u32 *tile_hist;                  // [nb][kTilesPerBlock][kMaxBins]
     u32 *bin_base;                   // [nb][kMaxBins]
     u32 *count;                      // [nb] length of the compacted pair list
+    u32 *count2;                     // [nb] scratch: survivors of the last round
+    u32 *tile_nf;                    // [nb][kTilesPerBlock] survivors per tile of the last refinement
     u8 *flags;                       // [nb * kSlot]
     int *tile_last_old;              // [nb][kTilesPerBlock]
     int *tile_last_new;              // [nb][kTilesPerBlock]

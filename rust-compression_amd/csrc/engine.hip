@@ -69,7 +69,7 @@ struct bz_gpu_engine {
     int level = 9;
     // batch workspace (sized by max_blocks)
     DevBuf lblocks, lcrc, SA, R, KA, VA, KB, VB, tile_hist, count, flags, tlo, tln, nonfinal, active, per_k,
-        per_shift, bin_base, sym_code, keyinfo, L, orig_ptr, inuse_bits, summ, summ_len, init_state, rank8, ztile_last, ztile_cnt, mtf,
+        per_shift, bin_base, sym_code, keyinfo, count2, tile_nf, L, orig_ptr, inuse_bits, summ, summ_len, init_state, rank8, ztile_last, ztile_cnt, mtf,
         mtf_freq, bout, selector, code_len, group_bitoff, lm_scratch, stream, error_flag, packlist;
     bool ws_ready = false;
     // own packed buffer / assemble list for the single-GPU convenience call
@@ -139,6 +139,8 @@ static int ensure_workspace(bz_gpu_engine *g)
     ENS(count, nb * 4);
     ENS(bin_base, nb * (size_t)kMaxBins * 4);
     ENS(sym_code, nb * (size_t)256);
+    ENS(count2, nb * 4);
+    ENS(tile_nf, nb * (size_t)kTilesPerBlock * 4);
     ENS(keyinfo, nb * (size_t)4);
     ENS(flags, nb * (size_t)kSlot);
     ENS(tlo, nb * (size_t)kTilesPerBlock * 4);
@@ -231,7 +233,7 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
     DevBuf *all[] = {&g->crc_tab, &g->xp16, &g->xp2, &g->tile_last, &g->carry_in, &g->tile_crc, &g->tile_count,
                      &g->tile_off, &g->scal, &g->rle, &g->blocks_all, &g->crc_all, &g->lblocks, &g->lcrc, &g->SA,
                      &g->R, &g->KA, &g->VA, &g->KB, &g->VB, &g->tile_hist, &g->count, &g->flags, &g->tlo, &g->tln,
-                     &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->bin_base, &g->sym_code, &g->keyinfo, &g->L, &g->orig_ptr, &g->inuse_bits,
+                     &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->bin_base, &g->sym_code, &g->keyinfo, &g->count2, &g->tile_nf, &g->L, &g->orig_ptr, &g->inuse_bits,
                      &g->summ, &g->summ_len, &g->init_state, &g->rank8, &g->ztile_last, &g->ztile_cnt, &g->mtf,
                      &g->mtf_freq, &g->bout, &g->selector, &g->code_len, &g->group_bitoff, &g->lm_scratch,
                      &g->stream, &g->error_flag, &g->packlist, &g->packed, &g->asmlist};
@@ -319,6 +321,8 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb)
     x.VB = g->VB.as<u32>();
     x.tile_hist = g->tile_hist.as<u32>();
     x.count = g->count.as<u32>();
+    x.count2 = g->count2.as<u32>();
+    x.tile_nf = g->tile_nf.as<u32>();
     x.bin_base = g->bin_base.as<u32>();
     x.flags = g->flags.as<u8>();
     x.tile_last_old = g->tlo.as<int>();

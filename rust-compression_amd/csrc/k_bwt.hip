@@ -36,7 +36,11 @@
 
 namespace bzgpu {
 
-enum { SRC_TEXT = 0, SRC_PAIRS = 1, SRC_MM = 2, SRC_WALK = 3 };
+enum { SRC_TEXT = 0, SRC_PAIRS = 1, SRC_MM = 2, SRC_WALK = 3, SRC_SURV = 4, SRC_LISTG = 5 };
+// sources whose sequence is the compacted list (length count[lb]) rather than all n positions
+template <int SRC> struct src_is_list {
+    static constexpr bool value = (SRC == SRC_PAIRS || SRC == SRC_SURV || SRC == SRC_LISTG);
+};
 
 // per-block key geometry, produced by k_key_params
 struct KeyInfo {
@@ -118,6 +122,32 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
             val[r] = ld_stream(Vin + base + c);
             ok |= (idx < cnt ? 1u : 0u) << r;
         }
+    } else if (SRC == SRC_SURV) {
+        // survivor round, first half: order the survivors by the rank of rotation j+h
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) {
+            const u32 idx = first + r * 64u;
+            const u32 c = idx < cnt ? idx : cnt - 1u;
+            val[r] = ld_stream(Vin + base + c);
+            ok |= (idx < cnt ? 1u : 0u) << r;
+        }
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) {
+            u32 t = val[r] + hm;
+            t = t >= n ? t - n : t;
+            key[r] = a.R[base + t] & ~kFinalBit;
+        }
+    } else if (SRC == SRC_LISTG) {
+        // survivor round, second half: walk that order, key = the survivor's own group
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) {
+            const u32 idx = first + r * 64u;
+            const u32 c = idx < cnt ? idx : cnt - 1u;
+            val[r] = ld_stream(Vin + base + c);
+            ok |= (idx < cnt ? 1u : 0u) << r;
+        }
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) key[r] = a.R[base + val[r]];
     } else {
 #pragma unroll
         for (u32 r = 0; r < 16; ++r) {
@@ -151,12 +181,12 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shif
     if (lb == 0xFFFFFFFFu) return;
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
-    const u32 cnt = (SRC == SRC_PAIRS) ? a.count[lb] : n;
+    const u32 cnt = src_is_list<SRC>::value ? a.count[lb] : n;
     const u32 start = tile * kSortTile;
     if (start >= cnt) return;
     const u8 *text = a.rle + d.rle_off;
     const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
-    const u32 hm = (SRC == SRC_MM) ? (((u32)ki.chars * 2u) << h) % n : 0u; // h = doubling step index
+    const u32 hm = (SRC == SRC_MM || SRC == SRC_SURV) ? (((u32)ki.chars * 2u) << h) % n : 0u; // h = step index
 
     for (u32 i = threadIdx.x; i < NB; i += kSortThreads) s_hist[i] = 0;
     if (SRC == SRC_TEXT || SRC == SRC_WALK)
@@ -187,7 +217,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scan(BwtArgs a)
     __shared__ u32 s_wsum[kSortThreads / 64];
     const u32 lb = blockIdx.x;
     const u32 n = a.blocks[lb].n;
-    const u32 cnt = (SRC == SRC_PAIRS) ? a.count[lb] : n;
+    const u32 cnt = src_is_list<SRC>::value ? a.count[lb] : n;
     const u32 ntiles = (cnt + kSortTile - 1) / kSortTile;
     u32 *hist = a.tile_hist + (size_t)lb * kTilesPerBlock * kMaxBins;
     u32 *bin_base = a.bin_base + (size_t)lb * kMaxBins;
@@ -233,7 +263,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scan(BwtArgs a)
         if (dgt < NB) bin_base[dgt] = base;
         base += tot[q];
     }
-    if (SRC != SRC_PAIRS && threadIdx.x == 0) a.count[lb] = total; // list length for the next passes
+    if (!src_is_list<SRC>::value && threadIdx.x == 0) a.count[lb] = total; // list length for the next passes
 }
 
 // ---- radix pass, part 3: stable scatter -----------------------------------------------
@@ -265,12 +295,12 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
     if (lb == 0xFFFFFFFFu) return;
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
-    const u32 cnt = (SRC == SRC_PAIRS) ? a.count[lb] : n;
+    const u32 cnt = src_is_list<SRC>::value ? a.count[lb] : n;
     const u32 start = tile * kSortTile;
     if (start >= cnt) return;
     const u8 *text = a.rle + d.rle_off;
     const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
-    const u32 hm = (SRC == SRC_MM) ? (((u32)ki.chars * 2u) << h) % n : 0u; // h = doubling step index
+    const u32 hm = (SRC == SRC_MM || SRC == SRC_SURV) ? (((u32)ki.chars * 2u) << h) % n : 0u; // h = step index
     const size_t base = (size_t)lb * kSlot;
 
     {
@@ -589,6 +619,7 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
     my_nonfinal = wave_sum(my_nonfinal);
     if (l == 0 && my_nonfinal) atomicAdd(&s_nonfinal, my_nonfinal);
     __syncthreads();
+    if (threadIdx.x == 0) a.tile_nf[lb * kTilesPerBlock + tile] = s_nonfinal;
     if (threadIdx.x == 0 && s_nonfinal) {
         atomicAdd(&a.nonfinal[lb], s_nonfinal);
         // the block still needs rounds only while the next comparison depth is below its length
@@ -596,6 +627,87 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
         const u32 h_next = ((u32)ki.chars * 2u) << next_step;
         if (h_next < n) atomicAdd(&a.active[round], (unsigned long long)s_nonfinal);
     }
+}
+
+// ---- survivors of a round, compacted in list order ------------------------------------------------
+// The list (V, flags) a round has just refined -> the rotations that are still not final, in the
+// same order (i.e. sorted by their new group head).  Used when few survive: the next round then
+// sorts the survivors explicitly instead of walking all of SA.
+__global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, const u32 *__restrict__ V,
+                                                                    u32 *__restrict__ VS)
+{
+    constexpr u32 NW = kSortThreads / 64;
+    __shared__ u32 s_off, s_wsum[NW];
+    u32 tile, lb;
+    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    const u32 cnt = a.count[lb];
+    const u32 start = tile * kSortTile;
+    const u32 ntiles = (cnt + kSortTile - 1) / kSortTile;
+    if (tile == 0 && threadIdx.x == 0) {
+        u32 tot = 0;
+        for (u32 t = 0; t < ntiles; ++t) tot += a.tile_nf[lb * kTilesPerBlock + t];
+        a.count2[lb] = tot;
+    }
+    if (start >= cnt) return;
+    if (a.tile_nf[lb * kTilesPerBlock + tile] == 0) return;
+    const size_t base = (size_t)lb * kSlot;
+    if (threadIdx.x == 0) {
+        u32 off = 0;
+        for (u32 t = 0; t < tile; ++t) off += a.tile_nf[lb * kTilesPerBlock + t];
+        s_off = off;
+    }
+    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const u32 wbase = start + w * 1024u;
+    u64 surv[16];
+    u32 jv[16];
+    u32 wcount = 0;
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 idx = wbase + r * 64u + l;
+        const u32 c = idx < cnt ? idx : cnt - 1u;
+        jv[r] = ld_stream(V + base + c);
+    }
+    u64 mn[17];
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 idx = wbase + r * 64u + l;
+        const u32 f = (idx < cnt) ? ld_stream(a.flags + base + idx) : 2u;
+        mn[r] = __ballot(f & 2u);
+    }
+    {
+        // flag of the element right after the wave's span
+        const u32 nx = wbase + 1024u;
+        mn[16] = (nx < cnt) ? ((a.flags[base + nx] & 2u) ? 1ull : 0ull) : 1ull;
+    }
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 idx = wbase + r * 64u + l;
+        bool next_new;
+        if (idx + 1 >= cnt) next_new = true;
+        else if (l < 63) next_new = (mn[r] >> (l + 1)) & 1ull;
+        else next_new = mn[r + 1] & 1ull;
+        const bool is_new = (mn[r] >> l) & 1ull;
+        const bool sv = (idx < cnt) && !(is_new && next_new);
+        surv[r] = __ballot(sv);
+        wcount += (u32)__popcll(surv[r]);
+    }
+    if (l == 0) s_wsum[w] = wcount;
+    __syncthreads();
+    u32 off = s_off;
+    for (u32 k = 0; k < w; ++k) off += s_wsum[k];
+    const u64 lt_mask = (l == 0) ? 0ull : (~0ull >> (64 - l));
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        if ((surv[r] >> l) & 1ull) VS[base + off + (u32)__popcll(surv[r] & lt_mask)] = jv[r];
+        off += (u32)__popcll(surv[r]);
+    }
+}
+
+__global__ void k_copy_counts(u32 *__restrict__ dst, const u32 *__restrict__ src, u32 nb)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nb) dst[i] = src[i];
 }
 
 // ---- periodic blocks (block = u^k): closed-form tie rule -------------------------------------
@@ -784,7 +896,7 @@ static void radix_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const
 {
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
     const u64 rd_hist = (SRC == SRC_TEXT) ? 1 : (SRC == SRC_PAIRS ? 4 : (SRC == SRC_WALK ? 5 : 8));
-    const u64 rd_scat = (SRC == SRC_TEXT) ? 1 : (SRC == SRC_WALK ? 5 : 8);
+    const u64 rd_scat = (SRC == SRC_TEXT) ? 1 : (SRC == SRC_WALK ? 5 : 8); // SURV / LISTG: list + rank = 8
     int p = prof ? prof->begin(st, KID_RADIX_HIST, elems * rd_hist) : -1;
     hipLaunchKernelGGL((k_radix_hist<SRC, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Kin, Vin);
     if (prof) prof->end(st, p);
@@ -839,6 +951,8 @@ int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned l
     hipLaunchKernelGGL((k_group_apply<true>), grid, dim3(kSortThreads), 0, st, a, 0u, 0u, a.KB, a.VB);
     if (prof) prof->end(st, p);
 
+    u32 *cK = a.KB, *cV = a.VB; // the list the last refinement ran on
+    u32 *fK = a.KA, *fV = a.VA; // the free pair
     u32 step = 0; // this round compares at depth h = 2c << step
     int rounds = 0;
     u32 slot = 0;
@@ -854,14 +968,27 @@ int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned l
         ++slot;
         ++rounds;
         (void)hipMemsetAsync(a.nonfinal, 0, a.nb * sizeof(u32), st);
-        // pass A walks all of SA (total_n), pass B and the refinement only the m survivors
-        radix_pass<SRC_MM, 10>(st, a, 0, step, nullptr, nullptr, a.KA, a.VA, total_n, prof);
-        radix_pass<SRC_PAIRS, 10>(st, a, 10, step, a.KA, a.VA, a.KB, a.VB, m, prof);
+        if (m * 4 < total_n) {
+            // few survivors: compact them (list order = sorted by group), order them by the rank
+            // of rotation j+h (2 passes), then stably by their own group (2 passes): O(m) work
+            hipLaunchKernelGGL(k_survivor_compact, grid, dim3(kSortThreads), 0, st, a, cV, fV);
+            hipLaunchKernelGGL(k_copy_counts, dim3((a.nb + 255) / 256), dim3(256), 0, st, a.count, a.count2, a.nb);
+            radix_pass<SRC_SURV, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof);
+            radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof);
+            radix_pass<SRC_LISTG, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof);
+            radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof);
+            u32 *t = cK; cK = fK; fK = t;
+            t = cV; cV = fV; fV = t;
+        } else {
+            // pass A walks all of SA (total_n), pass B and the refinement only the m survivors
+            radix_pass<SRC_MM, 10>(st, a, 0, step, nullptr, nullptr, fK, fV, total_n, prof);
+            radix_pass<SRC_PAIRS, 10>(st, a, 10, step, fK, fV, cK, cV, m, prof);
+        }
         p = prof ? prof->begin(st, KID_GROUP_FLAGS, m * 13) : -1;
-        hipLaunchKernelGGL((k_group_flags<false>), grid, dim3(kSortThreads), 0, st, a, step, a.KB, a.VB);
+        hipLaunchKernelGGL((k_group_flags<false>), grid, dim3(kSortThreads), 0, st, a, step, cK, cV);
         if (prof) prof->end(st, p);
         p = prof ? prof->begin(st, KID_GROUP_APPLY, m * 17) : -1;
-        hipLaunchKernelGGL((k_group_apply<false>), grid, dim3(kSortThreads), 0, st, a, step + 1, slot, a.KB, a.VB);
+        hipLaunchKernelGGL((k_group_apply<false>), grid, dim3(kSortThreads), 0, st, a, step + 1, slot, cK, cV);
         if (prof) prof->end(st, p);
         ++step;
     }
