@@ -25,7 +25,10 @@ constexpr u32 kGSize = 50;                  // BZ_G_SIZE, src/bzip2/mod.rs:20
 constexpr u32 kMaxSelectors = 18002;        // BZ_MAX_SELECTORS, src/bzip2/encoder.rs:295
 constexpr u32 kMaxAlpha = 258;
 constexpr u32 kRleTile = 4096;              // input bytes per RLE1/CRC tile (256 threads x 16 B)
-constexpr u32 kMtfChunk = 256;              // symbols per serial MTF chunk (one lane each)
+#ifndef BZ_MTF_CHUNK
+#define BZ_MTF_CHUNK 512
+#endif
+constexpr u32 kMtfChunk = BZ_MTF_CHUNK;     // symbols per serial MTF chunk (one lane each)
 constexpr u32 kMaxMtfChunks = (kMaxBlockLen + kMtfChunk - 1) / kMtfChunk; // 3516
 // words reserved per block bit string: header (<= ~27k bits) + 900001 symbols x 17 bits (+ slack)
 constexpr u32 kStreamWords = 480000;        // 1.92 MB

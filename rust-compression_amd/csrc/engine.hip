@@ -55,7 +55,8 @@ struct DevBuf {
 
 struct bz_gpu_engine {
     int device = 0;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr;   // rotation sort (and everything serial)
+    hipStream_t st2 = nullptr;  // MTF / Huffman / emission of the previous sub-batch
     size_t max_blocks = 0;
 
     // constant tables
@@ -85,27 +86,30 @@ struct bz_gpu_engine {
 
     struct Span {
         int stage;
+        hipStream_t st;
         hipEvent_t a, b;
     };
     std::vector<Span> spans;
 };
 
-static int span_begin(bz_gpu_engine *g, int stage)
+static int span_begin(bz_gpu_engine *g, int stage, hipStream_t st = nullptr)
 {
     bz_gpu_engine::Span s;
     s.stage = stage;
+    s.st = st ? st : g->st;
     if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return -1;
-    (void)hipEventRecord(s.a, g->st);
+    (void)hipEventRecord(s.a, s.st);
     g->spans.push_back(s);
     return (int)g->spans.size() - 1;
 }
 static void span_end(bz_gpu_engine *g, int idx)
 {
-    if (idx >= 0) (void)hipEventRecord(g->spans[idx].b, g->st);
+    if (idx >= 0) (void)hipEventRecord(g->spans[idx].b, g->spans[idx].st);
 }
 static void spans_collect(bz_gpu_engine *g)
 {
     (void)hipStreamSynchronize(g->st);
+    (void)hipStreamSynchronize(g->st2);
     g->prof.collect();
     for (auto &s : g->spans) {
         float ms = 0;
@@ -199,6 +203,7 @@ extern "C" int bz_gpu_engine_create(bz_gpu_engine **out, int device, size_t max_
     g->device = device;
     g->max_blocks = max_blocks_in_flight ? max_blocks_in_flight : 64;
     HIPCHK(hipStreamCreateWithFlags(&g->st, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&g->st2, hipStreamNonBlocking));
     HIPCHK(hipHostMalloc((void **)&g->h_active, 64, hipHostMallocDefault));
 
     // CRC byte table (src/crc32.rs:58-72) and powers of x
@@ -230,6 +235,7 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
     if (!g) return;
     (void)hipSetDevice(g->device);
     (void)hipStreamSynchronize(g->st);
+    (void)hipStreamSynchronize(g->st2);
     DevBuf *all[] = {&g->crc_tab, &g->xp16, &g->xp2, &g->tile_last, &g->carry_in, &g->tile_crc, &g->tile_count,
                      &g->tile_off, &g->scal, &g->rle, &g->blocks_all, &g->crc_all, &g->lblocks, &g->lcrc, &g->SA,
                      &g->R, &g->KA, &g->VA, &g->KB, &g->VB, &g->tile_hist, &g->count, &g->flags, &g->tlo, &g->tln,
@@ -240,6 +246,7 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
     for (DevBuf *b : all) b->release();
     if (g->h_active) (void)hipHostFree(g->h_active);
     if (g->st) (void)hipStreamDestroy(g->st);
+    if (g->st2) (void)hipStreamDestroy(g->st2);
     delete g;
 }
 
@@ -307,42 +314,85 @@ extern "C" int bz_gpu_partition(bz_gpu_engine *g, int level, const void *d_in, s
     return BZ_OK;
 }
 
-static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb)
+// Argument blocks for the sub-batch of `nb` blocks that starts at local block `o`.
+static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
 {
     BwtArgs x;
+    const size_t s = (size_t)o * kSlot, t = (size_t)o * kTilesPerBlock;
     x.rle = g->rle.as<u8>();
-    x.blocks = g->lblocks.as<BlockDesc>();
+    x.blocks = g->lblocks.as<BlockDesc>() + o;
     x.nb = nb;
-    x.SA = g->SA.as<u32>();
-    x.R = g->R.as<u32>();
-    x.KA = g->KA.as<u32>();
-    x.VA = g->VA.as<u32>();
-    x.KB = g->KB.as<u32>();
-    x.VB = g->VB.as<u32>();
-    x.tile_hist = g->tile_hist.as<u32>();
-    x.count = g->count.as<u32>();
-    x.count2 = g->count2.as<u32>();
-    x.tile_nf = g->tile_nf.as<u32>();
-    x.bin_base = g->bin_base.as<u32>();
-    x.flags = g->flags.as<u8>();
-    x.tile_last_old = g->tlo.as<int>();
-    x.tile_last_new = g->tln.as<int>();
-    x.nonfinal = g->nonfinal.as<u32>();
+    x.SA = g->SA.as<u32>() + s;
+    x.R = g->R.as<u32>() + s;
+    x.KA = g->KA.as<u32>() + s;
+    x.VA = g->VA.as<u32>() + s;
+    x.KB = g->KB.as<u32>() + s;
+    x.VB = g->VB.as<u32>() + s;
+    x.tile_hist = g->tile_hist.as<u32>() + t * kMaxBins;
+    x.count = g->count.as<u32>() + o;
+    x.count2 = g->count2.as<u32>() + o;
+    x.tile_nf = g->tile_nf.as<u32>() + t;
+    x.bin_base = g->bin_base.as<u32>() + (size_t)o * kMaxBins;
+    x.flags = g->flags.as<u8>() + s;
+    x.tile_last_old = g->tlo.as<int>() + t;
+    x.tile_last_new = g->tln.as<int>() + t;
+    x.nonfinal = g->nonfinal.as<u32>() + o;
     x.active = g->active.as<unsigned long long>();
-    x.per_k = g->per_k.as<u32>();
-    x.per_shift = g->per_shift.as<u32>();
-    x.sym_code = g->sym_code.as<u8>();
-    x.keyinfo = g->keyinfo.as<u8>();
+    x.per_k = g->per_k.as<u32>() + o;
+    x.per_shift = g->per_shift.as<u32>() + o;
+    x.sym_code = g->sym_code.as<u8>() + (size_t)o * 256;
+    x.keyinfo = g->keyinfo.as<u8>() + (size_t)o * 4;
     return x;
 }
 
-// symbols in use -> key geometry -> rotation sort.  Returns rounds (<0: error).
-static int sort_batch(bz_gpu_engine *g, const BwtArgs &ba, u32 max_n, u64 total_n, u64 *sorted, KernelProf *prof,
-                      u64 *round_active)
+static MtfArgs make_mtf_args(bz_gpu_engine *g, u32 nb, u32 o)
 {
-    launch_block_symbols(g->st, ba, g->inuse_bits.as<u32>(), g->sym_code.as<u8>(), g->keyinfo.as<u8>());
+    MtfArgs ma;
+    const size_t s = (size_t)o * kSlot, t = (size_t)o * kTilesPerBlock, c = (size_t)o * kMaxMtfChunks;
+    ma.blocks = g->lblocks.as<BlockDesc>() + o;
+    ma.nb = nb;
+    ma.L = g->L.as<u8>() + s;
+    ma.inuse_bits = g->inuse_bits.as<u32>() + (size_t)o * 8;
+    ma.summ = g->summ.as<u8>() + c * 256;
+    ma.summ_len = g->summ_len.as<u16>() + c;
+    ma.init_state = g->init_state.as<u8>() + c * 256;
+    ma.rank8 = g->rank8.as<u8>() + s;
+    ma.ztile_last = g->ztile_last.as<int>() + t;
+    ma.ztile_cnt = g->ztile_cnt.as<u32>() + t;
+    ma.mtf = g->mtf.as<u16>() + (size_t)o * kMtfStride;
+    ma.mtf_freq = g->mtf_freq.as<u32>() + (size_t)o * kMaxAlpha;
+    ma.out = g->bout.as<BlockOut>() + o;
+    return ma;
+}
+
+static HuffArgs make_huff_args(bz_gpu_engine *g, u32 nb, u32 o)
+{
+    HuffArgs ha;
+    ha.blocks = g->lblocks.as<BlockDesc>() + o;
+    ha.nb = nb;
+    ha.mtf = g->mtf.as<u16>() + (size_t)o * kMtfStride;
+    ha.mtf_stride = kMtfStride;
+    ha.mtf_freq = g->mtf_freq.as<u32>() + (size_t)o * kMaxAlpha;
+    ha.inuse_bits = g->inuse_bits.as<u32>() + (size_t)o * 8;
+    ha.crc = g->lcrc.as<u32>() + o;
+    ha.orig_ptr = g->orig_ptr.as<u32>() + o;
+    ha.selector = g->selector.as<u8>() + (size_t)o * kSelStride;
+    ha.code_len = g->code_len.as<u32>() + (size_t)o * 6 * kMaxAlpha;
+    ha.group_bitoff = g->group_bitoff.as<u32>() + (size_t)o * kGboStride;
+    ha.lm_scratch = g->lm_scratch.as<u32>() + (size_t)o * 6 * kLmWords;
+    ha.stream = g->stream.as<u32>() + (size_t)o * kStreamWords;
+    ha.out = g->bout.as<BlockOut>() + o;
+    ha.error_flag = g->error_flag.as<u32>();
+    return ha;
+}
+
+// symbols in use -> key geometry -> rotation sort.  Returns rounds (<0: error).
+static int sort_batch(bz_gpu_engine *g, const BwtArgs &ba, u32 *inuse_bits, u32 max_n, u64 total_n, u64 *sorted,
+                      KernelProf *prof, u64 *round_active)
+{
+    launch_block_symbols(g->st, ba, inuse_bits, const_cast<u8 *>(ba.sym_code), const_cast<u8 *>(ba.keyinfo));
     std::vector<u8> ki((size_t)ba.nb * 4);
-    if (hipMemcpyAsync(ki.data(), g->keyinfo.p, ki.size(), hipMemcpyDeviceToHost, g->st) != hipSuccess) return -1;
+    if (hipMemcpyAsync(ki.data(), ba.keyinfo, ki.size(), hipMemcpyDeviceToHost, g->st) != hipSuccess) return -1;
     if (hipStreamSynchronize(g->st) != hipSuccess) return -1;
     bool wide = false;
     u32 min_chars = 8;
@@ -354,58 +404,71 @@ static int sort_batch(bz_gpu_engine *g, const BwtArgs &ba, u32 max_n, u64 total_
 }
 
 // encode one batch of local blocks (descriptors already in g->lblocks / g->lcrc)
-static int encode_batch(bz_gpu_engine *g, u32 nb, u32 max_n, u64 total_n)
+// Encode one batch of local blocks (descriptors already in g->lblocks / g->lcrc; `descs` is the host
+// copy).  The batch is cut into sub-batches: the rotation sort of sub-batch q+1 runs on the main
+// stream while MTF / Huffman / emission of sub-batch q run on the second stream -- those stages are
+// dominated by single-lane serial sections (heap Huffman, list composition) and leave most issue
+// slots and bandwidth free.
+static int encode_batch(bz_gpu_engine *g, u32 nb, const std::vector<BlockDesc> &descs)
 {
-    const BwtArgs ba = make_bwt_args(g, nb);
+    static const u32 want_parts = getenv("BZ_PARTS") ? (u32)atoi(getenv("BZ_PARTS")) : 1u;
+    const u32 parts = (nb >= 64 && want_parts >= 1) ? want_parts : 1u;
+    std::vector<hipEvent_t> evs;
+    int rc = BZ_OK;
+    for (u32 q = 0; q < parts && rc == BZ_OK; ++q) {
+        const u32 o = (u32)(((u64)nb * q) / parts), o1 = (u32)(((u64)nb * (q + 1)) / parts);
+        const u32 nbq = o1 - o;
+        if (nbq == 0) continue;
+        u32 max_n = 0;
+        u64 total_n = 0;
+        for (u32 i = o; i < o1; ++i) {
+            max_n = std::max(max_n, descs[i].n);
+            total_n += descs[i].n;
+        }
+        const BwtArgs ba = make_bwt_args(g, nbq, o);
+        int sp = span_begin(g, 1);
+        u64 sorted = 0;
+        const int rounds = sort_batch(g, ba, g->inuse_bits.as<u32>() + (size_t)o * 8, max_n, total_n, &sorted, &g->prof,
+                                      g->round_active);
+        if (rounds < 0) {
+            rc = BZ_E_UNEXPECTED;
+            break;
+        }
+        launch_last_column(g->st, ba, g->L.as<u8>() + (size_t)o * kSlot, g->orig_ptr.as<u32>() + o, total_n, &g->prof);
+        span_end(g, sp);
+        g->bwt_stats[0] = std::max<u64>(g->bwt_stats[0], (u64)rounds);
+        g->bwt_stats[1] += sorted;
+        g->bwt_stats[2] += 1;
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            rc = BZ_E_UNEXPECTED;
+            break;
+        }
+        evs.push_back(ev);
+        (void)hipEventRecord(ev, g->st);
+        (void)hipStreamWaitEvent(g->st2, ev, 0);
 
-    int sp = span_begin(g, 1);
-    u64 sorted = 0;
-    const int rounds = sort_batch(g, ba, max_n, total_n, &sorted, &g->prof, g->round_active);
-    if (rounds < 0) return BZ_E_UNEXPECTED;
-    launch_last_column(g->st, ba, g->L.as<u8>(), g->orig_ptr.as<u32>(), total_n, &g->prof);
-    span_end(g, sp);
-    g->bwt_stats[0] += (u64)rounds;
-    g->bwt_stats[1] += sorted;
-    g->bwt_stats[2] += 1;
-
-    MtfArgs ma;
-    ma.blocks = ba.blocks;
-    ma.nb = nb;
-    ma.L = g->L.as<u8>();
-    ma.inuse_bits = g->inuse_bits.as<u32>();
-    ma.summ = g->summ.as<u8>();
-    ma.summ_len = g->summ_len.as<u16>();
-    ma.init_state = g->init_state.as<u8>();
-    ma.rank8 = g->rank8.as<u8>();
-    ma.ztile_last = g->ztile_last.as<int>();
-    ma.ztile_cnt = g->ztile_cnt.as<u32>();
-    ma.mtf = g->mtf.as<u16>();
-    ma.mtf_freq = g->mtf_freq.as<u32>();
-    ma.out = g->bout.as<BlockOut>();
-    sp = span_begin(g, 2);
-    launch_mtf(g->st, ma);
-    span_end(g, sp);
-
-    HuffArgs ha;
-    ha.blocks = ba.blocks;
-    ha.nb = nb;
-    ha.mtf = g->mtf.as<u16>();
-    ha.mtf_stride = kMtfStride;
-    ha.mtf_freq = g->mtf_freq.as<u32>();
-    ha.inuse_bits = g->inuse_bits.as<u32>();
-    ha.crc = g->lcrc.as<u32>();
-    ha.orig_ptr = g->orig_ptr.as<u32>();
-    ha.selector = g->selector.as<u8>();
-    ha.code_len = g->code_len.as<u32>();
-    ha.group_bitoff = g->group_bitoff.as<u32>();
-    ha.lm_scratch = g->lm_scratch.as<u32>();
-    ha.stream = g->stream.as<u32>();
-    ha.out = g->bout.as<BlockOut>();
-    ha.error_flag = g->error_flag.as<u32>();
-    sp = span_begin(g, 3);
-    launch_huffman(g->st, ha);
-    span_end(g, sp);
-    return BZ_OK;
+        const MtfArgs ma = make_mtf_args(g, nbq, o);
+        sp = span_begin(g, 2, g->st2);
+        launch_mtf(g->st2, ma);
+        span_end(g, sp);
+        const HuffArgs ha = make_huff_args(g, nbq, o);
+        sp = span_begin(g, 3, g->st2);
+        launch_huffman(g->st2, ha);
+        span_end(g, sp);
+    }
+    // the main stream continues only after the tail stages are done
+    hipEvent_t done;
+    if (hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess) {
+        (void)hipEventRecord(done, g->st2);
+        (void)hipStreamWaitEvent(g->st, done, 0);
+        evs.push_back(done);
+    } else {
+        (void)hipStreamSynchronize(g->st2);
+    }
+    (void)hipStreamSynchronize(g->st);
+    for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
+    return rc;
 }
 
 extern "C" int bz_gpu_encode_blocks(bz_gpu_engine *g, size_t first, size_t stride, void *d_packed,
@@ -434,19 +497,15 @@ extern "C" int bz_gpu_encode_blocks(bz_gpu_engine *g, size_t first, size_t strid
         const u32 nb = (u32)std::min(g->max_blocks, mine.size() - k0);
         descs.resize(nb);
         crcs.resize(nb);
-        u32 max_n = 0;
-        u64 total_n = 0;
         for (u32 i = 0; i < nb; ++i) {
             descs[i] = g->h_blocks[mine[k0 + i]];
             crcs[i] = g->h_crc[mine[k0 + i]];
-            max_n = std::max(max_n, descs[i].n);
-            total_n += descs[i].n;
             if (descs[i].n > kMaxBlockLen) return BZ_E_UNEXPECTED;
         }
         HIPCHK(hipMemcpyAsync(g->lblocks.p, descs.data(), nb * sizeof(BlockDesc), hipMemcpyHostToDevice, g->st));
         HIPCHK(hipMemcpyAsync(g->lcrc.p, crcs.data(), nb * 4, hipMemcpyHostToDevice, g->st));
         HIPCHK(hipStreamSynchronize(g->st)); // descs/crcs are reused by the next batch
-        rc = encode_batch(g, nb, max_n, total_n);
+        rc = encode_batch(g, nb, descs);
         if (rc != BZ_OK) return rc;
         outs.resize(nb);
         u32 err = 0;
@@ -623,7 +682,7 @@ extern "C" int bz_gpu_debug_bwt(bz_gpu_engine *g, const uint8_t *h_block, size_t
     HIPCHK(hipMemcpyAsync(g->lblocks.p, &d, sizeof(d), hipMemcpyHostToDevice, g->st));
     const BwtArgs ba = make_bwt_args(g, 1);
     u64 sorted = 0;
-    const int rounds = sort_batch(g, ba, (u32)n, (u64)n, &sorted, nullptr, nullptr);
+    const int rounds = sort_batch(g, ba, g->inuse_bits.as<u32>(), (u32)n, (u64)n, &sorted, nullptr, nullptr);
     if (rounds < 0) return BZ_E_UNEXPECTED;
     g->bwt_stats[0] = (u64)rounds;
     g->bwt_stats[1] = sorted;

@@ -830,10 +830,22 @@ __global__ __launch_bounds__(kSortThreads) void k_last_column(BwtArgs a, u8 *__r
     if (start >= n) return;
     const u8 *text = a.rle + d.rle_off;
     const size_t base = (size_t)lb * kSlot;
-    for (u32 i = start + threadIdx.x; i < n && i < start + kSortTile; i += kSortThreads) {
-        const u32 s = ld_stream(a.SA + base + i);
-        if (s == 0) orig_ptr[lb] = i;
-        L[base + i] = text[s == 0 ? n - 1 : s - 1];
+    u32 sv[16];
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 i = start + r * kSortThreads + threadIdx.x;
+        sv[r] = ld_stream(a.SA + base + (i < n ? i : n - 1u));
+    }
+    u8 cv[16];
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) cv[r] = text[sv[r] == 0 ? n - 1 : sv[r] - 1];
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 i = start + r * kSortThreads + threadIdx.x;
+        if (i < n) {
+            if (sv[r] == 0) orig_ptr[lb] = i;
+            L[base + i] = cv[r];
+        }
     }
 }
 

@@ -322,8 +322,22 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
                     }
                 }
                 selector[g] = (u8)bt;
-                for (u32 i = 0; i < cnt; ++i)
-                    atomicAdd(&s_rfreq[bt][(my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu], 1u);
+                // The eight smallest symbols (RUNA, RUNB, ranks 1..6) are most of a BWT block: count
+                // them in registers and add once per group -- one LDS atomic per symbol otherwise
+                // serialises the whole workgroup on a handful of hot counters.
+                u32 c8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (u32 i = 0; i < cnt; ++i) {
+                    const u32 sy = (my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
+                    if (sy < 8u) {
+#pragma unroll
+                        for (u32 q = 0; q < 8; ++q) c8[q] += (sy == q) ? 1u : 0u;
+                    } else {
+                        atomicAdd(&s_rfreq[bt][sy], 1u);
+                    }
+                }
+#pragma unroll
+                for (u32 q = 0; q < 8; ++q)
+                    if (c8[q]) atomicAdd(&s_rfreq[bt][q], c8[q]);
             }
             __syncthreads();
         }
@@ -405,57 +419,165 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
     }
     const u32 payload_bits = s_run;
 
-    // block header, written by one lane (it is a few hundred to ~25k bits)
+    // ---- block header (a few hundred to ~25k bits) ----------------------------------------
+    // Fixed fields and the coding tables are written by one lane; the selector list (up to
+    // 18002 unary codes of MTF positions, encoder.rs:511-517,567-574) by all lanes: the MTF
+    // position over <= 6 table ids is the number of ids seen more recently, which needs only
+    // each id's last occurrence -- six max-scans over the workgroup.
     u32 *stream = a.stream + (size_t)lb * kStreamWords;
+    const u32 *ubits = a.inuse_bits + lb * 8;
+    u32 in_use16 = 0, used_ranges = 0;
+    for (u32 i = 0; i < 16; ++i) {
+        const u32 half = (ubits[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
+        in_use16 = (in_use16 << 1) | (half ? 1u : 0u);
+        used_ranges += half ? 1u : 0u;
+    }
+    const u32 sel_bit0 = 48u + 32u + 1u + 24u + 16u + 16u * used_ranges + 3u + 15u; // first selector bit
+
+    // every lane: its contiguous share of the selectors
+    const u32 seg = (n_selectors + kHuffThreads - 1) / kHuffThreads;
+    const u32 g_lo = tid * seg < n_selectors ? tid * seg : n_selectors;
+    const u32 g_hi = (g_lo + seg < n_selectors) ? g_lo + seg : n_selectors;
+    int last[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) last[t] = -1000000;
+    for (u32 g = g_lo; g < g_hi; ++g) {
+        const u32 v = selector[g];
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+            if ((u32)t == v) last[t] = (int)g;
+    }
+    // exclusive max-scan of each id's last occurrence over the lanes
+    int start_last[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int inc = wave_incl_max32(last[t]);
+        if (lane == 63) s_scan[wave] = (u32)inc;
+        __syncthreads();
+        int carry = -1000000;
+        for (u32 k = 0; k < wave; ++k) carry = (int)s_scan[k] > carry ? (int)s_scan[k] : carry;
+        const int prev = __shfl_up(inc, 1, 64);
+        int ex = (lane == 0) ? -1000000 : prev;
+        ex = ex > carry ? ex : carry;
+        // never seen yet: the initial list is 0,1,2,... (id t is behind t smaller ids)
+        start_last[t] = (ex < 0) ? -(t + 1) : ex;
+        __syncthreads();
+    }
+    // first replay: bits of this lane's unary codes
+    u32 my_bits = 0;
+    {
+        int cur[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) cur[t] = start_last[t];
+        for (u32 g = g_lo; g < g_hi; ++g) {
+            const u32 v = selector[g];
+            int lv = 0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                if ((u32)t == v) lv = cur[t];
+            u32 pos = 0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) pos += (cur[t] > lv) ? 1u : 0u;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                if ((u32)t == v) cur[t] = (int)g;
+            my_bits += pos + 1u;
+        }
+    }
+    u32 sel_off, sel_total;
+    {
+        const u32 inc = wave_incl_sum(my_bits);
+        if (lane == 63) s_scan[wave] = inc;
+        __syncthreads();
+        u32 carry = 0, tot = 0;
+        for (u32 k = 0; k < kHuffThreads / 64; ++k) {
+            if (k < wave) carry += s_scan[k];
+            tot += s_scan[k];
+        }
+        sel_off = carry + inc - my_bits;
+        sel_total = tot;
+        __syncthreads();
+    }
+    const u32 tab_bit0 = sel_bit0 + sel_total;
+    // table bits: 5 + sum over symbols of (2*|delta| + 1), one lane per table
+    if (lane == 0 && wave < group_num) {
+        const u8 *l = s_len[wave];
+        u32 nb = 5, curr = l[0];
+        for (u32 i = 0; i < alpha; ++i) {
+            const u32 li = l[i];
+            nb += 2u * (li > curr ? li - curr : curr - li) + 1u;
+            curr = li;
+        }
+        s_first[wave][0] = nb; // s_first[t][0] is unused by the code assignment
+    }
+    __syncthreads();
+    u32 tab_off[7];
+    tab_off[0] = tab_bit0;
+    for (u32 t = 0; t < 6; ++t) tab_off[t + 1] = tab_off[t] + (t < group_num ? s_first[t][0] : 0u);
+    const u32 hb = tab_off[group_num];
+    // zero the header words, then everybody ORs its bits in
+    for (u32 w = tid; w <= (hb >> 5); w += kHuffThreads) stream[w] = 0;
+    __syncthreads();
+    auto put = [&](u32 bitpos, u32 v, u32 nbits) { // nbits <= 32, MSB-first
+        const u32 w = bitpos >> 5, o = bitpos & 31u;
+        const unsigned long long x = (unsigned long long)v << (64u - o - nbits);
+        atomicOr(&stream[w], (u32)(x >> 32));
+        if ((u32)x) atomicOr(&stream[w + 1], (u32)x);
+    };
     if (tid == 0) {
-        BitSink bs{stream, 0ull, 0u, 0u};
-        bs.put(0x314159u, 24); // encoder.rs:254-259
-        bs.put(0x265359u, 24);
-        bs.put(a.crc[lb], 32); // :262
-        bs.put(0, 1);          // :273
-        bs.put(a.orig_ptr[lb], 24); // :333
-        // mapping table, :527-554
-        const u32 *bits = a.inuse_bits + lb * 8;
-        u32 in_use16 = 0;
+        put(0, 0x314159u, 24);  // encoder.rs:254-259
+        put(24, 0x265359u, 24);
+        put(48, a.crc[lb], 32); // :262, the randomised bit (:273) stays 0
+        put(81, a.orig_ptr[lb], 24); // :333
+        put(105, in_use16, 16); // mapping table, :527-554
+        u32 bp = 121;
         for (u32 i = 0; i < 16; ++i) {
-            const u32 half = (bits[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
-            in_use16 = (in_use16 << 1) | (half ? 1u : 0u);
-        }
-        bs.put(in_use16, 16);
-        for (u32 i = 0; i < 16; ++i) {
-            const u32 half = (bits[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
-            if (half) bs.put(__brev(half) >> 16, 16); // byte value 16i+j is bit j: emit j = 0 first
-        }
-        // selectors, :567-574 with the MTF of :511-517
-        bs.put(group_num, 3);
-        bs.put(n_selectors, 15);
-        {
-            u32 lst = 0x543210u; // 4 bits per entry, entry 0 in the low nibble
-            for (u32 g = 0; g < n_selectors; ++g) {
-                const u32 v = selector[g];
-                u32 pos = 0;
-                while (((lst >> (4 * pos)) & 15u) != v) ++pos;
-                if (pos) {
-                    const u32 lowmask = (1u << (4 * pos)) - 1u;
-                    lst = (lst & ~((lowmask << 4) | 15u)) | ((lst & lowmask) << 4) | v;
-                }
-                bs.put((1u << (pos + 1)) - 2u, pos + 1);
+            const u32 half = (ubits[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
+            if (half) {
+                put(bp, __brev(half) >> 16, 16); // byte value 16i+j is bit j: emit j = 0 first
+                bp += 16;
             }
         }
-        // coding tables, :583-601
-        for (u32 t = 0; t < group_num; ++t) {
-            const u8 *l = s_len[t];
-            u32 curr = l[0];
-            bs.put(curr, 5);
-            for (u32 i = 0; i < alpha; ++i) {
-                const u32 li = l[i];
-                while (curr < li) { bs.put(2, 2); curr += 1; }
-                while (curr > li) { bs.put(3, 2); curr -= 1; }
-                bs.put(0, 1);
-            }
+        put(bp, group_num, 3); // :569-570
+        put(bp + 3, n_selectors, 15);
+    }
+    {
+        // second replay: write the unary codes (1 << (pos+1)) - 2, pos+1 bits (:572-574)
+        int cur[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) cur[t] = start_last[t];
+        u32 bp = sel_bit0 + sel_off;
+        for (u32 g = g_lo; g < g_hi; ++g) {
+            const u32 v = selector[g];
+            int lv = 0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                if ((u32)t == v) lv = cur[t];
+            u32 pos = 0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) pos += (cur[t] > lv) ? 1u : 0u;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                if ((u32)t == v) cur[t] = (int)g;
+            put(bp, (1u << (pos + 1u)) - 2u, pos + 1u);
+            bp += pos + 1u;
         }
-        bs.finish();
-        const u32 hb = bs.bits();
+    }
+    // coding tables, :583-601: one lane per table
+    if (lane == 0 && wave < group_num) {
+        const u8 *l = s_len[wave];
+        u32 bp = tab_off[wave];
+        u32 curr = l[0];
+        put(bp, curr, 5);
+        bp += 5;
+        for (u32 i = 0; i < alpha; ++i) {
+            const u32 li = l[i];
+            while (curr < li) { put(bp, 2, 2); bp += 2; curr += 1; }
+            while (curr > li) { put(bp, 3, 2); bp += 2; curr -= 1; }
+            bp += 1; // the terminating 0 bit
+        }
+    }
+    if (tid == 0) {
         bo.header_bits = hb;
         bo.total_bits = (u64)hb + payload_bits;
         bo.group_num = group_num;
@@ -465,14 +587,11 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
         bo.crc = a.crc[lb];
         bo.orig_ptr = a.orig_ptr[lb];
         if ((u64)hb + payload_bits + 96u > (u64)kStreamWords * 32u) atomicExch(a.error_flag, 1u);
-        s_run = hb;
     }
-    __syncthreads();
-    // zero the words the payload kernel will OR into
+    // zero the words the payload kernel will OR into (the header's last, partial word stays)
     {
-        const u32 hb = s_run;
         const u64 tb = (u64)hb + payload_bits;
-        u32 w0 = (hb + 31u) >> 5;
+        u32 w0 = (hb >> 5) + 1u;
         u32 w1 = (u32)(tb >> 5) + 2u;
         if (w1 > kStreamWords) w1 = kStreamWords;
         for (u32 w = w0 + tid; w < w1; w += kHuffThreads) stream[w] = 0;

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_mtf_summaries(MtfArgs a)
     u8 *out = a.summ + ((size_t)lb * kMaxMtfChunks + chunk) * 256u;
     u32 cnt = 0;
     // walk backwards, 16 bytes at a time (chunk starts are 256-byte aligned)
-    for (int v = 15; v >= 0 && cnt < alpha; --v) {
+    for (int v = (int)(kMtfChunk / 16u) - 1; v >= 0 && cnt < alpha; --v) {
         const u32 p0 = beg + (u32)v * 16u;
         if (p0 >= end) continue;
         const uint4 q = *reinterpret_cast<const uint4 *>(L + p0);
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void k_mtf_ranks(MtfArgs a)
     u32 *list = s_list + threadIdx.x * 65u;
     const u8 *L = a.L + (size_t)lb * kSlot;
     u8 *R8 = a.rank8 + (size_t)lb * kSlot;
-    for (u32 v = 0; v < 16; ++v) {
+    for (u32 v = 0; v < kMtfChunk / 16u; ++v) {
         const u32 p0 = beg + v * 16u;
         if (p0 >= end) break;
         const uint4 q = *reinterpret_cast<const uint4 *>(L + p0);
