@@ -43,7 +43,8 @@ __device__ void down_heap(u32 *buf, u32 nn, u32 len)
 
 // cano_huff_table.rs:58-151 ("reverse package merge"), scratch in global memory.
 // freq = the weights (all non-zero), n symbols, out = lengths in symbol order.
-__device__ void gen_code_lm(const u32 *freq, u32 n, u32 *scr, u8 *out)
+// `row` = words per package-merge row (>= 2n+4); scratch needs 4*kMaxAlpha + 64 + 2*lim*row words.
+__device__ void gen_code_lm(const u32 *freq, u32 n, u32 *scr, u32 row, u8 *out)
 {
     const u32 lim = kLim;
     u32 *map = scr;                 // [n]
@@ -51,8 +52,8 @@ __device__ void gen_code_lm(const u32 *freq, u32 n, u32 *scr, u8 *out)
     u32 *c = sfreq + kMaxAlpha;     // [n]
     u32 *misc = c + kMaxAlpha;      // max_elem[17], b[17], cur[17]
     u32 *max_elem = misc, *b = misc + 20, *cur = misc + 40;
-    u32 *val = misc + 64 + kMaxAlpha; // [lim][kLmRow]
-    u32 *ty = val + lim * kLmRow;     // [lim][kLmRow]
+    u32 *val = misc + 64 + kMaxAlpha; // [lim][row]
+    u32 *ty = val + lim * row;        // [lim][row]
 
     // stable sort by weight, descending (:64-70): insertion sort keeps equal keys in order
     for (u32 i = 0; i < n; ++i) {
@@ -83,11 +84,11 @@ __device__ void gen_code_lm(const u32 *freq, u32 n, u32 *scr, u8 *out)
         if (max_elem[j] > 2 * max_elem[j - 1] + b[j]) max_elem[j] = 2 * max_elem[j - 1] + b[j];
 
     for (u32 j = 0; j < lim; ++j)       // :97-98 (zero initialised vectors)
-        for (u32 t = 0; t < max_elem[j]; ++t) { val[j * kLmRow + t] = 0; ty[j * kLmRow + t] = 0; }
+        for (u32 t = 0; t < max_elem[j]; ++t) { val[j * row + t] = 0; ty[j * row + t] = 0; }
     for (u32 i = 0; i < n; ++i) c[i] = lim; // :99
     for (u32 t = 0; t < n && t < max_elem[lim - 1]; ++t) { // :101-104
-        val[(lim - 1) * kLmRow + t] = sfreq[t];
-        ty[(lim - 1) * kLmRow + t] = t;
+        val[(lim - 1) * row + t] = sfreq[t];
+        ty[(lim - 1) * row + t] = t;
     }
     if (b[lim - 1] == 1) {              // :107-110
         c[0] -= 1;
@@ -99,15 +100,15 @@ __device__ void gen_code_lm(const u32 *freq, u32 n, u32 *scr, u8 *out)
         u32 next = cur[j];
         for (u32 t = 0; t < max_elem[j - 1]; ++t) {
             const u32 weight = (next + 1 < max_elem[j])
-                                   ? weight_add(val[j * kLmRow + next], val[j * kLmRow + next + 1])
+                                   ? weight_add(val[j * row + next], val[j * row + next + 1])
                                    : 0u;
             if (weight > sfreq[i]) {
-                val[(j - 1) * kLmRow + t] = weight;
-                ty[(j - 1) * kLmRow + t] = n;
+                val[(j - 1) * row + t] = weight;
+                ty[(j - 1) * row + t] = n;
                 next += 2;
             } else {
-                val[(j - 1) * kLmRow + t] = sfreq[i];
-                ty[(j - 1) * kLmRow + t] = i;
+                val[(j - 1) * row + t] = sfreq[i];
+                ty[(j - 1) * row + t] = i;
                 i += 1;
                 if (i >= n) break;
             }
@@ -123,7 +124,7 @@ __device__ void gen_code_lm(const u32 *freq, u32 n, u32 *scr, u8 *out)
             while (sp >= 0) {
                 const u32 li = lvl[sp];
                 if (ph[sp] == 0) {
-                    const u32 x = ty[li * kLmRow + cur[li]];
+                    const u32 x = ty[li * row + cur[li]];
                     if (x == n) {
                         ph[sp] = 1;
                         ++sp;
@@ -152,7 +153,7 @@ __device__ void gen_code_lm(const u32 *freq, u32 n, u32 *scr, u8 *out)
 // cano_huff_table.rs:153-196 gen_code on the bzip2 weights (encoder.rs:641-651).
 // rfreq: symbol counts of this table; buf: 2*alpha words of LDS; returns 1 if the
 // length-limited path was taken.
-__device__ int make_code_lengths(const u32 *rfreq, u32 alpha, u32 *buf, u8 *out, u32 *lm_scr)
+__device__ int heap_code_lengths(const u32 *rfreq, u32 alpha, u32 *buf, u8 *out)
 {
     const u32 n = alpha;
     if (n == 1) { // cannot happen on this path (alpha >= 3), kept for the probe entry
@@ -185,16 +186,18 @@ __device__ int make_code_lengths(const u32 *rfreq, u32 alpha, u32 *buf, u8 *out,
         out[i] = (u8)l;
         if (l > kLim) too_long = 1;
     }
-    if (too_long) { // :190-194: redo from the weights
-        u32 *w = lm_scr + kLmWords - kMaxAlpha; // tail of the scratch holds the weights
-        for (u32 i = 0; i < n; ++i) {
-            const u32 f = rfreq[i];
-            w[i] = (f > 1u ? f : 1u) << 8;
-        }
-        gen_code_lm(w, n, lm_scr, out);
-        return 1;
+    return too_long; // 1: the caller must redo the table with gen_code_lm (:190-194)
+}
+
+// length-limited redo from the weights; scr/row as for gen_code_lm, the weights go to scr's tail
+__device__ void lm_code_lengths(const u32 *rfreq, u32 n, u32 *scr, u32 scr_words, u32 row, u8 *out)
+{
+    u32 *w = scr + scr_words - kMaxAlpha;
+    for (u32 i = 0; i < n; ++i) {
+        const u32 f = rfreq[i];
+        w[i] = (f > 1u ? f : 1u) << 8;
     }
-    return 0;
+    gen_code_lm(w, n, scr, row, out);
 }
 
 // MSB-first bit sink writing logical 32-bit words (single lane)
@@ -241,6 +244,7 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
     __shared__ unsigned long long s_pack[kMaxAlpha]; // 6 x 10-bit lengths per symbol
     __shared__ u32 s_buf[6][2 * kMaxAlpha + 4];
     __shared__ u32 s_lm[6];
+    __shared__ u32 s_need[6];
     __shared__ u32 s_scan[kHuffThreads / 64];
     __shared__ u32 s_run;
     __shared__ u32 s_first[6][24], s_lcount[6][24];
@@ -343,12 +347,42 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
         }
         __syncthreads();
         // one lane per table replays the serial heap procedure
-        if (lane == 0 && wave < group_num) {
-            const int lm = make_code_lengths(s_rfreq[wave], alpha, s_buf[wave], s_len[wave],
-                                             a.lm_scratch + ((size_t)lb * 6 + wave) * kLmWords);
-            if (lm) s_lm[wave] += 1;
-        }
+        if (lane == 0 && wave < group_num)
+            s_need[wave] = (u32)heap_code_lengths(s_rfreq[wave], alpha, s_buf[wave], s_len[wave]);
         __syncthreads();
+        // Tables whose longest code exceeds 17 bits are redone by the package-merge procedure
+        // (one lane each).  Its scratch is carved out of the symbol staging area (idle here):
+        // as many tables at a time as fit; global memory (8x the latency per step) only when the
+        // alphabet is too large for even one.
+        {
+            const u32 row = 2u * alpha + 4u;
+            const u32 need = 5u * kMaxAlpha + 64u + 2u * kLim * row;
+            const u32 slots = (kHuffThreads * kGSize / 2) / need;
+            u32 my_rank = 0, any = 0;
+            for (u32 t = 0; t < group_num; ++t) {
+                if (t < wave) my_rank += s_need[t] ? 1u : 0u;
+                any += s_need[t] ? 1u : 0u;
+            }
+            if (any) { // uniform
+                const u32 rounds_lm = slots ? (any + slots - 1) / slots : 1u;
+                for (u32 rd = 0; rd < rounds_lm; ++rd) {
+                    if (lane == 0 && wave < group_num && s_need[wave]) {
+                        if (slots == 0) {
+                            if (rd == 0) {
+                                lm_code_lengths(s_rfreq[wave], alpha, a.lm_scratch + ((size_t)lb * 6 + wave) * kLmWords,
+                                                kLmWords, kLmRow, s_len[wave]);
+                                s_lm[wave] += 1;
+                            }
+                        } else if (my_rank / slots == rd) {
+                            lm_code_lengths(s_rfreq[wave], alpha, s_sym + (my_rank % slots) * need, need, row,
+                                            s_len[wave]);
+                            s_lm[wave] += 1;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
     }
 
     // canonical codes, src/huffman/mod.rs:22-67 (stable by length, then symbol)
@@ -661,7 +695,9 @@ __global__ void k_probe_code_lengths(const u32 *freq, u32 alpha, u8 *out, u32 *l
     __shared__ u8 s_o[kMaxAlpha + 6];
     if (threadIdx.x == 0) {
         for (u32 i = 0; i < alpha; ++i) s_f[i] = freq[i];
-        *lm_flag = make_code_lengths(s_f, alpha, s_buf, s_o, lm_scr);
+        const int lm = heap_code_lengths(s_f, alpha, s_buf, s_o);
+        if (lm) lm_code_lengths(s_f, alpha, lm_scr, kLmWords, kLmRow, s_o);
+        *lm_flag = lm;
         for (u32 i = 0; i < alpha; ++i) out[i] = s_o[i];
     }
 }
