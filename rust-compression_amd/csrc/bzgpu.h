@@ -172,6 +172,8 @@ struct RleBuffers {
     i64 *carry_in;    // [ntiles] last run start before the tile
     u32 *tile_crc;    // [ntiles] raw CRC of the tile's bytes
     u32 *tile_count;  // [ntiles] RLE1 bytes the tile emits
+    u16 *sub_off;     // [ntiles][16] bytes emitted before each 256-byte sub-tile, inside its tile
+    i64 *sub_rs;      // [ntiles][16] run start live at each sub-tile's first byte
     u64 *tile_off;    // [ntiles+1] exclusive sum of tile_count
     u64 *total;       // [1]
     u64 *cut_result;  // [3] number of blocks, input bytes consumed, tail-block flag

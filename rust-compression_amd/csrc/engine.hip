@@ -62,7 +62,7 @@ struct bz_gpu_engine {
     // constant tables
     DevBuf crc_tab, xp16, xp2;
     // partition state (sized by the input)
-    DevBuf tile_last, carry_in, tile_crc, tile_count, tile_off, scal, rle, blocks_all, crc_all;
+    DevBuf tile_last, carry_in, tile_crc, tile_count, tile_off, sub_off, sub_rs, scal, rle, blocks_all, crc_all;
     std::vector<BlockDesc> h_blocks;
     std::vector<u32> h_crc;
     const u8 *d_in = nullptr;
@@ -237,7 +237,7 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
     (void)hipStreamSynchronize(g->st);
     (void)hipStreamSynchronize(g->st2);
     DevBuf *all[] = {&g->crc_tab, &g->xp16, &g->xp2, &g->tile_last, &g->carry_in, &g->tile_crc, &g->tile_count,
-                     &g->tile_off, &g->scal, &g->rle, &g->blocks_all, &g->crc_all, &g->lblocks, &g->lcrc, &g->SA,
+                     &g->tile_off, &g->sub_off, &g->sub_rs, &g->scal, &g->rle, &g->blocks_all, &g->crc_all, &g->lblocks, &g->lcrc, &g->SA,
                      &g->R, &g->KA, &g->VA, &g->KB, &g->VB, &g->tile_hist, &g->count, &g->flags, &g->tlo, &g->tln,
                      &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->bin_base, &g->sym_code, &g->keyinfo, &g->count2, &g->tile_nf, &g->L, &g->orig_ptr, &g->inuse_bits,
                      &g->summ, &g->summ_len, &g->init_state, &g->rank8, &g->ztile_last, &g->ztile_cnt, &g->mtf,
@@ -275,7 +275,8 @@ extern "C" int bz_gpu_partition(bz_gpu_engine *g, int level, const void *d_in, s
     int rc;
     if ((rc = g->tile_last.ensure(ntiles * 8)) || (rc = g->carry_in.ensure(ntiles * 8)) ||
         (rc = g->tile_crc.ensure(ntiles * 4)) || (rc = g->tile_count.ensure(ntiles * 4)) ||
-        (rc = g->tile_off.ensure((ntiles + 1) * 8)) || (rc = g->scal.ensure(64)) ||
+        (rc = g->tile_off.ensure((ntiles + 1) * 8)) || (rc = g->sub_off.ensure(ntiles * 32)) ||
+        (rc = g->sub_rs.ensure(ntiles * 128)) || (rc = g->scal.ensure(64)) ||
         (rc = g->rle.ensure(n + n / 4 + 256)) || (rc = g->blocks_all.ensure(max_blocks * sizeof(BlockDesc))) ||
         (rc = g->crc_all.ensure(max_blocks * 4)))
         return rc;
@@ -285,6 +286,8 @@ extern "C" int bz_gpu_partition(bz_gpu_engine *g, int level, const void *d_in, s
     rb.tile_crc = g->tile_crc.as<u32>();
     rb.tile_count = g->tile_count.as<u32>();
     rb.tile_off = g->tile_off.as<u64>();
+    rb.sub_off = g->sub_off.as<u16>();
+    rb.sub_rs = g->sub_rs.as<i64>();
     rb.total = g->scal.as<u64>();
     rb.cut_result = g->scal.as<u64>() + 2;
     const int emit_tail = (mode == BZ_ACTION_RUN) ? 0 : 1;

@@ -247,9 +247,12 @@ __device__ __forceinline__ i64 seg_run_start(const Seg &s, i64 tile_carry, i64 *
 }
 
 // ---- kernel C: bytes emitted per tile -------------------------------------------
+// Also records, for each 256-byte sub-tile, the bytes emitted before it inside its tile and the run
+// start live at its first byte -- the cut chain uses them to look at 2 KiB instead of whole tiles.
 __global__ __launch_bounds__(RT) void k_rle_count(const u8 *__restrict__ in, u64 n,
                                                    const i64 *__restrict__ carry_in,
-                                                   u32 *__restrict__ tile_count)
+                                                   u32 *__restrict__ tile_count, u16 *__restrict__ sub_off,
+                                                   i64 *__restrict__ sub_rs)
 {
     __shared__ i64 s_m[RT / 64 + 1];
     __shared__ u32 s_s[RT / 64];
@@ -260,8 +263,12 @@ __global__ __launch_bounds__(RT) void k_rle_count(const u8 *__restrict__ in, u64
     u8 e[16], cph[16];
     const u32 cnt = eval_seg(s, rs, e, cph);
     u32 tot;
-    (void)block_excl_sum(cnt, s_s, tot);
+    const u32 ex = block_excl_sum(cnt, s_s, tot);
     if (threadIdx.x == 0) tile_count[tile] = tot;
+    if ((threadIdx.x & 15u) == 0) {
+        sub_off[tile * 16u + (threadIdx.x >> 4)] = (u16)ex;
+        sub_rs[tile * 16u + (threadIdx.x >> 4)] = rs;
+    }
 }
 
 // ---- kernel D: exclusive sum over tiles (one workgroup), u64 offsets -------------
@@ -324,110 +331,252 @@ __global__ __launch_bounds__(RT) void k_rle_scatter(const u8 *__restrict__ in, u
     for (u32 i = threadIdx.x; i < tot; i += RT) dst[i] = s_out[i];
 }
 
-// ---- kernel F: the serial chain of block cuts (one workgroup) --------------------
+// ---- kernel F: the chain of block cuts (one workgroup) -------------------------------------
+// A cut depends on the previous one, but only weakly: a block holds between L and L+4 bytes
+// (L = 100000*level-19; the last chunk adds at most 5), so the k-th next block starts inside
+// [s + kL, s + k(L+4)].  Each of the CW waves therefore works on one FUTURE cut speculatively: it
+// finds the 256-byte sub-tile holding its earliest possible target, evaluates RLE1 over a window
+// from there into LDS, and lane i resolves the cut for the candidate target T+i.  The real chain
+// is then CW table lookups.  One round costs the latency of ~4 dependent global loads instead of
+// CW x that.  Windows are 2 KiB; data with long runs (63 output bytes can span 3.2 KB of input)
+// falls back to 12 KiB windows for the round that needs it.
 // Emits BlockDesc records.  emit_tail: also emit the remaining partial block.
-__global__ __launch_bounds__(RT) void k_rle_cuts(const u8 *__restrict__ in, u64 n,
-                                                  const i64 *__restrict__ carry_in,
+constexpr u32 CW = 16;                               // speculative cuts per round (waves)
+constexpr u32 CT = CW * 64;                          // threads
+constexpr u32 CSW_SMALL = 2, CSW_BIG = 12;           // sweeps of 64 segments (1 KiB) per window
+constexpr u32 CSEG = CSW_BIG * 64;                   // LDS slots per wave
+constexpr u64 CUT_END = ~0ull, CUT_OUT = ~0ull - 1;
+
+__global__ __launch_bounds__(CT) void k_rle_cuts(const u8 *__restrict__ in, u64 n,
+                                                  const u16 *__restrict__ sub_off,
+                                                  const i64 *__restrict__ sub_rs,
                                                   const u64 *__restrict__ tile_off, u64 ntiles,
                                                   u32 block_max_len, int emit_tail,
                                                   BlockDesc *__restrict__ blocks, u32 max_blocks,
                                                   u64 *__restrict__ out_nblocks_consumed /*[3]*/)
 {
-    __shared__ i64 s_m[RT / 64 + 1];
-    __shared__ u32 s_s[RT / 64];
-    __shared__ u64 s_tile;
-    __shared__ u32 s_w[RT / 64];
-    __shared__ u64 s_cut_rle, s_cut_in;
-    __shared__ int s_found;
+    __shared__ u16 s_pre[CW][CSEG];    // inclusive count of emitted bytes, per segment, from the window start
+    __shared__ u32 s_eb[CW][CSEG];     // 2 bits per position: bytes it emits
+    __shared__ u16 s_ce[CW][CSEG];     // chunk-end mask
+    __shared__ u64 s_res_rle[CW][64], s_res_in[CW][64];
+    __shared__ u64 s_tlo[CW];
 
+    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const u64 L = block_max_len;
     const u64 M = tile_off[ntiles];
     u64 s_rle = 0, s_in = 0;
-    u64 cur_tile = 0; // tile of the previous cut: tile_off[cur_tile] < every later target
+    u64 cur_tile = 0; // tile_off[cur_tile] < every later target
     u32 nb = 0;
+    bool broken = false;
+    u32 nsw = CSW_SMALL; // sweeps per window in this round
 
-    while (true) {
-        const u64 target = s_rle + block_max_len;
-        if (M < target || M == s_rle) break; // no chunk end reaches the limit any more
-        // tile holding the first position whose inclusive prefix >= target: the largest t with
-        // tile_off[t] < target.  Blocks are ~220 tiles apart on text, so probe windows of 256
-        // tiles forward from the previous cut (all lanes at once) instead of a dependent
-        // binary search; tile_off[ntiles] = M >= target bounds the walk.
-        {
-            u64 base_t = cur_tile;
-            while (true) {
-                const u64 t = base_t + threadIdx.x + 1; // candidate for "first t with off[t] >= target"
-                const bool hit = (t <= ntiles) && (tile_off[t] >= target);
-                const u64 bal = __ballot(hit);
-                if (lane_id() == 0) s_w[threadIdx.x >> 6] = bal ? (u32)(threadIdx.x + (u32)__builtin_ctzll(bal)) : 0xFFFFFFFFu;
-                __syncthreads();
-                u32 firsthit = 0xFFFFFFFFu;
-                for (u32 k = 0; k < RT / 64; ++k) firsthit = s_w[k] < firsthit ? s_w[k] : firsthit;
-                __syncthreads();
-                if (firsthit != 0xFFFFFFFFu) {
-                    cur_tile = base_t + firsthit; // = (first t with off[t] >= target) - 1
+    while (!broken) {
+        if (M < s_rle + L || M == s_rle) break; // no chunk end reaches the limit any more
+        // ---- phase 1: this wave's window ------------------------------------------------
+        const u64 T_lo = s_rle + (u64)(w + 1) * L; // smallest possible target of step w
+        const bool alive = T_lo <= M;
+        u64 t_lo = cur_tile;
+        u64 in0 = 0, base_off = 0;
+        i64 rs_carry = -1;
+        if (alive) {
+            // largest t with tile_off[t] < T_lo, galloping from cur_tile (tile_off[ntiles] = M >= T_lo)
+            u64 base = cur_tile;
+            while (true) { // coarse: 64 probes, 64 tiles apart
+                u64 t = base + (u64)(l + 1) * 64u;
+                if (t > ntiles) t = ntiles;
+                const u64 bal = __ballot(tile_off[t] >= T_lo);
+                if (bal) {
+                    base += (u64)__builtin_ctzll(bal) * 64u;
                     break;
                 }
-                base_t += RT;
+                base += 64u * 64u;
             }
-            if (threadIdx.x == 0) {
-                s_tile = cur_tile;
-                s_found = 0;
+            {
+                u64 t = base + (u64)(l + 1);
+                if (t > ntiles) t = ntiles;
+                const u64 bal = __ballot(tile_off[t] >= T_lo); // lane 63 always hits
+                t_lo = base + (u64)__builtin_ctzll(bal);
+            }
+            // sub-tile: the last of the 16 whose start offset is still below T_lo
+            const u64 toff = tile_off[t_lo];
+            const u32 so = sub_off[t_lo * 16u + (l & 15u)];
+            const u64 bal = __ballot((l < 16u) && (toff + so < T_lo)); // bit 0 always set
+            const u32 u = 63u - (u32)__builtin_clzll(bal);
+            in0 = t_lo * (u64)kRleTile + (u64)u * 256u;
+            base_off = toff + (u64)__shfl(so, (int)u, 64);
+            rs_carry = sub_rs[t_lo * 16u + u];
+        }
+        // ---- phase 2: RLE1 over the window, 64 consecutive segments (1 KiB) per sweep ----------------
+        if (alive) {
+            u32 off_carry = 0;
+            int prev_carry = (in0 > 0) ? (int)in[in0 - 1] : -1;
+            uint4 cur;
+            u32 cur_valid;
+            {
+                const u64 p0 = in0 + (u64)l * 16u;
+                if (p0 + 16 <= n) {
+                    cur = *reinterpret_cast<const uint4 *>(in + p0);
+                    cur_valid = 16;
+                } else {
+                    u32 t[4] = {0, 0, 0, 0};
+                    cur_valid = p0 < n ? (u32)(n - p0) : 0u;
+                    for (u32 k = 0; k < cur_valid; ++k) t[k >> 2] |= (u32)in[p0 + k] << ((k & 3u) * 8u);
+                    cur = make_uint4(t[0], t[1], t[2], t[3]);
+                }
+            }
+            for (u32 q = 0; q < nsw; ++q) {
+                // prefetch the next sweep while this one is evaluated
+                uint4 nxt = make_uint4(0, 0, 0, 0);
+                u32 nxt_valid = 0;
+                {
+                    const u64 p0 = in0 + (u64)((q + 1) * 64u + l) * 16u;
+                    if (p0 + 16 <= n) {
+                        nxt = *reinterpret_cast<const uint4 *>(in + p0);
+                        nxt_valid = 16;
+                    } else {
+                        u32 t[4] = {0, 0, 0, 0};
+                        nxt_valid = p0 < n ? (u32)(n - p0) : 0u;
+                        for (u32 k = 0; k < nxt_valid; ++k) t[k >> 2] |= (u32)in[p0 + k] << ((k & 3u) * 8u);
+                        nxt = make_uint4(t[0], t[1], t[2], t[3]);
+                    }
+                }
+                Seg sg;
+                sg.p0 = in0 + (u64)(q * 64u + l) * 16u;
+                sg.valid = cur_valid;
+                const u32 wv[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sg.b[k] = (u8)(wv[k >> 2] >> ((k & 3) * 8));
+                // neighbours' bytes by shuffle: previous segment's last byte, next segment's first
+                const int lastb = sg.valid ? (int)sg.b[(sg.valid - 1) & 15] : -1;
+                const int firstb = sg.valid ? (int)sg.b[0] : -1;
+                int pv = __shfl_up(lastb, 1, 64);
+                if (l == 0) pv = prev_carry;
+                int nx = __shfl_down(firstb, 1, 64);
+                const u32 nfw = __shfl(nxt.x, 0, 64), nfv = __shfl(nxt_valid, 0, 64);
+                if (l == 63) nx = nfv ? (int)(nfw & 0xFFu) : -1;
+                sg.prev = sg.valid ? pv : -1;
+                sg.next = (sg.valid == 16) ? nx : -1; // a short segment ends the input
+                i64 last = -1;
+                int pb = sg.prev;
+#pragma unroll
+                for (u32 k = 0; k < 16; ++k) {
+                    if (k < sg.valid) {
+                        if ((int)sg.b[k] != pb) last = (i64)(sg.p0 + k);
+                        pb = sg.b[k];
+                    }
+                }
+                const i64 inc = wave_incl_max64(last);
+                const i64 prv = __shfl_up(inc, 1, 64);
+                i64 rs = (l == 0) ? (i64)-1 : prv;
+                rs = rs > rs_carry ? rs : rs_carry;
+                u8 e[16], cph[16];
+                const u32 c = eval_seg(sg, rs, e, cph);
+                u32 eb = 0, ce = 0;
+#pragma unroll
+                for (u32 k = 0; k < 16; ++k) {
+                    if (k < sg.valid) {
+                        const int nbyte = (k + 1 < sg.valid) ? (int)sg.b[k + 1 < 16 ? k + 1 : 15] : sg.next;
+                        if (nbyte != (int)sg.b[k] || cph[k] == 254u) ce |= 1u << k;
+                        eb |= (u32)e[k] << (2u * k);
+                    }
+                }
+                const u32 incs = wave_incl_sum(c);
+                s_pre[w][q * 64u + l] = (u16)(off_carry + incs);
+                s_eb[w][q * 64u + l] = eb;
+                s_ce[w][q * 64u + l] = (u16)ce;
+                const i64 winc = __shfl(inc, 63, 64);
+                rs_carry = winc > rs_carry ? winc : rs_carry;
+                off_carry += __shfl(incs, 63, 64);
+                prev_carry = __shfl(lastb, 63, 64);
+                cur = nxt;
+                cur_valid = nxt_valid;
             }
         }
         __syncthreads();
-        const u64 tile = s_tile;
-        Seg s;
-        load_seg(in, n, tile, s);
-        const i64 rs = seg_run_start(s, carry_in[tile], s_m);
-        u8 e[16], cph[16];
-        const u32 cnt = eval_seg(s, rs, e, cph);
-        u32 tot;
-        const u32 ex = block_excl_sum(cnt, s_s, tot);
-        const u64 base = tile_off[tile] + ex;
-        if (base < target && base + cnt >= target) {
-            // this thread holds p0*: walk to it, then on to the end of its chunk
-            u64 acc = base;
-            u32 k = 0;
-            for (; k < 16; ++k) {
-                acc += e[k];
-                if (acc >= target) break;
+        // ---- phase 2b: lane i resolves the cut for target T_lo + i -----------------------------
+        {
+            const u32 nseg = nsw * 64u;
+            u64 r_rle = CUT_OUT, r_in = 0;
+            const u64 tgt = T_lo + l;
+            if (!alive || tgt > M) {
+                r_rle = CUT_END;
+            } else if (tgt - base_off <= (u64)s_pre[w][nseg - 1]) {
+                const u32 rel = (u32)(tgt - base_off);
+                u32 lo = 0, hi = nseg - 1;
+                while (lo < hi) {
+                    const u32 mid = (lo + hi) >> 1;
+                    if ((u32)s_pre[w][mid] >= rel) hi = mid; else lo = mid + 1;
+                }
+                u32 seg = lo, k = 0;
+                u32 acc = seg ? (u32)s_pre[w][seg - 1] : 0u;
+                u32 eb = s_eb[w][seg];
+                for (; k < 16; ++k) {
+                    acc += (eb >> (2u * k)) & 3u;
+                    if (acc >= rel) break;
+                }
+                // on to the end of the chunk
+                bool ok = true;
+                while (!((s_ce[w][seg] >> k) & 1u)) {
+                    if (++k == 16u) {
+                        k = 0;
+                        if (++seg == nseg) {
+                            ok = false;
+                            break;
+                        }
+                        eb = s_eb[w][seg];
+                    }
+                    acc += (eb >> (2u * k)) & 3u;
+                }
+                if (ok) {
+                    r_rle = base_off + acc;
+                    r_in = in0 + (u64)seg * 16u + k + 1u;
+                }
             }
-            u64 p = s.p0 + k;
-            u32 c = cph[k];
-            // advance to the chunk end (at most 254 steps)
-            while (true) {
-                const bool last = (p + 1 >= n);
-                const bool chunk_end = last || in[p + 1] != in[p] || c == 254u;
-                if (chunk_end) break;
-                ++p;
-                ++c;
-                acc += (c < 4u ? 1u : 0u);
-                const bool end2 = (p + 1 >= n) || in[p + 1] != in[p] || c == 254u;
-                if (end2 && c >= 3u) acc += 1u;
-            }
-            s_cut_rle = acc;
-            s_cut_in = p + 1;
-            s_found = 1;
+            s_res_rle[w][l] = r_rle;
+            s_res_in[w][l] = r_in;
+            if (l == 0) s_tlo[w] = t_lo;
         }
         __syncthreads();
-        if (!s_found) break; // cannot happen; guards against an endless loop
-        const u64 cut_rle = s_cut_rle, cut_in = s_cut_in;
-        if (threadIdx.x == 0 && nb < max_blocks) {
-            BlockDesc d;
-            d.rle_off = s_rle;
-            d.in_off = s_in;
-            d.in_end = cut_in;
-            d.n = (u32)(cut_rle - s_rle);
-            d.pad = 0;
-            blocks[nb] = d;
+        // ---- phase 3: the real chain, CW table lookups (every thread does the same) ---------------
+        const u64 round_s = s_rle;
+        bool need_big = false;
+        for (u32 q = 0; q < CW; ++q) {
+            const u64 target = s_rle + L;
+            if (M < target || M == s_rle) break;
+            const u64 idx = target - (round_s + (u64)(q + 1) * L);
+            if (idx > 63) { // cannot happen for q <= 15 (jitter <= 4 per step); stop the round
+                if (q == 0) broken = true;
+                break;
+            }
+            const u64 r = s_res_rle[q][idx];
+            if (r == CUT_END) break;
+            if (r == CUT_OUT) {
+                if (q == 0) {
+                    if (nsw == CSW_BIG) broken = true; // 12 KiB always hold step 0
+                    need_big = true;
+                }
+                break;
+            }
+            const u64 cut_in = s_res_in[q][idx];
+            if (threadIdx.x == 0 && nb < max_blocks) {
+                BlockDesc d;
+                d.rle_off = s_rle;
+                d.in_off = s_in;
+                d.in_end = cut_in;
+                d.n = (u32)(r - s_rle);
+                d.pad = 0;
+                blocks[nb] = d;
+            }
+            ++nb;
+            s_rle = r;
+            s_in = cut_in;
+            cur_tile = s_tlo[q];
         }
-        ++nb;
-        s_rle = cut_rle;
-        s_in = cut_in;
+        nsw = need_big ? CSW_BIG : CSW_SMALL;
         __syncthreads();
     }
     u32 tail = 0;
-    if (emit_tail && M > s_rle) {
+    if (emit_tail && M > s_rle && !broken) {
         tail = 1;
         if (threadIdx.x == 0 && nb < max_blocks) {
             BlockDesc d;
@@ -442,7 +591,7 @@ __global__ __launch_bounds__(RT) void k_rle_cuts(const u8 *__restrict__ in, u64 
         s_in = n;
     }
     if (threadIdx.x == 0) {
-        out_nblocks_consumed[0] = nb;
+        out_nblocks_consumed[0] = broken ? ~0ull : nb;
         out_nblocks_consumed[1] = s_in;
         out_nblocks_consumed[2] = tail; // 1: the last block is the unfinished tail, not one closed by a cut
     }
@@ -538,12 +687,13 @@ void launch_rle1(hipStream_t st, const u8 *d_in, u64 n, const u32 *crc_tab, cons
     hipLaunchKernelGGL(k_rle_tile_scan, dim3((u32)ntiles), dim3(RT), 0, st, d_in, n, crc_tab, xp16,
                        rb.tile_last, rb.tile_crc);
     hipLaunchKernelGGL(k_rle_scan_tiles_max, dim3(1), dim3(1024), 0, st, rb.tile_last, rb.carry_in, ntiles);
-    hipLaunchKernelGGL(k_rle_count, dim3((u32)ntiles), dim3(RT), 0, st, d_in, n, rb.carry_in, rb.tile_count);
+    hipLaunchKernelGGL(k_rle_count, dim3((u32)ntiles), dim3(RT), 0, st, d_in, n, rb.carry_in, rb.tile_count,
+                       rb.sub_off, rb.sub_rs);
     hipLaunchKernelGGL(k_rle_scan_tiles_sum, dim3(1), dim3(1024), 0, st, rb.tile_count, rb.tile_off, ntiles,
                        rb.total);
     hipLaunchKernelGGL(k_rle_scatter, dim3((u32)ntiles), dim3(RT), 0, st, d_in, n, rb.carry_in, rb.tile_off,
                        d_rle);
-    hipLaunchKernelGGL(k_rle_cuts, dim3(1), dim3(RT), 0, st, d_in, n, rb.carry_in, rb.tile_off, ntiles,
+    hipLaunchKernelGGL(k_rle_cuts, dim3(1), dim3(CT), 0, st, d_in, n, rb.sub_off, rb.sub_rs, rb.tile_off, ntiles,
                        block_max_len, emit_tail, d_blocks, max_blocks, rb.cut_result);
 }
 
