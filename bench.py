@@ -4,9 +4,11 @@
 A "step" is one pass of the whole hot path (RLE1+split+CRC -> BWT -> MTF/ZLE -> Huffman -> bit
 emission -> stream assembly) over the synthetic corpus, input and output resident in HBM.
 N = 1: BASELINE.json configs[1] (1 GiB repeating text, level 9, one MI355X).
-N > 1: configs[2] scaled weakly (1 GiB per GPU): every rank holds the corpus, splits it into
-blocks (cheap, deterministic), encodes blocks rank, rank+N, ..., and the block bit strings are
-gathered to rank 0 over RCCL (torch.distributed "nccl"), which assembles the serial stream.
+N > 1: configs[2] scaled weakly (1 GiB per GPU): every rank holds the corpus but works on its own
+slab of it (rust-compression_amd/sharded.py: the RLE1 split is sharded by input tiles, the cut
+chain is an 8-byte hand-off from rank to rank), encodes the blocks that end in its slab, and the
+block bit strings are gathered to rank 0 over RCCL (torch.distributed "nccl"), which assembles the
+serial stream.
 
 Prints ONE JSON line on rank 0.  Launch for N > 1:
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -85,9 +87,9 @@ def main():
         d_all = torch.empty((world, cap_words), dtype=torch.int32, device=dev) if rank == 0 else None
 
     def step_multi():
-        nb, _, _ = eng.partition(args.level, d_in.data_ptr(), n, pkg.Action.FINISH)
-        woff, blen, crc, used = eng.encode_blocks(rank, world, nb, d_packed.data_ptr(), cap_words)
-        res = sharded.exchange(woff, blen, crc, d_packed, used, nb, rank, world, dev, d_all)
+        nb = sharded.partition(eng, args.level, d_in.data_ptr(), n, rank, world, dev)
+        woff, blen, crc, used = eng.encode_blocks(0, 1, nb, d_packed.data_ptr(), cap_words)
+        res = sharded.exchange(woff, blen, crc, d_packed, used, rank, world, dev, d_all)
         if rank == 0:
             buf, w_off, b_len, crcs = res
             out_len, _, _, _ = eng.assemble(args.level, buf.data_ptr(), w_off, b_len, crcs, d_out.data_ptr(), cap)
@@ -155,7 +157,7 @@ def main():
             "config": {"workload": ("%d MiB synthetic repeating-text corpus (16 MiB Zipf chapters), level %d, "
                                     "%d KB blocks" % (n >> 20, args.level, args.level * 100)) if args.corpus == "text"
                        else "%d MiB stress T2 (4 KiB paragraph repeated)" % (n >> 20),
-                       "blocks": len(out) and (n // (args.level * 100000 - 19)) + 1, "parallelism": "blocks round-robin x%d" % world,
+                       "blocks": len(out) and (n // (args.level * 100000 - 19)) + 1, "parallelism": "input slabs x%d, blocks in stream order, RCCL gather to rank 0" % world,
                        "out_bytes": out_len, "ratio": round(out_len / n, 4)},
             "roofline": roofline,
             "pipeline_algorithmic_GBps_per_gpu": round(pipeline_bytes * args.steps / dt / 1e9 / world, 2),

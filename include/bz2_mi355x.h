@@ -133,6 +133,26 @@ int bz_gpu_encode_device(bz_gpu_engine *g, int level, const void *d_in, size_t n
 int bz_gpu_partition(bz_gpu_engine *g, int level, const void *d_in, size_t n, int mode,
                      size_t *n_blocks, size_t *consumed, int *tail_block);
 
+/* (a') The same split sharded over ranks by SLABS of 4 KiB input tiles (rank r owns tiles
+ * [tile0, tile1); every rank sees the whole input d_in[n] but touches only its slab plus the tail
+ * of the block that straddles its left edge).  Three steps with two tiny exchanges in between:
+ *   _slab_begin  run starts + tile CRCs of the slab; *slab_last_start = last run start inside it
+ *                (-1: none).              [exchange: all-gather of that one value]
+ *   _slab_count  carry_run = the last run start BEFORE the slab (max over lower ranks, -1: none);
+ *                RLE1 byte counts of the slab.
+ *   _slab_finish start_in = first input byte of this rank's first block (rank 0: 0; else the
+ *                next_in handed over by rank-1: a serial chain of one 8-byte message per rank);
+ *                is_last: the last rank also emits the unfinished tail block.  Produces this rank's
+ *                blocks (stream order = rank order) for bz_gpu_encode_blocks(g, 0, 1, ...).
+ * RLE1 restarted at a block cut equals RLE1 continued (a cut is a chunk start, encoder.rs:689-693),
+ * so a rank codes its first block afresh from the cut it is handed.
+ * bz_gpu_partition == these three calls over all tiles. */
+int bz_gpu_partition_slab_begin(bz_gpu_engine *g, int level, const void *d_in, size_t n,
+                                uint64_t tile0, uint64_t tile1, int64_t *slab_last_start);
+int bz_gpu_partition_slab_count(bz_gpu_engine *g, int64_t carry_run);
+int bz_gpu_partition_slab_finish(bz_gpu_engine *g, uint64_t start_in, int is_last, size_t *n_blocks,
+                                 uint64_t *next_in, int *tail_block);
+
 /* (b) Encode blocks first, first+stride, ... (< n_blocks) of the last
  * partition.  Each block's bit string (block magic .. last payload bit,
  * MSB-first) is appended to d_packed as host-endian uint32 words whose bit 31

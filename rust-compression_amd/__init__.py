@@ -60,7 +60,8 @@ EXPORTS = [
     "bz_enc_create", "bz_enc_write", "bz_enc_end", "bz_enc_read", "bz_enc_pending", "bz_enc_destroy",
     "bz_encode_buffer", "bz_free",
     "bz_gpu_engine_create", "bz_gpu_engine_destroy", "bz_encode_bound", "bz_gpu_encode_device",
-    "bz_gpu_partition", "bz_gpu_encode_blocks", "bz_gpu_assemble", "bz_gpu_last_timings",
+    "bz_gpu_partition", "bz_gpu_partition_slab_begin", "bz_gpu_partition_slab_count",
+    "bz_gpu_partition_slab_finish", "bz_gpu_encode_blocks", "bz_gpu_assemble", "bz_gpu_last_timings",
     "bz_gpu_last_bwt_stats", "bz_gpu_last_bwt_rounds", "bz_gpu_profile_enable", "bz_gpu_profile_kernels", "bz_gpu_profile_get",
     "bz_gpu_debug_bwt", "bz_gpu_debug_code_lengths", "bz_gpu_debug_block_stats",
 ]
@@ -120,6 +121,9 @@ def lib():
     L.bz_encode_bound.argtypes = [sz]
     L.bz_gpu_encode_device.argtypes = [vp, C.c_int, vp, sz, vp, sz, szp]
     L.bz_gpu_partition.argtypes = [vp, C.c_int, vp, sz, C.c_int, szp, szp, C.POINTER(C.c_int)]
+    L.bz_gpu_partition_slab_begin.argtypes = [vp, C.c_int, vp, sz, C.c_uint64, C.c_uint64, C.POINTER(C.c_int64)]
+    L.bz_gpu_partition_slab_count.argtypes = [vp, C.c_int64]
+    L.bz_gpu_partition_slab_finish.argtypes = [vp, C.c_uint64, C.c_int, szp, u64p, C.POINTER(C.c_int)]
     L.bz_gpu_encode_blocks.argtypes = [vp, sz, sz, vp, sz, u64p, u64p, u32p, szp]
     L.bz_gpu_assemble.argtypes = [vp, C.c_int, sz, vp, u64p, u64p, u32p, C.c_int, C.c_int, C.c_int,
                                   C.c_uint, C.c_uint, C.c_uint32, u32p, vp, sz, szp,
@@ -272,6 +276,21 @@ class GpuEngine:
         nb, cons, tail = C.c_size_t(0), C.c_size_t(0), C.c_int(0)
         _check(lib().bz_gpu_partition(self._h, level, d_in, n, int(mode), C.byref(nb), C.byref(cons), C.byref(tail)))
         return nb.value, cons.value, tail.value
+
+    TILE = 4096  # input bytes per split tile
+
+    def slab_begin(self, level, d_in, n, tile0, tile1):
+        last = C.c_int64(-1)
+        _check(lib().bz_gpu_partition_slab_begin(self._h, level, d_in, n, tile0, tile1, C.byref(last)))
+        return last.value
+
+    def slab_count(self, carry_run):
+        _check(lib().bz_gpu_partition_slab_count(self._h, carry_run))
+
+    def slab_finish(self, start_in, is_last):
+        nb, nxt, tail = C.c_size_t(0), C.c_uint64(0), C.c_int(0)
+        _check(lib().bz_gpu_partition_slab_finish(self._h, start_in, int(is_last), C.byref(nb), C.byref(nxt), C.byref(tail)))
+        return nb.value, nxt.value, tail.value
 
     def encode_blocks(self, first, stride, n_blocks, d_packed, cap_words):
         k = max(0, (n_blocks - first + stride - 1) // stride) if n_blocks > first else 0

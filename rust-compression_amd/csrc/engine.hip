@@ -67,6 +67,7 @@ struct bz_gpu_engine {
     std::vector<u32> h_crc;
     const u8 *d_in = nullptr;
     u64 n_in = 0;
+    u64 slab_t0 = 0, slab_t1 = 0; // tiles this engine splits (the whole input on one GPU)
     int level = 9;
     // batch workspace (sized by max_blocks)
     DevBuf lblocks, lcrc, SA, R, KA, VA, KB, VB, tile_hist, count, flags, tlo, tln, nonfinal, active, per_k,
@@ -250,36 +251,8 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
     delete g;
 }
 
-extern "C" int bz_gpu_partition(bz_gpu_engine *g, int level, const void *d_in, size_t n, int mode,
-                                size_t *n_blocks, size_t *consumed, int *tail_block)
+static RleBuffers rle_buffers(bz_gpu_engine *g)
 {
-    if (!g || level < 1 || level > 9) return BZ_E_PARAM;
-    if (n && ((uintptr_t)d_in & 15u)) return BZ_E_PARAM;
-    HIPCHK(hipSetDevice(g->device));
-    g->level = level;
-    g->d_in = (const u8 *)d_in;
-    g->n_in = n;
-    g->h_blocks.clear();
-    g->h_crc.clear();
-    for (double &t : g->t_stage) t = 0;
-    for (u64 &s : g->bwt_stats) s = 0;
-    for (u64 &s : g->round_active) s = 0;
-    if (n_blocks) *n_blocks = 0;
-    if (consumed) *consumed = 0;
-    if (tail_block) *tail_block = 0;
-    if (n == 0) return BZ_OK;
-
-    const u32 block_max_len = (u32)level * 100000u - 19u; // encoder.rs:186
-    const u64 ntiles = (n + kRleTile - 1) / kRleTile;
-    const size_t max_blocks = (size_t)((n + n / 4) / block_max_len + 2);
-    int rc;
-    if ((rc = g->tile_last.ensure(ntiles * 8)) || (rc = g->carry_in.ensure(ntiles * 8)) ||
-        (rc = g->tile_crc.ensure(ntiles * 4)) || (rc = g->tile_count.ensure(ntiles * 4)) ||
-        (rc = g->tile_off.ensure((ntiles + 1) * 8)) || (rc = g->sub_off.ensure(ntiles * 32)) ||
-        (rc = g->sub_rs.ensure(ntiles * 128)) || (rc = g->scal.ensure(64)) ||
-        (rc = g->rle.ensure(n + n / 4 + 256)) || (rc = g->blocks_all.ensure(max_blocks * sizeof(BlockDesc))) ||
-        (rc = g->crc_all.ensure(max_blocks * 4)))
-        return rc;
     RleBuffers rb;
     rb.tile_last = g->tile_last.as<i64>();
     rb.carry_in = g->carry_in.as<i64>();
@@ -290,10 +263,103 @@ extern "C" int bz_gpu_partition(bz_gpu_engine *g, int level, const void *d_in, s
     rb.sub_rs = g->sub_rs.as<i64>();
     rb.total = g->scal.as<u64>();
     rb.cut_result = g->scal.as<u64>() + 2;
-    const int emit_tail = (mode == BZ_ACTION_RUN) ? 0 : 1;
+    return rb;
+}
+
+// ---- the split, in three steps (a slab of tiles per rank; one rank = the whole input) ------------
+extern "C" int bz_gpu_partition_slab_begin(bz_gpu_engine *g, int level, const void *d_in, size_t n,
+                                           uint64_t tile0, uint64_t tile1, int64_t *slab_last_start)
+{
+    if (!g || level < 1 || level > 9) return BZ_E_PARAM;
+    if (n && ((uintptr_t)d_in & 15u)) return BZ_E_PARAM;
+    HIPCHK(hipSetDevice(g->device));
+    const u64 ntiles = (n + kRleTile - 1) / kRleTile;
+    if (tile1 > ntiles) tile1 = ntiles;
+    if (tile0 > tile1) tile0 = tile1;
+    g->level = level;
+    g->d_in = (const u8 *)d_in;
+    g->n_in = n;
+    g->slab_t0 = tile0;
+    g->slab_t1 = tile1;
+    g->h_blocks.clear();
+    g->h_crc.clear();
+    for (double &t : g->t_stage) t = 0;
+    for (u64 &s : g->bwt_stats) s = 0;
+    for (u64 &s : g->round_active) s = 0;
+    if (slab_last_start) *slab_last_start = -1;
+    if (ntiles == 0) return BZ_OK;
+    int rc;
+    if ((rc = g->tile_last.ensure(ntiles * 8)) || (rc = g->carry_in.ensure(ntiles * 8)) ||
+        (rc = g->tile_crc.ensure(ntiles * 4)) || (rc = g->tile_count.ensure(ntiles * 4)) ||
+        (rc = g->tile_off.ensure((ntiles + 1) * 8)) || (rc = g->sub_off.ensure(ntiles * 32)) ||
+        (rc = g->sub_rs.ensure(ntiles * 128)) || (rc = g->scal.ensure(128)))
+        return rc;
+    const RleBuffers rb = rle_buffers(g);
     const int sp = span_begin(g, 0);
-    launch_rle1(g->st, g->d_in, n, g->crc_tab.as<u32>(), g->xp16.as<u32>(), rb, g->rle.as<u8>(), block_max_len,
-                emit_tail, g->blocks_all.as<BlockDesc>(), (u32)max_blocks);
+    launch_rle_scan(g->st, g->d_in, n, tile0, tile1, 0, g->crc_tab.as<u32>(), g->xp16.as<u32>(), rb);
+    // the range's last run start falls out of the carry scan (its carries are redone in _count)
+    i64 *d_last = reinterpret_cast<i64 *>(g->scal.as<u64>() + 8);
+    if (tile1 > tile0) {
+        launch_slab_last(g->st, rb, tile0, tile1, d_last);
+        i64 last = -1;
+        HIPCHK(hipMemcpyAsync(&last, d_last, 8, hipMemcpyDeviceToHost, g->st));
+        span_end(g, sp);
+        HIPCHK(hipStreamSynchronize(g->st));
+        if (slab_last_start) *slab_last_start = last;
+    } else {
+        span_end(g, sp);
+    }
+    HIPCHK(hipGetLastError());
+    return BZ_OK;
+}
+
+extern "C" int bz_gpu_partition_slab_count(bz_gpu_engine *g, int64_t carry_run)
+{
+    if (!g) return BZ_E_PARAM;
+    HIPCHK(hipSetDevice(g->device));
+    if (g->slab_t1 <= g->slab_t0) return BZ_OK;
+    const RleBuffers rb = rle_buffers(g);
+    const int sp = span_begin(g, 0);
+    launch_rle_count(g->st, g->d_in, g->n_in, g->slab_t0, g->slab_t1, 0, carry_run, rb, nullptr);
+    span_end(g, sp);
+    HIPCHK(hipGetLastError());
+    return BZ_OK;
+}
+
+extern "C" int bz_gpu_partition_slab_finish(bz_gpu_engine *g, uint64_t start_in, int is_last, size_t *n_blocks,
+                                            uint64_t *next_in, int *tail_block)
+{
+    if (!g) return BZ_E_PARAM;
+    HIPCHK(hipSetDevice(g->device));
+    if (n_blocks) *n_blocks = 0;
+    if (next_in) *next_in = start_in;
+    if (tail_block) *tail_block = 0;
+    const u64 n = g->n_in;
+    if (n == 0) return BZ_OK;
+    const u64 t0 = g->slab_t0, t1 = g->slab_t1;
+    u64 tb = start_in / kRleTile; // tile holding the first byte of this rank's first block
+    if (tb > t0) tb = t0;         // (start_in never lies beyond the slab's first byte)
+    if (start_in > t0 * (u64)kRleTile) return BZ_E_PARAM;
+    const RleBuffers rb = rle_buffers(g);
+    const u32 block_max_len = (u32)g->level * 100000u - 19u; // encoder.rs:186
+    const int sp = span_begin(g, 0);
+    if (tb < t0) {
+        // left halo: the tail of the previous slab(s) that belongs to this rank's first block, coded
+        // afresh from the cut (RLE1 restarted at a cut is RLE1 continued)
+        launch_rle_scan(g->st, g->d_in, n, tb, t0, start_in, g->crc_tab.as<u32>(), g->xp16.as<u32>(), rb);
+        launch_rle_count(g->st, g->d_in, n, tb, t0, start_in, -1, rb, nullptr);
+    }
+    launch_rle_prefix(g->st, tb, t1, rb);
+    u64 total = 0;
+    HIPCHK(hipMemcpyAsync(&total, rb.total, 8, hipMemcpyDeviceToHost, g->st));
+    HIPCHK(hipStreamSynchronize(g->st));
+    const size_t max_blocks = (size_t)(total / block_max_len + 2);
+    int rc;
+    if ((rc = g->rle.ensure(total + 256)) || (rc = g->blocks_all.ensure(max_blocks * sizeof(BlockDesc))) ||
+        (rc = g->crc_all.ensure(max_blocks * 4)))
+        return rc;
+    launch_rle_finish(g->st, g->d_in, n, tb, t1, start_in, rb, g->rle.as<u8>(), block_max_len, is_last ? 1 : 0,
+                      g->blocks_all.as<BlockDesc>(), (u32)max_blocks);
     u64 res[3] = {0, 0, 0};
     HIPCHK(hipMemcpyAsync(res, rb.cut_result, sizeof(res), hipMemcpyDeviceToHost, g->st));
     HIPCHK(hipStreamSynchronize(g->st));
@@ -312,9 +378,27 @@ extern "C" int bz_gpu_partition(bz_gpu_engine *g, int level, const void *d_in, s
     spans_collect(g);
     HIPCHK(hipGetLastError());
     if (n_blocks) *n_blocks = nb;
-    if (consumed) *consumed = (size_t)res[1];
+    if (next_in) *next_in = nb || is_last ? res[1] : start_in;
     if (tail_block) *tail_block = (int)res[2];
     return BZ_OK;
+}
+
+extern "C" int bz_gpu_partition(bz_gpu_engine *g, int level, const void *d_in, size_t n, int mode,
+                                size_t *n_blocks, size_t *consumed, int *tail_block)
+{
+    if (!g || level < 1 || level > 9) return BZ_E_PARAM;
+    if (n_blocks) *n_blocks = 0;
+    if (consumed) *consumed = 0;
+    if (tail_block) *tail_block = 0;
+    const u64 ntiles = (n + kRleTile - 1) / kRleTile;
+    int64_t last = -1;
+    int rc = bz_gpu_partition_slab_begin(g, level, d_in, n, 0, ntiles, &last);
+    if (rc != BZ_OK || n == 0) return rc;
+    if ((rc = bz_gpu_partition_slab_count(g, -1)) != BZ_OK) return rc;
+    uint64_t next = 0;
+    rc = bz_gpu_partition_slab_finish(g, 0, mode == BZ_ACTION_RUN ? 0 : 1, n_blocks, &next, tail_block);
+    if (consumed) *consumed = (size_t)next;
+    return rc;
 }
 
 // Argument blocks for the sub-batch of `nb` blocks that starts at local block `o`.

@@ -63,9 +63,12 @@ struct Seg {
     int next;  // byte after the segment or -1 (end of input)
     u64 p0;
     u32 valid; // number of valid bytes (0..16)
+    u32 skip;  // leading bytes that lie before the region's first byte (treated as not there)
 };
 
-__device__ __forceinline__ void load_seg(const u8 *__restrict__ in, u64 n, u64 tile, Seg &s)
+// in_begin: first byte of the region being coded.  RLE1 restarted at a block cut is identical to
+// RLE1 continued (a cut is a chunk start), so a rank may start at the cut it was handed.
+__device__ __forceinline__ void load_seg(const u8 *__restrict__ in, u64 n, u64 tile, Seg &s, u64 in_begin = 0)
 {
     s.p0 = tile * (u64)kRleTile + (u64)threadIdx.x * 16u;
     if (s.p0 + 16 <= n) {
@@ -79,13 +82,14 @@ __device__ __forceinline__ void load_seg(const u8 *__restrict__ in, u64 n, u64 t
 #pragma unroll
         for (int k = 0; k < 16; ++k) s.b[k] = (u32)k < s.valid ? in[s.p0 + k] : (u8)0;
     }
-    s.prev = (s.p0 > 0 && s.valid > 0) ? (int)in[s.p0 - 1] : -1;
+    s.prev = (s.p0 > in_begin && s.valid > 0) ? (int)in[s.p0 - 1] : -1;
     s.next = (s.p0 + s.valid < n && s.valid > 0) ? (int)in[s.p0 + s.valid] : -1;
+    s.skip = (in_begin > s.p0) ? (u32)((in_begin - s.p0) < 16u ? (in_begin - s.p0) : 16u) : 0u;
 }
 
 // ---- kernel A: per-tile last run start + per-tile raw CRC ---------------------
 // crc_tab: 256-entry byte table (src/crc32.rs:58-72); xp16: x^(8*16*k) mod P, k=0..255
-__global__ __launch_bounds__(RT) void k_rle_tile_scan(const u8 *__restrict__ in, u64 n,
+__global__ __launch_bounds__(RT) void k_rle_tile_scan(const u8 *__restrict__ in, u64 n, u64 t0, u64 in_begin,
                                                        const u32 *__restrict__ crc_tab,
                                                        const u32 *__restrict__ xp16,
                                                        i64 *__restrict__ tile_last_start,
@@ -97,9 +101,9 @@ __global__ __launch_bounds__(RT) void k_rle_tile_scan(const u8 *__restrict__ in,
     s_tab[threadIdx.x] = crc_tab[threadIdx.x];
     __syncthreads();
 
-    const u64 tile = blockIdx.x;
+    const u64 tile = t0 + blockIdx.x;
     Seg s;
-    load_seg(in, n, tile, s);
+    load_seg(in, n, tile, s, in_begin);
 
     i64 last = -1;
     int pb = s.prev;
@@ -107,9 +111,11 @@ __global__ __launch_bounds__(RT) void k_rle_tile_scan(const u8 *__restrict__ in,
 #pragma unroll
     for (u32 k = 0; k < 16; ++k) {
         if (k < s.valid) {
-            if ((int)s.b[k] != pb) last = (i64)(s.p0 + k);
-            pb = s.b[k];
-            crc = s_tab[(crc >> 24) ^ s.b[k]] ^ (crc << 8);
+            if (k >= s.skip) {
+                if ((int)s.b[k] != pb) last = (i64)(s.p0 + k);
+                pb = s.b[k];
+            }
+            crc = s_tab[(crc >> 24) ^ s.b[k]] ^ (crc << 8); // the tile CRC covers every byte of the tile
         }
     }
     // shift this thread's CRC to the end of the tile: bytes after it inside the tile
@@ -152,24 +158,31 @@ __global__ __launch_bounds__(RT) void k_rle_tile_scan(const u8 *__restrict__ in,
 }
 
 // ---- kernel B: exclusive max-scan over tiles (one workgroup) -------------------
+// tiles [t0, t1); `init` = last run start before tile t0 (-1: none); *out_last = last run start in the range
 __global__ __launch_bounds__(1024) void k_rle_scan_tiles_max(const i64 *__restrict__ tile_last,
-                                                              i64 *__restrict__ carry_in, u64 ntiles)
+                                                              i64 *__restrict__ carry_in, u64 t0, u64 t1, i64 init,
+                                                              i64 *__restrict__ out_last)
 {
     __shared__ i64 s_part[1024];
+    const u64 ntiles = t1 - t0;
+    tile_last += t0;
+    carry_in += t0;
     const u64 per = (ntiles + 1023) / 1024;
-    const u64 a = (u64)threadIdx.x * per;
+    u64 a = (u64)threadIdx.x * per;
+    if (a > ntiles) a = ntiles;
     const u64 b = (a + per < ntiles) ? a + per : ntiles;
     i64 m = -1;
     for (u64 t = a; t < b; ++t) m = tile_last[t] > m ? tile_last[t] : m;
     s_part[threadIdx.x] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        i64 run = -1;
+        i64 run = init;
         for (u32 k = 0; k < 1024; ++k) {
             i64 v = s_part[k];
             s_part[k] = run;
             run = v > run ? v : run;
         }
+        if (out_last) *out_last = run;
     }
     __syncthreads();
     i64 run = s_part[threadIdx.x];
@@ -204,7 +217,7 @@ __device__ __forceinline__ u32 eval_seg(const Seg &s, i64 rs_in, u8 e[16], u8 cp
     for (u32 k = 0; k < 16; ++k) {
         u32 ek = 0;
         u32 ck = 0;
-        if (k < s.valid) {
+        if (k < s.valid && k >= s.skip) {
             const u64 p = s.p0 + k;
             if ((int)s.b[k] != pb) {
                 rs = (i64)p;
@@ -236,7 +249,7 @@ __device__ __forceinline__ i64 seg_run_start(const Seg &s, i64 tile_carry, i64 *
     int pb = s.prev;
 #pragma unroll
     for (u32 k = 0; k < 16; ++k) {
-        if (k < s.valid) {
+        if (k < s.valid && k >= s.skip) {
             if ((int)s.b[k] != pb) last = (i64)(s.p0 + k);
             pb = s.b[k];
         }
@@ -249,16 +262,16 @@ __device__ __forceinline__ i64 seg_run_start(const Seg &s, i64 tile_carry, i64 *
 // ---- kernel C: bytes emitted per tile -------------------------------------------
 // Also records, for each 256-byte sub-tile, the bytes emitted before it inside its tile and the run
 // start live at its first byte -- the cut chain uses them to look at 2 KiB instead of whole tiles.
-__global__ __launch_bounds__(RT) void k_rle_count(const u8 *__restrict__ in, u64 n,
+__global__ __launch_bounds__(RT) void k_rle_count(const u8 *__restrict__ in, u64 n, u64 t0, u64 in_begin,
                                                    const i64 *__restrict__ carry_in,
                                                    u32 *__restrict__ tile_count, u16 *__restrict__ sub_off,
                                                    i64 *__restrict__ sub_rs)
 {
     __shared__ i64 s_m[RT / 64 + 1];
     __shared__ u32 s_s[RT / 64];
-    const u64 tile = blockIdx.x;
+    const u64 tile = t0 + blockIdx.x;
     Seg s;
-    load_seg(in, n, tile, s);
+    load_seg(in, n, tile, s, in_begin);
     const i64 rs = seg_run_start(s, carry_in[tile], s_m);
     u8 e[16], cph[16];
     const u32 cnt = eval_seg(s, rs, e, cph);
@@ -272,13 +285,18 @@ __global__ __launch_bounds__(RT) void k_rle_count(const u8 *__restrict__ in, u64
 }
 
 // ---- kernel D: exclusive sum over tiles (one workgroup), u64 offsets -------------
+// tiles [t0, t1): tile_off[t0] = 0 ... tile_off[t1] = total (offsets are relative to the range)
 __global__ __launch_bounds__(1024) void k_rle_scan_tiles_sum(const u32 *__restrict__ tile_count,
-                                                              u64 *__restrict__ tile_off, u64 ntiles,
+                                                              u64 *__restrict__ tile_off, u64 t0, u64 t1,
                                                               u64 *__restrict__ total)
 {
     __shared__ u64 s_part[1024];
+    const u64 ntiles = t1 - t0;
+    tile_count += t0;
+    tile_off += t0;
     const u64 per = (ntiles + 1023) / 1024;
-    const u64 a = (u64)threadIdx.x * per;
+    u64 a = (u64)threadIdx.x * per;
+    if (a > ntiles) a = ntiles;
     const u64 b = (a + per < ntiles) ? a + per : ntiles;
     u64 m = 0;
     for (u64 t = a; t < b; ++t) m += tile_count[t];
@@ -303,7 +321,7 @@ __global__ __launch_bounds__(1024) void k_rle_scan_tiles_sum(const u32 *__restri
 }
 
 // ---- kernel E: scatter the RLE1 image -------------------------------------------
-__global__ __launch_bounds__(RT) void k_rle_scatter(const u8 *__restrict__ in, u64 n,
+__global__ __launch_bounds__(RT) void k_rle_scatter(const u8 *__restrict__ in, u64 n, u64 t0, u64 in_begin,
                                                      const i64 *__restrict__ carry_in,
                                                      const u64 *__restrict__ tile_off,
                                                      u8 *__restrict__ rle)
@@ -311,9 +329,9 @@ __global__ __launch_bounds__(RT) void k_rle_scatter(const u8 *__restrict__ in, u
     __shared__ i64 s_m[RT / 64 + 1];
     __shared__ u32 s_s[RT / 64];
     __shared__ u8 s_out[2 * kRleTile];
-    const u64 tile = blockIdx.x;
+    const u64 tile = t0 + blockIdx.x;
     Seg s;
-    load_seg(in, n, tile, s);
+    load_seg(in, n, tile, s, in_begin);
     const i64 rs = seg_run_start(s, carry_in[tile], s_m);
     u8 e[16], cph[16];
     const u32 cnt = eval_seg(s, rs, e, cph);
@@ -347,7 +365,9 @@ constexpr u32 CSW_SMALL = 2, CSW_BIG = 12;           // sweeps of 64 segments (1
 constexpr u32 CSEG = CSW_BIG * 64;                   // LDS slots per wave
 constexpr u64 CUT_END = ~0ull, CUT_OUT = ~0ull - 1;
 
-__global__ __launch_bounds__(CT) void k_rle_cuts(const u8 *__restrict__ in, u64 n,
+// Tiles [t_begin, ntiles) are in play; tile_off is relative to t_begin; the first block starts at
+// input byte in_begin (a cut handed over by the previous rank, or 0).
+__global__ __launch_bounds__(CT) void k_rle_cuts(const u8 *__restrict__ in, u64 n, u64 t_begin, u64 in_begin,
                                                   const u16 *__restrict__ sub_off,
                                                   const i64 *__restrict__ sub_rs,
                                                   const u64 *__restrict__ tile_off, u64 ntiles,
@@ -364,8 +384,8 @@ __global__ __launch_bounds__(CT) void k_rle_cuts(const u8 *__restrict__ in, u64 
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
     const u64 L = block_max_len;
     const u64 M = tile_off[ntiles];
-    u64 s_rle = 0, s_in = 0;
-    u64 cur_tile = 0; // tile_off[cur_tile] < every later target
+    u64 s_rle = 0, s_in = in_begin;
+    u64 cur_tile = t_begin; // tile_off[cur_tile] < every later target
     u32 nb = 0;
     bool broken = false;
     u32 nsw = CSW_SMALL; // sweeps per window in this round
@@ -409,7 +429,7 @@ __global__ __launch_bounds__(CT) void k_rle_cuts(const u8 *__restrict__ in, u64 
         // ---- phase 2: RLE1 over the window, 64 consecutive segments (1 KiB) per sweep ----------------
         if (alive) {
             u32 off_carry = 0;
-            int prev_carry = (in0 > 0) ? (int)in[in0 - 1] : -1;
+            int prev_carry = (in0 > in_begin) ? (int)in[in0 - 1] : -1;
             uint4 cur;
             u32 cur_valid;
             {
@@ -443,6 +463,7 @@ __global__ __launch_bounds__(CT) void k_rle_cuts(const u8 *__restrict__ in, u64 
                 Seg sg;
                 sg.p0 = in0 + (u64)(q * 64u + l) * 16u;
                 sg.valid = cur_valid;
+                sg.skip = (in_begin > sg.p0) ? (u32)((in_begin - sg.p0) < 16u ? (in_begin - sg.p0) : 16u) : 0u;
                 const u32 wv[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
                 for (int k = 0; k < 16; ++k) sg.b[k] = (u8)(wv[k >> 2] >> ((k & 3) * 8));
@@ -454,13 +475,13 @@ __global__ __launch_bounds__(CT) void k_rle_cuts(const u8 *__restrict__ in, u64 
                 int nx = __shfl_down(firstb, 1, 64);
                 const u32 nfw = __shfl(nxt.x, 0, 64), nfv = __shfl(nxt_valid, 0, 64);
                 if (l == 63) nx = nfv ? (int)(nfw & 0xFFu) : -1;
-                sg.prev = sg.valid ? pv : -1;
+                sg.prev = (sg.valid && sg.p0 > in_begin) ? pv : -1;
                 sg.next = (sg.valid == 16) ? nx : -1; // a short segment ends the input
                 i64 last = -1;
                 int pb = sg.prev;
 #pragma unroll
                 for (u32 k = 0; k < 16; ++k) {
-                    if (k < sg.valid) {
+                    if (k < sg.valid && k >= sg.skip) {
                         if ((int)sg.b[k] != pb) last = (i64)(sg.p0 + k);
                         pb = sg.b[k];
                     }
@@ -474,7 +495,7 @@ __global__ __launch_bounds__(CT) void k_rle_cuts(const u8 *__restrict__ in, u64 
                 u32 eb = 0, ce = 0;
 #pragma unroll
                 for (u32 k = 0; k < 16; ++k) {
-                    if (k < sg.valid) {
+                    if (k < sg.valid && k >= sg.skip) {
                         const int nbyte = (k + 1 < sg.valid) ? (int)sg.b[k + 1 < 16 ? k + 1 : 15] : sg.next;
                         if (nbyte != (int)sg.b[k] || cph[k] == 254u) ce |= 1u << k;
                         eb |= (u32)e[k] << (2u * k);
@@ -675,26 +696,64 @@ __global__ __launch_bounds__(RT) void k_block_crc(const u8 *__restrict__ in,
 }
 
 // ---- host launchers -----------------------------------------------------------------
-void launch_rle1(hipStream_t st, const u8 *d_in, u64 n, const u32 *crc_tab, const u32 *xp16,
-                 const RleBuffers &rb, u8 *d_rle, u32 block_max_len, int emit_tail,
-                 BlockDesc *d_blocks, u32 max_blocks)
+// last run start inside tiles [t0,t1) (-1: none)
+__global__ __launch_bounds__(1024) void k_slab_last(const i64 *__restrict__ tile_last, u64 t0, u64 t1,
+                                                     i64 *__restrict__ out)
 {
-    const u64 ntiles = (n + kRleTile - 1) / kRleTile;
-    if (ntiles == 0) {
+    __shared__ i64 s_m[1024];
+    i64 m = -1;
+    for (u64 t = t0 + threadIdx.x; t < t1; t += 1024) m = tile_last[t] > m ? tile_last[t] : m;
+    s_m[threadIdx.x] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (u32 k = 1; k < 1024; ++k) m = s_m[k] > m ? s_m[k] : m;
+        *out = m;
+    }
+}
+
+void launch_slab_last(hipStream_t st, const RleBuffers &rb, u64 t0, u64 t1, i64 *d_out)
+{
+    hipLaunchKernelGGL(k_slab_last, dim3(1), dim3(1024), 0, st, rb.tile_last, t0, t1, d_out);
+}
+
+// The split is driven in three steps so that a multi-GPU job can shard it by slabs of tiles:
+//   scan   : tiles [t0,t1): run starts + tile CRCs; *out_last = last run start of the range
+//   count  : tiles [t0,t1): carries from `init_carry`, RLE1 byte counts, sub-tile index
+//   finish : prefix over [tb,t1), the cut chain from byte in_begin, the RLE1 image
+void launch_rle_scan(hipStream_t st, const u8 *d_in, u64 n, u64 t0, u64 t1, u64 in_begin, const u32 *crc_tab,
+                     const u32 *xp16, const RleBuffers &rb)
+{
+    if (t1 <= t0) return;
+    hipLaunchKernelGGL(k_rle_tile_scan, dim3((u32)(t1 - t0)), dim3(RT), 0, st, d_in, n, t0, in_begin, crc_tab, xp16,
+                       rb.tile_last, rb.tile_crc);
+}
+
+void launch_rle_count(hipStream_t st, const u8 *d_in, u64 n, u64 t0, u64 t1, u64 in_begin, i64 init_carry,
+                      const RleBuffers &rb, i64 *d_out_last)
+{
+    if (t1 <= t0) return;
+    hipLaunchKernelGGL(k_rle_scan_tiles_max, dim3(1), dim3(1024), 0, st, rb.tile_last, rb.carry_in, t0, t1,
+                       init_carry, d_out_last);
+    hipLaunchKernelGGL(k_rle_count, dim3((u32)(t1 - t0)), dim3(RT), 0, st, d_in, n, t0, in_begin, rb.carry_in,
+                       rb.tile_count, rb.sub_off, rb.sub_rs);
+}
+
+void launch_rle_prefix(hipStream_t st, u64 tb, u64 t1, const RleBuffers &rb)
+{
+    hipLaunchKernelGGL(k_rle_scan_tiles_sum, dim3(1), dim3(1024), 0, st, rb.tile_count, rb.tile_off, tb, t1, rb.total);
+}
+
+void launch_rle_finish(hipStream_t st, const u8 *d_in, u64 n, u64 tb, u64 t1, u64 in_begin, const RleBuffers &rb,
+                       u8 *d_rle, u32 block_max_len, int emit_tail, BlockDesc *d_blocks, u32 max_blocks)
+{
+    if (t1 <= tb) {
         (void)hipMemsetAsync(rb.cut_result, 0, 3 * sizeof(u64), st);
         return;
     }
-    hipLaunchKernelGGL(k_rle_tile_scan, dim3((u32)ntiles), dim3(RT), 0, st, d_in, n, crc_tab, xp16,
-                       rb.tile_last, rb.tile_crc);
-    hipLaunchKernelGGL(k_rle_scan_tiles_max, dim3(1), dim3(1024), 0, st, rb.tile_last, rb.carry_in, ntiles);
-    hipLaunchKernelGGL(k_rle_count, dim3((u32)ntiles), dim3(RT), 0, st, d_in, n, rb.carry_in, rb.tile_count,
-                       rb.sub_off, rb.sub_rs);
-    hipLaunchKernelGGL(k_rle_scan_tiles_sum, dim3(1), dim3(1024), 0, st, rb.tile_count, rb.tile_off, ntiles,
-                       rb.total);
-    hipLaunchKernelGGL(k_rle_scatter, dim3((u32)ntiles), dim3(RT), 0, st, d_in, n, rb.carry_in, rb.tile_off,
-                       d_rle);
-    hipLaunchKernelGGL(k_rle_cuts, dim3(1), dim3(CT), 0, st, d_in, n, rb.sub_off, rb.sub_rs, rb.tile_off, ntiles,
-                       block_max_len, emit_tail, d_blocks, max_blocks, rb.cut_result);
+    hipLaunchKernelGGL(k_rle_scatter, dim3((u32)(t1 - tb)), dim3(RT), 0, st, d_in, n, tb, in_begin, rb.carry_in,
+                       rb.tile_off, d_rle);
+    hipLaunchKernelGGL(k_rle_cuts, dim3(1), dim3(CT), 0, st, d_in, n, tb, in_begin, rb.sub_off, rb.sub_rs,
+                       rb.tile_off, t1, block_max_len, emit_tail, d_blocks, max_blocks, rb.cut_result);
 }
 
 void launch_block_crc(hipStream_t st, const u8 *d_in, const BlockDesc *d_blocks, u32 nblocks,

@@ -1,5 +1,4 @@
-"""N > 1 path on CPU: two processes over gloo run the same block round-robin + exchange code the
-GPU bench uses (rust-compression_amd/sharded.py).  The per-block bit strings come from the oracle
+"""N > 1 path on CPU: two/three processes over gloo run the same exchange code the GPU bench uses (rust-compression_amd/sharded.py).  The per-block bit strings come from the oracle
 (this test's stand-in for the HIP engine) and rank 0's assembled stream must equal the oracle's
 serial stream byte for byte."""
 import importlib
@@ -91,10 +90,10 @@ def _worker(rank, world, port, level, q):
         stream, stats = oracle.encode(data, level, with_stats=True)
         blocks = _block_strings(stream, stats)
         nb = len(blocks)
-        mine = sharded.local_block_ids(nb, rank, world)
+        mine = sharded.split_contiguous(nb, rank, world)
         packed, woff, used = _pack([blocks[b] for b in mine])
         res = sharded.exchange(woff, [blocks[b][1] for b in mine], [blocks[b][2] for b in mine], packed, used,
-                               nb, rank, world, torch.device("cpu"))
+                               rank, world, torch.device("cpu"))
         if rank == 0:
             buf, w_off, b_len, crcs = res
             out = _assemble(level, buf.view(-1).tolist(), w_off, b_len, crcs)
@@ -119,8 +118,11 @@ def test_round_robin_exchange_and_assembly(world):
     assert nb >= 5 and same and n > 1000
 
 
-def test_local_block_ids():
+def test_split_helpers():
     sharded = importlib.import_module("rust-compression_amd.sharded")
-    assert sharded.local_block_ids(10, 1, 4) == [1, 5, 9]
-    assert sharded.local_block_ids(3, 3, 4) == []
-    assert sorted(sum((sharded.local_block_ids(11, r, 4) for r in range(4)), [])) == list(range(11))
+    assert sorted(sum((sharded.split_contiguous(11, r, 4) for r in range(4)), [])) == list(range(11))
+    assert sharded.split_contiguous(3, 3, 4) == [2]
+    n = 10 * 4096 + 5
+    spans = [sharded.slab_tiles(n, r, 3) for r in range(3)]
+    assert spans[0][0] == 0 and spans[-1][1] == 11
+    assert all(spans[i][1] == spans[i + 1][0] for i in range(2))
