@@ -36,7 +36,8 @@
 
 namespace bzgpu {
 
-enum { SRC_TEXT = 0, SRC_PAIRS = 1, SRC_MM = 2, SRC_WALK = 3, SRC_SURV = 4, SRC_LISTG = 5 };
+enum { SRC_TEXT = 0, SRC_PAIRS = 1, SRC_MM = 2, SRC_WALK = 3, SRC_SURV = 4, SRC_LISTG = 5,
+       SRC_TEXTK = 6, SRC_WALKK = 7 }; // ..K: the keys were stored by the histogram kernel of the pass
 // sources whose sequence is the compacted list (length count[lb]) rather than all n positions
 template <int SRC> struct src_is_list {
     static constexpr bool value = (SRC == SRC_PAIRS || SRC == SRC_SURV || SRC == SRC_LISTG);
@@ -113,6 +114,26 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
         }
 #pragma unroll
         for (u32 r = 0; r < 16; ++r) key[r] = pack_key(text, n, val[r], s_code, ki.bits, ki.chars);
+    } else if (SRC == SRC_TEXTK) {
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) {
+            const u32 idx = first + r * 64u;
+            const u32 c = idx < cnt ? idx : cnt - 1u;
+            key[r] = ld_stream(Kin + base + c);
+            val[r] = c;
+            ok |= (idx < cnt ? 1u : 0u) << r;
+        }
+    } else if (SRC == SRC_WALKK) {
+        const u32 cm = ki.chars % n;
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) {
+            const u32 idx = first + r * 64u;
+            const u32 c = idx < cnt ? idx : cnt - 1u;
+            key[r] = ld_stream(Kin + base + c);
+            const u32 s = ld_stream(Vin + base + c);
+            val[r] = (s >= cm) ? s - cm : s + n - cm;
+            ok |= (idx < cnt ? 1u : 0u) << r;
+        }
     } else if (SRC == SRC_PAIRS) {
 #pragma unroll
         for (u32 r = 0; r < 16; ++r) {
@@ -171,7 +192,8 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
 template <int SRC, int BITS>
 __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shift, u32 h,
                                                               const u32 *__restrict__ Kin,
-                                                              const u32 *__restrict__ Vin)
+                                                              const u32 *__restrict__ Vin,
+                                                              u32 *__restrict__ Kstore)
 {
     constexpr u32 NB = 1u << BITS;
     __shared__ u32 s_hist[NB];
@@ -200,6 +222,13 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shif
 #pragma unroll
         for (u32 r = 0; r < 16; ++r)
             if ((ok >> r) & 1u) atomicAdd(&s_hist[(key[r] >> shift) & (NB - 1)], 1u);
+        // keys that cost a gather to build are kept for the scatter kernel of the same pass
+        if ((SRC == SRC_TEXT || SRC == SRC_WALK) && Kstore) {
+            const size_t base = (size_t)lb * kSlot;
+#pragma unroll
+            for (u32 r = 0; r < 16; ++r)
+                if ((ok >> r) & 1u) Kstore[base + start + w * 1024u + r * 64u + l] = key[r];
+        }
     }
     __syncthreads();
     u32 *out = a.tile_hist + ((size_t)lb * kTilesPerBlock + tile) * kMaxBins;
@@ -904,20 +933,27 @@ void KernelProf::reset()
 //   scatter: the same reads (+4 for the value of PAIRS) + 8 written (key, value)
 template <int SRC, int BITS>
 static void radix_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const u32 *Kin, const u32 *Vin,
-                       u32 *Kout, u32 *Vout, u64 elems, KernelProf *prof)
+                       u32 *Kout, u32 *Vout, u64 elems, KernelProf *prof, u32 *Ktmp = nullptr)
 {
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
     const u64 rd_hist = (SRC == SRC_TEXT) ? 1 : (SRC == SRC_PAIRS ? 4 : (SRC == SRC_WALK ? 5 : 8));
     const u64 rd_scat = (SRC == SRC_TEXT) ? 1 : (SRC == SRC_WALK ? 5 : 8); // SURV / LISTG: list + rank = 8
     int p = prof ? prof->begin(st, KID_RADIX_HIST, elems * rd_hist) : -1;
-    hipLaunchKernelGGL((k_radix_hist<SRC, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Kin, Vin);
+    hipLaunchKernelGGL((k_radix_hist<SRC, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Kin, Vin, Ktmp);
     if (prof) prof->end(st, p);
     p = prof ? prof->begin(st, KID_RADIX_SCAN, (u64)a.nb * kTilesPerBlock * (1u << BITS) * 8u) : -1;
     hipLaunchKernelGGL((k_radix_scan<SRC, BITS>), dim3(a.nb), dim3(kSortThreads), 0, st, a);
     if (prof) prof->end(st, p);
     p = prof ? prof->begin(st, KID_RADIX_SCATTER, elems * (rd_scat + 8)) : -1;
-    hipLaunchKernelGGL((k_radix_scatter<SRC, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Kin, Vin,
-                       Kout, Vout);
+    if (SRC == SRC_TEXT && Ktmp)
+        hipLaunchKernelGGL((k_radix_scatter<SRC_TEXTK, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Ktmp,
+                           Vin, Kout, Vout);
+    else if (SRC == SRC_WALK && Ktmp)
+        hipLaunchKernelGGL((k_radix_scatter<SRC_WALKK, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Ktmp,
+                           Vin, Kout, Vout);
+    else
+        hipLaunchKernelGGL((k_radix_scatter<SRC, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Kin, Vin,
+                           Kout, Vout);
     if (prof) prof->end(st, p);
 }
 
@@ -933,10 +969,10 @@ template <int B0, int B1, int B2>
 static void init_sort(hipStream_t st, const BwtArgs &a, u64 total_n, KernelProf *prof)
 {
     // phase A: order by key(j); phase B: walk it, order by key(j - c) -> 2c symbols
-    radix_pass<SRC_TEXT, B0>(st, a, 0, 0, nullptr, nullptr, a.KA, a.VA, total_n, prof);
+    radix_pass<SRC_TEXT, B0>(st, a, 0, 0, nullptr, nullptr, a.KA, a.VA, total_n, prof, a.KB);
     radix_pass<SRC_PAIRS, B1>(st, a, B0, 0, a.KA, a.VA, a.KB, a.VB, total_n, prof);
     radix_pass<SRC_PAIRS, B2>(st, a, B0 + B1, 0, a.KB, a.VB, a.KA, a.VA, total_n, prof);
-    radix_pass<SRC_WALK, B0>(st, a, 0, 0, a.KA, a.VA, a.KB, a.VB, total_n, prof);
+    radix_pass<SRC_WALK, B0>(st, a, 0, 0, a.KA, a.VA, a.KB, a.VB, total_n, prof, a.KA);
     radix_pass<SRC_PAIRS, B1>(st, a, B0, 0, a.KB, a.VB, a.KA, a.VA, total_n, prof);
     radix_pass<SRC_PAIRS, B2>(st, a, B0 + B1, 0, a.KA, a.VA, a.KB, a.VB, total_n, prof);
 }
