@@ -37,7 +37,7 @@
 namespace bzgpu {
 
 enum { SRC_TEXT = 0, SRC_PAIRS = 1, SRC_MM = 2, SRC_WALK = 3, SRC_SURV = 4, SRC_LISTG = 5,
-       SRC_TEXTK = 6, SRC_WALKK = 7 }; // ..K: the keys were stored by the histogram kernel of the pass
+       SRC_TEXTK = 6, SRC_WALKK = 7, SRC_MMK = 8 }; // ..K: keys stored by the histogram kernel of the pass
 // sources whose sequence is the compacted list (length count[lb]) rather than all n positions
 template <int SRC> struct src_is_list {
     static constexpr bool value = (SRC == SRC_PAIRS || SRC == SRC_SURV || SRC == SRC_LISTG);
@@ -122,6 +122,16 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
             key[r] = ld_stream(Kin + base + c);
             val[r] = c;
             ok |= (idx < cnt ? 1u : 0u) << r;
+        }
+    } else if (SRC == SRC_MMK) {
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) {
+            const u32 idx = first + r * 64u;
+            const u32 c = idx < cnt ? idx : cnt - 1u;
+            key[r] = ld_stream(Kin + base + c);
+            const u32 s = ld_stream(a.SA + base + c);
+            val[r] = (s >= hm) ? s - hm : s + n - hm;
+            ok |= ((idx < cnt && !(key[r] & kFinalBit)) ? 1u : 0u) << r;
         }
     } else if (SRC == SRC_WALKK) {
         const u32 cm = ki.chars % n;
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shif
     if (start >= cnt) return;
     const u8 *text = a.rle + d.rle_off;
     const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
-    const u32 hm = (SRC == SRC_MM || SRC == SRC_SURV) ? (((u32)ki.chars * 2u) << h) % n : 0u; // h = step index
+    const u32 hm = (SRC == SRC_MM || SRC == SRC_MMK || SRC == SRC_SURV) ? (((u32)ki.chars * 2u) << h) % n : 0u;
 
     for (u32 i = threadIdx.x; i < NB; i += kSortThreads) s_hist[i] = 0;
     if (SRC == SRC_TEXT || SRC == SRC_WALK)
@@ -223,11 +233,13 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shif
         for (u32 r = 0; r < 16; ++r)
             if ((ok >> r) & 1u) atomicAdd(&s_hist[(key[r] >> shift) & (NB - 1)], 1u);
         // keys that cost a gather to build are kept for the scatter kernel of the same pass
-        if ((SRC == SRC_TEXT || SRC == SRC_WALK) && Kstore) {
+        if ((SRC == SRC_TEXT || SRC == SRC_WALK || SRC == SRC_MM) && Kstore) {
             const size_t base = (size_t)lb * kSlot;
 #pragma unroll
-            for (u32 r = 0; r < 16; ++r)
-                if ((ok >> r) & 1u) Kstore[base + start + w * 1024u + r * 64u + l] = key[r];
+            for (u32 r = 0; r < 16; ++r) {
+                const u32 idx = start + w * 1024u + r * 64u + l;
+                if (idx < cnt) Kstore[base + idx] = key[r]; // (MM: final rotations keep their final bit)
+            }
         }
     }
     __syncthreads();
@@ -329,7 +341,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
     if (start >= cnt) return;
     const u8 *text = a.rle + d.rle_off;
     const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
-    const u32 hm = (SRC == SRC_MM || SRC == SRC_SURV) ? (((u32)ki.chars * 2u) << h) % n : 0u; // h = step index
+    const u32 hm = (SRC == SRC_MM || SRC == SRC_MMK || SRC == SRC_SURV) ? (((u32)ki.chars * 2u) << h) % n : 0u;
     const size_t base = (size_t)lb * kSlot;
 
     {
@@ -951,6 +963,9 @@ static void radix_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const
     else if (SRC == SRC_WALK && Ktmp)
         hipLaunchKernelGGL((k_radix_scatter<SRC_WALKK, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Ktmp,
                            Vin, Kout, Vout);
+    else if (SRC == SRC_MM && Ktmp)
+        hipLaunchKernelGGL((k_radix_scatter<SRC_MMK, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Ktmp,
+                           Vin, Kout, Vout);
     else
         hipLaunchKernelGGL((k_radix_scatter<SRC, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Kin, Vin,
                            Kout, Vout);
@@ -1029,7 +1044,7 @@ int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned l
             t = cV; cV = fV; fV = t;
         } else {
             // pass A walks all of SA (total_n), pass B and the refinement only the m survivors
-            radix_pass<SRC_MM, 10>(st, a, 0, step, nullptr, nullptr, fK, fV, total_n, prof);
+            radix_pass<SRC_MM, 10>(st, a, 0, step, nullptr, nullptr, fK, fV, total_n, prof, cK);
             radix_pass<SRC_PAIRS, 10>(st, a, 10, step, fK, fV, cK, cV, m, prof);
         }
         p = prof ? prof->begin(st, KID_GROUP_FLAGS, m * 13) : -1;

@@ -20,7 +20,8 @@
 
 namespace bzgpu {
 
-constexpr u32 kChunkWGs = (kMaxMtfChunks + 255) / 256; // 14 workgroups of 256 chunks
+constexpr u32 kChunkWGs = (kMaxMtfChunks + 255) / 256;
+constexpr u32 kMtfSmallAlpha = 96;                     // blocks with at most this many symbols use k_mtf_ranks_small // 14 workgroups of 256 chunks
 
 __device__ __forceinline__ u32 popc8(const u32 *b)
 {
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(256) void k_mtf_ranks(MtfArgs a)
     const u32 n = a.blocks[lb].n;
     const u32 chunk0 = blockIdx.x * 256u;
     if (chunk0 * kMtfChunk >= n) return;
+    if (popc8(a.inuse_bits + lb * 8) <= kMtfSmallAlpha) return; // k_mtf_ranks_small takes those blocks
     const u32 nchunks = (n + kMtfChunk - 1) / kMtfChunk;
     // cooperative, coalesced load of up to 256 start lists (64 dwords each)
     {
@@ -194,6 +196,79 @@ __global__ __launch_bounds__(256) void k_mtf_ranks(MtfArgs a)
                         break;
                     }
                 }
+            }
+            ov[k >> 2] |= rank << ((k & 3) * 8);
+        }
+        *reinterpret_cast<uint4 *>(R8 + p0) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+    }
+}
+
+// ---- M3': the same for small alphabets, without the data-dependent list walk ------------------
+// rank(i) = number of symbols used more recently than symbol(i) = #{c : last[c] > last[sym(i)]},
+// where last[c] is the time of c's latest occurrence (start list: -1 for the front, -2, ...).
+// Every lane does alpha/2 packed compares per symbol whatever the data, so the 64 lanes of a wave
+// stay in step (the list walk above costs each step the LARGEST rank among its lanes).  The table
+// lives in LDS as [pair of symbols][lane] 2 x i16: conflict-free, 48 KiB for <= 96 symbols.
+constexpr u32 kMtfSmallPairs = kMtfSmallAlpha / 2;
+__global__ __launch_bounds__(256) void k_mtf_ranks_small(MtfArgs a)
+{
+    __shared__ u32 s_last[kMtfSmallPairs * 256];
+    __shared__ u8 s_code[256];
+    const u32 lb = blockIdx.y;
+    const u32 n = a.blocks[lb].n;
+    const u32 chunk0 = blockIdx.x * 256u;
+    if (chunk0 * kMtfChunk >= n) return;
+    const u32 *bits = a.inuse_bits + lb * 8;
+    const u32 alpha = popc8(bits);
+    if (alpha > kMtfSmallAlpha) return;
+    {
+        const u32 v = threadIdx.x; // byte value -> code (rank among the bytes in use)
+        u32 before = 0;
+        for (u32 q = 0; q < (v >> 5); ++q) before += __popc(bits[q]);
+        before += __popc(bits[v >> 5] & ((1u << (v & 31u)) - 1u));
+        s_code[v] = (u8)before;
+    }
+    __syncthreads();
+    const u32 chunk = chunk0 + threadIdx.x;
+    const u32 beg = chunk * kMtfChunk;
+    if (beg >= n) return;
+    const u32 end = (beg + kMtfChunk < n) ? beg + kMtfChunk : n;
+    const u32 npairs = (alpha + 1u) >> 1;
+    u32 *my = s_last + threadIdx.x;
+    for (u32 q = 0; q < npairs; ++q) my[q * 256u] = 0x80008000u; // both halves: -32768 = never seen
+    {
+        // start list -> times -1, -2, ...
+        const u8 *st = a.init_state + ((size_t)lb * kMaxMtfChunks + chunk) * 256u;
+        for (u32 q = 0; q < alpha; ++q) {
+            const u32 c = s_code[st[q]];
+            const u32 t = (u32)(0xFFFFu - q) & 0xFFFFu; // (i16)(-1 - q)
+            u32 wd = my[(c >> 1) * 256u];
+            wd = (c & 1u) ? ((wd & 0x0000FFFFu) | (t << 16)) : ((wd & 0xFFFF0000u) | t);
+            my[(c >> 1) * 256u] = wd;
+        }
+    }
+    const u8 *L = a.L + (size_t)lb * kSlot;
+    u8 *R8 = a.rank8 + (size_t)lb * kSlot;
+    for (u32 v = 0; v < kMtfChunk / 16u; ++v) {
+        const u32 p0 = beg + v * 16u;
+        if (p0 >= end) break;
+        const uint4 q4 = *reinterpret_cast<const uint4 *>(L + p0);
+        const u32 wv[4] = {q4.x, q4.y, q4.z, q4.w};
+        u32 ov[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (u32 k = 0; k < 16; ++k) {
+            u32 rank = 0;
+            if (p0 + k < end) {
+                const u32 c = s_code[(wv[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
+                const u32 wc = my[(c >> 1) * 256u];
+                const int ls = (int)(short)((c & 1u) ? (wc >> 16) : (wc & 0xFFFFu));
+                for (u32 q = 0; q < npairs; ++q) {
+                    const u32 wd = my[q * 256u];
+                    rank += ((int)(short)(wd & 0xFFFFu) > ls) ? 1u : 0u;
+                    rank += ((int)(short)(wd >> 16) > ls) ? 1u : 0u;
+                }
+                const u32 t = (v * 16u + k) & 0xFFFFu; // time inside the chunk, 0..kMtfChunk-1
+                my[(c >> 1) * 256u] = (c & 1u) ? ((wc & 0x0000FFFFu) | (t << 16)) : ((wc & 0xFFFF0000u) | t);
             }
             ov[k >> 2] |= rank << ((k & 3) * 8);
         }
@@ -387,6 +462,7 @@ void launch_mtf(hipStream_t st, const MtfArgs &a)
     (void)hipMemsetAsync(a.mtf_freq, 0, (size_t)a.nb * kMaxAlpha * sizeof(u32), st);
     hipLaunchKernelGGL(k_mtf_summaries, dim3(kChunkWGs, a.nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_mtf_compose, dim3(a.nb), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_mtf_ranks_small, dim3(kChunkWGs, a.nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_mtf_ranks, dim3(kChunkWGs, a.nb), dim3(256), 0, st, a);
     const dim3 grid(kTilesPerBlock, a.nb);
     hipLaunchKernelGGL(k_zle_last, grid, dim3(kSortThreads), 0, st, a);
