@@ -280,3 +280,37 @@ def test_slab_sharded_partition_equals_serial(pkg, oracle, world):
     assert got == oracle.encode(d, level)
     for e in engs:
         e.close()
+
+
+def _rand(n, seed, k=256):
+    rng = random.Random(seed)
+    return bytes(rng.randrange(k) for _ in range(n))
+
+
+WIDE = {
+    "random256_3blocks": lambda: _rand(2_500_000, 21),
+    "alphabet129": lambda: _rand(400_000, 22, 129),
+    "alphabet128": lambda: _rand(400_000, 23, 128),
+    "alphabet2": lambda: _rand(300_000, 24, 2),
+    "alphabet3_periodic_mix": lambda: (_rand(977, 25, 3) * 700)[:600_000] + _rand(100_000, 26, 3),
+    "zeros_40MB": lambda: b"\x00" * 40_000_000,
+    "long_runs_mixed": lambda: b"".join(bytes([i % 7]) * (3000 + 517 * (i % 11)) for i in range(4000)),
+    "t2_deep_lcp": lambda: __import__("corpus").stress_t2(2_400_000),
+    "text_zeros_random": lambda: _text(700_000, 31) + b"\x00" * 3_000_000 + _rand(500_000, 32) + _text(300_000, 33),
+    "run_255_boundaries": lambda: b"".join(b"a" * r + b"b" for r in (254, 255, 256, 257, 509, 510, 511, 1020, 4, 3, 5) * 4000),
+}
+
+
+@pytest.mark.parametrize("name", sorted(WIDE))
+def test_wide_inputs_level9(pkg, oracle, name):
+    """Alphabet sizes around the key-packing switches, long runs (cut windows, 255-cuts), deep LCPs."""
+    d = WIDE[name]()
+    out = pkg.compress(d, 9)
+    assert out == oracle.encode(d, 9), name
+    assert bz2.decompress(out) == d
+
+
+def test_wide_inputs_small_blocks(pkg, oracle):
+    d = WIDE["long_runs_mixed"]()[:6_000_000] + WIDE["text_zeros_random"]()[:2_000_000]
+    for level in (1, 4):
+        assert pkg.compress(d, level) == oracle.encode(d, level), level
