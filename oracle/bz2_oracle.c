@@ -1187,3 +1187,363 @@ BZO_EXPORT size_t bzo_mtf_zle(const uint8_t *block, size_t n, const size_t *sa,
     *in_use_count_out = (uint32_t)in_use_count;
     return mtf_count;
 }
+
+/* ==========================================================================
+ * BZip2 DECODER restatement (src/bzip2/decoder.rs, src/huffman/decoder.rs,
+ * src/bitio/reader.rs, src/bzip2/mtf.rs:45-65).  Same rules as above: test
+ * infrastructure only.
+ *
+ * Pinned by: data/sample1-4.bz2 -> sample1-4.ref (src/bzip2/mod.rs:84-148, incl.
+ * the two-stream sample4), round trips of the encoder restatement, and libbzip2
+ * streams.  Known deviation: where the reference PANICS on malformed code-length
+ * tables (unreachable!() / out-of-bounds in huffman/decoder.rs:150-206) this
+ * restatement reports DataError.
+ * ========================================================================== */
+#include "bz2_rnums.h"
+
+/* BZip2Error, src/bzip2/error.rs:5-11 (as negative status codes of the C ABI) */
+#define BZE_DATA (-1)
+#define BZE_EOF (-2)
+#define BZE_UNEXPECTED (-3)
+#define BZE_MAGIC_FIRST (-4)
+#define BZE_MAGIC (-5)
+
+/* BitReader<Left> over a byte buffer (bitio/reader.rs:70-186).  At the end of the input a read
+ * does not fail: it returns the bits that are left (possibly none) as a shorter number. */
+typedef struct { const uint8_t *p; uint64_t nbits, pos; } bit_reader;
+
+static uint32_t br_peek(const bit_reader *r, unsigned len, unsigned *got)
+{
+    uint64_t avail = r->nbits - r->pos;
+    unsigned k = (avail < len) ? (unsigned)avail : len;
+    uint32_t v = 0;
+    for (unsigned i = 0; i < k; i++) {
+        uint64_t b = r->pos + i;
+        v = (v << 1) | ((r->p[b >> 3] >> (7 - (b & 7))) & 1u);
+    }
+    *got = k;
+    return v;
+}
+static void br_skip(bit_reader *r, unsigned len)
+{
+    uint64_t avail = r->nbits - r->pos;
+    r->pos += (avail < len) ? avail : len;
+}
+static uint32_t br_read(bit_reader *r, unsigned len)
+{
+    unsigned got;
+    uint32_t v = br_peek(r, len, &got);
+    br_skip(r, got);
+    return v;
+}
+
+/* HuffmanDecoder::<Left>::new(l, 12) + dec (huffman/decoder.rs:98-233), as canonical first-code
+ * tables: equivalent for every table the reference accepts. */
+typedef struct {
+    uint8_t len[258];
+    uint32_t code[258];
+    unsigned alpha, max_len, stab_bits;
+    int valid;
+} huff_dec;
+
+static int huff_dec_new(huff_dec *h, const uint8_t *len, unsigned alpha)
+{
+    memset(h, 0, sizeof(*h));
+    h->alpha = alpha;
+    unsigned max_len = 0;
+    for (unsigned i = 0; i < alpha; i++) { h->len[i] = len[i]; if (len[i] > max_len) max_len = len[i]; }
+    h->max_len = max_len;
+    h->stab_bits = max_len < 12 ? max_len : 12;
+    if (max_len >= 32) return -1;                       /* "length error", :113-115 */
+    bzo_canonical_codes(len, alpha, h->code);           /* create_huffman_table, huffman/mod.rs:22-67 */
+    /* the reference fills a table / tree; an over-subscribed set of lengths indexes out of bounds
+     * (panic), a Leaf/Branch clash is Err -> DataError.  Both become "invalid" here. */
+    for (unsigned i = 0; i < alpha; i++)
+        if (len[i] && (h->code[i] >> len[i]) != 0) return -1;
+    h->valid = 1;
+    return 0;
+}
+
+/* returns symbol, or -1 = Ok(None) (no bits left), -2 = Err / unreachable */
+static int huff_dec_sym(const huff_dec *h, bit_reader *r)
+{
+    unsigned got;
+    uint32_t c = br_peek(r, h->stab_bits, &got);
+    if (got == 0) return -1;                            /* :204-207 */
+    (void)c;
+    /* walk the canonical code: read up to max_len bits (zero padded past the end, like the
+     * reference's shifted peek) and find the symbol whose code matches */
+    uint32_t acc = 0;
+    for (unsigned l = 1; l <= h->max_len; l++) {
+        unsigned g;
+        uint64_t save = r->pos;
+        r->pos += l - 1;
+        uint32_t bit = (r->pos < r->nbits) ? br_peek(r, 1, &g) : 0;
+        r->pos = save;
+        acc = (acc << 1) | bit;
+        for (unsigned s = 0; s < h->alpha; s++) {
+            if (h->len[s] == l && h->code[s] == acc) {
+                /* bits beyond the table width are consumed one by one by the tree walk, which
+                 * fails at the end of the input (:221-224) */
+                if (l > h->stab_bits && save + l > r->nbits) return -2;
+                br_skip(r, l);
+                return (int)s;
+            }
+        }
+    }
+    return -2; /* incomplete code hit: unreachable!() in the reference */
+}
+
+typedef struct {
+    bit_reader rd;
+    /* BZip2DecoderBase, decoder.rs:93-108 */
+    size_t block_no, block_size_100k;
+    uint32_t combined_crc, block_crc, crc_value;
+    uint32_t *tt; size_t tt_len;
+    size_t n_block_used;
+    uint32_t t_pos;
+    size_t rnd_n2go, rnd_tpos; int block_randomised;
+    size_t result_count, result_wrote_count; uint8_t result_charactor;
+    size_t stream_no;
+} bzo_dec;
+
+/* MtfPositionDecoder::pop, mtf.rs:51-64 */
+static size_t mtfd_pop(size_t *data, size_t value)
+{
+    if (value == 0) return data[0];
+    size_t t = data[value];
+    for (size_t i = value; i-- > 0;) data[i + 1] = data[i];
+    data[0] = t;
+    return t;
+}
+
+/* decoder.rs:163-525.  1 = Ok(true), 0 = Ok(false), <0 = Err */
+static int dec_init_block(bzo_dec *d)
+{
+    bit_reader *r = &d->rd;
+    for (;;) {
+        if (d->block_no == 0) {
+            int magic_err = d->stream_no == 1 ? BZE_MAGIC_FIRST : BZE_MAGIC;
+            (void)br_read(r, 8); (void)br_read(r, 8); (void)br_read(r, 8); /* 'B','Z','h': read, not compared (:175-180) */
+            uint32_t b = br_read(r, 8);
+            if (b < 1 + 0x30 || b > 9 + 0x30) return magic_err;            /* :184-186 */
+            d->block_size_100k = b - 0x30;
+        } else {
+            uint32_t data_block_crc = ~d->crc_value;                         /* :189-201 */
+            if (data_block_crc != d->block_crc) return BZE_DATA;
+            d->combined_crc = ((d->combined_crc << 1) | (d->combined_crc >> 31)) ^ d->block_crc;
+            d->crc_value = 0xFFFFFFFFu;
+        }
+        uint32_t head = br_read(r, 8);
+        if (head == 0x31) {
+            for (int k = 0; k < 5; k++) (void)br_read(r, 8);                 /* :207-221: read, not compared */
+            d->block_no += 1;
+            d->block_crc = br_read(r, 32);
+            d->block_randomised = br_read(r, 1) == 1;
+            size_t orig_pos = br_read(r, 24);
+            if (orig_pos > 10 + 100000 * d->block_size_100k) return BZE_DATA; /* :238 */
+            size_t seq2unseq[256], n_in_use = 0;
+            {
+                int in_use16[16];
+                for (int i = 0; i < 16; i++) in_use16[i] = br_read(r, 1) == 1;
+                for (int i = 0; i < 16; i++)
+                    if (in_use16[i])
+                        for (int j = 0; j < 16; j++)
+                            if (br_read(r, 1) == 1) seq2unseq[n_in_use++] = (size_t)(i * 16 + j);
+            }
+            if (n_in_use == 0) return BZE_DATA;                               /* :273-275 */
+            size_t alpha_size = n_in_use + 2;
+            size_t n_groups = br_read(r, 3);
+            if (n_groups < 2 || n_groups > 6) return BZE_DATA;
+            size_t n_selectors = br_read(r, 15);
+            if (n_selectors < 1) return BZE_DATA;
+            uint8_t *selector = (uint8_t *)malloc(n_selectors);
+            {
+                size_t lst[6];
+                for (size_t i = 0; i < n_groups; i++) lst[i] = i;
+                for (size_t s = 0; s < n_selectors; s++) {
+                    size_t j = 0;
+                    while (br_read(r, 1) != 0) {
+                        j += 1;
+                        if (j >= n_groups) { free(selector); return BZE_DATA; }
+                    }
+                    selector[s] = (uint8_t)mtfd_pop(lst, j);
+                }
+            }
+            uint8_t len[6][258];
+            for (size_t t = 0; t < n_groups; t++) {                            /* :318-348 */
+                uint32_t curr = br_read(r, 5);
+                for (size_t i = 0; i < alpha_size; i++) {
+                    while (br_read(r, 1) != 0) {
+                        if (curr < 1 || curr > 20) { free(selector); return BZE_DATA; }
+                        if (br_read(r, 1) == 0) curr += 1; else curr -= 1;
+                    }
+                    len[t][i] = (uint8_t)curr;
+                }
+            }
+            huff_dec *code = (huff_dec *)malloc(n_groups * sizeof(huff_dec));
+            for (size_t t = 0; t < n_groups; t++)
+                if (huff_dec_new(&code[t], len[t], (unsigned)alpha_size) != 0) { free(code); free(selector); return BZE_DATA; }
+            uint16_t eob = (uint16_t)(alpha_size - 1);
+            size_t nblock_max = 100000 * d->block_size_100k;
+            size_t unzftab[257];
+            memset(unzftab, 0, sizeof(unzftab));
+            d->tt = (uint32_t *)realloc(d->tt, (nblock_max + 1) * sizeof(uint32_t));
+            d->tt_len = 0;
+            int err = 0;
+            {
+                size_t group_no = 0, group_pos = 0, n = 1, es = 0;
+                size_t mtf[256];
+                for (size_t i = 0; i < n_in_use; i++) mtf[i] = i;
+                for (;;) {
+                    if (group_pos == 0) {
+                        group_no += 1;
+                        if (group_no > n_selectors) { err = BZE_DATA; break; }
+                        group_pos = BZ_G_SIZE;
+                    }
+                    group_pos -= 1;
+                    int sym = huff_dec_sym(&code[selector[group_no - 1]], r);
+                    if (sym < 0) { err = BZE_DATA; break; }
+                    if (es > 0 && sym != 0 && sym != 1) {
+                        size_t uc = seq2unseq[mtfd_pop(mtf, 0)];
+                        unzftab[uc + 1] += es;
+                        if (d->tt_len + es > nblock_max) { /* Vec::push would grow; the check below rejects it */
+                            err = BZE_DATA; break;
+                        }
+                        for (size_t k = 0; k < es; k++) d->tt[d->tt_len++] = (uint32_t)uc;
+                        if (d->tt_len >= nblock_max) { err = BZE_DATA; break; }
+                        n = 1; es = 0;
+                    }
+                    if ((uint16_t)sym == eob) break;
+                    if (n >= 2 * 1024 * 1024) { err = BZE_DATA; break; }
+                    if (sym == 0) { es += n; n <<= 1; }
+                    else if (sym == 1) { n <<= 1; es += n; }
+                    else {
+                        if (d->tt_len >= nblock_max) { err = BZE_DATA; break; }
+                        size_t uc = seq2unseq[mtfd_pop(mtf, (size_t)sym - 1)];
+                        unzftab[uc + 1] += 1;
+                        d->tt[d->tt_len++] = (uint32_t)uc;
+                    }
+                }
+            }
+            free(code); free(selector);
+            if (err) return err;
+            if (orig_pos >= d->tt_len) return BZE_DATA;                        /* :441-443 */
+            if (unzftab[0] != 0) return BZE_DATA;
+            for (size_t i = 1; i < 257; i++) {
+                unzftab[i] += unzftab[i - 1];
+                if (unzftab[i - 1] > unzftab[i]) return BZE_DATA;
+            }
+            if (unzftab[256] != d->tt_len) return BZE_DATA;
+            for (size_t i = 0; i < d->tt_len; i++) {                           /* :468-473 */
+                size_t uc = d->tt[i] & 0xFF;
+                d->tt[unzftab[uc]] |= (uint32_t)i << 8;
+                unzftab[uc] += 1;
+            }
+            d->t_pos = d->tt[orig_pos] >> 8;
+            d->n_block_used = 0;
+            if (d->block_randomised) { d->rnd_n2go = 0; d->rnd_tpos = 0; }
+            d->result_count = 0;
+            d->result_wrote_count = 0;
+            return 1;
+        } else if (head == 0x17) {
+            for (int k = 0; k < 5; k++) (void)br_read(r, 8);
+            uint32_t stored = br_read(r, 32);
+            if (stored != d->combined_crc) return BZE_DATA;
+            r->pos = (r->pos + 7) & ~(uint64_t)7;                              /* skip_to_next_byte */
+            if (r->pos > r->nbits) r->pos = r->nbits;
+            unsigned got;
+            (void)br_peek(r, 8, &got);
+            if (got == 8) {
+                d->block_no = 0;
+                d->combined_crc = 0;
+                d->stream_no += 1;
+            } else {
+                return 0;
+            }
+        } else {
+            return BZE_DATA;
+        }
+    }
+}
+
+/* decoder.rs:527-542 */
+static int dec_next_lfm(bzo_dec *d, uint8_t *out)
+{
+    uint32_t position = d->t_pos;
+    if (position >= 100000 * (uint32_t)d->block_size_100k) return BZE_DATA;
+    position = d->tt[position];
+    uint8_t k0 = (uint8_t)position;
+    d->t_pos = position >> 8;
+    d->n_block_used += 1;
+    if (d->block_randomised) {
+        if (d->rnd_n2go == 0) {
+            d->rnd_n2go = kBz2RNums[d->rnd_tpos];
+            d->rnd_tpos += 1;
+            if (d->rnd_tpos == 512) d->rnd_tpos = 0;
+        }
+        d->rnd_n2go -= 1;
+        k0 ^= (d->rnd_n2go == 1) ? 1 : 0;
+    }
+    *out = k0;
+    return 0;
+}
+
+/* BitDecodeService::next, decoder.rs:545-581.  1 = byte, 0 = None, <0 error */
+static int dec_next(bzo_dec *d, uint8_t *out)
+{
+    if (d->result_count == d->result_wrote_count) {
+        if (d->n_block_used == d->tt_len) {
+            int rc = dec_init_block(d);
+            if (rc <= 0) return rc;
+        }
+        uint8_t buffer;
+        int rc = dec_next_lfm(d, &buffer);
+        if (rc) return rc;
+        if (buffer == d->result_charactor && d->result_count < 4) {
+            d->result_count += 1;
+            d->result_wrote_count += 1;
+        } else {
+            d->result_charactor = buffer;
+            d->result_count = 1;
+            d->result_wrote_count = 1;
+        }
+        if (d->result_count == 4) {
+            uint8_t c;
+            rc = dec_next_lfm(d, &c);
+            if (rc) return rc;
+            d->result_count += c;
+        }
+    } else {
+        d->result_wrote_count += 1;
+    }
+    d->crc_value = crc_update_normal(d->crc_value, d->result_charactor);
+    *out = d->result_charactor;
+    return 1;
+}
+
+/* `bytes.decode(&mut BZip2Decoder::new()).collect()`: decodes until None or the first error.
+ * Returns the number of bytes produced (those before an error are kept, as the iterator would have
+ * yielded them); *status = 0 or the BZip2Error code. */
+BZO_EXPORT size_t bzo_decode_buffer(const uint8_t *in, size_t n, uint8_t *out, size_t cap, int *status)
+{
+    if (!g_crc_ready) crc_make_table_normal(0x04C11DB7u);
+    bzo_dec d;
+    memset(&d, 0, sizeof(d));
+    d.rd.p = in; d.rd.nbits = (uint64_t)n * 8; d.rd.pos = 0;
+    d.crc_value = 0xFFFFFFFFu;
+    d.stream_no = 1;
+    size_t o = 0;
+    int st = 0;
+    for (;;) {
+        uint8_t b;
+        int rc = dec_next(&d, &b);
+        if (rc == 0) break;
+        if (rc < 0) { st = rc; break; }
+        if (o >= cap) { st = -100; break; }
+        out[o++] = b;
+    }
+    free(d.tt);
+    if (status) *status = st;
+    return o;
+}

@@ -229,3 +229,20 @@ def mtf_zle(block: bytes, sa):
     iu = C.c_uint32(0)
     k = lib().bzo_mtf_zle(block, n, sa_c, out, freq, C.byref(op), C.byref(iu))
     return list(out[:k]), list(freq), op.value, iu.value
+
+
+def decode(z: bytes, cap: int = None):
+    """`z.iter().cloned().decode(&mut BZip2Decoder::new()).collect()`: returns (bytes, status);
+    status 0 = ok, else the BZip2Error code (-1 DataError, -2 UnexpectedEof, -3 Unexpected,
+    -4 DataErrorMagicFirst, -5 DataErrorMagic).  Bytes decoded before an error are returned too."""
+    z = bytes(z)
+    L = lib()
+    if not hasattr(L, "_dec_ready"):
+        L.bzo_decode_buffer.restype = C.c_size_t
+        L.bzo_decode_buffer.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_int)]
+        L._dec_ready = True
+    cap = cap or max(1 << 20, len(z) * 300 + 1024)
+    out = (C.c_uint8 * cap)()
+    st = C.c_int(0)
+    k = L.bzo_decode_buffer(z, len(z), out, cap, C.byref(st))
+    return C.string_at(out, k), st.value
