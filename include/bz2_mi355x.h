@@ -1,8 +1,10 @@
 /*
- * bz2_mi355x.h -- C ABI of the MI355X-native BZip2 block-encode path.
+ * bz2_mi355x.h -- C ABI of the MI355X-native BZip2 block-encode path (sections
+ * 1-2) and of the matching decode path (section 3).
  *
  * This is the drop-in boundary for ONE hot path of chalharu/rust-compression:
- *   `iter.encode(&mut BZip2Encoder::new(level), action)`  (BZip2 encode).
+ *   `iter.encode(&mut BZip2Encoder::new(level), action)`  (BZip2 encode),
+ * widened by its inverse `iter.decode(&mut BZip2Decoder::new())`.
  * The reference is pure Rust and has no FFI of its own; each entry point below
  * names the reference interface it replaces (paths relative to the reference
  * repo).  A Rust shim re-implements `Encoder::next` on top
@@ -29,7 +31,7 @@ extern "C" {
 /* ---- status codes -------------------------------------------------------
  * 0 = ok.  -1..-3 mirror CompressionError::{DataError,UnexpectedEof,Unexpected}
  * (src/error.rs:10-15); -4/-5 are BZip2Error::{DataErrorMagicFirst,DataErrorMagic}
- * (src/bzip2/error.rs:5-11, reserved for the decoder rows).  The encoder can
+ * (src/bzip2/error.rs:5-11, produced by the decoder entry points of section 3).  The encoder can
  * only fail with BZ_E_UNEXPECTED in the reference (src/bzip2/encoder.rs:623);
  * HIP failures map to it too. */
 #define BZ_OK 0
@@ -215,6 +217,52 @@ int bz_gpu_debug_code_lengths(bz_gpu_engine *g, const uint32_t *h_freq, size_t a
  * nblock, crc, origPtr, mtf_count, in_use_count, group_num, n_selectors, max_len */
 int bz_gpu_debug_block_stats(bz_gpu_engine *g, uint32_t *h_stats, size_t cap_blocks,
                              size_t *n_blocks);
+
+/* ========================================================================
+ * 3. Decoder  ==  `BZip2Decoder`  (src/bzip2/decoder.rs:583-612; the work is
+ *    BZip2DecoderBase::init_block / next, src/bzip2/decoder.rs:163-581)
+ *
+ * The decode calls return the DECODER'S verdict: BZ_OK, BZ_E_DATA
+ * (BZip2Error::DataError), BZ_E_MAGIC_FIRST / BZ_E_MAGIC (bad level digit of
+ * the first / a later stream header), or an infrastructure status
+ * (BZ_E_NOGPU, BZ_E_NOMEM, BZ_E_CAPACITY, BZ_E_UNEXPECTED).  With a decoder
+ * error the bytes of all blocks in front of the failing record are still
+ * produced -- exactly the items the reference's iterator yields before its
+ * Err (a block whose CRC is wrong is handed out first, src/bzip2/decoder.rs:189-201).
+ * Multi-stream files decode to the concatenation (src/bzip2/decoder.rs:503-516).
+ * ======================================================================== */
+
+/* Whole file on one GPU: d_in[n] (HBM, 4-byte aligned) -> d_out (HBM, cap
+ * bytes).  *out_len = bytes decoded.  d_out == NULL: sizes only (nothing is
+ * written, CRCs are not checked), to learn the capacity a second call needs. */
+int bz_gpu_decode_device(bz_gpu_engine *g, const void *d_in, size_t n,
+                         void *d_out, size_t cap, size_t *out_len);
+/* Seconds of GPU time of the last decode by stage (HIP events):
+ * [0] magic scan + Huffman [1] zero runs + inverse MTF [2] inverse BWT
+ * [3] RLE1 undo + CRC [4] total. */
+int bz_gpu_last_decode_timings(bz_gpu_engine *g, double out_seconds[5]);
+/* [0] block-magic candidates [1] blocks decoded [2] streams [3] blocks that
+ * started without the full 48-bit magic */
+int bz_gpu_last_decode_stats(bz_gpu_engine *g, uint64_t out[4]);
+
+/* One-shot over host buffers: `in.iter().cloned().decode(&mut BZip2Decoder::new())`
+ * collected until None or the first Err.  *out (malloc'ed, release with
+ * bz_free) holds the bytes yielded before the verdict, also when that is an error. */
+int bz_decode_buffer(int device, const uint8_t *in, size_t in_len,
+                     uint8_t **out, size_t *out_len);
+
+/* Streaming context == BZip2Decoder as the DecodeIterator drives it
+ * (src/traits/decoder.rs:73-86): compressed bytes in (bz_dec_write), end of
+ * the input iterator (bz_dec_end: decodes, returns the verdict), decoded bytes
+ * out in order (bz_dec_read: > 0 bytes copied; when nothing is left, the
+ * verdict -- 0 = `None`, negative = the `Err` item). */
+typedef struct bz_dec bz_dec;
+int bz_dec_create(bz_dec **out, int device);        /* BZip2Decoder::new, src/bzip2/decoder.rs:588-594 */
+int bz_dec_write(bz_dec *d, const uint8_t *data, size_t n);
+int bz_dec_end(bz_dec *d);
+long bz_dec_read(bz_dec *d, uint8_t *out, size_t cap);
+size_t bz_dec_pending(const bz_dec *d);
+void bz_dec_destroy(bz_dec *d);
 
 #ifdef __cplusplus
 }

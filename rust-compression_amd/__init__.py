@@ -1,6 +1,6 @@
-"""rust-compression_amd -- MI355X-native BZip2 block-encode path.
+"""rust-compression_amd -- MI355X-native BZip2 block-encode path (and its inverse, the decode path).
 
-Host-side mirror (Python flavour) of the reference's encode interface for this one path:
+Host-side mirror (Python flavour) of the reference's interface for this one path:
 
     reference (Rust)                                   here
     ------------------------------------------------   ---------------------------------------
@@ -9,6 +9,10 @@ Host-side mirror (Python flavour) of the reference's encode interface for this o
     BZip2Encoder::new(level)     bzip2/encoder.rs:58   BZip2Encoder(level)   (ValueError = the panic)
     Encoder::next(iter, action)  traits/encoder.rs:81  BZip2Encoder.next(iter, action) -> int | None
     iter.encode(&mut enc, act)   traits/encoder.rs:12  encode(iterable, enc, action) -> iterator of ints
+    BZip2Error                   bzip2/error.rs:5-11   BZip2Error(kind)  (a CompressionError, bzip2/error.rs:45-53)
+    BZip2Decoder::new()          bzip2/decoder.rs:588  BZip2Decoder()
+    Decoder::next(iter)          traits/decoder.rs:95  BZip2Decoder.next(iter) -> int | None, raises BZip2Error
+    iter.decode(&mut dec)        traits/decoder.rs:15  decode(iterable, dec) -> iterator of ints
 
 Everything below the iterator plumbing happens in the HIP library (csrc/, C ABI in
 include/bz2_mi355x.h) loaded with ctypes.  There is no CPU implementation in this package: if the
@@ -21,13 +25,15 @@ import os
 
 from . import _build
 
-__all__ = ["Action", "CompressionError", "BZip2Encoder", "encode", "compress", "GpuEngine",
+__all__ = ["Action", "CompressionError", "BZip2Error", "BZip2Encoder", "BZip2Decoder", "encode", "decode",
+           "compress", "decompress", "GpuEngine",
            "build", "lib", "device_count", "encode_bound"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 BZ_OK, BZ_E_DATA, BZ_E_EOF, BZ_E_UNEXPECTED = 0, -1, -2, -3
+BZ_E_MAGIC_FIRST, BZ_E_MAGIC = -4, -5
 BZ_E_PARAM, BZ_E_NOGPU, BZ_E_NOMEM, BZ_E_CAPACITY = -6, -7, -8, -9
 
 
@@ -50,6 +56,20 @@ class CompressionError(Exception):
         super().__init__("%s (%d): %s" % (self.kind, code, msg))
 
 
+class BZip2Error(CompressionError):
+    """src/bzip2/error.rs:5-11.  `kind` is the BZip2Error variant; as a CompressionError the two
+    magic variants are DataError (bzip2/error.rs:45-53)."""
+    BZ_KINDS = {BZ_E_DATA: "DataError", BZ_E_MAGIC_FIRST: "DataErrorMagicFirst", BZ_E_MAGIC: "DataErrorMagic",
+                BZ_E_EOF: "UnexpectedEof", BZ_E_UNEXPECTED: "Unexpected"}
+
+    def __init__(self, code, partial=b""):
+        super().__init__(code)
+        self.bzip2_kind = self.BZ_KINDS.get(code, "Unexpected")
+        if code in (BZ_E_MAGIC_FIRST, BZ_E_MAGIC):
+            self.kind = "DataError"
+        self.partial = partial  # bytes the iterator yielded before this Err
+
+
 def build(force=False):
     """Compile csrc/*.hip for gfx950 into rust-compression_amd/libbz2_mi355x.so (in-tree)."""
     return _build.build(force=force)
@@ -64,6 +84,8 @@ EXPORTS = [
     "bz_gpu_partition_slab_finish", "bz_gpu_encode_blocks", "bz_gpu_assemble", "bz_gpu_last_timings",
     "bz_gpu_last_bwt_stats", "bz_gpu_last_bwt_rounds", "bz_gpu_profile_enable", "bz_gpu_profile_kernels", "bz_gpu_profile_get",
     "bz_gpu_debug_bwt", "bz_gpu_debug_code_lengths", "bz_gpu_debug_block_stats",
+    "bz_gpu_decode_device", "bz_gpu_last_decode_timings", "bz_gpu_last_decode_stats", "bz_decode_buffer",
+    "bz_dec_create", "bz_dec_write", "bz_dec_end", "bz_dec_read", "bz_dec_pending", "bz_dec_destroy",
 ]
 
 
@@ -137,6 +159,19 @@ def lib():
     L.bz_gpu_debug_bwt.argtypes = [vp, C.c_char_p, sz, u32p]
     L.bz_gpu_debug_code_lengths.argtypes = [vp, u32p, sz, u8p, C.POINTER(C.c_int)]
     L.bz_gpu_debug_block_stats.argtypes = [vp, u32p, sz, szp]
+    L.bz_gpu_decode_device.argtypes = [vp, vp, sz, vp, sz, szp]
+    L.bz_gpu_last_decode_timings.argtypes = [vp, C.POINTER(C.c_double)]
+    L.bz_gpu_last_decode_stats.argtypes = [vp, u64p]
+    L.bz_decode_buffer.argtypes = [C.c_int, C.c_char_p, sz, C.POINTER(u8p), szp]
+    L.bz_dec_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.bz_dec_write.argtypes = [vp, C.c_char_p, sz]
+    L.bz_dec_end.argtypes = [vp]
+    L.bz_dec_read.restype = C.c_long
+    L.bz_dec_read.argtypes = [vp, u8p, sz]
+    L.bz_dec_pending.restype = sz
+    L.bz_dec_pending.argtypes = [vp]
+    L.bz_dec_destroy.restype = None
+    L.bz_dec_destroy.argtypes = [vp]
     _LIB = L
     return L
 
@@ -250,6 +285,100 @@ def compress(data, level=9, device=0):
         lib().bz_free(out)
 
 
+_DECODER_VERDICTS = (BZ_E_DATA, BZ_E_MAGIC_FIRST, BZ_E_MAGIC)
+
+
+class BZip2Decoder:
+    """`BZip2Decoder` (src/bzip2/decoder.rs:583-612) over the C ABI's streaming context."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().bz_dec_create(C.byref(self._h), device))
+        self._buf = (C.c_uint8 * 65536)()
+        self._ready = b""
+        self._pos = 0
+        self._ended = False
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _LIB is not None:
+            _LIB.bz_dec_destroy(self._h)
+            self._h = None
+
+    def _refill(self):
+        """bytes fetched, or 0 at the clean end; raises the decoder's Err item"""
+        k = lib().bz_dec_read(self._h, self._buf, len(self._buf))
+        if k < 0:
+            raise BZip2Error(k) if k in _DECODER_VERDICTS else CompressionError(k)
+        self._ready = C.string_at(self._buf, k)
+        self._pos = 0
+        return k
+
+    def _end(self):
+        if not self._ended:
+            self._ended = True
+            rc = lib().bz_dec_end(self._h)
+            if rc != BZ_OK and rc not in _DECODER_VERDICTS:
+                raise CompressionError(rc)  # infrastructure (no GPU, memory ...): nothing was decoded
+
+    def next(self, it):
+        """One `Decoder::next(iter)` call: an int byte, None at the end, raises BZip2Error for Err."""
+        if self._pos >= len(self._ready):
+            if not self._ended:
+                chunk = bytes(bytearray(it))  # the reference pulls bytes on demand; the bytes are the same
+                if chunk:
+                    _check(lib().bz_dec_write(self._h, chunk, len(chunk)))
+                self._end()
+            if self._refill() == 0:
+                return None
+        b = self._ready[self._pos]
+        self._pos += 1
+        return b
+
+    def decode_all(self, data):
+        """`data.decode(&mut self).collect::<Result<Vec<_>, _>>()`; BZip2Error.partial holds the bytes
+        yielded before an Err."""
+        data = bytes(data)
+        if data:
+            _check(lib().bz_dec_write(self._h, data, len(data)))
+        self._end()
+        out = bytearray(self._ready[self._pos:])
+        self._ready, self._pos = b"", 0
+        while True:
+            try:
+                if not self._refill():
+                    break
+            except BZip2Error as e:
+                e.partial = bytes(out)
+                raise
+            out += self._ready
+            self._ready, self._pos = b"", 0
+        return bytes(out)
+
+
+def decode(iterable, decoder):
+    """`DecodeExt::decode` / `DecodeIterator` (src/traits/decoder.rs:15-86)."""
+    it = iter(iterable)
+    while True:
+        b = decoder.next(it)
+        if b is None:
+            return
+        yield b
+
+
+def decompress(data, device=0):
+    """One-shot over host buffers (bz_decode_buffer) -> (bytes yielded, verdict code)."""
+    data = bytes(data)
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t(0)
+    rc = lib().bz_decode_buffer(device, data, len(data), C.byref(out), C.byref(n))
+    if rc != BZ_OK and rc not in _DECODER_VERDICTS:
+        raise CompressionError(rc)
+    try:
+        return C.string_at(out, n.value), rc
+    finally:
+        lib().bz_free(out)
+
+
 class GpuEngine:
     """Device-resident engine (section 2 of the C ABI).  Pointers are plain ints
     (e.g. torch.Tensor.data_ptr())."""
@@ -313,6 +442,26 @@ class GpuEngine:
                                      carry_bits, carry_byte, combined_crc, C.byref(comb), d_out, cap,
                                      C.byref(out_len), C.byref(ocb), C.byref(ocy)))
         return out_len.value, comb.value, ocb.value, ocy.value
+
+    DEC_STAGES = ("scan_huffman", "mtf", "inverse_bwt", "rle1_crc", "total")
+
+    def decode_device(self, d_in, n, d_out, cap):
+        """-> (bytes decoded, verdict).  d_out = None: sizes only."""
+        out_len = C.c_size_t(0)
+        rc = lib().bz_gpu_decode_device(self._h, d_in, n, d_out, cap, C.byref(out_len))
+        if rc != BZ_OK and rc not in _DECODER_VERDICTS:
+            raise CompressionError(rc)
+        return out_len.value, rc
+
+    def decode_timings(self):
+        t = (C.c_double * 5)()
+        _check(lib().bz_gpu_last_decode_timings(self._h, t))
+        return dict(zip(self.DEC_STAGES, t))
+
+    def decode_stats(self):
+        s = (C.c_uint64 * 4)()
+        _check(lib().bz_gpu_last_decode_stats(self._h, s))
+        return dict(zip(("candidates", "blocks", "streams", "forced_blocks"), [int(x) for x in s]))
 
     def timings(self):
         t = (C.c_double * 6)()

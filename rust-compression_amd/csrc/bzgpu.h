@@ -165,6 +165,22 @@ __host__ __device__ inline u32 gf_mulmod(u32 a, u32 b)
     return r;
 }
 
+// xp2[k] = x^(8 * 2^k) mod P, k = 0..47
+__device__ __forceinline__ u32 gf_xpow_bytes(u64 nbytes, const u32 *__restrict__ xp2)
+{
+    u32 r = 1u;
+    for (u32 k = 0; nbytes; ++k, nbytes >>= 1)
+        if (nbytes & 1u) r = gf_mulmod(r, xp2[k]);
+    return r;
+}
+
+__device__ __forceinline__ u32 crc_bytes_raw(const u8 *__restrict__ p, u64 len, const u32 *s_tab)
+{
+    u32 crc = 0;
+    for (u64 i = 0; i < len; ++i) crc = s_tab[(crc >> 24) ^ p[i]] ^ (crc << 8);
+    return crc;
+}
+
 
 // ---- argument blocks shared by the kernels (k_*.hip) and the host code (engine.hip) ----------
 struct RleBuffers {
@@ -247,6 +263,56 @@ struct AsmBlock {
 struct PackBlock {
     u64 src_word, dst_word, nwords;
 };
+
+// ---- decoder records -------------------------------------------------------------------------------
+constexpr int BZ_DEC_E_DATA = -1; // BZip2Error::DataError (src/bzip2/error.rs:5-11)
+struct DecCand {
+    u64 bitpos; // first bit of a 48-bit magic
+    u32 type;   // 1 block, 2 end of stream
+    u32 pad;
+};
+struct DecBlockInfo {
+    u64 end_bit;    // first bit after the block's data (after the stored CRC for an end-of-stream record)
+    u32 status;     // 0 or a BZ_DEC_E_* code (as u32)
+    u32 stored_crc; // block CRC / combined CRC
+    u32 orig_ptr;
+    u32 randomised;
+    u32 n_in_use;
+    u32 nsym;       // symbols decoded, EOB included
+    u8 seq2unseq[256];
+};
+
+constexpr u32 kDecSamples = kMaxBlockLen / 1024 + 3; // inverse-BWT sample nodes per block (+ the start node)
+constexpr u32 kDecTiles = kMaxBlockLen / 1024 + 2;   // RLE1-undo tiles per block
+struct DecArgs {
+    u32 nb;
+    const u32 *slot;              // [nb] candidate slot (index into info / sym) of each true block, stream order
+    const DecBlockInfo *info;     // [slots]
+    const u16 *sym;               // [slots][kMtfStride] Huffman symbols
+    const u32 *nblock_max;        // [nb] 100000 * level of the block's stream
+    u8 *perm;                     // [nb][kMaxMtfChunks][256] chunk permutations, then start lists
+    u32 *chunk_emit;              // [nb][kMaxMtfChunks] bytes a chunk emits, then their exclusive sums
+    u32 *tt_len;                  // [nb] length of the BWT column
+    u32 *err;                     // [nb] 0 or 1 (DataError found while rebuilding the block)
+    u8 *L;                        // [nb * kSlot] BWT column
+    u32 *T;                       // [nb * kSlot] T vector
+    u8 *X;                        // [nb * kSlot] RLE1 image
+    u32 *samp_next, *samp_len, *samp_off; // [nb][kDecSamples]
+    u32 *cycle_len;               // [nb]
+    u32 *tile_off, *tile_state;   // [nb][kDecTiles] RLE1 undo: output offset / state per 1024-byte tile
+    u32 *out_len;                 // [nb]
+    u32 *thist;                   // [nb][kTilesPerBlock][256] T-vector sort: per-tile byte counts
+    u32 *tbase;                   // [nb][256]
+    u32 *crc;                     // [nb] CRC of the block's output bytes
+};
+void launch_dec_scan(hipStream_t st, const u8 *in, u64 nbytes, DecCand *cands, u32 cap, u32 *count);
+void launch_dec_blocks(hipStream_t st, const u8 *in, u64 nbytes, const DecCand *cands, u32 ncand, DecBlockInfo *info,
+                       u16 *sym, u8 *sel_scratch);
+void launch_dec_mtf(hipStream_t st, const DecArgs &a);
+void launch_dec_walks(hipStream_t st, const DecArgs &a);
+void launch_dec_expand(hipStream_t st, const DecArgs &a, const u64 *out_base, u8 *out);
+void launch_dec_crc(hipStream_t st, const DecArgs &a, const u64 *out_base, const u8 *out, u32 max_out_len,
+                    const u32 *crc_tab, const u32 *xp2);
 
 // ---- per-kernel timing (HIP events on the launch stream) -------------------------------------------
 // Off by default.  When on, every launch of the listed kernels is bracketed by two events; the

@@ -1,0 +1,576 @@
+// dec_engine.hip -- host orchestration of the BZip2 DECODE path and its C ABI
+// (include/bz2_mi355x.h, section 3).  Kernels: k_dec.hip.
+//
+// Reference being replaced: `bytes.decode(&mut BZip2Decoder::new())` --
+// BZip2DecoderBase::init_block / next (src/bzip2/decoder.rs:163-581).
+//
+// The record chain of a .bz2 file (stream header, blocks, end-of-stream record, next stream ...)
+// is walked on the host from the per-candidate results of kernel D1; everything that touches
+// payload bytes runs on the GPU.  Error behaviour follows the reference's iterator: the bytes of
+// all blocks in front of the failing record are produced, then the error (a block CRC mismatch
+// is only noticed after that block's bytes were handed out, decoder.rs:189-201).
+#include "engine_state.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+
+constexpr u32 kForcedSlots = 16; // blocks per batch that start without a full 48-bit magic
+
+struct Ev {
+    hipEvent_t a = nullptr, b = nullptr;
+};
+
+} // namespace
+
+struct DecWorkspace {
+    size_t slots = 0;
+    DevBuf cands, count, info, sym, sel, slot, nbmax, perm, chunk_emit, tt_len, err, L, T, X, samp_next, samp_len,
+        samp_off, cycle_len, tile_off, tile_state, out_len, thist, tbase, crc, out_base, staging, cand_all;
+    double t_stage[5] = {0, 0, 0, 0, 0};
+    u64 stats[4] = {0, 0, 0, 0}; // candidates, blocks, streams, forced blocks
+};
+
+void dec_workspace_free(DecWorkspace *w)
+{
+    if (!w) return;
+    DevBuf *all[] = {&w->cands, &w->count, &w->info, &w->sym, &w->sel, &w->slot, &w->nbmax, &w->perm,
+                     &w->chunk_emit, &w->tt_len, &w->err, &w->L, &w->T, &w->X, &w->samp_next, &w->samp_len,
+                     &w->samp_off, &w->cycle_len, &w->tile_off, &w->tile_state, &w->out_len, &w->thist, &w->tbase,
+                     &w->crc, &w->out_base, &w->staging, &w->cand_all};
+    for (DevBuf *b : all) b->release();
+    delete w;
+}
+
+static int dec_ensure(DecWorkspace *w, size_t slots)
+{
+    if (slots <= w->slots) return BZ_OK;
+    int rc = BZ_OK;
+    const size_t s = slots;
+    if ((rc = w->cands.ensure(s * sizeof(DecCand))) || (rc = w->info.ensure(s * sizeof(DecBlockInfo))) ||
+        (rc = w->sym.ensure(s * (size_t)kMtfStride * 2 + 64)) || (rc = w->sel.ensure(s * 32768)) ||
+        (rc = w->slot.ensure(s * 4)) || (rc = w->nbmax.ensure(s * 4)) ||
+        (rc = w->perm.ensure(s * (size_t)kMaxMtfChunks * 256)) || (rc = w->chunk_emit.ensure(s * (size_t)kMaxMtfChunks * 4)) ||
+        (rc = w->tt_len.ensure(s * 4)) || (rc = w->err.ensure(s * 4)) || (rc = w->L.ensure(s * (size_t)kSlot + 64)) ||
+        (rc = w->T.ensure(s * (size_t)kSlot * 4)) || (rc = w->X.ensure(s * (size_t)kSlot + 64)) ||
+        (rc = w->samp_next.ensure(s * (size_t)kDecSamples * 4)) || (rc = w->samp_len.ensure(s * (size_t)kDecSamples * 4)) ||
+        (rc = w->samp_off.ensure(s * (size_t)kDecSamples * 4)) || (rc = w->cycle_len.ensure(s * 4)) ||
+        (rc = w->tile_off.ensure(s * (size_t)kDecTiles * 4)) || (rc = w->tile_state.ensure(s * (size_t)kDecTiles * 4)) ||
+        (rc = w->out_len.ensure(s * 4)) || (rc = w->thist.ensure(s * (size_t)kTilesPerBlock * 256 * 4)) ||
+        (rc = w->tbase.ensure(s * 256 * 4)) || (rc = w->crc.ensure(s * 4)) || (rc = w->out_base.ensure(s * 8)))
+        return rc;
+    w->slots = slots;
+    return BZ_OK;
+}
+
+namespace {
+
+// BitReader<Left> over the input in HBM, for the few header bytes the host looks at.  A read at
+// the end of the input returns the bits that are left as a shorter number (bitio/reader.rs:70-186).
+struct DevBits {
+    const u8 *d = nullptr;
+    u64 nbytes = 0;
+    u8 buf[64];
+    u64 base = ~0ull; // byte offset of buf[0]
+    u64 len = 0;
+    bool failed = false;
+    u32 byte_at(u64 i)
+    {
+        if (i >= nbytes) return 0;
+        if (base == ~0ull || i < base || i >= base + len) {
+            base = i & ~(u64)15;
+            len = (nbytes - base < sizeof(buf)) ? nbytes - base : sizeof(buf);
+            if (hipMemcpy(buf, d + base, len, hipMemcpyDeviceToHost) != hipSuccess) {
+                failed = true;
+                memset(buf, 0, sizeof(buf));
+            }
+        }
+        return buf[i - base];
+    }
+    u32 read(u64 &pos, u32 nbits)
+    {
+        const u64 total = nbytes * 8;
+        const u64 avail = total > pos ? total - pos : 0;
+        const u32 k = avail < nbits ? (u32)avail : nbits;
+        u32 v = 0;
+        for (u32 i = 0; i < k; ++i) {
+            const u64 b = pos + i;
+            v = (v << 1) | ((byte_at(b >> 3) >> (7u - (u32)(b & 7u))) & 1u);
+        }
+        pos += k;
+        return v;
+    }
+};
+
+// where decoded bytes go
+struct Sink {
+    u8 *d_out = nullptr; // device destination (device API) or nullptr
+    u64 cap = 0;
+    bool dry = false;    // sizes only
+    std::vector<u8> *host = nullptr; // host destination (one-shot over host buffers)
+    DevBuf *staging = nullptr;
+    u64 produced = 0;
+};
+
+} // namespace
+
+#define HIPDEC(x)                                                                                     \
+    do {                                                                                              \
+        hipError_t e_ = (x);                                                                          \
+        if (e_ != hipSuccess) {                                                                       \
+            fprintf(stderr, "bz2_mi355x: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__,   \
+                    __LINE__);                                                                        \
+            return BZ_E_UNEXPECTED;                                                                   \
+        }                                                                                             \
+    } while (0)
+
+static inline u32 rotl1(u32 x) { return (x << 1) | (x >> 31); }
+
+// Decodes d_in[n].  Returns an infrastructure status (BZ_OK, BZ_E_NOMEM, BZ_E_UNEXPECTED,
+// BZ_E_CAPACITY); the decoder's own verdict goes to *verdict (BZ_OK, BZ_E_DATA, BZ_E_MAGIC_FIRST,
+// BZ_E_MAGIC) and the bytes produced in front of it to sink.produced.
+static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int *verdict)
+{
+    HIPDEC(hipSetDevice(g->device));
+    if (!g->dec) g->dec = new DecWorkspace();
+    DecWorkspace *w = g->dec;
+    hipStream_t st = g->st;
+    for (double &t : w->t_stage) t = 0;
+    for (u64 &s : w->stats) s = 0;
+    *verdict = BZ_OK;
+    sink.produced = 0;
+    const u64 nbits = n * 8ull;
+
+    hipEvent_t ev[2];
+    HIPDEC(hipEventCreate(&ev[0]));
+    HIPDEC(hipEventCreate(&ev[1]));
+    auto stage_time = [&](int stage) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) w->t_stage[stage] += ms * 1e-3;
+    };
+    struct EvGuard {
+        hipEvent_t *e;
+        ~EvGuard()
+        {
+            (void)hipEventDestroy(e[0]);
+            (void)hipEventDestroy(e[1]);
+        }
+    } ev_guard{ev};
+
+    // ---- D0: every bit position that carries the 48-bit block magic
+    std::vector<DecCand> cands;
+    {
+        int rc;
+        if ((rc = w->count.ensure(16))) return rc;
+        u32 cap = (u32)std::min<u64>(n / 2048 + 1024, 0x7FFFFFFFu);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if ((rc = w->cand_all.ensure((size_t)cap * sizeof(DecCand)))) return rc;
+            HIPDEC(hipEventRecord(ev[0], st));
+            launch_dec_scan(st, d_in, n, w->cand_all.as<DecCand>(), cap, w->count.as<u32>());
+            HIPDEC(hipEventRecord(ev[1], st));
+            u32 cnt = 0;
+            HIPDEC(hipMemcpyAsync(&cnt, w->count.p, 4, hipMemcpyDeviceToHost, st));
+            HIPDEC(hipStreamSynchronize(st));
+            stage_time(0);
+            if (cnt <= cap) {
+                cands.resize(cnt);
+                if (cnt) HIPDEC(hipMemcpy(cands.data(), w->cand_all.p, (size_t)cnt * sizeof(DecCand), hipMemcpyDeviceToHost));
+                break;
+            }
+            cap = cnt;
+        }
+        cands.erase(std::remove_if(cands.begin(), cands.end(), [](const DecCand &c) { return c.type != 1u; }),
+                    cands.end());
+        std::sort(cands.begin(), cands.end(), [](const DecCand &a, const DecCand &b) { return a.bitpos < b.bitpos; });
+    }
+    const size_t nc = cands.size();
+    w->stats[0] = nc;
+
+    u32 B = 1024;
+    if (const char *e = getenv("BZ_DEC_BATCH")) {
+        const long v = atol(e);
+        if (v >= 1 && v <= 65536) B = (u32)v;
+    }
+    if (nc < B) B = (u32)(nc ? nc : 1);
+    {
+        const int rc = dec_ensure(w, (size_t)B + kForcedSlots);
+        if (rc) return rc;
+    }
+
+    DevBits rd;
+    rd.d = d_in;
+    rd.nbytes = n;
+    std::vector<DecBlockInfo> hinfo((size_t)B + kForcedSlots);
+
+    // BZip2DecoderBase state (decoder.rs:93-108) as far as the record chain needs it
+    u64 pos = 0;
+    u32 stream_no = 1, level = 0, combined = 0;
+    bool need_header = true;
+    size_t ci = 0;
+    bool finished = false;
+
+    while (!finished) {
+        // ---- D1 over the next batch of candidates
+        while (ci < nc && cands[ci].bitpos < pos) ++ci;
+        const u32 nb1 = (u32)std::min<size_t>(B, nc - ci);
+        if (nb1) {
+            HIPDEC(hipMemcpyAsync(w->cands.p, cands.data() + ci, (size_t)nb1 * sizeof(DecCand), hipMemcpyHostToDevice, st));
+            HIPDEC(hipEventRecord(ev[0], st));
+            launch_dec_blocks(st, d_in, n, w->cands.as<DecCand>(), nb1, w->info.as<DecBlockInfo>(), w->sym.as<u16>(),
+                              w->sel.as<u8>());
+            HIPDEC(hipEventRecord(ev[1], st));
+            HIPDEC(hipMemcpyAsync(hinfo.data(), w->info.p, (size_t)nb1 * sizeof(DecBlockInfo), hipMemcpyDeviceToHost, st));
+            HIPDEC(hipStreamSynchronize(st));
+            stage_time(0);
+        }
+        // ---- the record chain through this batch
+        std::vector<u32> bslot, bmax, bcrc;
+        u32 nforced = 0;
+        int term = 0; // 0: batch ended, more to come; 1: end of input reached cleanly; <0: error
+        size_t cj = ci;
+        bool stop = false;
+        while (!stop) {
+            if (need_header) { // decoder.rs:171-187: 'B','Z','h' are read, not compared; the level digit is
+                (void)rd.read(pos, 8);
+                (void)rd.read(pos, 8);
+                (void)rd.read(pos, 8);
+                const u32 lv = rd.read(pos, 8);
+                if (lv < 0x31u || lv > 0x39u) {
+                    term = (stream_no == 1) ? BZ_E_MAGIC_FIRST : BZ_E_MAGIC;
+                    break;
+                }
+                level = lv - 0x30u;
+                need_header = false;
+            }
+            u64 p = pos;
+            const u32 head = rd.read(p, 8);
+            if (head == 0x31u) {
+                while (cj < nc && cands[cj].bitpos < pos) ++cj;
+                int slot = -1;
+                if (cj < nc && cands[cj].bitpos == pos) {
+                    if (cj < ci + nb1) slot = (int)(cj - ci);
+                    else {
+                        stop = true; // decoded by the next batch
+                        break;
+                    }
+                } else {
+                    // only the first byte of the block magic is compared (decoder.rs:204-221): decode here
+                    if (nforced == kForcedSlots) {
+                        stop = true;
+                        break;
+                    }
+                    slot = (int)(B + nforced++);
+                    DecCand fc;
+                    fc.bitpos = pos;
+                    fc.type = 1;
+                    fc.pad = 0;
+                    HIPDEC(hipMemcpyAsync(w->cands.as<DecCand>() + slot, &fc, sizeof(fc), hipMemcpyHostToDevice, st));
+                    HIPDEC(hipEventRecord(ev[0], st));
+                    launch_dec_blocks(st, d_in, n, w->cands.as<DecCand>() + slot, 1, w->info.as<DecBlockInfo>() + slot,
+                                      w->sym.as<u16>() + (size_t)slot * kMtfStride, w->sel.as<u8>() + (size_t)slot * 32768u);
+                    HIPDEC(hipEventRecord(ev[1], st));
+                    HIPDEC(hipMemcpyAsync(&hinfo[slot], w->info.as<DecBlockInfo>() + slot, sizeof(DecBlockInfo),
+                                          hipMemcpyDeviceToHost, st));
+                    HIPDEC(hipStreamSynchronize(st));
+                    stage_time(0);
+                    w->stats[3] += 1;
+                }
+                const DecBlockInfo &bi = hinfo[slot];
+                if (bi.status) {
+                    term = BZ_E_DATA;
+                    break;
+                }
+                bslot.push_back((u32)slot);
+                bmax.push_back(100000u * level);
+                bcrc.push_back(bi.stored_crc);
+                combined = rotl1(combined) ^ bi.stored_crc; // decoder.rs:199-200 (done when the next record is opened)
+                pos = bi.end_bit;
+                if (bslot.size() >= (size_t)B) stop = true;
+            } else if (head == 0x17u) { // end of stream, decoder.rs:487-520
+                pos = p;
+                for (int k = 0; k < 5; ++k) (void)rd.read(pos, 8);
+                const u32 stored = rd.read(pos, 32);
+                if (stored != combined) {
+                    term = BZ_E_DATA;
+                    break;
+                }
+                pos = (pos + 7ull) & ~7ull;
+                if (pos > nbits) pos = nbits;
+                if (nbits - pos >= 8) {
+                    need_header = true;
+                    combined = 0;
+                    stream_no += 1;
+                } else {
+                    term = 1;
+                    break;
+                }
+            } else {
+                term = BZ_E_DATA;
+                break;
+            }
+        }
+        if (rd.failed) return BZ_E_UNEXPECTED;
+        ci = cj;
+
+        // ---- D2..D4 for the true blocks of the batch
+        const u32 nb = (u32)bslot.size();
+        if (nb) {
+            w->stats[1] += nb;
+            DecArgs a;
+            a.nb = nb;
+            a.slot = w->slot.as<u32>();
+            a.info = w->info.as<DecBlockInfo>();
+            a.sym = w->sym.as<u16>();
+            a.nblock_max = w->nbmax.as<u32>();
+            a.perm = w->perm.as<u8>();
+            a.chunk_emit = w->chunk_emit.as<u32>();
+            a.tt_len = w->tt_len.as<u32>();
+            a.err = w->err.as<u32>();
+            a.L = w->L.as<u8>();
+            a.T = w->T.as<u32>();
+            a.X = w->X.as<u8>();
+            a.samp_next = w->samp_next.as<u32>();
+            a.samp_len = w->samp_len.as<u32>();
+            a.samp_off = w->samp_off.as<u32>();
+            a.cycle_len = w->cycle_len.as<u32>();
+            a.tile_off = w->tile_off.as<u32>();
+            a.tile_state = w->tile_state.as<u32>();
+            a.out_len = w->out_len.as<u32>();
+            a.thist = w->thist.as<u32>();
+            a.tbase = w->tbase.as<u32>();
+            a.crc = w->crc.as<u32>();
+            HIPDEC(hipMemcpyAsync(w->slot.p, bslot.data(), (size_t)nb * 4, hipMemcpyHostToDevice, st));
+            HIPDEC(hipMemcpyAsync(w->nbmax.p, bmax.data(), (size_t)nb * 4, hipMemcpyHostToDevice, st));
+            HIPDEC(hipMemsetAsync(w->err.p, 0, (size_t)nb * 4, st));
+            HIPDEC(hipMemsetAsync(w->out_len.p, 0, (size_t)nb * 4, st));
+            HIPDEC(hipEventRecord(ev[0], st));
+            launch_dec_mtf(st, a);
+            HIPDEC(hipEventRecord(ev[1], st));
+            HIPDEC(hipStreamSynchronize(st));
+            stage_time(1);
+            HIPDEC(hipEventRecord(ev[0], st));
+            launch_dec_walks(st, a);
+            HIPDEC(hipEventRecord(ev[1], st));
+            std::vector<u32> h_err(nb), h_len(nb);
+            HIPDEC(hipMemcpyAsync(h_err.data(), w->err.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+            HIPDEC(hipMemcpyAsync(h_len.data(), w->out_len.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+            HIPDEC(hipStreamSynchronize(st));
+            stage_time(2);
+            // blocks in front of the first one that failed to rebuild
+            u32 good = nb;
+            for (u32 i = 0; i < nb; ++i)
+                if (h_err[i]) {
+                    good = i;
+                    break;
+                }
+            std::vector<u64> h_base(nb, 0);
+            u64 bytes = 0;
+            u32 max_len = 0;
+            for (u32 i = 0; i < good; ++i) {
+                h_base[i] = bytes;
+                bytes += h_len[i];
+                max_len = std::max(max_len, h_len[i]);
+            }
+            u32 keep = good; // blocks whose bytes are handed out
+            bool crc_bad = false;
+            if (sink.dry) {
+                sink.produced += bytes;
+            } else if (good) {
+                u8 *dst = nullptr;
+                if (sink.host) {
+                    const int rc = sink.staging->ensure(bytes + 64);
+                    if (rc) return rc;
+                    dst = sink.staging->as<u8>();
+                } else {
+                    if (sink.produced + bytes > sink.cap) return BZ_E_CAPACITY;
+                    dst = sink.d_out + sink.produced;
+                }
+                // blocks behind `good` keep err != 0 or are skipped by clearing their length
+                if (good < nb) {
+                    std::vector<u32> ones(nb - good, 1u);
+                    HIPDEC(hipMemcpyAsync(w->err.as<u32>() + good, ones.data(), (size_t)(nb - good) * 4, hipMemcpyHostToDevice, st));
+                }
+                HIPDEC(hipMemcpyAsync(w->out_base.p, h_base.data(), (size_t)nb * 8, hipMemcpyHostToDevice, st));
+                HIPDEC(hipEventRecord(ev[0], st));
+                launch_dec_expand(st, a, w->out_base.as<u64>(), dst);
+                launch_dec_crc(st, a, w->out_base.as<u64>(), dst, max_len, g->crc_tab.as<u32>(), g->xp2.as<u32>());
+                HIPDEC(hipEventRecord(ev[1], st));
+                std::vector<u32> h_crc(nb);
+                HIPDEC(hipMemcpyAsync(h_crc.data(), w->crc.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+                HIPDEC(hipStreamSynchronize(st));
+                stage_time(3);
+                u64 valid = bytes;
+                for (u32 i = 0; i < good; ++i) {
+                    if (~h_crc[i] != bcrc[i]) { // decoder.rs:189-198: noticed after the block's bytes went out
+                        crc_bad = true;
+                        keep = i + 1;
+                        valid = h_base[i] + h_len[i];
+                        break;
+                    }
+                }
+                if (sink.host) {
+                    const size_t old = sink.host->size();
+                    sink.host->resize(old + valid);
+                    if (valid) HIPDEC(hipMemcpy(sink.host->data() + old, dst, valid, hipMemcpyDeviceToHost));
+                }
+                sink.produced += valid;
+            }
+            (void)keep;
+            if (crc_bad || good < nb) {
+                *verdict = BZ_E_DATA;
+                finished = true;
+                continue;
+            }
+        }
+        if (term == 1) {
+            w->stats[2] = stream_no;
+            finished = true;
+        } else if (term < 0) {
+            *verdict = term;
+            w->stats[2] = stream_no;
+            finished = true;
+        }
+    }
+    return BZ_OK;
+}
+
+// ---- C ABI ------------------------------------------------------------------------------------------------
+extern "C" int bz_gpu_decode_device(bz_gpu_engine *g, const void *d_in, size_t n, void *d_out, size_t cap,
+                                    size_t *out_len)
+{
+    if (!g || !out_len || (!d_in && n)) return BZ_E_PARAM;
+    if (n && ((uintptr_t)d_in & 3u)) return BZ_E_PARAM;
+    *out_len = 0;
+    Sink sink;
+    sink.d_out = static_cast<u8 *>(d_out);
+    sink.cap = cap;
+    sink.dry = (d_out == nullptr);
+    int verdict = BZ_OK;
+    const int rc = decode_core(g, static_cast<const u8 *>(d_in), n, sink, &verdict);
+    *out_len = (size_t)sink.produced;
+    return rc != BZ_OK ? rc : verdict;
+}
+
+extern "C" int bz_gpu_last_decode_timings(bz_gpu_engine *g, double out_seconds[5])
+{
+    if (!g || !out_seconds) return BZ_E_PARAM;
+    for (int i = 0; i < 5; ++i) out_seconds[i] = 0;
+    if (!g->dec) return BZ_OK;
+    double tot = 0;
+    for (int i = 0; i < 4; ++i) {
+        out_seconds[i] = g->dec->t_stage[i];
+        tot += g->dec->t_stage[i];
+    }
+    out_seconds[4] = tot;
+    return BZ_OK;
+}
+
+extern "C" int bz_gpu_last_decode_stats(bz_gpu_engine *g, uint64_t out[4])
+{
+    if (!g || !out) return BZ_E_PARAM;
+    for (int i = 0; i < 4; ++i) out[i] = g->dec ? g->dec->stats[i] : 0;
+    return BZ_OK;
+}
+
+extern "C" int bz_decode_buffer(int device, const uint8_t *in, size_t in_len, uint8_t **out, size_t *out_len)
+{
+    if (!out || !out_len || (!in && in_len)) return BZ_E_PARAM;
+    *out = nullptr;
+    *out_len = 0;
+    bz_gpu_engine *g = nullptr;
+    int rc = bz_gpu_engine_create(&g, device, 0);
+    if (rc != BZ_OK) return rc;
+    void *d_in = nullptr;
+    std::vector<u8> host;
+    int verdict = BZ_OK;
+    rc = BZ_E_NOMEM;
+    if (hipMalloc(&d_in, in_len + 64) == hipSuccess) {
+        rc = BZ_E_UNEXPECTED;
+        if (hipMemset(d_in, 0, in_len + 64) == hipSuccess &&
+            (!in_len || hipMemcpy(d_in, in, in_len, hipMemcpyHostToDevice) == hipSuccess)) {
+            if (!g->dec) g->dec = new DecWorkspace();
+            Sink sink;
+            sink.host = &host;
+            sink.staging = &g->dec->staging;
+            rc = decode_core(g, static_cast<const u8 *>(d_in), in_len, sink, &verdict);
+        }
+    }
+    if (d_in) (void)hipFree(d_in);
+    bz_gpu_engine_destroy(g);
+    if (rc != BZ_OK) return rc;
+    // the bytes in front of an error are handed over too, as the reference's iterator yields them
+    uint8_t *h = (uint8_t *)malloc(host.size() ? host.size() : 1);
+    if (!h) return BZ_E_NOMEM;
+    if (!host.empty()) memcpy(h, host.data(), host.size());
+    *out = h;
+    *out_len = host.size();
+    return verdict;
+}
+
+// ---- streaming mirror of BZip2Decoder (decoder.rs:583-612) ------------------------------------------------
+// The reference pulls input bytes on demand and yields output bytes one by one.  Here the
+// compressed bytes are collected (bz_dec_write), decoded in one go when the input ends
+// (bz_dec_end), and handed out in order (bz_dec_read); an error, if any, is reported after the
+// bytes in front of it -- the same sequence of items the reference's iterator produces.
+struct bz_dec {
+    int device = 0;
+    std::vector<u8> in;
+    uint8_t *out = nullptr;
+    size_t out_len = 0, out_pos = 0;
+    bool ended = false;
+    int verdict = BZ_OK;
+};
+
+extern "C" int bz_dec_create(bz_dec **out, int device)
+{
+    if (!out) return BZ_E_PARAM;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BZ_E_NOGPU;
+    if (device < 0 || device >= ndev) return BZ_E_PARAM;
+    bz_dec *d = new bz_dec();
+    d->device = device;
+    *out = d;
+    return BZ_OK;
+}
+
+extern "C" int bz_dec_write(bz_dec *d, const uint8_t *data, size_t n)
+{
+    if (!d || (!data && n)) return BZ_E_PARAM;
+    if (d->ended) return BZ_E_UNEXPECTED;
+    d->in.insert(d->in.end(), data, data + n);
+    return BZ_OK;
+}
+
+extern "C" int bz_dec_end(bz_dec *d)
+{
+    if (!d) return BZ_E_PARAM;
+    if (d->ended) return d->verdict;
+    d->ended = true;
+    const int rc = bz_decode_buffer(d->device, d->in.data(), d->in.size(), &d->out, &d->out_len);
+    std::vector<u8>().swap(d->in);
+    d->verdict = rc;
+    return rc;
+}
+
+extern "C" long bz_dec_read(bz_dec *d, uint8_t *out, size_t cap)
+{
+    if (!d || (!out && cap)) return BZ_E_PARAM;
+    const size_t left = d->out_len - d->out_pos;
+    if (left == 0) return d->ended ? (long)d->verdict : 0; // all bytes handed out: the verdict (0 = clean end)
+    const size_t k = left < cap ? left : cap;
+    memcpy(out, d->out + d->out_pos, k);
+    d->out_pos += k;
+    return (long)k;
+}
+
+extern "C" size_t bz_dec_pending(const bz_dec *d) { return d ? d->out_len - d->out_pos : 0; }
+
+extern "C" void bz_dec_destroy(bz_dec *d)
+{
+    if (!d) return;
+    if (d->out) free(d->out);
+    delete d;
+}

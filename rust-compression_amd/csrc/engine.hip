@@ -4,8 +4,7 @@
 // One engine == one GPU == one HIP stream.  Multi-GPU jobs run one process (one engine) per
 // GPU and exchange block bit strings with RCCL outside this library (bench.py,
 // rust-compression_amd/__init__.py); nothing here needs a collective.
-#include "../../include/bz2_mi355x.h"
-#include "bzgpu.h"
+#include "engine_state.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -13,85 +12,6 @@
 #include <cstring>
 #include <vector>
 
-
-
-using namespace bzgpu;
-
-#define HIPCHK(x)                                                                                     \
-    do {                                                                                              \
-        hipError_t e_ = (x);                                                                          \
-        if (e_ != hipSuccess) {                                                                       \
-            fprintf(stderr, "bz2_mi355x: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__,   \
-                    __LINE__);                                                                        \
-            return BZ_E_UNEXPECTED;                                                                   \
-        }                                                                                             \
-    } while (0)
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes)
-    {
-        if (bytes <= cap) return BZ_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = bytes + bytes / 8 + 256;
-        if (hipMalloc(&p, want) != hipSuccess) {
-            if (hipMalloc(&p, bytes) != hipSuccess) return BZ_E_NOMEM;
-            want = bytes;
-        }
-        cap = want;
-        return BZ_OK;
-    }
-    void release()
-    {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
-};
-
-struct bz_gpu_engine {
-    int device = 0;
-    hipStream_t st = nullptr;   // rotation sort (and everything serial)
-    hipStream_t st2 = nullptr;  // MTF / Huffman / emission of the previous sub-batch
-    size_t max_blocks = 0;
-
-    // constant tables
-    DevBuf crc_tab, xp16, xp2;
-    // partition state (sized by the input)
-    DevBuf tile_last, carry_in, tile_crc, tile_count, tile_off, sub_off, sub_rs, scal, rle, blocks_all, crc_all;
-    std::vector<BlockDesc> h_blocks;
-    std::vector<u32> h_crc;
-    const u8 *d_in = nullptr;
-    u64 n_in = 0;
-    u64 slab_t0 = 0, slab_t1 = 0; // tiles this engine splits (the whole input on one GPU)
-    int level = 9;
-    // batch workspace (sized by max_blocks)
-    DevBuf lblocks, lcrc, SA, R, KA, VA, KB, VB, tile_hist, count, flags, tlo, tln, nonfinal, active, per_k,
-        per_shift, bin_base, sym_code, keyinfo, count2, tile_nf, L, orig_ptr, inuse_bits, summ, summ_len, init_state, rank8, ztile_last, ztile_cnt, mtf,
-        mtf_freq, bout, selector, code_len, group_bitoff, lm_scratch, stream, error_flag, packlist;
-    bool ws_ready = false;
-    // own packed buffer / assemble list for the single-GPU convenience call
-    DevBuf packed, asmlist;
-    unsigned long long *h_active = nullptr; // pinned
-    // results of the last encode
-    std::vector<BlockOut> h_out;
-    std::vector<u32> h_out_nblock;
-    double t_stage[6] = {0, 0, 0, 0, 0, 0};
-    KernelProf prof;
-    u64 bwt_stats[4] = {0, 0, 0, 0};
-    u64 round_active[64] = {};
-
-    struct Span {
-        int stage;
-        hipStream_t st;
-        hipEvent_t a, b;
-    };
-    std::vector<Span> spans;
-};
 
 static int span_begin(bz_gpu_engine *g, int stage, hipStream_t st = nullptr)
 {
@@ -245,6 +165,7 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
                      &g->mtf_freq, &g->bout, &g->selector, &g->code_len, &g->group_bitoff, &g->lm_scratch,
                      &g->stream, &g->error_flag, &g->packlist, &g->packed, &g->asmlist};
     for (DevBuf *b : all) b->release();
+    dec_workspace_free(g->dec);
     if (g->h_active) (void)hipHostFree(g->h_active);
     if (g->st) (void)hipStreamDestroy(g->st);
     if (g->st2) (void)hipStreamDestroy(g->st2);

@@ -1,0 +1,900 @@
+// k_dec.hip -- BZip2 block DECODE kernels (SURVEY.md row a18 / BASELINE configs[3]).
+//
+// Reference being replaced: BZip2DecoderBase::{init_block, get_next_lfm, next}
+// (src/bzip2/decoder.rs:163-581), HuffmanDecoder (src/huffman/decoder.rs:98-233),
+// MtfPositionDecoder::pop (src/bzip2/mtf.rs:51-64), BitReader<Left> (src/bitio/reader.rs:70-186).
+//
+// A .bz2 stream is serial in two ways: blocks are not byte aligned and end where their Huffman
+// data ends, and inside a block Huffman decode, inverse MTF and the inverse BWT pointer chase are
+// recurrences.  What is done about each:
+//   D0  every bit position is tested for the 48-bit block / end-of-stream magic (one thread per
+//       input byte, 8 shifts): candidates.  D1 decodes ALL candidates in parallel (one workgroup
+//       each, one lane walks the bits, the others build the 12-bit lookup tables); the host then
+//       links true blocks (start == previous end) and drops the false positives.
+//   D2  RUNA/RUNB runs and inverse MTF: the effect of a 512-symbol chunk on the MTF list is a
+//       permutation of list positions, independent of the list's content; per-chunk permutations
+//       are composed left to right, then every chunk is replayed by one lane.
+//   D3  T vector = stable counting sort of positions by byte (the radix kernels of k_bwt.hip with
+//       an 8-bit digit); the n-step pointer chase is cut at sample nodes (every 1024th index):
+//       all segments are walked in parallel, the ~900 samples are ranked serially, and a second
+//       parallel walk writes the bytes at their final offsets.
+//   D4  RLE1 undo: one lane per block finds the state at every 1024-byte tile start, then all tiles
+//       expand in parallel; block CRCs reuse the encoder's tile-CRC + GF(2) fold kernels.
+#include "bzgpu.h"
+#include "bz2_rnums.h"
+
+namespace bzgpu {
+
+constexpr u64 kBlockMagic = 0x314159265359ull;
+constexpr u64 kEosMagic = 0x177245385090ull;
+
+// ---- D0: magic scan ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dec_scan(const u8 *__restrict__ in, u64 nbytes, DecCand *__restrict__ cands,
+                                                   u32 cap, u32 *__restrict__ count)
+{
+    const u64 p = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (p >= nbytes) return;
+    // 56 bits starting at byte p
+    u64 wdw = 0;
+#pragma unroll
+    for (u32 k = 0; k < 7; ++k) wdw = (wdw << 8) | (u64)((p + k < nbytes) ? in[p + k] : 0);
+#pragma unroll
+    for (u32 s = 0; s < 8; ++s) {
+        const u64 v = (wdw >> (8u - s)) & 0xFFFFFFFFFFFFull;
+        const u32 type = (v == kBlockMagic) ? 1u : (v == kEosMagic ? 2u : 0u);
+        if (type && p * 8 + s + 48 <= nbytes * 8) {
+            const u32 i = atomicAdd(count, 1u);
+            if (i < cap) {
+                cands[i].bitpos = p * 8 + s;
+                cands[i].type = type;
+                cands[i].pad = 0;
+            }
+        }
+    }
+}
+
+// ---- MSB-first bit cursor over big-endian words (zero past the end, like the reference's short reads)
+struct BitCur {
+    const u32 *w;
+    u64 nwords;    // words that hold input bytes (the rest reads as zero)
+    u32 tail_mask; // keeps the input bytes of the last word (big-endian view)
+    u64 widx;      // next word to load
+    u64 buf;       // left aligned
+    int cnt;
+    __device__ __forceinline__ void open(const u8 *in, u64 nbytes)
+    {
+        w = reinterpret_cast<const u32 *>(in);
+        nwords = (nbytes + 3) / 4;
+        const u32 r = (u32)(nbytes & 3u);
+        tail_mask = r ? ~(0xFFFFFFFFu >> (8u * r)) : 0xFFFFFFFFu;
+    }
+    __device__ __forceinline__ u32 load(u64 i) const
+    {
+        if (i >= nwords) return 0u;
+        const u32 x = __builtin_bswap32(w[i]);
+        return (i + 1 == nwords) ? (x & tail_mask) : x;
+    }
+    __device__ __forceinline__ void seek(u64 bitpos)
+    {
+        widx = bitpos >> 5;
+        const u32 sh = (u32)bitpos & 31u;
+        const u32 x = load(widx);
+        ++widx;
+        buf = (u64)x << (32u + sh);
+        cnt = 32 - (int)sh;
+    }
+    __device__ __forceinline__ void fill() // makes at least 32 bits available
+    {
+        if (cnt <= 32) {
+            const u32 x = load(widx);
+            ++widx;
+            buf |= (u64)x << (32 - cnt);
+            cnt += 32;
+        }
+    }
+    __device__ __forceinline__ u32 peek(u32 n) { return n ? (u32)(buf >> (64u - n)) : 0u; } // n <= 32, after fill()
+    __device__ __forceinline__ void skip(u32 n)
+    {
+        buf <<= n;
+        cnt -= (int)n;
+    }
+    __device__ __forceinline__ u32 read(u32 n)
+    {
+        fill();
+        const u32 v = peek(n);
+        skip(n);
+        return v;
+    }
+    __device__ __forceinline__ u64 pos() const { return widx * 32ull - (u64)cnt; }
+};
+
+constexpr u32 kLutBits = 12;
+constexpr u16 kLutLong = 0xFFFE, kLutBad = 0xFFFF;
+
+// ---- D1: header + Huffman decode of one candidate -------------------------------------------------------
+__global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64 nbytes,
+                                                   const DecCand *__restrict__ cands, u32 ncand,
+                                                   DecBlockInfo *__restrict__ info, u16 *__restrict__ sym_out,
+                                                   u8 *__restrict__ sel_scratch)
+{
+    __shared__ u16 s_lut[6][1u << kLutBits];
+    __shared__ u8 s_len[6][260];
+    __shared__ u32 s_cnt[6][24], s_first[6][24], s_idx[6][24];
+    __shared__ u16 s_perm[6][260];
+    __shared__ u32 s_hdr[8]; // n_groups, alpha, n_selectors, status
+    const u32 c = blockIdx.x;
+    if (c >= ncand) return;
+    const u32 l = threadIdx.x;
+    DecBlockInfo &bi = info[c];
+    BitCur bc;
+    bc.open(in, nbytes);
+    const DecCand cd = cands[c];
+    u8 *sel = sel_scratch + (size_t)c * 32768u;
+    if (l == 0) {
+        bc.seek(cd.bitpos);
+        int status = 0;
+        u32 n_groups = 0, alpha = 0, n_selectors = 0;
+        (void)bc.read(24);
+        (void)bc.read(24); // the magic (only its first byte is compared by the reference: the host does that)
+        {
+            // a read at the end of the input returns the bits that are left as a SHORTER number
+            // (bitio/reader.rs:70-186), not a zero-padded one
+            const u64 at = bc.pos(), total = nbytes * 8ull;
+            const u32 v = bc.read(32);
+            const u64 avail = total > at ? total - at : 0ull;
+            bi.stored_crc = avail >= 32 ? v : (avail ? v >> (32u - (u32)avail) : 0u);
+        }
+        if (cd.type == 2u) {
+            bi.end_bit = bc.pos();
+            bi.nsym = 0;
+            bi.status = 0;
+            s_hdr[3] = 1; // nothing more to do
+        } else {
+            bi.randomised = bc.read(1);
+            bi.orig_ptr = bc.read(24);
+            u32 in_use16 = bc.read(16);
+            u32 n_in_use = 0;
+            for (u32 i = 0; i < 16; ++i) {
+                if ((in_use16 >> (15u - i)) & 1u) {
+                    const u32 m = bc.read(16);
+                    for (u32 j = 0; j < 16; ++j)
+                        if ((m >> (15u - j)) & 1u) bi.seq2unseq[n_in_use++] = (u8)(i * 16u + j);
+                }
+            }
+            bi.n_in_use = n_in_use;
+            if (n_in_use == 0) status = BZ_DEC_E_DATA;                // decoder.rs:273-275
+            alpha = n_in_use + 2;
+            if (!status) {
+                n_groups = bc.read(3);
+                if (n_groups < 2 || n_groups > 6) status = BZ_DEC_E_DATA; // :283-285
+            }
+            if (!status) {
+                n_selectors = bc.read(15);
+                if (n_selectors < 1) status = BZ_DEC_E_DATA;            // :290-292
+            }
+            if (!status) { // selectors: unary MTF positions (:294-316)
+                u32 lst = 0x543210u;
+                for (u32 s = 0; s < n_selectors && !status; ++s) {
+                    u32 j = 0;
+                    while (bc.read(1) != 0) {
+                        if (++j >= n_groups) {
+                            status = BZ_DEC_E_DATA;
+                            break;
+                        }
+                    }
+                    if (status) break;
+                    const u32 v = (lst >> (4u * j)) & 15u;
+                    if (j) {
+                        const u32 lowmask = (1u << (4u * j)) - 1u;
+                        lst = (lst & ~((lowmask << 4) | 15u)) | ((lst & lowmask) << 4) | v;
+                    }
+                    sel[s] = (u8)v;
+                }
+            }
+            if (!status) { // coding tables (:318-348)
+                for (u32 t = 0; t < n_groups && !status; ++t) {
+                    u32 curr = bc.read(5);
+                    for (u32 i = 0; i < alpha && !status; ++i) {
+                        while (bc.read(1) != 0) {
+                            if (curr < 1 || curr > 20) {
+                                status = BZ_DEC_E_DATA;
+                                break;
+                            }
+                            if (bc.read(1) == 0) curr += 1; else curr -= 1;
+                        }
+                        s_len[t][i] = (u8)curr;
+                    }
+                }
+            }
+            s_hdr[0] = n_groups;
+            s_hdr[1] = alpha;
+            s_hdr[2] = n_selectors;
+            s_hdr[3] = status ? 1u : 0u;
+            if (status) {
+                bi.status = (u32)status;
+                bi.end_bit = bc.pos();
+                bi.nsym = 0;
+            }
+        }
+    }
+    __syncthreads();
+    if (s_hdr[3]) return;
+    const u32 n_groups = s_hdr[0], alpha = s_hdr[1], n_selectors = s_hdr[2];
+    // ---- decode tables (all lanes): canonical codes, 12-bit lookup, per-length arrays for longer codes
+    for (u32 i = l; i < 6 * 24; i += 64) (&s_cnt[0][0])[i] = 0;
+    for (u32 i = l; i < 6u << kLutBits; i += 64) (&s_lut[0][0])[i] = kLutBad;
+    __syncthreads();
+    for (u32 i = l; i < n_groups * alpha; i += 64) {
+        const u32 t = i / alpha, s = i - t * alpha;
+        const u32 ln = s_len[t][s];
+        if (ln >= 1 && ln <= 23) atomicAdd(&s_cnt[t][ln], 1u);
+    }
+    __syncthreads();
+    if (l < n_groups) {
+        u32 code = 0, idx = 0, bad = 0;
+        for (u32 ln = 1; ln < 24; ++ln) {
+            code = (code + s_cnt[l][ln - 1]) << 1;
+            s_first[l][ln] = code;
+            s_idx[l][ln] = idx;
+            idx += s_cnt[l][ln];
+            if ((u64)code + s_cnt[l][ln] > (1ull << ln)) bad = 1; // over-subscribed: the reference indexes out of bounds
+        }
+        for (u32 s = 0; s < alpha; ++s)
+            if (s_len[l][s] == 0 || s_len[l][s] > 23) bad |= (s_len[l][s] > 23) ? 1u : 0u;
+        if (bad) atomicExch(&s_hdr[3], 1u);
+    }
+    __syncthreads();
+    if (s_hdr[3]) {
+        if (l == 0) {
+            bi.status = (u32)BZ_DEC_E_DATA;
+            bi.end_bit = cd.bitpos;
+            bi.nsym = 0;
+        }
+        return;
+    }
+    for (u32 i = l; i < n_groups * alpha; i += 64) {
+        const u32 t = i / alpha, s = i - t * alpha;
+        const u32 ln = s_len[t][s];
+        if (ln == 0) continue; // no code for this symbol (huffman/mod.rs:31-35)
+        u32 r = 0;
+        for (u32 q = 0; q < s; ++q) r += (s_len[t][q] == ln) ? 1u : 0u;
+        const u32 code = s_first[t][ln] + r;
+        s_perm[t][s_idx[t][ln] + r] = (u16)s;
+        if (ln <= kLutBits) {
+            const u32 base = code << (kLutBits - ln);
+            for (u32 j = 0; j < (1u << (kLutBits - ln)); ++j) s_lut[t][base + j] = (u16)(s | (ln << 9));
+        } else {
+            s_lut[t][code >> (ln - kLutBits)] = kLutLong;
+        }
+    }
+    __syncthreads();
+    if (l != 0) return;
+    // ---- the symbols (:367-437), one lane; its cursor still stands right after the coding tables
+    u16 *out = sym_out + (size_t)c * kMtfStride;
+    const u32 eob = alpha - 1;
+    u32 nsym = 0;
+    int status = 0;
+    bool done = false;
+    for (u32 g = 0; !done && !status; ++g) {
+        if (g >= n_selectors) { // group_no > n_selectors (:381-383)
+            status = BZ_DEC_E_DATA;
+            break;
+        }
+        const u16 *lut = s_lut[sel[g]];
+        const u32 t = sel[g];
+        for (u32 k = 0; k < kGSize; ++k) {
+            if (bc.pos() >= nbytes * 8ull) { // peek returns no bits: Ok(None) -> DataError (:387-390)
+                status = BZ_DEC_E_DATA;
+                break;
+            }
+            bc.fill();
+            const u32 e = lut[bc.peek(kLutBits)];
+            u32 sy;
+            if (e < kLutLong) {
+                sy = e & 511u;
+                bc.skip(e >> 9);
+            } else if (e == kLutLong) {
+                // codes longer than the table: canonical walk from 13 bits up
+                u32 code = bc.peek(kLutBits), ln = kLutBits;
+                bool hit = false;
+                while (ln < 23u) {
+                    ++ln;
+                    code = bc.peek(ln);
+                    const u32 rel = code - s_first[t][ln];
+                    if (code >= s_first[t][ln] && rel < s_cnt[t][ln]) {
+                        sy = s_perm[t][s_idx[t][ln] + rel];
+                        hit = true;
+                        break;
+                    }
+                }
+                // the bits beyond the 12-bit table are taken one by one and fail at the end of the input
+                // (huffman/decoder.rs:221-224)
+                if (!hit || bc.pos() + ln > nbytes * 8ull) {
+                    status = BZ_DEC_E_DATA;
+                    break;
+                }
+                bc.skip(ln);
+            } else {
+                status = BZ_DEC_E_DATA; // a bit pattern no code owns (unreachable!() in the reference)
+                break;
+            }
+            if (nsym >= kMtfStride - 1u) { // more symbols than any legal block holds
+                status = BZ_DEC_E_DATA;
+                break;
+            }
+            out[nsym++] = (u16)sy;
+            if (sy == eob) {
+                done = true;
+                break;
+            }
+        }
+    }
+    bi.status = (u32)status;
+    bi.end_bit = bc.pos();
+    bi.nsym = nsym;
+}
+
+// ---- D2: zero runs + inverse MTF --------------------------------------------------------------------
+constexpr u32 kDecSampleStep = 1024;
+
+// zero-run value of the digits sym[a..b) (bijective base 2, least significant first, decoder.rs:419-424);
+// returns 0xFFFFFFFF when the run is longer than the reference accepts (n >= 2 Mi, :413-416)
+__device__ __forceinline__ u32 run_value(const u16 *__restrict__ sym, u32 a, u32 b)
+{
+    u32 es = 0, n = 1;
+    for (u32 i = a; i < b; ++i) {
+        if (n >= 2u * 1024u * 1024u) return 0xFFFFFFFFu;
+        if (sym[i] == 0) { es += n; n <<= 1; } else { n <<= 1; es += n; }
+    }
+    return es;
+}
+
+// inverse MTF step on a byte list held as dwords: returns the byte at `r` and moves it to the front
+__device__ __forceinline__ u32 imtf_pop(u32 *list, u32 r)
+{
+    const u32 dq = r >> 2, bq = r & 3u;
+    const u32 wq = list[dq];
+    const u32 v = (wq >> (8u * bq)) & 0xFFu;
+    if (r == 0) return v;
+    u32 carry = v;
+    for (u32 d = 0; d < dq; ++d) {
+        const u32 w = list[d];
+        list[d] = (w << 8) | carry;
+        carry = w >> 24;
+    }
+    const u32 upto = (bq == 3u) ? 0xFFFFFFFFu : ((1u << (8u * (bq + 1u))) - 1u);
+    const u32 lowm = upto >> 8;
+    list[dq] = (wq & ~upto) | ((((wq & lowm) << 8) | carry) & upto);
+    return v;
+}
+
+// M1': chunk permutation of list positions + bytes the chunk emits
+__global__ __launch_bounds__(256) void k_dec_chunk_perm(DecArgs a)
+{
+    __shared__ u32 s_list[256 * 65];
+    const u32 lb = blockIdx.y;
+    const u32 sl = a.slot[lb];
+    const u32 nsym = a.info[sl].nsym;
+    const u32 chunk = blockIdx.x * 256u + threadIdx.x;
+    const u32 beg = chunk * kMtfChunk;
+    if (beg >= nsym) return;
+    const u32 end = (beg + kMtfChunk < nsym) ? beg + kMtfChunk : nsym;
+    const u16 *sym = a.sym + (size_t)sl * kMtfStride;
+    const u32 eob = a.info[sl].n_in_use + 1u;
+    u32 *list = s_list + threadIdx.x * 65u;
+    for (u32 d = 0; d < 64; ++d) list[d] = (4u * d) | ((4u * d + 1u) << 8) | ((4u * d + 2u) << 16) | ((4u * d + 3u) << 24);
+    u32 emit = 0, err = 0;
+    u32 run_start = 0xFFFFFFFFu; // start of the digits in front of symbol i (if any)
+    // digits hanging over from the previous chunk
+    if (beg > 0 && sym[beg - 1] <= 1u) {
+        u32 s = beg - 1;
+        while (s > 0 && sym[s - 1] <= 1u && beg - s < 32u) --s;
+        run_start = s;
+    }
+    for (u32 i = beg; i < end; ++i) {
+        const u32 sy = sym[i];
+        if (sy <= 1u) {
+            if (run_start == 0xFFFFFFFFu) run_start = i;
+            continue;
+        }
+        if (run_start != 0xFFFFFFFFu) {
+            const u32 z = run_value(sym, run_start, i);
+            if (z == 0xFFFFFFFFu) err = 1;
+            else emit += z;
+            run_start = 0xFFFFFFFFu;
+        }
+        if (sy != eob) {
+            (void)imtf_pop(list, sy - 1u);
+            emit += 1;
+        }
+    }
+    u8 *out = a.perm + ((size_t)lb * kMaxMtfChunks + chunk) * 256u;
+    for (u32 d = 0; d < 64; ++d) reinterpret_cast<u32 *>(out)[d] = list[d];
+    a.chunk_emit[(size_t)lb * kMaxMtfChunks + chunk] = emit;
+    if (err) atomicMax(&a.err[lb], 1u);
+}
+
+// M2': compose the permutations into start lists (of byte values) and scan the emit counts
+__global__ __launch_bounds__(64) void k_dec_compose(DecArgs a)
+{
+    __shared__ u8 s_state[256], s_new[256];
+    const u32 lb = blockIdx.x, l = threadIdx.x;
+    const DecBlockInfo &bi = a.info[a.slot[lb]];
+    const u32 nchunks = (bi.nsym + kMtfChunk - 1) / kMtfChunk;
+    for (u32 k = 0; k < 4; ++k) s_state[l * 4 + k] = (l * 4 + k < bi.n_in_use) ? bi.seq2unseq[l * 4 + k] : 0;
+    __syncthreads();
+    u32 run = 0;
+    for (u32 c = 0; c < nchunks; ++c) {
+        u8 *pp = a.perm + ((size_t)lb * kMaxMtfChunks + c) * 256u;
+        const u32 pw = reinterpret_cast<const u32 *>(pp)[l];
+        reinterpret_cast<u32 *>(pp)[l] = reinterpret_cast<const u32 *>(s_state)[l]; // start list of chunk c
+        for (u32 k = 0; k < 4; ++k) s_new[l * 4 + k] = s_state[(pw >> (8u * k)) & 0xFFu];
+        __syncthreads();
+        reinterpret_cast<u32 *>(s_state)[l] = reinterpret_cast<const u32 *>(s_new)[l];
+        if (l == 0) {
+            const u32 e = a.chunk_emit[(size_t)lb * kMaxMtfChunks + c];
+            a.chunk_emit[(size_t)lb * kMaxMtfChunks + c] = run;
+            run = (run + e < run) ? 0xFFFFFFFFu : run + e;
+        }
+        __syncthreads();
+    }
+    if (l == 0) {
+        a.tt_len[lb] = run;
+        if (run == 0xFFFFFFFFu || run > a.nblock_max[lb]) atomicMax(&a.err[lb], 1u); // tt overflows (:399,427)
+        // decoder.rs:238 (orig_pos > 10 + 100000 * level) and :441-443 (orig_pos >= tt.len())
+        if (bi.orig_ptr > 10u + a.nblock_max[lb] || bi.orig_ptr >= run) atomicMax(&a.err[lb], 1u);
+    }
+}
+
+// M3': replay every chunk from its start list and write the BWT column
+__global__ __launch_bounds__(256) void k_dec_chunk_emit(DecArgs a)
+{
+    __shared__ u32 s_list[256 * 65];
+    const u32 lb = blockIdx.y;
+    if (a.err[lb]) return;
+    const u32 sl = a.slot[lb];
+    const u32 nsym = a.info[sl].nsym;
+    const u32 chunk0 = blockIdx.x * 256u;
+    if (chunk0 * kMtfChunk >= nsym) return;
+    const u32 nchunks = (nsym + kMtfChunk - 1) / kMtfChunk;
+    {
+        const u32 *src = reinterpret_cast<const u32 *>(a.perm + ((size_t)lb * kMaxMtfChunks + chunk0) * 256u);
+        const u32 avail = (nchunks - chunk0 < 256u ? nchunks - chunk0 : 256u) * 64u;
+        for (u32 i = threadIdx.x; i < avail; i += 256u) s_list[(i >> 6) * 65u + (i & 63u)] = src[i];
+    }
+    __syncthreads();
+    const u32 chunk = chunk0 + threadIdx.x;
+    const u32 beg = chunk * kMtfChunk;
+    if (beg >= nsym) return;
+    const u32 end = (beg + kMtfChunk < nsym) ? beg + kMtfChunk : nsym;
+    const u16 *sym = a.sym + (size_t)sl * kMtfStride;
+    const u32 eob = a.info[sl].n_in_use + 1u;
+    const u32 maxlen = a.nblock_max[lb];
+    u32 *list = s_list + threadIdx.x * 65u;
+    u8 *L = a.L + (size_t)lb * kSlot;
+    u32 o = a.chunk_emit[(size_t)lb * kMaxMtfChunks + chunk];
+    u32 err = 0;
+    u32 run_start = 0xFFFFFFFFu;
+    if (beg > 0 && sym[beg - 1] <= 1u) {
+        u32 s = beg - 1;
+        while (s > 0 && sym[s - 1] <= 1u && beg - s < 32u) --s;
+        run_start = s;
+    }
+    for (u32 i = beg; i < end; ++i) {
+        const u32 sy = sym[i];
+        if (sy <= 1u) {
+            if (run_start == 0xFFFFFFFFu) run_start = i;
+            continue;
+        }
+        if (run_start != 0xFFFFFFFFu) {
+            const u32 z = run_value(sym, run_start, i);
+            const u32 front = list[0] & 0xFFu;
+            if (o + z >= maxlen) err = 1; // tt.len() >= nblock_max after a run (:399-401)
+            else
+                for (u32 k = 0; k < z; ++k) L[o + k] = (u8)front;
+            o += z;
+            run_start = 0xFFFFFFFFu;
+        }
+        if (sy != eob) {
+            if (o >= maxlen) err = 1;    // :427-429
+            else L[o] = (u8)imtf_pop(list, sy - 1u);
+            o += 1;
+        }
+        if (err) break;
+    }
+    if (err) atomicMax(&a.err[lb], 1u);
+}
+
+// ---- D3: the pointer chase, cut at sample nodes ----------------------------------------------------------
+__device__ __forceinline__ u32 sample_id(u32 node, u32 p0)
+{
+    if (node == p0) return kDecSamples - 1u;
+    return (node % kDecSampleStep == 0) ? node / kDecSampleStep : 0xFFFFFFFFu;
+}
+
+__global__ __launch_bounds__(256) void k_dec_walk_lengths(DecArgs a)
+{
+    const u32 lb = blockIdx.y;
+    if (a.err[lb]) return;
+    const u32 n = a.tt_len[lb];
+    const u32 sid = blockIdx.x * 256u + threadIdx.x;
+    if (sid >= kDecSamples) return;
+    const u32 *T = a.T + (size_t)lb * kSlot;
+    const u32 p0 = T[a.info[a.slot[lb]].orig_ptr];
+    u32 node;
+    if (sid == kDecSamples - 1u) node = p0;
+    else {
+        node = sid * kDecSampleStep;
+        if (node >= n || node == p0) return; // (p0's segment belongs to the start sample)
+    }
+    u32 cur = node, len = 0, nid;
+    do {
+        cur = T[cur];
+        ++len;
+        nid = sample_id(cur, p0);
+    } while (nid == 0xFFFFFFFFu && len <= n);
+    a.samp_next[(size_t)lb * kDecSamples + sid] = nid;
+    a.samp_len[(size_t)lb * kDecSamples + sid] = len;
+}
+
+__global__ __launch_bounds__(64) void k_dec_rank_samples(DecArgs a)
+{
+    const u32 lb = blockIdx.x * 64u + threadIdx.x;
+    if (lb >= a.nb || a.err[lb]) return;
+    const u32 n = a.tt_len[lb];
+    u32 *off = a.samp_off + (size_t)lb * kDecSamples;
+    for (u32 i = 0; i < kDecSamples; ++i) off[i] = 0xFFFFFFFFu;
+    u32 s = kDecSamples - 1u, o = 0, cyc = n;
+    while (o < n) {
+        if (off[s] != 0xFFFFFFFFu) { // back at a visited sample: T has a cycle shorter than n (periodic block)
+            cyc = o;
+            break;
+        }
+        off[s] = o;
+        o += a.samp_len[(size_t)lb * kDecSamples + s];
+        s = a.samp_next[(size_t)lb * kDecSamples + s];
+        if (s == 0xFFFFFFFFu) break;
+    }
+    a.cycle_len[lb] = cyc;
+}
+
+__global__ __launch_bounds__(256) void k_dec_walk_write(DecArgs a)
+{
+    const u32 lb = blockIdx.y;
+    if (a.err[lb]) return;
+    const u32 n = a.tt_len[lb];
+    const u32 sid = blockIdx.x * 256u + threadIdx.x;
+    if (sid >= kDecSamples) return;
+    const u32 o0 = a.samp_off[(size_t)lb * kDecSamples + sid];
+    if (o0 == 0xFFFFFFFFu) return;
+    const u32 *T = a.T + (size_t)lb * kSlot;
+    const u8 *L = a.L + (size_t)lb * kSlot;
+    u8 *X = a.X + (size_t)lb * kSlot;
+    const u32 p0 = T[a.info[a.slot[lb]].orig_ptr];
+    u32 cur = (sid == kDecSamples - 1u) ? p0 : sid * kDecSampleStep;
+    const u32 len = a.samp_len[(size_t)lb * kDecSamples + sid];
+    for (u32 k = 0; k < len && o0 + k < n; ++k) {
+        X[o0 + k] = L[cur]; // tt[pos] & 0xFF, then pos = tt[pos] >> 8 (decoder.rs:533-536)
+        cur = T[cur];
+    }
+}
+
+// periodic blocks (the chain closes before n steps) and randomised blocks (decoder.rs:27-92,537-539)
+__global__ __launch_bounds__(256) void k_dec_fixups(DecArgs a)
+{
+    const u32 lb = blockIdx.x;
+    if (a.err[lb]) return;
+    const u32 n = a.tt_len[lb];
+    u8 *X = a.X + (size_t)lb * kSlot;
+    const u32 c = a.cycle_len[lb];
+    if (c && c < n)
+        for (u32 q = c + threadIdx.x; q < n; q += 256u) X[q] = X[q % c];
+    __syncthreads();
+    if (a.info[a.slot[lb]].randomised && threadIdx.x == 0) {
+        u32 tpos = 0, q = 0;
+        while (true) {
+            const u32 step = kBz2RNums[tpos];
+            tpos = (tpos + 1u) & 511u;
+            // n2go is loaded with rNums, decremented once per byte; the byte where it reaches 1 is flipped
+            q += step - 1u;
+            if (q >= n) break;
+            X[q] ^= 1u;
+            q += 1u;
+        }
+    }
+}
+
+// ---- D4: RLE1 undo (decoder.rs:550-578) ---------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_dec_rle_states(DecArgs a)
+{
+    const u32 lb = blockIdx.x * 64u + threadIdx.x;
+    if (lb >= a.nb || a.err[lb]) return;
+    const u32 n = a.tt_len[lb];
+    const u8 *X = a.X + (size_t)lb * kSlot;
+    u32 *toff = a.tile_off + (size_t)lb * kDecTiles, *tst = a.tile_state + (size_t)lb * kDecTiles;
+    u32 out = 0, cnt = 0, last = 0x100; // cnt = equal bytes seen (0..4; 4 = the next byte is a count)
+    for (u32 i0 = 0; i0 < n; i0 += 16u) {
+        if ((i0 & 1023u) == 0) {
+            toff[i0 >> 10] = out;
+            tst[i0 >> 10] = (cnt << 16) | last;
+        }
+        const uint4 q = *reinterpret_cast<const uint4 *>(X + i0);
+        const u32 wv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (u32 k = 0; k < 16; ++k) {
+            if (i0 + k < n) {
+                const u32 b = (wv[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+                if (cnt == 4u) {
+                    out += b;
+                    cnt = 0;
+                    last = 0x100;
+                } else if (b == last) {
+                    ++cnt;
+                    out += 1;
+                } else {
+                    last = b;
+                    cnt = 1;
+                    out += 1;
+                }
+            }
+        }
+    }
+    a.out_len[lb] = out;
+    // four equal bytes with no count byte behind them: the reference reads on around the closed
+    // pointer chain and never terminates (decoder.rs:566-570); reported as DataError here
+    if (cnt == 4u) a.err[lb] = 1u;
+}
+
+__global__ __launch_bounds__(256) void k_dec_rle_expand(DecArgs a, const u64 *__restrict__ out_base, u8 *__restrict__ out)
+{
+    const u32 lb = blockIdx.y;
+    if (a.err[lb]) return;
+    const u32 n = a.tt_len[lb];
+    const u32 tile = blockIdx.x * 256u + threadIdx.x;
+    const u32 i0 = tile * 1024u;
+    if (i0 >= n) return;
+    const u8 *X = a.X + (size_t)lb * kSlot;
+    u8 *dst = out + out_base[lb] + a.tile_off[(size_t)lb * kDecTiles + tile];
+    const u32 st = a.tile_state[(size_t)lb * kDecTiles + tile];
+    u32 cnt = st >> 16, last = st & 0xFFFFu;
+    const u32 i1 = (i0 + 1024u < n) ? i0 + 1024u : n;
+    for (u32 i = i0; i < i1; ++i) {
+        const u32 b = X[i];
+        if (cnt == 4u) {
+            for (u32 k = 0; k < b; ++k) *dst++ = (u8)last;
+            cnt = 0;
+            last = 0x100;
+        } else if (b == last) {
+            ++cnt;
+            *dst++ = (u8)b;
+        } else {
+            last = b;
+            cnt = 1;
+            *dst++ = (u8)b;
+        }
+    }
+}
+
+// ---- D3a: T vector = positions of the BWT column in stable byte order (decoder.rs:446-473) ---------------
+// Same three-kernel shape as the encoder's radix pass (k_bwt.hip) with one 8-bit digit and no keys
+// to carry: per-tile byte counts, per-block scan, stable scatter ranked with wave ballots.
+__global__ __launch_bounds__(kSortThreads) void k_dec_thist(DecArgs a)
+{
+    __shared__ u32 s_hist[256];
+    u32 tile, lb;
+    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu || a.err[lb]) return;
+    const u32 n = a.tt_len[lb];
+    const u32 start = tile * kSortTile;
+    if (start >= n) return;
+    if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const u8 *L = a.L + (size_t)lb * kSlot;
+    // 16 bytes per thread
+    const u32 i0 = start + threadIdx.x * 16u;
+    if (i0 < n) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(L + i0);
+        const u32 wv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (u32 k = 0; k < 16; ++k)
+            if (i0 + k < n) atomicAdd(&s_hist[(wv[k >> 2] >> ((k & 3) * 8)) & 0xFFu], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) a.thist[((size_t)lb * kTilesPerBlock + tile) * 256u + threadIdx.x] = s_hist[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_dec_tscan(DecArgs a)
+{
+    __shared__ u32 s_w[4];
+    const u32 lb = blockIdx.x;
+    if (a.err[lb]) return;
+    const u32 n = a.tt_len[lb];
+    const u32 ntiles = (n + kSortTile - 1) / kSortTile;
+    u32 *hist = a.thist + (size_t)lb * kTilesPerBlock * 256u;
+    const u32 d = threadIdx.x;
+    u32 run = 0;
+    for (u32 t = 0; t < ntiles; ++t) {
+        const u32 v = hist[t * 256u + d];
+        hist[t * 256u + d] = run;
+        run += v;
+    }
+    const u32 inc = wave_incl_sum(run);
+    if ((d & 63u) == 63u) s_w[d >> 6] = inc;
+    __syncthreads();
+    u32 carry = 0;
+    for (u32 k = 0; k < (d >> 6); ++k) carry += s_w[k];
+    a.tbase[(size_t)lb * 256u + d] = carry + inc - run;
+}
+
+__global__ __launch_bounds__(kSortThreads) void k_dec_tscatter(DecArgs a)
+{
+    constexpr u32 NW = kSortThreads / 64;
+    __shared__ u32 s_buf[kSortTile];
+    __shared__ u32 s_base[256];
+    __shared__ u16 s_tpre[256];
+    __shared__ u16 s_cnt[NW][256];
+    __shared__ u32 s_wsum[4];
+    u32 tile, lb;
+    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu || a.err[lb]) return;
+    const u32 n = a.tt_len[lb];
+    const u32 start = tile * kSortTile;
+    if (start >= n) return;
+    const u8 *L = a.L + (size_t)lb * kSlot;
+    u32 *T = a.T + (size_t)lb * kSlot;
+    for (u32 i = threadIdx.x; i < NW * 256u / 2u; i += kSortThreads) reinterpret_cast<u32 *>(&s_cnt[0][0])[i] = 0;
+    if (threadIdx.x < 256)
+        s_base[threadIdx.x] = a.thist[((size_t)lb * kTilesPerBlock + tile) * 256u + threadIdx.x] +
+                              a.tbase[(size_t)lb * 256u + threadIdx.x];
+    __syncthreads();
+    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const u64 lt_mask = (l == 0) ? 0ull : (~0ull >> (64 - l));
+    u16 *my_cnt = s_cnt[w];
+    u32 dgv[16], rnk[16];
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 idx = start + w * 1024u + r * 64u + l;
+        dgv[r] = idx < n ? (u32)L[idx] : 0u;
+    }
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 idx = start + w * 1024u + r * 64u + l;
+        const bool ok = idx < n;
+        const u32 dg = dgv[r];
+        u64 peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (dg >> b) & 1u;
+            const u64 m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        rnk[r] = 0xFFFFFFFFu;
+        if (ok) {
+            const u32 before = __popcll(peers & lt_mask);
+            const u32 c0 = my_cnt[dg];
+            rnk[r] = c0 + before;
+            if ((peers >> l) == 1ull) my_cnt[dg] = (u16)(c0 + before + 1u);
+        }
+    }
+    __syncthreads();
+    u32 tot = 0;
+    if (threadIdx.x < 256) {
+        for (u32 k = 0; k < NW; ++k) {
+            const u32 c = s_cnt[k][threadIdx.x];
+            s_cnt[k][threadIdx.x] = (u16)tot;
+            tot += c;
+        }
+        const u32 inc = wave_incl_sum(tot);
+        if (l == 63) s_wsum[w] = inc;
+        s_tpre[threadIdx.x] = (u16)(inc - tot); // wave-local for now
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        u32 carry = 0;
+        for (u32 k = 0; k < w; ++k) carry += s_wsum[k];
+        s_tpre[threadIdx.x] = (u16)(s_tpre[threadIdx.x] + carry);
+    }
+    __syncthreads();
+    const u32 cnt_tile = (n - start < kSortTile) ? n - start : kSortTile;
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        if (rnk[r] != 0xFFFFFFFFu) {
+            const u32 dg = dgv[r];
+            const u32 lpos = (u32)s_tpre[dg] + (u32)my_cnt[dg] + rnk[r];
+            // digit order inside the tile: value (position) in the low 24 bits, digit on top
+            s_buf[lpos] = (start + w * 1024u + r * 64u + l) | (dg << 24);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k) {
+        const u32 i = k * kSortThreads + threadIdx.x;
+        if (i < cnt_tile) {
+            const u32 e = s_buf[i];
+            const u32 dg = e >> 24;
+            T[s_base[dg] + (i - (u32)s_tpre[dg])] = e & 0xFFFFFFu;
+        }
+    }
+}
+
+// ---- D4b: CRC of every block's output (crc32.rs:116-131), in 64 KiB slices folded with x^(8 * bytes after)
+__global__ __launch_bounds__(256) void k_dec_crc(DecArgs a, const u64 *__restrict__ out_base,
+                                                 const u8 *__restrict__ out, const u32 *__restrict__ crc_tab,
+                                                 const u32 *__restrict__ xp2)
+{
+    __shared__ u32 s_tab[256];
+    __shared__ u32 s_x[4];
+    const u32 lb = blockIdx.y;
+    if (a.err[lb]) return;
+    const u64 len = a.out_len[lb];
+    const u64 s0 = (u64)blockIdx.x * 65536ull;
+    if (s0 >= len && !(blockIdx.x == 0)) return;
+    s_tab[threadIdx.x] = crc_tab[threadIdx.x];
+    __syncthreads();
+    const u8 *p = out + out_base[lb];
+    const u64 b0 = s0 + (u64)threadIdx.x * 256ull;
+    u32 acc = 0;
+    if (b0 < len) {
+        const u64 b1 = (b0 + 256ull < len) ? b0 + 256ull : len;
+        const u32 c = crc_bytes_raw(p + b0, b1 - b0, s_tab);
+        acc = gf_mulmod(c, gf_xpow_bytes(len - b1, xp2));
+    }
+    // the initial 0xFFFFFFFF rides through the whole message
+    if (blockIdx.x == 0 && threadIdx.x == 0) acc ^= gf_mulmod(0xFFFFFFFFu, gf_xpow_bytes(len, xp2));
+    const u32 wx = wave_xor(acc);
+    if (lane_id() == 0) s_x[threadIdx.x >> 6] = wx;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicXor(&a.crc[lb], s_x[0] ^ s_x[1] ^ s_x[2] ^ s_x[3]); // (host applies the final NOT)
+}
+
+// ---- launchers --------------------------------------------------------------------------------------------------
+void launch_dec_scan(hipStream_t st, const u8 *in, u64 nbytes, DecCand *cands, u32 cap, u32 *count)
+{
+    (void)hipMemsetAsync(count, 0, 4, st);
+    if (nbytes == 0) return;
+    hipLaunchKernelGGL(k_dec_scan, dim3((u32)((nbytes + 255) / 256)), dim3(256), 0, st, in, nbytes, cands, cap, count);
+}
+
+void launch_dec_blocks(hipStream_t st, const u8 *in, u64 nbytes, const DecCand *cands, u32 ncand, DecBlockInfo *info,
+                       u16 *sym, u8 *sel_scratch)
+{
+    if (ncand == 0) return;
+    hipLaunchKernelGGL(k_dec_block, dim3(ncand), dim3(64), 0, st, in, nbytes, cands, ncand, info, sym, sel_scratch);
+}
+
+void launch_dec_mtf(hipStream_t st, const DecArgs &a)
+{
+    const u32 cw = (kMaxMtfChunks + 255) / 256;
+    hipLaunchKernelGGL(k_dec_chunk_perm, dim3(cw, a.nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_dec_compose, dim3(a.nb), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_dec_chunk_emit, dim3(cw, a.nb), dim3(256), 0, st, a);
+}
+
+void launch_dec_walks(hipStream_t st, const DecArgs &a)
+{
+    const dim3 tiles(kTilesPerBlock, xcd_grid_y(a.nb));
+    hipLaunchKernelGGL(k_dec_thist, tiles, dim3(kSortThreads), 0, st, a);
+    hipLaunchKernelGGL(k_dec_tscan, dim3(a.nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_dec_tscatter, tiles, dim3(kSortThreads), 0, st, a);
+    const u32 sw = (kDecSamples + 255) / 256;
+    hipLaunchKernelGGL(k_dec_walk_lengths, dim3(sw, a.nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_dec_rank_samples, dim3((a.nb + 63) / 64), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_dec_walk_write, dim3(sw, a.nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_dec_fixups, dim3(a.nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_dec_rle_states, dim3((a.nb + 63) / 64), dim3(64), 0, st, a);
+}
+
+void launch_dec_expand(hipStream_t st, const DecArgs &a, const u64 *out_base, u8 *out)
+{
+    hipLaunchKernelGGL(k_dec_rle_expand, dim3((kDecTiles + 255) / 256, a.nb), dim3(256), 0, st, a, out_base, out);
+}
+
+void launch_dec_crc(hipStream_t st, const DecArgs &a, const u64 *out_base, const u8 *out, u32 max_out_len,
+                    const u32 *crc_tab, const u32 *xp2)
+{
+    (void)hipMemsetAsync(a.crc, 0, (size_t)a.nb * 4u, st);
+    const u32 slices = max_out_len ? (max_out_len + 65535u) / 65536u : 1u;
+    hipLaunchKernelGGL(k_dec_crc, dim3(slices, a.nb), dim3(256), 0, st, a, out_base, out, crc_tab, xp2);
+}
+
+} // namespace bzgpu

@@ -619,22 +619,6 @@ __global__ __launch_bounds__(CT) void k_rle_cuts(const u8 *__restrict__ in, u64 
 }
 
 // ---- kernel G: block CRC from tile CRCs -------------------------------------------
-// xp2[k] = x^(8 * 2^k) mod P, k = 0..47
-__device__ __forceinline__ u32 gf_xpow_bytes(u64 nbytes, const u32 *__restrict__ xp2)
-{
-    u32 r = 1u;
-    for (u32 k = 0; nbytes; ++k, nbytes >>= 1)
-        if (nbytes & 1u) r = gf_mulmod(r, xp2[k]);
-    return r;
-}
-
-__device__ __forceinline__ u32 crc_bytes_raw(const u8 *__restrict__ p, u64 len, const u32 *s_tab)
-{
-    u32 crc = 0;
-    for (u64 i = 0; i < len; ++i) crc = s_tab[(crc >> 24) ^ p[i]] ^ (crc << 8);
-    return crc;
-}
-
 __global__ __launch_bounds__(RT) void k_block_crc(const u8 *__restrict__ in,
                                                    const BlockDesc *__restrict__ blocks,
                                                    const u32 *__restrict__ crc_tab,
