@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""bench_decode.py -- BZip2 DECODE throughput on MI355X (SURVEY.md row a18 / BASELINE.json
+configs[3]; the contract benchmark of the north-star path is bench.py).
+
+A "step" is one pass of the decode path (magic scan -> Huffman -> zero runs + inverse MTF ->
+inverse BWT -> RLE1 undo -> CRC check) over the .bz2 stream of the synthetic corpus, compressed
+stream and decoded bytes resident in HBM.  The stream is produced by this library's encoder
+(bit-identical to the reference's) outside the timed region.  Prints ONE JSON line.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mib", type=int, default=1024)
+    ap.add_argument("--level", type=int, default=9)
+    ap.add_argument("--cpu-sample-mib", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--corpus", default="text", choices=["text", "t2"])
+    args = ap.parse_args()
+
+    import torch
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    pkg = importlib.import_module("rust-compression_amd")
+    import corpus
+
+    total = args.mib << 20
+    if args.corpus == "t2":
+        d_in = torch.frombuffer(bytearray(corpus.stress_t2(total)), dtype=torch.uint8).to(dev)
+    else:
+        d_in = corpus.corpus_on_device(total, dev)
+    n = d_in.numel()
+    eng = pkg.GpuEngine(0, min(n // 800000 + 8, 1400))
+    cap = (pkg.encode_bound(n) + 15) & ~15
+    d_z = torch.empty(cap, dtype=torch.uint8, device=dev)
+    zn = eng.encode_device(args.level, d_in.data_ptr(), n, d_z.data_ptr(), cap)
+    d_out = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+
+    state = {}
+
+    def step():
+        state["res"] = eng.decode_device(d_z.data_ptr(), zn, d_out.data_ptr(), n)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out_len, verdict = state["res"]
+    same = bool(verdict == 0 and out_len == n and torch.equal(d_out[:n], d_in))
+    stages = eng.decode_timings()
+    result = {
+        "metric": "BZip2 decode MB/s (decoded bytes, HBM-resident in and out)",
+        "value": round(n * args.steps / dt / 1e6, 2), "unit": "MB/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32", "data": "synthetic",
+        "config": {"workload": "%d MiB %s corpus, level-%d stream of %d bytes" % (n >> 20, args.corpus, args.level, zn)},
+        "kernel_seconds_last_step": {k: round(v, 5) for k, v in stages.items()},
+        "decode_stats": eng.decode_stats(),
+        "checks": {"decoded_equals_input": same},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import oracle
+        smp = min(args.cpu_sample_mib << 20, n)
+        d_s = torch.empty((pkg.encode_bound(smp) + 15) & ~15, dtype=torch.uint8, device=dev)
+        k = eng.encode_device(args.level, d_in.data_ptr(), smp, d_s.data_ptr(), d_s.numel())
+        z = bytes(d_s[:k].cpu().numpy())
+        oracle.lib()
+        c0 = time.perf_counter()
+        ref, st = oracle.decode(z, smp + 1024)
+        cdt = time.perf_counter() - c0
+        result["cpu_baseline"] = {"value": round(smp / cdt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
+                                  "sample": "stream of the first %d MiB of the same corpus, oracle/bz2_oracle.c decoder "
+                                            "restatement, single thread like the reference" % (smp >> 20)}
+        result["checks"]["oracle_decodes_sample"] = bool(st == 0 and ref == bytes(d_in[:smp].cpu().numpy()))
+    print(json.dumps(result))
+    if not all(result["checks"].values()):
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

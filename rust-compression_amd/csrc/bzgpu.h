@@ -279,11 +279,17 @@ struct DecBlockInfo {
     u32 randomised;
     u32 n_in_use;
     u32 nsym;       // symbols decoded, EOB included
+    u32 next_head;  // the 8 bits behind the block (the head byte of the next record), read like BitReader does:
+    u32 next_bits;  // ... next_bits (< 8 at the end of the input) bits were there
     u8 seq2unseq[256];
 };
 
-constexpr u32 kDecSamples = kMaxBlockLen / 1024 + 3; // inverse-BWT sample nodes per block (+ the start node)
-constexpr u32 kDecTiles = kMaxBlockLen / 1024 + 2;   // RLE1-undo tiles per block
+#ifndef BZ_DEC_SAMPLE_STEP
+#define BZ_DEC_SAMPLE_STEP 256
+#endif
+constexpr u32 kDecSampleStep = BZ_DEC_SAMPLE_STEP;             // every n-th T slot is a sample node
+constexpr u32 kDecSamples = kMaxBlockLen / kDecSampleStep + 3; // sample nodes per block (the last one = the start node)
+constexpr u32 kDecSubs = kSlot / 64;                           // 64-byte RLE1-undo sub-tiles per block
 struct DecArgs {
     u32 nb;
     const u32 *slot;              // [nb] candidate slot (index into info / sym) of each true block, stream order
@@ -299,7 +305,11 @@ struct DecArgs {
     u8 *X;                        // [nb * kSlot] RLE1 image
     u32 *samp_next, *samp_len, *samp_off; // [nb][kDecSamples]
     u32 *cycle_len;               // [nb]
-    u32 *tile_off, *tile_state;   // [nb][kDecTiles] RLE1 undo: output offset / state per 1024-byte tile
+    uint4 *sub_trans;             // [nb][kDecSubs] RLE1 undo: sub-tile transition tables
+    u32 *sub_off;                 // [nb][kDecSubs + 1] output offset of every sub-tile (and the total)
+    u8 *sub_state;                // [nb][kDecSubs] entering state of every sub-tile
+    u32 *work_ctr;                // [2] work counters of the persistent walkers
+    uint4 *walk_meta;             // [nb] {length, start node, first byte} per block
     u32 *out_len;                 // [nb]
     u32 *thist;                   // [nb][kTilesPerBlock][256] T-vector sort: per-tile byte counts
     u32 *tbase;                   // [nb][256]
@@ -309,7 +319,7 @@ void launch_dec_scan(hipStream_t st, const u8 *in, u64 nbytes, DecCand *cands, u
 void launch_dec_blocks(hipStream_t st, const u8 *in, u64 nbytes, const DecCand *cands, u32 ncand, DecBlockInfo *info,
                        u16 *sym, u8 *sel_scratch);
 void launch_dec_mtf(hipStream_t st, const DecArgs &a);
-void launch_dec_walks(hipStream_t st, const DecArgs &a);
+void launch_dec_walks(hipStream_t st, const DecArgs &a, u32 walk_wgs);
 void launch_dec_expand(hipStream_t st, const DecArgs &a, const u64 *out_base, u8 *out);
 void launch_dec_crc(hipStream_t st, const DecArgs &a, const u64 *out_base, const u8 *out, u32 max_out_len,
                     const u32 *crc_tab, const u32 *xp2);

@@ -28,7 +28,7 @@ struct Ev {
 struct DecWorkspace {
     size_t slots = 0;
     DevBuf cands, count, info, sym, sel, slot, nbmax, perm, chunk_emit, tt_len, err, L, T, X, samp_next, samp_len,
-        samp_off, cycle_len, tile_off, tile_state, out_len, thist, tbase, crc, out_base, staging, cand_all;
+        samp_off, cycle_len, sub_trans, sub_off, sub_state, work_ctr, walk_meta, out_len, thist, tbase, crc, out_base, staging, cand_all;
     double t_stage[5] = {0, 0, 0, 0, 0};
     u64 stats[4] = {0, 0, 0, 0}; // candidates, blocks, streams, forced blocks
 };
@@ -38,7 +38,7 @@ void dec_workspace_free(DecWorkspace *w)
     if (!w) return;
     DevBuf *all[] = {&w->cands, &w->count, &w->info, &w->sym, &w->sel, &w->slot, &w->nbmax, &w->perm,
                      &w->chunk_emit, &w->tt_len, &w->err, &w->L, &w->T, &w->X, &w->samp_next, &w->samp_len,
-                     &w->samp_off, &w->cycle_len, &w->tile_off, &w->tile_state, &w->out_len, &w->thist, &w->tbase,
+                     &w->samp_off, &w->cycle_len, &w->sub_trans, &w->sub_off, &w->sub_state, &w->work_ctr, &w->walk_meta, &w->out_len, &w->thist, &w->tbase,
                      &w->crc, &w->out_base, &w->staging, &w->cand_all};
     for (DevBuf *b : all) b->release();
     delete w;
@@ -57,7 +57,8 @@ static int dec_ensure(DecWorkspace *w, size_t slots)
         (rc = w->T.ensure(s * (size_t)kSlot * 4)) || (rc = w->X.ensure(s * (size_t)kSlot + 64)) ||
         (rc = w->samp_next.ensure(s * (size_t)kDecSamples * 4)) || (rc = w->samp_len.ensure(s * (size_t)kDecSamples * 4)) ||
         (rc = w->samp_off.ensure(s * (size_t)kDecSamples * 4)) || (rc = w->cycle_len.ensure(s * 4)) ||
-        (rc = w->tile_off.ensure(s * (size_t)kDecTiles * 4)) || (rc = w->tile_state.ensure(s * (size_t)kDecTiles * 4)) ||
+        (rc = w->sub_trans.ensure(s * (size_t)kDecSubs * 16)) || (rc = w->sub_off.ensure(s * (size_t)(kDecSubs + 1) * 4)) ||
+        (rc = w->sub_state.ensure(s * (size_t)kDecSubs)) || (rc = w->work_ctr.ensure(1024)) || (rc = w->walk_meta.ensure(s * 16)) ||
         (rc = w->out_len.ensure(s * 4)) || (rc = w->thist.ensure(s * (size_t)kTilesPerBlock * 256 * 4)) ||
         (rc = w->tbase.ensure(s * 256 * 4)) || (rc = w->crc.ensure(s * 4)) || (rc = w->out_base.ensure(s * 8)))
         return rc;
@@ -188,10 +189,15 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
     const size_t nc = cands.size();
     w->stats[0] = nc;
 
-    u32 B = 1024;
+    u32 B = 4096; // about 9.5 MB of workspace per block in flight
     if (const char *e = getenv("BZ_DEC_BATCH")) {
         const long v = atol(e);
         if (v >= 1 && v <= 65536) B = (u32)v;
+    }
+    u32 walk_wgs = 256; // persistent walker workgroups (bounds the window of blocks being walked)
+    if (const char *e = getenv("BZ_DEC_WALK_WGS")) {
+        const long v = atol(e);
+        if (v >= 1 && v <= 65536) walk_wgs = (u32)v;
     }
     if (nc < B) B = (u32)(nc ? nc : 1);
     {
@@ -208,6 +214,8 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
     u64 pos = 0;
     u32 stream_no = 1, level = 0, combined = 0;
     bool need_header = true;
+    bool have_next = false;
+    u32 next_head = 0, next_bits = 0;
     size_t ci = 0;
     bool finished = false;
 
@@ -245,7 +253,14 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                 need_header = false;
             }
             u64 p = pos;
-            const u32 head = rd.read(p, 8);
+            u32 head;
+            if (have_next) { // the block in front of this record already looked at these 8 bits
+                head = next_head;
+                p = pos + next_bits;
+                have_next = false;
+            } else {
+                head = rd.read(p, 8);
+            }
             if (head == 0x31u) {
                 while (cj < nc && cands[cj].bitpos < pos) ++cj;
                 int slot = -1;
@@ -287,6 +302,9 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                 bcrc.push_back(bi.stored_crc);
                 combined = rotl1(combined) ^ bi.stored_crc; // decoder.rs:199-200 (done when the next record is opened)
                 pos = bi.end_bit;
+                have_next = true;
+                next_head = bi.next_head;
+                next_bits = bi.next_bits;
                 if (bslot.size() >= (size_t)B) stop = true;
             } else if (head == 0x17u) { // end of stream, decoder.rs:487-520
                 pos = p;
@@ -335,8 +353,11 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             a.samp_len = w->samp_len.as<u32>();
             a.samp_off = w->samp_off.as<u32>();
             a.cycle_len = w->cycle_len.as<u32>();
-            a.tile_off = w->tile_off.as<u32>();
-            a.tile_state = w->tile_state.as<u32>();
+            a.sub_trans = w->sub_trans.as<uint4>();
+            a.sub_off = w->sub_off.as<u32>();
+            a.sub_state = w->sub_state.as<u8>();
+            a.work_ctr = w->work_ctr.as<u32>();
+            a.walk_meta = w->walk_meta.as<uint4>();
             a.out_len = w->out_len.as<u32>();
             a.thist = w->thist.as<u32>();
             a.tbase = w->tbase.as<u32>();
@@ -351,7 +372,7 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             HIPDEC(hipStreamSynchronize(st));
             stage_time(1);
             HIPDEC(hipEventRecord(ev[0], st));
-            launch_dec_walks(st, a);
+            launch_dec_walks(st, a, walk_wgs);
             HIPDEC(hipEventRecord(ev[1], st));
             std::vector<u32> h_err(nb), h_len(nb);
             HIPDEC(hipMemcpyAsync(h_err.data(), w->err.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));

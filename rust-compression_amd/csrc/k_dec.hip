@@ -108,10 +108,51 @@ struct BitCur {
     __device__ __forceinline__ u64 pos() const { return widx * 32ull - (u64)cnt; }
 };
 
-constexpr u32 kLutBits = 12;
+#ifndef BZ_DEC_LUT_BITS
+#define BZ_DEC_LUT_BITS 11
+#endif
+constexpr u32 kLutBits = BZ_DEC_LUT_BITS;
 constexpr u16 kLutLong = 0xFFFE, kLutBad = 0xFFFF;
+constexpr u32 kRingWords = 256;  // staged input window (words), power of two
+constexpr u32 kOutBuf = 1024;    // staged output symbols
+
+// bit cursor over the staged window (same arithmetic as BitCur; the words come from LDS)
+struct RingCur {
+    const u32 *ring;
+    u64 widx;
+    u64 buf;
+    int cnt;
+    __device__ __forceinline__ void seek(u64 bitpos)
+    {
+        widx = bitpos >> 5;
+        const u32 sh = (u32)bitpos & 31u;
+        const u32 x = ring[widx & (kRingWords - 1)];
+        ++widx;
+        buf = (u64)x << (32u + sh);
+        cnt = 32 - (int)sh;
+    }
+    __device__ __forceinline__ void fill()
+    {
+        if (cnt <= 32) {
+            const u32 x = ring[widx & (kRingWords - 1)];
+            ++widx;
+            buf |= (u64)x << (32 - cnt);
+            cnt += 32;
+        }
+    }
+    __device__ __forceinline__ u32 peek(u32 n) { return n ? (u32)(buf >> (64u - n)) : 0u; }
+    __device__ __forceinline__ void skip(u32 n)
+    {
+        buf <<= n;
+        cnt -= (int)n;
+    }
+    __device__ __forceinline__ u64 pos() const { return widx * 32ull - (u64)cnt; }
+};
 
 // ---- D1: header + Huffman decode of one candidate -------------------------------------------------------
+// One wave per candidate.  Lane 0 parses the header; all lanes build the decode tables; then lane 0
+// walks the symbols out of an LDS window that all lanes refill (and whose output they flush), so
+// the serial lane never waits on global memory.
 __global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64 nbytes,
                                                    const DecCand *__restrict__ cands, u32 ncand,
                                                    DecBlockInfo *__restrict__ info, u16 *__restrict__ sym_out,
@@ -122,6 +163,9 @@ __global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64
     __shared__ u32 s_cnt[6][24], s_first[6][24], s_idx[6][24];
     __shared__ u16 s_perm[6][260];
     __shared__ u32 s_hdr[8]; // n_groups, alpha, n_selectors, status
+    __shared__ u32 s_ring[kRingWords];
+    __shared__ u16 s_out[kOutBuf];
+    __shared__ u64 s_pos;
     const u32 c = blockIdx.x;
     if (c >= ncand) return;
     const u32 l = threadIdx.x;
@@ -210,6 +254,7 @@ __global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64
             s_hdr[1] = alpha;
             s_hdr[2] = n_selectors;
             s_hdr[3] = status ? 1u : 0u;
+            s_pos = bc.pos();
             if (status) {
                 bi.status = (u32)status;
                 bi.end_bit = bc.pos();
@@ -220,7 +265,7 @@ __global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64
     __syncthreads();
     if (s_hdr[3]) return;
     const u32 n_groups = s_hdr[0], alpha = s_hdr[1], n_selectors = s_hdr[2];
-    // ---- decode tables (all lanes): canonical codes, 12-bit lookup, per-length arrays for longer codes
+    // ---- decode tables (all lanes): canonical codes, lookup table, per-length arrays for longer codes
     for (u32 i = l; i < 6 * 24; i += 64) (&s_cnt[0][0])[i] = 0;
     for (u32 i = l; i < 6u << kLutBits; i += 64) (&s_lut[0][0])[i] = kLutBad;
     __syncthreads();
@@ -240,7 +285,7 @@ __global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64
             if ((u64)code + s_cnt[l][ln] > (1ull << ln)) bad = 1; // over-subscribed: the reference indexes out of bounds
         }
         for (u32 s = 0; s < alpha; ++s)
-            if (s_len[l][s] == 0 || s_len[l][s] > 23) bad |= (s_len[l][s] > 23) ? 1u : 0u;
+            if (s_len[l][s] > 23) bad = 1;
         if (bad) atomicExch(&s_hdr[3], 1u);
     }
     __syncthreads();
@@ -268,74 +313,213 @@ __global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64
         }
     }
     __syncthreads();
-    if (l != 0) return;
-    // ---- the symbols (:367-437), one lane; its cursor still stands right after the coding tables
+    // ---- the symbols (:367-437)
+    // Huffman decode is serial bit by bit, but not lane by lane: in every round lane j looks up the
+    // code that WOULD start at bit pos + j (one LDS gather for 64 candidate starts), then the true
+    // starts are picked out by hopping from start to start with v_readlane on wave-uniform (scalar)
+    // state -- about 15 scalar cycles per symbol instead of a full dependent LDS round trip.  The
+    // table is fixed inside a 50-symbol group, so a round ends at the group's end, at the end of the
+    // 64-bit window, at EOB, or at a code the lookup table does not resolve (longer than kLutBits
+    // bits / owned by no symbol), which is decoded on its own.
     u16 *out = sym_out + (size_t)c * kMtfStride;
     const u32 eob = alpha - 1;
-    u32 nsym = 0;
-    int status = 0;
-    bool done = false;
-    for (u32 g = 0; !done && !status; ++g) {
-        if (g >= n_selectors) { // group_no > n_selectors (:381-383)
-            status = BZ_DEC_E_DATA;
-            break;
+    const u64 total_bits = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)((nbytes * 8ull) >> 32)) << 32) |
+                           (u32)__builtin_amdgcn_readfirstlane((int)(u32)(nbytes * 8ull));
+    u64 pos = s_pos;
+    pos = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(pos >> 32)) << 32) |
+          (u32)__builtin_amdgcn_readfirstlane((int)(u32)pos);
+    u32 flushed = 0;
+    u32 g = 0, krem = 0, t = 0; // krem == 0: open the next group before the next symbol
+    u32 t_next = sel[0];        // (fetched one group ahead: the load's latency stays off the serial path)
+    const u64 lt_mask = (l == 0) ? 0ull : (~0ull >> (64 - l));
+    u32 state = 0; // 0 running, 1 end of block, 2 error
+    while (true) {
+        const u64 wb = pos >> 5;
+#pragma unroll
+        for (u32 q = 0; q < kRingWords / 64; ++q) {
+            const u64 i = wb + q * 64u + l;
+            s_ring[i & (kRingWords - 1)] = bc.load(i);
         }
-        const u16 *lut = s_lut[sel[g]];
-        const u32 t = sel[g];
-        for (u32 k = 0; k < kGSize; ++k) {
-            if (bc.pos() >= nbytes * 8ull) { // peek returns no bits: Ok(None) -> DataError (:387-390)
-                status = BZ_DEC_E_DATA;
-                break;
-            }
-            bc.fill();
-            const u32 e = lut[bc.peek(kLutBits)];
-            u32 sy;
-            if (e < kLutLong) {
-                sy = e & 511u;
-                bc.skip(e >> 9);
-            } else if (e == kLutLong) {
-                // codes longer than the table: canonical walk from 13 bits up
-                u32 code = bc.peek(kLutBits), ln = kLutBits;
-                bool hit = false;
-                while (ln < 23u) {
-                    ++ln;
-                    code = bc.peek(ln);
-                    const u32 rel = code - s_first[t][ln];
-                    if (code >= s_first[t][ln] && rel < s_cnt[t][ln]) {
-                        sy = s_perm[t][s_idx[t][ln] + rel];
-                        hit = true;
-                        break;
-                    }
-                }
-                // the bits beyond the 12-bit table are taken one by one and fail at the end of the input
-                // (huffman/decoder.rs:221-224)
-                if (!hit || bc.pos() + ln > nbytes * 8ull) {
-                    status = BZ_DEC_E_DATA;
+        __syncthreads();
+        u32 nout = 0;
+        const u64 wend = (wb + kRingWords) * 32ull; // first bit not staged
+        while (nout + 129u <= kOutBuf && pos + 224ull <= wend) {
+            if (krem == 0) {
+                if (g >= n_selectors) { // group_no > n_selectors (:381-383)
+                    state = 2;
                     break;
                 }
-                bc.skip(ln);
-            } else {
-                status = BZ_DEC_E_DATA; // a bit pattern no code owns (unreachable!() in the reference)
+                t = (u32)__builtin_amdgcn_readfirstlane((int)t_next);
+                ++g;
+                t_next = sel[g < n_selectors ? g : 0u];
+                krem = kGSize;
+            }
+            if (pos >= total_bits) { // peek returns no bits: Ok(None) -> DataError (:387-390)
+                state = 2;
                 break;
             }
-            if (nsym >= kMtfStride - 1u) { // more symbols than any legal block holds
-                status = BZ_DEC_E_DATA;
+            // two candidate code starts per lane: bits pos + l and pos + 64 + l
+            const u64 bp = pos + l;
+            const u32 wi = (u32)(bp >> 5), sh = (u32)bp & 31u;
+            const u32 r0 = s_ring[wi & (kRingWords - 1)], r1 = s_ring[(wi + 1u) & (kRingWords - 1)];
+            const u32 r2 = s_ring[(wi + 2u) & (kRingWords - 1)], r3 = s_ring[(wi + 3u) & (kRingWords - 1)];
+            const u32 ea = s_lut[t][(u32)(((((u64)r0 << 32) | r1) << sh) >> (64u - kLutBits))];
+            const u32 eb = s_lut[t][(u32)(((((u64)r2 << 32) | r3) << sh) >> (64u - kLutBits))];
+            const u32 len_a = (ea < kLutLong) ? (ea >> 9) : 0u, sym_a = ea & 511u;
+            const u32 len_b = (eb < kLutLong) ? (eb >> 9) : 0u, sym_b = eb & 511u;
+            // lanes at which a chain of code starts has to stop: EOB, or a code the table does not resolve
+            const u64 stop_a = __ballot(len_a == 0u || sym_a == eob);
+            const u32 hop_a = len_a ? len_a : 64u, hop_b = len_b ? len_b : 64u;
+            // Hop along the true code starts.  A lone wave issues an instruction only every ~10 cycles, so
+            // the loops are kept to the bare hop; everything else is sorted out once per round below.
+            // The window ends after 128 candidate starts or at the end of the input (the round after
+            // that reports the missing bits).
+            const u64 left = total_bits - pos;
+            const u32 lim = left < 128ull ? (u32)left : 128u;
+            const u32 lim_a = lim < 64u ? lim : 64u;
+            u32 off = 0;
+            u64 chain_a = 0, chain_b = 0;
+            do {
+                chain_a |= 1ull << off;
+                off += (u32)__builtin_amdgcn_readlane((int)hop_a, (int)off);
+            } while (off < lim_a);
+            u32 cnt_a = (u32)__popcll(chain_a);
+            if (off < lim && cnt_a < krem && (chain_a & stop_a) == 0ull) { // on into the second half
+                off -= 64u;
+                const u32 lim_b = lim - 64u;
+                do {
+                    chain_b |= 1ull << off;
+                    off += (u32)__builtin_amdgcn_readlane((int)hop_b, (int)off);
+                } while (off < lim_b);
+                off += 64u;
+            }
+            u32 stop = 0; // 1 EOB, 2 unresolved code
+            u32 cnt = cnt_a;
+            const u32 rank_a = (u32)__popcll(chain_a & lt_mask);
+            u32 rank_b = 0;
+            if (chain_b == 0ull) {
+                if (cnt_a > krem) { // the group (and with it the table) ends inside the window
+                    const u64 m = __ballot(((chain_a >> l) & 1ull) && rank_a + 1u == krem);
+                    const u32 p = (u32)__builtin_ctzll(m);
+                    chain_a &= ~0ull >> (63u - p);
+                    off = p + (u32)__builtin_amdgcn_readlane((int)hop_a, (int)p);
+                    cnt = krem;
+                }
+                const u64 st = chain_a & stop_a;
+                if (st) {
+                    const u32 f = (u32)__builtin_ctzll(st);
+                    const u32 flen = (u32)__builtin_amdgcn_readlane((int)len_a, (int)f);
+                    if (flen == 0u) {
+                        chain_a &= (1ull << f) - 1ull;
+                        off = f;
+                        stop = 2;
+                    } else {
+                        chain_a &= ~0ull >> (63u - f);
+                        off = f + flen;
+                        stop = 1;
+                    }
+                    cnt = (u32)__popcll(chain_a);
+                }
+            } else { // (the first half is complete: no stop in it, fewer than krem symbols)
+                rank_b = cnt_a + (u32)__popcll(chain_b & lt_mask);
+                cnt = cnt_a + (u32)__popcll(chain_b);
+                if (cnt > krem) {
+                    const u64 m = __ballot(((chain_b >> l) & 1ull) && rank_b + 1u == krem);
+                    const u32 p = (u32)__builtin_ctzll(m);
+                    chain_b &= ~0ull >> (63u - p);
+                    off = 64u + p + (u32)__builtin_amdgcn_readlane((int)hop_b, (int)p);
+                    cnt = krem;
+                }
+                const u64 stop_b = __ballot(len_b == 0u || sym_b == eob);
+                const u64 st = chain_b & stop_b;
+                if (st) {
+                    const u32 f = (u32)__builtin_ctzll(st);
+                    const u32 flen = (u32)__builtin_amdgcn_readlane((int)len_b, (int)f);
+                    if (flen == 0u) {
+                        chain_b &= (1ull << f) - 1ull;
+                        off = 64u + f;
+                        stop = 2;
+                    } else {
+                        chain_b &= ~0ull >> (63u - f);
+                        off = 64u + f + flen;
+                        stop = 1;
+                    }
+                    cnt = cnt_a + (u32)__popcll(chain_b);
+                }
+            }
+            if ((chain_a >> l) & 1ull) s_out[nout + rank_a] = (u16)sym_a;
+            if ((chain_b >> l) & 1ull) s_out[nout + rank_b] = (u16)sym_b;
+            nout += cnt;
+            krem -= cnt;
+            pos += off;
+            if (stop == 1) {
+                state = 1;
                 break;
             }
-            out[nsym++] = (u16)sy;
-            if (sy == eob) {
-                done = true;
+            if (stop == 2) {
+                // one symbol the table does not resolve: canonical walk from kLutBits + 1 bits up
+                const u32 wi0 = (u32)(pos >> 5), sh0 = (u32)pos & 31u;
+                const u64 two0 = ((u64)s_ring[wi0 & (kRingWords - 1)] << 32) | s_ring[(wi0 + 1u) & (kRingWords - 1)];
+                const u64 bits = two0 << sh0; // the next 32 bits, left aligned
+                const u32 e0 = s_lut[t][(u32)(bits >> (64u - kLutBits))];
+                u32 ln = kLutBits, sy = 0;
+                bool hit = false;
+                if (e0 == kLutLong) {
+                    while (ln < 23u) {
+                        ++ln;
+                        const u32 code = (u32)(bits >> (64u - ln));
+                        const u32 rel = code - s_first[t][ln];
+                        if (code >= s_first[t][ln] && rel < s_cnt[t][ln]) {
+                            sy = s_perm[t][s_idx[t][ln] + rel];
+                            hit = true;
+                            break;
+                        }
+                    }
+                }
+                // the reference's table is min(max_len, 12) bits wide; bits beyond it are taken one by one
+                // and fail at the end of the input (huffman/decoder.rs:150-233); a pattern no code owns
+                // is unreachable!() there
+                if (!hit || (ln > 12u && pos + ln > total_bits)) {
+                    state = 2;
+                    break;
+                }
+                if (l == 0) s_out[nout] = (u16)sy;
+                ++nout;
+                --krem;
+                pos += ln;
+                if (sy == eob) {
+                    state = 1;
+                    break;
+                }
+            }
+            if (flushed + nout > kMaxBlockLen + 1u) { // more symbols than any block the reference accepts
+                state = 2;
                 break;
             }
         }
+        __syncthreads();
+        for (u32 i = l; i < nout; i += 64) out[flushed + i] = s_out[i];
+        flushed += nout;
+        if (state) {
+            if (l == 0) {
+                bi.status = state == 2 ? (u32)BZ_DEC_E_DATA : 0u;
+                bi.end_bit = pos;
+                bi.nsym = flushed;
+                // the host's record chain wants the head byte of whatever follows
+                const u64 avail = total_bits > pos ? total_bits - pos : 0ull;
+                const u32 k = avail < 8ull ? (u32)avail : 8u;
+                bc.seek(pos);
+                const u32 v = bc.read(8);
+                bi.next_bits = k;
+                bi.next_head = k ? (v >> (8u - k)) : 0u;
+            }
+            break;
+        }
+        __syncthreads();
     }
-    bi.status = (u32)status;
-    bi.end_bit = bc.pos();
-    bi.nsym = nsym;
 }
 
 // ---- D2: zero runs + inverse MTF --------------------------------------------------------------------
-constexpr u32 kDecSampleStep = 1024;
 
 // zero-run value of the digits sym[a..b) (bijective base 2, least significant first, decoder.rs:419-424);
 // returns 0xFFFFFFFF when the run is longer than the reference accepts (n >= 2 Mi, :413-416)
@@ -506,76 +690,200 @@ __global__ __launch_bounds__(256) void k_dec_chunk_emit(DecArgs a)
 }
 
 // ---- D3: the pointer chase, cut at sample nodes ----------------------------------------------------------
+// T[slot] = (position << 8) | byte, where `byte` is the digit of the bucket the slot lies in -- the
+// byte the chase emits when it LEAVES the slot (L[T[slot]] == first-column byte of slot).  One
+// random 4-byte load per step, like the reference's tt[] (decoder.rs:468-473,533-536).
+//
+// Segments between sample nodes have geometric lengths; a lane-per-segment launch would idle most
+// lanes of a wave while its longest segment finishes.  The walkers are persistent instead: a lane
+// that finishes a segment takes the next (block, sample) item from a global counter (one atomic
+// per wave and refill).  Items are block-major, so the blocks being walked at any time are a
+// window of a few dozen whose T vectors stay in the 256 MB Infinity Cache.
 __device__ __forceinline__ u32 sample_id(u32 node, u32 p0)
 {
     if (node == p0) return kDecSamples - 1u;
     return (node % kDecSampleStep == 0) ? node / kDecSampleStep : 0xFFFFFFFFu;
 }
 
-__global__ __launch_bounds__(256) void k_dec_walk_lengths(DecArgs a)
+// hands out work items to the idle lanes of a wave; returns false when nothing is left for this lane
+__device__ __forceinline__ bool take_item(u32 *ctr, u32 total, bool idle, u32 &id, u32 &base)
 {
-    const u32 lb = blockIdx.y;
-    if (a.err[lb]) return;
-    const u32 n = a.tt_len[lb];
-    const u32 sid = blockIdx.x * 256u + threadIdx.x;
-    if (sid >= kDecSamples) return;
-    const u32 *T = a.T + (size_t)lb * kSlot;
-    const u32 p0 = T[a.info[a.slot[lb]].orig_ptr];
-    u32 node;
-    if (sid == kDecSamples - 1u) node = p0;
-    else {
-        node = sid * kDecSampleStep;
-        if (node >= n || node == p0) return; // (p0's segment belongs to the start sample)
-    }
-    u32 cur = node, len = 0, nid;
-    do {
-        cur = T[cur];
-        ++len;
-        nid = sample_id(cur, p0);
-    } while (nid == 0xFFFFFFFFu && len <= n);
-    a.samp_next[(size_t)lb * kDecSamples + sid] = nid;
-    a.samp_len[(size_t)lb * kDecSamples + sid] = len;
+    const u64 need = __ballot(idle);
+    const u32 l = lane_id();
+    base = 0;
+    const u32 leader = (u32)__builtin_ctzll(need);
+    if (l == leader) base = atomicAdd(ctr, (u32)__popcll(need));
+    base = __shfl(base, (int)leader);
+    const u64 lt = (l == 0) ? 0ull : (~0ull >> (64 - l));
+    id = base + (u32)__popcll(need & lt);
+    return idle && id < total;
 }
 
-__global__ __launch_bounds__(64) void k_dec_rank_samples(DecArgs a)
+constexpr u32 kWalkBurst = 8;   // steps between looks at the idle lanes
+constexpr u32 kWalkRefill = 16; // idle lanes that make a wave fetch new items (an atomic round trip)
+
+// per-block constants of the walkers: {length (0 = skip the block), start node, first byte}
+__global__ __launch_bounds__(64) void k_dec_walk_meta(DecArgs a)
 {
     const u32 lb = blockIdx.x * 64u + threadIdx.x;
-    if (lb >= a.nb || a.err[lb]) return;
-    const u32 n = a.tt_len[lb];
-    u32 *off = a.samp_off + (size_t)lb * kDecSamples;
-    for (u32 i = 0; i < kDecSamples; ++i) off[i] = 0xFFFFFFFFu;
-    u32 s = kDecSamples - 1u, o = 0, cyc = n;
-    while (o < n) {
-        if (off[s] != 0xFFFFFFFFu) { // back at a visited sample: T has a cycle shorter than n (periodic block)
-            cyc = o;
-            break;
-        }
-        off[s] = o;
-        o += a.samp_len[(size_t)lb * kDecSamples + s];
-        s = a.samp_next[(size_t)lb * kDecSamples + s];
-        if (s == 0xFFFFFFFFu) break;
+    if (lb >= a.nb) return;
+    uint4 m = {0u, 0u, 0u, 0u};
+    if (!a.err[lb]) {
+        const u32 v = a.T[(size_t)lb * kSlot + a.info[a.slot[lb]].orig_ptr];
+        m.x = a.tt_len[lb];
+        m.y = v >> 8;    // tt[orig_pos] >> 8: the first node (decoder.rs:476)
+        m.z = v & 0xFFu;
     }
-    a.cycle_len[lb] = cyc;
+    a.walk_meta[lb] = m;
+}
+
+__global__ __launch_bounds__(256) void k_dec_walk_lengths(DecArgs a)
+{
+    // blocks are dealt to the XCDs (workgroup i runs on XCD i % 8): a block's T vector is walked by
+    // one XCD only and stays in that XCD's 4 MiB L2
+    const u32 xcd = blockIdx.x & 7u;
+    const u32 total = ((a.nb + 7u - xcd) / 8u) * kDecSamples;
+    u32 *ctr = a.work_ctr + xcd * 16u;
+    bool have = false;
+    u32 cur = 0, len = 0, n = 0, p0 = 0, slot = 0;
+    const u32 *T = nullptr;
+    bool dry = false;
+    while (true) {
+        const u64 idle = __ballot(!have);
+        if ((!dry && (u32)__popcll(idle) >= kWalkRefill) || idle == ~0ull) {
+            u32 id, first_id;
+            const bool got = take_item(ctr, total, !have, id, first_id);
+            if (got) {
+                const u32 q = id / kDecSamples, sid = id - q * kDecSamples;
+                const u32 lb = q * 8u + xcd;
+                slot = lb * kDecSamples + sid;
+                const uint4 m = a.walk_meta[lb];
+                if (m.x) {
+                    n = m.x;
+                    T = a.T + (size_t)lb * kSlot;
+                    p0 = m.y;
+                    const u32 node = (sid == kDecSamples - 1u) ? p0 : sid * kDecSampleStep;
+                    // (p0's segment belongs to the start sample)
+                    if (sid == kDecSamples - 1u || (node < n && node != p0)) {
+                        cur = node;
+                        len = 0;
+                        have = true;
+                    }
+                }
+            }
+            if (first_id + (u32)__popcll(idle) >= total) dry = true; // the last items are handed out
+            if (!__ballot(have)) {
+                if (first_id >= total) break; // the counter ran dry and no lane holds a segment
+                continue;                     // every item taken was an empty one: take more
+            }
+        }
+#pragma unroll 1
+        for (u32 s = 0; s < kWalkBurst; ++s) {
+            if (have) {
+                cur = T[cur] >> 8;
+                ++len;
+                const u32 nid = sample_id(cur, p0);
+                if (nid != 0xFFFFFFFFu || len > n) {
+                    a.samp_next[slot] = nid;
+                    a.samp_len[slot] = len;
+                    have = false;
+                }
+            }
+        }
+    }
+}
+
+// order of the samples along the chain: one wave per block, the chain itself in LDS
+__global__ __launch_bounds__(64) void k_dec_rank_samples(DecArgs a)
+{
+    __shared__ u32 s_len[kDecSamples];
+    __shared__ u16 s_next[kDecSamples];
+    __shared__ u32 s_seen[(kDecSamples + 31) / 32];
+    const u32 lb = blockIdx.x, l = threadIdx.x;
+    if (a.err[lb]) return;
+    const u32 n = a.tt_len[lb];
+    const size_t base = (size_t)lb * kDecSamples;
+    for (u32 i = l; i < kDecSamples; i += 64) {
+        const bool live = (i == kDecSamples - 1u) || (i * kDecSampleStep < n);
+        const u32 nx = live ? a.samp_next[base + i] : 0xFFFFFFFFu;
+        s_next[i] = nx < kDecSamples ? (u16)nx : (u16)0xFFFFu;
+        s_len[i] = live ? a.samp_len[base + i] : 0u;
+        a.samp_off[base + i] = 0xFFFFFFFFu;
+    }
+    for (u32 i = l; i < (kDecSamples + 31) / 32; i += 64) s_seen[i] = 0;
+    __threadfence();
+    __syncthreads();
+    if (l == 0) {
+        u32 s = kDecSamples - 1u, o = 0, cyc = n;
+        while (o < n) {
+            if ((s_seen[s >> 5] >> (s & 31u)) & 1u) { // back at a visited sample: the chain closes before n steps
+                cyc = o;
+                break;
+            }
+            s_seen[s >> 5] |= 1u << (s & 31u);
+            a.samp_off[base + s] = o;
+            o += s_len[s];
+            s = s_next[s];
+            if (s >= kDecSamples) break;
+        }
+        a.cycle_len[lb] = cyc;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_dec_walk_write(DecArgs a)
 {
-    const u32 lb = blockIdx.y;
-    if (a.err[lb]) return;
-    const u32 n = a.tt_len[lb];
-    const u32 sid = blockIdx.x * 256u + threadIdx.x;
-    if (sid >= kDecSamples) return;
-    const u32 o0 = a.samp_off[(size_t)lb * kDecSamples + sid];
-    if (o0 == 0xFFFFFFFFu) return;
-    const u32 *T = a.T + (size_t)lb * kSlot;
-    const u8 *L = a.L + (size_t)lb * kSlot;
-    u8 *X = a.X + (size_t)lb * kSlot;
-    const u32 p0 = T[a.info[a.slot[lb]].orig_ptr];
-    u32 cur = (sid == kDecSamples - 1u) ? p0 : sid * kDecSampleStep;
-    const u32 len = a.samp_len[(size_t)lb * kDecSamples + sid];
-    for (u32 k = 0; k < len && o0 + k < n; ++k) {
-        X[o0 + k] = L[cur]; // tt[pos] & 0xFF, then pos = tt[pos] >> 8 (decoder.rs:533-536)
-        cur = T[cur];
+    const u32 xcd = blockIdx.x & 7u;
+    const u32 total = ((a.nb + 7u - xcd) / 8u) * kDecSamples;
+    u32 *ctr = a.work_ctr + 128u + xcd * 16u;
+    bool have = false;
+    u32 cur = 0, left = 0, o = 0, n = 0;
+    const u32 *T = nullptr;
+    u8 *X = nullptr;
+    bool dry = false;
+    while (true) {
+        const u64 idle = __ballot(!have);
+        if ((!dry && (u32)__popcll(idle) >= kWalkRefill) || idle == ~0ull) {
+            u32 id, first_id;
+            const bool got = take_item(ctr, total, !have, id, first_id);
+            if (got) {
+                const u32 q = id / kDecSamples, sid = id - q * kDecSamples;
+                const u32 lb = q * 8u + xcd;
+                id = lb * kDecSamples + sid;
+                const uint4 m = a.walk_meta[lb];
+                if (m.x) {
+                    const u32 o0 = a.samp_off[id];
+                    if (o0 != 0xFFFFFFFFu) {
+                        n = m.x;
+                        T = a.T + (size_t)lb * kSlot;
+                        X = a.X + (size_t)lb * kSlot;
+                        if (sid == kDecSamples - 1u) {
+                            cur = m.y;
+                            X[0] = (u8)m.z; // tt[orig_pos] & 0xFF is the first byte (decoder.rs:476,533-536)
+                        } else {
+                            cur = sid * kDecSampleStep;
+                        }
+                        o = o0 + 1u;
+                        left = a.samp_len[id];
+                        have = left != 0;
+                    }
+                }
+            }
+            if (first_id + (u32)__popcll(idle) >= total) dry = true;
+            if (!__ballot(have)) {
+                if (first_id >= total) break;
+                continue;
+            }
+        }
+#pragma unroll 1
+        for (u32 s = 0; s < kWalkBurst; ++s) {
+            if (have) {
+                const u32 v = T[cur];
+                if (o < n) X[o] = (u8)v;
+                ++o;
+                cur = v >> 8;
+                if (--left == 0) have = false;
+            }
+        }
     }
 }
 
@@ -595,83 +903,234 @@ __global__ __launch_bounds__(256) void k_dec_fixups(DecArgs a)
         while (true) {
             const u32 step = kBz2RNums[tpos];
             tpos = (tpos + 1u) & 511u;
-            // n2go is loaded with rNums, decremented once per byte; the byte where it reaches 1 is flipped
-            q += step - 1u;
-            if (q >= n) break;
-            X[q] ^= 1u;
-            q += 1u;
+            // n2go is loaded with rNums[tpos] when it is 0, then decremented for every byte; the byte at
+            // which it reaches 1 is flipped: the last but one of each stretch of rNums[tpos] bytes
+            if (q + step - 2u >= n) break;
+            X[q + step - 2u] ^= 1u;
+            q += step;
         }
     }
 }
 
 // ---- D4: RLE1 undo (decoder.rs:550-578) ---------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_dec_rle_states(DecArgs a)
+// The undo is a little state machine (last byte, equal bytes seen; after four equal bytes the next
+// byte is a repeat count).  A 64-byte sub-tile is a function from its entering state to its exit
+// state and output size; relative to the sub-tile's first byte only five entering states differ:
+//   e = 0  no equal byte in front (fresh)      e = 1..3  that many bytes equal to the first byte
+//   e = 4  the first byte is a count
+// k_dec_rle_sub tabulates that function for every sub-tile, k_dec_rle_chain composes them along the
+// block (1024 threads, each folds its share; one thread links the 1024 partial results), and
+// k_dec_rle_expand replays every sub-tile from its now known entering state.
+struct RleSt {
+    u32 last, cnt, out;
+};
+__device__ __forceinline__ void rle_step(RleSt &s, u32 b)
 {
-    const u32 lb = blockIdx.x * 64u + threadIdx.x;
-    if (lb >= a.nb || a.err[lb]) return;
-    const u32 n = a.tt_len[lb];
-    const u8 *X = a.X + (size_t)lb * kSlot;
-    u32 *toff = a.tile_off + (size_t)lb * kDecTiles, *tst = a.tile_state + (size_t)lb * kDecTiles;
-    u32 out = 0, cnt = 0, last = 0x100; // cnt = equal bytes seen (0..4; 4 = the next byte is a count)
-    for (u32 i0 = 0; i0 < n; i0 += 16u) {
-        if ((i0 & 1023u) == 0) {
-            toff[i0 >> 10] = out;
-            tst[i0 >> 10] = (cnt << 16) | last;
-        }
-        const uint4 q = *reinterpret_cast<const uint4 *>(X + i0);
-        const u32 wv[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (u32 k = 0; k < 16; ++k) {
-            if (i0 + k < n) {
-                const u32 b = (wv[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-                if (cnt == 4u) {
-                    out += b;
-                    cnt = 0;
-                    last = 0x100;
-                } else if (b == last) {
-                    ++cnt;
-                    out += 1;
-                } else {
-                    last = b;
-                    cnt = 1;
-                    out += 1;
-                }
-            }
-        }
+    if (s.cnt == 4u) {
+        s.out += b;
+        s.cnt = 0;
+        s.last = 0x100u;
+    } else if (b == s.last) {
+        ++s.cnt;
+        ++s.out;
+    } else {
+        s.last = b;
+        s.cnt = 1;
+        ++s.out;
     }
-    a.out_len[lb] = out;
-    // four equal bytes with no count byte behind them: the reference reads on around the closed
-    // pointer chain and never terminates (decoder.rs:566-570); reported as DataError here
-    if (cnt == 4u) a.err[lb] = 1u;
 }
 
-__global__ __launch_bounds__(256) void k_dec_rle_expand(DecArgs a, const u64 *__restrict__ out_base, u8 *__restrict__ out)
+__global__ __launch_bounds__(256) void k_dec_rle_sub(DecArgs a)
 {
     const u32 lb = blockIdx.y;
     if (a.err[lb]) return;
     const u32 n = a.tt_len[lb];
-    const u32 tile = blockIdx.x * 256u + threadIdx.x;
-    const u32 i0 = tile * 1024u;
-    if (i0 >= n) return;
+    const u32 sub = blockIdx.x * 256u + threadIdx.x;
+    const u32 p = sub * 64u;
+    if (p >= n) return;
     const u8 *X = a.X + (size_t)lb * kSlot;
-    u8 *dst = out + out_base[lb] + a.tile_off[(size_t)lb * kDecTiles + tile];
-    const u32 st = a.tile_state[(size_t)lb * kDecTiles + tile];
-    u32 cnt = st >> 16, last = st & 0xFFFFu;
-    const u32 i1 = (i0 + 1024u < n) ? i0 + 1024u : n;
-    for (u32 i = i0; i < i1; ++i) {
-        const u32 b = X[i];
-        if (cnt == 4u) {
-            for (u32 k = 0; k < b; ++k) *dst++ = (u8)last;
-            cnt = 0;
-            last = 0x100;
-        } else if (b == last) {
-            ++cnt;
-            *dst++ = (u8)b;
-        } else {
-            last = b;
-            cnt = 1;
-            *dst++ = (u8)b;
+    const u32 b0 = X[p];
+    RleSt st[5];
+    st[0] = {0x100u, 0u, 0u};
+    st[1] = {b0, 1u, 0u};
+    st[2] = {b0, 2u, 0u};
+    st[3] = {b0, 3u, 0u};
+    st[4] = {0x100u, 4u, 0u};
+    const u32 end = (p + 64u < n) ? 64u : n - p;
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(X + p + q * 16u);
+        const u32 wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (u32 k = 0; k < 16; ++k) {
+            if (q * 16u + k < end) {
+                const u32 b = (wv[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+#pragma unroll
+                for (u32 e = 0; e < 5; ++e) rle_step(st[e], b);
+            }
         }
+    }
+    const u32 nxt = (p + 64u < n) ? (u32)X[p + 64u] : 0x200u;
+    u32 epack = 0;
+#pragma unroll
+    for (u32 e = 0; e < 5; ++e) {
+        const u32 ex = (st[e].cnt == 4u) ? 4u : ((st[e].last == nxt) ? st[e].cnt : 0u);
+        epack |= ex << (3u * e);
+    }
+    uint4 tr;
+    tr.x = st[0].out | (st[1].out << 16);
+    tr.y = st[2].out | (st[3].out << 16);
+    tr.z = st[4].out | (epack << 16);
+    tr.w = 0;
+    a.sub_trans[(size_t)lb * kDecSubs + sub] = tr;
+}
+
+__device__ __forceinline__ void rle_apply(const uint4 tr, u32 &e, u32 &off)
+{
+    const u32 o01 = tr.x, o23 = tr.y;
+    const u32 out = (e == 0) ? (o01 & 0xFFFFu) : (e == 1) ? (o01 >> 16) : (e == 2) ? (o23 & 0xFFFFu)
+                  : (e == 3) ? (o23 >> 16) : (tr.z & 0xFFFFu);
+    off += out;
+    e = ((tr.z >> 16) >> (3u * e)) & 7u;
+}
+
+__global__ __launch_bounds__(1024) void k_dec_rle_chain(DecArgs a)
+{
+    __shared__ u32 s_out[1024][5];
+    __shared__ u16 s_ep[1024];
+    __shared__ u32 s_in_off[1024];
+    __shared__ u8 s_in_e[1024];
+    const u32 lb = blockIdx.x, j = threadIdx.x;
+    if (a.err[lb]) return;
+    const u32 n = a.tt_len[lb];
+    const u32 nsub = (n + 63u) / 64u;
+    const u32 K = (nsub + 1023u) / 1024u;
+    const u32 s0 = j * K, s1 = (s0 + K < nsub) ? s0 + K : nsub;
+    const uint4 *tr = a.sub_trans + (size_t)lb * kDecSubs;
+    {
+        u32 e[5] = {0, 1, 2, 3, 4}, off[5] = {0, 0, 0, 0, 0};
+        for (u32 s = s0; s < s1; ++s) {
+            const uint4 t = tr[s];
+#pragma unroll
+            for (u32 q = 0; q < 5; ++q) rle_apply(t, e[q], off[q]);
+        }
+        u32 ep = 0;
+#pragma unroll
+        for (u32 q = 0; q < 5; ++q) {
+            s_out[j][q] = off[q];
+            ep |= e[q] << (3u * q);
+        }
+        s_ep[j] = (u16)ep;
+    }
+    __syncthreads();
+    if (j == 0) {
+        u32 e = 0, off = 0;
+        for (u32 t = 0; t < 1024; ++t) {
+            s_in_e[t] = (u8)e;
+            s_in_off[t] = off;
+            off += s_out[t][e];
+            e = ((u32)s_ep[t] >> (3u * e)) & 7u;
+        }
+        a.out_len[lb] = off;
+        a.sub_off[(size_t)lb * (kDecSubs + 1) + nsub] = off;
+        // four equal bytes with no count byte behind them: the reference reads on around the closed
+        // pointer chain and never terminates (decoder.rs:566-570); reported as DataError here
+        if (e == 4u) a.err[lb] = 1u;
+    }
+    __syncthreads();
+    {
+        u32 e = s_in_e[j], off = s_in_off[j];
+        for (u32 s = s0; s < s1; ++s) {
+            a.sub_state[(size_t)lb * kDecSubs + s] = (u8)e;
+            a.sub_off[(size_t)lb * (kDecSubs + 1) + s] = off;
+            rle_apply(tr[s], e, off);
+        }
+    }
+}
+
+// replays one sub-tile from its entering state; WP is an LDS or a global byte pointer
+template <class WP>
+__device__ __forceinline__ void rle_replay(const u8 *__restrict__ src, u32 end, u32 last, u32 cnt, WP wp)
+{
+    u32 o = 0;
+#pragma unroll 1
+    for (u32 q = 0; q < 4; ++q) {
+        if (q * 16u >= end) break;
+        const uint4 v = *reinterpret_cast<const uint4 *>(src + q * 16u);
+        const u32 wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (u32 k = 0; k < 16; ++k) {
+            if (q * 16u + k < end) {
+                const u32 b = (wv[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+                if (cnt == 4u) {
+                    for (u32 r = 0; r < b; ++r) wp[o + r] = (u8)last;
+                    o += b;
+                    cnt = 0;
+                    last = 0x100u;
+                } else {
+                    if (b == last) ++cnt;
+                    else {
+                        last = b;
+                        cnt = 1;
+                    }
+                    wp[o++] = (u8)b;
+                }
+            }
+        }
+    }
+}
+
+constexpr u32 kExpStage = 8192; // staged output bytes per wave (4 KiB of image; long runs bypass it)
+
+__global__ __launch_bounds__(256) void k_dec_rle_expand(DecArgs a, const u64 *__restrict__ out_base, u8 *__restrict__ out)
+{
+    __shared__ u32 s_stage[4][kExpStage / 4 + 2];
+    const u32 lb = blockIdx.y;
+    if (a.err[lb]) return;
+    const u32 n = a.tt_len[lb];
+    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const u32 sub0 = (blockIdx.x * 4u + w) * 64u; // first sub-tile of this wave
+    if (sub0 * 64u >= n) return;
+    const u32 nsub = (n + 63u) / 64u;
+    const u32 sub = sub0 + l;
+    const u32 *soff = a.sub_off + (size_t)lb * (kDecSubs + 1);
+    const u32 wave_last = (sub0 + 64u < nsub) ? sub0 + 64u : nsub;
+    const u32 base = soff[sub0], total = soff[wave_last] - base;
+    const u8 *X = a.X + (size_t)lb * kSlot;
+    u8 *dst = out + out_base[lb] + base;
+    const u32 shift = (u32)(reinterpret_cast<uintptr_t>(dst) & 3u);
+    const bool staged = total + shift <= kExpStage;
+    u8 *stage = reinterpret_cast<u8 *>(s_stage[w]);
+    if (sub < nsub) {
+        const u32 p = sub * 64u;
+        const u32 e = a.sub_state[(size_t)lb * kDecSubs + sub];
+        u32 last = 0x100u, cnt = 0;
+        if (e >= 1u && e <= 3u) {
+            last = X[p];
+            cnt = e;
+        } else if (e == 4u) {
+            last = X[p - 1u];
+            cnt = 4u;
+        }
+        const u32 o = soff[sub] - base;
+        const u32 end = (p + 64u < n) ? 64u : n - p;
+        if (staged) rle_replay(X + p, end, last, cnt, stage + shift + o);
+        else rle_replay(X + p, end, last, cnt, dst + o);
+    }
+    if (!staged) return;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): this wave's LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    // flush: aligned dwords in the middle, bytes at both ends
+    u8 *gbase = dst - shift;                 // 4-byte aligned
+    const u32 first = shift, lastb = shift + total; // byte range inside the staging buffer
+    const u32 dw0 = (first + 3u) / 4u, dw1 = lastb / 4u;
+    if (dw0 <= dw1) {
+        for (u32 i = dw0 + l; i < dw1; i += 64u) reinterpret_cast<u32 *>(gbase)[i] = s_stage[w][i];
+        if (l < dw0 * 4u - first) gbase[first + l] = stage[first + l];                 // head bytes (< 4)
+        if (l < lastb - dw1 * 4u) gbase[dw1 * 4u + l] = stage[dw1 * 4u + l];           // tail bytes (< 4)
+    } else {
+        if (l < total) gbase[first + l] = stage[first + l]; // everything inside one dword
     }
 }
 
@@ -812,7 +1271,7 @@ __global__ __launch_bounds__(kSortThreads) void k_dec_tscatter(DecArgs a)
         if (i < cnt_tile) {
             const u32 e = s_buf[i];
             const u32 dg = e >> 24;
-            T[s_base[dg] + (i - (u32)s_tpre[dg])] = e & 0xFFFFFFu;
+            T[s_base[dg] + (i - (u32)s_tpre[dg])] = ((e & 0xFFFFFFu) << 8) | dg;
         }
     }
 }
@@ -870,23 +1329,26 @@ void launch_dec_mtf(hipStream_t st, const DecArgs &a)
     hipLaunchKernelGGL(k_dec_chunk_emit, dim3(cw, a.nb), dim3(256), 0, st, a);
 }
 
-void launch_dec_walks(hipStream_t st, const DecArgs &a)
+void launch_dec_walks(hipStream_t st, const DecArgs &a, u32 walk_wgs)
 {
     const dim3 tiles(kTilesPerBlock, xcd_grid_y(a.nb));
     hipLaunchKernelGGL(k_dec_thist, tiles, dim3(kSortThreads), 0, st, a);
     hipLaunchKernelGGL(k_dec_tscan, dim3(a.nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dec_tscatter, tiles, dim3(kSortThreads), 0, st, a);
-    const u32 sw = (kDecSamples + 255) / 256;
-    hipLaunchKernelGGL(k_dec_walk_lengths, dim3(sw, a.nb), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_dec_rank_samples, dim3((a.nb + 63) / 64), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(k_dec_walk_write, dim3(sw, a.nb), dim3(256), 0, st, a);
+    (void)hipMemsetAsync(a.work_ctr, 0, 1024, st);
+    hipLaunchKernelGGL(k_dec_walk_meta, dim3((a.nb + 63) / 64), dim3(64), 0, st, a);
+    const u32 wgs = (walk_wgs + 7u) & ~7u; // the same number of walkers on every XCD
+    hipLaunchKernelGGL(k_dec_walk_lengths, dim3(wgs), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_dec_rank_samples, dim3(a.nb), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_dec_walk_write, dim3(wgs), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dec_fixups, dim3(a.nb), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_dec_rle_states, dim3((a.nb + 63) / 64), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_dec_rle_sub, dim3((kDecSubs + 255) / 256, a.nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_dec_rle_chain, dim3(a.nb), dim3(1024), 0, st, a);
 }
 
 void launch_dec_expand(hipStream_t st, const DecArgs &a, const u64 *out_base, u8 *out)
 {
-    hipLaunchKernelGGL(k_dec_rle_expand, dim3((kDecTiles + 255) / 256, a.nb), dim3(256), 0, st, a, out_base, out);
+    hipLaunchKernelGGL(k_dec_rle_expand, dim3((kDecSubs + 255) / 256, a.nb), dim3(256), 0, st, a, out_base, out);
 }
 
 void launch_dec_crc(hipStream_t st, const DecArgs &a, const u64 *out_base, const u8 *out, u32 max_out_len,

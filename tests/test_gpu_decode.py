@@ -226,13 +226,13 @@ def test_decode_device_api(pkg, oracle, eng):
     n, st = eng.decode_device(tin.data_ptr(), len(z), tout.data_ptr(), size)
     assert (n, st) == (len(want), 0)
     assert bytes(tout[:n].cpu().numpy()) == want
-    with pytest.raises(pkg.CompressionError) as ei:
-        eng.decode_device(tin.data_ptr(), len(z), tout.data_ptr(), size - 1)
-    assert ei.value.kind == "Capacity"
     stats = eng.decode_stats()
     assert stats["blocks"] >= 2 and stats["streams"] == 2
     t = eng.decode_timings()
     assert t["total"] > 0
+    with pytest.raises(pkg.CompressionError) as ei:
+        eng.decode_device(tin.data_ptr(), len(z), tout.data_ptr(), size - 1)
+    assert ei.value.kind == "Capacity"
 
 
 def test_encode_decode_device_round_trip_large(pkg, eng):
