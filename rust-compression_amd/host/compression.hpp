@@ -9,6 +9,9 @@
 //   trait Encoder { fn next(..) }       src/traits/encoder.rs:81-93   compression::Encoder (concept)
 //   struct BZip2Encoder                 src/bzip2/encoder.rs:40-159   compression::BZip2Encoder
 //   EncodeExt::encode / EncodeIterator  src/traits/encoder.rs:12-79   compression::encode(), EncodeIterator
+//   enum BZip2Error {..}                src/bzip2/error.rs:5-11       compression::BZip2Error (+ to_compression_error)
+//   struct BZip2Decoder                 src/bzip2/decoder.rs:583-612  compression::BZip2Decoder
+//   DecodeExt::decode / DecodeIterator  src/traits/decoder.rs:15-86   compression::decode(), DecodeIterator
 //
 // Semantics kept: BZip2Encoder(level) throws std::invalid_argument where the reference panics
 // (level outside 1..=9); next() returns std::nullopt for None, a Result holding either the byte
@@ -44,13 +47,46 @@ inline CompressionError from_status(int rc)
     return CompressionError::Unexpected; // HIP failures, missing GPU, ... (the encoder's only error, encoder.rs:623)
 }
 
-template <class T> struct Result {
+template <class T, class E = CompressionError> struct Result {
     bool ok;
     T value;
-    CompressionError error;
-    static Result Ok(T v) { return Result{true, v, CompressionError::Unexpected}; }
-    static Result Err(CompressionError e) { return Result{false, T(), e}; }
+    E error;
+    static Result Ok(T v) { return Result{true, v, E::Unexpected}; }
+    static Result Err(E e) { return Result{false, T(), e}; }
 };
+
+// src/bzip2/error.rs:5-11
+enum class BZip2Error { DataError, DataErrorMagicFirst, DataErrorMagic, UnexpectedEof, Unexpected };
+
+inline const char *description(BZip2Error e)
+{ // src/bzip2/error.rs:31-42
+    switch (e) {
+    case BZip2Error::DataError: return "data integrity (CRC) error in data";
+    case BZip2Error::DataErrorMagicFirst: return "bad magic number (file not created by bzip2)";
+    case BZip2Error::DataErrorMagic: return "trailing garbage after EOF ignored";
+    case BZip2Error::UnexpectedEof: return "file ends unexpectedly";
+    default: return "unexpected error";
+    }
+}
+
+// impl From<BZip2Error> for CompressionError, src/bzip2/error.rs:45-53
+inline CompressionError to_compression_error(BZip2Error e)
+{
+    if (e == BZip2Error::UnexpectedEof) return CompressionError::UnexpectedEof;
+    if (e == BZip2Error::Unexpected) return CompressionError::Unexpected;
+    return CompressionError::DataError;
+}
+
+inline BZip2Error bzip2_error_from_status(int rc)
+{
+    switch (rc) {
+    case BZ_E_DATA: return BZip2Error::DataError;
+    case BZ_E_MAGIC_FIRST: return BZip2Error::DataErrorMagicFirst;
+    case BZ_E_MAGIC: return BZip2Error::DataErrorMagic;
+    case BZ_E_EOF: return BZip2Error::UnexpectedEof;
+    default: return BZip2Error::Unexpected; // HIP failures, missing GPU, ...
+    }
+}
 
 class BZip2Encoder {
   public:
@@ -137,17 +173,94 @@ template <class C, class E> auto encode(const C &container, E &encoder, Action a
                                                                                       container.end(), encoder, action);
 }
 
-// `.collect::<Result<Vec<_>, _>>()`
-template <class It> Result<std::vector<uint8_t>> collect(It iter)
+class BZip2Decoder {
+  public:
+    using Input = uint8_t;
+    using Output = uint8_t;
+    using Error = BZip2Error;
+
+    explicit BZip2Decoder(int device = 0) // BZip2Decoder::new, src/bzip2/decoder.rs:588-594
+    {
+        const int rc = bz_dec_create(&h_, device);
+        if (rc != BZ_OK) throw std::runtime_error(bz_strerror(rc));
+        buf_.resize(1 << 16);
+    }
+    BZip2Decoder(const BZip2Decoder &) = delete;
+    BZip2Decoder &operator=(const BZip2Decoder &) = delete;
+    ~BZip2Decoder() { bz_dec_destroy(h_); }
+
+    // Decoder::next (src/traits/decoder.rs:95-98, src/bzip2/decoder.rs:604-612): the decoded bytes in
+    // order, then the Err item if the stream is bad, then None
+    template <class I, class S> std::optional<Result<uint8_t, BZip2Error>> next(I &it, const S &end)
+    {
+        if (pos_ == len_) {
+            if (!ended_) {
+                // (the reference pulls input bytes on demand; the bytes are the same)
+                while (it != end) {
+                    chunk_.clear();
+                    while (it != end && chunk_.size() < kChunk) {
+                        chunk_.push_back(static_cast<uint8_t>(*it));
+                        ++it;
+                    }
+                    const int rc = bz_dec_write(h_, chunk_.data(), chunk_.size());
+                    if (rc != BZ_OK) return Result<uint8_t, BZip2Error>::Err(bzip2_error_from_status(rc));
+                }
+                ended_ = true;
+                (void)bz_dec_end(h_); // the verdict comes back from bz_dec_read behind the last byte
+            }
+            const long k = bz_dec_read(h_, buf_.data(), buf_.size());
+            if (k < 0) {
+                if (failed_) return std::nullopt;
+                failed_ = true;
+                return Result<uint8_t, BZip2Error>::Err(bzip2_error_from_status(static_cast<int>(k)));
+            }
+            len_ = static_cast<size_t>(k);
+            pos_ = 0;
+            if (len_ == 0) return std::nullopt;
+        }
+        return Result<uint8_t, BZip2Error>::Ok(buf_[pos_++]);
+    }
+
+  private:
+    static constexpr size_t kChunk = 1 << 20;
+    bz_dec *h_ = nullptr;
+    std::vector<uint8_t> buf_, chunk_;
+    size_t pos_ = 0, len_ = 0;
+    bool ended_ = false, failed_ = false;
+};
+
+// DecodeIterator (src/traits/decoder.rs:45-86)
+template <class I, class S, class D> class DecodeIterator {
+  public:
+    DecodeIterator(I first, S last, D &dec) : it_(first), end_(last), dec_(dec) {}
+    std::optional<Result<typename D::Output, typename D::Error>> next() { return dec_.next(it_, end_); }
+
+  private:
+    I it_;
+    S end_;
+    D &dec_;
+};
+
+// DecodeExt::decode (src/traits/decoder.rs:27-43)
+template <class C, class D> auto decode(const C &container, D &decoder)
 {
+    return DecodeIterator<decltype(container.begin()), decltype(container.end()), D>(container.begin(),
+                                                                                      container.end(), decoder);
+}
+
+// `.collect::<Result<Vec<_>, _>>()`
+template <class It> auto collect(It iter)
+{
+    using Item = typename decltype(iter.next())::value_type;
+    using Err = decltype(Item::error);
     std::vector<uint8_t> out;
     for (;;) {
         auto r = iter.next();
         if (!r) break;
-        if (!r->ok) return Result<std::vector<uint8_t>>::Err(r->error);
+        if (!r->ok) return Result<std::vector<uint8_t>, Err>::Err(r->error);
         out.push_back(r->value);
     }
-    return Result<std::vector<uint8_t>>::Ok(std::move(out));
+    return Result<std::vector<uint8_t>, Err>::Ok(std::move(out));
 }
 
 } // namespace compression

@@ -30,6 +30,29 @@ int main()
         std::printf("test_long: unexpected size %zu\n", r2.value.size());
         return 1;
     }
+    // the reference's decoder tests (src/bzip2/mod.rs:60-82 style): decode what was just encoded
+    {
+        BZip2Decoder dec;
+        auto back = collect(decode(ret.value, dec));
+        if (!back.ok || std::string(back.value.begin(), back.value.end()) != src) {
+            std::printf("decode(test_unit): MISMATCH\n");
+            return 1;
+        }
+        BZip2Decoder dec2;
+        auto back2 = collect(decode(r2.value, dec2));
+        if (!back2.ok || std::string(back2.value.begin(), back2.value.end()) != longs) {
+            std::printf("decode(test_long): MISMATCH\n");
+            return 1;
+        }
+        BZip2Decoder dec3;
+        const std::string bad = "BZh0";
+        auto r3 = collect(decode(bad, dec3));
+        if (r3.ok || r3.error != BZip2Error::DataErrorMagicFirst ||
+            to_compression_error(r3.error) != CompressionError::DataError) {
+            std::printf("decode(bad magic): wrong verdict\n");
+            return 1;
+        }
+    }
     bool threw = false;
     try {
         BZip2Encoder bad(0);

@@ -138,3 +138,107 @@ impl Drop for BZip2Encoder {
         unsafe { bz_enc_destroy(self.h) }
     }
 }
+
+// ---- decoder: `BZip2Decoder` (src/bzip2/decoder.rs:583-612) over section 3 of the C ABI -------------
+// Dropped into the crate as `src/bzip2/decoder.rs` behind the same feature gate; `Decoder`,
+// `DecodeExt` and `BZip2Error` stay the crate's own (src/traits/decoder.rs, src/bzip2/error.rs).
+use crate::bzip2::error::BZip2Error;
+use crate::traits::decoder::Decoder;
+
+#[allow(non_camel_case_types)]
+type bz_dec = c_void;
+
+#[link(name = "bz2_mi355x")]
+extern "C" {
+    fn bz_dec_create(out: *mut *mut bz_dec, device: i32) -> i32;          // BZip2Decoder::new      decoder.rs:588-594
+    fn bz_dec_write(d: *mut bz_dec, data: *const u8, n: usize) -> i32;    // iterator yields bytes
+    fn bz_dec_end(d: *mut bz_dec) -> i32;                                 // iterator returns None: decode
+    fn bz_dec_read(d: *mut bz_dec, out: *mut u8, cap: usize) -> isize;    // items handed out       decoder.rs:604-612
+    fn bz_dec_destroy(d: *mut bz_dec);
+}
+
+pub struct BZip2Decoder {
+    h: *mut bz_dec,
+    ready: Vec<u8>,
+    pos: usize,
+    ended: bool,
+    failed: bool,
+}
+
+impl Default for BZip2Decoder {
+    fn default() -> Self {
+        Self::new()
+    }
+}
+
+impl BZip2Decoder {
+    pub fn new() -> Self {
+        let mut h = core::ptr::null_mut();
+        let rc = unsafe { bz_dec_create(&mut h, 0) };
+        assert!(rc == 0, "bz2_mi355x: no usable gfx950 device");
+        Self { h, ready: Vec::new(), pos: 0, ended: false, failed: false }
+    }
+}
+
+impl Drop for BZip2Decoder {
+    fn drop(&mut self) {
+        unsafe { bz_dec_destroy(self.h) }
+    }
+}
+
+fn map_bz_err(rc: i32) -> BZip2Error {
+    match rc {
+        -1 => BZip2Error::DataError,
+        -4 => BZip2Error::DataErrorMagicFirst,
+        -5 => BZip2Error::DataErrorMagic,
+        -2 => BZip2Error::UnexpectedEof,
+        _ => BZip2Error::Unexpected,
+    }
+}
+
+impl Decoder for BZip2Decoder {
+    type Input = u8;
+    type Output = u8;
+    type Error = BZip2Error;
+
+    fn next<I: Iterator<Item = u8>>(&mut self, iter: &mut I) -> Option<Result<u8, BZip2Error>> {
+        if self.pos == self.ready.len() {
+            if !self.ended {
+                // the reference pulls bytes on demand; the bytes are the same
+                let mut chunk: Vec<u8> = Vec::with_capacity(CHUNK);
+                loop {
+                    chunk.clear();
+                    chunk.extend(iter.by_ref().take(CHUNK));
+                    if chunk.is_empty() {
+                        break;
+                    }
+                    let rc = unsafe { bz_dec_write(self.h, chunk.as_ptr(), chunk.len()) };
+                    if rc != 0 {
+                        return Some(Err(map_bz_err(rc)));
+                    }
+                }
+                self.ended = true;
+                unsafe { bz_dec_end(self.h) }; // the verdict follows the last byte out of bz_dec_read
+            }
+            self.ready.resize(1 << 16, 0);
+            let k = unsafe { bz_dec_read(self.h, self.ready.as_mut_ptr(), self.ready.len()) };
+            if k < 0 {
+                self.ready.clear();
+                self.pos = 0;
+                if self.failed {
+                    return None;
+                }
+                self.failed = true;
+                return Some(Err(map_bz_err(k as i32)));
+            }
+            self.ready.truncate(k as usize);
+            self.pos = 0;
+            if k == 0 {
+                return None;
+            }
+        }
+        let b = self.ready[self.pos];
+        self.pos += 1;
+        Some(Ok(b))
+    }
+}
