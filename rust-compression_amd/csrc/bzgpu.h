@@ -289,6 +289,7 @@ struct DecBlockInfo {
 #endif
 constexpr u32 kDecSampleStep = BZ_DEC_SAMPLE_STEP;             // every n-th T slot is a sample node
 constexpr u32 kDecSamples = kMaxBlockLen / kDecSampleStep + 3; // sample nodes per block (the last one = the start node)
+constexpr u32 kSegCap = 4 * kDecSampleStep;                    // scratch bytes per segment (mean length = the step)
 constexpr u32 kDecSubs = kSlot / 64;                           // 64-byte RLE1-undo sub-tiles per block
 struct DecArgs {
     u32 nb;
@@ -310,6 +311,8 @@ struct DecArgs {
     u8 *sub_state;                // [nb][kDecSubs] entering state of every sub-tile
     u32 *work_ctr;                // [2] work counters of the persistent walkers
     uint4 *walk_meta;             // [nb] {length, start node, first byte} per block
+    u8 *seg_buf;                  // [nb][kDecSamples][kSegCap] bytes passed by each segment's walk
+    u32 *seg_cont;                // [nb][kDecSamples] node reached after kSegCap steps
     u32 *out_len;                 // [nb]
     u32 *thist;                   // [nb][kTilesPerBlock][256] T-vector sort: per-tile byte counts
     u32 *tbase;                   // [nb][256]

@@ -737,6 +737,9 @@ __global__ __launch_bounds__(64) void k_dec_walk_meta(DecArgs a)
     a.walk_meta[lb] = m;
 }
 
+// Walk 1: every segment (sample node -> next sample node) is walked once.  The bytes it passes are
+// kept in the segment's scratch row (dword stores, kSegCap bytes); its length and successor go to
+// the sample arrays.  The node reached after kSegCap steps is remembered for the few long segments.
 __global__ __launch_bounds__(256) void k_dec_walk_lengths(DecArgs a)
 {
     // blocks are dealt to the XCDs (workgroup i runs on XCD i % 8): a block's T vector is walked by
@@ -745,8 +748,9 @@ __global__ __launch_bounds__(256) void k_dec_walk_lengths(DecArgs a)
     const u32 total = ((a.nb + 7u - xcd) / 8u) * kDecSamples;
     u32 *ctr = a.work_ctr + xcd * 16u;
     bool have = false;
-    u32 cur = 0, len = 0, n = 0, p0 = 0, slot = 0;
+    u32 cur = 0, len = 0, n = 0, p0 = 0, slot = 0, acc = 0;
     const u32 *T = nullptr;
+    u8 *row = nullptr;
     bool dry = false;
     while (true) {
         const u64 idle = __ballot(!have);
@@ -767,6 +771,8 @@ __global__ __launch_bounds__(256) void k_dec_walk_lengths(DecArgs a)
                     if (sid == kDecSamples - 1u || (node < n && node != p0)) {
                         cur = node;
                         len = 0;
+                        acc = 0;
+                        row = a.seg_buf + (size_t)slot * kSegCap;
                         have = true;
                     }
                 }
@@ -780,10 +786,20 @@ __global__ __launch_bounds__(256) void k_dec_walk_lengths(DecArgs a)
 #pragma unroll 1
         for (u32 s = 0; s < kWalkBurst; ++s) {
             if (have) {
-                cur = T[cur] >> 8;
+                const u32 v = T[cur]; // tt[pos]: the byte in the low 8 bits, the next position above (decoder.rs:533-536)
+                cur = v >> 8;
+                if (len < kSegCap) {
+                    acc |= (v & 0xFFu) << (8u * (len & 3u));
+                    if ((len & 3u) == 3u) {
+                        *reinterpret_cast<u32 *>(row + (len - 3u)) = acc;
+                        acc = 0;
+                    }
+                }
                 ++len;
+                if (len == kSegCap) a.seg_cont[slot] = cur;
                 const u32 nid = sample_id(cur, p0);
                 if (nid != 0xFFFFFFFFu || len > n) {
+                    if (len < kSegCap && (len & 3u)) *reinterpret_cast<u32 *>(row + (len & ~3u)) = acc;
                     a.samp_next[slot] = nid;
                     a.samp_len[slot] = len;
                     have = false;
@@ -830,6 +846,30 @@ __global__ __launch_bounds__(64) void k_dec_rank_samples(DecArgs a)
     }
 }
 
+// Copy: the scratch rows go to their places in the RLE1 image, one wave per segment.
+__global__ __launch_bounds__(256) void k_dec_seg_copy(DecArgs a)
+{
+    const u32 lb = blockIdx.y;
+    const uint4 m = a.walk_meta[lb];
+    if (!m.x) return;
+    const u32 n = m.x;
+    const u32 sid = blockIdx.x * 4u + (threadIdx.x >> 6), l = threadIdx.x & 63u;
+    if (sid >= kDecSamples) return;
+    const u32 id = lb * kDecSamples + sid;
+    const u32 o0 = a.samp_off[id];
+    if (o0 == 0xFFFFFFFFu) return;
+    u8 *X = a.X + (size_t)lb * kSlot;
+    if (sid == kDecSamples - 1u && l == 0) X[0] = (u8)m.z; // tt[orig_pos] & 0xFF is the first byte (decoder.rs:476)
+    const u32 len = a.samp_len[id];
+    const u32 cnt = len < kSegCap ? len : kSegCap;
+    const u8 *row = a.seg_buf + (size_t)id * kSegCap;
+    for (u32 k = l; k < cnt; k += 64u) {
+        const u32 o = o0 + 1u + k;
+        if (o < n) X[o] = row[k];
+    }
+}
+
+// Walk 2: only what the scratch rows could not hold (segments longer than kSegCap) is walked again.
 __global__ __launch_bounds__(256) void k_dec_walk_write(DecArgs a)
 {
     const u32 xcd = blockIdx.x & 7u;
@@ -852,19 +892,15 @@ __global__ __launch_bounds__(256) void k_dec_walk_write(DecArgs a)
                 const uint4 m = a.walk_meta[lb];
                 if (m.x) {
                     const u32 o0 = a.samp_off[id];
-                    if (o0 != 0xFFFFFFFFu) {
+                    const u32 len = (o0 != 0xFFFFFFFFu) ? a.samp_len[id] : 0u;
+                    if (len > kSegCap) {
                         n = m.x;
                         T = a.T + (size_t)lb * kSlot;
                         X = a.X + (size_t)lb * kSlot;
-                        if (sid == kDecSamples - 1u) {
-                            cur = m.y;
-                            X[0] = (u8)m.z; // tt[orig_pos] & 0xFF is the first byte (decoder.rs:476,533-536)
-                        } else {
-                            cur = sid * kDecSampleStep;
-                        }
-                        o = o0 + 1u;
-                        left = a.samp_len[id];
-                        have = left != 0;
+                        cur = a.seg_cont[id];
+                        o = o0 + 1u + kSegCap;
+                        left = len - kSegCap;
+                        have = true;
                     }
                 }
             }
@@ -1340,6 +1376,7 @@ void launch_dec_walks(hipStream_t st, const DecArgs &a, u32 walk_wgs)
     const u32 wgs = (walk_wgs + 7u) & ~7u; // the same number of walkers on every XCD
     hipLaunchKernelGGL(k_dec_walk_lengths, dim3(wgs), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dec_rank_samples, dim3(a.nb), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_dec_seg_copy, dim3((kDecSamples + 3) / 4, a.nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dec_walk_write, dim3(wgs), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dec_fixups, dim3(a.nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dec_rle_sub, dim3((kDecSubs + 255) / 256, a.nb), dim3(256), 0, st, a);
