@@ -108,8 +108,12 @@ struct BitCur {
     __device__ __forceinline__ u64 pos() const { return widx * 32ull - (u64)cnt; }
 };
 
+// Lookup-table width.  The tables are the bulk of the kernel's LDS, and LDS decides how many blocks
+// are resident at once (10 bits: 21 KB per block, 7 per CU, 1792 on the chip; 11 bits: 4 per CU --
+// the 1189 blocks of a 1 GiB file then run as two rounds, twice the time).  Longer codes take the
+// canonical walk.
 #ifndef BZ_DEC_LUT_BITS
-#define BZ_DEC_LUT_BITS 11
+#define BZ_DEC_LUT_BITS 10
 #endif
 constexpr u32 kLutBits = BZ_DEC_LUT_BITS;
 constexpr u16 kLutLong = 0xFFFE, kLutBad = 0xFFFF;
@@ -169,6 +173,13 @@ __global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64
     const u32 c = blockIdx.x;
     if (c >= ncand) return;
     const u32 l = threadIdx.x;
+#ifdef BZ_DEC_TIMING
+    u64 tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 tq = clock64();
+#define BZ_T(i) { const u64 now_ = clock64(); tm[i] += now_ - tq; tq = now_; }
+#else
+#define BZ_T(i)
+#endif
     DecBlockInfo &bi = info[c];
     BitCur bc;
     bc.open(in, nbytes);
@@ -263,6 +274,7 @@ __global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64
         }
     }
     __syncthreads();
+    BZ_T(0)
     if (s_hdr[3]) return;
     const u32 n_groups = s_hdr[0], alpha = s_hdr[1], n_selectors = s_hdr[2];
     // ---- decode tables (all lanes): canonical codes, lookup table, per-length arrays for longer codes
@@ -313,6 +325,7 @@ __global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64
         }
     }
     __syncthreads();
+    BZ_T(1)
     // ---- the symbols (:367-437)
     // Huffman decode is serial bit by bit, but not lane by lane: in every round lane j looks up the
     // code that WOULD start at bit pos + j (one LDS gather for 64 candidate starts), then the true
@@ -341,6 +354,7 @@ __global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64
             s_ring[i & (kRingWords - 1)] = bc.load(i);
         }
         __syncthreads();
+        BZ_T(2)
         u32 nout = 0;
         const u64 wend = (wb + kRingWords) * 32ull; // first bit not staged
         while (nout + 129u <= kOutBuf && pos + 224ull <= wend) {
@@ -374,25 +388,36 @@ __global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64
             // the loops are kept to the bare hop; everything else is sorted out once per round below.
             // The window ends after 128 candidate starts or at the end of the input (the round after
             // that reports the missing bits).
+            BZ_T(3)
             const u64 left = total_bits - pos;
             const u32 lim = left < 128ull ? (u32)left : 128u;
             const u32 lim_a = lim < 64u ? lim : 64u;
             u32 off = 0;
             u64 chain_a = 0, chain_b = 0;
-            do {
-                chain_a |= 1ull << off;
-                off += (u32)__builtin_amdgcn_readlane((int)hop_a, (int)off);
-            } while (off < lim_a);
+            // (unrolled with forward exits: a taken branch restarts the wave's instruction fetch, which costs
+            // far more than the six instructions of a hop)
+            while (true) {
+#define BZ_HOP(CH, HV, LIM)                                                        \
+    CH |= 1ull << off;                                                             \
+    off += (u32)__builtin_amdgcn_readlane((int)(HV), (int)off);                    \
+    if (off >= (LIM)) break;
+                BZ_HOP(chain_a, hop_a, lim_a) BZ_HOP(chain_a, hop_a, lim_a) BZ_HOP(chain_a, hop_a, lim_a)
+                BZ_HOP(chain_a, hop_a, lim_a) BZ_HOP(chain_a, hop_a, lim_a) BZ_HOP(chain_a, hop_a, lim_a)
+                BZ_HOP(chain_a, hop_a, lim_a) BZ_HOP(chain_a, hop_a, lim_a)
+            }
             u32 cnt_a = (u32)__popcll(chain_a);
             if (off < lim && cnt_a < krem && (chain_a & stop_a) == 0ull) { // on into the second half
                 off -= 64u;
                 const u32 lim_b = lim - 64u;
-                do {
-                    chain_b |= 1ull << off;
-                    off += (u32)__builtin_amdgcn_readlane((int)hop_b, (int)off);
-                } while (off < lim_b);
+                while (true) {
+                    BZ_HOP(chain_b, hop_b, lim_b) BZ_HOP(chain_b, hop_b, lim_b) BZ_HOP(chain_b, hop_b, lim_b)
+                    BZ_HOP(chain_b, hop_b, lim_b) BZ_HOP(chain_b, hop_b, lim_b) BZ_HOP(chain_b, hop_b, lim_b)
+                    BZ_HOP(chain_b, hop_b, lim_b) BZ_HOP(chain_b, hop_b, lim_b)
+                }
+#undef BZ_HOP
                 off += 64u;
             }
+            BZ_T(4)
             u32 stop = 0; // 1 EOB, 2 unresolved code
             u32 cnt = cnt_a;
             const u32 rank_a = (u32)__popcll(chain_a & lt_mask);
@@ -496,10 +521,17 @@ __global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64
                 state = 2;
                 break;
             }
+            BZ_T(5)
         }
         __syncthreads();
         for (u32 i = l; i < nout; i += 64) out[flushed + i] = s_out[i];
         flushed += nout;
+        BZ_T(6)
+#ifdef BZ_DEC_TIMING
+        if (state && l == 0 && c == 7)
+            printf("D1 cycles: header %llu tables %llu refill %llu lookup %llu hop %llu post %llu flush %llu nsym %u\n", tm[0],
+                   tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], flushed);
+#endif
         if (state) {
             if (l == 0) {
                 bi.status = state == 2 ? (u32)BZ_DEC_E_DATA : 0u;
