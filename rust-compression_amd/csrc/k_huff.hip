@@ -234,7 +234,24 @@ __device__ __forceinline__ void stage_symbols(u32 *s_sym, const u16 *__restrict_
     const u32 nsym = avail < want ? avail : want;
     const u32 ndw = (nsym + 1u) >> 1;
     const u32 *src = reinterpret_cast<const u32 *>(mtf + first);
-    for (u32 i = threadIdx.x; i < ndw; i += blockDim.x) s_sym[i] = src[i];
+    // kGSize / 2 = 25 dwords per thread, fetched as batches of loads issued back to back: a thread
+    // waits for memory three times per call, not 25 times (all 25 at once costs the registers that
+    // let two workgroups share a CU)
+    constexpr u32 kBatch = 9;
+#pragma unroll
+    for (u32 k0 = 0; k0 < kGSize / 2; k0 += kBatch) {
+        u32 v[kBatch];
+#pragma unroll
+        for (u32 k = 0; k < kBatch; ++k) {
+            const u32 i = threadIdx.x + (k0 + k) * blockDim.x;
+            v[k] = (k0 + k < kGSize / 2 && i < ndw) ? src[i] : 0u;
+        }
+#pragma unroll
+        for (u32 k = 0; k < kBatch; ++k) {
+            const u32 i = threadIdx.x + (k0 + k) * blockDim.x;
+            if (k0 + k < kGSize / 2 && i < ndw) s_sym[i] = v[k];
+        }
+    }
 }
 
 __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
@@ -254,6 +271,13 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
 
     const u32 lb = blockIdx.x;
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+#ifdef BZ_HUFF_TIMING
+    u64 tm[6] = {0, 0, 0, 0, 0, 0};
+    u64 tq = clock64();
+#define BZ_HT(i) { const u64 now_ = clock64(); tm[i] += now_ - tq; tq = now_; }
+#else
+#define BZ_HT(i)
+#endif
     const u16 *mtf = a.mtf + (size_t)lb * a.mtf_stride;
     const u32 *mtf_freq = a.mtf_freq + (size_t)lb * kMaxAlpha;
     BlockOut &bo = a.out[lb];
@@ -314,8 +338,19 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
                 const u32 gs = g * kGSize;
                 const u32 cnt = (gs + kGSize < mtf_count) ? kGSize : mtf_count - gs;
                 const u32 *my = s_sym + tid * (kGSize / 2);
-                unsigned long long cost = 0;
-                for (u32 i = 0; i < cnt; ++i) cost += s_pack[(my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu];
+                // One pass over the group's symbols gives the cost under every table (6 x 10-bit sums) and
+                // the counts of the eight smallest symbols (RUNA, RUNB, ranks 1..6 -- most of a BWT block)
+                // as eight 8-bit fields of one register; the rarer symbols are counted by a second, almost
+                // empty pass once the table is known (one LDS atomic per symbol otherwise serialises the
+                // whole workgroup on a handful of hot counters).
+                unsigned long long cost = 0, c8 = 0;
+                u32 big = 0;
+                for (u32 i = 0; i < cnt; ++i) {
+                    const u32 sy = (my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
+                    cost += s_pack[sy];
+                    if (sy < 8u) c8 += 1ull << (8u * sy);
+                    else ++big;
+                }
                 // first minimum wins (min_by, encoder.rs:466)
                 u32 bt = 0, bc = (u32)(cost & 1023u);
                 for (u32 t = 1; t < group_num; ++t) {
@@ -326,30 +361,26 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
                     }
                 }
                 selector[g] = (u8)bt;
-                // The eight smallest symbols (RUNA, RUNB, ranks 1..6) are most of a BWT block: count
-                // them in registers and add once per group -- one LDS atomic per symbol otherwise
-                // serialises the whole workgroup on a handful of hot counters.
-                u32 c8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (u32 i = 0; i < cnt; ++i) {
-                    const u32 sy = (my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
-                    if (sy < 8u) {
-#pragma unroll
-                        for (u32 q = 0; q < 8; ++q) c8[q] += (sy == q) ? 1u : 0u;
-                    } else {
-                        atomicAdd(&s_rfreq[bt][sy], 1u);
+                if (big)
+                    for (u32 i = 0; i < cnt; ++i) {
+                        const u32 sy = (my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
+                        if (sy >= 8u) atomicAdd(&s_rfreq[bt][sy], 1u);
                     }
-                }
 #pragma unroll
-                for (u32 q = 0; q < 8; ++q)
-                    if (c8[q]) atomicAdd(&s_rfreq[bt][q], c8[q]);
+                for (u32 q = 0; q < 8; ++q) {
+                    const u32 c = (u32)(c8 >> (8u * q)) & 0xFFu;
+                    if (c) atomicAdd(&s_rfreq[bt][q], c);
+                }
             }
             __syncthreads();
         }
         __syncthreads();
+        BZ_HT(0)
         // one lane per table replays the serial heap procedure
         if (lane == 0 && wave < group_num)
             s_need[wave] = (u32)heap_code_lengths(s_rfreq[wave], alpha, s_buf[wave], s_len[wave]);
         __syncthreads();
+        BZ_HT(1)
         // Tables whose longest code exceeds 17 bits are redone by the package-merge procedure
         // (one lane each).  Its scratch is carved out of the symbol staging area (idle here):
         // as many tables at a time as fit; global memory (8x the latency per step) only when the
@@ -385,6 +416,7 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
         }
     }
 
+    BZ_HT(2)
     // canonical codes, src/huffman/mod.rs:22-67 (stable by length, then symbol)
     if (tid < 6 * 24) (&s_lcount[0][0])[tid] = 0;
     __syncthreads();
@@ -630,6 +662,11 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
         if (w1 > kStreamWords) w1 = kStreamWords;
         for (u32 w = w0 + tid; w < w1; w += kHuffThreads) stream[w] = 0;
     }
+    BZ_HT(3)
+#ifdef BZ_HUFF_TIMING
+    if (tid == 0 && lb == 7)
+        printf("k_huffman cycles: sweeps %llu heaps %llu lm %llu tail %llu\n", tm[0], tm[1], tm[2], tm[3]);
+#endif
 }
 
 // ---- payload: one lane per 50-symbol group (encoder.rs:609-629) ---------------------------
