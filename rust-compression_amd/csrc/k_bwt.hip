@@ -206,7 +206,10 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shif
                                                               u32 *__restrict__ Kstore)
 {
     constexpr u32 NB = 1u << BITS;
-    __shared__ u32 s_hist[NB];
+    // kHistCopies interleaved copies of the counters (the low lane bits pick one): text keys are skewed (the
+    // top digit is a key's first two symbols) and adds to one LDS word serialise
+    constexpr u32 kHistCopies = 4;
+    __shared__ u32 s_hist[kHistCopies][NB];
     __shared__ u8 s_code[256];
     u32 tile, lb;
     xcd_remap(kTilesPerBlock, a.nb, tile, lb);
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shif
     const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
     const u32 hm = (SRC == SRC_MM || SRC == SRC_MMK || SRC == SRC_SURV) ? (((u32)ki.chars * 2u) << h) % n : 0u;
 
-    for (u32 i = threadIdx.x; i < NB; i += kSortThreads) s_hist[i] = 0;
+    for (u32 i = threadIdx.x; i < kHistCopies * NB; i += kSortThreads) (&s_hist[0][0])[i] = 0;
     if (SRC == SRC_TEXT || SRC == SRC_WALK)
         for (u32 i = threadIdx.x; i < 256; i += kSortThreads) s_code[i] = a.sym_code[(size_t)lb * 256 + i];
     __syncthreads();
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shif
             fetch_rows<SRC>(a, lb, text, n, hm, Kin, Vin, start + w * 1024u + l, cnt, s_code, ki, key, val);
 #pragma unroll
         for (u32 r = 0; r < 16; ++r)
-            if ((ok >> r) & 1u) atomicAdd(&s_hist[(key[r] >> shift) & (NB - 1)], 1u);
+            if ((ok >> r) & 1u) atomicAdd(&s_hist[l & (kHistCopies - 1)][(key[r] >> shift) & (NB - 1)], 1u);
         // keys that cost a gather to build are kept for the scatter kernel of the same pass
         if ((SRC == SRC_TEXT || SRC == SRC_WALK || SRC == SRC_MM) && Kstore) {
             const size_t base = (size_t)lb * kSlot;
@@ -244,7 +247,12 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shif
     }
     __syncthreads();
     u32 *out = a.tile_hist + ((size_t)lb * kTilesPerBlock + tile) * kMaxBins;
-    for (u32 i = threadIdx.x; i < NB; i += kSortThreads) out[i] = s_hist[i];
+    for (u32 i = threadIdx.x; i < NB; i += kSortThreads) {
+        u32 sum = 0;
+#pragma unroll
+        for (u32 k = 0; k < kHistCopies; ++k) sum += s_hist[k][i];
+        out[i] = sum;
+    }
 }
 
 // ---- radix pass, part 2: per-block scan of the tile histograms ----------------------

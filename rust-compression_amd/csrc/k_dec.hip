@@ -1207,27 +1207,43 @@ __global__ __launch_bounds__(256) void k_dec_rle_expand(DecArgs a, const u64 *__
 // to carry: per-tile byte counts, per-block scan, stable scatter ranked with wave ballots.
 __global__ __launch_bounds__(kSortThreads) void k_dec_thist(DecArgs a)
 {
-    __shared__ u32 s_hist[256];
+    // four interleaved copies of the counters, and a thread adds a run of equal bytes at once: the BWT
+    // column is mostly runs, and single adds to one LDS word serialise
+    __shared__ u32 s_hist[4][256];
     u32 tile, lb;
     xcd_remap(kTilesPerBlock, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu || a.err[lb]) return;
     const u32 n = a.tt_len[lb];
     const u32 start = tile * kSortTile;
     if (start >= n) return;
-    if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
+    for (u32 i = threadIdx.x; i < 4u * 256u; i += kSortThreads) (&s_hist[0][0])[i] = 0;
     __syncthreads();
     const u8 *L = a.L + (size_t)lb * kSlot;
+    u32 *mine = s_hist[threadIdx.x & 3u];
     // 16 bytes per thread
     const u32 i0 = start + threadIdx.x * 16u;
     if (i0 < n) {
         const uint4 q = *reinterpret_cast<const uint4 *>(L + i0);
         const u32 wv[4] = {q.x, q.y, q.z, q.w};
+        u32 prev = wv[0] & 0xFFu, run = 0;
 #pragma unroll
-        for (u32 k = 0; k < 16; ++k)
-            if (i0 + k < n) atomicAdd(&s_hist[(wv[k >> 2] >> ((k & 3) * 8)) & 0xFFu], 1u);
+        for (u32 k = 0; k < 16; ++k) {
+            if (i0 + k < n) {
+                const u32 b = (wv[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+                if (b == prev) ++run;
+                else {
+                    atomicAdd(&mine[prev], run);
+                    prev = b;
+                    run = 1;
+                }
+            }
+        }
+        if (run) atomicAdd(&mine[prev], run);
     }
     __syncthreads();
-    if (threadIdx.x < 256) a.thist[((size_t)lb * kTilesPerBlock + tile) * 256u + threadIdx.x] = s_hist[threadIdx.x];
+    if (threadIdx.x < 256)
+        a.thist[((size_t)lb * kTilesPerBlock + tile) * 256u + threadIdx.x] =
+            s_hist[0][threadIdx.x] + s_hist[1][threadIdx.x] + s_hist[2][threadIdx.x] + s_hist[3][threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void k_dec_tscan(DecArgs a)
