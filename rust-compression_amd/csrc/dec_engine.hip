@@ -202,6 +202,18 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
     }
     if (nc < B) B = (u32)(nc ? nc : 1);
     {
+        // never plan for more than about half of the free HBM (the decoded bytes need room too)
+        const size_t per_slot = sizeof(DecCand) + sizeof(DecBlockInfo) + (size_t)kMtfStride * 2 + 32768 + 8 +
+                                (size_t)kMaxMtfChunks * 260 + (size_t)kSlot * 6 + (size_t)kDecSamples * (16 + kSegCap) +
+                                (size_t)kDecSubs * 21 + (size_t)kTilesPerBlock * 1024 + 2048;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && w->slots < (size_t)B + kForcedSlots) {
+            const size_t have = w->slots * per_slot; // what the workspace already holds is free to reuse
+            const size_t fit = (free_b / 2 + have) / per_slot;
+            if (fit < (size_t)B + kForcedSlots) B = fit > kForcedSlots + 1 ? (u32)(fit - kForcedSlots) : 1u;
+        }
+    }
+    {
         const int rc = dec_ensure(w, (size_t)B + kForcedSlots);
         if (rc) return rc;
     }

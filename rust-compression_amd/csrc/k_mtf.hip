@@ -416,6 +416,9 @@ __global__ __launch_bounds__(kSortThreads) void k_zle_emit(MtfArgs a)
         return;
     }
     u16 *out = a.mtf + (size_t)lb * kMtfStride + s_base + off;
+    // RUNA, RUNB and the two smallest ranks are most of the symbols: a thread counts them in
+    // registers and adds once (single adds to four hot LDS words serialise the workgroup)
+    u32 hot0 = 0, hot1 = 0, hot2 = 0, hot3 = 0;
     {
         int ln = lnz;
 #pragma unroll
@@ -426,7 +429,9 @@ __global__ __launch_bounds__(kSortThreads) void k_zle_emit(MtfArgs a)
                     ln = (int)p;
                     const u32 sym = (u32)s.r[k] + 1u; // encoder.rs:340,349
                     *out++ = (u16)sym;
-                    atomicAdd(&s_freq[sym], 1u);
+                    if (sym == 2u) ++hot2;
+                    else if (sym == 3u) ++hot3;
+                    else atomicAdd(&s_freq[sym], 1u);
                 } else {
                     const bool run_end = (k + 1 < s.valid) ? (s.r[(k + 1) & 15] != 0) : (s.next_nonzero != 0);
                     if (run_end) {
@@ -434,13 +439,24 @@ __global__ __launch_bounds__(kSortThreads) void k_zle_emit(MtfArgs a)
                         while (zc > 1u) {
                             const u32 run = zc & 1u;
                             *out++ = (u16)run;
-                            atomicAdd(&s_freq[run], 1u);
+                            hot0 += run ^ 1u;
+                            hot1 += run;
                             zc >>= 1;
                         }
                     }
                 }
             }
         }
+    }
+    hot0 = wave_sum(hot0);
+    hot1 = wave_sum(hot1);
+    hot2 = wave_sum(hot2);
+    hot3 = wave_sum(hot3);
+    if ((threadIdx.x & 63u) == 0) {
+        if (hot0) atomicAdd(&s_freq[0], hot0);
+        if (hot1) atomicAdd(&s_freq[1], hot1);
+        if (hot2) atomicAdd(&s_freq[2], hot2);
+        if (hot3) atomicAdd(&s_freq[3], hot3);
     }
     __syncthreads();
     const bool last_tile = (tile + 1) * kSortTile >= n;
