@@ -654,12 +654,8 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
             const u32 j = jv[r];
             const u32 p = g + (idx - (u32)rs);
             const u32 head = g + ((u32)ss - (u32)rs);
-#ifndef BZ_EXP_NO_SAWRITE
             st_stream(a.SA + base + p, j);
-#endif
-#ifndef BZ_EXP_NO_RWRITE
             a.R[base + j] = head | (fin ? kFinalBit : 0u);
-#endif
             my_nonfinal += fin ? 0u : 1u;
         }
         if (mo[r]) carry_old = (int)(rowbase + 63u - __clzll(mo[r]));

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Decode-stage timing sweep over environment knobs (run on the GPU box)."""
 import importlib, os, sys, json
-ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 pkg = importlib.import_module("rust-compression_amd")
 import corpus

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiling recipe (run on the GPU box through gpurun): kernel-trace stats, then PMC passes.
-# Usage: tools_profile.sh <tag> [bench args...]
+# Usage: tools/profile.sh <tag> [bench args...]
 set -u
 TAG=${1:-r01}; shift || true
 R=${GRAFT_REPO_ROOT:-/root/repo}

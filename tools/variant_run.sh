@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_variant_run.sh <variant.so> <cmd...>: runs cmd with the library swapped for a build variant
+# usage: tools/variant_run.sh <variant.so> <cmd...>: runs cmd with the library swapped for a build variant
 set -e
 cp rust-compression_amd/libbz2_mi355x.so /tmp/lib_default.so
 cp "$1" rust-compression_amd/libbz2_mi355x.so; shift
