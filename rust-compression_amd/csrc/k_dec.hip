@@ -154,10 +154,10 @@ struct RingCur {
 };
 
 // ---- D1: header + Huffman decode of one candidate -------------------------------------------------------
-// One wave per candidate.  Lane 0 parses the header; all lanes build the decode tables; then lane 0
-// walks the symbols out of an LDS window that all lanes refill (and whose output they flush), so
-// the serial lane never waits on global memory.
-__global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64 nbytes,
+// One workgroup of four waves per candidate.  Thread 0 parses the header; all threads build the
+// decode tables; the symbols are then found 256 candidate code starts at a time (below).
+constexpr u32 kD1Threads = 256;
+__global__ __launch_bounds__(kD1Threads) void k_dec_block(const u8 *__restrict__ in, u64 nbytes,
                                                    const DecCand *__restrict__ cands, u32 ncand,
                                                    DecBlockInfo *__restrict__ info, u16 *__restrict__ sym_out,
                                                    u8 *__restrict__ sel_scratch)
@@ -170,6 +170,9 @@ __global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64
     __shared__ u32 s_ring[kRingWords];
     __shared__ u16 s_out[kOutBuf];
     __shared__ u64 s_pos;
+    __shared__ u16 s_j[6][kD1Threads + 4]; // s_j[k][i]: the code start 2^k symbols behind start i (256 = outside the window)
+    __shared__ u16 s_e[kD1Threads];        // table entry of the code that would start at i
+    __shared__ u32 s_ctl[4];               // symbols taken, bits consumed, stop reason
     const u32 c = blockIdx.x;
     if (c >= ncand) return;
     const u32 l = threadIdx.x;
@@ -278,10 +281,10 @@ __global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64
     if (s_hdr[3]) return;
     const u32 n_groups = s_hdr[0], alpha = s_hdr[1], n_selectors = s_hdr[2];
     // ---- decode tables (all lanes): canonical codes, lookup table, per-length arrays for longer codes
-    for (u32 i = l; i < 6 * 24; i += 64) (&s_cnt[0][0])[i] = 0;
-    for (u32 i = l; i < 6u << kLutBits; i += 64) (&s_lut[0][0])[i] = kLutBad;
+    for (u32 i = l; i < 6 * 24; i += kD1Threads) (&s_cnt[0][0])[i] = 0;
+    for (u32 i = l; i < 6u << kLutBits; i += kD1Threads) (&s_lut[0][0])[i] = kLutBad;
     __syncthreads();
-    for (u32 i = l; i < n_groups * alpha; i += 64) {
+    for (u32 i = l; i < n_groups * alpha; i += kD1Threads) {
         const u32 t = i / alpha, s = i - t * alpha;
         const u32 ln = s_len[t][s];
         if (ln >= 1 && ln <= 23) atomicAdd(&s_cnt[t][ln], 1u);
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64
         }
         return;
     }
-    for (u32 i = l; i < n_groups * alpha; i += 64) {
+    for (u32 i = l; i < n_groups * alpha; i += kD1Threads) {
         const u32 t = i / alpha, s = i - t * alpha;
         const u32 ln = s_len[t][s];
         if (ln == 0) continue; // no code for this symbol (huffman/mod.rs:31-35)
@@ -327,43 +330,38 @@ __global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64
     __syncthreads();
     BZ_T(1)
     // ---- the symbols (:367-437)
-    // Huffman decode is serial bit by bit, but not lane by lane: in every round lane j looks up the
-    // code that WOULD start at bit pos + j (one LDS gather for 64 candidate starts), then the true
-    // starts are picked out by hopping from start to start with v_readlane on wave-uniform (scalar)
-    // state -- about 15 scalar cycles per symbol instead of a full dependent LDS round trip.  The
-    // table is fixed inside a 50-symbol group, so a round ends at the group's end, at the end of the
-    // 64-bit window, at EOB, or at a code the lookup table does not resolve (longer than kLutBits
-    // bits / owned by no symbol), which is decoded on its own.
+    // Huffman decode is serial bit by bit, but not thread by thread.  In every round thread i looks up
+    // the code that WOULD start at bit pos + i (256 candidate starts, one LDS gather); s_j[0][i] is
+    // where the next code would start.  Five pointer-doubling steps give the start 2, 4, .. 32 codes
+    // ahead of every candidate, and lane r of wave 0 then reaches the r-th TRUE code start from bit
+    // pos by following the set bits of r -- at most six dependent LDS reads instead of r hops.  The
+    // table is fixed inside a 50-symbol group, so a round ends at the group's end, after 64 symbols,
+    // at the end of the 256-bit window, at EOB, or at a code the lookup table does not resolve
+    // (longer than kLutBits bits / owned by no symbol), which is decoded on its own.
     u16 *out = sym_out + (size_t)c * kMtfStride;
     const u32 eob = alpha - 1;
-    const u64 total_bits = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)((nbytes * 8ull) >> 32)) << 32) |
-                           (u32)__builtin_amdgcn_readfirstlane((int)(u32)(nbytes * 8ull));
+    const u64 total_bits = nbytes * 8ull;
+    const u32 wv = l >> 6, ln_ = l & 63u; // wave, lane
     u64 pos = s_pos;
-    pos = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(pos >> 32)) << 32) |
-          (u32)__builtin_amdgcn_readfirstlane((int)(u32)pos);
     u32 flushed = 0;
     u32 g = 0, krem = 0, t = 0; // krem == 0: open the next group before the next symbol
     u32 t_next = sel[0];        // (fetched one group ahead: the load's latency stays off the serial path)
-    const u64 lt_mask = (l == 0) ? 0ull : (~0ull >> (64 - l));
-    u32 state = 0; // 0 running, 1 end of block, 2 error
+    u32 state = 0;              // 0 running, 1 end of block, 2 error
+    if (l < 6) s_j[l][kD1Threads] = (u16)kD1Threads; // outside stays outside
     while (true) {
         const u64 wb = pos >> 5;
-#pragma unroll
-        for (u32 q = 0; q < kRingWords / 64; ++q) {
-            const u64 i = wb + q * 64u + l;
-            s_ring[i & (kRingWords - 1)] = bc.load(i);
-        }
+        s_ring[(wb + l) & (kRingWords - 1)] = bc.load(wb + l);
         __syncthreads();
         BZ_T(2)
         u32 nout = 0;
         const u64 wend = (wb + kRingWords) * 32ull; // first bit not staged
-        while (nout + 129u <= kOutBuf && pos + 224ull <= wend) {
+        while (nout + 65u <= kOutBuf && pos + 352ull <= wend) {
             if (krem == 0) {
                 if (g >= n_selectors) { // group_no > n_selectors (:381-383)
                     state = 2;
                     break;
                 }
-                t = (u32)__builtin_amdgcn_readfirstlane((int)t_next);
+                t = t_next;
                 ++g;
                 t_next = sel[g < n_selectors ? g : 0u];
                 krem = kGSize;
@@ -372,111 +370,72 @@ __global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64
                 state = 2;
                 break;
             }
-            // two candidate code starts per lane: bits pos + l and pos + 64 + l
-            const u64 bp = pos + l;
-            const u32 wi = (u32)(bp >> 5), sh = (u32)bp & 31u;
-            const u32 r0 = s_ring[wi & (kRingWords - 1)], r1 = s_ring[(wi + 1u) & (kRingWords - 1)];
-            const u32 r2 = s_ring[(wi + 2u) & (kRingWords - 1)], r3 = s_ring[(wi + 3u) & (kRingWords - 1)];
-            const u32 ea = s_lut[t][(u32)(((((u64)r0 << 32) | r1) << sh) >> (64u - kLutBits))];
-            const u32 eb = s_lut[t][(u32)(((((u64)r2 << 32) | r3) << sh) >> (64u - kLutBits))];
-            const u32 len_a = (ea < kLutLong) ? (ea >> 9) : 0u, sym_a = ea & 511u;
-            const u32 len_b = (eb < kLutLong) ? (eb >> 9) : 0u, sym_b = eb & 511u;
-            // lanes at which a chain of code starts has to stop: EOB, or a code the table does not resolve
-            const u64 stop_a = __ballot(len_a == 0u || sym_a == eob);
-            const u32 hop_a = len_a ? len_a : 64u, hop_b = len_b ? len_b : 64u;
-            // Hop along the true code starts.  A lone wave issues an instruction only every ~10 cycles, so
-            // the loops are kept to the bare hop; everything else is sorted out once per round below.
-            // The window ends after 128 candidate starts or at the end of the input (the round after
-            // that reports the missing bits).
-            BZ_T(3)
-            const u64 left = total_bits - pos;
-            const u32 lim = left < 128ull ? (u32)left : 128u;
-            const u32 lim_a = lim < 64u ? lim : 64u;
-            u32 off = 0;
-            u64 chain_a = 0, chain_b = 0;
-            // (unrolled with forward exits: a taken branch restarts the wave's instruction fetch, which costs
-            // far more than the six instructions of a hop)
-            while (true) {
-#define BZ_HOP(CH, HV, LIM)                                                        \
-    CH |= 1ull << off;                                                             \
-    off += (u32)__builtin_amdgcn_readlane((int)(HV), (int)off);                    \
-    if (off >= (LIM)) break;
-                BZ_HOP(chain_a, hop_a, lim_a) BZ_HOP(chain_a, hop_a, lim_a) BZ_HOP(chain_a, hop_a, lim_a)
-                BZ_HOP(chain_a, hop_a, lim_a) BZ_HOP(chain_a, hop_a, lim_a) BZ_HOP(chain_a, hop_a, lim_a)
-                BZ_HOP(chain_a, hop_a, lim_a) BZ_HOP(chain_a, hop_a, lim_a)
-            }
-            u32 cnt_a = (u32)__popcll(chain_a);
-            if (off < lim && cnt_a < krem && (chain_a & stop_a) == 0ull) { // on into the second half
-                off -= 64u;
-                const u32 lim_b = lim - 64u;
-                while (true) {
-                    BZ_HOP(chain_b, hop_b, lim_b) BZ_HOP(chain_b, hop_b, lim_b) BZ_HOP(chain_b, hop_b, lim_b)
-                    BZ_HOP(chain_b, hop_b, lim_b) BZ_HOP(chain_b, hop_b, lim_b) BZ_HOP(chain_b, hop_b, lim_b)
-                    BZ_HOP(chain_b, hop_b, lim_b) BZ_HOP(chain_b, hop_b, lim_b)
+            // the candidate code at bit pos + l
+            {
+                const u64 bp = pos + l;
+                const u32 wi = (u32)(bp >> 5), sh = (u32)bp & 31u;
+                const u64 two = ((u64)s_ring[wi & (kRingWords - 1)] << 32) | s_ring[(wi + 1u) & (kRingWords - 1)];
+                const u32 e = s_lut[t][(u32)((two << sh) >> (64u - kLutBits))];
+                const u32 len = (e < kLutLong) ? (e >> 9) : 0u;
+                u32 nx = len ? l + len : kD1Threads; // an unresolved code ends the chain
+                nx = nx < kD1Threads ? nx : kD1Threads;
+                s_e[l] = (u16)e;
+                s_j[0][l] = (u16)nx;
+                __syncthreads();
+                BZ_T(3)
+                u32 cur = nx;
+#pragma unroll
+                for (u32 k = 1; k < 6; ++k) {
+                    cur = s_j[k - 1][cur];
+                    s_j[k][l] = (u16)cur;
+                    __syncthreads();
                 }
-#undef BZ_HOP
-                off += 64u;
             }
             BZ_T(4)
-            u32 stop = 0; // 1 EOB, 2 unresolved code
-            u32 cnt = cnt_a;
-            const u32 rank_a = (u32)__popcll(chain_a & lt_mask);
-            u32 rank_b = 0;
-            if (chain_b == 0ull) {
-                if (cnt_a > krem) { // the group (and with it the table) ends inside the window
-                    const u64 m = __ballot(((chain_a >> l) & 1ull) && rank_a + 1u == krem);
-                    const u32 p = (u32)__builtin_ctzll(m);
-                    chain_a &= ~0ull >> (63u - p);
-                    off = p + (u32)__builtin_amdgcn_readlane((int)hop_a, (int)p);
-                    cnt = krem;
-                }
-                const u64 st = chain_a & stop_a;
-                if (st) {
-                    const u32 f = (u32)__builtin_ctzll(st);
-                    const u32 flen = (u32)__builtin_amdgcn_readlane((int)len_a, (int)f);
-                    if (flen == 0u) {
-                        chain_a &= (1ull << f) - 1ull;
-                        off = f;
+            if (wv == 0) {
+                const u32 r = ln_;
+                u32 p = 0;
+#pragma unroll
+                for (u32 k = 0; k < 6; ++k)
+                    if ((r >> k) & 1u) p = s_j[k][p];
+                const bool inw = (p < kD1Threads) && (pos + p < total_bits);
+                const u32 e = inw ? (u32)s_e[p] : (u32)kLutBad;
+                const u32 len = (e < kLutLong) ? (e >> 9) : 0u;
+                const u32 sy = e & 511u;
+                const u64 vm = __ballot(inw); // a prefix of ones: code starts only move forward
+                const u32 nvalid = (vm == ~0ull) ? 64u : (u32)__builtin_ctzll(~vm);
+                const u32 lim = nvalid < krem ? nvalid : krem;
+                const u64 limmask = (lim >= 64u) ? ~0ull : ((1ull << lim) - 1ull);
+                const u64 su = __ballot(inw && len == 0u) & limmask;               // unresolved codes
+                const u64 se = __ballot(inw && len != 0u && sy == eob) & limmask;  // EOB
+                u32 cnt = lim, stop = 0; // stop: 1 EOB, 2 unresolved code
+                if (su | se) {
+                    const u32 f = (u32)__builtin_ctzll(su | se);
+                    if ((su >> f) & 1ull) {
+                        cnt = f;
                         stop = 2;
                     } else {
-                        chain_a &= ~0ull >> (63u - f);
-                        off = f + flen;
+                        cnt = f + 1u;
                         stop = 1;
                     }
-                    cnt = (u32)__popcll(chain_a);
                 }
-            } else { // (the first half is complete: no stop in it, fewer than krem symbols)
-                rank_b = cnt_a + (u32)__popcll(chain_b & lt_mask);
-                cnt = cnt_a + (u32)__popcll(chain_b);
-                if (cnt > krem) {
-                    const u64 m = __ballot(((chain_b >> l) & 1ull) && rank_b + 1u == krem);
-                    const u32 p = (u32)__builtin_ctzll(m);
-                    chain_b &= ~0ull >> (63u - p);
-                    off = 64u + p + (u32)__builtin_amdgcn_readlane((int)hop_b, (int)p);
-                    cnt = krem;
-                }
-                const u64 stop_b = __ballot(len_b == 0u || sym_b == eob);
-                const u64 st = chain_b & stop_b;
-                if (st) {
-                    const u32 f = (u32)__builtin_ctzll(st);
-                    const u32 flen = (u32)__builtin_amdgcn_readlane((int)len_b, (int)f);
-                    if (flen == 0u) {
-                        chain_b &= (1ull << f) - 1ull;
-                        off = 64u + f;
-                        stop = 2;
-                    } else {
-                        chain_b &= ~0ull >> (63u - f);
-                        off = 64u + f + flen;
-                        stop = 1;
-                    }
-                    cnt = cnt_a + (u32)__popcll(chain_b);
+                // bits consumed = start of the first symbol not taken
+                const u32 lastr = cnt ? cnt - 1u : 0u;
+                const u32 pl = (u32)__builtin_amdgcn_readlane((int)p, (int)lastr);
+                const u32 ll = (u32)__builtin_amdgcn_readlane((int)len, (int)lastr);
+                if (r < cnt) s_out[nout + r] = (u16)sy;
+                if (r == 0) {
+                    s_ctl[0] = cnt;
+                    s_ctl[1] = cnt ? pl + ll : 0u;
+                    s_ctl[2] = stop;
                 }
             }
-            if ((chain_a >> l) & 1ull) s_out[nout + rank_a] = (u16)sym_a;
-            if ((chain_b >> l) & 1ull) s_out[nout + rank_b] = (u16)sym_b;
+            __syncthreads();
+            const u32 cnt = s_ctl[0], off = s_ctl[1], stop = s_ctl[2];
             nout += cnt;
             krem -= cnt;
             pos += off;
+            BZ_T(5)
             if (stop == 1) {
                 state = 1;
                 break;
@@ -521,16 +480,15 @@ __global__ __launch_bounds__(64) void k_dec_block(const u8 *__restrict__ in, u64
                 state = 2;
                 break;
             }
-            BZ_T(5)
         }
         __syncthreads();
-        for (u32 i = l; i < nout; i += 64) out[flushed + i] = s_out[i];
+        for (u32 i = l; i < nout; i += kD1Threads) out[flushed + i] = s_out[i];
         flushed += nout;
         BZ_T(6)
 #ifdef BZ_DEC_TIMING
         if (state && l == 0 && c == 7)
-            printf("D1 cycles: header %llu tables %llu refill %llu lookup %llu hop %llu post %llu flush %llu nsym %u\n", tm[0],
-                   tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], flushed);
+            printf("D1 cycles: header %llu tables %llu refill %llu lookup %llu double %llu rank %llu flush %llu nsym %u\n",
+                   tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], flushed);
 #endif
         if (state) {
             if (l == 0) {
@@ -1402,7 +1360,7 @@ void launch_dec_blocks(hipStream_t st, const u8 *in, u64 nbytes, const DecCand *
                        u16 *sym, u8 *sel_scratch)
 {
     if (ncand == 0) return;
-    hipLaunchKernelGGL(k_dec_block, dim3(ncand), dim3(64), 0, st, in, nbytes, cands, ncand, info, sym, sel_scratch);
+    hipLaunchKernelGGL(k_dec_block, dim3(ncand), dim3(kD1Threads), 0, st, in, nbytes, cands, ncand, info, sym, sel_scratch);
 }
 
 void launch_dec_mtf(hipStream_t st, const DecArgs &a)
