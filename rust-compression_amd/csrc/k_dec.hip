@@ -511,38 +511,46 @@ __global__ __launch_bounds__(kD1Threads) void k_dec_block(const u8 *__restrict__
 
 // ---- D2: zero runs + inverse MTF --------------------------------------------------------------------
 
-// zero-run value of the digits sym[a..b) (bijective base 2, least significant first, decoder.rs:419-424);
-// returns 0xFFFFFFFF when the run is longer than the reference accepts (n >= 2 Mi, :413-416)
-__device__ __forceinline__ u32 run_value(const u16 *__restrict__ sym, u32 a, u32 b)
+// inverse MTF step on a byte list held as dwords: returns the byte at rank `r` and moves it to the
+// front.  The first eight entries (w0, w1) live in registers -- most ranks of a BWT block are tiny, and
+// a lane's steps are serial, so an LDS round trip per symbol would be the whole cost; words 2.. of the
+// list are in LDS (list[0], list[1] are stale while a chunk is being replayed).
+__device__ __forceinline__ u32 imtf_pop(u32 &w0, u32 &w1, u32 *list, u32 r)
 {
-    u32 es = 0, n = 1;
-    for (u32 i = a; i < b; ++i) {
-        if (n >= 2u * 1024u * 1024u) return 0xFFFFFFFFu;
-        if (sym[i] == 0) { es += n; n <<= 1; } else { n <<= 1; es += n; }
+    if (r < 4u) {
+        const u32 sh = 8u * r;
+        const u32 v = (w0 >> sh) & 0xFFu;
+        if (r) {
+            const u32 upto = (r == 3u) ? 0xFFFFFFFFu : ((1u << (sh + 8u)) - 1u);
+            w0 = (w0 & ~upto) | ((((w0 & (upto >> 8)) << 8) | v) & upto);
+        }
+        return v;
     }
-    return es;
-}
-
-// inverse MTF step on a byte list held as dwords: returns the byte at `r` and moves it to the front
-__device__ __forceinline__ u32 imtf_pop(u32 *list, u32 r)
-{
+    if (r < 8u) {
+        const u32 sh = 8u * (r - 4u);
+        const u32 v = (w1 >> sh) & 0xFFu;
+        const u32 carry = w0 >> 24;
+        w0 = (w0 << 8) | v;
+        const u32 upto = (r == 7u) ? 0xFFFFFFFFu : ((1u << (sh + 8u)) - 1u);
+        w1 = (w1 & ~upto) | ((((w1 & (upto >> 8)) << 8) | carry) & upto);
+        return v;
+    }
     const u32 dq = r >> 2, bq = r & 3u;
     const u32 wq = list[dq];
     const u32 v = (wq >> (8u * bq)) & 0xFFu;
-    if (r == 0) return v;
-    u32 carry = v;
-    for (u32 d = 0; d < dq; ++d) {
+    u32 carry = w1 >> 24;
+    w1 = (w1 << 8) | (w0 >> 24);
+    w0 = (w0 << 8) | v;
+    for (u32 d = 2; d < dq; ++d) {
         const u32 w = list[d];
         list[d] = (w << 8) | carry;
         carry = w >> 24;
     }
     const u32 upto = (bq == 3u) ? 0xFFFFFFFFu : ((1u << (8u * (bq + 1u))) - 1u);
-    const u32 lowm = upto >> 8;
-    list[dq] = (wq & ~upto) | ((((wq & lowm) << 8) | carry) & upto);
+    list[dq] = (wq & ~upto) | ((((wq & (upto >> 8)) << 8) | carry) & upto);
     return v;
 }
 
-// M1': chunk permutation of list positions + bytes the chunk emits
 __global__ __launch_bounds__(256) void k_dec_chunk_perm(DecArgs a)
 {
     __shared__ u32 s_list[256 * 65];
@@ -557,32 +565,53 @@ __global__ __launch_bounds__(256) void k_dec_chunk_perm(DecArgs a)
     const u32 eob = a.info[sl].n_in_use + 1u;
     u32 *list = s_list + threadIdx.x * 65u;
     for (u32 d = 0; d < 64; ++d) list[d] = (4u * d) | ((4u * d + 1u) << 8) | ((4u * d + 2u) << 16) | ((4u * d + 3u) << 24);
+    u32 w0 = 0x03020100u, w1 = 0x07060504u;
     u32 emit = 0, err = 0;
-    u32 run_start = 0xFFFFFFFFu; // start of the digits in front of symbol i (if any)
-    // digits hanging over from the previous chunk
+    // zero-run in progress: value so far and the weight of the next digit (decoder.rs:419-424); a run
+    // belongs to the chunk that holds the symbol behind it, so digits hanging over from the previous
+    // chunk are picked up first
+    u32 es = 0, nw = 1;
     if (beg > 0 && sym[beg - 1] <= 1u) {
-        u32 s = beg - 1;
-        while (s > 0 && sym[s - 1] <= 1u && beg - s < 32u) --s;
-        run_start = s;
+        u32 s0 = beg - 1;
+        while (s0 > 0 && sym[s0 - 1] <= 1u && beg - s0 < 32u) --s0;
+        for (u32 i = s0; i < beg; ++i) {
+            if (nw >= 2u * 1024u * 1024u) err = 1; // :413-416
+            else {
+                es += nw << sym[i];
+                nw <<= 1;
+            }
+        }
     }
-    for (u32 i = beg; i < end; ++i) {
-        const u32 sy = sym[i];
-        if (sy <= 1u) {
-            if (run_start == 0xFFFFFFFFu) run_start = i;
-            continue;
-        }
-        if (run_start != 0xFFFFFFFFu) {
-            const u32 z = run_value(sym, run_start, i);
-            if (z == 0xFFFFFFFFu) err = 1;
-            else emit += z;
-            run_start = 0xFFFFFFFFu;
-        }
-        if (sy != eob) {
-            (void)imtf_pop(list, sy - 1u);
-            emit += 1;
+    // sixteen symbols per trip to memory (a lane's chunk is contiguous, but the 64 lanes of a wave read
+    // 64 different lines: one load per symbol would cost a full memory round trip each)
+    for (u32 i0 = beg; i0 < end; i0 += 16u) {
+        const uint4 qa = *reinterpret_cast<const uint4 *>(sym + i0), qb = *reinterpret_cast<const uint4 *>(sym + i0 + 8u);
+        const u32 wv[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+        for (u32 k = 0; k < 16u; ++k) {
+            if (i0 + k < end) {
+                const u32 sy = (wv[k >> 1] >> ((k & 1u) * 16u)) & 0xFFFFu;
+                if (sy <= 1u) {
+                    if (nw >= 2u * 1024u * 1024u) err = 1;
+                    else {
+                        es += nw << sy; // RUNA adds the weight, RUNB twice the weight
+                        nw <<= 1;
+                    }
+                } else {
+                    emit += es;
+                    es = 0;
+                    nw = 1;
+                    if (sy != eob) {
+                        (void)imtf_pop(w0, w1, list, sy - 1u);
+                        emit += 1;
+                    }
+                }
+            }
         }
     }
     u8 *out = a.perm + ((size_t)lb * kMaxMtfChunks + chunk) * 256u;
+    list[0] = w0;
+    list[1] = w1;
     for (u32 d = 0; d < 64; ++d) reinterpret_cast<u32 *>(out)[d] = list[d];
     a.chunk_emit[(size_t)lb * kMaxMtfChunks + chunk] = emit;
     if (err) atomicMax(&a.err[lb], 1u);
@@ -645,36 +674,53 @@ __global__ __launch_bounds__(256) void k_dec_chunk_emit(DecArgs a)
     const u32 eob = a.info[sl].n_in_use + 1u;
     const u32 maxlen = a.nblock_max[lb];
     u32 *list = s_list + threadIdx.x * 65u;
+    u32 w0 = list[0], w1 = list[1];
     u8 *L = a.L + (size_t)lb * kSlot;
     u32 o = a.chunk_emit[(size_t)lb * kMaxMtfChunks + chunk];
     u32 err = 0;
-    u32 run_start = 0xFFFFFFFFu;
+    u32 es = 0, nw = 1;
     if (beg > 0 && sym[beg - 1] <= 1u) {
-        u32 s = beg - 1;
-        while (s > 0 && sym[s - 1] <= 1u && beg - s < 32u) --s;
-        run_start = s;
+        u32 s0 = beg - 1;
+        while (s0 > 0 && sym[s0 - 1] <= 1u && beg - s0 < 32u) --s0;
+        for (u32 i = s0; i < beg; ++i) {
+            if (nw >= 2u * 1024u * 1024u) err = 1;
+            else {
+                es += nw << sym[i];
+                nw <<= 1;
+            }
+        }
     }
-    for (u32 i = beg; i < end; ++i) {
-        const u32 sy = sym[i];
-        if (sy <= 1u) {
-            if (run_start == 0xFFFFFFFFu) run_start = i;
-            continue;
+    for (u32 i0 = beg; i0 < end && !err; i0 += 16u) {
+        const uint4 qa = *reinterpret_cast<const uint4 *>(sym + i0), qb = *reinterpret_cast<const uint4 *>(sym + i0 + 8u);
+        const u32 wv[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+        for (u32 k = 0; k < 16u; ++k) {
+            if (i0 + k < end && !err) {
+                const u32 sy = (wv[k >> 1] >> ((k & 1u) * 16u)) & 0xFFFFu;
+                if (sy <= 1u) {
+                    if (nw >= 2u * 1024u * 1024u) err = 1;
+                    else {
+                        es += nw << sy;
+                        nw <<= 1;
+                    }
+                } else {
+                    if (es) {
+                        const u32 front = w0 & 0xFFu;
+                        if (o + es >= maxlen) err = 1; // tt.len() >= nblock_max after a run (:399-401)
+                        else
+                            for (u32 q = 0; q < es; ++q) L[o + q] = (u8)front;
+                        o += es;
+                        es = 0;
+                        nw = 1;
+                    }
+                    if (sy != eob) {
+                        if (o >= maxlen) err = 1;    // :427-429
+                        else L[o] = (u8)imtf_pop(w0, w1, list, sy - 1u);
+                        o += 1;
+                    }
+                }
+            }
         }
-        if (run_start != 0xFFFFFFFFu) {
-            const u32 z = run_value(sym, run_start, i);
-            const u32 front = list[0] & 0xFFu;
-            if (o + z >= maxlen) err = 1; // tt.len() >= nblock_max after a run (:399-401)
-            else
-                for (u32 k = 0; k < z; ++k) L[o + k] = (u8)front;
-            o += z;
-            run_start = 0xFFFFFFFFu;
-        }
-        if (sy != eob) {
-            if (o >= maxlen) err = 1;    // :427-429
-            else L[o] = (u8)imtf_pop(list, sy - 1u);
-            o += 1;
-        }
-        if (err) break;
     }
     if (err) atomicMax(&a.err[lb], 1u);
 }
