@@ -313,6 +313,7 @@ struct DecArgs {
     uint4 *walk_meta;             // [nb] {length, start node, first byte} per block
     u8 *seg_buf;                  // [nb][kDecSamples][kSegCap] bytes passed by each segment's walk
     u32 *seg_cont;                // [nb][kDecSamples] node reached after kSegCap steps
+    u32 *long_list;               // [nb * kDecSamples] segments longer than kSegCap (count in work_ctr[256])
     u32 *out_len;                 // [nb]
     u32 *thist;                   // [nb][kTilesPerBlock][256] T-vector sort: per-tile byte counts
     u32 *tbase;                   // [nb][256]
@@ -322,7 +323,7 @@ void launch_dec_scan(hipStream_t st, const u8 *in, u64 nbytes, DecCand *cands, u
 void launch_dec_blocks(hipStream_t st, const u8 *in, u64 nbytes, const DecCand *cands, u32 ncand, DecBlockInfo *info,
                        u16 *sym, u8 *sel_scratch);
 void launch_dec_mtf(hipStream_t st, const DecArgs &a);
-void launch_dec_walks(hipStream_t st, const DecArgs &a, u32 walk_wgs);
+void launch_dec_walks(hipStream_t st, const DecArgs &a, u32 walk_wgs, hipStream_t st2, hipEvent_t ev_a, hipEvent_t ev_b);
 void launch_dec_expand(hipStream_t st, const DecArgs &a, const u64 *out_base, u8 *out);
 void launch_dec_crc(hipStream_t st, const DecArgs &a, const u64 *out_base, const u8 *out, u32 max_out_len,
                     const u32 *crc_tab, const u32 *xp2);

@@ -28,7 +28,8 @@ struct Ev {
 struct DecWorkspace {
     size_t slots = 0;
     DevBuf cands, count, info, sym, sel, slot, nbmax, perm, chunk_emit, tt_len, err, L, T, X, samp_next, samp_len,
-        samp_off, cycle_len, sub_trans, sub_off, sub_state, work_ctr, walk_meta, seg_buf, seg_cont, out_len, thist, tbase, crc, out_base, staging, cand_all;
+        samp_off, cycle_len, sub_trans, sub_off, sub_state, work_ctr, walk_meta, seg_buf, seg_cont, long_list, out_len, thist, tbase, crc, out_base, staging, cand_all;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr; // fork / join of the second walk
     double t_stage[5] = {0, 0, 0, 0, 0};
     u64 stats[4] = {0, 0, 0, 0}; // candidates, blocks, streams, forced blocks
 };
@@ -38,9 +39,11 @@ void dec_workspace_free(DecWorkspace *w)
     if (!w) return;
     DevBuf *all[] = {&w->cands, &w->count, &w->info, &w->sym, &w->sel, &w->slot, &w->nbmax, &w->perm,
                      &w->chunk_emit, &w->tt_len, &w->err, &w->L, &w->T, &w->X, &w->samp_next, &w->samp_len,
-                     &w->samp_off, &w->cycle_len, &w->sub_trans, &w->sub_off, &w->sub_state, &w->work_ctr, &w->walk_meta, &w->seg_buf, &w->seg_cont, &w->out_len, &w->thist, &w->tbase,
+                     &w->samp_off, &w->cycle_len, &w->sub_trans, &w->sub_off, &w->sub_state, &w->work_ctr, &w->walk_meta, &w->seg_buf, &w->seg_cont, &w->long_list, &w->out_len, &w->thist, &w->tbase,
                      &w->crc, &w->out_base, &w->staging, &w->cand_all};
     for (DevBuf *b : all) b->release();
+    if (w->ev_a) (void)hipEventDestroy(w->ev_a);
+    if (w->ev_b) (void)hipEventDestroy(w->ev_b);
     delete w;
 }
 
@@ -58,8 +61,8 @@ static int dec_ensure(DecWorkspace *w, size_t slots)
         (rc = w->samp_next.ensure(s * (size_t)kDecSamples * 4)) || (rc = w->samp_len.ensure(s * (size_t)kDecSamples * 4)) ||
         (rc = w->samp_off.ensure(s * (size_t)kDecSamples * 4)) || (rc = w->cycle_len.ensure(s * 4)) ||
         (rc = w->sub_trans.ensure(s * (size_t)kDecSubs * 16)) || (rc = w->sub_off.ensure(s * (size_t)(kDecSubs + 1) * 4)) ||
-        (rc = w->sub_state.ensure(s * (size_t)kDecSubs)) || (rc = w->work_ctr.ensure(1024)) || (rc = w->walk_meta.ensure(s * 16)) || (rc = w->seg_buf.ensure(s * (size_t)kDecSamples * kSegCap + 64)) ||
-        (rc = w->seg_cont.ensure(s * (size_t)kDecSamples * 4)) ||
+        (rc = w->sub_state.ensure(s * (size_t)kDecSubs)) || (rc = w->work_ctr.ensure(2048)) || (rc = w->walk_meta.ensure(s * 16)) || (rc = w->seg_buf.ensure(s * (size_t)kDecSamples * kSegCap + 64)) ||
+        (rc = w->seg_cont.ensure(s * (size_t)kDecSamples * 4)) || (rc = w->long_list.ensure(s * (size_t)kDecSamples * 4)) ||
         (rc = w->out_len.ensure(s * 4)) || (rc = w->thist.ensure(s * (size_t)kTilesPerBlock * 256 * 4)) ||
         (rc = w->tbase.ensure(s * 256 * 4)) || (rc = w->crc.ensure(s * 4)) || (rc = w->out_base.ensure(s * 8)))
         return rc;
@@ -138,6 +141,10 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
     HIPDEC(hipSetDevice(g->device));
     if (!g->dec) g->dec = new DecWorkspace();
     DecWorkspace *w = g->dec;
+    if (!w->ev_a) {
+        HIPDEC(hipEventCreateWithFlags(&w->ev_a, hipEventDisableTiming));
+        HIPDEC(hipEventCreateWithFlags(&w->ev_b, hipEventDisableTiming));
+    }
     hipStream_t st = g->st;
     for (double &t : w->t_stage) t = 0;
     for (u64 &s : w->stats) s = 0;
@@ -373,6 +380,7 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             a.walk_meta = w->walk_meta.as<uint4>();
             a.seg_buf = w->seg_buf.as<u8>();
             a.seg_cont = w->seg_cont.as<u32>();
+            a.long_list = w->long_list.as<u32>();
             a.out_len = w->out_len.as<u32>();
             a.thist = w->thist.as<u32>();
             a.tbase = w->tbase.as<u32>();
@@ -387,7 +395,7 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             HIPDEC(hipStreamSynchronize(st));
             stage_time(1);
             HIPDEC(hipEventRecord(ev[0], st));
-            launch_dec_walks(st, a, walk_wgs);
+            launch_dec_walks(st, a, walk_wgs, g->st2, w->ev_a, w->ev_b);
             HIPDEC(hipEventRecord(ev[1], st));
             std::vector<u32> h_err(nb), h_len(nb);
             HIPDEC(hipMemcpyAsync(h_err.data(), w->err.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));

@@ -832,7 +832,10 @@ __global__ __launch_bounds__(256) void k_dec_walk_lengths(DecArgs a)
                     }
                 }
                 ++len;
-                if (len == kSegCap) a.seg_cont[slot] = cur;
+                if (len == kSegCap) { // a long segment: remembered for the second walk
+                    a.seg_cont[slot] = cur;
+                    a.long_list[atomicAdd(a.work_ctr + 256, 1u)] = slot;
+                }
                 const u32 nid = sample_id(cur, p0);
                 if (nid != 0xFFFFFFFFu || len > n) {
                     if (len < kSegCap && (len & 3u)) *reinterpret_cast<u32 *>(row + (len & ~3u)) = acc;
@@ -905,56 +908,26 @@ __global__ __launch_bounds__(256) void k_dec_seg_copy(DecArgs a)
     }
 }
 
-// Walk 2: only what the scratch rows could not hold (segments longer than kSegCap) is walked again.
+// Walk 2: only what the scratch rows could not hold (the few segments longer than kSegCap, listed by
+// walk 1) is walked again, one lane per segment.
 __global__ __launch_bounds__(256) void k_dec_walk_write(DecArgs a)
 {
-    const u32 xcd = blockIdx.x & 7u;
-    const u32 total = ((a.nb + 7u - xcd) / 8u) * kDecSamples;
-    u32 *ctr = a.work_ctr + 128u + xcd * 16u;
-    bool have = false;
-    u32 cur = 0, left = 0, o = 0, n = 0;
-    const u32 *T = nullptr;
-    u8 *X = nullptr;
-    bool dry = false;
-    while (true) {
-        const u64 idle = __ballot(!have);
-        if ((!dry && (u32)__popcll(idle) >= kWalkRefill) || idle == ~0ull) {
-            u32 id, first_id;
-            const bool got = take_item(ctr, total, !have, id, first_id);
-            if (got) {
-                const u32 q = id / kDecSamples, sid = id - q * kDecSamples;
-                const u32 lb = q * 8u + xcd;
-                id = lb * kDecSamples + sid;
-                const uint4 m = a.walk_meta[lb];
-                if (m.x) {
-                    const u32 o0 = a.samp_off[id];
-                    const u32 len = (o0 != 0xFFFFFFFFu) ? a.samp_len[id] : 0u;
-                    if (len > kSegCap) {
-                        n = m.x;
-                        T = a.T + (size_t)lb * kSlot;
-                        X = a.X + (size_t)lb * kSlot;
-                        cur = a.seg_cont[id];
-                        o = o0 + 1u + kSegCap;
-                        left = len - kSegCap;
-                        have = true;
-                    }
-                }
-            }
-            if (first_id + (u32)__popcll(idle) >= total) dry = true;
-            if (!__ballot(have)) {
-                if (first_id >= total) break;
-                continue;
-            }
-        }
-#pragma unroll 1
-        for (u32 s = 0; s < kWalkBurst; ++s) {
-            if (have) {
-                const u32 v = T[cur];
-                if (o < n) X[o] = (u8)v;
-                ++o;
-                cur = v >> 8;
-                if (--left == 0) have = false;
-            }
+    const u32 total = a.work_ctr[256];
+    for (u32 it = blockIdx.x * 256u + threadIdx.x; it < total; it += gridDim.x * 256u) {
+        const u32 id = a.long_list[it];
+        const u32 lb = id / kDecSamples;
+        const uint4 m = a.walk_meta[lb];
+        const u32 o0 = a.samp_off[id];
+        if (!m.x || o0 == 0xFFFFFFFFu) continue;
+        const u32 n = m.x;
+        const u32 *T = a.T + (size_t)lb * kSlot;
+        u8 *X = a.X + (size_t)lb * kSlot;
+        u32 cur = a.seg_cont[id];
+        u32 o = o0 + 1u + kSegCap;
+        for (u32 left = a.samp_len[id] - kSegCap; left && o < n; --left) {
+            const u32 v = T[cur];
+            X[o++] = (u8)v;
+            cur = v >> 8;
         }
     }
 }
@@ -1417,19 +1390,25 @@ void launch_dec_mtf(hipStream_t st, const DecArgs &a)
     hipLaunchKernelGGL(k_dec_chunk_emit, dim3(cw, a.nb), dim3(256), 0, st, a);
 }
 
-void launch_dec_walks(hipStream_t st, const DecArgs &a, u32 walk_wgs)
+// st2 / ev: a second stream and two events, so that the second walk (little work, but as long as the
+// longest segment's tail) runs beside the copy instead of behind it
+void launch_dec_walks(hipStream_t st, const DecArgs &a, u32 walk_wgs, hipStream_t st2, hipEvent_t ev_a, hipEvent_t ev_b)
 {
     const dim3 tiles(kTilesPerBlock, xcd_grid_y(a.nb));
     hipLaunchKernelGGL(k_dec_thist, tiles, dim3(kSortThreads), 0, st, a);
     hipLaunchKernelGGL(k_dec_tscan, dim3(a.nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dec_tscatter, tiles, dim3(kSortThreads), 0, st, a);
-    (void)hipMemsetAsync(a.work_ctr, 0, 1024, st);
+    (void)hipMemsetAsync(a.work_ctr, 0, 2048, st);
     hipLaunchKernelGGL(k_dec_walk_meta, dim3((a.nb + 63) / 64), dim3(64), 0, st, a);
     const u32 wgs = (walk_wgs + 7u) & ~7u; // the same number of walkers on every XCD
     hipLaunchKernelGGL(k_dec_walk_lengths, dim3(wgs), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dec_rank_samples, dim3(a.nb), dim3(64), 0, st, a);
+    (void)hipEventRecord(ev_a, st);
+    (void)hipStreamWaitEvent(st2, ev_a, 0);
+    hipLaunchKernelGGL(k_dec_walk_write, dim3(wgs), dim3(256), 0, st2, a);
+    (void)hipEventRecord(ev_b, st2);
     hipLaunchKernelGGL(k_dec_seg_copy, dim3((kDecSamples + 3) / 4, a.nb), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_dec_walk_write, dim3(wgs), dim3(256), 0, st, a);
+    (void)hipStreamWaitEvent(st, ev_b, 0);
     hipLaunchKernelGGL(k_dec_fixups, dim3(a.nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dec_rle_sub, dim3((kDecSubs + 255) / 256, a.nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dec_rle_chain, dim3(a.nb), dim3(1024), 0, st, a);

@@ -99,19 +99,31 @@ __global__ __launch_bounds__(64) void k_mtf_compose(MtfArgs a)
     __syncthreads();
     const u32 alpha = popc8(bits);
     u32 *st32 = reinterpret_cast<u32 *>(s_state);
+    // the report of chunk c + 1 is fetched while chunk c is folded in: the loop is a chain of
+    // barriers, a memory round trip inside every link would double its length
+    const size_t rep0 = (size_t)lb * kMaxMtfChunks;
+    u32 m_next = nchunks > 1 ? (u32)a.summ_len[rep0] : 0u;
+    u32 w_next = nchunks > 1 ? reinterpret_cast<const u32 *>(a.summ + rep0 * 256u)[l] : 0u;
     for (u32 c = 0; c < nchunks; ++c) {
         // the list chunk c starts from
         u32 *dst = reinterpret_cast<u32 *>(a.init_state + ((size_t)lb * kMaxMtfChunks + c) * 256u);
         dst[l] = st32[l];
         if (c + 1 == nchunks) break;
-        const u32 m = a.summ_len[(size_t)lb * kMaxMtfChunks + c];
-        const u8 *sm = a.summ + ((size_t)lb * kMaxMtfChunks + c) * 256u;
+        const u32 m = m_next, w = w_next;
+        if (c + 2 < nchunks) {
+            m_next = a.summ_len[rep0 + c + 1];
+            w_next = reinterpret_cast<const u32 *>(a.summ + (rep0 + c + 1) * 256u)[l];
+        }
         reinterpret_cast<u32 *>(s_mark)[l] = 0;
         __syncthreads();
-        for (u32 i = l; i < m; i += 64) {
-            const u8 v = sm[i];
-            s_mark[v] = 1;
-            s_new[i] = v;
+#pragma unroll
+        for (u32 k = 0; k < 4; ++k) {
+            const u32 i = l * 4u + k;
+            if (i < m) {
+                const u8 v = (u8)(w >> (8u * k));
+                s_mark[v] = 1;
+                s_new[i] = v;
+            }
         }
         __syncthreads();
         // stable compaction of the old entries that are not in the report
