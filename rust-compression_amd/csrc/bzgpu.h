@@ -291,6 +291,7 @@ constexpr u32 kDecSampleStep = BZ_DEC_SAMPLE_STEP;             // every n-th T s
 constexpr u32 kDecSamples = kMaxBlockLen / kDecSampleStep + 3; // sample nodes per block (the last one = the start node)
 constexpr u32 kSegCap = 4 * kDecSampleStep;                    // scratch bytes per segment (mean length = the step)
 constexpr u32 kDecSubs = kSlot / 64;                           // 64-byte RLE1-undo sub-tiles per block
+struct KernelProf;
 struct DecArgs {
     u32 nb;
     const u32 *slot;              // [nb] candidate slot (index into info / sym) of each true block, stream order
@@ -322,8 +323,9 @@ struct DecArgs {
 void launch_dec_scan(hipStream_t st, const u8 *in, u64 nbytes, DecCand *cands, u32 cap, u32 *count);
 void launch_dec_blocks(hipStream_t st, const u8 *in, u64 nbytes, const DecCand *cands, u32 ncand, DecBlockInfo *info,
                        u16 *sym, u8 *sel_scratch);
-void launch_dec_mtf(hipStream_t st, const DecArgs &a);
-void launch_dec_walks(hipStream_t st, const DecArgs &a, u32 walk_wgs, hipStream_t st2, hipEvent_t ev_a, hipEvent_t ev_b);
+void launch_dec_mtf(hipStream_t st, const DecArgs &a, KernelProf *prof, int *rec);
+void launch_dec_walks(hipStream_t st, const DecArgs &a, u32 walk_wgs, hipStream_t st2, hipEvent_t ev_a, hipEvent_t ev_b,
+                      KernelProf *prof, int rec[4]);
 void launch_dec_expand(hipStream_t st, const DecArgs &a, const u64 *out_base, u8 *out);
 void launch_dec_crc(hipStream_t st, const DecArgs &a, const u64 *out_base, const u8 *out, u32 max_out_len,
                     const u32 *crc_tab, const u32 *xp2);
@@ -339,6 +341,14 @@ enum KernelId {
     KID_GROUP_FLAGS,
     KID_GROUP_APPLY,
     KID_LAST_COLUMN,
+    // decode path (k_dec.hip)
+    KID_DEC_BLOCK,   // header + Huffman
+    KID_DEC_MTF,     // chunk_perm + compose + chunk_emit
+    KID_DEC_TSORT,   // thist + tscan + tscatter
+    KID_DEC_WALK,    // k_dec_walk_lengths (the inverse BWT's random loads)
+    KID_DEC_PLACE,   // rank_samples + seg_copy + walk_write + fixups
+    KID_DEC_RLE,     // rle_sub + rle_chain + rle_expand
+    KID_DEC_CRC,
     KID_COUNT
 };
 struct KernelProf {
@@ -356,6 +366,7 @@ struct KernelProf {
     double seconds[KID_COUNT] = {};
     int begin(hipStream_t st, int id, u64 nbytes);
     void end(hipStream_t st, int idx);
+    void set_bytes(int idx, u64 nbytes) { if (idx >= 0) recs[idx].bytes = nbytes; } // when only known later
     void collect(); // call after the stream has been synchronised
     void reset();
 };

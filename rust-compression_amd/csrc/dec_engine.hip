@@ -233,6 +233,8 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
     // BZip2DecoderBase state (decoder.rs:93-108) as far as the record chain needs it
     u64 pos = 0;
     u32 stream_no = 1, level = 0, combined = 0;
+    KernelProf *prof = g->prof.on ? &g->prof : nullptr;
+    int d1_rec = -1;
     bool need_header = true;
     bool have_next = false;
     u32 next_head = 0, next_bits = 0;
@@ -246,14 +248,24 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
         if (nb1) {
             HIPDEC(hipMemcpyAsync(w->cands.p, cands.data() + ci, (size_t)nb1 * sizeof(DecCand), hipMemcpyHostToDevice, st));
             HIPDEC(hipEventRecord(ev[0], st));
+            const int prec = prof ? prof->begin(st, KID_DEC_BLOCK, 0) : -1;
             launch_dec_blocks(st, d_in, n, w->cands.as<DecCand>(), nb1, w->info.as<DecBlockInfo>(), w->sym.as<u16>(),
                               w->sel.as<u8>());
+            if (prof) prof->end(st, prec);
+            d1_rec = prec;
             HIPDEC(hipEventRecord(ev[1], st));
             HIPDEC(hipMemcpyAsync(hinfo.data(), w->info.p, (size_t)nb1 * sizeof(DecBlockInfo), hipMemcpyDeviceToHost, st));
             HIPDEC(hipStreamSynchronize(st));
             stage_time(0);
         }
         // ---- the record chain through this batch
+        if (d1_rec >= 0) { // algorithmic bytes of D1: the compressed bits of its candidates + 2 B per symbol
+            u64 by = 0;
+            for (u32 i = 0; i < nb1; ++i)
+                by += (hinfo[i].end_bit > cands[ci + i].bitpos ? (hinfo[i].end_bit - cands[ci + i].bitpos) / 8 : 0) + 2ull * hinfo[i].nsym;
+            prof->set_bytes(d1_rec, by);
+            d1_rec = -1;
+        }
         std::vector<u32> bslot, bmax, bcrc;
         u32 nforced = 0;
         int term = 0; // 0: batch ended, more to come; 1: end of input reached cleanly; <0: error
@@ -390,18 +402,32 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             HIPDEC(hipMemsetAsync(w->err.p, 0, (size_t)nb * 4, st));
             HIPDEC(hipMemsetAsync(w->out_len.p, 0, (size_t)nb * 4, st));
             HIPDEC(hipEventRecord(ev[0], st));
-            launch_dec_mtf(st, a);
+            int mtf_rec = -1, wrec[4] = {-1, -1, -1, -1};
+            launch_dec_mtf(st, a, prof, &mtf_rec);
             HIPDEC(hipEventRecord(ev[1], st));
             HIPDEC(hipStreamSynchronize(st));
             stage_time(1);
             HIPDEC(hipEventRecord(ev[0], st));
-            launch_dec_walks(st, a, walk_wgs, g->st2, w->ev_a, w->ev_b);
+            launch_dec_walks(st, a, walk_wgs, g->st2, w->ev_a, w->ev_b, prof, wrec);
             HIPDEC(hipEventRecord(ev[1], st));
-            std::vector<u32> h_err(nb), h_len(nb);
+            std::vector<u32> h_err(nb), h_len(nb), h_tt(prof ? nb : 0);
+            if (prof) HIPDEC(hipMemcpyAsync(h_tt.data(), w->tt_len.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
             HIPDEC(hipMemcpyAsync(h_err.data(), w->err.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
             HIPDEC(hipMemcpyAsync(h_len.data(), w->out_len.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
             HIPDEC(hipStreamSynchronize(st));
             stage_time(2);
+            if (prof) { // algorithmic bytes per stage, now that symbol counts and block lengths are known
+                u64 nsym = 0, ntt = 0;
+                for (u32 i = 0; i < nb; ++i) {
+                    nsym += hinfo[bslot[i]].nsym;
+                    ntt += h_err[i] ? 0 : h_tt[i];
+                }
+                prof->set_bytes(mtf_rec, nsym * 4 + ntt);    // symbols read twice (2 B), column written
+                prof->set_bytes(wrec[0], ntt * (1 + 1 + 4)); // column read twice, T written
+                prof->set_bytes(wrec[1], ntt * (4 + 1));     // one T entry read, one byte kept per step
+                prof->set_bytes(wrec[2], ntt * 2);           // rows read, image written
+                prof->set_bytes(wrec[3], ntt * (1 + 16.0 / 64 + 1)); // image read twice + tables
+            }
             // blocks in front of the first one that failed to rebuild
             u32 good = nb;
             for (u32 i = 0; i < nb; ++i)
@@ -438,8 +464,12 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                 }
                 HIPDEC(hipMemcpyAsync(w->out_base.p, h_base.data(), (size_t)nb * 8, hipMemcpyHostToDevice, st));
                 HIPDEC(hipEventRecord(ev[0], st));
+                int xrec = prof ? prof->begin(st, KID_DEC_RLE, bytes) : -1;
                 launch_dec_expand(st, a, w->out_base.as<u64>(), dst);
+                if (prof) prof->end(st, xrec);
+                xrec = prof ? prof->begin(st, KID_DEC_CRC, bytes) : -1;
                 launch_dec_crc(st, a, w->out_base.as<u64>(), dst, max_len, g->crc_tab.as<u32>(), g->xp2.as<u32>());
+                if (prof) prof->end(st, xrec);
                 HIPDEC(hipEventRecord(ev[1], st));
                 std::vector<u32> h_crc(nb);
                 HIPDEC(hipMemcpyAsync(h_crc.data(), w->crc.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
@@ -477,6 +507,7 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             finished = true;
         }
     }
+    if (prof) prof->collect();
     return BZ_OK;
 }
 

@@ -1382,26 +1382,34 @@ void launch_dec_blocks(hipStream_t st, const u8 *in, u64 nbytes, const DecCand *
     hipLaunchKernelGGL(k_dec_block, dim3(ncand), dim3(kD1Threads), 0, st, in, nbytes, cands, ncand, info, sym, sel_scratch);
 }
 
-void launch_dec_mtf(hipStream_t st, const DecArgs &a)
+void launch_dec_mtf(hipStream_t st, const DecArgs &a, KernelProf *prof, int *rec)
 {
+    *rec = prof ? prof->begin(st, KID_DEC_MTF, 0) : -1;
     const u32 cw = (kMaxMtfChunks + 255) / 256;
     hipLaunchKernelGGL(k_dec_chunk_perm, dim3(cw, a.nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dec_compose, dim3(a.nb), dim3(64), 0, st, a);
     hipLaunchKernelGGL(k_dec_chunk_emit, dim3(cw, a.nb), dim3(256), 0, st, a);
+    if (prof) prof->end(st, *rec);
 }
 
 // st2 / ev: a second stream and two events, so that the second walk (little work, but as long as the
 // longest segment's tail) runs beside the copy instead of behind it
-void launch_dec_walks(hipStream_t st, const DecArgs &a, u32 walk_wgs, hipStream_t st2, hipEvent_t ev_a, hipEvent_t ev_b)
+void launch_dec_walks(hipStream_t st, const DecArgs &a, u32 walk_wgs, hipStream_t st2, hipEvent_t ev_a, hipEvent_t ev_b,
+                      KernelProf *prof, int rec[4])
 {
     const dim3 tiles(kTilesPerBlock, xcd_grid_y(a.nb));
+    rec[0] = prof ? prof->begin(st, KID_DEC_TSORT, 0) : -1;
     hipLaunchKernelGGL(k_dec_thist, tiles, dim3(kSortThreads), 0, st, a);
     hipLaunchKernelGGL(k_dec_tscan, dim3(a.nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dec_tscatter, tiles, dim3(kSortThreads), 0, st, a);
+    if (prof) prof->end(st, rec[0]);
     (void)hipMemsetAsync(a.work_ctr, 0, 2048, st);
     hipLaunchKernelGGL(k_dec_walk_meta, dim3((a.nb + 63) / 64), dim3(64), 0, st, a);
     const u32 wgs = (walk_wgs + 7u) & ~7u; // the same number of walkers on every XCD
+    rec[1] = prof ? prof->begin(st, KID_DEC_WALK, 0) : -1;
     hipLaunchKernelGGL(k_dec_walk_lengths, dim3(wgs), dim3(256), 0, st, a);
+    if (prof) prof->end(st, rec[1]);
+    rec[2] = prof ? prof->begin(st, KID_DEC_PLACE, 0) : -1;
     hipLaunchKernelGGL(k_dec_rank_samples, dim3(a.nb), dim3(64), 0, st, a);
     (void)hipEventRecord(ev_a, st);
     (void)hipStreamWaitEvent(st2, ev_a, 0);
@@ -1410,8 +1418,11 @@ void launch_dec_walks(hipStream_t st, const DecArgs &a, u32 walk_wgs, hipStream_
     hipLaunchKernelGGL(k_dec_seg_copy, dim3((kDecSamples + 3) / 4, a.nb), dim3(256), 0, st, a);
     (void)hipStreamWaitEvent(st, ev_b, 0);
     hipLaunchKernelGGL(k_dec_fixups, dim3(a.nb), dim3(256), 0, st, a);
+    if (prof) prof->end(st, rec[2]);
+    rec[3] = prof ? prof->begin(st, KID_DEC_RLE, 0) : -1;
     hipLaunchKernelGGL(k_dec_rle_sub, dim3((kDecSubs + 255) / 256, a.nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dec_rle_chain, dim3(a.nb), dim3(1024), 0, st, a);
+    if (prof) prof->end(st, rec[3]);
 }
 
 void launch_dec_expand(hipStream_t st, const DecArgs &a, const u64 *out_base, u8 *out)

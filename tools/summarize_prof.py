@@ -13,6 +13,7 @@ import re
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+traffic_name = sys.argv[2] if len(sys.argv) > 2 else "pmc_traffic.json"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
@@ -65,7 +66,7 @@ if pmc:
         d["hbm_bytes_per_launch"] = int(d["FETCH_SIZE_KiB_x2"] * 1024 / lf + d["WRITE_SIZE_KiB"] * 1024 / lw)
         traffic[k] = d["hbm_bytes_per_launch"]
     json.dump(pmc, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
-    json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+    json.dump(traffic, open(os.path.join(dst, traffic_name), "w"), indent=1, sort_keys=True)
     print("wrote pmc for", len(pmc), "kernels")
 for f in ("bench_trace.json", "bench_fetch.json", "bench_write.json"):
     p = os.path.join(src, f)
