@@ -285,7 +285,7 @@ struct DecBlockInfo {
 };
 
 #ifndef BZ_DEC_SAMPLE_STEP
-#define BZ_DEC_SAMPLE_STEP 256
+#define BZ_DEC_SAMPLE_STEP 128
 #endif
 constexpr u32 kDecSampleStep = BZ_DEC_SAMPLE_STEP;             // every n-th T slot is a sample node
 constexpr u32 kDecSamples = kMaxBlockLen / kDecSampleStep + 3; // sample nodes per block (the last one = the start node)

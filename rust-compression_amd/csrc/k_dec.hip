@@ -827,7 +827,7 @@ __global__ __launch_bounds__(256) void k_dec_walk_lengths(DecArgs a)
                 if (len < kSegCap) {
                     acc |= (v & 0xFFu) << (8u * (len & 3u));
                     if ((len & 3u) == 3u) {
-                        *reinterpret_cast<u32 *>(row + (len - 3u)) = acc;
+                        __builtin_nontemporal_store(acc, reinterpret_cast<u32 *>(row + (len - 3u)));
                         acc = 0;
                     }
                 }
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(256) void k_dec_walk_lengths(DecArgs a)
                 }
                 const u32 nid = sample_id(cur, p0);
                 if (nid != 0xFFFFFFFFu || len > n) {
-                    if (len < kSegCap && (len & 3u)) *reinterpret_cast<u32 *>(row + (len & ~3u)) = acc;
+                    if (len < kSegCap && (len & 3u)) __builtin_nontemporal_store(acc, reinterpret_cast<u32 *>(row + (len & ~3u)));
                     a.samp_next[slot] = nid;
                     a.samp_len[slot] = len;
                     have = false;
