@@ -249,3 +249,29 @@ def test_encode_decode_device_round_trip_large(pkg, eng):
     assert (n, st) == (len(d), 0)
     assert torch.equal(tout[:n], tin)
     assert bz2.decompress(bytes(tz[:zn].cpu().numpy())) == d
+
+
+def test_full_size_round_trip_on_device(pkg, eng):
+    """BASELINE configs[1] size (1 GiB, level 9): decode(encode(x)) == x with both streams in HBM, and
+    the stress corpus T2 (deep repeats, periodic ties) at 256 MiB"""
+    import torch
+    import corpus
+    big = pkg.GpuEngine(0, 1400)
+    try:
+        for name, n in (("text", 1 << 30), ("t2", 256 << 20)):
+            if name == "text":
+                tin = corpus.corpus_on_device(n, torch.device("cuda", 0))
+            else:
+                tin = torch.frombuffer(bytearray(corpus.stress_t2(n)), dtype=torch.uint8).cuda()
+            cap = (pkg.encode_bound(n) + 15) & ~15
+            tz = torch.empty(cap, dtype=torch.uint8, device="cuda")
+            zn = big.encode_device(9, tin.data_ptr(), n, tz.data_ptr(), cap)
+            size, st = big.decode_device(tz.data_ptr(), zn, None, 0)
+            assert (size, st) == (n, 0), name
+            tout = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+            got, st = big.decode_device(tz.data_ptr(), zn, tout.data_ptr(), n)
+            assert (got, st) == (n, 0), name
+            assert torch.equal(tout[:n], tin), name
+            del tin, tz, tout
+    finally:
+        big.close()
