@@ -237,6 +237,20 @@ int bz_gpu_debug_block_stats(bz_gpu_engine *g, uint32_t *h_stats, size_t cap_blo
  * written, CRCs are not checked), to learn the capacity a second call needs. */
 int bz_gpu_decode_device(bz_gpu_engine *g, const void *d_in, size_t n,
                          void *d_out, size_t cap, size_t *out_len);
+/* The same over several GPUs (one process per GPU, every rank holds the whole
+ * compressed file): rank r decodes the r-th contiguous share of the blocks
+ * into ITS OWN d_out.  *out_len = bytes of this rank's slice, *out_offset =
+ * where the slice sits in the decoded file, *total_len = decoded bytes over all
+ * ranks; the verdict is the same on every rank.  `allgather` is the only
+ * collective the path needs (called twice, with a few bytes per block): it must
+ * copy `bytes` bytes from `send` of every rank, in rank order, into `recv`
+ * (world * bytes) -- RCCL, MPI or torch.distributed behind a C callback; return
+ * 0 on success.  Blocks must carry their full 48-bit magic (every encoder's do). */
+typedef int (*bz_allgather_fn)(void *ctx, const void *send, size_t bytes, void *recv);
+int bz_gpu_decode_device_sharded(bz_gpu_engine *g, const void *d_in, size_t n,
+                                 void *d_out, size_t cap, int rank, int world,
+                                 bz_allgather_fn allgather, void *ctx,
+                                 size_t *out_len, size_t *out_offset, size_t *total_len);
 /* Seconds of GPU time of the last decode by stage (HIP events):
  * [0] magic scan + Huffman [1] zero runs + inverse MTF [2] inverse BWT
  * [3] RLE1 undo + CRC [4] total. */

@@ -84,9 +84,13 @@ EXPORTS = [
     "bz_gpu_partition_slab_finish", "bz_gpu_encode_blocks", "bz_gpu_assemble", "bz_gpu_last_timings",
     "bz_gpu_last_bwt_stats", "bz_gpu_last_bwt_rounds", "bz_gpu_profile_enable", "bz_gpu_profile_kernels", "bz_gpu_profile_get",
     "bz_gpu_debug_bwt", "bz_gpu_debug_code_lengths", "bz_gpu_debug_block_stats",
-    "bz_gpu_decode_device", "bz_gpu_last_decode_timings", "bz_gpu_last_decode_stats", "bz_decode_buffer",
+    "bz_gpu_decode_device", "bz_gpu_decode_device_sharded", "bz_gpu_last_decode_timings", "bz_gpu_last_decode_stats", "bz_decode_buffer",
     "bz_dec_create", "bz_dec_write", "bz_dec_end", "bz_dec_read", "bz_dec_pending", "bz_dec_destroy",
 ]
+
+
+# int (*bz_allgather_fn)(void *ctx, const void *send, size_t bytes, void *recv)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
 def _share_hip_runtime_with_torch():
@@ -160,6 +164,7 @@ def lib():
     L.bz_gpu_debug_code_lengths.argtypes = [vp, u32p, sz, u8p, C.POINTER(C.c_int)]
     L.bz_gpu_debug_block_stats.argtypes = [vp, u32p, sz, szp]
     L.bz_gpu_decode_device.argtypes = [vp, vp, sz, vp, sz, szp]
+    L.bz_gpu_decode_device_sharded.argtypes = [vp, vp, sz, vp, sz, C.c_int, C.c_int, ALLGATHER_FN, vp, szp, szp, szp]
     L.bz_gpu_last_decode_timings.argtypes = [vp, C.POINTER(C.c_double)]
     L.bz_gpu_last_decode_stats.argtypes = [vp, u64p]
     L.bz_decode_buffer.argtypes = [C.c_int, C.c_char_p, sz, C.POINTER(u8p), szp]
@@ -452,6 +457,27 @@ class GpuEngine:
         if rc != BZ_OK and rc not in _DECODER_VERDICTS:
             raise CompressionError(rc)
         return out_len.value, rc
+
+    def decode_device_sharded(self, d_in, n, d_out, cap, rank, world, allgather):
+        """One rank of a multi-GPU decode.  `allgather(send: bytes) -> bytes` returns the concatenation of
+        every rank's `send`, in rank order (sharded.allgather_bytes wraps torch.distributed).
+        -> (bytes in this rank's slice, offset of the slice in the decoded file, total bytes, verdict)"""
+        def cb(_ctx, send, nbytes, recv):
+            try:
+                got = allgather(C.string_at(send, nbytes))
+                if len(got) != nbytes * world:
+                    return 1
+                C.memmove(recv, got, len(got))
+                return 0
+            except Exception:  # the C side turns this into BZ_E_UNEXPECTED
+                return 1
+        fn = ALLGATHER_FN(cb)
+        out_len, off, tot = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        rc = lib().bz_gpu_decode_device_sharded(self._h, d_in, n, d_out, cap, rank, world, fn, None,
+                                                C.byref(out_len), C.byref(off), C.byref(tot))
+        if rc != BZ_OK and rc not in _DECODER_VERDICTS:
+            raise CompressionError(rc)
+        return out_len.value, off.value, tot.value, rc
 
     def decode_timings(self):
         t = (C.c_double * 5)()

@@ -133,10 +133,34 @@ struct Sink {
 
 static inline u32 rotl1(u32 x) { return (x << 1) | (x >> 31); }
 
+// Multi-GPU decode: every rank holds the whole compressed file, scans it, and runs D1 on its own
+// contiguous range of block candidates.  What the record chain needs from every candidate is
+// exchanged with one all-gather; each rank then links the chain (the same, cheap host loop) and
+// rebuilds the true blocks of its own range into its own output slice.  A second all-gather
+// settles where the stream failed, if it did, and where each slice sits in the decoded file.
+namespace {
+struct ShardRec { // what the chain needs to know about one candidate
+    u64 end_bit;
+    u32 status, stored_crc, next_head, next_bits;
+};
+struct ShardSum { // one rank's result
+    u64 bytes;      // bytes of its blocks up to (CRC failure: including) its first failing block
+    u64 fail_ord;   // ordinal (in stream order) of its first failing block, ~0 if none
+    u64 first_ord;  // ordinal of its first block (~0: it owns none)
+    u64 pad;
+};
+struct Shard {
+    int rank = 0, world = 1;
+    bz_allgather_fn allgather = nullptr;
+    void *ctx = nullptr;
+    u64 out_offset = 0, total_len = 0; // results
+};
+} // namespace
+
 // Decodes d_in[n].  Returns an infrastructure status (BZ_OK, BZ_E_NOMEM, BZ_E_UNEXPECTED,
 // BZ_E_CAPACITY); the decoder's own verdict goes to *verdict (BZ_OK, BZ_E_DATA, BZ_E_MAGIC_FIRST,
 // BZ_E_MAGIC) and the bytes produced in front of it to sink.produced.
-static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int *verdict)
+static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int *verdict, Shard *sh = nullptr)
 {
     HIPDEC(hipSetDevice(g->device));
     if (!g->dec) g->dec = new DecWorkspace();
@@ -207,7 +231,14 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
         const long v = atol(e);
         if (v >= 1 && v <= 65536) walk_wgs = (u32)v;
     }
+    size_t c0 = 0, c1 = nc; // this rank's candidates
+    if (sh) {
+        c0 = nc * (size_t)sh->rank / (size_t)sh->world;
+        c1 = nc * (size_t)(sh->rank + 1) / (size_t)sh->world;
+        B = (u32)std::max<size_t>(c1 - c0, 1);
+    }
     if (nc < B) B = (u32)(nc ? nc : 1);
+    const u32 B_want = B;
     {
         // never plan for more than about half of the free HBM (the decoded bytes need room too)
         const size_t per_slot = sizeof(DecCand) + sizeof(DecBlockInfo) + (size_t)kMtfStride * 2 + 32768 + 8 +
@@ -220,15 +251,19 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             if (fit < (size_t)B + kForcedSlots) B = fit > kForcedSlots + 1 ? (u32)(fit - kForcedSlots) : 1u;
         }
     }
+    if (sh && B < B_want) return BZ_E_NOMEM; // a rank's share has to fit one batch
     {
         const int rc = dec_ensure(w, (size_t)B + kForcedSlots);
         if (rc) return rc;
     }
+    const u32 Bphys = B; // device slots
+    if (sh) B = (u32)(nc ? nc : 1); // the chain below sees all candidates as one batch
 
     DevBits rd;
     rd.d = d_in;
     rd.nbytes = n;
     std::vector<DecBlockInfo> hinfo((size_t)B + kForcedSlots);
+    std::vector<DecBlockInfo> hphys(sh ? (size_t)Bphys : 0);
 
     // BZip2DecoderBase state (decoder.rs:93-108) as far as the record chain needs it
     u64 pos = 0;
@@ -245,27 +280,58 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
         // ---- D1 over the next batch of candidates
         while (ci < nc && cands[ci].bitpos < pos) ++ci;
         const u32 nb1 = (u32)std::min<size_t>(B, nc - ci);
-        if (nb1) {
-            HIPDEC(hipMemcpyAsync(w->cands.p, cands.data() + ci, (size_t)nb1 * sizeof(DecCand), hipMemcpyHostToDevice, st));
+        const size_t d1_first = sh ? c0 : ci;
+        const u32 d1_count = sh ? (u32)(c1 - c0) : nb1;
+        DecBlockInfo *d1_host = sh ? hphys.data() : hinfo.data();
+        if (d1_count) {
+            HIPDEC(hipMemcpyAsync(w->cands.p, cands.data() + d1_first, (size_t)d1_count * sizeof(DecCand), hipMemcpyHostToDevice, st));
             HIPDEC(hipEventRecord(ev[0], st));
             const int prec = prof ? prof->begin(st, KID_DEC_BLOCK, 0) : -1;
-            launch_dec_blocks(st, d_in, n, w->cands.as<DecCand>(), nb1, w->info.as<DecBlockInfo>(), w->sym.as<u16>(),
+            launch_dec_blocks(st, d_in, n, w->cands.as<DecCand>(), d1_count, w->info.as<DecBlockInfo>(), w->sym.as<u16>(),
                               w->sel.as<u8>());
             if (prof) prof->end(st, prec);
             d1_rec = prec;
             HIPDEC(hipEventRecord(ev[1], st));
-            HIPDEC(hipMemcpyAsync(hinfo.data(), w->info.p, (size_t)nb1 * sizeof(DecBlockInfo), hipMemcpyDeviceToHost, st));
+            HIPDEC(hipMemcpyAsync(d1_host, w->info.p, (size_t)d1_count * sizeof(DecBlockInfo), hipMemcpyDeviceToHost, st));
             HIPDEC(hipStreamSynchronize(st));
             stage_time(0);
         }
-        // ---- the record chain through this batch
         if (d1_rec >= 0) { // algorithmic bytes of D1: the compressed bits of its candidates + 2 B per symbol
             u64 by = 0;
-            for (u32 i = 0; i < nb1; ++i)
-                by += (hinfo[i].end_bit > cands[ci + i].bitpos ? (hinfo[i].end_bit - cands[ci + i].bitpos) / 8 : 0) + 2ull * hinfo[i].nsym;
+            for (u32 i = 0; i < d1_count; ++i)
+                by += (d1_host[i].end_bit > cands[d1_first + i].bitpos ? (d1_host[i].end_bit - cands[d1_first + i].bitpos) / 8 : 0) +
+                      2ull * d1_host[i].nsym;
             prof->set_bytes(d1_rec, by);
             d1_rec = -1;
         }
+        if (sh) {
+            // exchange: every rank learns what the chain needs about every candidate
+            const size_t maxc = (nc + (size_t)sh->world - 1) / (size_t)sh->world;
+            std::vector<ShardRec> mine(maxc ? maxc : 1), all((maxc ? maxc : 1) * (size_t)sh->world);
+            memset(mine.data(), 0, mine.size() * sizeof(ShardRec));
+            for (size_t i = 0; i < c1 - c0; ++i) {
+                mine[i].end_bit = hphys[i].end_bit;
+                mine[i].status = hphys[i].status;
+                mine[i].stored_crc = hphys[i].stored_crc;
+                mine[i].next_head = hphys[i].next_head;
+                mine[i].next_bits = hphys[i].next_bits;
+            }
+            if (sh->allgather(sh->ctx, mine.data(), mine.size() * sizeof(ShardRec), all.data()) != 0) return BZ_E_UNEXPECTED;
+            for (int r = 0; r < sh->world; ++r) {
+                const size_t r0 = nc * (size_t)r / (size_t)sh->world, r1 = nc * (size_t)(r + 1) / (size_t)sh->world;
+                for (size_t i = r0; i < r1; ++i) {
+                    const ShardRec &s = all[(size_t)r * mine.size() + (i - r0)];
+                    DecBlockInfo &bi = hinfo[i];
+                    bi.end_bit = s.end_bit;
+                    bi.status = s.status;
+                    bi.stored_crc = s.stored_crc;
+                    bi.next_head = s.next_head;
+                    bi.next_bits = s.next_bits;
+                    bi.nsym = (i >= c0 && i < c1) ? hphys[i - c0].nsym : 0;
+                }
+            }
+        }
+        // ---- the record chain through this batch
         std::vector<u32> bslot, bmax, bcrc;
         u32 nforced = 0;
         int term = 0; // 0: batch ended, more to come; 1: end of input reached cleanly; <0: error
@@ -304,6 +370,7 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                     }
                 } else {
                     // only the first byte of the block magic is compared (decoder.rs:204-221): decode here
+                    if (sh) return BZ_E_UNEXPECTED; // (a sharded decode needs every block to carry its full magic)
                     if (nforced == kForcedSlots) {
                         stop = true;
                         break;
@@ -337,7 +404,7 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                 have_next = true;
                 next_head = bi.next_head;
                 next_bits = bi.next_bits;
-                if (bslot.size() >= (size_t)B) stop = true;
+                if (!sh && bslot.size() >= (size_t)B) stop = true; // (sharded: the chain is not batched)
             } else if (head == 0x17u) { // end of stream, decoder.rs:487-520
                 pos = p;
                 for (int k = 0; k < 5; ++k) (void)rd.read(pos, 8);
@@ -363,6 +430,24 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
         }
         if (rd.failed) return BZ_E_UNEXPECTED;
         ci = cj;
+        u64 my_first_ord = ~0ull; // stream ordinal of this rank's first block
+        const u64 n_true = bslot.size();
+        if (sh) {
+            std::vector<u32> ks, km, kc;
+            for (size_t i = 0; i < bslot.size(); ++i)
+                if (bslot[i] >= c0 && bslot[i] < c1) {
+                    if (my_first_ord == ~0ull) my_first_ord = i;
+                    ks.push_back((u32)(bslot[i] - c0));
+                    km.push_back(bmax[i]);
+                    kc.push_back(bcrc[i]);
+                }
+            bslot.swap(ks);
+            bmax.swap(km);
+            bcrc.swap(kc);
+        }
+        const std::vector<DecBlockInfo> &hslot = sh ? hphys : hinfo; // indexed by device slot
+        u64 local_fail = ~0ull; // index (in this rank's list) of its first failing block
+        int shard_rc = BZ_OK;   // an infrastructure error of this rank, told to the others
 
         // ---- D2..D4 for the true blocks of the batch
         const u32 nb = (u32)bslot.size();
@@ -419,7 +504,7 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             if (prof) { // algorithmic bytes per stage, now that symbol counts and block lengths are known
                 u64 nsym = 0, ntt = 0;
                 for (u32 i = 0; i < nb; ++i) {
-                    nsym += hinfo[bslot[i]].nsym;
+                    nsym += hslot[bslot[i]].nsym;
                     ntt += h_err[i] ? 0 : h_tt[i];
                 }
                 prof->set_bytes(mtf_rec, nsym * 4 + ntt);    // symbols read twice (2 B), column written
@@ -454,9 +539,13 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                     if (rc) return rc;
                     dst = sink.staging->as<u8>();
                 } else {
-                    if (sink.produced + bytes > sink.cap) return BZ_E_CAPACITY;
+                    if (sink.produced + bytes > sink.cap) {
+                        if (!sh) return BZ_E_CAPACITY;
+                        shard_rc = BZ_E_CAPACITY; // reported after the exchange: peers are waiting in it
+                    }
                     dst = sink.d_out + sink.produced;
                 }
+                if (shard_rc == BZ_OK) {
                 // blocks behind `good` keep err != 0 or are skipped by clearing their length
                 if (good < nb) {
                     std::vector<u32> ones(nb - good, 1u);
@@ -490,13 +579,45 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                     if (valid) HIPDEC(hipMemcpy(sink.host->data() + old, dst, valid, hipMemcpyDeviceToHost));
                 }
                 sink.produced += valid;
+                } // shard_rc == BZ_OK
             }
-            (void)keep;
-            if (crc_bad || good < nb) {
+            if (crc_bad) local_fail = keep - 1;
+            else if (good < nb) local_fail = good;
+            if (!sh && (crc_bad || good < nb)) {
                 *verdict = BZ_E_DATA;
                 finished = true;
                 continue;
             }
+        }
+        if (sh) {
+            // settle the verdict and the place of every slice
+            std::vector<ShardSum> sums((size_t)sh->world);
+            ShardSum mine;
+            mine.bytes = sink.produced;
+            mine.fail_ord = (local_fail == ~0ull) ? ~0ull : my_first_ord + local_fail;
+            mine.first_ord = my_first_ord;
+            mine.pad = (u64)(u32)(-shard_rc);
+            if (sh->allgather(sh->ctx, &mine, sizeof(mine), sums.data()) != 0) return BZ_E_UNEXPECTED;
+            for (const ShardSum &s : sums)
+                if (s.pad) return -(int)s.pad; // some rank could not hold its slice (BZ_E_CAPACITY ...)
+            u64 fail = ~0ull;
+            for (const ShardSum &s : sums) fail = std::min(fail, s.fail_ord);
+            u64 off = 0, tot = 0;
+            for (int r = 0; r < sh->world; ++r) {
+                // a rank whose blocks all lie behind the failing one contributes nothing
+                const u64 by = (sums[r].first_ord == ~0ull || sums[r].first_ord > fail) ? 0 : sums[r].bytes;
+                if (r < sh->rank) off += by;
+                if (r == sh->rank) sink.produced = by;
+                tot += by;
+            }
+            sh->out_offset = off;
+            sh->total_len = tot;
+            w->stats[1] = n_true;
+            w->stats[2] = stream_no;
+            if (fail != ~0ull) *verdict = BZ_E_DATA;
+            else if (term < 0) *verdict = term;
+            finished = true;
+            continue;
         }
         if (term == 1) {
             w->stats[2] = stream_no;
@@ -525,6 +646,30 @@ extern "C" int bz_gpu_decode_device(bz_gpu_engine *g, const void *d_in, size_t n
     int verdict = BZ_OK;
     const int rc = decode_core(g, static_cast<const u8 *>(d_in), n, sink, &verdict);
     *out_len = (size_t)sink.produced;
+    return rc != BZ_OK ? rc : verdict;
+}
+
+extern "C" int bz_gpu_decode_device_sharded(bz_gpu_engine *g, const void *d_in, size_t n, void *d_out, size_t cap,
+                                            int rank, int world, bz_allgather_fn allgather, void *ctx, size_t *out_len,
+                                            size_t *out_offset, size_t *total_len)
+{
+    if (!g || !out_len || !out_offset || !total_len || (!d_in && n) || !d_out || !allgather) return BZ_E_PARAM;
+    if (world < 1 || rank < 0 || rank >= world) return BZ_E_PARAM;
+    if (n && ((uintptr_t)d_in & 3u)) return BZ_E_PARAM;
+    *out_len = *out_offset = *total_len = 0;
+    Sink sink;
+    sink.d_out = static_cast<u8 *>(d_out);
+    sink.cap = cap;
+    Shard sh;
+    sh.rank = rank;
+    sh.world = world;
+    sh.allgather = allgather;
+    sh.ctx = ctx;
+    int verdict = BZ_OK;
+    const int rc = decode_core(g, static_cast<const u8 *>(d_in), n, sink, &verdict, &sh);
+    *out_len = (size_t)sink.produced;
+    *out_offset = (size_t)sh.out_offset;
+    *total_len = (size_t)sh.total_len;
     return rc != BZ_OK ? rc : verdict;
 }
 

@@ -105,3 +105,22 @@ def exchange(word_off, bit_len, crc, packed, words_used, rank, world, device, ga
         return gather_buf, woff, blen, crcs
     dist.gather(packed[:maxw], None, dst=0)
     return None
+
+
+def allgather_bytes(rank, world, dev):
+    """The one collective of the sharded decode (bz_gpu_decode_device_sharded): returns a function
+    send: bytes -> concatenation of every rank's bytes in rank order, over torch.distributed (RCCL
+    when the process group is "nccl": the few KB travel through a device tensor; gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+
+    def gather(send):
+        if world == 1:
+            return bytes(send)
+        t = torch.frombuffer(bytearray(send), dtype=torch.uint8)
+        if dev is not None and dev.type == "cuda":
+            t = t.to(dev)
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        return b"".join(bytes(o.cpu().numpy()) for o in outs)
+    return gather

@@ -275,3 +275,79 @@ def test_full_size_round_trip_on_device(pkg, eng):
             del tin, tz, tout
     finally:
         big.close()
+
+
+# ---- multi-GPU decode (bz_gpu_decode_device_sharded), emulated: one engine and one thread per rank on
+# ---- the same GPU, an in-process all-gather between them
+def _sharded_decode(pkg, z, world, cap_per_rank):
+    import threading
+    import torch
+    tin = torch.frombuffer(bytearray(z) + bytearray(64), dtype=torch.uint8).cuda()
+    box, barrier = [None] * world, threading.Barrier(world)
+    results, errors = [None] * world, []
+
+    def gather_for(rank):
+        def gather(send):
+            box[rank] = send
+            barrier.wait()
+            got = b"".join(box)
+            barrier.wait()
+            return got
+        return gather
+
+    def run(rank):
+        try:
+            e = pkg.GpuEngine(0, 16)
+            out = torch.zeros(cap_per_rank + 64, dtype=torch.uint8, device="cuda")
+            n, off, tot, verdict = e.decode_device_sharded(tin.data_ptr(), len(z), out.data_ptr(), cap_per_rank, rank, world,
+                                                           gather_for(rank))
+            results[rank] = (bytes(out[:n].cpu().numpy()), off, tot, verdict)
+            e.close()
+        except Exception as ex:  # keep the other threads from waiting forever
+            errors.append(ex)
+            barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    return results
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_decode_slices(pkg, oracle, world):
+    d = sample(1)[:98000] * 12 + b"k" * 150000 + sample(2)[:200000] * 3
+    z = bz2.compress(d, 1) + bz2.compress(b"second stream " * 1000, 2)  # ~18 blocks, two streams
+    want, st = oracle.decode(z)
+    assert st == 0
+    res = _sharded_decode(pkg, z, world, len(want))
+    assert all(r[3] == 0 and r[2] == len(want) for r in res)
+    assert b"".join(r[0] for r in res) == want
+    pos = 0
+    for piece, off, _, _ in res:  # slices are contiguous, in rank order
+        assert off == pos
+        pos += len(piece)
+
+
+def test_sharded_decode_errors(pkg, oracle):
+    d = sample(1)[:98000] * 10
+    z = bytearray(bz2.compress(d, 1))  # 10 blocks
+    # a bit flip in the middle of the file: the bytes in front of the failing block, then DataError
+    z[len(z) // 2] ^= 0x04
+    want, st = oracle.decode(bytes(z))
+    assert st == E_DATA
+    for world in (2, 4):
+        res = _sharded_decode(pkg, bytes(z), world, len(d))
+        assert all(r[3] == E_DATA and r[2] == len(want) for r in res)
+        assert b"".join(r[0] for r in res) == want
+    # trailing garbage: everything, then DataErrorMagic
+    z2 = bz2.compress(d, 1) + b"garbage!"
+    res = _sharded_decode(pkg, z2, 3, len(d))
+    assert all(r[3] == E_MAGIC for r in res) and b"".join(r[0] for r in res) == d
+    # a rank whose slice does not fit its buffer: every rank reports the capacity error
+    import threading
+    with pytest.raises(AssertionError) as ei:
+        _sharded_decode(pkg, bz2.compress(d, 1), 2, 1000)
+    assert "Capacity" in str(ei.value)

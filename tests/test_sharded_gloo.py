@@ -126,3 +126,40 @@ def test_split_helpers():
     spans = [sharded.slab_tiles(n, r, 3) for r in range(3)]
     assert spans[0][0] == 0 and spans[-1][1] == 11
     assert all(spans[i][1] == spans[i + 1][0] for i in range(2))
+
+
+def _allgather_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sharded = importlib.import_module("rust-compression_amd.sharded")
+        gather = sharded.allgather_bytes(rank, world, None)
+        # the two exchanges of the sharded decode: per-candidate records, then per-rank summaries
+        recs = bytes([rank + 1]) * 24 * 5
+        got = gather(recs)
+        ok = got == b"".join(bytes([r + 1]) * 24 * 5 for r in range(world))
+        summ = (rank * 1000 + 7).to_bytes(8, "little") * 4
+        got2 = gather(summ)
+        ok = ok and got2 == b"".join((r * 1000 + 7).to_bytes(8, "little") * 4 for r in range(world))
+        if rank == 0:
+            q.put(ok)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_decode_allgather_adapter(world):
+    """the collective behind bz_gpu_decode_device_sharded (sharded.allgather_bytes) over gloo"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_allgather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) is True
