@@ -328,7 +328,7 @@ void launch_dec_walks(hipStream_t st, const DecArgs &a, u32 walk_wgs, hipStream_
                       KernelProf *prof, int rec[4]);
 void launch_dec_expand(hipStream_t st, const DecArgs &a, const u64 *out_base, u8 *out);
 void launch_dec_crc(hipStream_t st, const DecArgs &a, const u64 *out_base, const u8 *out, u32 max_out_len,
-                    const u32 *crc_tab, const u32 *xp2);
+                    const u32 *crc_tab, const u32 *xp2, const u32 *xp16);
 
 // ---- per-kernel timing (HIP events on the launch stream) -------------------------------------------
 // Off by default.  When on, every launch of the listed kernels is bracketed by two events; the

@@ -557,7 +557,7 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                 launch_dec_expand(st, a, w->out_base.as<u64>(), dst);
                 if (prof) prof->end(st, xrec);
                 xrec = prof ? prof->begin(st, KID_DEC_CRC, bytes) : -1;
-                launch_dec_crc(st, a, w->out_base.as<u64>(), dst, max_len, g->crc_tab.as<u32>(), g->xp2.as<u32>());
+                launch_dec_crc(st, a, w->out_base.as<u64>(), dst, max_len, g->crc_tab.as<u32>(), g->xp2.as<u32>(), g->xp16.as<u32>());
                 if (prof) prof->end(st, xrec);
                 HIPDEC(hipEventRecord(ev[1], st));
                 std::vector<u32> h_crc(nb);

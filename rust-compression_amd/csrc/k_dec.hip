@@ -1337,34 +1337,82 @@ __global__ __launch_bounds__(kSortThreads) void k_dec_tscatter(DecArgs a)
     }
 }
 
-// ---- D4b: CRC of every block's output (crc32.rs:116-131), in 64 KiB slices folded with x^(8 * bytes after)
+// ---- D4b: CRC of every block's output (crc32.rs:116-131) ------------------------------------------------
+// Lanes read consecutive 16-byte pieces (aligned in memory, so the first piece may begin in front of
+// the block: those bytes are fed as zeros, which a CRC register that starts at zero ignores).  A
+// piece's CRC is moved to the end of its 4 KiB tile with the x^(128 k) table, tiles are chained with
+// x^(8*4096), and the slice (64 KiB per workgroup) is moved to the end of the block once.
 __global__ __launch_bounds__(256) void k_dec_crc(DecArgs a, const u64 *__restrict__ out_base,
                                                  const u8 *__restrict__ out, const u32 *__restrict__ crc_tab,
-                                                 const u32 *__restrict__ xp2)
+                                                 const u32 *__restrict__ xp2, const u32 *__restrict__ xp16)
 {
     __shared__ u32 s_tab[256];
     __shared__ u32 s_x[4];
+    __shared__ u32 s_tile[16];
     const u32 lb = blockIdx.y;
     if (a.err[lb]) return;
     const u64 len = a.out_len[lb];
-    const u64 s0 = (u64)blockIdx.x * 65536ull;
-    if (s0 >= len && !(blockIdx.x == 0)) return;
+    const uintptr_t A = reinterpret_cast<uintptr_t>(out + out_base[lb]); // first byte of the block
+    const uintptr_t a0 = A & ~(uintptr_t)15;
+    const u64 R = (u64)(A - a0) + len;  // bytes from the aligned start to the end of the block
+    const u64 npieces = (R + 15) / 16;  // the last one may be partial
+    const u64 p0 = (u64)blockIdx.x * 4096ull; // first piece of this workgroup's slice
+    if (p0 >= npieces && blockIdx.x != 0) return;
     s_tab[threadIdx.x] = crc_tab[threadIdx.x];
     __syncthreads();
-    const u8 *p = out + out_base[lb];
-    const u64 b0 = s0 + (u64)threadIdx.x * 256ull;
-    u32 acc = 0;
-    if (b0 < len) {
-        const u64 b1 = (b0 + 256ull < len) ? b0 + 256ull : len;
-        const u32 c = crc_bytes_raw(p + b0, b1 - b0, s_tab);
-        acc = gf_mulmod(c, gf_xpow_bytes(len - b1, xp2));
+    const u32 t = threadIdx.x;
+    for (u32 tile = 0; tile < 16; ++tile) {
+        const u64 i = p0 + tile * 256ull + t;
+        u32 c = 0;
+        if (i < npieces) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(a0 + i * 16);
+            const u32 wv[4] = {q.x, q.y, q.z, q.w};
+            const u64 pbeg = i * 16, pend = (pbeg + 16 < R) ? pbeg + 16 : R; // relative to a0
+            const u32 lo = (i == 0) ? (u32)(A - a0) : 0u, hi = (u32)(pend - pbeg);
+#pragma unroll
+            for (u32 k = 0; k < 16; ++k) {
+                if (k < hi) {
+                    const u32 b = (k >= lo) ? ((wv[k >> 2] >> ((k & 3) * 8)) & 0xFFu) : 0u;
+                    c = s_tab[(c >> 24) ^ b] ^ (c << 8);
+                }
+            }
+            // to the end of the tile (or, in the last tile of the block, to the end of the block)
+            const u64 tile_last = p0 + tile * 256ull + 255ull;            // last piece of a full tile
+            const u64 last = tile_last < npieces - 1 ? tile_last : npieces - 1; // last piece of this tile
+            if (pend == R) {
+                // (the block's last piece: nothing behind it)
+            } else if (last == npieces - 1 && (R & 15u)) {
+                // pieces in front of a ragged last piece: x^(128 * pieces between) * x^(8 * its bytes)
+                c = gf_mulmod(c, xp16[(u32)(last - 1 - i)]);
+                c = gf_mulmod(c, gf_xpow_bytes(R & 15u, xp2));
+            } else {
+                c = gf_mulmod(c, xp16[(u32)(last - i)]);
+            }
+        }
+        const u32 wx = wave_xor(c);
+        if (lane_id() == 0) s_x[t >> 6] = wx;
+        __syncthreads();
+        if (t == 0) s_tile[tile] = s_x[0] ^ s_x[1] ^ s_x[2] ^ s_x[3];
+        __syncthreads();
     }
-    // the initial 0xFFFFFFFF rides through the whole message
-    if (blockIdx.x == 0 && threadIdx.x == 0) acc ^= gf_mulmod(0xFFFFFFFFu, gf_xpow_bytes(len, xp2));
-    const u32 wx = wave_xor(acc);
-    if (lane_id() == 0) s_x[threadIdx.x >> 6] = wx;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicXor(&a.crc[lb], s_x[0] ^ s_x[1] ^ s_x[2] ^ s_x[3]); // (host applies the final NOT)
+    if (t == 0) {
+        // chain the tiles of the slice, then move the slice to the end of the block
+        u32 acc = 0;
+        u64 end_piece = 0; // one past the last piece covered so far
+        for (u32 tile = 0; tile < 16; ++tile) {
+            const u64 first = p0 + tile * 256ull;
+            if (first >= npieces) break;
+            const u64 lastp = (first + 255ull < npieces - 1) ? first + 255ull : npieces - 1;
+            // bytes this tile's result covers = up to the end of piece `lastp` (the block's end in the last tile)
+            const u64 cover_beg = first * 16, cover_end = (lastp == npieces - 1) ? R : (lastp + 1) * 16;
+            acc = gf_mulmod(acc, gf_xpow_bytes(cover_end - cover_beg, xp2)) ^ s_tile[tile];
+            end_piece = cover_end;
+        }
+        if (npieces) acc = gf_mulmod(acc, gf_xpow_bytes(R - end_piece, xp2));
+        // the initial 0xFFFFFFFF rides through the whole message
+        if (blockIdx.x == 0) acc ^= gf_mulmod(0xFFFFFFFFu, gf_xpow_bytes(len, xp2));
+        atomicXor(&a.crc[lb], acc); // (host applies the final NOT)
+    }
 }
 
 // ---- launchers --------------------------------------------------------------------------------------------------
@@ -1431,11 +1479,11 @@ void launch_dec_expand(hipStream_t st, const DecArgs &a, const u64 *out_base, u8
 }
 
 void launch_dec_crc(hipStream_t st, const DecArgs &a, const u64 *out_base, const u8 *out, u32 max_out_len,
-                    const u32 *crc_tab, const u32 *xp2)
+                    const u32 *crc_tab, const u32 *xp2, const u32 *xp16)
 {
     (void)hipMemsetAsync(a.crc, 0, (size_t)a.nb * 4u, st);
-    const u32 slices = max_out_len ? (max_out_len + 65535u) / 65536u : 1u;
-    hipLaunchKernelGGL(k_dec_crc, dim3(slices, a.nb), dim3(256), 0, st, a, out_base, out, crc_tab, xp2);
+    const u32 slices = (max_out_len + 15u + 65535u) / 65536u + 1u; // (+15: the aligned start may lie in front of the block)
+    hipLaunchKernelGGL(k_dec_crc, dim3(slices, a.nb), dim3(256), 0, st, a, out_base, out, crc_tab, xp2, xp16);
 }
 
 } // namespace bzgpu
