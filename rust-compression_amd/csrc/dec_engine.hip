@@ -19,10 +19,6 @@ namespace {
 
 constexpr u32 kForcedSlots = 16; // blocks per batch that start without a full 48-bit magic
 
-struct Ev {
-    hipEvent_t a = nullptr, b = nullptr;
-};
-
 } // namespace
 
 struct DecWorkspace {

@@ -7,19 +7,21 @@
 // A .bz2 stream is serial in two ways: blocks are not byte aligned and end where their Huffman
 // data ends, and inside a block Huffman decode, inverse MTF and the inverse BWT pointer chase are
 // recurrences.  What is done about each:
-//   D0  every bit position is tested for the 48-bit block / end-of-stream magic (one thread per
-//       input byte, 8 shifts): candidates.  D1 decodes ALL candidates in parallel (one workgroup
-//       each, one lane walks the bits, the others build the 12-bit lookup tables); the host then
-//       links true blocks (start == previous end) and drops the false positives.
+//   D0  every bit position is tested for the 48-bit block magic (one thread per input byte, 8
+//       shifts): candidates.  D1 decodes ALL candidates in parallel (one 256-thread workgroup each:
+//       256 candidate code starts per round, pointer doubling in LDS, the r-th true start in at most
+//       six dependent reads); the host then links true blocks (start == previous end) and drops
+//       the false positives.
 //   D2  RUNA/RUNB runs and inverse MTF: the effect of a 512-symbol chunk on the MTF list is a
 //       permutation of list positions, independent of the list's content; per-chunk permutations
 //       are composed left to right, then every chunk is replayed by one lane.
-//   D3  T vector = stable counting sort of positions by byte (the radix kernels of k_bwt.hip with
-//       an 8-bit digit); the n-step pointer chase is cut at sample nodes (every 1024th index):
-//       all segments are walked in parallel, the ~900 samples are ranked serially, and a second
-//       parallel walk writes the bytes at their final offsets.
-//   D4  RLE1 undo: one lane per block finds the state at every 1024-byte tile start, then all tiles
-//       expand in parallel; block CRCs reuse the encoder's tile-CRC + GF(2) fold kernels.
+//   D3  T vector = stable counting sort of positions by byte (the radix-pass shape of k_bwt.hip with
+//       an 8-bit digit); the n-step pointer chase is cut at sample nodes (every 128th index): all
+//       segments are walked once in parallel by persistent work-stealing lanes that keep the bytes
+//       they pass, the ~7000 samples are ranked serially in LDS, and the kept bytes are copied to
+//       their final offsets.
+//   D4  RLE1 undo as function composition over 64-byte sub-tiles; block CRCs from coalesced 16-byte
+//       pieces folded in GF(2).
 #include "bzgpu.h"
 #include "bz2_rnums.h"
 
@@ -119,39 +121,6 @@ constexpr u32 kLutBits = BZ_DEC_LUT_BITS;
 constexpr u16 kLutLong = 0xFFFE, kLutBad = 0xFFFF;
 constexpr u32 kRingWords = 256;  // staged input window (words), power of two
 constexpr u32 kOutBuf = 1024;    // staged output symbols
-
-// bit cursor over the staged window (same arithmetic as BitCur; the words come from LDS)
-struct RingCur {
-    const u32 *ring;
-    u64 widx;
-    u64 buf;
-    int cnt;
-    __device__ __forceinline__ void seek(u64 bitpos)
-    {
-        widx = bitpos >> 5;
-        const u32 sh = (u32)bitpos & 31u;
-        const u32 x = ring[widx & (kRingWords - 1)];
-        ++widx;
-        buf = (u64)x << (32u + sh);
-        cnt = 32 - (int)sh;
-    }
-    __device__ __forceinline__ void fill()
-    {
-        if (cnt <= 32) {
-            const u32 x = ring[widx & (kRingWords - 1)];
-            ++widx;
-            buf |= (u64)x << (32 - cnt);
-            cnt += 32;
-        }
-    }
-    __device__ __forceinline__ u32 peek(u32 n) { return n ? (u32)(buf >> (64u - n)) : 0u; }
-    __device__ __forceinline__ void skip(u32 n)
-    {
-        buf <<= n;
-        cnt -= (int)n;
-    }
-    __device__ __forceinline__ u64 pos() const { return widx * 32ull - (u64)cnt; }
-};
 
 // ---- D1: header + Huffman decode of one candidate -------------------------------------------------------
 // One workgroup of four waves per candidate.  Thread 0 parses the header; all threads build the
