@@ -196,7 +196,8 @@ class Encoder:
     def encode_iter(self, data: bytes, action) -> bytes:
         """`data.encode(&mut self, action).collect()` (drains until None)."""
         data = bytes(data)
-        cap = lib().bzo_encode_bound(len(data)) + 64
+        # (bytes pending from earlier calls -- up to a level-9 block -- may come out in this one)
+        cap = lib().bzo_encode_bound(len(data) + 2000000) + 64
         out = (C.c_uint8 * cap)()
         r = lib().bzo_enc_encode_iter(self._h, data, len(data), action, out, cap)
         if r < 0:

@@ -15,6 +15,7 @@ from oracle import oracle
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+flavour = sys.argv[3] if len(sys.argv) > 3 else "small"   # small | big | stream
 rng = random.Random(seed)
 
 
@@ -54,11 +55,51 @@ def gen():
     return bytes(rng.randrange(256) for _ in range(min(n, 20000)))
 
 
+def big():
+    """multi-block inputs (level 9 blocks are 900 kB): a few MB assembled from the generators"""
+    parts = []
+    want = rng.choice([900000, 1800010, 2500000, 3600000])
+    while sum(map(len, parts)) < want:
+        p = gen()
+        parts.append(p * rng.choice([1, 1, 3, 10]) if len(p) < 300000 else p)
+    return b"".join(parts)[:want + rng.randrange(-20, 20)]
+
+
+def stream_case():
+    """the streaming context: random write / Action sequences against the oracle's BZip2Encoder mirror"""
+    lvl = rng.choice([1, 1, 2, 9])
+    enc, ora = pkg.BZip2Encoder(lvl), oracle.Encoder(lvl)
+    d = gen() + gen()
+    pos = 0
+    while pos < len(d):
+        step = rng.choice([1, 7, 1000, 50000, 99981, 150000])
+        act = rng.choice([pkg.Action.RUN, pkg.Action.RUN, pkg.Action.FLUSH])
+        piece = d[pos:pos + step]
+        pos += step
+        if enc.encode_all(piece, act) != ora.encode_iter(piece, int(act)):
+            return False
+    last = rng.choice([pkg.Action.FINISH, pkg.Action.FINISH, pkg.Action.FLUSH])
+    return enc.encode_all(b"", last) == ora.encode_iter(b"", int(last))
+
+
 t0 = time.time()
 cases = enc_ok = dec_ok = 0
+while flavour == "stream" and time.time() - t0 < budget:
+    cases += 1
+    if not stream_case():
+        print("STREAM MISMATCH seed", seed, "case", cases)
+        sys.exit(1)
+if flavour == "stream":
+    print("fuzz ok: %d streaming sequences in %.0f s (seed %d)" % (cases, time.time() - t0, seed))
+    sys.exit(0)
+if flavour == "big":
+    _small = gen
+    gen_case = big
+else:
+    gen_case = gen
 while time.time() - t0 < budget:
-    d = gen()
-    lvl = rng.choice([1, 1, 1, 2, 9])
+    d = gen_case()
+    lvl = rng.choice([1, 1, 1, 2, 9]) if flavour == "small" else rng.choice([9, 9, 5])
     cases += 1
     want = oracle.encode(d, lvl)
     got = pkg.compress(d, lvl)
