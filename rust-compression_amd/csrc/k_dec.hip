@@ -820,7 +820,9 @@ __global__ __launch_bounds__(256) void k_dec_walk_lengths(DecArgs a)
 // order of the samples along the chain: one wave per block, the chain itself in LDS
 __global__ __launch_bounds__(64) void k_dec_rank_samples(DecArgs a)
 {
-    __shared__ u32 s_len[kDecSamples];
+    // 16-bit copies of the segment lengths (the rare longer one is fetched from memory): 29 KB of LDS
+    // per block instead of 43, so that all blocks of a 1 GiB file are resident at once
+    __shared__ u16 s_len[kDecSamples];
     __shared__ u16 s_next[kDecSamples];
     __shared__ u32 s_seen[(kDecSamples + 31) / 32];
     const u32 lb = blockIdx.x, l = threadIdx.x;
@@ -830,8 +832,9 @@ __global__ __launch_bounds__(64) void k_dec_rank_samples(DecArgs a)
     for (u32 i = l; i < kDecSamples; i += 64) {
         const bool live = (i == kDecSamples - 1u) || (i * kDecSampleStep < n);
         const u32 nx = live ? a.samp_next[base + i] : 0xFFFFFFFFu;
+        const u32 ln = live ? a.samp_len[base + i] : 0u;
         s_next[i] = nx < kDecSamples ? (u16)nx : (u16)0xFFFFu;
-        s_len[i] = live ? a.samp_len[base + i] : 0u;
+        s_len[i] = ln < 0xFFFFu ? (u16)ln : (u16)0xFFFFu;
         a.samp_off[base + i] = 0xFFFFFFFFu;
     }
     for (u32 i = l; i < (kDecSamples + 31) / 32; i += 64) s_seen[i] = 0;
@@ -846,7 +849,8 @@ __global__ __launch_bounds__(64) void k_dec_rank_samples(DecArgs a)
             }
             s_seen[s >> 5] |= 1u << (s & 31u);
             a.samp_off[base + s] = o;
-            o += s_len[s];
+            const u32 ln = s_len[s];
+            o += (ln == 0xFFFFu) ? a.samp_len[base + s] : ln;
             s = s_next[s];
             if (s >= kDecSamples) break;
         }
@@ -854,27 +858,43 @@ __global__ __launch_bounds__(64) void k_dec_rank_samples(DecArgs a)
     }
 }
 
-// Copy: the scratch rows go to their places in the RLE1 image, one wave per segment.
+// Copy: the scratch rows go to their places in the RLE1 image.  Sixteen lanes per segment (a row is
+// 128 bytes on average); aligned dword stores built from two aligned source dwords, single bytes
+// only at the ragged ends.
 __global__ __launch_bounds__(256) void k_dec_seg_copy(DecArgs a)
 {
     const u32 lb = blockIdx.y;
     const uint4 m = a.walk_meta[lb];
     if (!m.x) return;
     const u32 n = m.x;
-    const u32 sid = blockIdx.x * 4u + (threadIdx.x >> 6), l = threadIdx.x & 63u;
+    const u32 sid = blockIdx.x * 16u + (threadIdx.x >> 4), sl = threadIdx.x & 15u;
     if (sid >= kDecSamples) return;
     const u32 id = lb * kDecSamples + sid;
     const u32 o0 = a.samp_off[id];
     if (o0 == 0xFFFFFFFFu) return;
     u8 *X = a.X + (size_t)lb * kSlot;
-    if (sid == kDecSamples - 1u && l == 0) X[0] = (u8)m.z; // tt[orig_pos] & 0xFF is the first byte (decoder.rs:476)
+    if (sid == kDecSamples - 1u && sl == 0) X[0] = (u8)m.z; // tt[orig_pos] & 0xFF is the first byte (decoder.rs:476)
     const u32 len = a.samp_len[id];
-    const u32 cnt = len < kSegCap ? len : kSegCap;
+    u32 cnt = len < kSegCap ? len : kSegCap;
+    const u32 o = o0 + 1u;
+    if (o >= n) return;
+    if (o + cnt > n) cnt = n - o;
     const u8 *row = a.seg_buf + (size_t)id * kSegCap;
-    for (u32 k = l; k < cnt; k += 64u) {
-        const u32 o = o0 + 1u + k;
-        if (o < n) X[o] = row[k];
+    const u32 *rdw = reinterpret_cast<const u32 *>(row);
+    u8 *dst = X + o;
+    u32 head = (4u - (u32)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u;
+    if (head > cnt) head = cnt;
+    if (sl < head) dst[sl] = row[sl];
+    const u32 nd = (cnt - head) >> 2;
+    u32 *ddw = reinterpret_cast<u32 *>(dst + head);
+    const u32 sh = (head & 3u) * 8u;
+    for (u32 j = sl; j < nd; j += 16u) {
+        const u32 si = (head >> 2) + j; // (head < 4: source dword j, shifted by head bytes)
+        const u32 lo = rdw[si], hi = rdw[si + 1u];
+        ddw[j] = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
     }
+    const u32 done = head + nd * 4u;
+    if (sl < cnt - done) dst[done + sl] = row[done + sl];
 }
 
 // Walk 2: only what the scratch rows could not hold (the few segments longer than kSegCap, listed by
@@ -1432,7 +1452,7 @@ void launch_dec_walks(hipStream_t st, const DecArgs &a, u32 walk_wgs, hipStream_
     (void)hipStreamWaitEvent(st2, ev_a, 0);
     hipLaunchKernelGGL(k_dec_walk_write, dim3(wgs), dim3(256), 0, st2, a);
     (void)hipEventRecord(ev_b, st2);
-    hipLaunchKernelGGL(k_dec_seg_copy, dim3((kDecSamples + 3) / 4, a.nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_dec_seg_copy, dim3((kDecSamples + 15) / 16, a.nb), dim3(256), 0, st, a);
     (void)hipStreamWaitEvent(st, ev_b, 0);
     hipLaunchKernelGGL(k_dec_fixups, dim3(a.nb), dim3(256), 0, st, a);
     if (prof) prof->end(st, rec[2]);
