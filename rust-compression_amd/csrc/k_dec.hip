@@ -199,17 +199,16 @@ __global__ __launch_bounds__(kD1Threads) void k_dec_block(const u8 *__restrict__
                 n_selectors = bc.read(15);
                 if (n_selectors < 1) status = BZ_DEC_E_DATA;            // :290-292
             }
-            if (!status) { // selectors: unary MTF positions (:294-316)
+            if (!status) { // selectors: unary MTF positions (:294-316); a whole unary code per step
                 u32 lst = 0x543210u;
-                for (u32 s = 0; s < n_selectors && !status; ++s) {
-                    u32 j = 0;
-                    while (bc.read(1) != 0) {
-                        if (++j >= n_groups) {
-                            status = BZ_DEC_E_DATA;
-                            break;
-                        }
+                for (u32 s = 0; s < n_selectors; ++s) {
+                    bc.fill();
+                    const u32 j = (u32)__builtin_clz(~bc.peek(32) | 1u); // leading one bits (at most 31 counted)
+                    if (j >= n_groups) { // the reference gives up at the n_groups-th one bit
+                        status = BZ_DEC_E_DATA;
+                        break;
                     }
-                    if (status) break;
+                    bc.skip(j + 1u);
                     const u32 v = (lst >> (4u * j)) & 15u;
                     if (j) {
                         const u32 lowmask = (1u << (4u * j)) - 1u;
@@ -218,16 +217,23 @@ __global__ __launch_bounds__(kD1Threads) void k_dec_block(const u8 *__restrict__
                     sel[s] = (u8)v;
                 }
             }
-            if (!status) { // coding tables (:318-348)
+            if (!status) { // coding tables (:318-348); "10" = +1, "11" = -1, "0" = next symbol
                 for (u32 t = 0; t < n_groups && !status; ++t) {
                     u32 curr = bc.read(5);
                     for (u32 i = 0; i < alpha && !status; ++i) {
-                        while (bc.read(1) != 0) {
+                        while (true) {
+                            bc.fill();
+                            const u32 two = bc.peek(2);
+                            if ((two & 2u) == 0) {
+                                bc.skip(1);
+                                break;
+                            }
                             if (curr < 1 || curr > 20) {
                                 status = BZ_DEC_E_DATA;
                                 break;
                             }
-                            if (bc.read(1) == 0) curr += 1; else curr -= 1;
+                            curr += (two & 1u) ? 0xFFFFFFFFu : 1u;
+                            bc.skip(2);
                         }
                         s_len[t][i] = (u8)curr;
                     }
