@@ -267,9 +267,14 @@ int bz_decode_buffer(int device, const uint8_t *in, size_t in_len,
 
 /* Streaming context == BZip2Decoder as the DecodeIterator drives it
  * (src/traits/decoder.rs:73-86): compressed bytes in (bz_dec_write), end of
- * the input iterator (bz_dec_end: decodes, returns the verdict), decoded bytes
- * out in order (bz_dec_read: > 0 bytes copied; when nothing is left, the
- * verdict -- 0 = `None`, negative = the `Err` item). */
+ * the input iterator (bz_dec_end: returns the verdict), decoded bytes out in
+ * order (bz_dec_read: > 0 bytes copied; 0 = nothing ready yet; once the verdict
+ * is final and nothing is left, the verdict -- 0 = `None`, negative = the `Err`
+ * item).  Decoding is incremental: whenever BZ_DEC_CHUNK bytes (environment,
+ * default 256 MiB) have been written, the records that are wholly there are
+ * decoded and queued, and the chain state (bit position, stream number, level,
+ * combined CRC) is carried to the next call; bz_dec_end decodes the rest.  The
+ * reference decodes lazily block by block -- same items, coarser moments. */
 typedef struct bz_dec bz_dec;
 int bz_dec_create(bz_dec **out, int device);        /* BZip2Decoder::new, src/bzip2/decoder.rs:588-594 */
 int bz_dec_write(bz_dec *d, const uint8_t *data, size_t n);

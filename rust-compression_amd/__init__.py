@@ -294,7 +294,11 @@ _DECODER_VERDICTS = (BZ_E_DATA, BZ_E_MAGIC_FIRST, BZ_E_MAGIC)
 
 
 class BZip2Decoder:
-    """`BZip2Decoder` (src/bzip2/decoder.rs:583-612) over the C ABI's streaming context."""
+    """`BZip2Decoder` (src/bzip2/decoder.rs:583-612) over the C ABI's streaming context.  Input is
+    handed over in chunks; the library decodes whatever records are complete once BZ_DEC_CHUNK bytes
+    have come in and at the end, so bytes come out before the input is exhausted for long inputs."""
+
+    CHUNK = 1 << 20  # bytes pulled from the input iterator per refill
 
     def __init__(self, device=0):
         self._h = C.c_void_p()
@@ -310,7 +314,7 @@ class BZip2Decoder:
             self._h = None
 
     def _refill(self):
-        """bytes fetched, or 0 at the clean end; raises the decoder's Err item"""
+        """bytes fetched; 0 = nothing ready (or, after the end, the clean end); raises the decoder's Err item"""
         k = lib().bz_dec_read(self._h, self._buf, len(self._buf))
         if k < 0:
             raise BZip2Error(k) if k in _DECODER_VERDICTS else CompressionError(k)
@@ -323,29 +327,36 @@ class BZip2Decoder:
             self._ended = True
             rc = lib().bz_dec_end(self._h)
             if rc != BZ_OK and rc not in _DECODER_VERDICTS:
-                raise CompressionError(rc)  # infrastructure (no GPU, memory ...): nothing was decoded
+                raise CompressionError(rc)  # infrastructure (no GPU, memory ...)
 
     def next(self, it):
         """One `Decoder::next(iter)` call: an int byte, None at the end, raises BZip2Error for Err."""
-        if self._pos >= len(self._ready):
-            if not self._ended:
-                chunk = bytes(bytearray(it))  # the reference pulls bytes on demand; the bytes are the same
-                if chunk:
-                    _check(lib().bz_dec_write(self._h, chunk, len(chunk)))
-                self._end()
-            if self._refill() == 0:
+        while self._pos >= len(self._ready):
+            if self._refill():
+                break
+            if self._ended:
                 return None
+            chunk = bytearray()
+            for b in it:  # (the reference pulls bytes on demand; the bytes are the same)
+                chunk.append(b)
+                if len(chunk) >= self.CHUNK:
+                    break
+            if chunk:
+                _check(lib().bz_dec_write(self._h, bytes(chunk), len(chunk)))
+            if len(chunk) < self.CHUNK:
+                self._end()
         b = self._ready[self._pos]
         self._pos += 1
         return b
 
-    def decode_all(self, data):
-        """`data.decode(&mut self).collect::<Result<Vec<_>, _>>()`; BZip2Error.partial holds the bytes
-        yielded before an Err."""
+    # bulk helpers (same semantics, fewer Python-level calls)
+    def write(self, data):
         data = bytes(data)
         if data:
             _check(lib().bz_dec_write(self._h, data, len(data)))
-        self._end()
+
+    def read_available(self):
+        """decoded bytes that are ready now (raises the Err item once the bytes in front of it are out)"""
         out = bytearray(self._ready[self._pos:])
         self._ready, self._pos = b"", 0
         while True:
@@ -358,6 +369,13 @@ class BZip2Decoder:
             out += self._ready
             self._ready, self._pos = b"", 0
         return bytes(out)
+
+    def decode_all(self, data):
+        """`data.decode(&mut self).collect::<Result<Vec<_>, _>>()`; BZip2Error.partial holds the bytes
+        yielded before an Err."""
+        self.write(data)
+        self._end()
+        return self.read_available()
 
 
 def decode(iterable, decoder):

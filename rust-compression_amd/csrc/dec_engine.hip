@@ -145,6 +145,17 @@ struct ShardSum { // one rank's result
     u64 first_ord;  // ordinal of its first block (~0: it owns none)
     u64 pad;
 };
+// Incremental decode (the streaming context): the chain's state between two calls, and whether
+// more input may follow.  A call that is not the last one stops in front of the first record it
+// cannot be sure about (not wholly inside the bytes it has, or failing -- which near the end of a
+// buffer may just mean "cut off"); the caller keeps the input from `pos` on and calls again.
+struct Resume {
+    u64 pos = 0; // bit position of the next record (in: inside the buffer handed in; out: likewise)
+    u32 stream_no = 1, level = 0, combined = 0;
+    bool need_header = true;
+    bool final = true;    // no more input will come
+    bool stopped = false; // out: stopped in front of an unsure record, nothing wrong so far
+};
 struct Shard {
     int rank = 0, world = 1;
     bz_allgather_fn allgather = nullptr;
@@ -156,7 +167,8 @@ struct Shard {
 // Decodes d_in[n].  Returns an infrastructure status (BZ_OK, BZ_E_NOMEM, BZ_E_UNEXPECTED,
 // BZ_E_CAPACITY); the decoder's own verdict goes to *verdict (BZ_OK, BZ_E_DATA, BZ_E_MAGIC_FIRST,
 // BZ_E_MAGIC) and the bytes produced in front of it to sink.produced.
-static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int *verdict, Shard *sh = nullptr)
+static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int *verdict, Shard *sh = nullptr,
+                       Resume *rs = nullptr)
 {
     HIPDEC(hipSetDevice(g->device));
     if (!g->dec) g->dec = new DecWorkspace();
@@ -262,11 +274,17 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
     std::vector<DecBlockInfo> hphys(sh ? (size_t)Bphys : 0);
 
     // BZip2DecoderBase state (decoder.rs:93-108) as far as the record chain needs it
-    u64 pos = 0;
-    u32 stream_no = 1, level = 0, combined = 0;
+    u64 pos = rs ? rs->pos : 0;
+    u32 stream_no = rs ? rs->stream_no : 1, level = rs ? rs->level : 0, combined = rs ? rs->combined : 0;
     KernelProf *prof = g->prof.on ? &g->prof : nullptr;
     int d1_rec = -1;
-    bool need_header = true;
+    bool need_header = rs ? rs->need_header : true;
+    const bool partial = rs && !rs->final; // more input may follow: do not judge what is near the end
+    if (rs) rs->stopped = false;
+    // state at the start of the record being looked at (what a partial call falls back to)
+    u64 rec_pos = pos;
+    u32 rec_combined = combined, rec_stream_no = stream_no;
+    bool rec_need_header = need_header;
     bool have_next = false;
     u32 next_head = 0, next_bits = 0;
     size_t ci = 0;
@@ -334,6 +352,14 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
         size_t cj = ci;
         bool stop = false;
         while (!stop) {
+            rec_pos = pos;
+            rec_combined = combined;
+            rec_stream_no = stream_no;
+            rec_need_header = need_header;
+            if (partial && nbits - pos < 256) { // a header, a trailer or a block start may be cut off here
+                term = 2;
+                break;
+            }
             if (need_header) { // decoder.rs:171-187: 'B','Z','h' are read, not compared; the level digit is
                 (void)rd.read(pos, 8);
                 (void)rd.read(pos, 8);
@@ -388,6 +414,10 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                     w->stats[3] += 1;
                 }
                 const DecBlockInfo &bi = hinfo[slot];
+                if (partial && (bi.status || bi.end_bit + 64 > nbits)) { // cut off, perhaps: look again with more input
+                    term = 2;
+                    break;
+                }
                 if (bi.status) {
                     term = BZ_E_DATA;
                     break;
@@ -615,7 +645,14 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             finished = true;
             continue;
         }
-        if (term == 1) {
+        if (term == 2) { // (partial) stopped in front of a record: everything before it is decoded
+            rs->stopped = true;
+            pos = rec_pos;
+            combined = rec_combined;
+            stream_no = rec_stream_no;
+            need_header = rec_need_header;
+            finished = true;
+        } else if (term == 1) {
             w->stats[2] = stream_no;
             finished = true;
         } else if (term < 0) {
@@ -625,6 +662,13 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
         }
     }
     if (prof) prof->collect();
+    if (rs) {
+        rs->pos = pos;
+        rs->stream_no = stream_no;
+        rs->level = level;
+        rs->combined = combined;
+        rs->need_header = need_header;
+    }
     return BZ_OK;
 }
 
@@ -726,18 +770,67 @@ extern "C" int bz_decode_buffer(int device, const uint8_t *in, size_t in_len, ui
 }
 
 // ---- streaming mirror of BZip2Decoder (decoder.rs:583-612) ------------------------------------------------
-// The reference pulls input bytes on demand and yields output bytes one by one.  Here the
-// compressed bytes are collected (bz_dec_write), decoded in one go when the input ends
-// (bz_dec_end), and handed out in order (bz_dec_read); an error, if any, is reported after the
-// bytes in front of it -- the same sequence of items the reference's iterator produces.
+// The reference pulls input bytes on demand and yields output bytes one by one.  Here compressed
+// bytes are collected (bz_dec_write); whenever BZ_DEC_CHUNK bytes (default 256 MiB) have come in,
+// and when the input ends (bz_dec_end), the records that are wholly there are decoded and their
+// bytes queued (bz_dec_read).  The chain's state (bit position, stream number, level, combined
+// CRC) is carried between the calls, the bytes from the first undecided record on are kept.  An
+// error, if any, is reported after the bytes in front of it -- the same sequence of items the
+// reference's iterator produces; memory is bounded by the chunk, not by the file.
 struct bz_dec {
     int device = 0;
-    std::vector<u8> in;
-    uint8_t *out = nullptr;
-    size_t out_len = 0, out_pos = 0;
-    bool ended = false;
+    bz_gpu_engine *g = nullptr;
+    std::vector<u8> in;  // compressed bytes from the next record on
+    Resume rs;
+    std::vector<u8> out; // decoded bytes not yet handed out
+    size_t out_pos = 0;
+    DevBuf d_in;
+    size_t chunk = (size_t)256 << 20;
+    bool ended = false, done = false; // done: the verdict is final (error, or clean end)
     int verdict = BZ_OK;
 };
+
+static int dec_drain(bz_dec *d, bool final)
+{
+    if (d->done) return d->verdict;
+    if (!d->g) {
+        const int rc = bz_gpu_engine_create(&d->g, d->device, 0);
+        if (rc != BZ_OK) {
+            d->done = true;
+            return d->verdict = rc;
+        }
+    }
+    if (d->out_pos) { // drop what has been read
+        d->out.erase(d->out.begin(), d->out.begin() + (ptrdiff_t)d->out_pos);
+        d->out_pos = 0;
+    }
+    const size_t n = d->in.size();
+    int rc = d->d_in.ensure(n + 64);
+    if (rc == BZ_OK && hipMemset(d->d_in.p, 0, n + 64) != hipSuccess) rc = BZ_E_UNEXPECTED;
+    if (rc == BZ_OK && n && hipMemcpy(d->d_in.p, d->in.data(), n, hipMemcpyHostToDevice) != hipSuccess) rc = BZ_E_UNEXPECTED;
+    int verdict = BZ_OK;
+    if (rc == BZ_OK) {
+        if (!d->g->dec) d->g->dec = new DecWorkspace();
+        Sink sink;
+        sink.host = &d->out;
+        sink.staging = &d->g->dec->staging;
+        d->rs.final = final;
+        rc = decode_core(d->g, d->d_in.as<u8>(), n, sink, &verdict, nullptr, &d->rs);
+    }
+    if (rc != BZ_OK || verdict != BZ_OK) {
+        d->done = true;
+        return d->verdict = (rc != BZ_OK ? rc : verdict);
+    }
+    if (d->rs.stopped) { // keep the input from the undecided record on
+        const size_t used = (size_t)(d->rs.pos >> 3);
+        d->in.erase(d->in.begin(), d->in.begin() + (ptrdiff_t)used);
+        d->rs.pos &= 7u;
+        return BZ_OK;
+    }
+    d->in.clear();
+    d->done = true; // the file ended cleanly
+    return d->verdict = BZ_OK;
+}
 
 extern "C" int bz_dec_create(bz_dec **out, int device)
 {
@@ -748,6 +841,10 @@ extern "C" int bz_dec_create(bz_dec **out, int device)
     if (device < 0 || device >= ndev) return BZ_E_PARAM;
     bz_dec *d = new bz_dec();
     d->device = device;
+    if (const char *e = getenv("BZ_DEC_CHUNK")) {
+        const long long v = atoll(e);
+        if (v >= 1) d->chunk = (size_t)v;
+    }
     *out = d;
     return BZ_OK;
 }
@@ -756,37 +853,43 @@ extern "C" int bz_dec_write(bz_dec *d, const uint8_t *data, size_t n)
 {
     if (!d || (!data && n)) return BZ_E_PARAM;
     if (d->ended) return BZ_E_UNEXPECTED;
+    if (d->done) return BZ_OK; // (an error is waiting behind the queued bytes; further input is ignored)
     d->in.insert(d->in.end(), data, data + n);
+    if (d->in.size() >= d->chunk) {
+        const int rc = dec_drain(d, false);
+        if (rc != BZ_OK && rc != BZ_E_DATA && rc != BZ_E_MAGIC_FIRST && rc != BZ_E_MAGIC) return rc; // infrastructure
+    }
     return BZ_OK;
 }
 
 extern "C" int bz_dec_end(bz_dec *d)
 {
     if (!d) return BZ_E_PARAM;
-    if (d->ended) return d->verdict;
-    d->ended = true;
-    const int rc = bz_decode_buffer(d->device, d->in.data(), d->in.size(), &d->out, &d->out_len);
-    std::vector<u8>().swap(d->in);
-    d->verdict = rc;
-    return rc;
+    if (!d->ended) {
+        d->ended = true;
+        (void)dec_drain(d, true);
+    }
+    return d->verdict;
 }
 
 extern "C" long bz_dec_read(bz_dec *d, uint8_t *out, size_t cap)
 {
     if (!d || (!out && cap)) return BZ_E_PARAM;
-    const size_t left = d->out_len - d->out_pos;
-    if (left == 0) return d->ended ? (long)d->verdict : 0; // all bytes handed out: the verdict (0 = clean end)
+    const size_t left = d->out.size() - d->out_pos;
+    if (left == 0) return d->done ? (long)d->verdict : 0; // verdict (0 = clean end) once it is final, else "nothing yet"
     const size_t k = left < cap ? left : cap;
-    memcpy(out, d->out + d->out_pos, k);
+    memcpy(out, d->out.data() + d->out_pos, k);
     d->out_pos += k;
     return (long)k;
 }
 
-extern "C" size_t bz_dec_pending(const bz_dec *d) { return d ? d->out_len - d->out_pos : 0; }
+extern "C" size_t bz_dec_pending(const bz_dec *d) { return d ? d->out.size() - d->out_pos : 0; }
 
 extern "C" void bz_dec_destroy(bz_dec *d)
 {
     if (!d) return;
-    if (d->out) free(d->out);
+    if (d->g) (void)hipSetDevice(d->device);
+    d->d_in.release();
+    if (d->g) bz_gpu_engine_destroy(d->g);
     delete d;
 }

@@ -193,30 +193,33 @@ class BZip2Decoder {
     // order, then the Err item if the stream is bad, then None
     template <class I, class S> std::optional<Result<uint8_t, BZip2Error>> next(I &it, const S &end)
     {
-        if (pos_ == len_) {
-            if (!ended_) {
-                // (the reference pulls input bytes on demand; the bytes are the same)
-                while (it != end) {
-                    chunk_.clear();
-                    while (it != end && chunk_.size() < kChunk) {
-                        chunk_.push_back(static_cast<uint8_t>(*it));
-                        ++it;
-                    }
-                    const int rc = bz_dec_write(h_, chunk_.data(), chunk_.size());
-                    if (rc != BZ_OK) return Result<uint8_t, BZip2Error>::Err(bzip2_error_from_status(rc));
-                }
-                ended_ = true;
-                (void)bz_dec_end(h_); // the verdict comes back from bz_dec_read behind the last byte
-            }
+        while (pos_ == len_) {
             const long k = bz_dec_read(h_, buf_.data(), buf_.size());
             if (k < 0) {
                 if (failed_) return std::nullopt;
                 failed_ = true;
                 return Result<uint8_t, BZip2Error>::Err(bzip2_error_from_status(static_cast<int>(k)));
             }
-            len_ = static_cast<size_t>(k);
-            pos_ = 0;
-            if (len_ == 0) return std::nullopt;
+            if (k > 0) {
+                len_ = static_cast<size_t>(k);
+                pos_ = 0;
+                break;
+            }
+            if (ended_) return std::nullopt; // 0 after the end: the clean end
+            // nothing ready: hand over more input (the reference pulls bytes on demand; the bytes are the same)
+            chunk_.clear();
+            while (it != end && chunk_.size() < kChunk) {
+                chunk_.push_back(static_cast<uint8_t>(*it));
+                ++it;
+            }
+            if (!chunk_.empty()) {
+                const int rc = bz_dec_write(h_, chunk_.data(), chunk_.size());
+                if (rc != BZ_OK) return Result<uint8_t, BZip2Error>::Err(bzip2_error_from_status(rc));
+            }
+            if (it == end) {
+                ended_ = true;
+                (void)bz_dec_end(h_); // the verdict comes back from bz_dec_read behind the last byte
+            }
         }
         return Result<uint8_t, BZip2Error>::Ok(buf_[pos_++]);
     }

@@ -202,24 +202,7 @@ impl Decoder for BZip2Decoder {
     type Error = BZip2Error;
 
     fn next<I: Iterator<Item = u8>>(&mut self, iter: &mut I) -> Option<Result<u8, BZip2Error>> {
-        if self.pos == self.ready.len() {
-            if !self.ended {
-                // the reference pulls bytes on demand; the bytes are the same
-                let mut chunk: Vec<u8> = Vec::with_capacity(CHUNK);
-                loop {
-                    chunk.clear();
-                    chunk.extend(iter.by_ref().take(CHUNK));
-                    if chunk.is_empty() {
-                        break;
-                    }
-                    let rc = unsafe { bz_dec_write(self.h, chunk.as_ptr(), chunk.len()) };
-                    if rc != 0 {
-                        return Some(Err(map_bz_err(rc)));
-                    }
-                }
-                self.ended = true;
-                unsafe { bz_dec_end(self.h) }; // the verdict follows the last byte out of bz_dec_read
-            }
+        while self.pos == self.ready.len() {
             self.ready.resize(1 << 16, 0);
             let k = unsafe { bz_dec_read(self.h, self.ready.as_mut_ptr(), self.ready.len()) };
             if k < 0 {
@@ -233,8 +216,24 @@ impl Decoder for BZip2Decoder {
             }
             self.ready.truncate(k as usize);
             self.pos = 0;
-            if k == 0 {
-                return None;
+            if k > 0 {
+                break;
+            }
+            if self.ended {
+                return None; // 0 after the end: the clean end
+            }
+            // nothing ready yet: hand over more input (the reference pulls bytes on demand; the bytes
+            // are the same).  The library decodes complete records every BZ_DEC_CHUNK bytes.
+            let chunk: Vec<u8> = iter.by_ref().take(CHUNK).collect();
+            if !chunk.is_empty() {
+                let rc = unsafe { bz_dec_write(self.h, chunk.as_ptr(), chunk.len()) };
+                if rc != 0 {
+                    return Some(Err(map_bz_err(rc)));
+                }
+            }
+            if chunk.len() < CHUNK {
+                self.ended = true;
+                unsafe { bz_dec_end(self.h) }; // the verdict follows the last byte out of bz_dec_read
             }
         }
         let b = self.ready[self.pos];

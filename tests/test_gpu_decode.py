@@ -351,3 +351,59 @@ def test_sharded_decode_errors(pkg, oracle):
     with pytest.raises(AssertionError) as ei:
         _sharded_decode(pkg, bz2.compress(d, 1), 2, 1000)
     assert "Capacity" in str(ei.value)
+
+
+# ---- incremental streaming decode (bz_dec_*): chunks of compressed input in, decoded bytes out early
+def test_streaming_decoder_incremental(pkg, oracle, monkeypatch):
+    monkeypatch.setenv("BZ_DEC_CHUNK", "300000")  # decode whenever 300 kB of input have come in
+    d = sample(1)[:98000] * 9 + b"z" * 30000 + sample(2)[:190000] * 3
+    z = bz2.compress(d, 1) + bz2.compress(b"", 9) + bz2.compress(sample(3)[:50000], 9)
+    want = d + sample(3)[:50000]
+    rng = random.Random(51)
+    dec = pkg.BZip2Decoder()
+    got, pos, early = bytearray(), 0, 0
+    while pos < len(z):
+        step = rng.choice([1, 999, 64 << 10, 250000])
+        dec.write(z[pos:pos + step])
+        pos += step
+        part = dec.read_available()
+        if pos < len(z) and part:
+            early += len(part)
+        got += part
+    got += dec.decode_all(b"")
+    assert bytes(got) == want
+    assert early > len(want) // 2  # most of it came out before the input had ended
+    # byte-iterator form
+    dec = pkg.BZip2Decoder()
+    assert bytes(pkg.decode(iter(z), dec)) == want
+
+
+def test_streaming_decoder_incremental_errors(pkg, oracle, monkeypatch):
+    monkeypatch.setenv("BZ_DEC_CHUNK", "200000")
+    d = sample(1)[:98000] * 8
+    z = bytearray(bz2.compress(d, 1))
+    for where in (len(z) // 4, len(z) // 2, len(z) - 20):
+        bad = bytearray(z)
+        bad[where] ^= 0x20
+        want, st = oracle.decode(bytes(bad))
+        dec = pkg.BZip2Decoder()
+        got = bytearray()
+        with pytest.raises(pkg.BZip2Error) as ei:
+            for i in range(0, len(bad), 70000):
+                dec.write(bytes(bad[i:i + 70000]))
+                got += dec.read_available()
+            got += dec.decode_all(b"")
+        got += ei.value.partial
+        assert ei.value.code == st and bytes(got) == want, where
+    # truncated input and trailing junk: decided only when the input ends
+    for zz in (bytes(z[:len(z) // 2]), bytes(z) + b"xyz"):
+        want, st = oracle.decode(zz)
+        dec = pkg.BZip2Decoder()
+        got = bytearray()
+        with pytest.raises(pkg.BZip2Error) as ei:
+            for i in range(0, len(zz), 50000):
+                dec.write(zz[i:i + 50000])
+                got += dec.read_available()
+            got += dec.decode_all(b"")
+        got += ei.value.partial
+        assert ei.value.code == st and bytes(got) == want
