@@ -82,8 +82,49 @@ def stream_case():
     return enc.encode_all(b"", last) == ora.encode_iter(b"", int(last))
 
 
+def dstream_case():
+    """the streaming DEcoder: random write sizes and decode thresholds against the oracle's one-shot verdict"""
+    parts = [gen() for _ in range(rng.choice([1, 1, 2, 3]))]
+    z = b"".join(bz2.compress(p, rng.choice([1, 1, 9])) for p in parts)
+    mode = rng.randrange(4)
+    if mode == 1 and len(z) > 4:
+        z = z[:rng.randrange(len(z))]
+    elif mode == 2 and z:
+        zb = bytearray(z)
+        zb[rng.randrange(len(zb))] ^= 1 << rng.randrange(8)
+        z = bytes(zb)
+    elif mode == 3:
+        z += b"tail"
+    cap = max(1 << 20, 300 * len(z) + 1024)
+    want, st = oracle.decode(z, cap)
+    if st == -100:
+        return True
+    os.environ["BZ_DEC_CHUNK"] = str(rng.choice([1, 1000, 20000, 100000, 1 << 30]))
+    dec = pkg.BZip2Decoder()
+    got, code, pos = bytearray(), 0, 0
+    try:
+        while pos < len(z):
+            step = rng.choice([1, 3, 100, 5000, 70000, 1 << 20])
+            dec.write(z[pos:pos + step])
+            pos += step
+            got += dec.read_available()
+        got += dec.decode_all(b"")
+    except pkg.BZip2Error as e:
+        got += e.partial
+        code = e.code
+    return (bytes(got), code) == (want, st)
+
+
 t0 = time.time()
 cases = enc_ok = dec_ok = 0
+while flavour == "dstream" and time.time() - t0 < budget:
+    cases += 1
+    if not dstream_case():
+        print("DECODE-STREAM MISMATCH seed", seed, "case", cases)
+        sys.exit(1)
+if flavour == "dstream":
+    print("fuzz ok: %d streaming decodes in %.0f s (seed %d)" % (cases, time.time() - t0, seed))
+    sys.exit(0)
 while flavour == "stream" and time.time() - t0 < budget:
     cases += 1
     if not stream_case():
