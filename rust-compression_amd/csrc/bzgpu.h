@@ -213,7 +213,18 @@ struct BwtArgs {
     u32 *per_k, *per_shift;          // [nb] periodic blocks: repetition count, least-rotation start
     const u8 *sym_code;              // [nb][256] byte -> code (rank among the bytes in use)
     const u8 *keyinfo;               // [nb] KeyInfo {bits per symbol, symbols per key}
+    // fused radix passes (no per-pass histogram kernel; tile offsets by decoupled look-back)
+    u32 *gh_tiles;                   // [nb][kTilesPerBlock][3][kMaxBins] per-tile digit counts of a whole phase
+    u32 *gbase;                      // [nb][3][kMaxBins] digits smaller, per digit position
+    u32 *tile_state;                 // [nb][kTilesPerBlock][kMaxBins] look-back words: epoch | flag | value
+    u32 *tickets;                    // [kSortEpochs][8] tile tickets per pass and XCD
+    u32 *sort_err;                   // [1] a look-back that gave up
+    u32 *epoch;                      // host: the engine's pass counter (1 .. kSortEpochs-1)
+    u32 *tile_state_all;             // host: whole look-back buffer (cleared when the counter wraps)
+    u32 fused;                       // 1: use the fused passes (BZ_ONESWEEP=1); 0: histogram + scan + scatter
+    size_t tile_state_bytes;
 };
+constexpr u32 kSortEpochs = 1024;
 
 constexpr u32 kMtfStride = kSlot + 64;
 struct MtfArgs {

@@ -93,6 +93,15 @@ static int ensure_workspace(bz_gpu_engine *g)
     ENS(stream, nb * (size_t)kStreamWords * 4);
     ENS(error_flag, 4);
     ENS(packlist, nb * sizeof(PackBlock));
+    if (getenv("BZ_ONESWEEP") && atoi(getenv("BZ_ONESWEEP")) == 1) { // buffers of the fused radix passes (opt-in)
+        ENS(gh_tiles, nb * (size_t)kTilesPerBlock * 3 * kMaxBins * 4);
+        ENS(gbase, nb * (size_t)3 * kMaxBins * 4);
+        ENS(tile_state, nb * (size_t)kTilesPerBlock * kMaxBins * 4);
+        ENS(tickets, (size_t)kSortEpochs * 8 * 4 + 64);
+        if (hipMemset(g->tile_state.p, 0, g->tile_state.cap) != hipSuccess || hipMemset(g->tickets.p, 0, g->tickets.cap) != hipSuccess)
+            return BZ_E_UNEXPECTED;
+        g->sort_epoch = 0;
+    }
 #undef ENS
     g->ws_ready = true;
     return BZ_OK;
@@ -163,7 +172,8 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
                      &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->bin_base, &g->sym_code, &g->keyinfo, &g->count2, &g->tile_nf, &g->L, &g->orig_ptr, &g->inuse_bits,
                      &g->summ, &g->summ_len, &g->init_state, &g->rank8, &g->ztile_last, &g->ztile_cnt, &g->mtf,
                      &g->mtf_freq, &g->bout, &g->selector, &g->code_len, &g->group_bitoff, &g->lm_scratch,
-                     &g->stream, &g->error_flag, &g->packlist, &g->packed, &g->asmlist};
+                     &g->stream, &g->error_flag, &g->packlist, &g->packed, &g->asmlist, &g->gh_tiles, &g->gbase, &g->tile_state,
+                     &g->tickets};
     for (DevBuf *b : all) b->release();
     dec_workspace_free(g->dec);
     if (g->h_active) (void)hipHostFree(g->h_active);
@@ -350,6 +360,16 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
     x.per_shift = g->per_shift.as<u32>() + o;
     x.sym_code = g->sym_code.as<u8>() + (size_t)o * 256;
     x.keyinfo = g->keyinfo.as<u8>() + (size_t)o * 4;
+    x.gh_tiles = g->gh_tiles.as<u32>() + t * 3 * kMaxBins;
+    x.gbase = g->gbase.as<u32>() + (size_t)o * 3 * kMaxBins;
+    x.tile_state = g->tile_state.as<u32>() + t * kMaxBins;
+    x.tickets = g->tickets.as<u32>();
+    x.sort_err = g->tickets.as<u32>() + (size_t)kSortEpochs * 8;
+    x.epoch = &g->sort_epoch;
+    x.tile_state_all = g->tile_state.as<u32>();
+    x.tile_state_bytes = g->tile_state.cap;
+    static const u32 want_fused = (getenv("BZ_ONESWEEP") && atoi(getenv("BZ_ONESWEEP")) == 1) ? 1u : 0u;
+    x.fused = want_fused;
     return x;
 }
 

@@ -465,6 +465,315 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
     }
 }
 
+// =====================================================================================================
+// Fused radix passes ("one sweep"): no per-pass histogram kernel.  The digit counts of a whole phase
+// are taken once (the multiset of keys does not change while a phase permutes them: k_ghist_text for
+// the two init phases, k_group_apply for the walk round), k_ghist_scan turns them into per-block
+// digit bases, and every scatter pass finds its tile's offset inside a digit by decoupled look-back
+// over the tiles in front of it: a tile publishes its digit counts (AGG), adds up its predecessors'
+// until it meets an inclusive prefix (INCL), and publishes its own.  Tiles take tickets when they
+// start, so every predecessor of a running tile is running or done -- no tile waits for one that
+// has not been scheduled.  The words carry the pass number (epoch), so nothing is cleared between
+// passes.  What it saves: the histogram kernels (and, for the passes whose keys are gathered, the
+// round trip of the keys through memory).
+constexpr u32 kLbValMask = 0xFFFFFu, kLbAgg = 1u << 20, kLbIncl = 2u << 20, kLbFlagMask = 3u << 20;
+constexpr u32 kLbSpinMax = 1u << 22;
+
+// 16-byte accesses that other compute units observe (served by / written through to memory behind the
+// L2: sc1).  A 16-byte granule written by one store is seen whole.
+typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_sc1_x4(u32 *p, uint4 v)
+{
+    const u32x4_t r = {v.x, v.y, v.z, v.w};
+    // (s_nop: a store of more than 8 bytes reads its data registers a cycle late; the compiler's hazard
+    // recogniser does not look inside inline assembly)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(r) : "memory");
+}
+__device__ __forceinline__ uint4 ld_sc1_x4(const u32 *p)
+{
+    u32x4_t r;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+    return make_uint4(r.x, r.y, r.z, r.w);
+}
+
+template <int B0, int B1, int B2>
+__global__ __launch_bounds__(kSortThreads) void k_ghist_text(BwtArgs a, u32 *__restrict__ Kstore)
+{
+    constexpr u32 NB0 = 1u << B0, NB1 = 1u << B1, NB2 = 1u << B2;
+    __shared__ u32 s_h0[2][NB0], s_h1[2][NB1], s_h2[2][NB2];
+    __shared__ u8 s_code[256];
+    u32 tile, lb;
+    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    const BlockDesc d = a.blocks[lb];
+    const u32 n = d.n;
+    const u32 start = tile * kSortTile;
+    if (start >= n) return;
+    const u8 *text = a.rle + d.rle_off;
+    const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
+    for (u32 i = threadIdx.x; i < 2 * NB0; i += kSortThreads) (&s_h0[0][0])[i] = 0;
+    for (u32 i = threadIdx.x; i < 2 * NB1; i += kSortThreads) (&s_h1[0][0])[i] = 0;
+    for (u32 i = threadIdx.x; i < 2 * NB2; i += kSortThreads) (&s_h2[0][0])[i] = 0;
+    for (u32 i = threadIdx.x; i < 256; i += kSortThreads) s_code[i] = a.sym_code[(size_t)lb * 256 + i];
+    __syncthreads();
+    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    u32 key[16], val[16];
+    const u32 ok = fetch_rows<SRC_TEXT>(a, lb, text, n, 0, nullptr, nullptr, start + w * 1024u + l, n, s_code, ki, key, val);
+    const size_t base = (size_t)lb * kSlot;
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        if ((ok >> r) & 1u) {
+            atomicAdd(&s_h0[l & 1u][key[r] & (NB0 - 1)], 1u);
+            atomicAdd(&s_h1[l & 1u][(key[r] >> B0) & (NB1 - 1)], 1u);
+            atomicAdd(&s_h2[l & 1u][(key[r] >> (B0 + B1)) & (NB2 - 1)], 1u);
+            Kstore[base + start + w * 1024u + r * 64u + l] = key[r];
+        }
+    }
+    __syncthreads();
+    u32 *out = a.gh_tiles + ((size_t)lb * kTilesPerBlock + tile) * 3 * kMaxBins;
+    for (u32 i = threadIdx.x; i < NB0; i += kSortThreads) out[i] = s_h0[0][i] + s_h0[1][i];
+    for (u32 i = threadIdx.x; i < NB1; i += kSortThreads) out[kMaxBins + i] = s_h1[0][i] + s_h1[1][i];
+    for (u32 i = threadIdx.x; i < NB2; i += kSortThreads) out[2 * kMaxBins + i] = s_h2[0][i] + s_h2[1][i];
+}
+
+// per block and digit position: digits smaller (exclusive scan of the summed tile counts).
+// ntiles_from_count: the tiles that hold counts are those of the list of length count[lb] (the
+// refinement that took them), else those of the block.  Sets count[lb] to the number of keys.
+__global__ __launch_bounds__(kSortThreads) void k_ghist_scan(BwtArgs a, u32 ndig, u32 nbins0, u32 nbins1, u32 nbins2,
+                                                             u32 ntiles_from_count)
+{
+    __shared__ u32 s_wsum[kSortThreads / 64];
+    const u32 lb = blockIdx.x;
+    const u32 n = a.blocks[lb].n;
+    const u32 len = ntiles_from_count ? a.count[lb] : n;
+    const u32 ntiles = (len + kSortTile - 1) / kSortTile;
+    const u32 *gt = a.gh_tiles + (size_t)lb * kTilesPerBlock * 3 * kMaxBins;
+    u32 total0 = 0;
+    for (u32 dpos = 0; dpos < ndig; ++dpos) {
+        const u32 nbins = dpos == 0 ? nbins0 : (dpos == 1 ? nbins1 : nbins2);
+        const u32 per = (nbins + kSortThreads - 1) / kSortThreads; // bins per thread, consecutive (<= 4)
+        u32 tot[4] = {0, 0, 0, 0};
+        u32 mine = 0;
+        for (u32 q = 0; q < per; ++q) {
+            const u32 bin = threadIdx.x * per + q;
+            u32 sum = 0;
+            if (bin < nbins)
+                for (u32 t = 0; t < ntiles; ++t) sum += gt[(size_t)t * 3 * kMaxBins + dpos * kMaxBins + bin];
+            tot[q] = sum;
+            mine += sum;
+        }
+        const u32 inc = wave_incl_sum(mine);
+        __syncthreads();
+        if ((threadIdx.x & 63u) == 63u) s_wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        u32 carry = 0, total = 0;
+        for (u32 k = 0; k < kSortThreads / 64; ++k) {
+            if (k < (threadIdx.x >> 6)) carry += s_wsum[k];
+            total += s_wsum[k];
+        }
+        u32 run = carry + inc - mine;
+        for (u32 q = 0; q < per; ++q) {
+            const u32 bin = threadIdx.x * per + q;
+            if (bin < nbins) a.gbase[((size_t)lb * 3 + dpos) * kMaxBins + bin] = run;
+            run += tot[q];
+        }
+        if (dpos == 0) total0 = total;
+    }
+    if (threadIdx.x == 0) a.count[lb] = total0;
+}
+
+// the scatter of a fused pass; dpos selects the digit position inside gbase
+template <int SRC, int BITS>
+__global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h,
+                                                                    const u32 *__restrict__ Kin,
+                                                                    const u32 *__restrict__ Vin,
+                                                                    u32 *__restrict__ Kout, u32 *__restrict__ Vout,
+                                                                    u32 dpos, u32 epoch)
+{
+    constexpr u32 NB = 1u << BITS;
+    constexpr u32 NW = kSortThreads / 64;
+    __shared__ u32 s_buf[kSortTile];
+    __shared__ u32 s_base[NB];
+    __shared__ u16 s_tpre[NB];
+    __shared__ u32 s_wsum[NW];
+    __shared__ u32 s_total;
+    __shared__ u32 s_ticket;
+    __shared__ u8 s_code[256];
+    u16 *s_cnt = reinterpret_cast<u16 *>(s_buf); // [NW][NB] u16
+    // tiles are handed out in order, per XCD group of blocks (same placement as xcd_remap)
+    const u32 lid = blockIdx.x + gridDim.x * blockIdx.y;
+    const u32 xcd = lid & 7u;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&a.tickets[(size_t)epoch * 8u + xcd], 1u);
+    __syncthreads();
+    const u32 slot = s_ticket;
+    const u32 b8 = slot / kTilesPerBlock;
+    const u32 tile = slot - b8 * kTilesPerBlock;
+    const u32 lb = b8 * 8u + xcd;
+    if (lb >= a.nb) return;
+    const BlockDesc d = a.blocks[lb];
+    const u32 n = d.n;
+    const u32 cnt = src_is_list<SRC>::value ? a.count[lb] : n;
+    const u32 start = tile * kSortTile;
+    if (start >= cnt) return;
+    const u8 *text = a.rle + d.rle_off;
+    const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
+    const u32 hm = (SRC == SRC_MM || SRC == SRC_MMK || SRC == SRC_SURV) ? (((u32)ki.chars * 2u) << h) % n : 0u;
+    const size_t base = (size_t)lb * kSlot;
+    if (SRC == SRC_TEXT || SRC == SRC_WALK)
+        for (u32 i = threadIdx.x; i < 256; i += kSortThreads) s_code[i] = a.sym_code[(size_t)lb * 256 + i];
+    for (u32 i = threadIdx.x; i < NW * NB / 2; i += kSortThreads) s_buf[i] = 0;
+    __syncthreads();
+
+    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const u64 lt_mask = (l == 0) ? 0ull : (~0ull >> (64 - l));
+    u16 *my_cnt = s_cnt + w * NB;
+    u32 key[16], val[16];
+    u32 rnk[16]; // 0xFFFFFFFF = takes no part
+    const u32 okmask =
+        fetch_rows<SRC>(a, lb, text, n, hm, Kin, Vin, start + w * 1024u + l, cnt, s_code, ki, key, val);
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const bool ok = (okmask >> r) & 1u;
+        const u32 dg = (key[r] >> shift) & (NB - 1);
+        u64 peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < BITS; ++b) {
+            const bool bit = (dg >> b) & 1u;
+            const u64 m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        rnk[r] = 0xFFFFFFFFu;
+        if (ok) {
+            const u32 before = __popcll(peers & lt_mask);
+            const u32 c0 = my_cnt[dg];
+            rnk[r] = c0 + before;
+            if ((peers >> l) == 1ull) my_cnt[dg] = (u16)(c0 + before + 1u);
+        }
+    }
+    __syncthreads();
+    constexpr u32 PER = NB / kSortThreads; // digits per thread (2 or 4), consecutive
+    u32 tot[PER];
+    u32 mine = 0;
+#pragma unroll
+    for (u32 q = 0; q < PER; ++q) {
+        const u32 dg = threadIdx.x * PER + q;
+        u32 run = 0;
+#pragma unroll
+        for (u32 k = 0; k < NW; ++k) {
+            const u32 c = s_cnt[k * NB + dg];
+            s_cnt[k * NB + dg] = (u16)run;
+            run += c;
+        }
+        tot[q] = run;
+        mine += run;
+    }
+    // this tile's digit counts go out, the predecessors' come in: four digits per 16-byte word group
+    // (one sc1 store / load moves 16 bytes for the price of 4, MI355X_MICROARCH.md)
+#pragma unroll
+    for (u32 q = 0; q < PER; ++q) s_base[threadIdx.x * PER + q] = tot[q];
+    __syncthreads();
+    if (threadIdx.x < NB / 4u) {
+        const u32 d0 = threadIdx.x * 4u;
+        u32 *mystate = a.tile_state + ((size_t)lb * kTilesPerBlock + tile) * kMaxBins + d0;
+        const u32 etag = epoch << 22;
+        const u32 t4[4] = {s_base[d0], s_base[d0 + 1], s_base[d0 + 2], s_base[d0 + 3]};
+        const u32 f0 = etag | (tile ? kLbAgg : kLbIncl);
+        st_sc1_x4(mystate, make_uint4(f0 | t4[0], f0 | t4[1], f0 | t4[2], f0 | t4[3]));
+        u32 excl[4] = {0, 0, 0, 0};
+        if (tile) {
+            u32 open = 0xFu; // digits whose sum has not met an inclusive prefix yet
+            u32 spins = 0;
+            for (u32 p = tile; p > 0 && open;) {
+                --p;
+                const u32 *src = a.tile_state + ((size_t)lb * kTilesPerBlock + p) * kMaxBins + d0;
+                uint4 v = ld_sc1_x4(src);
+                while (true) {
+                    const u32 x[4] = {v.x, v.y, v.z, v.w};
+                    bool ready = true;
+#pragma unroll
+                    for (u32 k = 0; k < 4; ++k)
+                        if ((x[k] >> 22) != epoch || (x[k] & kLbFlagMask) == 0u) ready = false;
+                    if (ready) break; // (the four words of a group are written by one store)
+                    if (++spins > kLbSpinMax) {
+                        atomicExch(a.sort_err, 1u);
+                        v = make_uint4(etag | kLbIncl, etag | kLbIncl, etag | kLbIncl, etag | kLbIncl);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    v = ld_sc1_x4(src);
+                }
+                const u32 x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (u32 k = 0; k < 4; ++k) {
+                    if ((open >> k) & 1u) {
+                        excl[k] += x[k] & kLbValMask;
+                        if ((x[k] & kLbFlagMask) == kLbIncl) open &= ~(1u << k);
+                    }
+                }
+            }
+            const u32 fi = etag | kLbIncl;
+            st_sc1_x4(mystate, make_uint4(fi | (excl[0] + t4[0]), fi | (excl[1] + t4[1]), fi | (excl[2] + t4[2]),
+                                          fi | (excl[3] + t4[3])));
+        }
+        const u32 *gb = a.gbase + ((size_t)lb * 3 + dpos) * kMaxBins + d0;
+#pragma unroll
+        for (u32 k = 0; k < 4; ++k) s_base[d0 + k] = gb[k] + excl[k];
+    }
+    // exclusive scan of the totals over digits (digit order == thread order)
+    {
+        const u32 inc = wave_incl_sum(mine);
+        if (l == 63) s_wsum[w] = inc;
+        __syncthreads();
+        u32 carry = 0, total = 0;
+        for (u32 k = 0; k < NW; ++k) {
+            if (k < w) carry += s_wsum[k];
+            total += s_wsum[k];
+        }
+        u32 ex = carry + inc - mine;
+#pragma unroll
+        for (u32 q = 0; q < PER; ++q) {
+            s_tpre[threadIdx.x * PER + q] = (u16)ex;
+            ex += tot[q];
+        }
+        if (threadIdx.x == 0) s_total = total;
+    }
+    __syncthreads();
+    u32 lpos[16];
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 dg = (key[r] >> shift) & (NB - 1);
+        lpos[r] = (rnk[r] != 0xFFFFFFFFu) ? (u32)s_tpre[dg] + (u32)my_cnt[dg] + rnk[r] : 0xFFFFFFFFu;
+    }
+    const u32 total = s_total;
+    __syncthreads(); // counters are dead from here on: the buffer becomes the staging area
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r)
+        if (lpos[r] != 0xFFFFFFFFu) s_buf[lpos[r]] = key[r];
+    __syncthreads();
+    u32 dst[16];
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k) {
+        const u32 i = k * kSortThreads + threadIdx.x;
+        dst[k] = 0xFFFFFFFFu;
+        if (i < total) {
+            const u32 kk = s_buf[i];
+            const u32 dg = (kk >> shift) & (NB - 1);
+            dst[k] = s_base[dg] + (i - (u32)s_tpre[dg]);
+            Kout[base + dst[k]] = kk;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r)
+        if (lpos[r] != 0xFFFFFFFFu) s_buf[lpos[r]] = val[r];
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k) {
+        const u32 i = k * kSortThreads + threadIdx.x;
+        if (i < total) Vout[base + dst[k]] = s_buf[i];
+    }
+}
+
 // ---- group refinement, part 1: boundary flags over the sorted pair list ----------------
 // INIT: the list is all n rotations sorted by their first 2c symbols (one old group); K holds
 //       key(j) = symbols [0,c), the second half key(j+c) is re-read from the block (L2).
@@ -583,6 +892,9 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
     __shared__ int s_carry_old, s_carry_new;
     __shared__ int s_wold[NW], s_wnew[NW];
     __shared__ u32 s_nonfinal;
+    // digit counts of the keys of the next walk round (the group heads of the members that are not
+    // final yet): what its fused radix passes need instead of histogram kernels
+    __shared__ u32 s_gh[2][1024];
     u32 tile, lb;
     xcd_remap(kTilesPerBlock, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
@@ -591,6 +903,8 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
     const u32 start = tile * kSortTile;
     if (start >= cnt) return;
     const size_t base = (size_t)lb * kSlot;
+    if (a.fused)
+        for (u32 i = threadIdx.x; i < 2048u; i += kSortThreads) (&s_gh[0][0])[i] = 0;
 
     if (threadIdx.x == 0) {
         int co = -1, cn = -1;
@@ -657,6 +971,10 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
             st_stream(a.SA + base + p, j);
             a.R[base + j] = head | (fin ? kFinalBit : 0u);
             my_nonfinal += fin ? 0u : 1u;
+            if (a.fused && !fin) {
+                atomicAdd(&s_gh[0][head & 1023u], 1u);
+                atomicAdd(&s_gh[1][(head >> 10) & 1023u], 1u);
+            }
         }
         if (mo[r]) carry_old = (int)(rowbase + 63u - __clzll(mo[r]));
         if (mn[r]) carry_new = (int)(rowbase + 63u - __clzll(mn[r]));
@@ -665,6 +983,13 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
     if (l == 0 && my_nonfinal) atomicAdd(&s_nonfinal, my_nonfinal);
     __syncthreads();
     if (threadIdx.x == 0) a.tile_nf[lb * kTilesPerBlock + tile] = s_nonfinal;
+    if (a.fused) {
+        u32 *out = a.gh_tiles + ((size_t)lb * kTilesPerBlock + tile) * 3 * kMaxBins;
+        for (u32 i = threadIdx.x; i < 1024u; i += kSortThreads) {
+            out[i] = s_gh[0][i];
+            out[kMaxBins + i] = s_gh[1][i];
+        }
+    }
     if (threadIdx.x == 0 && s_nonfinal) {
         atomicAdd(&a.nonfinal[lb], s_nonfinal);
         // the block still needs rounds only while the next comparison depth is below its length
@@ -976,6 +1301,52 @@ static void radix_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const
     if (prof) prof->end(st, p);
 }
 
+// the tag of the next fused pass; the look-back words and tickets are cleared when the counter wraps
+static u32 next_epoch(hipStream_t st, const BwtArgs &a)
+{
+    u32 e = *a.epoch + 1u;
+    if (e >= kSortEpochs) {
+        (void)hipMemsetAsync(a.tile_state_all, 0, a.tile_state_bytes, st);
+        (void)hipMemsetAsync(a.tickets, 0, (size_t)kSortEpochs * 8 * 4, st);
+        e = 1;
+    }
+    *a.epoch = e;
+    return e;
+}
+
+template <int SRC, int BITS>
+static void fused_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const u32 *Kin, const u32 *Vin, u32 *Kout,
+                       u32 *Vout, u32 dpos, u64 elems, KernelProf *prof)
+{
+    const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
+    const u64 rd = (SRC == SRC_TEXTK) ? 4 : ((SRC == SRC_WALK) ? 5 : 8);
+    const u32 e = next_epoch(st, a);
+    const int p = prof ? prof->begin(st, KID_RADIX_SCATTER, elems * (rd + 8)) : -1;
+    hipLaunchKernelGGL((k_radix_scatter_lb<SRC, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Kin, Vin, Kout, Vout,
+                       dpos, e);
+    if (prof) prof->end(st, p);
+}
+
+template <int B0, int B1, int B2>
+static void init_sort_fused(hipStream_t st, const BwtArgs &a, u64 total_n, KernelProf *prof)
+{
+    const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
+    // the digit counts of key(j), once: both init phases sort the same multiset of keys
+    int p = prof ? prof->begin(st, KID_RADIX_HIST, total_n * 5) : -1;
+    hipLaunchKernelGGL((k_ghist_text<B0, B1, B2>), grid, dim3(kSortThreads), 0, st, a, a.KB);
+    if (prof) prof->end(st, p);
+    p = prof ? prof->begin(st, KID_RADIX_SCAN, (u64)a.nb * kTilesPerBlock * 3 * 1024 * 4) : -1;
+    hipLaunchKernelGGL(k_ghist_scan, dim3(a.nb), dim3(kSortThreads), 0, st, a, 3u, 1u << B0, 1u << B1, 1u << B2, 0u);
+    if (prof) prof->end(st, p);
+    // phase A: order by key(j); phase B: walk it, order by key(j - c) -> 2c symbols
+    fused_pass<SRC_TEXTK, B0>(st, a, 0, 0, a.KB, nullptr, a.KA, a.VA, 0, total_n, prof);
+    fused_pass<SRC_PAIRS, B1>(st, a, B0, 0, a.KA, a.VA, a.KB, a.VB, 1, total_n, prof);
+    fused_pass<SRC_PAIRS, B2>(st, a, B0 + B1, 0, a.KB, a.VB, a.KA, a.VA, 2, total_n, prof);
+    fused_pass<SRC_WALK, B0>(st, a, 0, 0, a.KA, a.VA, a.KB, a.VB, 0, total_n, prof);
+    fused_pass<SRC_PAIRS, B1>(st, a, B0, 0, a.KB, a.VB, a.KA, a.VA, 1, total_n, prof);
+    fused_pass<SRC_PAIRS, B2>(st, a, B0 + B1, 0, a.KA, a.VA, a.KB, a.VB, 2, total_n, prof);
+}
+
 void launch_block_symbols(hipStream_t st, const BwtArgs &a, u32 *inuse_bits, u8 *sym_code, u8 *keyinfo)
 {
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
@@ -1009,8 +1380,17 @@ int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned l
     (void)hipMemsetAsync(a.active, 0, 64 * sizeof(unsigned long long), st);
     (void)hipMemsetAsync(a.nonfinal, 0, a.nb * sizeof(u32), st);
 
-    if (wide_keys) init_sort<11, 11, 10>(st, a, total_n, prof);
-    else init_sort<10, 10, 10>(st, a, total_n, prof);
+    // The fused passes are an opt-in experiment (BZ_ONESWEEP=1): measured 129.7 ms per GiB against
+    // 132.3 ms for the three-kernel passes -- the look-back's sc1 traffic eats most of what the
+    // histogram kernels cost -- and the well-worn path stays the default.
+    const bool fused = a.fused != 0;
+    if (fused) {
+        if (wide_keys) init_sort_fused<11, 11, 10>(st, a, total_n, prof);
+        else init_sort_fused<10, 10, 10>(st, a, total_n, prof);
+    } else {
+        if (wide_keys) init_sort<11, 11, 10>(st, a, total_n, prof);
+        else init_sort<10, 10, 10>(st, a, total_n, prof);
+    }
     int p = prof ? prof->begin(st, KID_GROUP_FLAGS, total_n * 9) : -1;
     hipLaunchKernelGGL((k_group_flags<true>), grid, dim3(kSortThreads), 0, st, a, 0u, a.KB, a.VB);
     if (prof) prof->end(st, p);
@@ -1048,8 +1428,15 @@ int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned l
             t = cV; cV = fV; fV = t;
         } else {
             // pass A walks all of SA (total_n), pass B and the refinement only the m survivors
-            radix_pass<SRC_MM, 10>(st, a, 0, step, nullptr, nullptr, fK, fV, total_n, prof, cK);
-            radix_pass<SRC_PAIRS, 10>(st, a, 10, step, fK, fV, cK, cV, m, prof);
+            if (fused) {
+                // the keys are the group heads of the rotations that are not final: k_group_apply counted them
+                hipLaunchKernelGGL(k_ghist_scan, dim3(a.nb), dim3(kSortThreads), 0, st, a, 2u, 1024u, 1024u, 0u, 1u);
+                fused_pass<SRC_MM, 10>(st, a, 0, step, nullptr, nullptr, fK, fV, 0, total_n, prof);
+                fused_pass<SRC_PAIRS, 10>(st, a, 10, step, fK, fV, cK, cV, 1, m, prof);
+            } else {
+                radix_pass<SRC_MM, 10>(st, a, 0, step, nullptr, nullptr, fK, fV, total_n, prof, cK);
+                radix_pass<SRC_PAIRS, 10>(st, a, 10, step, fK, fV, cK, cV, m, prof);
+            }
         }
         p = prof ? prof->begin(st, KID_GROUP_FLAGS, m * 13) : -1;
         hipLaunchKernelGGL((k_group_flags<false>), grid, dim3(kSortThreads), 0, st, a, step, cK, cV);
@@ -1058,6 +1445,12 @@ int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned l
         hipLaunchKernelGGL((k_group_apply<false>), grid, dim3(kSortThreads), 0, st, a, step + 1, slot, cK, cV);
         if (prof) prof->end(st, p);
         ++step;
+    }
+    if (fused) { // a look-back that gave up (it never should) must not pass for a sorted block
+        u32 gave_up = 0;
+        if (hipMemcpyAsync(&gave_up, a.sort_err, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+        if (hipStreamSynchronize(st) != hipSuccess) return -1;
+        if (gave_up) return -1;
     }
     // periodic blocks: whatever is still non-final is a set of equal rotations
     (void)hipMemsetAsync(a.per_k, 0, a.nb * sizeof(u32), st);
