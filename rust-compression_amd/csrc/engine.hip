@@ -93,7 +93,7 @@ static int ensure_workspace(bz_gpu_engine *g)
     ENS(stream, nb * (size_t)kStreamWords * 4);
     ENS(error_flag, 4);
     ENS(packlist, nb * sizeof(PackBlock));
-    if (getenv("BZ_ONESWEEP") && atoi(getenv("BZ_ONESWEEP")) == 1) { // buffers of the fused radix passes (opt-in)
+    if (!(getenv("BZ_ONESWEEP") && atoi(getenv("BZ_ONESWEEP")) == 0)) { // buffers of the fused radix passes
         ENS(gh_tiles, nb * (size_t)kTilesPerBlock * 3 * kMaxBins * 4);
         ENS(gbase, nb * (size_t)3 * kMaxBins * 4);
         ENS(tile_state, nb * (size_t)kTilesPerBlock * kMaxBins * 4);
@@ -368,7 +368,7 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
     x.epoch = &g->sort_epoch;
     x.tile_state_all = g->tile_state.as<u32>();
     x.tile_state_bytes = g->tile_state.cap;
-    static const u32 want_fused = (getenv("BZ_ONESWEEP") && atoi(getenv("BZ_ONESWEEP")) == 1) ? 1u : 0u;
+    static const u32 want_fused = (getenv("BZ_ONESWEEP") && atoi(getenv("BZ_ONESWEEP")) == 0) ? 0u : 1u;
     x.fused = want_fused;
     return x;
 }

@@ -32,7 +32,9 @@
 //
 // Integer path: no MFMA.  Bound: HBM (streamed u32 arrays) + L2 gathers.
 #include "bzgpu.h"
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 namespace bzgpu {
 
@@ -479,20 +481,32 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
 constexpr u32 kLbValMask = 0xFFFFFu, kLbAgg = 1u << 20, kLbIncl = 2u << 20, kLbFlagMask = 3u << 20;
 constexpr u32 kLbSpinMax = 1u << 22;
 
-// 16-byte accesses that other compute units observe (served by / written through to memory behind the
-// L2: sc1).  A 16-byte granule written by one store is seen whole.
+// 16-byte accesses that the other compute units OF THE SAME XCD observe: plain stores are written
+// through to the XCD's L2 and stay there, `nt` loads bypass the L1 and are served by that L2
+// (MI355X_MICROARCH.md).  Producer and consumer of a look-back word always share an XCD (tickets are
+// taken from the counter of the XCD a workgroup runs on).  -DBZ_LB_SC1 selects accesses that are
+// coherent across XCDs instead (sc1; 2-3x the latency, and such stores drop the L2 line).  A 16-byte
+// granule written by one store is seen whole.
 typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_sc1_x4(u32 *p, uint4 v)
 {
     const u32x4_t r = {v.x, v.y, v.z, v.w};
     // (s_nop: a store of more than 8 bytes reads its data registers a cycle late; the compiler's hazard
     // recogniser does not look inside inline assembly)
+    #ifndef BZ_LB_SC1
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(r) : "memory");
+#else
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(r) : "memory");
+#endif
 }
 __device__ __forceinline__ uint4 ld_sc1_x4(const u32 *p)
 {
     u32x4_t r;
+    #ifndef BZ_LB_SC1
+    asm volatile("global_load_dwordx4 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+#else
     asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+#endif
     return make_uint4(r.x, r.y, r.z, r.w);
 }
 
@@ -600,16 +614,21 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
     __shared__ u32 s_ticket;
     __shared__ u8 s_code[256];
     u16 *s_cnt = reinterpret_cast<u16 *>(s_buf); // [NW][NB] u16
-    // tiles are handed out in order, per XCD group of blocks (same placement as xcd_remap)
-    const u32 lid = blockIdx.x + gridDim.x * blockIdx.y;
-    const u32 xcd = lid & 7u;
+    // Tiles are handed out in order, block by block, from one ticket counter per XCD -- the XCD this
+    // workgroup really runs on (HW_REG_XCC_ID), so that all tiles of a block are handled on one XCD
+    // and the look-back words can travel through that XCD's L2.  Workgroups are dealt to the XCDs
+    // round-robin (observed: XCC_ID == linear id % 8), so every XCD gets as many workgroups as it has
+    // tiles; the host checks that every counter reached its total and falls back to the three-kernel
+    // passes if a dispatch ever does it differently.
+    const u32 xcd = (u32)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u; // XCC_ID, bits 3:0
+    const u32 my_tiles = kTilesPerBlock * ((a.nb + 7u - xcd) / 8u);
     if (threadIdx.x == 0) s_ticket = atomicAdd(&a.tickets[(size_t)epoch * 8u + xcd], 1u);
     __syncthreads();
     const u32 slot = s_ticket;
+    if (slot >= my_tiles) return;
     const u32 b8 = slot / kTilesPerBlock;
     const u32 tile = slot - b8 * kTilesPerBlock;
     const u32 lb = b8 * 8u + xcd;
-    if (lb >= a.nb) return;
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
     const u32 cnt = src_is_list<SRC>::value ? a.count[lb] : n;
@@ -1327,8 +1346,26 @@ static void fused_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const
     if (prof) prof->end(st, p);
 }
 
+// did the fused pass tagged `epoch` hand out every tile on every XCD, and did no look-back give up?
+// (one small copy and a stream synchronisation)
+static bool fused_pass_ok(hipStream_t st, const BwtArgs &a, u32 epoch)
+{
+    static const bool fail_test = getenv("BZ_ONESWEEP_FAILTEST") != nullptr; // (tests: exercise the fallback)
+    if (fail_test) return false;
+    u32 tk[8], gave_up = 0;
+    if (hipMemcpyAsync(tk, a.tickets + (size_t)epoch * 8u, sizeof(tk), hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+    if (hipMemcpyAsync(&gave_up, a.sort_err, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+    if (hipStreamSynchronize(st) != hipSuccess) return false;
+    if (gave_up) return false;
+    for (u32 x = 0; x < 8; ++x)
+        if (tk[x] < kTilesPerBlock * ((a.nb + 7u - x) / 8u)) return false;
+    return true;
+}
+
+// false: the first pass did not behave (workgroups not dealt evenly to the XCDs, or a look-back gave
+// up); nothing of it is used then and the caller sorts with the three-kernel passes
 template <int B0, int B1, int B2>
-static void init_sort_fused(hipStream_t st, const BwtArgs &a, u64 total_n, KernelProf *prof)
+static bool init_sort_fused(hipStream_t st, const BwtArgs &a, u64 total_n, KernelProf *prof)
 {
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
     // the digit counts of key(j), once: both init phases sort the same multiset of keys
@@ -1340,11 +1377,13 @@ static void init_sort_fused(hipStream_t st, const BwtArgs &a, u64 total_n, Kerne
     if (prof) prof->end(st, p);
     // phase A: order by key(j); phase B: walk it, order by key(j - c) -> 2c symbols
     fused_pass<SRC_TEXTK, B0>(st, a, 0, 0, a.KB, nullptr, a.KA, a.VA, 0, total_n, prof);
+    if (!fused_pass_ok(st, a, *a.epoch)) return false;
     fused_pass<SRC_PAIRS, B1>(st, a, B0, 0, a.KA, a.VA, a.KB, a.VB, 1, total_n, prof);
     fused_pass<SRC_PAIRS, B2>(st, a, B0 + B1, 0, a.KB, a.VB, a.KA, a.VA, 2, total_n, prof);
     fused_pass<SRC_WALK, B0>(st, a, 0, 0, a.KA, a.VA, a.KB, a.VB, 0, total_n, prof);
     fused_pass<SRC_PAIRS, B1>(st, a, B0, 0, a.KB, a.VB, a.KA, a.VA, 1, total_n, prof);
     fused_pass<SRC_PAIRS, B2>(st, a, B0 + B1, 0, a.KA, a.VA, a.KB, a.VB, 2, total_n, prof);
+    return true;
 }
 
 void launch_block_symbols(hipStream_t st, const BwtArgs &a, u32 *inuse_bits, u8 *sym_code, u8 *keyinfo)
@@ -1373,21 +1412,31 @@ static void init_sort(hipStream_t st, const BwtArgs &a, u64 total_n, KernelProf 
 // symbols (32-bit keys, 11+11+10 bit digits; otherwise 30-bit keys, 10+10+10).  min_chars: the
 // smallest symbols-per-key of the batch.
 // Returns the number of doubling rounds executed, <0 on HIP error.
-int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned long long *h_active,
+int run_bwt(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 total_n, unsigned long long *h_active,
             u64 *sorted_elems, KernelProf *prof, u64 *round_active, bool wide_keys, u32 min_chars)
 {
+    BwtArgs a = a_in; // (a.fused is cleared below if the fused passes do not behave on this machine)
+    static bool fused_broken = false;
+    if (fused_broken) a.fused = 0;
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
     (void)hipMemsetAsync(a.active, 0, 64 * sizeof(unsigned long long), st);
     (void)hipMemsetAsync(a.nonfinal, 0, a.nb * sizeof(u32), st);
 
-    // The fused passes are an opt-in experiment (BZ_ONESWEEP=1): measured 129.7 ms per GiB against
-    // 132.3 ms for the three-kernel passes -- the look-back's sc1 traffic eats most of what the
-    // histogram kernels cost -- and the well-worn path stays the default.
-    const bool fused = a.fused != 0;
+    // Fused passes (k_radix_scatter_lb) unless switched off (BZ_ONESWEEP=0) or found not to behave: their
+    // first pass is checked, and the three-kernel passes redo the sort from the block if it fails.
+    bool fused = a.fused != 0;
+    const u32 epoch_first = *a.epoch + 1u; // (fused) the passes of this call, for the coverage check below
     if (fused) {
-        if (wide_keys) init_sort_fused<11, 11, 10>(st, a, total_n, prof);
-        else init_sort_fused<10, 10, 10>(st, a, total_n, prof);
-    } else {
+        const bool ok = wide_keys ? init_sort_fused<11, 11, 10>(st, a, total_n, prof) : init_sort_fused<10, 10, 10>(st, a, total_n, prof);
+        if (!ok) {
+            fprintf(stderr, "bz2_mi355x: fused radix passes disabled (tile tickets / look-back check failed)\n");
+            fused_broken = true;
+            fused = false;
+            a.fused = 0;
+            (void)hipMemsetAsync(a.sort_err, 0, 4, st);
+        }
+    }
+    if (!fused) {
         if (wide_keys) init_sort<11, 11, 10>(st, a, total_n, prof);
         else init_sort<10, 10, 10>(st, a, total_n, prof);
     }
@@ -1446,11 +1495,25 @@ int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned l
         if (prof) prof->end(st, p);
         ++step;
     }
-    if (fused) { // a look-back that gave up (it never should) must not pass for a sorted block
+    if (fused) {
+        // a look-back that gave up (it never should) must not pass for a sorted block, and every pass
+        // must have handed out all its tiles on every XCD (it does unless an XCD ran no workgroup)
         u32 gave_up = 0;
+        std::vector<u32> tk;
+        const u32 epoch_last = *a.epoch;
         if (hipMemcpyAsync(&gave_up, a.sort_err, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+        if (epoch_last >= epoch_first) { // (no wrap of the pass counter in between)
+            tk.resize((size_t)(epoch_last - epoch_first + 1u) * 8u);
+            if (hipMemcpyAsync(tk.data(), a.tickets + (size_t)epoch_first * 8u, tk.size() * 4, hipMemcpyDeviceToHost, st) !=
+                hipSuccess)
+                return -1;
+        }
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
         if (gave_up) return -1;
+        for (size_t i = 0; i < tk.size(); ++i) {
+            const u32 x = (u32)(i & 7u);
+            if (tk[i] < kTilesPerBlock * ((a.nb + 7u - x) / 8u)) return -1;
+        }
     }
     // periodic blocks: whatever is still non-final is a set of equal rotations
     (void)hipMemsetAsync(a.per_k, 0, a.nb * sizeof(u32), st);

@@ -9,7 +9,7 @@ import random
 
 import pytest
 
-from conftest import GOLDEN, product, sample
+from conftest import GOLDEN, ROOT, product, sample
 
 pytestmark = pytest.mark.gpu
 
@@ -314,3 +314,44 @@ def test_wide_inputs_small_blocks(pkg, oracle):
     d = WIDE["long_runs_mixed"]()[:6_000_000] + WIDE["text_zeros_random"]()[:2_000_000]
     for level in (1, 4):
         assert pkg.compress(d, level) == oracle.encode(d, level), level
+
+
+def test_radix_pass_flavours_agree(oracle):
+    """the fused radix passes (default), the three-kernel passes (BZ_ONESWEEP=0) and the fallback from
+    one to the other (BZ_ONESWEEP_FAILTEST) give the oracle's stream; each runs in its own process
+    because the switches are read once"""
+    import subprocess
+    import sys
+    code = (
+        "import importlib,sys,hashlib;sys.path.insert(0,%r);pkg=importlib.import_module('rust-compression_amd');"
+        "sys.path.insert(0,%r+'/tests');from conftest import sample;"
+        "d=sample(1)*3+bytes(range(256))*700+sample(2);"
+        "print(hashlib.sha256(pkg.compress(d,9)).hexdigest(), hashlib.sha256(pkg.compress(d,1)).hexdigest())" % (ROOT, ROOT))
+    d = sample(1) * 3 + bytes(range(256)) * 700 + sample(2)
+    want = "%s %s" % (hashlib.sha256(oracle.encode(d, 9)).hexdigest(), hashlib.sha256(oracle.encode(d, 1)).hexdigest())
+    for env in ({}, {"BZ_ONESWEEP": "0"}, {"BZ_ONESWEEP_FAILTEST": "1"}):
+        e = dict(os.environ)
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.strip().splitlines()[-1] == want, (env, out.stdout, out.stderr[-500:])
+        if "BZ_ONESWEEP_FAILTEST" in env:
+            assert "fused radix passes disabled" in out.stderr
+
+
+def test_pass_counter_wraps(pkg, oracle):
+    """one engine, enough sorts for the fused passes' epoch tag (1023 values) to wrap several times"""
+    import torch
+    d = sample(1)[:120000] + bytes(range(256)) * 40
+    want = oracle.encode(d, 1)
+    e = pkg.GpuEngine(0, 8)
+    tin = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+    cap = (pkg.encode_bound(len(d)) + 15) & ~15
+    tout = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    try:
+        for i in range(420):
+            n = e.encode_device(1, tin.data_ptr(), len(d), tout.data_ptr(), cap)
+            if i % 60 == 0 or i > 410:
+                assert bytes(tout[:n].cpu().numpy()) == want, i
+    finally:
+        e.close()
