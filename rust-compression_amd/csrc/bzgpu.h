@@ -352,6 +352,9 @@ enum KernelId {
     KID_GROUP_FLAGS,
     KID_GROUP_APPLY,
     KID_LAST_COLUMN,
+    KID_RADIX_SCATTER_LB, // fused pass: tile counts + look-back + scatter in one kernel
+    KID_GHIST_TEXT,       // the three digit counts of a phase, one read of the text
+    KID_GHIST_SCAN,
     // decode path (k_dec.hip)
     KID_DEC_BLOCK,   // header + Huffman
     KID_DEC_MTF,     // chunk_perm + compose + chunk_emit

@@ -747,6 +747,7 @@ extern "C" int bz_gpu_debug_code_lengths(bz_gpu_engine *g, const uint32_t *h_fre
 
 static const char *kKernelNames[KID_COUNT] = {"k_radix_hist", "k_radix_scan", "k_radix_scatter",
                                               "k_group_flags", "k_group_apply", "k_last_column",
+                                              "k_radix_scatter_lb", "k_ghist_text", "k_ghist_scan",
                                               "k_dec_block", "k_dec_mtf", "k_dec_tsort", "k_dec_walk_lengths",
                                               "k_dec_place", "k_dec_rle", "k_dec_crc"};
 

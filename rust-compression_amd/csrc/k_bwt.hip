@@ -1335,12 +1335,13 @@ static u32 next_epoch(hipStream_t st, const BwtArgs &a)
 
 template <int SRC, int BITS>
 static void fused_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const u32 *Kin, const u32 *Vin, u32 *Kout,
-                       u32 *Vout, u32 dpos, u64 elems, KernelProf *prof)
+                       u32 *Vout, u32 dpos, u64 elems, KernelProf *prof, u64 out_elems = ~0ull)
 {
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
     const u64 rd = (SRC == SRC_TEXTK) ? 4 : ((SRC == SRC_WALK) ? 5 : 8);
     const u32 e = next_epoch(st, a);
-    const int p = prof ? prof->begin(st, KID_RADIX_SCATTER, elems * (rd + 8)) : -1;
+    if (out_elems == ~0ull) out_elems = elems;
+    const int p = prof ? prof->begin(st, KID_RADIX_SCATTER_LB, elems * rd + out_elems * 8) : -1;
     hipLaunchKernelGGL((k_radix_scatter_lb<SRC, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Kin, Vin, Kout, Vout,
                        dpos, e);
     if (prof) prof->end(st, p);
@@ -1369,10 +1370,10 @@ static bool init_sort_fused(hipStream_t st, const BwtArgs &a, u64 total_n, Kerne
 {
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
     // the digit counts of key(j), once: both init phases sort the same multiset of keys
-    int p = prof ? prof->begin(st, KID_RADIX_HIST, total_n * 5) : -1;
+    int p = prof ? prof->begin(st, KID_GHIST_TEXT, total_n * 5) : -1;
     hipLaunchKernelGGL((k_ghist_text<B0, B1, B2>), grid, dim3(kSortThreads), 0, st, a, a.KB);
     if (prof) prof->end(st, p);
-    p = prof ? prof->begin(st, KID_RADIX_SCAN, (u64)a.nb * kTilesPerBlock * 3 * 1024 * 4) : -1;
+    p = prof ? prof->begin(st, KID_GHIST_SCAN, (u64)a.nb * kTilesPerBlock * 3 * 1024 * 4) : -1;
     hipLaunchKernelGGL(k_ghist_scan, dim3(a.nb), dim3(kSortThreads), 0, st, a, 3u, 1u << B0, 1u << B1, 1u << B2, 0u);
     if (prof) prof->end(st, p);
     // phase A: order by key(j); phase B: walk it, order by key(j - c) -> 2c symbols
@@ -1480,7 +1481,7 @@ int run_bwt(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 total_n, unsigne
             if (fused) {
                 // the keys are the group heads of the rotations that are not final: k_group_apply counted them
                 hipLaunchKernelGGL(k_ghist_scan, dim3(a.nb), dim3(kSortThreads), 0, st, a, 2u, 1024u, 1024u, 0u, 1u);
-                fused_pass<SRC_MM, 10>(st, a, 0, step, nullptr, nullptr, fK, fV, 0, total_n, prof);
+                fused_pass<SRC_MM, 10>(st, a, 0, step, nullptr, nullptr, fK, fV, 0, total_n, prof, m);
                 fused_pass<SRC_PAIRS, 10>(st, a, 10, step, fK, fV, cK, cV, 1, m, prof);
             } else {
                 radix_pass<SRC_MM, 10>(st, a, 0, step, nullptr, nullptr, fK, fV, total_n, prof, cK);
