@@ -31,7 +31,7 @@ PULL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 def build(force=False):
     """Compile oracle/libbz2oracle.so with gcc (building the checker is not using it)."""
     so = os.path.join(_HERE, "libbz2oracle.so")
-    src = [os.path.join(_HERE, f) for f in ("bz2_oracle.c", "sais_template.inc")]
+    src = [os.path.join(_HERE, f) for f in ("bz2_oracle.c", "sais_template.inc", "deflate_oracle.c")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "libbz2oracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -82,6 +82,29 @@ def lib():
         L.bzo_mtf_zle.restype = C.c_size_t
         L.bzo_mtf_zle.argtypes = [C.c_char_p, C.c_size_t, szp, C.POINTER(C.c_uint16),
                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        # Deflate path (oracle/deflate_oracle.c)
+        u32p = C.POINTER(C.c_uint32)
+        L.dfo_lzss_tokens.restype = C.c_size_t
+        L.dfo_lzss_tokens.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_size_t,
+                                      C.c_size_t, C.c_size_t, C.c_size_t, u32p, C.c_size_t]
+        L.dfo_convert.restype = None
+        L.dfo_convert.argtypes = [C.c_int, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+        L.dfo_enc_new.restype = C.c_void_p
+        L.dfo_enc_new.argtypes = [C.c_char_p, C.c_size_t]
+        L.dfo_enc_feed.restype = None
+        L.dfo_enc_feed.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int]
+        L.dfo_enc_output.restype = C.c_size_t
+        L.dfo_enc_output.argtypes = [C.c_void_p, C.POINTER(u8p)]
+        L.dfo_enc_blocks.restype = C.c_size_t
+        L.dfo_enc_blocks.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64))]
+        L.dfo_enc_free.restype = None
+        L.dfo_enc_free.argtypes = [C.c_void_p]
+        L.dfo_adler32.restype = C.c_uint32
+        L.dfo_adler32.argtypes = [C.c_char_p, C.c_size_t]
+        L.dfo_crc32.restype = C.c_uint32
+        L.dfo_crc32.argtypes = [C.c_char_p, C.c_size_t]
+        L.dfo_encode.restype = C.c_long
+        L.dfo_encode.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, u8p, C.c_size_t]
         _LIB = L
     return _LIB
 
@@ -247,3 +270,82 @@ def decode(z: bytes, cap: int = None):
     st = C.c_int(0)
     k = L.bzo_decode_buffer(z, len(z), out, cap, C.byref(st))
     return C.string_at(out, k), st.value
+
+
+# ---------------------------------------------------------------------------- Deflate path
+DEFLATE, ZLIB, GZIP = 0, 1, 2
+
+
+def lzss_tokens(data: bytes, dict_: bytes = b"", comparison: str = "deflate", window=0x8000, max_match=258,
+                min_match=3, lazy=3):
+    """LZSS codes of the reference's LzssEncoder: list of ("sym", byte) / ("ref", len, pos)."""
+    data, dict_ = bytes(data), bytes(dict_)
+    cap = len(data) + 16
+    buf = (C.c_uint32 * (2 * cap))()
+    n = lib().dfo_lzss_tokens(data, len(data), dict_, len(dict_), 1 if comparison == "lzss_tests" else 0, window,
+                              max_match, min_match, lazy, buf, cap)
+    assert n <= cap
+    return [("ref", buf[2 * i], buf[2 * i + 1]) if buf[2 * i] else ("sym", buf[2 * i + 1]) for i in range(n)]
+
+
+def lzss_tokens_raw(data: bytes):
+    """Deflate-parameter LZSS codes as a numpy uint32 array [n, 2] of (len, pos); len 0: literal pos."""
+    import numpy as np
+    data = bytes(data)
+    cap = len(data) + 16
+    buf = np.zeros((cap, 2), dtype=np.uint32)
+    n = lib().dfo_lzss_tokens(data, len(data), b"", 0, 0, 0x8000, 258, 3, 3,
+                              buf.ctypes.data_as(C.POINTER(C.c_uint32)), cap)
+    return buf[:n]
+
+
+def deflate_convert(which: int, value: int):
+    c, e, b = C.c_uint(0), C.c_uint(0), C.c_uint(0)
+    lib().dfo_convert(which, value, C.byref(c), C.byref(e), C.byref(b))
+    return c.value, e.value, b.value
+
+
+class DeflateEncoder:
+    """The reference's Inflater fed iterator by iterator: feed(bytes, action)."""
+
+    def __init__(self, dict_: bytes = b""):
+        self._h = lib().dfo_enc_new(bytes(dict_), len(dict_))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().dfo_enc_free(self._h)
+            self._h = None
+
+    def feed(self, data: bytes, action: int):
+        lib().dfo_enc_feed(self._h, bytes(data), len(data), action)
+
+    def output(self) -> bytes:
+        p = C.POINTER(C.c_uint8)()
+        n = lib().dfo_enc_output(self._h, C.byref(p))
+        return C.string_at(p, n) if n else b""
+
+    def blocks(self):
+        """[(tokens, bytes, btype, bits)] of the blocks written so far."""
+        p = C.POINTER(C.c_uint64)()
+        n = lib().dfo_enc_blocks(self._h, C.byref(p))
+        return [tuple(p[4 * i + k] for k in range(4)) for i in range(n)]
+
+
+def deflate_encode(data: bytes, kind: int = DEFLATE, dict_: bytes = b"") -> bytes:
+    data, dict_ = bytes(data), bytes(dict_)
+    cap = len(data) + len(data) // 8 + 1024
+    out = (C.c_uint8 * cap)()
+    n = lib().dfo_encode(kind, data, len(data), dict_, len(dict_), out, cap)
+    if n < 0:
+        cap = -n
+        out = (C.c_uint8 * cap)()
+        n = lib().dfo_encode(kind, data, len(data), dict_, len(dict_), out, cap)
+    return bytes(out[:n])
+
+
+def adler32(data: bytes) -> int:
+    return lib().dfo_adler32(bytes(data), len(data))
+
+
+def crc32_ieee(data: bytes) -> int:
+    return lib().dfo_crc32(bytes(data), len(data))

@@ -1,0 +1,128 @@
+"""The Deflate oracle (oracle/deflate_oracle.c) against every known-answer vector the reference's
+tests hold for the path (tests/golden/deflate_vectors.json, written by make_deflate_vectors.py),
+and against zlib as an independent decoder."""
+import json
+import os
+import random
+import zlib
+
+import pytest
+
+from oracle import oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+VEC = json.load(open(os.path.join(HERE, "golden", "deflate_vectors.json")))
+
+
+def expand(spec):
+    out = bytearray()
+    for s in spec or []:
+        if s[0] == "bytes":
+            out += bytes(s[1])
+        elif s[0] == "cycle":
+            lo, hi, n = s[1:]
+            out += bytes((lo + i % (hi - lo)) & 0xFF for i in range(n))
+        elif s[0] == "repeat":
+            out += bytes([s[1]]) * s[2]
+    return bytes(out)
+
+
+def pack_lsb(items):
+    acc, cnt, out = 0, 0, bytearray()
+    for v, n in items:
+        acc |= (v & ((1 << n) - 1)) << cnt
+        cnt += n
+        while cnt >= 8:
+            out.append(acc & 0xFF)
+            acc >>= 8
+            cnt -= 8
+    if cnt:
+        out.append(acc & 0xFF)
+    return bytes(out)
+
+
+@pytest.mark.parametrize("v", VEC["lzss"], ids=lambda v: v["name"])
+def test_lzss_token_vectors(v):
+    want = []
+    for tok, count in v["tokens"]:
+        want += [tuple(tok)] * count
+    got = oracle.lzss_tokens(expand(v["input"]), expand(v.get("dict")), v["comparison"], v["window"], v["max_match"],
+                             v["min_match"], v["lazy"])
+    assert got == want
+
+
+@pytest.mark.parametrize("v", VEC["deflate"], ids=lambda v: v["name"])
+def test_deflate_vectors(v):
+    want = bytes(v["bytes"]) if "bytes" in v else pack_lsb(v["bits"])
+    data = expand(v["input"])
+    got = oracle.deflate_encode(data)
+    assert got == want
+    assert zlib.decompress(got, -15) == data
+
+
+def test_code_tables():
+    for ln, pos, lcode, lext, lbits, dcode, dext, dbits in VEC["codes"]:
+        c, e, b = oracle.deflate_convert(0, ln - 3)
+        assert (c + 257, e, b) == (lcode, lext, lbits)
+        c, e, b = oracle.deflate_convert(1, pos)
+        assert (c, e, b) == (dcode, dext, dbits)
+
+
+@pytest.mark.parametrize("v", VEC["containers"], ids=lambda v: v["name"])
+def test_container_vectors(v):
+    kind = oracle.ZLIB if v["kind"] == "zlib" else oracle.GZIP
+    got = oracle.deflate_encode(expand(v["input"]), kind, expand(v.get("dict")))
+    assert got == bytes(v["bytes"])
+
+
+def test_checksums():
+    c = VEC["checksums"]["crc32_ieee_reverse"]
+    assert oracle.crc32_ieee(expand(c["input"])) == c["value"]
+    rnd = random.Random(5)
+    for n in (0, 1, 5549, 5550, 5551, 70000):
+        d = bytes(rnd.getrandbits(8) for _ in range(n))
+        assert oracle.adler32(d) == zlib.adler32(d)
+        assert oracle.crc32_ieee(d) == zlib.crc32(d)
+
+
+def _inputs():
+    rnd = random.Random(11)
+    words = [bytes(rnd.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(rnd.randint(1, 9))) for _ in range(300)]
+    text = b" ".join(rnd.choice(words) for _ in range(60000))
+    yield "text", text
+    yield "random", bytes(rnd.getrandbits(8) for _ in range(200000))
+    yield "runs", b"".join(bytes([rnd.randrange(4)]) * rnd.randint(1, 700) for _ in range(2000))
+    yield "dna", bytes(rnd.choice(b"ACGT") for _ in range(150000))
+    yield "period", bytes(range(256)) * 600
+    yield "short", b"hello hello hello"
+    yield "mixed", text[:70000] + bytes(rnd.getrandbits(8) for _ in range(70000)) + text[:70000]
+
+
+@pytest.mark.parametrize("name,data", list(_inputs()), ids=[n for n, _ in _inputs()])
+def test_streams_decode_with_zlib(name, data):
+    z = oracle.deflate_encode(data)
+    assert zlib.decompress(z, -15) == data
+    assert zlib.decompress(oracle.deflate_encode(data, oracle.ZLIB)) == data
+    import gzip
+    assert gzip.decompress(oracle.deflate_encode(data, oracle.GZIP)) == data
+    # the token stream re-expands to the input
+    out = bytearray()
+    for t in oracle.lzss_tokens(data):
+        if t[0] == "sym":
+            out.append(t[1])
+        else:
+            for _ in range(t[1]):
+                out.append(out[-1 - t[2]])
+    assert bytes(out) == data
+
+
+def test_blocks_and_segments():
+    rnd = random.Random(3)
+    data = bytes(rnd.choice(b"ab \n") for _ in range(300000))
+    e = oracle.DeflateEncoder()
+    e.feed(data[:100000], oracle.ACTION_RUN)
+    e.feed(data[100000:], oracle.ACTION_FINISH)
+    assert e.output() == oracle.deflate_encode(data)
+    blocks = e.blocks()
+    assert sum(b[1] for b in blocks) == len(data) and all(b[1] <= 0xFFFF for b in blocks)
+    assert sum(b[3] for b in blocks) <= 8 * len(e.output())
