@@ -283,6 +283,64 @@ long bz_dec_read(bz_dec *d, uint8_t *out, size_t cap);
 size_t bz_dec_pending(const bz_dec *d);
 void bz_dec_destroy(bz_dec *d);
 
+/* ========================================================================
+ * 4. Deflate / zlib / gzip ENCODE
+ *
+ * Replaces `Inflater` (src/deflate/encoder.rs:92-260: LzssEncoder with window
+ * 0x8000, matches 3..258, lazy level 3, hash chains of 255, src/lzss/encoder.rs,
+ * src/lzss/slidedict.rs; blocks of <= 0xFFFF bytes, stored / fixed / dynamic
+ * chosen by size, src/deflate/encoder.rs:454-547), `ZlibEncoder`
+ * (src/zlib/encoder.rs:55-157: 78 DA, Adler-32 big endian) and `GZipEncoder`
+ * (src/gzip/encoder.rs:50-135: 10-byte header, CRC-32 and ISIZE little endian),
+ * driven with Action::Finish.  The stream is the reference's, bit for bit.
+ * `kind`: 0 raw Deflate, 1 zlib, 2 gzip.
+ * Not offered on this path (refused with BZ_E_PARAM, never approximated):
+ * Action::Flush inside a stream, preset dictionaries (Inflater::with_dict),
+ * inputs of 2 GiB or more in one call.
+ * ======================================================================== */
+#define DF_KIND_DEFLATE 0
+#define DF_KIND_ZLIB 1
+#define DF_KIND_GZIP 2
+
+/* Upper bound of the stream length for n input bytes (every block stored). */
+size_t df_encode_bound(size_t n);
+/* d_in[n] (HBM, 4-byte aligned) -> d_out (HBM, cap bytes); *out_len = stream
+ * bytes.  d_out == NULL: length only.  Uses the engine's stream; workspace
+ * (about 17 bytes per input byte) is created by the first call and kept. */
+int df_gpu_encode_device(bz_gpu_engine *g, int kind, const void *d_in, size_t n,
+                         void *d_out, size_t cap, size_t *out_len);
+/* Seconds of GPU time of the last call by stage (HIP events): [0] hash chains
+ * (sort) [1] matches [2] parse [3] blocks + tables [4] emission + checksums [5] total. */
+int df_gpu_last_timings(bz_gpu_engine *g, double out_seconds[6]);
+/* [0] blocks [1] stored [2] fixed [3] dynamic [4] tables that took the
+ * length-limited path [5] stream bytes */
+int df_gpu_last_stats(bz_gpu_engine *g, uint64_t out[8]);
+/* Test hooks: the LZSS codes of the last call in stream order as (len, pos)
+ * pairs, len 0 = the literal `pos` (what LzssEncoder::next yields,
+ * src/lzss/encoder.rs:203-234); per block (start offset, bytes, BTYPE, bits). */
+int df_gpu_debug_codes(bz_gpu_engine *g, const void *d_in, size_t n,
+                       uint32_t *out_pairs, size_t cap, size_t *count);
+int df_gpu_debug_blocks(bz_gpu_engine *g, uint64_t *out4, size_t cap, size_t *count);
+
+/* One-shot over host buffers: `in.iter().cloned().encode(&mut Inflater::new(),
+ * Action::Finish)` collected (or ZlibEncoder / GZipEncoder).  *out is malloc'ed,
+ * release with bz_free. */
+int df_encode_buffer(int kind, int device, const uint8_t *in, size_t in_len,
+                     uint8_t **out, size_t *out_len);
+
+/* Streaming context == the Encoder::next contract of the three encoders:
+ * df_enc_write feeds bytes, df_enc_end(action) marks the end of an input
+ * iterator (0 Run: nothing happens; 2 Finish: the stream is produced; 1 Flush:
+ * BZ_E_PARAM), df_enc_read drains.  The whole input is kept until Finish: one
+ * window and one bit string run through all of it. */
+typedef struct df_enc df_enc;
+int df_enc_create(df_enc **out, int kind, int device);
+int df_enc_write(df_enc *e, const uint8_t *in, size_t n);
+int df_enc_end(df_enc *e, int action);
+long df_enc_read(df_enc *e, uint8_t *out, size_t cap);
+size_t df_enc_pending(const df_enc *e);
+void df_enc_destroy(df_enc *e);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,9 @@ EXPORTS = [
     "bz_gpu_debug_bwt", "bz_gpu_debug_code_lengths", "bz_gpu_debug_block_stats",
     "bz_gpu_decode_device", "bz_gpu_decode_device_sharded", "bz_gpu_last_decode_timings", "bz_gpu_last_decode_stats", "bz_decode_buffer",
     "bz_dec_create", "bz_dec_write", "bz_dec_end", "bz_dec_read", "bz_dec_pending", "bz_dec_destroy",
+    "df_encode_bound", "df_gpu_encode_device", "df_gpu_last_timings", "df_gpu_last_stats", "df_gpu_debug_codes",
+    "df_gpu_debug_blocks", "df_encode_buffer",
+    "df_enc_create", "df_enc_write", "df_enc_end", "df_enc_read", "df_enc_pending", "df_enc_destroy",
 ]
 
 
@@ -177,6 +180,23 @@ def lib():
     L.bz_dec_pending.argtypes = [vp]
     L.bz_dec_destroy.restype = None
     L.bz_dec_destroy.argtypes = [vp]
+    L.df_encode_bound.restype = sz
+    L.df_encode_bound.argtypes = [sz]
+    L.df_gpu_encode_device.argtypes = [vp, C.c_int, vp, sz, vp, sz, szp]
+    L.df_gpu_last_timings.argtypes = [vp, C.POINTER(C.c_double)]
+    L.df_gpu_last_stats.argtypes = [vp, u64p]
+    L.df_gpu_debug_codes.argtypes = [vp, vp, sz, u32p, sz, szp]
+    L.df_gpu_debug_blocks.argtypes = [vp, u64p, sz, szp]
+    L.df_encode_buffer.argtypes = [C.c_int, C.c_int, C.c_char_p, sz, C.POINTER(u8p), szp]
+    L.df_enc_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+    L.df_enc_write.argtypes = [vp, C.c_char_p, sz]
+    L.df_enc_end.argtypes = [vp, C.c_int]
+    L.df_enc_read.restype = C.c_long
+    L.df_enc_read.argtypes = [vp, u8p, sz]
+    L.df_enc_pending.restype = sz
+    L.df_enc_pending.argtypes = [vp]
+    L.df_enc_destroy.restype = None
+    L.df_enc_destroy.argtypes = [vp]
     _LIB = L
     return L
 
@@ -288,6 +308,104 @@ def compress(data, level=9, device=0):
         return C.string_at(out, n.value)
     finally:
         lib().bz_free(out)
+
+
+# ---------------------------------------------------------------------------- Deflate / zlib / gzip
+DEFLATE, ZLIB, GZIP = 0, 1, 2
+
+
+class Inflater:
+    """`Inflater` (src/deflate/encoder.rs:92-260) over the C ABI's streaming context: the reference's
+    name for its Deflate ENCODER.  Action.RUN accumulates, Action.FINISH produces the stream;
+    Action.FLUSH is not offered on this path (CompressionError BZ_E_PARAM)."""
+
+    KIND = DEFLATE
+    CHUNK = 1 << 20
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().df_enc_create(C.byref(self._h), self.KIND, device))
+        self._buf = (C.c_uint8 * 65536)()
+        self._ready = b""
+        self._pos = 0
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _LIB is not None:
+            _LIB.df_enc_destroy(self._h)
+            self._h = None
+
+    def _refill(self):
+        k = lib().df_enc_read(self._h, self._buf, len(self._buf))
+        if k < 0:
+            raise CompressionError(k)
+        self._ready = C.string_at(self._buf, k)
+        self._pos = 0
+        return k
+
+    def next(self, it, action):
+        """One `Encoder::next(iter, action)` call: an int byte, or None."""
+        if self._pos >= len(self._ready) and self._refill() == 0:
+            while True:
+                chunk = bytearray()
+                for b in it:
+                    chunk.append(b)
+                    if len(chunk) >= self.CHUNK:
+                        break
+                if chunk:
+                    _check(lib().df_enc_write(self._h, bytes(chunk), len(chunk)))
+                if len(chunk) < self.CHUNK:
+                    _check(lib().df_enc_end(self._h, int(action)))
+                    break
+            if self._refill() == 0:
+                return None
+        b = self._ready[self._pos]
+        self._pos += 1
+        return b
+
+    def write(self, data):
+        _check(lib().df_enc_write(self._h, bytes(data), len(data)))
+
+    def end(self, action):
+        _check(lib().df_enc_end(self._h, int(action)))
+
+    def read_all(self):
+        out = bytearray(self._ready[self._pos:])
+        self._ready, self._pos = b"", 0
+        while self._refill():
+            out += self._ready
+        self._ready, self._pos = b"", 0
+        return bytes(out)
+
+    def encode_all(self, data, action=Action.FINISH):
+        self.write(data)
+        self.end(action)
+        return self.read_all()
+
+
+class ZlibEncoder(Inflater):
+    """`ZlibEncoder` (src/zlib/encoder.rs:55-157)."""
+    KIND = ZLIB
+
+
+class GZipEncoder(Inflater):
+    """`GZipEncoder` (src/gzip/encoder.rs:50-135)."""
+    KIND = GZIP
+
+
+def deflate_compress(data, kind=DEFLATE, device=0):
+    """One-shot over host buffers (df_encode_buffer)."""
+    data = bytes(data)
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t(0)
+    _check(lib().df_encode_buffer(kind, device, data, len(data), C.byref(out), C.byref(n)))
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        lib().bz_free(out)
+
+
+def deflate_bound(n):
+    return lib().df_encode_bound(n)
 
 
 _DECODER_VERDICTS = (BZ_E_DATA, BZ_E_MAGIC_FIRST, BZ_E_MAGIC)
@@ -496,6 +614,38 @@ class GpuEngine:
         if rc != BZ_OK and rc not in _DECODER_VERDICTS:
             raise CompressionError(rc)
         return out_len.value, off.value, tot.value, rc
+
+    DEFLATE_STAGES = ("hash_chains", "matches", "parse", "blocks_tables", "emit_checksums", "total")
+
+    def deflate_encode_device(self, kind, d_in, n, d_out, cap):
+        out_len = C.c_size_t(0)
+        _check(lib().df_gpu_encode_device(self._h, kind, d_in, n, d_out, cap, C.byref(out_len)))
+        return out_len.value
+
+    def deflate_timings(self):
+        t = (C.c_double * 6)()
+        _check(lib().df_gpu_last_timings(self._h, t))
+        return dict(zip(self.DEFLATE_STAGES, t))
+
+    def deflate_stats(self):
+        s = (C.c_uint64 * 8)()
+        _check(lib().df_gpu_last_stats(self._h, s))
+        return dict(blocks=s[0], stored=s[1], fixed=s[2], dynamic=s[3], limited_tables=s[4], stream_bytes=s[5])
+
+    def deflate_debug_codes(self, d_in, n):
+        """numpy uint32 [count, 2] of (len, pos); len 0: literal pos"""
+        import numpy as np
+        buf = np.zeros((n + 1, 2), dtype=np.uint32)
+        cnt = C.c_size_t(0)
+        _check(lib().df_gpu_debug_codes(self._h, d_in, n, buf.ctypes.data_as(C.POINTER(C.c_uint32)), n + 1, C.byref(cnt)))
+        return buf[:cnt.value]
+
+    def deflate_debug_blocks(self):
+        cnt = C.c_size_t(0)
+        _check(lib().df_gpu_debug_blocks(self._h, None, 0, C.byref(cnt)))
+        buf = (C.c_uint64 * (4 * max(cnt.value, 1)))()
+        _check(lib().df_gpu_debug_blocks(self._h, buf, cnt.value, C.byref(cnt)))
+        return [tuple(buf[4 * i + k] for k in range(4)) for i in range(cnt.value)]
 
     def decode_timings(self):
         t = (C.c_double * 5)()

@@ -1,0 +1,402 @@
+// deflate_engine.hip -- orchestration and C ABI of the Deflate / zlib / gzip encode path
+// (include/bz2_mi355x.h section 4).  Kernels: k_deflate.hip.
+//
+// Replaces, behind the reference's Encoder surface: Inflater (deflate/encoder.rs:92-260), ZlibEncoder
+// (zlib/encoder.rs:55-157), GZipEncoder (gzip/encoder.rs:50-135) driven with Action::Finish (and
+// Action::Run in front of it).  Action::Flush in the middle of a stream and preset dictionaries are
+// not offered on this path yet and are refused with BZ_E_PARAM, never approximated.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "engine_state.h"
+#include "k_deflate.h"
+
+using namespace dfgpu;
+
+struct DfWorkspace {
+    DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, prevd, tabs, ents, bstart, nb, blocks, lens, hdr, lm, total,
+        stream, asum, bsum, crc;
+    size_t sort_tmp_bytes = 0;
+    double t_stage[6] = {0, 0, 0, 0, 0, 0}; // chains, matches, parse, blocks, emit, total
+    u64 stats[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // blocks, stored, fixed, dynamic, limited tables, stream bytes
+    hipEvent_t ev[7] = {};
+    bool ev_ready = false;
+    std::vector<DfBlock> h_blocks;
+    std::vector<u64> h_bstart;
+};
+
+void df_workspace_free(DfWorkspace *w)
+{
+    if (!w) return;
+    DevBuf *all[] = {&w->keys_in, &w->keys_out, &w->vals_in, &w->vals_out, &w->sort_tmp, &w->prevd, &w->tabs, &w->ents,
+                     &w->bstart, &w->nb, &w->blocks, &w->lens, &w->hdr, &w->lm, &w->total, &w->stream, &w->asum, &w->bsum,
+                     &w->crc};
+    for (DevBuf *b : all) b->release();
+    if (w->ev_ready)
+        for (hipEvent_t e : w->ev) (void)hipEventDestroy(e);
+    delete w;
+}
+
+extern "C" size_t df_encode_bound(size_t n)
+{
+    // stored blocks are the worst case: 5 bytes per 0xFFFF, plus container, plus word slack for the bit writer
+    return n + 5 * (n / 0xFFFF + 2) + 64;
+}
+
+// ---- reflected CRC-32 arithmetic on the host (crc32.rs:40-55): polynomials with bit 31 = x^0
+static u32 gf_mul_reflected(u32 a, u32 b)
+{
+    u32 p = 0;
+    for (u32 m = 1u << 31; m != 0 && a != 0; m >>= 1) { // a: coefficients from x^0 (bit 31) upwards
+        if (a & m) {
+            p ^= b;
+            a &= ~m;
+        }
+        b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1; // b * x
+    }
+    return p;
+}
+static u32 gf_xpow8_reflected(u64 nbytes) // x^(8 * nbytes) mod P
+{
+    u32 r = 1u << 31, sq = 1u << 23; // x^0, x^8
+    while (nbytes) {
+        if (nbytes & 1) r = gf_mul_reflected(r, sq);
+        sq = gf_mul_reflected(sq, sq);
+        nbytes >>= 1;
+    }
+    return r;
+}
+
+static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, u8 *d_out, size_t cap, size_t *out_len)
+{
+    if (n >= (1ull << 31)) return BZ_E_PARAM; // positions and bit offsets are sized for < 2 GiB per call
+    HIPCHK(hipSetDevice(g->device));
+    if (!g->df) g->df = new DfWorkspace();
+    DfWorkspace *w = g->df;
+    hipStream_t st = g->st;
+    if (!w->ev_ready) {
+        for (hipEvent_t &e : w->ev) HIPCHK(hipEventCreate(&e));
+        w->ev_ready = true;
+    }
+    const u64 npad = n + 16;
+    const u32 ntiles = (u32)((n + kPTile - 1) / kPTile) + (n == 0 ? 1u : 0u);
+    std::vector<u32> counts;
+    counts.push_back(ntiles);
+    while (counts.back() > 1) counts.push_back((counts.back() + kFan - 1) / kFan);
+    const u32 nlevels = (u32)counts.size();
+    size_t tab_words = 0, ent_words = 0;
+    for (u32 c : counts) { tab_words += (size_t)c * kEntries; ent_words += c + 8; }
+    const u32 bcap = (u32)(n / (kBlockMax - 300) + 2);
+
+    int rc;
+    {
+        size_t t = 0;
+        if (df_sort_temp_bytes(n, &t) != 0) return BZ_E_UNEXPECTED;
+        w->sort_tmp_bytes = t;
+    }
+    if ((rc = w->keys_in.ensure(npad * 2)) != BZ_OK) return rc;   // later: step[]
+    if ((rc = w->keys_out.ensure(npad * 2)) != BZ_OK) return rc;
+    if ((rc = w->vals_in.ensure(npad * 4)) != BZ_OK) return rc;   // later: M[]
+    if ((rc = w->vals_out.ensure(npad * 4)) != BZ_OK) return rc;  // later: code[]
+    if ((rc = w->sort_tmp.ensure(w->sort_tmp_bytes + 256)) != BZ_OK) return rc;
+    if ((rc = w->prevd.ensure(npad * 2)) != BZ_OK) return rc;
+    if ((rc = w->tabs.ensure(tab_words * 2 + 64)) != BZ_OK) return rc;
+    if ((rc = w->ents.ensure(ent_words * 2 + 64)) != BZ_OK) return rc;
+    if ((rc = w->bstart.ensure(((size_t)bcap + 2) * 8)) != BZ_OK) return rc;
+    if ((rc = w->nb.ensure(64)) != BZ_OK) return rc;
+    if ((rc = w->blocks.ensure((size_t)bcap * sizeof(DfBlock))) != BZ_OK) return rc;
+    if ((rc = w->lens.ensure((size_t)bcap * 320)) != BZ_OK) return rc;
+    if ((rc = w->hdr.ensure((size_t)bcap * kHdrWords * 4)) != BZ_OK) return rc;
+    if ((rc = w->lm.ensure((size_t)bcap * kDfLmWords * 4)) != BZ_OK) return rc;
+    if ((rc = w->total.ensure(64)) != BZ_OK) return rc;
+    const size_t bound = df_encode_bound(n);
+    if ((rc = w->stream.ensure(bound + 64)) != BZ_OK) return rc;
+    const u32 npieces = (u32)((n + kSumPiece - 1) / kSumPiece);
+    if (kind != 0) {
+        if ((rc = w->asum.ensure((size_t)(npieces + 1) * 8)) != BZ_OK) return rc;
+        if ((rc = w->bsum.ensure((size_t)(npieces + 1) * 8)) != BZ_OK) return rc;
+        if ((rc = w->crc.ensure((size_t)(npieces + 1) * 256 * 4)) != BZ_OK) return rc;
+    }
+
+    std::vector<u16 *> tabs(nlevels), ents(nlevels);
+    {
+        u16 *t = w->tabs.as<u16>(), *e = w->ents.as<u16>();
+        for (u32 l = 0; l < nlevels; ++l) {
+            tabs[l] = t; t += (size_t)counts[l] * kEntries;
+            ents[l] = e; e += counts[l] + 8;
+        }
+    }
+    u16 *step = w->keys_in.as<u16>();
+    u32 *M = w->vals_in.as<u32>();
+    u32 *code = w->vals_out.as<u32>();
+
+    HIPCHK(hipEventRecord(w->ev[0], st));
+    HIPCHK(hipMemsetAsync(w->stream.p, 0, bound + 64, st));
+    if (df_launch_chains(st, d_in, n, w->keys_in.as<u16>(), w->keys_out.as<u16>(), w->vals_in.as<u32>(), w->vals_out.as<u32>(),
+                         w->sort_tmp.p, w->sort_tmp_bytes, w->prevd.as<u16>()) != 0)
+        return BZ_E_UNEXPECTED;
+    HIPCHK(hipEventRecord(w->ev[1], st));
+    if (df_launch_match(st, d_in, w->prevd.as<u16>(), n, M) != 0) return BZ_E_UNEXPECTED;
+    HIPCHK(hipEventRecord(w->ev[2], st));
+    if (df_launch_parse(st, M, n, step, tabs.data(), ents.data(), counts.data(), nlevels, code) != 0) return BZ_E_UNEXPECTED;
+    HIPCHK(hipEventRecord(w->ev[3], st));
+    if (df_launch_blocks(st, d_in, code, n, w->bstart.as<u64>(), w->nb.as<u32>(), bcap, w->blocks.as<DfBlock>(),
+                         w->lens.as<u8>(), w->hdr.as<u32>(), w->lm.as<u32>(), w->total.as<u64>()) != 0)
+        return BZ_E_UNEXPECTED;
+    HIPCHK(hipEventRecord(w->ev[4], st));
+    if (df_launch_emit(st, d_in, code, w->bstart.as<u64>(), w->nb.as<u32>(), bcap, w->blocks.as<DfBlock>(), w->lens.as<u8>(),
+                       w->hdr.as<u32>(), w->stream.as<u32>()) != 0)
+        return BZ_E_UNEXPECTED;
+    if (kind != 0 && df_launch_sums(st, d_in, n, w->asum.as<u64>(), w->bsum.as<u64>(), w->crc.as<u32>()) != 0)
+        return BZ_E_UNEXPECTED;
+    HIPCHK(hipEventRecord(w->ev[5], st));
+    u64 total_bits = 0;
+    u32 nb = 0;
+    HIPCHK(hipMemcpyAsync(&total_bits, w->total.p, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&nb, w->nb.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (nb == 0xFFFFFFFFu || nb > bcap) {
+        fprintf(stderr, "bz2_mi355x: deflate parse produced no code start inside a block window (internal error)\n");
+        return BZ_E_UNEXPECTED;
+    }
+    const u64 body = (total_bits + 7) >> 3;
+
+    // container (zlib/encoder.rs:63-72,118-156; gzip/encoder.rs:62-75,88-134)
+    u8 head[10], tail[8];
+    size_t nhead = 0, ntail = 0;
+    if (kind == 1) {
+        head[0] = 0x78; head[1] = 0xDA; nhead = 2;
+    } else if (kind == 2) {
+        const u8 h[10] = {0x1F, 0x8B, 0x08, 0, 0, 0, 0, 0, 0, 0xFF};
+        memcpy(head, h, 10); nhead = 10;
+    }
+    if (kind != 0) {
+        std::vector<u64> a(npieces), b(npieces);
+        std::vector<u32> c((size_t)npieces * 256);
+        if (npieces) {
+            HIPCHK(hipMemcpy(a.data(), w->asum.p, (size_t)npieces * 8, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(b.data(), w->bsum.p, (size_t)npieces * 8, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(c.data(), w->crc.p, (size_t)npieces * 256 * 4, hipMemcpyDeviceToHost));
+        }
+        if (kind == 1) { // adler32.rs:20-66
+            u64 A = 1, B = 0;
+            for (u32 t = 0; t < npieces; ++t) {
+                const u64 len = (t + 1 == npieces) ? n - (u64)t * kSumPiece : kSumPiece;
+                B = (B + (len % 65521) * A + b[t]) % 65521;
+                A = (A + a[t]) % 65521;
+            }
+            const u32 h = (u32)((B << 16) | A);
+            tail[0] = (u8)(h >> 24); tail[1] = (u8)(h >> 16); tail[2] = (u8)(h >> 8); tail[3] = (u8)h; ntail = 4;
+        } else { // CRC-32 (reflected), little endian, then ISIZE
+            const u32 x256 = gf_xpow8_reflected(256);
+            u32 raw = 0; // register for a zero initial value over the whole input
+            for (u32 t = 0; t < npieces; ++t) {
+                const u64 len = (t + 1 == npieces) ? n - (u64)t * kSumPiece : kSumPiece;
+                for (u32 s = 0; (u64)s * 256 < len; ++s) {
+                    const u64 sl = (len - (u64)s * 256) < 256 ? (len - (u64)s * 256) : 256;
+                    raw = gf_mul_reflected(raw, sl == 256 ? x256 : gf_xpow8_reflected(sl)) ^ c[(size_t)t * 256 + s];
+                }
+            }
+            const u32 crc = raw ^ gf_mul_reflected(0xFFFFFFFFu, gf_xpow8_reflected(n)) ^ 0xFFFFFFFFu;
+            const u32 isz = (u32)n;
+            for (int i = 0; i < 4; ++i) tail[i] = (u8)(crc >> (8 * i));
+            for (int i = 0; i < 4; ++i) tail[4 + i] = (u8)(isz >> (8 * i));
+            ntail = 8;
+        }
+    }
+    const size_t need = nhead + body + ntail;
+    *out_len = need;
+    if (d_out) {
+        if (need > cap) return BZ_E_CAPACITY;
+        HIPCHK(hipMemcpyAsync(d_out + nhead, w->stream.p, body, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (nhead) HIPCHK(hipMemcpy(d_out, head, nhead, hipMemcpyHostToDevice));
+        if (ntail) HIPCHK(hipMemcpy(d_out + nhead + body, tail, ntail, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipEventRecord(w->ev[6], st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < 5; ++i) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, w->ev[i], w->ev[i + 1]);
+        w->t_stage[i] = ms * 1e-3;
+    }
+    {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, w->ev[0], w->ev[6]);
+        w->t_stage[5] = ms * 1e-3;
+    }
+    // statistics of the last call (tests, bench)
+    w->h_blocks.resize(nb);
+    w->h_bstart.resize((size_t)nb + 1);
+    HIPCHK(hipMemcpy(w->h_blocks.data(), w->blocks.p, (size_t)nb * sizeof(DfBlock), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(w->h_bstart.data(), w->bstart.p, ((size_t)nb + 1) * 8, hipMemcpyDeviceToHost));
+    memset(w->stats, 0, sizeof(w->stats));
+    w->stats[0] = nb;
+    for (const DfBlock &bi : w->h_blocks) {
+        w->stats[1 + (bi.btype < 3 ? bi.btype : 0)] += 1;
+        w->stats[4] += bi.lm;
+    }
+    w->stats[5] = need;
+    return BZ_OK;
+}
+
+// ---- C ABI ------------------------------------------------------------------------------------------------
+extern "C" int df_gpu_encode_device(bz_gpu_engine *g, int kind, const void *d_in, size_t n, void *d_out, size_t cap,
+                                    size_t *out_len)
+{
+    if (!g || !out_len || (!d_in && n) || kind < 0 || kind > 2) return BZ_E_PARAM;
+    if (n && ((uintptr_t)d_in & 3u)) return BZ_E_PARAM;
+    *out_len = 0;
+    return df_encode_core(g, kind, static_cast<const u8 *>(d_in), n, static_cast<u8 *>(d_out), cap, out_len);
+}
+
+extern "C" int df_gpu_last_timings(bz_gpu_engine *g, double out_seconds[6])
+{
+    if (!g || !out_seconds) return BZ_E_PARAM;
+    for (int i = 0; i < 6; ++i) out_seconds[i] = g->df ? g->df->t_stage[i] : 0.0;
+    return BZ_OK;
+}
+
+extern "C" int df_gpu_last_stats(bz_gpu_engine *g, uint64_t out[8])
+{
+    if (!g || !out) return BZ_E_PARAM;
+    for (int i = 0; i < 8; ++i) out[i] = g->df ? g->df->stats[i] : 0;
+    return BZ_OK;
+}
+
+// test hook: the LZSS codes of the last call in stream order as (len, pos) pairs, len 0 = literal `pos`
+// (what LzssEncoder::next yields, lzss/encoder.rs:203-234).  Returns the code count through *count.
+extern "C" int df_gpu_debug_codes(bz_gpu_engine *g, const void *d_in, size_t n, uint32_t *out_pairs, size_t cap, size_t *count)
+{
+    if (!g || !g->df || !count) return BZ_E_PARAM;
+    DfWorkspace *w = g->df;
+    std::vector<u32> code(n);
+    std::vector<u8> in(n);
+    if (n) {
+        HIPCHK(hipMemcpy(code.data(), w->vals_out.p, n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(in.data(), d_in, n, hipMemcpyDeviceToHost));
+    }
+    size_t k = 0;
+    for (size_t q = 0; q < n; ++q) {
+        const u32 c = code[q];
+        if (!(c & F_CODE)) continue;
+        if (k < cap) {
+            if (c & F_REF) { out_pairs[2 * k] = c & 511u; out_pairs[2 * k + 1] = (c >> 9) & 32767u; }
+            else { out_pairs[2 * k] = 0; out_pairs[2 * k + 1] = in[q]; }
+        }
+        ++k;
+    }
+    *count = k;
+    return BZ_OK;
+}
+
+// test hook: (tokens are not counted here) per block: start offset, bytes, btype, bits
+extern "C" int df_gpu_debug_blocks(bz_gpu_engine *g, uint64_t *out4, size_t cap, size_t *count)
+{
+    if (!g || !g->df || !count) return BZ_E_PARAM;
+    DfWorkspace *w = g->df;
+    *count = w->h_blocks.size();
+    for (size_t k = 0; k < w->h_blocks.size() && k < cap; ++k) {
+        const DfBlock &b = w->h_blocks[k];
+        out4[4 * k] = w->h_bstart[k];
+        out4[4 * k + 1] = b.bytes;
+        out4[4 * k + 2] = b.btype;
+        out4[4 * k + 3] = b.btype == 0 ? (((b.bit_off + 3 + 7) & ~7ull) + 32 + 8ull * b.bytes - b.bit_off) : b.bits;
+    }
+    return BZ_OK;
+}
+
+extern "C" int df_encode_buffer(int kind, int device, const uint8_t *in, size_t in_len, uint8_t **out, size_t *out_len)
+{
+    if (!out || !out_len || (!in && in_len) || kind < 0 || kind > 2) return BZ_E_PARAM;
+    *out = nullptr;
+    *out_len = 0;
+    bz_gpu_engine *g = nullptr;
+    int rc = bz_gpu_engine_create(&g, device, 1);
+    if (rc != BZ_OK) return rc;
+    void *d_in = nullptr, *d_out = nullptr;
+    const size_t cap = df_encode_bound(in_len);
+    uint8_t *h = nullptr;
+    size_t n_out = 0;
+    rc = BZ_E_NOMEM;
+    if (hipMalloc(&d_in, in_len + 64) != hipSuccess) goto done;
+    if (hipMalloc(&d_out, cap) != hipSuccess) goto done;
+    rc = BZ_E_UNEXPECTED;
+    if (in_len && hipMemcpy(d_in, in, in_len, hipMemcpyHostToDevice) != hipSuccess) goto done;
+    rc = df_gpu_encode_device(g, kind, d_in, in_len, d_out, cap, &n_out);
+    if (rc != BZ_OK) goto done;
+    h = (uint8_t *)malloc(n_out ? n_out : 1);
+    if (!h) { rc = BZ_E_NOMEM; goto done; }
+    if (hipMemcpy(h, d_out, n_out, hipMemcpyDeviceToHost) != hipSuccess) { free(h); rc = BZ_E_UNEXPECTED; goto done; }
+    *out = h;
+    *out_len = n_out;
+    rc = BZ_OK;
+done:
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    bz_gpu_engine_destroy(g);
+    return rc;
+}
+
+// ---- streaming context: the Encoder::next contract of Inflater / ZlibEncoder / GZipEncoder ----------------
+// Action::Run accumulates, Action::Finish encodes everything written so far (the stream of these encoders
+// depends on all of the input: one 32 KiB window, one bit string).  Action::Flush is refused.
+struct df_enc {
+    int kind = 0, device = 0;
+    std::vector<uint8_t> in, out;
+    size_t out_head = 0;
+    bool finished = false;
+};
+
+extern "C" int df_enc_create(df_enc **out, int kind, int device)
+{
+    if (!out || kind < 0 || kind > 2) return BZ_E_PARAM;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return BZ_E_NOGPU;
+    df_enc *e = new df_enc();
+    e->kind = kind;
+    e->device = device;
+    *out = e;
+    return BZ_OK;
+}
+
+extern "C" void df_enc_destroy(df_enc *e) { delete e; }
+
+extern "C" int df_enc_write(df_enc *e, const uint8_t *in, size_t n)
+{
+    if (!e || (!in && n)) return BZ_E_PARAM;
+    if (e->finished) return BZ_OK; // Inflater ignores input behind the final block (deflate/encoder.rs:638-660)
+    e->in.insert(e->in.end(), in, in + n);
+    return BZ_OK;
+}
+
+extern "C" int df_enc_end(df_enc *e, int action)
+{
+    if (!e) return BZ_E_PARAM;
+    if (action == 0) return BZ_OK;      // Run: nothing comes out before the end
+    if (action != 2) return BZ_E_PARAM; // Flush: not offered on this path
+    if (e->finished) return BZ_OK;
+    uint8_t *p = nullptr;
+    size_t n = 0;
+    const int rc = df_encode_buffer(e->kind, e->device, e->in.data(), e->in.size(), &p, &n);
+    if (rc != BZ_OK) return rc;
+    e->out.assign(p, p + n);
+    free(p);
+    e->in.clear();
+    e->in.shrink_to_fit();
+    e->finished = true;
+    return BZ_OK;
+}
+
+extern "C" size_t df_enc_pending(const df_enc *e) { return e ? e->out.size() - e->out_head : 0; }
+
+extern "C" long df_enc_read(df_enc *e, uint8_t *out, size_t cap)
+{
+    if (!e || (!out && cap)) return BZ_E_PARAM;
+    const size_t avail = e->out.size() - e->out_head;
+    const size_t k = avail < cap ? avail : cap;
+    if (k) memcpy(out, e->out.data() + e->out_head, k);
+    e->out_head += k;
+    return (long)k;
+}

@@ -176,6 +176,7 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
                      &g->tickets};
     for (DevBuf *b : all) b->release();
     dec_workspace_free(g->dec);
+    df_workspace_free(g->df);
     if (g->h_active) (void)hipHostFree(g->h_active);
     if (g->st) (void)hipStreamDestroy(g->st);
     if (g->st2) (void)hipStreamDestroy(g->st2);

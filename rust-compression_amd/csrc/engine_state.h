@@ -11,6 +11,8 @@ using namespace bzgpu;
 
 struct DecWorkspace;
 void dec_workspace_free(DecWorkspace *w);
+struct DfWorkspace;
+void df_workspace_free(DfWorkspace *w);
 
 #define HIPCHK(x)                                                                                     \
     do {                                                                                              \
@@ -89,5 +91,6 @@ struct bz_gpu_engine {
     };
     std::vector<Span> spans;
     DecWorkspace *dec = nullptr; // decode workspace, created by the first decode call
+    DfWorkspace *df = nullptr;   // Deflate encode workspace, created by the first df_gpu_encode_device call
 };
 

@@ -1,0 +1,52 @@
+// k_deflate.h -- declarations shared by the Deflate kernels (k_deflate.hip) and their orchestration
+// (deflate_engine.hip).  SURVEY.md rows f-2 (Inflater) and f-3 (zlib / gzip containers).
+#pragma once
+#include "bzgpu.h"
+
+namespace dfgpu {
+using bzgpu::u8;
+using bzgpu::u16;
+using bzgpu::u32;
+using bzgpu::u64;
+using bzgpu::i64;
+
+constexpr u32 kWin = 0x8000;       // Inflater::new: window (deflate/encoder.rs:117)
+constexpr u32 kMaxMatch = 258;     // LZSS_MAX_MATCH :110
+constexpr u32 kMinMatch = 3;       // LZSS_MIN_MATCH :109
+constexpr u32 kChain = 255;        // MATCH_SEARCH_COUNT - 1 (lzss/slidedict.rs:129, 232)
+constexpr u32 kBlockMax = 0xFFFF;  // MAX_BLOCK_SIZE (deflate/encoder.rs:270)
+constexpr u32 kMTile = 8192;       // positions per match workgroup
+constexpr u32 kMThreads = 1024;
+constexpr u32 kPTile = 4096;       // positions per parse tile
+constexpr u32 kEntries = 260;      // a step advances by at most 258 + 2: entry offsets 0..259
+constexpr u32 kFan = 64;           // tiles composed per level
+constexpr u32 kBThreads = 256;
+constexpr u32 kEThreads = 512;
+constexpr u32 kHdrWords = 160;     // bits of BFINAL + dynamic header: < 74 + 316 * 14
+constexpr u32 kDfLmTable = 3 * 288 + 64 + 2 * 15 * (2 * 288 + 4); // scratch words of one length-limited table
+constexpr u32 kDfLmWords = 2 * kDfLmTable;
+constexpr u32 kSumPiece = 65536;   // bytes per checksum piece
+constexpr u32 F_CODE = 0x80000000u; // code[q]: an LZSS code starts at q
+constexpr u32 F_REF = 0x40000000u;  //          it is a reference: len | (dist - 1) << 9
+
+struct DfBlock {
+    u32 btype;     // 0 stored, 1 fixed, 2 dynamic
+    u32 hdr_bits;  // BFINAL + BTYPE (+ dynamic header)
+    u32 bytes;     // decompress_len
+    u32 lm;        // tables that took the length-limited path
+    u64 bits;      // whole block, btype 1 / 2
+    u64 bit_off;   // where it starts in the stream
+};
+
+int df_sort_temp_bytes(u64 n, size_t *bytes);
+int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u16 *keys_in, u16 *keys_out, u32 *vals_in, u32 *vals_out,
+                     void *tmp, size_t tmp_bytes, u16 *prevd);
+int df_launch_match(hipStream_t st, const u8 *in, const u16 *prevd, u64 n, u32 *M);
+int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *tabs, u16 *const *ents, const u32 *counts,
+                    u32 nlevels, u32 *code);
+int df_launch_blocks(hipStream_t st, const u8 *in, const u32 *code, u64 n, u64 *bstart, u32 *nb, u32 cap, DfBlock *blocks,
+                     u8 *lens, u32 *hdr, u32 *lm_scratch, u64 *total_bits);
+int df_launch_emit(hipStream_t st, const u8 *in, const u32 *code, const u64 *bstart, const u32 *nb, u32 cap,
+                   const DfBlock *blocks, const u8 *lens, const u32 *hdr, u32 *out);
+int df_launch_sums(hipStream_t st, const u8 *in, u64 n, u64 *asum, u64 *bsum, u32 *crc);
+} // namespace dfgpu

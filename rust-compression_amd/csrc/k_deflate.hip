@@ -1,0 +1,842 @@
+// k_deflate.hip -- Deflate encode: the reference's LzssEncoder + Inflater,
+// re-derived as data-parallel stages.  Everything the reference decides serially is a pure
+// function of the input, which is what makes the stream reproducible bit for bit:
+//
+//   * SlideDict pushes EVERY position into a 16-bit hash of its 3 bytes (lzss/slidedict.rs:
+//     192-214, 80-115), so the chain it walks from position p (search_dic :216-267) is "the earlier
+//     positions with the same hash, nearest first, while the summed distance is <= 0x8000, at most
+//     255 of them, stopping behind the first one that matches to the limit".  Sorting positions by
+//     hash (stable) puts every chain in one run; k_df_prev turns the run into the reference's
+//     `pos` array (distance to the previous member, 0 = none within the window).
+//   * The candidate kept is the first one with the greatest length (the comparison closure of
+//     deflate/encoder.rs:34-51 can only prefer a new candidate that is strictly longer, because a
+//     later candidate is always farther): k_df_match, one window of 32 KiB + tile staged in LDS.
+//   * LzssEncoder::encode (lzss/encoder.rs:132-184) looks at the matches of p, p+1, p+2 and
+//     advances by `len + lazy_index`: adv(p) is a function of p, the parse is the orbit of 0
+//     under p -> p + adv(p).  Orbits are found per 4096-position tile for every possible entry
+//     offset (an entry is < 260 past the tile start), composed 64 tiles at a time, resolved top
+//     down, and marked by pointer doubling (k_df_tile_tab / k_df_compose / k_df_resolve / k_df_mark).
+//   * InflaterInner::next (deflate/encoder.rs:577-636) closes a block when the next code would
+//     take it past 0xFFFF bytes: the next block starts at the last code start <= start + 0xFFFF
+//     (k_df_cuts).  write_block (:454-547) then chooses stored / fixed / dynamic from the block's
+//     symbol counts: k_df_block replays make_table (huffman/cano_huff_table.rs, the serial heap
+//     procedure and the package-merge fallback, one lane per table) and the code-length run
+//     coding (:318-452) exactly; k_df_emit writes the bits LSB first (bitio/writer.rs, Right).
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "bzgpu.h"
+#include "k_deflate.h"
+
+namespace dfgpu {
+using namespace bzgpu;
+
+// ---------------------------------------------------------------------------------- hash + chains
+// slidedict.rs:80-87 on a 64-bit usize: the three bytes fold to a 24-bit value, times HASH_FRAC, top 16 bits
+__device__ __forceinline__ u32 hash16(u32 b0, u32 b1, u32 b2)
+{
+    const u64 h = (u64)((b0 << 16) | (b1 << 8) | b2);
+    return (u32)((h * 0x7A7C4F9F7A7C4F9Full) >> 48);
+}
+
+__global__ __launch_bounds__(256) void k_df_keys(const u8 *__restrict__ in, u64 ntri, u16 *__restrict__ keys,
+                                                 u32 *__restrict__ vals)
+{
+    // 4 positions per thread from two aligned dwords
+    const u64 i0 = ((u64)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= ntri) return;
+    const u64 n = ntri + 2;
+    u64 v = 0;
+    if (i0 + 8 <= n) { const u32 *w = reinterpret_cast<const u32 *>(in + i0); v = (u64)w[0] | ((u64)w[1] << 32); }
+    else
+        for (u32 b = 0; b < 8 && i0 + b < n; ++b) v |= (u64)in[i0 + b] << (8 * b);
+    for (u32 k = 0; k < 4 && i0 + k < ntri; ++k) {
+        const u32 b0 = (u32)(v >> (8 * k)) & 0xFF, b1 = (u32)(v >> (8 * k + 8)) & 0xFF, b2 = (u32)(v >> (8 * k + 16)) & 0xFF;
+        keys[i0 + k] = (u16)hash16(b0, b1, b2);
+        vals[i0 + k] = (u32)(i0 + k);
+    }
+}
+
+// sorted by (hash, position): distance to the previous position with the same hash, 0 = none in the window
+__global__ __launch_bounds__(256) void k_df_prev(const u16 *__restrict__ ks, const u32 *__restrict__ vs, u64 ntri,
+                                                 u16 *__restrict__ prevd)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ntri) return;
+    const u32 p = vs[i];
+    u32 d = 0;
+    if (i > 0 && ks[i - 1] == ks[i]) {
+        const u32 dd = p - vs[i - 1];
+        if (dd <= kWin) d = dd;
+    }
+    prevd[p] = (u16)d;
+}
+
+// ---------------------------------------------------------------------------------- matches
+constexpr u32 kMDataBytes = kWin + kMTile + 272;
+
+__global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ in, const u16 *__restrict__ prevd, u64 n,
+                                                        u32 *__restrict__ M)
+{
+    __shared__ u32 s_w[kMDataBytes / 4];
+    __shared__ u16 s_prev[kWin + kMTile];
+    const u32 tid = threadIdx.x;
+    const u64 t0 = (u64)blockIdx.x * kMTile;
+    const i64 base = (i64)t0 - (i64)kWin; // multiple of 4
+    for (u32 w = tid; w < kMDataBytes / 4; w += kMThreads) {
+        const i64 g = base + 4 * (i64)w;
+        u32 v = 0;
+        if (g >= 0 && (u64)g + 4 <= n) v = *reinterpret_cast<const u32 *>(in + g);
+        else if (g >= 0 && (u64)g < n)
+            for (u32 b = 0; b < 4 && (u64)g + b < n; ++b) v |= (u32)in[g + b] << (8 * b);
+        s_w[w] = v;
+    }
+    for (u32 k = tid; k < (kWin + kMTile) / 2; k += kMThreads) {
+        const i64 g = base + 2 * (i64)k;
+        u32 v = 0;
+        if (g >= 0 && (u64)g + 2 <= n) v = *reinterpret_cast<const u32 *>(prevd + g);
+        else if (g >= 0 && (u64)g < n) v = prevd[g];
+        reinterpret_cast<u32 *>(s_prev)[k] = v;
+    }
+    __syncthreads();
+    auto ld4 = [&](u32 byte) -> u32 { return __builtin_amdgcn_alignbyte(s_w[(byte >> 2) + 1], s_w[byte >> 2], byte & 3u); };
+    for (u32 k = tid; k < kMTile; k += kMThreads) {
+        const u64 p = t0 + k;
+        if (p >= n) break;
+        const u32 lp = kWin + k;
+        const u32 limit = (n - p) < (u64)kMaxMatch ? (u32)(n - p) : kMaxMatch; // search_dic :228
+        u32 best_len = 0, best_dist = 0, cum = 0, cnt = kChain;
+        u32 d = s_prev[lp];
+        const u32 a0 = ld4(lp);
+        while (d != 0 && cnt != 0) {
+            cum += d;
+            if (cum > kWin) break;
+            const u32 lc = lp - cum;
+            u32 x = a0 ^ ld4(lc);
+            u32 l;
+            if (x) l = (u32)__builtin_ctz(x) >> 3;
+            else {
+                l = 4;
+                while (l < limit) {
+                    x = ld4(lp + l) ^ ld4(lc + l);
+                    if (x) { l += (u32)__builtin_ctz(x) >> 3; break; }
+                    l += 4;
+                }
+            }
+            if (l > limit) l = limit;
+            if (l > best_len) { best_len = l; best_dist = cum; }
+            if (l == limit) break; // :258-259
+            --cnt;
+            d = s_prev[lc];
+        }
+        M[p] = best_len >= kMinMatch ? (best_len | ((best_dist - 1) << 9)) : 0u;
+    }
+}
+
+// ---------------------------------------------------------------------------------- parse
+// lzss/encoder.rs:132-184: step[p] = advance | lazy_index << 9 if a code sequence started at p
+__global__ __launch_bounds__(256) void k_df_adv(const u32 *__restrict__ M, u64 n, u16 *__restrict__ step)
+{
+    const u64 p = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const u32 m0 = M[p];
+    u32 out_len = m0 & 511u, out_pos = m0 >> 9, li = 0;
+    if (out_len < kMinMatch) { step[p] = 1; return; }
+    for (u32 i = 1; i < 3; ++i) {
+        if (out_len >= kMaxMatch) break;
+        const u32 it = (p + i < n) ? M[p + i] : 0u;
+        const u32 il = it & 511u, ip = it >> 9;
+        if (il > kMinMatch && (il << 3) + ip > (out_len << 3) + out_pos) { out_len = il; out_pos = ip; li = i; }
+    }
+    step[p] = (u16)((out_len + li) | (li << 9));
+}
+
+__global__ __launch_bounds__(256) void k_df_tile_tab(const u16 *__restrict__ step, u64 n, u16 *__restrict__ tab)
+{
+    __shared__ u16 s_nx[kPTile];
+    const u64 t0 = (u64)blockIdx.x * kPTile;
+    for (u32 k = threadIdx.x; k < kPTile; k += 256) {
+        const u64 p = t0 + k;
+        s_nx[k] = (u16)(k + (p < n ? (step[p] & 511u) : 1u));
+    }
+    for (u32 r = 0; r < 12; ++r) {
+        __syncthreads();
+        for (u32 k = threadIdx.x; k < kPTile; k += 256) {
+            const u32 v = s_nx[k];
+            if (v < kPTile) s_nx[k] = s_nx[v]; // in place: a fresher value is only farther along the same path
+        }
+    }
+    __syncthreads();
+    for (u32 e = threadIdx.x; e < kEntries; e += 256) tab[(u64)blockIdx.x * kEntries + e] = (u16)(s_nx[e] - kPTile);
+}
+
+__global__ __launch_bounds__(320) void k_df_compose(const u16 *__restrict__ tin, u32 nin, u16 *__restrict__ tout)
+{
+    const u32 e = threadIdx.x;
+    if (e >= kEntries) return;
+    const u32 c0 = blockIdx.x * kFan, c1 = (c0 + kFan < nin) ? c0 + kFan : nin;
+    u32 v = e;
+    for (u32 c = c0; c < c1; ++c) v = tin[(u64)c * kEntries + v];
+    tout[(u64)blockIdx.x * kEntries + e] = (u16)v;
+}
+
+__global__ __launch_bounds__(64) void k_df_resolve(const u16 *__restrict__ tab_child, u32 nchild,
+                                                   const u16 *__restrict__ ent_parent, u32 nparent,
+                                                   u16 *__restrict__ ent_child)
+{
+    const u32 g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= nparent) return;
+    u32 v = ent_parent[g];
+    const u32 c0 = g * kFan, c1 = (c0 + kFan < nchild) ? c0 + kFan : nchild;
+    for (u32 c = c0; c < c1; ++c) {
+        ent_child[c] = (u16)v;
+        v = tab_child[(u64)c * kEntries + v];
+    }
+}
+
+// marks the code starts of the steps that begin in this tile and writes code[] for every position those
+// steps cover (the ranges of consecutive tiles meet exactly)
+__global__ __launch_bounds__(256) void k_df_mark(const u16 *__restrict__ step, const u32 *__restrict__ M,
+                                                 const u16 *__restrict__ ent, u64 n, u32 *__restrict__ code)
+{
+    __shared__ u16 s_j[2][kPTile];
+    __shared__ u16 s_step[kPTile];
+    __shared__ u8 s_mark[kPTile];
+    __shared__ u8 s_type[kPTile + 264];
+    const u32 tid = threadIdx.x;
+    const u64 t0 = (u64)blockIdx.x * kPTile;
+    const u32 entry = ent[blockIdx.x];
+    for (u32 k = tid; k < kPTile; k += 256) {
+        const u64 p = t0 + k;
+        const u32 s = p < n ? step[p] : 1u;
+        s_step[k] = (u16)s;
+        s_j[0][k] = (u16)(k + (s & 511u));
+        s_mark[k] = (k == entry) ? 1 : 0;
+    }
+    for (u32 k = tid; k < kPTile + 264; k += 256) s_type[k] = 0;
+    for (u32 r = 0; r < 12; ++r) {
+        __syncthreads();
+        const u32 cur = r & 1u;
+        for (u32 k = tid; k < kPTile; k += 256) {
+            const u32 v = s_j[cur][k];
+            if (s_mark[k] && v < kPTile) s_mark[v] = 1;
+            s_j[cur ^ 1u][k] = (u16)(v < kPTile ? s_j[cur][v] : v);
+        }
+    }
+    __syncthreads();
+    // after 12 exact doublings every entry has left the tile: the exit of `entry`
+    const u32 exitp = (entry < kPTile) ? (u32)s_j[0][entry] : entry;
+    for (u32 k = tid; k < kPTile; k += 256) {
+        if (!s_mark[k]) continue;
+        const u32 s = s_step[k], adv = s & 511u, li = s >> 9;
+        if (adv == 1) s_type[k] = 1;
+        else {
+            for (u32 i = 0; i < li; ++i) s_type[k + i] = 1;
+            s_type[k + li] = 2;
+        }
+    }
+    __syncthreads();
+    for (u32 k = entry + tid; k < exitp; k += 256) {
+        const u64 q = t0 + k;
+        if (q >= n) break;
+        const u32 ty = s_type[k];
+        code[q] = ty == 0 ? 0u : (ty == 1 ? F_CODE : (F_CODE | F_REF | M[q]));
+    }
+}
+
+// block starts: b' = the last code start <= b + 0xFFFF (InflaterInner::next :585-593).  One wave.
+__global__ __launch_bounds__(64) void k_df_cuts(const u32 *__restrict__ code, u64 n, u64 *__restrict__ bstart,
+                                                u32 *__restrict__ nb_out, u32 cap)
+{
+    const u32 lane = threadIdx.x;
+    u64 b = 0;
+    u32 k = 0;
+    for (;;) {
+        if (lane == 0 && k < cap) bstart[k] = b;
+        ++k;
+        const u64 x = b + kBlockMax;
+        if (x >= n) break;
+        u64 q = x;
+        u32 tries = 0;
+        for (;;) {
+            const bool f = (q >= lane) && (code[q - lane] & F_CODE);
+            const u64 bal = __ballot(f);
+            if (bal) { b = q - (u64)(__ffsll((unsigned long long)bal) - 1); break; }
+            q -= 64;
+            if (++tries > 8) { // a code is at most 258 bytes long: cannot happen; never spin on a broken parse
+                if (lane == 0) *nb_out = 0xFFFFFFFFu;
+                return;
+            }
+        }
+    }
+    if (lane == 0) {
+        if (k < cap) bstart[k] = n;
+        *nb_out = k;
+    }
+}
+
+// ---------------------------------------------------------------------------------- tables
+// deflate/mod.rs:76-125 without the tables: code, extra bits, extra value of len-3 / dist-1
+__device__ __forceinline__ void len_code(u32 l3, u32 &code, u32 &eb, u32 &ev)
+{
+    if (l3 < 8) { code = l3; eb = 0; ev = 0; }
+    else if (l3 == 255) { code = 28; eb = 0; ev = 0; }
+    else {
+        const u32 hb = 31u - (u32)__builtin_clz(l3), nb = hb - 2;
+        code = ((nb + 1) << 2) | ((l3 >> nb) & 3u);
+        eb = nb;
+        ev = l3 & ((1u << nb) - 1);
+    }
+}
+__device__ __forceinline__ void dist_code(u32 d0, u32 &code, u32 &eb, u32 &ev)
+{
+    if (d0 < 4) { code = d0; eb = 0; ev = 0; }
+    else {
+        const u32 hb = 31u - (u32)__builtin_clz(d0), nb = hb - 1;
+        code = ((nb + 1) << 1) | ((d0 >> nb) & 1u);
+        eb = nb;
+        ev = d0 & ((1u << nb) - 1);
+    }
+}
+__device__ __forceinline__ u32 len_ext_bits(u32 c) { return (c < 8 || c == 28) ? 0u : (c >> 2) - 1; }
+__device__ __forceinline__ u32 dist_ext_bits(u32 c) { return c < 4 ? 0u : (c >> 1) - 1; }
+
+// cano_huff_table.rs:14-31
+__device__ void df_down_heap(u32 *buf, u32 nn, u32 len)
+{
+    const u32 tmp = buf[nn];
+    u32 leaf = (nn << 1) + 1;
+    while (leaf < len) {
+        if (leaf + 1 < len && buf[buf[leaf]] > buf[buf[leaf + 1]]) leaf += 1;
+        if (buf[tmp] < buf[buf[leaf]]) break;
+        buf[nn] = buf[leaf];
+        nn = leaf;
+        leaf = (nn << 1) + 1;
+    }
+    buf[nn] = tmp;
+}
+
+// cano_huff_table.rs:58-151 ("reverse package merge"), weights x + y.  freq: k non-zero weights, out: k lengths.
+// scr: 3*k + 64 + 2*lim*row words, row >= 2k + 4.
+__device__ void df_gen_code_lm(const u32 *freq, u32 n, u32 lim, u32 *scr, u8 *out)
+{
+    const u32 row = 2 * n + 4;
+    u32 *map = scr, *sfreq = map + n, *c = sfreq + n, *misc = c + n;
+    u32 *max_elem = misc, *b = misc + 20, *cur = misc + 40;
+    u32 *val = misc + 64, *ty = val + lim * row;
+    for (u32 i = 0; i < n; ++i) { // stable, descending (:64-70)
+        const u32 f = freq[i];
+        u32 p = i;
+        while (p > 0 && sfreq[p - 1] < f) { sfreq[p] = sfreq[p - 1]; map[p] = map[p - 1]; --p; }
+        sfreq[p] = f;
+        map[p] = i;
+    }
+    for (u32 j = 0; j < lim; ++j) { max_elem[j] = 0; b[j] = 0; cur[j] = 0; }
+    u32 excess = (1u << lim) - n;
+    const u32 half = 1u << (lim - 1);
+    max_elem[lim - 1] = n;
+    for (u32 j = 0; j < lim; ++j) {
+        if (excess >= half) { b[j] = 1; excess -= half; }
+        excess <<= 1;
+        if (lim >= 2 + j) max_elem[lim - 2 - j] = max_elem[lim - 1 - j] / 2 + n;
+    }
+    max_elem[0] = b[0];
+    for (u32 j = 1; j < lim; ++j)
+        if (max_elem[j] > 2 * max_elem[j - 1] + b[j]) max_elem[j] = 2 * max_elem[j - 1] + b[j];
+    for (u32 j = 0; j < lim; ++j)
+        for (u32 t = 0; t < max_elem[j]; ++t) { val[j * row + t] = 0; ty[j * row + t] = 0; }
+    for (u32 i = 0; i < n; ++i) c[i] = lim;
+    for (u32 t = 0; t < n && t < max_elem[lim - 1]; ++t) { val[(lim - 1) * row + t] = sfreq[t]; ty[(lim - 1) * row + t] = t; }
+    if (b[lim - 1] == 1) { c[0] -= 1; cur[lim - 1] += 1; }
+    u32 j = lim - 1;
+    while (j > 0) {
+        u32 i = 0, next = cur[j];
+        for (u32 t = 0; t < max_elem[j - 1]; ++t) {
+            const u32 weight = (next + 1 < max_elem[j]) ? val[j * row + next] + val[j * row + next + 1] : 0u;
+            if (weight > sfreq[i]) { val[(j - 1) * row + t] = weight; ty[(j - 1) * row + t] = n; next += 2; }
+            else {
+                val[(j - 1) * row + t] = sfreq[i];
+                ty[(j - 1) * row + t] = i;
+                i += 1;
+                if (i >= n) break;
+            }
+        }
+        j -= 1;
+        cur[j] = 0;
+        if (b[j] == 1) { // take_package (:40-55) with an explicit stack
+            u32 lvl[20], ph[20];
+            int sp = 0;
+            lvl[0] = j; ph[0] = 0;
+            while (sp >= 0) {
+                const u32 li = lvl[sp];
+                if (ph[sp] == 0) {
+                    const u32 x = ty[li * row + cur[li]];
+                    if (x == n) { ph[sp] = 1; ++sp; lvl[sp] = li + 1; ph[sp] = 0; }
+                    else { c[x] -= 1; cur[li] += 1; --sp; }
+                } else if (ph[sp] == 1) { ph[sp] = 2; ++sp; lvl[sp] = li + 1; ph[sp] = 0; }
+                else { cur[li] += 1; --sp; }
+            }
+        }
+    }
+    for (u32 i = 0; i < n; ++i) out[map[i]] = (u8)c[i];
+}
+
+// make_table (cano_huff_table.rs:198-230): lengths for the non-zero counts, 0 elsewhere; returns the
+// length of the reference's vector (one past the last non-zero count).  buf: 2*nsym words; w: nsym words;
+// lm_scr: scratch of df_gen_code_lm; sets *lm when the limited path ran.
+__device__ u32 df_make_table(const u32 *freq, u32 nsym, u32 lim, u8 *out, u32 *buf, u32 *w, u8 *tmp, u32 *lm_scr, u32 *lm)
+{
+    u32 k = 0, last = 0;
+    for (u32 i = 0; i < nsym; ++i) {
+        out[i] = 0;
+        if (freq[i]) { w[k++] = freq[i]; last = i + 1; }
+    }
+    if (k == 0) return 0;
+    if (k == 1) tmp[0] = 1; // gen_code :158-160
+    else {
+        const u32 n = k;
+        for (u32 i = 0; i < n; ++i) { buf[i] = n + i; buf[n + i] = w[i]; }
+        for (u32 i = n >> 1; i-- > 0;) df_down_heap(buf, i, n); // create_heap :33-38 (len = 2n, s = n)
+        for (u32 i = n - 1; i >= 1; --i) {
+            const u32 m1 = buf[0];
+            buf[0] = buf[i];
+            df_down_heap(buf, 0, i);
+            const u32 m2 = buf[0];
+            buf[i] = buf[m1] + buf[m2];
+            buf[0] = i;
+            buf[m1] = i;
+            buf[m2] = i;
+            df_down_heap(buf, 0, i);
+        }
+        buf[1] = 0;
+        for (u32 i = 2; i < n; ++i) buf[i] = buf[buf[i]] + 1;
+        bool too_long = false;
+        for (u32 i = 0; i < n; ++i) {
+            const u32 l = buf[buf[i + n]] + 1;
+            tmp[i] = (u8)l;
+            if (l > lim) too_long = true;
+        }
+        if (too_long) {
+            df_gen_code_lm(w, n, lim, lm_scr, tmp);
+            if (lm) *lm += 1;
+        }
+    }
+    k = 0;
+    for (u32 i = 0; i < nsym; ++i)
+        if (freq[i]) out[i] = tmp[k++];
+    return last;
+}
+
+// canonical codes, bit-reversed (huffman/mod.rs:16-63 with is_reverse)
+__device__ void df_make_codes(const u8 *len, u32 n, u16 *code)
+{
+    u32 cur = 0, last = 0;
+    for (u32 l = 1; l <= 15; ++l)
+        for (u32 s = 0; s < n; ++s)
+            if (len[s] == l) {
+                cur <<= (last < l ? l - last : 0);
+                last = l;
+                code[s] = (u16)(__brev(cur) >> (32 - l));
+                cur += 1;
+            }
+}
+
+struct LsbSink { // single lane, LSB first into 32-bit words
+    u32 *w;
+    u64 acc;
+    u32 nacc, widx;
+    __device__ void put(u32 v, u32 nbits)
+    {
+        if (!nbits) return;
+        acc |= (u64)v << nacc;
+        nacc += nbits;
+        if (nacc >= 32) { w[widx++] = (u32)acc; acc >>= 32; nacc -= 32; }
+    }
+    __device__ u32 bits() const { return widx * 32 + nacc; }
+    __device__ void finish() { if (nacc) w[widx] = (u32)acc; }
+};
+
+// enc_tab_to_freq (deflate/encoder.rs:318-376): run coding of one length table
+__device__ u32 df_tab_runs(const u8 *tab, u32 n, u8 *ls, u8 *le, u32 *freq)
+{
+    u32 k = 0, old = 255, len = 0;
+    for (u32 i = 0; i <= n; ++i) {
+        const u32 d = i < n ? tab[i] : 255u;
+        if (old != d) {
+            if (old == 0) {
+                if (len >= 11) { freq[18] += 1; ls[k] = 18; le[k++] = (u8)(len - 11); }
+                else if (len >= 3) { freq[17] += 1; ls[k] = 17; le[k++] = (u8)(len - 3); }
+                else { for (u32 t = 0; t < len; ++t) { ls[k] = 0; le[k++] = 0; } freq[0] += len; }
+            } else if (len >= 3) { freq[16] += 1; ls[k] = 16; le[k++] = (u8)(len - 3); }
+            else if (len > 0) { for (u32 t = 0; t < len; ++t) { ls[k] = (u8)old; le[k++] = 0; } freq[old] += len; }
+            if (d != 0 && d != 255) { ls[k] = (u8)d; le[k++] = 0; freq[d] += 1; len = 0; }
+            else len = 1;
+            old = d;
+        } else {
+            len += 1;
+            if (old == 0 && len == 138) { freq[18] += 1; ls[k] = 18; le[k++] = 127; len = 0; }
+            else if (old != 0 && len == 6) { freq[16] += 1; ls[k] = 16; le[k++] = 3; len = 0; }
+        }
+    }
+    return k;
+}
+
+// one workgroup per Deflate block: symbol counts, the three tables, the header, the choice of block type
+__global__ __launch_bounds__(kBThreads) void k_df_block(const u8 *__restrict__ in, const u32 *__restrict__ code,
+                                                        const u64 *__restrict__ bstart, const u32 *__restrict__ nb_p,
+                                                        DfBlock *__restrict__ blocks, u8 *__restrict__ lens,
+                                                        u32 *__restrict__ hdr, u32 *__restrict__ lm_scratch)
+{
+    __shared__ u32 s_sf[288], s_of[32];
+    __shared__ u32 s_buf[2][2 * 288], s_w[2][288];
+    __shared__ u8 s_tmp[2][288], s_sl[288], s_ol[32];
+    __shared__ u32 s_n[2], s_lm;
+    __shared__ u8 s_ls[2][320], s_le[2][320];
+    __shared__ u32 s_hdr[kHdrWords];
+    __shared__ u32 s_lm7[3 * 19 + 64 + 2 * 7 * (2 * 19 + 4)];
+    __shared__ u32 s_btype;
+    const u32 tid = threadIdx.x, k = blockIdx.x;
+    const u32 nblocks = *nb_p;
+    if (nblocks == 0xFFFFFFFFu || k >= nblocks) return;
+    const u64 b0 = bstart[k], b1 = bstart[k + 1];
+    const bool is_final = (k + 1 == nblocks);
+    for (u32 i = tid; i < 288; i += kBThreads) s_sf[i] = 0;
+    if (tid < 32) s_of[tid] = 0;
+    if (tid == 0) s_lm = 0;
+    __syncthreads();
+    for (u64 q = b0 + tid; q < b1; q += kBThreads) {
+        const u32 c = code[q];
+        if (!(c & F_CODE)) continue;
+        if (c & F_REF) {
+            u32 lc, eb, ev, dc;
+            len_code((c & 511u) - 3, lc, eb, ev);
+            dist_code((c >> 9) & 32767u, dc, eb, ev);
+            atomicAdd(&s_sf[257 + lc], 1u);
+            atomicAdd(&s_of[dc], 1u);
+        } else atomicAdd(&s_sf[in[q]], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) s_sf[256] += 1; // init_block :274-279
+    __syncthreads();
+    u32 *lm_scr = lm_scratch + (size_t)k * kDfLmWords;
+    if (tid == 0) s_n[0] = df_make_table(s_sf, 286, 15, s_sl, s_buf[0], s_w[0], s_tmp[0], lm_scr, &s_lm);
+    if (tid == 64) s_n[1] = df_make_table(s_of, 30, 15, s_ol, s_buf[1], s_w[1], s_tmp[1], lm_scr + kDfLmTable, &s_lm);
+    __syncthreads();
+    if (tid == 0) {
+        const u32 sym_n = s_n[0], off_n = s_n[1];
+        // create_custom_huffman_table :395-452
+        u32 lenfreq[19];
+        for (u32 i = 0; i < 19; ++i) lenfreq[i] = 0;
+        const u32 symk = df_tab_runs(s_sl, sym_n, s_ls[0], s_le[0], lenfreq);
+        const u32 offk = df_tab_runs(s_ol, off_n, s_ls[1], s_le[1], lenfreq);
+        u8 len_enc[19];
+        u32 *sb = s_buf[0], *sw = s_w[0];
+        u32 lm2 = 0;
+        const u32 len_enc_n = df_make_table(lenfreq, 19, 7, len_enc, sb, sw, s_tmp[0], s_lm7, &lm2);
+        const u32 len_map[19] = {3, 17, 15, 13, 11, 9, 7, 5, 4, 6, 8, 10, 12, 14, 16, 18, 0, 1, 2};
+        u8 len_tab[19];
+        for (u32 i = 0; i < 19; ++i) len_tab[i] = 0;
+        u32 len_count = 3;
+        for (u32 i = 0; i < len_enc_n; ++i)
+            if (len_enc[i]) { len_tab[len_map[i]] = len_enc[i]; if (len_map[i] > len_count) len_count = len_map[i]; }
+        u32 hlit = 0, hdist = 0;
+        for (u32 i = 0; i < sym_n; ++i) if (s_sl[i]) hlit = i;
+        hlit -= 256;
+        for (u32 i = 0; i < off_n; ++i) if (s_ol[i]) hdist = i;
+        u16 lcode[19];
+        for (u32 i = 0; i < 19; ++i) lcode[i] = 0;
+        df_make_codes(len_enc, len_enc_n, lcode);
+        LsbSink sk{s_hdr, 0, 0, 0};
+        sk.put(is_final ? 1u : 0u, 1);
+        sk.put(2, 2);
+        sk.put(hlit, 5);
+        sk.put(hdist, 5);
+        sk.put(len_count - 3, 4);
+        for (u32 i = 0; i <= len_count; ++i) sk.put(len_tab[i], 3);
+        for (u32 which = 0; which < 2; ++which) {
+            const u32 cnt = which ? offk : symk;
+            for (u32 i = 0; i < cnt; ++i) {
+                const u32 s = s_ls[which][i];
+                sk.put(lcode[s], len_enc[s]);
+                if (s == 16) sk.put(s_le[which][i], 2);
+                else if (s == 17) sk.put(s_le[which][i], 3);
+                else if (s == 18) sk.put(s_le[which][i], 7);
+            }
+        }
+        sk.finish();
+        const u32 hdr_bits = sk.bits(); // BFINAL + the header the reference counts (which includes BTYPE)
+        // cals_comp_len :549-575 for the custom and the fixed tables
+        u64 custom = hdr_bits - 1, fixed = 2;
+        for (u32 i = 0; i < 286; ++i) {
+            const u32 f = s_sf[i];
+            if (!f) continue;
+            const u32 ext = i >= 257 ? len_ext_bits(i - 257) : 0u;
+            if (i < sym_n) custom += (u64)f * (s_sl[i] + ext);
+            const u32 fl = i < 144 ? 8u : (i < 256 ? 9u : (i < 280 ? 7u : 8u));
+            fixed += (u64)f * (fl + ext);
+        }
+        for (u32 i = 0; i < 30; ++i) {
+            const u32 f = s_of[i];
+            if (!f) continue;
+            const u32 ext = dist_ext_bits(i);
+            if (i < off_n) custom += (u64)f * (s_ol[i] + ext);
+            fixed += (u64)f * (5u + ext);
+        }
+        const u64 dlen = b1 - b0;
+        const u64 original = (dlen << 3) + 2 + 16 + 16;
+        DfBlock o;
+        o.bytes = (u32)dlen;
+        o.lm = s_lm + lm2;
+        if (original <= custom && original <= fixed) { o.btype = 0; o.hdr_bits = 3; o.bits = 0; s_hdr[0] = is_final ? 1u : 0u; }
+        else if (fixed <= custom) { o.btype = 1; o.hdr_bits = 3; o.bits = 1 + fixed; s_hdr[0] = (is_final ? 1u : 0u) | 2u; }
+        else { o.btype = 2; o.hdr_bits = hdr_bits; o.bits = 1 + custom; }
+        blocks[k] = o;
+        s_btype = o.btype;
+    }
+    __syncthreads();
+    const u32 btype = s_btype;
+    for (u32 i = tid; i < 320; i += kBThreads) { // the lengths the emission codes with: 288 literal/length + 32 distance
+        u8 v = 0;
+        if (i < 288) {
+            if (btype == 1) v = (u8)(i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8))); // deflate/mod.rs:15-21
+            else if (btype == 2 && i < 286) v = s_sl[i];
+        } else {
+            if (btype == 1) v = 5;                                                       // :23-25
+            else if (btype == 2 && i - 288 < 30) v = s_ol[i - 288];
+        }
+        lens[(size_t)k * 320 + i] = v;
+    }
+    for (u32 i = tid; i < kHdrWords; i += kBThreads) hdr[(size_t)k * kHdrWords + i] = s_hdr[i];
+}
+
+// bit offset of every block; a stored block is padded to a byte behind its 3 header bits (:488-501)
+__global__ void k_df_offsets(DfBlock *__restrict__ blocks, const u32 *__restrict__ nb_p, u64 *__restrict__ total_bits)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    u64 off = 0;
+    const u32 nb = *nb_p;
+    if (nb == 0xFFFFFFFFu) return;
+    for (u32 k = 0; k < nb; ++k) {
+        blocks[k].bit_off = off;
+        if (blocks[k].btype == 0) off = ((off + 3 + 7) & ~7ull) + 32 + 8ull * blocks[k].bytes;
+        else off += blocks[k].bits;
+    }
+    *total_bits = off;
+}
+
+__device__ __forceinline__ void or_bits(u32 *out, u64 bit, u64 v, u32 nbits)
+{
+    if (!nbits) return;
+    const u64 w = bit >> 5;
+    const u32 sh = (u32)bit & 31u;
+    const u64 lo = v << sh;
+    const u32 hi = sh ? (u32)(v >> (64 - sh)) : 0u;
+    if ((u32)lo) atomicOr(&out[w], (u32)lo);
+    if ((u32)(lo >> 32)) atomicOr(&out[w + 1], (u32)(lo >> 32));
+    if (hi) atomicOr(&out[w + 2], hi);
+}
+
+__global__ __launch_bounds__(kEThreads) void k_df_emit(const u8 *__restrict__ in, const u32 *__restrict__ code,
+                                                       const u64 *__restrict__ bstart, const u32 *__restrict__ nb_p,
+                                                       const DfBlock *__restrict__ blocks, const u8 *__restrict__ lens,
+                                                       const u32 *__restrict__ hdr, u32 *__restrict__ out)
+{
+    __shared__ u16 s_sc[288], s_oc[32];
+    __shared__ u8 s_sl[288], s_ol[32];
+    __shared__ u32 s_wsum[kEThreads / 64];
+    __shared__ u64 s_base;
+    const u32 tid = threadIdx.x, k = blockIdx.x;
+    const u32 nblocks = *nb_p;
+    if (nblocks == 0xFFFFFFFFu || k >= nblocks) return;
+    const DfBlock bi = blocks[k];
+    const u64 b0 = bstart[k], b1 = bstart[k + 1];
+    u8 *out8 = reinterpret_cast<u8 *>(out);
+    if (bi.btype == 0) {
+        if (tid == 0) or_bits(out, bi.bit_off, hdr[(size_t)k * kHdrWords] & 7u, 3);
+        const u64 B = (bi.bit_off + 3 + 7) >> 3;
+        if (tid == 0) {
+            const u32 l = bi.bytes & 0xFFFFu, nl = l ^ 0xFFFFu;
+            out8[B] = (u8)l; out8[B + 1] = (u8)(l >> 8); out8[B + 2] = (u8)nl; out8[B + 3] = (u8)(nl >> 8);
+        }
+        for (u64 i = tid; i < b1 - b0; i += kEThreads) out8[B + 4 + i] = in[b0 + i];
+        return;
+    }
+    for (u32 i = tid; i < 288; i += kEThreads) { s_sl[i] = lens[(size_t)k * 320 + i]; s_sc[i] = 0; }
+    if (tid < 32) { s_ol[tid] = lens[(size_t)k * 320 + 288 + tid]; s_oc[tid] = 0; }
+    __syncthreads();
+    if (tid == 0) df_make_codes(s_sl, 288, s_sc);
+    if (tid == 64) df_make_codes(s_ol, 32, s_oc);
+    // header bits (BFINAL first)
+    for (u32 i = tid; i * 32 < bi.hdr_bits; i += kEThreads) {
+        const u32 nbits = bi.hdr_bits - i * 32 < 32 ? bi.hdr_bits - i * 32 : 32;
+        or_bits(out, bi.bit_off + (u64)i * 32, hdr[(size_t)k * kHdrWords + i], nbits);
+    }
+    if (tid == 0) s_base = bi.bit_off + bi.hdr_bits;
+    __syncthreads();
+    const u32 lane = tid & 63u, wave = tid >> 6;
+    for (u64 c0 = b0; c0 < b1; c0 += kEThreads * 4) {
+        // 4 consecutive positions per thread
+        u64 v[4];
+        u32 nb[4];
+        u32 tot = 0;
+        const u64 q0 = c0 + (u64)tid * 4;
+        for (u32 j = 0; j < 4; ++j) {
+            const u64 q = q0 + j;
+            v[j] = 0; nb[j] = 0;
+            if (q >= b1) continue;
+            const u32 c = code[q];
+            if (!(c & F_CODE)) continue;
+            if (c & F_REF) {
+                u32 lc, leb, lev, dc, deb, dev;
+                len_code((c & 511u) - 3, lc, leb, lev);
+                dist_code((c >> 9) & 32767u, dc, deb, dev);
+                u64 x = s_sc[257 + lc];
+                u32 nn = s_sl[257 + lc];
+                x |= (u64)lev << nn; nn += leb;
+                x |= (u64)s_oc[dc] << nn; nn += s_ol[dc];
+                x |= (u64)dev << nn; nn += deb;
+                v[j] = x; nb[j] = nn;
+            } else {
+                const u32 s = in[q];
+                v[j] = s_sc[s]; nb[j] = s_sl[s];
+            }
+            tot += nb[j];
+        }
+        // exclusive scan of tot over the workgroup
+        u32 inc = tot;
+        for (u32 d = 1; d < 64; d <<= 1) {
+            const u32 t = __shfl_up(inc, d);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        u32 wbase = 0, all = 0;
+        for (u32 w = 0; w < kEThreads / 64; ++w) {
+            const u32 t = s_wsum[w];
+            if (w < wave) wbase += t;
+            all += t;
+        }
+        u64 bit = s_base + wbase + (inc - tot);
+        for (u32 j = 0; j < 4; ++j) {
+            or_bits(out, bit, v[j], nb[j]);
+            bit += nb[j];
+        }
+        __syncthreads();
+        if (tid == 0) s_base += all;
+        __syncthreads();
+    }
+    if (tid == 0) or_bits(out, s_base, s_sc[256], s_sl[256]); // end of block
+}
+
+// ---------------------------------------------------------------------------------- checksums (f-3)
+// per 64 KiB piece: sum of bytes and sum of (len - i) * byte (Adler-32, adler32.rs:20-66), and the
+// reflected CRC-32 of the piece with a zero register (crc32.rs:40-55, 74-78); the host combines
+__global__ __launch_bounds__(256) void k_df_sums(const u8 *__restrict__ in, u64 n, u64 *__restrict__ asum,
+                                                 u64 *__restrict__ bsum, u32 *__restrict__ crc)
+{
+    __shared__ u32 s_tab[256];
+    __shared__ u64 s_a[256], s_b[256];
+    __shared__ u32 s_c[256];
+    const u32 tid = threadIdx.x;
+    {
+        u32 c = tid;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
+        s_tab[tid] = c;
+    }
+    __syncthreads();
+    const u64 p0 = (u64)blockIdx.x * kSumPiece;
+    const u64 plen = (n - p0) < (u64)kSumPiece ? (n - p0) : (u64)kSumPiece;
+    // thread t: bytes [t*256, t*256+256) of the piece
+    const u64 s0 = (u64)tid * 256;
+    u64 a = 0, b = 0;
+    u32 c = 0;
+    for (u64 i = s0; i < s0 + 256 && i < plen; ++i) {
+        const u32 d = in[p0 + i];
+        a += d;
+        b += (plen - i) * d;
+        c = s_tab[(c ^ d) & 0xFFu] ^ (c >> 8);
+    }
+    s_a[tid] = a; s_b[tid] = b; s_c[tid] = c;
+    __syncthreads();
+    if (tid == 0) {
+        u64 sa = 0, sb = 0;
+        for (u32 t = 0; t < 256; ++t) { sa += s_a[t]; sb += s_b[t]; }
+        asum[blockIdx.x] = sa;
+        bsum[blockIdx.x] = sb;
+    }
+    // sub-piece CRCs go out as they are; the host folds 256 of them per piece
+    crc[(u64)blockIdx.x * 256 + tid] = s_c[tid];
+}
+
+// ---------------------------------------------------------------------------------- launchers
+#define DFCHK(x) do { if ((x) != hipSuccess) return -1; } while (0)
+
+int df_sort_temp_bytes(u64 n, size_t *bytes)
+{
+    size_t t = 0;
+    u16 *k = nullptr;
+    u32 *v = nullptr;
+    if (rocprim::radix_sort_pairs(nullptr, t, k, k, v, v, (size_t)n, 0, 16, (hipStream_t) nullptr) != hipSuccess) return -1;
+    *bytes = t;
+    return 0;
+}
+
+int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u16 *keys_in, u16 *keys_out, u32 *vals_in, u32 *vals_out,
+                     void *tmp, size_t tmp_bytes, u16 *prevd)
+{
+    const u64 ntri = n >= 3 ? n - 2 : 0;
+    DFCHK(hipMemsetAsync(prevd, 0, (n + 8) * sizeof(u16), st));
+    if (!ntri) return 0;
+    hipLaunchKernelGGL(k_df_keys, dim3((u32)((ntri + 1023) / 1024)), dim3(256), 0, st, in, ntri, keys_in, vals_in);
+    DFCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)ntri, 0, 16, st));
+    hipLaunchKernelGGL(k_df_prev, dim3((u32)((ntri + 255) / 256)), dim3(256), 0, st, keys_out, vals_out, ntri, prevd);
+    return 0;
+}
+
+int df_launch_match(hipStream_t st, const u8 *in, const u16 *prevd, u64 n, u32 *M)
+{
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_df_match, dim3((u32)((n + kMTile - 1) / kMTile)), dim3(kMThreads), 0, st, in, prevd, n, M);
+    return 0;
+}
+
+int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *tabs, u16 *const *ents, const u32 *counts,
+                    u32 nlevels, u32 *code)
+{
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_df_adv, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, M, n, step);
+    hipLaunchKernelGGL(k_df_tile_tab, dim3(counts[0]), dim3(256), 0, st, step, n, tabs[0]);
+    for (u32 l = 1; l + 1 < nlevels; ++l)
+        hipLaunchKernelGGL(k_df_compose, dim3(counts[l]), dim3(320), 0, st, tabs[l - 1], counts[l - 1], tabs[l]);
+    DFCHK(hipMemsetAsync(ents[nlevels - 1], 0, sizeof(u16), st)); // the single top group is entered at 0
+    for (u32 l = nlevels - 1; l >= 1; --l)
+        hipLaunchKernelGGL(k_df_resolve, dim3((counts[l] + 63) / 64), dim3(64), 0, st, tabs[l - 1], counts[l - 1], ents[l],
+                           counts[l], ents[l - 1]);
+    hipLaunchKernelGGL(k_df_mark, dim3(counts[0]), dim3(256), 0, st, step, M, ents[0], n, code);
+    return 0;
+}
+
+int df_launch_blocks(hipStream_t st, const u8 *in, const u32 *code, u64 n, u64 *bstart, u32 *nb, u32 cap, DfBlock *blocks,
+                     u8 *lens, u32 *hdr, u32 *lm_scratch, u64 *total_bits)
+{
+    hipLaunchKernelGGL(k_df_cuts, dim3(1), dim3(64), 0, st, code, n, bstart, nb, cap);
+    hipLaunchKernelGGL(k_df_block, dim3(cap), dim3(kBThreads), 0, st, in, code, bstart, nb, blocks, lens, hdr, lm_scratch);
+    hipLaunchKernelGGL(k_df_offsets, dim3(1), dim3(64), 0, st, blocks, nb, total_bits);
+    return 0;
+}
+
+int df_launch_emit(hipStream_t st, const u8 *in, const u32 *code, const u64 *bstart, const u32 *nb, u32 cap,
+                   const DfBlock *blocks, const u8 *lens, const u32 *hdr, u32 *out)
+{
+    hipLaunchKernelGGL(k_df_emit, dim3(cap), dim3(kEThreads), 0, st, in, code, bstart, nb, blocks, lens, hdr, out);
+    return 0;
+}
+
+int df_launch_sums(hipStream_t st, const u8 *in, u64 n, u64 *asum, u64 *bsum, u32 *crc)
+{
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_df_sums, dim3((u32)((n + kSumPiece - 1) / kSumPiece)), dim3(256), 0, st, in, n, asum, bsum, crc);
+    return 0;
+}
+
+} // namespace dfgpu

@@ -12,7 +12,7 @@ from conftest import ROOT, product
 def _declared():
     src = open(os.path.join(ROOT, "include", "bz2_mi355x.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(bz_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b((?:bz|df)_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_symbols_exported(pkg):

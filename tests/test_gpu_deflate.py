@@ -1,0 +1,135 @@
+"""GPU parity tests of the Deflate / zlib / gzip ENCODE path (rows f-2, f-3; run with -m gpu on an
+MI355X): df_encode_buffer / df_enc_* / df_gpu_encode_device through the C ABI against the CPU
+oracle (oracle/deflate_oracle.c) -- LZSS codes, block decisions and the stream, bit for bit -- on
+the reference's own vectors (tests/golden/deflate_vectors.json) and on seeded inputs."""
+import gzip
+import json
+import os
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, sample
+from test_oracle_deflate import VEC, expand, pack_lsb
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(pkg):
+    e = pkg.GpuEngine(0, 1)
+    yield e
+    e.close()
+
+
+def dev_encode(pkg, eng, data, kind=0):
+    import torch
+    n = len(data)
+    tin = torch.frombuffer(bytearray(data) + bytearray(16), dtype=torch.uint8).cuda()
+    cap = pkg.deflate_bound(n)
+    tout = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    k = eng.deflate_encode_device(kind, tin.data_ptr(), n, tout.data_ptr(), cap)
+    return bytes(tout[:k].cpu().numpy()), tin
+
+
+def check(pkg, oracle, eng, data, codes=True):
+    got, tin = dev_encode(pkg, eng, data)
+    if codes:
+        want_codes = oracle.lzss_tokens_raw(data)
+        got_codes = eng.deflate_debug_codes(tin.data_ptr(), len(data))
+        assert got_codes.shape == want_codes.shape
+        bad = np.nonzero((got_codes != want_codes).any(axis=1))[0]
+        assert bad.size == 0, (int(bad[0]), got_codes[bad[0]].tolist(), want_codes[bad[0]].tolist())
+        e = oracle.DeflateEncoder()
+        e.feed(data, oracle.ACTION_FINISH)
+        want_blocks = [(b[1], b[2], b[3]) for b in e.blocks()]
+        got_blocks = [(b[1], b[2], b[3]) for b in eng.deflate_debug_blocks()]
+        assert got_blocks == want_blocks
+    want = oracle.deflate_encode(data)
+    assert got == want
+    assert zlib.decompress(got, -15) == data
+    return got
+
+
+@pytest.mark.parametrize("v", VEC["deflate"], ids=lambda v: v["name"])
+def test_reference_deflate_vectors(pkg, oracle, eng, v):
+    want = bytes(v["bytes"]) if "bytes" in v else pack_lsb(v["bits"])
+    data = expand(v["input"])
+    assert pkg.deflate_compress(data) == want
+    assert check(pkg, oracle, eng, data) == want
+
+
+@pytest.mark.parametrize("v", [v for v in VEC["containers"] if "dict" not in v], ids=lambda v: v["name"])
+def test_reference_container_vectors(pkg, v):
+    kind = pkg.ZLIB if v["kind"] == "zlib" else pkg.GZIP
+    assert pkg.deflate_compress(expand(v["input"]), kind) == bytes(v["bytes"])
+
+
+@pytest.mark.parametrize("v", [v for v in VEC["lzss"] if "dict" not in v and v["name"] not in ("test_7", "test_11")],
+                         ids=lambda v: v["name"])
+def test_lzss_inputs_with_deflate_parameters(pkg, oracle, eng, v):
+    """the inputs of the reference's LZSS tests under Inflater's parameters (window 0x8000, 258)"""
+    check(pkg, oracle, eng, expand(v["input"]))
+
+
+def _inputs():
+    rnd = random.Random(11)
+    words = [bytes(rnd.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(rnd.randint(1, 9))) for _ in range(300)]
+    text = b" ".join(rnd.choice(words) for _ in range(60000))
+    yield "text", text
+    yield "random", bytes(rnd.getrandbits(8) for _ in range(200000))
+    yield "runs", b"".join(bytes([rnd.randrange(4)]) * rnd.randint(1, 700) for _ in range(2000))
+    yield "dna", bytes(rnd.choice(b"ACGT") for _ in range(150000))
+    yield "period256", bytes(range(256)) * 600
+    yield "zeros", bytes(300000)
+    yield "far", b"abc" + b"d" * (0x8000 - 3) + b"abc" + b"e" * 40000 + b"abcd"
+    yield "mixed", text[:70000] + bytes(rnd.getrandbits(8) for _ in range(70000)) + text[:70000]
+    yield "skewed", bytes(min(255, int(rnd.expovariate(0.08))) for _ in range(120000))
+
+
+@pytest.mark.parametrize("name,data", list(_inputs()), ids=[n for n, _ in _inputs()])
+def test_seeded_inputs(pkg, oracle, eng, name, data):
+    check(pkg, oracle, eng, data)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 257, 258, 259, 260, 261, 262, 4095, 4096, 4097, 8191, 8192, 8193,
+                               32767, 32768, 32769, 65534, 65535, 65536, 65537, 131070, 131071])
+def test_sizes(pkg, oracle, eng, n):
+    rnd = random.Random(n)
+    check(pkg, oracle, eng, bytes(rnd.choice(b"ab") for _ in range(n)))
+    check(pkg, oracle, eng, bytes(rnd.choice(b"abcdefgh \n") for _ in range(n)))
+
+
+@pytest.mark.parametrize("i", [1, 2, 3])
+def test_samples(pkg, oracle, eng, i):
+    check(pkg, oracle, eng, sample(i)[:3000000])
+
+
+def test_containers_and_mirrors(pkg, oracle):
+    d = sample(1)[:400000]
+    assert pkg.deflate_compress(d, pkg.ZLIB) == oracle.deflate_encode(d, oracle.ZLIB)
+    assert pkg.deflate_compress(d, pkg.GZIP) == oracle.deflate_encode(d, oracle.GZIP)
+    assert zlib.decompress(pkg.deflate_compress(d, pkg.ZLIB)) == d
+    assert gzip.decompress(pkg.deflate_compress(d, pkg.GZIP)) == d
+    # `data.encode(&mut Inflater::new(), Action::Finish).collect()`
+    enc = pkg.Inflater()
+    assert bytes(pkg.encode(iter(d[:5000]), enc, pkg.Action.FINISH)) == oracle.deflate_encode(d[:5000])
+    # Run then Finish == one iterator (the reference's Run leaves everything pending)
+    enc = pkg.GZipEncoder()
+    enc.write(d[:100000]); enc.end(pkg.Action.RUN)
+    enc.write(d[100000:]); enc.end(pkg.Action.FINISH)
+    assert enc.read_all() == oracle.deflate_encode(d, oracle.GZIP)
+    with pytest.raises(pkg.CompressionError):
+        pkg.ZlibEncoder().end(pkg.Action.FLUSH)
+
+
+def test_big_corpus(pkg, oracle, eng):
+    """64 MiB of the bench corpus: stream equals the oracle's, inflates back with zlib"""
+    import corpus
+    d = corpus.corpus_bytes(64 << 20)
+    got, _ = dev_encode(pkg, eng, d)
+    assert zlib.decompress(got, -15) == d
+    want = oracle.deflate_encode(d)
+    assert got == want
