@@ -57,32 +57,51 @@ __global__ __launch_bounds__(256) void k_df_keys(const u8 *__restrict__ in, u64 
     }
 }
 
-// sorted by (hash, position): distance to the previous position with the same hash, 0 = none in the window
+// sorted by (hash, position): distance to the previous position with the same hash (0 = none in the window),
+// and the length of the chain search_dic would walk from it (how many earlier positions with this hash
+// lie within the window, at most 255): the match kernel groups positions of similar chain length
 __global__ __launch_bounds__(256) void k_df_prev(const u16 *__restrict__ ks, const u32 *__restrict__ vs, u64 ntri,
-                                                 u16 *__restrict__ prevd)
+                                                 u16 *__restrict__ prevd, u8 *__restrict__ est)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     if (i >= ntri) return;
     const u32 p = vs[i];
+    const u32 h = ks[i];
     u32 d = 0;
-    if (i > 0 && ks[i - 1] == ks[i]) {
+    if (i > 0 && ks[i - 1] == h) {
         const u32 dd = p - vs[i - 1];
         if (dd <= kWin) d = dd;
     }
     prevd[p] = (u16)d;
+    u32 e = 0;
+    if (d) { // smallest j in [i - 255, i) with the same hash and vs[j] + window >= p (monotone in j)
+        u64 lo = i >= kChain ? i - kChain : 0, hi = i - 1; // hi qualifies
+        while (lo < hi) {
+            const u64 mid = (lo + hi) >> 1;
+            if (ks[mid] == h && vs[mid] + kWin >= p) hi = mid; else lo = mid + 1;
+        }
+        e = (u32)(i - lo);
+    }
+    est[p] = (u8)e;
 }
 
 // ---------------------------------------------------------------------------------- matches
 constexpr u32 kMDataBytes = kWin + kMTile + 272;
 
-__global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ in, const u16 *__restrict__ prevd, u64 n,
-                                                        u32 *__restrict__ M)
+__global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ in, const u16 *__restrict__ prevd,
+                                                        const u8 *__restrict__ est, u64 n, u32 *__restrict__ M)
 {
     __shared__ u32 s_w[kMDataBytes / 4];
     __shared__ u16 s_prev[kWin + kMTile];
+    __shared__ u16 s_order[kMTile];
+    __shared__ u32 s_hist[256];
+    __shared__ u32 s_next;
     const u32 tid = threadIdx.x;
     const u64 t0 = (u64)blockIdx.x * kMTile;
     const i64 base = (i64)t0 - (i64)kWin; // multiple of 4
+    const u32 count = (n - t0) < (u64)kMTile ? (u32)(n - t0) : kMTile;
+    if (tid < 256) s_hist[tid] = 0;
+    if (tid == 0) s_next = 0;
     for (u32 w = tid; w < kMDataBytes / 4; w += kMThreads) {
         const i64 g = base + 4 * (i64)w;
         u32 v = 0;
@@ -99,37 +118,84 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
         reinterpret_cast<u32 *>(s_prev)[k] = v;
     }
     __syncthreads();
+    // positions of the tile ordered by chain length, longest first (a counting sort on 256 lengths): the 64
+    // lanes of a wave then walk chains of about the same length
+    u32 my_est[kMTile / kMThreads];
+    for (u32 j = 0; j < kMTile / kMThreads; ++j) {
+        const u32 k = j * kMThreads + tid;
+        my_est[j] = k < count ? 255u - est[t0 + k] : 0u;
+        if (k < count) atomicAdd(&s_hist[my_est[j]], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) { // exclusive prefix over the 256 bins
+        u32 v[4], s = 0;
+        for (u32 j = 0; j < 4; ++j) { v[j] = s_hist[tid * 4 + j]; s += v[j]; }
+        u32 inc = s;
+        for (u32 dlt = 1; dlt < 64; dlt <<= 1) {
+            const u32 o = __shfl_up(inc, dlt);
+            if (tid >= dlt) inc += o;
+        }
+        u32 run = inc - s;
+        for (u32 j = 0; j < 4; ++j) { s_hist[tid * 4 + j] = run; run += v[j]; }
+    }
+    __syncthreads();
+    for (u32 j = 0; j < kMTile / kMThreads; ++j) {
+        const u32 k = j * kMThreads + tid;
+        if (k < count) s_order[atomicAdd(&s_hist[my_est[j]], 1u)] = (u16)k;
+    }
+    __syncthreads();
+    // four bytes at any offset from two aligned dwords (an unaligned ds_read_b32 is legal on gfx950 but was
+    // measured slower here)
     auto ld4 = [&](u32 byte) -> u32 { return __builtin_amdgcn_alignbyte(s_w[(byte >> 2) + 1], s_w[byte >> 2], byte & 3u); };
-    for (u32 k = tid; k < kMTile; k += kMThreads) {
-        const u64 p = t0 + k;
-        if (p >= n) break;
+    const u32 lane = tid & 63u;
+    const u32 nchunks = (count + 63) / 64;
+    for (;;) {
+        u32 c = 0;
+        if (lane == 0) c = atomicAdd(&s_next, 1u);
+        c = (u32)__builtin_amdgcn_readfirstlane((int)c);
+        if (c >= nchunks) break;
+        const u32 idx = c * 64 + lane;
+        const bool valid = idx < count;
+        const u32 k = valid ? s_order[idx] : 0u;
         const u32 lp = kWin + k;
+        const u64 p = t0 + k;
         const u32 limit = (n - p) < (u64)kMaxMatch ? (u32)(n - p) : kMaxMatch; // search_dic :228
-        u32 best_len = 0, best_dist = 0, cum = 0, cnt = kChain;
-        u32 d = s_prev[lp];
-        const u32 a0 = ld4(lp);
-        while (d != 0 && cnt != 0) {
-            cum += d;
-            if (cum > kWin) break;
+        u32 cum = valid ? s_prev[lp] : 0u;                                       // (a first hop is never longer than the window)
+        bool active = cum != 0;
+        u32 best_len = 0, best_dist = 0, cnt = kChain;
+        // bytes p .. p+7
+        const u32 pw0 = s_w[lp >> 2], pw1 = s_w[(lp >> 2) + 1], pw2 = s_w[(lp >> 2) + 2];
+        const u32 a0 = __builtin_amdgcn_alignbyte(pw1, pw0, lp & 3u), a1 = __builtin_amdgcn_alignbyte(pw2, pw1, lp & 3u);
+        // The walk (search_dic :232-265) without branches per lane: lanes that are done keep computing on
+        // their last candidate and are masked out of the updates.
+        while (__ballot(active)) {
             const u32 lc = lp - cum;
-            u32 x = a0 ^ ld4(lc);
-            u32 l;
-            if (x) l = (u32)__builtin_ctz(x) >> 3;
-            else {
-                l = 4;
-                while (l < limit) {
-                    x = ld4(lp + l) ^ ld4(lc + l);
-                    if (x) { l += (u32)__builtin_ctz(x) >> 3; break; }
-                    l += 4;
+            const u32 cw0 = s_w[lc >> 2], cw1 = s_w[(lc >> 2) + 1], cw2 = s_w[(lc >> 2) + 2];
+            const u32 x0 = a0 ^ __builtin_amdgcn_alignbyte(cw1, cw0, lc & 3u);
+            const u32 x1 = a1 ^ __builtin_amdgcn_alignbyte(cw2, cw1, lc & 3u);
+            u32 l = x0 ? ((u32)__builtin_ctz(x0) >> 3) : (x1 ? 4u + ((u32)__builtin_ctz(x1) >> 3) : 8u);
+            const bool more8 = active && l == 8 && limit > 8;
+            if (__ballot(more8)) { // some lane matched 8 bytes: extend it (check_match :175-188)
+                if (more8) {
+                    while (l < limit) {
+                        const u32 x = ld4(lp + l) ^ ld4(lc + l);
+                        if (x) { l += (u32)__builtin_ctz(x) >> 3; break; }
+                        l += 4;
+                    }
                 }
             }
-            if (l > limit) l = limit;
-            if (l > best_len) { best_len = l; best_dist = cum; }
-            if (l == limit) break; // :258-259
-            --cnt;
-            d = s_prev[lc];
+            l = l < limit ? l : limit;
+            const bool better = active && l > best_len;
+            best_len = better ? l : best_len;
+            best_dist = better ? cum : best_dist;
+            const u32 d = s_prev[lc];
+            cnt -= 1;
+            const u32 ncum = cum + d;
+            const bool cont = active && l != limit && cnt != 0 && d != 0 && ncum <= kWin; // :258-262, :234
+            cum = cont ? ncum : cum;
+            active = cont;
         }
-        M[p] = best_len >= kMinMatch ? (best_len | ((best_dist - 1) << 9)) : 0u;
+        if (valid) M[p] = best_len >= kMinMatch ? (best_len | ((best_dist - 1) << 9)) : 0u;
     }
 }
 
@@ -782,21 +848,22 @@ int df_sort_temp_bytes(u64 n, size_t *bytes)
 }
 
 int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u16 *keys_in, u16 *keys_out, u32 *vals_in, u32 *vals_out,
-                     void *tmp, size_t tmp_bytes, u16 *prevd)
+                     void *tmp, size_t tmp_bytes, u16 *prevd, u8 *est)
 {
     const u64 ntri = n >= 3 ? n - 2 : 0;
     DFCHK(hipMemsetAsync(prevd, 0, (n + 8) * sizeof(u16), st));
+    DFCHK(hipMemsetAsync(est, 0, n + 8, st));
     if (!ntri) return 0;
     hipLaunchKernelGGL(k_df_keys, dim3((u32)((ntri + 1023) / 1024)), dim3(256), 0, st, in, ntri, keys_in, vals_in);
     DFCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)ntri, 0, 16, st));
-    hipLaunchKernelGGL(k_df_prev, dim3((u32)((ntri + 255) / 256)), dim3(256), 0, st, keys_out, vals_out, ntri, prevd);
+    hipLaunchKernelGGL(k_df_prev, dim3((u32)((ntri + 255) / 256)), dim3(256), 0, st, keys_out, vals_out, ntri, prevd, est);
     return 0;
 }
 
-int df_launch_match(hipStream_t st, const u8 *in, const u16 *prevd, u64 n, u32 *M)
+int df_launch_match(hipStream_t st, const u8 *in, const u16 *prevd, const u8 *est, u64 n, u32 *M)
 {
     if (!n) return 0;
-    hipLaunchKernelGGL(k_df_match, dim3((u32)((n + kMTile - 1) / kMTile)), dim3(kMThreads), 0, st, in, prevd, n, M);
+    hipLaunchKernelGGL(k_df_match, dim3((u32)((n + kMTile - 1) / kMTile)), dim3(kMThreads), 0, st, in, prevd, est, n, M);
     return 0;
 }
 
