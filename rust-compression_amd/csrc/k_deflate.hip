@@ -63,24 +63,36 @@ __global__ __launch_bounds__(256) void k_df_keys(const u8 *__restrict__ in, u64 
 __global__ __launch_bounds__(256) void k_df_prev(const u16 *__restrict__ ks, const u32 *__restrict__ vs, u64 ntri,
                                                  u16 *__restrict__ prevd, u8 *__restrict__ est)
 {
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    // the 255 entries in front of the workgroup's 256 and its own, staged once: the search runs in LDS
+    __shared__ u16 s_k[256 + 256];
+    __shared__ u32 s_v[256 + 256];
+    const u64 i0 = (u64)blockIdx.x * 256;
+    for (u32 j = threadIdx.x; j < 512; j += 256) {
+        const i64 g = (i64)i0 - 256 + (i64)j;
+        const bool ok = g >= 0 && (u64)g < ntri;
+        s_k[j] = ok ? ks[g] : (u16)0;
+        s_v[j] = ok ? vs[g] : 0u;
+    }
+    __syncthreads();
+    const u64 i = i0 + threadIdx.x;
     if (i >= ntri) return;
-    const u32 p = vs[i];
-    const u32 h = ks[i];
+    const u32 li = 256 + threadIdx.x;
+    const u32 p = s_v[li];
+    const u32 h = s_k[li];
     u32 d = 0;
-    if (i > 0 && ks[i - 1] == h) {
-        const u32 dd = p - vs[i - 1];
+    if (i > 0 && s_k[li - 1] == h) {
+        const u32 dd = p - s_v[li - 1];
         if (dd <= kWin) d = dd;
     }
     prevd[p] = (u16)d;
     u32 e = 0;
     if (d) { // smallest j in [i - 255, i) with the same hash and vs[j] + window >= p (monotone in j)
-        u64 lo = i >= kChain ? i - kChain : 0, hi = i - 1; // hi qualifies
+        u32 lo = i >= kChain ? li - kChain : li - (u32)i, hi = li - 1; // hi qualifies
         while (lo < hi) {
-            const u64 mid = (lo + hi) >> 1;
-            if (ks[mid] == h && vs[mid] + kWin >= p) hi = mid; else lo = mid + 1;
+            const u32 mid = (lo + hi) >> 1;
+            if (s_k[mid] == h && s_v[mid] + kWin >= p) hi = mid; else lo = mid + 1;
         }
-        e = (u32)(i - lo);
+        e = li - lo;
     }
     est[p] = (u8)e;
 }
@@ -166,32 +178,41 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
         // bytes p .. p+7
         const u32 pw0 = s_w[lp >> 2], pw1 = s_w[(lp >> 2) + 1], pw2 = s_w[(lp >> 2) + 2];
         const u32 a0 = __builtin_amdgcn_alignbyte(pw1, pw0, lp & 3u), a1 = __builtin_amdgcn_alignbyte(pw2, pw1, lp & 3u);
-        // The walk (search_dic :232-265) without branches per lane: lanes that are done keep computing on
-        // their last candidate and are masked out of the updates.
+        // The walk (search_dic :232-265).  A candidate replaces the best one only if it is strictly longer
+        // (deflate/encoder.rs:34-51 with a farther candidate), so it must agree with p at offset best_len:
+        // one byte decides for most candidates, the survivors are measured in full.  Lanes that are done
+        // keep computing on their last candidate and are masked out of the updates.
+        const u8 *s_b = reinterpret_cast<const u8 *>(s_w);
+        u32 pb = a0 & 0xFFu; // byte of p at offset best_len
         while (__ballot(active)) {
             const u32 lc = lp - cum;
-            const u32 cw0 = s_w[lc >> 2], cw1 = s_w[(lc >> 2) + 1], cw2 = s_w[(lc >> 2) + 2];
-            const u32 x0 = a0 ^ __builtin_amdgcn_alignbyte(cw1, cw0, lc & 3u);
-            const u32 x1 = a1 ^ __builtin_amdgcn_alignbyte(cw2, cw1, lc & 3u);
-            u32 l = x0 ? ((u32)__builtin_ctz(x0) >> 3) : (x1 ? 4u + ((u32)__builtin_ctz(x1) >> 3) : 8u);
-            const bool more8 = active && l == 8 && limit > 8;
-            if (__ballot(more8)) { // some lane matched 8 bytes: extend it (check_match :175-188)
-                if (more8) {
-                    while (l < limit) {
-                        const u32 x = ld4(lp + l) ^ ld4(lc + l);
-                        if (x) { l += (u32)__builtin_ctz(x) >> 3; break; }
-                        l += 4;
+            const bool surv = active && s_b[lc + best_len] == pb;
+            bool hit = false;
+            if (__ballot(surv)) {
+                if (surv) {
+                    const u32 cw0 = s_w[lc >> 2], cw1 = s_w[(lc >> 2) + 1], cw2 = s_w[(lc >> 2) + 2];
+                    const u32 x0 = a0 ^ __builtin_amdgcn_alignbyte(cw1, cw0, lc & 3u);
+                    const u32 x1 = a1 ^ __builtin_amdgcn_alignbyte(cw2, cw1, lc & 3u);
+                    u32 l = x0 ? ((u32)__builtin_ctz(x0) >> 3) : (x1 ? 4u + ((u32)__builtin_ctz(x1) >> 3) : 8u);
+                    if (l == 8) // check_match :175-188
+                        while (l < limit) {
+                            const u32 x = ld4(lp + l) ^ ld4(lc + l);
+                            if (x) { l += (u32)__builtin_ctz(x) >> 3; break; }
+                            l += 4;
+                        }
+                    l = l < limit ? l : limit;
+                    hit = l == limit;
+                    if (l > best_len) {
+                        best_len = l;
+                        best_dist = cum;
+                        pb = s_b[lp + l]; // (not compared again when l == limit: the walk ends)
                     }
                 }
             }
-            l = l < limit ? l : limit;
-            const bool better = active && l > best_len;
-            best_len = better ? l : best_len;
-            best_dist = better ? cum : best_dist;
             const u32 d = s_prev[lc];
             cnt -= 1;
             const u32 ncum = cum + d;
-            const bool cont = active && l != limit && cnt != 0 && d != 0 && ncum <= kWin; // :258-262, :234
+            const bool cont = active && !hit && cnt != 0 && d != 0 && ncum <= kWin; // :258-262, :234
             cum = cont ? ncum : cum;
             active = cont;
         }
