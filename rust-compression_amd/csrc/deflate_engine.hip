@@ -95,10 +95,11 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, u8 
         if (df_sort_temp_bytes(n, &t) != 0) return BZ_E_UNEXPECTED;
         w->sort_tmp_bytes = t;
     }
-    if ((rc = w->keys_in.ensure(npad * 2)) != BZ_OK) return rc;   // later: step[]
-    if ((rc = w->keys_out.ensure(npad * 2)) != BZ_OK) return rc;
-    if ((rc = w->vals_in.ensure(npad * 4)) != BZ_OK) return rc;   // later: M[]
-    if ((rc = w->vals_out.ensure(npad * 4)) != BZ_OK) return rc;  // later: code[]
+    const u64 nent = df_entries(n) + 16;
+    if ((rc = w->keys_in.ensure((nent > npad ? nent : npad) * 4)) != BZ_OK) return rc;   // later: step[]
+    if ((rc = w->keys_out.ensure(nent * 4)) != BZ_OK) return rc;
+    if ((rc = w->vals_in.ensure((nent > npad ? nent : npad) * 4)) != BZ_OK) return rc;   // later: M[]
+    if ((rc = w->vals_out.ensure((nent > npad ? nent : npad) * 4)) != BZ_OK) return rc;  // later: code[]
     if ((rc = w->sort_tmp.ensure(w->sort_tmp_bytes + 256)) != BZ_OK) return rc;
     if ((rc = w->prevd.ensure(npad * 2)) != BZ_OK) return rc;
     if ((rc = w->est.ensure(npad)) != BZ_OK) return rc;
@@ -134,7 +135,7 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, u8 
 
     HIPCHK(hipEventRecord(w->ev[0], st));
     HIPCHK(hipMemsetAsync(w->stream.p, 0, bound + 64, st));
-    if (df_launch_chains(st, d_in, n, w->keys_in.as<u16>(), w->keys_out.as<u16>(), w->vals_in.as<u32>(), w->vals_out.as<u32>(),
+    if (df_launch_chains(st, d_in, n, w->keys_in.as<u32>(), w->keys_out.as<u32>(), w->vals_in.as<u32>(), w->vals_out.as<u32>(),
                          w->sort_tmp.p, w->sort_tmp_bytes, w->prevd.as<u16>(), w->est.as<u8>()) != 0)
         return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[1], st));

@@ -15,6 +15,7 @@ constexpr u32 kMaxMatch = 258;     // LZSS_MAX_MATCH :110
 constexpr u32 kMinMatch = 3;       // LZSS_MIN_MATCH :109
 constexpr u32 kChain = 255;        // MATCH_SEARCH_COUNT - 1 (lzss/slidedict.rs:129, 232)
 constexpr u32 kBlockMax = 0xFFFF;  // MAX_BLOCK_SIZE (deflate/encoder.rs:270)
+constexpr u32 kChunk = 1u << 20;    // positions per sort chunk (hash chains are built chunk by chunk)
 constexpr u32 kMTile = 8192;       // positions per match workgroup
 constexpr u32 kMThreads = 1024;
 constexpr u32 kPTile = 4096;       // positions per parse tile
@@ -39,7 +40,8 @@ struct DfBlock {
 };
 
 int df_sort_temp_bytes(u64 n, size_t *bytes);
-int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u16 *keys_in, u16 *keys_out, u32 *vals_in, u32 *vals_out,
+u64 df_entries(u64 n); // entries the chain sort handles: trigram positions + 32 KiB of history per chunk
+int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *keys_in, u32 *keys_out, u32 *vals_in, u32 *vals_out,
                      void *tmp, size_t tmp_bytes, u16 *prevd, u8 *est);
 int df_launch_match(hipStream_t st, const u8 *in, const u16 *prevd, const u8 *est, u64 n, u32 *M);
 int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *tabs, u16 *const *ents, const u32 *counts,

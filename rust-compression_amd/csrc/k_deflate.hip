@@ -39,55 +39,63 @@ __device__ __forceinline__ u32 hash16(u32 b0, u32 b1, u32 b2)
     return (u32)((h * 0x7A7C4F9F7A7C4F9Full) >> 48);
 }
 
-__global__ __launch_bounds__(256) void k_df_keys(const u8 *__restrict__ in, u64 ntri, u16 *__restrict__ keys,
-                                                 u32 *__restrict__ vals)
+// Entries to sort: the trigram positions, chunk by chunk (kChunk positions each), every chunk preceded by the
+// 32 KiB of positions in front of it (they are the chain candidates of its first positions).  Key = chunk
+// << 16 | hash: one global sort leaves every chunk's entries in the chunk's own range, ordered by (hash,
+// position), and k_df_prev scatters into 3 MB per chunk instead of the whole input.
+__device__ __forceinline__ void df_entry(u64 e, u32 &chunk, u64 &pos)
 {
-    // 4 positions per thread from two aligned dwords
-    const u64 i0 = ((u64)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i0 >= ntri) return;
-    const u64 n = ntri + 2;
-    u64 v = 0;
-    if (i0 + 8 <= n) { const u32 *w = reinterpret_cast<const u32 *>(in + i0); v = (u64)w[0] | ((u64)w[1] << 32); }
-    else
-        for (u32 b = 0; b < 8 && i0 + b < n; ++b) v |= (u64)in[i0 + b] << (8 * b);
-    for (u32 k = 0; k < 4 && i0 + k < ntri; ++k) {
-        const u32 b0 = (u32)(v >> (8 * k)) & 0xFF, b1 = (u32)(v >> (8 * k + 8)) & 0xFF, b2 = (u32)(v >> (8 * k + 16)) & 0xFF;
-        keys[i0 + k] = (u16)hash16(b0, b1, b2);
-        vals[i0 + k] = (u32)(i0 + k);
-    }
+    if (e < kChunk) { chunk = 0; pos = e; return; }
+    const u64 r = e - kChunk;
+    chunk = 1 + (u32)(r / (kChunk + kWin));
+    pos = (u64)chunk * kChunk - kWin + (r % (kChunk + kWin));
 }
 
-// sorted by (hash, position): distance to the previous position with the same hash (0 = none in the window),
-// and the length of the chain search_dic would walk from it (how many earlier positions with this hash
-// lie within the window, at most 255): the match kernel groups positions of similar chain length
-__global__ __launch_bounds__(256) void k_df_prev(const u16 *__restrict__ ks, const u32 *__restrict__ vs, u64 ntri,
+__global__ __launch_bounds__(256) void k_df_keys(const u8 *__restrict__ in, u64 ntri, u64 nent, u32 *__restrict__ keys,
+                                                 u32 *__restrict__ vals)
+{
+    const u64 e = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nent) return;
+    u32 chunk;
+    u64 pos;
+    df_entry(e, chunk, pos);
+    keys[e] = (chunk << 16) | hash16(in[pos], in[pos + 1], in[pos + 2]);
+    vals[e] = (u32)pos;
+}
+
+// sorted by (chunk, hash, position): distance to the previous position with the same hash (0 = none in the
+// window), and the length of the chain search_dic would walk from it (how many earlier positions with this
+// hash lie within the window, at most 255): the match kernel groups positions of similar chain length.
+// The entries in front of a chunk's first position only serve as predecessors.
+__global__ __launch_bounds__(256) void k_df_prev(const u32 *__restrict__ ks, const u32 *__restrict__ vs, u64 nent,
                                                  u16 *__restrict__ prevd, u8 *__restrict__ est)
 {
     // the 255 entries in front of the workgroup's 256 and its own, staged once: the search runs in LDS
-    __shared__ u16 s_k[256 + 256];
+    __shared__ u32 s_k[256 + 256];
     __shared__ u32 s_v[256 + 256];
     const u64 i0 = (u64)blockIdx.x * 256;
     for (u32 j = threadIdx.x; j < 512; j += 256) {
         const i64 g = (i64)i0 - 256 + (i64)j;
-        const bool ok = g >= 0 && (u64)g < ntri;
-        s_k[j] = ok ? ks[g] : (u16)0;
+        const bool ok = g >= 0 && (u64)g < nent;
+        s_k[j] = ok ? ks[g] : 0xFFFFFFFFu;
         s_v[j] = ok ? vs[g] : 0u;
     }
     __syncthreads();
     const u64 i = i0 + threadIdx.x;
-    if (i >= ntri) return;
+    if (i >= nent) return;
     const u32 li = 256 + threadIdx.x;
     const u32 p = s_v[li];
     const u32 h = s_k[li];
+    if ((u64)p < (u64)(h >> 16) * kChunk) return; // history entry of this chunk: written by the chunk that owns it
     u32 d = 0;
-    if (i > 0 && s_k[li - 1] == h) {
+    if (s_k[li - 1] == h) {
         const u32 dd = p - s_v[li - 1];
         if (dd <= kWin) d = dd;
     }
     prevd[p] = (u16)d;
     u32 e = 0;
-    if (d) { // smallest j in [i - 255, i) with the same hash and vs[j] + window >= p (monotone in j)
-        u32 lo = i >= kChain ? li - kChain : li - (u32)i, hi = li - 1; // hi qualifies
+    if (d) { // smallest j in [i - 255, i) with the same key and vs[j] + window >= p (monotone in j)
+        u32 lo = li - kChain, hi = li - 1; // hi qualifies; entries before the array start carry key ~0
         while (lo < hi) {
             const u32 mid = (lo + hi) >> 1;
             if (s_k[mid] == h && s_v[mid] + kWin >= p) hi = mid; else lo = mid + 1;
@@ -858,26 +866,46 @@ __global__ __launch_bounds__(256) void k_df_sums(const u8 *__restrict__ in, u64 
 // ---------------------------------------------------------------------------------- launchers
 #define DFCHK(x) do { if ((x) != hipSuccess) return -1; } while (0)
 
+u64 df_entries(u64 n)
+{
+    const u64 ntri = n >= 3 ? n - 2 : 0;
+    if (ntri <= kChunk) return ntri;
+    const u64 nchunks = (ntri + kChunk - 1) / kChunk;
+    return ntri + (nchunks - 1) * kWin;
+}
+
+static u32 df_key_bits(u64 n)
+{
+    const u64 ntri = n >= 3 ? n - 2 : 0;
+    const u64 nchunks = ntri ? (ntri + kChunk - 1) / kChunk : 1;
+    u32 b = 16;
+    while ((1ull << (b - 16)) < nchunks) ++b;
+    return b;
+}
+
 int df_sort_temp_bytes(u64 n, size_t *bytes)
 {
     size_t t = 0;
-    u16 *k = nullptr;
+    u32 *k = nullptr;
     u32 *v = nullptr;
-    if (rocprim::radix_sort_pairs(nullptr, t, k, k, v, v, (size_t)n, 0, 16, (hipStream_t) nullptr) != hipSuccess) return -1;
+    if (rocprim::radix_sort_pairs(nullptr, t, k, k, v, v, (size_t)df_entries(n), 0, df_key_bits(n), (hipStream_t) nullptr) !=
+        hipSuccess)
+        return -1;
     *bytes = t;
     return 0;
 }
 
-int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u16 *keys_in, u16 *keys_out, u32 *vals_in, u32 *vals_out,
+int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *keys_in, u32 *keys_out, u32 *vals_in, u32 *vals_out,
                      void *tmp, size_t tmp_bytes, u16 *prevd, u8 *est)
 {
     const u64 ntri = n >= 3 ? n - 2 : 0;
+    const u64 nent = df_entries(n);
     DFCHK(hipMemsetAsync(prevd, 0, (n + 8) * sizeof(u16), st));
     DFCHK(hipMemsetAsync(est, 0, n + 8, st));
     if (!ntri) return 0;
-    hipLaunchKernelGGL(k_df_keys, dim3((u32)((ntri + 1023) / 1024)), dim3(256), 0, st, in, ntri, keys_in, vals_in);
-    DFCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)ntri, 0, 16, st));
-    hipLaunchKernelGGL(k_df_prev, dim3((u32)((ntri + 255) / 256)), dim3(256), 0, st, keys_out, vals_out, ntri, prevd, est);
+    hipLaunchKernelGGL(k_df_keys, dim3((u32)((nent + 255) / 256)), dim3(256), 0, st, in, ntri, nent, keys_in, vals_in);
+    DFCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)nent, 0, df_key_bits(n), st));
+    hipLaunchKernelGGL(k_df_prev, dim3((u32)((nent + 255) / 256)), dim3(256), 0, st, keys_out, vals_out, nent, prevd, est);
     return 0;
 }
 
