@@ -313,7 +313,10 @@ int df_gpu_encode_device(bz_gpu_engine *g, int kind, const void *d_in, size_t n,
  * (sort) [1] matches [2] parse [3] blocks + tables [4] emission + checksums [5] total. */
 int df_gpu_last_timings(bz_gpu_engine *g, double out_seconds[6]);
 /* [0] blocks [1] stored [2] fixed [3] dynamic [4] tables that took the
- * length-limited path [5] stream bytes */
+ * length-limited path [5] stream bytes [6] dynamic blocks without any match: for
+ * those the reference writes HDIST = 0 and no distance code length
+ * (src/deflate/encoder.rs:431-436, 449-451), which RFC 1951 decoders reject; the
+ * stream is reproduced as the reference writes it and counted here */
 int df_gpu_last_stats(bz_gpu_engine *g, uint64_t out[8]);
 /* Test hooks: the LZSS codes of the last call in stream order as (len, pos)
  * pairs, len 0 = the literal `pos` (what LzssEncoder::next yields,

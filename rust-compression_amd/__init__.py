@@ -630,7 +630,8 @@ class GpuEngine:
     def deflate_stats(self):
         s = (C.c_uint64 * 8)()
         _check(lib().df_gpu_last_stats(self._h, s))
-        return dict(blocks=s[0], stored=s[1], fixed=s[2], dynamic=s[3], limited_tables=s[4], stream_bytes=s[5])
+        return dict(blocks=s[0], stored=s[1], fixed=s[2], dynamic=s[3], limited_tables=s[4], stream_bytes=s[5],
+                    dynamic_without_distances=s[6])
 
     def deflate_debug_codes(self, d_in, n):
         """numpy uint32 [count, 2] of (len, pos); len 0: literal pos"""

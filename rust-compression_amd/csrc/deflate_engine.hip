@@ -19,7 +19,7 @@ struct DfWorkspace {
         stream, asum, bsum, crc;
     size_t sort_tmp_bytes = 0;
     double t_stage[6] = {0, 0, 0, 0, 0, 0}; // chains, matches, parse, blocks, emit, total
-    u64 stats[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // blocks, stored, fixed, dynamic, limited tables, stream bytes
+    u64 stats[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // blocks, stored, fixed, dynamic, limited tables, stream bytes, dynamic w/o distances
     hipEvent_t ev[7] = {};
     bool ev_ready = false;
     std::vector<DfBlock> h_blocks;
@@ -237,7 +237,8 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, u8 
     w->stats[0] = nb;
     for (const DfBlock &bi : w->h_blocks) {
         w->stats[1 + (bi.btype < 3 ? bi.btype : 0)] += 1;
-        w->stats[4] += bi.lm;
+        w->stats[4] += bi.lm & 0xFFu;
+        w->stats[6] += (bi.lm >> 8) & 1u; // dynamic block without any match: the reference's header has no distance length
     }
     w->stats[5] = need;
     return BZ_OK;

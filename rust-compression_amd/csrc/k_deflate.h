@@ -16,6 +16,7 @@ constexpr u32 kMinMatch = 3;       // LZSS_MIN_MATCH :109
 constexpr u32 kChain = 255;        // MATCH_SEARCH_COUNT - 1 (lzss/slidedict.rs:129, 232)
 constexpr u32 kBlockMax = 0xFFFF;  // MAX_BLOCK_SIZE (deflate/encoder.rs:270)
 constexpr u32 kChunk = 1u << 20;    // positions per sort chunk (hash chains are built chunk by chunk)
+constexpr u32 kPrevSpan = (kChunk + kWin) / 256; // 256-entry slices of one sort chunk
 constexpr u32 kMTile = 8192;       // positions per match workgroup
 constexpr u32 kMThreads = 1024;
 constexpr u32 kPTile = 4096;       // positions per parse tile

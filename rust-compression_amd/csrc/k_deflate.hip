@@ -73,12 +73,21 @@ __global__ __launch_bounds__(256) void k_df_prev(const u32 *__restrict__ ks, con
     // the 255 entries in front of the workgroup's 256 and its own, staged once: the search runs in LDS
     __shared__ u32 s_k[256 + 256];
     __shared__ u32 s_v[256 + 256];
-    const u64 i0 = (u64)blockIdx.x * 256;
+    // workgroups are dealt round-robin to the 8 XCDs: the r-th workgroup of XCD x takes the r-th slice of the
+    // x-th, (x+8)-th, ... group of kPrevSpan slices, so that the 3 MB a chunk scatters into stay in one L2
+    u64 slice = blockIdx.x;
+    {
+        const u64 x = blockIdx.x & 7u, r = blockIdx.x >> 3;
+        const u64 cand = ((r / kPrevSpan) * 8 + x) * kPrevSpan + (r % kPrevSpan);
+        const u64 nslices = (nent + 255) / 256, full = nslices / (8 * kPrevSpan) * (8 * kPrevSpan);
+        if (blockIdx.x < full) slice = cand; // the ragged tail keeps the plain order
+    }
+    const u64 i0 = slice * 256;
     for (u32 j = threadIdx.x; j < 512; j += 256) {
         const i64 g = (i64)i0 - 256 + (i64)j;
         const bool ok = g >= 0 && (u64)g < nent;
-        s_k[j] = ok ? ks[g] : 0xFFFFFFFFu;
-        s_v[j] = ok ? vs[g] : 0u;
+        s_k[j] = ok ? __builtin_nontemporal_load(ks + g) : 0xFFFFFFFFu; // streamed: must not evict the scatter lines
+        s_v[j] = ok ? __builtin_nontemporal_load(vs + g) : 0u;
     }
     __syncthreads();
     const u64 i = i0 + threadIdx.x;
@@ -188,7 +197,8 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
         const u32 a0 = __builtin_amdgcn_alignbyte(pw1, pw0, lp & 3u), a1 = __builtin_amdgcn_alignbyte(pw2, pw1, lp & 3u);
         // The walk (search_dic :232-265).  A candidate replaces the best one only if it is strictly longer
         // (deflate/encoder.rs:34-51 with a farther candidate), so it must agree with p at offset best_len:
-        // one byte decides for most candidates, the survivors are measured in full.  Lanes that are done
+        // one byte decides for most candidates, the survivors are measured in full at once (collecting them
+        // until a quarter of the wave waits was measured: slower, the waiting costs more than it saves).  Lanes that are done
         // keep computing on their last candidate and are masked out of the updates.
         const u8 *s_b = reinterpret_cast<const u8 *>(s_w);
         u32 pb = a0 & 0xFFu; // byte of p at offset best_len
@@ -684,7 +694,7 @@ __global__ __launch_bounds__(kBThreads) void k_df_block(const u8 *__restrict__ i
         o.lm = s_lm + lm2;
         if (original <= custom && original <= fixed) { o.btype = 0; o.hdr_bits = 3; o.bits = 0; s_hdr[0] = is_final ? 1u : 0u; }
         else if (fixed <= custom) { o.btype = 1; o.hdr_bits = 3; o.bits = 1 + fixed; s_hdr[0] = (is_final ? 1u : 0u) | 2u; }
-        else { o.btype = 2; o.hdr_bits = hdr_bits; o.bits = 1 + custom; }
+        else { o.btype = 2; o.hdr_bits = hdr_bits; o.bits = 1 + custom; if (off_n == 0) o.lm |= 0x100u; } // no distance code at all
         blocks[k] = o;
         s_btype = o.btype;
     }
@@ -705,18 +715,37 @@ __global__ __launch_bounds__(kBThreads) void k_df_block(const u8 *__restrict__ i
 }
 
 // bit offset of every block; a stored block is padded to a byte behind its 3 header bits (:488-501)
-__global__ void k_df_offsets(DfBlock *__restrict__ blocks, const u32 *__restrict__ nb_p, u64 *__restrict__ total_bits)
+__global__ __launch_bounds__(256) void k_df_offsets(DfBlock *__restrict__ blocks, const u32 *__restrict__ nb_p,
+                                                    u64 *__restrict__ total_bits)
 {
-    if (threadIdx.x || blockIdx.x) return;
-    u64 off = 0;
+    __shared__ u64 s_bits[1024]; // bits, or ~bytes for a stored block
+    __shared__ u64 s_off[1024];
+    __shared__ u64 s_run;
     const u32 nb = *nb_p;
     if (nb == 0xFFFFFFFFu) return;
-    for (u32 k = 0; k < nb; ++k) {
-        blocks[k].bit_off = off;
-        if (blocks[k].btype == 0) off = ((off + 3 + 7) & ~7ull) + 32 + 8ull * blocks[k].bytes;
-        else off += blocks[k].bits;
+    if (threadIdx.x == 0) s_run = 0;
+    for (u32 k0 = 0; k0 < nb; k0 += 1024) {
+        __syncthreads();
+        for (u32 j = threadIdx.x; j < 1024 && k0 + j < nb; j += 256) {
+            const DfBlock b = blocks[k0 + j];
+            s_bits[j] = b.btype == 0 ? ~(u64)b.bytes : b.bits;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u64 off = s_run;
+            for (u32 j = 0; j < 1024 && k0 + j < nb; ++j) {
+                s_off[j] = off;
+                const u64 v = s_bits[j];
+                if ((i64)v < 0) off = ((off + 3 + 7) & ~7ull) + 32 + 8ull * ~v;
+                else off += v;
+            }
+            s_run = off;
+        }
+        __syncthreads();
+        for (u32 j = threadIdx.x; j < 1024 && k0 + j < nb; j += 256) blocks[k0 + j].bit_off = s_off[j];
     }
-    *total_bits = off;
+    __syncthreads();
+    if (threadIdx.x == 0) *total_bits = s_run;
 }
 
 __device__ __forceinline__ void or_bits(u32 *out, u64 bit, u64 v, u32 nbits)
@@ -937,7 +966,7 @@ int df_launch_blocks(hipStream_t st, const u8 *in, const u32 *code, u64 n, u64 *
 {
     hipLaunchKernelGGL(k_df_cuts, dim3(1), dim3(64), 0, st, code, n, bstart, nb, cap);
     hipLaunchKernelGGL(k_df_block, dim3(cap), dim3(kBThreads), 0, st, in, code, bstart, nb, blocks, lens, hdr, lm_scratch);
-    hipLaunchKernelGGL(k_df_offsets, dim3(1), dim3(64), 0, st, blocks, nb, total_bits);
+    hipLaunchKernelGGL(k_df_offsets, dim3(1), dim3(256), 0, st, blocks, nb, total_bits);
     return 0;
 }
 

@@ -133,3 +133,13 @@ def test_big_corpus(pkg, oracle, eng):
     assert zlib.decompress(got, -15) == d
     want = oracle.deflate_encode(d)
     assert got == want
+
+
+def test_reference_quirk_match_free_dynamic_block(pkg, oracle, eng):
+    """match-free dynamic blocks: HDIST = 0 and no distance length, exactly as the reference writes them"""
+    d = bytes(b for i in range(32) for j in range(32) for b in (i, 32 + j))  # 64 symbols, no trigram twice
+    got, _ = dev_encode(pkg, eng, d)
+    assert got == oracle.deflate_encode(d)
+    assert eng.deflate_stats()["dynamic_without_distances"] == 1
+    with pytest.raises(zlib.error):
+        zlib.decompress(got, -15)

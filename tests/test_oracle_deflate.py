@@ -126,3 +126,16 @@ def test_blocks_and_segments():
     blocks = e.blocks()
     assert sum(b[1] for b in blocks) == len(data) and all(b[1] <= 0xFFFF for b in blocks)
     assert sum(b[3] for b in blocks) <= 8 * len(e.output())
+
+
+def test_reference_quirk_match_free_dynamic_block():
+    """A dynamic block without any match: the reference writes HDIST = 0 and no distance code length at all
+    (deflate/encoder.rs:431-436 `unwrap_or((0, &0))`, :449-451 with an empty offset list), which RFC 1951
+    decoders reject.  The restatement keeps it: the stream is the reference's."""
+    d = bytes(b for i in range(32) for j in range(32) for b in (i, 32 + j))  # 64 symbols, no trigram twice
+    assert all(t[0] == "sym" for t in oracle.lzss_tokens(d))
+    e = oracle.DeflateEncoder()
+    e.feed(d, oracle.ACTION_FINISH)
+    assert [b[2] for b in e.blocks()] == [2]
+    with pytest.raises(zlib.error):
+        zlib.decompress(e.output(), -15)
