@@ -153,6 +153,70 @@ class BZip2Encoder {
     size_t pos_ = 0, len_ = 0;
 };
 
+// Deflate / zlib / gzip encoders (include/bz2_mi355x.h section 4):
+//   Inflater     src/deflate/encoder.rs:92-260   (the reference's name for its Deflate ENCODER)
+//   ZlibEncoder  src/zlib/encoder.rs:55-157      GZipEncoder  src/gzip/encoder.rs:50-135
+// Action::Run accumulates, Action::Finish produces the stream; Action::Flush is not offered by the
+// library and comes back as CompressionError::Unexpected.
+template <int Kind> class DeflateFamilyEncoder {
+  public:
+    using In = uint8_t;
+    using Out = uint8_t;
+    using Error = CompressionError;
+
+    explicit DeflateFamilyEncoder(int device = 0)
+    {
+        const int rc = df_enc_create(&h_, Kind, device);
+        if (rc != BZ_OK) throw std::runtime_error(bz_strerror(rc));
+        buf_.resize(1 << 16);
+    }
+    DeflateFamilyEncoder(const DeflateFamilyEncoder &) = delete;
+    DeflateFamilyEncoder &operator=(const DeflateFamilyEncoder &) = delete;
+    ~DeflateFamilyEncoder() { df_enc_destroy(h_); }
+
+    template <class I, class S> std::optional<Result<uint8_t>> next(I &it, const S &end, Action action)
+    {
+        if (pos_ == len_) {
+            int rc = refill();
+            if (rc < 0) return Result<uint8_t>::Err(from_status(rc));
+            if (len_ == 0) {
+                while (it != end) {
+                    chunk_.clear();
+                    while (it != end && chunk_.size() < kChunk) {
+                        chunk_.push_back(static_cast<uint8_t>(*it));
+                        ++it;
+                    }
+                    rc = df_enc_write(h_, chunk_.data(), chunk_.size());
+                    if (rc != BZ_OK) return Result<uint8_t>::Err(from_status(rc));
+                }
+                rc = df_enc_end(h_, static_cast<int>(action));
+                if (rc != BZ_OK) return Result<uint8_t>::Err(from_status(rc));
+                rc = refill();
+                if (rc < 0) return Result<uint8_t>::Err(from_status(rc));
+                if (len_ == 0) return std::nullopt;
+            }
+        }
+        return Result<uint8_t>::Ok(buf_[pos_++]);
+    }
+
+  private:
+    int refill()
+    {
+        const long k = df_enc_read(h_, buf_.data(), buf_.size());
+        if (k < 0) return static_cast<int>(k);
+        len_ = static_cast<size_t>(k);
+        pos_ = 0;
+        return 0;
+    }
+    static constexpr size_t kChunk = 1 << 20;
+    df_enc *h_ = nullptr;
+    std::vector<uint8_t> buf_, chunk_;
+    size_t pos_ = 0, len_ = 0;
+};
+using Inflater = DeflateFamilyEncoder<DF_KIND_DEFLATE>;
+using ZlibEncoder = DeflateFamilyEncoder<DF_KIND_ZLIB>;
+using GZipEncoder = DeflateFamilyEncoder<DF_KIND_GZIP>;
+
 // EncodeIterator (src/traits/encoder.rs:41-79): a single-pass input range
 template <class I, class S, class E> class EncodeIterator {
   public:

@@ -53,6 +53,26 @@ int main()
             return 1;
         }
     }
+    // the reference's Deflate / zlib / gzip test_unit vectors (src/deflate/encoder.rs:681-701,
+    // src/zlib/encoder.rs:161-174, src/gzip/encoder.rs:147-164) through the C++ mirrors
+    {
+        const std::string a = "a";
+        Inflater inf;
+        auto d = collect(encode(a, inf, Action::Finish));
+        const uint8_t e0[] = {0x4B, 0x04, 0x00};
+        ZlibEncoder zl;
+        auto z = collect(encode(a, zl, Action::Finish));
+        const uint8_t e1[] = {0x78, 0xDA, 0x4B, 0x04, 0x00, 0x00, 0x62, 0x00, 0x62};
+        GZipEncoder gz;
+        auto g = collect(encode(a, gz, Action::Finish));
+        const uint8_t e2[] = {0x1f, 0x8b, 0x08, 0, 0, 0, 0, 0, 0, 0xFF, 0x4b, 0x04, 0x00, 0x43, 0xbe, 0xb7, 0xe8, 0x01, 0, 0, 0};
+        if (!d.ok || d.value.size() != sizeof(e0) || std::memcmp(d.value.data(), e0, sizeof(e0)) != 0 || !z.ok ||
+            z.value.size() != sizeof(e1) || std::memcmp(z.value.data(), e1, sizeof(e1)) != 0 || !g.ok ||
+            g.value.size() != sizeof(e2) || std::memcmp(g.value.data(), e2, sizeof(e2)) != 0) {
+            std::printf("deflate/zlib/gzip test_unit: MISMATCH\n");
+            return 1;
+        }
+    }
     bool threw = false;
     try {
         BZip2Encoder bad(0);

@@ -241,3 +241,119 @@ impl Decoder for BZip2Decoder {
         Some(Ok(b))
     }
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Deflate / zlib / gzip encoders (include/bz2_mi355x.h section 4): `Inflater`
+// (src/deflate/encoder.rs:92-260), `ZlibEncoder` (src/zlib/encoder.rs:55-157), `GZipEncoder`
+// (src/gzip/encoder.rs:50-135).  One body, three constructors.
+// ---------------------------------------------------------------------------------------------
+#[link(name = "bz2_mi355x")]
+extern "C" {
+    fn df_enc_create(out: *mut *mut c_void, kind: i32, device: i32) -> i32;
+    fn df_enc_write(e: *mut c_void, data: *const u8, n: usize) -> i32;
+    fn df_enc_end(e: *mut c_void, action: i32) -> i32;
+    fn df_enc_read(e: *mut c_void, out: *mut u8, cap: usize) -> isize;
+    fn df_enc_destroy(e: *mut c_void);
+}
+
+pub struct DeflateFamilyEncoder {
+    h: *mut c_void,
+    ready: Vec<u8>,
+    pos: usize,
+    chunk: Vec<u8>,
+}
+
+/// `Inflater::new()` -- the reference's name for its Deflate encoder
+pub struct Inflater(DeflateFamilyEncoder);
+pub struct ZlibEncoder(DeflateFamilyEncoder);
+pub struct GZipEncoder(DeflateFamilyEncoder);
+
+impl DeflateFamilyEncoder {
+    fn with_kind(kind: i32) -> Self {
+        let mut h: *mut c_void = core::ptr::null_mut();
+        let rc = unsafe { df_enc_create(&mut h, kind, 0) };
+        assert!(rc == 0, "bz2_mi355x: no usable MI355X (the path has no CPU fallback)");
+        Self { h, ready: Vec::new(), pos: 0, chunk: Vec::with_capacity(CHUNK) }
+    }
+
+    fn next<I: Iterator<Item = u8>>(&mut self, iter: &mut I, action: Action) -> Option<Result<u8, CompressionError>> {
+        while self.pos == self.ready.len() {
+            self.ready.resize(1 << 16, 0);
+            let k = unsafe { df_enc_read(self.h, self.ready.as_mut_ptr(), self.ready.len()) };
+            if k < 0 {
+                self.ready.clear();
+                self.pos = 0;
+                return Some(Err(map_err(k as i32)));
+            }
+            self.ready.truncate(k as usize);
+            self.pos = 0;
+            if k > 0 {
+                break;
+            }
+            // nothing ready: move the rest of this iterator in, then tell the library it ended
+            loop {
+                self.chunk.clear();
+                self.chunk.extend(iter.by_ref().take(CHUNK));
+                if !self.chunk.is_empty() {
+                    let rc = unsafe { df_enc_write(self.h, self.chunk.as_ptr(), self.chunk.len()) };
+                    if rc != 0 {
+                        return Some(Err(map_err(rc)));
+                    }
+                }
+                if self.chunk.len() < CHUNK {
+                    break;
+                }
+            }
+            // Flush is not offered by the library (BZ_E_PARAM): surfaces as CompressionError::Unexpected
+            let rc = unsafe { df_enc_end(self.h, action_code(action)) };
+            if rc != 0 {
+                return Some(Err(map_err(rc)));
+            }
+            self.ready.resize(1 << 16, 0);
+            let k = unsafe { df_enc_read(self.h, self.ready.as_mut_ptr(), self.ready.len()) };
+            if k <= 0 {
+                self.ready.clear();
+                self.pos = 0;
+                return if k < 0 { Some(Err(map_err(k as i32))) } else { None };
+            }
+            self.ready.truncate(k as usize);
+            self.pos = 0;
+        }
+        let b = self.ready[self.pos];
+        self.pos += 1;
+        Some(Ok(b))
+    }
+}
+
+impl Drop for DeflateFamilyEncoder {
+    fn drop(&mut self) {
+        unsafe { df_enc_destroy(self.h) }
+    }
+}
+
+macro_rules! deflate_family {
+    ($name:ident, $kind:expr) => {
+        impl $name {
+            pub fn new() -> Self {
+                $name(DeflateFamilyEncoder::with_kind($kind))
+            }
+        }
+        impl Default for $name {
+            fn default() -> Self {
+                Self::new()
+            }
+        }
+        impl Encoder for $name {
+            type Error = CompressionError;
+            type In = u8;
+            type Out = u8;
+            fn next<I: Iterator<Item = u8>>(&mut self, iter: &mut I, action: Action) -> Option<Result<u8, CompressionError>> {
+                self.0.next(iter, action)
+            }
+        }
+    };
+}
+deflate_family!(Inflater, 0);
+deflate_family!(ZlibEncoder, 1);
+deflate_family!(GZipEncoder, 2);
