@@ -204,7 +204,9 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
         u32 pb = a0 & 0xFFu; // byte of p at offset best_len
         while (__ballot(active)) {
             const u32 lc = lp - cum;
-            const bool surv = active && s_b[lc + best_len] == pb;
+            const u32 cb = s_b[lc + best_len];
+            const u32 d = s_prev[lc]; // (read together with the byte: one LDS round trip per candidate)
+            const bool surv = active && cb == pb;
             bool hit = false;
             if (__ballot(surv)) {
                 if (surv) {
@@ -227,7 +229,6 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
                     }
                 }
             }
-            const u32 d = s_prev[lc];
             cnt -= 1;
             const u32 ncum = cum + d;
             const bool cont = active && !hit && cnt != 0 && d != 0 && ncum <= kWin; // :258-262, :234
