@@ -213,12 +213,18 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
                     const u32 cw0 = s_w[lc >> 2], cw1 = s_w[(lc >> 2) + 1], cw2 = s_w[(lc >> 2) + 2];
                     const u32 x0 = a0 ^ __builtin_amdgcn_alignbyte(cw1, cw0, lc & 3u);
                     const u32 x1 = a1 ^ __builtin_amdgcn_alignbyte(cw2, cw1, lc & 3u);
-                    u32 l = x0 ? ((u32)__builtin_ctz(x0) >> 3) : (x1 ? 4u + ((u32)__builtin_ctz(x1) >> 3) : 8u);
-                    if (l == 8) // check_match :175-188
+                    const u64 xx = ((u64)x1 << 32) | x0; // no branches: first differing byte of the first eight
+                    u32 l = xx ? ((u32)__builtin_ctzll(xx) >> 3) : 8u;
+                    if (l == 8) // check_match :175-188, eight bytes per trip
                         while (l < limit) {
-                            const u32 x = ld4(lp + l) ^ ld4(lc + l);
-                            if (x) { l += (u32)__builtin_ctz(x) >> 3; break; }
-                            l += 4;
+                            const u32 pa = lp + l, ca = lc + l;
+                            const u32 p0 = s_w[pa >> 2], p1 = s_w[(pa >> 2) + 1], p2 = s_w[(pa >> 2) + 2];
+                            const u32 c0 = s_w[ca >> 2], c1 = s_w[(ca >> 2) + 1], c2 = s_w[(ca >> 2) + 2];
+                            const u32 y0 = __builtin_amdgcn_alignbyte(p1, p0, pa & 3u) ^ __builtin_amdgcn_alignbyte(c1, c0, ca & 3u);
+                            const u32 y1 = __builtin_amdgcn_alignbyte(p2, p1, pa & 3u) ^ __builtin_amdgcn_alignbyte(c2, c1, ca & 3u);
+                            const u64 yy = ((u64)y1 << 32) | y0;
+                            if (yy) { l += (u32)__builtin_ctzll(yy) >> 3; break; }
+                            l += 8;
                         }
                     l = l < limit ? l : limit;
                     hit = l == limit;
