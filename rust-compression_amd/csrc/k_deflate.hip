@@ -196,17 +196,20 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
         const u32 pw0 = s_w[lp >> 2], pw1 = s_w[(lp >> 2) + 1], pw2 = s_w[(lp >> 2) + 2];
         const u32 a0 = __builtin_amdgcn_alignbyte(pw1, pw0, lp & 3u), a1 = __builtin_amdgcn_alignbyte(pw2, pw1, lp & 3u);
         // The walk (search_dic :232-265).  A candidate replaces the best one only if it is strictly longer
-        // (deflate/encoder.rs:34-51 with a farther candidate), so it must agree with p at offset best_len:
-        // one byte decides for most candidates, the survivors are measured in full at once (collecting them
-        // until a quarter of the wave waits was measured: slower, the waiting costs more than it saves).  Lanes that are done
+        // (deflate/encoder.rs:34-51 with a farther candidate), so it must agree with p up to offset best_len:
+        // a few bytes decide for most candidates, the survivors are measured in full at once (collecting
+        // them until a quarter of the wave waits was measured: slower, the waiting costs more than it saves).  Lanes that are done
         // keep computing on their last candidate and are masked out of the updates.
-        const u8 *s_b = reinterpret_cast<const u8 *>(s_w);
-        u32 pb = a0 & 0xFFu; // byte of p at offset best_len
+        // The filter: a better candidate agrees with p on bytes 0 .. best_len, in particular on the last
+        // four of them (fewer while best_len < 3).  With one byte a fifth of the candidates passed and some
+        // lane of the 64 had a candidate to measure in almost every trip; four bytes make that rare.
+        u32 foff = 0, fmask = 0xFFu, fq = a0 & 0xFFu; // offset of the tested dword, its mask, p's bytes there
         while (__ballot(active)) {
             const u32 lc = lp - cum;
-            const u32 cb = s_b[lc + best_len];
-            const u32 d = s_prev[lc]; // (read together with the byte: one LDS round trip per candidate)
-            const bool surv = active && cb == pb;
+            const u32 fa = lc + foff;
+            const u32 fw0 = s_w[fa >> 2], fw1 = s_w[(fa >> 2) + 1];
+            const u32 d = s_prev[lc]; // (read together with the bytes: one LDS round trip per candidate)
+            const bool surv = active && ((__builtin_amdgcn_alignbyte(fw1, fw0, fa & 3u) ^ fq) & fmask) == 0;
             bool hit = false;
             if (__ballot(surv)) {
                 if (surv) {
@@ -231,7 +234,10 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
                     if (l > best_len) {
                         best_len = l;
                         best_dist = cum;
-                        pb = s_b[lp + l]; // (not compared again when l == limit: the walk ends)
+                        // (when l == limit the walk ends and the filter is not used again)
+                        foff = l >= 3 ? l - 3 : 0u;
+                        fmask = l >= 3 ? 0xFFFFFFFFu : ((1u << (8 * (l + 1))) - 1);
+                        fq = ld4(lp + foff) & fmask;
                     }
                 }
             }
