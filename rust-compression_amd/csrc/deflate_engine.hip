@@ -15,7 +15,7 @@
 using namespace dfgpu;
 
 struct DfWorkspace {
-    DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, prevd, est, tabs, ents, bstart, nb, blocks, lens, hdr, lm, total,
+    DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, prevd, est, segoff, tabs, ents, bstart, nb, blocks, lens, hdr, lm, total,
         stream, asum, bsum, crc;
     size_t sort_tmp_bytes = 0;
     double t_stage[6] = {0, 0, 0, 0, 0, 0}; // chains, matches, parse, blocks, emit, total
@@ -29,7 +29,7 @@ struct DfWorkspace {
 void df_workspace_free(DfWorkspace *w)
 {
     if (!w) return;
-    DevBuf *all[] = {&w->keys_in, &w->keys_out, &w->vals_in, &w->vals_out, &w->sort_tmp, &w->prevd, &w->est, &w->tabs, &w->ents,
+    DevBuf *all[] = {&w->keys_in, &w->keys_out, &w->vals_in, &w->vals_out, &w->sort_tmp, &w->prevd, &w->est, &w->segoff, &w->tabs, &w->ents,
                      &w->bstart, &w->nb, &w->blocks, &w->lens, &w->hdr, &w->lm, &w->total, &w->stream, &w->asum, &w->bsum,
                      &w->crc};
     for (DevBuf *b : all) b->release();
@@ -103,6 +103,7 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, u8 
     if ((rc = w->sort_tmp.ensure(w->sort_tmp_bytes + 256)) != BZ_OK) return rc;
     if ((rc = w->prevd.ensure(npad * 2)) != BZ_OK) return rc;
     if ((rc = w->est.ensure(npad)) != BZ_OK) return rc;
+    if ((rc = w->segoff.ensure((n / kChunk + 8) * 4)) != BZ_OK) return rc;
     if ((rc = w->tabs.ensure(tab_words * 2 + 64)) != BZ_OK) return rc;
     if ((rc = w->ents.ensure(ent_words * 2 + 64)) != BZ_OK) return rc;
     if ((rc = w->bstart.ensure(((size_t)bcap + 2) * 8)) != BZ_OK) return rc;
@@ -136,7 +137,7 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, u8 
     HIPCHK(hipEventRecord(w->ev[0], st));
     HIPCHK(hipMemsetAsync(w->stream.p, 0, bound + 64, st));
     if (df_launch_chains(st, d_in, n, w->keys_in.as<u32>(), w->keys_out.as<u32>(), w->vals_in.as<u32>(), w->vals_out.as<u32>(),
-                         w->sort_tmp.p, w->sort_tmp_bytes, w->prevd.as<u16>(), w->est.as<u8>()) != 0)
+                         w->sort_tmp.p, w->sort_tmp_bytes, w->prevd.as<u16>(), w->est.as<u8>(), w->segoff.as<u32>()) != 0)
         return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[1], st));
     if (df_launch_match(st, d_in, w->prevd.as<u16>(), w->est.as<u8>(), n, M) != 0) return BZ_E_UNEXPECTED;

@@ -22,7 +22,9 @@
 //     symbol counts: k_df_block replays make_table (huffman/cano_huff_table.rs, the serial heap
 //     procedure and the package-merge fallback, one lane per table) and the code-length run
 //     coding (:318-452) exactly; k_df_emit writes the bits LSB first (bitio/writer.rs, Right).
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 #include <rocprim/rocprim.hpp>
 
 #include "bzgpu.h"
@@ -925,20 +927,36 @@ static u32 df_key_bits(u64 n)
     return b;
 }
 
+static u32 df_chunks(u64 n)
+{
+    const u64 ntri = n >= 3 ? n - 2 : 0;
+    return ntri ? (u32)((ntri + kChunk - 1) / kChunk) : 1u;
+}
+
+static bool df_segmented() // DF_SEGSORT=0: one global sort on (chunk << 16 | hash) instead of one segment per chunk
+{
+    static const bool on = !(getenv("DF_SEGSORT") && getenv("DF_SEGSORT")[0] == '0');
+    return on;
+}
+
 int df_sort_temp_bytes(u64 n, size_t *bytes)
 {
-    size_t t = 0;
+    size_t t = 0, t2 = 0;
     u32 *k = nullptr;
     u32 *v = nullptr;
     if (rocprim::radix_sort_pairs(nullptr, t, k, k, v, v, (size_t)df_entries(n), 0, df_key_bits(n), (hipStream_t) nullptr) !=
         hipSuccess)
         return -1;
-    *bytes = t;
+    if (rocprim::segmented_radix_sort_pairs(nullptr, t2, k, k, v, v, (unsigned int)df_entries(n), df_chunks(n), v, v + 1, 0, 16,
+                                            (hipStream_t) nullptr) != hipSuccess)
+        return -1;
+    *bytes = t > t2 ? t : t2;
     return 0;
 }
 
+// seg_off: df_chunks(n) + 1 words of device memory (segment boundaries of the chunk-wise sort)
 int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *keys_in, u32 *keys_out, u32 *vals_in, u32 *vals_out,
-                     void *tmp, size_t tmp_bytes, u16 *prevd, u8 *est)
+                     void *tmp, size_t tmp_bytes, u16 *prevd, u8 *est, u32 *seg_off)
 {
     const u64 ntri = n >= 3 ? n - 2 : 0;
     const u64 nent = df_entries(n);
@@ -946,7 +964,21 @@ int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *keys_in, u32 *key
     DFCHK(hipMemsetAsync(est, 0, n + 8, st));
     if (!ntri) return 0;
     hipLaunchKernelGGL(k_df_keys, dim3((u32)((nent + 255) / 256)), dim3(256), 0, st, in, ntri, nent, keys_in, vals_in);
-    DFCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)nent, 0, df_key_bits(n), st));
+    const u32 nchunks = df_chunks(n);
+    if (df_segmented() && nchunks > 1) {
+        // every chunk (with its 32 KiB of history in front) is one segment: 16 key bits instead of 16 + log2(chunks)
+        std::vector<u32> off(nchunks + 1);
+        for (u32 c = 0; c <= nchunks; ++c) {
+            const u64 o = c == 0 ? 0 : (u64)c * kChunk + (u64)(c - 1) * kWin;
+            off[c] = (u32)(o < nent ? o : nent);
+        }
+        DFCHK(hipMemcpyAsync(seg_off, off.data(), (nchunks + 1) * sizeof(u32), hipMemcpyHostToDevice, st));
+        DFCHK(hipStreamSynchronize(st)); // (the host vector goes away)
+        DFCHK(rocprim::segmented_radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (unsigned int)nent, nchunks,
+                                                  seg_off, seg_off + 1, 0, 16, st));
+    } else {
+        DFCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)nent, 0, df_key_bits(n), st));
+    }
     hipLaunchKernelGGL(k_df_prev, dim3((u32)((nent + 255) / 256)), dim3(256), 0, st, keys_out, vals_out, nent, prevd, est);
     return 0;
 }
