@@ -101,8 +101,7 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, u8 
     if ((rc = w->vals_in.ensure((nent > npad ? nent : npad) * 4)) != BZ_OK) return rc;   // later: M[]
     if ((rc = w->vals_out.ensure((nent > npad ? nent : npad) * 4)) != BZ_OK) return rc;  // later: code[]
     if ((rc = w->sort_tmp.ensure(w->sort_tmp_bytes + 256)) != BZ_OK) return rc;
-    if ((rc = w->prevd.ensure(npad * 2)) != BZ_OK) return rc;
-    if ((rc = w->est.ensure(npad)) != BZ_OK) return rc;
+    if ((rc = w->prevd.ensure(npad * 4)) != BZ_OK) return rc; // per position: chain distance | chain length << 16
     if ((rc = w->segoff.ensure((n / kChunk + 8) * 4)) != BZ_OK) return rc;
     if ((rc = w->tabs.ensure(tab_words * 2 + 64)) != BZ_OK) return rc;
     if ((rc = w->ents.ensure(ent_words * 2 + 64)) != BZ_OK) return rc;
@@ -137,10 +136,10 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, u8 
     HIPCHK(hipEventRecord(w->ev[0], st));
     HIPCHK(hipMemsetAsync(w->stream.p, 0, bound + 64, st));
     if (df_launch_chains(st, d_in, n, w->keys_in.as<u32>(), w->keys_out.as<u32>(), w->vals_in.as<u32>(), w->vals_out.as<u32>(),
-                         w->sort_tmp.p, w->sort_tmp_bytes, w->prevd.as<u16>(), w->est.as<u8>(), w->segoff.as<u32>()) != 0)
+                         w->sort_tmp.p, w->sort_tmp_bytes, w->prevd.as<u32>(), w->segoff.as<u32>()) != 0)
         return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[1], st));
-    if (df_launch_match(st, d_in, w->prevd.as<u16>(), w->est.as<u8>(), n, M) != 0) return BZ_E_UNEXPECTED;
+    if (df_launch_match(st, d_in, w->prevd.as<u32>(), n, M) != 0) return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[2], st));
     if (df_launch_parse(st, M, n, step, tabs.data(), ents.data(), counts.data(), nlevels, code) != 0) return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[3], st));

@@ -43,8 +43,8 @@ struct DfBlock {
 int df_sort_temp_bytes(u64 n, size_t *bytes);
 u64 df_entries(u64 n); // entries the chain sort handles: trigram positions + 32 KiB of history per chunk
 int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *keys_in, u32 *keys_out, u32 *vals_in, u32 *vals_out,
-                     void *tmp, size_t tmp_bytes, u16 *prevd, u8 *est, u32 *seg_off);
-int df_launch_match(hipStream_t st, const u8 *in, const u16 *prevd, const u8 *est, u64 n, u32 *M);
+                     void *tmp, size_t tmp_bytes, u32 *pe, u32 *seg_off);
+int df_launch_match(hipStream_t st, const u8 *in, const u32 *pe, u64 n, u32 *M);
 int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *tabs, u16 *const *ents, const u32 *counts,
                     u32 nlevels, u32 *code);
 int df_launch_blocks(hipStream_t st, const u8 *in, const u32 *code, u64 n, u64 *bstart, u32 *nb, u32 cap, DfBlock *blocks,

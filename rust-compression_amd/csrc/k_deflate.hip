@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_df_keys(const u8 *__restrict__ in, u64 
 // hash lie within the window, at most 255): the match kernel groups positions of similar chain length.
 // The entries in front of a chunk's first position only serve as predecessors.
 __global__ __launch_bounds__(256) void k_df_prev(const u32 *__restrict__ ks, const u32 *__restrict__ vs, u64 nent,
-                                                 u16 *__restrict__ prevd, u8 *__restrict__ est)
+                                                 u32 *__restrict__ pe)
 {
     // the 255 entries in front of the workgroup's 256 and its own, staged once: the search runs in LDS
     __shared__ u32 s_k[256 + 256];
@@ -103,7 +103,6 @@ __global__ __launch_bounds__(256) void k_df_prev(const u32 *__restrict__ ks, con
         const u32 dd = p - s_v[li - 1];
         if (dd <= kWin) d = dd;
     }
-    prevd[p] = (u16)d;
     u32 e = 0;
     if (d) { // smallest j in [i - 255, i) with the same key and vs[j] + window >= p (monotone in j)
         u32 lo = li - kChain, hi = li - 1; // hi qualifies; entries before the array start carry key ~0
@@ -113,18 +112,19 @@ __global__ __launch_bounds__(256) void k_df_prev(const u32 *__restrict__ ks, con
         }
         e = li - lo;
     }
-    est[p] = (u8)e;
+    pe[p] = d | (e << 16); // one scattered store per position: distance (16 bits) and chain length
 }
 
 // ---------------------------------------------------------------------------------- matches
 constexpr u32 kMDataBytes = kWin + kMTile + 272;
 
-__global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ in, const u16 *__restrict__ prevd,
-                                                        const u8 *__restrict__ est, u64 n, u32 *__restrict__ M)
+__global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ in, const u32 *__restrict__ pe, u64 n,
+                                                        u32 *__restrict__ M)
 {
     __shared__ u32 s_w[kMDataBytes / 4];
     __shared__ u16 s_prev[kWin + kMTile];
     __shared__ u16 s_order[kMTile];
+    __shared__ u8 s_est[kMTile];
     __shared__ u32 s_hist[256];
     __shared__ u32 s_next;
     const u32 tid = threadIdx.x;
@@ -141,12 +141,20 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
             for (u32 b = 0; b < 4 && (u64)g + b < n; ++b) v |= (u32)in[g + b] << (8 * b);
         s_w[w] = v;
     }
-    for (u32 k = tid; k < (kWin + kMTile) / 2; k += kMThreads) {
-        const i64 g = base + 2 * (i64)k;
-        u32 v = 0;
-        if (g >= 0 && (u64)g + 2 <= n) v = *reinterpret_cast<const u32 *>(prevd + g);
-        else if (g >= 0 && (u64)g < n) v = prevd[g];
-        reinterpret_cast<u32 *>(s_prev)[k] = v;
+    for (u32 k4 = tid; k4 < (kWin + kMTile) / 4; k4 += kMThreads) { // four positions per load
+        const i64 g = base + 4 * (i64)k4;
+        u32 v[4] = {0, 0, 0, 0};
+        if (g >= 0 && (u64)g + 4 <= n) {
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(pe + g));
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else if (g >= 0)
+            for (u32 j = 0; j < 4 && (u64)g + j < n; ++j) v[j] = pe[g + j];
+        reinterpret_cast<u32 *>(s_prev)[2 * k4] = (v[0] & 0xFFFFu) | (v[1] << 16);
+        reinterpret_cast<u32 *>(s_prev)[2 * k4 + 1] = (v[2] & 0xFFFFu) | (v[3] << 16);
+        if (4 * k4 >= kWin) // the tile's own positions: their chain lengths
+            reinterpret_cast<u32 *>(s_est)[k4 - kWin / 4] =
+                ((v[0] >> 16) & 0xFFu) | (((v[1] >> 16) & 0xFFu) << 8) | (((v[2] >> 16) & 0xFFu) << 16) | (((v[3] >> 16) & 0xFFu) << 24);
     }
     __syncthreads();
     // positions of the tile ordered by chain length, longest first (a counting sort on 256 lengths): the 64
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
     u32 my_est[kMTile / kMThreads];
     for (u32 j = 0; j < kMTile / kMThreads; ++j) {
         const u32 k = j * kMThreads + tid;
-        my_est[j] = k < count ? 255u - est[t0 + k] : 0u;
+        my_est[j] = k < count ? 255u - s_est[k] : 0u;
         if (k < count) atomicAdd(&s_hist[my_est[j]], 1u);
     }
     __syncthreads();
@@ -956,12 +964,11 @@ int df_sort_temp_bytes(u64 n, size_t *bytes)
 
 // seg_off: df_chunks(n) + 1 words of device memory (segment boundaries of the chunk-wise sort)
 int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *keys_in, u32 *keys_out, u32 *vals_in, u32 *vals_out,
-                     void *tmp, size_t tmp_bytes, u16 *prevd, u8 *est, u32 *seg_off)
+                     void *tmp, size_t tmp_bytes, u32 *pe, u32 *seg_off)
 {
     const u64 ntri = n >= 3 ? n - 2 : 0;
     const u64 nent = df_entries(n);
-    DFCHK(hipMemsetAsync(prevd, 0, (n + 8) * sizeof(u16), st));
-    DFCHK(hipMemsetAsync(est, 0, n + 8, st));
+    DFCHK(hipMemsetAsync(pe, 0, (n + 8) * sizeof(u32), st));
     if (!ntri) return 0;
     hipLaunchKernelGGL(k_df_keys, dim3((u32)((nent + 255) / 256)), dim3(256), 0, st, in, ntri, nent, keys_in, vals_in);
     const u32 nchunks = df_chunks(n);
@@ -979,14 +986,14 @@ int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *keys_in, u32 *key
     } else {
         DFCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)nent, 0, df_key_bits(n), st));
     }
-    hipLaunchKernelGGL(k_df_prev, dim3((u32)((nent + 255) / 256)), dim3(256), 0, st, keys_out, vals_out, nent, prevd, est);
+    hipLaunchKernelGGL(k_df_prev, dim3((u32)((nent + 255) / 256)), dim3(256), 0, st, keys_out, vals_out, nent, pe);
     return 0;
 }
 
-int df_launch_match(hipStream_t st, const u8 *in, const u16 *prevd, const u8 *est, u64 n, u32 *M)
+int df_launch_match(hipStream_t st, const u8 *in, const u32 *pe, u64 n, u32 *M)
 {
     if (!n) return 0;
-    hipLaunchKernelGGL(k_df_match, dim3((u32)((n + kMTile - 1) / kMTile)), dim3(kMThreads), 0, st, in, prevd, est, n, M);
+    hipLaunchKernelGGL(k_df_match, dim3((u32)((n + kMTile - 1) / kMTile)), dim3(kMThreads), 0, st, in, pe, n, M);
     return 0;
 }
 
