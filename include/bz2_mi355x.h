@@ -306,7 +306,7 @@ void bz_dec_destroy(bz_dec *d);
 size_t df_encode_bound(size_t n);
 /* d_in[n] (HBM, 4-byte aligned) -> d_out (HBM, cap bytes); *out_len = stream
  * bytes.  d_out == NULL: length only.  Uses the engine's stream; workspace
- * (about 17 bytes per input byte) is created by the first call and kept. */
+ * (about 20 bytes per input byte) is created by the first call and kept. */
 int df_gpu_encode_device(bz_gpu_engine *g, int kind, const void *d_in, size_t n,
                          void *d_out, size_t cap, size_t *out_len);
 /* Seconds of GPU time of the last call by stage (HIP events): [0] hash chains
