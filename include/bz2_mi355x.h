@@ -295,8 +295,7 @@ void bz_dec_destroy(bz_dec *d);
  * driven with Action::Finish.  The stream is the reference's, bit for bit.
  * `kind`: 0 raw Deflate, 1 zlib, 2 gzip.
  * Not offered on this path (refused with BZ_E_PARAM, never approximated):
- * Action::Flush inside a stream, preset dictionaries (Inflater::with_dict),
- * inputs of 2 GiB or more in one call.
+ * Action::Flush inside a stream, inputs of 2 GiB or more in one call.
  * ======================================================================== */
 #define DF_KIND_DEFLATE 0
 #define DF_KIND_ZLIB 1
@@ -309,6 +308,14 @@ size_t df_encode_bound(size_t n);
  * (about 20 bytes per input byte) is created by the first call and kept. */
 int df_gpu_encode_device(bz_gpu_engine *g, int kind, const void *d_in, size_t n,
                          void *d_out, size_t cap, size_t *out_len);
+/* The same with a preset dictionary == Inflater::with_dict / ZlibEncoder::with_dict
+ * (src/deflate/encoder.rs:134-153, src/zlib/encoder.rs:74-93): `dict` is HOST
+ * memory; its last 0x8000 bytes are the window in front of the input
+ * (src/lzss/encoder.rs:104-130), the zlib header becomes 78 F9 + Adler-32 of the
+ * whole dictionary.  kind 2 (gzip) has no with_dict: BZ_E_PARAM. */
+int df_gpu_encode_device_dict(bz_gpu_engine *g, int kind, const void *d_in, size_t n,
+                              const uint8_t *dict, size_t dict_len,
+                              void *d_out, size_t cap, size_t *out_len);
 /* Seconds of GPU time of the last call by stage (HIP events): [0] hash chains
  * (sort) [1] matches [2] parse [3] blocks + tables [4] emission + checksums [5] total. */
 int df_gpu_last_timings(bz_gpu_engine *g, double out_seconds[6]);
@@ -330,6 +337,9 @@ int df_gpu_debug_blocks(bz_gpu_engine *g, uint64_t *out4, size_t cap, size_t *co
  * release with bz_free. */
 int df_encode_buffer(int kind, int device, const uint8_t *in, size_t in_len,
                      uint8_t **out, size_t *out_len);
+int df_encode_buffer_dict(int kind, int device, const uint8_t *in, size_t in_len,
+                          const uint8_t *dict, size_t dict_len,
+                          uint8_t **out, size_t *out_len);
 
 /* Streaming context == the Encoder::next contract of the three encoders:
  * df_enc_write feeds bytes, df_enc_end(action) marks the end of an input
@@ -338,6 +348,7 @@ int df_encode_buffer(int kind, int device, const uint8_t *in, size_t in_len,
  * window and one bit string run through all of it. */
 typedef struct df_enc df_enc;
 int df_enc_create(df_enc **out, int kind, int device);
+int df_enc_create_dict(df_enc **out, int kind, int device, const uint8_t *dict, size_t dict_len); /* ::with_dict */
 int df_enc_write(df_enc *e, const uint8_t *in, size_t n);
 int df_enc_end(df_enc *e, int action);
 long df_enc_read(df_enc *e, uint8_t *out, size_t cap);

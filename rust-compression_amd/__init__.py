@@ -87,7 +87,7 @@ EXPORTS = [
     "bz_gpu_decode_device", "bz_gpu_decode_device_sharded", "bz_gpu_last_decode_timings", "bz_gpu_last_decode_stats", "bz_decode_buffer",
     "bz_dec_create", "bz_dec_write", "bz_dec_end", "bz_dec_read", "bz_dec_pending", "bz_dec_destroy",
     "df_encode_bound", "df_gpu_encode_device", "df_gpu_last_timings", "df_gpu_last_stats", "df_gpu_debug_codes",
-    "df_gpu_debug_blocks", "df_encode_buffer",
+    "df_gpu_debug_blocks", "df_encode_buffer", "df_gpu_encode_device_dict", "df_encode_buffer_dict", "df_enc_create_dict",
     "df_enc_create", "df_enc_write", "df_enc_end", "df_enc_read", "df_enc_pending", "df_enc_destroy",
 ]
 
@@ -188,6 +188,9 @@ def lib():
     L.df_gpu_debug_codes.argtypes = [vp, vp, sz, u32p, sz, szp]
     L.df_gpu_debug_blocks.argtypes = [vp, u64p, sz, szp]
     L.df_encode_buffer.argtypes = [C.c_int, C.c_int, C.c_char_p, sz, C.POINTER(u8p), szp]
+    L.df_gpu_encode_device_dict.argtypes = [vp, C.c_int, vp, sz, C.c_char_p, sz, vp, sz, szp]
+    L.df_encode_buffer_dict.argtypes = [C.c_int, C.c_int, C.c_char_p, sz, C.c_char_p, sz, C.POINTER(u8p), szp]
+    L.df_enc_create_dict.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_char_p, sz]
     L.df_enc_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
     L.df_enc_write.argtypes = [vp, C.c_char_p, sz]
     L.df_enc_end.argtypes = [vp, C.c_int]
@@ -322,9 +325,10 @@ class Inflater:
     KIND = DEFLATE
     CHUNK = 1 << 20
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, dict_=b""):
         self._h = C.c_void_p()
-        _check(lib().df_enc_create(C.byref(self._h), self.KIND, device))
+        dict_ = bytes(dict_)
+        _check(lib().df_enc_create_dict(C.byref(self._h), self.KIND, device, dict_, len(dict_)))
         self._buf = (C.c_uint8 * 65536)()
         self._ready = b""
         self._pos = 0
@@ -333,6 +337,11 @@ class Inflater:
         if getattr(self, "_h", None) and _LIB is not None:
             _LIB.df_enc_destroy(self._h)
             self._h = None
+
+    @classmethod
+    def with_dict(cls, dict_, device=0):
+        """`Inflater::with_dict` / `ZlibEncoder::with_dict`"""
+        return cls(device, dict_)
 
     def _refill(self):
         k = lib().df_enc_read(self._h, self._buf, len(self._buf))
@@ -392,12 +401,12 @@ class GZipEncoder(Inflater):
     KIND = GZIP
 
 
-def deflate_compress(data, kind=DEFLATE, device=0):
-    """One-shot over host buffers (df_encode_buffer)."""
-    data = bytes(data)
+def deflate_compress(data, kind=DEFLATE, device=0, dict_=b""):
+    """One-shot over host buffers (df_encode_buffer / df_encode_buffer_dict)."""
+    data, dict_ = bytes(data), bytes(dict_)
     out = C.POINTER(C.c_uint8)()
     n = C.c_size_t(0)
-    _check(lib().df_encode_buffer(kind, device, data, len(data), C.byref(out), C.byref(n)))
+    _check(lib().df_encode_buffer_dict(kind, device, data, len(data), dict_, len(dict_), C.byref(out), C.byref(n)))
     try:
         return C.string_at(out, n.value)
     finally:
@@ -617,9 +626,10 @@ class GpuEngine:
 
     DEFLATE_STAGES = ("hash_chains", "matches", "parse", "blocks_tables", "emit_checksums", "total")
 
-    def deflate_encode_device(self, kind, d_in, n, d_out, cap):
+    def deflate_encode_device(self, kind, d_in, n, d_out, cap, dict_=b""):
         out_len = C.c_size_t(0)
-        _check(lib().df_gpu_encode_device(self._h, kind, d_in, n, d_out, cap, C.byref(out_len)))
+        dict_ = bytes(dict_)
+        _check(lib().df_gpu_encode_device_dict(self._h, kind, d_in, n, dict_, len(dict_), d_out, cap, C.byref(out_len)))
         return out_len.value
 
     def deflate_timings(self):

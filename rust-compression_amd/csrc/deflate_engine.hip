@@ -15,7 +15,7 @@
 using namespace dfgpu;
 
 struct DfWorkspace {
-    DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, prevd, est, segoff, tabs, ents, bstart, nb, blocks, lens, hdr, lm, total,
+    DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, prevd, est, segoff, concat, tabs, ents, bstart, nb, blocks, lens, hdr, lm, total,
         stream, asum, bsum, crc;
     size_t sort_tmp_bytes = 0;
     double t_stage[6] = {0, 0, 0, 0, 0, 0}; // chains, matches, parse, blocks, emit, total
@@ -29,7 +29,7 @@ struct DfWorkspace {
 void df_workspace_free(DfWorkspace *w)
 {
     if (!w) return;
-    DevBuf *all[] = {&w->keys_in, &w->keys_out, &w->vals_in, &w->vals_out, &w->sort_tmp, &w->prevd, &w->est, &w->segoff, &w->tabs, &w->ents,
+    DevBuf *all[] = {&w->keys_in, &w->keys_out, &w->vals_in, &w->vals_out, &w->sort_tmp, &w->prevd, &w->est, &w->segoff, &w->concat, &w->tabs, &w->ents,
                      &w->bstart, &w->nb, &w->blocks, &w->lens, &w->hdr, &w->lm, &w->total, &w->stream, &w->asum, &w->bsum,
                      &w->crc};
     for (DevBuf *b : all) b->release();
@@ -68,9 +68,13 @@ static u32 gf_xpow8_reflected(u64 nbytes) // x^(8 * nbytes) mod P
     return r;
 }
 
-static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, u8 *d_out, size_t cap, size_t *out_len)
+// dict (host memory, may be NULL): Inflater::with_dict / ZlibEncoder::with_dict (deflate/encoder.rs:134-153,
+// lzss/encoder.rs:104-130: the last 0x8000 bytes of it are history in front of the input)
+static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, const u8 *dict, size_t dict_len, u8 *d_out,
+                          size_t cap, size_t *out_len)
 {
-    if (n >= (1ull << 31)) return BZ_E_PARAM; // positions and bit offsets are sized for < 2 GiB per call
+    if (n >= (1ull << 31) - kWin) return BZ_E_PARAM;
+    if (dict_len && kind == 2) return BZ_E_PARAM; // GZipEncoder has no with_dict // positions and bit offsets are sized for < 2 GiB per call
     HIPCHK(hipSetDevice(g->device));
     if (!g->df) g->df = new DfWorkspace();
     DfWorkspace *w = g->df;
@@ -79,7 +83,9 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, u8 
         for (hipEvent_t &e : w->ev) HIPCHK(hipEventCreate(&e));
         w->ev_ready = true;
     }
-    const u64 npad = n + 16;
+    const u64 hist = dict_len < kWin ? dict_len : kWin; // bytes of history in front of the input
+    const u64 nall = hist + n;                           // positions the chain and match stages see
+    const u64 npad = nall + 16;
     const u32 ntiles = (u32)((n + kPTile - 1) / kPTile) + (n == 0 ? 1u : 0u);
     std::vector<u32> counts;
     counts.push_back(ntiles);
@@ -92,17 +98,18 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, u8 
     int rc;
     {
         size_t t = 0;
-        if (df_sort_temp_bytes(n, &t) != 0) return BZ_E_UNEXPECTED;
+        if (df_sort_temp_bytes(nall, &t) != 0) return BZ_E_UNEXPECTED;
         w->sort_tmp_bytes = t;
     }
-    const u64 nent = df_entries(n) + 16;
+    const u64 nent = df_entries(nall) + 16;
     if ((rc = w->keys_in.ensure((nent > npad ? nent : npad) * 4)) != BZ_OK) return rc;   // later: step[]
     if ((rc = w->keys_out.ensure(nent * 4)) != BZ_OK) return rc;
     if ((rc = w->vals_in.ensure((nent > npad ? nent : npad) * 4)) != BZ_OK) return rc;   // later: M[]
     if ((rc = w->vals_out.ensure((nent > npad ? nent : npad) * 4)) != BZ_OK) return rc;  // later: code[]
     if ((rc = w->sort_tmp.ensure(w->sort_tmp_bytes + 256)) != BZ_OK) return rc;
     if ((rc = w->prevd.ensure(npad * 4)) != BZ_OK) return rc; // per position: chain distance | chain length << 16
-    if ((rc = w->segoff.ensure((n / kChunk + 8) * 4)) != BZ_OK) return rc;
+    if ((rc = w->segoff.ensure((nall / kChunk + 8) * 4)) != BZ_OK) return rc;
+    if (hist && (rc = w->concat.ensure(nall + 64)) != BZ_OK) return rc;
     if ((rc = w->tabs.ensure(tab_words * 2 + 64)) != BZ_OK) return rc;
     if ((rc = w->ents.ensure(ent_words * 2 + 64)) != BZ_OK) return rc;
     if ((rc = w->bstart.ensure(((size_t)bcap + 2) * 8)) != BZ_OK) return rc;
@@ -130,16 +137,24 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, u8 
         }
     }
     u16 *step = w->keys_in.as<u16>();
-    u32 *M = w->vals_in.as<u32>();
+    u32 *Mall = w->vals_in.as<u32>();
+    u32 *M = Mall + hist; // match words of the input positions
     u32 *code = w->vals_out.as<u32>();
+    const u8 *d_all = d_in;
+    if (hist) { // history + input in one buffer for the chain and match stages
+        HIPCHK(hipMemcpy(w->concat.p, dict + (dict_len - hist), hist, hipMemcpyHostToDevice));
+        if (n) HIPCHK(hipMemcpyAsync(w->concat.as<u8>() + hist, d_in, n, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemsetAsync(w->concat.as<u8>() + nall, 0, 64, st));
+        d_all = w->concat.as<u8>();
+    }
 
     HIPCHK(hipEventRecord(w->ev[0], st));
     HIPCHK(hipMemsetAsync(w->stream.p, 0, bound + 64, st));
-    if (df_launch_chains(st, d_in, n, w->keys_in.as<u32>(), w->keys_out.as<u32>(), w->vals_in.as<u32>(), w->vals_out.as<u32>(),
+    if (df_launch_chains(st, d_all, nall, w->keys_in.as<u32>(), w->keys_out.as<u32>(), w->vals_in.as<u32>(), w->vals_out.as<u32>(),
                          w->sort_tmp.p, w->sort_tmp_bytes, w->prevd.as<u32>(), w->segoff.as<u32>()) != 0)
         return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[1], st));
-    if (df_launch_match(st, d_in, w->prevd.as<u32>(), n, M) != 0) return BZ_E_UNEXPECTED;
+    if (df_launch_match(st, d_all, w->prevd.as<u32>(), nall, Mall) != 0) return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[2], st));
     if (df_launch_parse(st, M, n, step, tabs.data(), ents.data(), counts.data(), nlevels, code) != 0) return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[3], st));
@@ -167,7 +182,13 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, u8 
     // container (zlib/encoder.rs:63-72,118-156; gzip/encoder.rs:62-75,88-134)
     u8 head[10], tail[8];
     size_t nhead = 0, ntail = 0;
-    if (kind == 1) {
+    if (kind == 1 && dict_len) { // zlib/encoder.rs:74-93: FDICT + Adler-32 of the whole dictionary
+        u32 a = 1, b = 0;
+        for (size_t i = 0; i < dict_len; ++i) { a = (a + dict[i]) % 65521; b = (b + a) % 65521; }
+        const u32 h = (b << 16) | a;
+        head[0] = 0x78; head[1] = 0xF9; head[2] = (u8)(h >> 24); head[3] = (u8)(h >> 16); head[4] = (u8)(h >> 8); head[5] = (u8)h;
+        nhead = 6;
+    } else if (kind == 1) {
         head[0] = 0x78; head[1] = 0xDA; nhead = 2;
     } else if (kind == 2) {
         const u8 h[10] = {0x1F, 0x8B, 0x08, 0, 0, 0, 0, 0, 0, 0xFF};
@@ -251,7 +272,16 @@ extern "C" int df_gpu_encode_device(bz_gpu_engine *g, int kind, const void *d_in
     if (!g || !out_len || (!d_in && n) || kind < 0 || kind > 2) return BZ_E_PARAM;
     if (n && ((uintptr_t)d_in & 3u)) return BZ_E_PARAM;
     *out_len = 0;
-    return df_encode_core(g, kind, static_cast<const u8 *>(d_in), n, static_cast<u8 *>(d_out), cap, out_len);
+    return df_encode_core(g, kind, static_cast<const u8 *>(d_in), n, nullptr, 0, static_cast<u8 *>(d_out), cap, out_len);
+}
+
+extern "C" int df_gpu_encode_device_dict(bz_gpu_engine *g, int kind, const void *d_in, size_t n, const uint8_t *dict,
+                                         size_t dict_len, void *d_out, size_t cap, size_t *out_len)
+{
+    if (!g || !out_len || (!d_in && n) || kind < 0 || kind > 2 || (!dict && dict_len)) return BZ_E_PARAM;
+    if (n && ((uintptr_t)d_in & 3u)) return BZ_E_PARAM;
+    *out_len = 0;
+    return df_encode_core(g, kind, static_cast<const u8 *>(d_in), n, dict, dict_len, static_cast<u8 *>(d_out), cap, out_len);
 }
 
 extern "C" int df_gpu_last_timings(bz_gpu_engine *g, double out_seconds[6])
@@ -310,16 +340,25 @@ extern "C" int df_gpu_debug_blocks(bz_gpu_engine *g, uint64_t *out4, size_t cap,
     return BZ_OK;
 }
 
+extern "C" int df_encode_buffer_dict(int kind, int device, const uint8_t *in, size_t in_len, const uint8_t *dict,
+                                     size_t dict_len, uint8_t **out, size_t *out_len);
+
 extern "C" int df_encode_buffer(int kind, int device, const uint8_t *in, size_t in_len, uint8_t **out, size_t *out_len)
 {
-    if (!out || !out_len || (!in && in_len) || kind < 0 || kind > 2) return BZ_E_PARAM;
+    return df_encode_buffer_dict(kind, device, in, in_len, nullptr, 0, out, out_len);
+}
+
+extern "C" int df_encode_buffer_dict(int kind, int device, const uint8_t *in, size_t in_len, const uint8_t *dict,
+                                     size_t dict_len, uint8_t **out, size_t *out_len)
+{
+    if (!out || !out_len || (!in && in_len) || kind < 0 || kind > 2 || (!dict && dict_len)) return BZ_E_PARAM;
     *out = nullptr;
     *out_len = 0;
     bz_gpu_engine *g = nullptr;
     int rc = bz_gpu_engine_create(&g, device, 1);
     if (rc != BZ_OK) return rc;
     void *d_in = nullptr, *d_out = nullptr;
-    const size_t cap = df_encode_bound(in_len);
+    const size_t cap = df_encode_bound(in_len) + 8;
     uint8_t *h = nullptr;
     size_t n_out = 0;
     rc = BZ_E_NOMEM;
@@ -327,7 +366,7 @@ extern "C" int df_encode_buffer(int kind, int device, const uint8_t *in, size_t 
     if (hipMalloc(&d_out, cap) != hipSuccess) goto done;
     rc = BZ_E_UNEXPECTED;
     if (in_len && hipMemcpy(d_in, in, in_len, hipMemcpyHostToDevice) != hipSuccess) goto done;
-    rc = df_gpu_encode_device(g, kind, d_in, in_len, d_out, cap, &n_out);
+    rc = df_gpu_encode_device_dict(g, kind, d_in, in_len, dict, dict_len, d_out, cap, &n_out);
     if (rc != BZ_OK) goto done;
     h = (uint8_t *)malloc(n_out ? n_out : 1);
     if (!h) { rc = BZ_E_NOMEM; goto done; }
@@ -347,7 +386,7 @@ done:
 // depends on all of the input: one 32 KiB window, one bit string).  Action::Flush is refused.
 struct df_enc {
     int kind = 0, device = 0;
-    std::vector<uint8_t> in, out;
+    std::vector<uint8_t> in, out, dict;
     size_t out_head = 0;
     bool finished = false;
 };
@@ -362,6 +401,14 @@ extern "C" int df_enc_create(df_enc **out, int kind, int device)
     e->device = device;
     *out = e;
     return BZ_OK;
+}
+
+extern "C" int df_enc_create_dict(df_enc **out, int kind, int device, const uint8_t *dict, size_t dict_len)
+{
+    if ((!dict && dict_len) || (dict_len && kind == 2)) return BZ_E_PARAM;
+    const int rc = df_enc_create(out, kind, device);
+    if (rc == BZ_OK && dict_len) (*out)->dict.assign(dict, dict + dict_len);
+    return rc;
 }
 
 extern "C" void df_enc_destroy(df_enc *e) { delete e; }
@@ -382,7 +429,7 @@ extern "C" int df_enc_end(df_enc *e, int action)
     if (e->finished) return BZ_OK;
     uint8_t *p = nullptr;
     size_t n = 0;
-    const int rc = df_encode_buffer(e->kind, e->device, e->in.data(), e->in.size(), &p, &n);
+    const int rc = df_encode_buffer_dict(e->kind, e->device, e->in.data(), e->in.size(), e->dict.data(), e->dict.size(), &p, &n);
     if (rc != BZ_OK) return rc;
     e->out.assign(p, p + n);
     free(p);

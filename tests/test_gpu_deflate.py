@@ -61,10 +61,10 @@ def test_reference_deflate_vectors(pkg, oracle, eng, v):
     assert check(pkg, oracle, eng, data) == want
 
 
-@pytest.mark.parametrize("v", [v for v in VEC["containers"] if "dict" not in v], ids=lambda v: v["name"])
+@pytest.mark.parametrize("v", VEC["containers"], ids=lambda v: v["name"])
 def test_reference_container_vectors(pkg, v):
     kind = pkg.ZLIB if v["kind"] == "zlib" else pkg.GZIP
-    assert pkg.deflate_compress(expand(v["input"]), kind) == bytes(v["bytes"])
+    assert pkg.deflate_compress(expand(v["input"]), kind, dict_=expand(v.get("dict"))) == bytes(v["bytes"])
 
 
 @pytest.mark.parametrize("v", [v for v in VEC["lzss"] if "dict" not in v and v["name"] not in ("test_7", "test_11")],
@@ -143,3 +143,38 @@ def test_reference_quirk_match_free_dynamic_block(pkg, oracle, eng):
     assert eng.deflate_stats()["dynamic_without_distances"] == 1
     with pytest.raises(zlib.error):
         zlib.decompress(got, -15)
+
+
+@pytest.mark.parametrize("dn", [1, 2, 3, 100, 32767, 32768, 32769, 100000])
+def test_with_dict(pkg, oracle, dn):
+    """Inflater::with_dict / ZlibEncoder::with_dict: the last 0x8000 bytes of the dictionary are the window"""
+    rnd = random.Random(dn)
+    words = [bytes(rnd.choice(b"abcdefgh") for _ in range(rnd.randint(2, 7))) for _ in range(40)]
+    text = b" ".join(rnd.choice(words) for _ in range(30000))
+    dict_, data = text[:dn], text[50000:50000 + 90000]
+    for kind, okind in ((pkg.DEFLATE, oracle.DEFLATE), (pkg.ZLIB, oracle.ZLIB)):
+        got = pkg.deflate_compress(data, kind, dict_=dict_)
+        assert got == oracle.deflate_encode(data, okind, dict_)
+    z = pkg.deflate_compress(data, pkg.ZLIB, dict_=dict_)
+    do = zlib.decompressobj(zdict=dict_)
+    assert do.decompress(z) == data
+    enc = pkg.ZlibEncoder.with_dict(dict_)
+    assert enc.encode_all(data) == z
+    with pytest.raises(pkg.CompressionError):
+        pkg.deflate_compress(data, pkg.GZIP, dict_=dict_)
+
+
+def test_length_limited_tables(pkg, oracle, eng):
+    """a block whose Huffman tree is deeper than the limit: make_table's package-merge path
+    (huffman/cano_huff_table.rs:58-151) on the GPU, same lengths as the oracle's"""
+    hits = 0
+    cases = []
+    for seed in (23, 99, 235):
+        rnd = random.Random(seed)
+        n = rnd.choice([300, 2000, 20000, 70000])
+        cases.append(bytes((rnd.getrandbits(8) & rnd.getrandbits(8) & rnd.getrandbits(8)) for _ in range(n)))
+    for data in cases:
+        got, _ = dev_encode(pkg, eng, data)
+        assert got == oracle.deflate_encode(data)
+        hits += eng.deflate_stats()["limited_tables"]
+    assert hits >= 1
