@@ -632,16 +632,29 @@ __global__ __launch_bounds__(kBThreads) void k_df_block(const u8 *__restrict__ i
     if (tid < 32) s_of[tid] = 0;
     if (tid == 0) s_lm = 0;
     __syncthreads();
-    for (u64 q = b0 + tid; q < b1; q += kBThreads) {
-        const u32 c = code[q];
-        if (!(c & F_CODE)) continue;
-        if (c & F_REF) {
-            u32 lc, eb, ev, dc;
-            len_code((c & 511u) - 3, lc, eb, ev);
-            dist_code((c >> 9) & 32767u, dc, eb, ev);
-            atomicAdd(&s_sf[257 + lc], 1u);
-            atomicAdd(&s_of[dc], 1u);
-        } else atomicAdd(&s_sf[in[q]], 1u);
+    for (u64 q0 = b0; q0 < b1; q0 += kBThreads * 8) { // eight independent loads in flight per thread
+        u32 c[8], lit[8];
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j) {
+            const u64 q = q0 + (u64)j * kBThreads + tid;
+            c[j] = q < b1 ? code[q] : 0u;
+        }
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j) {
+            const u64 q = q0 + (u64)j * kBThreads + tid;
+            lit[j] = ((c[j] & (F_CODE | F_REF)) == F_CODE) ? in[q] : 0u;
+        }
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j) {
+            if (!(c[j] & F_CODE)) continue;
+            if (c[j] & F_REF) {
+                u32 lc, eb, ev, dc;
+                len_code((c[j] & 511u) - 3, lc, eb, ev);
+                dist_code((c[j] >> 9) & 32767u, dc, eb, ev);
+                atomicAdd(&s_sf[257 + lc], 1u);
+                atomicAdd(&s_of[dc], 1u);
+            } else atomicAdd(&s_sf[lit[j]], 1u);
+        }
     }
     __syncthreads();
     if (tid == 0) s_sf[256] += 1; // init_block :274-279
