@@ -15,7 +15,7 @@
 using namespace dfgpu;
 
 struct DfWorkspace {
-    DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, prevd, est, segoff, concat, tabs, ents, bstart, nb, blocks, lens, hdr, lm, total,
+    DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, prevd, est, segoff, concat, bitmap, tabs, ents, bstart, nb, blocks, lens, hdr, lm, total,
         stream, asum, bsum, crc;
     size_t sort_tmp_bytes = 0;
     double t_stage[6] = {0, 0, 0, 0, 0, 0}; // chains, matches, parse, blocks, emit, total
@@ -29,7 +29,7 @@ struct DfWorkspace {
 void df_workspace_free(DfWorkspace *w)
 {
     if (!w) return;
-    DevBuf *all[] = {&w->keys_in, &w->keys_out, &w->vals_in, &w->vals_out, &w->sort_tmp, &w->prevd, &w->est, &w->segoff, &w->concat, &w->tabs, &w->ents,
+    DevBuf *all[] = {&w->keys_in, &w->keys_out, &w->vals_in, &w->vals_out, &w->sort_tmp, &w->prevd, &w->est, &w->segoff, &w->concat, &w->bitmap, &w->tabs, &w->ents,
                      &w->bstart, &w->nb, &w->blocks, &w->lens, &w->hdr, &w->lm, &w->total, &w->stream, &w->asum, &w->bsum,
                      &w->crc};
     for (DevBuf *b : all) b->release();
@@ -113,6 +113,7 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     if ((rc = w->tabs.ensure(tab_words * 2 + 64)) != BZ_OK) return rc;
     if ((rc = w->ents.ensure(ent_words * 2 + 64)) != BZ_OK) return rc;
     if ((rc = w->bstart.ensure(((size_t)bcap + 2) * 8)) != BZ_OK) return rc;
+    if ((rc = w->bitmap.ensure((n / 64 + 8) * 8)) != BZ_OK) return rc;
     if ((rc = w->nb.ensure(64)) != BZ_OK) return rc;
     if ((rc = w->blocks.ensure((size_t)bcap * sizeof(DfBlock))) != BZ_OK) return rc;
     if ((rc = w->lens.ensure((size_t)bcap * 320)) != BZ_OK) return rc;
@@ -158,7 +159,7 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     HIPCHK(hipEventRecord(w->ev[2], st));
     if (df_launch_parse(st, M, n, step, tabs.data(), ents.data(), counts.data(), nlevels, code) != 0) return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[3], st));
-    if (df_launch_blocks(st, d_in, code, n, w->bstart.as<u64>(), w->nb.as<u32>(), bcap, w->blocks.as<DfBlock>(),
+    if (df_launch_blocks(st, d_in, code, n, w->bitmap.as<u64>(), w->bstart.as<u64>(), w->nb.as<u32>(), bcap, w->blocks.as<DfBlock>(),
                          w->lens.as<u8>(), w->hdr.as<u32>(), w->lm.as<u32>(), w->total.as<u64>()) != 0)
         return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[4], st));

@@ -47,8 +47,8 @@ int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *keys_in, u32 *key
 int df_launch_match(hipStream_t st, const u8 *in, const u32 *pe, u64 n, u32 *M);
 int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *tabs, u16 *const *ents, const u32 *counts,
                     u32 nlevels, u32 *code);
-int df_launch_blocks(hipStream_t st, const u8 *in, const u32 *code, u64 n, u64 *bstart, u32 *nb, u32 cap, DfBlock *blocks,
-                     u8 *lens, u32 *hdr, u32 *lm_scratch, u64 *total_bits);
+int df_launch_blocks(hipStream_t st, const u8 *in, const u32 *code, u64 n, u64 *bm, u64 *bstart, u32 *nb, u32 cap,
+                     DfBlock *blocks, u8 *lens, u32 *hdr, u32 *lm_scratch, u64 *total_bits);
 int df_launch_emit(hipStream_t st, const u8 *in, const u32 *code, const u64 *bstart, const u32 *nb, u32 cap,
                    const DfBlock *blocks, const u8 *lens, const u32 *hdr, u32 *out);
 int df_launch_sums(hipStream_t st, const u8 *in, u64 n, u64 *asum, u64 *bsum, u32 *crc);

@@ -372,34 +372,85 @@ __global__ __launch_bounds__(256) void k_df_mark(const u16 *__restrict__ step, c
     }
 }
 
-// block starts: b' = the last code start <= b + 0xFFFF (InflaterInner::next :585-593).  One wave.
-__global__ __launch_bounds__(64) void k_df_cuts(const u32 *__restrict__ code, u64 n, u64 *__restrict__ bstart,
-                                                u32 *__restrict__ nb_out, u32 cap)
+// one bit per position: an LZSS code starts here
+__global__ __launch_bounds__(256) void k_df_bitmap(const u32 *__restrict__ code, u64 n, u64 *__restrict__ bm, u64 nwords)
 {
-    const u32 lane = threadIdx.x;
-    u64 b = 0;
-    u32 k = 0;
-    for (;;) {
-        if (lane == 0 && k < cap) bstart[k] = b;
-        ++k;
-        const u64 x = b + kBlockMax;
-        if (x >= n) break;
-        u64 q = x;
-        u32 tries = 0;
-        for (;;) {
-            const bool f = (q >= lane) && (code[q - lane] & F_CODE);
-            const u64 bal = __ballot(f);
-            if (bal) { b = q - (u64)(__ffsll((unsigned long long)bal) - 1); break; }
-            q -= 64;
-            if (++tries > 8) { // a code is at most 258 bytes long: cannot happen; never spin on a broken parse
-                if (lane == 0) *nb_out = 0xFFFFFFFFu;
-                return;
-            }
-        }
+    const u64 wv = ((u64)blockIdx.x * 256 + threadIdx.x) >> 6; // wave index: 16 words each
+    const u32 lane = threadIdx.x & 63u;
+    for (u32 j = 0; j < 16; ++j) {
+        const u64 word = wv * 16 + j;
+        if (word >= nwords) break;
+        const u64 q = word * 64 + lane;
+        const bool f = q < n && (code[q] & F_CODE);
+        const u64 m = __ballot(f);
+        if (lane == 0) bm[word] = m;
     }
-    if (lane == 0) {
-        if (k < cap) bstart[k] = n;
-        *nb_out = k;
+}
+
+// block starts: b' = the last code start <= b + 0xFFFF (InflaterInner::next :585-593).  A serial chain of
+// n / 65535 hops; a hop loses at most 257 bytes against b + 0xFFFF, so the bits that the next kCutGroup hops
+// can look at are known in advance: they are loaded together, the hops then run out of LDS.
+constexpr u32 kCutGroup = 32;
+constexpr u32 kCutWords = (257 * kCutGroup + 64) / 64 + 3;
+__global__ __launch_bounds__(256) void k_df_cuts(const u64 *__restrict__ bm, u64 n, u64 *__restrict__ bstart,
+                                                 u32 *__restrict__ nb_out, u32 cap)
+{
+    __shared__ u64 s_bm[kCutGroup][kCutWords];
+    __shared__ u64 s_b;
+    __shared__ u32 s_k, s_done;
+    const u32 tid = threadIdx.x;
+    const u64 nwords = (n + 63) / 64;
+    if (tid == 0) { s_b = 0; s_k = 0; s_done = 0; if (cap) bstart[0] = 0; }
+    __syncthreads();
+    for (;;) {
+        const u64 b = s_b;
+        const u64 x = b + kBlockMax;
+        if (x >= n || s_done) break;
+        // every region padded to kCutWords words ending at its highest word: all loads of a group are in
+        // flight together (one memory round trip per kCutGroup hops)
+        constexpr u32 kPer = (kCutGroup * kCutWords + 255) / 256;
+        u64 v[kPer];
+#pragma unroll
+        for (u32 i = 0; i < kPer; ++i) {
+            const u32 f = i * 256 + tid;
+            const u32 j = f / kCutWords, w = f % kCutWords;
+            const u64 whi = (x + (u64)j * kBlockMax) >> 6;
+            const i64 word = (i64)whi - (i64)(kCutWords - 1) + (i64)w;
+            v[i] = (j < kCutGroup && word >= 0 && (u64)word < nwords) ? bm[word] : 0ull;
+        }
+#pragma unroll
+        for (u32 i = 0; i < kPer; ++i) {
+            const u32 f = i * 256 + tid;
+            if (f < kCutGroup * kCutWords) s_bm[f / kCutWords][f % kCutWords] = v[i];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            u64 cur = b;
+            u32 k = s_k;
+            for (u32 j = 0; j < kCutGroup; ++j) {
+                const u64 xj = cur + kBlockMax;
+                if (xj >= n) break;
+                const i64 wlo = (i64)((x + (u64)j * kBlockMax) >> 6) - (i64)(kCutWords - 1); // word of s_bm[j][0]
+                i64 w = (i64)(xj >> 6) - wlo;
+                u64 m = s_bm[j][w] & (~0ull >> (63 - (u32)(xj & 63)));
+                while (!m && w > 0) { --w; m = s_bm[j][w]; }
+                if (!m) { s_done = 2; break; } // a code is at most 258 bytes long: cannot happen
+                cur = ((u64)(wlo + w) << 6) + 63 - (u64)__builtin_clzll(m);
+                ++k;
+                if (k < cap) bstart[k] = cur;
+            }
+            s_b = cur;
+            s_k = k;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const u32 k = s_k + 1; // blocks
+        if (s_done == 2) *nb_out = 0xFFFFFFFFu;
+        else {
+            if (k < cap + 1) bstart[k] = n;
+            *nb_out = k;
+        }
     }
 }
 
@@ -1026,10 +1077,12 @@ int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *
     return 0;
 }
 
-int df_launch_blocks(hipStream_t st, const u8 *in, const u32 *code, u64 n, u64 *bstart, u32 *nb, u32 cap, DfBlock *blocks,
-                     u8 *lens, u32 *hdr, u32 *lm_scratch, u64 *total_bits)
+int df_launch_blocks(hipStream_t st, const u8 *in, const u32 *code, u64 n, u64 *bm, u64 *bstart, u32 *nb, u32 cap,
+                     DfBlock *blocks, u8 *lens, u32 *hdr, u32 *lm_scratch, u64 *total_bits)
 {
-    hipLaunchKernelGGL(k_df_cuts, dim3(1), dim3(64), 0, st, code, n, bstart, nb, cap);
+    const u64 nwords = (n + 63) / 64;
+    if (nwords) hipLaunchKernelGGL(k_df_bitmap, dim3((u32)((nwords + 63) / 64)), dim3(256), 0, st, code, n, bm, nwords);
+    hipLaunchKernelGGL(k_df_cuts, dim3(1), dim3(256), 0, st, bm, n, bstart, nb, cap);
     hipLaunchKernelGGL(k_df_block, dim3(cap), dim3(kBThreads), 0, st, in, code, bstart, nb, blocks, lens, hdr, lm_scratch);
     hipLaunchKernelGGL(k_df_offsets, dim3(1), dim3(256), 0, st, blocks, nb, total_bits);
     return 0;
