@@ -206,31 +206,30 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
         const u32 pw0 = s_w[lp >> 2], pw1 = s_w[(lp >> 2) + 1], pw2 = s_w[(lp >> 2) + 2];
         const u32 a0 = __builtin_amdgcn_alignbyte(pw1, pw0, lp & 3u), a1 = __builtin_amdgcn_alignbyte(pw2, pw1, lp & 3u);
         // The walk (search_dic :232-265).  A candidate replaces the best one only if it is strictly longer
-        // (deflate/encoder.rs:34-51 with a farther candidate), so it must agree with p up to offset best_len:
-        // a few bytes decide for most candidates, the survivors are measured in full at once (collecting
-        // them until a quarter of the wave waits was measured: slower, the waiting costs more than it saves).  Lanes that are done
-        // keep computing on their last candidate and are masked out of the updates.
-        // The filter: a better candidate agrees with p on bytes 0 .. best_len, in particular on the last
-        // four of them (fewer while best_len < 3).  With one byte a fifth of the candidates passed and some
-        // lane of the 64 had a candidate to measure in almost every trip; four bytes make that rare.
+        // (deflate/encoder.rs:34-51 with a farther candidate), so it must agree with p on bytes 0 .. best_len,
+        // in particular on the last four of them (fewer while best_len < 3): that test is all the walk does.
+        // Candidates that pass are queued (four per lane) and measured later, for all lanes at once: the
+        // result is the first candidate of the greatest length either way, a stale best_len only lets a few
+        // more candidates into the queue, and a candidate that matches to the limit (where search_dic stops)
+        // is the first of the greatest length too -- walking past it until the next measuring changes nothing.
         u32 foff = 0, fmask = 0xFFu, fq = a0 & 0xFFu; // offset of the tested dword, its mask, p's bytes there
-        while (__ballot(active)) {
-            const u32 lc = lp - cum;
-            const u32 fa = lc + foff;
-            const u32 fw0 = s_w[fa >> 2], fw1 = s_w[(fa >> 2) + 1];
-            const u32 d = s_prev[lc]; // (read together with the bytes: one LDS round trip per candidate)
-            const bool surv = active && ((__builtin_amdgcn_alignbyte(fw1, fw0, fa & 3u) ^ fq) & fmask) == 0;
+        u64 queue = 0;                                // summed distances of the queued candidates, 16 bits each
+        u32 qn = 0;
+        auto measure = [&]() {
             bool hit = false;
-            if (__ballot(surv)) {
-                if (surv) {
-                    const u32 cw0 = s_w[lc >> 2], cw1 = s_w[(lc >> 2) + 1], cw2 = s_w[(lc >> 2) + 2];
-                    const u32 x0 = a0 ^ __builtin_amdgcn_alignbyte(cw1, cw0, lc & 3u);
-                    const u32 x1 = a1 ^ __builtin_amdgcn_alignbyte(cw2, cw1, lc & 3u);
-                    const u64 xx = ((u64)x1 << 32) | x0; // no branches: first differing byte of the first eight
+            for (u32 s = 0; s < 4; ++s) {
+                if (!__ballot(s < qn)) break;
+                if (s < qn && !hit) {
+                    const u32 ccum = (u32)(queue >> (16 * s)) & 0xFFFFu;
+                    const u32 lcq = lp - ccum;
+                    const u32 cw0 = s_w[lcq >> 2], cw1 = s_w[(lcq >> 2) + 1], cw2 = s_w[(lcq >> 2) + 2];
+                    const u32 x0 = a0 ^ __builtin_amdgcn_alignbyte(cw1, cw0, lcq & 3u);
+                    const u32 x1 = a1 ^ __builtin_amdgcn_alignbyte(cw2, cw1, lcq & 3u);
+                    const u64 xx = ((u64)x1 << 32) | x0; // first differing byte of the first eight, no branches
                     u32 l = xx ? ((u32)__builtin_ctzll(xx) >> 3) : 8u;
                     if (l == 8) // check_match :175-188, eight bytes per trip
                         while (l < limit) {
-                            const u32 pa = lp + l, ca = lc + l;
+                            const u32 pa = lp + l, ca = lcq + l;
                             const u32 p0 = s_w[pa >> 2], p1 = s_w[(pa >> 2) + 1], p2 = s_w[(pa >> 2) + 2];
                             const u32 c0 = s_w[ca >> 2], c1 = s_w[(ca >> 2) + 1], c2 = s_w[(ca >> 2) + 2];
                             const u32 y0 = __builtin_amdgcn_alignbyte(p1, p0, pa & 3u) ^ __builtin_amdgcn_alignbyte(c1, c0, ca & 3u);
@@ -240,23 +239,33 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
                             l += 8;
                         }
                     l = l < limit ? l : limit;
-                    hit = l == limit;
-                    if (l > best_len) {
-                        best_len = l;
-                        best_dist = cum;
-                        // (when l == limit the walk ends and the filter is not used again)
-                        foff = l >= 3 ? l - 3 : 0u;
-                        fmask = l >= 3 ? 0xFFFFFFFFu : ((1u << (8 * (l + 1))) - 1);
-                        fq = ld4(lp + foff) & fmask;
-                    }
+                    if (l > best_len) { best_len = l; best_dist = ccum; }
+                    hit = l == limit; // :258-259: nothing behind this candidate counts
                 }
             }
+            queue = 0;
+            qn = 0;
+            foff = best_len >= 3 ? best_len - 3 : 0u;
+            fmask = best_len >= 3 ? 0xFFFFFFFFu : ((1u << (8 * (best_len + 1))) - 1);
+            fq = best_len < limit ? (ld4(lp + foff) & fmask) : 0u;
+            if (hit) active = false;
+        };
+        while (__ballot(active)) {
+            const u32 lc = lp - cum;
+            const u32 fa = lc + foff;
+            const u32 fw0 = s_w[fa >> 2], fw1 = s_w[(fa >> 2) + 1];
+            const u32 d = s_prev[lc]; // (read together with the bytes: one LDS round trip per candidate)
+            const bool pass = active && ((__builtin_amdgcn_alignbyte(fw1, fw0, fa & 3u) ^ fq) & fmask) == 0;
+            queue |= pass ? ((u64)(cum & 0xFFFFu) << (16 * qn)) : 0ull;
+            qn += pass ? 1u : 0u;
             cnt -= 1;
             const u32 ncum = cum + d;
-            const bool cont = active && !hit && cnt != 0 && d != 0 && ncum <= kWin; // :258-262, :234
+            const bool cont = active && cnt != 0 && d != 0 && ncum <= kWin; // :262, :234
             cum = cont ? ncum : cum;
             active = cont;
+            if (__ballot(qn == 4)) measure();
         }
+        if (__ballot(qn != 0)) measure();
         if (valid) M[p] = best_len >= kMinMatch ? (best_len | ((best_dist - 1) << 9)) : 0u;
     }
 }
