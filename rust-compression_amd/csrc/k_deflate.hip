@@ -212,7 +212,9 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
         // result is the first candidate of the greatest length either way, a stale best_len only lets a few
         // more candidates into the queue, and a candidate that matches to the limit (where search_dic stops)
         // is the first of the greatest length too -- walking past it until the next measuring changes nothing.
-        u32 foff = 0, fmask = 0xFFu, fq = a0 & 0xFFu; // offset of the tested dword, its mask, p's bytes there
+        // (a match shorter than 3 is no match, lzss/encoder.rs:135-141: the walk starts as if 2 bytes were beaten)
+        best_len = 2;
+        u32 foff = 0, fmask = 0xFFFFFFu, fq = a0 & 0xFFFFFFu; // offset of the tested dword, its mask, p's bytes there
         u64 queue = 0;                                // summed distances of the queued candidates, 16 bits each
         u32 qn = 0;
         auto measure = [&]() {
