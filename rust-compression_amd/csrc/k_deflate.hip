@@ -125,6 +125,7 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
     __shared__ u16 s_prev[kWin + kMTile];
     __shared__ u16 s_order[kMTile];
     __shared__ u8 s_est[kMTile];
+    __shared__ u16 s_q[4][kMThreads]; // per lane: summed distances of the candidates waiting to be measured
     __shared__ u32 s_hist[256];
     __shared__ u32 s_next;
     const u32 tid = threadIdx.x;
@@ -215,14 +216,13 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
         // (a match shorter than 3 is no match, lzss/encoder.rs:135-141: the walk starts as if 2 bytes were beaten)
         best_len = 2;
         u32 foff = 0, fmask = 0xFFFFFFu, fq = a0 & 0xFFFFFFu; // offset of the tested dword, its mask, p's bytes there
-        u64 queue = 0;                                // summed distances of the queued candidates, 16 bits each
-        u32 qn = 0;
+        u32 qn = 0;                                   // candidates in this lane's queue (s_q[..][tid])
         auto measure = [&]() {
             bool hit = false;
             for (u32 s = 0; s < 4; ++s) {
                 if (!__ballot(s < qn)) break;
                 if (s < qn && !hit) {
-                    const u32 ccum = (u32)(queue >> (16 * s)) & 0xFFFFu;
+                    const u32 ccum = s_q[s][tid];
                     const u32 lcq = lp - ccum;
                     const u32 cw0 = s_w[lcq >> 2], cw1 = s_w[(lcq >> 2) + 1], cw2 = s_w[(lcq >> 2) + 2];
                     const u32 x0 = a0 ^ __builtin_amdgcn_alignbyte(cw1, cw0, lcq & 3u);
@@ -245,7 +245,6 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
                     hit = l == limit; // :258-259: nothing behind this candidate counts
                 }
             }
-            queue = 0;
             qn = 0;
             foff = best_len >= 3 ? best_len - 3 : 0u;
             fmask = best_len >= 3 ? 0xFFFFFFFFu : ((1u << (8 * (best_len + 1))) - 1);
@@ -258,7 +257,7 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
             const u32 fw0 = s_w[fa >> 2], fw1 = s_w[(fa >> 2) + 1];
             const u32 d = s_prev[lc]; // (read together with the bytes: one LDS round trip per candidate)
             const bool pass = active && ((__builtin_amdgcn_alignbyte(fw1, fw0, fa & 3u) ^ fq) & fmask) == 0;
-            queue |= pass ? ((u64)(cum & 0xFFFFu) << (16 * qn)) : 0ull;
+            if (pass) s_q[qn][tid] = (u16)cum;
             qn += pass ? 1u : 0u;
             cnt -= 1;
             const u32 ncum = cum + d;
