@@ -35,6 +35,24 @@ constexpr u32 kStreamWords = 480000;        // 1.92 MB
 
 constexpr u32 kFinalBit = 0x80000000u;      // rank word: rotation is alone in its group
 
+// Lanes of the wave that hold the same `bits`-bit digit as this lane (and take part): the "match any" of a
+// radix pass.  Per bit: the lanes that DIFFER from this one are ballot ^ (all ones if my bit is set), OR-ed
+// up in one three-input boolean instruction per half (v_bitop3_b32 on gfx950): 4 vector instructions per
+// bit instead of the 9 that the select form `peers &= bit ? m : ~m` compiles to.
+template <int BITS> __device__ __forceinline__ u64 wave_match_digit(u32 dg, bool ok)
+{
+    u32 diff_lo = 0, diff_hi = 0;
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) {
+        const u32 mine = (u32)((int)(dg << (31 - b)) >> 31); // all ones if bit b of dg is set
+        const u64 m = __ballot((int)mine < 0);
+        diff_lo |= (u32)m ^ mine;
+        diff_hi |= (u32)(m >> 32) ^ mine;
+    }
+    const u64 diff = ((u64)diff_hi << 32) | diff_lo;
+    return __ballot(ok) & ~diff;
+}
+
 // per-block record produced by the partition step (device + host mirror)
 struct BlockDesc {
     u64 rle_off;   // offset of the block's bytes in the RLE1 image

@@ -376,13 +376,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
     for (u32 r = 0; r < 16; ++r) {
         const bool ok = (okmask >> r) & 1u;
         const u32 dg = (key[r] >> shift) & (NB - 1);
-        u64 peers = __ballot(ok);
-#pragma unroll
-        for (int b = 0; b < BITS; ++b) {
-            const bool bit = (dg >> b) & 1u;
-            const u64 m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
+        const u64 peers = wave_match_digit<BITS>(dg, ok);
         rnk[r] = 0xFFFFFFFFu;
         if (ok) {
             const u32 before = __popcll(peers & lt_mask);
@@ -654,13 +648,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
     for (u32 r = 0; r < 16; ++r) {
         const bool ok = (okmask >> r) & 1u;
         const u32 dg = (key[r] >> shift) & (NB - 1);
-        u64 peers = __ballot(ok);
-#pragma unroll
-        for (int b = 0; b < BITS; ++b) {
-            const bool bit = (dg >> b) & 1u;
-            const u64 m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
+        const u64 peers = wave_match_digit<BITS>(dg, ok);
         rnk[r] = 0xFFFFFFFFu;
         if (ok) {
             const u32 before = __popcll(peers & lt_mask);

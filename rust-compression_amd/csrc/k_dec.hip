@@ -1276,13 +1276,7 @@ __global__ __launch_bounds__(kSortThreads) void k_dec_tscatter(DecArgs a)
         const u32 idx = start + w * 1024u + r * 64u + l;
         const bool ok = idx < n;
         const u32 dg = dgv[r];
-        u64 peers = __ballot(ok);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (dg >> b) & 1u;
-            const u64 m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
+        const u64 peers = wave_match_digit<8>(dg, ok);
         rnk[r] = 0xFFFFFFFFu;
         if (ok) {
             const u32 before = __popcll(peers & lt_mask);
