@@ -96,19 +96,14 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     const u32 bcap = (u32)(n / (kBlockMax - 300) + 2);
 
     int rc;
-    {
-        size_t t = 0;
-        if (df_sort_temp_bytes(nall, &t) != 0) return BZ_E_UNEXPECTED;
-        w->sort_tmp_bytes = t;
-    }
-    const u64 nent = df_entries(nall) + 16;
-    if ((rc = w->keys_in.ensure((nent > npad ? nent : npad) * 4)) != BZ_OK) return rc;   // later: step[]
-    if ((rc = w->keys_out.ensure(nent * 4)) != BZ_OK) return rc;
-    if ((rc = w->vals_in.ensure((nent > npad ? nent : npad) * 4)) != BZ_OK) return rc;   // later: M[]
-    if ((rc = w->vals_out.ensure((nent > npad ? nent : npad) * 4)) != BZ_OK) return rc;  // later: code[]
-    if ((rc = w->sort_tmp.ensure(w->sort_tmp_bytes + 256)) != BZ_OK) return rc;
+    const u64 nchunks = df_chunks(nall);
+    const u64 nsort = nchunks * kChunkStride + 16; // words of a sorted-position array
+    if ((rc = w->keys_in.ensure(npad * 2)) != BZ_OK) return rc;                          // step[]
+    if ((rc = w->vals_in.ensure((nsort > npad ? nsort : npad) * 4)) != BZ_OK) return rc;  // pass 0 output, later M[]
+    if ((rc = w->vals_out.ensure((nsort > npad ? nsort : npad) * 4)) != BZ_OK) return rc; // sorted positions, later code[]
+    if ((rc = w->sort_tmp.ensure((nchunks * kChunkTiles + 1) * 256 * 4)) != BZ_OK) return rc; // per-tile digit counts
+    if ((rc = w->keys_out.ensure((nchunks + 1) * 256 * 4)) != BZ_OK) return rc;           // per-chunk digit bases
     if ((rc = w->prevd.ensure(npad * 4)) != BZ_OK) return rc; // per position: chain distance | chain length << 16
-    if ((rc = w->segoff.ensure((nall / kChunk + 8) * 4)) != BZ_OK) return rc;
     if (hist && (rc = w->concat.ensure(nall + 64)) != BZ_OK) return rc;
     if ((rc = w->tabs.ensure(tab_words * 2 + 64)) != BZ_OK) return rc;
     if ((rc = w->ents.ensure(ent_words * 2 + 64)) != BZ_OK) return rc;
@@ -151,8 +146,8 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
 
     HIPCHK(hipEventRecord(w->ev[0], st));
     HIPCHK(hipMemsetAsync(w->stream.p, 0, bound + 64, st));
-    if (df_launch_chains(st, d_all, nall, w->keys_in.as<u32>(), w->keys_out.as<u32>(), w->vals_in.as<u32>(), w->vals_out.as<u32>(),
-                         w->sort_tmp.p, w->sort_tmp_bytes, w->prevd.as<u32>(), w->segoff.as<u32>()) != 0)
+    if (df_launch_chains(st, d_all, nall, w->vals_in.as<u32>(), w->vals_out.as<u32>(), w->sort_tmp.as<u32>(), w->keys_out.as<u32>(),
+                         w->prevd.as<u32>()) != 0)
         return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[1], st));
     if (df_launch_match(st, d_all, w->prevd.as<u32>(), nall, Mall) != 0) return BZ_E_UNEXPECTED;

@@ -16,7 +16,9 @@ constexpr u32 kMinMatch = 3;       // LZSS_MIN_MATCH :109
 constexpr u32 kChain = 255;        // MATCH_SEARCH_COUNT - 1 (lzss/slidedict.rs:129, 232)
 constexpr u32 kBlockMax = 0xFFFF;  // MAX_BLOCK_SIZE (deflate/encoder.rs:270)
 constexpr u32 kChunk = 1u << 20;    // positions per sort chunk (hash chains are built chunk by chunk)
-constexpr u32 kPrevSpan = (kChunk + kWin) / 256; // 256-entry slices of one sort chunk
+constexpr u32 kChunkStride = kChunk + kWin;          // entries of one sort chunk: its positions and the 32 KiB in front
+constexpr u32 kChunkTiles = kChunkStride / bzgpu::kSortTile; // 132 tiles of 8192 entries
+constexpr u32 kPrevSpan = kChunkStride / 256;         // 256-entry slices of one sort chunk
 constexpr u32 kMTile = 8192;       // positions per match workgroup
 constexpr u32 kMThreads = 1024;
 constexpr u32 kPTile = 4096;       // positions per parse tile
@@ -40,10 +42,8 @@ struct DfBlock {
     u64 bit_off;   // where it starts in the stream
 };
 
-int df_sort_temp_bytes(u64 n, size_t *bytes);
-u64 df_entries(u64 n); // entries the chain sort handles: trigram positions + 32 KiB of history per chunk
-int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *keys_in, u32 *keys_out, u32 *vals_in, u32 *vals_out,
-                     void *tmp, size_t tmp_bytes, u32 *pe, u32 *seg_off);
+u32 df_chunks(u64 n); // sort chunks of an input of n bytes
+int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *v0, u32 *s, u32 *hist, u32 *tbase, u32 *pe);
 int df_launch_match(hipStream_t st, const u8 *in, const u32 *pe, u64 n, u32 *M);
 int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *tabs, u16 *const *ents, const u32 *counts,
                     u32 nlevels, u32 *code);

@@ -6,7 +6,8 @@
 //     192-214, 80-115), so the chain it walks from position p (search_dic :216-267) is "the earlier
 //     positions with the same hash, nearest first, while the summed distance is <= 0x8000, at most
 //     255 of them, stopping behind the first one that matches to the limit".  Sorting positions by
-//     hash (stable) puts every chain in one run; k_df_prev turns the run into the reference's
+//     hash (stable, two counting passes per 1 Mi-position chunk: k_df_shist / k_df_sscan /
+//     k_df_sscatter) puts every chain in one run; k_df_prev turns the run into the reference's
 //     `pos` array (distance to the previous member, 0 = none within the window).
 //   * The candidate kept is the first one with the greatest length (the comparison closure of
 //     deflate/encoder.rs:34-51 can only prefer a new candidate that is strictly longer, because a
@@ -24,8 +25,6 @@
 //     coding (:318-452) exactly; k_df_emit writes the bits LSB first (bitio/writer.rs, Right).
 #include <cstdlib>
 #include <cstring>
-#include <vector>
-#include <rocprim/rocprim.hpp>
 
 #include "bzgpu.h"
 #include "k_deflate.h"
@@ -41,71 +40,222 @@ __device__ __forceinline__ u32 hash16(u32 b0, u32 b1, u32 b2)
     return (u32)((h * 0x7A7C4F9F7A7C4F9Full) >> 48);
 }
 
-// Entries to sort: the trigram positions, chunk by chunk (kChunk positions each), every chunk preceded by the
-// 32 KiB of positions in front of it (they are the chain candidates of its first positions).  Key = chunk
-// << 16 | hash: one global sort leaves every chunk's entries in the chunk's own range, ordered by (hash,
-// position), and k_df_prev scatters into 3 MB per chunk instead of the whole input.
-__device__ __forceinline__ void df_entry(u64 e, u32 &chunk, u64 &pos)
+// The chain sort.  Trigram positions are handled in chunks of kChunk, every chunk together with the 32 KiB of
+// positions in front of it (they are the chain candidates of its first positions): entry j of chunk c is
+// position c * kChunk - kWin + j, j < kChunkStride; entries in front of position 0 or behind the last trigram
+// do not exist.  Two stable counting passes (low byte of the hash, then high byte) order a chunk by (hash,
+// position); the hash is recomputed from the text each time (the chunk's 1 MB of text sits in L2), so only
+// positions are moved.  Same three-kernel shape as the decoder's T-vector sort (k_dec.hip).
+// hash of the trigram at pos: one unaligned dword load (legal on gfx950) except at the very end of the text
+__device__ __forceinline__ u32 df_hash_at(const u8 *__restrict__ in, u32 pos, u64 ntri)
 {
-    if (e < kChunk) { chunk = 0; pos = e; return; }
-    const u64 r = e - kChunk;
-    chunk = 1 + (u32)(r / (kChunk + kWin));
-    pos = (u64)chunk * kChunk - kWin + (r % (kChunk + kWin));
+    u32 w;
+    if ((u64)pos + 2 <= ntri) { // pos + 3 < n: the fourth byte exists
+        typedef u32 __attribute__((aligned(1))) u32u;
+        w = *reinterpret_cast<const u32u *>(in + pos);
+    } else w = (u32)in[pos] | ((u32)in[pos + 1] << 8) | ((u32)in[pos + 2] << 16);
+    return hash16(w & 0xFFu, (w >> 8) & 0xFFu, (w >> 16) & 0xFFu);
 }
 
-__global__ __launch_bounds__(256) void k_df_keys(const u8 *__restrict__ in, u64 ntri, u64 nent, u32 *__restrict__ keys,
-                                                 u32 *__restrict__ vals)
+__device__ __forceinline__ u32 df_chunk_count(u32 c, u64 ntri, u32 &j0)
 {
-    const u64 e = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (e >= nent) return;
-    u32 chunk;
-    u64 pos;
-    df_entry(e, chunk, pos);
-    keys[e] = (chunk << 16) | hash16(in[pos], in[pos + 1], in[pos + 2]);
-    vals[e] = (u32)pos;
+    j0 = c == 0 ? kWin : 0u;
+    const u64 lim = ntri - (u64)c * kChunk + kWin; // entries j with position < ntri
+    return (u32)(lim < kChunkStride ? lim : kChunkStride) - j0;
 }
 
-// sorted by (chunk, hash, position): distance to the previous position with the same hash (0 = none in the
+// element `idx` of the pass input of chunk c.  PASS 0: the chunk's positions in order, digit = low byte of the
+// hash; what it hands on is the position relative to the chunk (21 bits) with the HIGH byte of the hash on top,
+// so that PASS 1 (digit = that byte) does not touch the text again.
+template <int PASS>
+__device__ __forceinline__ bool df_pass_elem(const u8 *__restrict__ in, u64 ntri, const u32 *__restrict__ src, u32 c, u32 idx,
+                                             u32 count, u32 j0, u32 &val, u32 &dg)
+{
+    if (idx >= count) { val = 0; dg = 0; return false; }
+    if (PASS == 0) {
+        const u32 rel = j0 + idx;
+        const u32 h = df_hash_at(in, c * kChunk - kWin + rel, ntri);
+        dg = h & 0xFFu;
+        val = rel | ((h >> 8) << 24);
+    } else {
+        const u32 e = src[(size_t)c * kChunkStride + idx];
+        dg = e >> 24;
+        val = c * kChunk - kWin + (e & 0xFFFFFFu); // the position itself goes out
+    }
+    return true;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(kSortThreads) void k_df_shist(const u8 *__restrict__ in, u64 ntri, const u32 *__restrict__ src,
+                                                           u32 *__restrict__ hist)
+{
+    __shared__ u32 s_hist[4][256];
+    const u32 c = blockIdx.x / kChunkTiles, tile = blockIdx.x % kChunkTiles;
+    u32 j0;
+    const u32 count = df_chunk_count(c, ntri, j0);
+    const u32 start = tile * kSortTile;
+    for (u32 i = threadIdx.x; i < 4u * 256u; i += kSortThreads) (&s_hist[0][0])[i] = 0;
+    __syncthreads();
+    if (start < count) {
+        u32 *mine = s_hist[threadIdx.x & 3u];
+#pragma unroll 4
+        for (u32 r = 0; r < 16; ++r) {
+            u32 pos, dg;
+            if (df_pass_elem<PASS>(in, ntri, src, c, start + r * kSortThreads + threadIdx.x, count, j0, pos, dg)) atomicAdd(&mine[dg], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 256)
+        hist[(size_t)blockIdx.x * 256u + threadIdx.x] =
+            s_hist[0][threadIdx.x] + s_hist[1][threadIdx.x] + s_hist[2][threadIdx.x] + s_hist[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_df_sscan(u32 *__restrict__ hist, u32 *__restrict__ tbase)
+{
+    __shared__ u32 s_w[4];
+    const u32 c = blockIdx.x, d = threadIdx.x;
+    u32 *h = hist + (size_t)c * kChunkTiles * 256u;
+    u32 run = 0;
+    for (u32 t = 0; t < kChunkTiles; ++t) {
+        const u32 v = h[t * 256u + d];
+        h[t * 256u + d] = run;
+        run += v;
+    }
+    const u32 inc = wave_incl_sum(run);
+    if ((d & 63u) == 63u) s_w[d >> 6] = inc;
+    __syncthreads();
+    u32 carry = 0;
+    for (u32 k = 0; k < (d >> 6); ++k) carry += s_w[k];
+    tbase[(size_t)c * 256u + d] = carry + inc - run;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(kSortThreads) void k_df_sscatter(const u8 *__restrict__ in, u64 ntri, const u32 *__restrict__ src,
+                                                              const u32 *__restrict__ hist, const u32 *__restrict__ tbase,
+                                                              u32 *__restrict__ dst)
+{
+    constexpr u32 NW = kSortThreads / 64;
+    __shared__ u32 s_buf[kSortTile];
+    __shared__ u8 s_dg[kSortTile];
+    __shared__ u32 s_base[256];
+    __shared__ u16 s_tpre[256];
+    __shared__ u16 s_cnt[NW][256];
+    __shared__ u32 s_wsum[4];
+    const u32 c = blockIdx.x / kChunkTiles, tile = blockIdx.x % kChunkTiles;
+    u32 j0;
+    const u32 count = df_chunk_count(c, ntri, j0);
+    const u32 start = tile * kSortTile;
+    if (start >= count) return;
+    for (u32 i = threadIdx.x; i < NW * 256u / 2u; i += kSortThreads) reinterpret_cast<u32 *>(&s_cnt[0][0])[i] = 0;
+    if (threadIdx.x < 256) s_base[threadIdx.x] = hist[(size_t)blockIdx.x * 256u + threadIdx.x] + tbase[(size_t)c * 256u + threadIdx.x];
+    __syncthreads();
+    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const u64 lt_mask = (l == 0) ? 0ull : (~0ull >> (64 - l));
+    u16 *my_cnt = s_cnt[w];
+    u32 posv[16], dgv[16], rnk[16];
+    u32 okmask = 0;
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r)
+        okmask |= (df_pass_elem<PASS>(in, ntri, src, c, start + w * 1024u + r * 64u + l, count, j0, posv[r], dgv[r]) ? 1u : 0u) << r;
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const bool ok = (okmask >> r) & 1u;
+        const u32 dg = dgv[r];
+        const u64 peers = wave_match_digit<8>(dg, ok);
+        rnk[r] = 0xFFFFFFFFu;
+        if (ok) {
+            const u32 before = __popcll(peers & lt_mask);
+            const u32 c0 = my_cnt[dg];
+            rnk[r] = c0 + before;
+            if ((peers >> l) == 1ull) my_cnt[dg] = (u16)(c0 + before + 1u);
+        }
+    }
+    __syncthreads();
+    u32 tot = 0;
+    if (threadIdx.x < 256) {
+        for (u32 k = 0; k < NW; ++k) {
+            const u32 cc = s_cnt[k][threadIdx.x];
+            s_cnt[k][threadIdx.x] = (u16)tot;
+            tot += cc;
+        }
+        const u32 inc = wave_incl_sum(tot);
+        if (l == 63) s_wsum[w] = inc;
+        s_tpre[threadIdx.x] = (u16)(inc - tot); // wave-local for now
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        u32 carry = 0;
+        for (u32 k = 0; k < w; ++k) carry += s_wsum[k];
+        s_tpre[threadIdx.x] = (u16)(s_tpre[threadIdx.x] + carry);
+    }
+    __syncthreads();
+    const u32 cnt_tile = (count - start < kSortTile) ? count - start : kSortTile;
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        if (rnk[r] != 0xFFFFFFFFu) {
+            const u32 lpos = (u32)s_tpre[dgv[r]] + (u32)my_cnt[dgv[r]] + rnk[r];
+            s_buf[lpos] = posv[r]; // digit order inside the tile, so that consecutive lanes store consecutive words
+            s_dg[lpos] = (u8)dgv[r];
+        }
+    }
+    __syncthreads();
+    u32 *out = dst + (size_t)c * kChunkStride;
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k) {
+        const u32 i = k * kSortThreads + threadIdx.x;
+        if (i < cnt_tile) {
+            const u32 dg = s_dg[i];
+            out[s_base[dg] + (i - (u32)s_tpre[dg])] = s_buf[i];
+        }
+    }
+}
+
+// a chunk ordered by (hash, position): distance to the previous position with the same hash (0 = none in the
 // window), and the length of the chain search_dic would walk from it (how many earlier positions with this
 // hash lie within the window, at most 255): the match kernel groups positions of similar chain length.
 // The entries in front of a chunk's first position only serve as predecessors.
-__global__ __launch_bounds__(256) void k_df_prev(const u32 *__restrict__ ks, const u32 *__restrict__ vs, u64 nent,
+__global__ __launch_bounds__(256) void k_df_prev(const u8 *__restrict__ in, u64 ntri, const u32 *__restrict__ S,
                                                  u32 *__restrict__ pe)
 {
     // the 255 entries in front of the workgroup's 256 and its own, staged once: the search runs in LDS
     __shared__ u32 s_k[256 + 256];
     __shared__ u32 s_v[256 + 256];
     // workgroups are dealt round-robin to the 8 XCDs: the r-th workgroup of XCD x takes the r-th slice of the
-    // x-th, (x+8)-th, ... group of kPrevSpan slices, so that the 3 MB a chunk scatters into stay in one L2
-    u64 slice = blockIdx.x;
+    // x-th, (x+8)-th, ... chunk, so that the 4 MB a chunk scatters into stay in one L2
+    u32 slice = blockIdx.x;
     {
-        const u64 x = blockIdx.x & 7u, r = blockIdx.x >> 3;
-        const u64 cand = ((r / kPrevSpan) * 8 + x) * kPrevSpan + (r % kPrevSpan);
-        const u64 nslices = (nent + 255) / 256, full = nslices / (8 * kPrevSpan) * (8 * kPrevSpan);
+        const u32 x = blockIdx.x & 7u, r = blockIdx.x >> 3;
+        const u32 cand = ((r / kPrevSpan) * 8 + x) * kPrevSpan + (r % kPrevSpan);
+        const u32 full = gridDim.x / (8 * kPrevSpan) * (8 * kPrevSpan);
         if (blockIdx.x < full) slice = cand; // the ragged tail keeps the plain order
     }
-    const u64 i0 = slice * 256;
+    const u32 c = slice / kPrevSpan, i0 = (slice % kPrevSpan) * 256;
+    u32 j0;
+    const u32 count = df_chunk_count(c, ntri, j0);
+    if (i0 >= count) return;
+    const u32 *Sc = S + (size_t)c * kChunkStride;
     for (u32 j = threadIdx.x; j < 512; j += 256) {
         const i64 g = (i64)i0 - 256 + (i64)j;
-        const bool ok = g >= 0 && (u64)g < nent;
-        s_k[j] = ok ? __builtin_nontemporal_load(ks + g) : 0xFFFFFFFFu; // streamed: must not evict the scatter lines
-        s_v[j] = ok ? __builtin_nontemporal_load(vs + g) : 0u;
+        const bool ok = g >= 0 && (u64)g < count;
+        const u32 v = ok ? __builtin_nontemporal_load(Sc + g) : 0u; // streamed: must not evict the scatter lines
+        s_v[j] = v;
+        s_k[j] = ok ? df_hash_at(in, v, ntri) : 0xFFFFFFFFu;
     }
     __syncthreads();
-    const u64 i = i0 + threadIdx.x;
-    if (i >= nent) return;
+    const u32 i = i0 + threadIdx.x;
+    if (i >= count) return;
     const u32 li = 256 + threadIdx.x;
     const u32 p = s_v[li];
     const u32 h = s_k[li];
-    if ((u64)p < (u64)(h >> 16) * kChunk) return; // history entry of this chunk: written by the chunk that owns it
+    if ((u64)p < (u64)c * kChunk) return; // history entry of this chunk: written by the chunk that owns it
     u32 d = 0;
     if (s_k[li - 1] == h) {
         const u32 dd = p - s_v[li - 1];
         if (dd <= kWin) d = dd;
     }
     u32 e = 0;
-    if (d) { // smallest j in [i - 255, i) with the same key and vs[j] + window >= p (monotone in j)
-        u32 lo = li - kChain, hi = li - 1; // hi qualifies; entries before the array start carry key ~0
+    if (d) { // smallest j in [i - 255, i) with the same hash and S[j] + window >= p (monotone in j)
+        u32 lo = li - kChain, hi = li - 1; // hi qualifies; entries before the chunk start carry key ~0
         while (lo < hi) {
             const u32 mid = (lo + hi) >> 1;
             if (s_k[mid] == h && s_v[mid] + kWin >= p) hi = mid; else lo = mid + 1;
@@ -992,75 +1142,27 @@ __global__ __launch_bounds__(256) void k_df_sums(const u8 *__restrict__ in, u64 
 // ---------------------------------------------------------------------------------- launchers
 #define DFCHK(x) do { if ((x) != hipSuccess) return -1; } while (0)
 
-u64 df_entries(u64 n)
+u32 df_chunks(u64 n)
 {
     const u64 ntri = n >= 3 ? n - 2 : 0;
-    if (ntri <= kChunk) return ntri;
-    const u64 nchunks = (ntri + kChunk - 1) / kChunk;
-    return ntri + (nchunks - 1) * kWin;
+    return ntri ? (u32)((ntri + kChunk - 1) / kChunk) : 0u;
 }
 
-static u32 df_key_bits(u64 n)
+// v0, s: df_chunks(n) * kChunkStride words each; hist: df_chunks(n) * kChunkTiles * 256 words; tbase: df_chunks(n) * 256
+int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *v0, u32 *s, u32 *hist, u32 *tbase, u32 *pe)
 {
     const u64 ntri = n >= 3 ? n - 2 : 0;
-    const u64 nchunks = ntri ? (ntri + kChunk - 1) / kChunk : 1;
-    u32 b = 16;
-    while ((1ull << (b - 16)) < nchunks) ++b;
-    return b;
-}
-
-static u32 df_chunks(u64 n)
-{
-    const u64 ntri = n >= 3 ? n - 2 : 0;
-    return ntri ? (u32)((ntri + kChunk - 1) / kChunk) : 1u;
-}
-
-static bool df_segmented() // DF_SEGSORT=0: one global sort on (chunk << 16 | hash) instead of one segment per chunk
-{
-    static const bool on = !(getenv("DF_SEGSORT") && getenv("DF_SEGSORT")[0] == '0');
-    return on;
-}
-
-int df_sort_temp_bytes(u64 n, size_t *bytes)
-{
-    size_t t = 0, t2 = 0;
-    u32 *k = nullptr;
-    u32 *v = nullptr;
-    if (rocprim::radix_sort_pairs(nullptr, t, k, k, v, v, (size_t)df_entries(n), 0, df_key_bits(n), (hipStream_t) nullptr) !=
-        hipSuccess)
-        return -1;
-    if (rocprim::segmented_radix_sort_pairs(nullptr, t2, k, k, v, v, (unsigned int)df_entries(n), df_chunks(n), v, v + 1, 0, 16,
-                                            (hipStream_t) nullptr) != hipSuccess)
-        return -1;
-    *bytes = t > t2 ? t : t2;
-    return 0;
-}
-
-// seg_off: df_chunks(n) + 1 words of device memory (segment boundaries of the chunk-wise sort)
-int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *keys_in, u32 *keys_out, u32 *vals_in, u32 *vals_out,
-                     void *tmp, size_t tmp_bytes, u32 *pe, u32 *seg_off)
-{
-    const u64 ntri = n >= 3 ? n - 2 : 0;
-    const u64 nent = df_entries(n);
     DFCHK(hipMemsetAsync(pe, 0, (n + 8) * sizeof(u32), st));
     if (!ntri) return 0;
-    hipLaunchKernelGGL(k_df_keys, dim3((u32)((nent + 255) / 256)), dim3(256), 0, st, in, ntri, nent, keys_in, vals_in);
     const u32 nchunks = df_chunks(n);
-    if (df_segmented() && nchunks > 1) {
-        // every chunk (with its 32 KiB of history in front) is one segment: 16 key bits instead of 16 + log2(chunks)
-        std::vector<u32> off(nchunks + 1);
-        for (u32 c = 0; c <= nchunks; ++c) {
-            const u64 o = c == 0 ? 0 : (u64)c * kChunk + (u64)(c - 1) * kWin;
-            off[c] = (u32)(o < nent ? o : nent);
-        }
-        DFCHK(hipMemcpyAsync(seg_off, off.data(), (nchunks + 1) * sizeof(u32), hipMemcpyHostToDevice, st));
-        DFCHK(hipStreamSynchronize(st)); // (the host vector goes away)
-        DFCHK(rocprim::segmented_radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (unsigned int)nent, nchunks,
-                                                  seg_off, seg_off + 1, 0, 16, st));
-    } else {
-        DFCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)nent, 0, df_key_bits(n), st));
-    }
-    hipLaunchKernelGGL(k_df_prev, dim3((u32)((nent + 255) / 256)), dim3(256), 0, st, keys_out, vals_out, nent, pe);
+    const dim3 tiles(nchunks * kChunkTiles);
+    hipLaunchKernelGGL((k_df_shist<0>), tiles, dim3(kSortThreads), 0, st, in, ntri, (const u32 *)nullptr, hist);
+    hipLaunchKernelGGL(k_df_sscan, dim3(nchunks), dim3(256), 0, st, hist, tbase);
+    hipLaunchKernelGGL((k_df_sscatter<0>), tiles, dim3(kSortThreads), 0, st, in, ntri, (const u32 *)nullptr, hist, tbase, v0);
+    hipLaunchKernelGGL((k_df_shist<1>), tiles, dim3(kSortThreads), 0, st, in, ntri, v0, hist);
+    hipLaunchKernelGGL(k_df_sscan, dim3(nchunks), dim3(256), 0, st, hist, tbase);
+    hipLaunchKernelGGL((k_df_sscatter<1>), tiles, dim3(kSortThreads), 0, st, in, ntri, v0, hist, tbase, s);
+    hipLaunchKernelGGL(k_df_prev, dim3(nchunks * kPrevSpan), dim3(256), 0, st, in, ntri, s, pe);
     return 0;
 }
 
