@@ -102,7 +102,8 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     if ((rc = w->vals_in.ensure((nsort > npad ? nsort : npad) * 4)) != BZ_OK) return rc;  // pass 0 output, later M[]
     if ((rc = w->vals_out.ensure((nsort > npad ? nsort : npad) * 4)) != BZ_OK) return rc; // sorted positions, later code[]
     if ((rc = w->sort_tmp.ensure((nchunks * kChunkTiles + 1) * 256 * 4)) != BZ_OK) return rc; // per-tile digit counts
-    if ((rc = w->keys_out.ensure((nchunks + 1) * 256 * 4)) != BZ_OK) return rc;           // per-chunk digit bases
+    if ((rc = w->keys_out.ensure(2 * (nchunks + 1) * 256 * 4)) != BZ_OK) return rc;       // per-chunk digit bases, both passes
+    if ((rc = w->est.ensure(nsort * 2)) != BZ_OK) return rc;                              // hashes of the sorted positions
     if ((rc = w->prevd.ensure(npad * 4)) != BZ_OK) return rc; // per position: chain distance | chain length << 16
     if (hist && (rc = w->concat.ensure(nall + 64)) != BZ_OK) return rc;
     if ((rc = w->tabs.ensure(tab_words * 2 + 64)) != BZ_OK) return rc;
@@ -146,7 +147,7 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
 
     HIPCHK(hipEventRecord(w->ev[0], st));
     HIPCHK(hipMemsetAsync(w->stream.p, 0, bound + 64, st));
-    if (df_launch_chains(st, d_all, nall, w->vals_in.as<u32>(), w->vals_out.as<u32>(), w->sort_tmp.as<u32>(), w->keys_out.as<u32>(),
+    if (df_launch_chains(st, d_all, nall, w->vals_in.as<u32>(), w->vals_out.as<u32>(), w->est.as<u16>(), w->sort_tmp.as<u32>(), w->keys_out.as<u32>(),
                          w->prevd.as<u32>()) != 0)
         return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[1], st));

@@ -132,11 +132,14 @@ __global__ __launch_bounds__(256) void k_df_sscan(u32 *__restrict__ hist, u32 *_
 template <int PASS>
 __global__ __launch_bounds__(kSortThreads) void k_df_sscatter(const u8 *__restrict__ in, u64 ntri, const u32 *__restrict__ src,
                                                               const u32 *__restrict__ hist, const u32 *__restrict__ tbase,
-                                                              u32 *__restrict__ dst)
+                                                              u32 *__restrict__ dst, const u32 *__restrict__ tbase0,
+                                                              u16 *__restrict__ hash_out)
 {
     constexpr u32 NW = kSortThreads / 64;
     __shared__ u32 s_buf[kSortTile];
     __shared__ u8 s_dg[kSortTile];
+    __shared__ u8 s_lo[PASS ? kSortTile : 4];
+    __shared__ u32 s_b0[PASS ? 256 : 4]; // PASS 1: where the low-byte buckets of pass 0 begin in this chunk
     __shared__ u32 s_base[256];
     __shared__ u16 s_tpre[256];
     __shared__ u16 s_cnt[NW][256];
@@ -148,6 +151,7 @@ __global__ __launch_bounds__(kSortThreads) void k_df_sscatter(const u8 *__restri
     if (start >= count) return;
     for (u32 i = threadIdx.x; i < NW * 256u / 2u; i += kSortThreads) reinterpret_cast<u32 *>(&s_cnt[0][0])[i] = 0;
     if (threadIdx.x < 256) s_base[threadIdx.x] = hist[(size_t)blockIdx.x * 256u + threadIdx.x] + tbase[(size_t)c * 256u + threadIdx.x];
+    if (PASS && threadIdx.x < 256) s_b0[threadIdx.x] = tbase0[(size_t)c * 256u + threadIdx.x];
     __syncthreads();
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
     const u64 lt_mask = (l == 0) ? 0ull : (~0ull >> (64 - l));
@@ -196,6 +200,15 @@ __global__ __launch_bounds__(kSortThreads) void k_df_sscatter(const u8 *__restri
             const u32 lpos = (u32)s_tpre[dgv[r]] + (u32)my_cnt[dgv[r]] + rnk[r];
             s_buf[lpos] = posv[r]; // digit order inside the tile, so that consecutive lanes store consecutive words
             s_dg[lpos] = (u8)dgv[r];
+            if (PASS) {
+                // the input of pass 1 is ordered by the low byte: the bucket an input index falls into IS that byte
+                const u32 idx = start + w * 1024u + r * 64u + l;
+                u32 lo = 0;
+#pragma unroll
+                for (u32 s = 128; s; s >>= 1)
+                    if (s_b0[lo + s] <= idx) lo += s;
+                s_lo[lpos] = (u8)lo;
+            }
         }
     }
     __syncthreads();
@@ -205,7 +218,9 @@ __global__ __launch_bounds__(kSortThreads) void k_df_sscatter(const u8 *__restri
         const u32 i = k * kSortThreads + threadIdx.x;
         if (i < cnt_tile) {
             const u32 dg = s_dg[i];
-            out[s_base[dg] + (i - (u32)s_tpre[dg])] = s_buf[i];
+            const u32 o = s_base[dg] + (i - (u32)s_tpre[dg]);
+            out[o] = s_buf[i];
+            if (PASS) hash_out[(size_t)c * kChunkStride + o] = (u16)((dg << 8) | s_lo[i]);
         }
     }
 }
@@ -214,7 +229,7 @@ __global__ __launch_bounds__(kSortThreads) void k_df_sscatter(const u8 *__restri
 // window), and the length of the chain search_dic would walk from it (how many earlier positions with this
 // hash lie within the window, at most 255): the match kernel groups positions of similar chain length.
 // The entries in front of a chunk's first position only serve as predecessors.
-__global__ __launch_bounds__(256) void k_df_prev(const u8 *__restrict__ in, u64 ntri, const u32 *__restrict__ S,
+__global__ __launch_bounds__(256) void k_df_prev(u64 ntri, const u32 *__restrict__ S, const u16 *__restrict__ H,
                                                  u32 *__restrict__ pe)
 {
     // the 255 entries in front of the workgroup's 256 and its own, staged once: the search runs in LDS
@@ -234,12 +249,12 @@ __global__ __launch_bounds__(256) void k_df_prev(const u8 *__restrict__ in, u64 
     const u32 count = df_chunk_count(c, ntri, j0);
     if (i0 >= count) return;
     const u32 *Sc = S + (size_t)c * kChunkStride;
+    const u16 *Hc = H + (size_t)c * kChunkStride;
     for (u32 j = threadIdx.x; j < 512; j += 256) {
         const i64 g = (i64)i0 - 256 + (i64)j;
         const bool ok = g >= 0 && (u64)g < count;
-        const u32 v = ok ? __builtin_nontemporal_load(Sc + g) : 0u; // streamed: must not evict the scatter lines
-        s_v[j] = v;
-        s_k[j] = ok ? df_hash_at(in, v, ntri) : 0xFFFFFFFFu;
+        s_v[j] = ok ? __builtin_nontemporal_load(Sc + g) : 0u; // streamed: must not evict the scatter lines
+        s_k[j] = ok ? (u32)__builtin_nontemporal_load(Hc + g) : 0xFFFFFFFFu;
     }
     __syncthreads();
     const u32 i = i0 + threadIdx.x;
@@ -1148,21 +1163,25 @@ u32 df_chunks(u64 n)
     return ntri ? (u32)((ntri + kChunk - 1) / kChunk) : 0u;
 }
 
-// v0, s: df_chunks(n) * kChunkStride words each; hist: df_chunks(n) * kChunkTiles * 256 words; tbase: df_chunks(n) * 256
-int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *v0, u32 *s, u32 *hist, u32 *tbase, u32 *pe)
+// v0, s: df_chunks(n) * kChunkStride words each, hs as many u16; hist: df_chunks(n) * kChunkTiles * 256 words;
+// tbase: 2 * df_chunks(n) * 256 words (the digit bases of both passes)
+int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *v0, u32 *s, u16 *hs, u32 *hist, u32 *tbase, u32 *pe)
 {
     const u64 ntri = n >= 3 ? n - 2 : 0;
-    DFCHK(hipMemsetAsync(pe, 0, (n + 8) * sizeof(u32), st));
+    // every trigram position is written by the chunk that owns it; the last two positions have no trigram
+    DFCHK(hipMemsetAsync(pe + ntri, 0, (n - ntri + 8) * sizeof(u32), st));
     if (!ntri) return 0;
     const u32 nchunks = df_chunks(n);
     const dim3 tiles(nchunks * kChunkTiles);
     hipLaunchKernelGGL((k_df_shist<0>), tiles, dim3(kSortThreads), 0, st, in, ntri, (const u32 *)nullptr, hist);
     hipLaunchKernelGGL(k_df_sscan, dim3(nchunks), dim3(256), 0, st, hist, tbase);
-    hipLaunchKernelGGL((k_df_sscatter<0>), tiles, dim3(kSortThreads), 0, st, in, ntri, (const u32 *)nullptr, hist, tbase, v0);
+    u32 *tbase1 = tbase + (size_t)nchunks * 256;
+    hipLaunchKernelGGL((k_df_sscatter<0>), tiles, dim3(kSortThreads), 0, st, in, ntri, (const u32 *)nullptr, hist, tbase, v0,
+                       (const u32 *)nullptr, (u16 *)nullptr);
     hipLaunchKernelGGL((k_df_shist<1>), tiles, dim3(kSortThreads), 0, st, in, ntri, v0, hist);
-    hipLaunchKernelGGL(k_df_sscan, dim3(nchunks), dim3(256), 0, st, hist, tbase);
-    hipLaunchKernelGGL((k_df_sscatter<1>), tiles, dim3(kSortThreads), 0, st, in, ntri, v0, hist, tbase, s);
-    hipLaunchKernelGGL(k_df_prev, dim3(nchunks * kPrevSpan), dim3(256), 0, st, in, ntri, s, pe);
+    hipLaunchKernelGGL(k_df_sscan, dim3(nchunks), dim3(256), 0, st, hist, tbase1);
+    hipLaunchKernelGGL((k_df_sscatter<1>), tiles, dim3(kSortThreads), 0, st, in, ntri, v0, hist, tbase1, s, tbase, hs);
+    hipLaunchKernelGGL(k_df_prev, dim3(nchunks * kPrevSpan), dim3(256), 0, st, ntri, s, hs, pe);
     return 0;
 }
 
