@@ -17,7 +17,6 @@ using namespace dfgpu;
 struct DfWorkspace {
     DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, prevd, est, segoff, concat, bitmap, tabs, ents, bstart, nb, blocks, lens, hdr, lm, total,
         stream, asum, bsum, crc;
-    size_t sort_tmp_bytes = 0;
     double t_stage[6] = {0, 0, 0, 0, 0, 0}; // chains, matches, parse, blocks, emit, total
     u64 stats[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // blocks, stored, fixed, dynamic, limited tables, stream bytes, dynamic w/o distances
     hipEvent_t ev[7] = {};
