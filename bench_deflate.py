@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--kind", type=int, default=0)
     ap.add_argument("--cpu-sample-mib", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify-full", action="store_true", help="inflate the whole stream with zlib and compare (slow)")
     args = ap.parse_args()
     if args.gpus != 1:
         sys.exit("bench_deflate.py: the path does not shard inside a stream; run one replica per GPU")
@@ -92,6 +93,16 @@ def main():
         "deflate_stats": stats,
         "checks": {"head_inflates_to_input": bool(ok)},
     }
+    if args.verify_full:
+        do = zlib.decompressobj(-15 if args.kind == 0 else (15 if args.kind == 1 else 31))
+        zall = bytes(d_out[:zn].cpu().numpy())
+        host = bytes(d_in.cpu().numpy())
+        pos, okf = 0, True
+        for off in range(0, len(zall), 16 << 20):
+            piece = do.decompress(zall[off:off + (16 << 20)])
+            okf = okf and piece == host[pos:pos + len(piece)]
+            pos += len(piece)
+        result["checks"]["whole_stream_inflates_to_input"] = bool(okf and pos == n and do.eof)
     if not args.no_cpu_baseline:
         from oracle import oracle
         smp = min(args.cpu_sample_mib << 20, n)
