@@ -15,7 +15,10 @@ constexpr u32 kMaxMatch = 258;     // LZSS_MAX_MATCH :110
 constexpr u32 kMinMatch = 3;       // LZSS_MIN_MATCH :109
 constexpr u32 kChain = 255;        // MATCH_SEARCH_COUNT - 1 (lzss/slidedict.rs:129, 232)
 constexpr u32 kBlockMax = 0xFFFF;  // MAX_BLOCK_SIZE (deflate/encoder.rs:270)
-constexpr u32 kChunk = 1u << 20;    // positions per sort chunk (hash chains are built chunk by chunk)
+#ifndef DF_CHUNK_LOG2
+#define DF_CHUNK_LOG2 19
+#endif
+constexpr u32 kChunk = 1u << DF_CHUNK_LOG2; // positions per sort chunk (hash chains are built chunk by chunk)
 constexpr u32 kChunkStride = kChunk + kWin;          // entries of one sort chunk: its positions and the 32 KiB in front
 constexpr u32 kChunkTiles = kChunkStride / bzgpu::kSortTile; // 132 tiles of 8192 entries
 constexpr u32 kPrevSpan = kChunkStride / 256;         // 256-entry slices of one sort chunk
