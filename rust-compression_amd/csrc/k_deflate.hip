@@ -454,23 +454,27 @@ __global__ __launch_bounds__(256) void k_df_adv(const u32 *__restrict__ M, u64 n
     step[p] = (u16)((out_len + li) | (li << 9));
 }
 
-__global__ __launch_bounds__(256) void k_df_tile_tab(const u16 *__restrict__ step, u64 n, u16 *__restrict__ tab)
+#ifndef DF_TAB_THREADS
+#define DF_TAB_THREADS 512
+#endif
+constexpr u32 kTabThreads = DF_TAB_THREADS;
+__global__ __launch_bounds__(kTabThreads) void k_df_tile_tab(const u16 *__restrict__ step, u64 n, u16 *__restrict__ tab)
 {
     __shared__ u16 s_nx[kPTile];
     const u64 t0 = (u64)blockIdx.x * kPTile;
-    for (u32 k = threadIdx.x; k < kPTile; k += 256) {
+    for (u32 k = threadIdx.x; k < kPTile; k += kTabThreads) {
         const u64 p = t0 + k;
         s_nx[k] = (u16)(k + (p < n ? (step[p] & 511u) : 1u));
     }
     for (u32 r = 0; r < 12; ++r) {
         __syncthreads();
-        for (u32 k = threadIdx.x; k < kPTile; k += 256) {
+        for (u32 k = threadIdx.x; k < kPTile; k += kTabThreads) {
             const u32 v = s_nx[k];
             if (v < kPTile) s_nx[k] = s_nx[v]; // in place: a fresher value is only farther along the same path
         }
     }
     __syncthreads();
-    for (u32 e = threadIdx.x; e < kEntries; e += 256) tab[(u64)blockIdx.x * kEntries + e] = (u16)(s_nx[e] - kPTile);
+    for (u32 e = threadIdx.x; e < kEntries; e += kTabThreads) tab[(u64)blockIdx.x * kEntries + e] = (u16)(s_nx[e] - kPTile);
 }
 
 __global__ __launch_bounds__(320) void k_df_compose(const u16 *__restrict__ tin, u32 nin, u16 *__restrict__ tout)
@@ -499,7 +503,11 @@ __global__ __launch_bounds__(64) void k_df_resolve(const u16 *__restrict__ tab_c
 
 // marks the code starts of the steps that begin in this tile and writes code[] for every position those
 // steps cover (the ranges of consecutive tiles meet exactly)
-__global__ __launch_bounds__(256) void k_df_mark(const u16 *__restrict__ step, const u32 *__restrict__ M,
+#ifndef DF_MARK_THREADS
+#define DF_MARK_THREADS 512
+#endif
+constexpr u32 kMarkThreads = DF_MARK_THREADS;
+__global__ __launch_bounds__(kMarkThreads) void k_df_mark(const u16 *__restrict__ step, const u32 *__restrict__ M,
                                                  const u16 *__restrict__ ent, u64 n, u32 *__restrict__ code)
 {
     __shared__ u16 s_j[2][kPTile];
@@ -509,18 +517,18 @@ __global__ __launch_bounds__(256) void k_df_mark(const u16 *__restrict__ step, c
     const u32 tid = threadIdx.x;
     const u64 t0 = (u64)blockIdx.x * kPTile;
     const u32 entry = ent[blockIdx.x];
-    for (u32 k = tid; k < kPTile; k += 256) {
+    for (u32 k = tid; k < kPTile; k += kMarkThreads) {
         const u64 p = t0 + k;
         const u32 s = p < n ? step[p] : 1u;
         s_step[k] = (u16)s;
         s_j[0][k] = (u16)(k + (s & 511u));
         s_mark[k] = (k == entry) ? 1 : 0;
     }
-    for (u32 k = tid; k < kPTile + 264; k += 256) s_type[k] = 0;
+    for (u32 k = tid; k < kPTile + 264; k += kMarkThreads) s_type[k] = 0;
     for (u32 r = 0; r < 12; ++r) {
         __syncthreads();
         const u32 cur = r & 1u;
-        for (u32 k = tid; k < kPTile; k += 256) {
+        for (u32 k = tid; k < kPTile; k += kMarkThreads) {
             const u32 v = s_j[cur][k];
             if (s_mark[k] && v < kPTile) s_mark[v] = 1;
             s_j[cur ^ 1u][k] = (u16)(v < kPTile ? s_j[cur][v] : v);
@@ -529,7 +537,7 @@ __global__ __launch_bounds__(256) void k_df_mark(const u16 *__restrict__ step, c
     __syncthreads();
     // after 12 exact doublings every entry has left the tile: the exit of `entry`
     const u32 exitp = (entry < kPTile) ? (u32)s_j[0][entry] : entry;
-    for (u32 k = tid; k < kPTile; k += 256) {
+    for (u32 k = tid; k < kPTile; k += kMarkThreads) {
         if (!s_mark[k]) continue;
         const u32 s = s_step[k], adv = s & 511u, li = s >> 9;
         if (adv == 1) s_type[k] = 1;
@@ -539,7 +547,7 @@ __global__ __launch_bounds__(256) void k_df_mark(const u16 *__restrict__ step, c
         }
     }
     __syncthreads();
-    for (u32 k = entry + tid; k < exitp; k += 256) {
+    for (u32 k = entry + tid; k < exitp; k += kMarkThreads) {
         const u64 q = t0 + k;
         if (q >= n) break;
         const u32 ty = s_type[k];
@@ -1197,14 +1205,14 @@ int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *
 {
     if (!n) return 0;
     hipLaunchKernelGGL(k_df_adv, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, M, n, step);
-    hipLaunchKernelGGL(k_df_tile_tab, dim3(counts[0]), dim3(256), 0, st, step, n, tabs[0]);
+    hipLaunchKernelGGL(k_df_tile_tab, dim3(counts[0]), dim3(kTabThreads), 0, st, step, n, tabs[0]);
     for (u32 l = 1; l + 1 < nlevels; ++l)
         hipLaunchKernelGGL(k_df_compose, dim3(counts[l]), dim3(320), 0, st, tabs[l - 1], counts[l - 1], tabs[l]);
     DFCHK(hipMemsetAsync(ents[nlevels - 1], 0, sizeof(u16), st)); // the single top group is entered at 0
     for (u32 l = nlevels - 1; l >= 1; --l)
         hipLaunchKernelGGL(k_df_resolve, dim3((counts[l] + 63) / 64), dim3(64), 0, st, tabs[l - 1], counts[l - 1], ents[l],
                            counts[l], ents[l - 1]);
-    hipLaunchKernelGGL(k_df_mark, dim3(counts[0]), dim3(256), 0, st, step, M, ents[0], n, code);
+    hipLaunchKernelGGL(k_df_mark, dim3(counts[0]), dim3(kMarkThreads), 0, st, step, M, ents[0], n, code);
     return 0;
 }
 
