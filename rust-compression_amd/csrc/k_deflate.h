@@ -27,8 +27,14 @@ constexpr u32 kMThreads = 1024;
 constexpr u32 kPTile = 4096;       // positions per parse tile
 constexpr u32 kEntries = 260;      // a step advances by at most 258 + 2: entry offsets 0..259
 constexpr u32 kFan = 64;           // tiles composed per level
-constexpr u32 kBThreads = 256;
-constexpr u32 kEThreads = 512;
+#ifndef DF_BLOCK_THREADS
+#define DF_BLOCK_THREADS 128
+#endif
+constexpr u32 kBThreads = DF_BLOCK_THREADS;
+#ifndef DF_EMIT_THREADS
+#define DF_EMIT_THREADS 128
+#endif
+constexpr u32 kEThreads = DF_EMIT_THREADS;
 constexpr u32 kHdrWords = 160;     // bits of BFINAL + dynamic header: < 74 + 316 * 14
 constexpr u32 kDfLmTable = 3 * 288 + 64 + 2 * 15 * (2 * 288 + 4); // scratch words of one length-limited table
 constexpr u32 kDfLmWords = 2 * kDfLmTable;
