@@ -438,20 +438,44 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
 
 // ---------------------------------------------------------------------------------- parse
 // lzss/encoder.rs:132-184: step[p] = advance | lazy_index << 9 if a code sequence started at p
+__device__ __forceinline__ u32 df_step_word(u32 m0, u32 m1, u32 m2)
+{
+    u32 out_len = m0 & 511u, out_pos = m0 >> 9, li = 0;
+    if (out_len < kMinMatch) return 1u;
+    if (out_len < kMaxMatch) {
+        const u32 il = m1 & 511u, ip = m1 >> 9;
+        if (il > kMinMatch && (il << 3) + ip > (out_len << 3) + out_pos) { out_len = il; out_pos = ip; li = 1; }
+    }
+    if (out_len < kMaxMatch) {
+        const u32 il = m2 & 511u, ip = m2 >> 9;
+        if (il > kMinMatch && (il << 3) + ip > (out_len << 3) + out_pos) { out_len = il; out_pos = ip; li = 2; }
+    }
+    return (out_len + li) | (li << 9);
+}
+
+// four positions per thread: two aligned 16-byte loads of match words, one 8-byte store of step words
 __global__ __launch_bounds__(256) void k_df_adv(const u32 *__restrict__ M, u64 n, u16 *__restrict__ step)
 {
-    const u64 p = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (p >= n) return;
-    const u32 m0 = M[p];
-    u32 out_len = m0 & 511u, out_pos = m0 >> 9, li = 0;
-    if (out_len < kMinMatch) { step[p] = 1; return; }
-    for (u32 i = 1; i < 3; ++i) {
-        if (out_len >= kMaxMatch) break;
-        const u32 it = (p + i < n) ? M[p + i] : 0u;
-        const u32 il = it & 511u, ip = it >> 9;
-        if (il > kMinMatch && (il << 3) + ip > (out_len << 3) + out_pos) { out_len = il; out_pos = ip; li = i; }
-    }
-    step[p] = (u16)((out_len + li) | (li << 9));
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+    const u64 p0 = ((u64)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p0 >= n) return;
+    u32 m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool al = (reinterpret_cast<uintptr_t>(M) & 15u) == 0 && (reinterpret_cast<uintptr_t>(step) & 7u) == 0;
+    if (al && p0 + 8 <= n) {
+        const u32x4 a = *reinterpret_cast<const u32x4 *>(M + p0), b = *reinterpret_cast<const u32x4 *>(M + p0 + 4);
+        m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+    } else
+        for (u32 j = 0; j < 8 && p0 + j < n; ++j) m[j] = M[p0 + j]; // (a match word behind the end is "no match")
+    u32 s[4];
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) s[j] = df_step_word(m[j], m[j + 1], m[j + 2]);
+    if (al && p0 + 4 <= n) {
+        u32x2 o;
+        o.x = s[0] | (s[1] << 16); o.y = s[2] | (s[3] << 16);
+        *reinterpret_cast<u32x2 *>(step + p0) = o;
+    } else
+        for (u32 j = 0; j < 4 && p0 + j < n; ++j) step[p0 + j] = (u16)s[j];
 }
 
 #ifndef DF_TAB_THREADS
@@ -1204,7 +1228,7 @@ int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *
                     u32 nlevels, u32 *code)
 {
     if (!n) return 0;
-    hipLaunchKernelGGL(k_df_adv, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, M, n, step);
+    hipLaunchKernelGGL(k_df_adv, dim3((u32)((n + 1023) / 1024)), dim3(256), 0, st, M, n, step);
     hipLaunchKernelGGL(k_df_tile_tab, dim3(counts[0]), dim3(kTabThreads), 0, st, step, n, tabs[0]);
     for (u32 l = 1; l + 1 < nlevels; ++l)
         hipLaunchKernelGGL(k_df_compose, dim3(counts[l]), dim3(320), 0, st, tabs[l - 1], counts[l - 1], tabs[l]);
