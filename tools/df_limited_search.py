@@ -1,3 +1,5 @@
+"""Searches seeded inputs for Deflate blocks whose Huffman tree is deeper than its limit (the package-merge
+path of make_table), checking parity with the oracle on the way; prints the seeds that take it.  Run on a GPU box."""
 import sys, importlib, random
 sys.path.insert(0, "/root/repo")
 pkg = importlib.import_module("rust-compression_amd")
