@@ -178,3 +178,20 @@ def test_length_limited_tables(pkg, oracle, eng):
         assert got == oracle.deflate_encode(data)
         hits += eng.deflate_stats()["limited_tables"]
     assert hits >= 1
+
+
+@pytest.mark.parametrize("n", [524286, 524287, 524288, 524289, 524290, 524291, 557055, 557056, 557057, 1048575, 1048576,
+                               1048577, 1048578, 1081343, 1081344, 1081345])
+def test_sort_chunk_boundaries(pkg, oracle, eng, n):
+    """sizes around the 512 Ki-position sort chunks (and chunk + window): chains must run across the seams"""
+    rnd = random.Random(n)
+    words = [bytes(rnd.choice(b"abcdefghij") for _ in range(rnd.randint(1, 6))) for _ in range(60)]
+    d = b" ".join(rnd.choice(words) for _ in range(n // 3))[:n]
+    assert len(d) == n
+    check(pkg, oracle, eng, d)
+
+
+def test_empty_inputs_in_containers(pkg, oracle):
+    for kind, okind in ((pkg.DEFLATE, oracle.DEFLATE), (pkg.ZLIB, oracle.ZLIB), (pkg.GZIP, oracle.GZIP)):
+        assert pkg.deflate_compress(b"", kind) == oracle.deflate_encode(b"", okind)
+    assert pkg.deflate_compress(b"", pkg.ZLIB, dict_=b"abc") == oracle.deflate_encode(b"", oracle.ZLIB, b"abc")
