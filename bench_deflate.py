@@ -4,8 +4,10 @@ configs[4]; the contract benchmark of the north-star path is bench.py).
 
 A "step" is one pass of the path (hash chains -> matches -> parse -> blocks + Huffman tables ->
 emission) over the synthetic corpus, input and stream resident in HBM.  Prints ONE JSON line.
-Replicas only for N > 1: one 32 KiB window and one bit string run through the whole input, so the
-path does not shard inside a stream.
+N > 1 (python -m torch.distributed.run --nproc-per-node N ... bench_deflate.py --gpus N): replicas only --
+one 32 KiB window and one bit string run through a whole input, so the path does not shard inside a
+stream; every rank encodes its own GiB as its own stream, the only collective is the
+barrier / max of the timing.
 """
 import argparse
 import importlib
@@ -30,19 +32,30 @@ def main():
     ap.add_argument("--cpu-sample-mib", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-full", action="store_true", help="inflate the whole stream with zlib and compare (slow)")
+    ap.add_argument("--force-replicas", action="store_true", help="run the N > 1 code path with one rank")
     args = ap.parse_args()
-    if args.gpus != 1:
-        sys.exit("bench_deflate.py: the path does not shard inside a stream; run one replica per GPU")
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        sys.exit("bench_deflate.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(local_rank)
+    replicas = world > 1 or args.force_replicas
+    if replicas:  # one independent stream per GPU: no data-path collective, only the barrier of the timing
+        import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     pkg = importlib.import_module("rust-compression_amd")
     import corpus
 
     n = args.mib << 20
-    d_in = corpus.corpus_on_device(n, dev)
-    eng = pkg.GpuEngine(0, 1)
+    d_in = corpus.corpus_on_device(n * world, dev)[rank * n:(rank + 1) * n].clone() if world > 1 else corpus.corpus_on_device(n, dev)
+    eng = pkg.GpuEngine(local_rank, 1)
     cap = pkg.deflate_bound(n)
     d_out = torch.zeros(cap, dtype=torch.uint8, device=dev)
     state = {}
@@ -50,14 +63,24 @@ def main():
     def step():
         state["len"] = eng.deflate_encode_device(args.kind, d_in.data_ptr(), n, d_out.data_ptr(), cap)
 
+    def sync():
+        torch.cuda.synchronize()
+        if replicas:
+            dist.barrier()
+            torch.cuda.synchronize()
+
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
+    if replicas:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
     zn = state["len"]
     stages = eng.deflate_timings()
     stats = eng.deflate_stats()
@@ -79,11 +102,12 @@ def main():
             traffic = None
     result = {
         "metric": "Deflate encode MB/s (input bytes, HBM-resident in and out)",
-        "value": round(n * args.steps / dt / 1e6, 2), "unit": "MB/s", "n_gpus": 1, "steps": args.steps,
+        "value": round(n * world * args.steps / dt / 1e6, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32", "data": "synthetic",
         "config": {"workload": "%d MiB synthetic repeating-text corpus, Inflater (window 32 KiB, chains of 255, lazy 3), "
-                               "kind %d" % (args.mib, args.kind), "out_bytes": zn, "ratio": round(zn / n, 4)},
+                               "kind %d%s" % (args.mib, args.kind, ", one independent stream per GPU (replicas)" if replicas else ""),
+                   "out_bytes": zn, "ratio": round(zn / n, 4)},
         "roofline": {"bound": "hbm", "kernel": "k_df_match", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "launches": 1,
                      "avg_launch_ms": round(match_s * 1e3, 3), "algorithmic_bytes_per_launch": alg,
@@ -117,7 +141,15 @@ def main():
                                   "sample": "first %d MiB of the same corpus, oracle/deflate_oracle.c (C restatement of "
                                             "the reference algorithm, single thread like the reference)" % (smp >> 20)}
         result["checks"]["gpu_equals_oracle_on_cpu_sample"] = bool(bytes(d_s[:k].cpu().numpy()) == ref)
-    print(json.dumps(result))
+    if replicas:
+        okt = torch.tensor([1 if all(result["checks"].values()) else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        result["checks"]["every_replica_ok"] = bool(okt.item() == 1)
+    if rank == 0:
+        print(json.dumps(result))
+    if replicas:
+        dist.barrier()
+        dist.destroy_process_group()
     if not all(result["checks"].values()):
         sys.exit(3)
 
