@@ -121,7 +121,7 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     if (kind != 0) {
         if ((rc = w->asum.ensure((size_t)(npieces + 1) * 8)) != BZ_OK) return rc;
         if ((rc = w->bsum.ensure((size_t)(npieces + 1) * 8)) != BZ_OK) return rc;
-        if ((rc = w->crc.ensure((size_t)(npieces + 1) * 256 * 4)) != BZ_OK) return rc;
+        if ((rc = w->crc.ensure((size_t)(npieces + 1) * 4 + 256 * 4)) != BZ_OK) return rc; // per piece, + the last piece's sub-pieces
     }
 
     std::vector<u16 *> tabs(nlevels), ents(nlevels);
@@ -161,8 +161,12 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     if (df_launch_emit(st, d_in, code, w->bstart.as<u64>(), w->nb.as<u32>(), bcap, w->blocks.as<DfBlock>(), w->lens.as<u8>(),
                        w->hdr.as<u32>(), w->stream.as<u32>()) != 0)
         return BZ_E_UNEXPECTED;
-    if (kind != 0 && df_launch_sums(st, d_in, n, w->asum.as<u64>(), w->bsum.as<u64>(), w->crc.as<u32>()) != 0)
-        return BZ_E_UNEXPECTED;
+    if (kind != 0) {
+        DfCrcShifts xk;
+        for (u32 k = 0; k < 8; ++k) xk.x[k] = gf_xpow8_reflected(256ull << k);
+        if (df_launch_sums(st, d_in, n, w->asum.as<u64>(), w->bsum.as<u64>(), w->crc.as<u32>(), w->crc.as<u32>() + npieces + 1, xk) != 0)
+            return BZ_E_UNEXPECTED;
+    }
     HIPCHK(hipEventRecord(w->ev[5], st));
     u64 total_bits = 0;
     u32 nb = 0;
@@ -192,11 +196,11 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     }
     if (kind != 0) {
         std::vector<u64> a(npieces), b(npieces);
-        std::vector<u32> c((size_t)npieces * 256);
+        std::vector<u32> c((size_t)npieces + 1 + 256);
         if (npieces) {
             HIPCHK(hipMemcpy(a.data(), w->asum.p, (size_t)npieces * 8, hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(b.data(), w->bsum.p, (size_t)npieces * 8, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(c.data(), w->crc.p, (size_t)npieces * 256 * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(c.data(), w->crc.p, ((size_t)npieces + 1 + 256) * 4, hipMemcpyDeviceToHost));
         }
         if (kind == 1) { // adler32.rs:20-66
             u64 A = 1, B = 0;
@@ -208,14 +212,16 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
             const u32 h = (u32)((B << 16) | A);
             tail[0] = (u8)(h >> 24); tail[1] = (u8)(h >> 16); tail[2] = (u8)(h >> 8); tail[3] = (u8)h; ntail = 4;
         } else { // CRC-32 (reflected), little endian, then ISIZE
-            const u32 x256 = gf_xpow8_reflected(256);
+            const u32 xpiece = gf_xpow8_reflected(kSumPiece);
             u32 raw = 0; // register for a zero initial value over the whole input
             for (u32 t = 0; t < npieces; ++t) {
                 const u64 len = (t + 1 == npieces) ? n - (u64)t * kSumPiece : kSumPiece;
-                for (u32 s = 0; (u64)s * 256 < len; ++s) {
-                    const u64 sl = (len - (u64)s * 256) < 256 ? (len - (u64)s * 256) : 256;
-                    raw = gf_mul_reflected(raw, sl == 256 ? x256 : gf_xpow8_reflected(sl)) ^ c[(size_t)t * 256 + s];
-                }
+                if (len == kSumPiece) raw = gf_mul_reflected(raw, xpiece) ^ c[t]; // folded on the device
+                else
+                    for (u32 s = 0; (u64)s * 256 < len; ++s) { // the last, partial piece: its sub-pieces
+                        const u64 sl = (len - (u64)s * 256) < 256 ? (len - (u64)s * 256) : 256;
+                        raw = gf_mul_reflected(raw, gf_xpow8_reflected(sl)) ^ c[(size_t)npieces + 1 + s];
+                    }
             }
             const u32 crc = raw ^ gf_mul_reflected(0xFFFFFFFFu, gf_xpow8_reflected(n)) ^ 0xFFFFFFFFu;
             const u32 isz = (u32)n;

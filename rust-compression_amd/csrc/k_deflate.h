@@ -60,5 +60,6 @@ int df_launch_blocks(hipStream_t st, const u8 *in, const u32 *code, u64 n, u64 *
                      DfBlock *blocks, u8 *lens, u32 *hdr, u32 *lm_scratch, u64 *total_bits);
 int df_launch_emit(hipStream_t st, const u8 *in, const u32 *code, const u64 *bstart, const u32 *nb, u32 cap,
                    const DfBlock *blocks, const u8 *lens, const u32 *hdr, u32 *out);
-int df_launch_sums(hipStream_t st, const u8 *in, u64 n, u64 *asum, u64 *bsum, u32 *crc);
+struct DfCrcShifts { u32 x[8]; }; // x^(8 * 256 * 2^k) mod P, reflected: moves a CRC register over 256 * 2^k bytes
+int df_launch_sums(hipStream_t st, const u8 *in, u64 n, u64 *asum, u64 *bsum, u32 *crc, u32 *last_sub, DfCrcShifts xk);
 } // namespace dfgpu

@@ -1150,11 +1150,13 @@ __global__ __launch_bounds__(kEThreads) void k_df_emit(const u8 *__restrict__ in
 // per 64 KiB piece: sum of bytes and sum of (len - i) * byte (Adler-32, adler32.rs:20-66), and the
 // reflected CRC-32 of the piece with a zero register (crc32.rs:40-55, 74-78); the host combines
 __global__ __launch_bounds__(256) void k_df_sums(const u8 *__restrict__ in, u64 n, u64 *__restrict__ asum,
-                                                 u64 *__restrict__ bsum, u32 *__restrict__ crc)
+                                                 u64 *__restrict__ bsum, u32 *__restrict__ crc, u32 *__restrict__ last_sub,
+                                                 DfCrcShifts xk)
 {
     __shared__ u32 s_tab[256];
     __shared__ u64 s_a[256], s_b[256];
     __shared__ u32 s_c[256];
+    __shared__ u32 s_piece[kSumPiece / 4 + 256];
     const u32 tid = threadIdx.x;
     {
         u32 c = tid;
@@ -1164,15 +1166,33 @@ __global__ __launch_bounds__(256) void k_df_sums(const u8 *__restrict__ in, u64 
     __syncthreads();
     const u64 p0 = (u64)blockIdx.x * kSumPiece;
     const u64 plen = (n - p0) < (u64)kSumPiece ? (n - p0) : (u64)kSumPiece;
+    // the piece is staged with coalesced loads; a thread's 256 bytes are 64 words apart from its neighbour's, plus
+    // one word per thread so that the threads of a wave read different banks
+    for (u32 w = tid; w < kSumPiece / 4; w += 256) {
+        const u64 g = p0 + 4ull * w;
+        u32 v = 0;
+        if ((reinterpret_cast<uintptr_t>(in) & 3u) == 0 && g + 4 <= n) v = *reinterpret_cast<const u32 *>(in + g);
+        else
+            for (u32 b = 0; b < 4 && g + b < n; ++b) v |= (u32)in[g + b] << (8 * b);
+        s_piece[w + (w >> 6)] = v;
+    }
+    __syncthreads();
     // thread t: bytes [t*256, t*256+256) of the piece
     const u64 s0 = (u64)tid * 256;
     u64 a = 0, b = 0;
     u32 c = 0;
-    for (u64 i = s0; i < s0 + 256 && i < plen; ++i) {
-        const u32 d = in[p0 + i];
-        a += d;
-        b += (plen - i) * d;
-        c = s_tab[(c ^ d) & 0xFFu] ^ (c >> 8);
+    for (u32 wq = 0; wq < 64; ++wq) {
+        const u32 v = s_piece[tid * 65 + wq];
+#pragma unroll
+        for (u32 k = 0; k < 4; ++k) {
+            const u64 i = s0 + wq * 4 + k;
+            if (i < plen) {
+                const u32 d = (v >> (8 * k)) & 0xFFu;
+                a += d;
+                b += (plen - i) * d;
+                c = s_tab[(c ^ d) & 0xFFu] ^ (c >> 8);
+            }
+        }
     }
     s_a[tid] = a; s_b[tid] = b; s_c[tid] = c;
     __syncthreads();
@@ -1182,8 +1202,24 @@ __global__ __launch_bounds__(256) void k_df_sums(const u8 *__restrict__ in, u64 
         asum[blockIdx.x] = sa;
         bsum[blockIdx.x] = sb;
     }
-    // sub-piece CRCs go out as they are; the host folds 256 of them per piece
-    crc[(u64)blockIdx.x * 256 + tid] = s_c[tid];
+    // a full piece folds its 256 sub-piece registers here: crc(A || B) = crc(A) * x^(8 |B|) ^ crc(B) for registers
+    // that start at zero, eight levels with x^(8 * 256 * 2^level) from the host.  The last, partial piece hands
+    // its sub-piece registers to the host (their lengths differ).
+    if (plen == kSumPiece) {
+        for (u32 lv = 0; lv < 8; ++lv) {
+            const u32 stride = 1u << lv;
+            if ((tid & (2 * stride - 1)) == 0) {
+                u32 a0 = s_c[tid], bb = xk.x[lv], pr = 0; // a0 * bb in GF(2)[x] / P, reflected (bit 31 = x^0)
+                for (u32 m = 1u << 31; m != 0 && a0 != 0; m >>= 1) {
+                    if (a0 & m) { pr ^= bb; a0 &= ~m; }
+                    bb = (bb & 1u) ? (bb >> 1) ^ 0xEDB88320u : bb >> 1;
+                }
+                s_c[tid] = pr ^ s_c[tid + stride];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) crc[blockIdx.x] = s_c[0];
+    } else last_sub[tid] = s_c[tid];
 }
 
 // ---------------------------------------------------------------------------------- launchers
@@ -1258,10 +1294,10 @@ int df_launch_emit(hipStream_t st, const u8 *in, const u32 *code, const u64 *bst
     return 0;
 }
 
-int df_launch_sums(hipStream_t st, const u8 *in, u64 n, u64 *asum, u64 *bsum, u32 *crc)
+int df_launch_sums(hipStream_t st, const u8 *in, u64 n, u64 *asum, u64 *bsum, u32 *crc, u32 *last_sub, DfCrcShifts xk)
 {
     if (!n) return 0;
-    hipLaunchKernelGGL(k_df_sums, dim3((u32)((n + kSumPiece - 1) / kSumPiece)), dim3(256), 0, st, in, n, asum, bsum, crc);
+    hipLaunchKernelGGL(k_df_sums, dim3((u32)((n + kSumPiece - 1) / kSumPiece)), dim3(256), 0, st, in, n, asum, bsum, crc, last_sub, xk);
     return 0;
 }
 
