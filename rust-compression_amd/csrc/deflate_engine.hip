@@ -152,7 +152,7 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     HIPCHK(hipEventRecord(w->ev[1], st));
     if (df_launch_match(st, d_all, w->prevd.as<u32>(), nall, Mall) != 0) return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[2], st));
-    if (df_launch_parse(st, M, n, step, tabs.data(), ents.data(), counts.data(), nlevels, code) != 0) return BZ_E_UNEXPECTED;
+    if (df_launch_parse(st, M, n, step, tabs.data(), ents.data(), counts.data(), nlevels, code, w->bitmap.as<u64>()) != 0) return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[3], st));
     if (df_launch_blocks(st, d_in, code, n, w->bitmap.as<u64>(), w->bstart.as<u64>(), w->nb.as<u32>(), bcap, w->blocks.as<DfBlock>(),
                          w->lens.as<u8>(), w->hdr.as<u32>(), w->lm.as<u32>(), w->total.as<u64>()) != 0)

@@ -55,7 +55,7 @@ u32 df_chunks(u64 n); // sort chunks of an input of n bytes
 int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *v0, u32 *s, u16 *hs, u32 *hist, u32 *tbase, u32 *pe);
 int df_launch_match(hipStream_t st, const u8 *in, const u32 *pe, u64 n, u32 *M);
 int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *tabs, u16 *const *ents, const u32 *counts,
-                    u32 nlevels, u32 *code);
+                    u32 nlevels, u32 *code, u64 *bm);
 int df_launch_blocks(hipStream_t st, const u8 *in, const u32 *code, u64 n, u64 *bm, u64 *bstart, u32 *nb, u32 cap,
                      DfBlock *blocks, u8 *lens, u32 *hdr, u32 *lm_scratch, u64 *total_bits);
 int df_launch_emit(hipStream_t st, const u8 *in, const u32 *code, const u64 *bstart, const u32 *nb, u32 cap,

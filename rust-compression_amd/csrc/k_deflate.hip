@@ -532,7 +532,8 @@ __global__ __launch_bounds__(64) void k_df_resolve(const u16 *__restrict__ tab_c
 #endif
 constexpr u32 kMarkThreads = DF_MARK_THREADS;
 __global__ __launch_bounds__(kMarkThreads) void k_df_mark(const u16 *__restrict__ step, const u32 *__restrict__ M,
-                                                 const u16 *__restrict__ ent, u64 n, u32 *__restrict__ code)
+                                                 const u16 *__restrict__ ent, u64 n, u32 *__restrict__ code,
+                                                 u64 *__restrict__ bm)
 {
     __shared__ u16 s_j[2][kPTile];
     __shared__ u16 s_step[kPTile];
@@ -571,26 +572,20 @@ __global__ __launch_bounds__(kMarkThreads) void k_df_mark(const u16 *__restrict_
         }
     }
     __syncthreads();
-    for (u32 k = entry + tid; k < exitp; k += kMarkThreads) {
+    // code words, and one bit per position for the block cuts (the 64 positions of a wave straddle two words)
+    for (u32 k0 = entry + (tid & ~63u); k0 < exitp; k0 += kMarkThreads) {
+        const u32 k = k0 + (tid & 63u);
         const u64 q = t0 + k;
-        if (q >= n) break;
-        const u32 ty = s_type[k];
-        code[q] = ty == 0 ? 0u : (ty == 1 ? F_CODE : (F_CODE | F_REF | M[q]));
-    }
-}
-
-// one bit per position: an LZSS code starts here
-__global__ __launch_bounds__(256) void k_df_bitmap(const u32 *__restrict__ code, u64 n, u64 *__restrict__ bm, u64 nwords)
-{
-    const u64 wv = ((u64)blockIdx.x * 256 + threadIdx.x) >> 6; // wave index: 16 words each
-    const u32 lane = threadIdx.x & 63u;
-    for (u32 j = 0; j < 16; ++j) {
-        const u64 word = wv * 16 + j;
-        if (word >= nwords) break;
-        const u64 q = word * 64 + lane;
-        const bool f = q < n && (code[q] & F_CODE);
-        const u64 m = __ballot(f);
-        if (lane == 0) bm[word] = m;
+        const bool ok = k < exitp && q < n;
+        const u32 ty = ok ? s_type[k] : 0u;
+        if (ok) code[q] = ty == 0 ? 0u : (ty == 1 ? F_CODE : (F_CODE | F_REF | M[q]));
+        const u64 bal = __ballot(ty != 0);
+        if ((tid & 63u) == 0 && bal) {
+            const u64 q0 = t0 + k0;
+            const u32 sh = (u32)(q0 & 63u);
+            atomicOr(reinterpret_cast<unsigned long long *>(bm + (q0 >> 6)), (unsigned long long)(bal << sh));
+            if (sh && (bal >> (64 - sh))) atomicOr(reinterpret_cast<unsigned long long *>(bm + (q0 >> 6) + 1), (unsigned long long)(bal >> (64 - sh)));
+        }
     }
 }
 
@@ -1014,6 +1009,7 @@ __global__ __launch_bounds__(256) void k_df_offsets(DfBlock *__restrict__ blocks
 {
     __shared__ u64 s_bits[1024]; // bits, or ~bytes for a stored block
     __shared__ u64 s_off[1024];
+    __shared__ u64 s_wv[4];
     __shared__ u64 s_run;
     const u32 nb = *nb_p;
     if (nb == 0xFFFFFFFFu) return;
@@ -1025,7 +1021,27 @@ __global__ __launch_bounds__(256) void k_df_offsets(DfBlock *__restrict__ blocks
             s_bits[j] = b.btype == 0 ? ~(u64)b.bytes : b.bits;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        // a batch without a stored block is a plain prefix sum (stored blocks are padded to a byte: serial)
+        bool stored = false;
+        for (u32 j = threadIdx.x; j < 1024 && k0 + j < nb; j += 256) stored = stored || (i64)s_bits[j] < 0;
+        if (!__syncthreads_or(stored)) {
+            const u32 j0 = threadIdx.x * 4;
+            u64 v[4], sum = 0;
+            for (u32 j = 0; j < 4; ++j) { v[j] = (k0 + j0 + j < nb) ? s_bits[j0 + j] : 0ull; sum += v[j]; }
+            u64 inc = sum;
+            for (u32 dlt = 1; dlt < 64; dlt <<= 1) {
+                const u64 o = __shfl_up(inc, dlt);
+                if ((threadIdx.x & 63u) >= dlt) inc += o;
+            }
+            if ((threadIdx.x & 63u) == 63u) s_wv[threadIdx.x >> 6] = inc;
+            __syncthreads();
+            u64 carry = s_run;
+            for (u32 w = 0; w < (threadIdx.x >> 6); ++w) carry += s_wv[w];
+            u64 off = carry + inc - sum;
+            for (u32 j = 0; j < 4; ++j) { s_off[j0 + j] = off; off += v[j]; }
+            __syncthreads();
+            if (threadIdx.x == 255) s_run = off;
+        } else if (threadIdx.x == 0) {
             u64 off = s_run;
             for (u32 j = 0; j < 1024 && k0 + j < nb; ++j) {
                 s_off[j] = off;
@@ -1261,9 +1277,10 @@ int df_launch_match(hipStream_t st, const u8 *in, const u32 *pe, u64 n, u32 *M)
 }
 
 int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *tabs, u16 *const *ents, const u32 *counts,
-                    u32 nlevels, u32 *code)
+                    u32 nlevels, u32 *code, u64 *bm)
 {
     if (!n) return 0;
+    DFCHK(hipMemsetAsync(bm, 0, ((n + 63) / 64 + 2) * sizeof(u64), st));
     hipLaunchKernelGGL(k_df_adv, dim3((u32)((n + 1023) / 1024)), dim3(256), 0, st, M, n, step);
     hipLaunchKernelGGL(k_df_tile_tab, dim3(counts[0]), dim3(kTabThreads), 0, st, step, n, tabs[0]);
     for (u32 l = 1; l + 1 < nlevels; ++l)
@@ -1272,15 +1289,13 @@ int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *
     for (u32 l = nlevels - 1; l >= 1; --l)
         hipLaunchKernelGGL(k_df_resolve, dim3((counts[l] + 63) / 64), dim3(64), 0, st, tabs[l - 1], counts[l - 1], ents[l],
                            counts[l], ents[l - 1]);
-    hipLaunchKernelGGL(k_df_mark, dim3(counts[0]), dim3(kMarkThreads), 0, st, step, M, ents[0], n, code);
+    hipLaunchKernelGGL(k_df_mark, dim3(counts[0]), dim3(kMarkThreads), 0, st, step, M, ents[0], n, code, bm);
     return 0;
 }
 
 int df_launch_blocks(hipStream_t st, const u8 *in, const u32 *code, u64 n, u64 *bm, u64 *bstart, u32 *nb, u32 cap,
                      DfBlock *blocks, u8 *lens, u32 *hdr, u32 *lm_scratch, u64 *total_bits)
 {
-    const u64 nwords = (n + 63) / 64;
-    if (nwords) hipLaunchKernelGGL(k_df_bitmap, dim3((u32)((nwords + 63) / 64)), dim3(256), 0, st, code, n, bm, nwords);
     hipLaunchKernelGGL(k_df_cuts, dim3(1), dim3(256), 0, st, bm, n, bstart, nb, cap);
     hipLaunchKernelGGL(k_df_block, dim3(cap), dim3(kBThreads), 0, st, in, code, bstart, nb, blocks, lens, hdr, lm_scratch);
     hipLaunchKernelGGL(k_df_offsets, dim3(1), dim3(256), 0, st, blocks, nb, total_bits);
