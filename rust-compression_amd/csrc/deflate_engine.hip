@@ -3,8 +3,8 @@
 //
 // Replaces, behind the reference's Encoder surface: Inflater (deflate/encoder.rs:92-260), ZlibEncoder
 // (zlib/encoder.rs:55-157), GZipEncoder (gzip/encoder.rs:50-135) driven with Action::Finish (and
-// Action::Run in front of it).  Action::Flush in the middle of a stream and preset dictionaries are
-// not offered on this path yet and are refused with BZ_E_PARAM, never approximated.
+// Action::Run in front of it), with or without a preset dictionary (::with_dict).  Action::Flush in the
+// middle of a stream is not offered on this path and is refused with BZ_E_PARAM, never approximated.
 #include <cstring>
 #include <string>
 #include <vector>
@@ -72,8 +72,8 @@ static u32 gf_xpow8_reflected(u64 nbytes) // x^(8 * nbytes) mod P
 static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, const u8 *dict, size_t dict_len, u8 *d_out,
                           size_t cap, size_t *out_len)
 {
-    if (n >= (1ull << 31) - kWin) return BZ_E_PARAM;
-    if (dict_len && kind == 2) return BZ_E_PARAM; // GZipEncoder has no with_dict // positions and bit offsets are sized for < 2 GiB per call
+    if (n >= (1ull << 31) - kWin) return BZ_E_PARAM; // positions and bit offsets are sized for < 2 GiB per call
+    if (dict_len && kind == 2) return BZ_E_PARAM;    // GZipEncoder has no with_dict
     HIPCHK(hipSetDevice(g->device));
     if (!g->df) g->df = new DfWorkspace();
     DfWorkspace *w = g->df;
