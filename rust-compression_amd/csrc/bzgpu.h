@@ -46,8 +46,9 @@ template <int BITS> __device__ __forceinline__ u64 wave_match_digit(u32 dg, bool
     for (int b = 0; b < BITS; ++b) {
         const u32 mine = (u32)((int)(dg << (31 - b)) >> 31); // all ones if bit b of dg is set
         const u64 m = __ballot((int)mine < 0);
-        diff_lo |= (u32)m ^ mine;
-        diff_hi |= (u32)(m >> 32) ^ mine;
+        // diff | (ballot ^ mine) in one v_bitop3_b32 (truth table 0xF6: source 0 is the most significant index bit)
+        diff_lo = __builtin_amdgcn_bitop3_b32(diff_lo, (u32)m, mine, 0xF6);
+        diff_hi = __builtin_amdgcn_bitop3_b32(diff_hi, (u32)(m >> 32), mine, 0xF6);
     }
     const u64 diff = ((u64)diff_hi << 32) | diff_lo;
     return __ballot(ok) & ~diff;
