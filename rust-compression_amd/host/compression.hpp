@@ -170,6 +170,19 @@ template <int Kind> class DeflateFamilyEncoder {
         if (rc != BZ_OK) throw std::runtime_error(bz_strerror(rc));
         buf_.resize(1 << 16);
     }
+    // ::with_dict (src/deflate/encoder.rs:134-153, src/zlib/encoder.rs:74-93; GZipEncoder has none)
+    static DeflateFamilyEncoder *with_dict(const uint8_t *dict, size_t dict_len, int device = 0)
+    {
+        auto *e = new DeflateFamilyEncoder(device);
+        df_enc_destroy(e->h_);
+        e->h_ = nullptr;
+        const int rc = df_enc_create_dict(&e->h_, Kind, device, dict, dict_len);
+        if (rc != BZ_OK) {
+            delete e;
+            throw std::runtime_error(bz_strerror(rc));
+        }
+        return e;
+    }
     DeflateFamilyEncoder(const DeflateFamilyEncoder &) = delete;
     DeflateFamilyEncoder &operator=(const DeflateFamilyEncoder &) = delete;
     ~DeflateFamilyEncoder() { df_enc_destroy(h_); }

@@ -251,6 +251,7 @@ impl Decoder for BZip2Decoder {
 #[link(name = "bz2_mi355x")]
 extern "C" {
     fn df_enc_create(out: *mut *mut c_void, kind: i32, device: i32) -> i32;
+    fn df_enc_create_dict(out: *mut *mut c_void, kind: i32, device: i32, dict: *const u8, dict_len: usize) -> i32;
     fn df_enc_write(e: *mut c_void, data: *const u8, n: usize) -> i32;
     fn df_enc_end(e: *mut c_void, action: i32) -> i32;
     fn df_enc_read(e: *mut c_void, out: *mut u8, cap: usize) -> isize;
@@ -270,6 +271,13 @@ pub struct ZlibEncoder(DeflateFamilyEncoder);
 pub struct GZipEncoder(DeflateFamilyEncoder);
 
 impl DeflateFamilyEncoder {
+    fn with_kind_and_dict(kind: i32, dict: &[u8]) -> Self {
+        let mut h: *mut c_void = core::ptr::null_mut();
+        let rc = unsafe { df_enc_create_dict(&mut h, kind, 0, dict.as_ptr(), dict.len()) };
+        assert!(rc == 0, "bz2_mi355x: no usable MI355X (the path has no CPU fallback)");
+        Self { h, ready: Vec::new(), pos: 0, chunk: Vec::with_capacity(CHUNK) }
+    }
+
     fn with_kind(kind: i32) -> Self {
         let mut h: *mut c_void = core::ptr::null_mut();
         let rc = unsafe { df_enc_create(&mut h, kind, 0) };
@@ -353,6 +361,18 @@ macro_rules! deflate_family {
             }
         }
     };
+}
+impl Inflater {
+    /// `Inflater::with_dict` (src/deflate/encoder.rs:134-153)
+    pub fn with_dict(dict: &[u8]) -> Self {
+        Inflater(DeflateFamilyEncoder::with_kind_and_dict(0, dict))
+    }
+}
+impl ZlibEncoder {
+    /// `ZlibEncoder::with_dict` (src/zlib/encoder.rs:74-93)
+    pub fn with_dict(dict: &[u8]) -> Self {
+        ZlibEncoder(DeflateFamilyEncoder::with_kind_and_dict(1, dict))
+    }
 }
 deflate_family!(Inflater, 0);
 deflate_family!(ZlibEncoder, 1);
