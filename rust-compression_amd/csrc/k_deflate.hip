@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
     __shared__ u16 s_prev[kWin + kMTile];
     __shared__ u16 s_order[kMTile];
     __shared__ u8 s_est[kMTile];
-    __shared__ u16 s_q[4][kMThreads]; // per lane: summed distances of the candidates waiting to be measured
+    __shared__ u16 s_q[5][kMThreads]; // per lane: summed distances of the candidates waiting to be measured
     __shared__ u32 s_hist[256];
     __shared__ u32 s_next;
     const u32 tid = threadIdx.x;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
         u32 qn = 0;                                   // candidates in this lane's queue (s_q[..][tid])
         auto measure = [&]() {
             bool hit = false;
-            for (u32 s = 0; s < 4; ++s) {
+            for (u32 s = 0; s < 5; ++s) {
                 if (!__ballot(s < qn)) break;
                 if (s < qn && !hit) {
                     const u32 ccum = s_q[s][tid];
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
             fq = best_len < limit ? (ld4(lp + foff) & fmask) : 0u;
             if (hit) active = false;
         };
-        while (__ballot(active)) {
+        auto hop = [&]() { // one candidate: the byte test, the queue, the next link
             const u32 lc = lp - cum;
             const u32 fa = lc + foff;
             const u32 fw0 = s_w[fa >> 2], fw1 = s_w[(fa >> 2) + 1];
@@ -429,7 +429,11 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
             const bool cont = active && cnt != 0 && d != 0 && ncum <= kWin; // :262, :234
             cum = cont ? ncum : cum;
             active = cont;
-            if (__ballot(qn == 4)) measure();
+        };
+        while (__ballot(active)) { // two candidates per trip (the queue holds five, measuring starts at four)
+            hop();
+            hop();
+            if (__ballot(qn >= 4)) measure();
         }
         if (__ballot(qn != 0)) measure();
         if (valid) M[p] = best_len >= kMinMatch ? (best_len | ((best_dist - 1) << 9)) : 0u;
