@@ -281,6 +281,10 @@ __global__ __launch_bounds__(256) void k_df_prev(u64 ntri, const u32 *__restrict
 }
 
 // ---------------------------------------------------------------------------------- matches
+#ifndef DF_HOPS
+#define DF_HOPS 4
+#endif
+constexpr u32 kHops = DF_HOPS, kQSlots = 3 + DF_HOPS;
 constexpr u32 kMDataBytes = kWin + kMTile + 272;
 
 __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ in, const u32 *__restrict__ pe, u64 n,
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
     __shared__ u16 s_prev[kWin + kMTile];
     __shared__ u16 s_order[kMTile];
     __shared__ u8 s_est[kMTile];
-    __shared__ u16 s_q[5][kMThreads]; // per lane: summed distances of the candidates waiting to be measured
+    __shared__ u16 s_q[kQSlots][kMThreads]; // per lane: summed distances of the candidates waiting to be measured
     __shared__ u32 s_hist[256];
     __shared__ u32 s_next;
     const u32 tid = threadIdx.x;
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
         u32 qn = 0;                                   // candidates in this lane's queue (s_q[..][tid])
         auto measure = [&]() {
             bool hit = false;
-            for (u32 s = 0; s < 5; ++s) {
+            for (u32 s = 0; s < kQSlots; ++s) {
                 if (!__ballot(s < qn)) break;
                 if (s < qn && !hit) {
                     const u32 ccum = s_q[s][tid];
@@ -430,9 +434,9 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
             cum = cont ? ncum : cum;
             active = cont;
         };
-        while (__ballot(active)) { // two candidates per trip (the queue holds five, measuring starts at four)
-            hop();
-            hop();
+        while (__ballot(active)) { // kHops candidates per trip (the queue holds 3 + kHops, measuring starts at four)
+#pragma unroll
+            for (u32 hh = 0; hh < kHops; ++hh) hop();
             if (__ballot(qn >= 4)) measure();
         }
         if (__ballot(qn != 0)) measure();
