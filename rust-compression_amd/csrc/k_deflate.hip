@@ -293,8 +293,8 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
     __shared__ u32 s_w[kMDataBytes / 4];
     __shared__ u16 s_prev[kWin + kMTile];
     __shared__ u16 s_order[kMTile];
-    __shared__ u8 s_est[kMTile];
     __shared__ u16 s_q[kQSlots][kMThreads]; // per lane: summed distances of the candidates waiting to be measured
+    u8 *s_est = reinterpret_cast<u8 *>(&s_q[0][0]); // chain lengths of the tile: only needed while the positions are ordered
     __shared__ u32 s_hist[256];
     __shared__ u32 s_next;
     const u32 tid = threadIdx.x;
