@@ -4,15 +4,20 @@
 A "step" is one pass of the whole hot path (RLE1+split+CRC -> BWT -> MTF/ZLE -> Huffman -> bit
 emission -> stream assembly) over the synthetic corpus, input and output resident in HBM.
 N = 1: BASELINE.json configs[1] (1 GiB repeating text, level 9, one MI355X).
-N > 1: configs[2] scaled weakly (1 GiB per GPU): every rank holds the corpus but works on its own
-slab of it (rust-compression_amd/sharded.py: the RLE1 split is sharded by input tiles, the cut
-chain is an 8-byte hand-off from rank to rank), encodes the blocks that end in its slab, and the
-block bit strings are gathered to rank 0 over RCCL (torch.distributed "nccl"), which assembles the
-serial stream.
+N > 1: configs[2] scaled weakly (1 GiB per GPU): one process per GPU; every rank holds the corpus but
+works on its own slab of it (bz_gpu_encode_sharded: the RLE1 split is sharded by input tiles, the cut
+chain is a 16-byte hand-off from rank to rank), encodes the blocks that end in its slab, and the block
+bit strings are gathered to rank 0 over RCCL (torch.distributed "nccl" behind the library's four
+transport callbacks), which assembles the serial stream.
 
-Prints ONE JSON line on rank 0.  Launch for N > 1:
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-      --master-port P bench.py --gpus N --steps K --warmup W
+`python3 bench.py --gpus N` starts the N rank processes itself (fresh children, before anything
+touches a GPU); under `python -m torch.distributed.run ... bench.py --gpus N` the ranks already exist
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  Rank 0 prints ONE JSON line.
+
+Besides the headline (value, roofline, cpu_baseline) the line carries, at N = 1 and outside the timed
+region: end_to_end (host buffer -> host buffer through the C ABI), extra.decode and extra.deflate
+(BASELINE.json configs[3] and [4] on the same corpus, each with its own roofline and cpu_baseline),
+the stress corpus T2, and the all-cores CPU baseline.
 """
 import argparse
 import bz2
@@ -20,6 +25,8 @@ import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,7 +37,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -39,24 +46,101 @@ def main():
     ap.add_argument("--level", type=int, default=9)
     ap.add_argument("--cpu-sample-mib", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--corpus", default="text", choices=["text", "t2"])
-    ap.add_argument("--force-sharded", action="store_true",
-                    help="run the partition / encode_blocks / exchange / assemble path even with one rank")
-    args = ap.parse_args()
+    ap.add_argument("--force-sharded", action="store_true", help="run bz_gpu_encode_sharded even with one rank")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="ranks share the visible GPUs (rank r -> device r mod count) and talk over gloo: lets "
+                         "the N > 1 path run on a box with fewer GPUs than ranks (not a scaling measurement)")
+    return ap.parse_args()
 
+
+def self_launch(args):
+    """--gpus N from a plain shell: start N rank processes (this process never touches a GPU)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0:
+                rc = rc or code
+                for q in alive:  # a rank died: its peers would wait in a collective for ever
+                    q.terminate()
+    sys.exit(rc)
+
+
+def timed(fn, reps, sync):
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / reps
+
+
+def roofline_of(kprof, names, pmc):
+    """roofline object of the slowest of `names` (kernels with launches) from the in-library HIP-event profile"""
+    cand = {k: v for k, v in kprof.items() if k in names and v["launches"] and v["seconds"] > 0}
+    if not cand:
+        return None
+    name, d = max(cand.items(), key=lambda kv: kv[1]["seconds"])
+    achieved = d["bytes"] / d["seconds"] / 1e9
+    return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": pmc.get(name), "launches": d["launches"],
+            "avg_launch_ms": round(d["seconds"] / d["launches"] * 1e3, 4),
+            "algorithmic_bytes_per_launch": d["bytes"] // d["launches"]}
+
+
+def load_json(*path):
+    p = os.path.join(ROOT, *path)
+    try:
+        return json.load(open(p))
+    except (OSError, ValueError):
+        return {}
+
+
+ENC_KERNELS = ("k_radix_hist", "k_radix_scan", "k_radix_scatter", "k_group_flags", "k_group_apply", "k_last_column",
+               "k_radix_scatter_lb", "k_ghist_text", "k_ghist_scan", "k_bucket_sort", "k_rank_place")
+DEC_KERNELS = ("k_dec_block", "k_dec_mtf", "k_dec_tsort", "k_dec_walk_lengths", "k_dec_place", "k_dec_rle", "k_dec_crc")
+
+
+def main():
+    args = parse_args()
+    if "RANK" not in os.environ and args.gpus > 1:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        sys.exit("bench.py: no GPU visible (the HIP path has no CPU fallback)")
+    share = args.share_gpu or ndev < world
+    dev_index = local_rank % ndev if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = importlib.import_module("rust-compression_amd")  # after torch: shares its HIP runtime
     import corpus
@@ -64,38 +148,36 @@ def main():
 
     total = args.mib_per_gpu * world << 20
     if args.corpus == "t2":
-        host = corpus.stress_t2(total)
-        d_in = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
+        d_in = torch.frombuffer(bytearray(corpus.stress_t2(total)), dtype=torch.uint8).to(dev)
     else:
         d_in = corpus.corpus_on_device(total, dev)
     n = d_in.numel()
     est_blocks = n // 800000 + 8
     local_blocks = (est_blocks + world - 1) // world + 2
-    eng = pkg.GpuEngine(local_rank, min(local_blocks, 1400))
+    eng = pkg.GpuEngine(dev_index, min(local_blocks, 1400))
     cap = (pkg.encode_bound(n) + 15) & ~15
     d_out = torch.empty(cap if rank == 0 else 16, dtype=torch.uint8, device=dev)
-
     state = {}
 
     def step_single():
         state["out_len"] = eng.encode_device(args.level, d_in.data_ptr(), n, d_out.data_ptr(), cap)
 
-    # multi-GPU buffers
-    if world > 1 or args.force_sharded:
-        cap_words = pkg.encode_bound(n // world + (2 << 20)) // 4 + 4 * local_blocks + 64
-        d_packed = torch.empty(cap_words, dtype=torch.int32, device=dev)
-        d_all = torch.empty((world, cap_words), dtype=torch.int32, device=dev) if rank == 0 else None
+    multi = world > 1 or args.force_sharded
+    if multi:
+        comm = sharded.TorchComm(rank, world, dev)
+        cap_words = pkg.encode_bound(n // world + (48 << 20)) // 4 + 4 * local_blocks + 64
+        d_packed = comm.register(torch.empty(cap_words, dtype=torch.int32, device=dev))
+        gather_words = pkg.encode_bound(n) // 4 + 4 * est_blocks + 64
+        d_gather = comm.register(torch.empty(gather_words, dtype=torch.int32, device=dev)) if rank == 0 else None
 
     def step_multi():
-        nb = sharded.partition(eng, args.level, d_in.data_ptr(), n, rank, world, dev)
-        woff, blen, crc, used = eng.encode_blocks(0, 1, nb, d_packed.data_ptr(), cap_words)
-        res = sharded.exchange(woff, blen, crc, d_packed, used, rank, world, dev, d_all)
+        k = eng.encode_sharded(args.level, d_in.data_ptr(), n, comm, d_out.data_ptr(), cap if rank == 0 else 16,
+                               packed=(d_packed.data_ptr(), cap_words),
+                               gather=(d_gather.data_ptr(), gather_words) if rank == 0 else None)
         if rank == 0:
-            buf, w_off, b_len, crcs = res
-            out_len, _, _, _ = eng.assemble(args.level, buf.data_ptr(), w_off, b_len, crcs, d_out.data_ptr(), cap)
-            state["out_len"] = out_len
+            state["out_len"] = k
 
-    step = step_single if (world == 1 and not args.force_sharded) else step_multi
+    step = step_multi if multi else step_single
 
     def sync():
         torch.cuda.synchronize()
@@ -115,40 +197,50 @@ def main():
     kprof = eng.kernel_profile()
     stages = eng.timings()
     bstats = eng.bwt_stats()
+    nblocks_rank = len(eng.block_stats())
     eng.profile(False)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        wire = torch.device("cpu") if share else dev
+        tmax = torch.tensor([dt], dtype=torch.float64, device=wire)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = torch.tensor([float(nblocks_rank)], dtype=torch.float64, device=wire)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt = float(tmax.item())
+        nblocks = int(tsum.item())
+    else:
+        nblocks = nblocks_rank
 
     result = None
     if rank == 0:
+        golden = load_json("tests", "golden", "corpus_hashes.json")
+        pmc = load_json("profiles", "pmc_traffic.json")
         out_len = state["out_len"]
         out = bytes(d_out[:out_len].cpu().numpy())
+        sha = hashlib.sha256(out).hexdigest()
         # size-independent checks outside the timed region: the stream decodes, and its head is the corpus
         try:
             head = bz2.BZ2Decompressor().decompress(out[:min(len(out), 48 << 20)], 32 << 20)
             ok_head = len(head) > 0 and head == bytes(d_in[:len(head)].cpu().numpy())
         except (OSError, ValueError, EOFError):
             ok_head = False
+        checks = {"head_decodes_to_input": bool(ok_head)}
+        gkey = None
+        if args.level == 9 and n % (1 << 20) == 0:
+            size = "%dgib" % (n >> 30) if n % (1 << 30) == 0 else "%dmib" % (n >> 20)
+            gkey = "bzip2_l9_%s_%s" % (args.corpus, size)
+        if gkey in golden:  # the oracle's stream for this exact corpus (tests/golden/make_corpus_hashes.py)
+            checks["stream_sha_equals_oracle_golden"] = bool(golden[gkey]["sha256"] == sha and golden[gkey]["bytes"] == out_len)
         value = n * args.steps / dt / 1e6
-        # dominant kernel by measured time
-        dom = max(kprof.items(), key=lambda kv: kv[1]["seconds"])
-        dname, d = dom
-        avg = d["seconds"] / max(d["launches"], 1)
-        achieved = d["bytes"] / d["seconds"] / 1e9 if d["seconds"] > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(dname)
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": dname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                    "launches": d["launches"], "avg_launch_ms": round(avg * 1e3, 4),
-                    "algorithmic_bytes_per_launch": d["bytes"] // max(d["launches"], 1)}
-        pipeline_bytes = 24 * n + out_len  # whole-pipeline algorithmic traffic
+        roofline = roofline_of(kprof, ENC_KERNELS, pmc)
+        # whole-pipeline algorithmic traffic (24 N_in + N_out) over the kernel time, per GPU
+        pipeline_bytes = 24 * n + out_len
+        pipe = pipeline_bytes * args.steps / dt / 1e9 / world
+        roofline["pipeline_8d"] = {"achieved": round(pipe, 2), "unit": "GB/s", "frac": round(pipe / HBM_PEAK_GBPS, 5),
+                                   "bytes_per_input_byte": round(pipeline_bytes / n, 3),
+                                   "definition": "(24 N_in + N_out) / step time, per GPU (SURVEY.md 8(d))"}
+        if "__total_bytes_per_step" in pmc:
+            roofline["hbm_traffic_bytes_per_input_byte"] = round(pmc["__total_bytes_per_step"] / pmc["__input_bytes"], 1)
+            roofline["hbm_traffic_source"] = pmc.get("__source")
         result = {
             "metric": "BZip2 level-%d encode MB/s (input bytes, HBM-resident in and out)" % args.level,
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -157,19 +249,21 @@ def main():
             "config": {"workload": ("%d MiB synthetic repeating-text corpus (16 MiB Zipf chapters), level %d, "
                                     "%d KB blocks" % (n >> 20, args.level, args.level * 100)) if args.corpus == "text"
                        else "%d MiB stress T2 (4 KiB paragraph repeated)" % (n >> 20),
-                       "blocks": len(out) and (n // (args.level * 100000 - 19)) + 1, "parallelism": "input slabs x%d, blocks in stream order, RCCL gather to rank 0" % world,
+                       "blocks": nblocks,
+                       "parallelism": ("input slabs x%d (bz_gpu_encode_sharded), blocks in stream order, %s gather to rank 0"
+                                       % (world, "gloo (ranks share GPUs: not a scaling run)" if share and world > 1 else "RCCL"))
+                       if multi else "one engine, one GPU",
                        "out_bytes": out_len, "ratio": round(out_len / n, 4)},
             "roofline": roofline,
-            "pipeline_algorithmic_GBps_per_gpu": round(pipeline_bytes * args.steps / dt / 1e9 / world, 2),
             "kernel_seconds_last_step_rank0": {k: round(v, 5) for k, v in stages.items()},
             "bwt": bstats,
             "kernels": {k: {"launches": v["launches"], "ms": round(v["seconds"] * 1e3, 3),
                             "GBps": round(v["bytes"] / v["seconds"] / 1e9, 1) if v["seconds"] else 0}
-                        for k, v in kprof.items()},
-            "stream_sha256": hashlib.sha256(out).hexdigest(),
-            "checks": {"head_decodes_to_input": bool(ok_head)},
+                        for k, v in kprof.items() if v["launches"]},
+            "stream_sha256": sha,
+            "checks": checks,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             # cpu_baseline leg: the oracle (a C restatement of the reference algorithm, 1 thread like the
             # reference) on a bounded sample of the same corpus; its output doubles as a parity check.
             from oracle import oracle
@@ -181,12 +275,17 @@ def main():
             cdt = time.perf_counter() - c0
             d_s = torch.empty((pkg.encode_bound(smp) + 15) & ~15, dtype=torch.uint8, device=dev)
             k = eng.encode_device(args.level, d_in.data_ptr(), smp, d_s.data_ptr(), d_s.numel())
-            same = bytes(d_s[:k].cpu().numpy()) == ref
+            sample_stream = bytes(d_s[:k].cpu().numpy())
+            same = sample_stream == ref
             result["cpu_baseline"] = {"value": round(smp / cdt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
                                       "sample": "first %d MiB of the same corpus, oracle/bz2_oracle.c (C restatement "
                                                 "of the reference algorithm, single thread like the reference)" % (smp >> 20),
                                       "host_cpus": os.cpu_count()}
-            result["checks"]["gpu_equals_oracle_on_cpu_sample"] = bool(same)
+            checks["gpu_equals_oracle_on_cpu_sample"] = bool(same)
+            if not args.no_extras:
+                result["cpu_baseline_all_cores"] = all_cores_baseline(oracle, sample, args.level)
+        if not args.no_extras and world == 1 and args.corpus == "text":
+            extras(result, args, pkg, eng, torch, dev, d_in, n, d_out, out_len, golden, corpus)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -194,6 +293,155 @@ def main():
         print(json.dumps(result))
         if not all(result["checks"].values()):
             sys.exit(3)
+
+
+def all_cores_baseline(oracle, sample, level):
+    """the oracle block-parallel on all host cores -- independent 16 MiB pieces of the
+    sample, one per thread at a time (ctypes releases the GIL); a throughput figure, not one stream."""
+    from concurrent.futures import ThreadPoolExecutor
+    threads = min(os.cpu_count() or 1, 256)
+    piece = 16 << 20
+    pieces = [sample[i:i + piece] for i in range(0, len(sample), piece)] or [sample]
+    work = [pieces[i % len(pieces)] for i in range(max(threads, len(pieces)))]
+    c0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(lambda p: len(oracle.encode(p, level)), work))
+    cdt = time.perf_counter() - c0
+    return {"value": round(sum(len(p) for p in work) / cdt / 1e6, 2), "unit": "MB/s", "cores": threads, "kind": "port",
+            "sample": "%d independent 16 MiB pieces of the corpus, one oracle encoder per thread (block-parallel "
+                      "throughput of the reference algorithm; the pieces are separate streams)" % len(work)}
+
+
+def extras(result, args, pkg, eng, torch, dev, d_in, n, d_out, out_len, golden, corpus):
+    """Non-headline measurements, each outside the headline's timed region and bounded in time."""
+    from oracle import oracle
+    pmc_dec = load_json("profiles", "pmc_traffic_decode.json")
+    pmc_df = load_json("profiles", "pmc_traffic_deflate.json")
+    checks = result["checks"]
+
+    def sync():
+        torch.cuda.synchronize()
+
+    # ---- decode (BASELINE.json configs[3]: BZip2Decoder on the stream just produced, HBM -> HBM)
+    d_dec = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    eng.decode_device(d_out.data_ptr(), out_len, d_dec.data_ptr(), n + 64)  # warm-up: workspace
+    eng.profile(True)
+    res = {}
+
+    def dec_step():
+        res["r"] = eng.decode_device(d_out.data_ptr(), out_len, d_dec.data_ptr(), n + 64)
+    ddt = timed(dec_step, 3, sync)
+    kp = eng.kernel_profile()
+    eng.profile(False)
+    k, verdict = res["r"]
+    checks["decode_round_trip_equals_input"] = bool(verdict == 0 and k == n and torch.equal(d_dec[:n], d_in))
+    dec = {"metric": "BZip2 decode MB/s (decoded bytes, HBM-resident in and out)", "value": round(n / ddt / 1e6, 2),
+           "unit": "MB/s", "ms_per_step": round(ddt * 1e3, 3), "steps": 3,
+           "stages_s": {a: round(b, 5) for a, b in eng.decode_timings().items()},
+           "roofline": roofline_of(kp, DEC_KERNELS, pmc_dec)}
+    if not args.no_cpu_baseline:
+        smp = min(args.cpu_sample_mib << 20, n)
+        d_s = torch.empty((pkg.encode_bound(smp) + 15) & ~15, dtype=torch.uint8, device=dev)
+        ks = eng.encode_device(args.level, d_in.data_ptr(), smp, d_s.data_ptr(), d_s.numel())
+        sstream = bytes(d_s[:ks].cpu().numpy())
+        c0 = time.perf_counter()
+        back, v = oracle.decode(sstream)
+        cdt = time.perf_counter() - c0
+        dec["cpu_baseline"] = {"value": round(len(back) / cdt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
+                               "sample": "the stream of the first %d MiB, oracle decoder (C restatement of BZip2Decoder)" % (smp >> 20)}
+        kk, vv = eng.decode_device(d_s.data_ptr(), ks, d_dec.data_ptr(), n + 64)
+        checks["decode_equals_oracle_on_cpu_sample"] = bool(v == 0 and vv == 0 and kk == len(back) and
+                                                            bytes(d_dec[:kk].cpu().numpy()) == back)
+    del d_dec
+
+    # ---- Deflate (BASELINE.json configs[4]: Inflater on the same corpus, HBM -> HBM); one call takes < 2 GiB
+    result["extra"] = {"decode": dec}
+    if n < (1 << 31):
+        dcap = (pkg.lib().df_encode_bound(n) + 15) & ~15
+        d_df = torch.empty(dcap, dtype=torch.uint8, device=dev)
+        eng.deflate_encode_device(pkg.DEFLATE, d_in.data_ptr(), n, d_df.data_ptr(), dcap)  # warm-up: workspace
+        st = {}
+
+        def df_step():
+            st["k"] = eng.deflate_encode_device(pkg.DEFLATE, d_in.data_ptr(), n, d_df.data_ptr(), dcap)
+        fdt = timed(df_step, 2, sync)
+        dft = eng.deflate_timings()
+        dsha = hashlib.sha256(bytes(d_df[:st["k"]].cpu().numpy())).hexdigest()
+        size = "%dgib" % (n >> 30) if n % (1 << 30) == 0 else "%dmib" % (n >> 20)
+        gk = "deflate_text_%s" % size
+        if gk in golden:
+            checks["deflate_sha_equals_oracle_golden"] = bool(golden[gk]["sha256"] == dsha and golden[gk]["bytes"] == st["k"])
+        # dominant kernel: the match finder; 7 algorithmic bytes per position (DESIGN.md section 11)
+        ach = 7.0 * n / dft["matches"] / 1e9 if dft["matches"] > 0 else 0.0
+        df = {"metric": "Deflate (Inflater) encode MB/s (input bytes, HBM-resident in and out)",
+              "value": round(n / fdt / 1e6, 2), "unit": "MB/s", "ms_per_step": round(fdt * 1e3, 3), "steps": 2,
+              "out_bytes": st["k"], "ratio": round(st["k"] / n, 4), "stream_sha256": dsha,
+              "stages_s": {a: round(b, 5) for a, b in dft.items()},
+              "roofline": {"bound": "hbm", "kernel": "k_df_match", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
+                           "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": pmc_df.get("k_df_match"),
+                           "avg_launch_ms": round(dft["matches"] * 1e3, 3), "algorithmic_bytes_per_launch": 7 * n,
+                           "note": "VALU-issue-bound, not HBM-bound (DESIGN.md section 11)"}}
+        if not args.no_cpu_baseline:
+            smp = min(16 << 20, n)
+            sample = bytes(d_in[:smp].cpu().numpy())
+            c0 = time.perf_counter()
+            ref = oracle.deflate_encode(sample, 0)
+            cdt = time.perf_counter() - c0
+            ks = eng.deflate_encode_device(pkg.DEFLATE, d_in.data_ptr(), smp, d_df.data_ptr(), dcap)
+            checks["deflate_equals_oracle_on_cpu_sample"] = bool(bytes(d_df[:ks].cpu().numpy()) == ref)
+            df["cpu_baseline"] = {"value": round(smp / cdt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
+                                  "sample": "first %d MiB of the corpus, oracle/deflate_oracle.c (C restatement of Inflater)" % (smp >> 20)}
+        result["extra"]["deflate"] = df
+        del d_df
+
+    # ---- stress corpus T2 (4 KiB paragraph repeated: deep LCPs, 18 doubling rounds), 256 MiB, one step
+    t2n = min(n, 256 << 20)
+    d_t2 = torch.frombuffer(bytearray(corpus.stress_t2(t2n)), dtype=torch.uint8).to(dev)
+    res2 = {}
+
+    def t2_step():
+        res2["k"] = eng.encode_device(args.level, d_t2.data_ptr(), t2n, d_out.data_ptr(), d_out.numel())
+    t2_step()
+    tdt = timed(t2_step, 1, sync)
+    t2 = bytes(d_out[:res2["k"]].cpu().numpy())
+    try:
+        ok_t2 = bz2.decompress(t2) == bytes(d_t2.cpu().numpy())
+    except (OSError, ValueError, EOFError):
+        ok_t2 = False
+    checks["t2_stress_decodes_to_input"] = bool(ok_t2)
+    result["t2_stress"] = {"value": round(t2n / tdt / 1e6, 2), "unit": "MB/s", "mib": t2n >> 20,
+                           "rounds": eng.bwt_stats()["rounds"], "out_bytes": res2["k"]}
+    del d_t2
+
+    # ---- end to end: host buffer -> host buffer through the C ABI (PCIe both ways inside the clock)
+    import ctypes
+    host = bytes(d_in.cpu().numpy())
+    pkg.compress(host[:64 << 20], args.level)  # warm-up: engine, pinned staging
+    outp_c, outn_c = ctypes.POINTER(ctypes.c_uint8)(), ctypes.c_size_t(0)
+    c0 = time.perf_counter()
+    rc = pkg.lib().bz_encode_buffer(args.level, dev.index, host, n, ctypes.byref(outp_c), ctypes.byref(outn_c))
+    e1 = time.perf_counter() - c0
+    got = ctypes.string_at(outp_c, outn_c.value) if rc == 0 else b""
+    pkg.lib().bz_free(outp_c)
+    checks["end_to_end_buffer_equals_device_stream"] = bool(hashlib.sha256(got).hexdigest() == result["stream_sha256"])
+    enc = pkg.BZip2Encoder(args.level)
+    c0 = time.perf_counter()
+    piece = 1 << 20
+    outp = []
+    mv = memoryview(host)
+    for i in range(0, n, piece):
+        enc.write(mv[i:i + piece])
+        r = enc.read_available()
+        if r:
+            outp.append(r)
+    enc.end(pkg.Action.FINISH)
+    outp.append(enc.read_all())
+    e2 = time.perf_counter() - c0
+    checks["end_to_end_streaming_equals_device_stream"] = bool(hashlib.sha256(b"".join(outp)).hexdigest() == result["stream_sha256"])
+    result["end_to_end"] = {"unit": "MB/s", "bz_encode_buffer": round(n / e1 / 1e6, 2),
+                            "bz_enc_write_read_1MiB_pieces": round(n / e2 / 1e6, 2),
+                            "note": "host buffer in -> host buffer out, one GPU, H2D/D2H inside the clock; pageable caller "
+                                    "memory on both sides (python bytes)"}
 
 
 if __name__ == "__main__":

@@ -184,6 +184,46 @@ int bz_gpu_assemble(bz_gpu_engine *g, int level, size_t n_blocks,
                     void *d_out, size_t cap, size_t *out_len,
                     unsigned *out_carry_bits, unsigned *out_carry_byte);
 
+/* ---- the whole stream over several GPUs (BASELINE.json configs[2]) ----------------
+ * One process (one engine) per GPU; every rank calls bz_gpu_encode_sharded with the same level and n.
+ * Rank r splits its SLAB of the input -- an equal share of the 4 KiB tiles, [ntiles*r/world,
+ * ntiles*(r+1)/world) -- with the three _slab_ calls above, encodes the blocks that END in its slab
+ * (stream order == rank order) and the block bit strings are gathered to rank 0, which assembles the
+ * serial stream (bz_gpu_assemble).  d_in is addressed as the whole input, but a rank only reads its
+ * slab and, in front of it, the input bytes of the block that straddles its left edge (a level-9
+ * block covers at most 900000 * 255 / 5 = 45.9 MB of input), so the rest need not be backed by memory.
+ * The transport is the caller's: RCCL (ncclAllGather / ncclSend / ncclRecv over xGMI), MPI or
+ * torch.distributed behind four C callbacks, each returning 0 on success.  Every rank takes part in
+ * every exchange; a rank-local error is carried in the exchanged status words and returned by ALL
+ * ranks (no rank is left waiting in a collective).
+ *   allgather(ctx, send, bytes, recv)   HOST memory: `bytes` bytes of every rank, in rank order, into recv
+ *   send(ctx, dst, buf, bytes) / recv(ctx, src, buf, bytes)   HOST memory, 16 bytes along the cut chain
+ *   gatherv(ctx, d_send, send_bytes, d_recv, recv_off, recv_bytes)   DEVICE memory: rank r's send_bytes
+ *       bytes land at d_recv + recv_off[r] on rank 0 (recv_bytes[r] == that rank's send_bytes; the
+ *       two arrays are valid on every rank, d_recv only on rank 0; rank 0's own part included)
+ * d_packed / d_gather: optional caller-owned device buffers (e.g. registered with the transport) for
+ * this rank's bit strings and, on rank 0, everybody's; NULL = the engine's own.  On rank 0 *out_len
+ * receives the stream length and d_out the stream; the other ranks get *out_len = 0. */
+typedef struct bz_shard_comm {
+    void *ctx;
+    int rank, world;
+    int (*allgather)(void *ctx, const void *send, size_t bytes, void *recv);
+    int (*send)(void *ctx, int dst, const void *buf, size_t bytes);
+    int (*recv)(void *ctx, int src, void *buf, size_t bytes);
+    int (*gatherv)(void *ctx, const void *d_send, size_t send_bytes, void *d_recv,
+                   const uint64_t *recv_off, const uint64_t *recv_bytes);
+} bz_shard_comm;
+int bz_gpu_encode_sharded(bz_gpu_engine *g, int level, const void *d_in, size_t n,
+                          const bz_shard_comm *comm, void *d_packed, size_t packed_cap_words,
+                          void *d_gather, size_t gather_cap_words, void *d_out, size_t cap,
+                          size_t *out_len);
+
+/* Runs known patterns through a transport's four callbacks, shaped like the exchanges above (every
+ * rank calls it): BZ_OK, BZ_E_DATA (bytes arrived wrong somewhere; the same verdict on every rank) or
+ * BZ_E_UNEXPECTED (a callback failed).  host_memory != 0: the buffers handed to gatherv are host
+ * memory (a CPU transport under test; needs no GPU), else device memory. */
+int bz_shard_comm_selftest(const bz_shard_comm *comm, int host_memory);
+
 /* Seconds of GPU time spent in the kernels of the last bz_gpu_encode_device /
  * bz_gpu_encode_blocks call, by stage (HIP events on the engine's stream):
  * [0] rle1+crc+split [1] bwt [2] mtf+zle [3] huffman [4] emit+assemble [5] total. */

@@ -81,7 +81,8 @@ EXPORTS = [
     "bz_encode_buffer", "bz_free",
     "bz_gpu_engine_create", "bz_gpu_engine_destroy", "bz_encode_bound", "bz_gpu_encode_device",
     "bz_gpu_partition", "bz_gpu_partition_slab_begin", "bz_gpu_partition_slab_count",
-    "bz_gpu_partition_slab_finish", "bz_gpu_encode_blocks", "bz_gpu_assemble", "bz_gpu_last_timings",
+    "bz_gpu_partition_slab_finish", "bz_gpu_encode_blocks", "bz_gpu_assemble", "bz_gpu_encode_sharded",
+    "bz_shard_comm_selftest", "bz_gpu_last_timings",
     "bz_gpu_last_bwt_stats", "bz_gpu_last_bwt_rounds", "bz_gpu_profile_enable", "bz_gpu_profile_kernels", "bz_gpu_profile_get",
     "bz_gpu_debug_bwt", "bz_gpu_debug_code_lengths", "bz_gpu_debug_block_stats",
     "bz_gpu_decode_device", "bz_gpu_decode_device_sharded", "bz_gpu_last_decode_timings", "bz_gpu_last_decode_stats", "bz_decode_buffer",
@@ -157,6 +158,8 @@ def lib():
     L.bz_gpu_assemble.argtypes = [vp, C.c_int, sz, vp, u64p, u64p, u32p, C.c_int, C.c_int, C.c_int,
                                   C.c_uint, C.c_uint, C.c_uint32, u32p, vp, sz, szp,
                                   C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+    L.bz_gpu_encode_sharded.argtypes = [vp, C.c_int, vp, sz, vp, vp, sz, vp, sz, vp, sz, szp]
+    L.bz_shard_comm_selftest.argtypes = [vp, C.c_int]
     L.bz_gpu_last_timings.argtypes = [vp, C.POINTER(C.c_double)]
     L.bz_gpu_last_bwt_stats.argtypes = [vp, u64p]
     L.bz_gpu_last_bwt_rounds.argtypes = [vp, u64p]
@@ -281,6 +284,8 @@ class BZip2Encoder:
             out += self._ready
         self._ready, self._pos = b"", 0
         return bytes(out)
+
+    read_available = read_all  # what is complete now (chunks are encoded while the caller goes on writing)
 
     def encode_all(self, data, action=Action.FINISH):
         """`data.encode(&mut self, action).collect()`"""
@@ -592,6 +597,17 @@ class GpuEngine:
                                      carry_bits, carry_byte, combined_crc, C.byref(comb), d_out, cap,
                                      C.byref(out_len), C.byref(ocb), C.byref(ocy)))
         return out_len.value, comb.value, ocb.value, ocy.value
+
+    def encode_sharded(self, level, d_in, n, comm, d_out, cap, packed=None, gather=None):
+        """One rank of a multi-GPU encode (bz_gpu_encode_sharded).  `comm` carries a `struct` attribute
+        holding a bz_shard_comm (sharded.TorchComm).  packed / gather: optional (pointer, words)
+        device buffers for this rank's bit strings / everybody's on rank 0.  -> stream bytes (0 on ranks > 0)."""
+        out_len = C.c_size_t(0)
+        pp, pw = packed if packed else (None, 0)
+        gp, gw = gather if gather else (None, 0)
+        _check(lib().bz_gpu_encode_sharded(self._h, level, d_in, n, C.byref(comm.struct), pp, pw, gp, gw, d_out, cap,
+                                           C.byref(out_len)))
+        return out_len.value
 
     DEC_STAGES = ("scan_huffman", "mtf", "inverse_bwt", "rle1_crc", "total")
 

@@ -17,9 +17,15 @@
 #include "../../include/bz2_mi355x.h"
 #include "bzgpu.h"
 
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 using namespace bzgpu;
@@ -43,14 +49,159 @@ extern "C" const char *bz_strerror(int code)
 
 extern "C" const char *bz_version(void) { return "bz2_mi355x 0.1 (gfx950)"; }
 
+// ---- the pipeline behind a context -------------------------------------------------------------
+// Host bytes reach the GPU in CHUNKS (BZ_ENC_CHUNK_MIB, default 64 MiB) through two pinned staging
+// buffers: bz_enc_write copies the caller's bytes into the pinned buffer being filled (the only CPU
+// copy; pieces of 4 MiB or more are split over up to four threads) and, when it is full, starts its
+// upload (hipMemcpyAsync on a copy stream) into a device staging buffer and hands the chunk to the
+// context's WORKER thread.  The worker puts the unconsumed tail of the previous chunk and the new
+// chunk side by side in device memory, replays the reference's write_block calls for them on the
+// engine (process), downloads the stream bytes through a pinned buffer and appends them to the
+// output queue.  So the upload of chunk k+1 (DMA) and the copy of chunk k+2 (CPU, caller's thread) run
+// beside the encode of chunk k; bz_enc_read hands out whatever is complete.  bz_enc_end submits the
+// partial chunk with the caller's Action and waits for the worker, so that everything the
+// reference's iterator would have yielded by then is readable.  One-shot calls (bz_encode_buffer) run
+// the same pipeline; engines and buffers of destroyed contexts are kept for the next one (a
+// per-device cache), so a call does not pay hipMalloc / hipHostMalloc again.
+struct EncResources {
+    int device = 0;
+    bz_gpu_engine *g = nullptr;
+    size_t chunk = 0;            // bytes per pinned / device staging buffer
+    u8 *h_in[2] = {nullptr, nullptr};   // pinned
+    void *d_stage[2] = {nullptr, nullptr};
+    void *d_buf[2] = {nullptr, nullptr}; // composed input: tail of the previous chunk + the chunk
+    size_t d_buf_cap[2] = {0, 0};
+    void *d_out = nullptr;
+    size_t d_out_cap = 0;
+    void *d_packed = nullptr;
+    size_t d_packed_cap = 0;
+    u8 *h_out[2] = {nullptr, nullptr};   // pinned: stream bytes on their way to the output queue
+    size_t h_out_cap[2] = {0, 0};
+    hipStream_t st_up = nullptr, st_io = nullptr, st_down = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr};
+    hipEvent_t ev_down[2] = {nullptr, nullptr};
+};
+
+static bool enc_trace()
+{
+    static const bool v = getenv("BZ_ENC_TRACE") != nullptr;
+    return v;
+}
+static double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+static std::mutex g_cache_mu;
+static std::vector<EncResources *> g_cache; // resources of destroyed contexts, ready for reuse
+
+static size_t enc_chunk_bytes()
+{
+    static const size_t v = [] {
+        const char *s = getenv("BZ_ENC_CHUNK_MIB");
+        long mib = s ? atol(s) : 64;
+        if (mib < 1) mib = 1;
+        if (mib > 1024) mib = 1024;
+        return (size_t)mib << 20;
+    }();
+    return v;
+}
+
+static void resources_free(EncResources *r)
+{
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    for (int i = 0; i < 2; ++i) {
+        if (r->h_in[i]) (void)hipHostFree(r->h_in[i]);
+        if (r->d_stage[i]) (void)hipFree(r->d_stage[i]);
+        if (r->d_buf[i]) (void)hipFree(r->d_buf[i]);
+        if (r->ev_up[i]) (void)hipEventDestroy(r->ev_up[i]);
+        if (r->ev_down[i]) (void)hipEventDestroy(r->ev_down[i]);
+        if (r->h_out[i]) (void)hipHostFree(r->h_out[i]);
+    }
+    if (r->d_out) (void)hipFree(r->d_out);
+    if (r->d_packed) (void)hipFree(r->d_packed);
+    if (r->st_up) (void)hipStreamDestroy(r->st_up);
+    if (r->st_io) (void)hipStreamDestroy(r->st_io);
+    if (r->st_down) (void)hipStreamDestroy(r->st_down);
+    if (r->g) bz_gpu_engine_destroy(r->g);
+    delete r;
+}
+
+static int resources_get(int device, EncResources **out)
+{
+    *out = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (size_t i = 0; i < g_cache.size(); ++i)
+            if (g_cache[i]->device == device && g_cache[i]->chunk == enc_chunk_bytes()) {
+                *out = g_cache[i];
+                g_cache.erase(g_cache.begin() + (ptrdiff_t)i);
+                return BZ_OK;
+            }
+    }
+    EncResources *r = new EncResources();
+    r->device = device;
+    r->chunk = enc_chunk_bytes();
+    // blocks in flight: a chunk of level-9 text is chunk / 0.9 MB blocks (lower levels and run-heavy
+    // inputs take several batches)
+    const size_t blocks = r->chunk / 800000 + 16;
+    int rc = bz_gpu_engine_create(&r->g, device, blocks);
+    if (rc != BZ_OK) {
+        delete r;
+        return rc;
+    }
+    bool ok = hipSetDevice(device) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i) {
+        ok = ok && hipHostMalloc((void **)&r->h_in[i], r->chunk, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipMalloc(&r->d_stage[i], r->chunk + 64) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&r->ev_up[i], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&r->ev_down[i], hipEventDisableTiming) == hipSuccess;
+    }
+    ok = ok && hipStreamCreateWithFlags(&r->st_up, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&r->st_io, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&r->st_down, hipStreamNonBlocking) == hipSuccess;
+    if (!ok) {
+        resources_free(r);
+        return BZ_E_NOMEM;
+    }
+    *out = r;
+    return BZ_OK;
+}
+
+static void resources_put(EncResources *r)
+{
+    if (!r) return;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if (g_cache.size() < 2) g_cache.push_back(r);
+    else resources_free(r);
+}
+
+struct EncJob {
+    int slot;        // pinned / staging buffer holding the chunk (-1: no data, only the Action)
+    size_t n;        // bytes of the chunk
+    int mode;        // BZ_ACTION_*
+    size_t tail_run; // length of the run of equal bytes at the chunk's end (n: the chunk is one run)
+};
+
 struct bz_enc {
     int level = 9;
     int device = 0;
-    bz_gpu_engine *g = nullptr;
-    std::vector<u8> in;    // input bytes since the last block cut (includes the pending run)
-    std::vector<u8> out;   // encoded bytes not yet read
-    size_t out_head = 0;
-    // reference state
+    EncResources *r = nullptr;
+    // output queue: a malloc'ed byte buffer (the drainer thread appends, bz_enc_read takes from the front;
+    // realloc grows it -- the kernel remaps large blocks instead of copying them -- and the one-shot call
+    // hands the buffer itself to its caller)
+    std::mutex out_mu;
+    u8 *out = nullptr;
+    size_t out_len = 0, out_cap = 0, out_head = 0;
+    // stream bytes leave the device through two pinned buffers: the worker starts the download of a
+    // chunk's bytes and goes on with the next chunk; the drainer waits for it and appends
+    std::thread drainer;
+    std::deque<std::pair<int, size_t>> drains; // (pinned buffer, bytes)
+    u64 drained = 0, drain_queued = 0;
+    int down_slot = 0;
+    // reference state (owned by the worker while jobs are in flight)
     bool finished = false;       // BZip2Encoder.finished      (encoder.rs:45)
     bool bit_finished = false;   // BZip2Encoder.bit_finished  (encoder.rs:48)
     bool inner_finished = false; // EncoderInner.finished      (encoder.rs:164)
@@ -58,14 +209,22 @@ struct bz_enc {
     u32 combined_crc = 0;        // encoder.rs:167
     unsigned carry_bits = 0;     // BitWriter.counter          (writer.rs:167)
     unsigned carry_byte = 0;     // BitWriter.buf              (writer.rs:166)
-    // device staging
-    void *d_in = nullptr;
-    size_t d_in_cap = 0;
-    void *d_out = nullptr;
-    size_t d_out_cap = 0;
-    void *d_packed = nullptr;
-    size_t d_packed_cap = 0;
-    size_t threshold = (size_t)64 << 20; // buffered bytes that trigger encoding of complete blocks
+    // input side (caller's thread)
+    int fill_slot = 0;
+    size_t fill = 0;
+    u64 submitted = 0;           // data chunks handed to the worker
+    // device input of the worker: d_buf[cur] holds `tail_len` unconsumed bytes at offset `tail_off`
+    int cur = 0;
+    size_t tail_off = 0, tail_len = 0;
+    // worker
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<EncJob> jobs;
+    u64 composed = 0;            // data chunks whose staging buffer the worker has released
+    u64 done = 0, queued = 0;    // jobs finished / queued
+    bool stop = false;
+    int err = BZ_OK;             // sticky
 };
 
 static int grow(void **p, size_t *cap, size_t want)
@@ -77,6 +236,345 @@ static int grow(void **p, size_t *cap, size_t want)
     const size_t sz = want + want / 4 + 4096;
     if (hipMalloc(p, sz) != hipSuccess) return BZ_E_NOMEM;
     *cap = sz;
+    return BZ_OK;
+}
+static int grow_pinned(u8 **p, size_t *cap, size_t want)
+{
+    if (want <= *cap) return BZ_OK;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t sz = want + want / 4 + 4096;
+    if (hipHostMalloc((void **)p, sz, hipHostMallocDefault) != hipSuccess) return BZ_E_NOMEM;
+    *cap = sz;
+    return BZ_OK;
+}
+
+static inline u32 rotl1(u32 v) { return (v << 1) | (v >> 31); }
+
+// Start of the pending chunk of the device input d[0..n): the run that is still open at its end, cut
+// every 255 bytes from its start (encoder.rs:676-690).  `tail_run` bytes at the end are known to be
+// equal (the caller scanned its chunk); only when that covers the whole chunk does the run reach
+// back into bytes that exist on the device alone, which are then fetched in windows from the end.
+static int pending_chunk_start(bz_enc *e, const u8 *d, size_t n, size_t chunk_n, size_t tail_run, size_t *start)
+{
+    *start = 0;
+    if (n == 0) return BZ_OK;
+    size_t run = tail_run < chunk_n ? tail_run : chunk_n;
+    if (run == 0) run = 1;
+    if (run >= chunk_n && n > run) {
+        // the whole chunk (or no chunk at all) is one run: look at the bytes in front of it
+        u8 b = 0;
+        if (hipMemcpy(&b, d + n - 1, 1, hipMemcpyDeviceToHost) != hipSuccess) return BZ_E_UNEXPECTED;
+        size_t pos = n - run; // bytes [pos, n) are equal to b
+        std::vector<u8> w;
+        size_t win = 65536;
+        while (pos > 0) {
+            const size_t k = pos < win ? pos : win;
+            w.resize(k);
+            if (hipMemcpy(w.data(), d + pos - k, k, hipMemcpyDeviceToHost) != hipSuccess) return BZ_E_UNEXPECTED;
+            size_t i = k;
+            while (i > 0 && w[i - 1] == b) --i;
+            pos -= k - i;
+            if (i > 0) break;
+            win *= 4;
+        }
+        run = n - pos;
+    }
+    (void)e;
+    const size_t rs = n - run;
+    const size_t q = n - 1 - rs;
+    *start = n - 1 - (q % 255);
+    return BZ_OK;
+}
+
+// appends to the output queue (out_mu held by the caller)
+static int out_append_locked(bz_enc *e, const u8 *p, size_t n)
+{
+    if (e->out_head && e->out_head == e->out_len) e->out_head = e->out_len = 0;
+    if (e->out_len + n > e->out_cap) {
+        if (e->out_head) { // make room by dropping what has been read
+            memmove(e->out, e->out + e->out_head, e->out_len - e->out_head);
+            e->out_len -= e->out_head;
+            e->out_head = 0;
+        }
+        if (e->out_len + n > e->out_cap) {
+            const size_t want = std::max(e->out_len + n, e->out_cap + e->out_cap / 2 + 4096);
+            u8 *q = (u8 *)realloc(e->out, want);
+            if (!q) return BZ_E_NOMEM;
+            e->out = q;
+            e->out_cap = want;
+        }
+    }
+    memcpy(e->out + e->out_len, p, n);
+    e->out_len += n;
+    return BZ_OK;
+}
+
+static void drainer_main(bz_enc *e)
+{
+    for (;;) {
+        std::pair<int, size_t> d;
+        {
+            std::unique_lock<std::mutex> lk(e->mu);
+            e->cv.wait(lk, [&] { return e->stop || !e->drains.empty(); });
+            if (e->drains.empty()) return; // stop
+            d = e->drains.front();
+            e->drains.pop_front();
+        }
+        int rc;
+        {
+            std::lock_guard<std::mutex> lk(e->out_mu);
+            rc = out_append_locked(e, e->r->h_out[d.first], d.second);
+        }
+        {
+            std::lock_guard<std::mutex> lk(e->mu);
+            if (rc != BZ_OK && e->err == BZ_OK) e->err = rc;
+            e->drained += 1;
+        }
+        e->cv.notify_all();
+    }
+}
+
+// One bulk replay of the write_block calls the reference would have made for `mode` over the device
+// input d[0..n_all) (worker thread).  *drop = input bytes that went into blocks.
+static int process(bz_enc *e, const u8 *d, size_t n_all, size_t chunk_n, size_t tail_run, int mode, size_t *drop)
+{
+    EncResources *r = e->r;
+    *drop = 0;
+    size_t n_eff = n_all;
+    int rc;
+    if (mode != BZ_ACTION_FINISH && (rc = pending_chunk_start(e, d, n_all, chunk_n, tail_run, &n_eff)) != BZ_OK) return rc;
+    size_t n_blocks = 0, consumed = 0;
+    int tail = 0;
+    std::vector<uint64_t> woff, blen;
+    std::vector<uint32_t> crc;
+    const double t0 = now_ms();
+    double t1 = t0, t2 = t0;
+    if (n_eff > 0) {
+        rc = bz_gpu_partition(r->g, e->level, d, n_eff, mode, &n_blocks, &consumed, &tail);
+        if (rc != BZ_OK) return rc;
+        t1 = now_ms();
+        if (n_blocks) {
+            woff.resize(n_blocks);
+            blen.resize(n_blocks);
+            crc.resize(n_blocks);
+            const size_t cap_words = bz_encode_bound(n_eff) / 4 + 2 * n_blocks + 16;
+            if ((rc = grow(&r->d_packed, &r->d_packed_cap, cap_words * 4)) != BZ_OK) return rc;
+            size_t used = 0;
+            rc = bz_gpu_encode_blocks(r->g, 0, 1, r->d_packed, cap_words, woff.data(), blen.data(), crc.data(), &used);
+            if (rc != BZ_OK) return rc;
+        }
+        t2 = now_ms();
+    }
+    if (mode == BZ_ACTION_RUN && n_blocks == 0) return BZ_OK; // no write_block call happened
+
+    // The flush()/finish() call itself sees an empty block_buf when every byte went into
+    // blocks closed by a cut (or there was nothing at all).
+    const bool final_call_empty =
+        (mode == BZ_ACTION_FLUSH && !(n_blocks > 0 && tail)) || (mode == BZ_ACTION_FINISH && n_blocks == 0);
+    u32 comb = e->combined_crc;
+    const int write_header = e->any_block ? 0 : 1; // block_no == 1 (encoder.rs:245)
+    if (final_call_empty && n_blocks == 0) comb = rotl1(comb) ^ 0u; // encoder.rs:237-238, crc of nothing = 0
+    const int trailer = (mode == BZ_ACTION_FINISH) ? 1 : 0;
+
+    size_t bits_bound = 0;
+    for (size_t k = 0; k < n_blocks; ++k) bits_bound += (size_t)blen[k];
+    const size_t out_cap = bits_bound / 8 + 64;
+    if ((rc = grow(&r->d_out, &r->d_out_cap, out_cap)) != BZ_OK) return rc;
+    size_t out_len = 0;
+    unsigned ocb = 0, ocy = 0;
+    u32 comb_out = comb;
+    rc = bz_gpu_assemble(r->g, e->level, n_blocks, r->d_packed, woff.data(), blen.data(), crc.data(), write_header,
+                         trailer, 0, e->carry_bits, e->carry_byte, comb, &comb_out, r->d_out, r->d_out_cap, &out_len,
+                         &ocb, &ocy);
+    if (rc != BZ_OK) return rc;
+    if (out_len) {
+        // device -> pinned buffer (waited for: the next chunk's assembly reuses d_out), then over to the
+        // drainer thread, which appends to the output queue while the worker goes on
+        const int s = e->down_slot;
+        {
+            std::unique_lock<std::mutex> lk(e->mu);
+            e->cv.wait(lk, [&] { return e->drained + 2 > e->drain_queued; }); // pinned buffer s is free again
+        }
+        if ((rc = grow_pinned(&r->h_out[s], &r->h_out_cap[s], out_len)) != BZ_OK) return rc;
+        if (hipMemcpyAsync(r->h_out[s], r->d_out, out_len, hipMemcpyDeviceToHost, r->st_io) != hipSuccess ||
+            hipStreamSynchronize(r->st_io) != hipSuccess)
+            return BZ_E_UNEXPECTED;
+        {
+            std::lock_guard<std::mutex> lk(e->mu);
+            e->drains.emplace_back(s, out_len);
+            e->drain_queued += 1;
+        }
+        e->cv.notify_all();
+        e->down_slot ^= 1;
+    }
+    if (enc_trace())
+        fprintf(stderr, "bz_enc job: mode %d, %zu bytes, %zu blocks: split %.2f ms, encode %.2f ms, assemble+download %.2f ms (at %.1f)\n",
+                mode, n_all, n_blocks, t1 - t0, t2 - t1, now_ms() - t2, now_ms());
+    e->carry_bits = ocb;
+    e->carry_byte = ocy;
+    if (final_call_empty && n_blocks > 0) comb_out = rotl1(comb_out); // the extra, empty write_block(false)
+    e->combined_crc = comb_out;
+    if (n_blocks > 0) e->any_block = true;
+    // the bytes that went into blocks
+    *drop = (mode == BZ_ACTION_RUN) ? consumed : n_eff;
+    if (mode == BZ_ACTION_FINISH) {
+        *drop = n_all;
+        e->inner_finished = true;
+    }
+    return BZ_OK;
+}
+
+// worker: one job = (optional chunk of input) + the Action it arrived under
+static int run_job(bz_enc *e, const EncJob &j)
+{
+    EncResources *r = e->r;
+    if (hipSetDevice(e->device) != hipSuccess) return BZ_E_UNEXPECTED;
+    if (e->inner_finished) {
+        // Input that arrives after Finish is not encoded.  (The reference keeps collecting it, EncoderInner::next
+        // has no `finished` test, encoder.rs:671-697, and would write further blocks BEHIND the trailer once
+        // another 900 KB have come in; flush() and finish() do nothing any more, :718-739.  Such output is no
+        // .bz2 stream; the corner is not mirrored -- documented in INTEGRATION.md.)
+        if (j.n) {
+            if (hipEventSynchronize(r->ev_up[j.slot]) != hipSuccess) return BZ_E_UNEXPECTED;
+            {
+                std::lock_guard<std::mutex> lk(e->mu);
+                e->composed += 1;
+            }
+            e->cv.notify_all();
+        }
+        return BZ_OK;
+    }
+    const size_t n_all = e->tail_len + j.n;
+    const u8 *d = nullptr;
+    if (j.n) {
+        // compose: the unconsumed tail of the previous input, then the new chunk
+        const int other = e->cur ^ 1;
+        int rc = grow(&r->d_buf[other], &r->d_buf_cap[other], n_all + 64);
+        if (rc != BZ_OK) return rc;
+        if (e->tail_len &&
+            hipMemcpyAsync(r->d_buf[other], (const u8 *)r->d_buf[e->cur] + e->tail_off, e->tail_len, hipMemcpyDeviceToDevice,
+                           r->st_io) != hipSuccess)
+            return BZ_E_UNEXPECTED;
+        if (hipStreamWaitEvent(r->st_io, r->ev_up[j.slot], 0) != hipSuccess) return BZ_E_UNEXPECTED;
+        if (hipMemcpyAsync((u8 *)r->d_buf[other] + e->tail_len, r->d_stage[j.slot], j.n, hipMemcpyDeviceToDevice, r->st_io) !=
+                hipSuccess ||
+            hipStreamSynchronize(r->st_io) != hipSuccess)
+            return BZ_E_UNEXPECTED;
+        e->cur = other;
+        e->tail_off = 0;
+        e->tail_len = n_all;
+        {
+            std::lock_guard<std::mutex> lk(e->mu);
+            e->composed += 1; // the staging buffer may take the next upload
+        }
+        e->cv.notify_all();
+        d = (const u8 *)r->d_buf[e->cur];
+    } else if (e->tail_len) {
+        // (the composed input is 16-byte aligned at offset 0 only: move a tail that is not at the start)
+        if (e->tail_off) {
+            const int other = e->cur ^ 1;
+            int rc = grow(&r->d_buf[other], &r->d_buf_cap[other], n_all + 64);
+            if (rc != BZ_OK) return rc;
+            if (hipMemcpyAsync(r->d_buf[other], (const u8 *)r->d_buf[e->cur] + e->tail_off, e->tail_len, hipMemcpyDeviceToDevice,
+                               r->st_io) != hipSuccess ||
+                hipStreamSynchronize(r->st_io) != hipSuccess)
+                return BZ_E_UNEXPECTED;
+            e->cur = other;
+            e->tail_off = 0;
+        }
+        d = (const u8 *)r->d_buf[e->cur];
+    }
+    size_t drop = 0;
+    const int rc = process(e, d, n_all, j.n, j.tail_run, j.mode, &drop);
+    if (rc != BZ_OK) return rc;
+    e->tail_off += drop;
+    e->tail_len = n_all - drop;
+    return BZ_OK;
+}
+
+static void worker_main(bz_enc *e)
+{
+    for (;;) {
+        EncJob j;
+        {
+            std::unique_lock<std::mutex> lk(e->mu);
+            e->cv.wait(lk, [&] { return e->stop || !e->jobs.empty(); });
+            if (e->jobs.empty()) return; // stop
+            j = e->jobs.front();
+            e->jobs.pop_front();
+        }
+        int rc = BZ_OK;
+        {
+            std::unique_lock<std::mutex> lk(e->mu);
+            rc = e->err;
+        }
+        if (rc == BZ_OK) rc = run_job(e, j);
+        {
+            std::lock_guard<std::mutex> lk(e->mu);
+            if (rc != BZ_OK && e->err == BZ_OK) e->err = rc;
+            if (rc != BZ_OK && j.n) e->composed = e->submitted; // nobody waits for a staging buffer of a failed context
+            e->done += 1;
+        }
+        e->cv.notify_all();
+    }
+}
+
+static int ensure_started(bz_enc *e)
+{
+    if (e->r) return BZ_OK;
+    int rc = resources_get(e->device, &e->r);
+    if (rc != BZ_OK) return rc;
+    e->worker = std::thread(worker_main, e);
+    e->drainer = std::thread(drainer_main, e);
+    return BZ_OK;
+}
+
+// hands the chunk being filled (possibly empty) to the worker together with `mode`
+static int submit(bz_enc *e, int mode, bool wait)
+{
+    EncResources *r = e->r;
+    EncJob j;
+    j.slot = -1;
+    j.n = e->fill;
+    j.mode = mode;
+    j.tail_run = 0;
+    if (e->fill) {
+        const int s = e->fill_slot;
+        const u8 *h = r->h_in[s];
+        size_t run = 1;
+        while (run < e->fill && h[e->fill - 1 - run] == h[e->fill - 1]) ++run;
+        j.tail_run = run;
+        j.slot = s;
+        {
+            // the device staging buffer of this slot is free once the worker has composed the chunk
+            // that used it last (two chunks back)
+            std::unique_lock<std::mutex> lk(e->mu);
+            e->cv.wait(lk, [&] { return e->submitted < 2 || e->composed + 2 > e->submitted || e->err != BZ_OK; });
+            if (e->err != BZ_OK) return e->err;
+        }
+        if (enc_trace()) fprintf(stderr, "bz_enc upload: %zu bytes from pinned buffer %d (at %.1f)\n", e->fill, s, now_ms());
+        if (hipSetDevice(e->device) != hipSuccess) return BZ_E_UNEXPECTED;
+        if (hipMemcpyAsync(r->d_stage[s], h, e->fill, hipMemcpyHostToDevice, r->st_up) != hipSuccess ||
+            hipEventRecord(r->ev_up[s], r->st_up) != hipSuccess)
+            return BZ_E_UNEXPECTED;
+        e->fill_slot ^= 1;
+        e->fill = 0;
+    }
+    u64 ticket;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (j.n) e->submitted += 1;
+        e->jobs.push_back(j);
+        ticket = ++e->queued;
+    }
+    e->cv.notify_all();
+    if (wait) { // until the job is done and its bytes are in the output queue
+        std::unique_lock<std::mutex> lk(e->mu);
+        e->cv.wait(lk, [&] { return e->done >= ticket && e->drained >= e->drain_queued; });
+        return e->err;
+    }
     return BZ_OK;
 }
 
@@ -95,131 +593,98 @@ extern "C" int bz_enc_create(bz_enc **out, int level, int device)
 extern "C" void bz_enc_destroy(bz_enc *e)
 {
     if (!e) return;
-    if (e->g) {
+    if (e->r) {
+        {
+            std::lock_guard<std::mutex> lk(e->mu);
+            e->stop = true;
+        }
+        e->cv.notify_all();
+        if (e->worker.joinable()) e->worker.join();
+        if (e->drainer.joinable()) e->drainer.join();
         (void)hipSetDevice(e->device);
-        if (e->d_in) (void)hipFree(e->d_in);
-        if (e->d_out) (void)hipFree(e->d_out);
-        if (e->d_packed) (void)hipFree(e->d_packed);
-        bz_gpu_engine_destroy(e->g);
+        (void)hipStreamSynchronize(e->r->st_up);
+        (void)hipStreamSynchronize(e->r->st_io);
+        if (e->err == BZ_OK) resources_put(e->r);
+        else resources_free(e->r);
     }
+    free(e->out);
     delete e;
 }
 
-// start of the pending chunk: the run that is still open at the end of the buffer, cut
-// every 255 bytes from its start (encoder.rs:676-690)
-static size_t pending_chunk_start(const std::vector<u8> &in)
+static void copy_in(u8 *dst, const u8 *src, size_t n)
 {
-    const size_t n = in.size();
-    if (n == 0) return 0;
-    size_t rs = n - 1;
-    const u8 b = in[n - 1];
-    while (rs > 0 && in[rs - 1] == b) --rs;
-    const size_t q = n - 1 - rs;
-    return n - 1 - (q % 255);
-}
-
-static inline u32 rotl1(u32 v) { return (v << 1) | (v >> 31); }
-
-// One bulk replay of the write_block calls the reference would have made for `mode`.
-static int process(bz_enc *e, int mode)
-{
-    const size_t n_all = e->in.size();
-    const size_t n_eff = (mode == BZ_ACTION_FINISH) ? n_all : pending_chunk_start(e->in);
-    size_t n_blocks = 0, consumed = 0;
-    int tail = 0;
-    std::vector<uint64_t> woff, blen;
-    std::vector<uint32_t> crc;
-    int rc;
-    if (n_eff > 0) {
-        if (!e->g) {
-            rc = bz_gpu_engine_create(&e->g, e->device, 80);
-            if (rc != BZ_OK) return rc;
-        }
-        if (hipSetDevice(e->device) != hipSuccess) return BZ_E_UNEXPECTED;
-        if ((rc = grow(&e->d_in, &e->d_in_cap, n_eff + 64)) != BZ_OK) return rc;
-        if (hipMemcpy(e->d_in, e->in.data(), n_eff, hipMemcpyHostToDevice) != hipSuccess) return BZ_E_UNEXPECTED;
-        rc = bz_gpu_partition(e->g, e->level, e->d_in, n_eff, mode, &n_blocks, &consumed, &tail);
-        if (rc != BZ_OK) return rc;
-        if (n_blocks) {
-            woff.resize(n_blocks);
-            blen.resize(n_blocks);
-            crc.resize(n_blocks);
-            const size_t cap_words = bz_encode_bound(n_eff) / 4 + 2 * n_blocks + 16;
-            if ((rc = grow(&e->d_packed, &e->d_packed_cap, cap_words * 4)) != BZ_OK) return rc;
-            size_t used = 0;
-            rc = bz_gpu_encode_blocks(e->g, 0, 1, e->d_packed, cap_words, woff.data(), blen.data(), crc.data(),
-                                      &used);
-            if (rc != BZ_OK) return rc;
-        }
+    // the one CPU copy of the input: caller's memory -> pinned staging; large pieces on several threads
+    constexpr size_t kPar = (size_t)4 << 20;
+    if (n < kPar) {
+        memcpy(dst, src, n);
+        return;
     }
-    if (mode == BZ_ACTION_RUN && n_blocks == 0) return BZ_OK; // no write_block call happened
-
-    // The flush()/finish() call itself sees an empty block_buf when every byte went into
-    // blocks closed by a cut (or there was nothing at all).
-    const bool final_call_empty =
-        (mode == BZ_ACTION_FLUSH && !(n_blocks > 0 && tail)) || (mode == BZ_ACTION_FINISH && n_blocks == 0);
-    u32 comb = e->combined_crc;
-    int write_header = e->any_block ? 0 : 1; // block_no == 1 (encoder.rs:245)
-    if (final_call_empty && n_blocks == 0) comb = rotl1(comb) ^ 0u; // encoder.rs:237-238, crc of nothing = 0
-    const int trailer = (mode == BZ_ACTION_FINISH) ? 1 : 0;
-
-    size_t bits_bound = 0;
-    for (size_t k = 0; k < n_blocks; ++k) bits_bound += (size_t)blen[k];
-    const size_t out_cap = bits_bound / 8 + 64;
-    if (!e->g) { // nothing was ever encoded: frame bits only
-        rc = bz_gpu_engine_create(&e->g, e->device, 80);
-        if (rc != BZ_OK) return rc;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nt = hw >= 8 ? 4 : (hw >= 4 ? 2 : 1);
+    if (nt == 1) {
+        memcpy(dst, src, n);
+        return;
     }
-    if ((rc = grow(&e->d_out, &e->d_out_cap, out_cap)) != BZ_OK) return rc;
-    size_t out_len = 0;
-    unsigned ocb = 0, ocy = 0;
-    u32 comb_out = comb;
-    rc = bz_gpu_assemble(e->g, e->level, n_blocks, e->d_packed, woff.data(), blen.data(), crc.data(), write_header,
-                         trailer, 0, e->carry_bits, e->carry_byte, comb, &comb_out, e->d_out, e->d_out_cap, &out_len,
-                         &ocb, &ocy);
-    if (rc != BZ_OK) return rc;
-    if (out_len) {
-        const size_t old = e->out.size();
-        e->out.resize(old + out_len);
-        if (hipMemcpy(e->out.data() + old, e->d_out, out_len, hipMemcpyDeviceToHost) != hipSuccess)
-            return BZ_E_UNEXPECTED;
+    std::vector<std::thread> th;
+    const size_t per = (n / nt + 4095) & ~(size_t)4095;
+    for (size_t t = 1; t < nt; ++t) {
+        const size_t a = t * per, b = (t + 1 == nt) ? n : (t + 1) * per;
+        if (a < n) th.emplace_back([=] { memcpy(dst + a, src + a, (b < n ? b : n) - a); });
     }
-    e->carry_bits = ocb;
-    e->carry_byte = ocy;
-    if (final_call_empty && n_blocks > 0) comb_out = rotl1(comb_out); // the extra, empty write_block(false)
-    e->combined_crc = comb_out;
-    if (n_blocks > 0) e->any_block = true;
-    // drop the bytes that went into blocks
-    size_t drop = (mode == BZ_ACTION_RUN) ? consumed : n_eff;
-    if (mode == BZ_ACTION_FINISH) drop = n_all;
-    if (drop) e->in.erase(e->in.begin(), e->in.begin() + (ptrdiff_t)drop);
-    if (mode == BZ_ACTION_FINISH) e->inner_finished = true;
-    return BZ_OK;
+    memcpy(dst, src, per < n ? per : n);
+    for (auto &t : th) t.join();
 }
 
 extern "C" int bz_enc_write(bz_enc *e, const uint8_t *in, size_t n)
 {
     if (!e || (!in && n)) return BZ_E_PARAM;
-    e->in.insert(e->in.end(), in, in + n);
-    if (!e->inner_finished && e->in.size() >= e->threshold) return process(e, BZ_ACTION_RUN);
-    return BZ_OK;
+    if (n == 0) return e->err;
+    int rc = ensure_started(e);
+    if (rc != BZ_OK) return rc;
+    EncResources *r = e->r;
+    while (n) {
+        if (e->fill == 0) {
+            // the pinned buffer of this slot is free once its last upload has completed
+            if (hipSetDevice(e->device) != hipSuccess || hipEventSynchronize(r->ev_up[e->fill_slot]) != hipSuccess)
+                return BZ_E_UNEXPECTED;
+        }
+        const size_t k = std::min(n, r->chunk - e->fill);
+        copy_in(r->h_in[e->fill_slot] + e->fill, in, k);
+        e->fill += k;
+        in += k;
+        n -= k;
+        if (e->fill == r->chunk) {
+            // complete blocks of this chunk are encoded while the caller goes on writing (after Finish
+            // the reference ignores further input: inner_finished is checked by the worker's state)
+            if ((rc = submit(e, BZ_ACTION_RUN, false)) != BZ_OK) return rc;
+        }
+    }
+    std::lock_guard<std::mutex> lk(e->mu);
+    return e->err;
 }
 
 extern "C" int bz_enc_end(bz_enc *e, int action)
 {
     if (!e || action < BZ_ACTION_RUN || action > BZ_ACTION_FINISH) return BZ_E_PARAM;
-    int rc;
+    int rc = ensure_started(e);
+    if (rc != BZ_OK) return rc;
+    // everything below looks at state the worker owns: wait for the jobs in flight first
+    {
+        std::unique_lock<std::mutex> lk(e->mu);
+        e->cv.wait(lk, [&] { return e->done >= e->queued && e->drained >= e->drain_queued; });
+        if (e->err != BZ_OK) return e->err;
+    }
     // blocks the reference would already have emitted while it was consuming the input
     if (!e->inner_finished && action == BZ_ACTION_RUN) {
-        if ((rc = process(e, BZ_ACTION_RUN)) != BZ_OK) return rc;
+        if ((rc = submit(e, BZ_ACTION_RUN, true)) != BZ_OK) return rc;
     }
     for (;;) {
         // next_bits: queue empty and the iterator is exhausted (encoder.rs:86-110)
         if (!e->finished) {
             if (action == BZ_ACTION_FLUSH && !e->inner_finished) {       // :718-727
-                if ((rc = process(e, BZ_ACTION_FLUSH)) != BZ_OK) return rc;
+                if ((rc = submit(e, BZ_ACTION_FLUSH, true)) != BZ_OK) return rc;
             } else if (action == BZ_ACTION_FINISH && !e->inner_finished) { // :729-739
-                if ((rc = process(e, BZ_ACTION_FINISH)) != BZ_OK) return rc;
+                if ((rc = submit(e, BZ_ACTION_FINISH, true)) != BZ_OK) return rc;
             }
             e->finished = true;
         }
@@ -232,27 +697,39 @@ extern "C" int bz_enc_end(bz_enc *e, int action)
         if (action == BZ_ACTION_RUN) break;
         e->bit_finished = true;
         if (e->carry_bits == 0) break; // writer.flush() -> None (writer.rs:226-242)
-        e->out.push_back((u8)e->carry_byte);
+        {
+            std::lock_guard<std::mutex> lk(e->out_mu);
+            const u8 b = (u8)e->carry_byte;
+            if ((rc = out_append_locked(e, &b, 1)) != BZ_OK) return rc;
+        }
         e->carry_bits = 0;
         e->carry_byte = 0;
     }
     return BZ_OK;
 }
 
-extern "C" size_t bz_enc_pending(const bz_enc *e) { return e ? e->out.size() - e->out_head : 0; }
+extern "C" size_t bz_enc_pending(const bz_enc *e)
+{
+    if (!e) return 0;
+    bz_enc *m = const_cast<bz_enc *>(e);
+    std::lock_guard<std::mutex> lk(m->out_mu);
+    return e->out_len - e->out_head;
+}
 
 extern "C" long bz_enc_read(bz_enc *e, uint8_t *out, size_t cap)
 {
     if (!e || (!out && cap)) return BZ_E_PARAM;
-    const size_t avail = e->out.size() - e->out_head;
-    const size_t k = avail < cap ? avail : cap;
-    if (k) memcpy(out, e->out.data() + e->out_head, k);
-    e->out_head += k;
-    if (e->out_head == e->out.size()) {
-        e->out.clear();
-        e->out_head = 0;
+    {
+        std::lock_guard<std::mutex> lk(e->out_mu);
+        const size_t avail = e->out_len - e->out_head;
+        const size_t k = avail < cap ? avail : cap;
+        if (k) memcpy(out, e->out + e->out_head, k);
+        e->out_head += k;
+        if (e->out_head == e->out_len) e->out_head = e->out_len = 0;
+        if (k) return (long)k;
     }
-    return (long)k;
+    std::lock_guard<std::mutex> lk(e->mu);
+    return e->err != BZ_OK ? (long)e->err : 0;
 }
 
 extern "C" void bz_free(void *p) { free(p); }
@@ -264,37 +741,27 @@ extern "C" int bz_encode_buffer(int level, int device, const uint8_t *in, size_t
     *out = nullptr;
     *out_len = 0;
     if (level < 1 || level > 9) return BZ_E_PARAM;
-    const size_t est_blocks = in_len / 700000 + 2;
-    bz_gpu_engine *g = nullptr;
-    int rc = bz_gpu_engine_create(&g, device, est_blocks < 256 ? est_blocks : 256);
+    bz_enc *e = nullptr;
+    int rc = bz_enc_create(&e, level, device);
     if (rc != BZ_OK) return rc;
-    void *d_in = nullptr, *d_out = nullptr;
-    const size_t cap = (bz_encode_bound(in_len) + 15) & ~(size_t)15;
-    uint8_t *h = nullptr;
-    size_t n_out = 0;
-    rc = BZ_E_NOMEM;
-    if (hipMalloc(&d_in, in_len + 64) != hipSuccess) goto done;
-    if (hipMalloc(&d_out, cap) != hipSuccess) goto done;
-    rc = BZ_E_UNEXPECTED;
-    if (in_len && hipMemcpy(d_in, in, in_len, hipMemcpyHostToDevice) != hipSuccess) goto done;
-    rc = bz_gpu_encode_device(g, level, d_in, in_len, d_out, cap, &n_out);
-    if (rc != BZ_OK) goto done;
-    h = (uint8_t *)malloc(n_out ? n_out : 1);
-    if (!h) {
-        rc = BZ_E_NOMEM;
-        goto done;
+    // the same pipeline as the streaming context: chunks are uploaded and encoded while the rest of the
+    // input is still being copied to the pinned staging buffers
+    if (in_len) rc = bz_enc_write(e, in, in_len);
+    if (rc == BZ_OK) rc = bz_enc_end(e, BZ_ACTION_FINISH);
+    if (rc == BZ_OK) {
+        std::lock_guard<std::mutex> lk(e->out_mu);
+        // the output queue's buffer itself goes to the caller (nothing has been read from it)
+        if (!e->out) e->out = (u8 *)malloc(1);
+        if (!e->out) {
+            rc = BZ_E_NOMEM;
+        } else {
+            if (e->out_head) memmove(e->out, e->out + e->out_head, e->out_len - e->out_head);
+            *out = e->out;
+            *out_len = e->out_len - e->out_head;
+            e->out = nullptr;
+            e->out_len = e->out_cap = e->out_head = 0;
+        }
     }
-    if (hipMemcpy(h, d_out, n_out, hipMemcpyDeviceToHost) != hipSuccess) {
-        free(h);
-        rc = BZ_E_UNEXPECTED;
-        goto done;
-    }
-    *out = h;
-    *out_len = n_out;
-    rc = BZ_OK;
-done:
-    if (d_in) (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
-    bz_gpu_engine_destroy(g);
+    bz_enc_destroy(e);
     return rc;
 }

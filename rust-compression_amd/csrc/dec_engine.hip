@@ -161,6 +161,7 @@ struct Shard {
     bz_allgather_fn allgather = nullptr;
     void *ctx = nullptr;
     u64 out_offset = 0, total_len = 0; // results
+    int phase = 0; // exchanges this rank has been through: 0 none, 1 the candidate records, 2 all (or the transport failed)
 };
 } // namespace
 
@@ -259,7 +260,11 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             if (fit < (size_t)B + kForcedSlots) B = fit > kForcedSlots + 1 ? (u32)(fit - kForcedSlots) : 1u;
         }
     }
-    if (sh && B < B_want) return BZ_E_NOMEM; // a rank's share has to fit one batch
+    if (sh && B < B_want) return BZ_E_NOMEM; // a rank's share has to fit one batch (reported to the peers by the caller)
+    int inject_rank = -1, inject_phase = -1; // (tests) BZ_DEC_SHARD_FAIL=<rank>:<phase>: that rank fails on its own there
+    if (sh)
+        if (const char *e = getenv("BZ_DEC_SHARD_FAIL")) (void)sscanf(e, "%d:%d", &inject_rank, &inject_phase);
+    if (sh && inject_rank == sh->rank && inject_phase == 0) return BZ_E_NOMEM;
     {
         const int rc = dec_ensure(w, (size_t)B + kForcedSlots);
         if (rc) return rc;
@@ -319,6 +324,23 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             d1_rec = -1;
         }
         if (sh) {
+            // Before the exchange whose size depends on the scan: 8 bytes of status per rank.  A rank that
+            // failed on its own before this point (memory, a HIP error) reports it here (the caller of
+            // decode_core does, bz_gpu_decode_device_sharded) and every rank returns that error instead of
+            // waiting in a collective its peer never enters.
+            {
+                int64_t st0 = 0;
+                std::vector<int64_t> sts((size_t)sh->world, 0);
+                if (sh->allgather(sh->ctx, &st0, 8, sts.data()) != 0) {
+                    sh->phase = 2;
+                    return BZ_E_UNEXPECTED;
+                }
+                for (int r = 0; r < sh->world; ++r)
+                    if (sts[(size_t)r] != 0) {
+                        sh->phase = 2;
+                        return (int)sts[(size_t)r];
+                    }
+            }
             // exchange: every rank learns what the chain needs about every candidate
             const size_t maxc = (nc + (size_t)sh->world - 1) / (size_t)sh->world;
             std::vector<ShardRec> mine(maxc ? maxc : 1), all((maxc ? maxc : 1) * (size_t)sh->world);
@@ -330,7 +352,12 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                 mine[i].next_head = hphys[i].next_head;
                 mine[i].next_bits = hphys[i].next_bits;
             }
-            if (sh->allgather(sh->ctx, mine.data(), mine.size() * sizeof(ShardRec), all.data()) != 0) return BZ_E_UNEXPECTED;
+            if (sh->allgather(sh->ctx, mine.data(), mine.size() * sizeof(ShardRec), all.data()) != 0) {
+                sh->phase = 2;
+                return BZ_E_UNEXPECTED;
+            }
+            sh->phase = 1; // from here on a rank-local error travels in the second exchange (ShardSum.pad)
+            if (inject_rank == sh->rank && inject_phase == 1) return BZ_E_UNEXPECTED;
             for (int r = 0; r < sh->world; ++r) {
                 const size_t r0 = nc * (size_t)r / (size_t)sh->world, r1 = nc * (size_t)(r + 1) / (size_t)sh->world;
                 for (size_t i = r0; i < r1; ++i) {
@@ -414,7 +441,13 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                     w->stats[3] += 1;
                 }
                 const DecBlockInfo &bi = hinfo[slot];
-                if (partial && (bi.status || bi.end_bit + 64 > nbits)) { // cut off, perhaps: look again with more input
+                // (partial) a block that ends at the edge of what has arrived, or fails and starts within one
+                // maximal block of that edge, may just be cut off: look again with more input.  A block that
+                // fails further in front cannot be repaired by more input (a record is at most a header of
+                // < 2^16 bits and 900001 codes of <= 20 bits): its verdict is final now, and the context does
+                // not keep -- and re-scan -- everything behind it until the input ends.
+                constexpr u64 kMaxRecordBits = 65536ull + 900001ull * 20ull;
+                if (partial && (bi.end_bit + 64 > nbits || (bi.status && nbits - rec_pos <= kMaxRecordBits))) {
                     term = 2;
                     break;
                 }
@@ -623,6 +656,7 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             mine.fail_ord = (local_fail == ~0ull) ? ~0ull : my_first_ord + local_fail;
             mine.first_ord = my_first_ord;
             mine.pad = (u64)(u32)(-shard_rc);
+            sh->phase = 2;
             if (sh->allgather(sh->ctx, &mine, sizeof(mine), sums.data()) != 0) return BZ_E_UNEXPECTED;
             for (const ShardSum &s : sums)
                 if (s.pad) return -(int)s.pad; // some rank could not hold its slice (BZ_E_CAPACITY ...)
@@ -707,6 +741,23 @@ extern "C" int bz_gpu_decode_device_sharded(bz_gpu_engine *g, const void *d_in, 
     sh.ctx = ctx;
     int verdict = BZ_OK;
     const int rc = decode_core(g, static_cast<const u8 *>(d_in), n, sink, &verdict, &sh);
+    if (rc != BZ_OK && sh.phase < 2) {
+        // this rank failed on its own in front of an exchange its peers are about to enter: go through
+        // that exchange with the error in the status word (they return it too)
+        if (sh.phase == 0) {
+            int64_t st0 = rc;
+            std::vector<int64_t> sts((size_t)world, 0);
+            (void)allgather(ctx, &st0, 8, sts.data());
+        } else {
+            ShardSum mine;
+            mine.bytes = 0;
+            mine.fail_ord = ~0ull;
+            mine.first_ord = ~0ull;
+            mine.pad = (u64)(u32)(-rc);
+            std::vector<ShardSum> sums((size_t)world);
+            (void)allgather(ctx, &mine, sizeof(mine), sums.data());
+        }
+    }
     *out_len = (size_t)sink.produced;
     *out_offset = (size_t)sh.out_offset;
     *total_len = (size_t)sh.total_len;

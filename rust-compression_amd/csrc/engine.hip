@@ -172,7 +172,7 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
                      &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->bin_base, &g->sym_code, &g->keyinfo, &g->count2, &g->tile_nf, &g->L, &g->orig_ptr, &g->inuse_bits,
                      &g->summ, &g->summ_len, &g->init_state, &g->rank8, &g->ztile_last, &g->ztile_cnt, &g->mtf,
                      &g->mtf_freq, &g->bout, &g->selector, &g->code_len, &g->group_bitoff, &g->lm_scratch,
-                     &g->stream, &g->error_flag, &g->packlist, &g->packed, &g->asmlist, &g->gh_tiles, &g->gbase, &g->tile_state,
+                     &g->stream, &g->error_flag, &g->packlist, &g->packed, &g->gathered, &g->asmlist, &g->gh_tiles, &g->gbase, &g->tile_state,
                      &g->tickets};
     for (DevBuf *b : all) b->release();
     dec_workspace_free(g->dec);
@@ -365,7 +365,7 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
     x.gbase = g->gbase.as<u32>() + (size_t)o * 3 * kMaxBins;
     x.tile_state = g->tile_state.as<u32>() + t * kMaxBins;
     x.tickets = g->tickets.as<u32>();
-    x.sort_err = g->tickets.as<u32>() + (size_t)kSortEpochs * 8;
+    x.sort_err = g->tickets.p ? g->tickets.as<u32>() + (size_t)kSortEpochs * 8 : nullptr; // (no fused passes: not allocated)
     x.epoch = &g->sort_epoch;
     x.tile_state_all = g->tile_state.as<u32>();
     x.tile_state_bytes = g->tile_state.cap;
@@ -651,6 +651,212 @@ extern "C" int bz_gpu_encode_device(bz_gpu_engine *g, int level, const void *d_i
     }
     return bz_gpu_assemble(g, level, nblocks, g->packed.p, woff.data(), blen.data(), crc.data(), 1, 1, 1, 0, 0, 0,
                            nullptr, d_out, cap, out_len, nullptr, nullptr);
+}
+
+// ---- the whole stream over several GPUs: one process (one engine) per GPU --------------------------
+// Rank r splits its SLAB of the input (an equal share of the 4 KiB tiles), encodes the blocks that
+// end in it and hands their bit strings to rank 0, which assembles the serial stream.  What crosses
+// ranks (all through the caller's bz_shard_comm; RCCL, MPI or torch.distributed sit behind it):
+//   1. all-gather of 8 bytes per rank: the last run start inside each slab (the RLE1 phase at
+//      every slab's left edge);
+//   2. the cut chain: rank r-1 tells rank r where r's first block starts (16 bytes per hop: the
+//      position and the sender's status, so that an error runs down the chain instead of leaving
+//      the later ranks waiting);
+//   3. all-gather of 24 bytes per rank (block count, words, status), then of 24 bytes per block
+//      (word offset, bit length, CRC), padded to the largest count;
+//   4. ONE variable-length gather of the packed bit strings (device memory) to rank 0.
+// Every rank takes part in every exchange whatever happened to it locally: a rank-local error is
+// carried in the status words and returned by ALL ranks after the exchange that reveals it.
+struct ShardHead {
+    u64 blocks, words;
+    i64 status;
+};
+struct ShardBlock {
+    u64 word_off, bit_len;
+    u32 crc, pad;
+};
+
+extern "C" int bz_gpu_encode_sharded(bz_gpu_engine *g, int level, const void *d_in, size_t n,
+                                     const bz_shard_comm *comm, void *d_packed, size_t packed_cap_words,
+                                     void *d_gather, size_t gather_cap_words, void *d_out, size_t cap,
+                                     size_t *out_len)
+{
+    if (!g || !comm || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world) return BZ_E_PARAM;
+    if (level < 1 || level > 9) return BZ_E_PARAM;
+    if (out_len) *out_len = 0;
+    const int rank = comm->rank, world = comm->world;
+    if (world > 1 && (!comm->allgather || !comm->send || !comm->recv || !comm->gatherv)) return BZ_E_PARAM;
+    const u64 ntiles = (n + kRleTile - 1) / kRleTile;
+    const u64 t0 = ntiles * (u64)rank / (u64)world, t1 = ntiles * (u64)(rank + 1) / (u64)world;
+    int rc = BZ_OK; // this rank's status; collectives go on regardless
+
+    // 1. slab scan + the RLE1 phase at the left edge
+    int64_t last = -1;
+    rc = bz_gpu_partition_slab_begin(g, level, d_in, n, t0, t1, &last);
+    std::vector<int64_t> lasts((size_t)world, -1);
+    if (world > 1) {
+        if (comm->allgather(comm->ctx, &last, 8, lasts.data()) != 0) return BZ_E_UNEXPECTED; // (the transport itself failed: nothing to wait for)
+    } else {
+        lasts[0] = last;
+    }
+    int64_t carry = -1;
+    for (int r = 0; r < rank; ++r) carry = std::max(carry, lasts[(size_t)r]);
+    if (rc == BZ_OK) rc = bz_gpu_partition_slab_count(g, carry);
+
+    // 2. the cut chain
+    uint64_t hop[2] = {0, 0}; // {first input byte of the receiver's first block, sender's status}
+    if (rank > 0 && comm->recv(comm->ctx, rank - 1, hop, sizeof(hop)) != 0) return BZ_E_UNEXPECTED;
+    if (rc == BZ_OK && hop[1] != 0) rc = -(int)hop[1];
+    size_t nb = 0;
+    uint64_t next = hop[0];
+    if (rc == BZ_OK) rc = bz_gpu_partition_slab_finish(g, hop[0], rank == world - 1, &nb, &next, nullptr);
+    if (rank < world - 1) {
+        uint64_t out_hop[2] = {next, (uint64_t)(rc == BZ_OK ? 0 : -rc)};
+        if (comm->send(comm->ctx, rank + 1, out_hop, sizeof(out_hop)) != 0) return BZ_E_UNEXPECTED;
+    }
+
+    // this rank's blocks (the sort starts as soon as its own cuts are known)
+    std::vector<uint64_t> woff(nb + 1), blen(nb + 1);
+    std::vector<uint32_t> crc(nb + 1);
+    size_t used = 0;
+    if (rc == BZ_OK && nb) {
+        if (!d_packed) {
+            packed_cap_words = bz_encode_bound(n / (size_t)world + ((size_t)48 << 20)) / 4 + 2 * nb + 16;
+            rc = g->packed.ensure(packed_cap_words * 4);
+            d_packed = g->packed.p;
+        }
+        if (rc == BZ_OK)
+            rc = bz_gpu_encode_blocks(g, 0, 1, d_packed, packed_cap_words, woff.data(), blen.data(), crc.data(), &used);
+    }
+    if (world == 1) {
+        if (rc != BZ_OK) return rc;
+        return bz_gpu_assemble(g, level, nb, d_packed, woff.data(), blen.data(), crc.data(), 1, 1, 1, 0, 0, 0, nullptr,
+                               d_out, cap, out_len, nullptr, nullptr);
+    }
+
+    // 3. who has how much, and the first error if there is one
+    ShardHead mine = {(u64)nb, (u64)used, (i64)rc};
+    std::vector<ShardHead> heads((size_t)world);
+    if (comm->allgather(comm->ctx, &mine, sizeof(mine), heads.data()) != 0) return BZ_E_UNEXPECTED;
+    u64 kmax = 1, total_words = 0, total_blocks = 0;
+    for (int r = 0; r < world; ++r) {
+        if (heads[(size_t)r].status != 0) return (int)heads[(size_t)r].status; // the same verdict on every rank
+        kmax = std::max(kmax, heads[(size_t)r].blocks);
+        total_words += heads[(size_t)r].words;
+        total_blocks += heads[(size_t)r].blocks;
+    }
+    std::vector<ShardBlock> meta((size_t)kmax), metas((size_t)kmax * (size_t)world);
+    for (size_t k = 0; k < (size_t)kmax; ++k) {
+        meta[k].word_off = k < nb ? woff[k] : 0;
+        meta[k].bit_len = k < nb ? blen[k] : 0;
+        meta[k].crc = k < nb ? crc[k] : 0;
+        meta[k].pad = 0;
+    }
+    if (comm->allgather(comm->ctx, meta.data(), (size_t)kmax * sizeof(ShardBlock), metas.data()) != 0) return BZ_E_UNEXPECTED;
+
+    // 4. the bit strings -> rank 0 (room is settled first so that a rank that cannot receive says so before the gather)
+    int grc = BZ_OK;
+    if (rank == 0) {
+        if (!d_gather) {
+            grc = g->gathered.ensure((size_t)(total_words + 16) * 4);
+            d_gather = g->gathered.p;
+        } else if (gather_cap_words < total_words) {
+            grc = BZ_E_CAPACITY;
+        }
+    }
+    std::vector<int64_t> grcs((size_t)world, 0);
+    int64_t g64 = grc;
+    if (comm->allgather(comm->ctx, &g64, 8, grcs.data()) != 0) return BZ_E_UNEXPECTED;
+    if (grcs[0] != 0) return (int)grcs[0];
+    std::vector<uint64_t> roff((size_t)world), rlen((size_t)world);
+    u64 cursor = 0;
+    for (int r = 0; r < world; ++r) {
+        roff[(size_t)r] = cursor * 4;
+        rlen[(size_t)r] = heads[(size_t)r].words * 4;
+        cursor += heads[(size_t)r].words;
+    }
+    HIPCHK(hipStreamSynchronize(g->st)); // the packed words are complete before the transport reads them
+    if (comm->gatherv(comm->ctx, d_packed, (size_t)used * 4, rank == 0 ? d_gather : nullptr, roff.data(), rlen.data()) != 0)
+        return BZ_E_UNEXPECTED;
+    if (rank != 0) return BZ_OK;
+
+    std::vector<uint64_t> awoff((size_t)total_blocks + 1), ablen((size_t)total_blocks + 1);
+    std::vector<uint32_t> acrc((size_t)total_blocks + 1);
+    size_t q = 0;
+    for (int r = 0; r < world; ++r)
+        for (u64 k = 0; k < heads[(size_t)r].blocks; ++k, ++q) {
+            const ShardBlock &m = metas[(size_t)r * (size_t)kmax + (size_t)k];
+            awoff[q] = m.word_off + roff[(size_t)r] / 4;
+            ablen[q] = m.bit_len;
+            acrc[q] = m.crc;
+        }
+    return bz_gpu_assemble(g, level, (size_t)total_blocks, d_gather, awoff.data(), ablen.data(), acrc.data(), 1, 1, 1, 0, 0, 0,
+                           nullptr, d_out, cap, out_len, nullptr, nullptr);
+}
+
+// Exercises a transport (the four callbacks of a bz_shard_comm) with known patterns, shaped like the
+// exchanges of bz_gpu_encode_sharded; every rank calls it.  host_memory != 0: the "device" buffers of
+// gatherv are plain host memory (a CPU transport under test), else hipMalloc'ed on the current device.
+extern "C" int bz_shard_comm_selftest(const bz_shard_comm *comm, int host_memory)
+{
+    if (!comm || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world) return BZ_E_PARAM;
+    if (!comm->allgather || !comm->send || !comm->recv || !comm->gatherv) return BZ_E_PARAM;
+    const int rank = comm->rank, world = comm->world;
+    int bad = 0;
+    // all-gather of 24 bytes per rank
+    uint64_t mine[3] = {0x1111111111111111ull * (uint64_t)(rank + 1), (uint64_t)rank, ~(uint64_t)rank};
+    std::vector<uint64_t> all((size_t)world * 3, 0);
+    if (comm->allgather(comm->ctx, mine, sizeof(mine), all.data()) != 0) return BZ_E_UNEXPECTED;
+    for (int r = 0; r < world; ++r)
+        if (all[(size_t)r * 3] != 0x1111111111111111ull * (uint64_t)(r + 1) || all[(size_t)r * 3 + 1] != (uint64_t)r ||
+            all[(size_t)r * 3 + 2] != ~(uint64_t)r)
+            bad |= 1;
+    // the chain: every rank adds its number + 1 to what it is handed
+    uint64_t hop[2] = {0, 0};
+    if (rank > 0 && comm->recv(comm->ctx, rank - 1, hop, sizeof(hop)) != 0) return BZ_E_UNEXPECTED;
+    if (hop[0] != (uint64_t)rank * (uint64_t)(rank + 1) / 2 || hop[1] != (uint64_t)rank) bad |= 2;
+    hop[0] += (uint64_t)rank + 1;
+    hop[1] += 1;
+    if (rank < world - 1 && comm->send(comm->ctx, rank + 1, hop, sizeof(hop)) != 0) return BZ_E_UNEXPECTED;
+    // variable-length gather: rank r contributes 1000 * (r + 1) + 7 bytes (rank 1 of a world > 2: nothing)
+    std::vector<uint64_t> off((size_t)world), len((size_t)world);
+    uint64_t total = 0;
+    for (int r = 0; r < world; ++r) {
+        len[(size_t)r] = (world > 2 && r == 1) ? 0 : 1000ull * (uint64_t)(r + 1) + 7;
+        off[(size_t)r] = total;
+        total += len[(size_t)r];
+    }
+    const size_t my_len = (size_t)len[(size_t)rank];
+    std::vector<uint8_t> h_send(my_len + 1), h_recv((size_t)total + 1, 0);
+    for (size_t i = 0; i < my_len; ++i) h_send[i] = (uint8_t)(i * 7 + (size_t)rank * 13 + 1);
+    void *d_send = nullptr, *d_recv = nullptr;
+    if (host_memory) {
+        d_send = h_send.data();
+        d_recv = h_recv.data();
+    } else {
+        HIPCHK(hipMalloc(&d_send, my_len + 16));
+        HIPCHK(hipMalloc(&d_recv, (size_t)total + 16));
+        HIPCHK(hipMemcpy(d_send, h_send.data(), my_len, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(d_recv, 0, (size_t)total + 16));
+    }
+    const int grc = comm->gatherv(comm->ctx, d_send, my_len, rank == 0 ? d_recv : nullptr, off.data(), len.data());
+    if (!host_memory) {
+        if (rank == 0 && grc == 0) (void)hipMemcpy(h_recv.data(), d_recv, (size_t)total, hipMemcpyDeviceToHost);
+        (void)hipFree(d_send);
+        (void)hipFree(d_recv);
+    }
+    if (grc != 0) return BZ_E_UNEXPECTED;
+    if (rank == 0)
+        for (int r = 0; r < world; ++r)
+            for (size_t i = 0; i < (size_t)len[(size_t)r]; ++i)
+                if (h_recv[(size_t)off[(size_t)r] + i] != (uint8_t)(i * 7 + (size_t)r * 13 + 1)) bad |= 4;
+    // the verdict is shared, like the status words of the real path
+    int64_t v = bad;
+    std::vector<int64_t> vs((size_t)world, 0);
+    if (comm->allgather(comm->ctx, &v, 8, vs.data()) != 0) return BZ_E_UNEXPECTED;
+    for (int r = 0; r < world; ++r)
+        if (vs[(size_t)r] != 0) return BZ_E_DATA;
+    return BZ_OK;
 }
 
 extern "C" int bz_gpu_last_timings(bz_gpu_engine *g, double out_seconds[6])

@@ -74,7 +74,7 @@ struct bz_gpu_engine {
     u32 sort_epoch = 0; // fused radix passes: tag of the current pass in tile_state / tickets
     bool ws_ready = false;
     // own packed buffer / assemble list for the single-GPU convenience call
-    DevBuf packed, asmlist;
+    DevBuf packed, gathered, asmlist;
     unsigned long long *h_active = nullptr; // pinned
     // results of the last encode
     std::vector<BlockOut> h_out;

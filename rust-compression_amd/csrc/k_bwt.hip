@@ -32,6 +32,7 @@
 //
 // Integer path: no MFMA.  Bound: HBM (streamed u32 arrays) + L2 gathers.
 #include "bzgpu.h"
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -198,6 +199,38 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
         }
     }
     return ok;
+}
+
+// Stable rank of this lane's element among the elements of its wave that carry digit `dg` (rows are
+// ranked one after the other; `cnt` = this wave's u16 counters in LDS).  0xFFFFFFFF: takes no part.
+//  * match-any form: the lanes with the same digit are found with ballots, the lowest peers come first,
+//    the highest peer publishes the new count.
+//  * -DBZ_RANK_ATOMIC: one returning LDS atomic add per row on the 32-bit word that holds the digit's u16
+//    counter.  Lanes of one wave instruction that hit the same word are served in ascending lane order on
+//    gfx950 (tools/ubench/ldsorder.hip checks exactly this), so the returned values ARE the stable ranks.
+template <int BITS>
+__device__ __forceinline__ u32 rank_in_wave(u16 *cnt, u32 dg, bool ok, u32 l, u64 lt_mask)
+{
+    u32 rnk = 0xFFFFFFFFu;
+#ifdef BZ_RANK_ATOMIC
+    (void)l;
+    (void)lt_mask;
+    if (ok) {
+        const u32 sh = (dg & 1u) * 16u;
+        const u32 old = __hip_atomic_fetch_add(reinterpret_cast<u32 *>(cnt) + (dg >> 1), 1u << sh, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+        rnk = (old >> sh) & 0xFFFFu;
+    }
+#else
+    const u64 peers = wave_match_digit<BITS>(dg, ok);
+    if (ok) {
+        const u32 before = __popcll(peers & lt_mask);
+        const u32 c0 = cnt[dg];
+        rnk = c0 + before;
+        if ((peers >> l) == 1ull) cnt[dg] = (u16)(c0 + before + 1u);
+    }
+#endif
+    return rnk;
 }
 
 // ---- radix pass, part 1: per-tile digit histogram ---------------------------------
@@ -376,15 +409,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
     for (u32 r = 0; r < 16; ++r) {
         const bool ok = (okmask >> r) & 1u;
         const u32 dg = (key[r] >> shift) & (NB - 1);
-        const u64 peers = wave_match_digit<BITS>(dg, ok);
-        rnk[r] = 0xFFFFFFFFu;
-        if (ok) {
-            const u32 before = __popcll(peers & lt_mask);
-            const u32 c0 = my_cnt[dg];
-            rnk[r] = c0 + before;
-            // the highest lane of the peer set publishes the new count
-            if ((peers >> l) == 1ull) my_cnt[dg] = (u16)(c0 + before + 1u);
-        }
+        rnk[r] = rank_in_wave<BITS>(my_cnt, dg, ok, l, lt_mask);
         // LDS ops of one wave retire in order: the next row's reads see this row's writes
     }
     __syncthreads();
@@ -648,14 +673,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
     for (u32 r = 0; r < 16; ++r) {
         const bool ok = (okmask >> r) & 1u;
         const u32 dg = (key[r] >> shift) & (NB - 1);
-        const u64 peers = wave_match_digit<BITS>(dg, ok);
-        rnk[r] = 0xFFFFFFFFu;
-        if (ok) {
-            const u32 before = __popcll(peers & lt_mask);
-            const u32 c0 = my_cnt[dg];
-            rnk[r] = c0 + before;
-            if ((peers >> l) == 1ull) my_cnt[dg] = (u16)(c0 + before + 1u);
-        }
+        rnk[r] = rank_in_wave<BITS>(my_cnt, dg, ok, l, lt_mask);
     }
     __syncthreads();
     constexpr u32 PER = NB / kSortThreads; // digits per thread (2 or 4), consecutive
@@ -1401,15 +1419,22 @@ static void init_sort(hipStream_t st, const BwtArgs &a, u64 total_n, KernelProf 
 // symbols (32-bit keys, 11+11+10 bit digits; otherwise 30-bit keys, 10+10+10).  min_chars: the
 // smallest symbols-per-key of the batch.
 // Returns the number of doubling rounds executed, <0 on HIP error.
-int run_bwt(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 total_n, unsigned long long *h_active,
-            u64 *sorted_elems, KernelProf *prof, u64 *round_active, bool wide_keys, u32 min_chars)
+// One attempt.  Returns the rounds executed, -1 on a HIP error, -2 when a fused pass did not behave
+// (a look-back gave up or an XCD handed out fewer tickets than it has tiles -- another kernel shared
+// the device, or workgroups were not dealt to the XCDs as assumed): nothing of the attempt can be
+// trusted then, but the block text is untouched and the caller sorts again with the three-kernel passes.
+static std::atomic<bool> g_fused_broken{false}; // process-wide: once the fused passes misbehave they stay off
+
+static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 total_n, unsigned long long *h_active,
+                        u64 *sorted_elems, KernelProf *prof, u64 *round_active, bool wide_keys, u32 min_chars,
+                        bool allow_fused)
 {
-    BwtArgs a = a_in; // (a.fused is cleared below if the fused passes do not behave on this machine)
-    static bool fused_broken = false;
-    if (fused_broken) a.fused = 0;
+    BwtArgs a = a_in;
+    if (!allow_fused || g_fused_broken.load()) a.fused = 0;
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
     (void)hipMemsetAsync(a.active, 0, 64 * sizeof(unsigned long long), st);
     (void)hipMemsetAsync(a.nonfinal, 0, a.nb * sizeof(u32), st);
+    if (a.sort_err) (void)hipMemsetAsync(a.sort_err, 0, 4, st); // a failure of an earlier call must not stick
 
     // Fused passes (k_radix_scatter_lb) unless switched off (BZ_ONESWEEP=0) or found not to behave: their
     // first pass is checked, and the three-kernel passes redo the sort from the block if it fails.
@@ -1419,7 +1444,7 @@ int run_bwt(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 total_n, unsigne
         const bool ok = wide_keys ? init_sort_fused<11, 11, 10>(st, a, total_n, prof) : init_sort_fused<10, 10, 10>(st, a, total_n, prof);
         if (!ok) {
             fprintf(stderr, "bz2_mi355x: fused radix passes disabled (tile tickets / look-back check failed)\n");
-            fused_broken = true;
+            g_fused_broken.store(true);
             fused = false;
             a.fused = 0;
             (void)hipMemsetAsync(a.sort_err, 0, 4, st);
@@ -1498,10 +1523,15 @@ int run_bwt(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 total_n, unsigne
                 return -1;
         }
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
-        if (gave_up) return -1;
+        static const bool late_fail_test = getenv("BZ_ONESWEEP_LATEFAILTEST") != nullptr; // (tests: exercise the redo)
+        bool bad = gave_up != 0 || late_fail_test;
         for (size_t i = 0; i < tk.size(); ++i) {
             const u32 x = (u32)(i & 7u);
-            if (tk[i] < kTilesPerBlock * ((a.nb + 7u - x) / 8u)) return -1;
+            if (tk[i] < kTilesPerBlock * ((a.nb + 7u - x) / 8u)) bad = true;
+        }
+        if (bad) {
+            (void)hipMemsetAsync(a.sort_err, 0, 4, st);
+            return -2;
         }
     }
     // periodic blocks: whatever is still non-final is a set of equal rotations
@@ -1510,6 +1540,28 @@ int run_bwt(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 total_n, unsigne
     hipLaunchKernelGGL(k_periodic_stats, grid, dim3(kSortThreads), 0, st, a);
     hipLaunchKernelGGL(k_periodic_place, grid, dim3(kSortThreads), 0, st, a);
     return rounds;
+}
+
+int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned long long *h_active,
+            u64 *sorted_elems, KernelProf *prof, u64 *round_active, bool wide_keys, u32 min_chars)
+{
+    const u64 sorted0 = sorted_elems ? *sorted_elems : 0;
+    u64 ra0[64];
+    if (round_active)
+        for (int i = 0; i < 64; ++i) ra0[i] = round_active[i];
+    int r = run_bwt_once(st, a, max_n, total_n, h_active, sorted_elems, prof, round_active, wide_keys, min_chars, true);
+    if (r == -2) {
+        // a pass after the first one misbehaved: redo this batch's sort from the block text without them
+        fprintf(stderr, "bz2_mi355x: a fused radix pass misbehaved; batch sorted again with the three-kernel passes, "
+                        "fused passes disabled\n");
+        g_fused_broken.store(true);
+        if (sorted_elems) *sorted_elems = sorted0;
+        if (round_active)
+            for (int i = 0; i < 64; ++i) round_active[i] = ra0[i];
+        r = run_bwt_once(st, a, max_n, total_n, h_active, sorted_elems, prof, round_active, wide_keys, min_chars, false);
+        if (r == -2) r = -1;
+    }
+    return r;
 }
 
 void launch_last_column(hipStream_t st, const BwtArgs &a, u8 *L, u32 *orig_ptr, u64 total_n, KernelProf *prof)

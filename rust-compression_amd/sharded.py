@@ -1,124 +1,157 @@
-"""Multi-GPU orchestration of the block-encode path: one process per GPU.
+"""Multi-GPU transport for the block-encode / decode paths: one process per GPU.
 
-The path shards naturally: once the input is split into blocks, every block is
-independent.  Rank r owns a SLAB of the input (a contiguous range of 4 KiB tiles) and encodes the
-blocks that END inside it; stream order is rank order.  What crosses ranks:
+The sharding itself lives in the library (bz_gpu_encode_sharded, bz_gpu_decode_device_sharded,
+csrc/engine.hip, csrc/dec_engine.hip): rank r owns a SLAB of the input (a contiguous range of 4 KiB
+tiles), encodes the blocks that END inside it, stream order is rank order.  What crosses ranks goes
+through four C callbacks (struct bz_shard_comm, include/bz2_mi355x.h):
 
-  1. all-gather of ONE int64 per rank (the last run start inside each slab) so that every rank knows
-     the RLE1 phase at its left edge                                            -- 8 B per rank
-  2. the cut chain: rank r-1 tells rank r where its first block starts          -- 8 B per hop
-  3. all-gather of per-block (word offset, bit length, CRC)                     -- a few KB
-  4. a variable-length gather of the packed bit strings to rank 0               -- ~0.2 x input bytes
+  1. all-gather of 8 B per rank (the last run start inside each slab: the RLE1 phase at every
+     slab's left edge)
+  2. the cut chain: rank r-1 tells rank r where its first block starts          -- 16 B per hop
+  3. all-gather of per-rank (blocks, words, status), then per-block (word offset, bit length, CRC)
+  4. ONE variable-length gather of the packed bit strings to rank 0             -- ~0.2 x input bytes
 
-and rank 0 assembles the stream (bit-granular concatenation + header/trailer).  With backend "nccl"
-the collectives are RCCL over xGMI; the same code runs on CPU tensors with "gloo"
-(tests/test_sharded_gloo.py).  There is no other collective on the data path.
+This module is the torch.distributed implementation of those callbacks: with backend "nccl" the
+collectives are RCCL over xGMI (device tensors); with "gloo" the same calls run on host tensors
+(device buffers are staged through the host), which is how the path is tested with several processes
+on one GPU and on CPU (tests/test_sharded_gloo.py, tests/test_gpu_sharded.py).
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
 TILE = 4096
 
+# the four callbacks of struct bz_shard_comm
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+SEND_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t)
+RECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t)
+GATHERV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64),
+                         C.POINTER(C.c_uint64))
+
+
+class ShardComm(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int), ("world", C.c_int), ("allgather", ALLGATHER_FN),
+                ("send", SEND_FN), ("recv", RECV_FN), ("gatherv", GATHERV_FN)]
+
 
 def slab_tiles(n, rank, world):
-    """Tile range [t0, t1) of `rank`: equal shares of the ceil(n / 4096) tiles."""
+    """Tile range [t0, t1) of `rank`: equal shares of the ceil(n / 4096) tiles (the library's split)."""
     ntiles = (n + TILE - 1) // TILE
     return ntiles * rank // world, ntiles * (rank + 1) // world
 
 
-def split_contiguous(n_blocks, rank, world):
-    """(CPU stand-in for the slab split) blocks of `rank` when blocks are dealt contiguously."""
-    return list(range(n_blocks * rank // world, n_blocks * (rank + 1) // world))
+class _DevBytes:
+    """A raw device pointer as something torch.as_tensor understands."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
 
 
-def partition(eng, level, d_in, n, rank, world, device):
-    """Slab-sharded split: returns this rank's block count (its blocks are then encoded with
-    eng.encode_blocks(0, 1, nb, ...))."""
-    t0, t1 = slab_tiles(n, rank, world)
-    last = eng.slab_begin(level, d_in, n, t0, t1)
-    if world > 1:
-        mine = torch.tensor([last], dtype=torch.int64, device=device)
-        parts = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine)
-        lasts = [int(p.item()) for p in parts]
-    else:
-        lasts = [last]
-    eng.slab_count(max(lasts[:rank], default=-1))
-    start = 0
-    if rank > 0:
-        buf = torch.zeros(1, dtype=torch.int64, device=device)
-        dist.recv(buf, src=rank - 1)
-        start = int(buf.item())
-    nb, nxt, _tail = eng.slab_finish(start, rank == world - 1)
-    if rank < world - 1:
-        dist.send(torch.tensor([nxt], dtype=torch.int64, device=device), dst=rank + 1)
-    return nb
+class TorchComm:
+    """struct bz_shard_comm over torch.distributed.
 
+    device: torch.device of this rank's GPU, or None / cpu when the "device" buffers of gatherv are host
+    memory (CPU tests).  Buffers handed to the library as d_packed / d_gather should be registered
+    (register(tensor)) so that gatherv finds the tensor behind a pointer; unregistered pointers are
+    wrapped through __cuda_array_interface__ (cuda) or ctypes (cpu)."""
 
-def exchange(word_off, bit_len, crc, packed, words_used, rank, world, device, gather_buf=None):
-    """Block bit strings of every rank -> rank 0, stream order = rank order.
+    def __init__(self, rank, world, device=None, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.device = device if device is not None else torch.device("cpu")
+        backend = dist.get_backend(group) if world > 1 else "none"
+        # RCCL moves device tensors; gloo moves host tensors
+        self.wire = self.device if (backend == "nccl") else torch.device("cpu")
+        self._tensors = {}
+        self.errors = []
+        self._cbs = (ALLGATHER_FN(self._allgather), SEND_FN(self._send), RECV_FN(self._recv), GATHERV_FN(self._gatherv))
+        self.struct = ShardComm(None, rank, world, *self._cbs)
 
-    word_off/bit_len/crc: python lists for this rank's blocks; packed: int32 tensor holding their
-    bit strings (words_used words are meaningful).
-    Returns on rank 0: (all_packed [world, row] int32 tensor, lists woff, blen, crcs in stream order,
-    woff indexing all_packed.view(-1)); on other ranks None."""
-    k = len(word_off)
-    head = torch.tensor([k, words_used], dtype=torch.int64, device=device)
-    if world > 1:
-        heads = [torch.empty_like(head) for _ in range(world)]
-        dist.all_gather(heads, head)
-        heads = torch.stack(heads).cpu()
-    else:
-        heads = head.unsqueeze(0).cpu()
-    kmax = max(int(heads[:, 0].max().item()), 1)
-    maxw = max(int(heads[:, 1].max().item()), 1)
-    meta = torch.zeros((kmax, 3), dtype=torch.int64)
-    if k:
-        meta[:k, 0] = torch.tensor(word_off, dtype=torch.int64)
-        meta[:k, 1] = torch.tensor(bit_len, dtype=torch.int64)
-        meta[:k, 2] = torch.tensor(crc, dtype=torch.int64)
-    meta = meta.to(device)
-    if world > 1:
-        parts = [torch.empty_like(meta) for _ in range(world)]
-        dist.all_gather(parts, meta)
-        am = torch.stack(parts).cpu()
-    else:
-        am = meta.unsqueeze(0).cpu()
-    if packed.numel() < maxw:  # every rank must contribute the same number of words
-        grown = torch.zeros(maxw, dtype=packed.dtype, device=packed.device)
-        grown[:packed.numel()] = packed
-        packed = grown
-    if rank == 0:
-        if gather_buf is None or gather_buf.shape[0] < world or gather_buf.shape[1] < maxw:
-            gather_buf = torch.empty((world, maxw), dtype=torch.int32, device=device)
-        row = gather_buf.shape[1]
-        if world > 1:
-            dist.gather(packed[:maxw], [gather_buf[r, :maxw] for r in range(world)], dst=0)
-        else:
-            gather_buf[0, :maxw] = packed[:maxw]
-        woff, blen, crcs = [], [], []
-        for r in range(world):
-            kr = int(heads[r, 0].item())
-            woff += (am[r, :kr, 0] + r * row).tolist()
-            blen += am[r, :kr, 1].tolist()
-            crcs += am[r, :kr, 2].tolist()
-        return gather_buf, woff, blen, crcs
-    dist.gather(packed[:maxw], None, dst=0)
-    return None
+    def register(self, t):
+        self._tensors[t.data_ptr()] = t
+        return t
+
+    # ---- helpers -----------------------------------------------------------------------------
+    def _host_bytes(self, ptr, n):
+        return torch.frombuffer((C.c_uint8 * n).from_address(ptr), dtype=torch.uint8) if n else torch.empty(0, dtype=torch.uint8)
+
+    def _buffer(self, ptr, nbytes):
+        """uint8 view of `nbytes` bytes at `ptr` in the memory space of self.device"""
+        if nbytes == 0:
+            return torch.empty(0, dtype=torch.uint8, device=self.device)
+        for base, t in self._tensors.items():
+            size = t.numel() * t.element_size()
+            if base <= ptr and ptr + nbytes <= base + size:
+                flat = t.view(-1).view(torch.uint8)
+                return flat[ptr - base:ptr - base + nbytes]
+        if self.device.type == "cuda":
+            return torch.as_tensor(_DevBytes(ptr, nbytes), device=self.device)
+        return self._host_bytes(ptr, nbytes)
+
+    def _guard(self, fn, *a):
+        try:
+            fn(*a)
+            return 0
+        except Exception as e:  # the C side turns a non-zero return into BZ_E_UNEXPECTED
+            self.errors.append(repr(e))
+            return 1
+
+    # ---- the callbacks ------------------------------------------------------------------------
+    def _allgather(self, _ctx, send, nbytes, recv):
+        def run():
+            mine = self._host_bytes(send, nbytes).clone()
+            parts = [torch.empty(nbytes, dtype=torch.uint8, device=self.wire) for _ in range(self.world)]
+            dist.all_gather(parts, mine.to(self.wire), group=self.group)
+            self._host_bytes(recv, self.world * nbytes).copy_(torch.cat(parts).cpu())
+        return self._guard(run)
+
+    def _send(self, _ctx, dst, buf, nbytes):
+        def run():
+            dist.send(self._host_bytes(buf, nbytes).clone().to(self.wire), dst=dst, group=self.group)
+        return self._guard(run)
+
+    def _recv(self, _ctx, src, buf, nbytes):
+        def run():
+            t = torch.empty(nbytes, dtype=torch.uint8, device=self.wire)
+            dist.recv(t, src=src, group=self.group)
+            self._host_bytes(buf, nbytes).copy_(t.cpu())
+        return self._guard(run)
+
+    def _gatherv(self, _ctx, d_send, send_bytes, d_recv, recv_off, recv_bytes):
+        def run():
+            mine = self._buffer(d_send, send_bytes)
+            if self.rank != 0:
+                if send_bytes:
+                    dist.send(mine.to(self.wire).contiguous(), dst=0, group=self.group)
+                return
+            offs = [int(recv_off[r]) for r in range(self.world)]
+            lens = [int(recv_bytes[r]) for r in range(self.world)]
+            whole = self._buffer(d_recv, max(o + k for o, k in zip(offs, lens)))
+            whole[offs[0]:offs[0] + lens[0]].copy_(mine)
+            for r in range(1, self.world):
+                if lens[r] == 0:
+                    continue
+                part = whole[offs[r]:offs[r] + lens[r]]
+                if self.wire == part.device:
+                    dist.recv(part, src=r, group=self.group)
+                else:
+                    t = torch.empty(lens[r], dtype=torch.uint8, device=self.wire)
+                    dist.recv(t, src=r, group=self.group)
+                    part.copy_(t)
+        return self._guard(run)
 
 
 def allgather_bytes(rank, world, dev):
     """The one collective of the sharded decode (bz_gpu_decode_device_sharded): returns a function
     send: bytes -> concatenation of every rank's bytes in rank order, over torch.distributed (RCCL
     when the process group is "nccl": the few KB travel through a device tensor; gloo on CPU)."""
-    import torch
-    import torch.distributed as dist
 
     def gather(send):
         if world == 1:
             return bytes(send)
         t = torch.frombuffer(bytearray(send), dtype=torch.uint8)
-        if dev is not None and dev.type == "cuda":
+        if dev is not None and dev.type == "cuda" and dist.get_backend() == "nccl":
             t = t.to(dev)
         outs = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(outs, t)

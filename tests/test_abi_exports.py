@@ -56,6 +56,8 @@ def test_fails_loudly_without_gpu(pkg):
     with pytest.raises(pkg.CompressionError):
         pkg.GpuEngine(0, 4)
     enc = pkg.BZip2Encoder(9)           # creating the context does not touch the GPU
-    enc.write(b"hello")
+    with pytest.raises(pkg.CompressionError) as ei:
+        enc.write(b"hello")             # the first bytes start the upload pipeline: that needs the device
+    assert ei.value.kind == "NoGpu"
     with pytest.raises(pkg.CompressionError):
         enc.end(pkg.Action.FINISH)

@@ -279,7 +279,7 @@ def test_full_size_round_trip_on_device(pkg, eng):
 
 # ---- multi-GPU decode (bz_gpu_decode_device_sharded), emulated: one engine and one thread per rank on
 # ---- the same GPU, an in-process all-gather between them
-def _sharded_decode(pkg, z, world, cap_per_rank):
+def _sharded_decode(pkg, z, world, cap_per_rank, collect_errors=False):
     import threading
     import torch
     tin = torch.frombuffer(bytearray(z) + bytearray(64), dtype=torch.uint8).cuda()
@@ -289,9 +289,9 @@ def _sharded_decode(pkg, z, world, cap_per_rank):
     def gather_for(rank):
         def gather(send):
             box[rank] = send
-            barrier.wait()
+            barrier.wait(120)
             got = b"".join(box)
-            barrier.wait()
+            barrier.wait(120)
             return got
         return gather
 
@@ -303,9 +303,12 @@ def _sharded_decode(pkg, z, world, cap_per_rank):
                                                            gather_for(rank))
             results[rank] = (bytes(out[:n].cpu().numpy()), off, tot, verdict)
             e.close()
-        except Exception as ex:  # keep the other threads from waiting forever
+        except Exception as ex:
+            if collect_errors:  # (every rank is expected to come back by itself)
+                results[rank] = ex
+                return
             errors.append(ex)
-            barrier.abort()
+            barrier.abort()  # keep the other threads from waiting forever
 
     th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     for t in th:
@@ -351,6 +354,43 @@ def test_sharded_decode_errors(pkg, oracle):
     with pytest.raises(AssertionError) as ei:
         _sharded_decode(pkg, bz2.compress(d, 1), 2, 1000)
     assert "Capacity" in str(ei.value)
+
+
+@pytest.mark.parametrize("phase,kind", [(0, "NoMemory"), (1, "Unexpected")])
+def test_sharded_decode_rank_local_failure_reaches_every_rank(pkg, monkeypatch, phase, kind):
+    """A rank that fails on its own (memory, a HIP error) in front of the first or between the two
+    exchanges still goes through them with its status, so its peers return the same error instead of
+    waiting in a collective (BZ_DEC_SHARD_FAIL=<rank>:<phase> injects the failure)."""
+    monkeypatch.setenv("BZ_DEC_SHARD_FAIL", "1:%d" % phase)
+    d = sample(1)[:98000] * 10
+    res = _sharded_decode(pkg, bz2.compress(d, 1), 3, len(d), collect_errors=True)
+    assert all(isinstance(r, pkg.CompressionError) and r.kind == kind for r in res), res
+
+
+def test_streaming_decoder_corrupt_block_far_from_the_end(pkg, oracle, monkeypatch):
+    """A block that fails far in front of the end of what has arrived cannot be a cut-off one: the
+    verdict comes at once (bytes in front of it, then DataError) and the context does not keep
+    collecting and re-scanning input until the end."""
+    monkeypatch.setenv("BZ_DEC_CHUNK", "200000")
+    d = sample(1)[:98000] * 60  # 60 level-1 blocks, ~2.3 MB compressed
+    z = bytearray(bz2.compress(d, 1))
+    z[len(z) // 10] ^= 0x10  # inside the sixth block or so
+    want, st = oracle.decode(bytes(z))
+    assert st == E_DATA and 0 < len(want) < len(d) // 4
+    dec = pkg.BZip2Decoder()
+    got = bytearray()
+    err_at = None
+    for pos in range(0, len(z), 100000):
+        dec.write(bytes(z[pos:pos + 100000]))
+        try:
+            got += dec.read_available()
+        except pkg.BZip2Error as e:
+            got += e.partial
+            err_at = pos
+            assert e.bzip2_kind == "DataError"
+            break
+    assert err_at is not None and err_at < len(z) - 300000  # long before the input ended
+    assert bytes(got) == want
 
 
 # ---- incremental streaming decode (bz_dec_*): chunks of compressed input in, decoded bytes out early

@@ -318,7 +318,8 @@ def test_wide_inputs_small_blocks(pkg, oracle):
 
 def test_radix_pass_flavours_agree(oracle):
     """the fused radix passes (default), the three-kernel passes (BZ_ONESWEEP=0) and the fallback from
-    one to the other (BZ_ONESWEEP_FAILTEST) give the oracle's stream; each runs in its own process
+    one to the other (BZ_ONESWEEP_FAILTEST at the first pass, BZ_ONESWEEP_LATEFAILTEST at the end of a sort)
+    give the oracle's stream; each runs in its own process
     because the switches are read once"""
     import subprocess
     import sys
@@ -329,7 +330,7 @@ def test_radix_pass_flavours_agree(oracle):
         "print(hashlib.sha256(pkg.compress(d,9)).hexdigest(), hashlib.sha256(pkg.compress(d,1)).hexdigest())" % (ROOT, ROOT))
     d = sample(1) * 3 + bytes(range(256)) * 700 + sample(2)
     want = "%s %s" % (hashlib.sha256(oracle.encode(d, 9)).hexdigest(), hashlib.sha256(oracle.encode(d, 1)).hexdigest())
-    for env in ({}, {"BZ_ONESWEEP": "0"}, {"BZ_ONESWEEP_FAILTEST": "1"}):
+    for env in ({}, {"BZ_ONESWEEP": "0"}, {"BZ_ONESWEEP_FAILTEST": "1"}, {"BZ_ONESWEEP_LATEFAILTEST": "1"}):
         e = dict(os.environ)
         e.update(env)
         out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
@@ -337,6 +338,8 @@ def test_radix_pass_flavours_agree(oracle):
         assert out.stdout.strip().splitlines()[-1] == want, (env, out.stdout, out.stderr[-500:])
         if "BZ_ONESWEEP_FAILTEST" in env:
             assert "fused radix passes disabled" in out.stderr
+        if "BZ_ONESWEEP_LATEFAILTEST" in env:  # a pass after the first misbehaves: the batch is sorted again
+            assert "batch sorted again" in out.stderr
 
 
 def test_pass_counter_wraps(pkg, oracle):

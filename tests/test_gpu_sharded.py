@@ -1,0 +1,104 @@
+"""The multi-GPU encode path in REAL processes: `world` ranks, each with its own engine and HIP
+context, share the one GPU of the test box and run bz_gpu_encode_sharded end to end -- slab split,
+all-gather of the slab run starts, the send/recv cut chain, block encode, the variable-length
+gather, assembly on rank 0 -- with torch.distributed (gloo: two ranks cannot share a device under
+RCCL) carrying the four C callbacks.  Rank 0's stream must equal the oracle's, byte for byte, and
+the single-engine stream.  bench.py --gpus N runs the same code over RCCL, one GPU per rank."""
+import importlib
+import os
+import random
+import socket
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _text(n, seed):
+    import corpus
+    return corpus.chapter(seed, max(n, 1 << 16))[:n]
+
+
+def _input(kind):
+    if kind == "mixed":
+        rng = random.Random(77)
+        runs = b"".join(bytes([rng.randrange(3)]) * rng.randint(1, 900) for _ in range(1500))
+        return _text(300_000, 7) + runs + _text(260_000, 8) + b"z" * 70_000 + _text(100_001, 9), 1
+    if kind == "text9":
+        return _text(5_000_000, 3), 9
+    if kind == "tiny":
+        return b"abc" * 1000, 9      # fewer blocks than ranks: some ranks own none
+    raise KeyError(kind)
+
+
+def _worker(rank, world, port, kind, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = importlib.import_module("rust-compression_amd")
+        sharded = importlib.import_module("rust-compression_amd.sharded")
+        dev = torch.device("cuda", 0)
+        data, level = _input(kind)
+        n = len(data)
+        d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+        eng = pkg.GpuEngine(0, 8)
+        comm = sharded.TorchComm(rank, world, dev)
+        cap = (pkg.encode_bound(n) + 15) & ~15
+        d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+        # once with the engine's own buffers (pointers the transport has never seen), once with
+        # registered caller-owned ones
+        k1 = eng.encode_sharded(level, d_in.data_ptr(), n, comm, d_out.data_ptr(), cap)
+        out1 = bytes(d_out[:k1].cpu().numpy())
+        words = cap // 4 + 64
+        packed = comm.register(torch.empty(words, dtype=torch.int32, device=dev))
+        gather = comm.register(torch.empty(words * world, dtype=torch.int32, device=dev)) if rank == 0 else None
+        k2 = eng.encode_sharded(level, d_in.data_ptr(), n, comm, d_out.data_ptr(), cap,
+                                packed=(packed.data_ptr(), words),
+                                gather=(gather.data_ptr(), words * world) if rank == 0 else None)
+        out2 = bytes(d_out[:k2].cpu().numpy())
+        single = None
+        if rank == 0:
+            ks = eng.encode_device(level, d_in.data_ptr(), n, d_out.data_ptr(), cap)
+            single = bytes(d_out[:ks].cpu().numpy())
+        q.put((rank, out1, out2, single, list(comm.errors)))
+        eng.close()
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind", [(2, "mixed"), (3, "mixed"), (2, "text9"), (4, "tiny")])
+def test_sharded_encode_in_real_processes(oracle, world, kind):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    data, level = _input(kind)
+    want = oracle.encode(data, level)
+    assert [g[4] for g in got] == [[]] * world
+    assert got[0][1] == want and got[0][2] == want and got[0][3] == want
+    for r in range(1, world):
+        assert got[r][1] == b"" and got[r][2] == b""

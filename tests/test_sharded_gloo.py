@@ -1,6 +1,8 @@
-"""N > 1 path on CPU: two/three processes over gloo run the same exchange code the GPU bench uses (rust-compression_amd/sharded.py).  The per-block bit strings come from the oracle
-(this test's stand-in for the HIP engine) and rank 0's assembled stream must equal the oracle's
-serial stream byte for byte."""
+"""N > 1 path on CPU: two/three processes over gloo drive the transport the multi-GPU encode and
+decode use (rust-compression_amd/sharded.py: the C callbacks of bz_shard_comm / bz_allgather_fn over
+torch.distributed) from the library's own C side (bz_shard_comm_selftest: the exchanges of
+bz_gpu_encode_sharded with known patterns).  The data path itself needs a GPU:
+tests/test_gpu_sharded.py runs it in two real processes."""
 import importlib
 import os
 import socket
@@ -11,7 +13,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import ROOT, sample
+from conftest import ROOT
 
 
 def _free_port():
@@ -22,110 +24,59 @@ def _free_port():
     return p
 
 
-def _bits_of(stream: bytes):
-    return int.from_bytes(stream, "big"), len(stream) * 8
-
-
-def _block_strings(stream: bytes, stats):
-    """Cut the oracle stream into per-block bit strings using the per-block bit counts."""
-    v, total = _bits_of(stream)
-    pos = 32
-    out = []
-    for st in stats:
-        nb = st["bits"]
-        chunk = (v >> (total - pos - nb)) & ((1 << nb) - 1)
-        out.append((chunk, nb, st["block_crc"]))
-        pos += nb
-    return out
-
-
-def _pack(blocks):
-    """Bit strings -> logical 32-bit words (bit 31 first), the layout bz_gpu_encode_blocks produces."""
-    words, woff = [], []
-    for chunk, nb, _ in blocks:
-        woff.append(len(words))
-        nw = (nb + 31) // 32
-        padded = chunk << (nw * 32 - nb)
-        for k in range(nw):
-            words.append((padded >> ((nw - 1 - k) * 32)) & 0xFFFFFFFF)
-    t = torch.tensor(words if words else [0], dtype=torch.int64)
-    return (t - ((t >> 31) << 32)).to(torch.int32), woff, len(words)
-
-
-def _assemble(level, flat, woff, blen, crcs):
-    """Pure-python restatement of bz_gpu_assemble (header, blocks, trailer, pad) for the CPU test."""
-    v, nbits = 0, 0
-
-    def put(x, n):
-        nonlocal v, nbits
-        v = (v << n) | (x & ((1 << n) - 1))
-        nbits += n
-    put(0x425A68, 24)
-    put(0x30 + level, 8)
-    comb = 0
-    for off, nb, crc in zip(woff, blen, crcs):
-        nw = (nb + 31) // 32
-        chunk = 0
-        for k in range(nw):
-            chunk = (chunk << 32) | (int(flat[off + k]) & 0xFFFFFFFF)
-        put(chunk >> (nw * 32 - nb), nb)
-        comb = (((comb << 1) | (comb >> 31)) & 0xFFFFFFFF) ^ crc
-    put(0x177245385090, 48)
-    put(comb, 32)
-    pad = (-nbits) % 8
-    put(0, pad)
-    return v.to_bytes(nbits // 8, "big")
-
-
-def _worker(rank, world, port, level, q):
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def _comm_worker(rank, world, port, q):
+    """every rank: the library's transport self-test (patterns shaped like the exchanges of
+    bz_gpu_encode_sharded) through sharded.TorchComm over gloo, buffers in host memory"""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from oracle import oracle
+        import ctypes
+        pkg = importlib.import_module("rust-compression_amd")
         sharded = importlib.import_module("rust-compression_amd.sharded")
-        data = sample(2) + sample(1) + sample(4)
-        stream, stats = oracle.encode(data, level, with_stats=True)
-        blocks = _block_strings(stream, stats)
-        nb = len(blocks)
-        mine = sharded.split_contiguous(nb, rank, world)
-        packed, woff, used = _pack([blocks[b] for b in mine])
-        res = sharded.exchange(woff, [blocks[b][1] for b in mine], [blocks[b][2] for b in mine], packed, used,
-                               rank, world, torch.device("cpu"))
-        if rank == 0:
-            buf, w_off, b_len, crcs = res
-            out = _assemble(level, buf.view(-1).tolist(), w_off, b_len, crcs)
-            q.put((nb, out == stream, len(out)))
+        comm = sharded.TorchComm(rank, world, torch.device("cpu"))
+        rc = pkg.lib().bz_shard_comm_selftest(ctypes.byref(comm.struct), 1)
+        q.put((rank, rc, list(comm.errors)))
     finally:
         dist.barrier()
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_round_robin_exchange_and_assembly(world):
+def test_shard_comm_callbacks_over_gloo(world):
+    """the four C callbacks of bz_shard_comm (all-gather, chain send/recv, variable-length gather),
+    driven from the library's C side, carried by torch.distributed"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, 1, q)) for r in range(world)]
+    procs = [ctx.Process(target=_comm_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    nb, same, n = q.get(timeout=10)
-    assert nb >= 5 and same and n > 1000
+    got = sorted(q.get(timeout=10) for _ in range(world))
+    assert got == [(r, 0, []) for r in range(world)]
 
 
 def test_split_helpers():
     sharded = importlib.import_module("rust-compression_amd.sharded")
-    assert sorted(sum((sharded.split_contiguous(11, r, 4) for r in range(4)), [])) == list(range(11))
-    assert sharded.split_contiguous(3, 3, 4) == [2]
     n = 10 * 4096 + 5
     spans = [sharded.slab_tiles(n, r, 3) for r in range(3)]
     assert spans[0][0] == 0 and spans[-1][1] == 11
     assert all(spans[i][1] == spans[i + 1][0] for i in range(2))
+
+
+def test_shard_comm_parameter_checks():
+    import ctypes
+    pkg = importlib.import_module("rust-compression_amd")
+    sharded = importlib.import_module("rust-compression_amd.sharded")
+    L = pkg.lib()
+    assert L.bz_shard_comm_selftest(None, 1) == pkg.BZ_E_PARAM
+    bad = sharded.ShardComm(None, 3, 2)  # rank outside the world
+    assert L.bz_shard_comm_selftest(ctypes.byref(bad), 1) == pkg.BZ_E_PARAM
+    assert L.bz_gpu_encode_sharded(None, 9, None, 0, ctypes.byref(bad), None, 0, None, 0, None, 0, None) == pkg.BZ_E_PARAM
 
 
 def _allgather_worker(rank, world, port, q):
