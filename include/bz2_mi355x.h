@@ -155,6 +155,9 @@ int bz_gpu_partition_slab_count(bz_gpu_engine *g, int64_t carry_run);
 int bz_gpu_partition_slab_finish(bz_gpu_engine *g, uint64_t start_in, int is_last, size_t *n_blocks,
                                  uint64_t *next_in, int *tail_block);
 
+/* Blocks of the last partition (what *n_blocks returned): sizes the host arrays of (b). */
+size_t bz_gpu_block_count(const bz_gpu_engine *g);
+
 /* (b) Encode blocks first, first+stride, ... (< n_blocks) of the last
  * partition.  Each block's bit string (block magic .. last payload bit,
  * MSB-first) is appended to d_packed as host-endian uint32 words whose bit 31

@@ -81,7 +81,7 @@ EXPORTS = [
     "bz_encode_buffer", "bz_free",
     "bz_gpu_engine_create", "bz_gpu_engine_destroy", "bz_encode_bound", "bz_gpu_encode_device",
     "bz_gpu_partition", "bz_gpu_partition_slab_begin", "bz_gpu_partition_slab_count",
-    "bz_gpu_partition_slab_finish", "bz_gpu_encode_blocks", "bz_gpu_assemble", "bz_gpu_encode_sharded",
+    "bz_gpu_partition_slab_finish", "bz_gpu_block_count", "bz_gpu_encode_blocks", "bz_gpu_assemble", "bz_gpu_encode_sharded",
     "bz_shard_comm_selftest", "bz_gpu_last_timings",
     "bz_gpu_last_bwt_stats", "bz_gpu_last_bwt_rounds", "bz_gpu_profile_enable", "bz_gpu_profile_kernels", "bz_gpu_profile_get",
     "bz_gpu_debug_bwt", "bz_gpu_debug_code_lengths", "bz_gpu_debug_block_stats",
@@ -154,6 +154,8 @@ def lib():
     L.bz_gpu_partition_slab_begin.argtypes = [vp, C.c_int, vp, sz, C.c_uint64, C.c_uint64, C.POINTER(C.c_int64)]
     L.bz_gpu_partition_slab_count.argtypes = [vp, C.c_int64]
     L.bz_gpu_partition_slab_finish.argtypes = [vp, C.c_uint64, C.c_int, szp, u64p, C.POINTER(C.c_int)]
+    L.bz_gpu_block_count.restype = sz
+    L.bz_gpu_block_count.argtypes = [vp]
     L.bz_gpu_encode_blocks.argtypes = [vp, sz, sz, vp, sz, u64p, u64p, u32p, szp]
     L.bz_gpu_assemble.argtypes = [vp, C.c_int, sz, vp, u64p, u64p, u32p, C.c_int, C.c_int, C.c_int,
                                   C.c_uint, C.c_uint, C.c_uint32, u32p, vp, sz, szp,
@@ -358,6 +360,9 @@ class Inflater:
 
     def next(self, it, action):
         """One `Encoder::next(iter, action)` call: an int byte, or None."""
+        if int(action) == Action.FLUSH:
+            # refused BEFORE any input is pulled: the caller's iterator is left untouched
+            raise CompressionError(BZ_E_PARAM)
         if self._pos >= len(self._ready) and self._refill() == 0:
             while True:
                 chunk = bytearray()
@@ -577,6 +582,10 @@ class GpuEngine:
         return nb.value, nxt.value, tail.value
 
     def encode_blocks(self, first, stride, n_blocks, d_packed, cap_words):
+        # the library writes one entry per block of ITS last partition: size the arrays from that count
+        have = lib().bz_gpu_block_count(self._h)
+        if n_blocks != have:
+            raise ValueError("encode_blocks: %d blocks asked for, the last partition made %d" % (n_blocks, have))
         k = max(0, (n_blocks - first + stride - 1) // stride) if n_blocks > first else 0
         woff = (C.c_uint64 * max(k, 1))()
         blen = (C.c_uint64 * max(k, 1))()

@@ -230,6 +230,7 @@ struct BwtArgs {
     u32 *nonfinal;                   // [nb]
     unsigned long long *active;      // [64] per-round count of non-final rotations in unfinished blocks
     u32 *per_k, *per_shift;          // [nb] periodic blocks: repetition count, least-rotation start
+    u32 *bin_cursor;                 // [nb][1024] rank words binned so far (k_group_apply -> k_rank_place)
     const u8 *sym_code;              // [nb][256] byte -> code (rank among the bytes in use)
     const u8 *keyinfo;               // [nb] KeyInfo {bits per symbol, symbols per key}
     // fused radix passes (no per-pass histogram kernel; tile offsets by decoupled look-back)
@@ -374,6 +375,7 @@ enum KernelId {
     KID_RADIX_SCATTER_LB, // fused pass: tile counts + look-back + scatter in one kernel
     KID_GHIST_TEXT,       // the three digit counts of a phase, one read of the text
     KID_GHIST_SCAN,
+    KID_RANK_PLACE,       // binned rank words -> the rank array, whole lines
     // decode path (k_dec.hip)
     KID_DEC_BLOCK,   // header + Huffman
     KID_DEC_MTF,     // chunk_perm + compose + chunk_emit

@@ -908,10 +908,23 @@ __global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 ste
 }
 
 // ---- group refinement, part 2: positions, new ranks, final bits ---------------------------
+// The new rank of rotation j is NOT written to R[j] from here: 4-byte stores at random into the 3.6 MB
+// rank array of a level-9 block run at 80-100 G/s (every store dirties a sector of its own; the lines
+// leave the XCD's L2 before they are full).  Instead the ranks are BINNED by j >> 10: a tile counts
+// its elements per bin in LDS, draws room for each bin from the block's bin cursors (one global
+// atomic per tile and non-empty bin -- the order inside a bin does not matter, so no look-back is
+// needed), re-orders the tile through LDS and writes runs of consecutive words; k_rank_place then
+// takes one bin (1024 ranks) per wave, puts the words in place in LDS and writes the rank array in
+// whole lines.  A word is (j & 1023) | head << 10 | final << 31; bin b owns the 1024 words behind
+// b * 1024 of the free key array (a rotation occurs once, so a bin cannot overflow).
+constexpr u32 kRankBinShift = 10, kRankBins = kSlot >> kRankBinShift; // 880 bins of 1024 rotations
+static_assert(kRankBins <= 1024 && (kRankBins << kRankBinShift) == kSlot, "bins tile the slot");
+
 template <bool INIT>
 __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 next_step, u32 round,
                                                                const u32 *__restrict__ K,
-                                                               const u32 *__restrict__ V)
+                                                               const u32 *__restrict__ V,
+                                                               u32 *__restrict__ W)
 {
     constexpr u32 NW = kSortThreads / 64;
     __shared__ int s_carry_old, s_carry_new;
@@ -920,6 +933,12 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
     // digit counts of the keys of the next walk round (the group heads of the members that are not
     // final yet): what its fused radix passes need instead of histogram kernels
     __shared__ u32 s_gh[2][1024];
+    // the bin scatter
+    __shared__ u32 s_stage[kSortTile];
+    __shared__ u16 s_binof[kSortTile];
+    __shared__ u32 s_bcnt[1024];  // elements of this tile per bin, then the bin's first output word
+    __shared__ u16 s_bpre[1024];  // exclusive prefix of the counts inside the tile
+    __shared__ u32 s_wsum[NW];
     u32 tile, lb;
     xcd_remap(kTilesPerBlock, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
@@ -930,6 +949,7 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
     const size_t base = (size_t)lb * kSlot;
     if (a.fused)
         for (u32 i = threadIdx.x; i < 2048u; i += kSortThreads) (&s_gh[0][0])[i] = 0;
+    for (u32 i = threadIdx.x; i < 1024u; i += kSortThreads) s_bcnt[i] = 0;
 
     if (threadIdx.x == 0) {
         int co = -1, cn = -1;
@@ -973,10 +993,13 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
     }
     const u64 le_mask = (l == 63) ? ~0ull : ((2ull << l) - 1ull);
     u32 my_nonfinal = 0;
+    u32 word[16], lrank[16]; // the rank word of each element and its number inside (tile, bin); ~0: none
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
         const u32 rowbase = wbase + r * 64u;
         const u32 idx = rowbase + l;
+        lrank[r] = 0xFFFFFFFFu;
+        word[r] = 0;
         if (idx < cnt) {
             const u64 o = mo[r] & le_mask, q = mn[r] & le_mask;
             const int rs = o ? (int)(rowbase + 63u - __clzll(o)) : carry_old;
@@ -994,7 +1017,8 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
             const u32 p = g + (idx - (u32)rs);
             const u32 head = g + ((u32)ss - (u32)rs);
             st_stream(a.SA + base + p, j);
-            a.R[base + j] = head | (fin ? kFinalBit : 0u);
+            word[r] = (j & 1023u) | (head << kRankBinShift) | (fin ? kFinalBit : 0u);
+            lrank[r] = atomicAdd(&s_bcnt[j >> kRankBinShift], 1u);
             my_nonfinal += fin ? 0u : 1u;
             if (a.fused && !fin) {
                 atomicAdd(&s_gh[0][head & 1023u], 1u);
@@ -1022,6 +1046,85 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
         const u32 h_next = ((u32)ki.chars * 2u) << next_step;
         if (h_next < n) atomicAdd(&a.active[round], (unsigned long long)s_nonfinal);
     }
+    // ---- bin scatter of the rank words
+    // exclusive prefix of the bin counts inside the tile (two consecutive bins per thread), and room
+    // for every non-empty bin from the block's cursors
+    {
+        const u32 b0 = threadIdx.x * 2u;
+        const u32 c0 = s_bcnt[b0], c1 = s_bcnt[b0 + 1];
+        const u32 mine = c0 + c1;
+        const u32 inc = wave_incl_sum(mine);
+        if (l == 63) s_wsum[w] = inc;
+        u32 g0 = 0, g1 = 0;
+        u32 *cur = a.bin_cursor + (size_t)lb * 1024u;
+        if (c0) g0 = atomicAdd(&cur[b0], c0);
+        if (c1) g1 = atomicAdd(&cur[b0 + 1], c1);
+        __syncthreads();
+        u32 carry = 0;
+        for (u32 k = 0; k < w; ++k) carry += s_wsum[k];
+        const u32 ex = carry + inc - mine;
+        s_bpre[b0] = (u16)ex;
+        s_bpre[b0 + 1] = (u16)(ex + c0);
+        s_bcnt[b0] = (b0 << kRankBinShift) + g0;
+        s_bcnt[b0 + 1] = ((b0 + 1u) << kRankBinShift) + g1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        if (lrank[r] != 0xFFFFFFFFu) {
+            const u32 bin = jv[r] >> kRankBinShift;
+            const u32 pos = (u32)s_bpre[bin] + lrank[r];
+            s_stage[pos] = word[r];
+            s_binof[pos] = (u16)bin;
+        }
+    }
+    __syncthreads();
+    const u32 total = (cnt - start) < kSortTile ? (cnt - start) : kSortTile;
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k) {
+        const u32 i = k * kSortThreads + threadIdx.x;
+        if (i < total) {
+            const u32 bin = s_binof[i];
+            W[base + s_bcnt[bin] + (i - (u32)s_bpre[bin])] = s_stage[i];
+        }
+    }
+}
+
+// One wave per bin: the rank words of bin b (a.bin_cursor[b] of them, behind W[b * 1024]) go to
+// R[b * 1024 + (word & 1023)].  A full bin (every round-0 bin but the last) is put in order in LDS and
+// written as whole lines; a partly filled one updates the lines it is loaded into; a sparse one
+// (later rounds) is scattered directly.
+__global__ __launch_bounds__(kSortThreads) void k_rank_place(BwtArgs a, const u32 *__restrict__ W)
+{
+    __shared__ u32 s_r[kSortThreads / 64][1024];
+    u32 tile, lb;
+    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    const u32 n = a.blocks[lb].n;
+    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const u32 bin = tile * (kSortThreads / 64) + w;
+    const u32 j0 = bin << kRankBinShift;
+    if (j0 >= n) return;
+    const u32 c = a.bin_cursor[(size_t)lb * 1024u + bin];
+    if (c == 0) return;
+    const size_t base = (size_t)lb * kSlot + j0;
+    const u32 span = (n - j0) < 1024u ? (n - j0) : 1024u;
+    u32 *mine = s_r[w];
+    if (c < 128u) {
+        for (u32 i = l; i < c; i += 64u) {
+            const u32 x = ld_stream(W + base + i);
+            a.R[base + (x & 1023u)] = ((x >> kRankBinShift) & 0xFFFFFu) | (x & kFinalBit);
+        }
+        return;
+    }
+    if (c < span)
+        for (u32 i = l; i < span; i += 64u) mine[i] = a.R[base + i];
+    // (LDS accesses of one wave retire in order: no barrier between the phases of a wave's own region)
+    for (u32 i = l; i < c; i += 64u) {
+        const u32 x = ld_stream(W + base + i);
+        mine[x & 1023u] = ((x >> kRankBinShift) & 0xFFFFFu) | (x & kFinalBit);
+    }
+    for (u32 i = l; i < span; i += 64u) a.R[base + i] = mine[i];
 }
 
 // ---- survivors of a round, compacted in list order ------------------------------------------------
@@ -1457,8 +1560,12 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
     int p = prof ? prof->begin(st, KID_GROUP_FLAGS, total_n * 9) : -1;
     hipLaunchKernelGGL((k_group_flags<true>), grid, dim3(kSortThreads), 0, st, a, 0u, a.KB, a.VB);
     if (prof) prof->end(st, p);
+    (void)hipMemsetAsync(a.bin_cursor, 0, (size_t)a.nb * 1024 * sizeof(u32), st);
     p = prof ? prof->begin(st, KID_GROUP_APPLY, total_n * 13) : -1;
-    hipLaunchKernelGGL((k_group_apply<true>), grid, dim3(kSortThreads), 0, st, a, 0u, 0u, a.KB, a.VB);
+    hipLaunchKernelGGL((k_group_apply<true>), grid, dim3(kSortThreads), 0, st, a, 0u, 0u, a.KB, a.VB, a.KA);
+    if (prof) prof->end(st, p);
+    p = prof ? prof->begin(st, KID_RANK_PLACE, total_n * 8) : -1;
+    hipLaunchKernelGGL(k_rank_place, grid, dim3(kSortThreads), 0, st, a, a.KA);
     if (prof) prof->end(st, p);
 
     u32 *cK = a.KB, *cV = a.VB; // the list the last refinement ran on
@@ -1504,8 +1611,12 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         p = prof ? prof->begin(st, KID_GROUP_FLAGS, m * 13) : -1;
         hipLaunchKernelGGL((k_group_flags<false>), grid, dim3(kSortThreads), 0, st, a, step, cK, cV);
         if (prof) prof->end(st, p);
+        (void)hipMemsetAsync(a.bin_cursor, 0, (size_t)a.nb * 1024 * sizeof(u32), st);
         p = prof ? prof->begin(st, KID_GROUP_APPLY, m * 17) : -1;
-        hipLaunchKernelGGL((k_group_apply<false>), grid, dim3(kSortThreads), 0, st, a, step + 1, slot, cK, cV);
+        hipLaunchKernelGGL((k_group_apply<false>), grid, dim3(kSortThreads), 0, st, a, step + 1, slot, cK, cV, fK);
+        if (prof) prof->end(st, p);
+        p = prof ? prof->begin(st, KID_RANK_PLACE, m * 8) : -1;
+        hipLaunchKernelGGL(k_rank_place, grid, dim3(kSortThreads), 0, st, a, fK);
         if (prof) prof->end(st, p);
         ++step;
     }

@@ -358,3 +358,45 @@ def test_pass_counter_wraps(pkg, oracle):
                 assert bytes(tout[:n].cpu().numpy()) == want, i
     finally:
         e.close()
+
+
+def test_streaming_across_chunk_boundaries(oracle):
+    """The host pipeline with 1 MiB chunks (BZ_ENC_CHUNK_MIB=1, read once per process): many chunks per
+    stream, block tails carried from chunk to chunk on the device, runs that cover whole chunks (the
+    pending-run scan then reads back device memory), Run / Flush / Finish sequences in between --
+    against the oracle's BZip2Encoder mirror, and the one-shot call against the oracle's stream."""
+    import subprocess
+    import sys
+    code = r'''
+import importlib, random, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+pkg = importlib.import_module("rust-compression_amd")
+from oracle import oracle
+from conftest import sample
+rng = random.Random(5)
+text = (sample(1) + sample(2)) * 6
+inputs = [
+    (text[:5_300_000], 1),
+    (text[:3_000_000] + b"\0" * 3_400_000 + text[:700_000] + b"q" * 1_048_576 + b"r" * 1_048_577 + text[:100], 1),
+    (b"\0" * 4_194_304, 9),
+    (text[:2_500_000], 9),
+]
+for data, level in inputs:
+    assert pkg.compress(data, level) == oracle.encode(data, level), ("one-shot", len(data), level)
+    enc, ref = pkg.BZip2Encoder(level), oracle.Encoder(level)
+    got, want, pos = bytearray(), bytearray(), 0
+    while pos < len(data):
+        k = rng.choice([1, 4096, 300_000, 1 << 20, (1 << 20) + 1, 2_500_000])
+        piece = data[pos:pos + k]
+        pos += len(piece)
+        act = rng.choice([0, 0, 0, 1]) if pos < len(data) else 2
+        enc.write(piece)
+        enc.end(act)
+        got += enc.read_all()
+        want += ref.encode_iter(piece, act)
+    assert bytes(got) == bytes(want), ("stream", len(data), level)
+print("ok")
+''' % (ROOT, ROOT)
+    e = dict(os.environ, BZ_ENC_CHUNK_MIB="1")
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-500:] + out.stderr[-3000:]
