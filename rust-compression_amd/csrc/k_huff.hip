@@ -17,7 +17,10 @@
 
 namespace bzgpu {
 
-constexpr u32 kHuffThreads = 512;
+#ifndef BZ_HUFF_THREADS
+#define BZ_HUFF_THREADS 512
+#endif
+constexpr u32 kHuffThreads = BZ_HUFF_THREADS;
 
 // encoder.rs:647-650
 __device__ __forceinline__ u32 weight_add(u32 x, u32 y)
@@ -294,6 +297,9 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
     else group_num = 6;
     const u32 n_selectors = (mtf_count + kGSize - 1) / kGSize;
 
+    // lanes 0 .. group_num-1 of wave 0 each own one coding table in the single-lane sections
+    const bool tab_lane = (wave == 0 && lane < group_num);
+    const u32 tb = lane; // the table of a tab_lane
     if (tid < 6) s_lm[tid] = 0;
     // initial tables, encoder.rs:379-426.  The scan produces n_part = group_num..1; its
     // k-th result is table (group_num-1-k) in selector order... which the reference then
@@ -333,6 +339,7 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
         for (u32 g0 = 0; g0 < n_selectors; g0 += kHuffThreads) {
             stage_symbols(s_sym, mtf, g0, mtf_count);
             __syncthreads();
+            BZ_HT(4)
             const u32 g = g0 + tid;
             if (g < n_selectors) {
                 const u32 gs = g * kGSize;
@@ -361,6 +368,7 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
                     }
                 }
                 selector[g] = (u8)bt;
+                BZ_HT(5)
                 if (big)
                     for (u32 i = 0; i < cnt; ++i) {
                         const u32 sy = (my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
@@ -376,9 +384,10 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
         }
         __syncthreads();
         BZ_HT(0)
-        // one lane per table replays the serial heap procedure
-        if (lane == 0 && wave < group_num)
-            s_need[wave] = (u32)heap_code_lengths(s_rfreq[wave], alpha, s_buf[wave], s_len[wave]);
+        // one lane per table replays the serial heap procedure: lanes 0..5 of wave 0, in lockstep (the
+        // tables are independent and run the same code; one wave instead of six keeps the workgroup
+        // free to be any size)
+        if (tab_lane) s_need[tb] = (u32)heap_code_lengths(s_rfreq[tb], alpha, s_buf[tb], s_len[tb]);
         __syncthreads();
         BZ_HT(1)
         // Tables whose longest code exceeds 17 bits are redone by the package-merge procedure
@@ -391,23 +400,23 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
             const u32 slots = (kHuffThreads * kGSize / 2) / need;
             u32 my_rank = 0, any = 0;
             for (u32 t = 0; t < group_num; ++t) {
-                if (t < wave) my_rank += s_need[t] ? 1u : 0u;
+                if (t < tb) my_rank += s_need[t] ? 1u : 0u;
                 any += s_need[t] ? 1u : 0u;
             }
             if (any) { // uniform
                 const u32 rounds_lm = slots ? (any + slots - 1) / slots : 1u;
                 for (u32 rd = 0; rd < rounds_lm; ++rd) {
-                    if (lane == 0 && wave < group_num && s_need[wave]) {
+                    if (tab_lane && s_need[tb]) {
                         if (slots == 0) {
                             if (rd == 0) {
-                                lm_code_lengths(s_rfreq[wave], alpha, a.lm_scratch + ((size_t)lb * 6 + wave) * kLmWords,
-                                                kLmWords, kLmRow, s_len[wave]);
-                                s_lm[wave] += 1;
+                                lm_code_lengths(s_rfreq[tb], alpha, a.lm_scratch + ((size_t)lb * 6 + tb) * kLmWords,
+                                                kLmWords, kLmRow, s_len[tb]);
+                                s_lm[tb] += 1;
                             }
                         } else if (my_rank / slots == rd) {
-                            lm_code_lengths(s_rfreq[wave], alpha, s_sym + (my_rank % slots) * need, need, row,
-                                            s_len[wave]);
-                            s_lm[wave] += 1;
+                            lm_code_lengths(s_rfreq[tb], alpha, s_sym + (my_rank % slots) * need, need, row,
+                                            s_len[tb]);
+                            s_lm[tb] += 1;
                         }
                     }
                     __syncthreads();
@@ -566,15 +575,15 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
     }
     const u32 tab_bit0 = sel_bit0 + sel_total;
     // table bits: 5 + sum over symbols of (2*|delta| + 1), one lane per table
-    if (lane == 0 && wave < group_num) {
-        const u8 *l = s_len[wave];
+    if (tab_lane) {
+        const u8 *l = s_len[tb];
         u32 nb = 5, curr = l[0];
         for (u32 i = 0; i < alpha; ++i) {
             const u32 li = l[i];
             nb += 2u * (li > curr ? li - curr : curr - li) + 1u;
             curr = li;
         }
-        s_first[wave][0] = nb; // s_first[t][0] is unused by the code assignment
+        s_first[tb][0] = nb; // s_first[t][0] is unused by the code assignment
     }
     __syncthreads();
     u32 tab_off[7];
@@ -630,9 +639,9 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
         }
     }
     // coding tables, :583-601: one lane per table
-    if (lane == 0 && wave < group_num) {
-        const u8 *l = s_len[wave];
-        u32 bp = tab_off[wave];
+    if (tab_lane) {
+        const u8 *l = s_len[tb];
+        u32 bp = tab_off[tb];
         u32 curr = l[0];
         put(bp, curr, 5);
         bp += 5;
@@ -665,7 +674,7 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
     BZ_HT(3)
 #ifdef BZ_HUFF_TIMING
     if (tid == 0 && lb == 7)
-        printf("k_huffman cycles: sweeps %llu heaps %llu lm %llu tail %llu\n", tm[0], tm[1], tm[2], tm[3]);
+        printf("k_huffman cycles: sweeps(hist+barriers) %llu heaps %llu lm %llu tail %llu staging %llu cost-loop %llu\n", tm[0], tm[1], tm[2], tm[3], tm[4], tm[5]);
 #endif
 }
 

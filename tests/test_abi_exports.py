@@ -61,3 +61,30 @@ def test_fails_loudly_without_gpu(pkg):
     assert ei.value.kind == "NoGpu"
     with pytest.raises(pkg.CompressionError):
         enc.end(pkg.Action.FINISH)
+
+
+def test_rust_crate_ffi_matches_the_library(pkg):
+    """rust_shim/ (the crate skeleton; no Rust toolchain here to build it): every extern "C" function
+    its src/ffi.rs declares is exported by the library and declared in the C header with the same
+    number of parameters; the crate has the reference's feature flags and prelude names."""
+    base = os.path.join(ROOT, "rust-compression_amd", "rust_shim")
+    ffi = open(os.path.join(base, "src", "ffi.rs")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "bz2_mi355x.h")).read(), flags=re.S)
+    L = pkg.lib()
+    decls = re.findall(r"pub fn ((?:bz|df)_[a-z0-9_]+)\(([^)]*)\)", ffi)
+    assert len(decls) >= 18
+    for name, params in decls:
+        assert hasattr(L, name), name
+        m = re.search(r"\b%s\s*\(([^)]*)\)" % name, hdr)
+        assert m, name
+        n_c = 0 if m.group(1).strip() in ("", "void") else m.group(1).count(",") + 1
+        n_rs = 0 if not params.strip() else params.count(",") + 1
+        assert n_c == n_rs, (name, n_c, n_rs)
+    cargo = open(os.path.join(base, "Cargo.toml")).read()
+    for feat in ("default", "all", "bzip2", "gzip", "deflate", "zlib", "std", "docs", "mi355x"):
+        assert re.search(r"^%s\s*=" % feat, cargo, flags=re.M), feat
+    lib_rs = open(os.path.join(base, "src", "lib.rs")).read()
+    for name in ("Action", "BZip2Decoder", "BZip2Encoder", "BZip2Error", "Inflater", "GZipEncoder", "ZlibEncoder",
+                 "CompressionError", "DecodeExt", "DecodeIterator", "Decoder", "EncodeExt", "EncodeIterator", "Encoder"):
+        assert re.search(r"pub use [a-z0-9_:]+(::|\{[^}]*)\b%s\b" % name, lib_rs), name
+    assert os.path.exists(os.path.join(base, "build.rs"))
