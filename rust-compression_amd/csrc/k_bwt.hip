@@ -616,7 +616,9 @@ __global__ __launch_bounds__(kSortThreads) void k_ghist_scan(BwtArgs a, u32 ndig
 }
 
 // the scatter of a fused pass; dpos selects the digit position inside gbase
-template <int SRC, int BITS>
+// WRITE_K = false: the keys are not stored (the pass that ends phase A of the init: phase B re-builds its
+// keys from the block and only walks the order)
+template <int SRC, int BITS, bool WRITE_K = true>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h,
                                                                     const u32 *__restrict__ Kin,
                                                                     const u32 *__restrict__ Vin,
@@ -784,7 +786,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
             const u32 kk = s_buf[i];
             const u32 dg = (kk >> shift) & (NB - 1);
             dst[k] = s_base[dg] + (i - (u32)s_tpre[dg]);
-            Kout[base + dst[k]] = kk;
+            if (WRITE_K) Kout[base + dst[k]] = kk;
         }
     }
     __syncthreads();
@@ -1016,7 +1018,7 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
             const u32 j = jv[r];
             const u32 p = g + (idx - (u32)rs);
             const u32 head = g + ((u32)ss - (u32)rs);
-            st_stream(a.SA + base + p, j);
+            if (!INIT) st_stream(a.SA + base + p, j); // (INIT: the list IS SA, p == idx)
             word[r] = (j & 1023u) | (head << kRankBinShift) | (fin ? kFinalBit : 0u);
             lrank[r] = atomicAdd(&s_bcnt[j >> kRankBinShift], 1u);
             my_nonfinal += fin ? 0u : 1u;
@@ -1442,7 +1444,7 @@ static u32 next_epoch(hipStream_t st, const BwtArgs &a)
     return e;
 }
 
-template <int SRC, int BITS>
+template <int SRC, int BITS, bool WRITE_K = true>
 static void fused_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const u32 *Kin, const u32 *Vin, u32 *Kout,
                        u32 *Vout, u32 dpos, u64 elems, KernelProf *prof, u64 out_elems = ~0ull)
 {
@@ -1450,8 +1452,8 @@ static void fused_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const
     const u64 rd = (SRC == SRC_TEXTK) ? 4 : ((SRC == SRC_WALK) ? 5 : 8);
     const u32 e = next_epoch(st, a);
     if (out_elems == ~0ull) out_elems = elems;
-    const int p = prof ? prof->begin(st, KID_RADIX_SCATTER_LB, elems * rd + out_elems * 8) : -1;
-    hipLaunchKernelGGL((k_radix_scatter_lb<SRC, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Kin, Vin, Kout, Vout,
+    const int p = prof ? prof->begin(st, KID_RADIX_SCATTER_LB, elems * rd + out_elems * (WRITE_K ? 8 : 4)) : -1;
+    hipLaunchKernelGGL((k_radix_scatter_lb<SRC, BITS, WRITE_K>), grid, dim3(kSortThreads), 0, st, a, shift, h, Kin, Vin, Kout, Vout,
                        dpos, e);
     if (prof) prof->end(st, p);
 }
@@ -1489,10 +1491,11 @@ static bool init_sort_fused(hipStream_t st, const BwtArgs &a, u64 total_n, Kerne
     fused_pass<SRC_TEXTK, B0>(st, a, 0, 0, a.KB, nullptr, a.KA, a.VA, 0, total_n, prof);
     if (!fused_pass_ok(st, a, *a.epoch)) return false;
     fused_pass<SRC_PAIRS, B1>(st, a, B0, 0, a.KA, a.VA, a.KB, a.VB, 1, total_n, prof);
-    fused_pass<SRC_PAIRS, B2>(st, a, B0 + B1, 0, a.KB, a.VB, a.KA, a.VA, 2, total_n, prof);
+    fused_pass<SRC_PAIRS, B2, false>(st, a, B0 + B1, 0, a.KB, a.VB, a.KA, a.VA, 2, total_n, prof); // (order only)
     fused_pass<SRC_WALK, B0>(st, a, 0, 0, a.KA, a.VA, a.KB, a.VB, 0, total_n, prof);
     fused_pass<SRC_PAIRS, B1>(st, a, B0, 0, a.KB, a.VB, a.KA, a.VA, 1, total_n, prof);
-    fused_pass<SRC_PAIRS, B2>(st, a, B0 + B1, 0, a.KA, a.VA, a.KB, a.VB, 2, total_n, prof);
+    // the last pass puts the order straight into SA: the first refinement leaves every rotation where it is
+    fused_pass<SRC_PAIRS, B2>(st, a, B0 + B1, 0, a.KA, a.VA, a.KB, a.SA, 2, total_n, prof);
     return true;
 }
 
@@ -1513,7 +1516,7 @@ static void init_sort(hipStream_t st, const BwtArgs &a, u64 total_n, KernelProf 
     radix_pass<SRC_PAIRS, B2>(st, a, B0 + B1, 0, a.KB, a.VB, a.KA, a.VA, total_n, prof);
     radix_pass<SRC_WALK, B0>(st, a, 0, 0, a.KA, a.VA, a.KB, a.VB, total_n, prof, a.KA);
     radix_pass<SRC_PAIRS, B1>(st, a, B0, 0, a.KB, a.VB, a.KA, a.VA, total_n, prof);
-    radix_pass<SRC_PAIRS, B2>(st, a, B0 + B1, 0, a.KA, a.VA, a.KB, a.VB, total_n, prof);
+    radix_pass<SRC_PAIRS, B2>(st, a, B0 + B1, 0, a.KA, a.VA, a.KB, a.SA, total_n, prof); // (the order goes straight into SA)
 }
 
 // Sorts the rotations of every block of the batch; leaves the order in a.SA.
@@ -1558,18 +1561,19 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         else init_sort<10, 10, 10>(st, a, total_n, prof);
     }
     int p = prof ? prof->begin(st, KID_GROUP_FLAGS, total_n * 9) : -1;
-    hipLaunchKernelGGL((k_group_flags<true>), grid, dim3(kSortThreads), 0, st, a, 0u, a.KB, a.VB);
+    hipLaunchKernelGGL((k_group_flags<true>), grid, dim3(kSortThreads), 0, st, a, 0u, a.KB, a.SA);
     if (prof) prof->end(st, p);
     (void)hipMemsetAsync(a.bin_cursor, 0, (size_t)a.nb * 1024 * sizeof(u32), st);
     p = prof ? prof->begin(st, KID_GROUP_APPLY, total_n * 13) : -1;
-    hipLaunchKernelGGL((k_group_apply<true>), grid, dim3(kSortThreads), 0, st, a, 0u, 0u, a.KB, a.VB, a.KA);
+    hipLaunchKernelGGL((k_group_apply<true>), grid, dim3(kSortThreads), 0, st, a, 0u, 0u, a.KB, a.SA, a.KA);
     if (prof) prof->end(st, p);
     p = prof ? prof->begin(st, KID_RANK_PLACE, total_n * 8) : -1;
     hipLaunchKernelGGL(k_rank_place, grid, dim3(kSortThreads), 0, st, a, a.KA);
     if (prof) prof->end(st, p);
 
-    u32 *cK = a.KB, *cV = a.VB; // the list the last refinement ran on
+    u32 *cK = a.KB, *cV = a.VB; // the list the last refinement ran on (after the init: keys in KB, order in SA)
     u32 *fK = a.KA, *fV = a.VA; // the free pair
+    const u32 *lastV = a.SA;    // the order that refinement ran on
     u32 step = 0; // this round compares at depth h = 2c << step
     int rounds = 0;
     u32 slot = 0;
@@ -1588,7 +1592,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         if (m * 4 < total_n) {
             // few survivors: compact them (list order = sorted by group), order them by the rank
             // of rotation j+h (2 passes), then stably by their own group (2 passes): O(m) work
-            hipLaunchKernelGGL(k_survivor_compact, grid, dim3(kSortThreads), 0, st, a, cV, fV);
+            hipLaunchKernelGGL(k_survivor_compact, grid, dim3(kSortThreads), 0, st, a, lastV, fV);
             hipLaunchKernelGGL(k_copy_counts, dim3((a.nb + 255) / 256), dim3(256), 0, st, a.count, a.count2, a.nb);
             radix_pass<SRC_SURV, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof);
             radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof);
@@ -1618,6 +1622,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         p = prof ? prof->begin(st, KID_RANK_PLACE, m * 8) : -1;
         hipLaunchKernelGGL(k_rank_place, grid, dim3(kSortThreads), 0, st, a, fK);
         if (prof) prof->end(st, p);
+        lastV = cV;
         ++step;
     }
     if (fused) {

@@ -222,6 +222,13 @@ __global__ __launch_bounds__(256) void k_mtf_ranks(MtfArgs a)
 // stay in step (the list walk above costs each step the LARGEST rank among its lanes).  The table
 // lives in LDS as [pair of symbols][lane] 2 x i16: conflict-free, 48 KiB for <= 96 symbols.
 constexpr u32 kMtfSmallPairs = kMtfSmallAlpha / 2;
+typedef short short2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ short2_t as_short2(u32 v)
+{
+    short2_t r;
+    __builtin_memcpy(&r, &v, 4);
+    return r;
+}
 __global__ __launch_bounds__(256) void k_mtf_ranks_small(MtfArgs a)
 {
     __shared__ u32 s_last[kMtfSmallPairs * 256];
@@ -273,12 +280,17 @@ __global__ __launch_bounds__(256) void k_mtf_ranks_small(MtfArgs a)
             if (p0 + k < end) {
                 const u32 c = s_code[(wv[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
                 const u32 wc = my[(c >> 1) * 256u];
-                const int ls = (int)(short)((c & 1u) ? (wc >> 16) : (wc & 0xFFFFu));
+                const u32 lsu = (c & 1u) ? (wc >> 16) : (wc & 0xFFFFu);
+                // both halves of a table word against the symbol's own time in packed 16-bit arithmetic:
+                // ls - t saturates (a never-seen -32768 must not wrap), its sign says t > ls
+                const short2_t ls2 = as_short2(lsu | (lsu << 16));
+                short2_t acc = {0, 0};
                 for (u32 q = 0; q < npairs; ++q) {
-                    const u32 wd = my[q * 256u];
-                    rank += ((int)(short)(wd & 0xFFFFu) > ls) ? 1u : 0u;
-                    rank += ((int)(short)(wd >> 16) > ls) ? 1u : 0u;
+                    const short2_t wd = as_short2(my[q * 256u]);
+                    const short2_t neg = __builtin_elementwise_sub_sat(ls2, wd) >> (short2_t){15, 15}; // -1 where t > ls
+                    acc -= neg;
                 }
+                rank = (u32)(int)acc.x + (u32)(int)acc.y;
                 const u32 t = (v * 16u + k) & 0xFFFFu; // time inside the chunk, 0..kMtfChunk-1
                 my[(c >> 1) * 256u] = (c & 1u) ? ((wc & 0x0000FFFFu) | (t << 16)) : ((wc & 0xFFFF0000u) | t);
             }
