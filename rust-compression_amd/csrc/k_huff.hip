@@ -257,7 +257,7 @@ __device__ __forceinline__ void stage_symbols(u32 *s_sym, const u16 *__restrict_
     }
 }
 
-__global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
+__global__ __launch_bounds__(kHuffThreads, 4) void k_huffman(HuffArgs a) // (4 waves per SIMD = two workgroups per CU)
 {
     __shared__ u8 s_len[6][kMaxAlpha + 6];
     __shared__ u32 s_rfreq[6][kMaxAlpha];
@@ -352,11 +352,34 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
                 // whole workgroup on a handful of hot counters).
                 unsigned long long cost = 0, c8 = 0;
                 u32 big = 0;
-                for (u32 i = 0; i < cnt; ++i) {
-                    const u32 sy = (my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
-                    cost += s_pack[sy];
-                    if (sy < 8u) c8 += 1ull << (8u * sy);
-                    else ++big;
+                if (cnt == kGSize) {
+                    // a full group (all but a block's last): fixed trip count, so the LDS reads are issued
+                    // in batches instead of one dependent pair per symbol (the loop was bound by LDS latency:
+                    // ~300 cycles per symbol with four waves per SIMD).  Five dwords = ten symbols at a time:
+                    // more in flight costs the registers that let two workgroups share a CU.
+#pragma unroll 1
+                    for (u32 k0 = 0; k0 < kGSize / 2; k0 += 5) {
+                        u32 dw[5];
+#pragma unroll
+                        for (u32 k = 0; k < 5; ++k) dw[k] = my[k0 + k];
+#pragma unroll
+                        for (u32 k = 0; k < 5; ++k) {
+                            const u32 s0 = dw[k] & 0xFFFFu, s1 = dw[k] >> 16;
+                            cost += s_pack[s0];
+                            cost += s_pack[s1];
+                            if (s0 < 8u) c8 += 1ull << (8u * s0);
+                            else ++big;
+                            if (s1 < 8u) c8 += 1ull << (8u * s1);
+                            else ++big;
+                        }
+                    }
+                } else {
+                    for (u32 i = 0; i < cnt; ++i) {
+                        const u32 sy = (my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
+                        cost += s_pack[sy];
+                        if (sy < 8u) c8 += 1ull << (8u * sy);
+                        else ++big;
+                    }
                 }
                 // first minimum wins (min_by, encoder.rs:466)
                 u32 bt = 0, bc = (u32)(cost & 1023u);
@@ -369,11 +392,22 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
                 }
                 selector[g] = (u8)bt;
                 BZ_HT(5)
-                if (big)
-                    for (u32 i = 0; i < cnt; ++i) {
-                        const u32 sy = (my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
-                        if (sy >= 8u) atomicAdd(&s_rfreq[bt][sy], 1u);
+                if (big) {
+                    if (cnt == kGSize) {
+#pragma unroll 5
+                        for (u32 k = 0; k < kGSize / 2; ++k) {
+                            const u32 d = my[k];
+                            const u32 s0 = d & 0xFFFFu, s1 = d >> 16;
+                            if (s0 >= 8u) atomicAdd(&s_rfreq[bt][s0], 1u);
+                            if (s1 >= 8u) atomicAdd(&s_rfreq[bt][s1], 1u);
+                        }
+                    } else {
+                        for (u32 i = 0; i < cnt; ++i) {
+                            const u32 sy = (my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
+                            if (sy >= 8u) atomicAdd(&s_rfreq[bt][sy], 1u);
+                        }
                     }
+                }
 #pragma unroll
                 for (u32 q = 0; q < 8; ++q) {
                     const u32 c = (u32)(c8 >> (8u * q)) & 0xFFu;
@@ -477,7 +511,15 @@ __global__ __launch_bounds__(kHuffThreads) void k_huffman(HuffArgs a)
             const u32 cnt = (gs + kGSize < mtf_count) ? kGSize : mtf_count - gs;
             const u32 *my = s_sym + tid * (kGSize / 2);
             const u8 *l = s_len[selector[g]];
-            for (u32 i = 0; i < cnt; ++i) bits += l[(my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu];
+            if (cnt == kGSize) {
+#pragma unroll 5
+                for (u32 k = 0; k < kGSize / 2; ++k) {
+                    const u32 d = my[k];
+                    bits += (u32)l[d & 0xFFFFu] + (u32)l[d >> 16];
+                }
+            } else {
+                for (u32 i = 0; i < cnt; ++i) bits += l[(my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu];
+            }
         }
         const u32 inc = wave_incl_sum(bits);
         if (lane == 63) s_scan[wave] = inc;
