@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--level", type=int, default=9)
     ap.add_argument("--cpu-sample-mib", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="(accepted for tools/profile.sh; this bench has no extras)")
     ap.add_argument("--corpus", default="text", choices=["text", "t2"])
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path even with one rank")
     args = ap.parse_args()

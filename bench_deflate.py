@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--kind", type=int, default=0)
     ap.add_argument("--cpu-sample-mib", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="(accepted for tools/profile.sh; this bench has no extras)")
     ap.add_argument("--verify-full", action="store_true", help="inflate the whole stream with zlib and compare (slow)")
     ap.add_argument("--force-replicas", action="store_true", help="run the N > 1 code path with one rank")
     args = ap.parse_args()

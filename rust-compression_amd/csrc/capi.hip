@@ -67,19 +67,23 @@ extern "C" const char *bz_version(void) { return "bz2_mi355x 0.1 (gfx950)"; }
 // per-device cache), so a call does not pay hipMalloc / hipHostMalloc again.
 struct EncResources {
     int device = 0;
-    bz_gpu_engine *g = nullptr;
+    // Two LANES: jobs alternate between them (two engines, each with its own streams and buffers), so
+    // that the latency-bound tail of one chunk's encode (Huffman: one workgroup per block) runs beside
+    // the bandwidth-bound sort of the next.  The second engine is created when a second job is in flight.
+    bz_gpu_engine *g[2] = {nullptr, nullptr};
+    size_t engine_blocks = 0;
     size_t chunk = 0;            // bytes per pinned / device staging buffer
     u8 *h_in[2] = {nullptr, nullptr};   // pinned
     void *d_stage[2] = {nullptr, nullptr};
-    void *d_buf[2] = {nullptr, nullptr}; // composed input: tail of the previous chunk + the chunk
+    void *d_buf[2] = {nullptr, nullptr}; // per lane: composed input = tail of the previous job's input + the chunk
     size_t d_buf_cap[2] = {0, 0};
-    void *d_out = nullptr;
-    size_t d_out_cap = 0;
-    void *d_packed = nullptr;
-    size_t d_packed_cap = 0;
+    void *d_out[2] = {nullptr, nullptr};
+    size_t d_out_cap[2] = {0, 0};
+    void *d_packed[2] = {nullptr, nullptr};
+    size_t d_packed_cap[2] = {0, 0};
     u8 *h_out[2] = {nullptr, nullptr};   // pinned: stream bytes on their way to the output queue
     size_t h_out_cap[2] = {0, 0};
-    hipStream_t st_up = nullptr, st_io = nullptr, st_down = nullptr;
+    hipStream_t st_up = nullptr, st_io[2] = {nullptr, nullptr};
     hipEvent_t ev_up[2] = {nullptr, nullptr};
     hipEvent_t ev_down[2] = {nullptr, nullptr};
 };
@@ -121,13 +125,12 @@ static void resources_free(EncResources *r)
         if (r->ev_up[i]) (void)hipEventDestroy(r->ev_up[i]);
         if (r->ev_down[i]) (void)hipEventDestroy(r->ev_down[i]);
         if (r->h_out[i]) (void)hipHostFree(r->h_out[i]);
+        if (r->d_out[i]) (void)hipFree(r->d_out[i]);
+        if (r->d_packed[i]) (void)hipFree(r->d_packed[i]);
+        if (r->st_io[i]) (void)hipStreamDestroy(r->st_io[i]);
+        if (r->g[i]) bz_gpu_engine_destroy(r->g[i]);
     }
-    if (r->d_out) (void)hipFree(r->d_out);
-    if (r->d_packed) (void)hipFree(r->d_packed);
     if (r->st_up) (void)hipStreamDestroy(r->st_up);
-    if (r->st_io) (void)hipStreamDestroy(r->st_io);
-    if (r->st_down) (void)hipStreamDestroy(r->st_down);
-    if (r->g) bz_gpu_engine_destroy(r->g);
     delete r;
 }
 
@@ -148,8 +151,8 @@ static int resources_get(int device, EncResources **out)
     r->chunk = enc_chunk_bytes();
     // blocks in flight: a chunk of level-9 text is chunk / 0.9 MB blocks (lower levels and run-heavy
     // inputs take several batches)
-    const size_t blocks = r->chunk / 800000 + 16;
-    int rc = bz_gpu_engine_create(&r->g, device, blocks);
+    r->engine_blocks = r->chunk / 800000 + 16;
+    int rc = bz_gpu_engine_create(&r->g[0], device, r->engine_blocks);
     if (rc != BZ_OK) {
         delete r;
         return rc;
@@ -162,8 +165,8 @@ static int resources_get(int device, EncResources **out)
         ok = ok && hipEventCreateWithFlags(&r->ev_down[i], hipEventDisableTiming) == hipSuccess;
     }
     ok = ok && hipStreamCreateWithFlags(&r->st_up, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&r->st_io, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&r->st_down, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&r->st_io[0], hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&r->st_io[1], hipStreamNonBlocking) == hipSuccess;
     if (!ok) {
         resources_free(r);
         return BZ_E_NOMEM;
@@ -181,6 +184,7 @@ static void resources_put(EncResources *r)
 }
 
 struct EncJob {
+    u64 seq;         // number of the job in the stream; its lane is seq & 1
     int slot;        // pinned / staging buffer holding the chunk (-1: no data, only the Action)
     size_t n;        // bytes of the chunk
     int mode;        // BZ_ACTION_*
@@ -202,11 +206,13 @@ struct bz_enc {
     std::thread drainer;
     std::deque<std::pair<int, size_t>> drains; // (pinned buffer, bytes)
     u64 drained = 0, drain_queued = 0;
-    int down_slot = 0;
+    bool drain_busy[2] = {false, false}; // a lane's pinned output buffer is waiting for the drainer
     // reference state (owned by the worker while jobs are in flight)
     bool finished = false;       // BZip2Encoder.finished      (encoder.rs:45)
     bool bit_finished = false;   // BZip2Encoder.bit_finished  (encoder.rs:48)
-    bool inner_finished = false; // EncoderInner.finished      (encoder.rs:164)
+    bool inner_finished = false; // EncoderInner.finished      (encoder.rs:164), set by the worker that assembles Finish
+    bool finish_submitted = false; // ... and the caller's copy: a Finish job has been handed over
+    bool oneshot = false;          // bz_encode_buffer: the output queue is read only at the end
     bool any_block = false;      // block_no > 1               (encoder.rs:168,179)
     u32 combined_crc = 0;        // encoder.rs:167
     unsigned carry_bits = 0;     // BitWriter.counter          (writer.rs:167)
@@ -214,12 +220,17 @@ struct bz_enc {
     // input side (caller's thread)
     int fill_slot = 0;
     size_t fill = 0;
+    u64 chunks_filled = 0;       // chunks handed over so far
     u64 submitted = 0;           // data chunks handed to the worker
-    // device input of the worker: d_buf[cur] holds `tail_len` unconsumed bytes at offset `tail_off`
-    int cur = 0;
+    // Chain state 1 (handed from a job's SPLIT phase to the next job's): the unconsumed input lies in
+    // d_buf[tail_lane], `tail_len` bytes at offset `tail_off`; finish_seen: a Finish job has been split
+    int tail_lane = 0;
     size_t tail_off = 0, tail_len = 0;
-    // worker
-    std::thread worker;
+    bool finish_seen = false;
+    u64 split_done = 0; // jobs whose split phase is over
+    u64 asm_done = 0;   // jobs whose assembly phase is over (chain state 2: carry bits, combined CRC, any_block)
+    // workers: one per lane
+    std::thread worker[2];
     std::mutex mu;
     std::condition_variable cv;
     std::deque<EncJob> jobs;
@@ -290,6 +301,8 @@ static int pending_chunk_start(bz_enc *e, const u8 *d, size_t n, size_t chunk_n,
     return BZ_OK;
 }
 
+static void copy_in(u8 *dst, const u8 *src, size_t n);
+
 // appends to the output queue (out_mu held by the caller)
 static int out_append_locked(bz_enc *e, const u8 *p, size_t n)
 {
@@ -308,8 +321,25 @@ static int out_append_locked(bz_enc *e, const u8 *p, size_t n)
             e->out_cap = want;
         }
     }
-    memcpy(e->out + e->out_len, p, n);
+    copy_in(e->out + e->out_len, p, n); // (large pieces on several threads)
     e->out_len += n;
+    if (e->oneshot && n >= ((size_t)1 << 20)) {
+        // One-shot call: nobody reads the queue before the end, and the bytes of the LAST job are copied
+        // with nothing left to hide them behind.  Make room for a piece like this one now and touch its
+        // pages (first-touch page faults cost more than the copy), while the GPU is busy with the next job.
+        const size_t want = e->out_len + n + n / 4;
+        if (want > e->out_cap) {
+            u8 *q = (u8 *)realloc(e->out, want);
+            if (q) {
+                e->out = q;
+                e->out_cap = want;
+            }
+        }
+        if (e->out_cap > e->out_len) {
+            volatile u8 *t = e->out + e->out_len;
+            for (size_t i = 0; i < e->out_cap - e->out_len; i += 4096) t[i] = 0;
+        }
+    }
     return BZ_OK;
 }
 
@@ -332,112 +362,43 @@ static void drainer_main(bz_enc *e)
         {
             std::lock_guard<std::mutex> lk(e->mu);
             if (rc != BZ_OK && e->err == BZ_OK) e->err = rc;
+            e->drain_busy[d.first] = false;
             e->drained += 1;
         }
         e->cv.notify_all();
     }
 }
 
-// One bulk replay of the write_block calls the reference would have made for `mode` over the device
-// input d[0..n_all) (worker thread).  *drop = input bytes that went into blocks.
-static int process(bz_enc *e, const u8 *d, size_t n_all, size_t chunk_n, size_t tail_run, int mode, size_t *drop)
-{
-    EncResources *r = e->r;
-    *drop = 0;
-    size_t n_eff = n_all;
-    int rc;
-    if (mode != BZ_ACTION_FINISH && (rc = pending_chunk_start(e, d, n_all, chunk_n, tail_run, &n_eff)) != BZ_OK) return rc;
-    size_t n_blocks = 0, consumed = 0;
+// ---- one job = (optional chunk of input) + the Action it arrived under, in three phases -----------
+// A job replays in bulk the write_block calls the reference would have made for its Action over the
+// input that is pending (src/bzip2/encoder.rs:671-739, :224-291):
+//   SPLIT     compose the device input (unconsumed tail of the previous job + the chunk), RLE1 + block
+//             split on the lane's engine.  Serial from job to job: it needs the previous job's tail and
+//             hands its own on (chain state 1).
+//   ENCODE    the blocks (rotation sort, MTF, Huffman, bit emission).  Independent of every other job:
+//             two jobs (one per lane) are in this phase at the same time.
+//   ASSEMBLE  concatenate the block bit strings behind the stream so far (BitWriter carry, combined
+//             CRC, "has a block been written": chain state 2), download, queue for the output.
+//             Serial from job to job.
+struct JobState {
+    const u8 *d = nullptr;
+    size_t n_all = 0, n_eff = 0, n_blocks = 0, consumed = 0;
     int tail = 0;
+    bool skipped = false; // input after Finish
     std::vector<uint64_t> woff, blen;
     std::vector<uint32_t> crc;
-    const double t0 = now_ms();
-    double t1 = t0, t2 = t0;
-    if (n_eff > 0) {
-        rc = bz_gpu_partition(r->g, e->level, d, n_eff, mode, &n_blocks, &consumed, &tail);
-        if (rc != BZ_OK) return rc;
-        t1 = now_ms();
-        if (n_blocks) {
-            woff.resize(n_blocks);
-            blen.resize(n_blocks);
-            crc.resize(n_blocks);
-            const size_t cap_words = bz_encode_bound(n_eff) / 4 + 2 * n_blocks + 16;
-            if ((rc = grow(&r->d_packed, &r->d_packed_cap, cap_words * 4)) != BZ_OK) return rc;
-            size_t used = 0;
-            rc = bz_gpu_encode_blocks(r->g, 0, 1, r->d_packed, cap_words, woff.data(), blen.data(), crc.data(), &used);
-            if (rc != BZ_OK) return rc;
-        }
-        t2 = now_ms();
-    }
-    if (mode == BZ_ACTION_RUN && n_blocks == 0) return BZ_OK; // no write_block call happened
+    double t0 = 0, t1 = 0, t2 = 0;
+};
 
-    // The flush()/finish() call itself sees an empty block_buf when every byte went into
-    // blocks closed by a cut (or there was nothing at all).
-    const bool final_call_empty =
-        (mode == BZ_ACTION_FLUSH && !(n_blocks > 0 && tail)) || (mode == BZ_ACTION_FINISH && n_blocks == 0);
-    u32 comb = e->combined_crc;
-    const int write_header = e->any_block ? 0 : 1; // block_no == 1 (encoder.rs:245)
-    if (final_call_empty && n_blocks == 0) comb = rotl1(comb) ^ 0u; // encoder.rs:237-238, crc of nothing = 0
-    const int trailer = (mode == BZ_ACTION_FINISH) ? 1 : 0;
-
-    size_t bits_bound = 0;
-    for (size_t k = 0; k < n_blocks; ++k) bits_bound += (size_t)blen[k];
-    const size_t out_cap = bits_bound / 8 + 64;
-    if ((rc = grow(&r->d_out, &r->d_out_cap, out_cap)) != BZ_OK) return rc;
-    size_t out_len = 0;
-    unsigned ocb = 0, ocy = 0;
-    u32 comb_out = comb;
-    rc = bz_gpu_assemble(r->g, e->level, n_blocks, r->d_packed, woff.data(), blen.data(), crc.data(), write_header,
-                         trailer, 0, e->carry_bits, e->carry_byte, comb, &comb_out, r->d_out, r->d_out_cap, &out_len,
-                         &ocb, &ocy);
-    if (rc != BZ_OK) return rc;
-    if (out_len) {
-        // device -> pinned buffer (waited for: the next chunk's assembly reuses d_out), then over to the
-        // drainer thread, which appends to the output queue while the worker goes on
-        const int s = e->down_slot;
-        {
-            std::unique_lock<std::mutex> lk(e->mu);
-            e->cv.wait(lk, [&] { return e->drained + 2 > e->drain_queued; }); // pinned buffer s is free again
-        }
-        if ((rc = grow_pinned(&r->h_out[s], &r->h_out_cap[s], out_len)) != BZ_OK) return rc;
-        if (hipMemcpyAsync(r->h_out[s], r->d_out, out_len, hipMemcpyDeviceToHost, r->st_io) != hipSuccess ||
-            hipStreamSynchronize(r->st_io) != hipSuccess)
-            return BZ_E_UNEXPECTED;
-        {
-            std::lock_guard<std::mutex> lk(e->mu);
-            e->drains.emplace_back(s, out_len);
-            e->drain_queued += 1;
-        }
-        e->cv.notify_all();
-        e->down_slot ^= 1;
-    }
-    if (enc_trace())
-        fprintf(stderr, "bz_enc job: mode %d, %zu bytes, %zu blocks: split %.2f ms, encode %.2f ms, assemble+download %.2f ms (at %.1f)\n",
-                mode, n_all, n_blocks, t1 - t0, t2 - t1, now_ms() - t2, now_ms());
-    e->carry_bits = ocb;
-    e->carry_byte = ocy;
-    if (final_call_empty && n_blocks > 0) comb_out = rotl1(comb_out); // the extra, empty write_block(false)
-    e->combined_crc = comb_out;
-    if (n_blocks > 0) e->any_block = true;
-    // the bytes that went into blocks
-    *drop = (mode == BZ_ACTION_RUN) ? consumed : n_eff;
-    if (mode == BZ_ACTION_FINISH) {
-        *drop = n_all;
-        e->inner_finished = true;
-    }
-    return BZ_OK;
-}
-
-// worker: one job = (optional chunk of input) + the Action it arrived under
-static int run_job(bz_enc *e, const EncJob &j)
+static int job_split(bz_enc *e, const EncJob &j, int lane, JobState &js)
 {
     EncResources *r = e->r;
-    if (hipSetDevice(e->device) != hipSuccess) return BZ_E_UNEXPECTED;
-    if (e->inner_finished) {
+    if (e->finish_seen) {
         // Input that arrives after Finish is not encoded.  (The reference keeps collecting it, EncoderInner::next
         // has no `finished` test, encoder.rs:671-697, and would write further blocks BEHIND the trailer once
         // another 900 KB have come in; flush() and finish() do nothing any more, :718-739.  Such output is no
         // .bz2 stream; the corner is not mirrored -- documented in INTEGRATION.md.)
+        js.skipped = true;
         if (j.n) {
             if (hipEventSynchronize(r->ev_up[j.slot]) != hipSuccess) return BZ_E_UNEXPECTED;
             {
@@ -448,75 +409,183 @@ static int run_job(bz_enc *e, const EncJob &j)
         }
         return BZ_OK;
     }
-    const size_t n_all = e->tail_len + j.n;
-    const u8 *d = nullptr;
-    if (j.n) {
-        // compose: the unconsumed tail of the previous input, then the new chunk
-        const int other = e->cur ^ 1;
-        int rc = grow(&r->d_buf[other], &r->d_buf_cap[other], n_all + 64);
+    if (!r->g[lane]) { // the second lane's engine: created when a second job is in flight
+        const int rc = bz_gpu_engine_create(&r->g[lane], e->device, r->engine_blocks);
         if (rc != BZ_OK) return rc;
-        if (e->tail_len &&
-            hipMemcpyAsync(r->d_buf[other], (const u8 *)r->d_buf[e->cur] + e->tail_off, e->tail_len, hipMemcpyDeviceToDevice,
-                           r->st_io) != hipSuccess)
-            return BZ_E_UNEXPECTED;
-        if (hipStreamWaitEvent(r->st_io, r->ev_up[j.slot], 0) != hipSuccess) return BZ_E_UNEXPECTED;
-        if (hipMemcpyAsync((u8 *)r->d_buf[other] + e->tail_len, r->d_stage[j.slot], j.n, hipMemcpyDeviceToDevice, r->st_io) !=
-                hipSuccess ||
-            hipStreamSynchronize(r->st_io) != hipSuccess)
-            return BZ_E_UNEXPECTED;
-        e->cur = other;
-        e->tail_off = 0;
-        e->tail_len = n_all;
-        {
-            std::lock_guard<std::mutex> lk(e->mu);
-            e->composed += 1; // the staging buffer may take the next upload
-        }
-        e->cv.notify_all();
-        d = (const u8 *)r->d_buf[e->cur];
-    } else if (e->tail_len) {
-        // (the composed input is 16-byte aligned at offset 0 only: move a tail that is not at the start)
-        if (e->tail_off) {
-            const int other = e->cur ^ 1;
-            int rc = grow(&r->d_buf[other], &r->d_buf_cap[other], n_all + 64);
-            if (rc != BZ_OK) return rc;
-            if (hipMemcpyAsync(r->d_buf[other], (const u8 *)r->d_buf[e->cur] + e->tail_off, e->tail_len, hipMemcpyDeviceToDevice,
-                               r->st_io) != hipSuccess ||
-                hipStreamSynchronize(r->st_io) != hipSuccess)
-                return BZ_E_UNEXPECTED;
-            e->cur = other;
-            e->tail_off = 0;
-        }
-        d = (const u8 *)r->d_buf[e->cur];
     }
-    size_t drop = 0;
-    const int rc = process(e, d, n_all, j.n, j.tail_run, j.mode, &drop);
-    if (rc != BZ_OK) return rc;
-    e->tail_off += drop;
-    e->tail_len = n_all - drop;
+    js.t0 = now_ms();
+    js.n_all = e->tail_len + j.n;
+    if (js.n_all) {
+        // compose: the unconsumed tail of the previous job's input, then the new chunk
+        int rc = grow(&r->d_buf[lane], &r->d_buf_cap[lane], js.n_all + 64);
+        if (rc != BZ_OK) return rc;
+        hipStream_t st = r->st_io[lane];
+        if (e->tail_len && !(e->tail_lane == lane && e->tail_off == 0) &&
+            hipMemcpyAsync(r->d_buf[lane], (const u8 *)r->d_buf[e->tail_lane] + e->tail_off, e->tail_len,
+                           hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return BZ_E_UNEXPECTED; // (same lane: forward move by tail_off >= tail_len is not guaranteed -- see below)
+        if (j.n) {
+            if (hipStreamWaitEvent(st, r->ev_up[j.slot], 0) != hipSuccess) return BZ_E_UNEXPECTED;
+            if (hipMemcpyAsync((u8 *)r->d_buf[lane] + e->tail_len, r->d_stage[j.slot], j.n, hipMemcpyDeviceToDevice, st) !=
+                hipSuccess)
+                return BZ_E_UNEXPECTED;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) return BZ_E_UNEXPECTED;
+        if (j.n) {
+            {
+                std::lock_guard<std::mutex> lk(e->mu);
+                e->composed += 1; // the staging buffer may take the next upload
+            }
+            e->cv.notify_all();
+        }
+        js.d = (const u8 *)r->d_buf[lane];
+    }
+    js.n_eff = js.n_all;
+    int rc;
+    if (j.mode != BZ_ACTION_FINISH &&
+        (rc = pending_chunk_start(e, js.d, js.n_all, j.n, j.tail_run, &js.n_eff)) != BZ_OK)
+        return rc;
+    if (js.n_eff > 0) {
+        rc = bz_gpu_partition(r->g[lane], e->level, js.d, js.n_eff, j.mode, &js.n_blocks, &js.consumed, &js.tail);
+        if (rc != BZ_OK) return rc;
+    }
+    js.t1 = now_ms();
+    // the bytes that went into blocks; what is left is the next job's tail
+    size_t drop;
+    if (j.mode == BZ_ACTION_RUN) drop = js.n_blocks ? js.consumed : 0;
+    else if (j.mode == BZ_ACTION_FLUSH) drop = js.n_eff;
+    else drop = js.n_all;
+    e->tail_lane = lane;
+    e->tail_off = drop;
+    e->tail_len = js.n_all - drop;
+    if (j.mode == BZ_ACTION_FINISH) e->finish_seen = true;
     return BZ_OK;
 }
 
-static void worker_main(bz_enc *e)
+static int job_encode(bz_enc *e, int lane, JobState &js)
+{
+    EncResources *r = e->r;
+    if (js.skipped || js.n_blocks == 0) {
+        js.t2 = now_ms();
+        return BZ_OK;
+    }
+    js.woff.resize(js.n_blocks);
+    js.blen.resize(js.n_blocks);
+    js.crc.resize(js.n_blocks);
+    const size_t cap_words = bz_encode_bound(js.n_eff) / 4 + 2 * js.n_blocks + 16;
+    int rc = grow(&r->d_packed[lane], &r->d_packed_cap[lane], cap_words * 4);
+    if (rc != BZ_OK) return rc;
+    size_t used = 0;
+    rc = bz_gpu_encode_blocks(r->g[lane], 0, 1, r->d_packed[lane], cap_words, js.woff.data(), js.blen.data(), js.crc.data(),
+                              &used);
+    js.t2 = now_ms();
+    return rc;
+}
+
+static int job_assemble(bz_enc *e, const EncJob &j, int lane, JobState &js)
+{
+    EncResources *r = e->r;
+    const int mode = j.mode;
+    const size_t n_blocks = js.n_blocks;
+    if (js.skipped) return BZ_OK;
+    if (mode == BZ_ACTION_RUN && n_blocks == 0) return BZ_OK; // no write_block call happened
+
+    // The flush()/finish() call itself sees an empty block_buf when every byte went into
+    // blocks closed by a cut (or there was nothing at all).
+    const bool final_call_empty =
+        (mode == BZ_ACTION_FLUSH && !(n_blocks > 0 && js.tail)) || (mode == BZ_ACTION_FINISH && n_blocks == 0);
+    u32 comb = e->combined_crc;
+    const int write_header = e->any_block ? 0 : 1; // block_no == 1 (encoder.rs:245)
+    if (final_call_empty && n_blocks == 0) comb = rotl1(comb) ^ 0u; // encoder.rs:237-238, crc of nothing = 0
+    const int trailer = (mode == BZ_ACTION_FINISH) ? 1 : 0;
+
+    size_t bits_bound = 0;
+    for (size_t k = 0; k < n_blocks; ++k) bits_bound += (size_t)js.blen[k];
+    const size_t out_cap = bits_bound / 8 + 64;
+    int rc;
+    if ((rc = grow(&r->d_out[lane], &r->d_out_cap[lane], out_cap)) != BZ_OK) return rc;
+    size_t out_len = 0;
+    unsigned ocb = 0, ocy = 0;
+    u32 comb_out = comb;
+    rc = bz_gpu_assemble(r->g[lane], e->level, n_blocks, r->d_packed[lane], js.woff.data(), js.blen.data(), js.crc.data(),
+                         write_header, trailer, 0, e->carry_bits, e->carry_byte, comb, &comb_out, r->d_out[lane],
+                         r->d_out_cap[lane], &out_len, &ocb, &ocy);
+    if (rc != BZ_OK) return rc;
+    if (out_len) {
+        // device -> the lane's pinned buffer (free again once the drainer has appended the lane's previous
+        // bytes), then over to the drainer thread, which appends to the output queue while the workers go on
+        {
+            std::unique_lock<std::mutex> lk(e->mu);
+            e->cv.wait(lk, [&] { return !e->drain_busy[lane]; });
+        }
+        if ((rc = grow_pinned(&r->h_out[lane], &r->h_out_cap[lane], out_len)) != BZ_OK) return rc;
+        if (hipMemcpyAsync(r->h_out[lane], r->d_out[lane], out_len, hipMemcpyDeviceToHost, r->st_io[lane]) != hipSuccess ||
+            hipStreamSynchronize(r->st_io[lane]) != hipSuccess)
+            return BZ_E_UNEXPECTED;
+        {
+            std::lock_guard<std::mutex> lk(e->mu);
+            e->drain_busy[lane] = true;
+            e->drains.emplace_back(lane, out_len);
+            e->drain_queued += 1;
+        }
+        e->cv.notify_all();
+    }
+    if (enc_trace())
+        fprintf(stderr, "bz_enc job %llu (lane %d): mode %d, %zu bytes, %zu blocks: split %.2f ms, encode %.2f ms, assemble+download %.2f ms (at %.1f)\n",
+                (unsigned long long)j.seq, lane, mode, js.n_all, n_blocks, js.t1 - js.t0, js.t2 - js.t1, now_ms() - js.t2, now_ms());
+    e->carry_bits = ocb;
+    e->carry_byte = ocy;
+    if (final_call_empty && n_blocks > 0) comb_out = rotl1(comb_out); // the extra, empty write_block(false)
+    e->combined_crc = comb_out;
+    if (n_blocks > 0) e->any_block = true;
+    if (mode == BZ_ACTION_FINISH) e->inner_finished = true;
+    return BZ_OK;
+}
+
+// worker of one lane: takes the jobs whose number has its parity
+static void worker_main(bz_enc *e, int lane)
 {
     for (;;) {
         EncJob j;
         {
             std::unique_lock<std::mutex> lk(e->mu);
-            e->cv.wait(lk, [&] { return e->stop || !e->jobs.empty(); });
-            if (e->jobs.empty()) return; // stop
+            e->cv.wait(lk, [&] { return e->stop || (!e->jobs.empty() && (int)(e->jobs.front().seq & 1u) == lane); });
+            if (e->jobs.empty() || (int)(e->jobs.front().seq & 1u) != lane) return; // stop
             j = e->jobs.front();
             e->jobs.pop_front();
         }
-        int rc = BZ_OK;
+        e->cv.notify_all(); // (the other lane may find its job at the front now)
+        (void)hipSetDevice(e->device);
+        JobState js;
+        int rc;
+        // SPLIT, in job order
         {
             std::unique_lock<std::mutex> lk(e->mu);
+            e->cv.wait(lk, [&] { return e->split_done == j.seq; });
             rc = e->err;
         }
-        if (rc == BZ_OK) rc = run_job(e, j);
+        if (rc == BZ_OK) rc = job_split(e, j, lane, js);
         {
             std::lock_guard<std::mutex> lk(e->mu);
             if (rc != BZ_OK && e->err == BZ_OK) e->err = rc;
             if (rc != BZ_OK && j.n) e->composed = e->submitted; // nobody waits for a staging buffer of a failed context
+            e->split_done += 1;
+        }
+        e->cv.notify_all();
+        // ENCODE, beside the other lane's
+        if (rc == BZ_OK) rc = job_encode(e, lane, js);
+        // ASSEMBLE, in job order
+        {
+            std::unique_lock<std::mutex> lk(e->mu);
+            if (rc != BZ_OK && e->err == BZ_OK) e->err = rc;
+            e->cv.wait(lk, [&] { return e->asm_done == j.seq; });
+            if (rc == BZ_OK) rc = e->err;
+        }
+        if (rc == BZ_OK) rc = job_assemble(e, j, lane, js);
+        {
+            std::lock_guard<std::mutex> lk(e->mu);
+            if (rc != BZ_OK && e->err == BZ_OK) e->err = rc;
+            e->asm_done += 1;
             e->done += 1;
         }
         e->cv.notify_all();
@@ -528,7 +597,8 @@ static int ensure_started(bz_enc *e)
     if (e->r) return BZ_OK;
     int rc = resources_get(e->device, &e->r);
     if (rc != BZ_OK) return rc;
-    e->worker = std::thread(worker_main, e);
+    e->worker[0] = std::thread(worker_main, e, 0);
+    e->worker[1] = std::thread(worker_main, e, 1);
     e->drainer = std::thread(drainer_main, e);
     return BZ_OK;
 }
@@ -538,6 +608,7 @@ static int submit(bz_enc *e, int mode, bool wait)
 {
     EncResources *r = e->r;
     EncJob j;
+    j.seq = 0;
     j.slot = -1;
     j.n = e->fill;
     j.mode = mode;
@@ -563,11 +634,13 @@ static int submit(bz_enc *e, int mode, bool wait)
             return BZ_E_UNEXPECTED;
         e->fill_slot ^= 1;
         e->fill = 0;
+        e->chunks_filled += 1;
     }
     u64 ticket;
     {
         std::lock_guard<std::mutex> lk(e->mu);
         if (j.n) e->submitted += 1;
+        j.seq = e->queued; // jobs are numbered in stream order
         e->jobs.push_back(j);
         ticket = ++e->queued;
     }
@@ -601,11 +674,13 @@ extern "C" void bz_enc_destroy(bz_enc *e)
             e->stop = true;
         }
         e->cv.notify_all();
-        if (e->worker.joinable()) e->worker.join();
+        for (auto &w : e->worker)
+            if (w.joinable()) w.join();
         if (e->drainer.joinable()) e->drainer.join();
         (void)hipSetDevice(e->device);
         (void)hipStreamSynchronize(e->r->st_up);
-        (void)hipStreamSynchronize(e->r->st_io);
+        (void)hipStreamSynchronize(e->r->st_io[0]);
+        (void)hipStreamSynchronize(e->r->st_io[1]);
         if (e->err == BZ_OK) resources_put(e->r);
         else resources_free(e->r);
     }
@@ -645,7 +720,9 @@ extern "C" int bz_enc_write(bz_enc *e, const uint8_t *in, size_t n)
     if (rc != BZ_OK) return rc;
     EncResources *r = e->r;
     while (n) {
-        if (e->fill == r->chunk) {
+        // (the first chunk of a stream is a quarter of the others: the GPU has work sooner)
+        const size_t cap = e->chunks_filled == 0 ? r->chunk / 4 : r->chunk;
+        if (e->fill == cap) {
             // A full chunk goes to the worker when MORE input arrives (its complete blocks are encoded
             // while the caller goes on writing); the last chunk of a stream is left for bz_enc_end, which
             // sends it together with the caller's Action instead of paying a job for the tail block alone.
@@ -656,7 +733,7 @@ extern "C" int bz_enc_write(bz_enc *e, const uint8_t *in, size_t n)
             if (hipSetDevice(e->device) != hipSuccess || hipEventSynchronize(r->ev_up[e->fill_slot]) != hipSuccess)
                 return BZ_E_UNEXPECTED;
         }
-        const size_t k = std::min(n, r->chunk - e->fill);
+        const size_t k = std::min(n, cap - e->fill);
         copy_in(r->h_in[e->fill_slot] + e->fill, in, k);
         e->fill += k;
         in += k;
@@ -671,23 +748,27 @@ extern "C" int bz_enc_end(bz_enc *e, int action)
     if (!e || action < BZ_ACTION_RUN || action > BZ_ACTION_FINISH) return BZ_E_PARAM;
     int rc = ensure_started(e);
     if (rc != BZ_OK) return rc;
-    // everything below looks at state the worker owns: wait for the jobs in flight first
-    {
-        std::unique_lock<std::mutex> lk(e->mu);
-        e->cv.wait(lk, [&] { return e->done >= e->queued && e->drained >= e->drain_queued; });
-        if (e->err != BZ_OK) return e->err;
-    }
+    // (The chunk still being filled goes to the workers with the caller's Action WITHOUT waiting for the
+    // jobs in flight first -- its upload and split run beside them; `finish_submitted` is the caller's
+    // copy of EncoderInner.finished, which a worker sets only when the Finish job is assembled.  A job
+    // that is waited for has every earlier job in front of it done, too: assembly is in job order.)
     // blocks the reference would already have emitted while it was consuming the input
-    if (!e->inner_finished && action == BZ_ACTION_RUN) {
+    if (!e->finish_submitted && action == BZ_ACTION_RUN) {
         if ((rc = submit(e, BZ_ACTION_RUN, true)) != BZ_OK) return rc;
     }
     for (;;) {
         // next_bits: queue empty and the iterator is exhausted (encoder.rs:86-110)
         if (!e->finished) {
-            if (action == BZ_ACTION_FLUSH && !e->inner_finished) {       // :718-727
+            if (action == BZ_ACTION_FLUSH && !e->finish_submitted) {       // :718-727
                 if ((rc = submit(e, BZ_ACTION_FLUSH, true)) != BZ_OK) return rc;
-            } else if (action == BZ_ACTION_FINISH && !e->inner_finished) { // :729-739
+            } else if (action == BZ_ACTION_FINISH && !e->finish_submitted) { // :729-739
+                e->finish_submitted = true;
                 if ((rc = submit(e, BZ_ACTION_FINISH, true)) != BZ_OK) return rc;
+            } else {
+                // nothing to encode: the state below must still be the workers' last word
+                std::unique_lock<std::mutex> lk(e->mu);
+                e->cv.wait(lk, [&] { return e->done >= e->queued && e->drained >= e->drain_queued; });
+                if (e->err != BZ_OK) return e->err;
             }
             e->finished = true;
         }
@@ -747,6 +828,7 @@ extern "C" int bz_encode_buffer(int level, int device, const uint8_t *in, size_t
     bz_enc *e = nullptr;
     int rc = bz_enc_create(&e, level, device);
     if (rc != BZ_OK) return rc;
+    e->oneshot = true;
     // the same pipeline as the streaming context: chunks are uploaded and encoded while the rest of the
     // input is still being copied to the pinned staging buffers
     if (in_len) rc = bz_enc_write(e, in, in_len);

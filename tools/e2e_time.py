@@ -30,3 +30,28 @@ enc.end(pkg.Action.FINISH)
 tot += len(enc.read_all())
 dt = time.perf_counter() - t0
 print("streaming 1 MiB pieces: %.1f ms = %.0f MB/s (%d bytes)" % (dt * 1e3, n / dt / 1e6, tot))
+
+# the same through raw ctypes pointers (no Python-side copies of the pieces)
+h = ctypes.c_void_p()
+assert L.bz_enc_create(ctypes.byref(h), 9, 0) == 0
+base = ctypes.cast(ctypes.c_char_p(host), ctypes.c_void_p).value
+L.bz_enc_write.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+buf = (ctypes.c_uint8 * (4 << 20))()
+t0 = time.perf_counter()
+tot = 0
+for i in range(0, n, 1 << 20):
+    assert L.bz_enc_write(h, base + i, min(1 << 20, n - i)) == 0
+    while True:
+        k = L.bz_enc_read(h, buf, len(buf))
+        if k <= 0:
+            break
+        tot += k
+assert L.bz_enc_end(h, 2) == 0
+while True:
+    k = L.bz_enc_read(h, buf, len(buf))
+    if k <= 0:
+        break
+    tot += k
+dt = time.perf_counter() - t0
+L.bz_enc_destroy(h)
+print("streaming 1 MiB pieces, raw pointers: %.1f ms = %.0f MB/s (%d bytes)" % (dt * 1e3, n / dt / 1e6, tot))

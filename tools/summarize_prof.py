@@ -65,6 +65,25 @@ if pmc:
         lf, lw = max(d["launches_fetch"], 1), max(d["launches_write"], 1)
         d["hbm_bytes_per_launch"] = int(d["FETCH_SIZE_KiB_x2"] * 1024 / lf + d["WRITE_SIZE_KiB"] * 1024 / lw)
         traffic[k] = d["hbm_bytes_per_launch"]
+    # whole-step totals (the PMC passes run ONE step): what bench.py reports as HBM bytes per input byte
+    total = sum(d["FETCH_SIZE_KiB_x2"] + d["WRITE_SIZE_KiB"] for k, d in pmc.items() if k.startswith("k_")) * 1024
+    traffic["__total_bytes_per_step"] = int(total)
+    traffic["__source"] = tag + "_pmc.json"
+    for f in ("bench_fetch.json",):
+        pth = os.path.join(src, f)
+        try:
+            line = [x for x in open(pth).read().splitlines() if x.startswith("{")][-1]
+            b = json.loads(line)
+            cfg = b.get("config", {})
+            if "input_bytes" in cfg:
+                traffic["__input_bytes"] = cfg["input_bytes"]
+            elif "mib" in cfg:
+                traffic["__input_bytes"] = cfg["mib"] << 20
+            else:
+                m = re.match(r"(\d+) MiB", str(cfg.get("workload", "")))
+                traffic["__input_bytes"] = (int(m.group(1)) << 20) if m else None
+        except Exception:
+            pass
     json.dump(pmc, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
     json.dump(traffic, open(os.path.join(dst, traffic_name), "w"), indent=1, sort_keys=True)
     print("wrote pmc for", len(pmc), "kernels")
