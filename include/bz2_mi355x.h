@@ -337,8 +337,11 @@ void bz_dec_destroy(bz_dec *d);
  * (src/gzip/encoder.rs:50-135: 10-byte header, CRC-32 and ISIZE little endian),
  * driven with Action::Finish.  The stream is the reference's, bit for bit.
  * `kind`: 0 raw Deflate, 1 zlib, 2 gzip.
- * Not offered on this path (refused with BZ_E_PARAM, never approximated):
- * Action::Flush inside a stream, inputs of 2 GiB or more in one call.
+ * Action::Flush inside a stream is offered for Inflater through the streaming context (df_enc_end):
+ * the stream becomes a sequence of byte-aligned segments (src/deflate/encoder.rs:170-195, :227-235,
+ * :638-647).  Not offered (refused with BZ_E_PARAM, never approximated): Action::Flush on the zlib /
+ * gzip wrappers (they end their container at the first None, src/zlib/encoder.rs:131-151), and more than
+ * 2 GiB in one call or segment.
  * ======================================================================== */
 #define DF_KIND_DEFLATE 0
 #define DF_KIND_ZLIB 1
@@ -386,9 +389,11 @@ int df_encode_buffer_dict(int kind, int device, const uint8_t *in, size_t in_len
 
 /* Streaming context == the Encoder::next contract of the three encoders:
  * df_enc_write feeds bytes, df_enc_end(action) marks the end of an input
- * iterator (0 Run: nothing happens; 2 Finish: the stream is produced; 1 Flush:
- * BZ_E_PARAM), df_enc_read drains.  The whole input is kept until Finish: one
- * window and one bit string run through all of it. */
+ * iterator (0 Run: nothing happens -- the bytes of a stream depend on all of its input;
+ * 1 Flush, kind 0 only: the bytes written since the last segment come out as one segment:
+ * LZSS stage drained, current block closed without the final bit, padded to a byte, window and
+ * decompress_len carried over; 2 Finish: the last segment, final bit, container trailer),
+ * df_enc_read drains.  The stream so far stays in device memory until Finish. */
 typedef struct df_enc df_enc;
 int df_enc_create(df_enc **out, int kind, int device);
 int df_enc_create_dict(df_enc **out, int kind, int device, const uint8_t *dict, size_t dict_len); /* ::with_dict */

@@ -326,8 +326,9 @@ DEFLATE, ZLIB, GZIP = 0, 1, 2
 
 class Inflater:
     """`Inflater` (src/deflate/encoder.rs:92-260) over the C ABI's streaming context: the reference's
-    name for its Deflate ENCODER.  Action.RUN accumulates, Action.FINISH produces the stream;
-    Action.FLUSH is not offered on this path (CompressionError BZ_E_PARAM)."""
+    name for its Deflate ENCODER.  Action.RUN accumulates, Action.FLUSH writes the bytes so far as a
+    byte-aligned segment (non-final block; the window and decompress_len carry over), Action.FINISH ends
+    the stream.  ZlibEncoder / GZipEncoder refuse Action.FLUSH (CompressionError BZ_E_PARAM)."""
 
     KIND = DEFLATE
     CHUNK = 1 << 20
@@ -360,8 +361,9 @@ class Inflater:
 
     def next(self, it, action):
         """One `Encoder::next(iter, action)` call: an int byte, or None."""
-        if int(action) == Action.FLUSH:
-            # refused BEFORE any input is pulled: the caller's iterator is left untouched
+        if int(action) == Action.FLUSH and self.KIND != DEFLATE:
+            # the zlib / gzip wrappers are not offered with Flush (they end their container at the first None,
+            # zlib/encoder.rs:131-151): refused BEFORE any input is pulled, the caller's iterator is left untouched
             raise CompressionError(BZ_E_PARAM)
         if self._pos >= len(self._ready) and self._refill() == 0:
             while True:

@@ -3,8 +3,8 @@
 //
 // Replaces, behind the reference's Encoder surface: Inflater (deflate/encoder.rs:92-260), ZlibEncoder
 // (zlib/encoder.rs:55-157), GZipEncoder (gzip/encoder.rs:50-135) driven with Action::Finish (and
-// Action::Run in front of it), with or without a preset dictionary (::with_dict).  Action::Flush in the
-// middle of a stream is not offered on this path and is refused with BZ_E_PARAM, never approximated.
+// Action::Run in front of it), with or without a preset dictionary (::with_dict), and -- for Inflater -- with
+// Action::Flush in the middle of a stream (a stream is then a sequence of byte-aligned SEGMENTS, df_enc_end).
 #include <cstring>
 #include <string>
 #include <vector>
@@ -69,11 +69,24 @@ static u32 gf_xpow8_reflected(u64 nbytes) // x^(8 * nbytes) mod P
 
 // dict (host memory, may be NULL): Inflater::with_dict / ZlibEncoder::with_dict (deflate/encoder.rs:134-153,
 // lzss/encoder.rs:104-130: the last 0x8000 bytes of it are history in front of the input)
+// A SEGMENT of a stream (Action::Flush cuts a stream into segments: the LZSS stage is drained, the current block
+// is closed WITHOUT the final bit and the bit string is padded to a byte, deflate/encoder.rs:170-195, :638-647,
+// :236-246; the window and `decompress_len` live on).  d_in[0, n) is the segment; `prior` = stream bytes in
+// front of it, readable at d_in[-prior, 0) (history of the match finder next to the dictionary's; a stored first
+// block reaches back dl0 <= prior bytes); dl0 = decompress_len carried in; `final`: the segment ends the stream;
+// head / tail: write the container's header / trailer (the trailer's checksums cover d_in[-prior, n)).
+// *dl_out = decompress_len behind the segment.  A whole stream is the one segment (prior 0, dl0 0, final).
+struct DfSeg {
+    u64 prior = 0;
+    u32 dl0 = 0;
+    bool final = true, head = true, tail = true;
+};
 static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, const u8 *dict, size_t dict_len, u8 *d_out,
-                          size_t cap, size_t *out_len)
+                          size_t cap, size_t *out_len, const DfSeg &seg = DfSeg(), u32 *dl_out = nullptr)
 {
     if (n >= (1ull << 31) - kWin) return BZ_E_PARAM; // positions and bit offsets are sized for < 2 GiB per call
     if (dict_len && kind == 2) return BZ_E_PARAM;    // GZipEncoder has no with_dict
+    if (seg.dl0 > kBlockMax || seg.dl0 > seg.prior) return BZ_E_PARAM;
     HIPCHK(hipSetDevice(g->device));
     if (!g->df) g->df = new DfWorkspace();
     DfWorkspace *w = g->df;
@@ -82,7 +95,10 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
         for (hipEvent_t &e : w->ev) HIPCHK(hipEventCreate(&e));
         w->ev_ready = true;
     }
-    const u64 hist = dict_len < kWin ? dict_len : kWin; // bytes of history in front of the input
+    // history in front of the segment: the last 32 KiB of (dictionary, then the stream so far)
+    const u64 hist_dev = seg.prior < kWin ? seg.prior : kWin;
+    const u64 hist_dict = dict_len < kWin - hist_dev ? dict_len : kWin - hist_dev;
+    const u64 hist = hist_dict + hist_dev;
     const u64 nall = hist + n;                           // positions the chain and match stages see
     const u64 npad = nall + 16;
     const u32 ntiles = (u32)((n + kPTile - 1) / kPTile) + (n == 0 ? 1u : 0u);
@@ -117,7 +133,8 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     if ((rc = w->total.ensure(64)) != BZ_OK) return rc;
     const size_t bound = df_encode_bound(n);
     if ((rc = w->stream.ensure(bound + 64)) != BZ_OK) return rc;
-    const u32 npieces = (u32)((n + kSumPiece - 1) / kSumPiece);
+    const u64 ntot = seg.prior + n; // bytes the container's checksums cover
+    const u32 npieces = (u32)((ntot + kSumPiece - 1) / kSumPiece);
     if (kind != 0) {
         if ((rc = w->asum.ensure((size_t)(npieces + 1) * 8)) != BZ_OK) return rc;
         if ((rc = w->bsum.ensure((size_t)(npieces + 1) * 8)) != BZ_OK) return rc;
@@ -138,8 +155,9 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     u32 *code = w->vals_out.as<u32>();
     const u8 *d_all = d_in;
     if (hist) { // history + input in one buffer for the chain and match stages
-        HIPCHK(hipMemcpy(w->concat.p, dict + (dict_len - hist), hist, hipMemcpyHostToDevice));
-        if (n) HIPCHK(hipMemcpyAsync(w->concat.as<u8>() + hist, d_in, n, hipMemcpyDeviceToDevice, st));
+        if (hist_dict) HIPCHK(hipMemcpy(w->concat.p, dict + (dict_len - hist_dict), hist_dict, hipMemcpyHostToDevice));
+        if (hist_dev + n)
+            HIPCHK(hipMemcpyAsync(w->concat.as<u8>() + hist_dict, d_in - hist_dev, hist_dev + n, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemsetAsync(w->concat.as<u8>() + nall, 0, 64, st));
         d_all = w->concat.as<u8>();
     }
@@ -155,16 +173,16 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     if (df_launch_parse(st, M, n, step, tabs.data(), ents.data(), counts.data(), nlevels, code, w->bitmap.as<u64>()) != 0) return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[3], st));
     if (df_launch_blocks(st, d_in, code, n, w->bitmap.as<u64>(), w->bstart.as<u64>(), w->nb.as<u32>(), bcap, w->blocks.as<DfBlock>(),
-                         w->lens.as<u8>(), w->hdr.as<u32>(), w->lm.as<u32>(), w->total.as<u64>()) != 0)
+                         w->lens.as<u8>(), w->hdr.as<u32>(), w->lm.as<u32>(), w->total.as<u64>(), seg.dl0, seg.final ? 1u : 0u) != 0)
         return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[4], st));
     if (df_launch_emit(st, d_in, code, w->bstart.as<u64>(), w->nb.as<u32>(), bcap, w->blocks.as<DfBlock>(), w->lens.as<u8>(),
                        w->hdr.as<u32>(), w->stream.as<u32>()) != 0)
         return BZ_E_UNEXPECTED;
-    if (kind != 0) {
+    if (kind != 0 && seg.tail) {
         DfCrcShifts xk;
         for (u32 k = 0; k < 8; ++k) xk.x[k] = gf_xpow8_reflected(256ull << k);
-        if (df_launch_sums(st, d_in, n, w->asum.as<u64>(), w->bsum.as<u64>(), w->crc.as<u32>(), w->crc.as<u32>() + npieces + 1, xk) != 0)
+        if (df_launch_sums(st, d_in - seg.prior, ntot, w->asum.as<u64>(), w->bsum.as<u64>(), w->crc.as<u32>(), w->crc.as<u32>() + npieces + 1, xk) != 0)
             return BZ_E_UNEXPECTED;
     }
     HIPCHK(hipEventRecord(w->ev[5], st));
@@ -182,7 +200,9 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     // container (zlib/encoder.rs:63-72,118-156; gzip/encoder.rs:62-75,88-134)
     u8 head[10], tail[8];
     size_t nhead = 0, ntail = 0;
-    if (kind == 1 && dict_len) { // zlib/encoder.rs:74-93: FDICT + Adler-32 of the whole dictionary
+    if (!seg.head) {
+        // (a later segment of a stream: the header went out with the first one)
+    } else if (kind == 1 && dict_len) { // zlib/encoder.rs:74-93: FDICT + Adler-32 of the whole dictionary
         u32 a = 1, b = 0;
         for (size_t i = 0; i < dict_len; ++i) { a = (a + dict[i]) % 65521; b = (b + a) % 65521; }
         const u32 h = (b << 16) | a;
@@ -194,7 +214,7 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
         const u8 h[10] = {0x1F, 0x8B, 0x08, 0, 0, 0, 0, 0, 0, 0xFF};
         memcpy(head, h, 10); nhead = 10;
     }
-    if (kind != 0) {
+    if (kind != 0 && seg.tail) {
         std::vector<u64> a(npieces), b(npieces);
         std::vector<u32> c((size_t)npieces + 1 + 256);
         if (npieces) {
@@ -205,7 +225,7 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
         if (kind == 1) { // adler32.rs:20-66
             u64 A = 1, B = 0;
             for (u32 t = 0; t < npieces; ++t) {
-                const u64 len = (t + 1 == npieces) ? n - (u64)t * kSumPiece : kSumPiece;
+                const u64 len = (t + 1 == npieces) ? ntot - (u64)t * kSumPiece : kSumPiece;
                 B = (B + (len % 65521) * A + b[t]) % 65521;
                 A = (A + a[t]) % 65521;
             }
@@ -215,7 +235,7 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
             const u32 xpiece = gf_xpow8_reflected(kSumPiece);
             u32 raw = 0; // register for a zero initial value over the whole input
             for (u32 t = 0; t < npieces; ++t) {
-                const u64 len = (t + 1 == npieces) ? n - (u64)t * kSumPiece : kSumPiece;
+                const u64 len = (t + 1 == npieces) ? ntot - (u64)t * kSumPiece : kSumPiece;
                 if (len == kSumPiece) raw = gf_mul_reflected(raw, xpiece) ^ c[t]; // folded on the device
                 else
                     for (u32 s = 0; (u64)s * 256 < len; ++s) { // the last, partial piece: its sub-pieces
@@ -223,8 +243,8 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
                         raw = gf_mul_reflected(raw, gf_xpow8_reflected(sl)) ^ c[(size_t)npieces + 1 + s];
                     }
             }
-            const u32 crc = raw ^ gf_mul_reflected(0xFFFFFFFFu, gf_xpow8_reflected(n)) ^ 0xFFFFFFFFu;
-            const u32 isz = (u32)n;
+            const u32 crc = raw ^ gf_mul_reflected(0xFFFFFFFFu, gf_xpow8_reflected(ntot)) ^ 0xFFFFFFFFu;
+            const u32 isz = (u32)ntot;
             for (int i = 0; i < 4; ++i) tail[i] = (u8)(crc >> (8 * i));
             for (int i = 0; i < 4; ++i) tail[4 + i] = (u8)(isz >> (8 * i));
             ntail = 8;
@@ -264,6 +284,7 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
         w->stats[6] += (bi.lm >> 8) & 1u; // dynamic block without any match: the reference's header has no distance length
     }
     w->stats[5] = need;
+    if (dl_out) *dl_out = (u32)((nb == 1 ? seg.dl0 : 0u) + (n - w->h_bstart[nb - 1]));
     return BZ_OK;
 }
 
@@ -388,9 +409,17 @@ done:
 // depends on all of the input: one 32 KiB window, one bit string).  Action::Flush is refused.
 struct df_enc {
     int kind = 0, device = 0;
-    std::vector<uint8_t> in, out, dict;
+    std::vector<uint8_t> in, out, dict; // in: bytes written since the last segment went to the device
     size_t out_head = 0;
     bool finished = false;
+    // the stream so far lives on the device: a segment needs the 32 KiB in front of it as history, a stored
+    // block behind a flush up to 0xFFFF bytes, the container's checksums all of it
+    bz_gpu_engine *g = nullptr;
+    DevBuf d_data, d_out;
+    size_t total = 0;   // stream bytes on the device
+    size_t encoded = 0; // ... of which segments have been written for
+    uint32_t dl = 0;    // InflaterInner.decompress_len behind the last segment (deflate/encoder.rs:267)
+    bool wrote_head = false;
 };
 
 extern "C" int df_enc_create(df_enc **out, int kind, int device)
@@ -413,7 +442,17 @@ extern "C" int df_enc_create_dict(df_enc **out, int kind, int device, const uint
     return rc;
 }
 
-extern "C" void df_enc_destroy(df_enc *e) { delete e; }
+extern "C" void df_enc_destroy(df_enc *e)
+{
+    if (!e) return;
+    if (e->g) {
+        (void)hipSetDevice(e->device);
+        e->d_data.release();
+        e->d_out.release();
+        bz_gpu_engine_destroy(e->g);
+    }
+    delete e;
+}
 
 extern "C" int df_enc_write(df_enc *e, const uint8_t *in, size_t n)
 {
@@ -423,21 +462,64 @@ extern "C" int df_enc_write(df_enc *e, const uint8_t *in, size_t n)
     return BZ_OK;
 }
 
+// Action::Run: everything stays pending (the LZSS stage holds 261 bytes of look-ahead, the block stage up to
+// 0xFFFF bytes, and the bytes of a stream depend on all of its input: nothing can come out earlier).
+// Action::Flush (Inflater only): the bytes written since the last segment are encoded as one SEGMENT -- the LZSS
+// stage drained (lzss/encoder.rs:196-200, :224-226), the block closed without the final bit
+// (deflate/encoder.rs:177-184, :638-647), the bit string padded to a byte (:227-235); the 32 KiB window and
+// decompress_len carry over.  Action::Finish: the last segment, final bit set, container trailer.
+// The zlib / gzip wrappers end their container at the first None they see, whatever the action
+// (zlib/encoder.rs:131-151): a Flush there is a Finish without the final block -- not mirrored: BZ_E_PARAM.
 extern "C" int df_enc_end(df_enc *e, int action)
 {
-    if (!e) return BZ_E_PARAM;
-    if (action == 0) return BZ_OK;      // Run: nothing comes out before the end
-    if (action != 2) return BZ_E_PARAM; // Flush: not offered on this path
-    if (e->finished) return BZ_OK;
-    uint8_t *p = nullptr;
-    size_t n = 0;
-    const int rc = df_encode_buffer_dict(e->kind, e->device, e->in.data(), e->in.size(), e->dict.data(), e->dict.size(), &p, &n);
-    if (rc != BZ_OK) return rc;
-    e->out.assign(p, p + n);
-    free(p);
+    if (!e || action < 0 || action > 2) return BZ_E_PARAM;
+    if (action == 0) return BZ_OK;
+    if (action == 1 && e->kind != 0) return BZ_E_PARAM;
+    if (e->finished) return BZ_OK; // flush() / finish() behind the final block do nothing (:636-660)
+    int rc;
+    if (!e->g && (rc = bz_gpu_engine_create(&e->g, e->device, 0)) != BZ_OK) return rc;
+    HIPCHK(hipSetDevice(e->device));
+    const size_t add = e->in.size();
+    if (e->total + add - e->encoded >= ((size_t)1 << 31) - kWin) return BZ_E_PARAM; // one SEGMENT handles < 2 GiB
+    if (e->total + add + 64 > e->d_data.cap) { // grow, keeping the stream so far
+        DevBuf bigger;
+        if ((rc = bigger.ensure((e->total + add) * 2 + 4096)) != BZ_OK) return rc;
+        if (e->total) HIPCHK(hipMemcpy(bigger.p, e->d_data.p, e->total, hipMemcpyDeviceToDevice));
+        e->d_data.release();
+        e->d_data = bigger;
+    }
+    if (add) HIPCHK(hipMemcpy(e->d_data.as<u8>() + e->total, e->in.data(), add, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(e->d_data.as<u8>() + e->total + add, 0, 64));
+    e->total += add;
     e->in.clear();
-    e->in.shrink_to_fit();
-    e->finished = true;
+    DfSeg seg;
+    seg.prior = e->encoded;
+    seg.dl0 = e->dl;
+    seg.final = (action == 2);
+    seg.head = !e->wrote_head;
+    seg.tail = (action == 2);
+    const size_t n = e->total - e->encoded;
+    const size_t cap = df_encode_bound(n) + 64;
+    if ((rc = e->d_out.ensure(cap)) != BZ_OK) return rc;
+    size_t k = 0;
+    uint32_t dl = 0;
+    rc = df_encode_core(e->g, e->kind, e->d_data.as<u8>() + e->encoded, n, e->dict.data(), e->dict.size(), e->d_out.as<u8>(), cap,
+                        &k, seg, &dl);
+    if (rc != BZ_OK) return rc;
+    if (e->out_head && e->out_head == e->out.size()) {
+        e->out.clear();
+        e->out_head = 0;
+    }
+    const size_t old = e->out.size();
+    e->out.resize(old + k);
+    if (k) HIPCHK(hipMemcpy(e->out.data() + old, e->d_out.p, k, hipMemcpyDeviceToHost));
+    e->wrote_head = true;
+    e->encoded = e->total;
+    e->dl = dl;
+    if (action == 2) {
+        e->finished = true;
+        e->d_data.release();
+    }
     return BZ_OK;
 }
 

@@ -56,8 +56,11 @@ int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *v0, u32 *s, u16 *
 int df_launch_match(hipStream_t st, const u8 *in, const u32 *pe, u64 n, u32 *M);
 int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *tabs, u16 *const *ents, const u32 *counts,
                     u32 nlevels, u32 *code, u64 *bm);
+// dl0: decompress_len carried into the segment (0 unless it follows an Action::Flush); last_is_final: the
+// segment ends the stream (Finish) rather than being flushed.  `in` is the segment's first byte; the dl0 bytes
+// in front of it must be readable (a stored first block copies them).
 int df_launch_blocks(hipStream_t st, const u8 *in, const u32 *code, u64 n, u64 *bm, u64 *bstart, u32 *nb, u32 cap,
-                     DfBlock *blocks, u8 *lens, u32 *hdr, u32 *lm_scratch, u64 *total_bits);
+                     DfBlock *blocks, u8 *lens, u32 *hdr, u32 *lm_scratch, u64 *total_bits, u32 dl0, u32 last_is_final);
 int df_launch_emit(hipStream_t st, const u8 *in, const u32 *code, const u64 *bstart, const u32 *nb, u32 cap,
                    const DfBlock *blocks, const u8 *lens, const u32 *hdr, u32 *out);
 struct DfCrcShifts { u32 x[8]; }; // x^(8 * 256 * 2^k) mod P, reflected: moves a CRC register over 256 * 2^k bytes

@@ -602,19 +602,22 @@ __global__ __launch_bounds__(kMarkThreads) void k_df_mark(const u16 *__restrict_
 // can look at are known in advance: they are loaded together, the hops then run out of LDS.
 constexpr u32 kCutGroup = 32;
 constexpr u32 kCutWords = (257 * kCutGroup + 64) / 64 + 3;
+// dl0: InflaterInner.decompress_len at the segment's first code (not 0 behind an Action::Flush, which closes a
+// block without resetting it, :638-647 against :585-593): the first block then counts as having started dl0
+// bytes in front of the segment -- the chain starts at the (negative) position -dl0.
 __global__ __launch_bounds__(256) void k_df_cuts(const u64 *__restrict__ bm, u64 n, u64 *__restrict__ bstart,
-                                                 u32 *__restrict__ nb_out, u32 cap)
+                                                 u32 *__restrict__ nb_out, u32 cap, u32 dl0)
 {
     __shared__ u64 s_bm[kCutGroup][kCutWords];
-    __shared__ u64 s_b;
+    __shared__ i64 s_b;
     __shared__ u32 s_k, s_done;
     const u32 tid = threadIdx.x;
     const u64 nwords = (n + 63) / 64;
-    if (tid == 0) { s_b = 0; s_k = 0; s_done = 0; if (cap) bstart[0] = 0; }
+    if (tid == 0) { s_b = -(i64)dl0; s_k = 0; s_done = 0; if (cap) bstart[0] = 0; }
     __syncthreads();
     for (;;) {
-        const u64 b = s_b;
-        const u64 x = b + kBlockMax;
+        const i64 b = s_b;
+        const u64 x = (u64)(b + (i64)kBlockMax); // >= 0: dl0 <= 0xFFFF
         if (x >= n || s_done) break;
         // every region padded to kCutWords words ending at its highest word: all loads of a group are in
         // flight together (one memory round trip per kCutGroup hops)
@@ -635,19 +638,19 @@ __global__ __launch_bounds__(256) void k_df_cuts(const u64 *__restrict__ bm, u64
         }
         __syncthreads();
         if (tid == 0) {
-            u64 cur = b;
+            i64 cur = b;
             u32 k = s_k;
             for (u32 j = 0; j < kCutGroup; ++j) {
-                const u64 xj = cur + kBlockMax;
+                const u64 xj = (u64)(cur + (i64)kBlockMax);
                 if (xj >= n) break;
                 const i64 wlo = (i64)((x + (u64)j * kBlockMax) >> 6) - (i64)(kCutWords - 1); // word of s_bm[j][0]
                 i64 w = (i64)(xj >> 6) - wlo;
                 u64 m = s_bm[j][w] & (~0ull >> (63 - (u32)(xj & 63)));
                 while (!m && w > 0) { --w; m = s_bm[j][w]; }
                 if (!m) { s_done = 2; break; } // a code is at most 258 bytes long: cannot happen
-                cur = ((u64)(wlo + w) << 6) + 63 - (u64)__builtin_clzll(m);
+                cur = (i64)(((u64)(wlo + w) << 6) + 63 - (u64)__builtin_clzll(m));
                 ++k;
-                if (k < cap) bstart[k] = cur;
+                if (k < cap) bstart[k] = (u64)cur;
             }
             s_b = cur;
             s_k = k;
@@ -874,7 +877,8 @@ __device__ u32 df_tab_runs(const u8 *tab, u32 n, u8 *ls, u8 *le, u32 *freq)
 __global__ __launch_bounds__(kBThreads) void k_df_block(const u8 *__restrict__ in, const u32 *__restrict__ code,
                                                         const u64 *__restrict__ bstart, const u32 *__restrict__ nb_p,
                                                         DfBlock *__restrict__ blocks, u8 *__restrict__ lens,
-                                                        u32 *__restrict__ hdr, u32 *__restrict__ lm_scratch)
+                                                        u32 *__restrict__ hdr, u32 *__restrict__ lm_scratch, u32 dl0,
+                                                        u32 last_is_final)
 {
     __shared__ u32 s_sf[288], s_of[32];
     __shared__ u32 s_buf[2][2 * 288], s_w[2][288];
@@ -888,7 +892,7 @@ __global__ __launch_bounds__(kBThreads) void k_df_block(const u8 *__restrict__ i
     const u32 nblocks = *nb_p;
     if (nblocks == 0xFFFFFFFFu || k >= nblocks) return;
     const u64 b0 = bstart[k], b1 = bstart[k + 1];
-    const bool is_final = (k + 1 == nblocks);
+    const bool is_final = (k + 1 == nblocks) && last_is_final; // (a flushed segment ends with a non-final block)
     for (u32 i = tid; i < 288; i += kBThreads) s_sf[i] = 0;
     if (tid < 32) s_of[tid] = 0;
     if (tid == 0) s_lm = 0;
@@ -984,7 +988,9 @@ __global__ __launch_bounds__(kBThreads) void k_df_block(const u8 *__restrict__ i
             if (i < off_n) custom += (u64)f * (s_ol[i] + ext);
             fixed += (u64)f * (5u + ext);
         }
-        const u64 dlen = b1 - b0;
+        // decompress_len: the bytes of this block's codes -- and, for the first block of a segment behind a
+        // flush, the dl0 bytes the counter still holds (a stored block then repeats them, :488-501)
+        const u64 dlen = b1 - b0 + (k == 0 ? dl0 : 0u);
         const u64 original = (dlen << 3) + 2 + 16 + 16;
         DfBlock o;
         o.bytes = (u32)dlen;
@@ -1100,7 +1106,10 @@ __global__ __launch_bounds__(kEThreads) void k_df_emit(const u8 *__restrict__ in
             const u32 l = bi.bytes & 0xFFFFu, nl = l ^ 0xFFFFu;
             out8[B] = (u8)l; out8[B + 1] = (u8)(l >> 8); out8[B + 2] = (u8)nl; out8[B + 3] = (u8)(nl >> 8);
         }
-        for (u64 i = tid; i < b1 - b0; i += kEThreads) out8[B + 4 + i] = in[b0 + i];
+        // the last `bytes` bytes up to the block's end (nocomp_buf[decompress_len - i], :496-499): behind a flush
+        // that reaches back in front of the block, into bytes an earlier block has carried already
+        const u8 *src = in + b1 - bi.bytes;
+        for (u64 i = tid; i < bi.bytes; i += kEThreads) out8[B + 4 + i] = src[i];
         return;
     }
     for (u32 i = tid; i < 288; i += kEThreads) { s_sl[i] = lens[(size_t)k * 320 + i]; s_sc[i] = 0; }
@@ -1302,10 +1311,11 @@ int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *
 }
 
 int df_launch_blocks(hipStream_t st, const u8 *in, const u32 *code, u64 n, u64 *bm, u64 *bstart, u32 *nb, u32 cap,
-                     DfBlock *blocks, u8 *lens, u32 *hdr, u32 *lm_scratch, u64 *total_bits)
+                     DfBlock *blocks, u8 *lens, u32 *hdr, u32 *lm_scratch, u64 *total_bits, u32 dl0, u32 last_is_final)
 {
-    hipLaunchKernelGGL(k_df_cuts, dim3(1), dim3(256), 0, st, bm, n, bstart, nb, cap);
-    hipLaunchKernelGGL(k_df_block, dim3(cap), dim3(kBThreads), 0, st, in, code, bstart, nb, blocks, lens, hdr, lm_scratch);
+    hipLaunchKernelGGL(k_df_cuts, dim3(1), dim3(256), 0, st, bm, n, bstart, nb, cap, dl0);
+    hipLaunchKernelGGL(k_df_block, dim3(cap), dim3(kBThreads), 0, st, in, code, bstart, nb, blocks, lens, hdr, lm_scratch, dl0,
+                       last_is_final);
     hipLaunchKernelGGL(k_df_offsets, dim3(1), dim3(256), 0, st, blocks, nb, total_bits);
     return 0;
 }

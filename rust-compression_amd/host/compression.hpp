@@ -108,6 +108,7 @@ class BZip2Encoder {
     // Encoder::next (src/traits/encoder.rs:87-92, src/bzip2/encoder.rs:120-158)
     template <class I, class S> std::optional<Result<uint8_t>> next(I &it, const S &end, Action action)
     {
+        if (action == Action::Flush && Kind != DF_KIND_DEFLATE) return Result<uint8_t>::Err(from_status(BZ_E_PARAM));
         if (pos_ == len_) {
             int rc = refill();
             if (rc < 0) return Result<uint8_t>::Err(from_status(rc));
@@ -156,8 +157,9 @@ class BZip2Encoder {
 // Deflate / zlib / gzip encoders (include/bz2_mi355x.h section 4):
 //   Inflater     src/deflate/encoder.rs:92-260   (the reference's name for its Deflate ENCODER)
 //   ZlibEncoder  src/zlib/encoder.rs:55-157      GZipEncoder  src/gzip/encoder.rs:50-135
-// Action::Run accumulates, Action::Finish produces the stream; Action::Flush is not offered by the
-// library and comes back as CompressionError::Unexpected.
+// Action::Run accumulates, Action::Finish produces the stream; Action::Flush writes the bytes so far as a
+// byte-aligned segment (Inflater only: the zlib / gzip wrappers refuse it BEFORE pulling any input --
+// CompressionError::Unexpected -- because the reference's wrappers end their container at the first None).
 template <int Kind> class DeflateFamilyEncoder {
   public:
     using In = uint8_t;
@@ -189,6 +191,7 @@ template <int Kind> class DeflateFamilyEncoder {
 
     template <class I, class S> std::optional<Result<uint8_t>> next(I &it, const S &end, Action action)
     {
+        if (action == Action::Flush && Kind != DF_KIND_DEFLATE) return Result<uint8_t>::Err(from_status(BZ_E_PARAM));
         if (pos_ == len_) {
             int rc = refill();
             if (rc < 0) return Result<uint8_t>::Err(from_status(rc));

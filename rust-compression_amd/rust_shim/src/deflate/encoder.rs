@@ -21,6 +21,7 @@ fn action_code(a: Action) -> i32 {
 }
 
 pub struct DeflateFamilyEncoder {
+    kind: i32,
     h: *mut c_void,
     ready: Vec<u8>,
     pos: usize,
@@ -35,7 +36,7 @@ impl DeflateFamilyEncoder {
             crate::mi355x::note_status(rc);
             panic!("bz2_mi355x: cannot create a Deflate encoder context: {:?}", crate::mi355x::Status::from_code(rc));
         }
-        Self { h, ready: Vec::new(), pos: 0, chunk: Vec::with_capacity(CHUNK) }
+        Self { kind, h, ready: Vec::new(), pos: 0, chunk: Vec::with_capacity(CHUNK) }
     }
 
     pub(crate) fn with_kind(kind: i32) -> Self {
@@ -45,10 +46,15 @@ impl DeflateFamilyEncoder {
             crate::mi355x::note_status(rc);
             panic!("bz2_mi355x: cannot create a Deflate encoder context: {:?}", crate::mi355x::Status::from_code(rc));
         }
-        Self { h, ready: Vec::new(), pos: 0, chunk: Vec::with_capacity(CHUNK) }
+        Self { kind, h, ready: Vec::new(), pos: 0, chunk: Vec::with_capacity(CHUNK) }
     }
 
     pub(crate) fn next<I: Iterator<Item = u8>>(&mut self, iter: &mut I, action: Action) -> Option<Result<u8, CompressionError>> {
+        // Action::Flush: a byte-aligned segment for Inflater; the zlib / gzip wrappers refuse it before any
+        // input is pulled (the reference's wrappers end their container at the first None they see)
+        if action == Action::Flush && self.kind != ffi::DF_KIND_DEFLATE {
+            return Some(Err(map_err(ffi::BZ_E_PARAM)));
+        }
         while self.pos == self.ready.len() {
             self.ready.resize(1 << 16, 0);
             let k = unsafe { df_enc_read(self.h, self.ready.as_mut_ptr(), self.ready.len()) };
@@ -76,7 +82,6 @@ impl DeflateFamilyEncoder {
                     break;
                 }
             }
-            // Flush is not offered by the library (BZ_E_PARAM): surfaces as CompressionError::Unexpected
             let rc = unsafe { df_enc_end(self.h, action_code(action)) };
             if rc != 0 {
                 return Some(Err(map_err(rc)));

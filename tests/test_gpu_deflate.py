@@ -195,3 +195,67 @@ def test_empty_inputs_in_containers(pkg, oracle):
     for kind, okind in ((pkg.DEFLATE, oracle.DEFLATE), (pkg.ZLIB, oracle.ZLIB), (pkg.GZIP, oracle.GZIP)):
         assert pkg.deflate_compress(b"", kind) == oracle.deflate_encode(b"", okind)
     assert pkg.deflate_compress(b"", pkg.ZLIB, dict_=b"abc") == oracle.deflate_encode(b"", oracle.ZLIB, b"abc")
+
+
+# ---- Action::Flush inside a stream (deflate/encoder.rs:170-195, :227-235, :638-647): byte-aligned segments,
+# ---- the window and decompress_len carry over; against the oracle's Inflater fed iterator by iterator
+def _flush_case(pkg, oracle, pieces, dict_=b""):
+    """pieces: [(bytes, action)]; returns (gpu stream, oracle stream)"""
+    enc = pkg.Inflater(dict_=dict_)
+    ref = oracle.DeflateEncoder(dict_)
+    got = bytearray()
+    for data, act in pieces:
+        enc.write(data)
+        enc.end(act)
+        got += enc.read_all()
+        ref.feed(data, int(act))
+    return bytes(got), ref.output()
+
+
+def test_flush_segments(pkg, oracle):
+    A = pkg.Action
+    text = sample(1)
+    rnd = random.Random(11)
+    noise = bytes(rnd.randrange(256) for _ in range(200000))
+    cases = {
+        "two_segments": [(text[:50000], A.FLUSH), (text[50000:120000], A.FINISH)],
+        "window_carries_over": [(text[:40000], A.FLUSH), (text[:40000], A.FLUSH), (text[:40000], A.FINISH)],
+        "flush_at_start_and_twice": [(b"", A.FLUSH), (text[:1000], A.FLUSH), (b"", A.FLUSH), (text[1000:3000], A.FINISH)],
+        "flush_then_empty_finish": [(text[:70000], A.FLUSH), (b"", A.FINISH)],
+        "run_between": [(text[:10], A.RUN), (text[10:30000], A.FLUSH), (text[30000:30001], A.RUN), (text[30001:90000], A.FINISH)],
+        "single_bytes": [(b"a", A.FLUSH), (b"a", A.FLUSH), (b"b", A.FLUSH), (b"", A.FINISH)],
+        # decompress_len carried over a flush: the first block behind it closes early ...
+        "carry_closes_block_early": [(text[:60000], A.FLUSH), (text[60000:140000], A.FINISH)],
+        # ... at once, empty, when the carry is within one code of 0xFFFF ...
+        "carry_0xFFFF_empty_first_block": [(text[:0xFFFF], A.FLUSH), (text[0xFFFF:0xFFFF + 5000], A.FINISH)],
+        "carry_0xFFFE": [(noise[:0xFFFE], A.FLUSH), (b"\0" * 600, A.FINISH)],
+        # ... and a stored block behind a flush repeats the carried bytes (incompressible input)
+        "stored_blocks_repeat_bytes": [(noise[:30000], A.FLUSH), (noise[30000:70000], A.FLUSH), (noise[70000:200000], A.FINISH)],
+        "finish_then_more": [(text[:5000], A.FINISH), (text[:100], A.FLUSH), (b"", A.FINISH)],
+        "many_small": [(text[i * 997:(i + 1) * 997], A.FLUSH) for i in range(40)] + [(b"", A.FINISH)],
+    }
+    for name, pieces in cases.items():
+        got, want = _flush_case(pkg, oracle, pieces)
+        assert got == want, name
+    got, want = _flush_case(pkg, oracle, [(text[:20000], A.FLUSH), (text[20000:50000], A.FINISH)], dict_=text[60000:100000])
+    assert got == want, "with_dict"
+    # a flushed stream whose padding happens to be empty inflates (a sanity check of the bytes, not of parity)
+    rng = random.Random(5)
+    for trial in range(30):
+        pieces, pos = [], 0
+        while pos < 300000:
+            k = rng.choice([0, 1, 17, 4000, 65535, 70000])
+            pieces.append((text[pos:pos + k], rng.choice([A.RUN, A.FLUSH, A.FLUSH])))
+            pos += k
+        pieces.append((b"", A.FINISH))
+        got, want = _flush_case(pkg, oracle, pieces)
+        assert got == want, ("random", trial)
+
+
+def test_flush_refused_for_containers_before_input_is_pulled(pkg):
+    it = iter(b"hello world")
+    with pytest.raises(pkg.CompressionError):
+        pkg.ZlibEncoder().next(it, pkg.Action.FLUSH)
+    assert bytes(it) == b"hello world"  # the caller's iterator is untouched
+    with pytest.raises(pkg.CompressionError):
+        pkg.GZipEncoder().end(pkg.Action.FLUSH)
