@@ -231,6 +231,8 @@ struct BwtArgs {
     unsigned long long *active;      // [64] per-round count of non-final rotations in unfinished blocks
     u32 *per_k, *per_shift;          // [nb] periodic blocks: repetition count, least-rotation start
     u32 *bin_cursor;                 // [nb][1024] rank words binned so far (k_group_apply -> k_rank_place)
+    u8 *L;                           // [nb * kSlot] last column, written as rotations become final
+    u32 *orig_ptr;                   // [nb] position of rotation 0 in the sorted order
     const u8 *sym_code;              // [nb][256] byte -> code (rank among the bytes in use)
     const u8 *keyinfo;               // [nb] KeyInfo {bits per symbol, symbols per key}
     // fused radix passes (no per-pass histogram kernel; tile offsets by decoupled look-back)

@@ -361,6 +361,8 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
     x.per_k = g->per_k.as<u32>() + o;
     x.per_shift = g->per_shift.as<u32>() + o;
     x.bin_cursor = g->bin_cursor.as<u32>() + (size_t)o * 1024;
+    x.L = g->L.as<u8>() + s;
+    x.orig_ptr = g->orig_ptr.as<u32>() + o;
     x.sym_code = g->sym_code.as<u8>() + (size_t)o * 256;
     x.keyinfo = g->keyinfo.as<u8>() + (size_t)o * 4;
     x.gh_tiles = g->gh_tiles.as<u32>() + t * 3 * kMaxBins;

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shif
         for (u32 r = 0; r < 16; ++r)
             if ((ok >> r) & 1u) atomicAdd(&s_hist[l & (kHistCopies - 1)][(key[r] >> shift) & (NB - 1)], 1u);
         // keys that cost a gather to build are kept for the scatter kernel of the same pass
-        if ((SRC == SRC_TEXT || SRC == SRC_WALK || SRC == SRC_MM) && Kstore) {
+        if ((SRC == SRC_TEXT || SRC == SRC_WALK || SRC == SRC_MM || SRC == SRC_SURV || SRC == SRC_LISTG) && Kstore) {
             const size_t base = (size_t)lb * kSlot;
 #pragma unroll
             for (u32 r = 0; r < 16; ++r) {
@@ -861,6 +861,8 @@ __global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 ste
             pj = t >= n ? t - n : t;
         }
         if (INIT) {
+            // (a table of the packed keys, one gather instead of three plus the re-coding, was measured: the flags
+            // gain 0.6 ms, the walk pass loses 2.5 -- the table is 3.6 MB per block against 0.9 MB of text in the L2)
 #pragma unroll
             for (u32 r = 0; r < 16; ++r) s2[r] = pack_key(text, n, jj[r], s_code, ki.bits, ki.chars);
             if (need_prev) ps20 = pack_key(text, n, pj, s_code, ki.bits, ki.chars);
@@ -944,7 +946,9 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
     u32 tile, lb;
     xcd_remap(kTilesPerBlock, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
-    const u32 n = a.blocks[lb].n;
+    const BlockDesc d = a.blocks[lb];
+    const u32 n = d.n;
+    const u8 *__restrict__ text = a.rle + d.rle_off;
     const u32 cnt = a.count[lb];
     const u32 start = tile * kSortTile;
     if (start >= cnt) return;
@@ -1019,6 +1023,13 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
             const u32 p = g + (idx - (u32)rs);
             const u32 head = g + ((u32)ss - (u32)rs);
             if (!INIT) st_stream(a.SA + base + p, j); // (INIT: the list IS SA, p == idx)
+            if (fin) {
+                // a rotation becomes final exactly once, here (or, in a periodic block, in k_periodic_place):
+                // its byte of the last column goes out now -- L[i] = block[(SA[i]-1) mod n], origPtr = i where
+                // SA[i] == 0 (src/bzip2/encoder.rs:331-338) -- instead of a pass over SA at the end
+                a.L[base + p] = text[j ? j - 1u : n - 1u];
+                if (j == 0) a.orig_ptr[lb] = p;
+            }
             word[r] = (j & 1023u) | (head << kRankBinShift) | (fin ? kFinalBit : 0u);
             lrank[r] = atomicAdd(&s_bcnt[j >> kRankBinShift], 1u);
             my_nonfinal += fin ? 0u : 1u;
@@ -1244,7 +1255,9 @@ __global__ __launch_bounds__(kSortThreads) void k_periodic_place(BwtArgs a)
     xcd_remap(kTilesPerBlock, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
     if (a.nonfinal[lb] == 0) return;
-    const u32 n = a.blocks[lb].n;
+    const BlockDesc d = a.blocks[lb];
+    const u32 n = d.n;
+    const u8 *__restrict__ text = a.rle + d.rle_off;
     const size_t base = (size_t)lb * kSlot;
     const u32 k = a.per_k[lb], shift = a.per_shift[lb];
     if (k == 0) return;
@@ -1256,6 +1269,8 @@ __global__ __launch_bounds__(kSortThreads) void k_periodic_place(BwtArgs a)
         // members j = i0 + t*p of one group, DESCENDING (j - shift) mod n
         const u32 pos = (i0 >= shift) ? (k - 1u - t) : (t == 0 ? 0u : k - t);
         a.SA[base + r + pos] = j;
+        a.L[base + r + pos] = text[j ? j - 1u : n - 1u]; // (the last column of what was not final before)
+        if (j == 0) a.orig_ptr[lb] = r + pos;
     }
 }
 
@@ -1424,6 +1439,9 @@ static void radix_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const
                            Vin, Kout, Vout);
     else if (SRC == SRC_MM && Ktmp)
         hipLaunchKernelGGL((k_radix_scatter<SRC_MMK, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Ktmp,
+                           Vin, Kout, Vout);
+    else if ((SRC == SRC_SURV || SRC == SRC_LISTG) && Ktmp) // the gathered ranks were kept: a plain pair list now
+        hipLaunchKernelGGL((k_radix_scatter<SRC_PAIRS, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Ktmp,
                            Vin, Kout, Vout);
     else
         hipLaunchKernelGGL((k_radix_scatter<SRC, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Kin, Vin,
@@ -1594,9 +1612,11 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             // of rotation j+h (2 passes), then stably by their own group (2 passes): O(m) work
             hipLaunchKernelGGL(k_survivor_compact, grid, dim3(kSortThreads), 0, st, a, lastV, fV);
             hipLaunchKernelGGL(k_copy_counts, dim3((a.nb + 255) / 256), dim3(256), 0, st, a.count, a.count2, a.nb);
-            radix_pass<SRC_SURV, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof);
+            // (the ranks a histogram kernel gathers are kept in the free key array for its scatter kernel: with few
+            // survivors per block the rank arrays of the blocks in flight do not fit the L2, a gather costs a sector)
+            radix_pass<SRC_SURV, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK);
             radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof);
-            radix_pass<SRC_LISTG, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof);
+            radix_pass<SRC_LISTG, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK);
             radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof);
             u32 *t = cK; cK = fK; fK = t;
             t = cV; cV = fV; fV = t;
@@ -1682,6 +1702,10 @@ int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned l
 
 void launch_last_column(hipStream_t st, const BwtArgs &a, u8 *L, u32 *orig_ptr, u64 total_n, KernelProf *prof)
 {
+    // The last column is written by k_group_apply / k_periodic_place when a rotation becomes final; the pass over
+    // SA is kept as a cross-check (BZ_LASTCOL_PASS=1 redoes the column from SA: same bytes).
+    static const bool redo = getenv("BZ_LASTCOL_PASS") && atoi(getenv("BZ_LASTCOL_PASS")) != 0;
+    if (!redo) return;
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
     const int p = prof ? prof->begin(st, KID_LAST_COLUMN, total_n * 6) : -1;
     hipLaunchKernelGGL(k_last_column, grid, dim3(kSortThreads), 0, st, a, L, orig_ptr);

@@ -47,21 +47,31 @@ __global__ __launch_bounds__(256) void k_mtf_summaries(MtfArgs a)
     const u8 *L = a.L + (size_t)lb * kSlot;
     u8 *out = a.summ + ((size_t)lb * kMaxMtfChunks + chunk) * 256u;
     u32 cnt = 0;
-    // walk backwards, 16 bytes at a time (chunk starts are 256-byte aligned)
-    for (int v = (int)(kMtfChunk / 16u) - 1; v >= 0 && cnt < alpha; --v) {
-        const u32 p0 = beg + (u32)v * 16u;
-        if (p0 >= end) continue;
-        const uint4 q = *reinterpret_cast<const uint4 *>(L + p0);
-        const u32 wv[4] = {q.x, q.y, q.z, q.w};
+    // walk backwards, 64 bytes per visit (four 16-byte loads issued together: a line is fetched once and used
+    // while it is there; chunk starts are 256-byte aligned)
+    for (int v4 = (int)(kMtfChunk / 64u) - 1; v4 >= 0 && cnt < alpha; --v4) {
+        if (beg + (u32)v4 * 64u >= end) continue;
+        uint4 q4[4];
 #pragma unroll
-        for (int k = 15; k >= 0; --k) {
-            if (p0 + (u32)k < end) {
-                const u32 c = (wv[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-                const u32 bit = 1u << (c & 31u);
-                const u32 wd = s_seen[(c >> 5) * 256 + threadIdx.x];
-                if (!(wd & bit)) {
-                    s_seen[(c >> 5) * 256 + threadIdx.x] = wd | bit;
-                    out[cnt++] = (u8)c;
+        for (int u = 0; u < 4; ++u) {
+            const u32 pl = beg + (u32)v4 * 64u + (u32)u * 16u;
+            q4[u] = (pl < end) ? *reinterpret_cast<const uint4 *>(L + pl) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 3; u >= 0; --u) {
+            const u32 p0 = beg + (u32)v4 * 64u + (u32)u * 16u;
+            if (p0 >= end || cnt >= alpha) continue;
+            const u32 wv[4] = {q4[u].x, q4[u].y, q4[u].z, q4[u].w};
+#pragma unroll
+            for (int k = 15; k >= 0; --k) {
+                if (p0 + (u32)k < end) {
+                    const u32 c = (wv[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+                    const u32 bit = 1u << (c & 31u);
+                    const u32 wd = s_seen[(c >> 5) * 256 + threadIdx.x];
+                    if (!(wd & bit)) {
+                        s_seen[(c >> 5) * 256 + threadIdx.x] = wd | bit;
+                        out[cnt++] = (u8)c;
+                    }
                 }
             }
         }

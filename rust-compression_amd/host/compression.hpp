@@ -108,7 +108,6 @@ class BZip2Encoder {
     // Encoder::next (src/traits/encoder.rs:87-92, src/bzip2/encoder.rs:120-158)
     template <class I, class S> std::optional<Result<uint8_t>> next(I &it, const S &end, Action action)
     {
-        if (action == Action::Flush && Kind != DF_KIND_DEFLATE) return Result<uint8_t>::Err(from_status(BZ_E_PARAM));
         if (pos_ == len_) {
             int rc = refill();
             if (rc < 0) return Result<uint8_t>::Err(from_status(rc));
@@ -191,6 +190,7 @@ template <int Kind> class DeflateFamilyEncoder {
 
     template <class I, class S> std::optional<Result<uint8_t>> next(I &it, const S &end, Action action)
     {
+        if (action == Action::Flush && Kind != DF_KIND_DEFLATE) return Result<uint8_t>::Err(from_status(BZ_E_PARAM));
         if (action == Action::Flush && Kind != DF_KIND_DEFLATE) return Result<uint8_t>::Err(from_status(BZ_E_PARAM));
         if (pos_ == len_) {
             int rc = refill();

@@ -115,9 +115,37 @@ def dstream_case():
     return (bytes(got), code) == (want, st)
 
 
+def deflate_flush_case():
+    """an Inflater stream fed iterator by iterator with Run / Flush / Finish in between, against the oracle's"""
+    d = big()[:rng.choice([70000, 200000, 400000])] if rng.random() < 0.2 else gen()
+    dict_ = gen()[:rng.choice([0, 0, 100, 40000])] if rng.random() < 0.3 else b""
+    enc, ref = pkg.Inflater(dict_=dict_), oracle.DeflateEncoder(dict_)
+    got, pos, trace = bytearray(), 0, []
+    while True:
+        k = rng.choice([0, 1, 3, 100, 5000, 65535, 65536, 70000, len(d)])
+        piece = d[pos:pos + k]
+        pos += len(piece)
+        act = 2 if (pos >= len(d) and rng.random() < 0.5) else rng.choice([0, 1, 1])
+        trace.append((len(piece), act))
+        enc.write(piece)
+        enc.end(act)
+        got += enc.read_all()
+        ref.feed(piece, act)
+        if act == 2:
+            break
+    if bytes(got) != ref.output():
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        open(os.path.join(ROOT, "gpurun_out", "fuzz_deflate_flush_fail.bin"), "wb").write(d)
+        print("deflate flush mismatch: n", len(d), "dict", len(dict_), "pieces", trace[:40])
+        return False
+    return True
+
+
 def deflate_case():
     """Deflate / zlib / gzip streams against the oracle; every so often a multi-block input"""
     import zlib
+    if rng.random() < 0.35:
+        return deflate_flush_case()
     d = big()[:rng.choice([70000, 200000, 700000])] if rng.random() < 0.15 else gen()
     kind = rng.randrange(3)
     got = pkg.deflate_compress(d, kind)
