@@ -1006,6 +1006,8 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
         const u32 idx = rowbase + l;
         lrank[r] = 0xFFFFFFFFu;
         word[r] = 0;
+        bool nf = false;  // this lane's element stays unordered: it is counted for the next walk round
+        u32 nf_head = 0;
         if (idx < cnt) {
             const u64 o = mo[r] & le_mask, q = mn[r] & le_mask;
             const int rs = o ? (int)(rowbase + 63u - __clzll(o)) : carry_old;
@@ -1033,9 +1035,24 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
             word[r] = (j & 1023u) | (head << kRankBinShift) | (fin ? kFinalBit : 0u);
             lrank[r] = atomicAdd(&s_bcnt[j >> kRankBinShift], 1u);
             my_nonfinal += fin ? 0u : 1u;
-            if (a.fused && !fin) {
-                atomicAdd(&s_gh[0][head & 1023u], 1u);
-                atomicAdd(&s_gh[1][(head >> 10) & 1023u], 1u);
+            nf = !fin;
+            nf_head = head;
+        }
+        if (a.fused) {
+            // Group heads rise along the list, so the 64 heads of a row share their high digit (almost always):
+            // one lane adds the count for all of them -- 64 single adds to one LDS word serialise.
+            const u64 mnf = __ballot(nf);
+            if (mnf) {
+                if (nf) atomicAdd(&s_gh[0][nf_head & 1023u], 1u);
+                const u32 lead = (u32)__ffsll((long long)mnf) - 1u;
+                const u32 hi = (nf_head >> 10) & 1023u;
+                const u32 hi0 = __shfl(hi, lead, 64);
+                const u64 same = __ballot(nf && hi == hi0);
+                if (same == mnf) {
+                    if (l == lead) atomicAdd(&s_gh[1][hi0], (u32)__popcll(mnf));
+                } else if (nf) {
+                    atomicAdd(&s_gh[1][hi], 1u);
+                }
             }
         }
         if (mo[r]) carry_old = (int)(rowbase + 63u - __clzll(mo[r]));

@@ -123,22 +123,31 @@ class TorchComm:
             mine = self._buffer(d_send, send_bytes)
             if self.rank != 0:
                 if send_bytes:
-                    dist.send(mine.to(self.wire).contiguous(), dst=0, group=self.group)
+                    for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine.to(self.wire).contiguous(), 0, self.group)]):
+                        req.wait()
                 return
             offs = [int(recv_off[r]) for r in range(self.world)]
             lens = [int(recv_bytes[r]) for r in range(self.world)]
             whole = self._buffer(d_recv, max(o + k for o, k in zip(offs, lens)))
             whole[offs[0]:offs[0] + lens[0]].copy_(mine)
+            # all receives are posted together (one grouped RCCL call: the peers' bit strings arrive over their
+            # own xGMI links side by side, not one after the other)
+            ops, staged = [], []
             for r in range(1, self.world):
                 if lens[r] == 0:
                     continue
                 part = whole[offs[r]:offs[r] + lens[r]]
                 if self.wire == part.device:
-                    dist.recv(part, src=r, group=self.group)
+                    ops.append(dist.P2POp(dist.irecv, part, r, self.group))
                 else:
                     t = torch.empty(lens[r], dtype=torch.uint8, device=self.wire)
-                    dist.recv(t, src=r, group=self.group)
-                    part.copy_(t)
+                    ops.append(dist.P2POp(dist.irecv, t, r, self.group))
+                    staged.append((part, t))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            for part, t in staged:
+                part.copy_(t)
         return self._guard(run)
 
 
