@@ -435,34 +435,41 @@ def extras(result, args, pkg, eng, torch, dev, d_in, n, d_out, out_len, golden, 
     saved = write.argtypes
     write.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     base = ctypes.cast(ctypes.c_char_p(host), ctypes.c_void_p).value
-    buf = (ctypes.c_uint8 * (4 << 20))()
-    sha = hashlib.sha256()
+    sink = (ctypes.c_uint8 * (out_len + (8 << 20)))()  # the caller's output buffer (touched: no page faults in the clock)
+    ctypes.memset(sink, 0, len(sink))
+    sink_addr = ctypes.addressof(sink)
+    read = L.bz_enc_read
+    saved_r = read.argtypes
+    read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     piece = 1 << 20
+    got_n = 0
     c0 = time.perf_counter()
     ok = True
     for i in range(0, n, piece):
         ok = ok and write(h, base + i, min(piece, n - i)) == 0
         while True:
-            k = L.bz_enc_read(h, buf, len(buf))
+            k = read(h, sink_addr + got_n, len(sink) - got_n)
             if k <= 0:
                 break
-            sha.update(memoryview(buf)[:k])
+            got_n += k
     ok = ok and L.bz_enc_end(h, int(pkg.Action.FINISH)) == 0
     while True:
-        k = L.bz_enc_read(h, buf, len(buf))
+        k = read(h, sink_addr + got_n, len(sink) - got_n)
         if k <= 0:
             break
-        sha.update(memoryview(buf)[:k])
+        got_n += k
     e2 = time.perf_counter() - c0
     write.argtypes = saved
+    read.argtypes = saved_r
     L.bz_enc_destroy(h)
-    checks["end_to_end_streaming_equals_device_stream"] = bool(ok and sha.hexdigest() == result["stream_sha256"])
+    checks["end_to_end_streaming_equals_device_stream"] = bool(
+        ok and got_n == out_len and hashlib.sha256(memoryview(sink)[:got_n]).hexdigest() == result["stream_sha256"])
     best = max(n / e1, n / e2) / 1e6
     result["end_to_end"] = {"unit": "MB/s", "bz_encode_buffer": round(n / e1 / 1e6, 2),
                             "bz_enc_write_read_1MiB_pieces": round(n / e2 / 1e6, 2),
                             "fraction_of_hbm_resident_rate": round(best / result["value"], 3),
                             "note": "host buffer in -> host buffer out, one GPU, H2D/D2H inside the clock; pageable caller "
-                                    "memory on both sides; the streaming figure includes hashing the output as it is read"}
+                                    "memory on both sides"}
 
 
 if __name__ == "__main__":

@@ -50,9 +50,10 @@ extern "C" const char *bz_strerror(int code)
 extern "C" const char *bz_version(void) { return "bz2_mi355x 0.1 (gfx950)"; }
 
 // ---- the pipeline behind a context -------------------------------------------------------------
-// Host bytes reach the GPU in CHUNKS (BZ_ENC_CHUNK_MIB, default 256 MiB: a batch of ~300 level-9 blocks
-// keeps the latency-bound stages -- one workgroup per block in the Huffman stage -- a small share of a
-// batch; measured on 1 GiB: 64 MiB chunks 4.6 GB/s host to host, 128 MiB 5.9, 256 MiB 6.5) through two pinned staging
+// Host bytes reach the GPU in CHUNKS (BZ_ENC_CHUNK_MIB, default 384 MiB, the first one of a stream 64 MiB: a
+// large batch keeps the latency-bound stages -- one workgroup per block in the Huffman stage -- a small share
+// of a job; measured on 1 GiB with one lane: 64 MiB chunks 4.6 GB/s host to host, 128 MiB 5.9, 256 MiB 6.5)
+// through two pinned staging
 // buffers: bz_enc_write copies the caller's bytes into the pinned buffer being filled (the only CPU
 // copy; pieces of 4 MiB or more are split over up to four threads) and, when it is full, starts its
 // upload (hipMemcpyAsync on a copy stream) into a device staging buffer and hands the chunk to the
@@ -73,8 +74,10 @@ struct EncResources {
     bz_gpu_engine *g[2] = {nullptr, nullptr};
     size_t engine_blocks = 0;
     size_t chunk = 0;            // bytes per pinned / device staging buffer
-    u8 *h_in[2] = {nullptr, nullptr};   // pinned
+    u8 *h_in[2] = {nullptr, nullptr};   // pinned; sized by the chunks they have held (h_cap)
+    size_t h_cap[2] = {0, 0};
     void *d_stage[2] = {nullptr, nullptr};
+    size_t stage_cap[2] = {0, 0};
     void *d_buf[2] = {nullptr, nullptr}; // per lane: composed input = tail of the previous job's input + the chunk
     size_t d_buf_cap[2] = {0, 0};
     void *d_out[2] = {nullptr, nullptr};
@@ -106,7 +109,7 @@ static size_t enc_chunk_bytes()
 {
     static const size_t v = [] {
         const char *s = getenv("BZ_ENC_CHUNK_MIB");
-        long mib = s ? atol(s) : 256;
+        long mib = s ? atol(s) : 384;
         if (mib < 1) mib = 1;
         if (mib > 1024) mib = 1024;
         return (size_t)mib << 20;
@@ -158,9 +161,7 @@ static int resources_get(int device, EncResources **out)
         return rc;
     }
     bool ok = hipSetDevice(device) == hipSuccess;
-    for (int i = 0; i < 2 && ok; ++i) {
-        ok = ok && hipHostMalloc((void **)&r->h_in[i], r->chunk, hipHostMallocDefault) == hipSuccess;
-        ok = ok && hipMalloc(&r->d_stage[i], r->chunk + 64) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i) { // (pinned and device staging buffers come with the chunks: grow / grow_pinned)
         ok = ok && hipEventCreateWithFlags(&r->ev_up[i], hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&r->ev_down[i], hipEventDisableTiming) == hipSuccess;
     }
@@ -213,6 +214,7 @@ struct bz_enc {
     bool inner_finished = false; // EncoderInner.finished      (encoder.rs:164), set by the worker that assembles Finish
     bool finish_submitted = false; // ... and the caller's copy: a Finish job has been handed over
     bool oneshot = false;          // bz_encode_buffer: the output queue is read only at the end
+    bool reserve_stop = false;     // (out_mu) tells reserve_output to give up
     bool any_block = false;      // block_no > 1               (encoder.rs:168,179)
     u32 combined_crc = 0;        // encoder.rs:167
     unsigned carry_bits = 0;     // BitWriter.counter          (writer.rs:167)
@@ -323,24 +325,29 @@ static int out_append_locked(bz_enc *e, const u8 *p, size_t n)
     }
     copy_in(e->out + e->out_len, p, n); // (large pieces on several threads)
     e->out_len += n;
-    if (e->oneshot && n >= ((size_t)1 << 20)) {
-        // One-shot call: nobody reads the queue before the end, and the bytes of the LAST job are copied
-        // with nothing left to hide them behind.  Make room for a piece like this one now and touch its
-        // pages (first-touch page faults cost more than the copy), while the GPU is busy with the next job.
-        const size_t want = e->out_len + n + n / 4;
-        if (want > e->out_cap) {
-            u8 *q = (u8 *)realloc(e->out, want);
-            if (q) {
-                e->out = q;
-                e->out_cap = want;
-            }
-        }
-        if (e->out_cap > e->out_len) {
-            volatile u8 *t = e->out + e->out_len;
-            for (size_t i = 0; i < e->out_cap - e->out_len; i += 4096) t[i] = 0;
-        }
-    }
     return BZ_OK;
+}
+
+// One-shot call: nobody reads the output queue before the end, and the bytes of the last jobs are copied with
+// nothing left to hide them behind.  First-touch page faults cost more than the copy itself (226 MB: ~40 ms
+// against ~10), so room for the expected result is reserved and touched by a helper thread while the GPU
+// works (in slices, under the queue's lock: an append may move the buffer in between).
+static void reserve_output(bz_enc *e, size_t expect)
+{
+    constexpr size_t kSlice = (size_t)8 << 20;
+    for (size_t pos = 0; pos < expect; pos += kSlice) {
+        std::lock_guard<std::mutex> lk(e->out_mu);
+        if (e->reserve_stop) return;
+        if (e->out_cap < expect) {
+            u8 *q = (u8 *)realloc(e->out, expect);
+            if (!q) return;
+            e->out = q;
+            e->out_cap = expect;
+        }
+        const size_t a = std::max(pos, e->out_len), b = std::min(pos + kSlice, e->out_cap);
+        volatile u8 *t = e->out;
+        for (size_t i = a; i < b; i += 4096) t[i] = 0;
+    }
 }
 
 static void drainer_main(bz_enc *e)
@@ -629,6 +636,10 @@ static int submit(bz_enc *e, int mode, bool wait)
         }
         if (enc_trace()) fprintf(stderr, "bz_enc upload: %zu bytes from pinned buffer %d (at %.1f)\n", e->fill, s, now_ms());
         if (hipSetDevice(e->device) != hipSuccess) return BZ_E_UNEXPECTED;
+        {
+            const int grc = grow(&r->d_stage[s], &r->stage_cap[s], e->fill + 64);
+            if (grc != BZ_OK) return grc;
+        }
         if (hipMemcpyAsync(r->d_stage[s], h, e->fill, hipMemcpyHostToDevice, r->st_up) != hipSuccess ||
             hipEventRecord(r->ev_up[s], r->st_up) != hipSuccess)
             return BZ_E_UNEXPECTED;
@@ -720,8 +731,9 @@ extern "C" int bz_enc_write(bz_enc *e, const uint8_t *in, size_t n)
     if (rc != BZ_OK) return rc;
     EncResources *r = e->r;
     while (n) {
-        // (the first chunk of a stream is a quarter of the others: the GPU has work sooner)
-        const size_t cap = e->chunks_filled == 0 ? r->chunk / 4 : r->chunk;
+        // (the first chunk of a stream is small -- 64 MiB at most: the GPU has work sooner, and a short stream
+        // takes little pinned memory; the staging buffers grow with the chunks they hold)
+        const size_t cap = e->chunks_filled == 0 ? std::min(r->chunk, (size_t)64 << 20) : r->chunk;
         if (e->fill == cap) {
             // A full chunk goes to the worker when MORE input arrives (its complete blocks are encoded
             // while the caller goes on writing); the last chunk of a stream is left for bz_enc_end, which
@@ -732,6 +744,18 @@ extern "C" int bz_enc_write(bz_enc *e, const uint8_t *in, size_t n)
             // the pinned buffer of this slot is free once its last upload has completed
             if (hipSetDevice(e->device) != hipSuccess || hipEventSynchronize(r->ev_up[e->fill_slot]) != hipSuccess)
                 return BZ_E_UNEXPECTED;
+        }
+        if (e->fill + std::min(n, cap - e->fill) > r->h_cap[e->fill_slot]) {
+            // room for what this call adds (short streams stay small), for a whole chunk once it is half full
+            size_t want = e->fill + std::min(n, cap - e->fill);
+            want = std::max(want, 2 * r->h_cap[e->fill_slot]); // (geometric: many small writes, few reallocations)
+            if (want > cap / 2) want = cap;
+            u8 *nh = nullptr;
+            if (hipHostMalloc((void **)&nh, want, hipHostMallocDefault) != hipSuccess) return BZ_E_NOMEM;
+            if (e->fill) memcpy(nh, r->h_in[e->fill_slot], e->fill);
+            if (r->h_in[e->fill_slot]) (void)hipHostFree(r->h_in[e->fill_slot]);
+            r->h_in[e->fill_slot] = nh;
+            r->h_cap[e->fill_slot] = want;
         }
         const size_t k = std::min(n, cap - e->fill);
         copy_in(r->h_in[e->fill_slot] + e->fill, in, k);
@@ -829,10 +853,19 @@ extern "C" int bz_encode_buffer(int level, int device, const uint8_t *in, size_t
     int rc = bz_enc_create(&e, level, device);
     if (rc != BZ_OK) return rc;
     e->oneshot = true;
+    std::thread reserver;
+    if (in_len >= ((size_t)8 << 20)) reserver = std::thread(reserve_output, e, in_len / 3 + ((size_t)1 << 20));
     // the same pipeline as the streaming context: chunks are uploaded and encoded while the rest of the
     // input is still being copied to the pinned staging buffers
     if (in_len) rc = bz_enc_write(e, in, in_len);
     if (rc == BZ_OK) rc = bz_enc_end(e, BZ_ACTION_FINISH);
+    if (reserver.joinable()) {
+        {
+            std::lock_guard<std::mutex> lk(e->out_mu);
+            e->reserve_stop = true;
+        }
+        reserver.join();
+    }
     if (rc == BZ_OK) {
         std::lock_guard<std::mutex> lk(e->out_mu);
         // the output queue's buffer itself goes to the caller (nothing has been read from it)

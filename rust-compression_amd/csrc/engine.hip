@@ -42,10 +42,17 @@ static void spans_collect(bz_gpu_engine *g)
     g->t_stage[5] = g->t_stage[0] + g->t_stage[1] + g->t_stage[2] + g->t_stage[3] + g->t_stage[4];
 }
 
-static int ensure_workspace(bz_gpu_engine *g)
+// The batch workspace holds `ws_blocks` blocks in flight: as many as the call at hand needs (up to
+// max_blocks, the batch size), grown when a later call needs more -- a context that only ever sees small
+// inputs does not take 31.5 MB x max_blocks of HBM.
+static int ensure_workspace(bz_gpu_engine *g, size_t need_blocks)
 {
-    if (g->ws_ready) return BZ_OK;
-    const size_t nb = g->max_blocks;
+    if (need_blocks > g->max_blocks) need_blocks = g->max_blocks;
+    if (need_blocks < 8) need_blocks = 8;
+    if (g->ws_blocks >= need_blocks) return BZ_OK;
+    // (grow in steps: a stream of growing chunks does not reallocate for every one)
+    size_t nb = need_blocks + need_blocks / 4;
+    if (nb > g->max_blocks) nb = g->max_blocks;
     int rc = BZ_OK;
 #define ENS(buf, bytes)                         \
     do {                                        \
@@ -104,7 +111,7 @@ static int ensure_workspace(bz_gpu_engine *g)
         g->sort_epoch = 0;
     }
 #undef ENS
-    g->ws_ready = true;
+    g->ws_blocks = nb;
     return BZ_OK;
 }
 
@@ -519,7 +526,7 @@ extern "C" int bz_gpu_encode_blocks(bz_gpu_engine *g, size_t first, size_t strid
     std::vector<size_t> mine;
     for (size_t b = first; b < total; b += stride) mine.push_back(b);
     if (mine.empty()) return BZ_OK;
-    int rc = ensure_workspace(g);
+    int rc = ensure_workspace(g, mine.size());
     if (rc != BZ_OK) return rc;
     HIPCHK(hipMemsetAsync(g->error_flag.p, 0, 4, g->st));
 
@@ -528,8 +535,8 @@ extern "C" int bz_gpu_encode_blocks(bz_gpu_engine *g, size_t first, size_t strid
     std::vector<u32> crcs;
     std::vector<BlockOut> outs;
     std::vector<PackBlock> pbs;
-    for (size_t k0 = 0; k0 < mine.size(); k0 += g->max_blocks) {
-        const u32 nb = (u32)std::min(g->max_blocks, mine.size() - k0);
+    for (size_t k0 = 0; k0 < mine.size(); k0 += g->ws_blocks) {
+        const u32 nb = (u32)std::min(g->ws_blocks, mine.size() - k0);
         descs.resize(nb);
         crcs.resize(nb);
         for (u32 i = 0; i < nb; ++i) {
@@ -910,7 +917,7 @@ extern "C" int bz_gpu_debug_bwt(bz_gpu_engine *g, const uint8_t *h_block, size_t
 {
     if (!g || n == 0 || n > kMaxBlockLen) return BZ_E_PARAM;
     HIPCHK(hipSetDevice(g->device));
-    int rc = ensure_workspace(g);
+    int rc = ensure_workspace(g, 1);
     if (rc != BZ_OK) return rc;
     if ((rc = g->rle.ensure(n + 256)) != BZ_OK) return rc;
     HIPCHK(hipMemcpyAsync(g->rle.p, h_block, n, hipMemcpyHostToDevice, g->st));

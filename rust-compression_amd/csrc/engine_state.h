@@ -72,7 +72,7 @@ struct bz_gpu_engine {
         mtf_freq, bout, selector, code_len, group_bitoff, lm_scratch, stream, error_flag, packlist, gh_tiles, gbase,
         tile_state, tickets;
     u32 sort_epoch = 0; // fused radix passes: tag of the current pass in tile_state / tickets
-    bool ws_ready = false;
+    size_t ws_blocks = 0; // blocks the batch workspace holds now (<= max_blocks)
     // own packed buffer / assemble list for the single-GPU convenience call
     DevBuf packed, gathered, asmlist;
     unsigned long long *h_active = nullptr; // pinned

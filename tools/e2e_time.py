@@ -32,6 +32,7 @@ dt = time.perf_counter() - t0
 print("streaming 1 MiB pieces: %.1f ms = %.0f MB/s (%d bytes)" % (dt * 1e3, n / dt / 1e6, tot))
 
 # the same through raw ctypes pointers (no Python-side copies of the pieces)
+del enc  # (its engines and staging buffers go back to the library's cache for the next context)
 h = ctypes.c_void_p()
 assert L.bz_enc_create(ctypes.byref(h), 9, 0) == 0
 base = ctypes.cast(ctypes.c_char_p(host), ctypes.c_void_p).value
