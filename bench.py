@@ -49,6 +49,10 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--corpus", default="text", choices=["text", "t2"])
     ap.add_argument("--force-sharded", action="store_true", help="run bz_gpu_encode_sharded even with one rank")
+    ap.add_argument("--transport", default="torch", choices=["torch", "rccl"],
+                    help="N > 1: who carries the four transport callbacks of bz_gpu_encode_sharded -- torch.distributed "
+                         "(backend nccl = RCCL; the default) or the library's own RCCL transport "
+                         "(libbz2_mi355x_rccl.so: ncclAllGather / ncclSend / ncclRecv from C, no Python in the data path)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="ranks share the visible GPUs (rank r -> device r mod count) and talk over gloo: lets "
                          "the N > 1 path run on a box with fewer GPUs than ranks (not a scaling measurement)")
@@ -136,8 +140,9 @@ def main():
     dev_index = local_rank % ndev if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    native = args.transport == "rccl" and not share
     if world > 1:
-        if share:
+        if share or native:  # (native transport: torch.distributed only carries the id, the barrier and the timing)
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -164,7 +169,13 @@ def main():
 
     multi = world > 1 or args.force_sharded
     if multi:
-        comm = sharded.TorchComm(rank, world, dev)
+        if native:
+            ids = [pkg.rccl_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)
+            comm = pkg.RcclComm(ids[0], rank, world, dev_index)
+        else:
+            comm = sharded.TorchComm(rank, world, dev)
         cap_words = pkg.encode_bound(n // world + (48 << 20)) // 4 + 4 * local_blocks + 64
         d_packed = comm.register(torch.empty(cap_words, dtype=torch.int32, device=dev))
         gather_words = pkg.encode_bound(n) // 4 + 4 * est_blocks + 64
@@ -200,7 +211,7 @@ def main():
     nblocks_rank = len(eng.block_stats())
     eng.profile(False)
     if world > 1:
-        wire = torch.device("cpu") if share else dev
+        wire = torch.device("cpu") if (share or native) else dev
         tmax = torch.tensor([dt], dtype=torch.float64, device=wire)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = torch.tensor([float(nblocks_rank)], dtype=torch.float64, device=wire)
@@ -251,7 +262,8 @@ def main():
                        else "%d MiB stress T2 (4 KiB paragraph repeated)" % (n >> 20),
                        "input_bytes": n, "blocks": nblocks,
                        "parallelism": ("input slabs x%d (bz_gpu_encode_sharded), blocks in stream order, %s gather to rank 0"
-                                       % (world, "gloo (ranks share GPUs: not a scaling run)" if share and world > 1 else "RCCL"))
+                                       % (world, "gloo (ranks share GPUs: not a scaling run)" if share and world > 1
+                                          else ("RCCL (library transport)" if native else "RCCL (torch.distributed)")))
                        if multi else "one engine, one GPU",
                        "out_bytes": out_len, "ratio": round(out_len / n, 4)},
             "roofline": roofline,

@@ -221,6 +221,17 @@ int bz_gpu_encode_sharded(bz_gpu_engine *g, int level, const void *d_in, size_t 
                           void *d_gather, size_t gather_cap_words, void *d_out, size_t cap,
                           size_t *out_len);
 
+/* A ready-made transport: the four callbacks over RCCL (xGMI inside a node).  These three entry points are
+ * exported by a SECOND library, libbz2_mi355x_rccl.so (it links librccl; the codec library does not):
+ * rank 0 draws an id and ships its BZ_RCCL_ID_BYTES bytes to the other ranks by any means; every rank then
+ * creates its communicator (collective: ncclCommInitRank) on the device its engine lives on.  Small host-byte
+ * exchanges go through a pinned + a device staging buffer, the bit strings travel as one group of
+ * ncclSend / ncclRecv between the callers' device buffers. */
+#define BZ_RCCL_ID_BYTES 128
+int bz_rccl_unique_id(uint8_t id[BZ_RCCL_ID_BYTES]);
+int bz_rccl_comm_create(bz_shard_comm **out, const uint8_t id[BZ_RCCL_ID_BYTES], int rank, int world, int device);
+void bz_rccl_comm_destroy(bz_shard_comm *comm);
+
 /* Runs known patterns through a transport's four callbacks, shaped like the exchanges above (every
  * rank calls it): BZ_OK, BZ_E_DATA (bytes arrived wrong somewhere; the same verdict on every rank) or
  * BZ_E_UNEXPECTED (a callback failed).  host_memory != 0: the buffers handed to gatherv are host

@@ -27,7 +27,7 @@ from . import _build
 
 __all__ = ["Action", "CompressionError", "BZip2Error", "BZip2Encoder", "BZip2Decoder", "encode", "decode",
            "compress", "decompress", "GpuEngine",
-           "build", "lib", "device_count", "encode_bound"]
+           "build", "lib", "device_count", "encode_bound", "rccl_lib", "rccl_unique_id", "RcclComm"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -212,6 +212,75 @@ def lib():
 def _check(rc):
     if rc != BZ_OK:
         raise CompressionError(rc)
+
+
+_RCCL_LIB = None
+RCCL_EXPORTS = ["bz_rccl_unique_id", "bz_rccl_comm_create", "bz_rccl_comm_destroy"]
+
+
+def rccl_lib():
+    """The RCCL transport library (libbz2_mi355x_rccl.so, csrc/rccl_comm.hip): only it links librccl.  When
+    torch is installed its bundled librccl is loaded first, so that the process has ONE RCCL."""
+    global _RCCL_LIB
+    if _RCCL_LIB is not None:
+        return _RCCL_LIB
+    lib()
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+    so = os.path.join(_HERE, "libbz2_mi355x_rccl.so")
+    if not os.path.exists(so):
+        so = _build.build_rccl()
+    L = C.CDLL(so)
+    L.bz_rccl_unique_id.argtypes = [C.c_char_p]
+    L.bz_rccl_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_int, C.c_int]
+    L.bz_rccl_comm_destroy.restype = None
+    L.bz_rccl_comm_destroy.argtypes = [C.c_void_p]
+    _RCCL_LIB = L
+    return L
+
+
+def rccl_unique_id():
+    """rank 0: the 128 bytes every rank needs to join the communicator (ship them by any means)"""
+    buf = C.create_string_buffer(128)
+    _check(rccl_lib().bz_rccl_unique_id(buf))
+    return buf.raw
+
+
+class RcclComm:
+    """struct bz_shard_comm over RCCL, implemented inside libbz2_mi355x_rccl.so (no Python in the data path).
+    Creating it is collective (ncclCommInitRank): every rank calls it with the id rank 0 drew."""
+
+    def __init__(self, unique_id, rank, world, device):
+        self._p = C.c_void_p()
+        _check(rccl_lib().bz_rccl_comm_create(C.byref(self._p), bytes(unique_id), rank, world, device))
+        self.rank, self.world = rank, world
+        self.errors = []
+
+    @property
+    def struct(self):
+        """the bz_shard_comm the library filled in (GpuEngine.encode_sharded passes its address)"""
+        from .sharded import ShardComm
+        return ShardComm.from_address(self._p.value)
+
+    def register(self, t):
+        return t  # (device pointers are used as they are)
+
+    def close(self):
+        if getattr(self, "_p", None) and self._p.value and _RCCL_LIB is not None:
+            _RCCL_LIB.bz_rccl_comm_destroy(self._p)
+            self._p = C.c_void_p()
+
+    __del__ = close
 
 
 def device_count():

@@ -47,7 +47,24 @@ def build(force=False, verbose=False):
     if force or procs or _stale(SO, objs):
         cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", SO] + objs
         subprocess.check_call(cmd)
+    build_rccl(force=force, verbose=verbose)
     return SO
+
+
+RCCL_SO = os.path.join(HERE, "libbz2_mi355x_rccl.so")
+
+
+def build_rccl(force=False, verbose=False):
+    """The RCCL transport (csrc/rccl_comm.hip) as its own library: only it links librccl."""
+    src = os.path.join(CSRC, "rccl_comm.hip")
+    hdr = os.path.join(CSRC, "..", "..", "include", "bz2_mi355x.h")
+    if not (force or _stale(RCCL_SO, [src, hdr])):
+        return RCCL_SO
+    cmd = [HIPCC] + FLAGS + ["-shared", src, "-o", RCCL_SO, "-L/opt/rocm/lib", "-lrccl"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return RCCL_SO
 
 
 if __name__ == "__main__":

@@ -434,7 +434,8 @@ static int sort_batch(bz_gpu_engine *g, const BwtArgs &ba, u32 *inuse_bits, u32 
     std::vector<u8> ki((size_t)ba.nb * 4);
     if (hipMemcpyAsync(ki.data(), ba.keyinfo, ki.size(), hipMemcpyDeviceToHost, g->st) != hipSuccess) return -1;
     if (hipStreamSynchronize(g->st) != hipSuccess) return -1;
-    bool wide = false;
+    static const bool force_wide = getenv("BZ_FORCE_WIDE") != nullptr; // (experiment: 11+11+10-bit digits for every batch)
+    bool wide = force_wide;
     u32 min_chars = 8;
     for (u32 i = 0; i < ba.nb; ++i) {
         if (ki[(size_t)i * 4] >= 8) wide = true;

@@ -19,9 +19,15 @@ def test_header_symbols_exported(pkg):
     L = pkg.lib()
     names = _declared()
     assert len(names) >= 20
+    rccl = [n for n in names if n.startswith("bz_rccl_")]  # the transport library's (it alone links librccl)
+    names = [n for n in names if not n.startswith("bz_rccl_")]
     for n in names:
         assert hasattr(L, n), n
     assert sorted(pkg.EXPORTS) == names
+    R = pkg.rccl_lib()
+    for n in rccl:
+        assert hasattr(R, n), n
+    assert sorted(pkg.RCCL_EXPORTS) == rccl
 
 
 def test_no_oracle_in_product():

@@ -102,3 +102,24 @@ def test_sharded_encode_in_real_processes(oracle, world, kind):
     assert got[0][1] == want and got[0][2] == want and got[0][3] == want
     for r in range(1, world):
         assert got[r][1] == b"" and got[r][2] == b""
+
+
+def test_rccl_transport_library_single_rank(pkg, oracle):
+    """libbz2_mi355x_rccl.so (the callbacks over RCCL, implemented in C): a one-rank communicator on the test
+    box's one GPU goes through the library's transport self-test (all-gather, the variable-length gather of
+    device memory -- its own part) and carries a sharded encode.  More ranks need more GPUs: RCCL refuses two
+    ranks on one device (the driver's multi-GPU run is where `bench.py --gpus N --transport rccl` can run)."""
+    import ctypes
+    import torch
+    comm = pkg.RcclComm(pkg.rccl_unique_id(), 0, 1, 0)
+    assert pkg.lib().bz_shard_comm_selftest(ctypes.byref(comm.struct), 0) == 0
+    data, level = _input("mixed")
+    dev = torch.device("cuda", 0)
+    d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+    eng = pkg.GpuEngine(0, 16)
+    cap = (pkg.encode_bound(len(data)) + 15) & ~15
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    k = eng.encode_sharded(level, d_in.data_ptr(), len(data), comm, d_out.data_ptr(), cap)
+    assert bytes(d_out[:k].cpu().numpy()) == oracle.encode(data, level)
+    eng.close()
+    comm.close()

@@ -1,9 +1,5 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2q
-timeout 1800 python3 -m pytest tests -x -q -m gpu > gpurun_out/r2q/pytest.txt 2>&1
-tail -4 gpurun_out/r2q/pytest.txt
-timeout 900 python3 bench.py --steps 5 --warmup 2 > gpurun_out/r2q/bench.json 2> gpurun_out/r2q/bench.err; tail -3 gpurun_out/r2q/bench.err
-python3 -c "
-import json
-d=json.load(open('gpurun_out/r2q/bench.json'))
-for k in ('value','ms_per_step','checks','end_to_end','t2_stress'): print(k, d.get(k))"
+mkdir -p gpurun_out/r2t
+timeout 1200 python3 -m pytest tests/test_gpu_sharded.py -x -q -m gpu > gpurun_out/r2t/pytest.txt 2>&1
+tail -12 gpurun_out/r2t/pytest.txt
+timeout 600 python3 bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline --force-sharded --transport rccl --mib-per-gpu 256 > gpurun_out/r2t/b_rccl1.json 2> gpurun_out/r2t/b_rccl1.err; tail -3 gpurun_out/r2t/b_rccl1.err; tail -c 400 gpurun_out/r2t/b_rccl1.json
