@@ -80,9 +80,27 @@ struct DfSeg {
     u64 prior = 0;
     u32 dl0 = 0;
     bool final = true, head = true, tail = true;
+    // A PART of a long segment (one call handles < 2 GiB of positions): `more` = the input goes on behind
+    // d_in[n) without a flush, and the n bytes handed in include look-ahead: only the blocks whose cuts and
+    // codes cannot change with the bytes behind d_in[n) are written, *consumed tells where the next part
+    // starts (a block start, so a code start: the parse from there is the same parse).  bit0 / carry_byte:
+    // the bits (0..7) of the output's first byte that the previous part has already filled.
+    bool more = false;
+    u32 bit0 = 0;
+    u8 carry_byte = 0;
+    bool accumulate_stats = false;
 };
+struct DfPartOut {
+    u64 consumed = 0;   // input bytes of the part that went into written blocks
+    u32 end_bits = 0;   // bits (0..7) filled in the byte behind the bytes returned (more == true)
+    u8 end_byte = 0;
+};
+// bytes at the end of a part that is not the last one whose codes or cuts may still change: a cut looks 0xFFFF
+// bytes ahead, the code there another 258 + 2 + 258
+constexpr u64 kPartGuard = 0x10000ull + 1024ull;
 static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, const u8 *dict, size_t dict_len, u8 *d_out,
-                          size_t cap, size_t *out_len, const DfSeg &seg = DfSeg(), u32 *dl_out = nullptr)
+                          size_t cap, size_t *out_len, const DfSeg &seg = DfSeg(), u32 *dl_out = nullptr,
+                          DfPartOut *part_out = nullptr)
 {
     if (n >= (1ull << 31) - kWin) return BZ_E_PARAM; // positions and bit offsets are sized for < 2 GiB per call
     if (dict_len && kind == 2) return BZ_E_PARAM;    // GZipEncoder has no with_dict
@@ -172,9 +190,28 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     HIPCHK(hipEventRecord(w->ev[2], st));
     if (df_launch_parse(st, M, n, step, tabs.data(), ents.data(), counts.data(), nlevels, code, w->bitmap.as<u64>()) != 0) return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[3], st));
-    if (df_launch_blocks(st, d_in, code, n, w->bitmap.as<u64>(), w->bstart.as<u64>(), w->nb.as<u32>(), bcap, w->blocks.as<DfBlock>(),
-                         w->lens.as<u8>(), w->hdr.as<u32>(), w->lm.as<u32>(), w->total.as<u64>(), seg.dl0, seg.final ? 1u : 0u) != 0)
+    if (df_launch_cuts(st, n, w->bitmap.as<u64>(), w->bstart.as<u64>(), w->nb.as<u32>(), bcap, seg.dl0) != 0) return BZ_E_UNEXPECTED;
+    u64 consumed = n;
+    if (seg.more) {
+        // keep the blocks that START at or before n - guard: their ends (cuts) and codes are final
+        u32 nb_all = 0;
+        HIPCHK(hipMemcpyAsync(&nb_all, w->nb.p, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (nb_all == 0xFFFFFFFFu || nb_all > bcap || n <= kPartGuard) return BZ_E_UNEXPECTED;
+        std::vector<u64> hb((size_t)nb_all + 1);
+        HIPCHK(hipMemcpy(hb.data(), w->bstart.p, ((size_t)nb_all + 1) * 8, hipMemcpyDeviceToHost));
+        u32 keep = 0;
+        while (keep < nb_all && hb[keep] + kPartGuard <= n) ++keep; // block `keep`-1 is the last one kept
+        if (keep == 0 || keep >= nb_all) return BZ_E_UNEXPECTED;       // (a part is much longer than the guard)
+        consumed = hb[keep];
+        HIPCHK(hipMemcpyAsync(w->nb.p, &keep, 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st)); // (`keep` lives on this stack frame)
+    }
+    if (df_launch_blocks(st, d_in, code, w->bstart.as<u64>(), w->nb.as<u32>(), bcap, w->blocks.as<DfBlock>(),
+                         w->lens.as<u8>(), w->hdr.as<u32>(), w->lm.as<u32>(), w->total.as<u64>(), seg.dl0,
+                         (seg.final && !seg.more) ? 1u : 0u, seg.bit0) != 0)
         return BZ_E_UNEXPECTED;
+    if (seg.bit0) HIPCHK(hipMemcpyAsync(w->stream.p, &seg.carry_byte, 1, hipMemcpyHostToDevice, st)); // (the stream was cleared above)
     HIPCHK(hipEventRecord(w->ev[4], st));
     if (df_launch_emit(st, d_in, code, w->bstart.as<u64>(), w->nb.as<u32>(), bcap, w->blocks.as<DfBlock>(), w->lens.as<u8>(),
                        w->hdr.as<u32>(), w->stream.as<u32>()) != 0)
@@ -195,7 +232,15 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
         fprintf(stderr, "bz2_mi355x: deflate parse produced no code start inside a block window (internal error)\n");
         return BZ_E_UNEXPECTED;
     }
-    const u64 body = (total_bits + 7) >> 3;
+    // (a part that is not the last one hands on its last, partly filled byte instead of writing it)
+    const u64 body = seg.more ? (total_bits >> 3) : ((total_bits + 7) >> 3);
+    if (part_out) {
+        part_out->consumed = consumed;
+        part_out->end_bits = seg.more ? (u32)(total_bits & 7u) : 0u;
+        part_out->end_byte = 0;
+        HIPCHK(hipStreamSynchronize(st));
+        if (part_out->end_bits) HIPCHK(hipMemcpy(&part_out->end_byte, w->stream.as<u8>() + body, 1, hipMemcpyDeviceToHost));
+    }
 
     // container (zlib/encoder.rs:63-72,118-156; gzip/encoder.rs:62-75,88-134)
     u8 head[10], tail[8];
@@ -276,16 +321,69 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     w->h_bstart.resize((size_t)nb + 1);
     HIPCHK(hipMemcpy(w->h_blocks.data(), w->blocks.p, (size_t)nb * sizeof(DfBlock), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(w->h_bstart.data(), w->bstart.p, ((size_t)nb + 1) * 8, hipMemcpyDeviceToHost));
-    memset(w->stats, 0, sizeof(w->stats));
-    w->stats[0] = nb;
+    const u64 prev_bytes = seg.accumulate_stats ? w->stats[5] : 0;
+    if (!seg.accumulate_stats) memset(w->stats, 0, sizeof(w->stats));
+    w->stats[0] += nb;
     for (const DfBlock &bi : w->h_blocks) {
         w->stats[1 + (bi.btype < 3 ? bi.btype : 0)] += 1;
         w->stats[4] += bi.lm & 0xFFu;
         w->stats[6] += (bi.lm >> 8) & 1u; // dynamic block without any match: the reference's header has no distance length
     }
-    w->stats[5] = need;
+    w->stats[5] = prev_bytes + need;
     if (dl_out) *dl_out = (u32)((nb == 1 ? seg.dl0 : 0u) + (n - w->h_bstart[nb - 1]));
     return BZ_OK;
+}
+
+// A segment of any length: parts of at most BZ_DF_PART_MIB (default 1024 MiB) positions each, so that
+// positions and bit offsets stay inside 32 bits.  A part that is not the last one is handed kPartGuard bytes
+// of look-ahead and writes the blocks that cannot change any more; the next part starts at the first block it
+// left out (a code start: the lazy parse from a code start does not depend on what came before,
+// lzss/encoder.rs:132-184), with the 32 KiB in front of it as history and in the middle of the byte its
+// predecessor ended in.  The bytes are those of one pass over the whole segment.
+static u64 df_part_bytes()
+{
+    static const u64 v = [] {
+        const char *s = getenv("BZ_DF_PART_MIB");
+        long mib = s ? atol(s) : 1024;
+        if (mib < 1) mib = 1;
+        if (mib > 1536) mib = 1536;
+        return (u64)mib << 20;
+    }();
+    return v;
+}
+
+static int df_encode_parts(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, const u8 *dict, size_t dict_len, u8 *d_out,
+                           size_t cap, size_t *out_len, const DfSeg &seg0 = DfSeg(), u32 *dl_out = nullptr)
+{
+    const u64 part = df_part_bytes();
+    if (n <= part + kPartGuard) return df_encode_core(g, kind, d_in, n, dict, dict_len, d_out, cap, out_len, seg0, dl_out);
+    u64 pos = 0;
+    size_t written = 0;
+    DfSeg seg = seg0;
+    *out_len = 0;
+    for (u32 k = 0;; ++k) {
+        const u64 left = n - pos;
+        const bool last = left <= part + kPartGuard;
+        const u64 len = last ? left : part + kPartGuard;
+        seg.prior = seg0.prior + pos;
+        seg.dl0 = pos ? 0u : seg0.dl0; // (a part starts at a block start)
+        seg.head = seg0.head && pos == 0;
+        seg.tail = seg0.tail && last;
+        seg.final = seg0.final;
+        seg.more = !last;
+        seg.accumulate_stats = k > 0;
+        size_t got = 0;
+        DfPartOut po;
+        const int rc = df_encode_core(g, kind, d_in + pos, len, dict, dict_len, d_out ? d_out + written : nullptr,
+                                      d_out ? cap - written : 0, &got, seg, last ? dl_out : nullptr, &po);
+        if (rc != BZ_OK) return rc;
+        written += got;
+        *out_len = written;
+        if (last) return BZ_OK;
+        pos += po.consumed;
+        seg.bit0 = po.end_bits;
+        seg.carry_byte = po.end_byte;
+    }
 }
 
 // ---- C ABI ------------------------------------------------------------------------------------------------
@@ -295,7 +393,7 @@ extern "C" int df_gpu_encode_device(bz_gpu_engine *g, int kind, const void *d_in
     if (!g || !out_len || (!d_in && n) || kind < 0 || kind > 2) return BZ_E_PARAM;
     if (n && ((uintptr_t)d_in & 3u)) return BZ_E_PARAM;
     *out_len = 0;
-    return df_encode_core(g, kind, static_cast<const u8 *>(d_in), n, nullptr, 0, static_cast<u8 *>(d_out), cap, out_len);
+    return df_encode_parts(g, kind, static_cast<const u8 *>(d_in), n, nullptr, 0, static_cast<u8 *>(d_out), cap, out_len);
 }
 
 extern "C" int df_gpu_encode_device_dict(bz_gpu_engine *g, int kind, const void *d_in, size_t n, const uint8_t *dict,
@@ -304,7 +402,7 @@ extern "C" int df_gpu_encode_device_dict(bz_gpu_engine *g, int kind, const void 
     if (!g || !out_len || (!d_in && n) || kind < 0 || kind > 2 || (!dict && dict_len)) return BZ_E_PARAM;
     if (n && ((uintptr_t)d_in & 3u)) return BZ_E_PARAM;
     *out_len = 0;
-    return df_encode_core(g, kind, static_cast<const u8 *>(d_in), n, dict, dict_len, static_cast<u8 *>(d_out), cap, out_len);
+    return df_encode_parts(g, kind, static_cast<const u8 *>(d_in), n, dict, dict_len, static_cast<u8 *>(d_out), cap, out_len);
 }
 
 extern "C" int df_gpu_last_timings(bz_gpu_engine *g, double out_seconds[6])
@@ -480,7 +578,6 @@ extern "C" int df_enc_end(df_enc *e, int action)
     if (!e->g && (rc = bz_gpu_engine_create(&e->g, e->device, 0)) != BZ_OK) return rc;
     HIPCHK(hipSetDevice(e->device));
     const size_t add = e->in.size();
-    if (e->total + add - e->encoded >= ((size_t)1 << 31) - kWin) return BZ_E_PARAM; // one SEGMENT handles < 2 GiB
     if (e->total + add + 64 > e->d_data.cap) { // grow, keeping the stream so far
         DevBuf bigger;
         if ((rc = bigger.ensure((e->total + add) * 2 + 4096)) != BZ_OK) return rc;
@@ -503,7 +600,7 @@ extern "C" int df_enc_end(df_enc *e, int action)
     if ((rc = e->d_out.ensure(cap)) != BZ_OK) return rc;
     size_t k = 0;
     uint32_t dl = 0;
-    rc = df_encode_core(e->g, e->kind, e->d_data.as<u8>() + e->encoded, n, e->dict.data(), e->dict.size(), e->d_out.as<u8>(), cap,
+    rc = df_encode_parts(e->g, e->kind, e->d_data.as<u8>() + e->encoded, n, e->dict.data(), e->dict.size(), e->d_out.as<u8>(), cap,
                         &k, seg, &dl);
     if (rc != BZ_OK) return rc;
     if (e->out_head && e->out_head == e->out.size()) {

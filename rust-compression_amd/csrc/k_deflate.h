@@ -58,9 +58,13 @@ int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *
                     u32 nlevels, u32 *code, u64 *bm);
 // dl0: decompress_len carried into the segment (0 unless it follows an Action::Flush); last_is_final: the
 // segment ends the stream (Finish) rather than being flushed.  `in` is the segment's first byte; the dl0 bytes
-// in front of it must be readable (a stored first block copies them).
-int df_launch_blocks(hipStream_t st, const u8 *in, const u32 *code, u64 n, u64 *bm, u64 *bstart, u32 *nb, u32 cap,
-                     DfBlock *blocks, u8 *lens, u32 *hdr, u32 *lm_scratch, u64 *total_bits, u32 dl0, u32 last_is_final);
+// in front of it must be readable (a stored first block copies them).  The block chain (df_launch_cuts) is its
+// own launch so that the host can drop the blocks at the end of a PART of a long stream (those whose cuts could
+// still change with the input behind the part) before tables and offsets are made; bit0: the first block starts
+// at this bit (0..7) of the output's first byte.
+int df_launch_cuts(hipStream_t st, u64 n, u64 *bm, u64 *bstart, u32 *nb, u32 cap, u32 dl0);
+int df_launch_blocks(hipStream_t st, const u8 *in, const u32 *code, u64 *bstart, u32 *nb, u32 cap,
+                     DfBlock *blocks, u8 *lens, u32 *hdr, u32 *lm_scratch, u64 *total_bits, u32 dl0, u32 last_is_final, u32 bit0);
 int df_launch_emit(hipStream_t st, const u8 *in, const u32 *code, const u64 *bstart, const u32 *nb, u32 cap,
                    const DfBlock *blocks, const u8 *lens, const u32 *hdr, u32 *out);
 struct DfCrcShifts { u32 x[8]; }; // x^(8 * 256 * 2^k) mod P, reflected: moves a CRC register over 256 * 2^k bytes

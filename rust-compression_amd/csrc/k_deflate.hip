@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(kBThreads) void k_df_block(const u8 *__restrict__ i
 
 // bit offset of every block; a stored block is padded to a byte behind its 3 header bits (:488-501)
 __global__ __launch_bounds__(256) void k_df_offsets(DfBlock *__restrict__ blocks, const u32 *__restrict__ nb_p,
-                                                    u64 *__restrict__ total_bits)
+                                                    u64 *__restrict__ total_bits, u32 bit0)
 {
     __shared__ u64 s_bits[1024]; // bits, or ~bytes for a stored block
     __shared__ u64 s_off[1024];
@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(256) void k_df_offsets(DfBlock *__restrict__ blocks
     __shared__ u64 s_run;
     const u32 nb = *nb_p;
     if (nb == 0xFFFFFFFFu) return;
-    if (threadIdx.x == 0) s_run = 0;
+    if (threadIdx.x == 0) s_run = bit0; // (a later part of a long stream goes on inside the byte its predecessor ended in)
     for (u32 k0 = 0; k0 < nb; k0 += 1024) {
         __syncthreads();
         for (u32 j = threadIdx.x; j < 1024 && k0 + j < nb; j += 256) {
@@ -1310,13 +1310,18 @@ int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *
     return 0;
 }
 
-int df_launch_blocks(hipStream_t st, const u8 *in, const u32 *code, u64 n, u64 *bm, u64 *bstart, u32 *nb, u32 cap,
-                     DfBlock *blocks, u8 *lens, u32 *hdr, u32 *lm_scratch, u64 *total_bits, u32 dl0, u32 last_is_final)
+int df_launch_cuts(hipStream_t st, u64 n, u64 *bm, u64 *bstart, u32 *nb, u32 cap, u32 dl0)
 {
     hipLaunchKernelGGL(k_df_cuts, dim3(1), dim3(256), 0, st, bm, n, bstart, nb, cap, dl0);
+    return 0;
+}
+
+int df_launch_blocks(hipStream_t st, const u8 *in, const u32 *code, u64 *bstart, u32 *nb, u32 cap,
+                     DfBlock *blocks, u8 *lens, u32 *hdr, u32 *lm_scratch, u64 *total_bits, u32 dl0, u32 last_is_final, u32 bit0)
+{
     hipLaunchKernelGGL(k_df_block, dim3(cap), dim3(kBThreads), 0, st, in, code, bstart, nb, blocks, lens, hdr, lm_scratch, dl0,
                        last_is_final);
-    hipLaunchKernelGGL(k_df_offsets, dim3(1), dim3(256), 0, st, blocks, nb, total_bits);
+    hipLaunchKernelGGL(k_df_offsets, dim3(1), dim3(256), 0, st, blocks, nb, total_bits, bit0);
     return 0;
 }
 

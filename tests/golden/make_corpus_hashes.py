@@ -8,8 +8,8 @@ oracle/deflate_oracle.c; single thread, one serial stream each).
     python3 tests/golden/make_corpus_hashes.py [--only KEY[,KEY...]] [--jobs N]
 
 Entries (key -> corpus):  bzip2_l9_text_<N>gib (N = 1, 2, 4, 8: corpus.corpus_bytes(N GiB), the stream of
-bench.py --gpus N), bzip2_l9_text_64mib, bzip2_l9_t2_1gib, deflate_text_1gib, deflate_text_64mib
-(raw Deflate; zlib / gzip wrap the same bits)."""
+bench.py --gpus N), bzip2_l9_text_64mib, bzip2_l9_t2_1gib, deflate_text_1gib, deflate_text_64mib, deflate_text_2gib
+(raw Deflate; zlib / gzip wrap the same bits; 2 GiB: more than one call of the GPU path handles in one part)."""
 import argparse
 import hashlib
 import json
@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tests", "golden", "corpus_hashes.json")
 
 KEYS = ["bzip2_l9_text_64mib", "deflate_text_64mib", "bzip2_l9_text_1gib", "deflate_text_1gib", "bzip2_l9_t2_1gib",
-        "bzip2_l9_text_2gib", "bzip2_l9_text_4gib", "bzip2_l9_text_8gib"]
+        "bzip2_l9_text_2gib", "bzip2_l9_text_4gib", "bzip2_l9_text_8gib", "deflate_text_2gib"]
 
 
 def make(key):

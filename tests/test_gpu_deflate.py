@@ -259,3 +259,47 @@ def test_flush_refused_for_containers_before_input_is_pulled(pkg):
     assert bytes(it) == b"hello world"  # the caller's iterator is untouched
     with pytest.raises(pkg.CompressionError):
         pkg.GZipEncoder().end(pkg.Action.FLUSH)
+
+
+def test_long_streams_in_parts(oracle):
+    """A segment longer than BZ_DF_PART_MIB (default 1 GiB; 1 MiB here, read once per process) is encoded in
+    parts: each but the last with look-ahead, keeping the blocks that cannot change, the next one starting at
+    the first block left out, inside the byte the previous one ended in.  Same bytes as one pass (oracle)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import importlib, random, sys, zlib
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+pkg = importlib.import_module("rust-compression_amd")
+from oracle import oracle
+from conftest import sample
+rng = random.Random(3)
+text = (sample(1) + sample(2)) * 8
+noise = bytes(rng.randrange(256) for _ in range(1 << 20))
+inputs = {
+    "text": text[:5_500_000],
+    "zeros": b"\0" * 3_300_000,
+    "noise_text": noise + text[:1_500_000] + noise[:700_000] + text[:900_000],
+    "just_over": text[:(1 << 20) + 0x10000 + 1025],
+    "exactly_guard": text[:(1 << 20) + 0x10000 + 1024],
+}
+for name, d in inputs.items():
+    for kind in (0, 1, 2):
+        got = pkg.deflate_compress(d, kind)
+        assert got == oracle.deflate_encode(d, kind), (name, kind, len(got))
+    assert zlib.decompress(pkg.deflate_compress(d, 1)) == d, name
+d = inputs["text"]
+assert pkg.deflate_compress(d[100000:], 0, dict_=d[:100000]) == oracle.deflate_encode(d[100000:], 0, d[:100000])
+# flushed segments that are themselves longer than a part
+A = pkg.Action
+enc, ref = pkg.Inflater(), oracle.DeflateEncoder()
+got = bytearray()
+for piece, act in [(d[:2_600_000], A.FLUSH), (d[2_600_000:2_600_010], A.FLUSH), (d[2_600_010:], A.FINISH)]:
+    enc.write(piece); enc.end(act); got += enc.read_all(); ref.feed(piece, int(act))
+assert bytes(got) == ref.output()
+print("ok")
+''' % (ROOT, ROOT)
+    e = dict(os.environ, BZ_DF_PART_MIB="1")
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-500:] + out.stderr[-3000:]
