@@ -351,8 +351,8 @@ void bz_dec_destroy(bz_dec *d);
  * Action::Flush inside a stream is offered for Inflater through the streaming context (df_enc_end):
  * the stream becomes a sequence of byte-aligned segments (src/deflate/encoder.rs:170-195, :227-235,
  * :638-647).  Not offered (refused with BZ_E_PARAM, never approximated): Action::Flush on the zlib /
- * gzip wrappers (they end their container at the first None, src/zlib/encoder.rs:131-151), and more than
- * 2 GiB in one call or segment.
+ * gzip wrappers (they end their container at the first None, src/zlib/encoder.rs:131-151).  Inputs of
+ * any length: a call works through a long segment in parts of BZ_DF_PART_MIB (default 1024) MiB.
  * ======================================================================== */
 #define DF_KIND_DEFLATE 0
 #define DF_KIND_ZLIB 1

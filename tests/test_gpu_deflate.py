@@ -303,3 +303,25 @@ print("ok")
     e = dict(os.environ, BZ_DF_PART_MIB="1")
     out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-500:] + out.stderr[-3000:]
+
+
+def test_two_gib_stream_equals_oracle_golden(pkg, eng):
+    """2 GiB of the bench corpus through df_gpu_encode_device: more positions than one part holds (1 GiB +
+    look-ahead), i.e. two parts with a bit-level seam; SHA-256 and length against the oracle's stream
+    (tests/golden/corpus_hashes.json, made by tests/golden/make_corpus_hashes.py)."""
+    import hashlib
+    import torch
+    import corpus
+    gold = json.load(open(os.path.join(GOLDEN, "corpus_hashes.json"))).get("deflate_text_2gib")
+    if gold is None:
+        pytest.skip("no golden hash for the 2 GiB Deflate stream")
+    n = 2 << 30
+    d_in = corpus.corpus_on_device(n, torch.device("cuda", 0))
+    cap = (pkg.lib().df_encode_bound(n) + 15) & ~15
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    k = eng.deflate_encode_device(pkg.DEFLATE, d_in.data_ptr(), n, d_out.data_ptr(), cap)
+    assert k == gold["bytes"]
+    h = hashlib.sha256()
+    for off in range(0, k, 256 << 20):
+        h.update(bytes(d_out[off:min(k, off + (256 << 20))].cpu().numpy()))
+    assert h.hexdigest() == gold["sha256"]
