@@ -427,10 +427,13 @@ static int job_split(bz_enc *e, const EncJob &j, int lane, JobState &js)
         int rc = grow(&r->d_buf[lane], &r->d_buf_cap[lane], js.n_all + 64);
         if (rc != BZ_OK) return rc;
         hipStream_t st = r->st_io[lane];
-        if (e->tail_len && !(e->tail_lane == lane && e->tail_off == 0) &&
+        // (consecutive jobs run on different lanes, so the tail always comes from the other lane's buffer; that job
+        // may still be encoding -- it only reads its RLE1 image by then)
+        if (e->tail_len && e->tail_lane == lane) return BZ_E_UNEXPECTED;
+        if (e->tail_len &&
             hipMemcpyAsync(r->d_buf[lane], (const u8 *)r->d_buf[e->tail_lane] + e->tail_off, e->tail_len,
                            hipMemcpyDeviceToDevice, st) != hipSuccess)
-            return BZ_E_UNEXPECTED; // (same lane: forward move by tail_off >= tail_len is not guaranteed -- see below)
+            return BZ_E_UNEXPECTED;
         if (j.n) {
             if (hipStreamWaitEvent(st, r->ev_up[j.slot], 0) != hipSuccess) return BZ_E_UNEXPECTED;
             if (hipMemcpyAsync((u8 *)r->d_buf[lane] + e->tail_len, r->d_stage[j.slot], j.n, hipMemcpyDeviceToDevice, st) !=
