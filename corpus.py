@@ -106,7 +106,11 @@ def corpus_on_device(total_bytes, device, first_chapter=0):
         parts.append(ch.repeat(reps)[:want])
         done += want
         g += 1
-    return parts[0] if len(parts) == 1 else torch.cat(parts)
+    out = parts[0] if len(parts) == 1 else torch.cat(parts)
+    # The engines run on their own streams: the corpus must be complete -- and the pieces it was made of back in
+    # torch's allocator for good -- before a pointer to it (or to a buffer allocated after it) is handed to one.
+    torch.cuda.synchronize(device)
+    return out
 
 
 def stress_t2(total_bytes):

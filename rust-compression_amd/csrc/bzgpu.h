@@ -231,6 +231,8 @@ struct BwtArgs {
     unsigned long long *active;      // [64] per-round count of non-final rotations in unfinished blocks
     u32 *per_k, *per_shift;          // [nb] periodic blocks: repetition count, least-rotation start
     u32 *bin_cursor;                 // [nb][1024] rank words binned so far (k_group_apply -> k_rank_place)
+    u32 *pb_gate;                    // [nb] != 0: phase B of the init by the global passes (0: k_phase_b_local did it)
+    u32 *loc_stats;                  // [4] k_phase_b_local: segments, overflows, segments out of order, LDS passes
     u8 *L;                           // [nb * kSlot] last column, written as rotations become final
     u32 *orig_ptr;                   // [nb] position of rotation 0 in the sorted order
     const u8 *sym_code;              // [nb][256] byte -> code (rank among the bytes in use)
@@ -378,6 +380,7 @@ enum KernelId {
     KID_GHIST_TEXT,       // the three digit counts of a phase, one read of the text
     KID_GHIST_SCAN,
     KID_RANK_PLACE,       // binned rank words -> the rank array, whole lines
+    KID_PHASE_B_LOCAL,    // phase B of the init inside LDS
     // decode path (k_dec.hip)
     KID_DEC_BLOCK,   // header + Huffman
     KID_DEC_MTF,     // chunk_perm + compose + chunk_emit

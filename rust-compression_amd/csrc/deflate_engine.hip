@@ -83,15 +83,21 @@ struct DfSeg {
     // A PART of a long segment (one call handles < 2 GiB of positions): `more` = the input goes on behind
     // d_in[n) without a flush, and the n bytes handed in include look-ahead: only the blocks whose cuts and
     // codes cannot change with the bytes behind d_in[n) are written, *consumed tells where the next part
-    // starts (a block start, so a code start: the parse from there is the same parse).  bit0 / carry_byte:
-    // the bits (0..7) of the output's first byte that the previous part has already filled.
+    // starts: at the STEP of the LZSS parse that holds the first block left out.  A block starts at a code,
+    // but a step of the parse (lzss/encoder.rs:132-184) can emit one or two literals and then a reference, and
+    // a block may be cut between them; the parse can only be taken up at the step's first byte, where the
+    // decision was made.  skip = the literals of that step (0..2 bytes) that went out with the part before: the
+    // first block of this part starts behind them.  bit0 / carry_byte: the bits (0..7) of the output's first
+    // byte that the previous part has already filled.
     bool more = false;
+    u32 skip = 0;
     u32 bit0 = 0;
     u8 carry_byte = 0;
     bool accumulate_stats = false;
 };
 struct DfPartOut {
-    u64 consumed = 0;   // input bytes of the part that went into written blocks
+    u64 consumed = 0;   // where the next part starts (the step that holds the first block left out)
+    u32 skip = 0;       // bytes behind it that are already written (that step's literals)
     u32 end_bits = 0;   // bits (0..7) filled in the byte behind the bytes returned (more == true)
     u8 end_byte = 0;
 };
@@ -190,8 +196,10 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     HIPCHK(hipEventRecord(w->ev[2], st));
     if (df_launch_parse(st, M, n, step, tabs.data(), ents.data(), counts.data(), nlevels, code, w->bitmap.as<u64>()) != 0) return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[3], st));
-    if (df_launch_cuts(st, n, w->bitmap.as<u64>(), w->bstart.as<u64>(), w->nb.as<u32>(), bcap, seg.dl0) != 0) return BZ_E_UNEXPECTED;
+    if (seg.skip > 2 || (seg.skip && seg.dl0)) return BZ_E_PARAM;
+    if (df_launch_cuts(st, n, w->bitmap.as<u64>(), w->bstart.as<u64>(), w->nb.as<u32>(), bcap, seg.dl0, seg.skip) != 0) return BZ_E_UNEXPECTED;
     u64 consumed = n;
+    u32 next_skip = 0;
     if (seg.more) {
         // keep the blocks that START at or before n - guard: their ends (cuts) and codes are final
         u32 nb_all = 0;
@@ -203,7 +211,14 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
         u32 keep = 0;
         while (keep < nb_all && hb[keep] + kPartGuard <= n) ++keep; // block `keep`-1 is the last one kept
         if (keep == 0 || keep >= nb_all) return BZ_E_UNEXPECTED;       // (a part is much longer than the guard)
-        consumed = hb[keep];
+        // the step of the parse that emitted the code at hb[keep]: at most two literals in front of it
+        const u64 bcut = hb[keep];
+        if (bcut < 2) return BZ_E_UNEXPECTED;
+        u32 cw[3] = {0, 0, 0};
+        HIPCHK(hipMemcpy(cw, code + (bcut - 2), sizeof(cw), hipMemcpyDeviceToHost));
+        next_skip = (cw[2] & F_STEP) ? 0u : ((cw[1] & F_STEP) ? 1u : 2u);
+        if (!(cw[2 - next_skip] & F_STEP) || !(cw[2] & F_CODE)) return BZ_E_UNEXPECTED;
+        consumed = bcut - next_skip;
         HIPCHK(hipMemcpyAsync(w->nb.p, &keep, 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st)); // (`keep` lives on this stack frame)
     }
@@ -236,6 +251,7 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     const u64 body = seg.more ? (total_bits >> 3) : ((total_bits + 7) >> 3);
     if (part_out) {
         part_out->consumed = consumed;
+        part_out->skip = next_skip;
         part_out->end_bits = seg.more ? (u32)(total_bits & 7u) : 0u;
         part_out->end_byte = 0;
         HIPCHK(hipStreamSynchronize(st));
@@ -377,10 +393,17 @@ static int df_encode_parts(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, co
         const int rc = df_encode_core(g, kind, d_in + pos, len, dict, dict_len, d_out ? d_out + written : nullptr,
                                       d_out ? cap - written : 0, &got, seg, last ? dl_out : nullptr, &po);
         if (rc != BZ_OK) return rc;
+        static const bool trace = getenv("BZ_DF_TRACE") != nullptr;
+        if (trace)
+            fprintf(stderr, "bz2_mi355x: deflate part %u: input [%llu, +%llu) of %llu, kept %llu bytes of it, %zu stream bytes, "
+                            "%u bits handed on, %llu blocks\n", k, (unsigned long long)pos, (unsigned long long)len,
+                    (unsigned long long)n, (unsigned long long)(last ? len : po.consumed), got, last ? 0u : po.end_bits,
+                    (unsigned long long)g->df->h_blocks.size());
         written += got;
         *out_len = written;
         if (last) return BZ_OK;
         pos += po.consumed;
+        seg.skip = po.skip;
         seg.bit0 = po.end_bits;
         seg.carry_byte = po.end_byte;
     }

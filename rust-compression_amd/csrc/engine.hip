@@ -82,6 +82,8 @@ static int ensure_workspace(bz_gpu_engine *g, size_t need_blocks)
     ENS(per_k, nb * 4);
     ENS(per_shift, nb * 4);
     ENS(bin_cursor, nb * (size_t)1024 * 4);
+    ENS(pb_gate, nb * (size_t)4 + 64);
+    if (hipMemset(g->pb_gate.p, 0, g->pb_gate.cap) != hipSuccess) return BZ_E_UNEXPECTED;
     ENS(L, nb * (size_t)kSlot + 64);
     ENS(orig_ptr, nb * 4);
     ENS(inuse_bits, nb * 32);
@@ -177,7 +179,7 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
     DevBuf *all[] = {&g->crc_tab, &g->xp16, &g->xp2, &g->tile_last, &g->carry_in, &g->tile_crc, &g->tile_count,
                      &g->tile_off, &g->sub_off, &g->sub_rs, &g->scal, &g->rle, &g->blocks_all, &g->crc_all, &g->lblocks, &g->lcrc, &g->SA,
                      &g->R, &g->KA, &g->VA, &g->KB, &g->VB, &g->tile_hist, &g->count, &g->flags, &g->tlo, &g->tln,
-                     &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->bin_cursor, &g->bin_base, &g->sym_code, &g->keyinfo, &g->count2, &g->tile_nf, &g->L, &g->orig_ptr, &g->inuse_bits,
+                     &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->bin_cursor, &g->pb_gate, &g->bin_base, &g->sym_code, &g->keyinfo, &g->count2, &g->tile_nf, &g->L, &g->orig_ptr, &g->inuse_bits,
                      &g->summ, &g->summ_len, &g->init_state, &g->rank8, &g->ztile_last, &g->ztile_cnt, &g->mtf,
                      &g->mtf_freq, &g->bout, &g->selector, &g->code_len, &g->group_bitoff, &g->lm_scratch,
                      &g->stream, &g->error_flag, &g->packlist, &g->packed, &g->gathered, &g->asmlist, &g->gh_tiles, &g->gbase, &g->tile_state,
@@ -368,6 +370,8 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
     x.per_k = g->per_k.as<u32>() + o;
     x.per_shift = g->per_shift.as<u32>() + o;
     x.bin_cursor = g->bin_cursor.as<u32>() + (size_t)o * 1024;
+    x.pb_gate = g->pb_gate.as<u32>() + o;
+    x.loc_stats = g->pb_gate.as<u32>() + g->ws_blocks; // (behind the gates)
     x.L = g->L.as<u8>() + s;
     x.orig_ptr = g->orig_ptr.as<u32>() + o;
     x.sym_code = g->sym_code.as<u8>() + (size_t)o * 256;
@@ -968,7 +972,7 @@ extern "C" int bz_gpu_debug_code_lengths(bz_gpu_engine *g, const uint32_t *h_fre
 
 static const char *kKernelNames[KID_COUNT] = {"k_radix_hist", "k_radix_scan", "k_radix_scatter",
                                               "k_group_flags", "k_group_apply", "k_last_column",
-                                              "k_radix_scatter_lb", "k_ghist_text", "k_ghist_scan", "k_rank_place",
+                                              "k_radix_scatter_lb", "k_ghist_text", "k_ghist_scan", "k_rank_place", "k_phase_b_local",
                                               "k_dec_block", "k_dec_mtf", "k_dec_tsort", "k_dec_walk_lengths",
                                               "k_dec_place", "k_dec_rle", "k_dec_crc"};
 

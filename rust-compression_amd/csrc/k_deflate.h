@@ -41,6 +41,8 @@ constexpr u32 kDfLmWords = 2 * kDfLmTable;
 constexpr u32 kSumPiece = 65536;   // bytes per checksum piece
 constexpr u32 F_CODE = 0x80000000u; // code[q]: an LZSS code starts at q
 constexpr u32 F_REF = 0x40000000u;  //          it is a reference: len | (dist - 1) << 9
+constexpr u32 F_STEP = 0x20000000u; //          a step of the LZSS parse starts at q (lzss/encoder.rs:132-184: a step emits up
+                                    //          to two literals and then a reference; only its first code is a step start)
 
 struct DfBlock {
     u32 btype;     // 0 stored, 1 fixed, 2 dynamic
@@ -62,7 +64,7 @@ int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *
 // own launch so that the host can drop the blocks at the end of a PART of a long stream (those whose cuts could
 // still change with the input behind the part) before tables and offsets are made; bit0: the first block starts
 // at this bit (0..7) of the output's first byte.
-int df_launch_cuts(hipStream_t st, u64 n, u64 *bm, u64 *bstart, u32 *nb, u32 cap, u32 dl0);
+int df_launch_cuts(hipStream_t st, u64 n, u64 *bm, u64 *bstart, u32 *nb, u32 cap, u32 dl0, u32 first);
 int df_launch_blocks(hipStream_t st, const u8 *in, const u32 *code, u64 *bstart, u32 *nb, u32 cap,
                      DfBlock *blocks, u8 *lens, u32 *hdr, u32 *lm_scratch, u64 *total_bits, u32 dl0, u32 last_is_final, u32 bit0);
 int df_launch_emit(hipStream_t st, const u8 *in, const u32 *code, const u64 *bstart, const u32 *nb, u32 cap,

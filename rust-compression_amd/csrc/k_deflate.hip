@@ -573,10 +573,12 @@ __global__ __launch_bounds__(kMarkThreads) void k_df_mark(const u16 *__restrict_
     for (u32 k = tid; k < kPTile; k += kMarkThreads) {
         if (!s_mark[k]) continue;
         const u32 s = s_step[k], adv = s & 511u, li = s >> 9;
-        if (adv == 1) s_type[k] = 1;
+        // (4: a step of the parse starts here -- with li > 0 the step's reference is a code start that is not one)
+        if (adv == 1) s_type[k] = 1 | 4;
         else {
             for (u32 i = 0; i < li; ++i) s_type[k + i] = 1;
             s_type[k + li] = 2;
+            s_type[k] |= 4;
         }
     }
     __syncthreads();
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(kMarkThreads) void k_df_mark(const u16 *__restrict_
         const u64 q = t0 + k;
         const bool ok = k < exitp && q < n;
         const u32 ty = ok ? s_type[k] : 0u;
-        if (ok) code[q] = ty == 0 ? 0u : (ty == 1 ? F_CODE : (F_CODE | F_REF | M[q]));
+        if (ok) code[q] = ty == 0 ? 0u : (((ty & 3u) == 1 ? F_CODE : (F_CODE | F_REF | M[q])) | ((ty & 4u) ? F_STEP : 0u));
         const u64 bal = __ballot(ty != 0);
         if ((tid & 63u) == 0 && bal) {
             const u64 q0 = t0 + k0;
@@ -605,15 +607,17 @@ constexpr u32 kCutWords = (257 * kCutGroup + 64) / 64 + 3;
 // dl0: InflaterInner.decompress_len at the segment's first code (not 0 behind an Action::Flush, which closes a
 // block without resetting it, :638-647 against :585-593): the first block then counts as having started dl0
 // bytes in front of the segment -- the chain starts at the (negative) position -dl0.
+// first: the first block starts at this code start (not 0 when a part of a long stream begins with the literals of a
+// step whose reference opens its first block; they went out with the part before).
 __global__ __launch_bounds__(256) void k_df_cuts(const u64 *__restrict__ bm, u64 n, u64 *__restrict__ bstart,
-                                                 u32 *__restrict__ nb_out, u32 cap, u32 dl0)
+                                                 u32 *__restrict__ nb_out, u32 cap, u32 dl0, u32 first)
 {
     __shared__ u64 s_bm[kCutGroup][kCutWords];
     __shared__ i64 s_b;
     __shared__ u32 s_k, s_done;
     const u32 tid = threadIdx.x;
     const u64 nwords = (n + 63) / 64;
-    if (tid == 0) { s_b = -(i64)dl0; s_k = 0; s_done = 0; if (cap) bstart[0] = 0; }
+    if (tid == 0) { s_b = (i64)first - (i64)dl0; s_k = 0; s_done = 0; if (cap) bstart[0] = first; }
     __syncthreads();
     for (;;) {
         const i64 b = s_b;
@@ -1310,9 +1314,9 @@ int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *
     return 0;
 }
 
-int df_launch_cuts(hipStream_t st, u64 n, u64 *bm, u64 *bstart, u32 *nb, u32 cap, u32 dl0)
+int df_launch_cuts(hipStream_t st, u64 n, u64 *bm, u64 *bstart, u32 *nb, u32 cap, u32 dl0, u32 first)
 {
-    hipLaunchKernelGGL(k_df_cuts, dim3(1), dim3(256), 0, st, bm, n, bstart, nb, cap, dl0);
+    hipLaunchKernelGGL(k_df_cuts, dim3(1), dim3(256), 0, st, bm, n, bstart, nb, cap, dl0, first);
     return 0;
 }
 

@@ -11,7 +11,7 @@ import zlib
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, sample
+from conftest import GOLDEN, ROOT, sample
 from test_oracle_deflate import VEC, expand, pack_lsb
 
 pytestmark = pytest.mark.gpu
@@ -305,6 +305,26 @@ print("ok")
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-500:] + out.stderr[-3000:]
 
 
+@pytest.mark.parametrize("part_mib", [2, 3])
+def test_many_part_seams_equal_oracle_golden(part_mib):
+    """64 MiB of the bench corpus in parts of 2 / 3 MiB: some thirty seams, several of them at a block that starts
+    between the literals and the reference of one step of the lazy parse (the next part then has to take the
+    parse up at the step, not at the block).  SHA-256 against the oracle's stream (corpus_hashes.json)."""
+    import subprocess
+    import sys
+    gold = json.load(open(os.path.join(GOLDEN, "corpus_hashes.json")))["deflate_text_64mib"]
+    code = (
+        "import importlib,sys,hashlib;sys.path.insert(0,%r);pkg=importlib.import_module('rust-compression_amd');"
+        "import torch,corpus;n=64<<20;eng=pkg.GpuEngine(0,1);d=corpus.corpus_on_device(n,torch.device('cuda',0));"
+        "cap=(pkg.lib().df_encode_bound(n)+15)&~15;o=torch.empty(cap,dtype=torch.uint8,device='cuda');torch.cuda.synchronize();"
+        "k=eng.deflate_encode_device(pkg.DEFLATE,d.data_ptr(),n,o.data_ptr(),cap);"
+        "print(k,hashlib.sha256(bytes(o[:k].cpu().numpy())).hexdigest())" % ROOT)
+    e = dict(os.environ, BZ_DF_PART_MIB=str(part_mib))
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "%d %s" % (gold["bytes"], gold["sha256"]), out.stdout[-300:]
+
+
 def test_two_gib_stream_equals_oracle_golden(pkg, eng):
     """2 GiB of the bench corpus through df_gpu_encode_device: more positions than one part holds (1 GiB +
     look-ahead), i.e. two parts with a bit-level seam; SHA-256 and length against the oracle's stream
@@ -319,6 +339,7 @@ def test_two_gib_stream_equals_oracle_golden(pkg, eng):
     d_in = corpus.corpus_on_device(n, torch.device("cuda", 0))
     cap = (pkg.lib().df_encode_bound(n) + 15) & ~15
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
     k = eng.deflate_encode_device(pkg.DEFLATE, d_in.data_ptr(), n, d_out.data_ptr(), cap)
     assert k == gold["bytes"]
     h = hashlib.sha256()

@@ -342,6 +342,36 @@ def test_radix_pass_flavours_agree(oracle):
             assert "batch sorted again" in out.stderr
 
 
+def test_phase_b_in_lds_flavour(oracle):
+    """BZ_LOCAL_B=1: the second half of the initial sort is done segment by segment inside LDS (k_phase_b_local)
+    for the blocks that fit; blocks with a group of equal prefixes too long for a segment (the runs of "ab"
+    below), or with more than 128 symbols, take the global passes in the same batch.  Same streams."""
+    import subprocess
+    import sys
+    code = (
+        "import importlib,sys,hashlib;sys.path.insert(0,%r);pkg=importlib.import_module('rust-compression_amd');"
+        "import corpus;t=corpus.corpus_bytes(1<<21);"
+        "d=t[:1200000]+b'ab'*150000+t[1200000:1500000]+bytes(range(256))*300+t[1500000:];"
+        "print(hashlib.sha256(pkg.compress(d,9)).hexdigest(), hashlib.sha256(pkg.compress(d,2)).hexdigest())" % ROOT)
+    import corpus
+    t = corpus.corpus_bytes(1 << 21)
+    d = t[:1200000] + b"ab" * 150000 + t[1200000:1500000] + bytes(range(256)) * 300 + t[1500000:]
+    want = "%s %s" % (hashlib.sha256(oracle.encode(d, 9)).hexdigest(), hashlib.sha256(oracle.encode(d, 2)).hexdigest())
+    e = dict(os.environ)
+    e.update({"BZ_LOCAL_B": "1", "BZ_LOCAL_TRACE": "1"})
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == want, (out.stdout, out.stderr[-800:])
+    lines = [ln for ln in out.stderr.splitlines() if "phase B in LDS" in ln]
+    assert lines, out.stderr[-800:]
+    import re
+    seen = [tuple(int(x) for x in re.search(r"(\d+) segments so far \((\d+) too long, (\d+) out of order", ln).groups())
+            for ln in lines]
+    assert seen[-1][0] > 0 and seen[-1][1] > 0 and seen[-1][2] == 0, seen  # segments sorted, some refused, none unstable
+    gated = [tuple(int(x) for x in re.search(r"(\d+) of (\d+) blocks", ln).groups()) for ln in lines]
+    assert any(0 < g < nb for g, nb in gated), gated  # a batch with both kinds of block
+
+
 def test_pass_counter_wraps(pkg, oracle):
     """one engine, enough sorts for the fused passes' epoch tag (1023 values) to wrap several times"""
     import torch

@@ -1,13 +1,2 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2x
-timeout 900 python3 bench.py --gpus 2 --share-gpu --mib-per-gpu 256 --steps 2 --warmup 1 > gpurun_out/r2x/bench2.json 2> gpurun_out/r2x/bench2.err
-tail -3 gpurun_out/r2x/bench2.err
-python3 -c "
-import json
-line=[l for l in open('gpurun_out/r2x/bench2.json') if l.startswith('{')][-1]
-d=json.loads(line); print(d['value'], d['n_gpus'], d['checks'], d.get('extra'))"
-timeout 900 python3 bench.py --gpus 3 --share-gpu --mib-per-gpu 128 --steps 1 --warmup 1 > gpurun_out/r2x/bench3.json 2> gpurun_out/r2x/bench3.err
-python3 -c "
-import json
-line=[l for l in open('gpurun_out/r2x/bench3.json') if l.startswith('{')][-1]
-d=json.loads(line); print(d['value'], d['n_gpus'], d['checks'], d.get('extra'))"
+timeout 1500 python3 -m pytest tests/test_gpu_deflate.py -x -q -m gpu -k "seams or two_gib or parts" 2>&1 | tail -8
