@@ -14,6 +14,13 @@
  * any signature; device pointers are `void*`/`const void*` and a HIP stream is
  * an opaque `void*` (0 = the engine's own stream).
  *
+ * Stream ordering: an engine launches its kernels on its OWN HIP stream, and every device-pointer
+ * call returns after that stream has drained.  The caller makes sure that the input behind a device
+ * pointer is complete before the call (synchronise the stream that produced it), and does not hand
+ * the engine a buffer that a stream-ordered allocator may still be reading on another stream (a
+ * PyTorch tensor allocated right after asynchronous work that freed its inputs is such a buffer:
+ * torch.cuda.synchronize() first).
+ *
  * Results are bit-identical to the reference encoder (checked against the CPU
  * oracle in oracle/).  There is NO CPU fallback: without a gfx950 device every
  * compute entry point returns BZ_E_NOGPU.

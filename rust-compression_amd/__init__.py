@@ -22,6 +22,7 @@ for device memory (tensor.data_ptr()); nothing here imports torch.
 import ctypes as C
 import enum
 import os
+import sys
 
 from . import _build
 
@@ -212,6 +213,15 @@ def lib():
 def _check(rc):
     if rc != BZ_OK:
         raise CompressionError(rc)
+
+
+def _settle():
+    """Before a device-pointer call: an engine runs on its own HIP stream, the pointers handed in here usually
+    belong to torch tensors whose contents (or whose memory, with torch's stream-ordered allocator) may still be
+    in use by work queued on torch's streams.  Waits for that work (include/bz2_mi355x.h, "Stream ordering")."""
+    t = sys.modules.get("torch")
+    if t is not None and t.cuda.is_available() and t.cuda.is_initialized():
+        t.cuda.synchronize()
 
 
 _RCCL_LIB = None
@@ -628,11 +638,13 @@ class GpuEngine:
     __del__ = close
 
     def encode_device(self, level, d_in, n, d_out, cap):
+        _settle()
         out_len = C.c_size_t(0)
         _check(lib().bz_gpu_encode_device(self._h, level, d_in, n, d_out, cap, C.byref(out_len)))
         return out_len.value
 
     def partition(self, level, d_in, n, mode=Action.FINISH):
+        _settle()
         nb, cons, tail = C.c_size_t(0), C.c_size_t(0), C.c_int(0)
         _check(lib().bz_gpu_partition(self._h, level, d_in, n, int(mode), C.byref(nb), C.byref(cons), C.byref(tail)))
         return nb.value, cons.value, tail.value
@@ -640,6 +652,7 @@ class GpuEngine:
     TILE = 4096  # input bytes per split tile
 
     def slab_begin(self, level, d_in, n, tile0, tile1):
+        _settle()
         last = C.c_int64(-1)
         _check(lib().bz_gpu_partition_slab_begin(self._h, level, d_in, n, tile0, tile1, C.byref(last)))
         return last.value
@@ -653,6 +666,7 @@ class GpuEngine:
         return nb.value, nxt.value, tail.value
 
     def encode_blocks(self, first, stride, n_blocks, d_packed, cap_words):
+        _settle()
         # the library writes one entry per block of ITS last partition: size the arrays from that count
         have = lib().bz_gpu_block_count(self._h)
         if n_blocks != have:
@@ -667,6 +681,7 @@ class GpuEngine:
 
     def assemble(self, level, d_packed, word_off, bit_len, crc, d_out, cap, header=True, trailer=True, pad=True,
                  carry_bits=0, carry_byte=0, combined_crc=0):
+        _settle()
         k = len(word_off)
         woff = (C.c_uint64 * max(k, 1))(*word_off)
         blen = (C.c_uint64 * max(k, 1))(*bit_len)
@@ -682,6 +697,7 @@ class GpuEngine:
         """One rank of a multi-GPU encode (bz_gpu_encode_sharded).  `comm` carries a `struct` attribute
         holding a bz_shard_comm (sharded.TorchComm).  packed / gather: optional (pointer, words)
         device buffers for this rank's bit strings / everybody's on rank 0.  -> stream bytes (0 on ranks > 0)."""
+        _settle()
         out_len = C.c_size_t(0)
         pp, pw = packed if packed else (None, 0)
         gp, gw = gather if gather else (None, 0)
@@ -693,6 +709,7 @@ class GpuEngine:
 
     def decode_device(self, d_in, n, d_out, cap):
         """-> (bytes decoded, verdict).  d_out = None: sizes only."""
+        _settle()
         out_len = C.c_size_t(0)
         rc = lib().bz_gpu_decode_device(self._h, d_in, n, d_out, cap, C.byref(out_len))
         if rc != BZ_OK and rc not in _DECODER_VERDICTS:
@@ -703,6 +720,7 @@ class GpuEngine:
         """One rank of a multi-GPU decode.  `allgather(send: bytes) -> bytes` returns the concatenation of
         every rank's `send`, in rank order (sharded.allgather_bytes wraps torch.distributed).
         -> (bytes in this rank's slice, offset of the slice in the decoded file, total bytes, verdict)"""
+        _settle()
         def cb(_ctx, send, nbytes, recv):
             try:
                 got = allgather(C.string_at(send, nbytes))
@@ -723,6 +741,7 @@ class GpuEngine:
     DEFLATE_STAGES = ("hash_chains", "matches", "parse", "blocks_tables", "emit_checksums", "total")
 
     def deflate_encode_device(self, kind, d_in, n, d_out, cap, dict_=b""):
+        _settle()
         out_len = C.c_size_t(0)
         dict_ = bytes(dict_)
         _check(lib().df_gpu_encode_device_dict(self._h, kind, d_in, n, dict_, len(dict_), d_out, cap, C.byref(out_len)))
