@@ -177,7 +177,7 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
     (void)hipStreamSynchronize(g->st);
     (void)hipStreamSynchronize(g->st2);
     DevBuf *all[] = {&g->crc_tab, &g->xp16, &g->xp2, &g->tile_last, &g->carry_in, &g->tile_crc, &g->tile_count,
-                     &g->tile_off, &g->sub_off, &g->sub_rs, &g->scal, &g->rle, &g->blocks_all, &g->crc_all, &g->lblocks, &g->lcrc, &g->SA,
+                     &g->tile_off, &g->sub_off, &g->sub_rs, &g->scal, &g->scan_part, &g->rle, &g->blocks_all, &g->crc_all, &g->lblocks, &g->lcrc, &g->SA,
                      &g->R, &g->KA, &g->VA, &g->KB, &g->VB, &g->tile_hist, &g->count, &g->flags, &g->tlo, &g->tln,
                      &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->bin_cursor, &g->pb_gate, &g->bin_base, &g->sym_code, &g->keyinfo, &g->count2, &g->tile_nf, &g->L, &g->orig_ptr, &g->inuse_bits,
                      &g->summ, &g->summ_len, &g->init_state, &g->rank8, &g->ztile_last, &g->ztile_cnt, &g->mtf,
@@ -205,6 +205,7 @@ static RleBuffers rle_buffers(bz_gpu_engine *g)
     rb.sub_rs = g->sub_rs.as<i64>();
     rb.total = g->scal.as<u64>();
     rb.cut_result = g->scal.as<u64>() + 2;
+    rb.scan_part = g->scan_part.as<u64>();
     return rb;
 }
 
@@ -234,7 +235,8 @@ extern "C" int bz_gpu_partition_slab_begin(bz_gpu_engine *g, int level, const vo
     if ((rc = g->tile_last.ensure(ntiles * 8)) || (rc = g->carry_in.ensure(ntiles * 8)) ||
         (rc = g->tile_crc.ensure(ntiles * 4)) || (rc = g->tile_count.ensure(ntiles * 4)) ||
         (rc = g->tile_off.ensure((ntiles + 1) * 8)) || (rc = g->sub_off.ensure(ntiles * 32)) ||
-        (rc = g->sub_rs.ensure(ntiles * 128)) || (rc = g->scal.ensure(128)))
+        (rc = g->sub_rs.ensure(ntiles * 128)) || (rc = g->scal.ensure(128)) ||
+        (rc = g->scan_part.ensure((ntiles / 1024 + 2) * 8)))
         return rc;
     const RleBuffers rb = rle_buffers(g);
     const int sp = span_begin(g, 0);
@@ -300,10 +302,12 @@ extern "C" int bz_gpu_partition_slab_finish(bz_gpu_engine *g, uint64_t start_in,
     if ((rc = g->rle.ensure(total + 256)) || (rc = g->blocks_all.ensure(max_blocks * sizeof(BlockDesc))) ||
         (rc = g->crc_all.ensure(max_blocks * 4)))
         return rc;
-    launch_rle_finish(g->st, g->d_in, n, tb, t1, start_in, rb, g->rle.as<u8>(), block_max_len, is_last ? 1 : 0,
+    // (everything the cuts read is complete: the host has just waited for g->st; g->st2 is idle between calls)
+    launch_rle_finish(g->st, g->st2, g->d_in, n, tb, t1, start_in, rb, g->rle.as<u8>(), block_max_len, is_last ? 1 : 0,
                       g->blocks_all.as<BlockDesc>(), (u32)max_blocks);
     u64 res[3] = {0, 0, 0};
-    HIPCHK(hipMemcpyAsync(res, rb.cut_result, sizeof(res), hipMemcpyDeviceToHost, g->st));
+    HIPCHK(hipMemcpyAsync(res, rb.cut_result, sizeof(res), hipMemcpyDeviceToHost, g->st2));
+    HIPCHK(hipStreamSynchronize(g->st2));
     HIPCHK(hipStreamSynchronize(g->st));
     const size_t nb = (size_t)res[0];
     if (nb > max_blocks) return BZ_E_UNEXPECTED;

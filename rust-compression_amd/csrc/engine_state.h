@@ -59,7 +59,7 @@ struct bz_gpu_engine {
     // constant tables
     DevBuf crc_tab, xp16, xp2;
     // partition state (sized by the input)
-    DevBuf tile_last, carry_in, tile_crc, tile_count, tile_off, sub_off, sub_rs, scal, rle, blocks_all, crc_all;
+    DevBuf tile_last, carry_in, tile_crc, tile_count, tile_off, sub_off, sub_rs, scal, scan_part, rle, blocks_all, crc_all;
     std::vector<BlockDesc> h_blocks;
     std::vector<u32> h_crc;
     const u8 *d_in = nullptr;

@@ -1589,10 +1589,31 @@ __global__ __launch_bounds__(kSortThreads) void k_block_symbols(BwtArgs a, u32 *
     const u8 *text = a.rle + d.rle_off;
     if (threadIdx.x < 8) s_bits[threadIdx.x] = 0;
     __syncthreads();
-    u32 seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (u32 i = start + threadIdx.x; i < n && i < start + kSortTile; i += kSortThreads) {
-        const u8 c = text[i];
-        seen[c >> 5] |= 1u << (c & 31u);
+    // 16 bytes per load, from the 16-byte boundary in front of the tile (the image is padded at both ends of a block's
+    // bytes by its neighbours or by the buffer's slack); four 64-bit sets, picked with selects
+    const u32 cnt = (n - start) < kSortTile ? (n - start) : kSortTile;
+    const uintptr_t p0 = reinterpret_cast<uintptr_t>(text + start);
+    const u32 lead = (u32)(p0 & 15u);
+    const uint4 *src = reinterpret_cast<const uint4 *>(p0 - lead);
+    u64 set[4] = {0, 0, 0, 0};
+    for (u32 c = threadIdx.x; c * 16u < lead + cnt; c += kSortThreads) {
+        const uint4 v = src[c];
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (u32 k = 0; k < 16; ++k) {
+            const u32 pos = c * 16u + k;
+            const u32 b = (w[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu;
+            const u64 bit = (pos >= lead && pos < lead + cnt) ? (1ull << (b & 63u)) : 0ull;
+            const u32 hi = b >> 6;
+#pragma unroll
+            for (u32 q = 0; q < 4; ++q) set[q] |= (hi == q) ? bit : 0ull;
+        }
+    }
+    u32 seen[8];
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+        seen[2 * q] = (u32)set[q];
+        seen[2 * q + 1] = (u32)(set[q] >> 32);
     }
 #pragma unroll
     for (u32 q = 0; q < 8; ++q) {
