@@ -1205,7 +1205,12 @@ __global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 ste
 // takes one bin (1024 ranks) per wave, puts the words in place in LDS and writes the rank array in
 // whole lines.  A word is (j & 1023) | head << 10 | final << 31; bin b owns the 1024 words behind
 // b * 1024 of the free key array (a rotation occurs once, so a bin cannot overflow).
-constexpr u32 kRankBinShift = 10, kRankBins = kSlot >> kRankBinShift; // 880 bins of 1024 rotations
+#ifndef BZ_RANK_BIN_SHIFT
+#define BZ_RANK_BIN_SHIFT 10
+#endif
+constexpr u32 kRankBinShift = BZ_RANK_BIN_SHIFT, kRankBins = kSlot >> kRankBinShift; // 880 bins of 1024 rotations
+constexpr u32 kRankBinSize = 1u << kRankBinShift, kRankBinMask = kRankBinSize - 1u;
+static_assert(kRankBinShift + 20u + 1u <= 32u, "j inside the bin, a 20-bit head and the final bit share a word");
 static_assert(kRankBins <= 1024 && (kRankBins << kRankBinShift) == kSlot, "bins tile the slot");
 
 template <bool INIT>
@@ -1316,7 +1321,7 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
                 a.L[base + p] = text[j ? j - 1u : n - 1u];
                 if (j == 0) a.orig_ptr[lb] = p;
             }
-            word[r] = (j & 1023u) | (head << kRankBinShift) | (fin ? kFinalBit : 0u);
+            word[r] = (j & kRankBinMask) | (head << kRankBinShift) | (fin ? kFinalBit : 0u);
             lrank[r] = atomicAdd(&s_bcnt[j >> kRankBinShift], 1u);
             my_nonfinal += fin ? 0u : 1u;
             nf = !fin;
@@ -1410,7 +1415,7 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
 // (later rounds) is scattered directly.
 __global__ __launch_bounds__(kSortThreads) void k_rank_place(BwtArgs a, const u32 *__restrict__ W)
 {
-    __shared__ u32 s_r[kSortThreads / 64][1024];
+    __shared__ u32 s_r[kSortThreads / 64][kRankBinSize];
     u32 tile, lb;
     xcd_remap(kTilesPerBlock, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
@@ -1422,12 +1427,12 @@ __global__ __launch_bounds__(kSortThreads) void k_rank_place(BwtArgs a, const u3
     const u32 c = a.bin_cursor[(size_t)lb * 1024u + bin];
     if (c == 0) return;
     const size_t base = (size_t)lb * kSlot + j0;
-    const u32 span = (n - j0) < 1024u ? (n - j0) : 1024u;
+    const u32 span = (n - j0) < kRankBinSize ? (n - j0) : kRankBinSize;
     u32 *mine = s_r[w];
     if (c < 128u) {
         for (u32 i = l; i < c; i += 64u) {
             const u32 x = ld_stream(W + base + i);
-            a.R[base + (x & 1023u)] = ((x >> kRankBinShift) & 0xFFFFFu) | (x & kFinalBit);
+            a.R[base + (x & kRankBinMask)] = ((x >> kRankBinShift) & 0xFFFFFu) | (x & kFinalBit);
         }
         return;
     }
@@ -1436,7 +1441,7 @@ __global__ __launch_bounds__(kSortThreads) void k_rank_place(BwtArgs a, const u3
     // (LDS accesses of one wave retire in order: no barrier between the phases of a wave's own region)
     for (u32 i = l; i < c; i += 64u) {
         const u32 x = ld_stream(W + base + i);
-        mine[x & 1023u] = ((x >> kRankBinShift) & 0xFFFFFu) | (x & kFinalBit);
+        mine[x & kRankBinMask] = ((x >> kRankBinShift) & 0xFFFFFu) | (x & kFinalBit);
     }
     for (u32 i = l; i < span; i += 64u) a.R[base + i] = mine[i];
 }

@@ -1,11 +1,17 @@
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
-for v in zle3 zle4; do
-OUT=$R/gpurun_out/prof_$v
+OUT=$R/gpurun_out/decpmc
 mkdir -p $OUT
-cp rust-compression_amd/libbz2_mi355x.so /tmp/lib_default.so
-cp rust-compression_amd/build/var/$v.so rust-compression_amd/libbz2_mi355x.so
-(cd /tmp && TMPDIR=/tmp timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o q -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 > $OUT/bench_trace.json 2> $OUT/trace.err)
-cp /tmp/lib_default.so rust-compression_amd/libbz2_mi355x.so
-echo "== $v"; grep "k_zle_emit" $OUT/trace/q_kernel_stats.csv | cut -d, -f1-4
-done
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d $OUT -o d -- python3 $R/bench_decode.py --steps 1 --warmup 0 > $OUT/bench.json 2> $OUT/err.txt
+tail -3 $OUT/err.txt
+python3 - <<PY
+import csv, glob, collections, re
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+for fn in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(fn)):
+        m = re.search(r"(k_[a-z0-9_]+)", r["Kernel_Name"])
+        if m: agg[m.group(1)][r["Counter_Name"]] += float(r["Counter_Value"])
+for k, v in agg.items():
+    if 'walk' in k or 'tscatter' in k or 'seg_copy' in k: print(k, {a: "%.4g" % b for a, b in v.items()})
+PY
