@@ -419,9 +419,9 @@ void launch_rle_scan(hipStream_t st, const u8 *d_in, u64 n, u64 t0, u64 t1, u64 
 void launch_rle_count(hipStream_t st, const u8 *d_in, u64 n, u64 t0, u64 t1, u64 in_begin, i64 init_carry,
                       const RleBuffers &rb, i64 *d_out_last);
 void launch_rle_prefix(hipStream_t st, u64 tb, u64 t1, const RleBuffers &rb);
-void launch_rle_finish(hipStream_t st, hipStream_t st_cuts, const u8 *d_in, u64 n, u64 tb, u64 t1, u64 in_begin,
-                       const RleBuffers &rb, u8 *d_rle, u32 block_max_len, int emit_tail, BlockDesc *d_blocks,
-                       u32 max_blocks);
+void launch_rle_cuts(hipStream_t st, const u8 *d_in, u64 n, u64 tb, u64 t1, u64 in_begin, const RleBuffers &rb,
+                     u32 block_max_len, int emit_tail, BlockDesc *d_blocks, u32 max_blocks);
+void launch_rle_image(hipStream_t st, const u8 *d_in, u64 n, u64 tb, u64 t1, u64 in_begin, const RleBuffers &rb, u8 *d_rle);
 void launch_block_crc(hipStream_t st, const u8 *d_in, const BlockDesc *d_blocks, u32 nblocks,
                       const u32 *crc_tab, const u32 *xp2, const u32 *tile_crc, u32 *d_crc);
 void launch_block_symbols(hipStream_t st, const BwtArgs &a, u32 *inuse_bits, u8 *sym_code, u8 *keyinfo);

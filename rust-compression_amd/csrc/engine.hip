@@ -143,7 +143,14 @@ extern "C" int bz_gpu_engine_create(bz_gpu_engine **out, int device, size_t max_
     g->device = device;
     g->max_blocks = max_blocks_in_flight ? max_blocks_in_flight : 64;
     HIPCHK(hipStreamCreateWithFlags(&g->st, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&g->st2, hipStreamNonBlocking));
+    {
+        // st2 carries the small serial kernels that run beside a chip-filling one on st (the chain of block cuts
+        // beside the RLE1 image): with equal priorities its single workgroup sometimes waits behind 262 144 others
+        // and takes 3.2 ms instead of 1.8
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        HIPCHK(hipStreamCreateWithPriority(&g->st2, hipStreamNonBlocking, greatest));
+    }
     HIPCHK(hipHostMalloc((void **)&g->h_active, 64, hipHostMallocDefault));
 
     // CRC byte table (src/crc32.rs:58-72) and powers of x
@@ -270,10 +277,21 @@ extern "C" int bz_gpu_partition_slab_count(bz_gpu_engine *g, int64_t carry_run)
     return BZ_OK;
 }
 
-extern "C" int bz_gpu_partition_slab_finish(bz_gpu_engine *g, uint64_t start_in, int is_last, size_t *n_blocks,
-                                            uint64_t *next_in, int *tail_block)
+// The last step of the split in two halves, so that a rank of a sharded job can hand the cut on before it writes
+// its image: only the chain of cuts depends on the rank before (and the next rank's on this one's).
+//   slab_cuts : left halo, tile offsets, the cut chain from start_in -> blocks, next_in, tail
+//   slab_image: the RLE1 image of [tb, t1), block CRCs, the host copies of the block records
+struct SlabCuts {
+    u64 tb = 0, start_in = 0;
+    size_t nb = 0;
+    int span = -1;
+    bool pending = false, image_done = false;
+};
+// image_beside: the image is written on g->st while the cut chain runs on g->st2 (nobody waits for the cut)
+static int slab_cuts(bz_gpu_engine *g, uint64_t start_in, int is_last, bool image_beside, SlabCuts &sc, size_t *n_blocks,
+                     uint64_t *next_in, int *tail_block)
 {
-    if (!g) return BZ_E_PARAM;
+    sc = SlabCuts();
     HIPCHK(hipSetDevice(g->device));
     if (n_blocks) *n_blocks = 0;
     if (next_in) *next_in = start_in;
@@ -286,7 +304,7 @@ extern "C" int bz_gpu_partition_slab_finish(bz_gpu_engine *g, uint64_t start_in,
     if (start_in > t0 * (u64)kRleTile) return BZ_E_PARAM;
     const RleBuffers rb = rle_buffers(g);
     const u32 block_max_len = (u32)g->level * 100000u - 19u; // encoder.rs:186
-    const int sp = span_begin(g, 0);
+    sc.span = span_begin(g, 0);
     if (tb < t0) {
         // left halo: the tail of the previous slab(s) that belongs to this rank's first block, coded
         // afresh from the cut (RLE1 restarted at a cut is RLE1 continued)
@@ -303,14 +321,33 @@ extern "C" int bz_gpu_partition_slab_finish(bz_gpu_engine *g, uint64_t start_in,
         (rc = g->crc_all.ensure(max_blocks * 4)))
         return rc;
     // (everything the cuts read is complete: the host has just waited for g->st; g->st2 is idle between calls)
-    launch_rle_finish(g->st, g->st2, g->d_in, n, tb, t1, start_in, rb, g->rle.as<u8>(), block_max_len, is_last ? 1 : 0,
-                      g->blocks_all.as<BlockDesc>(), (u32)max_blocks);
+    launch_rle_cuts(g->st2, g->d_in, n, tb, t1, start_in, rb, block_max_len, is_last ? 1 : 0,
+                    g->blocks_all.as<BlockDesc>(), (u32)max_blocks);
+    if (image_beside) {
+        launch_rle_image(g->st, g->d_in, n, tb, t1, start_in, rb, g->rle.as<u8>());
+        sc.image_done = true;
+    }
     u64 res[3] = {0, 0, 0};
     HIPCHK(hipMemcpyAsync(res, rb.cut_result, sizeof(res), hipMemcpyDeviceToHost, g->st2));
     HIPCHK(hipStreamSynchronize(g->st2));
-    HIPCHK(hipStreamSynchronize(g->st));
     const size_t nb = (size_t)res[0];
     if (nb > max_blocks) return BZ_E_UNEXPECTED;
+    sc.tb = tb;
+    sc.start_in = start_in;
+    sc.nb = nb;
+    sc.pending = true;
+    if (n_blocks) *n_blocks = nb;
+    if (next_in) *next_in = nb || is_last ? res[1] : start_in;
+    if (tail_block) *tail_block = (int)res[2];
+    return BZ_OK;
+}
+static int slab_image(bz_gpu_engine *g, SlabCuts &sc)
+{
+    if (!sc.pending) return BZ_OK;
+    sc.pending = false;
+    const RleBuffers rb = rle_buffers(g);
+    if (!sc.image_done) launch_rle_image(g->st, g->d_in, g->n_in, sc.tb, g->slab_t1, sc.start_in, rb, g->rle.as<u8>());
+    const size_t nb = sc.nb;
     g->h_blocks.resize(nb);
     g->h_crc.resize(nb);
     if (nb) {
@@ -320,13 +357,24 @@ extern "C" int bz_gpu_partition_slab_finish(bz_gpu_engine *g, uint64_t start_in,
                               g->st));
         HIPCHK(hipMemcpyAsync(g->h_crc.data(), g->crc_all.p, nb * 4, hipMemcpyDeviceToHost, g->st));
     }
-    span_end(g, sp);
+    span_end(g, sc.span);
     spans_collect(g);
     HIPCHK(hipGetLastError());
-    if (n_blocks) *n_blocks = nb;
-    if (next_in) *next_in = nb || is_last ? res[1] : start_in;
-    if (tail_block) *tail_block = (int)res[2];
     return BZ_OK;
+}
+
+extern "C" int bz_gpu_partition_slab_finish(bz_gpu_engine *g, uint64_t start_in, int is_last, size_t *n_blocks,
+                                            uint64_t *next_in, int *tail_block)
+{
+    if (!g) return BZ_E_PARAM;
+    SlabCuts sc;
+    // (one GPU, or a caller that drives the steps itself: the image is written beside the cut chain)
+    const int rc = slab_cuts(g, start_in, is_last, true, sc, n_blocks, next_in, tail_block);
+    if (rc != BZ_OK) {
+        if (sc.span >= 0) { span_end(g, sc.span); spans_collect(g); }
+        return rc;
+    }
+    return slab_image(g, sc);
 }
 
 extern "C" int bz_gpu_partition(bz_gpu_engine *g, int level, const void *d_in, size_t n, int mode,
@@ -731,11 +779,16 @@ extern "C" int bz_gpu_encode_sharded(bz_gpu_engine *g, int level, const void *d_
     if (rc == BZ_OK && hop[1] != 0) rc = -(int)hop[1];
     size_t nb = 0;
     uint64_t next = hop[0];
-    if (rc == BZ_OK) rc = bz_gpu_partition_slab_finish(g, hop[0], rank == world - 1, &nb, &next, nullptr);
+    // (the cut goes to the next rank before this rank writes its image: the chain over the ranks is serial, and
+    // only the cuts are part of it)
+    SlabCuts sc;
+    if (rc == BZ_OK) rc = slab_cuts(g, hop[0], rank == world - 1, world == 1, sc, &nb, &next, nullptr);
     if (rank < world - 1) {
         uint64_t out_hop[2] = {next, (uint64_t)(rc == BZ_OK ? 0 : -rc)};
         if (comm->send(comm->ctx, rank + 1, out_hop, sizeof(out_hop)) != 0) return BZ_E_UNEXPECTED;
     }
+    if (rc == BZ_OK) rc = slab_image(g, sc);
+    else if (sc.span >= 0) { span_end(g, sc.span); spans_collect(g); }
 
     // this rank's blocks (the sort starts as soon as its own cuts are known)
     std::vector<uint64_t> woff(nb + 1), blen(nb + 1);

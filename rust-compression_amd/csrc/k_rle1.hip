@@ -770,18 +770,22 @@ void launch_rle_prefix(hipStream_t st, u64 tb, u64 t1, const RleBuffers &rb)
     tiles_scan<false>(st, rb.tile_count, rb.tile_off, tb, t1, rb.scan_part, 0ull, rb.total, rb.tile_off + t1);
 }
 
-// The chain of cuts is one workgroup that reads the input and the tile tables, not the image: it runs on
-// st_cuts beside the scatter on st (the caller has waited for the tables and waits for both streams).
-void launch_rle_finish(hipStream_t st, hipStream_t st_cuts, const u8 *d_in, u64 n, u64 tb, u64 t1, u64 in_begin,
-                       const RleBuffers &rb, u8 *d_rle, u32 block_max_len, int emit_tail, BlockDesc *d_blocks,
-                       u32 max_blocks)
+// The chain of cuts is one workgroup that reads the input and the tile tables, not the image: the two are
+// separate launches (one GPU: side by side on two streams; a rank of a sharded job: the cuts first, the cut is
+// handed to the next rank, then the image).
+void launch_rle_cuts(hipStream_t st, const u8 *d_in, u64 n, u64 tb, u64 t1, u64 in_begin, const RleBuffers &rb,
+                     u32 block_max_len, int emit_tail, BlockDesc *d_blocks, u32 max_blocks)
 {
     if (t1 <= tb) {
-        (void)hipMemsetAsync(rb.cut_result, 0, 3 * sizeof(u64), st_cuts);
+        (void)hipMemsetAsync(rb.cut_result, 0, 3 * sizeof(u64), st);
         return;
     }
-    hipLaunchKernelGGL(k_rle_cuts, dim3(1), dim3(CT), 0, st_cuts, d_in, n, tb, in_begin, rb.sub_off, rb.sub_rs,
+    hipLaunchKernelGGL(k_rle_cuts, dim3(1), dim3(CT), 0, st, d_in, n, tb, in_begin, rb.sub_off, rb.sub_rs,
                        rb.tile_off, t1, block_max_len, emit_tail, d_blocks, max_blocks, rb.cut_result);
+}
+void launch_rle_image(hipStream_t st, const u8 *d_in, u64 n, u64 tb, u64 t1, u64 in_begin, const RleBuffers &rb, u8 *d_rle)
+{
+    if (t1 <= tb) return;
     hipLaunchKernelGGL(k_rle_scatter, dim3((u32)(t1 - tb)), dim3(RT), 0, st, d_in, n, tb, in_begin, rb.carry_in,
                        rb.tile_off, d_rle);
 }
