@@ -236,6 +236,8 @@ struct BwtArgs {
     u32 *loc_stats;                  // [4] k_phase_b_local: segments, overflows, segments out of order, LDS passes
     u8 *L;                           // [nb * kSlot] last column, written as rotations become final
     u32 *orig_ptr;                   // [nb] position of rotation 0 in the sorted order
+    u8 *ptext;                       // [nb * kSlot] the blocks' symbols packed for pkey() (k_pack_text); borrowed: the
+                                     //   MTF stage's rank bytes live here once the sort is done
     const u8 *sym_code;              // [nb][256] byte -> code (rank among the bytes in use)
     const u8 *keyinfo;               // [nb] KeyInfo {bits per symbol, symbols per key}
     // fused radix passes (no per-pass histogram kernel; tile offsets by decoupled look-back)

@@ -426,6 +426,7 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
     x.loc_stats = g->pb_gate.as<u32>() + g->ws_blocks; // (behind the gates)
     x.L = g->L.as<u8>() + s;
     x.orig_ptr = g->orig_ptr.as<u32>() + o;
+    x.ptext = g->rank8.as<u8>() + s; // (free until launch_mtf writes the ranks of this sub-batch)
     x.sym_code = g->sym_code.as<u8>() + (size_t)o * 256;
     x.keyinfo = g->keyinfo.as<u8>() + (size_t)o * 4;
     x.gh_tiles = g->gh_tiles.as<u32>() + t * 3 * kMaxBins;

@@ -54,34 +54,18 @@ struct KeyInfo {
 };
 
 // key(j): `chars` re-coded symbols of the rotation starting at j, first symbol most significant.
-// s_code: the block's 256-entry byte -> code table (in LDS).
-__device__ __forceinline__ u32 pack_key(const u8 *__restrict__ t, u32 n, u32 j, const u8 *s_code, u32 bits,
-                                        u32 chars)
+// The block's symbols are kept a second time as a PACKED string (k_pack_text): `bits` bits per symbol, first
+// symbol in the most significant bits of the first byte, and the first 16 symbols once more behind the last one
+// (rotations are cyclic).  A key is then `chars * bits` consecutive bits of that string: one unaligned 8-byte
+// load, a byte swap and a shift -- instead of three dword loads, a look-up per symbol in a byte -> code table in
+// LDS and the shifts that put the codes together (and 0.68 MB per block in the L2 instead of 0.9).
+__device__ __forceinline__ u32 pkey(const u8 *__restrict__ pt, u32 j, u32 bits, u32 chars)
 {
-    u32 k = 0;
-    if (j + 8u <= n) {
-        // 8 bytes from an arbitrary address out of three aligned dwords (the image is padded)
-        const uintptr_t p = reinterpret_cast<uintptr_t>(t + j);
-        const u32 *ap = reinterpret_cast<const u32 *>(p & ~(uintptr_t)3);
-        const u32 sh = (u32)(p & 3u) * 8u;
-        const u32 w0 = ap[0], w1 = ap[1], w2 = ap[2];
-        const u32 lo = sh ? ((w0 >> sh) | (w1 << (32u - sh))) : w0;
-        const u32 hi = sh ? ((w1 >> sh) | (w2 << (32u - sh))) : w1;
-#pragma unroll
-        for (u32 q = 0; q < 8; ++q) {
-            if (q < chars) {
-                const u32 byte = ((q < 4 ? lo >> (8u * q) : hi >> (8u * (q - 4u)))) & 0xFFu;
-                k = (k << bits) | s_code[byte];
-            }
-        }
-    } else {
-        u32 p = j;
-        for (u32 q = 0; q < chars; ++q) {
-            k = (k << bits) | s_code[t[p]];
-            p = (p + 1u == n) ? 0u : p + 1u; // rotations are cyclic
-        }
-    }
-    return k;
+    const u32 bitpos = j * bits, kb = bits * chars; // (kb <= 32, bitpos < 2^23)
+    u64 v;
+    __builtin_memcpy(&v, pt + (bitpos >> 3), 8); // (one global_load_dwordx2: unaligned access is on for HSA code objects)
+    v = __builtin_bswap64(v);
+    return (u32)(v >> (64u - (bitpos & 7u) - kb)) & (u32)((1ull << kb) - 1ull);
 }
 
 // Batched form: the 16 rows of one lane.  All primary loads are issued back to back (clamped
@@ -89,9 +73,9 @@ __device__ __forceinline__ u32 pack_key(const u8 *__restrict__ t, u32 n, u32 j, 
 // operations in flight instead of one -- these kernels are latency-bound otherwise.
 // first = index of the lane's row-0 element; rows are 64 apart.  Returns the participation mask.
 template <int SRC>
-__device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__restrict__ text, u32 n, u32 hm,
+__device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__restrict__ pt, u32 n, u32 hm,
                                           const u32 *__restrict__ Kin, const u32 *__restrict__ Vin, u32 first,
-                                          u32 cnt, const u8 *s_code, KeyInfo ki, u32 (&key)[16], u32 (&val)[16])
+                                          u32 cnt, KeyInfo ki, u32 (&key)[16], u32 (&val)[16])
 {
     const size_t base = (size_t)lb * kSlot;
     u32 ok = 0;
@@ -100,7 +84,7 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
         for (u32 r = 0; r < 16; ++r) {
             const u32 idx = first + r * 64u;
             const u32 c = idx < cnt ? idx : cnt - 1u;
-            key[r] = pack_key(text, n, c, s_code, ki.bits, ki.chars);
+            key[r] = pkey(pt, c, ki.bits, ki.chars);
             val[r] = c;
             ok |= (idx < cnt ? 1u : 0u) << r;
         }
@@ -116,7 +100,7 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
             ok |= (idx < cnt ? 1u : 0u) << r;
         }
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) key[r] = pack_key(text, n, val[r], s_code, ki.bits, ki.chars);
+        for (u32 r = 0; r < 16; ++r) key[r] = pkey(pt, val[r], ki.bits, ki.chars);
     } else if (SRC == SRC_TEXTK) {
 #pragma unroll
         for (u32 r = 0; r < 16; ++r) {
@@ -245,7 +229,6 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shif
     // top digit is a key's first two symbols) and adds to one LDS word serialise
     constexpr u32 kHistCopies = 4;
     __shared__ u32 s_hist[kHistCopies][NB];
-    __shared__ u8 s_code[256];
     u32 tile, lb;
     xcd_remap(kTilesPerBlock, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
@@ -255,18 +238,17 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shif
     const u32 start = tile * kSortTile;
     if (start >= cnt) return;
     const u8 *text = a.rle + d.rle_off;
+    const u8 *pt = a.ptext + (size_t)lb * kSlot;
     const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
     const u32 hm = (SRC == SRC_MM || SRC == SRC_MMK || SRC == SRC_SURV) ? (((u32)ki.chars * 2u) << h) % n : 0u;
 
     for (u32 i = threadIdx.x; i < kHistCopies * NB; i += kSortThreads) (&s_hist[0][0])[i] = 0;
-    if (SRC == SRC_TEXT || SRC == SRC_WALK)
-        for (u32 i = threadIdx.x; i < 256; i += kSortThreads) s_code[i] = a.sym_code[(size_t)lb * 256 + i];
     __syncthreads();
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
     {
         u32 key[16], val[16];
         const u32 ok =
-            fetch_rows<SRC>(a, lb, text, n, hm, Kin, Vin, start + w * 1024u + l, cnt, s_code, ki, key, val);
+            fetch_rows<SRC>(a, lb, pt, n, hm, Kin, Vin, start + w * 1024u + l, cnt, ki, key, val);
 #pragma unroll
         for (u32 r = 0; r < 16; ++r)
             if ((ok >> r) & 1u) atomicAdd(&s_hist[l & (kHistCopies - 1)][(key[r] >> shift) & (NB - 1)], 1u);
@@ -372,7 +354,6 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
     __shared__ u16 s_tpre[NB];
     __shared__ u32 s_wsum[NW];
     __shared__ u32 s_total;
-    __shared__ u8 s_code[256];
     u16 *s_cnt = reinterpret_cast<u16 *>(s_buf); // [NW][NB] u16 <= 64 KiB
     u32 tile, lb;
     xcd_remap(kTilesPerBlock, a.nb, tile, lb);
@@ -383,13 +364,12 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
     const u32 start = tile * kSortTile;
     if (start >= cnt) return;
     const u8 *text = a.rle + d.rle_off;
+    const u8 *pt = a.ptext + (size_t)lb * kSlot;
     const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
     const u32 hm = (SRC == SRC_MM || SRC == SRC_MMK || SRC == SRC_SURV) ? (((u32)ki.chars * 2u) << h) % n : 0u;
     const size_t base = (size_t)lb * kSlot;
 
     {
-        if (SRC == SRC_TEXT || SRC == SRC_WALK)
-            for (u32 i = threadIdx.x; i < 256; i += kSortThreads) s_code[i] = a.sym_code[(size_t)lb * 256 + i];
         for (u32 i = threadIdx.x; i < NW * NB / 2; i += kSortThreads) s_buf[i] = 0;
         const u32 *hist = a.tile_hist + ((size_t)lb * kTilesPerBlock + tile) * kMaxBins;
         const u32 *bin_base = a.bin_base + (size_t)lb * kMaxBins;
@@ -404,7 +384,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
     u32 key[16], val[16];
     u32 rnk[16]; // 0xFFFFFFFF = takes no part
     const u32 okmask =
-        fetch_rows<SRC>(a, lb, text, n, hm, Kin, Vin, start + w * 1024u + l, cnt, s_code, ki, key, val);
+        fetch_rows<SRC>(a, lb, pt, n, hm, Kin, Vin, start + w * 1024u + l, cnt, ki, key, val);
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
         const bool ok = (okmask >> r) & 1u;
@@ -534,7 +514,6 @@ __global__ __launch_bounds__(kSortThreads) void k_ghist_text(BwtArgs a, u32 *__r
 {
     constexpr u32 NB0 = 1u << B0, NB1 = 1u << B1, NB2 = 1u << B2;
     __shared__ u32 s_h0[2][NB0], s_h1[2][NB1], s_h2[2][NB2];
-    __shared__ u8 s_code[256];
     u32 tile, lb;
     xcd_remap(kTilesPerBlock, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
@@ -543,15 +522,15 @@ __global__ __launch_bounds__(kSortThreads) void k_ghist_text(BwtArgs a, u32 *__r
     const u32 start = tile * kSortTile;
     if (start >= n) return;
     const u8 *text = a.rle + d.rle_off;
+    const u8 *pt = a.ptext + (size_t)lb * kSlot;
     const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
     for (u32 i = threadIdx.x; i < 2 * NB0; i += kSortThreads) (&s_h0[0][0])[i] = 0;
     for (u32 i = threadIdx.x; i < 2 * NB1; i += kSortThreads) (&s_h1[0][0])[i] = 0;
     for (u32 i = threadIdx.x; i < 2 * NB2; i += kSortThreads) (&s_h2[0][0])[i] = 0;
-    for (u32 i = threadIdx.x; i < 256; i += kSortThreads) s_code[i] = a.sym_code[(size_t)lb * 256 + i];
     __syncthreads();
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
     u32 key[16], val[16];
-    const u32 ok = fetch_rows<SRC_TEXT>(a, lb, text, n, 0, nullptr, nullptr, start + w * 1024u + l, n, s_code, ki, key, val);
+    const u32 ok = fetch_rows<SRC_TEXT>(a, lb, pt, n, 0, nullptr, nullptr, start + w * 1024u + l, n, ki, key, val);
     const size_t base = (size_t)lb * kSlot;
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
@@ -634,7 +613,6 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
     __shared__ u32 s_wsum[NW];
     __shared__ u32 s_total;
     __shared__ u32 s_ticket;
-    __shared__ u8 s_code[256];
     u16 *s_cnt = reinterpret_cast<u16 *>(s_buf); // [NW][NB] u16
     // Tiles are handed out in order, block by block, from one ticket counter per XCD -- the XCD this
     // workgroup really runs on (HW_REG_XCC_ID), so that all tiles of a block are handled on one XCD
@@ -658,11 +636,10 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
     const u32 start = tile * kSortTile;
     if (start >= cnt) return;
     const u8 *text = a.rle + d.rle_off;
+    const u8 *pt = a.ptext + (size_t)lb * kSlot;
     const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
     const u32 hm = (SRC == SRC_MM || SRC == SRC_MMK || SRC == SRC_SURV) ? (((u32)ki.chars * 2u) << h) % n : 0u;
     const size_t base = (size_t)lb * kSlot;
-    if (SRC == SRC_TEXT || SRC == SRC_WALK)
-        for (u32 i = threadIdx.x; i < 256; i += kSortThreads) s_code[i] = a.sym_code[(size_t)lb * 256 + i];
     for (u32 i = threadIdx.x; i < NW * NB / 2; i += kSortThreads) s_buf[i] = 0;
     __syncthreads();
 
@@ -672,7 +649,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
     u32 key[16], val[16];
     u32 rnk[16]; // 0xFFFFFFFF = takes no part
     const u32 okmask =
-        fetch_rows<SRC>(a, lb, text, n, hm, Kin, Vin, start + w * 1024u + l, cnt, s_code, ki, key, val);
+        fetch_rows<SRC>(a, lb, pt, n, hm, Kin, Vin, start + w * 1024u + l, cnt, ki, key, val);
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
         const bool ok = (okmask >> r) & 1u;
@@ -924,7 +901,6 @@ __global__ __launch_bounds__(kLocThreads) void k_phase_b_local(BwtArgs a, const 
     __shared__ u32 s_wsum[kLocSets];
     __shared__ u32 s_seg[2];
     __shared__ u32 s_bad;
-    __shared__ u8 s_code[256];
     u32 tile, lb;
     xcd_remap(kTilesPerBlock, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
@@ -940,6 +916,7 @@ __global__ __launch_bounds__(kLocThreads) void k_phase_b_local(BwtArgs a, const 
     }
     const size_t base = (size_t)lb * kSlot;
     const u8 *text = a.rle + d.rle_off;
+    const u8 *pt = a.ptext + (size_t)lb * kSlot;
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
     if (w == 0) {
         const u32 s = first_group_start(K + base, start, n, kLocCap + 64u);
@@ -948,7 +925,6 @@ __global__ __launch_bounds__(kLocThreads) void k_phase_b_local(BwtArgs a, const 
         const u32 s = first_group_start(K + base, start + kSortTile, n, kLocCap + 64u);
         if (l == 0) s_seg[1] = s;
     }
-    for (u32 i = threadIdx.x; i < 256; i += kLocThreads) s_code[i] = a.sym_code[(size_t)lb * 256 + i];
     if (threadIdx.x == 0) s_bad = 0;
     __syncthreads();
     const u32 s0 = (u32)__builtin_amdgcn_readfirstlane((int)s_seg[0]), s1 = (u32)__builtin_amdgcn_readfirstlane((int)s_seg[1]);
@@ -989,7 +965,7 @@ __global__ __launch_bounds__(kLocThreads) void k_phase_b_local(BwtArgs a, const 
             const bool f = (i < len) && (i == 0 || kk != pk);
             u32 t = v + cm;
             t = t >= n ? t - n : t;
-            const u32 k2 = pack_key(text, n, t, s_code, ki.bits, ki.chars);
+            const u32 k2 = pkey(pt, t, ki.bits, ki.chars);
             if (i < len) s_e[i] = ((u64)(f ? 1u : 0u) << 63) | ((u64)k2 << 20) | (u64)v;
             tot += (u32)__popcll(__ballot(f));
         }
@@ -1094,7 +1070,6 @@ __global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 ste
                                                                const u32 *__restrict__ V)
 {
     __shared__ int s_old, s_new;
-    __shared__ u8 s_code[256];
     u32 tile, lb;
     xcd_remap(kTilesPerBlock, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
@@ -1106,14 +1081,13 @@ __global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 ste
     const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
     const u32 hm = INIT ? (u32)ki.chars % n : (((u32)ki.chars * 2u) << step) % n;
     const u8 *text = a.rle + d.rle_off;
+    const u8 *pt = a.ptext + (size_t)lb * kSlot;
     const size_t base = (size_t)lb * kSlot;
     if (INIT && a.pb_gate[lb] == 0u) K = a.KA; // phase B was done in LDS: phase A's keys are the list's keys
     if (threadIdx.x == 0) {
         s_old = -1;
         s_new = -1;
     }
-    if (INIT)
-        for (u32 i = threadIdx.x; i < 256; i += kSortThreads) s_code[i] = a.sym_code[(size_t)lb * 256 + i];
     __syncthreads();
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
     int last_old = -1, last_new = -1;
@@ -1148,8 +1122,8 @@ __global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 ste
             // (a table of the packed keys, one gather instead of three plus the re-coding, was measured: the flags
             // gain 0.6 ms, the walk pass loses 2.5 -- the table is 3.6 MB per block against 0.9 MB of text in the L2)
 #pragma unroll
-            for (u32 r = 0; r < 16; ++r) s2[r] = pack_key(text, n, jj[r], s_code, ki.bits, ki.chars);
-            if (need_prev) ps20 = pack_key(text, n, pj, s_code, ki.bits, ki.chars);
+            for (u32 r = 0; r < 16; ++r) s2[r] = pkey(pt, jj[r], ki.bits, ki.chars);
+            if (need_prev) ps20 = pkey(pt, pj, ki.bits, ki.chars);
         } else {
 #pragma unroll
             for (u32 r = 0; r < 16; ++r) s1[r] = a.R[base + jj[r]];
@@ -1592,6 +1566,7 @@ __global__ __launch_bounds__(kSortThreads) void k_block_symbols(BwtArgs a, u32 *
     const u32 start = tile * kSortTile;
     if (start >= n) return;
     const u8 *text = a.rle + d.rle_off;
+    const u8 *pt = a.ptext + (size_t)lb * kSlot;
     if (threadIdx.x < 8) s_bits[threadIdx.x] = 0;
     __syncthreads();
     // 16 bytes per load, from the 16-byte boundary in front of the tile (the image is padded at both ends of a block's
@@ -1658,6 +1633,58 @@ __global__ __launch_bounds__(256) void k_key_params(const u32 *__restrict__ inus
     }
 }
 
+// The block's symbols as a packed string for pkey(): `bits` bits per re-coded symbol, most significant bit first,
+// symbols n .. n+15 = symbols 0 .. 15 of the cyclic text.  A thread packs groups of eight symbols (= `bits` whole
+// bytes); a tile's bytes leave through LDS as dwords.
+__global__ __launch_bounds__(kSortThreads) void k_pack_text(BwtArgs a, u8 *__restrict__ ptext)
+{
+    __shared__ u8 s_code[256];
+    __shared__ u32 s_out[kSortTile / 4]; // 1024 groups x at most 8 bytes
+    u32 tile, lb;
+    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    const BlockDesc d = a.blocks[lb];
+    const u32 n = d.n;
+    const u32 start = tile * kSortTile;
+    if (n == 0 || start >= n + 16u) return;
+    const u8 *text = a.rle + d.rle_off;
+    const u32 bits = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb].bits;
+    for (u32 i = threadIdx.x; i < 256; i += kSortThreads) s_code[i] = a.sym_code[(size_t)lb * 256 + i];
+    __syncthreads();
+    u8 *s_bytes = reinterpret_cast<u8 *>(s_out);
+#pragma unroll
+    for (u32 h = 0; h < 2; ++h) {
+        const u32 g = h * kSortThreads + threadIdx.x; // group inside the tile
+        const u32 i0 = start + g * 8u;
+        u32 lo = 0, hi = 0;
+        if (i0 + 8u <= n) {
+            const uintptr_t p = reinterpret_cast<uintptr_t>(text + i0);
+            const u32 *ap = reinterpret_cast<const u32 *>(p & ~(uintptr_t)3);
+            const u32 w0 = ap[0], w1 = ap[1], w2 = ap[2];
+            lo = __builtin_amdgcn_alignbyte(w1, w0, (u32)(p & 3u));
+            hi = __builtin_amdgcn_alignbyte(w2, w1, (u32)(p & 3u));
+        } else if (i0 < n + 16u) {
+            for (u32 q = 0; q < 8; ++q) {
+                const u32 i = i0 + q;
+                const u32 c = (i < n + 16u) ? (u32)text[i < n ? i : (i - n) % n] : 0u;
+                if (q < 4) lo |= c << (8u * q);
+                else hi |= c << (8u * (q - 4u));
+            }
+        }
+        u64 v = 0;
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
+            const u32 byte = ((q < 4 ? lo >> (8u * q) : hi >> (8u * (q - 4u)))) & 0xFFu;
+            v = (v << bits) | (u64)s_code[byte];
+        }
+        // the 8 * bits bits of v, most significant byte first
+        for (u32 k = 0; k < bits; ++k) s_bytes[g * bits + k] = (u8)(v >> (8u * (bits - 1u - k)));
+    }
+    __syncthreads();
+    u32 *dst = reinterpret_cast<u32 *>(ptext + (size_t)lb * kSlot + (size_t)tile * 1024u * bits);
+    for (u32 i = threadIdx.x; i < 256u * bits; i += kSortThreads) dst[i] = s_out[i];
+}
+
 // ---- last column, origPtr ---------------------------------------------------------------------------
 // L[i] = block[(SA[i]-1) mod n]  (src/bzip2/encoder.rs:331-338); origPtr = i with SA[i]==0 (:332-334)
 __global__ __launch_bounds__(kSortThreads) void k_last_column(BwtArgs a, u8 *__restrict__ L,
@@ -1671,6 +1698,7 @@ __global__ __launch_bounds__(kSortThreads) void k_last_column(BwtArgs a, u8 *__r
     const u32 start = tile * kSortTile;
     if (start >= n) return;
     const u8 *text = a.rle + d.rle_off;
+    const u8 *pt = a.ptext + (size_t)lb * kSlot;
     const size_t base = (size_t)lb * kSlot;
     u32 sv[16];
 #pragma unroll
@@ -1864,6 +1892,7 @@ void launch_block_symbols(hipStream_t st, const BwtArgs &a, u32 *inuse_bits, u8 
     (void)hipMemsetAsync(inuse_bits, 0, (size_t)a.nb * 8 * sizeof(u32), st);
     hipLaunchKernelGGL(k_block_symbols, grid, dim3(kSortThreads), 0, st, a, inuse_bits);
     hipLaunchKernelGGL(k_key_params, dim3(a.nb), dim3(256), 0, st, inuse_bits, sym_code, keyinfo);
+    hipLaunchKernelGGL(k_pack_text, grid, dim3(kSortThreads), 0, st, a, a.ptext);
 }
 
 template <int B0, int B1, int B2>
