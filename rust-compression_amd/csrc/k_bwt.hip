@@ -538,7 +538,7 @@ __global__ __launch_bounds__(kSortThreads) void k_ghist_text(BwtArgs a, u32 *__r
             atomicAdd(&s_h0[l & 1u][key[r] & (NB0 - 1)], 1u);
             atomicAdd(&s_h1[l & 1u][(key[r] >> B0) & (NB1 - 1)], 1u);
             atomicAdd(&s_h2[l & 1u][(key[r] >> (B0 + B1)) & (NB2 - 1)], 1u);
-            Kstore[base + start + w * 1024u + r * 64u + l] = key[r];
+            if (Kstore) Kstore[base + start + w * 1024u + r * 64u + l] = key[r];
         }
     }
     __syncthreads();
@@ -1823,7 +1823,7 @@ static void fused_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const
                        const u32 *gate = nullptr)
 {
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
-    const u64 rd = (SRC == SRC_TEXTK) ? 4 : ((SRC == SRC_WALK) ? 5 : 8);
+    const u64 rd = (SRC == SRC_TEXTK) ? 4 : ((SRC == SRC_TEXT) ? 1 : ((SRC == SRC_WALK) ? 5 : 8));
     const u32 e = next_epoch(st, a);
     if (out_elems == ~0ull) out_elems = elems;
     const int p = prof ? prof->begin(st, KID_RADIX_SCATTER_LB, elems * rd + out_elems * (WRITE_K ? 8 : 4)) : -1;
@@ -1855,14 +1855,15 @@ static bool init_sort_fused(hipStream_t st, const BwtArgs &a, u64 total_n, Kerne
 {
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
     // the digit counts of key(j), once: both init phases sort the same multiset of keys
-    int p = prof ? prof->begin(st, KID_GHIST_TEXT, total_n * 5) : -1;
-    hipLaunchKernelGGL((k_ghist_text<B0, B1, B2>), grid, dim3(kSortThreads), 0, st, a, a.KB);
+    // (the keys are not kept: with the packed text a key costs one load, less than a stored key's write and read)
+    int p = prof ? prof->begin(st, KID_GHIST_TEXT, total_n * 1) : -1;
+    hipLaunchKernelGGL((k_ghist_text<B0, B1, B2>), grid, dim3(kSortThreads), 0, st, a, (u32 *)nullptr);
     if (prof) prof->end(st, p);
     p = prof ? prof->begin(st, KID_GHIST_SCAN, (u64)a.nb * kTilesPerBlock * 3 * 1024 * 4) : -1;
     hipLaunchKernelGGL(k_ghist_scan, dim3(a.nb), dim3(kSortThreads), 0, st, a, 3u, 1u << B0, 1u << B1, 1u << B2, 0u);
     if (prof) prof->end(st, p);
     // phase A: order by key(j); phase B: walk it, order by key(j - c) -> 2c symbols
-    fused_pass<SRC_TEXTK, B0>(st, a, 0, 0, a.KB, nullptr, a.KA, a.VA, 0, total_n, prof);
+    fused_pass<SRC_TEXT, B0>(st, a, 0, 0, nullptr, nullptr, a.KA, a.VA, 0, total_n, prof);
     if (!fused_pass_ok(st, a, *a.epoch)) return false;
     fused_pass<SRC_PAIRS, B1>(st, a, B0, 0, a.KA, a.VA, a.KB, a.VB, 1, total_n, prof);
     const u32 *gate = nullptr;
