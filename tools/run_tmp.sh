@@ -1,11 +1,10 @@
 cd $GRAFT_REPO_ROOT
-R=$GRAFT_REPO_ROOT
-timeout 400 bash tools/profile.sh r02 > /dev/null 2>&1
-BENCH=bench_decode.py timeout 400 bash tools/profile.sh r02dec > /dev/null 2>&1
-BENCH=bench_deflate.py timeout 400 bash tools/profile.sh r02df > /dev/null 2>&1
-cd $R
-timeout 500 python3 bench.py > gpurun_out/bench_r02_final.json 2> gpurun_out/bench_r02_final.err
-timeout 300 python3 bench_decode.py > gpurun_out/bench_decode_r02.json 2> gpurun_out/bench_decode_r02.err
-timeout 300 python3 bench_deflate.py > gpurun_out/bench_deflate_r02.json 2> gpurun_out/bench_deflate_r02.err
-tail -c 600 gpurun_out/bench_r02_final.json | head -c 600; echo
-ls gpurun_out/prof_r02 gpurun_out/prof_r02dec gpurun_out/prof_r02df
+mkdir -p gpurun_out/r2y
+timeout 300 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_sharded.py -x -q -m gpu 2>&1 | tail -2
+for i in 1 2 3; do
+timeout 200 python3 bench.py --steps 5 --warmup 2 --no-extras --no-cpu-baseline > gpurun_out/r2y/bench_q.json 2> gpurun_out/r2y/bench_q.err
+python3 -c "
+import json
+line=[l for l in open('gpurun_out/r2y/bench_q.json') if l.startswith('{')][-1]
+d=json.loads(line); print(d['value'], d['ms_per_step'], d['kernel_seconds_last_step_rank0'])"
+done
