@@ -754,7 +754,10 @@ extern "C" int bz_enc_write(bz_enc *e, const uint8_t *in, size_t n)
             // room for what this call adds (short streams stay small), for a whole chunk once it is half full
             size_t want = e->fill + std::min(n, cap - e->fill);
             want = std::max(want, 2 * r->h_cap[e->fill_slot]); // (geometric: many small writes, few reallocations)
-            if (want > cap / 2) want = cap;
+            // (a one-shot call's balanced chunks are shorter than the resources' chunk size; the buffers still get that
+            // size, or the next context, which fills whole chunks, would have to replace them: 2 x 384 MiB of pinned
+            // memory cost 1.5 s)
+            if (want > cap / 2) want = e->chunk_bytes ? std::max(cap, r->chunk) : cap;
             u8 *nh = nullptr;
             if (hipHostMalloc((void **)&nh, want, hipHostMallocDefault) != hipSuccess) return BZ_E_NOMEM;
             if (e->fill) memcpy(nh, r->h_in[e->fill_slot], e->fill);

@@ -257,7 +257,10 @@ __device__ __forceinline__ void stage_symbols(u32 *s_sym, const u16 *__restrict_
     }
 }
 
-__global__ __launch_bounds__(kHuffThreads, 4) void k_huffman(HuffArgs a) // (4 waves per SIMD = two workgroups per CU)
+#ifndef BZ_HUFF_WAVES
+#define BZ_HUFF_WAVES 4
+#endif
+__global__ __launch_bounds__(kHuffThreads, BZ_HUFF_WAVES) void k_huffman(HuffArgs a) // (4 waves per SIMD = two workgroups per CU)
 {
     __shared__ u8 s_len[6][kMaxAlpha + 6];
     __shared__ u32 s_rfreq[6][kMaxAlpha];
