@@ -1,8 +1,12 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2y
-timeout 200 python3 tools/e2e_time.py 1024 2>&1 | grep -v amdgpu.ids | tail -5
-timeout 600 python3 -m pytest tests -x -q -m gpu > gpurun_out/r2y/pytest.txt 2>&1; grep -n "passed\|failed" gpurun_out/r2y/pytest.txt | tail -2
-timeout 500 python3 bench.py > gpurun_out/bench_r02_final.json 2> gpurun_out/bench_r02_final.err
+mkdir -p gpurun_out/r2x
+timeout 600 python3 bench.py --gpus 2 --share-gpu --mib-per-gpu 256 --steps 2 --warmup 1 > gpurun_out/r2x/bench2.json 2> gpurun_out/r2x/bench2.err
 python3 -c "
 import json
-d=json.loads([l for l in open('gpurun_out/bench_r02_final.json') if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'], d['end_to_end'], all(d['checks'].values()))"
+line=[l for l in open('gpurun_out/r2x/bench2.json') if l.startswith('{')][-1]
+d=json.loads(line); print(d['value'], d['n_gpus'], d['checks'], (d.get('extra') or {}).get('decode',{}).get('value'))"
+timeout 600 python3 bench.py --gpus 3 --share-gpu --mib-per-gpu 128 --steps 1 --warmup 1 --transport rccl > gpurun_out/r2x/bench3.json 2> gpurun_out/r2x/bench3.err; tail -2 gpurun_out/r2x/bench3.err
+python3 -c "
+import json
+line=[l for l in open('gpurun_out/r2x/bench3.json') if l.startswith('{')][-1]
+d=json.loads(line); print(d['value'], d['n_gpus'], d['checks'], (d.get('extra') or {}).get('decode',{}).get('value'))"
