@@ -1410,9 +1410,27 @@ __global__ __launch_bounds__(kSortThreads) void k_rank_place(BwtArgs a, const u3
         }
         return;
     }
+    // (LDS accesses of one wave retire in order: no barrier between the phases of a wave's own region)
+    if (c == kRankBinSize) {
+        // a full bin (every bin of the first refinement but a block's last): 16 bytes per load and store
+        typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(W + base);
+        uint4 *dst = reinterpret_cast<uint4 *>(a.R + base);
+        u32x4 q[kRankBinSize / 256];
+#pragma unroll
+        for (u32 k = 0; k < kRankBinSize / 256; ++k) q[k] = __builtin_nontemporal_load(src + k * 64u + l);
+#pragma unroll
+        for (u32 k = 0; k < kRankBinSize / 256; ++k) {
+            const u32 x[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+            for (u32 e = 0; e < 4; ++e) mine[x[e] & kRankBinMask] = ((x[e] >> kRankBinShift) & 0xFFFFFu) | (x[e] & kFinalBit);
+        }
+#pragma unroll
+        for (u32 k = 0; k < kRankBinSize / 256; ++k) dst[k * 64u + l] = reinterpret_cast<const uint4 *>(mine)[k * 64u + l];
+        return;
+    }
     if (c < span)
         for (u32 i = l; i < span; i += 64u) mine[i] = a.R[base + i];
-    // (LDS accesses of one wave retire in order: no barrier between the phases of a wave's own region)
     for (u32 i = l; i < c; i += 64u) {
         const u32 x = ld_stream(W + base + i);
         mine[x & kRankBinMask] = ((x >> kRankBinShift) & 0xFFFFFu) | (x & kFinalBit);
