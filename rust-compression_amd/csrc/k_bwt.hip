@@ -9,8 +9,9 @@
 // A serial induced sort is the wrong shape for a GPU; this is a prefix-doubling
 // rotation sort built from LDS-tiled stable radix passes:
 //
-//   init   : the block's bytes are re-coded to b = ceil(log2(#symbols in use)) bits and c of them
-//            (c = 30/b, at most 8; 4 when b = 8) packed into one key.  Phase A sorts the rotations
+//   init   : the block's bytes are re-coded to b = ceil(log2(#symbols in use)) bits (k_pack_text keeps the
+//            block as a string of b-bit symbols, so that a key is one 8-byte load and a shift) and c of them
+//            (c = 30/b, at most 8; 4 when b = 8) make one key.  Phase A sorts the rotations
 //            by key(j) (3 LSD radix passes); phase B walks that order, i -> j = V[i]-c, and sorts
 //            the sequence stably by key(j) again (3 more passes): the result is ordered by the
 //            first 2c symbols without ever holding more than 8 bytes per element.  Text of 36
@@ -22,11 +23,13 @@
 //            sequence by R[j] (20 bits = two 10-bit passes; pass A also compacts
 //            away final rotations) yields the 2h-order inside every old group.
 //            Then flags (old group start / new group start), a max-scan, and the
-//            scatter of SA and the refined ranks.  h doubles: 2c, 4c, ...
+//            scatter of SA and the refined ranks (binned by j >> 10, put in place by k_rank_place).
+//            h doubles: 2c, 4c, ...  When fewer than a quarter of the rotations are left, a round
+//            compacts them and sorts only them (four passes over the survivors).
 //   stop   : no non-final rotation left (or h >= n: the block is periodic, finish
 //            with the closed-form tie rule).
 //
-// Everything is per-block independent; a launch covers (55 tiles) x (blocks of the
+// Everything is per-block independent; a launch covers (110 tiles of 8192) x (blocks of the
 // batch).  Tiles of one block are mapped to one XCD (bzgpu::xcd_remap) so the
 // block's 3.6 MB rank array stays in that XCD's L2 for the gathers.
 //
