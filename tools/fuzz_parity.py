@@ -204,7 +204,11 @@ while time.time() - t0 < budget:
     d = gen_case()
     lvl = rng.choice([1, 1, 1, 2, 9]) if flavour == "small" else rng.choice([9, 9, 5])
     cases += 1
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("case", cases, "len", len(d), "level", lvl, "t %.1f" % (time.time() - t0), flush=True)
     want = oracle.encode(d, lvl)
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("  oracle done t %.1f" % (time.time() - t0), flush=True)
     got = pkg.compress(d, lvl)
     if got != want:
         open("/tmp/fuzz_fail_enc.bin", "wb").write(d)

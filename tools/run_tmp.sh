@@ -1,12 +1,6 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2x
-timeout 600 python3 bench.py --gpus 2 --share-gpu --mib-per-gpu 256 --steps 2 --warmup 1 > gpurun_out/r2x/bench2.json 2> gpurun_out/r2x/bench2.err
-python3 -c "
-import json
-line=[l for l in open('gpurun_out/r2x/bench2.json') if l.startswith('{')][-1]
-d=json.loads(line); print(d['value'], d['n_gpus'], d['checks'], (d.get('extra') or {}).get('decode',{}).get('value'))"
-timeout 600 python3 bench.py --gpus 3 --share-gpu --mib-per-gpu 128 --steps 1 --warmup 1 --transport rccl > gpurun_out/r2x/bench3.json 2> gpurun_out/r2x/bench3.err; tail -2 gpurun_out/r2x/bench3.err
-python3 -c "
-import json
-line=[l for l in open('gpurun_out/r2x/bench3.json') if l.startswith('{')][-1]
-d=json.loads(line); print(d['value'], d['n_gpus'], d['checks'], (d.get('extra') or {}).get('decode',{}).get('value'))"
+(timeout 220 python3 tools/fuzz_parity.py 180 31 small 2>&1 | tail -1)
+(timeout 220 python3 tools/fuzz_parity.py 180 32 big 2>&1 | tail -1)
+(timeout 120 python3 tools/fuzz_parity.py 80 33 dstream 2>&1 | tail -1)
+(timeout 120 python3 tools/fuzz_parity.py 80 34 stream 2>&1 | tail -1)
+(BZ_DF_PART_MIB=1 timeout 150 python3 tools/fuzz_parity.py 100 35 deflate 2>&1 | tail -1)
