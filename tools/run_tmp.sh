@@ -1,6 +1,9 @@
 cd $GRAFT_REPO_ROOT
-(timeout 220 python3 tools/fuzz_parity.py 180 31 small 2>&1 | tail -1)
-(timeout 220 python3 tools/fuzz_parity.py 180 32 big 2>&1 | tail -1)
-(timeout 120 python3 tools/fuzz_parity.py 80 33 dstream 2>&1 | tail -1)
-(timeout 120 python3 tools/fuzz_parity.py 80 34 stream 2>&1 | tail -1)
-(BZ_DF_PART_MIB=1 timeout 150 python3 tools/fuzz_parity.py 100 35 deflate 2>&1 | tail -1)
+mkdir -p gpurun_out/r2y
+for t in 1 2 3 4 6; do
+BZ_TAIL_SLICES=$t timeout 200 python3 bench.py --steps 5 --warmup 2 --no-extras --no-cpu-baseline > gpurun_out/r2y/bench_q.json 2> gpurun_out/r2y/bench_q.err
+python3 -c "
+import json
+line=[l for l in open('gpurun_out/r2y/bench_q.json') if l.startswith('{')][-1]
+d=json.loads(line); print('slices $t', d['value'], d['ms_per_step'], d['checks']['stream_sha_equals_oracle_golden'], d['kernel_seconds_last_step_rank0'])"
+done
