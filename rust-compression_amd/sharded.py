@@ -89,6 +89,13 @@ class TorchComm:
             return torch.as_tensor(_DevBytes(ptr, nbytes), device=self.device)
         return self._host_bytes(ptr, nbytes)
 
+    def _settle(self):
+        """With RCCL a request's wait() only orders torch's current stream behind the transfer; the library goes on
+        on ITS stream (rank 0 assembles out of d_recv, the others write the next bit strings into d_send), so the
+        transfer has to be over when the callback returns (csrc/rccl_comm.hip ends with a stream synchronise too)."""
+        if self.wire.type == "cuda":
+            torch.cuda.synchronize(self.wire)
+
     def _guard(self, fn, *a):
         try:
             fn(*a)
@@ -125,6 +132,7 @@ class TorchComm:
                 if send_bytes:
                     for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine.to(self.wire).contiguous(), 0, self.group)]):
                         req.wait()
+                self._settle()
                 return
             offs = [int(recv_off[r]) for r in range(self.world)]
             lens = [int(recv_bytes[r]) for r in range(self.world)]
@@ -148,6 +156,7 @@ class TorchComm:
                     req.wait()
             for part, t in staged:
                 part.copy_(t)
+            self._settle()
         return self._guard(run)
 
 
