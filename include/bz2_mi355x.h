@@ -210,7 +210,10 @@ int bz_gpu_assemble(bz_gpu_engine *g, int level, size_t n_blocks,
  *   send(ctx, dst, buf, bytes) / recv(ctx, src, buf, bytes)   HOST memory, 16 bytes along the cut chain
  *   gatherv(ctx, d_send, send_bytes, d_recv, recv_off, recv_bytes)   DEVICE memory: rank r's send_bytes
  *       bytes land at d_recv + recv_off[r] on rank 0 (recv_bytes[r] == that rank's send_bytes; the
- *       two arrays are valid on every rank, d_recv only on rank 0; rank 0's own part included)
+ *       two arrays are valid on every rank, d_recv only on rank 0; rank 0's own part included).  The transfer
+ *       must be OVER when the callback returns: the library reads d_recv (rank 0) and overwrites d_send (every
+ *       rank, at its next call) on its own stream right away; a transport that queues the transfer on a stream
+ *       synchronises that stream first (an RCCL request's wait only orders streams).
  * d_packed / d_gather: optional caller-owned device buffers (e.g. registered with the transport) for
  * this rank's bit strings and, on rank 0, everybody's; NULL = the engine's own.  On rank 0 *out_len
  * receives the stream length and d_out the stream; the other ranks get *out_len = 0. */
