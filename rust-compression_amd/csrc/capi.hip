@@ -869,7 +869,7 @@ extern "C" int bz_encode_buffer(int level, int device, const uint8_t *in, size_t
         // Chunks of equal size, and an even number of them behind the first one: jobs alternate between the two
         // lanes, and a last chunk that is shorter than the others (or one too many) runs alone at the end with half
         // the GPU idle (1 GiB in 64 + 384 + 384 + 192 MiB: the last 22 ms).
-        const size_t first = (size_t)64 << 20, most = enc_chunk_bytes();
+        const size_t most = enc_chunk_bytes(), first = std::min(most, (size_t)64 << 20);
         if (in_len > first + most) {
             const size_t rest = in_len - first;
             size_t k = (rest + most - 1) / most;
