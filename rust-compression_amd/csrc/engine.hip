@@ -143,14 +143,7 @@ extern "C" int bz_gpu_engine_create(bz_gpu_engine **out, int device, size_t max_
     g->device = device;
     g->max_blocks = max_blocks_in_flight ? max_blocks_in_flight : 64;
     HIPCHK(hipStreamCreateWithFlags(&g->st, hipStreamNonBlocking));
-    {
-        // st2 carries the small serial kernels that run beside a chip-filling one on st (the chain of block cuts
-        // beside the RLE1 image): with equal priorities its single workgroup sometimes waits behind 262 144 others
-        // and takes 3.2 ms instead of 1.8
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        HIPCHK(hipStreamCreateWithPriority(&g->st2, hipStreamNonBlocking, greatest));
-    }
+    HIPCHK(hipStreamCreateWithFlags(&g->st2, hipStreamNonBlocking));
     HIPCHK(hipHostMalloc((void **)&g->h_active, 64, hipHostMallocDefault));
 
     // CRC byte table (src/crc32.rs:58-72) and powers of x
