@@ -73,6 +73,17 @@ typedef struct bz_enc bz_enc;
  * first call that has work for it. */
 int bz_enc_create(bz_enc **out, int level, int device);
 
+/* The same encoder over SEVERAL devices of one process (SURVEY.md 8(b) "Surface"; in the shims
+ * `BZip2Encoder::with_devices(level, &[0, 1, ..])`, still src/bzip2/encoder.rs:58-72 for the caller, who drives it
+ * through the unchanged Encoder::next of src/traits/encoder.rs:41-79).  Every entry of `devices` (HIP ordinals; an
+ * ordinal may be listed more than once) gets two LANES -- an engine with its own streams and buffers each; the
+ * input is cut into chunks, chunk q is uploaded to and encoded on lane q mod (2 n_devices), the unconsumed tail of a
+ * chunk's input crosses to the next lane's device (hipMemcpyPeerAsync: xGMI between the GPUs of a node), and the
+ * block bit strings are concatenated in chunk order with the BitWriter carry, the combined CRC and "a block has
+ * been written" handed from chunk to chunk on the host.  The bytes are those of bz_enc_create for any device list
+ * and any chunk size.  bz_enc_create(out, level, d) == bz_enc_create_multi(out, level, &d, 1). */
+int bz_enc_create_multi(bz_enc **out, int level, const int *devices, int n_devices);
+
 /* The input iterator yielded `n` more bytes (src/bzip2/encoder.rs:80-85,
  * EncoderInner::next :671-697).  Bytes are copied; complete blocks may be
  * encoded immediately. */
@@ -99,7 +110,17 @@ void bz_enc_destroy(bz_enc *e);
  * *out is malloc'ed by the library; release with bz_free. */
 int bz_encode_buffer(int level, int device, const uint8_t *in, size_t in_len,
                      uint8_t **out, size_t *out_len);
+/* ... over several devices (see bz_enc_create_multi).  A one-shot call knows its length: it cuts the input into
+ * equal chunks, a whole number of rounds over the lanes. */
+int bz_encode_buffer_multi(int level, const int *devices, int n_devices, const uint8_t *in, size_t in_len,
+                           uint8_t **out, size_t *out_len);
 void bz_free(void *p);
+/* Contexts and one-shot calls park their engines (batch workspace: about 31.5 MB of HBM per block of the largest
+ * chunk seen, i.e. up to ~16 GB per lane), device staging buffers and 2 x BZ_ENC_CHUNK_MIB of pinned host memory in
+ * a per-process cache (two device lists at most) when they end, so that the next one does not pay hipMalloc /
+ * hipHostMalloc again (2 x 384 MiB of pinned memory cost 1.5 s).  This call releases what is parked;
+ * BZ_ENC_NO_CACHE=1 in the environment turns the cache off. */
+void bz_release_cached_resources(void);
 
 /* ========================================================================
  * 2. Device-resident engine (what bz_enc drives; also the bench / multi-GPU
@@ -252,7 +273,9 @@ int bz_shard_comm_selftest(const bz_shard_comm *comm, int host_memory);
  * bz_gpu_encode_blocks call, by stage (HIP events on the engine's stream):
  * [0] rle1+crc+split [1] bwt [2] mtf+zle [3] huffman [4] emit+assemble [5] total. */
 int bz_gpu_last_timings(bz_gpu_engine *g, double out_seconds[6]);
-/* BWT rounds executed (prefix doubling) and total sorted elements, last call */
+/* [0] BWT rounds executed (prefix doubling), [1] total sorted elements, [2] batches of the last call; [3] sorts of
+ * this engine since its creation that fell back from the fused radix passes to the three-kernel passes (a
+ * look-back gave up or tile tickets were not handed out evenly: the engine then stays on the three-kernel passes) */
 int bz_gpu_last_bwt_stats(bz_gpu_engine *g, uint64_t out[4]);
 /* rotations still unordered after the initial 4-byte sort (out[0]) and after each doubling
  * round (out[1..]), summed over the blocks of the last encode */

@@ -600,3 +600,112 @@ DFO_EXPORT long dfo_encode(int kind, const uint8_t *in, size_t n, const uint8_t 
     dfo_enc_free(e);
     return ret;
 }
+
+/* ---------------------------------------------------------------- ZlibEncoder / GZipEncoder at the iterator level
+ * ZlibEncoder::next (zlib/encoder.rs:118-152) and GZipEncoder::next (gzip/encoder.rs:88-135), byte by byte: the
+ * header first; then the inner Inflater's bytes, pulled through a ScanIterator that feeds every input byte it
+ * passes to the checksum; at the FIRST None of the inner encoder -- whatever the Action -- the checksum is
+ * finished and the trailer follows (zlib: Adler-32 big endian; gzip: CRC-32 then ISIZE, little endian); from then
+ * on the encoder yields None without touching the caller's iterator.  So Action::Run gives header + the whole
+ * bytes of the blocks the Inflater has closed so far + trailer, Action::Flush header + the flushed segment +
+ * trailer, and every later call nothing.  No reference test drives a wrapper with Run or Flush: this part of the
+ * oracle is a restatement without a pin (like the mid-stream Flush of Inflater). */
+typedef struct dfo_wrap {
+    int kind;              /* 1 zlib, 2 gzip */
+    dfo_enc *inner;        /* Inflater */
+    size_t inner_pos;      /* bytes of the inner encoder's output already handed on */
+    uint8_t header[10];
+    unsigned header_n, header_len; /* header.len(), header_len (zlib/encoder.rs:58,126-129) */
+    int has_hash;          /* hash: Option<u32> */
+    uint32_t hash;
+    unsigned hashlen, i_size_len;
+    uint32_t i_size;
+    bytes seen;            /* what the ScanIterator's closure has been shown (adler32.write_u8 / crc32.write_u8) */
+} dfo_wrap;
+
+DFO_EXPORT dfo_wrap *dfo_wrap_new(int kind, const uint8_t *dict, size_t dict_n)
+{
+    if (kind != 1 && kind != 2) return NULL;
+    dfo_wrap *w = (dfo_wrap *)calloc(1, sizeof(dfo_wrap));
+    w->kind = kind;
+    if (kind == 1 && dict_n) { /* ZlibEncoder::with_dict zlib/encoder.rs:88-113 */
+        const uint32_t h = dfo_adler32(dict, dict_n);
+        const uint8_t hd[6] = {0x78, 0xF9, (uint8_t)(h >> 24), (uint8_t)(h >> 16), (uint8_t)(h >> 8), (uint8_t)h};
+        memcpy(w->header, hd, 6); w->header_n = w->header_len = 6;
+        w->inner = dfo_enc_new(dict, dict_n);
+    } else if (kind == 1) {    /* ZlibEncoder::new :70-86 */
+        w->header[0] = 0x78; w->header[1] = 0xDA; w->header_n = w->header_len = 2;
+        w->inner = dfo_enc_new(NULL, 0);
+    } else {                   /* GZipEncoder::new gzip/encoder.rs:66-80 */
+        static const uint8_t hd[10] = {0x1F, 0x8B, 0x08, 0, 0, 0, 0, 0, 0, 0xFF};
+        memcpy(w->header, hd, 10); w->header_n = w->header_len = 10;
+        w->inner = dfo_enc_new(NULL, 0);
+    }
+    w->hashlen = 3; w->i_size_len = 4;
+    return w;
+}
+
+DFO_EXPORT void dfo_wrap_free(dfo_wrap *w)
+{
+    if (!w) return;
+    dfo_enc_free(w->inner);
+    free(w->seen.p);
+    free(w);
+}
+
+/* `in.iter().cloned().encode(&mut wrapper, action).collect()`: the bytes until next() returns None.  *pulled =
+ * how many of the n bytes the encoder took from the iterator (all of them, or none once it is finished).
+ * Returns the byte count, or the needed capacity negated. */
+DFO_EXPORT long dfo_wrap_encode_iter(dfo_wrap *w, const uint8_t *in, size_t n, int action, uint8_t *out, size_t cap,
+                                     size_t *pulled)
+{
+    bytes o = {0, 0, 0};
+    int fed = 0;
+    if (pulled) *pulled = 0;
+    for (;;) {
+        if (w->header_len > 0) {                       /* :125-129 */
+            bytes_push(&o, w->header[w->header_n - w->header_len]);
+            w->header_len -= 1;
+        } else if (w->has_hash) {                      /* :130-136 / gzip :103-118 */
+            if (w->hashlen == 0) {
+                if (w->kind == 1 || w->i_size_len == 0) break; /* None */
+                w->i_size_len -= 1;
+                bytes_push(&o, (uint8_t)w->i_size);
+                w->i_size >>= 8;
+            } else {
+                w->hashlen -= 1;
+                if (w->kind == 1) bytes_push(&o, (uint8_t)(w->hash >> (w->hashlen << 3)));
+                else { bytes_push(&o, (uint8_t)w->hash); w->hash >>= 8; }
+            }
+        } else {
+            /* self.inflater.next(&mut ScanIterator::new(iter, ..), action) :138-145: the Inflater pulls the iterator
+             * dry before it can return None (deflate/encoder.rs:206-259), the closure sees every byte on the way */
+            if (!fed) {
+                for (size_t i = 0; i < n; i++) bytes_push(&w->seen, in[i]);
+                if (w->kind == 2) w->i_size += (uint32_t)n;
+                dfo_enc_feed(w->inner, in, n, action);
+                fed = 1;
+                if (pulled) *pulled = n;
+            }
+            const uint8_t *p;
+            const size_t m = dfo_enc_output(w->inner, &p);
+            if (w->inner_pos < m) {
+                bytes_push(&o, p[w->inner_pos++]);
+            } else {                                   /* ret.is_none() :146-150 / gzip :129-133 */
+                w->has_hash = 1;
+                if (w->kind == 1) {
+                    w->hash = dfo_adler32(w->seen.p, w->seen.n);
+                    bytes_push(&o, (uint8_t)(w->hash >> 24));
+                } else {
+                    const uint32_t h = dfo_crc32(w->seen.p, w->seen.n);
+                    bytes_push(&o, (uint8_t)h);
+                    w->hash = h >> 8;
+                }
+            }
+        }
+    }
+    long ret;
+    if (o.n <= cap) { if (o.n) memcpy(out, o.p, o.n); ret = (long)o.n; } else ret = -(long)o.n;
+    free(o.p);
+    return ret;
+}

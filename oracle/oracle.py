@@ -331,6 +331,40 @@ class DeflateEncoder:
         return [tuple(p[4 * i + k] for k in range(4)) for i in range(n)]
 
 
+class WrapperEncoder:
+    """The reference's ZlibEncoder (kind 1) / GZipEncoder (kind 2) at the iterator level:
+    encode_iter(bytes, action) == `bytes.encode(&mut enc, action).collect()`."""
+
+    def __init__(self, kind: int, dict_: bytes = b""):
+        L = lib()
+        if not hasattr(L, "_wrap_ready"):
+            L.dfo_wrap_new.restype = C.c_void_p
+            L.dfo_wrap_new.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+            L.dfo_wrap_free.restype = None
+            L.dfo_wrap_free.argtypes = [C.c_void_p]
+            L.dfo_wrap_encode_iter.restype = C.c_long
+            L.dfo_wrap_encode_iter.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint8), C.c_size_t,
+                                               C.POINTER(C.c_size_t)]
+            L._wrap_ready = True
+        self._h = L.dfo_wrap_new(kind, bytes(dict_), len(dict_))
+        self.pulled = 0  # input bytes the last encode_iter took from its iterator
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().dfo_wrap_free(self._h)
+            self._h = None
+
+    def encode_iter(self, data: bytes, action: int) -> bytes:
+        data = bytes(data)
+        cap = len(data) + len(data) // 8 + 4096
+        out = (C.c_uint8 * cap)()
+        took = C.c_size_t(0)
+        n = lib().dfo_wrap_encode_iter(self._h, data, len(data), int(action), out, cap, C.byref(took))
+        assert n >= 0, "oracle: capacity"
+        self.pulled = took.value
+        return bytes(out[:n])
+
+
 def deflate_encode(data: bytes, kind: int = DEFLATE, dict_: bytes = b"") -> bytes:
     data, dict_ = bytes(data), bytes(dict_)
     cap = len(data) + len(data) // 8 + 1024

@@ -27,7 +27,7 @@ import sys
 from . import _build
 
 __all__ = ["Action", "CompressionError", "BZip2Error", "BZip2Encoder", "BZip2Decoder", "encode", "decode",
-           "compress", "decompress", "GpuEngine",
+           "compress", "decompress", "GpuEngine", "release_cached_resources",
            "build", "lib", "device_count", "encode_bound", "rccl_lib", "rccl_unique_id", "RcclComm"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -79,7 +79,7 @@ def build(force=False):
 EXPORTS = [
     "bz_strerror", "bz_version", "bz_device_count",
     "bz_enc_create", "bz_enc_write", "bz_enc_end", "bz_enc_read", "bz_enc_pending", "bz_enc_destroy",
-    "bz_encode_buffer", "bz_free",
+    "bz_encode_buffer", "bz_free", "bz_enc_create_multi", "bz_encode_buffer_multi", "bz_release_cached_resources",
     "bz_gpu_engine_create", "bz_gpu_engine_destroy", "bz_encode_bound", "bz_gpu_encode_device",
     "bz_gpu_partition", "bz_gpu_partition_slab_begin", "bz_gpu_partition_slab_count",
     "bz_gpu_partition_slab_finish", "bz_gpu_block_count", "bz_gpu_encode_blocks", "bz_gpu_assemble", "bz_gpu_encode_sharded",
@@ -143,6 +143,10 @@ def lib():
     L.bz_enc_destroy.restype = None
     L.bz_enc_destroy.argtypes = [vp]
     L.bz_encode_buffer.argtypes = [C.c_int, C.c_int, C.c_char_p, sz, C.POINTER(u8p), szp]
+    L.bz_enc_create_multi.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int), C.c_int]
+    L.bz_encode_buffer_multi.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_char_p, sz, C.POINTER(u8p), szp]
+    L.bz_release_cached_resources.restype = None
+    L.bz_release_cached_resources.argtypes = []
     L.bz_free.restype = None
     L.bz_free.argtypes = [vp]
     L.bz_gpu_engine_create.argtypes = [C.POINTER(vp), C.c_int, sz]
@@ -306,11 +310,15 @@ class BZip2Encoder:
 
     CHUNK = 1 << 20  # bytes pulled from the input iterator per refill
 
-    def __init__(self, level=9, device=0):
+    def __init__(self, level=9, device=0, devices=None):
         if level < 1 or level > 9:
             raise ValueError("invalid level")  # the reference panics (encoder.rs:59-61)
         self._h = C.c_void_p()
-        _check(lib().bz_enc_create(C.byref(self._h), level, device))
+        if devices is None:
+            _check(lib().bz_enc_create(C.byref(self._h), level, device))
+        else:
+            devs = (C.c_int * len(devices))(*devices)
+            _check(lib().bz_enc_create_multi(C.byref(self._h), level, devs, len(devices)))
         self._buf = (C.c_uint8 * 65536)()
         self._ready = b""
         self._pos = 0
@@ -319,6 +327,12 @@ class BZip2Encoder:
         if getattr(self, "_h", None) and _LIB is not None:
             _LIB.bz_enc_destroy(self._h)
             self._h = None
+
+    @classmethod
+    def with_devices(cls, level, devices):
+        """The same encoder over several GPUs of this process (bz_enc_create_multi): chunks of the input go round
+        two lanes per listed device; the stream is the one `BZip2Encoder(level)` writes."""
+        return cls(level, devices=list(devices))
 
     def _refill(self):
         k = lib().bz_enc_read(self._h, self._buf, len(self._buf))
@@ -385,14 +399,25 @@ def encode(iterable, encoder, action):
         yield b
 
 
-def compress(data, level=9, device=0):
-    """One-shot over host buffers (bz_encode_buffer)."""
+def release_cached_resources():
+    """Frees what finished contexts parked for the next one (bz_release_cached_resources)."""
+    lib().bz_release_cached_resources()
+
+
+def compress(data, level=9, device=0, devices=None):
+    """One-shot over host buffers (bz_encode_buffer; `devices`: bz_encode_buffer_multi over that list of GPUs)."""
     if level < 1 or level > 9:
         raise ValueError("invalid level")
-    data = bytes(data)
+    if not isinstance(data, (bytes, bytearray)):
+        data = bytes(data)
+    buf = data if isinstance(data, bytes) else (C.c_char * len(data)).from_buffer(data)
     out = C.POINTER(C.c_uint8)()
     n = C.c_size_t(0)
-    _check(lib().bz_encode_buffer(level, device, data, len(data), C.byref(out), C.byref(n)))
+    if devices is None:
+        _check(lib().bz_encode_buffer(level, device, buf, len(data), C.byref(out), C.byref(n)))
+    else:
+        devs = (C.c_int * len(devices))(*devices)
+        _check(lib().bz_encode_buffer_multi(level, devs, len(devices), buf, len(data), C.byref(out), C.byref(n)))
     try:
         return C.string_at(out, n.value)
     finally:

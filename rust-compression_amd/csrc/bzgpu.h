@@ -247,6 +247,8 @@ struct BwtArgs {
     u32 *tickets;                    // [kSortEpochs][8] tile tickets per pass and XCD
     u32 *sort_err;                   // [1] a look-back that gave up
     u32 *epoch;                      // host: the engine's pass counter (1 .. kSortEpochs-1)
+    u32 *fused_state;                // host, per engine: [0] != 0: the fused passes misbehaved once and stay off for
+                                     //   this engine, [1] sorts that fell back to the three-kernel passes
     u32 *tile_state_all;             // host: whole look-back buffer (cleared when the counter wraps)
     u32 fused;                       // 1: use the fused passes (BZ_ONESWEEP=1); 0: histogram + scan + scatter
     size_t tile_state_bytes;

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -50,45 +51,53 @@ extern "C" const char *bz_strerror(int code)
 extern "C" const char *bz_version(void) { return "bz2_mi355x 0.1 (gfx950)"; }
 
 // ---- the pipeline behind a context -------------------------------------------------------------
-// Host bytes reach the GPU in CHUNKS (BZ_ENC_CHUNK_MIB, default 384 MiB, the first one of a stream 64 MiB: a
+// Host bytes reach the GPUs in CHUNKS (BZ_ENC_CHUNK_MIB, default 384 MiB, the first one of a stream 64 MiB: a
 // large batch keeps the latency-bound stages -- one workgroup per block in the Huffman stage -- a small share
 // of a job; measured on 1 GiB with one lane: 64 MiB chunks 4.6 GB/s host to host, 128 MiB 5.9, 256 MiB 6.5)
-// through two pinned staging
-// buffers: bz_enc_write copies the caller's bytes into the pinned buffer being filled (the only CPU
-// copy; pieces of 4 MiB or more are split over up to four threads) and, when it is full, starts its
-// upload (hipMemcpyAsync on a copy stream) into a device staging buffer and hands the chunk to the
-// context's WORKER thread.  The worker puts the unconsumed tail of the previous chunk and the new
-// chunk side by side in device memory, replays the reference's write_block calls for them on the
-// engine (process), downloads the stream bytes through a pinned buffer and appends them to the
-// output queue.  So the upload of chunk k+1 (DMA) and the copy of chunk k+2 (CPU, caller's thread) run
-// beside the encode of chunk k; bz_enc_read hands out whatever is complete.  bz_enc_end submits the
-// partial chunk with the caller's Action and waits for the worker, so that everything the
-// reference's iterator would have yielded by then is readable.  One-shot calls (bz_encode_buffer) run
-// the same pipeline; engines and buffers of destroyed contexts are kept for the next one (a
-// per-device cache), so a call does not pay hipMalloc / hipHostMalloc again.
-struct EncResources {
+// through two pinned staging buffers: bz_enc_write copies the caller's bytes into the pinned buffer being
+// filled (the only CPU copy; pieces of 4 MiB or more are split over threads, four per device) and, when it is
+// full, starts its upload (hipMemcpyAsync on the lane's copy stream) into the device staging buffer of the LANE
+// the chunk's job will run on and hands the chunk to that lane's worker thread.
+//
+// A context drives one or several devices (bz_enc_create_multi): every entry of the caller's device list gets
+// TWO lanes (an engine with its own streams and buffers each), lane l lives on devices[l mod n_devices], and job
+// q runs on lane q mod (2 n_devices) -- consecutive jobs go to different devices, and the latency-bound tail of
+// one job's encode (Huffman: one workgroup per block) runs beside the bandwidth-bound sort of the job that
+// shares its device.  A job puts the unconsumed tail of the previous job's input (it lies in the previous lane's
+// buffer: a device-to-device copy, across xGMI with hipMemcpyPeerAsync when the lanes sit on different devices)
+// and its chunk side by side in device memory, replays the reference's write_block calls for them on its engine,
+// downloads the stream bytes through a pinned buffer and hands them to the drainer thread, which appends them
+// to the output queue in job order.  So the upload of chunk k+1 (DMA) and the copy of chunk k+2 (CPU, caller's
+// thread) run beside the encode of chunk k; bz_enc_read hands out whatever is complete.  bz_enc_end submits the
+// partial chunk with the caller's Action and waits for that job, so that everything the reference's iterator
+// would have yielded by then is readable.  One-shot calls (bz_encode_buffer[_multi]) run the same pipeline;
+// engines and buffers of destroyed contexts are kept for the next one (a cache keyed by the device list; see
+// bz_release_cached_resources), so a call does not pay hipMalloc / hipHostMalloc again.
+struct Lane {
     int device = 0;
-    // Two LANES: jobs alternate between them (two engines, each with its own streams and buffers), so
-    // that the latency-bound tail of one chunk's encode (Huffman: one workgroup per block) runs beside
-    // the bandwidth-bound sort of the next.  The second engine is created when a second job is in flight.
-    bz_gpu_engine *g[2] = {nullptr, nullptr};
+    bz_gpu_engine *g = nullptr;  // created when the lane gets its first job
+    void *d_stage = nullptr;     // the chunk as uploaded
+    size_t stage_cap = 0;
+    void *d_buf = nullptr;       // composed input = tail of the previous job's input + the chunk
+    size_t d_buf_cap = 0;
+    void *d_out = nullptr;
+    size_t d_out_cap = 0;
+    void *d_packed = nullptr;
+    size_t d_packed_cap = 0;
+    u8 *h_out = nullptr;         // pinned: stream bytes on their way to the output queue
+    size_t h_out_cap = 0;
+    hipStream_t st_up = nullptr, st_io = nullptr;
+    hipEvent_t ev_up = nullptr;  // the lane's last upload
+};
+
+struct EncResources {
+    std::vector<int> devices;    // as the caller listed them (a device may appear more than once: more lanes on it)
+    std::vector<Lane> lanes;     // 2 per entry of `devices`; lane l -> devices[l % devices.size()]
     size_t engine_blocks = 0;
-    size_t chunk = 0;            // bytes per pinned / device staging buffer
-    u8 *h_in[2] = {nullptr, nullptr};   // pinned; sized by the chunks they have held (h_cap)
+    size_t chunk = 0;            // bytes per chunk (BZ_ENC_CHUNK_MIB)
+    u8 *h_in[2] = {nullptr, nullptr};   // pinned (portable), sized by the chunks they have held (h_cap)
     size_t h_cap[2] = {0, 0};
-    void *d_stage[2] = {nullptr, nullptr};
-    size_t stage_cap[2] = {0, 0};
-    void *d_buf[2] = {nullptr, nullptr}; // per lane: composed input = tail of the previous job's input + the chunk
-    size_t d_buf_cap[2] = {0, 0};
-    void *d_out[2] = {nullptr, nullptr};
-    size_t d_out_cap[2] = {0, 0};
-    void *d_packed[2] = {nullptr, nullptr};
-    size_t d_packed_cap[2] = {0, 0};
-    u8 *h_out[2] = {nullptr, nullptr};   // pinned: stream bytes on their way to the output queue
-    size_t h_out_cap[2] = {0, 0};
-    hipStream_t st_up = nullptr, st_io[2] = {nullptr, nullptr};
-    hipEvent_t ev_up[2] = {nullptr, nullptr};
-    hipEvent_t ev_down[2] = {nullptr, nullptr};
+    int h_lane[2] = {-1, -1};    // the lane a pinned buffer was uploaded to last (its ev_up tells when the buffer is free)
 };
 
 static bool enc_trace()
@@ -120,54 +129,64 @@ static size_t enc_chunk_bytes()
 static void resources_free(EncResources *r)
 {
     if (!r) return;
-    (void)hipSetDevice(r->device);
-    for (int i = 0; i < 2; ++i) {
-        if (r->h_in[i]) (void)hipHostFree(r->h_in[i]);
-        if (r->d_stage[i]) (void)hipFree(r->d_stage[i]);
-        if (r->d_buf[i]) (void)hipFree(r->d_buf[i]);
-        if (r->ev_up[i]) (void)hipEventDestroy(r->ev_up[i]);
-        if (r->ev_down[i]) (void)hipEventDestroy(r->ev_down[i]);
-        if (r->h_out[i]) (void)hipHostFree(r->h_out[i]);
-        if (r->d_out[i]) (void)hipFree(r->d_out[i]);
-        if (r->d_packed[i]) (void)hipFree(r->d_packed[i]);
-        if (r->st_io[i]) (void)hipStreamDestroy(r->st_io[i]);
-        if (r->g[i]) bz_gpu_engine_destroy(r->g[i]);
+    for (Lane &l : r->lanes) {
+        (void)hipSetDevice(l.device);
+        if (l.d_stage) (void)hipFree(l.d_stage);
+        if (l.d_buf) (void)hipFree(l.d_buf);
+        if (l.ev_up) (void)hipEventDestroy(l.ev_up);
+        if (l.h_out) (void)hipHostFree(l.h_out);
+        if (l.d_out) (void)hipFree(l.d_out);
+        if (l.d_packed) (void)hipFree(l.d_packed);
+        if (l.st_io) (void)hipStreamDestroy(l.st_io);
+        if (l.st_up) (void)hipStreamDestroy(l.st_up);
+        if (l.g) bz_gpu_engine_destroy(l.g);
     }
-    if (r->st_up) (void)hipStreamDestroy(r->st_up);
+    for (int i = 0; i < 2; ++i)
+        if (r->h_in[i]) (void)hipHostFree(r->h_in[i]);
     delete r;
 }
 
-static int resources_get(int device, EncResources **out)
+static int resources_get(const std::vector<int> &devices, EncResources **out)
 {
     *out = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         for (size_t i = 0; i < g_cache.size(); ++i)
-            if (g_cache[i]->device == device && g_cache[i]->chunk == enc_chunk_bytes()) {
+            if (g_cache[i]->devices == devices && g_cache[i]->chunk == enc_chunk_bytes()) {
                 *out = g_cache[i];
                 g_cache.erase(g_cache.begin() + (ptrdiff_t)i);
                 return BZ_OK;
             }
     }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BZ_E_NOGPU;
+    for (int d : devices)
+        if (d < 0 || d >= ndev) return BZ_E_PARAM;
     EncResources *r = new EncResources();
-    r->device = device;
+    r->devices = devices;
     r->chunk = enc_chunk_bytes();
     // blocks in flight: a chunk of level-9 text is chunk / 0.9 MB blocks (lower levels and run-heavy
     // inputs take several batches)
     r->engine_blocks = r->chunk / 800000 + 16;
-    int rc = bz_gpu_engine_create(&r->g[0], device, r->engine_blocks);
-    if (rc != BZ_OK) {
-        delete r;
-        return rc;
+    r->lanes.resize(2 * devices.size());
+    bool ok = true;
+    for (size_t l = 0; l < r->lanes.size() && ok; ++l) { // (engines and buffers come with the jobs: job_split, grow)
+        Lane &ln = r->lanes[l];
+        ln.device = devices[l % devices.size()];
+        ok = ok && hipSetDevice(ln.device) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&ln.ev_up, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&ln.st_up, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&ln.st_io, hipStreamNonBlocking) == hipSuccess;
     }
-    bool ok = hipSetDevice(device) == hipSuccess;
-    for (int i = 0; i < 2 && ok; ++i) { // (pinned and device staging buffers come with the chunks: grow / grow_pinned)
-        ok = ok && hipEventCreateWithFlags(&r->ev_up[i], hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&r->ev_down[i], hipEventDisableTiming) == hipSuccess;
-    }
-    ok = ok && hipStreamCreateWithFlags(&r->st_up, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&r->st_io[0], hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&r->st_io[1], hipStreamNonBlocking) == hipSuccess;
+    // the tail of a job's input crosses to the next lane's device: direct access where the fabric offers it
+    // (hipMemcpyPeerAsync works without, through the host)
+    for (size_t a = 0; a < devices.size() && ok; ++a)
+        for (size_t b = 0; b < devices.size(); ++b) {
+            int can = 0;
+            if (devices[a] == devices[b] || hipDeviceCanAccessPeer(&can, devices[a], devices[b]) != hipSuccess || !can) continue;
+            if (hipSetDevice(devices[a]) == hipSuccess) (void)hipDeviceEnablePeerAccess(devices[b], 0);
+            (void)hipGetLastError(); // (already enabled: not an error worth keeping)
+        }
     if (!ok) {
         resources_free(r);
         return BZ_E_NOMEM;
@@ -179,35 +198,55 @@ static int resources_get(int device, EncResources **out)
 static void resources_put(EncResources *r)
 {
     if (!r) return;
+    static const bool no_cache = getenv("BZ_ENC_NO_CACHE") != nullptr;
     std::lock_guard<std::mutex> lk(g_cache_mu);
-    if (g_cache.size() < 2) g_cache.push_back(r);
+    if (!no_cache && g_cache.size() < 2) g_cache.push_back(r);
     else resources_free(r);
 }
 
+// What a finished context leaves behind for the next one -- engines with their batch workspace (about 31.5 MB per
+// block of the largest job seen), device staging buffers, 2 x chunk of pinned host memory -- is released here.
+extern "C" void bz_release_cached_resources(void)
+{
+    std::vector<EncResources *> all;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        all.swap(g_cache);
+    }
+    for (EncResources *r : all) resources_free(r);
+}
+
 struct EncJob {
-    u64 seq;         // number of the job in the stream; its lane is seq & 1
-    int slot;        // pinned / staging buffer holding the chunk (-1: no data, only the Action)
-    size_t n;        // bytes of the chunk
+    u64 seq;         // number of the job in the stream; its lane is seq mod (number of lanes)
+    int slot;        // pinned buffer that held the chunk (-1: no data, only the Action)
+    size_t n;        // bytes of the chunk (uploaded to the lane's staging buffer)
     int mode;        // BZ_ACTION_*
     size_t tail_run; // length of the run of equal bytes at the chunk's end (n: the chunk is one run)
 };
 
+struct Drain {
+    int lane;
+    size_t bytes;
+};
+
 struct bz_enc {
     int level = 9;
-    int device = 0;
+    std::vector<int> devices;
     EncResources *r = nullptr;
+    size_t n_lanes = 0;
     // output queue: a malloc'ed byte buffer (the drainer thread appends, bz_enc_read takes from the front;
     // realloc grows it -- the kernel remaps large blocks instead of copying them -- and the one-shot call
     // hands the buffer itself to its caller)
     std::mutex out_mu;
     u8 *out = nullptr;
     size_t out_len = 0, out_cap = 0, out_head = 0;
-    // stream bytes leave the device through two pinned buffers: the worker starts the download of a
-    // chunk's bytes and goes on with the next chunk; the drainer waits for it and appends
+    // stream bytes leave a device through its lane's pinned buffer: the worker downloads a job's bytes (outside
+    // the serial assembly section: the next job assembles meanwhile) and posts them; the drainer appends the
+    // posts in job order
     std::thread drainer;
-    std::deque<std::pair<int, size_t>> drains; // (pinned buffer, bytes)
-    u64 drained = 0, drain_queued = 0;
-    bool drain_busy[2] = {false, false}; // a lane's pinned output buffer is waiting for the drainer
+    std::map<u64, Drain> drains; // job number -> (lane, bytes); every job posts one (0 bytes: nothing came out)
+    u64 drained = 0;             // jobs whose bytes are in the output queue (== the next job number the drainer takes)
+    std::vector<char> drain_busy; // per lane: its pinned output buffer is waiting for the drainer
     // reference state (owned by the worker while jobs are in flight)
     bool finished = false;       // BZip2Encoder.finished      (encoder.rs:45)
     bool bit_finished = false;   // BZip2Encoder.bit_finished  (encoder.rs:48)
@@ -224,22 +263,21 @@ struct bz_enc {
     size_t fill = 0;
     u64 chunks_filled = 0;       // chunks handed over so far
     size_t chunk_bytes = 0;      // 0: the resources' chunk size; a one-shot call knows its length and balances them
-    u64 submitted = 0;           // data chunks handed to the worker
     // Chain state 1 (handed from a job's SPLIT phase to the next job's): the unconsumed input lies in
-    // d_buf[tail_lane], `tail_len` bytes at offset `tail_off`; finish_seen: a Finish job has been split
+    // lanes[tail_lane].d_buf, `tail_len` bytes at offset `tail_off`; finish_seen: a Finish job has been split
     int tail_lane = 0;
     size_t tail_off = 0, tail_len = 0;
     bool finish_seen = false;
     u64 split_done = 0; // jobs whose split phase is over
     u64 asm_done = 0;   // jobs whose assembly phase is over (chain state 2: carry bits, combined CRC, any_block)
     // workers: one per lane
-    std::thread worker[2];
+    std::vector<std::thread> worker;
     std::mutex mu;
     std::condition_variable cv;
     std::deque<EncJob> jobs;
-    u64 composed = 0;            // data chunks whose staging buffer the worker has released
-    u64 done = 0, queued = 0;    // jobs finished / queued
-    bool stop = false;
+    std::vector<u64> lane_uploads, lane_composed; // per lane: chunks uploaded to its staging buffer / released by its worker
+    u64 queued = 0;              // jobs queued
+    bool stop = false, drain_stop = false;
     int err = BZ_OK;             // sticky
 };
 
@@ -261,7 +299,7 @@ static int grow_pinned(u8 **p, size_t *cap, size_t want)
     *p = nullptr;
     *cap = 0;
     const size_t sz = want + want / 4 + 4096;
-    if (hipHostMalloc((void **)p, sz, hipHostMallocDefault) != hipSuccess) return BZ_E_NOMEM;
+    if (hipHostMalloc((void **)p, sz, hipHostMallocPortable) != hipSuccess) return BZ_E_NOMEM;
     *cap = sz;
     return BZ_OK;
 }
@@ -272,7 +310,7 @@ static inline u32 rotl1(u32 v) { return (v << 1) | (v >> 31); }
 // every 255 bytes from its start (encoder.rs:676-690).  `tail_run` bytes at the end are known to be
 // equal (the caller scanned its chunk); only when that covers the whole chunk does the run reach
 // back into bytes that exist on the device alone, which are then fetched in windows from the end.
-static int pending_chunk_start(bz_enc *e, const u8 *d, size_t n, size_t chunk_n, size_t tail_run, size_t *start)
+static int pending_chunk_start(const u8 *d, size_t n, size_t chunk_n, size_t tail_run, size_t *start)
 {
     *start = 0;
     if (n == 0) return BZ_OK;
@@ -297,14 +335,13 @@ static int pending_chunk_start(bz_enc *e, const u8 *d, size_t n, size_t chunk_n,
         }
         run = n - pos;
     }
-    (void)e;
     const size_t rs = n - run;
     const size_t q = n - 1 - rs;
     *start = n - 1 - (q % 255);
     return BZ_OK;
 }
 
-static void copy_in(u8 *dst, const u8 *src, size_t n);
+static void copy_in(u8 *dst, const u8 *src, size_t n, size_t n_devices);
 
 // appends to the output queue (out_mu held by the caller)
 static int out_append_locked(bz_enc *e, const u8 *p, size_t n)
@@ -324,7 +361,7 @@ static int out_append_locked(bz_enc *e, const u8 *p, size_t n)
             e->out_cap = want;
         }
     }
-    copy_in(e->out + e->out_len, p, n); // (large pieces on several threads)
+    copy_in(e->out + e->out_len, p, n, e->devices.size()); // (large pieces on several threads)
     e->out_len += n;
     return BZ_OK;
 }
@@ -354,23 +391,24 @@ static void reserve_output(bz_enc *e, size_t expect)
 static void drainer_main(bz_enc *e)
 {
     for (;;) {
-        std::pair<int, size_t> d;
+        Drain d;
         {
             std::unique_lock<std::mutex> lk(e->mu);
-            e->cv.wait(lk, [&] { return e->stop || !e->drains.empty(); });
-            if (e->drains.empty()) return; // stop
-            d = e->drains.front();
-            e->drains.pop_front();
+            e->cv.wait(lk, [&] { return e->drain_stop || e->drains.count(e->drained) != 0; });
+            auto it = e->drains.find(e->drained);
+            if (it == e->drains.end()) return; // stop (the workers have gone: nothing more will be posted)
+            d = it->second;
+            e->drains.erase(it);
         }
-        int rc;
-        {
+        int rc = BZ_OK;
+        if (d.bytes) {
             std::lock_guard<std::mutex> lk(e->out_mu);
-            rc = out_append_locked(e, e->r->h_out[d.first], d.second);
+            rc = out_append_locked(e, e->r->lanes[(size_t)d.lane].h_out, d.bytes);
         }
         {
             std::lock_guard<std::mutex> lk(e->mu);
             if (rc != BZ_OK && e->err == BZ_OK) e->err = rc;
-            e->drain_busy[d.first] = false;
+            if (d.bytes) e->drain_busy[(size_t)d.lane] = 0;
             e->drained += 1;
         }
         e->cv.notify_all();
@@ -384,23 +422,34 @@ static void drainer_main(bz_enc *e)
 //             split on the lane's engine.  Serial from job to job: it needs the previous job's tail and
 //             hands its own on (chain state 1).
 //   ENCODE    the blocks (rotation sort, MTF, Huffman, bit emission).  Independent of every other job:
-//             two jobs (one per lane) are in this phase at the same time.
+//             as many jobs as there are lanes are in this phase at the same time.
 //   ASSEMBLE  concatenate the block bit strings behind the stream so far (BitWriter carry, combined
-//             CRC, "has a block been written": chain state 2), download, queue for the output.
-//             Serial from job to job.
+//             CRC, "has a block been written": chain state 2).  Serial from job to job.
+//   DOWNLOAD  device -> the lane's pinned buffer -> (drainer thread, in job order) the output queue.
 struct JobState {
     const u8 *d = nullptr;
     size_t n_all = 0, n_eff = 0, n_blocks = 0, consumed = 0;
+    size_t out_len = 0;
     int tail = 0;
     bool skipped = false; // input after Finish
     std::vector<uint64_t> woff, blen;
     std::vector<uint32_t> crc;
-    double t0 = 0, t1 = 0, t2 = 0;
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
 };
+
+static void chunk_composed(bz_enc *e, int lane)
+{
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        e->lane_composed[(size_t)lane] += 1; // the lane's staging buffer may take the next upload
+    }
+    e->cv.notify_all();
+}
 
 static int job_split(bz_enc *e, const EncJob &j, int lane, JobState &js)
 {
     EncResources *r = e->r;
+    Lane &ln = r->lanes[(size_t)lane];
     if (e->finish_seen) {
         // Input that arrives after Finish is not encoded.  (The reference keeps collecting it, EncoderInner::next
         // has no `finished` test, encoder.rs:671-697, and would write further blocks BEHIND the trailer once
@@ -408,56 +457,48 @@ static int job_split(bz_enc *e, const EncJob &j, int lane, JobState &js)
         // .bz2 stream; the corner is not mirrored -- documented in INTEGRATION.md.)
         js.skipped = true;
         if (j.n) {
-            if (hipEventSynchronize(r->ev_up[j.slot]) != hipSuccess) return BZ_E_UNEXPECTED;
-            {
-                std::lock_guard<std::mutex> lk(e->mu);
-                e->composed += 1;
-            }
-            e->cv.notify_all();
+            if (hipEventSynchronize(ln.ev_up) != hipSuccess) return BZ_E_UNEXPECTED;
+            chunk_composed(e, lane);
         }
         return BZ_OK;
     }
-    if (!r->g[lane]) { // the second lane's engine: created when a second job is in flight
-        const int rc = bz_gpu_engine_create(&r->g[lane], e->device, r->engine_blocks);
+    if (!ln.g) { // a lane's engine is created when the lane gets its first job
+        const int rc = bz_gpu_engine_create(&ln.g, ln.device, r->engine_blocks);
         if (rc != BZ_OK) return rc;
     }
     js.t0 = now_ms();
     js.n_all = e->tail_len + j.n;
     if (js.n_all) {
         // compose: the unconsumed tail of the previous job's input, then the new chunk
-        int rc = grow(&r->d_buf[lane], &r->d_buf_cap[lane], js.n_all + 64);
+        int rc = grow(&ln.d_buf, &ln.d_buf_cap, js.n_all + 64);
         if (rc != BZ_OK) return rc;
-        hipStream_t st = r->st_io[lane];
-        // (consecutive jobs run on different lanes, so the tail always comes from the other lane's buffer; that job
+        hipStream_t st = ln.st_io;
+        // (consecutive jobs run on different lanes, so the tail always comes from another lane's buffer; that job
         // may still be encoding -- it only reads its RLE1 image by then)
         if (e->tail_len && e->tail_lane == lane) return BZ_E_UNEXPECTED;
-        if (e->tail_len &&
-            hipMemcpyAsync(r->d_buf[lane], (const u8 *)r->d_buf[e->tail_lane] + e->tail_off, e->tail_len,
-                           hipMemcpyDeviceToDevice, st) != hipSuccess)
-            return BZ_E_UNEXPECTED;
+        if (e->tail_len) {
+            const Lane &from = r->lanes[(size_t)e->tail_lane];
+            const u8 *src = (const u8 *)from.d_buf + e->tail_off;
+            const hipError_t ce = from.device == ln.device
+                                      ? hipMemcpyAsync(ln.d_buf, src, e->tail_len, hipMemcpyDeviceToDevice, st)
+                                      : hipMemcpyPeerAsync(ln.d_buf, ln.device, src, from.device, e->tail_len, st); // xGMI
+            if (ce != hipSuccess) return BZ_E_UNEXPECTED;
+        }
         if (j.n) {
-            if (hipStreamWaitEvent(st, r->ev_up[j.slot], 0) != hipSuccess) return BZ_E_UNEXPECTED;
-            if (hipMemcpyAsync((u8 *)r->d_buf[lane] + e->tail_len, r->d_stage[j.slot], j.n, hipMemcpyDeviceToDevice, st) !=
-                hipSuccess)
+            if (hipStreamWaitEvent(st, ln.ev_up, 0) != hipSuccess) return BZ_E_UNEXPECTED;
+            if (hipMemcpyAsync((u8 *)ln.d_buf + e->tail_len, ln.d_stage, j.n, hipMemcpyDeviceToDevice, st) != hipSuccess)
                 return BZ_E_UNEXPECTED;
         }
         if (hipStreamSynchronize(st) != hipSuccess) return BZ_E_UNEXPECTED;
-        if (j.n) {
-            {
-                std::lock_guard<std::mutex> lk(e->mu);
-                e->composed += 1; // the staging buffer may take the next upload
-            }
-            e->cv.notify_all();
-        }
-        js.d = (const u8 *)r->d_buf[lane];
+        if (j.n) chunk_composed(e, lane);
+        js.d = (const u8 *)ln.d_buf;
     }
     js.n_eff = js.n_all;
     int rc;
-    if (j.mode != BZ_ACTION_FINISH &&
-        (rc = pending_chunk_start(e, js.d, js.n_all, j.n, j.tail_run, &js.n_eff)) != BZ_OK)
+    if (j.mode != BZ_ACTION_FINISH && (rc = pending_chunk_start(js.d, js.n_all, j.n, j.tail_run, &js.n_eff)) != BZ_OK)
         return rc;
     if (js.n_eff > 0) {
-        rc = bz_gpu_partition(r->g[lane], e->level, js.d, js.n_eff, j.mode, &js.n_blocks, &js.consumed, &js.tail);
+        rc = bz_gpu_partition(ln.g, e->level, js.d, js.n_eff, j.mode, &js.n_blocks, &js.consumed, &js.tail);
         if (rc != BZ_OK) return rc;
     }
     js.t1 = now_ms();
@@ -466,16 +507,18 @@ static int job_split(bz_enc *e, const EncJob &j, int lane, JobState &js)
     if (j.mode == BZ_ACTION_RUN) drop = js.n_blocks ? js.consumed : 0;
     else if (j.mode == BZ_ACTION_FLUSH) drop = js.n_eff;
     else drop = js.n_all;
-    e->tail_lane = lane;
-    e->tail_off = drop;
-    e->tail_len = js.n_all - drop;
+    if (js.n_all) { // (a job without any input leaves the tail where it is)
+        e->tail_lane = lane;
+        e->tail_off = drop;
+        e->tail_len = js.n_all - drop;
+    }
     if (j.mode == BZ_ACTION_FINISH) e->finish_seen = true;
     return BZ_OK;
 }
 
 static int job_encode(bz_enc *e, int lane, JobState &js)
 {
-    EncResources *r = e->r;
+    Lane &ln = e->r->lanes[(size_t)lane];
     if (js.skipped || js.n_blocks == 0) {
         js.t2 = now_ms();
         return BZ_OK;
@@ -484,18 +527,17 @@ static int job_encode(bz_enc *e, int lane, JobState &js)
     js.blen.resize(js.n_blocks);
     js.crc.resize(js.n_blocks);
     const size_t cap_words = bz_encode_bound(js.n_eff) / 4 + 2 * js.n_blocks + 16;
-    int rc = grow(&r->d_packed[lane], &r->d_packed_cap[lane], cap_words * 4);
+    int rc = grow(&ln.d_packed, &ln.d_packed_cap, cap_words * 4);
     if (rc != BZ_OK) return rc;
     size_t used = 0;
-    rc = bz_gpu_encode_blocks(r->g[lane], 0, 1, r->d_packed[lane], cap_words, js.woff.data(), js.blen.data(), js.crc.data(),
-                              &used);
+    rc = bz_gpu_encode_blocks(ln.g, 0, 1, ln.d_packed, cap_words, js.woff.data(), js.blen.data(), js.crc.data(), &used);
     js.t2 = now_ms();
     return rc;
 }
 
 static int job_assemble(bz_enc *e, const EncJob &j, int lane, JobState &js)
 {
-    EncResources *r = e->r;
+    Lane &ln = e->r->lanes[(size_t)lane];
     const int mode = j.mode;
     const size_t n_blocks = js.n_blocks;
     if (js.skipped) return BZ_OK;
@@ -514,36 +556,14 @@ static int job_assemble(bz_enc *e, const EncJob &j, int lane, JobState &js)
     for (size_t k = 0; k < n_blocks; ++k) bits_bound += (size_t)js.blen[k];
     const size_t out_cap = bits_bound / 8 + 64;
     int rc;
-    if ((rc = grow(&r->d_out[lane], &r->d_out_cap[lane], out_cap)) != BZ_OK) return rc;
-    size_t out_len = 0;
+    if (!ln.g && (rc = bz_gpu_engine_create(&ln.g, ln.device, e->r->engine_blocks)) != BZ_OK) return rc; // (an Action-only first job)
+    if ((rc = grow(&ln.d_out, &ln.d_out_cap, out_cap)) != BZ_OK) return rc;
     unsigned ocb = 0, ocy = 0;
     u32 comb_out = comb;
-    rc = bz_gpu_assemble(r->g[lane], e->level, n_blocks, r->d_packed[lane], js.woff.data(), js.blen.data(), js.crc.data(),
-                         write_header, trailer, 0, e->carry_bits, e->carry_byte, comb, &comb_out, r->d_out[lane],
-                         r->d_out_cap[lane], &out_len, &ocb, &ocy);
+    rc = bz_gpu_assemble(ln.g, e->level, n_blocks, ln.d_packed, js.woff.data(), js.blen.data(), js.crc.data(), write_header,
+                         trailer, 0, e->carry_bits, e->carry_byte, comb, &comb_out, ln.d_out, ln.d_out_cap, &js.out_len, &ocb,
+                         &ocy);
     if (rc != BZ_OK) return rc;
-    if (out_len) {
-        // device -> the lane's pinned buffer (free again once the drainer has appended the lane's previous
-        // bytes), then over to the drainer thread, which appends to the output queue while the workers go on
-        {
-            std::unique_lock<std::mutex> lk(e->mu);
-            e->cv.wait(lk, [&] { return !e->drain_busy[lane]; });
-        }
-        if ((rc = grow_pinned(&r->h_out[lane], &r->h_out_cap[lane], out_len)) != BZ_OK) return rc;
-        if (hipMemcpyAsync(r->h_out[lane], r->d_out[lane], out_len, hipMemcpyDeviceToHost, r->st_io[lane]) != hipSuccess ||
-            hipStreamSynchronize(r->st_io[lane]) != hipSuccess)
-            return BZ_E_UNEXPECTED;
-        {
-            std::lock_guard<std::mutex> lk(e->mu);
-            e->drain_busy[lane] = true;
-            e->drains.emplace_back(lane, out_len);
-            e->drain_queued += 1;
-        }
-        e->cv.notify_all();
-    }
-    if (enc_trace())
-        fprintf(stderr, "bz_enc job %llu (lane %d): mode %d, %zu bytes, %zu blocks: split %.2f ms, encode %.2f ms, assemble+download %.2f ms (at %.1f)\n",
-                (unsigned long long)j.seq, lane, mode, js.n_all, n_blocks, js.t1 - js.t0, js.t2 - js.t1, now_ms() - js.t2, now_ms());
     e->carry_bits = ocb;
     e->carry_byte = ocy;
     if (final_call_empty && n_blocks > 0) comb_out = rotl1(comb_out); // the extra, empty write_block(false)
@@ -553,20 +573,38 @@ static int job_assemble(bz_enc *e, const EncJob &j, int lane, JobState &js)
     return BZ_OK;
 }
 
-// worker of one lane: takes the jobs whose number has its parity
+// device -> the lane's pinned buffer (free again once the drainer has appended the lane's previous bytes)
+static int job_download(bz_enc *e, int lane, JobState &js)
+{
+    Lane &ln = e->r->lanes[(size_t)lane];
+    if (js.out_len == 0) return BZ_OK;
+    {
+        std::unique_lock<std::mutex> lk(e->mu);
+        e->cv.wait(lk, [&] { return !e->drain_busy[(size_t)lane]; });
+    }
+    int rc;
+    if ((rc = grow_pinned(&ln.h_out, &ln.h_out_cap, js.out_len)) != BZ_OK) return rc;
+    if (hipMemcpyAsync(ln.h_out, ln.d_out, js.out_len, hipMemcpyDeviceToHost, ln.st_io) != hipSuccess ||
+        hipStreamSynchronize(ln.st_io) != hipSuccess)
+        return BZ_E_UNEXPECTED;
+    return BZ_OK;
+}
+
+// worker of one lane: takes the jobs whose number is the lane's modulo the number of lanes
 static void worker_main(bz_enc *e, int lane)
 {
+    const u64 nl = (u64)e->n_lanes;
     for (;;) {
         EncJob j;
         {
             std::unique_lock<std::mutex> lk(e->mu);
-            e->cv.wait(lk, [&] { return e->stop || (!e->jobs.empty() && (int)(e->jobs.front().seq & 1u) == lane); });
-            if (e->jobs.empty() || (int)(e->jobs.front().seq & 1u) != lane) return; // stop
+            e->cv.wait(lk, [&] { return e->stop || (!e->jobs.empty() && (int)(e->jobs.front().seq % nl) == lane); });
+            if (e->jobs.empty() || (int)(e->jobs.front().seq % nl) != lane) return; // stop
             j = e->jobs.front();
             e->jobs.pop_front();
         }
-        e->cv.notify_all(); // (the other lane may find its job at the front now)
-        (void)hipSetDevice(e->device);
+        e->cv.notify_all(); // (another lane may find its job at the front now)
+        (void)hipSetDevice(e->r->lanes[(size_t)lane].device);
         JobState js;
         int rc;
         // SPLIT, in job order
@@ -579,11 +617,12 @@ static void worker_main(bz_enc *e, int lane)
         {
             std::lock_guard<std::mutex> lk(e->mu);
             if (rc != BZ_OK && e->err == BZ_OK) e->err = rc;
-            if (rc != BZ_OK && j.n) e->composed = e->submitted; // nobody waits for a staging buffer of a failed context
+            // nobody waits for a staging buffer of a failed context
+            if (rc != BZ_OK && j.n) e->lane_composed[(size_t)lane] = e->lane_uploads[(size_t)lane];
             e->split_done += 1;
         }
         e->cv.notify_all();
-        // ENCODE, beside the other lane's
+        // ENCODE, beside the other lanes'
         if (rc == BZ_OK) rc = job_encode(e, lane, js);
         // ASSEMBLE, in job order
         {
@@ -593,11 +632,28 @@ static void worker_main(bz_enc *e, int lane)
             if (rc == BZ_OK) rc = e->err;
         }
         if (rc == BZ_OK) rc = job_assemble(e, j, lane, js);
+        js.t3 = now_ms();
         {
             std::lock_guard<std::mutex> lk(e->mu);
             if (rc != BZ_OK && e->err == BZ_OK) e->err = rc;
             e->asm_done += 1;
-            e->done += 1;
+        }
+        e->cv.notify_all();
+        // DOWNLOAD beside the next job's assembly; the drainer appends in job order
+        if (rc == BZ_OK) rc = job_download(e, lane, js);
+        if (enc_trace())
+            fprintf(stderr, "bz_enc job %llu (lane %d, device %d): mode %d, %zu bytes, %zu blocks: split %.2f ms, encode %.2f ms, "
+                            "assemble %.2f ms, download %.2f ms (at %.1f)\n",
+                    (unsigned long long)j.seq, lane, e->r->lanes[(size_t)lane].device, j.mode, js.n_all, js.n_blocks, js.t1 - js.t0,
+                    js.t2 - js.t1, js.t3 - js.t2, now_ms() - js.t3, now_ms());
+        {
+            std::lock_guard<std::mutex> lk(e->mu);
+            if (rc != BZ_OK && e->err == BZ_OK) e->err = rc;
+            Drain d;
+            d.lane = lane;
+            d.bytes = rc == BZ_OK ? js.out_len : 0;
+            if (d.bytes) e->drain_busy[(size_t)lane] = 1;
+            e->drains[j.seq] = d;
         }
         e->cv.notify_all();
     }
@@ -606,25 +662,30 @@ static void worker_main(bz_enc *e, int lane)
 static int ensure_started(bz_enc *e)
 {
     if (e->r) return BZ_OK;
-    int rc = resources_get(e->device, &e->r);
+    int rc = resources_get(e->devices, &e->r);
     if (rc != BZ_OK) return rc;
-    e->worker[0] = std::thread(worker_main, e, 0);
-    e->worker[1] = std::thread(worker_main, e, 1);
+    e->n_lanes = e->r->lanes.size();
+    e->drain_busy.assign(e->n_lanes, 0);
+    e->lane_uploads.assign(e->n_lanes, 0);
+    e->lane_composed.assign(e->n_lanes, 0);
+    for (size_t l = 0; l < e->n_lanes; ++l) e->worker.emplace_back(worker_main, e, (int)l);
     e->drainer = std::thread(drainer_main, e);
     return BZ_OK;
 }
 
-// hands the chunk being filled (possibly empty) to the worker together with `mode`
+// hands the chunk being filled (possibly empty) to its lane's worker together with `mode`
 static int submit(bz_enc *e, int mode, bool wait)
 {
     EncResources *r = e->r;
     EncJob j;
-    j.seq = 0;
+    j.seq = e->queued; // (only the caller's thread queues jobs) jobs are numbered in stream order
     j.slot = -1;
     j.n = e->fill;
     j.mode = mode;
     j.tail_run = 0;
+    const int lane = (int)(j.seq % (u64)e->n_lanes);
     if (e->fill) {
+        Lane &ln = r->lanes[(size_t)lane];
         const int s = e->fill_slot;
         const u8 *h = r->h_in[s];
         size_t run = 1;
@@ -632,21 +693,23 @@ static int submit(bz_enc *e, int mode, bool wait)
         j.tail_run = run;
         j.slot = s;
         {
-            // the device staging buffer of this slot is free once the worker has composed the chunk
-            // that used it last (two chunks back)
+            // the lane's device staging buffer is free once its worker has composed the chunk that used it last
             std::unique_lock<std::mutex> lk(e->mu);
-            e->cv.wait(lk, [&] { return e->submitted < 2 || e->composed + 2 > e->submitted || e->err != BZ_OK; });
+            e->cv.wait(lk, [&] { return e->lane_composed[(size_t)lane] >= e->lane_uploads[(size_t)lane] || e->err != BZ_OK; });
             if (e->err != BZ_OK) return e->err;
         }
-        if (enc_trace()) fprintf(stderr, "bz_enc upload: %zu bytes from pinned buffer %d (at %.1f)\n", e->fill, s, now_ms());
-        if (hipSetDevice(e->device) != hipSuccess) return BZ_E_UNEXPECTED;
+        if (enc_trace())
+            fprintf(stderr, "bz_enc upload: %zu bytes from pinned buffer %d to lane %d (device %d) (at %.1f)\n", e->fill, s, lane,
+                    ln.device, now_ms());
+        if (hipSetDevice(ln.device) != hipSuccess) return BZ_E_UNEXPECTED;
         {
-            const int grc = grow(&r->d_stage[s], &r->stage_cap[s], e->fill + 64);
+            const int grc = grow(&ln.d_stage, &ln.stage_cap, e->fill + 64);
             if (grc != BZ_OK) return grc;
         }
-        if (hipMemcpyAsync(r->d_stage[s], h, e->fill, hipMemcpyHostToDevice, r->st_up) != hipSuccess ||
-            hipEventRecord(r->ev_up[s], r->st_up) != hipSuccess)
+        if (hipMemcpyAsync(ln.d_stage, h, e->fill, hipMemcpyHostToDevice, ln.st_up) != hipSuccess ||
+            hipEventRecord(ln.ev_up, ln.st_up) != hipSuccess)
             return BZ_E_UNEXPECTED;
+        r->h_lane[s] = lane;
         e->fill_slot ^= 1;
         e->fill = 0;
         e->chunks_filled += 1;
@@ -654,31 +717,35 @@ static int submit(bz_enc *e, int mode, bool wait)
     u64 ticket;
     {
         std::lock_guard<std::mutex> lk(e->mu);
-        if (j.n) e->submitted += 1;
-        j.seq = e->queued; // jobs are numbered in stream order
+        if (j.n) e->lane_uploads[(size_t)lane] += 1;
         e->jobs.push_back(j);
         ticket = ++e->queued;
     }
     e->cv.notify_all();
     if (wait) { // until the job is done and its bytes are in the output queue
         std::unique_lock<std::mutex> lk(e->mu);
-        e->cv.wait(lk, [&] { return e->done >= ticket && e->drained >= e->drain_queued; });
+        e->cv.wait(lk, [&] { return e->drained >= ticket; });
         return e->err;
     }
     return BZ_OK;
 }
 
-extern "C" int bz_enc_create(bz_enc **out, int level, int device)
+extern "C" int bz_enc_create_multi(bz_enc **out, int level, const int *devices, int n_devices)
 {
     if (!out) return BZ_E_PARAM;
     *out = nullptr;
     if (level < 1 || level > 9) return BZ_E_PARAM; // the reference panics (encoder.rs:59-61)
+    if (!devices || n_devices < 1 || n_devices > 64) return BZ_E_PARAM;
+    for (int i = 0; i < n_devices; ++i)
+        if (devices[i] < 0) return BZ_E_PARAM;
     bz_enc *e = new bz_enc();
     e->level = level;
-    e->device = device;
+    e->devices.assign(devices, devices + n_devices);
     *out = e;
     return BZ_OK;
 }
+
+extern "C" int bz_enc_create(bz_enc **out, int level, int device) { return bz_enc_create_multi(out, level, &device, 1); }
 
 extern "C" void bz_enc_destroy(bz_enc *e)
 {
@@ -691,11 +758,17 @@ extern "C" void bz_enc_destroy(bz_enc *e)
         e->cv.notify_all();
         for (auto &w : e->worker)
             if (w.joinable()) w.join();
+        {
+            std::lock_guard<std::mutex> lk(e->mu);
+            e->drain_stop = true;
+        }
+        e->cv.notify_all();
         if (e->drainer.joinable()) e->drainer.join();
-        (void)hipSetDevice(e->device);
-        (void)hipStreamSynchronize(e->r->st_up);
-        (void)hipStreamSynchronize(e->r->st_io[0]);
-        (void)hipStreamSynchronize(e->r->st_io[1]);
+        for (Lane &l : e->r->lanes) {
+            (void)hipSetDevice(l.device);
+            (void)hipStreamSynchronize(l.st_up);
+            (void)hipStreamSynchronize(l.st_io);
+        }
         if (e->err == BZ_OK) resources_put(e->r);
         else resources_free(e->r);
     }
@@ -703,17 +776,20 @@ extern "C" void bz_enc_destroy(bz_enc *e)
     delete e;
 }
 
-static void copy_in(u8 *dst, const u8 *src, size_t n)
+static void copy_in(u8 *dst, const u8 *src, size_t n, size_t n_devices)
 {
-    // the one CPU copy of the input: caller's memory -> pinned staging; large pieces on several threads
+    // the one CPU copy of the input: caller's memory -> pinned staging; large pieces on several threads (four per
+    // device of the context: the copy has to keep every device's upload fed)
     constexpr size_t kPar = (size_t)4 << 20;
     if (n < kPar) {
         memcpy(dst, src, n);
         return;
     }
     const unsigned hw = std::thread::hardware_concurrency();
-    const size_t nt = hw >= 8 ? 4 : (hw >= 4 ? 2 : 1);
-    if (nt == 1) {
+    size_t nt = hw >= 8 ? 4 : (hw >= 4 ? 2 : 1);
+    if (n_devices > 1) nt = std::min<size_t>(nt * n_devices, std::max<size_t>(hw / 2, 1));
+    nt = std::min(nt, n / ((size_t)1 << 20));
+    if (nt <= 1) {
         memcpy(dst, src, n);
         return;
     }
@@ -745,10 +821,11 @@ extern "C" int bz_enc_write(bz_enc *e, const uint8_t *in, size_t n)
             // sends it together with the caller's Action instead of paying a job for the tail block alone.
             if ((rc = submit(e, BZ_ACTION_RUN, false)) != BZ_OK) return rc;
         }
-        if (e->fill == 0) {
+        if (e->fill == 0 && r->h_lane[e->fill_slot] >= 0) {
             // the pinned buffer of this slot is free once its last upload has completed
-            if (hipSetDevice(e->device) != hipSuccess || hipEventSynchronize(r->ev_up[e->fill_slot]) != hipSuccess)
-                return BZ_E_UNEXPECTED;
+            const Lane &ul = r->lanes[(size_t)r->h_lane[e->fill_slot]];
+            if (hipSetDevice(ul.device) != hipSuccess || hipEventSynchronize(ul.ev_up) != hipSuccess) return BZ_E_UNEXPECTED;
+            r->h_lane[e->fill_slot] = -1;
         }
         if (e->fill + std::min(n, cap - e->fill) > r->h_cap[e->fill_slot]) {
             // room for what this call adds (short streams stay small), for a whole chunk once it is half full
@@ -759,14 +836,16 @@ extern "C" int bz_enc_write(bz_enc *e, const uint8_t *in, size_t n)
             // memory cost 1.5 s)
             if (want > cap / 2) want = e->chunk_bytes ? std::max(cap, r->chunk) : cap;
             u8 *nh = nullptr;
-            if (hipHostMalloc((void **)&nh, want, hipHostMallocDefault) != hipSuccess) return BZ_E_NOMEM;
+            if (hipSetDevice(r->lanes[0].device) != hipSuccess ||
+                hipHostMalloc((void **)&nh, want, hipHostMallocPortable) != hipSuccess)
+                return BZ_E_NOMEM;
             if (e->fill) memcpy(nh, r->h_in[e->fill_slot], e->fill);
             if (r->h_in[e->fill_slot]) (void)hipHostFree(r->h_in[e->fill_slot]);
             r->h_in[e->fill_slot] = nh;
             r->h_cap[e->fill_slot] = want;
         }
         const size_t k = std::min(n, cap - e->fill);
-        copy_in(r->h_in[e->fill_slot] + e->fill, in, k);
+        copy_in(r->h_in[e->fill_slot] + e->fill, in, k, e->devices.size());
         e->fill += k;
         in += k;
         n -= k;
@@ -799,7 +878,7 @@ extern "C" int bz_enc_end(bz_enc *e, int action)
             } else {
                 // nothing to encode: the state below must still be the workers' last word
                 std::unique_lock<std::mutex> lk(e->mu);
-                e->cv.wait(lk, [&] { return e->done >= e->queued && e->drained >= e->drain_queued; });
+                e->cv.wait(lk, [&] { return e->drained >= e->queued; });
                 if (e->err != BZ_OK) return e->err;
             }
             e->finished = true;
@@ -850,15 +929,15 @@ extern "C" long bz_enc_read(bz_enc *e, uint8_t *out, size_t cap)
 
 extern "C" void bz_free(void *p) { free(p); }
 
-extern "C" int bz_encode_buffer(int level, int device, const uint8_t *in, size_t in_len, uint8_t **out,
-                                size_t *out_len)
+extern "C" int bz_encode_buffer_multi(int level, const int *devices, int n_devices, const uint8_t *in, size_t in_len,
+                                      uint8_t **out, size_t *out_len)
 {
     if (!out || !out_len || (!in && in_len)) return BZ_E_PARAM;
     *out = nullptr;
     *out_len = 0;
     if (level < 1 || level > 9) return BZ_E_PARAM;
     bz_enc *e = nullptr;
-    int rc = bz_enc_create(&e, level, device);
+    int rc = bz_enc_create_multi(&e, level, devices, n_devices);
     if (rc != BZ_OK) return rc;
     e->oneshot = true;
     std::thread reserver;
@@ -866,14 +945,22 @@ extern "C" int bz_encode_buffer(int level, int device, const uint8_t *in, size_t
     // the same pipeline as the streaming context: chunks are uploaded and encoded while the rest of the
     // input is still being copied to the pinned staging buffers
     {
-        // Chunks of equal size, and an even number of them behind the first one: jobs alternate between the two
-        // lanes, and a last chunk that is shorter than the others (or one too many) runs alone at the end with half
-        // the GPU idle (1 GiB in 64 + 384 + 384 + 192 MiB: the last 22 ms).
+        // Chunks of equal size, and a whole number of rounds over the lanes behind the first one: jobs go round the
+        // lanes, and a last chunk that is shorter than the others (or one too many) runs alone at the end with the rest
+        // of the GPUs idle (1 GiB on one device in 64 + 384 + 384 + 192 MiB: the last 22 ms).  With several devices the
+        // chunks get smaller rather than leave lanes without a job, down to 32 MiB (a job of 40 blocks still fills a
+        // device's 256 CUs in the sort, and the per-job latencies of the tail stages run side by side).
         const size_t most = enc_chunk_bytes(), first = std::min(most, (size_t)64 << 20);
-        if (in_len > first + most) {
+        const size_t lanes = 2 * (size_t)n_devices, least = std::min(most, (size_t)32 << 20);
+        if (in_len > first + most || (n_devices > 1 && in_len > first + 2 * least)) {
             const size_t rest = in_len - first;
             size_t k = (rest + most - 1) / most;
             k += k & 1u;
+            if (n_devices > 1) {
+                const size_t k0 = k;
+                k = (k + lanes - 1) / lanes * lanes;
+                while (k > k0 && rest / k < least) k -= 2;
+            }
             e->chunk_bytes = (((rest + k - 1) / k) + 4095) & ~(size_t)4095;
         }
     }
@@ -902,4 +989,9 @@ extern "C" int bz_encode_buffer(int level, int device, const uint8_t *in, size_t
     }
     bz_enc_destroy(e);
     return rc;
+}
+
+extern "C" int bz_encode_buffer(int level, int device, const uint8_t *in, size_t in_len, uint8_t **out, size_t *out_len)
+{
+    return bz_encode_buffer_multi(level, &device, 1, in, in_len, out, out_len);
 }

@@ -446,7 +446,10 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                 // fails further in front cannot be repaired by more input (a record is at most a header of
                 // < 2^16 bits and 900001 codes of <= 20 bits): its verdict is final now, and the context does
                 // not keep -- and re-scan -- everything behind it until the input ends.
-                constexpr u64 kMaxRecordBits = 65536ull + 900001ull * 20ull;
+                // (header: magic 48 + CRC 32 + randomised 1 + origPtr 24 + in-use maps 16 + 256 + tables 3 + selectors 15,
+                // 18002 selectors of <= 6 bits, six tables of 5 + 258 * (up to 39 delta bits) -- about 170 Kbit)
+                constexpr u64 kMaxRecordBits = (48 + 32 + 1 + 24 + 16 + 256 + 3 + 15) + 18002ull * 6ull + 6ull * (5ull + 258ull * 39ull) +
+                                               900001ull * 20ull;
                 if (partial && (bi.end_bit + 64 > nbits || (bi.status && nbits - rec_pos <= kMaxRecordBits))) {
                     term = 2;
                     break;

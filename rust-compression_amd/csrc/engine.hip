@@ -54,6 +54,7 @@ static int ensure_workspace(bz_gpu_engine *g, size_t need_blocks)
     size_t nb = need_blocks + need_blocks / 4;
     if (nb > g->max_blocks) nb = g->max_blocks;
     int rc = BZ_OK;
+    g->ws_blocks = 0; // (a growth that fails half way leaves some buffers NULL: the next call must ensure them all again)
 #define ENS(buf, bytes)                         \
     do {                                        \
         rc = g->buf.ensure((size_t)(bytes));    \
@@ -435,6 +436,7 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
     x.tickets = g->tickets.as<u32>();
     x.sort_err = g->tickets.p ? g->tickets.as<u32>() + (size_t)kSortEpochs * 8 : nullptr; // (no fused passes: not allocated)
     x.epoch = &g->sort_epoch;
+    x.fused_state = g->fused_state;
     x.tile_state_all = g->tile_state.as<u32>();
     x.tile_state_bytes = g->tile_state.cap;
     static const u32 want_fused = (getenv("BZ_ONESWEEP") && atoi(getenv("BZ_ONESWEEP")) == 0) ? 0u : 1u;
@@ -945,7 +947,8 @@ extern "C" int bz_gpu_last_timings(bz_gpu_engine *g, double out_seconds[6])
 extern "C" int bz_gpu_last_bwt_stats(bz_gpu_engine *g, uint64_t out[4])
 {
     if (!g) return BZ_E_PARAM;
-    for (int i = 0; i < 4; ++i) out[i] = g->bwt_stats[i];
+    for (int i = 0; i < 3; ++i) out[i] = g->bwt_stats[i];
+    out[3] = g->fused_state[1]; // sorts of this engine (since its creation) that fell back to the three-kernel passes
     return BZ_OK;
 }
 

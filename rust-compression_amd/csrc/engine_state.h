@@ -72,6 +72,7 @@ struct bz_gpu_engine {
         mtf_freq, bout, selector, code_len, group_bitoff, lm_scratch, stream, error_flag, packlist, gh_tiles, gbase,
         tile_state, tickets;
     u32 sort_epoch = 0; // fused radix passes: tag of the current pass in tile_state / tickets
+    u32 fused_state[2] = {0, 0}; // [0] fused passes found misbehaving on THIS engine (they stay off for it), [1] fallbacks
     hipEvent_t ev_aux = nullptr; // work that runs on st2 beside st (the RLE1 image beside the cut chain)
     size_t ws_blocks = 0; // blocks the batch workspace holds now (<= max_blocks)
     // own packed buffer / assemble list for the single-GPU convenience call

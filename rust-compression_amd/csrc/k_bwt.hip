@@ -1939,14 +1939,15 @@ static void init_sort(hipStream_t st, const BwtArgs &a, u64 total_n, KernelProf 
 // (a look-back gave up or an XCD handed out fewer tickets than it has tiles -- another kernel shared
 // the device, or workgroups were not dealt to the XCDs as assumed): nothing of the attempt can be
 // trusted then, but the block text is untouched and the caller sorts again with the three-kernel passes.
-static std::atomic<bool> g_fused_broken{false}; // process-wide: once the fused passes misbehave they stay off
+// (a.fused_state is the engine's: an engine whose fused passes misbehaved once keeps off them; other engines --
+// the other lane of a host context, other devices -- are not affected)
 
 static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 total_n, unsigned long long *h_active,
                         u64 *sorted_elems, KernelProf *prof, u64 *round_active, bool wide_keys, u32 min_chars,
                         bool allow_fused)
 {
     BwtArgs a = a_in;
-    if (!allow_fused || g_fused_broken.load()) a.fused = 0;
+    if (!allow_fused || a.fused_state[0]) a.fused = 0;
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
     (void)hipMemsetAsync(a.active, 0, 64 * sizeof(unsigned long long), st);
     (void)hipMemsetAsync(a.nonfinal, 0, a.nb * sizeof(u32), st);
@@ -1965,7 +1966,8 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
                                   : init_sort_fused<10, 10, 10>(st, a, total_n, prof, want_local);
         if (!ok) {
             fprintf(stderr, "bz2_mi355x: fused radix passes disabled (tile tickets / look-back check failed)\n");
-            g_fused_broken.store(true);
+            a.fused_state[0] = 1;
+            a.fused_state[1] += 1;
             fused = false;
             a.fused = 0;
             (void)hipMemsetAsync(a.sort_err, 0, 4, st);
@@ -2103,7 +2105,8 @@ int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned l
         // a pass after the first one misbehaved: redo this batch's sort from the block text without them
         fprintf(stderr, "bz2_mi355x: a fused radix pass misbehaved; batch sorted again with the three-kernel passes, "
                         "fused passes disabled\n");
-        g_fused_broken.store(true);
+        a.fused_state[0] = 1;
+        a.fused_state[1] += 1;
         if (sorted_elems) *sorted_elems = sorted0;
         if (round_active)
             for (int i = 0; i < 64; ++i) round_active[i] = ra0[i];

@@ -101,6 +101,14 @@ class BZip2Encoder {
         if (rc != BZ_OK) throw std::runtime_error(bz_strerror(rc));
         buf_.resize(1 << 16);
     }
+    // BZip2Encoder::with_devices: the same encoder over several GPUs of this process (bz_enc_create_multi)
+    BZip2Encoder(int level, const std::vector<int> &devices)
+    {
+        const int rc = bz_enc_create_multi(&h_, level, devices.data(), static_cast<int>(devices.size()));
+        if (rc == BZ_E_PARAM) throw std::invalid_argument("invalid level or device list");
+        if (rc != BZ_OK) throw std::runtime_error(bz_strerror(rc));
+        buf_.resize(1 << 16);
+    }
     BZip2Encoder(const BZip2Encoder &) = delete;
     BZip2Encoder &operator=(const BZip2Encoder &) = delete;
     ~BZip2Encoder() { bz_enc_destroy(h_); }
@@ -190,7 +198,6 @@ template <int Kind> class DeflateFamilyEncoder {
 
     template <class I, class S> std::optional<Result<uint8_t>> next(I &it, const S &end, Action action)
     {
-        if (action == Action::Flush && Kind != DF_KIND_DEFLATE) return Result<uint8_t>::Err(from_status(BZ_E_PARAM));
         if (action == Action::Flush && Kind != DF_KIND_DEFLATE) return Result<uint8_t>::Err(from_status(BZ_E_PARAM));
         if (pos_ == len_) {
             int rc = refill();

@@ -8,7 +8,9 @@ use alloc::vec::Vec;
 
 use crate::action::Action;
 use crate::error::CompressionError;
-use crate::ffi::{self, bz_enc, bz_enc_create, bz_enc_destroy, bz_enc_end, bz_enc_pending, bz_enc_read, bz_enc_write};
+use crate::ffi::{
+    self, bz_enc, bz_enc_create, bz_enc_create_multi, bz_enc_destroy, bz_enc_end, bz_enc_pending, bz_enc_read, bz_enc_write,
+};
 use crate::mi355x::Status;
 use crate::traits::encoder::Encoder;
 
@@ -51,6 +53,22 @@ impl BZip2Encoder {
             return Err(Status::from_code(rc));
         }
         Ok(Self { h, ready: Vec::new(), pos: 0, chunk: Vec::with_capacity(CHUNK) })
+    }
+
+    /// The same encoder over several GPUs of this process (`bz_enc_create_multi`): chunks of the input go round two
+    /// lanes per listed device, the tail of a chunk's input crosses devices over xGMI, and the stream is the one
+    /// `BZip2Encoder::new(level)` writes.  Panics like `new` for an invalid level or an empty list.
+    pub fn with_devices(level: usize, devices: &[i32]) -> Self {
+        if !(1..=9).contains(&level) {
+            panic!("invalid level"); // src/bzip2/encoder.rs:59-61
+        }
+        let mut h = core::ptr::null_mut();
+        let rc = unsafe { bz_enc_create_multi(&mut h, level as i32, devices.as_ptr(), devices.len() as i32) };
+        if rc != ffi::BZ_OK {
+            crate::mi355x::note_status(rc);
+            panic!("bz2_mi355x: cannot create an encoder context: {:?}", Status::from_code(rc));
+        }
+        Self { h, ready: Vec::new(), pos: 0, chunk: Vec::with_capacity(CHUNK) }
     }
 
     fn refill(&mut self) -> Result<usize, CompressionError> {

@@ -22,6 +22,7 @@ extern "C" {
 
     // section 1: BZip2Encoder (src/bzip2/encoder.rs:40-159)
     pub fn bz_enc_create(out: *mut *mut bz_enc, level: i32, device: i32) -> i32;
+    pub fn bz_enc_create_multi(out: *mut *mut bz_enc, level: i32, devices: *const i32, n_devices: i32) -> i32;
     pub fn bz_enc_write(e: *mut bz_enc, data: *const u8, n: usize) -> i32;
     pub fn bz_enc_end(e: *mut bz_enc, action: i32) -> i32;
     pub fn bz_enc_read(e: *mut bz_enc, out: *mut u8, cap: usize) -> isize;

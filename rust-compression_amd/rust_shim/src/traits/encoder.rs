@@ -5,7 +5,10 @@
 use crate::action::Action;
 use crate::error::CompressionError;
 
-pub trait Encoder {
+pub trait Encoder
+where
+    CompressionError: From<Self::Error>,
+{
     type Error;
     type In;
     type Out;
@@ -39,6 +42,7 @@ where
     }
 }
 
+#[derive(Debug)]
 pub struct EncodeIterator<'a, I, E>
 where
     I: Iterator<Item = E::In>,

@@ -95,6 +95,10 @@ class TorchComm:
         transfer has to be over when the callback returns (csrc/rccl_comm.hip ends with a stream synchronise too)."""
         if self.wire.type == "cuda":
             torch.cuda.synchronize(self.wire)
+        elif self.device.type == "cuda":
+            # host wire (gloo), device buffers: rank 0's own part is an asynchronous device-to-device copy on
+            # torch's stream, and with no other contributor nothing else would wait for it
+            torch.cuda.synchronize(self.device)
 
     def _guard(self, fn, *a):
         try:

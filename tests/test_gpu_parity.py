@@ -430,3 +430,59 @@ print("ok")
     e = dict(os.environ, BZ_ENC_CHUNK_MIB="1")
     out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-500:] + out.stderr[-3000:]
+
+
+def test_multi_device_context_equals_oracle(oracle):
+    """bz_enc_create_multi / bz_encode_buffer_multi (== BZip2Encoder::with_devices): several lanes go round the
+    device list -- [0, 0, 0] = six lanes on the one GPU of the test box -- with 1 MiB chunks, so the tail of
+    every chunk's input crosses from lane to lane (hipMemcpyPeerAsync between devices), action-only jobs shift
+    the lane a chunk lands on, and runs cover whole chunks.  One-shot streams against the oracle's, Run / Flush /
+    Finish sequences against the oracle's BZip2Encoder mirror; the single-device entries give the same bytes."""
+    import subprocess
+    import sys
+    code = r'''
+import importlib, random, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+pkg = importlib.import_module("rust-compression_amd")
+from oracle import oracle
+from conftest import sample
+rng = random.Random(11)
+text = (sample(1) + sample(2)) * 8
+inputs = [
+    (text[:9_700_000], 1),
+    (text[:3_000_000] + b"\0" * 3_400_000 + text[:700_000] + b"q" * 1_048_576 + b"r" * 1_048_577 + text[:100], 1),
+    (b"\0" * 6_291_456, 9),
+    (text[:7_500_000], 9),
+    (b"", 9),
+    (b"ab" * 40, 5),
+]
+for devices in ([0, 0, 0], [0, 0], [0]):
+    for data, level in inputs:
+        want = oracle.encode(data, level)
+        assert pkg.compress(data, level, devices=devices) == want, ("one-shot", devices, len(data), level)
+        enc, ref = pkg.BZip2Encoder.with_devices(level, devices), oracle.Encoder(level)
+        got, exp, pos = bytearray(), bytearray(), 0
+        while True:
+            k = rng.choice([1, 4096, 300_000, 1 << 20, (1 << 20) + 1, 2_500_000])
+            piece = data[pos:pos + k]
+            pos += len(piece)
+            act = rng.choice([0, 0, 0, 1]) if pos < len(data) else 2
+            enc.write(piece)
+            enc.end(act)
+            if rng.random() < 0.2 and act != 2:
+                enc.end(act)                      # an Action with no input at all: a job of its own
+                exp += ref.encode_iter(piece, act) + ref.encode_iter(b"", act)
+            else:
+                exp += ref.encode_iter(piece, act)
+            got += enc.read_all()
+            if act == 2:
+                break
+        assert bytes(got) == bytes(exp), ("stream", devices, len(data), level)
+        del enc
+    pkg.release_cached_resources()
+assert pkg.compress(inputs[0][0], 1) == oracle.encode(inputs[0][0], 1)
+print("ok")
+''' % (ROOT, ROOT)
+    e = dict(os.environ, BZ_ENC_CHUNK_MIB="1")
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-500:] + out.stderr[-3000:]

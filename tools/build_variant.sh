@@ -13,7 +13,9 @@ for s in k_rle1 k_bwt k_mtf k_huff k_emit k_dec k_deflate engine dec_engine defl
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -D__HIP_PLATFORM_AMD__ "$@" -c $C/$s.hip -o $O/$s.o &
   pids+=($!)
 done
-for p in "${pids[@]}"; do wait $p; done
+fail=0
+for p in "${pids[@]}"; do wait $p || fail=1; done
+if [ $fail -ne 0 ]; then echo "build_variant: a compile failed" >&2; rm -rf $O; exit 1; fi
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $R/rust-compression_amd/build/var/$NAME.so $O/*.o
 rm -rf $O
 ls -la $R/rust-compression_amd/build/var/$NAME.so
