@@ -262,6 +262,12 @@ int bz_gpu_encode_sharded(bz_gpu_engine *g, int level, const void *d_in, size_t 
 int bz_rccl_unique_id(uint8_t id[BZ_RCCL_ID_BYTES]);
 int bz_rccl_comm_create(bz_shard_comm **out, const uint8_t id[BZ_RCCL_ID_BYTES], int rank, int world, int device);
 void bz_rccl_comm_destroy(bz_shard_comm *comm);
+/* ranks of the communicator as RCCL counts them (ncclCommCount), or a negative status */
+int bz_rccl_comm_count(const bz_shard_comm *comm);
+/* No exchange of this transport waits for ever: each one polls its stream, the communicator's asynchronous
+ * error state and a deadline (BZ_RCCL_TIMEOUT_S in the environment, default 300 s); on an error or a timeout
+ * the communicator is aborted (ncclCommAbort), the callback fails and bz_gpu_encode_sharded returns
+ * BZ_E_UNEXPECTED on this rank. */
 
 /* Runs known patterns through a transport's four callbacks, shaped like the exchanges above (every
  * rank calls it): BZ_OK, BZ_E_DATA (bytes arrived wrong somewhere; the same verdict on every rank) or
@@ -383,8 +389,9 @@ void bz_dec_destroy(bz_dec *d);
  * `kind`: 0 raw Deflate, 1 zlib, 2 gzip.
  * Action::Flush inside a stream is offered for Inflater through the streaming context (df_enc_end):
  * the stream becomes a sequence of byte-aligned segments (src/deflate/encoder.rs:170-195, :227-235,
- * :638-647).  Not offered (refused with BZ_E_PARAM, never approximated): Action::Flush on the zlib /
- * gzip wrappers (they end their container at the first None, src/zlib/encoder.rs:131-151).  Inputs of
+ * :638-647).  The zlib / gzip wrappers end their container at the first None of their inner Inflater whatever
+ * the Action (src/zlib/encoder.rs:138-150, src/gzip/encoder.rs:120-133): df_enc_end(Run) / (Flush) on kinds 1 / 2
+ * write header + what the Inflater yields under that Action + trailer, and the context is finished.  Inputs of
  * any length: a call works through a long segment in parts of BZ_DF_PART_MIB (default 1024) MiB.
  * ======================================================================== */
 #define DF_KIND_DEFLATE 0
@@ -433,16 +440,22 @@ int df_encode_buffer_dict(int kind, int device, const uint8_t *in, size_t in_len
 
 /* Streaming context == the Encoder::next contract of the three encoders:
  * df_enc_write feeds bytes, df_enc_end(action) marks the end of an input
- * iterator (0 Run: nothing happens -- the bytes of a stream depend on all of its input;
- * 1 Flush, kind 0 only: the bytes written since the last segment come out as one segment:
+ * iterator (0 Run, kind 0: nothing comes out yet -- the blocks the reference hands out while it
+ * consumes input come with the next Flush / Finish, the bytes are the same;
+ * 1 Flush: the bytes written since the last segment come out as one segment:
  * LZSS stage drained, current block closed without the final bit, padded to a byte, window and
- * decompress_len carried over; 2 Finish: the last segment, final bit, container trailer),
- * df_enc_read drains.  The stream so far stays in device memory until Finish. */
+ * decompress_len carried over; 2 Finish: the last segment, final bit, container trailer;
+ * kinds 1 / 2 (ZlibEncoder / GZipEncoder): ANY action ends the container -- Run: header, the whole bytes of
+ * the blocks the Inflater has closed with 261 bytes of look-ahead held back, trailer; Flush: header, the
+ * flushed segment, trailer -- and the encoder is finished: later input is not even pulled
+ * (src/zlib/encoder.rs:130-136)), df_enc_read drains.  The stream so far stays in device memory until the
+ * context is finished.  df_enc_finished: 1 once the final block (kind 0) / the trailer (kinds 1, 2) is out. */
 typedef struct df_enc df_enc;
 int df_enc_create(df_enc **out, int kind, int device);
 int df_enc_create_dict(df_enc **out, int kind, int device, const uint8_t *dict, size_t dict_len); /* ::with_dict */
 int df_enc_write(df_enc *e, const uint8_t *in, size_t n);
 int df_enc_end(df_enc *e, int action);
+int df_enc_finished(const df_enc *e);
 long df_enc_read(df_enc *e, uint8_t *out, size_t cap);
 size_t df_enc_pending(const df_enc *e);
 void df_enc_destroy(df_enc *e);

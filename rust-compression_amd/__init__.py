@@ -90,7 +90,7 @@ EXPORTS = [
     "bz_dec_create", "bz_dec_write", "bz_dec_end", "bz_dec_read", "bz_dec_pending", "bz_dec_destroy",
     "df_encode_bound", "df_gpu_encode_device", "df_gpu_last_timings", "df_gpu_last_stats", "df_gpu_debug_codes",
     "df_gpu_debug_blocks", "df_encode_buffer", "df_gpu_encode_device_dict", "df_encode_buffer_dict", "df_enc_create_dict",
-    "df_enc_create", "df_enc_write", "df_enc_end", "df_enc_read", "df_enc_pending", "df_enc_destroy",
+    "df_enc_create", "df_enc_write", "df_enc_end", "df_enc_read", "df_enc_pending", "df_enc_destroy", "df_enc_finished",
 ]
 
 
@@ -204,6 +204,7 @@ def lib():
     L.df_enc_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
     L.df_enc_write.argtypes = [vp, C.c_char_p, sz]
     L.df_enc_end.argtypes = [vp, C.c_int]
+    L.df_enc_finished.argtypes = [vp]
     L.df_enc_read.restype = C.c_long
     L.df_enc_read.argtypes = [vp, u8p, sz]
     L.df_enc_pending.restype = sz
@@ -229,7 +230,7 @@ def _settle():
 
 
 _RCCL_LIB = None
-RCCL_EXPORTS = ["bz_rccl_unique_id", "bz_rccl_comm_create", "bz_rccl_comm_destroy"]
+RCCL_EXPORTS = ["bz_rccl_unique_id", "bz_rccl_comm_create", "bz_rccl_comm_destroy", "bz_rccl_comm_count"]
 
 
 def rccl_lib():
@@ -251,14 +252,13 @@ def rccl_lib():
                 C.CDLL(cand, mode=C.RTLD_GLOBAL)
             except OSError:
                 pass
-    so = os.path.join(_HERE, "libbz2_mi355x_rccl.so")
-    if not os.path.exists(so):
-        so = _build.build_rccl()
+    so = _build.build_rccl()  # (a no-op when the library is newer than its source)
     L = C.CDLL(so)
     L.bz_rccl_unique_id.argtypes = [C.c_char_p]
     L.bz_rccl_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_int, C.c_int]
     L.bz_rccl_comm_destroy.restype = None
     L.bz_rccl_comm_destroy.argtypes = [C.c_void_p]
+    L.bz_rccl_comm_count.argtypes = [C.c_void_p]
     _RCCL_LIB = L
     return L
 
@@ -288,6 +288,13 @@ class RcclComm:
 
     def register(self, t):
         return t  # (device pointers are used as they are)
+
+    def count(self):
+        """ranks of the communicator as RCCL counts them (ncclCommCount)"""
+        n = rccl_lib().bz_rccl_comm_count(self._p)
+        if n < 0:
+            raise CompressionError(n)
+        return n
 
     def close(self):
         if getattr(self, "_p", None) and self._p.value and _RCCL_LIB is not None:
@@ -432,7 +439,9 @@ class Inflater:
     """`Inflater` (src/deflate/encoder.rs:92-260) over the C ABI's streaming context: the reference's
     name for its Deflate ENCODER.  Action.RUN accumulates, Action.FLUSH writes the bytes so far as a
     byte-aligned segment (non-final block; the window and decompress_len carry over), Action.FINISH ends
-    the stream.  ZlibEncoder / GZipEncoder refuse Action.FLUSH (CompressionError BZ_E_PARAM)."""
+    the stream.  ZlibEncoder / GZipEncoder end their container at the first None of the inner Inflater whatever
+    the Action (zlib/encoder.rs:138-150): Run / Flush give header + what the Inflater yields + trailer, and the
+    encoder then returns None without pulling its caller's iterator."""
 
     KIND = DEFLATE
     CHUNK = 1 << 20
@@ -465,11 +474,9 @@ class Inflater:
 
     def next(self, it, action):
         """One `Encoder::next(iter, action)` call: an int byte, or None."""
-        if int(action) == Action.FLUSH and self.KIND != DEFLATE:
-            # the zlib / gzip wrappers are not offered with Flush (they end their container at the first None,
-            # zlib/encoder.rs:131-151): refused BEFORE any input is pulled, the caller's iterator is left untouched
-            raise CompressionError(BZ_E_PARAM)
         if self._pos >= len(self._ready) and self._refill() == 0:
+            if self.KIND != DEFLATE and lib().df_enc_finished(self._h):
+                return None  # the trailer is out: the wrappers do not touch the iterator any more (zlib/encoder.rs:130-136)
             while True:
                 chunk = bytearray()
                 for b in it:

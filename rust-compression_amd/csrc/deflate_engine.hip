@@ -90,6 +90,12 @@ struct DfSeg {
     // first block of this part starts behind them.  bit0 / carry_byte: the bits (0..7) of the output's first
     // byte that the previous part has already filled.
     bool more = false;
+    // Action::Run seen by a zlib / gzip wrapper (its container ends at the inner encoder's first None,
+    // zlib/encoder.rs:146-150): write exactly the blocks the reference's Inflater has CLOSED once the iterator is dry.
+    // The LZSS stage decides a step of its parse only with 258 + 3 bytes of look-ahead (lzss/encoder.rs:186-194), so
+    // the codes of the steps that start at p <= n - 261 are out and are those of any longer input; a block is closed by
+    // the arrival of the next block's first code (deflate/encoder.rs:585-593).  Only whole bytes leave the BitWriter.
+    bool run = false;
     u32 skip = 0;
     u32 bit0 = 0;
     u8 carry_byte = 0;
@@ -222,9 +228,36 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
         HIPCHK(hipMemcpyAsync(w->nb.p, &keep, 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st)); // (`keep` lives on this stack frame)
     }
+    if (seg.run && !seg.more) {
+        u32 nb_all = 0;
+        HIPCHK(hipMemcpyAsync(&nb_all, w->nb.p, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (nb_all == 0xFFFFFFFFu || nb_all > bcap) return BZ_E_UNEXPECTED;
+        std::vector<u64> hb((size_t)nb_all + 1);
+        if (nb_all) HIPCHK(hipMemcpy(hb.data(), w->bstart.p, ((size_t)nb_all + 1) * 8, hipMemcpyDeviceToHost));
+        // block j-1 is closed when the code at hb[j] has arrived: the step of the parse that holds it (at most two
+        // literals in front of a reference) starts at or before n - 261.  (With a `skip` the first block starts
+        // inside a step of the previous part; cuts further on are at least 0xFFFF - 257 bytes behind it.)
+        u32 keep = 0;
+        for (u32 j = nb_all; j-- > 1;) {
+            const u64 bcut = hb[j];
+            u32 cw[3] = {0, 0, 0};
+            const u64 lo = bcut < 2 ? bcut : 2;
+            HIPCHK(hipMemcpy(cw + (2 - lo), code + (bcut - lo), (size_t)(lo + 1) * 4, hipMemcpyDeviceToHost));
+            if (!(cw[2] & F_CODE)) return BZ_E_UNEXPECTED;
+            const u32 back = (cw[2] & F_STEP) ? 0u : ((cw[1] & F_STEP) ? 1u : 2u);
+            if (back > lo || !(cw[2 - back] & F_STEP)) return BZ_E_UNEXPECTED;
+            if (bcut - back + 261 <= n) {
+                keep = j;
+                break;
+            }
+        }
+        HIPCHK(hipMemcpyAsync(w->nb.p, &keep, 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st)); // (`keep` lives on this stack frame)
+    }
     if (df_launch_blocks(st, d_in, code, w->bstart.as<u64>(), w->nb.as<u32>(), bcap, w->blocks.as<DfBlock>(),
                          w->lens.as<u8>(), w->hdr.as<u32>(), w->lm.as<u32>(), w->total.as<u64>(), seg.dl0,
-                         (seg.final && !seg.more) ? 1u : 0u, seg.bit0) != 0)
+                         (seg.final && !seg.more && !seg.run) ? 1u : 0u, seg.bit0) != 0)
         return BZ_E_UNEXPECTED;
     if (seg.bit0) HIPCHK(hipMemcpyAsync(w->stream.p, &seg.carry_byte, 1, hipMemcpyHostToDevice, st)); // (the stream was cleared above)
     HIPCHK(hipEventRecord(w->ev[4], st));
@@ -248,7 +281,8 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
         return BZ_E_UNEXPECTED;
     }
     // (a part that is not the last one hands on its last, partly filled byte instead of writing it)
-    const u64 body = seg.more ? (total_bits >> 3) : ((total_bits + 7) >> 3);
+    // ... and the bits of a partly filled byte never leave the BitWriter of a wrapper that ends under Action::Run
+    const u64 body = (seg.more || seg.run) ? (total_bits >> 3) : ((total_bits + 7) >> 3);
     if (part_out) {
         part_out->consumed = consumed;
         part_out->skip = next_skip;
@@ -346,7 +380,7 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
         w->stats[6] += (bi.lm >> 8) & 1u; // dynamic block without any match: the reference's header has no distance length
     }
     w->stats[5] = prev_bytes + need;
-    if (dl_out) *dl_out = (u32)((nb == 1 ? seg.dl0 : 0u) + (n - w->h_bstart[nb - 1]));
+    if (dl_out) *dl_out = nb ? (u32)((nb == 1 ? seg.dl0 : 0u) + (n - w->h_bstart[nb - 1])) : seg.dl0;
     return BZ_OK;
 }
 
@@ -387,6 +421,7 @@ static int df_encode_parts(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, co
         seg.tail = seg0.tail && last;
         seg.final = seg0.final;
         seg.more = !last;
+        seg.run = seg0.run && last;
         seg.accumulate_stats = k > 0;
         size_t got = 0;
         DfPartOut po;
@@ -583,20 +618,25 @@ extern "C" int df_enc_write(df_enc *e, const uint8_t *in, size_t n)
     return BZ_OK;
 }
 
-// Action::Run: everything stays pending (the LZSS stage holds 261 bytes of look-ahead, the block stage up to
-// 0xFFFF bytes, and the bytes of a stream depend on all of its input: nothing can come out earlier).
+// Action::Run (Inflater): everything stays pending (the LZSS stage holds 261 bytes of look-ahead, the block stage up
+// to 0xFFFF bytes; the blocks the reference would hand out early come with the next Flush / Finish: same bytes,
+// coarser moments).
 // Action::Flush (Inflater only): the bytes written since the last segment are encoded as one SEGMENT -- the LZSS
 // stage drained (lzss/encoder.rs:196-200, :224-226), the block closed without the final bit
 // (deflate/encoder.rs:177-184, :638-647), the bit string padded to a byte (:227-235); the 32 KiB window and
 // decompress_len carry over.  Action::Finish: the last segment, final bit set, container trailer.
 // The zlib / gzip wrappers end their container at the first None they see, whatever the action
-// (zlib/encoder.rs:131-151): a Flush there is a Finish without the final block -- not mirrored: BZ_E_PARAM.
+// (zlib/encoder.rs:131-151): see `ends_container` below.
 extern "C" int df_enc_end(df_enc *e, int action)
 {
     if (!e || action < 0 || action > 2) return BZ_E_PARAM;
-    if (action == 0) return BZ_OK;
-    if (action == 1 && e->kind != 0) return BZ_E_PARAM;
+    if (action == 0 && e->kind == 0) return BZ_OK;
     if (e->finished) return BZ_OK; // flush() / finish() behind the final block do nothing (:636-660)
+    // zlib / gzip: the container ends at the first None of the inner Inflater whatever the Action
+    // (zlib/encoder.rs:146-150, gzip/encoder.rs:129-133): header + what the Inflater yields under this Action
+    // (Run: the whole bytes of the blocks it has closed; Flush: the flushed segment) + the trailer over everything
+    // the iterator handed over; afterwards the encoder yields None and leaves its caller's iterator alone.
+    const bool ends_container = e->kind != 0;
     int rc;
     if (!e->g && (rc = bz_gpu_engine_create(&e->g, e->device, 0)) != BZ_OK) return rc;
     HIPCHK(hipSetDevice(e->device));
@@ -616,8 +656,9 @@ extern "C" int df_enc_end(df_enc *e, int action)
     seg.prior = e->encoded;
     seg.dl0 = e->dl;
     seg.final = (action == 2);
+    seg.run = (action == 0);
     seg.head = !e->wrote_head;
-    seg.tail = (action == 2);
+    seg.tail = (action == 2) || ends_container;
     const size_t n = e->total - e->encoded;
     const size_t cap = df_encode_bound(n) + 64;
     if ((rc = e->d_out.ensure(cap)) != BZ_OK) return rc;
@@ -636,12 +677,14 @@ extern "C" int df_enc_end(df_enc *e, int action)
     e->wrote_head = true;
     e->encoded = e->total;
     e->dl = dl;
-    if (action == 2) {
+    if (action == 2 || ends_container) {
         e->finished = true;
         e->d_data.release();
     }
     return BZ_OK;
 }
+
+extern "C" int df_enc_finished(const df_enc *e) { return e && e->finished ? 1 : 0; }
 
 extern "C" size_t df_enc_pending(const df_enc *e) { return e ? e->out.size() - e->out_head : 0; }
 

@@ -833,8 +833,14 @@ extern "C" int bz_gpu_encode_sharded(bz_gpu_engine *g, int level, const void *d_
     if (comm->allgather(comm->ctx, meta.data(), (size_t)kmax * sizeof(ShardBlock), metas.data()) != 0) return BZ_E_UNEXPECTED;
 
     // 4. the bit strings -> rank 0 (room is settled first so that a rank that cannot receive says so before the gather)
+    // (the packed words must be complete before the transport reads them; a HIP failure here travels with the
+    // same status word, so that no rank is left waiting in the gather)
     int grc = BZ_OK;
-    if (rank == 0) {
+    if (hipStreamSynchronize(g->st) != hipSuccess) {
+        fprintf(stderr, "bz2_mi355x: rank %d: HIP error while finishing its blocks\n", rank);
+        grc = BZ_E_UNEXPECTED;
+    }
+    if (rank == 0 && grc == BZ_OK) {
         if (!d_gather) {
             grc = g->gathered.ensure((size_t)(total_words + 16) * 4);
             d_gather = g->gathered.p;
@@ -845,7 +851,8 @@ extern "C" int bz_gpu_encode_sharded(bz_gpu_engine *g, int level, const void *d_
     std::vector<int64_t> grcs((size_t)world, 0);
     int64_t g64 = grc;
     if (comm->allgather(comm->ctx, &g64, 8, grcs.data()) != 0) return BZ_E_UNEXPECTED;
-    if (grcs[0] != 0) return (int)grcs[0];
+    for (int r = 0; r < world; ++r)
+        if (grcs[(size_t)r] != 0) return (int)grcs[(size_t)r]; // the same verdict on every rank
     std::vector<uint64_t> roff((size_t)world), rlen((size_t)world);
     u64 cursor = 0;
     for (int r = 0; r < world; ++r) {
@@ -853,7 +860,6 @@ extern "C" int bz_gpu_encode_sharded(bz_gpu_engine *g, int level, const void *d_
         rlen[(size_t)r] = heads[(size_t)r].words * 4;
         cursor += heads[(size_t)r].words;
     }
-    HIPCHK(hipStreamSynchronize(g->st)); // the packed words are complete before the transport reads them
     if (comm->gatherv(comm->ctx, d_packed, (size_t)used * 4, rank == 0 ? d_gather : nullptr, roff.data(), rlen.data()) != 0)
         return BZ_E_UNEXPECTED;
     if (rank != 0) return BZ_OK;

@@ -17,9 +17,11 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace {
 
@@ -46,6 +48,45 @@ bool ok_nccl(ncclResult_t r, const char *what)
     return false;
 }
 
+// Every exchange ends with a wait for the transport's stream.  A peer that died (or never arrives) would leave
+// hipStreamSynchronize waiting for ever, so the wait polls: the stream, the communicator's asynchronous error
+// state, and a deadline (BZ_RCCL_TIMEOUT_S, default 300 s).  On error or timeout the communicator is aborted
+// (ncclCommAbort), this callback and every later one fail, and bz_gpu_encode_sharded returns BZ_E_UNEXPECTED
+// instead of hanging.
+double timeout_seconds()
+{
+    static const double v = [] {
+        const char *s = getenv("BZ_RCCL_TIMEOUT_S");
+        const double t = s ? atof(s) : 300.0;
+        return t > 0 ? t : 300.0;
+    }();
+    return v;
+}
+
+bool wait_stream(RcclComm *c, const char *what)
+{
+    using clock = std::chrono::steady_clock;
+    const clock::time_point t0 = clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = hipStreamQuery(c->st);
+        if (q == hipSuccess) return true;
+        if (q != hipErrorNotReady) return ok_hip(q, what);
+        (void)hipGetLastError(); // (hipErrorNotReady is sticky for hipGetLastError otherwise)
+        if (spins < 20000) continue; // the small exchanges of the cut chain take microseconds: spin first
+        ncclResult_t ar = ncclSuccess;
+        const bool broken = ncclCommGetAsyncError(c->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress;
+        const double waited = std::chrono::duration<double>(clock::now() - t0).count();
+        if (broken || waited > timeout_seconds()) {
+            fprintf(stderr, "bz2_mi355x_rccl: rank %d: %s did not complete (%s after %.1f s): communicator aborted\n", c->api.rank, what,
+                    broken ? ncclGetErrorString(ar) : "timeout", waited);
+            (void)ncclCommAbort(c->comm);
+            c->comm = nullptr;
+            return false;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+}
+
 // room for `bytes` bytes per rank, send + receive side
 int ensure_small(RcclComm *c, size_t bytes)
 {
@@ -66,14 +107,14 @@ int ensure_small(RcclComm *c, size_t bytes)
 int cb_allgather(void *ctx, const void *send, size_t bytes, void *recv)
 {
     RcclComm *c = static_cast<RcclComm *>(ctx);
-    if (!ok_hip(hipSetDevice(c->device), "hipSetDevice") || ensure_small(c, bytes)) return 1;
+    if (!c->comm || !ok_hip(hipSetDevice(c->device), "hipSetDevice") || ensure_small(c, bytes)) return 1;
     const size_t world = (size_t)c->api.world;
     memcpy(c->h_pin, send, bytes);
     unsigned char *d_send = c->d_small, *d_recv = c->d_small + ((bytes + 255) & ~(size_t)255);
     if (!ok_hip(hipMemcpyAsync(d_send, c->h_pin, bytes, hipMemcpyHostToDevice, c->st), "H2D")) return 1;
     if (!ok_nccl(ncclAllGather(d_send, d_recv, bytes, ncclUint8, c->comm, c->st), "ncclAllGather")) return 1;
     if (!ok_hip(hipMemcpyAsync(c->h_pin, d_recv, bytes * world, hipMemcpyDeviceToHost, c->st), "D2H")) return 1;
-    if (!ok_hip(hipStreamSynchronize(c->st), "sync")) return 1;
+    if (!wait_stream(c, "all-gather")) return 1;
     memcpy(recv, c->h_pin, bytes * world);
     return 0;
 }
@@ -81,20 +122,20 @@ int cb_allgather(void *ctx, const void *send, size_t bytes, void *recv)
 int cb_send(void *ctx, int dst, const void *buf, size_t bytes)
 {
     RcclComm *c = static_cast<RcclComm *>(ctx);
-    if (!ok_hip(hipSetDevice(c->device), "hipSetDevice") || ensure_small(c, bytes)) return 1;
+    if (!c->comm || !ok_hip(hipSetDevice(c->device), "hipSetDevice") || ensure_small(c, bytes)) return 1;
     memcpy(c->h_pin, buf, bytes);
     if (!ok_hip(hipMemcpyAsync(c->d_small, c->h_pin, bytes, hipMemcpyHostToDevice, c->st), "H2D")) return 1;
     if (!ok_nccl(ncclSend(c->d_small, bytes, ncclUint8, dst, c->comm, c->st), "ncclSend")) return 1;
-    return ok_hip(hipStreamSynchronize(c->st), "sync") ? 0 : 1;
+    return wait_stream(c, "send") ? 0 : 1;
 }
 
 int cb_recv(void *ctx, int src, void *buf, size_t bytes)
 {
     RcclComm *c = static_cast<RcclComm *>(ctx);
-    if (!ok_hip(hipSetDevice(c->device), "hipSetDevice") || ensure_small(c, bytes)) return 1;
+    if (!c->comm || !ok_hip(hipSetDevice(c->device), "hipSetDevice") || ensure_small(c, bytes)) return 1;
     if (!ok_nccl(ncclRecv(c->d_small, bytes, ncclUint8, src, c->comm, c->st), "ncclRecv")) return 1;
     if (!ok_hip(hipMemcpyAsync(c->h_pin, c->d_small, bytes, hipMemcpyDeviceToHost, c->st), "D2H")) return 1;
-    if (!ok_hip(hipStreamSynchronize(c->st), "sync")) return 1;
+    if (!wait_stream(c, "receive")) return 1;
     memcpy(buf, c->h_pin, bytes);
     return 0;
 }
@@ -103,7 +144,7 @@ int cb_gatherv(void *ctx, const void *d_send, size_t send_bytes, void *d_recv, c
                const uint64_t *recv_bytes)
 {
     RcclComm *c = static_cast<RcclComm *>(ctx);
-    if (!ok_hip(hipSetDevice(c->device), "hipSetDevice")) return 1;
+    if (!c->comm || !ok_hip(hipSetDevice(c->device), "hipSetDevice")) return 1;
     const int rank = c->api.rank, world = c->api.world;
     if (rank == 0 && send_bytes &&
         !ok_hip(hipMemcpyAsync(static_cast<unsigned char *>(d_recv) + recv_off[0], d_send, send_bytes, hipMemcpyDeviceToDevice,
@@ -120,7 +161,7 @@ int cb_gatherv(void *ctx, const void *d_send, size_t send_bytes, void *d_recv, c
         fine = fine && ok_nccl(ncclSend(d_send, send_bytes, ncclUint8, 0, c->comm, c->st), "ncclSend");
     }
     fine = ok_nccl(ncclGroupEnd(), "ncclGroupEnd") && fine;
-    return (fine && ok_hip(hipStreamSynchronize(c->st), "sync")) ? 0 : 1;
+    return (fine && wait_stream(c, "gather of the bit strings")) ? 0 : 1;
 }
 
 } // namespace
@@ -164,12 +205,21 @@ extern "C" int bz_rccl_comm_create(bz_shard_comm **out, const uint8_t id[BZ_RCCL
     return BZ_OK;
 }
 
+extern "C" int bz_rccl_comm_count(const bz_shard_comm *comm)
+{
+    if (!comm) return BZ_E_PARAM;
+    const RcclComm *c = static_cast<const RcclComm *>(comm->ctx);
+    int n = 0;
+    if (!c->comm || !ok_nccl(ncclCommCount(c->comm, &n), "ncclCommCount")) return BZ_E_UNEXPECTED;
+    return n;
+}
+
 extern "C" void bz_rccl_comm_destroy(bz_shard_comm *comm)
 {
     if (!comm) return;
     RcclComm *c = static_cast<RcclComm *>(comm->ctx);
     (void)hipSetDevice(c->device);
-    if (c->st) (void)hipStreamSynchronize(c->st);
+    if (c->st && c->comm) (void)hipStreamSynchronize(c->st); // (an aborted communicator's stream may never drain)
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->d_small) (void)hipFree(c->d_small);

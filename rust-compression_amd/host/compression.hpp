@@ -198,11 +198,12 @@ template <int Kind> class DeflateFamilyEncoder {
 
     template <class I, class S> std::optional<Result<uint8_t>> next(I &it, const S &end, Action action)
     {
-        if (action == Action::Flush && Kind != DF_KIND_DEFLATE) return Result<uint8_t>::Err(from_status(BZ_E_PARAM));
         if (pos_ == len_) {
             int rc = refill();
             if (rc < 0) return Result<uint8_t>::Err(from_status(rc));
             if (len_ == 0) {
+                // the wrappers do not touch the iterator once their trailer is out (src/zlib/encoder.rs:130-136)
+                if (Kind != DF_KIND_DEFLATE && df_enc_finished(h_)) return std::nullopt;
                 while (it != end) {
                     chunk_.clear();
                     while (it != end && chunk_.size() < kChunk) {

@@ -8,7 +8,9 @@ use core::ffi::c_void;
 
 use crate::action::Action;
 use crate::error::CompressionError;
-use crate::ffi::{self, df_enc_create, df_enc_create_dict, df_enc_destroy, df_enc_end, df_enc_read, df_enc_write};
+use crate::ffi::{
+    self, df_enc_create, df_enc_create_dict, df_enc_destroy, df_enc_end, df_enc_finished, df_enc_read, df_enc_write,
+};
 
 const CHUNK: usize = 1 << 20;
 
@@ -50,11 +52,9 @@ impl DeflateFamilyEncoder {
     }
 
     pub(crate) fn next<I: Iterator<Item = u8>>(&mut self, iter: &mut I, action: Action) -> Option<Result<u8, CompressionError>> {
-        // Action::Flush: a byte-aligned segment for Inflater; the zlib / gzip wrappers refuse it before any
-        // input is pulled (the reference's wrappers end their container at the first None they see)
-        if action == Action::Flush && self.kind != ffi::DF_KIND_DEFLATE {
-            return Some(Err(map_err(ffi::BZ_E_PARAM)));
-        }
+        // Action::Flush: a byte-aligned segment for Inflater.  The zlib / gzip wrappers end their container at the
+        // first None of the inner Inflater whatever the Action (src/zlib/encoder.rs:138-150): the library writes
+        // header + what the Inflater yields + trailer, and from then on the iterator is not pulled (:130-136).
         while self.pos == self.ready.len() {
             self.ready.resize(1 << 16, 0);
             let k = unsafe { df_enc_read(self.h, self.ready.as_mut_ptr(), self.ready.len()) };
@@ -67,6 +67,10 @@ impl DeflateFamilyEncoder {
             self.pos = 0;
             if k > 0 {
                 break;
+            }
+            if self.kind != ffi::DF_KIND_DEFLATE && unsafe { df_enc_finished(self.h) } != 0 {
+                self.ready.clear();
+                return None;
             }
             // nothing ready: move the rest of this iterator in, then tell the library it ended
             loop {

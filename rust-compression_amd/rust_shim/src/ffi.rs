@@ -41,6 +41,7 @@ extern "C" {
     pub fn df_enc_create_dict(out: *mut *mut df_enc, kind: i32, device: i32, dict: *const u8, dict_len: usize) -> i32;
     pub fn df_enc_write(e: *mut df_enc, data: *const u8, n: usize) -> i32;
     pub fn df_enc_end(e: *mut df_enc, action: i32) -> i32;
+    pub fn df_enc_finished(e: *const df_enc) -> i32;
     pub fn df_enc_read(e: *mut df_enc, out: *mut u8, cap: usize) -> isize;
     pub fn df_enc_destroy(e: *mut df_enc);
 }

@@ -116,13 +116,16 @@ def test_containers_and_mirrors(pkg, oracle):
     # `data.encode(&mut Inflater::new(), Action::Finish).collect()`
     enc = pkg.Inflater()
     assert bytes(pkg.encode(iter(d[:5000]), enc, pkg.Action.FINISH)) == oracle.deflate_encode(d[:5000])
-    # Run then Finish == one iterator (the reference's Run leaves everything pending)
-    enc = pkg.GZipEncoder()
+    # Inflater: Run then Finish == one iterator (the bytes the reference hands out under Run come with the Finish)
+    enc = pkg.Inflater()
     enc.write(d[:100000]); enc.end(pkg.Action.RUN)
     enc.write(d[100000:]); enc.end(pkg.Action.FINISH)
-    assert enc.read_all() == oracle.deflate_encode(d, oracle.GZIP)
-    with pytest.raises(pkg.CompressionError):
-        pkg.ZlibEncoder().end(pkg.Action.FLUSH)
+    assert enc.read_all() == oracle.deflate_encode(d, oracle.DEFLATE)
+    # GZipEncoder: Run ends the container (gzip/encoder.rs:120-133); the Finish behind it yields nothing
+    enc, ref = pkg.GZipEncoder(), oracle.WrapperEncoder(oracle.GZIP)
+    enc.write(d[:100000]); enc.end(pkg.Action.RUN)
+    enc.write(d[100000:]); enc.end(pkg.Action.FINISH)
+    assert enc.read_all() == ref.encode_iter(d[:100000], oracle.ACTION_RUN) + ref.encode_iter(d[100000:], oracle.ACTION_FINISH)
 
 
 def test_big_corpus(pkg, oracle, eng):
@@ -252,13 +255,33 @@ def test_flush_segments(pkg, oracle):
         assert got == want, ("random", trial)
 
 
-def test_flush_refused_for_containers_before_input_is_pulled(pkg):
-    it = iter(b"hello world")
-    with pytest.raises(pkg.CompressionError):
-        pkg.ZlibEncoder().next(it, pkg.Action.FLUSH)
-    assert bytes(it) == b"hello world"  # the caller's iterator is untouched
-    with pytest.raises(pkg.CompressionError):
-        pkg.GZipEncoder().end(pkg.Action.FLUSH)
+def test_wrappers_end_their_container_at_the_first_none(pkg, oracle):
+    """ZlibEncoder / GZipEncoder under Action::Run and Action::Flush (zlib/encoder.rs:118-152,
+    gzip/encoder.rs:88-135): header + what the inner Inflater yields under that action + trailer, piece by piece
+    against the oracle's iterator-level restatement; afterwards nothing, and the caller's iterator is not pulled."""
+    A = pkg.Action
+    text = sample(1)
+    rnd = random.Random(21)
+    noise = bytes(rnd.randrange(256) for _ in range(150000))
+    inputs = [b"", b"a", text[:260], text[:261], text[:262], text[:300], text[:65535], text[:65536], text[:65536 + 261],
+              text[:65536 + 600], text[:140000], noise[:70000], noise, b"\0" * 200000, text[:30000] + noise[:66000] + text[:9000]]
+    for kind, cls in ((oracle.ZLIB, pkg.ZlibEncoder), (oracle.GZIP, pkg.GZipEncoder)):
+        for act in (A.RUN, A.FLUSH, A.FINISH):
+            for i, d in enumerate(inputs):
+                enc, ref = cls(), oracle.WrapperEncoder(kind)
+                got = enc.encode_all(d, act)
+                assert got == ref.encode_iter(d, int(act)), (kind, int(act), i, len(d))
+                # finished: a second iterator yields nothing and is left alone
+                it = iter(b"more input")
+                assert enc.next(it, A.FINISH) is None and bytes(it) == b"more input"
+                assert ref.encode_iter(b"more input", int(A.FINISH)) == b"" and ref.pulled == 0
+                assert enc.encode_all(b"xyz", A.FINISH) == b""
+    # Run over more than one closed block, with a dictionary (zlib only), through the byte iterator
+    d = text[:100000] + noise[:50000]
+    enc, ref = pkg.ZlibEncoder.with_dict(text[200000:240000]), oracle.WrapperEncoder(oracle.ZLIB, text[200000:240000])
+    assert bytes(pkg.encode(d, enc, A.RUN)) == ref.encode_iter(d, int(A.RUN))
+    # the Finish stream is the one-shot stream
+    assert pkg.GZipEncoder().encode_all(d, A.FINISH) == oracle.deflate_encode(d, oracle.GZIP)
 
 
 def test_long_streams_in_parts(oracle):

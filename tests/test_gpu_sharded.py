@@ -123,3 +123,63 @@ def test_rccl_transport_library_single_rank(pkg, oracle):
     assert bytes(d_out[:k].cpu().numpy()) == oracle.encode(data, level)
     eng.close()
     comm.close()
+
+
+def _bench_ranks(world, extra_args, env_extra, timeout):
+    """bench.py's ranks started by hand (as torch.distributed.run would: RANK / WORLD_SIZE / MASTER_* in the
+    environment), so that nobody but the ranks themselves reacts to a peer's death."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), **env_extra)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--share-gpu"] + extra_args,
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, e = p.communicate()
+            o += "\n<<killed by the test: still running after %d s>>" % timeout
+        outs.append((p.returncode, o, e))
+    return outs
+
+
+def test_bench_two_ranks_line_is_self_sufficient():
+    """bench.py --gpus 2 (two real rank processes sharing the box's one GPU, gloo): the N > 1 line carries
+    cpu_baseline, roofline.pipeline_8d, per-step median / min, the rank count, the sharded decode round trip and
+    the single-process end-to-end figure over the run's devices -- everything a SCALE line needs."""
+    import json
+    outs = _bench_ranks(2, ["--steps", "2", "--warmup", "1", "--mib-per-gpu", "32", "--cpu-sample-mib", "8",
+                            "--hang-timeout", "240"], {}, 900)
+    assert [o[0] for o in outs] == [0, 0], outs[0][2][-2000:] + outs[1][2][-2000:]
+    line = json.loads(outs[0][1].strip().splitlines()[-1])
+    assert outs[1][1].strip() == ""                      # only rank 0 prints
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] == 1
+    assert line["roofline"]["pipeline_8d"]["frac"] > 0 and line["roofline"]["frac"] > 0
+    assert line["step_ms"]["n"] == 2 and line["step_ms"]["min"] <= line["step_ms"]["median"]
+    assert line["config"]["ranks"]["world"] == 2
+    assert line["end_to_end"]["devices"] == [0, 0] and line["end_to_end"]["bz_encode_buffer_multi"] > 0
+    assert line["extra"]["decode"]["round_trip_equals_input_on_every_rank"] is True
+    assert all(line["checks"].values()), line["checks"]
+    for k in ("stream_sha_equals_oracle_golden", "gpu_equals_oracle_on_cpu_sample", "decode_sharded_round_trip",
+              "end_to_end_buffer_equals_device_stream"):
+        assert k in line["checks"], k
+
+
+def test_bench_rank_death_does_not_hang_the_others():
+    """Rank 1 dies in front of its second timed step (BZ_BENCH_DIE=1:1); rank 0 is then inside a collective
+    whose peer is gone.  It must leave with a non-zero status well inside the hang timeout's reach instead of
+    waiting for ever -- through the transport's own error or bench.py's watchdog (status 5)."""
+    import time
+    t0 = time.time()
+    outs = _bench_ranks(2, ["--steps", "4", "--warmup", "1", "--mib-per-gpu", "32", "--no-extras", "--no-cpu-baseline",
+                            "--hang-timeout", "45"], {"BZ_BENCH_DIE": "1:1"}, 300)
+    took = time.time() - t0
+    assert outs[1][0] == 9
+    assert outs[0][0] not in (0, None) and "killed by the test" not in outs[0][1], outs[0][2][-1500:]
+    assert took < 240

@@ -139,3 +139,39 @@ def test_reference_quirk_match_free_dynamic_block():
     assert [b[2] for b in e.blocks()] == [2]
     with pytest.raises(zlib.error):
         zlib.decompress(e.output(), -15)
+
+
+def test_wrapper_iterator_level_restatement():
+    """ZlibEncoder::next / GZipEncoder::next (zlib/encoder.rs:118-152, gzip/encoder.rs:88-135) at the iterator
+    level: with Action::Finish the bytes are the reference's container vectors; with Run / Flush the container
+    still ends at the inner encoder's first None: header + the Inflater's bytes so far + trailer, then nothing."""
+    import struct
+    with open(os.path.join(HERE, "golden", "sample1.ref"), "rb") as f:
+        text = f.read()
+    for kind in (oracle.ZLIB, oracle.GZIP):
+        for d in (b"", b"a", text[:70000], text[:200000]):
+            w = oracle.WrapperEncoder(kind)
+            assert w.encode_iter(d, oracle.ACTION_FINISH) == oracle.deflate_encode(d, kind)
+            assert w.pulled == len(d)
+            assert w.encode_iter(b"abc", oracle.ACTION_FINISH) == b"" and w.pulled == 0
+    hdr = {oracle.ZLIB: 2, oracle.GZIP: 10}
+    for kind in (oracle.ZLIB, oracle.GZIP):
+        for d in (b"", text[:300], text[:70000], text[:200000]):
+            # Run: the Inflater alone, fed the same bytes, has handed out exactly these bytes
+            inner = oracle.DeflateEncoder()
+            inner.feed(d, oracle.ACTION_RUN)
+            body = inner.output()
+            got = oracle.WrapperEncoder(kind).encode_iter(d, oracle.ACTION_RUN)
+            trailer = struct.pack(">I", zlib.adler32(d)) if kind == oracle.ZLIB else struct.pack("<II", zlib.crc32(d), len(d))
+            assert got[hdr[kind]:] == body + trailer
+            if len(d) > 70000:
+                assert len(body) > 1000     # closed blocks did come out under Run
+            elif len(d) < 65536:
+                assert body == b""
+            # Flush: the flushed segment (non-final block, byte aligned), then the trailer
+            inner = oracle.DeflateEncoder()
+            inner.feed(d, oracle.ACTION_FLUSH)
+            got = oracle.WrapperEncoder(kind).encode_iter(d, oracle.ACTION_FLUSH)
+            assert got[hdr[kind]:] == inner.output() + trailer
+            z = zlib.decompressobj(-15)
+            assert z.decompress(inner.output()) == d   # a flushed segment inflates to its input

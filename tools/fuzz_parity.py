@@ -141,11 +141,34 @@ def deflate_flush_case():
     return True
 
 
+def deflate_wrapper_case():
+    """ZlibEncoder / GZipEncoder driven with Run or Flush: the container ends at the inner encoder's first None
+    (zlib/encoder.rs:138-150) -- against the oracle's iterator-level restatement, piece by piece"""
+    d = big()[:rng.choice([70000, 140000, 200000, 400000])] if rng.random() < 0.5 else gen()
+    kind = rng.choice([1, 2])
+    dict_ = gen()[:rng.choice([100, 40000])] if (kind == 1 and rng.random() < 0.2) else b""
+    enc = (pkg.ZlibEncoder if kind == 1 else pkg.GZipEncoder)(dict_=dict_)
+    ref = oracle.WrapperEncoder(kind, dict_)
+    cut = rng.randrange(len(d) + 1)
+    acts = [rng.randrange(3), rng.randrange(3)]
+    for piece, act in ((d[:cut], acts[0]), (d[cut:], acts[1])):
+        enc.write(piece)
+        enc.end(act)
+        if enc.read_all() != ref.encode_iter(piece, act):
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            open(os.path.join(ROOT, "gpurun_out", "fuzz_deflate_wrapper_fail.bin"), "wb").write(d)
+            print("deflate wrapper mismatch: n", len(d), "kind", kind, "cut", cut, "actions", acts, "dict", len(dict_))
+            return False
+    return True
+
+
 def deflate_case():
     """Deflate / zlib / gzip streams against the oracle; every so often a multi-block input"""
     import zlib
     if rng.random() < 0.35:
         return deflate_flush_case()
+    if rng.random() < 0.2:
+        return deflate_wrapper_case()
     d = big()[:rng.choice([70000, 200000, 700000])] if rng.random() < 0.15 else gen()
     kind = rng.randrange(3)
     got = pkg.deflate_compress(d, kind)
