@@ -163,7 +163,7 @@ def load_json(*path):
 
 
 ENC_KERNELS = ("k_radix_hist", "k_radix_scan", "k_radix_scatter", "k_group_flags", "k_group_apply", "k_last_column",
-               "k_radix_scatter_lb", "k_ghist_text", "k_ghist_scan", "k_bucket_sort", "k_rank_place")
+               "k_radix_scatter_lb", "k_ghist_text", "k_ghist_scan", "k_bucket_sort", "k_rank_place", "k_group_refine")
 DEC_KERNELS = ("k_dec_block", "k_dec_mtf", "k_dec_tsort", "k_dec_walk_lengths", "k_dec_place", "k_dec_rle", "k_dec_crc")
 
 

@@ -226,6 +226,7 @@ struct BwtArgs {
     u32 *count2;                     // [nb] scratch: survivors of the last round
     u32 *tile_nf;                    // [nb][kTilesPerBlock] survivors per tile of the last refinement
     u8 *flags;                       // [nb * kSlot]
+    u64 *newbits;                    // [nb * kSlot / 64] new-group starts of the last refined list, one bit per element
     int *tile_last_old;              // [nb][kTilesPerBlock]
     int *tile_last_new;              // [nb][kTilesPerBlock]
     u32 *nonfinal;                   // [nb]
@@ -386,6 +387,7 @@ enum KernelId {
     KID_GHIST_SCAN,
     KID_RANK_PLACE,       // binned rank words -> the rank array, whole lines
     KID_PHASE_B_LOCAL,    // phase B of the init inside LDS
+    KID_GROUP_REFINE,     // flags + apply in one pass (look-back for the two group carries)
     // decode path (k_dec.hip)
     KID_DEC_BLOCK,   // header + Huffman
     KID_DEC_MTF,     // chunk_perm + compose + chunk_emit

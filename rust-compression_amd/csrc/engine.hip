@@ -76,6 +76,7 @@ static int ensure_workspace(bz_gpu_engine *g, size_t need_blocks)
     ENS(tile_nf, nb * (size_t)kTilesPerBlock * 4);
     ENS(keyinfo, nb * (size_t)4);
     ENS(flags, nb * (size_t)kSlot);
+    ENS(newbits, nb * (size_t)kSlot / 8 + 256);
     ENS(tlo, nb * (size_t)kTilesPerBlock * 4);
     ENS(tln, nb * (size_t)kTilesPerBlock * 4);
     ENS(nonfinal, nb * 4);
@@ -180,7 +181,7 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
     DevBuf *all[] = {&g->crc_tab, &g->xp16, &g->xp2, &g->tile_last, &g->carry_in, &g->tile_crc, &g->tile_count,
                      &g->tile_off, &g->sub_off, &g->sub_rs, &g->scal, &g->scan_part, &g->rle, &g->blocks_all, &g->crc_all, &g->lblocks, &g->lcrc, &g->SA,
                      &g->R, &g->KA, &g->VA, &g->KB, &g->VB, &g->tile_hist, &g->count, &g->flags, &g->tlo, &g->tln,
-                     &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->bin_cursor, &g->pb_gate, &g->bin_base, &g->sym_code, &g->keyinfo, &g->count2, &g->tile_nf, &g->L, &g->orig_ptr, &g->inuse_bits,
+                     &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->bin_cursor, &g->pb_gate, &g->newbits, &g->bin_base, &g->sym_code, &g->keyinfo, &g->count2, &g->tile_nf, &g->L, &g->orig_ptr, &g->inuse_bits,
                      &g->summ, &g->summ_len, &g->init_state, &g->rank8, &g->ztile_last, &g->ztile_cnt, &g->mtf,
                      &g->mtf_freq, &g->bout, &g->selector, &g->code_len, &g->group_bitoff, &g->lm_scratch,
                      &g->stream, &g->error_flag, &g->packlist, &g->packed, &g->gathered, &g->asmlist, &g->gh_tiles, &g->gbase, &g->tile_state,
@@ -416,6 +417,7 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
     x.tile_nf = g->tile_nf.as<u32>() + t;
     x.bin_base = g->bin_base.as<u32>() + (size_t)o * kMaxBins;
     x.flags = g->flags.as<u8>() + s;
+    x.newbits = g->newbits.as<u64>() + s / 64;
     x.tile_last_old = g->tlo.as<int>() + t;
     x.tile_last_new = g->tln.as<int>() + t;
     x.nonfinal = g->nonfinal.as<u32>() + o;
@@ -1039,7 +1041,7 @@ extern "C" int bz_gpu_debug_code_lengths(bz_gpu_engine *g, const uint32_t *h_fre
 
 static const char *kKernelNames[KID_COUNT] = {"k_radix_hist", "k_radix_scan", "k_radix_scatter",
                                               "k_group_flags", "k_group_apply", "k_last_column",
-                                              "k_radix_scatter_lb", "k_ghist_text", "k_ghist_scan", "k_rank_place", "k_phase_b_local",
+                                              "k_radix_scatter_lb", "k_ghist_text", "k_ghist_scan", "k_rank_place", "k_phase_b_local", "k_group_refine",
                                               "k_dec_block", "k_dec_mtf", "k_dec_tsort", "k_dec_walk_lengths",
                                               "k_dec_place", "k_dec_rle", "k_dec_crc"};
 

@@ -43,7 +43,8 @@
 namespace bzgpu {
 
 enum { SRC_TEXT = 0, SRC_PAIRS = 1, SRC_MM = 2, SRC_WALK = 3, SRC_SURV = 4, SRC_LISTG = 5,
-       SRC_TEXTK = 6, SRC_WALKK = 7, SRC_MMK = 8 }; // ..K: keys stored by the histogram kernel of the pass
+       SRC_TEXTK = 6, SRC_WALKK = 7, SRC_MMK = 8, // ..K: keys stored by the histogram kernel of the pass
+       SRC_MMC = 9 }; // MM that also CARRIES the rank of rotation j+h along (k_radix_scatter_lb, first walk round)
 // sources whose sequence is the compacted list (length count[lb]) rather than all n positions
 template <int SRC> struct src_is_list {
     static constexpr bool value = (SRC == SRC_PAIRS || SRC == SRC_SURV || SRC == SRC_LISTG);
@@ -69,6 +70,23 @@ __device__ __forceinline__ u32 pkey(const u8 *__restrict__ pt, u32 j, u32 bits, 
     __builtin_memcpy(&v, pt + (bitpos >> 3), 8); // (one global_load_dwordx2: unaligned access is on for HSA code objects)
     v = __builtin_bswap64(v);
     return (u32)(v >> (64u - (bitpos & 7u) - kb)) & (u32)((1ull << kb) - 1ull);
+}
+
+// The new-group starts of a refined list as a BITMAP: one 64-bit word per row of 64 list elements (the ballot a
+// refinement takes anyway), written by k_group_flags / k_group_refine, read by k_survivor_compact and by the walk
+// pass that carries ranks along (k_radix_scatter_lb<SRC_MMC>).  Rows are read 16 at a time: lane r < 17 loads the
+// word of row r (one 136-byte access per wave), the others take it with a lane read.  Elements at or beyond `cnt`
+// count as starts (`fill`), words of rows that lie wholly beyond it were never written.
+__device__ __forceinline__ u64 newbits_lane_word(const u64 *__restrict__ bits, size_t base, u32 wbase, u32 cnt, u32 l, bool fill)
+{
+    const u32 rowbase = wbase + l * 64u;
+    u64 m = 0;
+    if (l < 17u && rowbase < cnt) m = bits[(base + rowbase) >> 6];
+    if (fill && l < 17u) {
+        if (rowbase >= cnt) m = ~0ull;
+        else if (cnt - rowbase < 64u) m |= ~0ull << (cnt - rowbase);
+    }
+    return m;
 }
 
 // Batched form: the 16 rows of one lane.  All primary loads are issued back to back (clamped
@@ -641,7 +659,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
     const u8 *text = a.rle + d.rle_off;
     const u8 *pt = a.ptext + (size_t)lb * kSlot;
     const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
-    const u32 hm = (SRC == SRC_MM || SRC == SRC_MMK || SRC == SRC_SURV) ? (((u32)ki.chars * 2u) << h) % n : 0u;
+    const u32 hm = (SRC == SRC_MM || SRC == SRC_MMC || SRC == SRC_MMK || SRC == SRC_SURV) ? (((u32)ki.chars * 2u) << h) % n : 0u;
     const size_t base = (size_t)lb * kSlot;
     for (u32 i = threadIdx.x; i < NW * NB / 2; i += kSortThreads) s_buf[i] = 0;
     __syncthreads();
@@ -653,6 +671,31 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
     u32 rnk[16]; // 0xFFFFFFFF = takes no part
     const u32 okmask =
         fetch_rows<SRC>(a, lb, pt, n, hm, Kin, Vin, start + w * 1024u + l, cnt, ki, key, val);
+    // SRC_MMC (the walk round that follows the first refinement): the list this pass builds is refined by
+    // (group of j, rank of rotation j+h), and the rotation j+h of the element walked at position i is SA[i]: its rank
+    // is the head of the group position i lies in -- the last new-group start at or before i, which the first
+    // refinement left as flag bytes in SA order.  That head travels with the element in the 12 spare bits of key and
+    // value (both are 20-bit numbers), so the refinement needs no gather of the rank array (k_group_refine<false>).
+    // (The head goes into the spare bits at once -- the digits of this pass and the next are the low 20 bits of the
+    // key; an element in front of its wave's first group start gets 0xFFFFF, "the start lies in front of this wave",
+    // and is patched once the waves in front have said where: no mask is kept in registers.)
+    __shared__ int s_wlast[NW];
+    if (SRC == SRC_MMC) {
+        int wl = -1;
+        const u64 le_mask = (l == 63) ? ~0ull : ((2ull << l) - 1ull);
+        const u64 myword = newbits_lane_word(a.newbits, base, start + w * 1024u, cnt, l, false);
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) {
+            const u32 rowbase = start + w * 1024u + r * 64u;
+            const u64 mnew = __shfl(myword, r, 64);
+            const u64 q = mnew & le_mask;
+            const u32 head = q ? rowbase + 63u - (u32)__clzll(q) : (wl >= 0 ? (u32)wl : 0xFFFFFu);
+            key[r] = (key[r] & (0xFFFFFu | kFinalBit)) | ((head & 0xFFFu) << 20);
+            val[r] = val[r] | ((head >> 12) << 20);
+            if (mnew) wl = (int)(rowbase + 63u - (u32)__clzll(mnew));
+        }
+        if (l == 0) s_wlast[w] = wl;
+    }
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
         const bool ok = (okmask >> r) & 1u;
@@ -755,6 +798,18 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
     }
     const u32 total = s_total;
     __syncthreads(); // counters are dead from here on: the buffer becomes the staging area
+    if (SRC == SRC_MMC) {
+        int carry = tile ? a.tile_last_new[lb * kTilesPerBlock + tile - 1u] : 0; // (settled by k_group_refine<true>)
+        for (u32 k = 0; k < w; ++k) carry = s_wlast[k] > carry ? s_wlast[k] : carry;
+        const u32 ck = ((u32)carry & 0xFFFu) << 20, cv = ((u32)carry >> 12) << 20;
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) {
+            if ((key[r] >> 20) == 0xFFFu && (val[r] >> 20) == 0xFFu) {
+                key[r] = (key[r] & 0xFFFFFu) | ck;
+                val[r] = (val[r] & 0xFFFFFu) | cv;
+            }
+        }
+    }
 #pragma unroll
     for (u32 r = 0; r < 16; ++r)
         if (lpos[r] != 0xFFFFFFFFu) s_buf[lpos[r]] = key[r];
@@ -1147,13 +1202,16 @@ __global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 ste
             p1 = q1;
             p2 = q2;
         }
+        bool ns = false;
         if (ok) {
             const bool os = (idx == 0) || (g[r] != pg);
-            const bool ns = os || (s1[r] != p1) || (s2[r] != p2);
+            ns = os || (s1[r] != p1) || (s2[r] != p2);
             a.flags[base + idx] = (u8)((os ? 1u : 0u) | (ns ? 2u : 0u));
             if (os) last_old = (int)idx;
             if (ns) last_new = (int)idx;
         }
+        const u64 mrow = __ballot(ns);
+        if (l == 0 && idx < cnt) a.newbits[(base + idx) >> 6] = mrow;
     }
 #pragma unroll
     for (u32 dd = 32; dd >= 1; dd >>= 1) {
@@ -1386,6 +1444,317 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
     }
 }
 
+// ---- group refinement in ONE pass: flags + positions + rank words ----------------------------------
+// k_group_flags and k_group_apply read the same pair list twice (and hand the flag bytes and two tile carries
+// through memory in between).  Here a tile computes its boundary flags (the gathers of k_group_flags), keeps them as
+// wave ballots, and goes straight on with the work of k_group_apply; the two things a tile needs from the tiles in
+// front of it -- the last old-group start and the last new-group start before its first element -- come by the same
+// decoupled look-back the fused radix passes use (tickets per XCD, epoch-tagged words in tile_state, XCD-local L2):
+// a tile publishes the last starts it holds itself (AGG; "none" = 0xFFFFF) as soon as its flags are known, looks back
+// until both are settled (almost always one hop: a tile without a group start is rare), and publishes the settled
+// pair (INCL).  The one flag a tile needs from BEHIND itself -- does the element after a wave's span start a new
+// group -- is computed from that element directly (one extra gather per wave).  The new-group starts leave as a
+// bitmap (one ballot per row): k_survivor_compact and the walk pass of the next round read it.
+//   INIT : the first refinement (the list is SA in the order of the first 2c symbols; the secondary key is gathered
+//          from the packed text).  Its settled last new-group start per tile is kept in tile_last_new.
+//   else : the refinement of the walk round that follows it.  The secondary key -- the rank of rotation j+h -- came
+//          along in the spare bits of key and value (k_radix_scatter_lb<SRC_MMC>): no gather at all.
+// Later rounds keep k_group_flags + k_group_apply: with few elements the 131 k tickets of a launch cost more than
+// the second read of the list (1.5 ms against 0.15), and a walk round further on has no flags in SA order to carry.
+// Used when the fused radix passes are (a.fused); BZ_FUSED_REFINE=0 keeps the two kernels everywhere.
+constexpr u32 kLbNone = 0xFFFFFu;
+template <bool INIT>
+__global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32 step, u32 next_step, u32 round,
+                                                                const u32 *__restrict__ K,
+                                                                const u32 *__restrict__ V, u32 *__restrict__ W,
+                                                                u32 epoch)
+{
+    constexpr u32 NW = kSortThreads / 64;
+    __shared__ int s_carry_old, s_carry_new;
+    __shared__ int s_wold[NW], s_wnew[NW];
+    __shared__ u32 s_nonfinal, s_ticket;
+    __shared__ u32 s_gh[2][1024];
+    __shared__ u32 s_stage[kSortTile];
+    __shared__ u16 s_binof[kSortTile];
+    __shared__ u32 s_bcnt[1024];
+    __shared__ u16 s_bpre[1024];
+    __shared__ u32 s_wsum[NW];
+    const u32 xcd = (u32)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u; // XCC_ID (see k_radix_scatter_lb)
+    const u32 my_tiles = kTilesPerBlock * ((a.nb + 7u - xcd) / 8u);
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&a.tickets[(size_t)epoch * 8u + xcd], 1u);
+    __syncthreads();
+    const u32 slot = s_ticket;
+    if (slot >= my_tiles) return;
+    const u32 b8 = slot / kTilesPerBlock;
+    const u32 tile = slot - b8 * kTilesPerBlock;
+    const u32 lb = b8 * 8u + xcd;
+    const BlockDesc d = a.blocks[lb];
+    const u32 n = d.n;
+    const u8 *__restrict__ text = a.rle + d.rle_off;
+    const u32 cnt = a.count[lb];
+    const u32 start = tile * kSortTile;
+    if (start >= cnt) return;
+    const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
+    const u32 hm = INIT ? (u32)ki.chars % n : (((u32)ki.chars * 2u) << step) % n;
+    const u8 *pt = a.ptext + (size_t)lb * kSlot;
+    const size_t base = (size_t)lb * kSlot;
+    if (INIT && a.pb_gate[lb] == 0u) K = a.KA; // phase B was done in LDS: phase A's keys are the list's keys
+    for (u32 i = threadIdx.x; i < 2048u; i += kSortThreads) (&s_gh[0][0])[i] = 0;
+    for (u32 i = threadIdx.x; i < 1024u; i += kSortThreads) s_bcnt[i] = 0;
+    if (threadIdx.x == 0) s_nonfinal = 0;
+    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const u32 wbase = start + w * 1024u;
+    const u32 first = wbase + l;
+
+    // ---- the pair list and the secondary keys (k_group_flags)
+    u32 gk[16], jv[16], s1[16], s2[16];
+    u32 pg0 = 0, ps10 = 0, ps20 = 0; // the element in front of the wave's span (lane 0)
+    u32 ng0 = 0, ns10 = 0, ns20 = 0; // the element behind it (lane 63)
+    const bool need_prev = (l == 0) && (first > 0) && (first < cnt);
+    const bool need_next = (l == 63) && (wbase + 1024u < cnt);
+    {
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) {
+            const u32 idx = first + r * 64u;
+            const u32 c = idx < cnt ? idx : cnt - 1u;
+            const u32 kk = ld_stream(K + base + c);
+            const u32 vv = ld_stream(V + base + c);
+            if (INIT) {
+                jv[r] = vv;
+                const u32 t = vv + hm;
+                s2[r] = t >= n ? t - n : t; // (the position of the secondary key, for now)
+                gk[r] = 0u;
+                s1[r] = kk;
+            } else { // key = group | rank bits 0..11, value = rotation | rank bits 12..19 (k_radix_scatter_lb<SRC_MMC>)
+                jv[r] = vv & 0xFFFFFu;
+                gk[r] = kk & 0xFFFFFu;
+                s1[r] = (kk >> 20) | ((vv >> 20) << 12);
+                s2[r] = 0u;
+            }
+        }
+        u32 pj = 0, nj = 0;
+        if (need_prev) {
+            const u32 kk = K[base + wbase - 1], vv = V[base + wbase - 1];
+            pg0 = INIT ? 0u : (kk & 0xFFFFFu);
+            ps10 = INIT ? kk : ((kk >> 20) | ((vv >> 20) << 12));
+            const u32 t = vv + hm;
+            pj = t >= n ? t - n : t;
+        }
+        if (need_next) {
+            const u32 kk = K[base + wbase + 1024u], vv = V[base + wbase + 1024u];
+            ng0 = INIT ? 0u : (kk & 0xFFFFFu);
+            ns10 = INIT ? kk : ((kk >> 20) | ((vv >> 20) << 12));
+            const u32 t = vv + hm;
+            nj = t >= n ? t - n : t;
+        }
+        if (INIT) {
+#pragma unroll
+            for (u32 r = 0; r < 16; ++r) s2[r] = pkey(pt, s2[r], ki.bits, ki.chars);
+            if (need_prev) ps20 = pkey(pt, pj, ki.bits, ki.chars);
+            if (need_next) ns20 = pkey(pt, nj, ki.bits, ki.chars);
+        }
+    }
+    // ---- boundary flags as ballots; the bytes go out for k_survivor_compact
+    u64 mo[16] = {}, mn[16];
+    int wl_old = -1, wl_new = -1;
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 idx = first + r * 64u;
+        const bool ok = idx < cnt;
+        u32 pg = __shfl_up(gk[r], 1, 64), p1 = __shfl_up(s1[r], 1, 64), p2 = __shfl_up(s2[r], 1, 64);
+        const u32 qg = (r == 0) ? pg0 : __shfl(gk[(r + 15) & 15], 63, 64);
+        const u32 q1 = (r == 0) ? ps10 : __shfl(s1[(r + 15) & 15], 63, 64);
+        const u32 q2 = (r == 0) ? ps20 : __shfl(s2[(r + 15) & 15], 63, 64);
+        if (l == 0) {
+            pg = qg;
+            p1 = q1;
+            p2 = q2;
+        }
+        const bool os = ok && ((idx == 0) || (!INIT && gk[r] != pg));
+        const bool ns = ok && (os || (s1[r] != p1) || (s2[r] != p2));
+        mn[r] = __ballot(ns);
+        if (l == 0 && ok) a.newbits[(base + idx) >> 6] = mn[r];
+        if (mn[r]) wl_new = (int)(wbase + r * 64u + 63u - __clzll(mn[r]));
+        if (!INIT) { // (INIT: the whole list is one old group that starts at 0)
+            mo[r] = __ballot(os);
+            if (mo[r]) wl_old = (int)(wbase + r * 64u + 63u - __clzll(mo[r]));
+        }
+    }
+    // does the element behind the wave's span start a new group?  (lane 63 holds both sides)
+    bool next_after = true;
+    if (need_next) next_after = (gk[15] != ng0) || (s1[15] != ns10) || (s2[15] != ns20);
+    next_after = __shfl((u32)next_after, 63, 64) != 0u;
+    if (l == 0) {
+        s_wold[w] = INIT ? 0 : wl_old;
+        s_wnew[w] = wl_new;
+    }
+    __syncthreads();
+    // ---- the carries from the tiles in front: decoupled look-back
+    if (threadIdx.x == 0) {
+        int lo = INIT ? 0 : -1, ln = -1; // (INIT: one old group, it starts at 0)
+        for (u32 k = 0; k < NW; ++k) {
+            lo = s_wold[k] > lo ? s_wold[k] : lo;
+            ln = s_wnew[k] > ln ? s_wnew[k] : ln;
+        }
+        u32 *mystate = a.tile_state + ((size_t)lb * kTilesPerBlock + tile) * kMaxBins;
+        const u32 etag = epoch << 22;
+        const u32 f0 = etag | (tile ? kLbAgg : kLbIncl);
+        const u32 vo = lo >= 0 ? (u32)lo : kLbNone, vn = ln >= 0 ? (u32)ln : kLbNone;
+        st_sc1_x4(mystate, make_uint4(f0 | vo, f0 | vn, f0, f0));
+        int co = -1, cn = -1;
+        if (tile) {
+            u32 spins = 0;
+            for (u32 p = tile; p > 0 && (co < 0 || cn < 0);) {
+                --p;
+                const u32 *src = a.tile_state + ((size_t)lb * kTilesPerBlock + p) * kMaxBins;
+                uint4 v = ld_sc1_x4(src);
+                while ((v.x >> 22) != epoch || (v.x & kLbFlagMask) == 0u || (v.y >> 22) != epoch || (v.y & kLbFlagMask) == 0u) {
+                    if (++spins > kLbSpinMax) {
+                        atomicExch(a.sort_err, 1u);
+                        v = make_uint4(etag | kLbIncl, etag | kLbIncl, 0, 0); // (give up: the host redoes the sort)
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    v = ld_sc1_x4(src);
+                }
+                const u32 xo = v.x & kLbValMask, xn = v.y & kLbValMask;
+                if (co < 0 && xo != kLbNone) co = (int)xo;
+                if (cn < 0 && xn != kLbNone) cn = (int)xn;
+            }
+            const u32 fi = etag | kLbIncl;
+            const u32 io = lo >= 0 ? (u32)lo : (u32)co, in = ln >= 0 ? (u32)ln : (u32)cn;
+            st_sc1_x4(mystate, make_uint4(fi | (io & kLbValMask), fi | (in & kLbValMask), fi, fi));
+        }
+        // (the walk pass of the next round starts its tiles from these)
+        a.tile_last_new[lb * kTilesPerBlock + tile] = ln >= 0 ? ln : cn;
+        a.tile_last_old[lb * kTilesPerBlock + tile] = lo >= 0 ? lo : co;
+        s_carry_old = co;
+        s_carry_new = cn;
+    }
+    __syncthreads();
+    int carry_old = INIT ? 0 : s_carry_old, carry_new = s_carry_new;
+    for (u32 k = 0; k < w; ++k) {
+        if (!INIT) carry_old = s_wold[k] > carry_old ? s_wold[k] : carry_old;
+        carry_new = s_wnew[k] > carry_new ? s_wnew[k] : carry_new;
+    }
+    // ---- positions, rank words, last column (k_group_apply)
+    const u64 le_mask = (l == 63) ? ~0ull : ((2ull << l) - 1ull);
+    u32 my_nonfinal = 0;
+    u32 word[16], lrank[16];
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 rowbase = wbase + r * 64u;
+        const u32 idx = rowbase + l;
+        lrank[r] = 0xFFFFFFFFu;
+        word[r] = 0;
+        bool nf = false;
+        u32 nf_head = 0;
+        if (idx < cnt) {
+            int rs = 0;
+            if (!INIT) {
+                const u64 o = mo[r] & le_mask;
+                rs = o ? (int)(rowbase + 63u - __clzll(o)) : carry_old;
+            }
+            const u64 q = mn[r] & le_mask;
+            const int ss = q ? (int)(rowbase + 63u - __clzll(q)) : carry_new;
+            bool next_new;
+            if (idx + 1 >= cnt) next_new = true;
+            else if (l < 63) next_new = (mn[r] >> (l + 1)) & 1ull;
+            else if (r < 15) next_new = mn[(r + 1) & 15] & 1ull;
+            else next_new = next_after;
+            const bool is_new = (mn[r] >> l) & 1ull;
+            const bool fin = is_new && next_new;
+            const u32 g = gk[r];
+            const u32 j = jv[r];
+            const u32 p = g + (idx - (u32)rs);
+            const u32 head = g + ((u32)ss - (u32)rs);
+            if (!INIT) st_stream(a.SA + base + p, j); // (INIT: the list IS SA, p == idx)
+            if (fin) {
+                a.L[base + p] = text[j ? j - 1u : n - 1u]; // src/bzip2/encoder.rs:331-338, as in k_group_apply
+                if (j == 0) a.orig_ptr[lb] = p;
+            }
+            word[r] = (j & kRankBinMask) | (head << kRankBinShift) | (fin ? kFinalBit : 0u);
+            lrank[r] = atomicAdd(&s_bcnt[j >> kRankBinShift], 1u);
+            my_nonfinal += fin ? 0u : 1u;
+            nf = !fin;
+            nf_head = head;
+        }
+        {
+            const u64 mnf = __ballot(nf);
+            if (mnf) {
+                if (nf) atomicAdd(&s_gh[0][nf_head & 1023u], 1u);
+                const u32 lead = (u32)__ffsll((long long)mnf) - 1u;
+                const u32 hi = (nf_head >> 10) & 1023u;
+                const u32 hi0 = __shfl(hi, lead, 64);
+                const u64 same = __ballot(nf && hi == hi0);
+                if (same == mnf) {
+                    if (l == lead) atomicAdd(&s_gh[1][hi0], (u32)__popcll(mnf));
+                } else if (nf) {
+                    atomicAdd(&s_gh[1][hi], 1u);
+                }
+            }
+        }
+        if (!INIT && mo[r]) carry_old = (int)(rowbase + 63u - __clzll(mo[r]));
+        if (mn[r]) carry_new = (int)(rowbase + 63u - __clzll(mn[r]));
+    }
+    my_nonfinal = wave_sum(my_nonfinal);
+    if (l == 0 && my_nonfinal) atomicAdd(&s_nonfinal, my_nonfinal);
+    __syncthreads();
+    if (threadIdx.x == 0) a.tile_nf[lb * kTilesPerBlock + tile] = s_nonfinal;
+    {
+        u32 *out = a.gh_tiles + ((size_t)lb * kTilesPerBlock + tile) * 3 * kMaxBins;
+        for (u32 i = threadIdx.x; i < 1024u; i += kSortThreads) {
+            out[i] = s_gh[0][i];
+            out[kMaxBins + i] = s_gh[1][i];
+        }
+    }
+    if (threadIdx.x == 0 && s_nonfinal) {
+        atomicAdd(&a.nonfinal[lb], s_nonfinal);
+        const u32 h_next = ((u32)ki.chars * 2u) << next_step;
+        if (h_next < n) atomicAdd(&a.active[round], (unsigned long long)s_nonfinal);
+    }
+    // ---- bin scatter of the rank words (as in k_group_apply)
+    {
+        const u32 b0 = threadIdx.x * 2u;
+        const u32 c0 = s_bcnt[b0], c1 = s_bcnt[b0 + 1];
+        const u32 mine = c0 + c1;
+        const u32 inc = wave_incl_sum(mine);
+        if (l == 63) s_wsum[w] = inc;
+        u32 g0 = 0, g1 = 0;
+        u32 *cur = a.bin_cursor + (size_t)lb * 1024u;
+        if (c0) g0 = atomicAdd(&cur[b0], c0);
+        if (c1) g1 = atomicAdd(&cur[b0 + 1], c1);
+        __syncthreads();
+        u32 carry = 0;
+        for (u32 k = 0; k < w; ++k) carry += s_wsum[k];
+        const u32 ex = carry + inc - mine;
+        s_bpre[b0] = (u16)ex;
+        s_bpre[b0 + 1] = (u16)(ex + c0);
+        s_bcnt[b0] = (b0 << kRankBinShift) + g0;
+        s_bcnt[b0 + 1] = ((b0 + 1u) << kRankBinShift) + g1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        if (lrank[r] != 0xFFFFFFFFu) {
+            const u32 bin = jv[r] >> kRankBinShift;
+            const u32 pos = (u32)s_bpre[bin] + lrank[r];
+            s_stage[pos] = word[r];
+            s_binof[pos] = (u16)bin;
+        }
+    }
+    __syncthreads();
+    const u32 total = (cnt - start) < kSortTile ? (cnt - start) : kSortTile;
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k) {
+        const u32 i = k * kSortThreads + threadIdx.x;
+        if (i < total) {
+            const u32 bin = s_binof[i];
+            W[base + s_bcnt[bin] + (i - (u32)s_bpre[bin])] = s_stage[i];
+        }
+    }
+}
+
 // One wave per bin: the rank words of bin b (a.bin_cursor[b] of them, behind W[b * 1024]) go to
 // R[b * 1024 + (word & 1023)].  A full bin (every round-0 bin but the last) is put in order in LDS and
 // written as whole lines; a partly filled one updates the lines it is loaded into; a sparse one
@@ -1478,19 +1847,13 @@ __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, co
     for (u32 r = 0; r < 16; ++r) {
         const u32 idx = wbase + r * 64u + l;
         const u32 c = idx < cnt ? idx : cnt - 1u;
-        jv[r] = ld_stream(V + base + c);
+        jv[r] = ld_stream(V + base + c) & 0xFFFFFu; // (the list of a walk round may carry ranks in the spare bits)
     }
-    u64 mn[17];
-#pragma unroll
-    for (u32 r = 0; r < 16; ++r) {
-        const u32 idx = wbase + r * 64u + l;
-        const u32 f = (idx < cnt) ? ld_stream(a.flags + base + idx) : 2u;
-        mn[r] = __ballot(f & 2u);
-    }
+    u64 mn[17]; // (row 16: the element right after the wave's span)
     {
-        // flag of the element right after the wave's span
-        const u32 nx = wbase + 1024u;
-        mn[16] = (nx < cnt) ? ((a.flags[base + nx] & 2u) ? 1ull : 0ull) : 1ull;
+        const u64 myword = newbits_lane_word(a.newbits, base, wbase, cnt, l, true);
+#pragma unroll
+        for (u32 r = 0; r < 17; ++r) mn[r] = __shfl(myword, r, 64);
     }
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
@@ -1844,7 +2207,7 @@ static void fused_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const
                        const u32 *gate = nullptr)
 {
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
-    const u64 rd = (SRC == SRC_TEXTK) ? 4 : ((SRC == SRC_TEXT) ? 1 : ((SRC == SRC_WALK) ? 5 : 8));
+    const u64 rd = (SRC == SRC_TEXTK) ? 4 : ((SRC == SRC_TEXT) ? 1 : ((SRC == SRC_WALK) ? 5 : (SRC == SRC_MMC ? 9 : 8)));
     const u32 e = next_epoch(st, a);
     if (out_elems == ~0ull) out_elems = elems;
     const int p = prof ? prof->begin(st, KID_RADIX_SCATTER_LB, elems * rd + out_elems * (WRITE_K ? 8 : 4)) : -1;
@@ -1978,13 +2341,27 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         if (wide_keys) init_sort<11, 11, 10>(st, a, total_n, prof);
         else init_sort<10, 10, 10>(st, a, total_n, prof);
     }
-    int p = prof ? prof->begin(st, KID_GROUP_FLAGS, total_n * 9) : -1;
-    hipLaunchKernelGGL((k_group_flags<true>), grid, dim3(kSortThreads), 0, st, a, 0u, a.KB, a.SA);
-    if (prof) prof->end(st, p);
+    // flags + apply in one pass (k_group_refine) whenever the fused radix passes are in use; BZ_FUSED_REFINE=0 keeps
+    // the two kernels (A/B measurements, tests)
+    static const bool want_refine = !(getenv("BZ_FUSED_REFINE") && atoi(getenv("BZ_FUSED_REFINE")) == 0);
+    static const bool local_b_on = getenv("BZ_LOCAL_B") && atoi(getenv("BZ_LOCAL_B")) != 0;
+    // (BZ_LOCAL_B=1: the first refinement reads phase A's keys from KA, the array its rank words go to: two kernels)
+    const bool refine = fused && want_refine && !local_b_on;
+    int p;
     (void)hipMemsetAsync(a.bin_cursor, 0, (size_t)a.nb * 1024 * sizeof(u32), st);
-    p = prof ? prof->begin(st, KID_GROUP_APPLY, total_n * 13) : -1;
-    hipLaunchKernelGGL((k_group_apply<true>), grid, dim3(kSortThreads), 0, st, a, 0u, 0u, a.KB, a.SA, a.KA);
-    if (prof) prof->end(st, p);
+    if (refine) {
+        const u32 e = next_epoch(st, a);
+        p = prof ? prof->begin(st, KID_GROUP_REFINE, total_n * 14) : -1; // K 4, V 4, flag byte 1, rank word 4, last column 1
+        hipLaunchKernelGGL((k_group_refine<true>), grid, dim3(kSortThreads), 0, st, a, 0u, 0u, 0u, a.KB, a.SA, a.KA, e);
+        if (prof) prof->end(st, p);
+    } else {
+        p = prof ? prof->begin(st, KID_GROUP_FLAGS, total_n * 9) : -1;
+        hipLaunchKernelGGL((k_group_flags<true>), grid, dim3(kSortThreads), 0, st, a, 0u, a.KB, a.SA);
+        if (prof) prof->end(st, p);
+        p = prof ? prof->begin(st, KID_GROUP_APPLY, total_n * 13) : -1;
+        hipLaunchKernelGGL((k_group_apply<true>), grid, dim3(kSortThreads), 0, st, a, 0u, 0u, a.KB, a.SA, a.KA);
+        if (prof) prof->end(st, p);
+    }
     p = prof ? prof->begin(st, KID_RANK_PLACE, total_n * 8) : -1;
     hipLaunchKernelGGL(k_rank_place, grid, dim3(kSortThreads), 0, st, a, a.KA);
     if (prof) prof->end(st, p);
@@ -2006,6 +2383,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         if (m == 0 || step > 24 || ((u64)(2u * min_chars) << step) >= max_n) break;
         ++slot;
         ++rounds;
+        bool carried = false;
         (void)hipMemsetAsync(a.nonfinal, 0, a.nb * sizeof(u32), st);
         if (m * 4 < total_n) {
             // few survivors: compact them (list order = sorted by group), order them by the rank
@@ -2025,20 +2403,31 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             if (fused) {
                 // the keys are the group heads of the rotations that are not final: k_group_apply counted them
                 hipLaunchKernelGGL(k_ghist_scan, dim3(a.nb), dim3(kSortThreads), 0, st, a, 2u, 1024u, 1024u, 0u, 1u);
-                fused_pass<SRC_MM, 10>(st, a, 0, step, nullptr, nullptr, fK, fV, 0, total_n, prof, m);
+                // the round behind the first refinement: its flags lie in SA order, the rank of rotation j+h travels
+                // with the element and the refinement gathers nothing (k_group_refine<false>)
+                carried = refine && rounds == 1;
+                if (carried) fused_pass<SRC_MMC, 10>(st, a, 0, step, nullptr, nullptr, fK, fV, 0, total_n, prof, m);
+                else fused_pass<SRC_MM, 10>(st, a, 0, step, nullptr, nullptr, fK, fV, 0, total_n, prof, m);
                 fused_pass<SRC_PAIRS, 10>(st, a, 10, step, fK, fV, cK, cV, 1, m, prof);
             } else {
                 radix_pass<SRC_MM, 10>(st, a, 0, step, nullptr, nullptr, fK, fV, total_n, prof, cK);
                 radix_pass<SRC_PAIRS, 10>(st, a, 10, step, fK, fV, cK, cV, m, prof);
             }
         }
-        p = prof ? prof->begin(st, KID_GROUP_FLAGS, m * 13) : -1;
-        hipLaunchKernelGGL((k_group_flags<false>), grid, dim3(kSortThreads), 0, st, a, step, cK, cV);
-        if (prof) prof->end(st, p);
         (void)hipMemsetAsync(a.bin_cursor, 0, (size_t)a.nb * 1024 * sizeof(u32), st);
-        p = prof ? prof->begin(st, KID_GROUP_APPLY, m * 17) : -1;
-        hipLaunchKernelGGL((k_group_apply<false>), grid, dim3(kSortThreads), 0, st, a, step + 1, slot, cK, cV, fK);
-        if (prof) prof->end(st, p);
+        if (carried) {
+            const u32 e = next_epoch(st, a);
+            p = prof ? prof->begin(st, KID_GROUP_REFINE, m * 18) : -1; // K 4, V 4, flag 1, SA 4, rank word 4, column 1
+            hipLaunchKernelGGL((k_group_refine<false>), grid, dim3(kSortThreads), 0, st, a, step, step + 1, slot, cK, cV, fK, e);
+            if (prof) prof->end(st, p);
+        } else {
+            p = prof ? prof->begin(st, KID_GROUP_FLAGS, m * 13) : -1;
+            hipLaunchKernelGGL((k_group_flags<false>), grid, dim3(kSortThreads), 0, st, a, step, cK, cV);
+            if (prof) prof->end(st, p);
+            p = prof ? prof->begin(st, KID_GROUP_APPLY, m * 17) : -1;
+            hipLaunchKernelGGL((k_group_apply<false>), grid, dim3(kSortThreads), 0, st, a, step + 1, slot, cK, cV, fK);
+            if (prof) prof->end(st, p);
+        }
         p = prof ? prof->begin(st, KID_RANK_PLACE, m * 8) : -1;
         hipLaunchKernelGGL(k_rank_place, grid, dim3(kSortThreads), 0, st, a, fK);
         if (prof) prof->end(st, p);

@@ -156,8 +156,10 @@ def test_bench_two_ranks_line_is_self_sufficient():
     outs = _bench_ranks(2, ["--steps", "2", "--warmup", "1", "--mib-per-gpu", "32", "--cpu-sample-mib", "8",
                             "--hang-timeout", "240"], {}, 900)
     assert [o[0] for o in outs] == [0, 0], outs[0][2][-2000:] + outs[1][2][-2000:]
-    line = json.loads(outs[0][1].strip().splitlines()[-1])
-    assert outs[1][1].strip() == ""                      # only rank 0 prints
+    lines0 = [x for x in outs[0][1].splitlines() if x.startswith("{")]
+    assert len(lines0) == 1                              # ONE JSON line, from rank 0 only
+    assert not [x for x in outs[1][1].splitlines() if x.startswith("{")]
+    line = json.loads(lines0[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] == 1
     assert line["roofline"]["pipeline_8d"]["frac"] > 0 and line["roofline"]["frac"] > 0

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT -o $TAG -- python3 $R/bench.py --no-cpu-baseline --steps 1 --warmup 0 --mib-per-gpu $MIB > $OUT/bench.json 2> $OUT/err.txt
+rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT -o $TAG -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 0 --mib-per-gpu $MIB > $OUT/bench.json 2> $OUT/err.txt
 python3 - <<PY
 import csv, glob, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
