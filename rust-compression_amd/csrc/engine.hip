@@ -84,7 +84,7 @@ static int ensure_workspace(bz_gpu_engine *g, size_t need_blocks)
     ENS(per_k, nb * 4);
     ENS(per_shift, nb * 4);
     ENS(bin_cursor, nb * (size_t)1024 * 4);
-    ENS(pb_gate, nb * (size_t)4 + 64);
+    ENS(pb_gate, nb * (size_t)4 + 256); // (+ loc_stats behind the gates)
     if (hipMemset(g->pb_gate.p, 0, g->pb_gate.cap) != hipSuccess) return BZ_E_UNEXPECTED;
     ENS(L, nb * (size_t)kSlot + 64);
     ENS(orig_ptr, nb * 4);

@@ -499,7 +499,15 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
 // passes.  What it saves: the histogram kernels (and, for the passes whose keys are gathered, the
 // round trip of the keys through memory).
 constexpr u32 kLbValMask = 0xFFFFFu, kLbAgg = 1u << 20, kLbIncl = 2u << 20, kLbFlagMask = 3u << 20;
-constexpr u32 kLbSpinMax = 1u << 22;
+// A spin gives up after about a second -- or as soon as another tile of the launch has given up (sort_err): one
+// look-back that cannot complete leaves every tile behind it waiting, and each of them for the full bound otherwise.
+constexpr u32 kLbSpinMax = 1u << 20;
+__device__ __forceinline__ bool lb_give_up(u32 &spins, const u32 *sort_err, u32 limit)
+{
+    ++spins;
+    if (spins > limit) return true;
+    return (spins & 255u) == 0u && __hip_atomic_load(sort_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+}
 
 // 16-byte accesses that the other compute units OF THE SAME XCD observe: plain stores are written
 // through to the XCD's L2 and stay there, `nt` loads bypass the L1 and are served by that L2
@@ -746,7 +754,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
                     for (u32 k = 0; k < 4; ++k)
                         if ((x[k] >> 22) != epoch || (x[k] & kLbFlagMask) == 0u) ready = false;
                     if (ready) break; // (the four words of a group are written by one store)
-                    if (++spins > kLbSpinMax) {
+                    if (lb_give_up(spins, a.sort_err, kLbSpinMax)) {
                         atomicExch(a.sort_err, 1u);
                         v = make_uint4(etag | kLbIncl, etag | kLbIncl, etag | kLbIncl, etag | kLbIncl);
                         break;
@@ -1463,6 +1471,14 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
 // the second read of the list (1.5 ms against 0.15), and a walk round further on has no flags in SA order to carry.
 // Used when the fused radix passes are (a.fused); BZ_FUSED_REFINE=0 keeps the two kernels everywhere.
 constexpr u32 kLbNone = 0xFFFFFu;
+// -DBZ_REFINE_TIMING: cycles (>> 4) per phase of a tile, summed over tiles into loc_stats[16 + 8 * INIT + k]
+// (a barrier at every mark; BZ_LOCAL_TRACE=1 prints them): 0 ticket + set-up, 1 list + secondary keys, 2 flags,
+// 3 look-back, 4 positions / rank words / last column, 5 counts out + bin offsets, 6 staging + rank words out
+#ifdef BZ_REFINE_TIMING
+#define RF_T(k) do { __syncthreads(); const u64 t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&a.loc_stats[16 + (INIT ? 8 : 0) + (k)], (u32)((t_ - t_prev) >> 4)); t_prev = t_; } while (0)
+#else
+#define RF_T(k) do { } while (0)
+#endif
 template <bool INIT>
 __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32 step, u32 next_step, u32 round,
                                                                 const u32 *__restrict__ K,
@@ -1479,6 +1495,9 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
     __shared__ u32 s_bcnt[1024];
     __shared__ u16 s_bpre[1024];
     __shared__ u32 s_wsum[NW];
+#ifdef BZ_REFINE_TIMING
+    u64 t_prev = __builtin_readcyclecounter();
+#endif
     const u32 xcd = (u32)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u; // XCC_ID (see k_radix_scatter_lb)
     const u32 my_tiles = kTilesPerBlock * ((a.nb + 7u - xcd) / 8u);
     if (threadIdx.x == 0) s_ticket = atomicAdd(&a.tickets[(size_t)epoch * 8u + xcd], 1u);
@@ -1506,6 +1525,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
     const u32 wbase = start + w * 1024u;
     const u32 first = wbase + l;
 
+    RF_T(0);
     // ---- the pair list and the secondary keys (k_group_flags)
     u32 gk[16], jv[16], s1[16], s2[16];
     u32 pg0 = 0, ps10 = 0, ps20 = 0; // the element in front of the wave's span (lane 0)
@@ -1554,7 +1574,8 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
             if (need_next) ns20 = pkey(pt, nj, ki.bits, ki.chars);
         }
     }
-    // ---- boundary flags as ballots; the bytes go out for k_survivor_compact
+    RF_T(1);
+    // ---- boundary flags as ballots; the new-group starts go out as a bitmap
     u64 mo[16] = {}, mn[16];
     int wl_old = -1, wl_new = -1;
 #pragma unroll
@@ -1588,7 +1609,26 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
         s_wold[w] = INIT ? 0 : wl_old;
         s_wnew[w] = wl_new;
     }
+    // Which rotations become final is known from the flags alone (a new group whose successor starts one too): their
+    // bytes of the last column are gathered now, all rows in flight, while the look-back below is under way.
+    u32 finbits = 0;
+    u32 lcol[16];
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 idx = first + r * 64u;
+        bool next_new;
+        if (idx + 1 >= cnt) next_new = true;
+        else if (l < 63) next_new = (mn[r] >> (l + 1)) & 1ull;
+        else if (r < 15) next_new = mn[(r + 1) & 15] & 1ull;
+        else next_new = next_after;
+        const bool fin = (idx < cnt) && ((mn[r] >> l) & 1ull) && next_new;
+        finbits |= (fin ? 1u : 0u) << r;
+        lcol[r] = 0;
+        // (the walk round's refinement has no registers to spare for sixteen bytes in flight: it gathers in its loop)
+        if (INIT && fin) lcol[r] = text[jv[r] ? jv[r] - 1u : n - 1u]; // src/bzip2/encoder.rs:331-338
+    }
     __syncthreads();
+    RF_T(2);
     // ---- the carries from the tiles in front: decoupled look-back
     if (threadIdx.x == 0) {
         int lo = INIT ? 0 : -1, ln = -1; // (INIT: one old group, it starts at 0)
@@ -1609,7 +1649,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
                 const u32 *src = a.tile_state + ((size_t)lb * kTilesPerBlock + p) * kMaxBins;
                 uint4 v = ld_sc1_x4(src);
                 while ((v.x >> 22) != epoch || (v.x & kLbFlagMask) == 0u || (v.y >> 22) != epoch || (v.y & kLbFlagMask) == 0u) {
-                    if (++spins > kLbSpinMax) {
+                    if (lb_give_up(spins, a.sort_err, kLbSpinMax >> 3)) { // (a predecessor publishes some tens of microseconds after its ticket)
                         atomicExch(a.sort_err, 1u);
                         v = make_uint4(etag | kLbIncl, etag | kLbIncl, 0, 0); // (give up: the host redoes the sort)
                         break;
@@ -1632,6 +1672,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
         s_carry_new = cn;
     }
     __syncthreads();
+    RF_T(3);
     int carry_old = INIT ? 0 : s_carry_old, carry_new = s_carry_new;
     for (u32 k = 0; k < w; ++k) {
         if (!INIT) carry_old = s_wold[k] > carry_old ? s_wold[k] : carry_old;
@@ -1639,7 +1680,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
     }
     // ---- positions, rank words, last column (k_group_apply)
     const u64 le_mask = (l == 63) ? ~0ull : ((2ull << l) - 1ull);
-    u32 my_nonfinal = 0;
+    u32 my_nonfinal = 0; // (wave-uniform)
     u32 word[16], lrank[16];
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
@@ -1657,32 +1698,34 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
             }
             const u64 q = mn[r] & le_mask;
             const int ss = q ? (int)(rowbase + 63u - __clzll(q)) : carry_new;
-            bool next_new;
-            if (idx + 1 >= cnt) next_new = true;
-            else if (l < 63) next_new = (mn[r] >> (l + 1)) & 1ull;
-            else if (r < 15) next_new = mn[(r + 1) & 15] & 1ull;
-            else next_new = next_after;
-            const bool is_new = (mn[r] >> l) & 1ull;
-            const bool fin = is_new && next_new;
+            const bool fin = (finbits >> r) & 1u;
             const u32 g = gk[r];
             const u32 j = jv[r];
             const u32 p = g + (idx - (u32)rs);
             const u32 head = g + ((u32)ss - (u32)rs);
             if (!INIT) st_stream(a.SA + base + p, j); // (INIT: the list IS SA, p == idx)
             if (fin) {
-                a.L[base + p] = text[j ? j - 1u : n - 1u]; // src/bzip2/encoder.rs:331-338, as in k_group_apply
+                a.L[base + p] = INIT ? (u8)lcol[r] : text[j ? j - 1u : n - 1u];
                 if (j == 0) a.orig_ptr[lb] = p;
             }
             word[r] = (j & kRankBinMask) | (head << kRankBinShift) | (fin ? kFinalBit : 0u);
             lrank[r] = atomicAdd(&s_bcnt[j >> kRankBinShift], 1u);
-            my_nonfinal += fin ? 0u : 1u;
             nf = !fin;
             nf_head = head;
         }
         {
             const u64 mnf = __ballot(nf);
             if (mnf) {
-                if (nf) atomicAdd(&s_gh[0][nf_head & 1023u], 1u);
+                my_nonfinal += (u32)__popcll(mnf);
+                // low digit of the heads: the members of a group are neighbours, so the first member inside the row
+                // adds the length of the row's stretch of the group (one LDS add per group and row, not per member)
+                // (a stretch begins at a new-group start or at lane 0; the starts above a lane are mn[r]'s bits above it)
+                if (nf && (l == 0 || ((mn[r] >> l) & 1ull))) {
+                    const u64 rest = (l == 63) ? 0ull : (mn[r] >> (l + 1u));
+                    u32 len = rest ? (u32)__ffsll((long long)rest) : 64u - l;
+                    len = len < cnt - idx ? len : cnt - idx;
+                    atomicAdd(&s_gh[0][nf_head & 1023u], len);
+                }
                 const u32 lead = (u32)__ffsll((long long)mnf) - 1u;
                 const u32 hi = (nf_head >> 10) & 1023u;
                 const u32 hi0 = __shfl(hi, lead, 64);
@@ -1697,9 +1740,9 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
         if (!INIT && mo[r]) carry_old = (int)(rowbase + 63u - __clzll(mo[r]));
         if (mn[r]) carry_new = (int)(rowbase + 63u - __clzll(mn[r]));
     }
-    my_nonfinal = wave_sum(my_nonfinal);
     if (l == 0 && my_nonfinal) atomicAdd(&s_nonfinal, my_nonfinal);
     __syncthreads();
+    RF_T(4);
     if (threadIdx.x == 0) a.tile_nf[lb * kTilesPerBlock + tile] = s_nonfinal;
     {
         u32 *out = a.gh_tiles + ((size_t)lb * kTilesPerBlock + tile) * 3 * kMaxBins;
@@ -1734,6 +1777,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
         s_bcnt[b0 + 1] = ((b0 + 1u) << kRankBinShift) + g1;
     }
     __syncthreads();
+    RF_T(5);
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
         if (lrank[r] != 0xFFFFFFFFu) {
@@ -1753,6 +1797,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
             W[base + s_bcnt[bin] + (i - (u32)s_bpre[bin])] = s_stage[i];
         }
     }
+    RF_T(6);
 }
 
 // One wave per bin: the rank words of bin b (a.bin_cursor[b] of them, behind W[b * 1024]) go to
@@ -2472,6 +2517,16 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
                         "of this batch by the global passes\n", ls[0], ls[1], ls[2], ls[3], ng, a.nb);
 #ifdef BZ_LOC_TIMERS
         fprintf(stderr, "  cycles/16 per phase (bounds, load, fill, passes, out): %u %u %u %u %u\n", ls[4], ls[5], ls[6], ls[7], ls[8]);
+#endif
+#ifdef BZ_REFINE_TIMING
+        {
+            u32 rt[16] = {};
+            (void)hipMemcpy(rt, a.loc_stats + 16, sizeof(rt), hipMemcpyDeviceToHost);
+            fprintf(stderr, "  k_group_refine cycles/16 per phase (set-up, list+keys, flags, look-back, apply, counts, out): first refinement "
+                            "%u %u %u %u %u %u %u; walk round %u %u %u %u %u %u %u\n", rt[8], rt[9], rt[10], rt[11], rt[12], rt[13], rt[14],
+                    rt[0], rt[1], rt[2], rt[3], rt[4], rt[5], rt[6]);
+            (void)hipMemset(a.loc_stats + 16, 0, sizeof(rt));
+        }
 #endif
     }
     // periodic blocks: whatever is still non-final is a set of equal rotations

@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """No test waits for ever: a GPU test that has not come back after ten minutes fails with the stacks of all
+    threads (pytest-timeout, when it is installed) instead of holding the whole session."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600, method="thread"))
+
+
 def product():
     """The product package (directory name has a hyphen, hence importlib)."""
     return importlib.import_module("rust-compression_amd")
