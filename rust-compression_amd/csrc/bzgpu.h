@@ -291,6 +291,11 @@ struct HuffArgs {
     u32 *code_len;         // [nb][6][kMaxAlpha]   code | len << 24
     u32 *group_bitoff;     // [nb][kGboStride]  payload bit offset of each 50-symbol group
     u32 *lm_scratch;       // [nb][6][kLmWords]
+    // between the kernels of the split stage (k_huff_tables / k_huff_sweep / k_huff_gbits / k_huff_header)
+    u8 *glen;              // [nb][6][kMaxAlpha + 6] code lengths, tables in selector order
+    unsigned long long *pack; // [nb][kMaxAlpha] the same as 6 x 10 bits per symbol
+    u32 *rfreq;            // [nb][6][kMaxAlpha] symbol counts per selected table of the sweep under way
+    u32 *hlm;              // [nb] tables that took the length-limited path
     u32 *stream;           // [nb][kStreamWords]  block bit string, logical MSB-first words
     BlockOut *out;         // [nb]
     u32 *error_flag;       // [1]

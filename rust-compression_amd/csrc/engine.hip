@@ -102,6 +102,10 @@ static int ensure_workspace(bz_gpu_engine *g, size_t need_blocks)
     ENS(code_len, nb * (size_t)6 * kMaxAlpha * 4);
     ENS(group_bitoff, nb * (size_t)kGboStride * 4);
     ENS(lm_scratch, nb * (size_t)6 * kLmWords * 4);
+    ENS(hglen, nb * (size_t)6 * (kMaxAlpha + 6));
+    ENS(hpack, nb * (size_t)kMaxAlpha * 8);
+    ENS(hrfreq, nb * (size_t)6 * kMaxAlpha * 4);
+    ENS(hlm, nb * 4);
     ENS(stream, nb * (size_t)kStreamWords * 4);
     ENS(error_flag, 4);
     ENS(packlist, nb * sizeof(PackBlock));
@@ -183,7 +187,7 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
                      &g->R, &g->KA, &g->VA, &g->KB, &g->VB, &g->tile_hist, &g->count, &g->flags, &g->tlo, &g->tln,
                      &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->bin_cursor, &g->pb_gate, &g->newbits, &g->bin_base, &g->sym_code, &g->keyinfo, &g->count2, &g->tile_nf, &g->L, &g->orig_ptr, &g->inuse_bits,
                      &g->summ, &g->summ_len, &g->init_state, &g->rank8, &g->ztile_last, &g->ztile_cnt, &g->mtf,
-                     &g->mtf_freq, &g->bout, &g->selector, &g->code_len, &g->group_bitoff, &g->lm_scratch,
+                     &g->mtf_freq, &g->bout, &g->selector, &g->code_len, &g->group_bitoff, &g->lm_scratch, &g->hglen, &g->hpack, &g->hrfreq, &g->hlm,
                      &g->stream, &g->error_flag, &g->packlist, &g->packed, &g->gathered, &g->asmlist, &g->gh_tiles, &g->gbase, &g->tile_state,
                      &g->tickets};
     for (DevBuf *b : all) b->release();
@@ -481,6 +485,10 @@ static HuffArgs make_huff_args(bz_gpu_engine *g, u32 nb, u32 o)
     ha.code_len = g->code_len.as<u32>() + (size_t)o * 6 * kMaxAlpha;
     ha.group_bitoff = g->group_bitoff.as<u32>() + (size_t)o * kGboStride;
     ha.lm_scratch = g->lm_scratch.as<u32>() + (size_t)o * 6 * kLmWords;
+    ha.glen = g->hglen.as<u8>() + (size_t)o * 6 * (kMaxAlpha + 6);
+    ha.pack = g->hpack.as<unsigned long long>() + (size_t)o * kMaxAlpha;
+    ha.rfreq = g->hrfreq.as<u32>() + (size_t)o * 6 * kMaxAlpha;
+    ha.hlm = g->hlm.as<u32>() + o;
     ha.stream = g->stream.as<u32>() + (size_t)o * kStreamWords;
     ha.out = g->bout.as<BlockOut>() + o;
     ha.error_flag = g->error_flag.as<u32>();

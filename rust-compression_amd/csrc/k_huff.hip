@@ -14,6 +14,7 @@
 // (encoder.rs:452-454, 504-508, 520-524, 585); here tables are kept in selector order
 // t = 0..group_num-1, which is the order the stream carries them in.
 #include "bzgpu.h"
+#include <cstdlib>
 
 namespace bzgpu {
 
@@ -119,8 +120,10 @@ __device__ void gen_code_lm(const u32 *freq, u32 n, u32 *scr, u32 row, u8 *out)
         j -= 1;
         cur[j] = 0;
         if (b[j] == 1) {
-            // take_package(ty, c, cur, j) (:40-55) with an explicit stack
-            u32 lvl[20], ph[20];
+            // take_package(ty, c, cur, j) (:40-55) with an explicit stack -- kept in the scratch area (the words
+            // between misc and val are free): a local array indexed at run time would live in scratch memory, i.e.
+            // behind a global-memory round trip per access
+            u32 *lvl = misc + 64, *ph = misc + 84;
             int sp = 0;
             lvl[0] = j;
             ph[0] = 0;
@@ -772,25 +775,714 @@ __global__ __launch_bounds__(256) void k_emit_payload(HuffArgs a)
     if (nacc) atomicOr(&stream[widx], (u32)(acc >> 32)); // shared with the next group
 }
 
+// =====================================================================================================
+// The same stage as SEVERAL kernels (the default).  k_huffman holds a block in one workgroup for ~2.3 ms -- the
+// sweeps over its symbols (60 % of that) run on 512 lanes while 1189 blocks wait for 512 workgroup slots: three
+// rounds, the last one a third full.  Split, the sweeps become bandwidth-shaped launches over (groups, blocks) and
+// what is serial -- one lane per table replaying the reference's heap procedure -- is a 64-thread workgroup per
+// block, all blocks resident at once:
+//   k_huff_tables(0)            table count, initial tables (encoder.rs:370-426)
+//   4 x [k_huff_sweep           cost of every 50-symbol group under every table, selector, symbol counts per
+//                               selected table (:433-503)
+//        k_huff_tables(i)]      code lengths from the counts: heap procedure, package-merge fallback (:504-509)
+//   k_huff_gbits                payload bits of every group under the final tables
+//   k_huff_header               canonical codes (src/huffman/mod.rs:22-67), group bit offsets, selector MTF and the
+//                               block header (:511-601) -- the tail of k_huffman
+// The tables travel between the kernels as lengths (glen), as 6 x 10-bit packed lengths per symbol (pack) and
+// as counts (rfreq).  BZ_HUFF_SPLIT=0 selects k_huffman.
+constexpr u32 kSweepThreads = 256;  // groups per sweep step
+constexpr u32 kSweepTilesX = 12;    // workgroups per block (each loops over its share of the group tiles)
+// k_huff_tables' scratch arena in LDS: the heap procedure's work arrays (6 x (2 * 258 + 4) words), then -- they are
+// dead by then -- the package-merge scratch of as many tables at a time as fit (one of up to 40 symbols: text; larger
+// alphabets use global memory).  With the other arrays 24.6 KB per workgroup: six workgroups share a CU and every
+// block of a 1 GiB batch is resident at once (at 40 KB it took two rounds of 0.6 ms each, four times over).
+constexpr u32 kTabArena = 4200;
+
+__device__ __forceinline__ u32 huff_group_num(u32 mtf_count) // encoder.rs:370-376
+{
+    if (mtf_count < 200) return 2;
+    if (mtf_count < 600) return 3;
+    if (mtf_count < 1200) return 4;
+    if (mtf_count < 2400) return 5;
+    return 6;
+}
+
+// gen_code_lm (cano_huff_table.rs:58-151) by a whole WAVE.  Single-lane, the procedure costs 0.48 ms for a
+// 38-symbol table -- 1300 merge steps of a few dependent LDS accesses each -- and with it k_huff_tables is four
+// times 1.1 ms.  What is serial in the reference is a two-pointer merge per level: the packages of level j (sums of
+// neighbouring pairs, :113-116) against the sorted leaf weights, "package if its weight is GREATER, else leaf"
+// (:117-127).  Both sequences are non-increasing -- the leaves by the sort (:64-70), the packages because level j is
+// itself such a merge and weight_add is monotone on sorted pairs (equal sums of the high parts force equal high
+// parts, and then the depth bytes are ordered too) -- so the merge is a matter of ranks: package k lands behind the
+// k packages in front of it and the leaves whose weight is >= its own (ties go to the leaf), leaf i behind the i
+// leaves in front of it and the packages whose weight is > its own; what lands at or beyond max_elem[j-1] is cut off
+// (:112), and so is every package behind the last leaf (the loop ends with the leaves, :125).  Ranks are binary
+// searches, one element per lane.  The stable sort (:64-70) is a rank sort.  The bookkeeping between the levels
+// (take_package, :40-55, :129-141) runs level by level, the items of a level side by side.  Same scratch layout as gen_code_lm; the packages of a level are
+// kept in its own val row (dead once the level below exists).  All 64 lanes of ONE wave call it; the workgroup
+// is that wave.
+__device__ void lm_code_lengths_wave(const u32 *rfreq, u32 n, u32 *scr, u32 scr_words, u32 row, u8 *out, u32 lane)
+{
+    const u32 lim = kLim;
+    u32 *map = scr;
+    u32 *sfreq = map + kMaxAlpha;
+    u32 *c = sfreq + kMaxAlpha;
+    u32 *misc = c + kMaxAlpha;
+    u32 *max_elem = misc, *b = misc + 20, *cur = misc + 40;
+    u32 *val = misc + 64 + kMaxAlpha;
+    u32 *ty = val + lim * row;
+    u32 *w = scr + scr_words - kMaxAlpha; // the weights, encoder.rs:642-645
+    for (u32 i = lane; i < n; i += 64u) {
+        const u32 f = rfreq[i];
+        w[i] = (f > 1u ? f : 1u) << 8;
+    }
+    __syncthreads();
+    // stable sort by weight, descending (:64-70), as ranks
+    for (u32 i = lane; i < n; i += 64u) {
+        const u32 f = w[i];
+        u32 r = 0;
+        for (u32 q = 0; q < n; ++q) {
+            const u32 x = w[q];
+            r += (x > f || (x == f && q < i)) ? 1u : 0u;
+        }
+        sfreq[r] = f;
+        map[r] = i;
+    }
+    if (lane == 0) {
+        for (u32 j = 0; j < lim; ++j) { max_elem[j] = 0; b[j] = 0; cur[j] = 0; }
+        u32 excess = (1u << lim) - n;       // :75
+        const u32 half = 1u << (lim - 1);   // :76
+        max_elem[lim - 1] = n;              // :77
+        for (u32 j = 0; j < lim; ++j) {     // :79-88
+            if (excess >= half) {
+                b[j] = 1;
+                excess -= half;
+            }
+            excess <<= 1;
+            if (lim >= 2 + j) max_elem[lim - 2 - j] = max_elem[lim - 1 - j] / 2 + n;
+        }
+        max_elem[0] = b[0];                 // :90-95
+        for (u32 j = 1; j < lim; ++j)
+            if (max_elem[j] > 2 * max_elem[j - 1] + b[j]) max_elem[j] = 2 * max_elem[j - 1] + b[j];
+    }
+    __syncthreads();
+    for (u32 j = 0; j < lim; ++j)           // :97-98 (zero initialised vectors)
+        for (u32 t = lane; t < max_elem[j]; t += 64u) { val[j * row + t] = 0; ty[j * row + t] = 0; }
+    for (u32 i = lane; i < n; i += 64u) c[i] = lim; // :99
+    __syncthreads();
+    for (u32 t = lane; t < n && t < max_elem[lim - 1]; t += 64u) { // :101-104
+        val[(lim - 1) * row + t] = sfreq[t];
+        ty[(lim - 1) * row + t] = t;
+    }
+    if (lane == 0 && b[lim - 1] == 1) {     // :107-110
+        c[0] -= 1;
+        cur[lim - 1] += 1;
+    }
+    __syncthreads();
+    const u32 last_leaf = sfreq[n - 1];
+    for (u32 j = lim - 1; j > 0;) {         // :112-142
+        const u32 next0 = cur[j], me = max_elem[j], cap = max_elem[j - 1];
+        const u32 K = (me > next0 + 1u) ? (me - next0) / 2u : 0u; // packages: pairs (next, next + 1) with next + 1 < max_elem[j]
+        u32 *vj = val + j * row, *dv = val + (j - 1) * row, *dt = ty + (j - 1) * row;
+        for (u32 k0 = 0; k0 < K; k0 += 64u) {
+            const u32 k = k0 + lane;
+            u32 pk = 0;
+            if (k < K) pk = weight_add(vj[next0 + 2u * k], vj[next0 + 2u * k + 1u]);
+            __syncthreads();
+            if (k < K) vj[k] = pk; // (writes [k0, k0 + 64) lie in front of every later read, at >= next0 + 2 (k0 + 64))
+        }
+        __syncthreads();
+        for (u32 k = lane; k < K; k += 64u) {
+            const u32 pk = vj[k];
+            if (pk > last_leaf) {            // (a package behind the last leaf is never placed, :125)
+                u32 lo = 0, hi = n;          // leaves in front of it: weight >= its own
+                while (lo < hi) {
+                    const u32 mid = (lo + hi) >> 1;
+                    if (sfreq[mid] >= pk) lo = mid + 1u;
+                    else hi = mid;
+                }
+                const u32 pos = k + lo;
+                if (pos < cap) {
+                    dv[pos] = pk;
+                    dt[pos] = n;
+                }
+            }
+        }
+        for (u32 i = lane; i < n; i += 64u) {
+            const u32 sf = sfreq[i];
+            u32 lo = 0, hi = K;              // packages in front of it: weight > its own
+            while (lo < hi) {
+                const u32 mid = (lo + hi) >> 1;
+                if (vj[mid] > sf) lo = mid + 1u;
+                else hi = mid;
+            }
+            const u32 pos = i + lo;
+            if (pos < cap) {
+                dv[pos] = sf;
+                dt[pos] = i;
+            }
+        }
+        __syncthreads();
+        j -= 1;
+        if (lane == 0) cur[j] = 0;
+        __syncthreads();
+        if (b[j] == 1) { // (uniform)
+            // take_package(ty, c, cur, j) (:40-55), level by level instead of depth first: it takes the next item of
+            // level j; an item that is a package takes the next two of the level below, and so on.  Which items a
+            // level loses is settled by how many packages the level above lost -- always "the next ones" -- and what
+            // losing one does (a leaf's count goes down, the level's cursor up) commutes, so the order is free.  A level's
+            // list holds every leaf at most once: the lanes touch different counts.
+            u32 need = 1;
+            for (u32 li = j; need > 0u && li < lim; ++li) {
+                const u32 c0 = cur[li];
+                u32 npk = 0;
+                for (u32 t0 = 0; t0 < need; t0 += 64u) {
+                    const u32 t = t0 + lane;
+                    bool isp = false;
+                    if (t < need) {
+                        const u32 x = ty[li * row + c0 + t];
+                        if (x == n) isp = true;
+                        else c[x] -= 1;
+                    }
+                    npk += (u32)__popcll(__ballot(isp));
+                }
+                __syncthreads();
+                if (lane == 0) cur[li] = c0 + need;
+                need = 2u * npk;
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+    }
+    for (u32 i = lane; i < n; i += 64u) out[map[i]] = (u8)c[i]; // :144-150
+    __syncthreads();
+}
+
+// staging for any workgroup size (stage_symbols assumes its batch fits the 512-thread kernel's registers)
+template <u32 THREADS>
+__device__ __forceinline__ void stage_symbols_n(u32 *s_sym, const u16 *__restrict__ mtf, u32 g0, u32 mtf_count)
+{
+    const u32 first = g0 * kGSize;
+    const u32 avail = mtf_count - first;
+    const u32 want = THREADS * kGSize;
+    const u32 nsym = avail < want ? avail : want;
+    const u32 ndw = (nsym + 1u) >> 1;
+    const u32 *src = reinterpret_cast<const u32 *>(mtf + first);
+    u32 v[kGSize / 2];
+#pragma unroll
+    for (u32 k = 0; k < kGSize / 2; ++k) {
+        const u32 i = threadIdx.x + k * THREADS;
+        v[k] = (i < ndw) ? src[i] : 0u;
+    }
+#pragma unroll
+    for (u32 k = 0; k < kGSize / 2; ++k) {
+        const u32 i = threadIdx.x + k * THREADS;
+        if (i < ndw) s_sym[i] = v[k];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_huff_tables(HuffArgs a, u32 iter)
+{
+    __shared__ u8 s_len[6][kMaxAlpha + 6];
+    __shared__ u32 s_rfreq[6][kMaxAlpha];
+    __shared__ u32 s_arena[kTabArena];
+    __shared__ u32 s_need[6];
+    __shared__ u32 s_lmcount;
+    static_assert(kTabArena >= 6 * (2 * kMaxAlpha + 4), "the heap work arrays fit the arena");
+    const u32 lb = blockIdx.x, lane = threadIdx.x;
+    const BlockOut &bo = a.out[lb];
+    const u32 mtf_count = bo.mtf_count;
+    const u32 alpha = bo.in_use_count + 2; // encoder.rs:367
+    const u32 group_num = huff_group_num(mtf_count);
+    const u32 *mtf_freq = a.mtf_freq + (size_t)lb * kMaxAlpha;
+    u32 *rfreq = a.rfreq + (size_t)lb * 6 * kMaxAlpha;
+    u8 *glen = a.glen + (size_t)lb * 6 * (kMaxAlpha + 6);
+    const bool tab_lane = lane < group_num;
+    const u32 tb = lane;
+    if (lane == 0) s_lmcount = 0;
+    if (iter == 0) {
+        // initial tables, encoder.rs:379-426 (see k_huffman)
+        if (lane == 0) {
+            u32 rem = mtf_count;
+            int gs = 0;
+            for (u32 k = 0; k < group_num; ++k) {
+                const u32 n_part = group_num - k;
+                const u32 t_freq = rem / n_part;
+                int ge = gs - 1;
+                u32 a_freq = 0;
+                while (a_freq < t_freq && ge < (int)alpha - 1) {
+                    ge += 1;
+                    a_freq += mtf_freq[ge];
+                }
+                if (ge > gs && n_part != group_num && n_part != 1 && (((group_num - n_part) & 1u) == 1u)) {
+                    a_freq -= mtf_freq[ge];
+                    ge -= 1;
+                }
+                u8 *l = s_len[group_num - 1 - k];
+                for (int i = 0; i < (int)alpha; ++i) l[i] = (i >= gs && i <= ge) ? 0 : 15; // :297-298
+                rem -= a_freq;
+                gs = ge + 1;
+            }
+            a.hlm[lb] = 0;
+        }
+        for (u32 i = lane; i < 6 * kMaxAlpha; i += 64u) rfreq[i] = 0;
+        __syncthreads();
+    } else {
+        // the counts of the sweep come in, and are cleared for the next one
+        for (u32 i = lane; i < 6 * kMaxAlpha; i += 64u) {
+            (&s_rfreq[0][0])[i] = rfreq[i];
+            rfreq[i] = 0;
+        }
+        __syncthreads();
+        if (tab_lane) s_need[tb] = (u32)heap_code_lengths(s_rfreq[tb], alpha, s_arena + tb * (2 * kMaxAlpha + 4), s_len[tb]);
+        __syncthreads();
+        // tables whose longest code exceeds 17 bits: package-merge, one lane each, as many tables at a time as fit
+        // the arena, side by side in global memory when not even one does
+        const u32 row = 2u * alpha + 4u;
+        const u32 need = 5u * kMaxAlpha + 64u + 2u * kLim * row;
+        const u32 slots = kTabArena / need;
+        u32 my_rank = 0, any = 0;
+        for (u32 t = 0; t < group_num; ++t) {
+            if (t < tb) my_rank += s_need[t] ? 1u : 0u;
+            any += s_need[t] ? 1u : 0u;
+        }
+        (void)my_rank;
+        if (any) { // uniform
+            if (slots) {
+                // one table after the other, each by the whole wave (lm_code_lengths_wave)
+                for (u32 t = 0; t < group_num; ++t) {
+                    if (s_need[t]) { // uniform
+                        lm_code_lengths_wave(s_rfreq[t], alpha, s_arena, need, row, s_len[t], lane);
+                        if (lane == 0) s_lmcount += 1;
+                    }
+                }
+                __syncthreads();
+            } else {
+                if (tab_lane && s_need[tb]) {
+                    lm_code_lengths(s_rfreq[tb], alpha, a.lm_scratch + ((size_t)lb * 6 + tb) * kLmWords, kLmWords, kLmRow, s_len[tb]);
+                    atomicAdd(&s_lmcount, 1u);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // lengths and the packed form the sweeps add up
+    for (u32 i = lane; i < 6 * (kMaxAlpha + 6); i += 64u) glen[i] = (&s_len[0][0])[i];
+    unsigned long long *pack = a.pack + (size_t)lb * kMaxAlpha;
+    for (u32 i = lane; i < alpha; i += 64u) {
+        unsigned long long p = 0;
+        for (u32 t = 0; t < group_num; ++t) p |= (unsigned long long)s_len[t][i] << (10 * t);
+        pack[i] = p;
+    }
+    if (lane == 0 && s_lmcount) a.hlm[lb] += s_lmcount;
+}
+
+__global__ __launch_bounds__(kSweepThreads) void k_huff_sweep(HuffArgs a)
+{
+    __shared__ unsigned long long s_pack[kMaxAlpha];
+    __shared__ u32 s_rfreq[6][kMaxAlpha];
+    __shared__ u32 s_sym[kSweepThreads * kGSize / 2];
+    const u32 lb = blockIdx.y, tid = threadIdx.x;
+    const u32 mtf_count = a.out[lb].mtf_count;
+    const u32 n_selectors = (mtf_count + kGSize - 1) / kGSize;
+    if (blockIdx.x * kSweepThreads >= n_selectors) return;
+    const u32 alpha = a.out[lb].in_use_count + 2;
+    const u32 group_num = huff_group_num(mtf_count);
+    const u16 *mtf = a.mtf + (size_t)lb * a.mtf_stride;
+    u8 *selector = a.selector + (size_t)lb * kSelStride;
+    const unsigned long long *pack = a.pack + (size_t)lb * kMaxAlpha;
+    for (u32 i = tid; i < alpha; i += kSweepThreads) s_pack[i] = pack[i];
+    for (u32 i = tid; i < 6 * kMaxAlpha; i += kSweepThreads) (&s_rfreq[0][0])[i] = 0;
+    for (u32 g0 = blockIdx.x * kSweepThreads; g0 < n_selectors; g0 += kSweepTilesX * kSweepThreads) {
+        __syncthreads(); // (the staging area is free again; first trip: tables and counters are set)
+        stage_symbols_n<kSweepThreads>(s_sym, mtf, g0, mtf_count);
+        __syncthreads();
+        const u32 g = g0 + tid;
+        if (g < n_selectors) {
+            const u32 gs = g * kGSize;
+            const u32 cnt = (gs + kGSize < mtf_count) ? kGSize : mtf_count - gs;
+            const u32 *my = s_sym + tid * (kGSize / 2);
+            // (as in k_huffman: the cost under every table as 6 x 10-bit sums, the eight smallest symbols counted
+            // in eight 8-bit fields, the rarer ones by a second, almost empty pass once the table is known)
+            unsigned long long cost = 0, c8 = 0;
+            u32 big = 0;
+            if (cnt == kGSize) {
+#pragma unroll 5
+                for (u32 k = 0; k < kGSize / 2; ++k) {
+                    const u32 dw = my[k];
+                    const u32 s0 = dw & 0xFFFFu, s1 = dw >> 16;
+                    cost += s_pack[s0];
+                    cost += s_pack[s1];
+                    if (s0 < 8u) c8 += 1ull << (8u * s0);
+                    else ++big;
+                    if (s1 < 8u) c8 += 1ull << (8u * s1);
+                    else ++big;
+                }
+            } else {
+                for (u32 i = 0; i < cnt; ++i) {
+                    const u32 sy = (my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
+                    cost += s_pack[sy];
+                    if (sy < 8u) c8 += 1ull << (8u * sy);
+                    else ++big;
+                }
+            }
+            u32 bt = 0, bc = (u32)(cost & 1023u); // first minimum wins (min_by, encoder.rs:466)
+            for (u32 t = 1; t < group_num; ++t) {
+                const u32 ct = (u32)((cost >> (10 * t)) & 1023u);
+                if (ct < bc) {
+                    bc = ct;
+                    bt = t;
+                }
+            }
+            selector[g] = (u8)bt;
+            if (big) {
+                for (u32 i = 0; i < cnt; ++i) {
+                    const u32 sy = (my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
+                    if (sy >= 8u) atomicAdd(&s_rfreq[bt][sy], 1u);
+                }
+            }
+#pragma unroll
+            for (u32 q = 0; q < 8; ++q) {
+                const u32 c = (u32)(c8 >> (8u * q)) & 0xFFu;
+                if (c) atomicAdd(&s_rfreq[bt][q], c);
+            }
+        }
+    }
+    __syncthreads();
+    u32 *rfreq = a.rfreq + (size_t)lb * 6 * kMaxAlpha;
+    for (u32 i = tid; i < group_num * kMaxAlpha; i += kSweepThreads) {
+        const u32 c = (&s_rfreq[0][0])[i];
+        if (c) atomicAdd(&rfreq[i], c);
+    }
+}
+
+// payload bits of every group under the final tables (raw, not yet summed) -> group_bitoff
+__global__ __launch_bounds__(kSweepThreads) void k_huff_gbits(HuffArgs a)
+{
+    __shared__ u8 s_len[6][kMaxAlpha + 6];
+    __shared__ u32 s_sym[kSweepThreads * kGSize / 2];
+    const u32 lb = blockIdx.y, tid = threadIdx.x;
+    const u32 mtf_count = a.out[lb].mtf_count;
+    const u32 n_selectors = (mtf_count + kGSize - 1) / kGSize;
+    if (blockIdx.x * kSweepThreads >= n_selectors) return;
+    const u16 *mtf = a.mtf + (size_t)lb * a.mtf_stride;
+    const u8 *selector = a.selector + (size_t)lb * kSelStride;
+    const u8 *glen = a.glen + (size_t)lb * 6 * (kMaxAlpha + 6);
+    u32 *gbo = a.group_bitoff + (size_t)lb * kGboStride;
+    for (u32 i = tid; i < 6 * (kMaxAlpha + 6); i += kSweepThreads) (&s_len[0][0])[i] = glen[i];
+    for (u32 g0 = blockIdx.x * kSweepThreads; g0 < n_selectors; g0 += kSweepTilesX * kSweepThreads) {
+        __syncthreads();
+        stage_symbols_n<kSweepThreads>(s_sym, mtf, g0, mtf_count);
+        __syncthreads();
+        const u32 g = g0 + tid;
+        if (g < n_selectors) {
+            const u32 gs = g * kGSize;
+            const u32 cnt = (gs + kGSize < mtf_count) ? kGSize : mtf_count - gs;
+            const u32 *my = s_sym + tid * (kGSize / 2);
+            const u8 *l = s_len[selector[g]];
+            u32 bits = 0;
+            if (cnt == kGSize) {
+#pragma unroll 5
+                for (u32 k = 0; k < kGSize / 2; ++k) {
+                    const u32 d = my[k];
+                    bits += (u32)l[d & 0xFFFFu] + (u32)l[d >> 16];
+                }
+            } else {
+                for (u32 i = 0; i < cnt; ++i) bits += l[(my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu];
+            }
+            gbo[g] = bits;
+        }
+    }
+}
+
+// canonical codes, the exclusive scan of the group bits, selector MTF, block header: the tail of k_huffman
+__global__ __launch_bounds__(kHuffThreads) void k_huff_header(HuffArgs a)
+{
+    __shared__ u8 s_len[6][kMaxAlpha + 6];
+    __shared__ u32 s_scan[kHuffThreads / 64];
+    __shared__ u32 s_run;
+    __shared__ u32 s_first[6][24], s_lcount[6][24];
+    const u32 lb = blockIdx.x;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    BlockOut &bo = a.out[lb];
+    const u32 mtf_count = bo.mtf_count;
+    const u32 alpha = bo.in_use_count + 2;
+    const u32 group_num = huff_group_num(mtf_count);
+    const u32 n_selectors = (mtf_count + kGSize - 1) / kGSize;
+    const u8 *selector = a.selector + (size_t)lb * kSelStride;
+    const u8 *glen = a.glen + (size_t)lb * 6 * (kMaxAlpha + 6);
+    const bool tab_lane = (wave == 0 && lane < group_num);
+    const u32 tb = lane;
+    for (u32 i = tid; i < 6 * (kMaxAlpha + 6); i += kHuffThreads) (&s_len[0][0])[i] = glen[i];
+    // canonical codes, src/huffman/mod.rs:22-67 (stable by length, then symbol)
+    if (tid < 6 * 24) (&s_lcount[0][0])[tid] = 0;
+    __syncthreads();
+    for (u32 i = tid; i < group_num * alpha; i += kHuffThreads) {
+        const u32 t = i / alpha, sy = i - t * alpha;
+        atomicAdd(&s_lcount[t][s_len[t][sy]], 1u);
+    }
+    __syncthreads();
+    if (tid < group_num) {
+        u32 code = 0;
+        for (u32 l = 1; l < 24; ++l) {
+            code = (code + s_lcount[tid][l - 1]) << 1;
+            s_first[tid][l] = code;
+        }
+    }
+    __syncthreads();
+    u32 *code_len = a.code_len + (size_t)lb * 6 * kMaxAlpha;
+    u32 my_max = 0;
+    for (u32 i = tid; i < group_num * alpha; i += kHuffThreads) {
+        const u32 t = i / alpha, sy = i - t * alpha;
+        const u32 l = s_len[t][sy];
+        u32 r = 0;
+        for (u32 q = 0; q < sy; ++q) r += (s_len[t][q] == l) ? 1u : 0u;
+        code_len[t * kMaxAlpha + sy] = (s_first[t][l] + r) | (l << 24);
+        my_max = l > my_max ? l : my_max;
+    }
+#pragma unroll
+    for (u32 dd = 32; dd >= 1; dd >>= 1) {
+        const u32 o = __shfl_xor(my_max, dd, 64);
+        my_max = o > my_max ? o : my_max;
+    }
+    if (tid == 0) s_run = 0;
+    if (tid < kHuffThreads / 64) s_scan[tid] = 0;
+    __syncthreads();
+    if (lane == 0) atomicMax(&s_scan[0], my_max);
+    __syncthreads();
+    const u32 max_len = s_scan[0];
+    __syncthreads();
+
+    // payload bit offset of every group: exclusive scan of the bits k_huff_gbits left
+    u32 *gbo = a.group_bitoff + (size_t)lb * kGboStride;
+    for (u32 g0 = 0; g0 < n_selectors; g0 += kHuffThreads) {
+        const u32 g = g0 + tid;
+        const u32 bits = (g < n_selectors) ? gbo[g] : 0u;
+        const u32 inc = wave_incl_sum(bits);
+        if (lane == 63) s_scan[wave] = inc;
+        __syncthreads();
+        u32 carry = s_run, tot = 0;
+        for (u32 k = 0; k < kHuffThreads / 64; ++k) {
+            if (k < wave) carry += s_scan[k];
+            tot += s_scan[k];
+        }
+        if (g < n_selectors) gbo[g] = carry + inc - bits;
+        __syncthreads();
+        if (tid == 0) s_run += tot;
+        __syncthreads();
+    }
+    const u32 payload_bits = s_run;
+
+    // ---- block header: as in k_huffman
+    u32 *stream = a.stream + (size_t)lb * kStreamWords;
+    const u32 *ubits = a.inuse_bits + lb * 8;
+    u32 in_use16 = 0, used_ranges = 0;
+    for (u32 i = 0; i < 16; ++i) {
+        const u32 half = (ubits[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
+        in_use16 = (in_use16 << 1) | (half ? 1u : 0u);
+        used_ranges += half ? 1u : 0u;
+    }
+    const u32 sel_bit0 = 48u + 32u + 1u + 24u + 16u + 16u * used_ranges + 3u + 15u; // first selector bit
+    const u32 seg = (n_selectors + kHuffThreads - 1) / kHuffThreads;
+    const u32 g_lo = tid * seg < n_selectors ? tid * seg : n_selectors;
+    const u32 g_hi = (g_lo + seg < n_selectors) ? g_lo + seg : n_selectors;
+    int last[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) last[t] = -1000000;
+    for (u32 g = g_lo; g < g_hi; ++g) {
+        const u32 v = selector[g];
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+            if ((u32)t == v) last[t] = (int)g;
+    }
+    int start_last[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int inc = wave_incl_max32(last[t]);
+        if (lane == 63) s_scan[wave] = (u32)inc;
+        __syncthreads();
+        int carry = -1000000;
+        for (u32 k = 0; k < wave; ++k) carry = (int)s_scan[k] > carry ? (int)s_scan[k] : carry;
+        const int prev = __shfl_up(inc, 1, 64);
+        int ex = (lane == 0) ? -1000000 : prev;
+        ex = ex > carry ? ex : carry;
+        start_last[t] = (ex < 0) ? -(t + 1) : ex;
+        __syncthreads();
+    }
+    u32 my_bits = 0;
+    {
+        int cur[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) cur[t] = start_last[t];
+        for (u32 g = g_lo; g < g_hi; ++g) {
+            const u32 v = selector[g];
+            int lv = 0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                if ((u32)t == v) lv = cur[t];
+            u32 pos = 0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) pos += (cur[t] > lv) ? 1u : 0u;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                if ((u32)t == v) cur[t] = (int)g;
+            my_bits += pos + 1u;
+        }
+    }
+    u32 sel_off, sel_total;
+    {
+        const u32 inc = wave_incl_sum(my_bits);
+        if (lane == 63) s_scan[wave] = inc;
+        __syncthreads();
+        u32 carry = 0, tot = 0;
+        for (u32 k = 0; k < kHuffThreads / 64; ++k) {
+            if (k < wave) carry += s_scan[k];
+            tot += s_scan[k];
+        }
+        sel_off = carry + inc - my_bits;
+        sel_total = tot;
+        __syncthreads();
+    }
+    const u32 tab_bit0 = sel_bit0 + sel_total;
+    if (tab_lane) {
+        const u8 *l = s_len[tb];
+        u32 nb = 5, curr = l[0];
+        for (u32 i = 0; i < alpha; ++i) {
+            const u32 li = l[i];
+            nb += 2u * (li > curr ? li - curr : curr - li) + 1u;
+            curr = li;
+        }
+        s_first[tb][0] = nb;
+    }
+    __syncthreads();
+    u32 tab_off[7];
+    tab_off[0] = tab_bit0;
+    for (u32 t = 0; t < 6; ++t) tab_off[t + 1] = tab_off[t] + (t < group_num ? s_first[t][0] : 0u);
+    const u32 hb = tab_off[group_num];
+    for (u32 w = tid; w <= (hb >> 5); w += kHuffThreads) stream[w] = 0;
+    __syncthreads();
+    auto put = [&](u32 bitpos, u32 v, u32 nbits) { // nbits <= 32, MSB-first
+        const u32 w = bitpos >> 5, o = bitpos & 31u;
+        const unsigned long long x = (unsigned long long)v << (64u - o - nbits);
+        atomicOr(&stream[w], (u32)(x >> 32));
+        if ((u32)x) atomicOr(&stream[w + 1], (u32)x);
+    };
+    if (tid == 0) {
+        put(0, 0x314159u, 24);  // encoder.rs:254-259
+        put(24, 0x265359u, 24);
+        put(48, a.crc[lb], 32); // :262, the randomised bit (:273) stays 0
+        put(81, a.orig_ptr[lb], 24); // :333
+        put(105, in_use16, 16); // mapping table, :527-554
+        u32 bp = 121;
+        for (u32 i = 0; i < 16; ++i) {
+            const u32 half = (ubits[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
+            if (half) {
+                put(bp, __brev(half) >> 16, 16);
+                bp += 16;
+            }
+        }
+        put(bp, group_num, 3); // :569-570
+        put(bp + 3, n_selectors, 15);
+    }
+    {
+        int cur[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) cur[t] = start_last[t];
+        u32 bp = sel_bit0 + sel_off;
+        for (u32 g = g_lo; g < g_hi; ++g) {
+            const u32 v = selector[g];
+            int lv = 0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                if ((u32)t == v) lv = cur[t];
+            u32 pos = 0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) pos += (cur[t] > lv) ? 1u : 0u;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                if ((u32)t == v) cur[t] = (int)g;
+            put(bp, (1u << (pos + 1u)) - 2u, pos + 1u); // :572-574
+            bp += pos + 1u;
+        }
+    }
+    if (tab_lane) { // coding tables, :583-601
+        const u8 *l = s_len[tb];
+        u32 bp = tab_off[tb];
+        u32 curr = l[0];
+        put(bp, curr, 5);
+        bp += 5;
+        for (u32 i = 0; i < alpha; ++i) {
+            const u32 li = l[i];
+            while (curr < li) { put(bp, 2, 2); bp += 2; curr += 1; }
+            while (curr > li) { put(bp, 3, 2); bp += 2; curr -= 1; }
+            bp += 1;
+        }
+    }
+    if (tid == 0) {
+        bo.header_bits = hb;
+        bo.total_bits = (u64)hb + payload_bits;
+        bo.group_num = group_num;
+        bo.n_selectors = n_selectors;
+        bo.max_len = max_len;
+        bo.lm_tables = a.hlm[lb];
+        bo.crc = a.crc[lb];
+        bo.orig_ptr = a.orig_ptr[lb];
+        if ((u64)hb + payload_bits + 96u > (u64)kStreamWords * 32u) atomicExch(a.error_flag, 1u);
+    }
+    {
+        const u64 tbits = (u64)hb + payload_bits;
+        u32 w0 = (hb >> 5) + 1u;
+        u32 w1 = (u32)(tbits >> 5) + 2u;
+        if (w1 > kStreamWords) w1 = kStreamWords;
+        for (u32 w = w0 + tid; w < w1; w += kHuffThreads) stream[w] = 0;
+    }
+}
+
 void launch_huffman(hipStream_t st, const HuffArgs &a)
 {
-    hipLaunchKernelGGL(k_huffman, dim3(a.nb), dim3(kHuffThreads), 0, st, a);
+    static const bool split = !(getenv("BZ_HUFF_SPLIT") && atoi(getenv("BZ_HUFF_SPLIT")) == 0);
+    if (split) {
+        const dim3 sweep_grid(kSweepTilesX, a.nb);
+        hipLaunchKernelGGL(k_huff_tables, dim3(a.nb), dim3(64), 0, st, a, 0u);
+        for (u32 iter = 1; iter <= 4; ++iter) { // BZ_N_ITERS, encoder.rs:294,433
+            hipLaunchKernelGGL(k_huff_sweep, sweep_grid, dim3(kSweepThreads), 0, st, a);
+            hipLaunchKernelGGL(k_huff_tables, dim3(a.nb), dim3(64), 0, st, a, iter);
+        }
+        hipLaunchKernelGGL(k_huff_gbits, sweep_grid, dim3(kSweepThreads), 0, st, a);
+        hipLaunchKernelGGL(k_huff_header, dim3(a.nb), dim3(kHuffThreads), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(k_huffman, dim3(a.nb), dim3(kHuffThreads), 0, st, a);
+    }
     hipLaunchKernelGGL(k_emit_payload, dim3((kMaxSelectors + 255) / 256, a.nb), dim3(256), 0, st, a);
 }
 
 // ---- probe: code lengths of one frequency table through the device code --------------------
+// (one wave; both forms of the length-limited procedure run and must agree: the single-lane replay and the
+// wave-parallel one of k_huff_tables -- a disagreement is reported as lengths of 0xFF)
 __global__ void k_probe_code_lengths(const u32 *freq, u32 alpha, u8 *out, u32 *lm_scr, int *lm_flag)
 {
     __shared__ u32 s_buf[2 * kMaxAlpha + 4];
     __shared__ u32 s_f[kMaxAlpha];
-    __shared__ u8 s_o[kMaxAlpha + 6];
+    __shared__ u8 s_o[kMaxAlpha + 6], s_o2[kMaxAlpha + 6];
+    __shared__ int s_lm;
     if (threadIdx.x == 0) {
         for (u32 i = 0; i < alpha; ++i) s_f[i] = freq[i];
         const int lm = heap_code_lengths(s_f, alpha, s_buf, s_o);
         if (lm) lm_code_lengths(s_f, alpha, lm_scr, kLmWords, kLmRow, s_o);
         *lm_flag = lm;
-        for (u32 i = 0; i < alpha; ++i) out[i] = s_o[i];
+        s_lm = lm;
     }
+    __syncthreads();
+    if (s_lm) { // uniform
+        lm_code_lengths_wave(s_f, alpha, lm_scr, kLmWords, kLmRow, s_o2, threadIdx.x);
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (u32 i = 0; i < alpha; ++i)
+                if (s_o2[i] != s_o[i]) s_o[i] = 0xFF;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (u32 i = 0; i < alpha; ++i) out[i] = s_o[i];
 }
 
 void launch_probe_code_lengths(hipStream_t st, const u32 *d_freq, u32 alpha, u8 *d_out, u32 *lm_scr,

@@ -16,13 +16,13 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    """No test waits for ever: a GPU test that has not come back after ten minutes fails with the stacks of all
+    """No test waits for ever: a GPU test that has not come back after five minutes fails with the stacks of all
     threads (pytest-timeout, when it is installed) instead of holding the whole session."""
     if not config.pluginmanager.hasplugin("timeout"):
         return
     for item in items:
         if item.get_closest_marker("timeout") is None:
-            item.add_marker(pytest.mark.timeout(600, method="thread"))
+            item.add_marker(pytest.mark.timeout(300, method="thread"))
 
 
 def product():
