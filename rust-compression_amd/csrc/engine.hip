@@ -83,6 +83,8 @@ static int ensure_workspace(bz_gpu_engine *g, size_t need_blocks)
     ENS(active, 64 * 8);
     ENS(per_k, nb * 4);
     ENS(per_shift, nb * 4);
+    ENS(lin_p, nb * 4);
+    ENS(lin_sig, nb * 4);
     ENS(bin_cursor, nb * (size_t)1024 * 4);
     ENS(pb_gate, nb * (size_t)4 + 256); // (+ loc_stats behind the gates)
     if (hipMemset(g->pb_gate.p, 0, g->pb_gate.cap) != hipSuccess) return BZ_E_UNEXPECTED;
@@ -185,7 +187,7 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
     DevBuf *all[] = {&g->crc_tab, &g->xp16, &g->xp2, &g->tile_last, &g->carry_in, &g->tile_crc, &g->tile_count,
                      &g->tile_off, &g->sub_off, &g->sub_rs, &g->scal, &g->scan_part, &g->rle, &g->blocks_all, &g->crc_all, &g->lblocks, &g->lcrc, &g->SA,
                      &g->R, &g->KA, &g->VA, &g->KB, &g->VB, &g->tile_hist, &g->count, &g->flags, &g->tlo, &g->tln,
-                     &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->bin_cursor, &g->pb_gate, &g->newbits, &g->bin_base, &g->sym_code, &g->keyinfo, &g->count2, &g->tile_nf, &g->L, &g->orig_ptr, &g->inuse_bits,
+                     &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->lin_p, &g->lin_sig, &g->bin_cursor, &g->pb_gate, &g->newbits, &g->bin_base, &g->sym_code, &g->keyinfo, &g->count2, &g->tile_nf, &g->L, &g->orig_ptr, &g->inuse_bits,
                      &g->summ, &g->summ_len, &g->init_state, &g->rank8, &g->ztile_last, &g->ztile_cnt, &g->mtf,
                      &g->mtf_freq, &g->bout, &g->selector, &g->code_len, &g->group_bitoff, &g->lm_scratch, &g->hglen, &g->hpack, &g->hrfreq, &g->hlm,
                      &g->stream, &g->error_flag, &g->packlist, &g->packed, &g->gathered, &g->asmlist, &g->gh_tiles, &g->gbase, &g->tile_state,
@@ -428,6 +430,8 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
     x.active = g->active.as<unsigned long long>();
     x.per_k = g->per_k.as<u32>() + o;
     x.per_shift = g->per_shift.as<u32>() + o;
+    x.lin_p = g->lin_p.as<u32>() + o;
+    x.lin_sig = g->lin_sig.as<u32>() + o;
     x.bin_cursor = g->bin_cursor.as<u32>() + (size_t)o * 1024;
     x.pb_gate = g->pb_gate.as<u32>() + o;
     x.loc_stats = g->pb_gate.as<u32>() + g->ws_blocks; // (behind the gates)

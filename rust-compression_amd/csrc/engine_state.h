@@ -68,7 +68,7 @@ struct bz_gpu_engine {
     int level = 9;
     // batch workspace (sized by max_blocks)
     DevBuf lblocks, lcrc, SA, R, KA, VA, KB, VB, tile_hist, count, flags, tlo, tln, nonfinal, active, per_k,
-        per_shift, bin_cursor, pb_gate, bin_base, newbits, sym_code, keyinfo, count2, tile_nf, L, orig_ptr, inuse_bits, summ, summ_len, init_state, rank8, ztile_last, ztile_cnt, mtf,
+        per_shift, lin_p, lin_sig, bin_cursor, pb_gate, bin_base, newbits, sym_code, keyinfo, count2, tile_nf, L, orig_ptr, inuse_bits, summ, summ_len, init_state, rank8, ztile_last, ztile_cnt, mtf,
         mtf_freq, bout, selector, code_len, group_bitoff, lm_scratch, hglen, hpack, hrfreq, hlm, stream, error_flag, packlist, gh_tiles, gbase,
         tile_state, tickets;
     u32 sort_epoch = 0; // fused radix passes: tag of the current pass in tile_state / tickets

@@ -44,10 +44,11 @@ namespace bzgpu {
 
 enum { SRC_TEXT = 0, SRC_PAIRS = 1, SRC_MM = 2, SRC_WALK = 3, SRC_SURV = 4, SRC_LISTG = 5,
        SRC_TEXTK = 6, SRC_WALKK = 7, SRC_MMK = 8, // ..K: keys stored by the histogram kernel of the pass
-       SRC_MMC = 9 }; // MM that also CARRIES the rank of rotation j+h along (k_radix_scatter_lb, first walk round)
+       SRC_MMC = 9, // MM that also CARRIES the rank of rotation j+h along (k_radix_scatter_lb, first walk round)
+       SRC_PERJ = 10 }; // the survivors keyed by their own start (the period round, see k_block_period)
 // sources whose sequence is the compacted list (length count[lb]) rather than all n positions
 template <int SRC> struct src_is_list {
-    static constexpr bool value = (SRC == SRC_PAIRS || SRC == SRC_SURV || SRC == SRC_LISTG);
+    static constexpr bool value = (SRC == SRC_PAIRS || SRC == SRC_SURV || SRC == SRC_LISTG || SRC == SRC_PERJ);
 };
 
 // per-block key geometry, produced by k_key_params
@@ -175,6 +176,18 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
             u32 t = val[r] + hm;
             t = t >= n ? t - n : t;
             key[r] = a.R[base + t] & ~kFinalBit;
+        }
+    } else if (SRC == SRC_PERJ) {
+        // the period round: order the survivors by where they start -- ascending or descending, as the block's
+        // period decides (k_block_period)
+        const bool desc = a.lin_sig[lb] == 2u;
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) {
+            const u32 idx = first + r * 64u;
+            const u32 c = idx < cnt ? idx : cnt - 1u;
+            val[r] = ld_stream(Vin + base + c);
+            key[r] = desc ? (n - 1u - val[r]) : val[r];
+            ok |= (idx < cnt ? 1u : 0u) << r;
         }
     } else if (SRC == SRC_LISTG) {
         // survivor round, second half: walk that order, key = the survivor's own group
@@ -1131,9 +1144,14 @@ __global__ __launch_bounds__(kLocThreads) void k_phase_b_local(BwtArgs a, const 
 //       key(j) = symbols [0,c), the second half key(j+c) is re-read from the block (L2).
 // else: list sorted by old group head g = K; secondary key = rank of rotation j+h.
 // `step` is the doubling step: h = 2c << step.
+// `impure` != nullptr (the period round, not INIT): the list is ordered by (group, start of the rotation) and the
+// secondary key is the start itself -- every member of a group becomes a group of its own -- unless the group holds
+// rotations of different residues modulo the block's period (impure[group head] != 0, k_period_mark) or the block has
+// no period: those groups stay as they are.
 template <bool INIT>
 __global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 step, const u32 *__restrict__ K,
-                                                               const u32 *__restrict__ V)
+                                                               const u32 *__restrict__ V,
+                                                               const u8 *__restrict__ impure = nullptr)
 {
     __shared__ int s_old, s_new;
     u32 tile, lb;
@@ -1190,6 +1208,17 @@ __global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 ste
 #pragma unroll
             for (u32 r = 0; r < 16; ++r) s2[r] = pkey(pt, jj[r], ki.bits, ki.chars);
             if (need_prev) ps20 = pkey(pt, pj, ki.bits, ki.chars);
+        } else if (impure) {
+            const bool per = a.lin_p[lb] != 0u;
+#pragma unroll
+            for (u32 r = 0; r < 16; ++r) {
+                const u32 jr = jj[r] >= hm ? jj[r] - hm : jj[r] + n - hm; // (the rotation itself)
+                s1[r] = (per && impure[base + g[r]] == 0) ? jr + 1u : 0u;
+            }
+            if (need_prev) {
+                const u32 jr = pj >= hm ? pj - hm : pj + n - hm;
+                ps10 = (per && impure[base + pg0] == 0) ? jr + 1u : 0u;
+            }
         } else {
 #pragma unroll
             for (u32 r = 0; r < 16; ++r) s1[r] = a.R[base + jj[r]];
@@ -1983,6 +2012,110 @@ __global__ __launch_bounds__(kSortThreads) void k_periodic_place(BwtArgs a)
     }
 }
 
+// ---- blocks with a LINEAR period: deep repeats without the doubling rounds ---------------------------------
+// A block that is a paragraph repeated (stress corpus T2: 4 KiB x 220) has common prefixes of almost its whole length,
+// and prefix doubling pays log2(n / 2c) = 17 full rounds for it.  If T[i] == T[i + p] for all i < n - p (p the
+// smallest such period, p not a divisor of n), rotations i and i + p agree until the later one runs over the end of
+// the block: at offset d = n - p - i + e rotation i reads T[n - p + e] and rotation i + p reads T[e], for EVERY i.
+// So with e* the first e in [0, p) where T[n - p + e] != T[e] (it exists: the period is primitive and n mod p != 0),
+// rot(i) < rot(i + p) for all i < n - p if T[n - p + e*] < T[e*], and rot(i) > rot(i + p) for all of them otherwise:
+// rotations whose starts are congruent modulo p are ordered by their starts, ascending or descending.  A group of
+// still-equal rotations that are all congruent modulo p is therefore finished by ONE sort by start -- the period
+// round of run_bwt_once -- instead of the rounds that are left; groups that mix residues go on doubling (their common
+// prefixes are short: they end inside the paragraph).  The reference (sais.rs:266-272) only fixes the ORDER, which
+// this is.  k_block_period finds p, checks it over the whole block and settles the direction; blocks without such a
+// period (lin_p = 0) take no harm from the round: their groups are left alone.
+__global__ __launch_bounds__(kSortThreads) void k_block_period(BwtArgs a)
+{
+    __shared__ u32 s_best, s_bad, s_e;
+    const u32 lb = blockIdx.x, tid = threadIdx.x;
+    const BlockDesc d = a.blocks[lb];
+    const u32 n = d.n;
+    const u8 *__restrict__ text = a.rle + d.rle_off;
+    if (tid == 0) {
+        a.lin_p[lb] = 0;
+        a.lin_sig[lb] = 0;
+    }
+    if (n < 256u) return;
+    u64 h0, h1;
+    __builtin_memcpy(&h0, text, 8);
+    __builtin_memcpy(&h1, text + 8, 8);
+    u32 from = 1, p = 0;
+    for (u32 attempt = 0; attempt < 8u; ++attempt) { // (uniform)
+        if (tid == 0) {
+            s_best = 0xFFFFFFFFu;
+            s_bad = 0;
+        }
+        __syncthreads();
+        // the smallest shift >= from under which the first 16 bytes recur
+        for (u32 q = from + tid; q <= n / 2u && q < s_best; q += kSortThreads) {
+            u64 x0, x1;
+            __builtin_memcpy(&x0, text + q, 8);
+            __builtin_memcpy(&x1, text + q + 8, 8);
+            if (x0 == h0 && x1 == h1) {
+                atomicMin(&s_best, q);
+                break;
+            }
+        }
+        __syncthreads();
+        const u32 cand = s_best;
+        if (cand == 0xFFFFFFFFu) return;
+        // is it a period of the whole block?
+        const u32 len = n - cand;
+        for (u32 i = tid * 8u; i < len && !s_bad; i += kSortThreads * 8u) {
+            if (i + 8u <= len) {
+                u64 x, y;
+                __builtin_memcpy(&x, text + i, 8);
+                __builtin_memcpy(&y, text + i + cand, 8);
+                if (x != y) s_bad = 1;
+            } else {
+                for (u32 k = i; k < len; ++k)
+                    if (text[k] != text[k + cand]) s_bad = 1;
+            }
+        }
+        __syncthreads();
+        if (!s_bad) {
+            p = cand;
+            break;
+        }
+        from = cand + 1u;
+        __syncthreads();
+    }
+    if (p == 0 || n % p == 0u) return; // (none found; or the block is periodic as a CYCLE: k_periodic_place's case)
+    if (tid == 0) s_e = 0xFFFFFFFFu;
+    __syncthreads();
+    for (u32 e = tid; e < p && e < s_e; e += kSortThreads)
+        if (text[n - p + e] != text[e]) {
+            atomicMin(&s_e, e);
+            break;
+        }
+    __syncthreads();
+    if (tid == 0 && s_e != 0xFFFFFFFFu) {
+        a.lin_p[lb] = p;
+        a.lin_sig[lb] = text[n - p + s_e] < text[s_e] ? 1u : 2u; // 1: ascending starts, 2: descending
+    }
+}
+
+// the period round's list, ordered by (group, start): a group that holds two neighbours of different residues modulo
+// the period is marked impure (one byte per group head)
+__global__ __launch_bounds__(kSortThreads) void k_period_mark(BwtArgs a, const u32 *__restrict__ K, const u32 *__restrict__ V,
+                                                               u8 *__restrict__ impure)
+{
+    u32 tile, lb;
+    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    const u32 cnt = a.count[lb];
+    const u32 start = tile * kSortTile;
+    const u32 p = a.lin_p[lb];
+    if (start >= cnt || p == 0u) return;
+    const size_t base = (size_t)lb * kSlot;
+    for (u32 idx = start + threadIdx.x; idx < cnt && idx < start + kSortTile; idx += kSortThreads) {
+        if (idx == 0) continue;
+        const u32 g = K[base + idx], gp = K[base + idx - 1];
+        if (g == gp && (V[base + idx] % p) != (V[base + idx - 1] % p)) impure[base + g] = 1;
+    }
+}
+
 // ---- symbols in use and key geometry (before the sort) ----------------------------------------------
 __global__ __launch_bounds__(kSortThreads) void k_block_symbols(BwtArgs a, u32 *__restrict__ inuse_bits /*[nb][8]*/)
 {
@@ -2417,6 +2550,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
     u32 step = 0; // this round compares at depth h = 2c << step
     int rounds = 0;
     u32 slot = 0;
+    bool period_done = false;
     while (true) {
         if (hipMemcpyAsync(h_active, a.active + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, st) !=
             hipSuccess)
@@ -2430,7 +2564,25 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         ++rounds;
         bool carried = false;
         (void)hipMemsetAsync(a.nonfinal, 0, a.nb * sizeof(u32), st);
-        if (m * 4 < total_n) {
+        // Most rotations still unordered after two rounds (4c symbols and more compared): deep repeats.  One period
+        // round (k_block_period) finishes the groups of a periodic block; what it cannot take goes on doubling.
+        static const bool want_period = !(getenv("BZ_PERIOD_ROUND") && atoi(getenv("BZ_PERIOD_ROUND")) == 0);
+        const bool per_round = want_period && !period_done && rounds >= 3 && m * 4 >= total_n * 3;
+        u8 *impure = a.ptext; // (the packed text is not read any more once the init is over)
+        if (per_round) {
+            period_done = true;
+            hipLaunchKernelGGL(k_block_period, dim3(a.nb), dim3(kSortThreads), 0, st, a);
+            (void)hipMemsetAsync(impure, 0, (size_t)a.nb * kSlot, st);
+            hipLaunchKernelGGL(k_survivor_compact, grid, dim3(kSortThreads), 0, st, a, lastV, fV);
+            hipLaunchKernelGGL(k_copy_counts, dim3((a.nb + 255) / 256), dim3(256), 0, st, a.count, a.count2, a.nb);
+            radix_pass<SRC_PERJ, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof);
+            radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof);
+            radix_pass<SRC_LISTG, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK);
+            radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof);
+            u32 *t = cK; cK = fK; fK = t;
+            t = cV; cV = fV; fV = t;
+            hipLaunchKernelGGL(k_period_mark, grid, dim3(kSortThreads), 0, st, a, cK, cV, impure);
+        } else if (m * 4 < total_n) {
             // few survivors: compact them (list order = sorted by group), order them by the rank
             // of rotation j+h (2 passes), then stably by their own group (2 passes): O(m) work
             hipLaunchKernelGGL(k_survivor_compact, grid, dim3(kSortThreads), 0, st, a, lastV, fV);
@@ -2460,7 +2612,15 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             }
         }
         (void)hipMemsetAsync(a.bin_cursor, 0, (size_t)a.nb * 1024 * sizeof(u32), st);
-        if (carried) {
+        if (per_round) {
+            // (the comparison depth does not move: the next round doubles from where the last one stood)
+            p = prof ? prof->begin(st, KID_GROUP_FLAGS, m * 13) : -1;
+            hipLaunchKernelGGL((k_group_flags<false>), grid, dim3(kSortThreads), 0, st, a, step, cK, cV, impure);
+            if (prof) prof->end(st, p);
+            p = prof ? prof->begin(st, KID_GROUP_APPLY, m * 17) : -1;
+            hipLaunchKernelGGL((k_group_apply<false>), grid, dim3(kSortThreads), 0, st, a, step, slot, cK, cV, fK);
+            if (prof) prof->end(st, p);
+        } else if (carried) {
             const u32 e = next_epoch(st, a);
             p = prof ? prof->begin(st, KID_GROUP_REFINE, m * 18) : -1; // K 4, V 4, flag 1, SA 4, rank word 4, column 1
             hipLaunchKernelGGL((k_group_refine<false>), grid, dim3(kSortThreads), 0, st, a, step, step + 1, slot, cK, cV, fK, e);
@@ -2477,7 +2637,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         hipLaunchKernelGGL(k_rank_place, grid, dim3(kSortThreads), 0, st, a, fK);
         if (prof) prof->end(st, p);
         lastV = cV;
-        ++step;
+        if (!per_round) ++step;
     }
     if (fused) {
         // a look-back that gave up (it never should) must not pass for a sorted block, and every pass

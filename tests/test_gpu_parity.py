@@ -486,3 +486,43 @@ print("ok")
     e = dict(os.environ, BZ_ENC_CHUNK_MIB="1")
     out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-500:] + out.stderr[-3000:]
+
+
+def test_period_round_on_deep_repeats(pkg, oracle, eng):
+    """Blocks with a LINEAR period (a paragraph repeated, the block length no multiple of it): the sort finishes
+    their groups with one sort by start position instead of log2(n) doubling rounds (k_block_period, the period
+    round of run_bwt_once).  Rotation order against the oracle for both directions of the wrap comparison, for
+    tiny and large periods, for paragraphs whose first 16 bytes recur inside them (the period search has to reject
+    candidates), for a cyclic period (n a multiple of p: k_periodic_place's case, the round must keep its hands
+    off) and for a defect in the middle (no linear period: the doubling rounds do it)."""
+    rng = random.Random(77)
+
+    def para(k, alpha=b"abcdefgh "):
+        return bytes(rng.choice(alpha) for _ in range(k))
+
+    cases = []
+    for p_len in (2, 3, 7, 64, 1000, 4096, 30011):
+        for n in (70_001, 99_000):
+            q = para(p_len) if p_len > 3 else (b"ab", b"abc")[p_len - 2]
+            cases.append((q * (n // p_len + 1))[:n])
+    # both directions: the byte after the last whole period decides
+    base = para(500)
+    cases.append((base * 200)[:90_123])
+    cases.append((bytes(255 - b for b in base) * 200)[:90_123])
+    # the first 16 bytes recur inside the paragraph
+    tricky = b"0123456789abcdef" + para(100) + b"0123456789abcdef" + para(333) + b"0123456789abcdeX" + para(50)
+    cases.append((tricky * 300)[:95_000])
+    # cyclic period, and a defect in the middle
+    cases.append(para(1000) * 90)
+    d = bytearray((para(777) * 130)[:96_000])
+    d[40_000] ^= 1
+    cases.append(bytes(d))
+    for i, blk in enumerate(cases):
+        got = eng.debug_bwt(blk)
+        assert got == oracle.bwt(blk), (i, len(blk))
+    # the round did run: a deep-repeat block takes a handful of rounds, not seventeen
+    eng.debug_bwt((para(4096) * 25)[:99_981])
+    assert eng.bwt_stats()["rounds"] <= 6
+    # and whole streams (several periodic blocks per stream) against the oracle
+    for data, level in (((para(4096) * 400)[:1_500_000], 5), ((b"ab" * 300_000)[:555_555], 1)):
+        assert pkg.compress(data, level) == oracle.encode(data, level)
