@@ -231,6 +231,7 @@ struct BwtArgs {
     int *tile_last_new;              // [nb][kTilesPerBlock]
     u32 *nonfinal;                   // [nb]
     unsigned long long *active;      // [64] per-round count of non-final rotations in unfinished blocks
+    u32 *maxnf;                      // [64] per round: the largest number of non-final rotations any block is left with
     u32 *per_k, *per_shift;          // [nb] periodic blocks: repetition count, least-rotation start
     u32 *lin_p, *lin_sig;            // [nb] blocks with a linear period (k_block_period): the period (0: none), 1 / 2 =
                                      //   rotations congruent modulo it are ordered by ascending / descending start

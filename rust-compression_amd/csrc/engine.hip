@@ -80,7 +80,7 @@ static int ensure_workspace(bz_gpu_engine *g, size_t need_blocks)
     ENS(tlo, nb * (size_t)kTilesPerBlock * 4);
     ENS(tln, nb * (size_t)kTilesPerBlock * 4);
     ENS(nonfinal, nb * 4);
-    ENS(active, 64 * 8);
+    ENS(active, 64 * 8 + 64 * 4);
     ENS(per_k, nb * 4);
     ENS(per_shift, nb * 4);
     ENS(lin_p, nb * 4);
@@ -428,6 +428,7 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
     x.tile_last_new = g->tln.as<int>() + t;
     x.nonfinal = g->nonfinal.as<u32>() + o;
     x.active = g->active.as<unsigned long long>();
+    x.maxnf = reinterpret_cast<u32 *>(g->active.as<unsigned long long>() + 64);
     x.per_k = g->per_k.as<u32>() + o;
     x.per_shift = g->per_shift.as<u32>() + o;
     x.lin_p = g->lin_p.as<u32>() + o;

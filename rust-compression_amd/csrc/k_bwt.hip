@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shif
     constexpr u32 kHistCopies = 4;
     __shared__ u32 s_hist[kHistCopies][NB];
     u32 tile, lb;
-    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
     __shared__ u32 s_total;
     u16 *s_cnt = reinterpret_cast<u16 *>(s_buf); // [NW][NB] u16 <= 64 KiB
     u32 tile, lb;
-    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(kSortThreads) void k_ghist_text(BwtArgs a, u32 *__r
     constexpr u32 NB0 = 1u << B0, NB1 = 1u << B1, NB2 = 1u << B2;
     __shared__ u32 s_h0[2][NB0], s_h1[2][NB1], s_h2[2][NB2];
     u32 tile, lb;
-    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
@@ -981,7 +981,7 @@ __global__ __launch_bounds__(kLocThreads) void k_phase_b_local(BwtArgs a, const 
     __shared__ u32 s_seg[2];
     __shared__ u32 s_bad;
     u32 tile, lb;
-    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 ste
 {
     __shared__ int s_old, s_new;
     u32 tile, lb;
-    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
     __shared__ u16 s_bpre[1024];  // exclusive prefix of the counts inside the tile
     __shared__ u32 s_wsum[NW];
     u32 tile, lb;
-    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
@@ -1431,7 +1431,9 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
         }
     }
     if (threadIdx.x == 0 && s_nonfinal) {
-        atomicAdd(&a.nonfinal[lb], s_nonfinal);
+        // (the largest of these sums over a block's tiles is the block's total: the host sizes the next round's
+        // launches by it)
+        atomicMax(&a.maxnf[round], atomicAdd(&a.nonfinal[lb], s_nonfinal) + s_nonfinal);
         // the block still needs rounds only while the next comparison depth is below its length
         const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
         const u32 h_next = ((u32)ki.chars * 2u) << next_step;
@@ -1781,7 +1783,9 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
         }
     }
     if (threadIdx.x == 0 && s_nonfinal) {
-        atomicAdd(&a.nonfinal[lb], s_nonfinal);
+        // (the largest of these sums over a block's tiles is the block's total: the host sizes the next round's
+        // launches by it)
+        atomicMax(&a.maxnf[round], atomicAdd(&a.nonfinal[lb], s_nonfinal) + s_nonfinal);
         const u32 h_next = ((u32)ki.chars * 2u) << next_step;
         if (h_next < n) atomicAdd(&a.active[round], (unsigned long long)s_nonfinal);
     }
@@ -1837,7 +1841,7 @@ __global__ __launch_bounds__(kSortThreads) void k_rank_place(BwtArgs a, const u3
 {
     __shared__ u32 s_r[kSortThreads / 64][kRankBinSize];
     u32 tile, lb;
-    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
     const u32 n = a.blocks[lb].n;
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
@@ -1894,7 +1898,7 @@ __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, co
     constexpr u32 NW = kSortThreads / 64;
     __shared__ u32 s_off, s_wsum[NW];
     u32 tile, lb;
-    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
     const u32 cnt = a.count[lb];
     const u32 start = tile * kSortTile;
@@ -1963,7 +1967,7 @@ __global__ void k_copy_counts(u32 *__restrict__ dst, const u32 *__restrict__ src
 __global__ __launch_bounds__(kSortThreads) void k_periodic_stats(BwtArgs a)
 {
     u32 tile, lb;
-    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
     if (a.nonfinal[lb] == 0) return;
     const u32 n = a.blocks[lb].n;
@@ -1990,7 +1994,7 @@ __global__ __launch_bounds__(kSortThreads) void k_periodic_stats(BwtArgs a)
 __global__ __launch_bounds__(kSortThreads) void k_periodic_place(BwtArgs a)
 {
     u32 tile, lb;
-    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
     if (a.nonfinal[lb] == 0) return;
     const BlockDesc d = a.blocks[lb];
@@ -2102,7 +2106,7 @@ __global__ __launch_bounds__(kSortThreads) void k_period_mark(BwtArgs a, const u
                                                                u8 *__restrict__ impure)
 {
     u32 tile, lb;
-    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
     const u32 cnt = a.count[lb];
     const u32 start = tile * kSortTile;
@@ -2121,7 +2125,7 @@ __global__ __launch_bounds__(kSortThreads) void k_block_symbols(BwtArgs a, u32 *
 {
     __shared__ u32 s_bits[8];
     u32 tile, lb;
-    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
@@ -2203,7 +2207,7 @@ __global__ __launch_bounds__(kSortThreads) void k_pack_text(BwtArgs a, u8 *__res
     __shared__ u8 s_code[256];
     __shared__ u32 s_out[kSortTile / 4]; // 1024 groups x at most 8 bytes
     u32 tile, lb;
-    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
@@ -2253,7 +2257,7 @@ __global__ __launch_bounds__(kSortThreads) void k_last_column(BwtArgs a, u8 *__r
                                                                u32 *__restrict__ orig_ptr)
 {
     u32 tile, lb;
-    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
@@ -2334,11 +2338,13 @@ void KernelProf::reset()
 // Algorithmic bytes per element of each radix kernel, by source:
 //   hist   : TEXT 1 (block byte), PAIRS 4 (key), MM 8 (SA + rank), WALK 5 (order + block byte)
 //   scatter: the same reads (+4 for the value of PAIRS) + 8 written (key, value)
+// `tiles`: tiles per block the launches cover (a list of a round is often a few tiles long: launching 110 tiles for
+// every block costs ~60 us per kernel in workgroups that have nothing to do)
 template <int SRC, int BITS>
 static void radix_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const u32 *Kin, const u32 *Vin,
-                       u32 *Kout, u32 *Vout, u64 elems, KernelProf *prof, u32 *Ktmp = nullptr)
+                       u32 *Kout, u32 *Vout, u64 elems, KernelProf *prof, u32 *Ktmp = nullptr, u32 tiles = kTilesPerBlock)
 {
-    const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
+    const dim3 grid(tiles, xcd_grid_y(a.nb));
     const u64 rd_hist = (SRC == SRC_TEXT) ? 1 : (SRC == SRC_PAIRS ? 4 : (SRC == SRC_WALK ? 5 : 8));
     const u64 rd_scat = (SRC == SRC_TEXT) ? 1 : (SRC == SRC_WALK ? 5 : 8); // SURV / LISTG: list + rank = 8
     int p = prof ? prof->begin(st, KID_RADIX_HIST, elems * rd_hist) : -1;
@@ -2491,6 +2497,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
     if (!allow_fused || a.fused_state[0]) a.fused = 0;
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
     (void)hipMemsetAsync(a.active, 0, 64 * sizeof(unsigned long long), st);
+    (void)hipMemsetAsync(a.maxnf, 0, 64 * sizeof(u32), st);
     (void)hipMemsetAsync(a.nonfinal, 0, a.nb * sizeof(u32), st);
     if (a.sort_err) (void)hipMemsetAsync(a.sort_err, 0, 4, st); // a failure of an earlier call must not stick
 
@@ -2551,12 +2558,23 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
     int rounds = 0;
     u32 slot = 0;
     bool period_done = false;
+    u32 list_tiles = kTilesPerBlock; // (the first refinement ran on all of SA)
     while (true) {
         if (hipMemcpyAsync(h_active, a.active + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, st) !=
-            hipSuccess)
+                hipSuccess ||
+            hipMemcpyAsync(h_active + 1, a.maxnf + slot, sizeof(u32), hipMemcpyDeviceToHost, st) != hipSuccess)
             return -1;
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
         const u64 m = *h_active; // rotations still to be ordered (in unfinished blocks)
+        // tiles of the longest list of the coming round (its members are the rotations the last refinement left
+        // unordered), and of the list that refinement ran on
+        const u32 list_tiles_prev = list_tiles;
+        {
+            const u32 mx = *reinterpret_cast<const u32 *>(h_active + 1);
+            list_tiles = (mx + kSortTile - 1) / kSortTile + 1u;
+            if (list_tiles > kTilesPerBlock) list_tiles = kTilesPerBlock;
+        }
+        const dim3 grid_list(list_tiles, xcd_grid_y(a.nb)), grid_prev(list_tiles_prev, xcd_grid_y(a.nb));
         if (sorted_elems) *sorted_elems += m;
         if (round_active && slot < 64) round_active[slot] += m;
         if (m == 0 || step > 24 || ((u64)(2u * min_chars) << step) >= max_n) break;
@@ -2573,26 +2591,26 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             period_done = true;
             hipLaunchKernelGGL(k_block_period, dim3(a.nb), dim3(kSortThreads), 0, st, a);
             (void)hipMemsetAsync(impure, 0, (size_t)a.nb * kSlot, st);
-            hipLaunchKernelGGL(k_survivor_compact, grid, dim3(kSortThreads), 0, st, a, lastV, fV);
+            hipLaunchKernelGGL(k_survivor_compact, grid_prev, dim3(kSortThreads), 0, st, a, lastV, fV);
             hipLaunchKernelGGL(k_copy_counts, dim3((a.nb + 255) / 256), dim3(256), 0, st, a.count, a.count2, a.nb);
-            radix_pass<SRC_PERJ, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof);
-            radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof);
-            radix_pass<SRC_LISTG, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK);
-            radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof);
+            radix_pass<SRC_PERJ, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, nullptr, list_tiles);
+            radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof, nullptr, list_tiles);
+            radix_pass<SRC_LISTG, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK, list_tiles);
+            radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof, nullptr, list_tiles);
             u32 *t = cK; cK = fK; fK = t;
             t = cV; cV = fV; fV = t;
-            hipLaunchKernelGGL(k_period_mark, grid, dim3(kSortThreads), 0, st, a, cK, cV, impure);
+            hipLaunchKernelGGL(k_period_mark, grid_list, dim3(kSortThreads), 0, st, a, cK, cV, impure);
         } else if (m * 4 < total_n) {
             // few survivors: compact them (list order = sorted by group), order them by the rank
             // of rotation j+h (2 passes), then stably by their own group (2 passes): O(m) work
-            hipLaunchKernelGGL(k_survivor_compact, grid, dim3(kSortThreads), 0, st, a, lastV, fV);
+            hipLaunchKernelGGL(k_survivor_compact, grid_prev, dim3(kSortThreads), 0, st, a, lastV, fV);
             hipLaunchKernelGGL(k_copy_counts, dim3((a.nb + 255) / 256), dim3(256), 0, st, a.count, a.count2, a.nb);
             // (the ranks a histogram kernel gathers are kept in the free key array for its scatter kernel: with few
             // survivors per block the rank arrays of the blocks in flight do not fit the L2, a gather costs a sector)
-            radix_pass<SRC_SURV, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK);
-            radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof);
-            radix_pass<SRC_LISTG, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK);
-            radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof);
+            radix_pass<SRC_SURV, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK, list_tiles);
+            radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof, nullptr, list_tiles);
+            radix_pass<SRC_LISTG, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK, list_tiles);
+            radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof, nullptr, list_tiles);
             u32 *t = cK; cK = fK; fK = t;
             t = cV; cV = fV; fV = t;
         } else {
@@ -2615,10 +2633,10 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         if (per_round) {
             // (the comparison depth does not move: the next round doubles from where the last one stood)
             p = prof ? prof->begin(st, KID_GROUP_FLAGS, m * 13) : -1;
-            hipLaunchKernelGGL((k_group_flags<false>), grid, dim3(kSortThreads), 0, st, a, step, cK, cV, impure);
+            hipLaunchKernelGGL((k_group_flags<false>), grid_list, dim3(kSortThreads), 0, st, a, step, cK, cV, impure);
             if (prof) prof->end(st, p);
             p = prof ? prof->begin(st, KID_GROUP_APPLY, m * 17) : -1;
-            hipLaunchKernelGGL((k_group_apply<false>), grid, dim3(kSortThreads), 0, st, a, step, slot, cK, cV, fK);
+            hipLaunchKernelGGL((k_group_apply<false>), grid_list, dim3(kSortThreads), 0, st, a, step, slot, cK, cV, fK);
             if (prof) prof->end(st, p);
         } else if (carried) {
             const u32 e = next_epoch(st, a);
@@ -2627,10 +2645,10 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             if (prof) prof->end(st, p);
         } else {
             p = prof ? prof->begin(st, KID_GROUP_FLAGS, m * 13) : -1;
-            hipLaunchKernelGGL((k_group_flags<false>), grid, dim3(kSortThreads), 0, st, a, step, cK, cV);
+            hipLaunchKernelGGL((k_group_flags<false>), grid_list, dim3(kSortThreads), 0, st, a, step, cK, cV);
             if (prof) prof->end(st, p);
             p = prof ? prof->begin(st, KID_GROUP_APPLY, m * 17) : -1;
-            hipLaunchKernelGGL((k_group_apply<false>), grid, dim3(kSortThreads), 0, st, a, step + 1, slot, cK, cV, fK);
+            hipLaunchKernelGGL((k_group_apply<false>), grid_list, dim3(kSortThreads), 0, st, a, step + 1, slot, cK, cV, fK);
             if (prof) prof->end(st, p);
         }
         p = prof ? prof->begin(st, KID_RANK_PLACE, m * 8) : -1;

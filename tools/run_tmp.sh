@@ -1,22 +1,7 @@
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-for lv in 9 3; do
-  timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $R/gpurun_out/r3dec_$lv -o t -- python3 $R/bench_decode.py --level $lv --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/r3dec_$lv.json 2> $R/gpurun_out/r3dec_$lv.err
-  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/r3decf_$lv -o t -- python3 $R/bench_decode.py --level $lv --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
-done
-cd $R
-python3 - <<'PY'
-import csv,glob,collections
-for lv in (9,3):
-    agg=collections.defaultdict(float); dur=0
-    for fn in glob.glob("gpurun_out/r3dec_%d/**/*counter_collection.csv"%lv, recursive=True):
-        for r in csv.DictReader(open(fn)):
-            if "k_dec_walk_lengths" in r["Kernel_Name"]: agg[r["Counter_Name"]]+=float(r["Counter_Value"])
-    for fn in glob.glob("gpurun_out/r3decf_%d/**/*counter_collection.csv"%lv, recursive=True):
-        for r in csv.DictReader(open(fn)):
-            if "k_dec_walk_lengths" in r["Kernel_Name"]: agg[r["Counter_Name"]]+=float(r["Counter_Value"])
-    for fn in glob.glob("gpurun_out/r3dec_%d/**/*kernel_trace.csv"%lv, recursive=True):
-        for r in csv.DictReader(open(fn)):
-            if "k_dec_walk_lengths" in r["Kernel_Name"]: dur+=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6
-    print("level",lv,dict(agg),"ms",dur)
-PY
+timeout 420 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > /tmp/o.txt 2>&1; echo "parity rc=$? $(tail -1 /tmp/o.txt)"; grep -v "^tests\|^$\|^\.\|passed" /tmp/o.txt | tail -30 | cut -c1-220
+timeout 300 python bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline --hang-timeout 100 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['step_ms'], d['checks'], d['kernel_seconds_last_step_rank0'])"
+timeout 300 python bench.py --corpus t2 --mib-per-gpu 256 --steps 3 --warmup 1 --no-extras --no-cpu-baseline --hang-timeout 100 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('t2', d['value'], d['ms_per_step'], d['checks'], d['bwt']['rounds'], d['stream_sha256'][:16])"
