@@ -170,6 +170,48 @@ __device__ __forceinline__ void xcd_remap(u32 tiles, u32 nblocks, u32 &tile, u32
 // grid.y for such a launch: blocks rounded up to a multiple of 8
 inline u32 xcd_grid_y(u32 nblocks) { return (nblocks + 7u) & ~7u; }
 
+// ---- decoupled look-back between the tiles of a block (fused radix passes, k_group_refine, k_zle_fused) ----
+constexpr u32 kLbValMask = 0xFFFFFu, kLbAgg = 1u << 20, kLbIncl = 2u << 20, kLbFlagMask = 3u << 20;
+// A spin gives up after about a second -- or as soon as another tile of the launch has given up (sort_err): one
+// look-back that cannot complete leaves every tile behind it waiting, and each of them for the full bound otherwise.
+constexpr u32 kLbSpinMax = 1u << 20;
+__device__ __forceinline__ bool lb_give_up(u32 &spins, const u32 *sort_err, u32 limit)
+{
+    ++spins;
+    if (spins > limit) return true;
+    return (spins & 255u) == 0u && __hip_atomic_load(sort_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+}
+
+// 16-byte accesses that the other compute units OF THE SAME XCD observe: plain stores are written
+// through to the XCD's L2 and stay there, `nt` loads bypass the L1 and are served by that L2
+// (MI355X_MICROARCH.md).  Producer and consumer of a look-back word always share an XCD (tickets are
+// taken from the counter of the XCD a workgroup runs on).  -DBZ_LB_SC1 selects accesses that are
+// coherent across XCDs instead (sc1; 2-3x the latency, and such stores drop the L2 line).  A 16-byte
+// granule written by one store is seen whole.
+typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_sc1_x4(u32 *p, uint4 v)
+{
+    const u32x4_t r = {v.x, v.y, v.z, v.w};
+    // (s_nop: a store of more than 8 bytes reads its data registers a cycle late; the compiler's hazard
+    // recogniser does not look inside inline assembly)
+    #ifndef BZ_LB_SC1
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(r) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(r) : "memory");
+#endif
+}
+__device__ __forceinline__ uint4 ld_sc1_x4(const u32 *p)
+{
+    u32x4_t r;
+    #ifndef BZ_LB_SC1
+    asm volatile("global_load_dwordx4 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+#else
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+#endif
+    return make_uint4(r.x, r.y, r.z, r.w);
+}
+
+
 // ---- CRC-32/BZIP2 arithmetic in GF(2)[x] / 0x104C11DB7 ------------------------
 constexpr u32 kCrcPoly = 0x04C11DB7u;
 
@@ -271,6 +313,9 @@ struct MtfArgs {
     u8 *rank8;               // [nb * kSlot]
     int *ztile_last;         // [nb][kTilesPerBlock] last position with a non-zero rank
     u32 *ztile_cnt;          // [nb][kTilesPerBlock]
+    u32 *zstate;             // [nb][kTilesPerBlock][4] look-back words of k_zle_fused
+    u32 *ztick;              // [16] its tile tickets per XCD, [8]: a look-back gave up
+    u32 fused_zle;           // 1: k_zle_fused; 0: k_zle_last + k_zle_emit<false> + k_zle_emit<true>
     u16 *mtf;                // [nb][kMtfStride] output symbols
     u32 *mtf_freq;           // [nb][kMaxAlpha]
     BlockOut *out;           // [nb]

@@ -97,6 +97,8 @@ static int ensure_workspace(bz_gpu_engine *g, size_t need_blocks)
     ENS(rank8, nb * (size_t)kSlot + 64);
     ENS(ztile_last, nb * (size_t)kTilesPerBlock * 4);
     ENS(ztile_cnt, nb * (size_t)kTilesPerBlock * 4);
+    ENS(zstate, nb * (size_t)kTilesPerBlock * 16);
+    ENS(ztick, 64);
     ENS(mtf, nb * (size_t)kMtfStride * 2);
     ENS(mtf_freq, nb * (size_t)kMaxAlpha * 4);
     ENS(bout, nb * sizeof(BlockOut));
@@ -455,7 +457,7 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
     return x;
 }
 
-static MtfArgs make_mtf_args(bz_gpu_engine *g, u32 nb, u32 o)
+static MtfArgs make_mtf_args(bz_gpu_engine *g, u32 nb, u32 o, u32 total_nb)
 {
     MtfArgs ma;
     const size_t s = (size_t)o * kSlot, t = (size_t)o * kTilesPerBlock, c = (size_t)o * kMaxMtfChunks;
@@ -469,6 +471,10 @@ static MtfArgs make_mtf_args(bz_gpu_engine *g, u32 nb, u32 o)
     ma.rank8 = g->rank8.as<u8>() + s;
     ma.ztile_last = g->ztile_last.as<int>() + t;
     ma.ztile_cnt = g->ztile_cnt.as<u32>() + t;
+    ma.zstate = g->zstate.as<u32>() + t * 4;
+    ma.ztick = g->ztick.as<u32>();
+    static const bool want_fused_zle = !(getenv("BZ_FUSED_ZLE") && atoi(getenv("BZ_FUSED_ZLE")) == 0);
+    ma.fused_zle = (want_fused_zle && !g->zle_fused_broken && o == 0 && nb == total_nb) ? 1u : 0u; // (one sub-batch: one set of tickets)
     ma.mtf = g->mtf.as<u16>() + (size_t)o * kMtfStride;
     ma.mtf_freq = g->mtf_freq.as<u32>() + (size_t)o * kMaxAlpha;
     ma.out = g->bout.as<BlockOut>() + o;
@@ -530,6 +536,7 @@ static int encode_batch(bz_gpu_engine *g, u32 nb, const std::vector<BlockDesc> &
     const u32 parts = (nb >= 64 && want_parts >= 1) ? want_parts : 1u;
     std::vector<hipEvent_t> evs;
     int rc = BZ_OK;
+    bool used_fused_zle = false;
     for (u32 q = 0; q < parts && rc == BZ_OK; ++q) {
         const u32 o = (u32)(((u64)nb * q) / parts), o1 = (u32)(((u64)nb * (q + 1)) / parts);
         const u32 nbq = o1 - o;
@@ -563,7 +570,8 @@ static int encode_batch(bz_gpu_engine *g, u32 nb, const std::vector<BlockDesc> &
         (void)hipEventRecord(ev, g->st);
         (void)hipStreamWaitEvent(g->st2, ev, 0);
 
-        const MtfArgs ma = make_mtf_args(g, nbq, o);
+        const MtfArgs ma = make_mtf_args(g, nbq, o, nb);
+        used_fused_zle = used_fused_zle || ma.fused_zle;
         sp = span_begin(g, 2, g->st2);
         launch_mtf(g->st2, ma);
         span_end(g, sp);
@@ -583,6 +591,24 @@ static int encode_batch(bz_gpu_engine *g, u32 nb, const std::vector<BlockDesc> &
     }
     (void)hipStreamSynchronize(g->st);
     for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
+    if (rc == BZ_OK && used_fused_zle) {
+        // did the one-launch ZLE stage hand out every tile on every XCD, and did no look-back give up?  If not (it never
+        // has), the MTF / ZLE and Huffman stages run again with the three ZLE kernels, and the engine stays on them.
+        u32 tk[9] = {};
+        static const bool fail_test = getenv("BZ_FUSED_ZLE_FAILTEST") != nullptr; // (tests: exercise the redo)
+        if (hipMemcpy(tk, g->ztick.p, sizeof(tk), hipMemcpyDeviceToHost) != hipSuccess) return BZ_E_UNEXPECTED;
+        bool bad = tk[8] != 0 || fail_test;
+        for (u32 x = 0; x < 8; ++x)
+            if (tk[x] < kTilesPerBlock * ((nb + 7u - x) / 8u)) bad = true;
+        if (bad) {
+            fprintf(stderr, "bz2_mi355x: the one-launch ZLE stage misbehaved (tile tickets / look-back); stage redone with three kernels\n");
+            g->zle_fused_broken = true;
+            const MtfArgs ma = make_mtf_args(g, nb, 0, nb);
+            launch_mtf(g->st, ma);
+            launch_huffman(g->st, make_huff_args(g, nb, 0));
+            if (hipStreamSynchronize(g->st) != hipSuccess) return BZ_E_UNEXPECTED;
+        }
+    }
     return rc;
 }
 

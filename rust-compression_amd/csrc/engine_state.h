@@ -68,10 +68,11 @@ struct bz_gpu_engine {
     int level = 9;
     // batch workspace (sized by max_blocks)
     DevBuf lblocks, lcrc, SA, R, KA, VA, KB, VB, tile_hist, count, flags, tlo, tln, nonfinal, active, per_k,
-        per_shift, lin_p, lin_sig, bin_cursor, pb_gate, bin_base, newbits, sym_code, keyinfo, count2, tile_nf, L, orig_ptr, inuse_bits, summ, summ_len, init_state, rank8, ztile_last, ztile_cnt, mtf,
+        per_shift, lin_p, lin_sig, bin_cursor, pb_gate, bin_base, newbits, sym_code, keyinfo, count2, tile_nf, L, orig_ptr, inuse_bits, summ, summ_len, init_state, rank8, ztile_last, ztile_cnt, zstate, ztick, mtf,
         mtf_freq, bout, selector, code_len, group_bitoff, lm_scratch, hglen, hpack, hrfreq, hlm, stream, error_flag, packlist, gh_tiles, gbase,
         tile_state, tickets;
     u32 sort_epoch = 0; // fused radix passes: tag of the current pass in tile_state / tickets
+    bool zle_fused_broken = false; // the one-launch ZLE stage misbehaved on this engine once: it stays on the three kernels
     u32 fused_state[2] = {0, 0}; // [0] fused passes found misbehaving on THIS engine (they stay off for it), [1] fallbacks
     hipEvent_t ev_aux = nullptr; // work that runs on st2 beside st (the RLE1 image beside the cut chain)
     size_t ws_blocks = 0; // blocks the batch workspace holds now (<= max_blocks)

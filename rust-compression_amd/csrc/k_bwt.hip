@@ -511,46 +511,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
 // has not been scheduled.  The words carry the pass number (epoch), so nothing is cleared between
 // passes.  What it saves: the histogram kernels (and, for the passes whose keys are gathered, the
 // round trip of the keys through memory).
-constexpr u32 kLbValMask = 0xFFFFFu, kLbAgg = 1u << 20, kLbIncl = 2u << 20, kLbFlagMask = 3u << 20;
-// A spin gives up after about a second -- or as soon as another tile of the launch has given up (sort_err): one
-// look-back that cannot complete leaves every tile behind it waiting, and each of them for the full bound otherwise.
-constexpr u32 kLbSpinMax = 1u << 20;
-__device__ __forceinline__ bool lb_give_up(u32 &spins, const u32 *sort_err, u32 limit)
-{
-    ++spins;
-    if (spins > limit) return true;
-    return (spins & 255u) == 0u && __hip_atomic_load(sort_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-}
-
-// 16-byte accesses that the other compute units OF THE SAME XCD observe: plain stores are written
-// through to the XCD's L2 and stay there, `nt` loads bypass the L1 and are served by that L2
-// (MI355X_MICROARCH.md).  Producer and consumer of a look-back word always share an XCD (tickets are
-// taken from the counter of the XCD a workgroup runs on).  -DBZ_LB_SC1 selects accesses that are
-// coherent across XCDs instead (sc1; 2-3x the latency, and such stores drop the L2 line).  A 16-byte
-// granule written by one store is seen whole.
-typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st_sc1_x4(u32 *p, uint4 v)
-{
-    const u32x4_t r = {v.x, v.y, v.z, v.w};
-    // (s_nop: a store of more than 8 bytes reads its data registers a cycle late; the compiler's hazard
-    // recogniser does not look inside inline assembly)
-    #ifndef BZ_LB_SC1
-    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(r) : "memory");
-#else
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(r) : "memory");
-#endif
-}
-__device__ __forceinline__ uint4 ld_sc1_x4(const u32 *p)
-{
-    u32x4_t r;
-    #ifndef BZ_LB_SC1
-    asm volatile("global_load_dwordx4 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
-#else
-    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
-#endif
-    return make_uint4(r.x, r.y, r.z, r.w);
-}
-
+// (kLb*, lb_give_up, st_sc1_x4 / ld_sc1_x4: bzgpu.h -- the ZLE stage uses the same look-back)
 template <int B0, int B1, int B2>
 __global__ __launch_bounds__(kSortThreads) void k_ghist_text(BwtArgs a, u32 *__restrict__ Kstore)
 {

@@ -529,6 +529,183 @@ __global__ __launch_bounds__(kSortThreads) void k_zle_emit(MtfArgs a)
         if (s_freq[i]) atomicAdd(&a.mtf_freq[(size_t)lb * kMaxAlpha + i], s_freq[i]);
 }
 
+// Z1 + Z2 + Z3 in ONE launch.  What a tile needs from the tiles in front of it -- the last position with a non-zero
+// rank (a zero run is written by the tile it ends in, with the digits of its whole length) and the number of symbols
+// they write -- comes by decoupled look-back, as in the fused radix passes: tiles take tickets from the counter of
+// the XCD they run on (all tiles of a block on one XCD, the words travel through that XCD's L2), a tile publishes what
+// it holds itself (AGG), looks back until its predecessors' sums are settled, publishes the settled value (INCL).
+// Two words of one 16-byte granule per tile: x = last non-zero position (0xFFFFF: none), y = symbols written; both
+// cleared before the launch (flag 0 = not there yet).  The look-back for the symbol count runs after the tile has
+// filled its staging buffer, so only the copy-out waits for it.  ztick[0..7]: tickets, ztick[8]: a look-back gave up
+// -- the host checks both after the batch and redoes the stage with the three kernels if they are not as expected.
+__global__ __launch_bounds__(kSortThreads) void k_zle_fused(MtfArgs a)
+{
+    __shared__ int s_mi[16];
+    __shared__ u32 s_su[16];
+    __shared__ u32 s_freq[kMaxAlpha + 2];
+    __shared__ int s_carry;
+    __shared__ u32 s_base, s_ticket;
+    __shared__ u16 s_out[kSortTile + 64];
+    const u32 xcd = (u32)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u; // XCC_ID
+    const u32 my_tiles = kTilesPerBlock * ((a.nb + 7u - xcd) / 8u);
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&a.ztick[xcd], 1u);
+    __syncthreads();
+    const u32 slot = s_ticket;
+    if (slot >= my_tiles) return;
+    const u32 b8 = slot / kTilesPerBlock;
+    const u32 tile = slot - b8 * kTilesPerBlock;
+    const u32 lb = b8 * 8u + xcd;
+    const u32 n = a.blocks[lb].n;
+    if (tile * kSortTile >= n) return; // (tiles beyond the block publish nothing; nobody looks back at them)
+    for (u32 i = threadIdx.x; i < kMaxAlpha + 2; i += kSortThreads) s_freq[i] = 0;
+    ZSeg s;
+    zload(a.rank8 + (size_t)lb * kSlot, n, tile, s);
+    int last = -1;
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k)
+        if (k < s.valid && s.r[k]) last = (int)(s.p0 + k);
+    int lnz = block_excl_max_int(last, s_mi); // last non-zero position before this segment, inside the tile
+    u32 *mystate = a.zstate + ((size_t)lb * kTilesPerBlock + tile) * 4u;
+    u32 w_last = 0; // (thread 0) this tile's settled x word
+    if (threadIdx.x == 0) {
+        int tl = -1; // the tile's own last non-zero position (s_mi holds the waves' inclusive maxima)
+        for (u32 k = 0; k < kSortThreads / 64; ++k) tl = s_mi[k] > tl ? s_mi[k] : tl;
+        const u32 vl = tl >= 0 ? (u32)tl : kLbValMask;
+        st_sc1_x4(mystate, make_uint4((tile ? kLbAgg : kLbIncl) | vl, 0u, 0u, 0u));
+        int c = -1;
+        if (tile) {
+            u32 spins = 0;
+            for (u32 p = tile; p > 0 && c < 0;) {
+                --p;
+                const u32 *src = a.zstate + ((size_t)lb * kTilesPerBlock + p) * 4u;
+                uint4 v = ld_sc1_x4(src);
+                while ((v.x & kLbFlagMask) == 0u) {
+                    if (lb_give_up(spins, a.ztick + 8, kLbSpinMax >> 3)) {
+                        atomicExch(a.ztick + 8, 1u);
+                        v = make_uint4(kLbIncl, 0u, 0u, 0u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    v = ld_sc1_x4(src);
+                }
+                const u32 x = v.x & kLbValMask;
+                if (x != kLbValMask) c = (int)x;
+                else if ((v.x & kLbFlagMask) == kLbIncl) break; // nothing non-zero in front at all
+            }
+        }
+        w_last = kLbIncl | (tl >= 0 ? (u32)tl : (c >= 0 ? (u32)c : kLbValMask));
+        if (tile) st_sc1_x4(mystate, make_uint4(w_last, 0u, 0u, 0u));
+        s_carry = c;
+    }
+    __syncthreads();
+    lnz = lnz > s_carry ? lnz : s_carry;
+    // pass 1: count
+    u32 cnt = 0;
+    {
+        int ln = lnz;
+#pragma unroll
+        for (u32 k = 0; k < 16; ++k) {
+            if (k < s.valid) {
+                const u32 p = s.p0 + k;
+                if (s.r[k]) {
+                    ln = (int)p;
+                    cnt += 1;
+                } else {
+                    const bool run_end = (k + 1 < s.valid) ? (s.r[(k + 1) & 15] != 0) : (s.next_nonzero != 0);
+                    if (run_end) cnt += run_digits((u32)((int)p - ln));
+                }
+            }
+        }
+    }
+    u32 total;
+    const u32 off = block_excl_sum1024(cnt, s_su, total);
+    if (threadIdx.x == 0) st_sc1_x4(mystate, make_uint4(w_last, (tile ? kLbAgg : kLbIncl) | total, 0u, 0u));
+    // pass 2: the symbols into the staging buffer (as k_zle_emit<true>)
+    u16 *out = s_out + off;
+    u32 hot0 = 0, hot1 = 0, hot2 = 0, hot3 = 0;
+    {
+        int ln = lnz;
+#pragma unroll
+        for (u32 k = 0; k < 16; ++k) {
+            if (k < s.valid) {
+                const u32 p = s.p0 + k;
+                if (s.r[k]) {
+                    ln = (int)p;
+                    const u32 sym = (u32)s.r[k] + 1u; // encoder.rs:340,349
+                    *out++ = (u16)sym;
+                    if (sym == 2u) ++hot2;
+                    else if (sym == 3u) ++hot3;
+                    else atomicAdd(&s_freq[sym], 1u);
+                } else {
+                    const bool run_end = (k + 1 < s.valid) ? (s.r[(k + 1) & 15] != 0) : (s.next_nonzero != 0);
+                    if (run_end) {
+                        u32 zc = (u32)((int)p - ln) + 1u; // encoder.rs:659-667
+                        while (zc > 1u) {
+                            const u32 run = zc & 1u;
+                            *out++ = (u16)run;
+                            hot0 += run ^ 1u;
+                            hot1 += run;
+                            zc >>= 1;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    hot0 = wave_sum(hot0);
+    hot1 = wave_sum(hot1);
+    hot2 = wave_sum(hot2);
+    hot3 = wave_sum(hot3);
+    if ((threadIdx.x & 63u) == 0) {
+        if (hot0) atomicAdd(&s_freq[0], hot0);
+        if (hot1) atomicAdd(&s_freq[1], hot1);
+        if (hot2) atomicAdd(&s_freq[2], hot2);
+        if (hot3) atomicAdd(&s_freq[3], hot3);
+    }
+    // where the tile's symbols go: the symbols of the tiles in front
+    if (threadIdx.x == 0) {
+        u32 base = 0;
+        if (tile) {
+            u32 spins = 0;
+            for (u32 p = tile; p > 0;) {
+                --p;
+                const u32 *src = a.zstate + ((size_t)lb * kTilesPerBlock + p) * 4u;
+                uint4 v = ld_sc1_x4(src);
+                while ((v.y & kLbFlagMask) == 0u) {
+                    if (lb_give_up(spins, a.ztick + 8, kLbSpinMax >> 3)) {
+                        atomicExch(a.ztick + 8, 1u);
+                        v = make_uint4(0u, kLbIncl, 0u, 0u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    v = ld_sc1_x4(src);
+                }
+                base += v.y & kLbValMask;
+                if ((v.y & kLbFlagMask) == kLbIncl) break;
+            }
+            st_sc1_x4(mystate, make_uint4(w_last, kLbIncl | ((base + total) & kLbValMask), 0u, 0u));
+        }
+        s_base = base;
+    }
+    __syncthreads();
+    {
+        u16 *dst = a.mtf + (size_t)lb * kMtfStride + s_base;
+        for (u32 i = threadIdx.x; i < total; i += kSortThreads) dst[i] = s_out[i];
+    }
+    const bool last_tile = (tile + 1) * kSortTile >= n;
+    if (last_tile && threadIdx.x == 0) {
+        const u32 alpha_in = popc8(a.inuse_bits + lb * 8);
+        const u32 eob = alpha_in + 1u; // encoder.rs:316
+        a.mtf[(size_t)lb * kMtfStride + s_base + total] = (u16)eob;
+        atomicAdd(&s_freq[eob], 1u);
+        a.out[lb].mtf_count = s_base + total + 1u;
+        a.out[lb].in_use_count = alpha_in;
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < kMaxAlpha; i += kSortThreads)
+        if (s_freq[i]) atomicAdd(&a.mtf_freq[(size_t)lb * kMaxAlpha + i], s_freq[i]);
+}
+
 void launch_mtf(hipStream_t st, const MtfArgs &a)
 {
     (void)hipMemsetAsync(a.mtf_freq, 0, (size_t)a.nb * kMaxAlpha * sizeof(u32), st);
@@ -536,6 +713,12 @@ void launch_mtf(hipStream_t st, const MtfArgs &a)
     hipLaunchKernelGGL(k_mtf_compose, dim3(a.nb), dim3(64), 0, st, a);
     hipLaunchKernelGGL(k_mtf_ranks_small, dim3(kChunkWGs, a.nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_mtf_ranks, dim3(kChunkWGs, a.nb), dim3(256), 0, st, a);
+    if (a.fused_zle) {
+        (void)hipMemsetAsync(a.zstate, 0, (size_t)a.nb * kTilesPerBlock * 16, st);
+        (void)hipMemsetAsync(a.ztick, 0, 64, st);
+        hipLaunchKernelGGL(k_zle_fused, dim3(kTilesPerBlock, xcd_grid_y(a.nb)), dim3(kSortThreads), 0, st, a);
+        return;
+    }
     const dim3 grid(kTilesPerBlock, a.nb);
     hipLaunchKernelGGL(k_zle_last, grid, dim3(kSortThreads), 0, st, a);
     hipLaunchKernelGGL((k_zle_emit<false>), grid, dim3(kSortThreads), 0, st, a);

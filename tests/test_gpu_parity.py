@@ -319,8 +319,10 @@ def test_wide_inputs_small_blocks(pkg, oracle):
 def test_radix_pass_flavours_agree(oracle):
     """the fused radix passes (default), the three-kernel passes (BZ_ONESWEEP=0) and the fallback from
     one to the other (BZ_ONESWEEP_FAILTEST at the first pass, BZ_ONESWEEP_LATEFAILTEST at the end of a sort)
-    give the oracle's stream; each runs in its own process
-    because the switches are read once"""
+    give the oracle's stream; so do the round-3 alternatives: flags + apply as two kernels everywhere
+    (BZ_FUSED_REFINE=0), the Huffman stage in one workgroup per block (BZ_HUFF_SPLIT=0), the ZLE stage as three
+    kernels (BZ_FUSED_ZLE=0) and its redo after a failed ticket check (BZ_FUSED_ZLE_FAILTEST), no period round
+    (BZ_PERIOD_ROUND=0).  Each runs in its own process because the switches are read once."""
     import subprocess
     import sys
     code = (
@@ -330,7 +332,9 @@ def test_radix_pass_flavours_agree(oracle):
         "print(hashlib.sha256(pkg.compress(d,9)).hexdigest(), hashlib.sha256(pkg.compress(d,1)).hexdigest())" % (ROOT, ROOT))
     d = sample(1) * 3 + bytes(range(256)) * 700 + sample(2)
     want = "%s %s" % (hashlib.sha256(oracle.encode(d, 9)).hexdigest(), hashlib.sha256(oracle.encode(d, 1)).hexdigest())
-    for env in ({}, {"BZ_ONESWEEP": "0"}, {"BZ_ONESWEEP_FAILTEST": "1"}, {"BZ_ONESWEEP_LATEFAILTEST": "1"}):
+    for env in ({}, {"BZ_ONESWEEP": "0"}, {"BZ_ONESWEEP_FAILTEST": "1"}, {"BZ_ONESWEEP_LATEFAILTEST": "1"},
+                {"BZ_FUSED_REFINE": "0"}, {"BZ_HUFF_SPLIT": "0"}, {"BZ_FUSED_ZLE": "0"}, {"BZ_FUSED_ZLE_FAILTEST": "1"},
+                {"BZ_PERIOD_ROUND": "0"}):
         e = dict(os.environ)
         e.update(env)
         out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
@@ -340,6 +344,8 @@ def test_radix_pass_flavours_agree(oracle):
             assert "fused radix passes disabled" in out.stderr
         if "BZ_ONESWEEP_LATEFAILTEST" in env:  # a pass after the first misbehaves: the batch is sorted again
             assert "batch sorted again" in out.stderr
+        if "BZ_FUSED_ZLE_FAILTEST" in env:
+            assert "stage redone with three kernels" in out.stderr
 
 
 def test_phase_b_in_lds_flavour(oracle):

@@ -1,7 +1,7 @@
-timeout 420 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > /tmp/o.txt 2>&1; echo "parity rc=$? $(tail -1 /tmp/o.txt)"; grep -v "^tests\|^$\|^\.\|passed" /tmp/o.txt | tail -30 | cut -c1-220
-timeout 300 python bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline --hang-timeout 100 2>&1 | tail -1 | python -c "
+timeout 1600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > /tmp/o.txt 2>&1; echo "parity rc=$? $(tail -1 /tmp/o.txt)"; grep -v "^tests\|^$\|^\.\|passed" /tmp/o.txt | head -40 | cut -c1-220
+for m in 1 0; do
+BZ_FUSED_ZLE=$m timeout 300 python bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline --hang-timeout 100 2>&1 | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['step_ms'], d['checks'], d['kernel_seconds_last_step_rank0'])"
-timeout 300 python bench.py --corpus t2 --mib-per-gpu 256 --steps 3 --warmup 1 --no-extras --no-cpu-baseline --hang-timeout 100 2>&1 | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('t2', d['value'], d['ms_per_step'], d['checks'], d['bwt']['rounds'], d['stream_sha256'][:16])"
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('fused_zle=$m', d['value'], d['ms_per_step'], d['step_ms'], d['checks'], d['kernel_seconds_last_step_rank0'])"
+done
+BZ_FUSED_ZLE_FAILTEST=1 timeout 300 python bench.py --steps 1 --warmup 0 --no-extras --no-cpu-baseline --hang-timeout 100 --mib-per-gpu 64 2>&1 | tail -2 | cut -c1-300
