@@ -786,8 +786,13 @@ static void copy_in(u8 *dst, const u8 *src, size_t n, size_t n_devices)
         return;
     }
     const unsigned hw = std::thread::hardware_concurrency();
-    size_t nt = hw >= 8 ? 4 : (hw >= 4 ? 2 : 1);
-    if (n_devices > 1) nt = std::min<size_t>(nt * n_devices, std::max<size_t>(hw / 2, 1));
+    static const long per_dev = [] {
+        const char *s = getenv("BZ_ENC_COPY_THREADS"); // copy threads per device of the context
+        const long v = s ? atol(s) : 0;
+        return v > 0 && v <= 64 ? v : 0L;
+    }();
+    size_t nt = per_dev ? (size_t)per_dev : (hw >= 8 ? 4 : (hw >= 4 ? 2 : 1));
+    if (n_devices > 1 || per_dev) nt = std::min<size_t>(nt * n_devices, std::max<size_t>(hw / 2, 1));
     nt = std::min(nt, n / ((size_t)1 << 20));
     if (nt <= 1) {
         memcpy(dst, src, n);

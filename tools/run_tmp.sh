@@ -1,7 +1,1 @@
-timeout 1600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > /tmp/o.txt 2>&1; echo "parity rc=$? $(tail -1 /tmp/o.txt)"; grep -v "^tests\|^$\|^\.\|passed" /tmp/o.txt | head -40 | cut -c1-220
-for m in 1 0; do
-BZ_FUSED_ZLE=$m timeout 300 python bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline --hang-timeout 100 2>&1 | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('fused_zle=$m', d['value'], d['ms_per_step'], d['step_ms'], d['checks'], d['kernel_seconds_last_step_rank0'])"
-done
-BZ_FUSED_ZLE_FAILTEST=1 timeout 300 python bench.py --steps 1 --warmup 0 --no-extras --no-cpu-baseline --hang-timeout 100 --mib-per-gpu 64 2>&1 | tail -2 | cut -c1-300
+BZ_ENC_TRACE=1 timeout 300 python tools/e2e_multi.py 1024 0 2>&1 | grep "bz_enc" | tail -11
