@@ -17,6 +17,7 @@
 //   Z1-Z3  zero runs -> RUNA/RUNB digits (bijective base 2, LSB first), rank r>0 ->
 //       symbol r+1, EOB appended, symbol histogram (LDS atomics).
 #include "bzgpu.h"
+#include <cstdlib>
 
 namespace bzgpu {
 
@@ -154,6 +155,145 @@ __global__ __launch_bounds__(64) void k_mtf_compose(MtfArgs a)
         __syncthreads();
         st32[l] = reinterpret_cast<u32 *>(s_new)[l];
         __syncthreads();
+    }
+}
+
+// ---- M2 in three short steps instead of one chain of 1758 links per block ---------------------------------------
+// A chunk's report R acts on the list as  list -> R ++ (list \ R)  (its symbols, most recent first, move to the
+// front).  Two chunks in a row act as ONE report: R2 ++ (R1 \ R2) -- the same operation applied to the list R1.  So
+// the reports of a GROUP of 32 chunks are merged into running prefixes (32 links, all groups side by side, in place
+// over the reports), one wave per block takes the list through the 55 group totals (55 links), and every chunk's start
+// list is its group's start list under the prefix in front of the chunk (one link, all chunks side by side).
+// 1758 dependent links of four barriers each (1.48 ms per GiB) become 32 + 55 + 8.
+constexpr u32 kMtfGroup = 32;
+constexpr u32 kMtfGroups = (kMaxMtfChunks + kMtfGroup - 1) / kMtfGroup;
+
+// list (s_list[0..len), one wave, lane l holds entries 4l..4l+3) -> R ++ (list \ R); R = m bytes, lane l's four in w.
+// Returns the new length.  s_new / s_mark: 256 bytes each.  The caller's workgroup may hold several waves (each with
+// its own arrays) as long as all of them call this the same number of times.
+__device__ __forceinline__ u32 mtf_apply_report(u8 *s_list, u32 len, u32 m, u32 w, u8 *s_new, u8 *s_mark, u32 l)
+{
+    reinterpret_cast<u32 *>(s_mark)[l] = 0;
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) {
+        const u32 i = l * 4u + k;
+        if (i < m) {
+            const u8 v = (u8)(w >> (8u * k));
+            s_mark[v] = 1;
+            s_new[i] = v;
+        }
+    }
+    __syncthreads();
+    u32 keep[4], nk = 0;
+    u8 ev[4];
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) {
+        const u32 e = l * 4 + k;
+        ev[k] = s_list[e];
+        keep[k] = (e < len && !s_mark[ev[k]]) ? 1u : 0u;
+        nk += keep[k];
+    }
+    const u32 inc = wave_incl_sum(nk);
+    u32 pos = m + inc - nk;
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k)
+        if (keep[k]) s_new[pos++] = ev[k];
+    const u32 kept = __shfl(inc, 63, 64);
+    __syncthreads();
+    reinterpret_cast<u32 *>(s_list)[l] = reinterpret_cast<u32 *>(s_new)[l];
+    __syncthreads();
+    return m + kept;
+}
+
+// step 1: running merges of the reports inside every group (in place: summ[c] becomes the report of chunks g0..c)
+__global__ __launch_bounds__(64) void k_mtf_merge_groups(MtfArgs a)
+{
+    __shared__ u8 s_cur[256], s_new[256], s_mark[256];
+    const u32 lb = blockIdx.y, l = threadIdx.x;
+    const u32 n = a.blocks[lb].n;
+    const u32 nchunks = (n + kMtfChunk - 1) / kMtfChunk;
+    const u32 c0 = blockIdx.x * kMtfGroup;
+    if (c0 + 2u > nchunks) return; // (the last chunk's report is never applied)
+    const size_t rep0 = (size_t)lb * kMaxMtfChunks;
+    // (a list holds at most `alpha` bytes: only the lanes in front of that touch memory -- 36 bytes of a 256-byte
+    // slot for text)
+    const bool act = l * 4u < popc8(a.inuse_bits + lb * 8);
+    u32 len = a.summ_len[rep0 + c0];
+    reinterpret_cast<u32 *>(s_cur)[l] = act ? reinterpret_cast<const u32 *>(a.summ + (rep0 + c0) * 256u)[l] : 0u;
+    __syncthreads();
+    u32 c1 = c0 + kMtfGroup;
+    if (c1 > nchunks - 1u) c1 = nchunks - 1u;
+    u32 m_next = c0 + 1u < c1 ? (u32)a.summ_len[rep0 + c0 + 1u] : 0u;
+    u32 w_next = (c0 + 1u < c1 && act) ? reinterpret_cast<const u32 *>(a.summ + (rep0 + c0 + 1u) * 256u)[l] : 0u;
+    for (u32 c = c0 + 1u; c < c1; ++c) {
+        const u32 m = m_next, w = w_next;
+        if (c + 1u < c1) { // (the next report is on its way while this one is folded in)
+            m_next = a.summ_len[rep0 + c + 1u];
+            w_next = act ? reinterpret_cast<const u32 *>(a.summ + (rep0 + c + 1u) * 256u)[l] : 0u;
+        }
+        len = mtf_apply_report(s_cur, len, m, w, s_new, s_mark, l);
+        if (act) reinterpret_cast<u32 *>(a.summ + (rep0 + c) * 256u)[l] = reinterpret_cast<u32 *>(s_cur)[l];
+        if (l == 0) a.summ_len[rep0 + c] = (u16)len;
+    }
+}
+
+// step 2: the list at the start of every group (one wave per block, the group totals one after the other)
+__global__ __launch_bounds__(64) void k_mtf_group_starts(MtfArgs a)
+{
+    __shared__ u8 s_state[256], s_new[256], s_mark[256];
+    const u32 lb = blockIdx.x, l = threadIdx.x;
+    const u32 n = a.blocks[lb].n;
+    const u32 nchunks = (n + kMtfChunk - 1) / kMtfChunk;
+    const u32 *bits = a.inuse_bits + lb * 8;
+    { // identity list: in-use byte values ascending (as in k_mtf_compose)
+        u32 before = 0;
+        for (u32 q = 0; q < (l * 4u) / 32u; ++q) before += __popc(bits[q]);
+        const u32 wd = bits[(l * 4u) >> 5];
+        const u32 sh = (l * 4u) & 31u;
+        before += __popc(wd & ((1u << sh) - 1u));
+        reinterpret_cast<u32 *>(s_state)[l] = 0;
+        __syncthreads();
+        u32 pos = before;
+        for (u32 k = 0; k < 4; ++k)
+            if ((wd >> (sh + k)) & 1u) s_state[pos++] = (u8)(l * 4u + k);
+    }
+    __syncthreads();
+    const u32 alpha = popc8(bits);
+    const size_t rep0 = (size_t)lb * kMaxMtfChunks;
+    const bool act = l * 4u < alpha;
+    for (u32 c0 = 0; c0 < nchunks; c0 += kMtfGroup) {
+        if (act) reinterpret_cast<u32 *>(a.init_state + (rep0 + c0) * 256u)[l] = reinterpret_cast<u32 *>(s_state)[l];
+        if (c0 + 2u > nchunks) break;
+        u32 e = c0 + kMtfGroup - 1u; // the group's last report that is applied: its total
+        if (e > nchunks - 2u) e = nchunks - 2u;
+        const u32 m = a.summ_len[rep0 + e];
+        const u32 w = act ? reinterpret_cast<const u32 *>(a.summ + (rep0 + e) * 256u)[l] : 0u;
+        (void)mtf_apply_report(s_state, alpha, m, w, s_new, s_mark, l);
+    }
+}
+
+// step 3: the list every other chunk starts from = its group's start list under the merged reports in front of it
+__global__ __launch_bounds__(256) void k_mtf_chunk_starts(MtfArgs a)
+{
+    __shared__ u8 s_state[4][256], s_new[4][256], s_mark[4][256];
+    const u32 lb = blockIdx.y, l = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const u32 n = a.blocks[lb].n;
+    const u32 nchunks = (n + kMtfChunk - 1) / kMtfChunk;
+    const u32 c0 = blockIdx.x * kMtfGroup;
+    if (c0 + 1u >= nchunks) return;
+    const u32 alpha = popc8(a.inuse_bits + lb * 8);
+    const size_t rep0 = (size_t)lb * kMaxMtfChunks;
+    const bool act = l * 4u < alpha;
+    const u32 g32 = act ? reinterpret_cast<const u32 *>(a.init_state + (rep0 + c0) * 256u)[l] : 0u;
+    for (u32 k = 0; k < kMtfGroup / 4u; ++k) { // (uniform trip count: the barriers inside are the workgroup's)
+        const u32 c = c0 + 1u + k * 4u + wv;
+        const bool live = c < nchunks && c < c0 + kMtfGroup;
+        reinterpret_cast<u32 *>(s_state[wv])[l] = g32;
+        const u32 m = live ? (u32)a.summ_len[rep0 + c - 1u] : 0u;
+        const u32 w = (live && act) ? reinterpret_cast<const u32 *>(a.summ + (rep0 + c - 1u) * 256u)[l] : 0u;
+        (void)mtf_apply_report(s_state[wv], alpha, m, w, s_new[wv], s_mark[wv], l);
+        if (live && act) reinterpret_cast<u32 *>(a.init_state + (rep0 + c) * 256u)[l] = reinterpret_cast<u32 *>(s_state[wv])[l];
     }
 }
 
@@ -710,7 +850,14 @@ void launch_mtf(hipStream_t st, const MtfArgs &a)
 {
     (void)hipMemsetAsync(a.mtf_freq, 0, (size_t)a.nb * kMaxAlpha * sizeof(u32), st);
     hipLaunchKernelGGL(k_mtf_summaries, dim3(kChunkWGs, a.nb), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_mtf_compose, dim3(a.nb), dim3(64), 0, st, a);
+    static const bool serial_compose = getenv("BZ_MTF_COMPOSE_SERIAL") && atoi(getenv("BZ_MTF_COMPOSE_SERIAL")) != 0;
+    if (serial_compose) {
+        hipLaunchKernelGGL(k_mtf_compose, dim3(a.nb), dim3(64), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(k_mtf_merge_groups, dim3(kMtfGroups, a.nb), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_mtf_group_starts, dim3(a.nb), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_mtf_chunk_starts, dim3(kMtfGroups, a.nb), dim3(256), 0, st, a);
+    }
     hipLaunchKernelGGL(k_mtf_ranks_small, dim3(kChunkWGs, a.nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_mtf_ranks, dim3(kChunkWGs, a.nb), dim3(256), 0, st, a);
     if (a.fused_zle) {

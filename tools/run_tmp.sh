@@ -1,8 +1,4 @@
-for v in ds64 ds32; do
-for w in 256 512; do
-echo "--- $v walk_wgs $w"
-BZ_DEC_WALK_WGS=$w bash tools/variant_run.sh rust-compression_amd/build/var/$v.so timeout 200 python bench_decode.py --level 9 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+timeout 1600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > /tmp/o.txt 2>&1; echo "parity rc=$? $(tail -1 /tmp/o.txt)"; grep -v "^tests\|^$\|^\.\|passed" /tmp/o.txt | head -40 | cut -c1-220
+timeout 300 python bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline --hang-timeout 100 2>&1 | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d.get('stages_s'), (d.get('roofline') or {}).get('avg_launch_ms'), d.get('checks'))"
-done
-done
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['step_ms'], d['checks'], d['kernel_seconds_last_step_rank0'])"
