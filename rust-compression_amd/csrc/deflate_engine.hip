@@ -644,12 +644,15 @@ extern "C" int df_enc_end(df_enc *e, int action)
     if (e->total + add + 64 > e->d_data.cap) { // grow, keeping the stream so far
         DevBuf bigger;
         if ((rc = bigger.ensure((e->total + add) * 2 + 4096)) != BZ_OK) return rc;
-        if (e->total) HIPCHK(hipMemcpy(bigger.p, e->d_data.p, e->total, hipMemcpyDeviceToDevice));
+        if (e->total) { // (on the engine's stream and waited for: a device-to-device copy need not be over when it returns)
+            HIPCHK(hipMemcpyAsync(bigger.p, e->d_data.p, e->total, hipMemcpyDeviceToDevice, e->g->st));
+            HIPCHK(hipStreamSynchronize(e->g->st));
+        }
         e->d_data.release();
         e->d_data = bigger;
     }
     if (add) HIPCHK(hipMemcpy(e->d_data.as<u8>() + e->total, e->in.data(), add, hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(e->d_data.as<u8>() + e->total + add, 0, 64));
+    HIPCHK(hipMemsetAsync(e->d_data.as<u8>() + e->total + add, 0, 64, e->g->st)); // (ordered in front of the engine's kernels)
     e->total += add;
     e->in.clear();
     DfSeg seg;

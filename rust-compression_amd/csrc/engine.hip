@@ -87,7 +87,9 @@ static int ensure_workspace(bz_gpu_engine *g, size_t need_blocks)
     ENS(lin_sig, nb * 4);
     ENS(bin_cursor, nb * (size_t)1024 * 4);
     ENS(pb_gate, nb * (size_t)4 + 256); // (+ loc_stats behind the gates)
-    if (hipMemset(g->pb_gate.p, 0, g->pb_gate.cap) != hipSuccess) return BZ_E_UNEXPECTED;
+    // (cleared ON THE ENGINE'S STREAM: a memset on the null stream is not ordered against work on a non-blocking stream,
+    // and it need not be over when the call returns)
+    if (hipMemsetAsync(g->pb_gate.p, 0, g->pb_gate.cap, g->st) != hipSuccess) return BZ_E_UNEXPECTED;
     ENS(L, nb * (size_t)kSlot + 64);
     ENS(orig_ptr, nb * 4);
     ENS(inuse_bits, nb * 32);
@@ -118,7 +120,8 @@ static int ensure_workspace(bz_gpu_engine *g, size_t need_blocks)
         ENS(gbase, nb * (size_t)3 * kMaxBins * 4);
         ENS(tile_state, nb * (size_t)kTilesPerBlock * kMaxBins * 4);
         ENS(tickets, (size_t)kSortEpochs * 8 * 4 + 64);
-        if (hipMemset(g->tile_state.p, 0, g->tile_state.cap) != hipSuccess || hipMemset(g->tickets.p, 0, g->tickets.cap) != hipSuccess)
+        if (hipMemsetAsync(g->tile_state.p, 0, g->tile_state.cap, g->st) != hipSuccess ||
+            hipMemsetAsync(g->tickets.p, 0, g->tickets.cap, g->st) != hipSuccess)
             return BZ_E_UNEXPECTED;
         g->sort_epoch = 0;
     }
