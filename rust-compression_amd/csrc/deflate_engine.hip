@@ -194,11 +194,17 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
 
     HIPCHK(hipEventRecord(w->ev[0], st));
     HIPCHK(hipMemsetAsync(w->stream.p, 0, bound + 64, st));
+    // BZ_DF_MATCH=walk: the chain-walking match kernel of rounds 1 and 2 (k_df_prev + k_df_match) instead of the one
+    // that reads the candidates off the sorted order (k_df_match2); same match words either way
+    const char *mv = getenv("BZ_DF_MATCH");
+    const bool walk = mv && strcmp(mv, "walk") == 0;
     if (df_launch_chains(st, d_all, nall, w->vals_in.as<u32>(), w->vals_out.as<u32>(), w->est.as<u16>(), w->sort_tmp.as<u32>(), w->keys_out.as<u32>(),
-                         w->prevd.as<u32>()) != 0)
+                         walk ? w->prevd.as<u32>() : nullptr) != 0)
         return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[1], st));
-    if (df_launch_match(st, d_all, w->prevd.as<u32>(), nall, Mall) != 0) return BZ_E_UNEXPECTED;
+    if ((walk ? df_launch_match(st, d_all, w->prevd.as<u32>(), nall, Mall)
+              : df_launch_match2(st, d_all, nall, w->vals_out.as<u32>(), w->est.as<u16>(), Mall)) != 0)
+        return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[2], st));
     if (df_launch_parse(st, M, n, step, tabs.data(), ents.data(), counts.data(), nlevels, code, w->bitmap.as<u64>()) != 0) return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[3], st));

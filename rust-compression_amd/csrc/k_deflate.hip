@@ -444,6 +444,253 @@ __global__ __launch_bounds__(kMThreads) void k_df_match(const u8 *__restrict__ i
     }
 }
 
+// ---------------------------------------------------------------------------------- matches, from the sorted order
+// The same search (search_dic, lzss/slidedict.rs:218-266) without a walk.  In a chunk ordered by (hash, position)
+// the candidates of the entry at index i are the entries i-1, i-2, ... while the hash is the same, the distance
+// is within the window and k <= 255: the chain IS the run in front of the entry.  A lane takes one entry, a wave
+// 64 neighbouring ones (chains of about the same length without any ordering step), and in step k every lane
+// compares the first 16 bytes of its own text with those of entry i-k -- staged in LDS once per workgroup, read
+// back with one ds_read_b128 at consecutive addresses -- by four XORs, four find-first-bit and two three-way
+// minima: no chain links, no dependent loads, no byte tests.  What is kept is the first candidate of the
+// greatest length (deflate/encoder.rs:34-51: a farther candidate replaces the kept one only if it is strictly
+// longer).  Candidates that agree on all 16 bytes (1.2 % of the pairs on text) are queued per lane and measured in
+// batches against the text in global memory (the chunk's 544 KB sit in its XCD's L2), after the four-byte test
+// at the kept length that the walking kernel applies to every candidate; measuring late changes nothing (see
+// there), and a candidate that reaches the limit ends the lane's search (:258-259).
+constexpr u32 kM2Threads = DF_M2_THREADS; // entries per workgroup
+constexpr u32 kM2Span = kChunkStride / kM2Threads;
+constexpr u32 kM2Hist = 256;              // entries staged in front of them (255 are needed)
+static_assert(kChunkStride % kM2Threads == 0, "workgroups tile a sort chunk");
+
+__device__ __forceinline__ u32 ffbl_raw(u32 x) // index of the lowest set bit, 0xFFFFFFFF for 0
+{
+    u32 r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+typedef u32 df_u32u __attribute__((aligned(1)));
+typedef u64 df_u64u __attribute__((aligned(1)));
+typedef u32 df_u32x4 __attribute__((ext_vector_type(4)));
+typedef df_u32x4 __attribute__((aligned(1))) df_u32x4u;
+
+// eight text bytes at q; `avail` bytes exist there
+__device__ __forceinline__ u64 df_ld8(const u8 *__restrict__ in, u64 q, u64 avail)
+{
+    if (avail >= 8) return *reinterpret_cast<const df_u64u *>(in + q);
+    u64 v = 0;
+    for (u32 b = 0; b < 8 && b < avail; ++b) v |= (u64)in[q + b] << (8 * b);
+    return v;
+}
+
+// the first 16 text bytes at pos, zeros behind the end of the text
+__device__ __forceinline__ df_u32x4 df_snippet(const u8 *__restrict__ in, u32 pos, u64 n)
+{
+    if ((u64)pos + 16 <= n) return *reinterpret_cast<const df_u32x4u *>(in + pos);
+    u32 w[4] = {0, 0, 0, 0};
+    for (u32 b = 0; b < 16 && (u64)pos + b < n; ++b) w[b >> 2] |= (u32)in[pos + b] << (8 * (b & 3u));
+    df_u32x4 sn;
+    sn.x = w[0]; sn.y = w[1]; sn.z = w[2]; sn.w = w[3];
+    return sn;
+}
+
+// first differing bit of two 16-byte pieces, 128 if none
+__device__ __forceinline__ u32 df_diff16(df_u32x4 x, df_u32x4 y)
+{
+    const u32 f0 = ffbl_raw(x.x ^ y.x), f1 = ffbl_raw(x.y ^ y.y) | 32u, f2 = ffbl_raw(x.z ^ y.z) | 64u, f3 = ffbl_raw(x.w ^ y.w) | 96u;
+    u32 r = f0 < f1 ? f0 : f1;
+    r = r < f2 ? r : f2;
+    u32 r2 = f3 < 128u ? f3 : 128u;
+    return r < r2 ? r : r2;
+}
+
+__global__ __launch_bounds__(kM2Threads) void k_df_match2(const u8 *__restrict__ in, u64 n, u64 ntri, const u32 *__restrict__ S,
+                                                          const u16 *__restrict__ H, u32 *__restrict__ M)
+{
+    typedef df_u32x4 u32x4;
+    __shared__ u32x4 s_snip[kM2Hist + kM2Threads];
+    __shared__ u32 s_pos[kM2Hist + kM2Threads];
+    __shared__ u32 s_key[kM2Hist + kM2Threads];
+    // workgroups are dealt round-robin to the 8 XCDs (as in k_df_prev): one chunk's text, and the 2 MB of match
+    // words its entries scatter into, stay in one L2
+    u32 slice = blockIdx.x;
+    {
+        const u32 x = blockIdx.x & 7u, r = blockIdx.x >> 3;
+        const u32 cand = ((r / kM2Span) * 8 + x) * kM2Span + (r % kM2Span);
+        const u32 full = gridDim.x / (8 * kM2Span) * (8 * kM2Span);
+        if (blockIdx.x < full) slice = cand;
+    }
+    const u32 c = slice / kM2Span, i0 = (slice % kM2Span) * kM2Threads;
+    u32 j0;
+    const u32 count = df_chunk_count(c, ntri, j0);
+    if (i0 >= count) return;
+    const u32 *Sc = S + (size_t)c * kChunkStride;
+    const u16 *Hc = H + (size_t)c * kChunkStride;
+    const u32 tid = threadIdx.x;
+    // the workgroup's entries and the 256 in front of them: position, hash, the first 16 text bytes
+    for (u32 t = tid; t < kM2Hist + kM2Threads; t += kM2Threads) {
+        const i64 g = (i64)i0 - (i64)kM2Hist + (i64)t;
+        u32 pos = 0, key = 0xFFFFFFFFu;
+        u32x4 sn = {0, 0, 0, 0};
+        if (g >= 0 && (u64)g < count) {
+            pos = __builtin_nontemporal_load(Sc + g);
+            key = (u32)__builtin_nontemporal_load(Hc + g);
+            sn = df_snippet(in, pos, n);
+        }
+        s_pos[t] = pos;
+        s_key[t] = key;
+        s_snip[t] = sn;
+    }
+    __syncthreads();
+    const u32 li = kM2Hist + tid;
+    const u32 p = s_pos[li], h = s_key[li];
+    const u32x4 a = s_snip[li];
+    const bool own = i0 + tid < count && (u64)p >= (u64)c * kChunk; // a history entry is written by the chunk that owns it
+    // chain length: the entries in front with the same hash and within the window form one run (monotone in j)
+    u32 e = 0;
+    if (own && s_key[li - 1] == h && p - s_pos[li - 1] <= kWin) {
+        u32 lo = li - kChain, hi = li - 1;
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (s_key[mid] == h && s_pos[mid] + kWin >= p) hi = mid; else lo = mid + 1;
+        }
+        e = li - lo;
+    }
+    const u32 limit = (n - p) < (u64)kMaxMatch ? (u32)(n - p) : kMaxMatch; // search_dic :228
+    // A step gives r = first differing bit of the 16 bytes, at most `cap` (the limit where it lies inside them, else
+    // 128: "all 16 agree, the rest is to be measured").  What a lane keeps is the greatest key
+    //     (r | 7) << 24 | (255 - k) << 16
+    // -- the longest, and among equally long ones the nearest --; bit 31 of a step's key says "to be measured", and
+    // the last 32 of those bits wait in `qm` (one v_alignbit per step) until the wave measures them together.
+    u32 cap = limit < 16 ? limit * 8 : 128u;
+    asm volatile("" : "+v"(cap)); // (keeps the select out of the loop)
+    u32 best = ((2u * 8 + 7) << 24) | (255u << 16); // a match shorter than 3 is none (lzss/encoder.rs:135-141)
+    u32 qm = 0;
+    u32 mkey = 0;          // the longest measured candidate: length << 8 | 255 - k
+    // Measuring the candidates whose bits are set in qm (bit j belongs to step kcur - j): every lane offers its oldest
+    // one -- so that a later candidate only counts if it is strictly longer --, and the WAVE measures the offered
+    // candidates one after the other, four in flight: lane i compares the dwords at byte 16 + 4 i of the two texts
+    // (two coalesced 256-byte reads instead of 64 lanes reading 16 bytes each at unrelated places, trip after trip: a
+    // match to the limit costs the same two reads as one of 17 bytes), a ballot finds the first difference.  Text
+    // offsets fit 32 bits (a part is at most 1 GiB + history).
+    const u32 lane = tid & 63u;
+    auto measure = [&](u32 kcur) {
+        for (;;) {
+            bool has = qm != 0 && e != 0;
+            if (!has) qm = 0;
+            if (!__ballot(has)) break;
+            u32 k_item = 0, cp_item = 0;
+            if (has) {
+                const u32 j = 31u - (u32)__clz(qm);
+                qm &= ~(1u << j);
+                k_item = (kcur < e ? kcur : e) - j; // (a lane's bits stop moving when its chain ends)
+                cp_item = s_pos[li - k_item];
+                // to count, it must be longer than the longest one measured so far: the four bytes that end at that
+                // length have to agree (the walking kernel's test; one small read per lane instead of a measurement)
+                const u32 mlen = mkey >> 8;
+                if (mlen) has = *reinterpret_cast<const df_u32u *>(in + (cp_item + mlen - 3)) == *reinterpret_cast<const df_u32u *>(in + (p + mlen - 3));
+            }
+            u64 B = __ballot(has);
+            while (B) {
+                u32 sl[4], ps[4], cs[4], lim[4], xa[4], xb[4];
+                bool fast[4];
+#pragma unroll
+                for (u32 i = 0; i < 4; ++i) { // (fewer than four left: the last one is measured again, which changes nothing)
+                    sl[i] = (u32)__builtin_ctzll(B);
+                    if (B & (B - 1)) B &= B - 1; else if (i == 3) B = 0;
+                    ps[i] = (u32)__builtin_amdgcn_readlane((int)p, (int)sl[i]);
+                    cs[i] = (u32)__builtin_amdgcn_readlane((int)cp_item, (int)sl[i]);
+                    lim[i] = (u32)__builtin_amdgcn_readlane((int)limit, (int)sl[i]);
+                    fast[i] = (u64)ps[i] + 16 + 256 <= n;
+                    if (fast[i]) {
+                        xa[i] = *reinterpret_cast<const df_u32u *>(in + (ps[i] + 16) + 4 * lane);
+                        xb[i] = *reinterpret_cast<const df_u32u *>(in + (cs[i] + 16) + 4 * lane);
+                    } else { // the text ends within the 256 bytes: byte by byte, zeros behind the end on both sides
+                        xa[i] = xb[i] = 0;
+                        for (u32 b = 0; b < 4; ++b) {
+                            const u64 qa = (u64)ps[i] + 16 + 4 * lane + b, qb = (u64)cs[i] + 16 + 4 * lane + b;
+                            if (qa < n) { xa[i] |= (u32)in[qa] << (8 * b); xb[i] |= (u32)in[qb] << (8 * b); }
+                        }
+                    }
+                }
+#pragma unroll
+                for (u32 i = 0; i < 4; ++i) {
+                    const u32 x = xa[i] ^ xb[i];
+                    const u64 nz = __ballot(x != 0) & ((1ull << 61) - 1); // 61 dwords reach byte 260
+                    u32 l = 16 + 61 * 4;
+                    if (nz) {
+                        const u32 f = (u32)__builtin_ctzll(nz);
+                        const u32 xv = (u32)__builtin_amdgcn_readlane((int)x, (int)f);
+                        l = 16 + 4 * f + ((u32)__builtin_ctz(xv) >> 3);
+                    }
+                    l = l < lim[i] ? l : lim[i];
+                    if (lane == sl[i]) {
+                        if (l > (mkey >> 8)) mkey = (l << 8) | (255u - k_item);
+                        if (l == lim[i]) e = 0; // :258-259: nothing behind this candidate counts
+                    }
+                }
+            }
+        }
+    };
+    // One step, as the 17 vector instructions it takes (the compiler's rendering of the same C++ needs 21 and a
+    // branch): the lanes whose chain has ended drop out of EXEC (v_cmpx), four XORs, four find-first-bit, the word
+    // offsets, two three-way minima (the second one also applies the cap), the key, its top bit into qm, the maximum.
+#define DF_M2_STEP(D, J)                                                                                                      \
+    "s_add_u32 %[k], %[k0], " #J "\n"                                                                                         \
+    "s_sub_u32 %[kc], 0x7ff, %[k]\n"                                                                                          \
+    "s_lshl_b32 %[kc], %[kc], 16\n"                                                                                           \
+    "v_cmpx_le_u32_e32 vcc, %[k], %[e]\n"                                                                                     \
+    "v_xor_b32_e32 %[t0], %[a0], %[" #D "0]\n"                                                                                \
+    "v_xor_b32_e32 %[t1], %[a1], %[" #D "1]\n"                                                                                \
+    "v_xor_b32_e32 %[t2], %[a2], %[" #D "2]\n"                                                                                \
+    "v_xor_b32_e32 %[t3], %[a3], %[" #D "3]\n"                                                                                \
+    "v_ffbl_b32_e32 %[t0], %[t0]\n"                                                                                           \
+    "v_ffbl_b32_e32 %[t1], %[t1]\n"                                                                                           \
+    "v_ffbl_b32_e32 %[t2], %[t2]\n"                                                                                           \
+    "v_ffbl_b32_e32 %[t3], %[t3]\n"                                                                                           \
+    "v_or_b32_e32 %[t1], 32, %[t1]\n"                                                                                         \
+    "v_or_b32_e32 %[t2], 64, %[t2]\n"                                                                                         \
+    "v_or_b32_e32 %[t3], 0x60, %[t3]\n"                                                                                       \
+    "v_min3_u32 %[t0], %[t0], %[t1], %[t2]\n"                                                                                 \
+    "v_min3_u32 %[t0], %[t0], %[t3], %[cap]\n"                                                                                \
+    "v_lshl_or_b32 %[t0], %[t0], 24, %[kc]\n"                                                                                 \
+    "v_alignbit_b32 %[qm], %[qm], %[t0], 31\n"                                                                                \
+    "v_max_u32_e32 %[best], %[best], %[t0]\n"
+#define DF_M2_PAIR(CA, CB, JA, JB)                                                                                            \
+    asm volatile("s_mov_b64 %[sv], exec\n" DF_M2_STEP(da, JA) DF_M2_STEP(db, JB) "s_mov_b64 exec, %[sv]\n"                    \
+                 : [best] "+v"(best), [qm] "+v"(qm), [k] "=&s"(ks), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),           \
+                   [t3] "=&v"(t3), [sv] "=&s"(sv), [kc] "=&s"(kc)                                                             \
+                 : [k0] "s"(k0u), [a0] "v"(a.x), [a1] "v"(a.y), [a2] "v"(a.z), [a3] "v"(a.w), [e] "v"(e), [cap] "v"(cap),     \
+                   [da0] "v"(CA.x), [da1] "v"(CA.y), [da2] "v"(CA.z), [da3] "v"(CA.w), [db0] "v"(CB.x), [db1] "v"(CB.y),      \
+                   [db2] "v"(CB.z), [db3] "v"(CB.w)                                                                           \
+                 : "vcc", "scc")
+    u32 ro = li;
+    u32 k0 = 0;
+    while (__ballot(k0 < e)) { // steps k0 + 1 .. k0 + 8: eight reads in flight, then the steps
+        ro -= 8;
+        asm volatile("" : "+v"(ro)); // (so that the reads below take immediate offsets)
+        u32 t0, t1, t2, t3, kc, ks;
+        u64 sv;
+        const u32 k0u = (u32)__builtin_amdgcn_readfirstlane((int)k0);
+        const u32x4 c1 = s_snip[ro + 7], c2 = s_snip[ro + 6], c3 = s_snip[ro + 5], c4 = s_snip[ro + 4], c5 = s_snip[ro + 3],
+                    c6 = s_snip[ro + 2], c7 = s_snip[ro + 1], c8 = s_snip[ro];
+        DF_M2_PAIR(c1, c2, 1, 2);
+        DF_M2_PAIR(c3, c4, 3, 4);
+        DF_M2_PAIR(c5, c6, 5, 6);
+        DF_M2_PAIR(c7, c8, 7, 8);
+        k0 += 8;
+        if ((k0 & 31u) == 0 && __ballot(qm != 0)) measure(k0);
+    }
+#undef DF_M2_PAIR
+#undef DF_M2_STEP
+    if (__ballot(qm != 0)) measure(k0);
+    if (own) {
+        u32 best_len = best >> 27, best_k = 255u - ((best >> 16) & 0xFFu);
+        if (mkey) { best_len = mkey >> 8; best_k = 255u - (mkey & 0xFFu); }
+        M[p] = best_len >= kMinMatch ? (best_len | ((p - s_pos[li - best_k] - 1) << 9)) : 0u;
+    }
+}
+
 // ---------------------------------------------------------------------------------- parse
 // lzss/encoder.rs:132-184: step[p] = advance | lazy_index << 9 if a code sequence started at p
 __device__ __forceinline__ u32 df_step_word(u32 m0, u32 m1, u32 m2)
@@ -1274,7 +1521,7 @@ int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *v0, u32 *s, u16 *
 {
     const u64 ntri = n >= 3 ? n - 2 : 0;
     // every trigram position is written by the chunk that owns it; the last two positions have no trigram
-    DFCHK(hipMemsetAsync(pe + ntri, 0, (n - ntri + 8) * sizeof(u32), st));
+    if (pe) DFCHK(hipMemsetAsync(pe + ntri, 0, (n - ntri + 8) * sizeof(u32), st));
     if (!ntri) return 0;
     const u32 nchunks = df_chunks(n);
     const dim3 tiles(nchunks * kChunkTiles);
@@ -1286,7 +1533,18 @@ int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *v0, u32 *s, u16 *
     hipLaunchKernelGGL((k_df_shist<1>), tiles, dim3(kSortThreads), 0, st, in, ntri, v0, hist);
     hipLaunchKernelGGL(k_df_sscan, dim3(nchunks), dim3(256), 0, st, hist, tbase1);
     hipLaunchKernelGGL((k_df_sscatter<1>), tiles, dim3(kSortThreads), 0, st, in, ntri, v0, hist, tbase1, s, tbase, hs);
-    hipLaunchKernelGGL(k_df_prev, dim3(nchunks * kPrevSpan), dim3(256), 0, st, ntri, s, hs, pe);
+    if (pe) hipLaunchKernelGGL(k_df_prev, dim3(nchunks * kPrevSpan), dim3(256), 0, st, ntri, s, hs, pe);
+    return 0;
+}
+
+// matches straight from the sorted chunks (s, hs of df_launch_chains with pe == nullptr)
+int df_launch_match2(hipStream_t st, const u8 *in, u64 n, const u32 *s, const u16 *hs, u32 *M)
+{
+    if (!n) return 0;
+    const u64 ntri = n >= 3 ? n - 2 : 0;
+    DFCHK(hipMemsetAsync(M + ntri, 0, (n - ntri + 8) * sizeof(u32), st)); // the last two positions have no trigram
+    if (!ntri) return 0;
+    hipLaunchKernelGGL(k_df_match2, dim3(df_chunks(n) * kM2Span), dim3(kM2Threads), 0, st, in, n, ntri, s, hs, M);
     return 0;
 }
 

@@ -194,6 +194,59 @@ def test_sort_chunk_boundaries(pkg, oracle, eng, n):
     check(pkg, oracle, eng, d)
 
 
+def _hash16(t):
+    return ((((t[0] << 16) | (t[1] << 8) | t[2]) * 0x7A7C4F9F7A7C4F9F) & 0xFFFFFFFFFFFFFFFF) >> 48
+
+
+def _match_cases():
+    rnd = random.Random(77)
+    # repeats of every length around the 16 bytes a step of k_df_match2 compares and around the 258-byte limit,
+    # each one behind a different filler so that the candidates of one trigram differ in length
+    para = bytes(rnd.choice(b"abcdefghijklmnopqrstuvwxyz ") for _ in range(600))
+    parts = []
+    for ln in list(range(3, 36)) + [63, 64, 65, 255, 256, 257, 258, 259, 260, 300, 520]:
+        parts.append(para[:ln] + bytes([rnd.randrange(128, 256)]) * rnd.randint(1, 5))
+    rnd.shuffle(parts)
+    yield "lengths", b"".join(parts) * 3
+    # the same, ending inside a repeat: limits below 16, between 16 and 272, and a match that runs to the last byte
+    body = b"".join(parts)
+    for cut in (1, 2, 3, 5, 15, 16, 17, 31, 100, 271, 272, 273):
+        yield "tail%d" % cut, body + para[:300] + b"#" + para[:cut]
+    # more than 255 candidates, the long ones beyond the first 255 (they must not be found) and just inside
+    short = b"".join(b"xyz" + bytes([65 + (i % 23), 97 + (i % 19)]) for i in range(400))
+    yield "chain255", b"xyz0123456789ABCDEFGHIJ" + short[:5 * 254] + b"xyz0123456789ABCDEFGHIJ" + short + b"xyz0123456789ABCDEFGHIJ"
+    # equally long candidates: the nearest one wins
+    yield "ties", (b"hello world, this is it:" + b"A") + (b"hello world, this is it:" + b"B") * 5 + b"hello world, this is it:C" * 2
+    # two trigrams with the same 16-bit hash share a chain
+    seen = {}
+    pair = None
+    for t in range(1 << 24):
+        tri = (t * 2654435761) & 0xFFFFFF
+        b3 = bytes([tri >> 16, (tri >> 8) & 255, tri & 255])
+        hh = _hash16(b3)
+        if hh in seen and seen[hh] != b3:
+            pair = (seen[hh], b3)
+            break
+        seen[hh] = b3
+    assert pair is not None
+    x, y = pair
+    yield "collide", (x + b"0123456789abcdefgh" + y + b"0123456789abcdefgh") * 40 + x + b"0123456789abcdefXY" + y + b"0123"
+    # a paragraph repeated (every candidate agrees to the limit) and four symbols at random (full chains, short matches)
+    yield "deep", para[:400] * 200
+    yield "dna", bytes(rnd.choice(b"ACGT") for _ in range(90000))
+
+
+@pytest.mark.parametrize("name,data", list(_match_cases()), ids=[n for n, _ in _match_cases()])
+def test_match_kernels_on_long_and_tied_candidates(pkg, oracle, eng, name, data, monkeypatch):
+    """Both match kernels -- candidates read off the sorted order (k_df_match2, the default) and the chain walk of
+    rounds 1 and 2 (BZ_DF_MATCH=walk) -- give the oracle's LZSS codes on inputs made for the places where they differ:
+    candidates that agree on exactly 15, 16, 17 ... bytes, matches cut by the end of the text, chains of more than
+    255, ties, hash collisions."""
+    check(pkg, oracle, eng, data)
+    monkeypatch.setenv("BZ_DF_MATCH", "walk")
+    check(pkg, oracle, eng, data)
+
+
 def test_empty_inputs_in_containers(pkg, oracle):
     for kind, okind in ((pkg.DEFLATE, oracle.DEFLATE), (pkg.ZLIB, oracle.ZLIB), (pkg.GZIP, oracle.GZIP)):
         assert pkg.deflate_compress(b"", kind) == oracle.deflate_encode(b"", okind)

@@ -1,5 +1,8 @@
-fails=0
-for i in $(seq 1 25); do
-  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "test_multi_device_context" > /tmp/o.txt 2>&1 || { fails=$((fails+1)); echo "--- failure in iteration $i"; grep -E "AssertionError: \(|bz2_mi355x|fault" /tmp/o.txt | head -4 | cut -c1-200; }
-done
-echo "multi-device: $fails failures of 25"
+#!/bin/bash
+cd /root/repo
+mkdir -p gpurun_out/m2
+timeout 1200 python -m pytest tests/test_gpu_deflate.py -x -q 2>&1 | tail -8 > gpurun_out/m2/tests.txt
+timeout 300 python tools/df_time.py 1024 2>&1 | grep hash_chains > gpurun_out/m2/time.txt
+timeout 300 python tools/df_t2.py 2>&1 | tail -2 >> gpurun_out/m2/time.txt
+timeout 300 python tools/df_dna.py 2>&1 | tail -2 >> gpurun_out/m2/time.txt
+cat gpurun_out/m2/tests.txt gpurun_out/m2/time.txt
