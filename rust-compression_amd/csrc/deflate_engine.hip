@@ -203,7 +203,7 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
         return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[1], st));
     if ((walk ? df_launch_match(st, d_all, w->prevd.as<u32>(), nall, Mall)
-              : df_launch_match2(st, d_all, nall, w->vals_out.as<u32>(), w->est.as<u16>(), Mall)) != 0)
+              : df_launch_match2(st, d_all, nall, w->vals_out.as<u32>(), Mall)) != 0)
         return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[2], st));
     if (df_launch_parse(st, M, n, step, tabs.data(), ents.data(), counts.data(), nlevels, code, w->bitmap.as<u64>()) != 0) return BZ_E_UNEXPECTED;

@@ -59,7 +59,7 @@ struct DfBlock {
 u32 df_chunks(u64 n); // sort chunks of an input of n bytes
 int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *v0, u32 *s, u16 *hs, u32 *hist, u32 *tbase, u32 *pe);
 int df_launch_match(hipStream_t st, const u8 *in, const u32 *pe, u64 n, u32 *M);
-int df_launch_match2(hipStream_t st, const u8 *in, u64 n, const u32 *s, const u16 *hs, u32 *M);
+int df_launch_match2(hipStream_t st, const u8 *in, u64 n, const u32 *s, u32 *M);
 int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *tabs, u16 *const *ents, const u32 *counts,
                     u32 nlevels, u32 *code, u64 *bm);
 // dl0: decompress_len carried into the segment (0 unless it follows an Action::Flush); last_is_final: the

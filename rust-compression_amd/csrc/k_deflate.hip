@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kSortThreads) void k_df_sscatter(const u8 *__restri
             const u32 lpos = (u32)s_tpre[dgv[r]] + (u32)my_cnt[dgv[r]] + rnk[r];
             s_buf[lpos] = posv[r]; // digit order inside the tile, so that consecutive lanes store consecutive words
             s_dg[lpos] = (u8)dgv[r];
-            if (PASS) {
+            if (PASS && hash_out) {
                 // the input of pass 1 is ordered by the low byte: the bucket an input index falls into IS that byte
                 const u32 idx = start + w * 1024u + r * 64u + l;
                 u32 lo = 0;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(kSortThreads) void k_df_sscatter(const u8 *__restri
             const u32 dg = s_dg[i];
             const u32 o = s_base[dg] + (i - (u32)s_tpre[dg]);
             out[o] = s_buf[i];
-            if (PASS) hash_out[(size_t)c * kChunkStride + o] = (u16)((dg << 8) | s_lo[i]);
+            if (PASS && hash_out) hash_out[(size_t)c * kChunkStride + o] = (u16)((dg << 8) | s_lo[i]);
         }
     }
 }
@@ -505,7 +505,7 @@ __device__ __forceinline__ u32 df_diff16(df_u32x4 x, df_u32x4 y)
 }
 
 __global__ __launch_bounds__(kM2Threads) void k_df_match2(const u8 *__restrict__ in, u64 n, u64 ntri, const u32 *__restrict__ S,
-                                                          const u16 *__restrict__ H, u32 *__restrict__ M)
+                                                          u32 *__restrict__ M)
 {
     typedef df_u32x4 u32x4;
     __shared__ u32x4 s_snip[kM2Hist + kM2Threads];
@@ -525,7 +525,6 @@ __global__ __launch_bounds__(kM2Threads) void k_df_match2(const u8 *__restrict__
     const u32 count = df_chunk_count(c, ntri, j0);
     if (i0 >= count) return;
     const u32 *Sc = S + (size_t)c * kChunkStride;
-    const u16 *Hc = H + (size_t)c * kChunkStride;
     const u32 tid = threadIdx.x;
     // the workgroup's entries and the 256 in front of them: position, hash, the first 16 text bytes
     for (u32 t = tid; t < kM2Hist + kM2Threads; t += kM2Threads) {
@@ -534,8 +533,8 @@ __global__ __launch_bounds__(kM2Threads) void k_df_match2(const u8 *__restrict__
         u32x4 sn = {0, 0, 0, 0};
         if (g >= 0 && (u64)g < count) {
             pos = __builtin_nontemporal_load(Sc + g);
-            key = (u32)__builtin_nontemporal_load(Hc + g);
             sn = df_snippet(in, pos, n);
+            key = hash16(sn.x & 0xFFu, (sn.x >> 8) & 0xFFu, (sn.x >> 16) & 0xFFu); // (every entry has its three bytes)
         }
         s_pos[t] = pos;
         s_key[t] = key;
@@ -556,6 +555,10 @@ __global__ __launch_bounds__(kM2Threads) void k_df_match2(const u8 *__restrict__
         }
         e = li - lo;
     }
+    // Where the chain ends because the entries in front have another hash, running on does no harm (another hash is
+    // another trigram: fewer than three bytes agree, which never beats "no match"); only a chain cut by the window, by
+    // the 255 candidates or by the start of the chunk's entries has to be masked.  em: the step a lane is masked from.
+    const u32 em = (own && !(s_key[li - e - 1] != 0xFFFFFFFFu && s_key[li - e - 1] != h)) ? e : 0xFFFFFFFFu;
     const u32 limit = (n - p) < (u64)kMaxMatch ? (u32)(n - p) : kMaxMatch; // search_dic :228
     // A step gives r = first differing bit of the 16 bytes, at most `cap` (the limit where it lies inside them, else
     // 128: "all 16 agree, the rest is to be measured").  What a lane keeps is the greatest key
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(kM2Threads) void k_df_match2(const u8 *__restrict__
             if (has) {
                 const u32 j = 31u - (u32)__clz(qm);
                 qm &= ~(1u << j);
-                k_item = (kcur < e ? kcur : e) - j; // (a lane's bits stop moving when its chain ends)
+                k_item = (kcur < em ? kcur : em) - j; // (a masked lane's bits stop moving when its chain ends)
                 cp_item = s_pos[li - k_item];
                 // to count, it must be longer than the longest one measured so far: the four bytes that end at that
                 // length have to agree (the walking kernel's test; one small read per lane instead of a measurement)
@@ -632,14 +635,14 @@ __global__ __launch_bounds__(kM2Threads) void k_df_match2(const u8 *__restrict__
             }
         }
     };
-    // One step, as the 17 vector instructions it takes (the compiler's rendering of the same C++ needs 21 and a
-    // branch): the lanes whose chain has ended drop out of EXEC (v_cmpx), four XORs, four find-first-bit, the word
+    // One step, as the 16 or 17 vector instructions it takes (the compiler's rendering of the same C++ needs 21 and a
+    // branch): where a chain is cut, its lane drops out of EXEC (v_cmpx); four XORs, four find-first-bit, the word
     // offsets, two three-way minima (the second one also applies the cap), the key, its top bit into qm, the maximum.
-#define DF_M2_STEP(D, J)                                                                                                      \
+#define DF_M2_STEP(D, J, CMPX)                                                                                                \
     "s_add_u32 %[k], %[k0], " #J "\n"                                                                                         \
     "s_sub_u32 %[kc], 0x7ff, %[k]\n"                                                                                          \
     "s_lshl_b32 %[kc], %[kc], 16\n"                                                                                           \
-    "v_cmpx_le_u32_e32 vcc, %[k], %[e]\n"                                                                                     \
+    CMPX                                                                                                                      \
     "v_xor_b32_e32 %[t0], %[a0], %[" #D "0]\n"                                                                                \
     "v_xor_b32_e32 %[t1], %[a1], %[" #D "1]\n"                                                                                \
     "v_xor_b32_e32 %[t2], %[a2], %[" #D "2]\n"                                                                                \
@@ -656,11 +659,12 @@ __global__ __launch_bounds__(kM2Threads) void k_df_match2(const u8 *__restrict__
     "v_lshl_or_b32 %[t0], %[t0], 24, %[kc]\n"                                                                                 \
     "v_alignbit_b32 %[qm], %[qm], %[t0], 31\n"                                                                                \
     "v_max_u32_e32 %[best], %[best], %[t0]\n"
-#define DF_M2_PAIR(CA, CB, JA, JB)                                                                                            \
-    asm volatile("s_mov_b64 %[sv], exec\n" DF_M2_STEP(da, JA) DF_M2_STEP(db, JB) "s_mov_b64 exec, %[sv]\n"                    \
+#define DF_M2_CMPX "v_cmpx_le_u32_e32 vcc, %[k], %[e]\n"
+#define DF_M2_PAIR(CA, CB, JA, JB, PRE, CMPX, POST)                                                                           \
+    asm volatile(PRE DF_M2_STEP(da, JA, CMPX) DF_M2_STEP(db, JB, CMPX) POST                                                   \
                  : [best] "+v"(best), [qm] "+v"(qm), [k] "=&s"(ks), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),           \
                    [t3] "=&v"(t3), [sv] "=&s"(sv), [kc] "=&s"(kc)                                                             \
-                 : [k0] "s"(k0u), [a0] "v"(a.x), [a1] "v"(a.y), [a2] "v"(a.z), [a3] "v"(a.w), [e] "v"(e), [cap] "v"(cap),     \
+                 : [k0] "s"(k0u), [a0] "v"(a.x), [a1] "v"(a.y), [a2] "v"(a.z), [a3] "v"(a.w), [e] "v"(em), [cap] "v"(cap),    \
                    [da0] "v"(CA.x), [da1] "v"(CA.y), [da2] "v"(CA.z), [da3] "v"(CA.w), [db0] "v"(CB.x), [db1] "v"(CB.y),      \
                    [db2] "v"(CB.z), [db3] "v"(CB.w)                                                                           \
                  : "vcc", "scc")
@@ -674,14 +678,22 @@ __global__ __launch_bounds__(kM2Threads) void k_df_match2(const u8 *__restrict__
         const u32 k0u = (u32)__builtin_amdgcn_readfirstlane((int)k0);
         const u32x4 c1 = s_snip[ro + 7], c2 = s_snip[ro + 6], c3 = s_snip[ro + 5], c4 = s_snip[ro + 4], c5 = s_snip[ro + 3],
                     c6 = s_snip[ro + 2], c7 = s_snip[ro + 1], c8 = s_snip[ro];
-        DF_M2_PAIR(c1, c2, 1, 2);
-        DF_M2_PAIR(c3, c4, 3, 4);
-        DF_M2_PAIR(c5, c6, 5, 6);
-        DF_M2_PAIR(c7, c8, 7, 8);
+        if (__ballot(em < k0 + 8)) { // some lane's chain is cut inside these eight steps
+            DF_M2_PAIR(c1, c2, 1, 2, "s_mov_b64 %[sv], exec\n", DF_M2_CMPX, "s_mov_b64 exec, %[sv]\n");
+            DF_M2_PAIR(c3, c4, 3, 4, "s_mov_b64 %[sv], exec\n", DF_M2_CMPX, "s_mov_b64 exec, %[sv]\n");
+            DF_M2_PAIR(c5, c6, 5, 6, "s_mov_b64 %[sv], exec\n", DF_M2_CMPX, "s_mov_b64 exec, %[sv]\n");
+            DF_M2_PAIR(c7, c8, 7, 8, "s_mov_b64 %[sv], exec\n", DF_M2_CMPX, "s_mov_b64 exec, %[sv]\n");
+        } else {
+            DF_M2_PAIR(c1, c2, 1, 2, "", "", "");
+            DF_M2_PAIR(c3, c4, 3, 4, "", "", "");
+            DF_M2_PAIR(c5, c6, 5, 6, "", "", "");
+            DF_M2_PAIR(c7, c8, 7, 8, "", "", "");
+        }
         k0 += 8;
         if ((k0 & 31u) == 0 && __ballot(qm != 0)) measure(k0);
     }
 #undef DF_M2_PAIR
+#undef DF_M2_CMPX
 #undef DF_M2_STEP
     if (__ballot(qm != 0)) measure(k0);
     if (own) {
@@ -1532,19 +1544,20 @@ int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *v0, u32 *s, u16 *
                        (const u32 *)nullptr, (u16 *)nullptr);
     hipLaunchKernelGGL((k_df_shist<1>), tiles, dim3(kSortThreads), 0, st, in, ntri, v0, hist);
     hipLaunchKernelGGL(k_df_sscan, dim3(nchunks), dim3(256), 0, st, hist, tbase1);
-    hipLaunchKernelGGL((k_df_sscatter<1>), tiles, dim3(kSortThreads), 0, st, in, ntri, v0, hist, tbase1, s, tbase, hs);
+    // (the hashes of the sorted positions are only kept for k_df_prev: k_df_match2 has the trigrams in hand)
+    hipLaunchKernelGGL((k_df_sscatter<1>), tiles, dim3(kSortThreads), 0, st, in, ntri, v0, hist, tbase1, s, tbase, pe ? hs : (u16 *)nullptr);
     if (pe) hipLaunchKernelGGL(k_df_prev, dim3(nchunks * kPrevSpan), dim3(256), 0, st, ntri, s, hs, pe);
     return 0;
 }
 
-// matches straight from the sorted chunks (s, hs of df_launch_chains with pe == nullptr)
-int df_launch_match2(hipStream_t st, const u8 *in, u64 n, const u32 *s, const u16 *hs, u32 *M)
+// matches straight from the sorted chunks (s of df_launch_chains with pe == nullptr)
+int df_launch_match2(hipStream_t st, const u8 *in, u64 n, const u32 *s, u32 *M)
 {
     if (!n) return 0;
     const u64 ntri = n >= 3 ? n - 2 : 0;
     DFCHK(hipMemsetAsync(M + ntri, 0, (n - ntri + 8) * sizeof(u32), st)); // the last two positions have no trigram
     if (!ntri) return 0;
-    hipLaunchKernelGGL(k_df_match2, dim3(df_chunks(n) * kM2Span), dim3(kM2Threads), 0, st, in, n, ntri, s, hs, M);
+    hipLaunchKernelGGL(k_df_match2, dim3(df_chunks(n) * kM2Span), dim3(kM2Threads), 0, st, in, n, ntri, s, M);
     return 0;
 }
 
