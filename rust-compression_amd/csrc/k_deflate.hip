@@ -594,42 +594,46 @@ __global__ __launch_bounds__(kM2Threads) void k_df_match2(const u8 *__restrict__
                 if (mlen) has = *reinterpret_cast<const df_u32u *>(in + (cp_item + mlen - 3)) == *reinterpret_cast<const df_u32u *>(in + (p + mlen - 3));
             }
             u64 B = __ballot(has);
-            while (B) {
+            while (B) { // up to four of them in flight
                 u32 sl[4], ps[4], cs[4], lim[4], xa[4], xb[4];
-                bool fast[4];
+                bool use[4];
 #pragma unroll
-                for (u32 i = 0; i < 4; ++i) { // (fewer than four left: the last one is measured again, which changes nothing)
-                    sl[i] = (u32)__builtin_ctzll(B);
-                    if (B & (B - 1)) B &= B - 1; else if (i == 3) B = 0;
-                    ps[i] = (u32)__builtin_amdgcn_readlane((int)p, (int)sl[i]);
-                    cs[i] = (u32)__builtin_amdgcn_readlane((int)cp_item, (int)sl[i]);
-                    lim[i] = (u32)__builtin_amdgcn_readlane((int)limit, (int)sl[i]);
-                    fast[i] = (u64)ps[i] + 16 + 256 <= n;
-                    if (fast[i]) {
-                        xa[i] = *reinterpret_cast<const df_u32u *>(in + (ps[i] + 16) + 4 * lane);
-                        xb[i] = *reinterpret_cast<const df_u32u *>(in + (cs[i] + 16) + 4 * lane);
-                    } else { // the text ends within the 256 bytes: byte by byte, zeros behind the end on both sides
-                        xa[i] = xb[i] = 0;
-                        for (u32 b = 0; b < 4; ++b) {
-                            const u64 qa = (u64)ps[i] + 16 + 4 * lane + b, qb = (u64)cs[i] + 16 + 4 * lane + b;
-                            if (qa < n) { xa[i] |= (u32)in[qa] << (8 * b); xb[i] |= (u32)in[qb] << (8 * b); }
+                for (u32 i = 0; i < 4; ++i) {
+                    use[i] = B != 0;
+                    if (use[i]) {
+                        sl[i] = (u32)__builtin_ctzll(B);
+                        B &= B - 1;
+                        ps[i] = (u32)__builtin_amdgcn_readlane((int)p, (int)sl[i]);
+                        cs[i] = (u32)__builtin_amdgcn_readlane((int)cp_item, (int)sl[i]);
+                        lim[i] = (u32)__builtin_amdgcn_readlane((int)limit, (int)sl[i]);
+                        if ((u64)ps[i] + 16 + 256 <= n) {
+                            xa[i] = *reinterpret_cast<const df_u32u *>(in + (ps[i] + 16) + 4 * lane);
+                            xb[i] = *reinterpret_cast<const df_u32u *>(in + (cs[i] + 16) + 4 * lane);
+                        } else { // the text ends within the 256 bytes: byte by byte, zeros behind the end on both sides
+                            xa[i] = xb[i] = 0;
+                            for (u32 b = 0; b < 4; ++b) {
+                                const u64 qa = (u64)ps[i] + 16 + 4 * lane + b, qb = (u64)cs[i] + 16 + 4 * lane + b;
+                                if (qa < n) { xa[i] |= (u32)in[qa] << (8 * b); xb[i] |= (u32)in[qb] << (8 * b); }
+                            }
                         }
                     }
                 }
 #pragma unroll
                 for (u32 i = 0; i < 4; ++i) {
-                    const u32 x = xa[i] ^ xb[i];
-                    const u64 nz = __ballot(x != 0) & ((1ull << 61) - 1); // 61 dwords reach byte 260
-                    u32 l = 16 + 61 * 4;
-                    if (nz) {
-                        const u32 f = (u32)__builtin_ctzll(nz);
-                        const u32 xv = (u32)__builtin_amdgcn_readlane((int)x, (int)f);
-                        l = 16 + 4 * f + ((u32)__builtin_ctz(xv) >> 3);
-                    }
-                    l = l < lim[i] ? l : lim[i];
-                    if (lane == sl[i]) {
-                        if (l > (mkey >> 8)) mkey = (l << 8) | (255u - k_item);
-                        if (l == lim[i]) e = 0; // :258-259: nothing behind this candidate counts
+                    if (use[i]) {
+                        const u32 x = xa[i] ^ xb[i];
+                        const u64 nz = __ballot(x != 0) & ((1ull << 61) - 1); // 61 dwords reach byte 260
+                        u32 l = 16 + 61 * 4;
+                        if (nz) {
+                            const u32 f = (u32)__builtin_ctzll(nz);
+                            const u32 xv = (u32)__builtin_amdgcn_readlane((int)x, (int)f);
+                            l = 16 + 4 * f + ((u32)__builtin_ctz(xv) >> 3);
+                        }
+                        l = l < lim[i] ? l : lim[i];
+                        if (lane == sl[i]) {
+                            if (l > (mkey >> 8)) mkey = (l << 8) | (255u - k_item);
+                            if (l == lim[i]) e = 0; // :258-259: nothing behind this candidate counts
+                        }
                     }
                 }
             }
