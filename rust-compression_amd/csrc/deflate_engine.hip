@@ -148,8 +148,14 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     if ((rc = w->vals_out.ensure((nsort > npad ? nsort : npad) * 4)) != BZ_OK) return rc; // sorted positions, later code[]
     if ((rc = w->sort_tmp.ensure((nchunks * kChunkTiles + 1) * 256 * 4)) != BZ_OK) return rc; // per-tile digit counts
     if ((rc = w->keys_out.ensure(2 * (nchunks + 1) * 256 * 4)) != BZ_OK) return rc;       // per-chunk digit bases, both passes
-    if ((rc = w->est.ensure(nsort * 2)) != BZ_OK) return rc;                              // hashes of the sorted positions
-    if ((rc = w->prevd.ensure(npad * 4)) != BZ_OK) return rc; // per position: chain distance | chain length << 16
+    // BZ_DF_MATCH=walk: the chain-walking match kernel of rounds 1 and 2 (k_df_prev + k_df_match) instead of the one
+    // that reads the candidates off the sorted order (k_df_match2); same match words either way
+    const char *mv = getenv("BZ_DF_MATCH");
+    const bool walk = mv && strcmp(mv, "walk") == 0;
+    if (walk) {
+        if ((rc = w->est.ensure(nsort * 2)) != BZ_OK) return rc;  // hashes of the sorted positions
+        if ((rc = w->prevd.ensure(npad * 4)) != BZ_OK) return rc; // per position: chain distance | chain length << 16
+    }
     if (hist && (rc = w->concat.ensure(nall + 64)) != BZ_OK) return rc;
     if ((rc = w->tabs.ensure(tab_words * 2 + 64)) != BZ_OK) return rc;
     if ((rc = w->ents.ensure(ent_words * 2 + 64)) != BZ_OK) return rc;
@@ -194,10 +200,6 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
 
     HIPCHK(hipEventRecord(w->ev[0], st));
     HIPCHK(hipMemsetAsync(w->stream.p, 0, bound + 64, st));
-    // BZ_DF_MATCH=walk: the chain-walking match kernel of rounds 1 and 2 (k_df_prev + k_df_match) instead of the one
-    // that reads the candidates off the sorted order (k_df_match2); same match words either way
-    const char *mv = getenv("BZ_DF_MATCH");
-    const bool walk = mv && strcmp(mv, "walk") == 0;
     if (df_launch_chains(st, d_all, nall, w->vals_in.as<u32>(), w->vals_out.as<u32>(), w->est.as<u16>(), w->sort_tmp.as<u32>(), w->keys_out.as<u32>(),
                          walk ? w->prevd.as<u32>() : nullptr) != 0)
         return BZ_E_UNEXPECTED;
