@@ -642,11 +642,14 @@ __global__ __launch_bounds__(kM2Threads) void k_df_match2(const u8 *__restrict__
     // One step, as the 16 or 17 vector instructions it takes (the compiler's rendering of the same C++ needs 21 and a
     // branch): where a chain is cut, its lane drops out of EXEC (v_cmpx); four XORs, four find-first-bit, the word
     // offsets, two three-way minima (the second one also applies the cap), the key, its top bit into qm, the maximum.
-#define DF_M2_STEP(D, J, CMPX)                                                                                                \
+#define DF_M2_STEP(D, J)                                                                                                      \
     "s_add_u32 %[k], %[k0], " #J "\n"                                                                                         \
     "s_sub_u32 %[kc], 0x7ff, %[k]\n"                                                                                          \
     "s_lshl_b32 %[kc], %[kc], 16\n"                                                                                           \
-    CMPX                                                                                                                      \
+    "s_cmp_eq_u32 %[nm], 0\n"                                                                                                 \
+    "s_cbranch_scc1 1f\n"                                                                                                     \
+    "v_cmpx_le_u32_e32 vcc, %[k], %[e]\n"                                                                                     \
+    "1:\n"                                                                                                                    \
     "v_xor_b32_e32 %[t0], %[a0], %[" #D "0]\n"                                                                                \
     "v_xor_b32_e32 %[t1], %[a1], %[" #D "1]\n"                                                                                \
     "v_xor_b32_e32 %[t2], %[a2], %[" #D "2]\n"                                                                                \
@@ -663,43 +666,40 @@ __global__ __launch_bounds__(kM2Threads) void k_df_match2(const u8 *__restrict__
     "v_lshl_or_b32 %[t0], %[t0], 24, %[kc]\n"                                                                                 \
     "v_alignbit_b32 %[qm], %[qm], %[t0], 31\n"                                                                                \
     "v_max_u32_e32 %[best], %[best], %[t0]\n"
-#define DF_M2_CMPX "v_cmpx_le_u32_e32 vcc, %[k], %[e]\n"
-#define DF_M2_PAIR(CA, CB, JA, JB, PRE, CMPX, POST)                                                                           \
-    asm volatile(PRE DF_M2_STEP(da, JA, CMPX) DF_M2_STEP(db, JB, CMPX) POST                                                   \
+#define DF_M2_PAIR(CA, CB, JA, JB)                                                                                            \
+    asm volatile("s_mov_b64 %[sv], exec\n" DF_M2_STEP(da, JA) DF_M2_STEP(db, JB) "s_mov_b64 exec, %[sv]\n"                    \
                  : [best] "+v"(best), [qm] "+v"(qm), [k] "=&s"(ks), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),           \
                    [t3] "=&v"(t3), [sv] "=&s"(sv), [kc] "=&s"(kc)                                                             \
-                 : [k0] "s"(k0u), [a0] "v"(a.x), [a1] "v"(a.y), [a2] "v"(a.z), [a3] "v"(a.w), [e] "v"(em), [cap] "v"(cap),    \
-                   [da0] "v"(CA.x), [da1] "v"(CA.y), [da2] "v"(CA.z), [da3] "v"(CA.w), [db0] "v"(CB.x), [db1] "v"(CB.y),      \
-                   [db2] "v"(CB.z), [db3] "v"(CB.w)                                                                           \
+                 : [k0] "s"(k0s), [nm] "s"(needmask), [a0] "v"(a.x), [a1] "v"(a.y), [a2] "v"(a.z), [a3] "v"(a.w),              \
+                   [e] "v"(em), [cap] "v"(cap), [da0] "v"(CA.x), [da1] "v"(CA.y), [da2] "v"(CA.z), [da3] "v"(CA.w),           \
+                   [db0] "v"(CB.x), [db1] "v"(CB.y), [db2] "v"(CB.z), [db3] "v"(CB.w)                                         \
                  : "vcc", "scc")
-    u32 ro = li;
+    u32 roff = li * 16; // byte offset of the lane's own row of s_snip
     u32 k0 = 0;
-    while (__ballot(k0 < e)) { // steps k0 + 1 .. k0 + 8: eight reads in flight, then the steps
-        ro -= 8;
-        asm volatile("" : "+v"(ro)); // (so that the reads below take immediate offsets)
-        u32 t0, t1, t2, t3, kc, ks;
-        u64 sv;
-        const u32 k0u = (u32)__builtin_amdgcn_readfirstlane((int)k0);
-        const u32x4 c1 = s_snip[ro + 7], c2 = s_snip[ro + 6], c3 = s_snip[ro + 5], c4 = s_snip[ro + 4], c5 = s_snip[ro + 3],
-                    c6 = s_snip[ro + 2], c7 = s_snip[ro + 1], c8 = s_snip[ro];
-        if (__ballot(em < k0 + 8)) { // some lane's chain is cut inside these eight steps
-            DF_M2_PAIR(c1, c2, 1, 2, "s_mov_b64 %[sv], exec\n", DF_M2_CMPX, "s_mov_b64 exec, %[sv]\n");
-            DF_M2_PAIR(c3, c4, 3, 4, "s_mov_b64 %[sv], exec\n", DF_M2_CMPX, "s_mov_b64 exec, %[sv]\n");
-            DF_M2_PAIR(c5, c6, 5, 6, "s_mov_b64 %[sv], exec\n", DF_M2_CMPX, "s_mov_b64 exec, %[sv]\n");
-            DF_M2_PAIR(c7, c8, 7, 8, "s_mov_b64 %[sv], exec\n", DF_M2_CMPX, "s_mov_b64 exec, %[sv]\n");
-        } else {
-            DF_M2_PAIR(c1, c2, 1, 2, "", "", "");
-            DF_M2_PAIR(c3, c4, 3, 4, "", "", "");
-            DF_M2_PAIR(c5, c6, 5, 6, "", "", "");
-            DF_M2_PAIR(c7, c8, 7, 8, "", "", "");
+    while (__ballot(k0 < e)) {
+        // up to 32 steps, then the measuring (its changes to e and mkey stay out of the inner loop's registers)
+        for (u32 q = 0; q < 4; ++q) { // steps k0 + 1 .. k0 + 8: eight reads in flight, then the steps
+            if (q && !__ballot(k0 < e)) break;
+            roff -= 8 * 16;
+            asm volatile("" : "+v"(roff)); // (so that the reads below take immediate offsets)
+            const u32x4 *row = reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(s_snip) + roff);
+            u32 t0, t1, t2, t3, kc, ks;
+            u64 sv;
+            const u32x4 c1 = row[7], c2 = row[6], c3 = row[5], c4 = row[4], c5 = row[3], c6 = row[2], c7 = row[1], c8 = row[0];
+            // some lane's chain is cut inside these eight steps: then (and only then) the steps carry their v_cmpx
+            const u64 cut = __ballot(em < k0 + 8);
+            const u32 needmask = (u32)cut | (u32)(cut >> 32);
+            const u32 k0s = (u32)__builtin_amdgcn_readfirstlane((int)k0);
+            DF_M2_PAIR(c1, c2, 1, 2);
+            DF_M2_PAIR(c3, c4, 3, 4);
+            DF_M2_PAIR(c5, c6, 5, 6);
+            DF_M2_PAIR(c7, c8, 7, 8);
+            k0 = k0s + 8;
         }
-        k0 += 8;
-        if ((k0 & 31u) == 0 && __ballot(qm != 0)) measure(k0);
+        if (__ballot(qm != 0)) measure(k0);
     }
 #undef DF_M2_PAIR
-#undef DF_M2_CMPX
 #undef DF_M2_STEP
-    if (__ballot(qm != 0)) measure(k0);
     if (own) {
         u32 best_len = best >> 27, best_k = 255u - ((best >> 16) & 0xFFu);
         if (mkey) { best_len = mkey >> 8; best_k = 255u - (mkey & 0xFFu); }
