@@ -31,6 +31,7 @@
 
 namespace dfgpu {
 using namespace bzgpu;
+typedef int i32;
 
 // ---------------------------------------------------------------------------------- hash + chains
 // slidedict.rs:80-87 on a 64-bit usize: the three bytes fold to a 24-bit value, times HASH_FRAC, top 16 bits
@@ -526,19 +527,29 @@ __global__ __launch_bounds__(kM2Threads) void k_df_match2(const u8 *__restrict__
     if (i0 >= count) return;
     const u32 *Sc = S + (size_t)c * kChunkStride;
     const u32 tid = threadIdx.x;
-    // the workgroup's entries and the 256 in front of them: position, hash, the first 16 text bytes
-    for (u32 t = tid; t < kM2Hist + kM2Threads; t += kM2Threads) {
-        const i64 g = (i64)i0 - (i64)kM2Hist + (i64)t;
-        u32 pos = 0, key = 0xFFFFFFFFu;
-        u32x4 sn = {0, 0, 0, 0};
-        if (g >= 0 && (u64)g < count) {
-            pos = __builtin_nontemporal_load(Sc + g);
-            sn = df_snippet(in, pos, n);
-            key = hash16(sn.x & 0xFFu, (sn.x >> 8) & 0xFFu, (sn.x >> 16) & 0xFFu); // (every entry has its three bytes)
-        }
-        s_pos[t] = pos;
-        s_key[t] = key;
-        s_snip[t] = sn;
+    // the workgroup's entries and the 256 in front of them: position, hash, the first 16 text bytes (positions fit
+    // 32 bits: a part of a long stream is at most 1 GiB + history)
+    const u32 n32 = (u32)n;
+    static_assert(kM2Threads == kM2Hist, "one entry in front and one own entry per thread");
+    {
+        const i32 g0 = (i32)i0 - (i32)kM2Hist + (i32)tid, g1 = (i32)(i0 + tid);
+        const bool ok0 = g0 >= 0, ok1 = (u32)g1 < count; // (g0 < i0 < count)
+        u32 pos0 = 0, pos1 = 0;
+        if (ok0) pos0 = __builtin_nontemporal_load(Sc + g0);
+        if (ok1) pos1 = __builtin_nontemporal_load(Sc + g1);
+        u32x4 sn0 = {0, 0, 0, 0}, sn1 = {0, 0, 0, 0};
+        const bool in0 = ok0 && pos0 + 16 <= n32, in1 = ok1 && pos1 + 16 <= n32;
+        if (in0) sn0 = *reinterpret_cast<const df_u32x4u *>(in + pos0);
+        if (in1) sn1 = *reinterpret_cast<const df_u32x4u *>(in + pos1);
+        if (ok0 && !in0) sn0 = df_snippet(in, pos0, n); // (the text ends within the 16 bytes)
+        if (ok1 && !in1) sn1 = df_snippet(in, pos1, n);
+        // (every entry has its three bytes: the hash is that of its trigram)
+        s_pos[tid] = pos0;
+        s_key[tid] = ok0 ? hash16(sn0.x & 0xFFu, (sn0.x >> 8) & 0xFFu, (sn0.x >> 16) & 0xFFu) : 0xFFFFFFFFu;
+        s_snip[tid] = sn0;
+        s_pos[kM2Hist + tid] = pos1;
+        s_key[kM2Hist + tid] = ok1 ? hash16(sn1.x & 0xFFu, (sn1.x >> 8) & 0xFFu, (sn1.x >> 16) & 0xFFu) : 0xFFFFFFFFu;
+        s_snip[kM2Hist + tid] = sn1;
     }
     __syncthreads();
     const u32 li = kM2Hist + tid;
@@ -559,7 +570,7 @@ __global__ __launch_bounds__(kM2Threads) void k_df_match2(const u8 *__restrict__
     // another trigram: fewer than three bytes agree, which never beats "no match"); only a chain cut by the window, by
     // the 255 candidates or by the start of the chunk's entries has to be masked.  em: the step a lane is masked from.
     const u32 em = (own && !(s_key[li - e - 1] != 0xFFFFFFFFu && s_key[li - e - 1] != h)) ? e : 0xFFFFFFFFu;
-    const u32 limit = (n - p) < (u64)kMaxMatch ? (u32)(n - p) : kMaxMatch; // search_dic :228
+    const u32 limit = (n32 - p) < kMaxMatch ? n32 - p : kMaxMatch; // search_dic :228
     // A step gives r = first differing bit of the 16 bytes, at most `cap` (the limit where it lies inside them, else
     // 128: "all 16 agree, the rest is to be measured").  What a lane keeps is the greatest key
     //     (r | 7) << 24 | (255 - k) << 16
