@@ -35,7 +35,7 @@ constexpr u32 kFan = 64;           // tiles composed per level
 #endif
 constexpr u32 kBThreads = DF_BLOCK_THREADS;
 #ifndef DF_EMIT_THREADS
-#define DF_EMIT_THREADS 128
+#define DF_EMIT_THREADS 64
 #endif
 constexpr u32 kEThreads = DF_EMIT_THREADS;
 constexpr u32 kHdrWords = 160;     // bits of BFINAL + dynamic header: < 74 + 316 * 14

@@ -1394,7 +1394,7 @@ __global__ __launch_bounds__(kEThreads) void k_df_emit(const u8 *__restrict__ in
     if (tid < 32) { s_ol[tid] = lens[(size_t)k * 320 + 288 + tid]; s_oc[tid] = 0; }
     __syncthreads();
     if (tid == 0) df_make_codes(s_sl, 288, s_sc);
-    if (tid == 64) df_make_codes(s_ol, 32, s_oc);
+    if (tid == kEThreads / 2) df_make_codes(s_ol, 32, s_oc); // (another wave where there is one)
     // header bits (BFINAL first)
     for (u32 i = tid; i * 32 < bi.hdr_bits; i += kEThreads) {
         const u32 nbits = bi.hdr_bits - i * 32 < 32 ? bi.hdr_bits - i * 32 : 32;
