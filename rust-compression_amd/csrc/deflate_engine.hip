@@ -15,7 +15,7 @@
 using namespace dfgpu;
 
 struct DfWorkspace {
-    DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, prevd, est, segoff, concat, bitmap, tabs, ents, bstart, nb, blocks, lens, hdr, lm, total,
+    DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, prevd, est, segoff, concat, bitmap, canon, tabs, ents, bstart, nb, blocks, lens, hdr, lm, total,
         stream, asum, bsum, crc;
     double t_stage[6] = {0, 0, 0, 0, 0, 0}; // chains, matches, parse, blocks, emit, total
     u64 stats[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // blocks, stored, fixed, dynamic, limited tables, stream bytes, dynamic w/o distances
@@ -28,7 +28,7 @@ struct DfWorkspace {
 void df_workspace_free(DfWorkspace *w)
 {
     if (!w) return;
-    DevBuf *all[] = {&w->keys_in, &w->keys_out, &w->vals_in, &w->vals_out, &w->sort_tmp, &w->prevd, &w->est, &w->segoff, &w->concat, &w->bitmap, &w->tabs, &w->ents,
+    DevBuf *all[] = {&w->keys_in, &w->keys_out, &w->vals_in, &w->vals_out, &w->sort_tmp, &w->prevd, &w->est, &w->segoff, &w->concat, &w->bitmap, &w->canon, &w->tabs, &w->ents,
                      &w->bstart, &w->nb, &w->blocks, &w->lens, &w->hdr, &w->lm, &w->total, &w->stream, &w->asum, &w->bsum,
                      &w->crc};
     for (DevBuf *b : all) b->release();
@@ -152,6 +152,11 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     // that reads the candidates off the sorted order (k_df_match2); same match words either way
     const char *mv = getenv("BZ_DF_MATCH");
     const bool walk = mv && strcmp(mv, "walk") == 0;
+    // BZ_DF_PARSE=doubling: the parse by pointer doubling of rounds 1 and 2 (k_df_tile_tab / k_df_mark) instead of
+    // the canonical orbits (k_df_tile_orbit / k_df_mark2); same code words either way
+    const char *pv = getenv("BZ_DF_PARSE");
+    const bool doubling = pv && strcmp(pv, "doubling") == 0;
+    if (!doubling && (rc = w->canon.ensure((size_t)ntiles * 64 * 8 + 64)) != BZ_OK) return rc; // a tile's canonical orbit, one bit per position
     if (walk) {
         if ((rc = w->est.ensure(nsort * 2)) != BZ_OK) return rc;  // hashes of the sorted positions
         if ((rc = w->prevd.ensure(npad * 4)) != BZ_OK) return rc; // per position: chain distance | chain length << 16
@@ -208,7 +213,9 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
               : df_launch_match2(st, d_all, nall, w->vals_out.as<u32>(), Mall)) != 0)
         return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[2], st));
-    if (df_launch_parse(st, M, n, step, tabs.data(), ents.data(), counts.data(), nlevels, code, w->bitmap.as<u64>()) != 0) return BZ_E_UNEXPECTED;
+    if (df_launch_parse(st, M, n, step, tabs.data(), ents.data(), counts.data(), nlevels, code, w->bitmap.as<u64>(),
+                        doubling ? nullptr : w->canon.as<u64>()) != 0)
+        return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[3], st));
     if (seg.skip > 2 || (seg.skip && seg.dl0)) return BZ_E_PARAM;
     if (df_launch_cuts(st, n, w->bitmap.as<u64>(), w->bstart.as<u64>(), w->nb.as<u32>(), bcap, seg.dl0, seg.skip) != 0) return BZ_E_UNEXPECTED;

@@ -61,7 +61,7 @@ int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *v0, u32 *s, u16 *
 int df_launch_match(hipStream_t st, const u8 *in, const u32 *pe, u64 n, u32 *M);
 int df_launch_match2(hipStream_t st, const u8 *in, u64 n, const u32 *s, u32 *M);
 int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *tabs, u16 *const *ents, const u32 *counts,
-                    u32 nlevels, u32 *code, u64 *bm);
+                    u32 nlevels, u32 *code, u64 *bm, u64 *canon);
 // dl0: decompress_len carried into the segment (0 unless it follows an Action::Flush); last_is_final: the
 // segment ends the stream (Finish) rather than being flushed.  `in` is the segment's first byte; the dl0 bytes
 // in front of it must be readable (a stored first block copies them).  The block chain (df_launch_cuts) is its

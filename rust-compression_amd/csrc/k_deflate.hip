@@ -873,6 +873,142 @@ __global__ __launch_bounds__(kMarkThreads) void k_df_mark(const u16 *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------- parse, without doubling (round 3)
+// Orbits of p -> p + adv(p) that start at different places fall into step after a few codes (a literal moves by one,
+// so any orbit soon lands on a position another one visits), and from there on they ARE the same orbit.  So a tile
+// needs one orbit in full -- the one entered at its first position, the "canonical" one -- and every other entry
+// only has to be followed until it lands on a position of that orbit:
+//   k_df_tile_orbit  the canonical orbit of a tile as a bitmap (kept in global memory for k_df_mark2) and the exit of
+//                    every entry offset (the table k_df_tile_tab made with twelve doubling rounds over 4096 positions).
+//                    The canonical orbit itself is put together from 64 speculative walks, one lane per 64
+//                    positions starting at the sub-tile's first position: where the orbit enters a sub-tile it
+//                    either lands on the lane's path at once (then the lane's path from there and the lane's exit
+//                    are the orbit's) or is followed until it does.
+//   k_df_mark2       the orbit of the tile's true entry = its steps up to the first position on the canonical orbit +
+//                    the canonical orbit from there; then the code words as in k_df_mark.
+// Every step taken is checked against the bitmap, nothing is assumed: an input whose orbits never meet (none is
+// known with short steps) only makes the walks longer.
+constexpr u32 kOrbThreads = 320;
+static_assert(kOrbThreads >= kEntries && kPTile == 64 * 64, "one lane per entry offset, 64 sub-tiles of 64 positions");
+
+__device__ __forceinline__ void df_stage_steps(const u16 *__restrict__ step, u64 n, u64 t0, u32 tid, u32 nthreads, u16 *s_step)
+{
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    const bool al = (reinterpret_cast<uintptr_t>(step) & 15u) == 0;
+    for (u32 c = tid; c < kPTile / 8; c += nthreads) {
+        const u64 p = t0 + (u64)c * 8;
+        if (al && p + 8 <= n) *reinterpret_cast<u32x4 *>(s_step + c * 8) = *reinterpret_cast<const u32x4 *>(step + p);
+        else
+            for (u32 j = 0; j < 8; ++j) s_step[c * 8 + j] = p + j < n ? step[p + j] : (u16)1;
+    }
+}
+// advance of a step word (never 0: a walk must move)
+__device__ __forceinline__ u32 df_adv_of(u32 s) { const u32 a = s & 511u; return a ? a : 1u; }
+
+__global__ __launch_bounds__(kOrbThreads) void k_df_tile_orbit(const u16 *__restrict__ step, u64 n, u16 *__restrict__ tab,
+                                                               u64 *__restrict__ canon)
+{
+    __shared__ __attribute__((aligned(16))) u16 s_step[kPTile];
+    __shared__ u64 s_m[64], s_C[64];
+    __shared__ u32 s_x[64];
+    __shared__ u32 s_exit;
+    const u32 tid = threadIdx.x;
+    const u64 t0 = (u64)blockIdx.x * kPTile;
+    df_stage_steps(step, n, t0, tid, kOrbThreads, s_step);
+    if (tid < 64) s_C[tid] = 0;
+    __syncthreads();
+    if (tid < 64) { // one lane per sub-tile: the path from its first position, and where it leaves
+        u32 pos = tid * 64;
+        const u32 end = pos + 64;
+        u64 m = 0;
+        do {
+            m |= 1ull << (pos & 63u);
+            pos += df_adv_of(s_step[pos]);
+        } while (pos < end);
+        s_m[tid] = m;
+        s_x[tid] = pos;
+    }
+    __syncthreads();
+    if (tid == 0) { // the canonical orbit, sub-tile by sub-tile
+        u32 cur = 0;
+        while (cur < kPTile) {
+            const u32 sb = cur >> 6, off = cur & 63u;
+            const u64 m = s_m[sb];
+            if ((m >> off) & 1ull) { s_C[sb] |= m & (~0ull << off); cur = s_x[sb]; }
+            else { s_C[sb] |= 1ull << off; cur += df_adv_of(s_step[cur]); }
+        }
+        s_exit = cur;
+    }
+    __syncthreads();
+    const u32 cexit = s_exit;
+    if (tid < kEntries) {
+        u32 cur = tid;
+        while (cur < kPTile && !((s_C[cur >> 6] >> (cur & 63u)) & 1ull)) cur += df_adv_of(s_step[cur]);
+        tab[(u64)blockIdx.x * kEntries + tid] = (u16)((cur < kPTile ? cexit : cur) - kPTile);
+    }
+    if (tid < 64) canon[(u64)blockIdx.x * 64 + tid] = s_C[tid];
+}
+
+__global__ __launch_bounds__(kMarkThreads) void k_df_mark2(const u16 *__restrict__ step, const u32 *__restrict__ M,
+                                                           const u16 *__restrict__ ent, const u16 *__restrict__ tab,
+                                                           const u64 *__restrict__ canon, u64 n, u32 *__restrict__ code,
+                                                           u64 *__restrict__ bm)
+{
+    __shared__ __attribute__((aligned(16))) u16 s_step[kPTile];
+    __shared__ u64 s_C[64], s_mk[64];
+    __shared__ u8 s_type[kPTile + 264];
+    __shared__ u32 s_exitp, s_mw;
+    const u32 tid = threadIdx.x;
+    const u64 t0 = (u64)blockIdx.x * kPTile;
+    const u32 entry = ent[blockIdx.x];
+    df_stage_steps(step, n, t0, tid, kMarkThreads, s_step);
+    if (tid < 64) { s_C[tid] = canon[(u64)blockIdx.x * 64 + tid]; s_mk[tid] = 0; }
+    for (u32 k = tid; k < kPTile + 264; k += kMarkThreads) s_type[k] = 0;
+    __syncthreads();
+    if (tid == 0) { // from the entry to the first position on the canonical orbit (or out of the tile)
+        u32 cur = entry, mw = 64;
+        while (cur < kPTile) {
+            const u32 sb = cur >> 6, off = cur & 63u;
+            if ((s_C[sb] >> off) & 1ull) { s_mk[sb] |= s_C[sb] & (~0ull << off); mw = sb; break; }
+            s_mk[sb] |= 1ull << off;
+            cur += df_adv_of(s_step[cur]);
+        }
+        s_mw = mw;
+        s_exitp = mw < 64 ? (u32)tab[(u64)blockIdx.x * kEntries] + kPTile : cur; // (entry offset 0 is on the canonical orbit)
+    }
+    __syncthreads();
+    if (tid < 64 && tid > s_mw) s_mk[tid] = s_C[tid]; // behind the meeting point: the canonical orbit
+    __syncthreads();
+    const u32 exitp = s_exitp;
+    for (u32 k = tid; k < kPTile; k += kMarkThreads) {
+        if (!((s_mk[k >> 6] >> (k & 63u)) & 1ull)) continue;
+        const u32 s = s_step[k], adv = s & 511u, li = s >> 9;
+        // (4: a step of the parse starts here -- with li > 0 the step's reference is a code start that is not one)
+        if (adv <= 1) s_type[k] = 1 | 4;
+        else {
+            for (u32 i = 0; i < li; ++i) s_type[k + i] = 1;
+            s_type[k + li] = 2;
+            s_type[k] |= 4;
+        }
+    }
+    __syncthreads();
+    // code words, and one bit per position for the block cuts (the 64 positions of a wave straddle two words)
+    for (u32 k0 = entry + (tid & ~63u); k0 < exitp; k0 += kMarkThreads) {
+        const u32 k = k0 + (tid & 63u);
+        const u64 q = t0 + k;
+        const bool ok = k < exitp && q < n;
+        const u32 ty = ok ? s_type[k] : 0u;
+        if (ok) code[q] = ty == 0 ? 0u : (((ty & 3u) == 1 ? F_CODE : (F_CODE | F_REF | M[q])) | ((ty & 4u) ? F_STEP : 0u));
+        const u64 bal = __ballot(ty != 0);
+        if ((tid & 63u) == 0 && bal) {
+            const u64 q0 = t0 + k0;
+            const u32 sh = (u32)(q0 & 63u);
+            atomicOr(reinterpret_cast<unsigned long long *>(bm + (q0 >> 6)), (unsigned long long)(bal << sh));
+            if (sh && (bal >> (64 - sh))) atomicOr(reinterpret_cast<unsigned long long *>(bm + (q0 >> 6) + 1), (unsigned long long)(bal >> (64 - sh)));
+        }
+    }
+}
+
 // block starts: b' = the last code start <= b + 0xFFFF (InflaterInner::next :585-593).  A serial chain of
 // n / 65535 hops; a hop loses at most 257 bytes against b + 0xFFFF, so the bits that the next kCutGroup hops
 // can look at are known in advance: they are loaded together, the hops then run out of LDS.
@@ -1583,20 +1719,24 @@ int df_launch_match(hipStream_t st, const u8 *in, const u32 *pe, u64 n, u32 *M)
     return 0;
 }
 
+// canon: counts[0] * 64 words for the tiles' canonical orbits (k_df_tile_orbit / k_df_mark2), or nullptr for the
+// doubling kernels of rounds 1 and 2 (k_df_tile_tab / k_df_mark)
 int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *tabs, u16 *const *ents, const u32 *counts,
-                    u32 nlevels, u32 *code, u64 *bm)
+                    u32 nlevels, u32 *code, u64 *bm, u64 *canon)
 {
     if (!n) return 0;
     DFCHK(hipMemsetAsync(bm, 0, ((n + 63) / 64 + 2) * sizeof(u64), st));
     hipLaunchKernelGGL(k_df_adv, dim3((u32)((n + 1023) / 1024)), dim3(256), 0, st, M, n, step);
-    hipLaunchKernelGGL(k_df_tile_tab, dim3(counts[0]), dim3(kTabThreads), 0, st, step, n, tabs[0]);
+    if (canon) hipLaunchKernelGGL(k_df_tile_orbit, dim3(counts[0]), dim3(kOrbThreads), 0, st, step, n, tabs[0], canon);
+    else hipLaunchKernelGGL(k_df_tile_tab, dim3(counts[0]), dim3(kTabThreads), 0, st, step, n, tabs[0]);
     for (u32 l = 1; l + 1 < nlevels; ++l)
         hipLaunchKernelGGL(k_df_compose, dim3(counts[l]), dim3(320), 0, st, tabs[l - 1], counts[l - 1], tabs[l]);
     DFCHK(hipMemsetAsync(ents[nlevels - 1], 0, sizeof(u16), st)); // the single top group is entered at 0
     for (u32 l = nlevels - 1; l >= 1; --l)
         hipLaunchKernelGGL(k_df_resolve, dim3((counts[l] + 63) / 64), dim3(64), 0, st, tabs[l - 1], counts[l - 1], ents[l],
                            counts[l], ents[l - 1]);
-    hipLaunchKernelGGL(k_df_mark, dim3(counts[0]), dim3(kMarkThreads), 0, st, step, M, ents[0], n, code, bm);
+    if (canon) hipLaunchKernelGGL(k_df_mark2, dim3(counts[0]), dim3(kMarkThreads), 0, st, step, M, ents[0], tabs[0], canon, n, code, bm);
+    else hipLaunchKernelGGL(k_df_mark, dim3(counts[0]), dim3(kMarkThreads), 0, st, step, M, ents[0], n, code, bm);
     return 0;
 }
 

@@ -231,6 +231,11 @@ def _match_cases():
     assert pair is not None
     x, y = pair
     yield "collide", (x + b"0123456789abcdefgh" + y + b"0123456789abcdefgh") * 40 + x + b"0123456789abcdefXY" + y + b"0123"
+    # codes of one length in a row (orbits of the parse that start one byte apart stay apart for long stretches)
+    w3 = [bytes(rnd.choice(b"abcdefgh") for _ in range(3)) for _ in range(40)]
+    yield "words3", b"".join(rnd.choice(w3) for _ in range(30000))
+    w5 = [bytes(rnd.choice(b"abcdefgh") for _ in range(5)) for _ in range(200)]
+    yield "words5", b"".join(rnd.choice(w5) for _ in range(20000))
     # a paragraph repeated (every candidate agrees to the limit) and four symbols at random (full chains, short matches)
     yield "deep", para[:400] * 200
     yield "dna", bytes(rnd.choice(b"ACGT") for _ in range(90000))
@@ -244,6 +249,7 @@ def test_match_kernels_on_long_and_tied_candidates(pkg, oracle, eng, name, data,
     255, ties, hash collisions."""
     check(pkg, oracle, eng, data)
     monkeypatch.setenv("BZ_DF_MATCH", "walk")
+    monkeypatch.setenv("BZ_DF_PARSE", "doubling")  # (and the parse by pointer doubling instead of canonical orbits)
     check(pkg, oracle, eng, data)
 
 
