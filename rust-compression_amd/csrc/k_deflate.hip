@@ -888,8 +888,14 @@ __global__ __launch_bounds__(kMarkThreads) void k_df_mark(const u16 *__restrict_
 //                    the canonical orbit from there; then the code words as in k_df_mark.
 // Every step taken is checked against the bitmap, nothing is assumed: an input whose orbits never meet (none is
 // known with short steps) only makes the walks longer.
-constexpr u32 kOrbThreads = 320;
-static_assert(kOrbThreads >= kEntries && kPTile == 64 * 64, "one lane per entry offset, 64 sub-tiles of 64 positions");
+#ifndef DF_ORB_THREADS
+#define DF_ORB_THREADS 128
+#endif
+#ifndef DF_MARK2_THREADS
+#define DF_MARK2_THREADS 256
+#endif
+constexpr u32 kOrbThreads = DF_ORB_THREADS, kMark2Threads = DF_MARK2_THREADS;
+static_assert(kOrbThreads >= 64 && kMark2Threads >= 64 && kPTile == 64 * 64, "64 sub-tiles of 64 positions, one lane each");
 
 __device__ __forceinline__ void df_stage_steps(const u16 *__restrict__ step, u64 n, u64 t0, u32 tid, u32 nthreads, u16 *s_step)
 {
@@ -941,15 +947,15 @@ __global__ __launch_bounds__(kOrbThreads) void k_df_tile_orbit(const u16 *__rest
     }
     __syncthreads();
     const u32 cexit = s_exit;
-    if (tid < kEntries) {
-        u32 cur = tid;
+    for (u32 e = tid; e < kEntries; e += kOrbThreads) {
+        u32 cur = e;
         while (cur < kPTile && !((s_C[cur >> 6] >> (cur & 63u)) & 1ull)) cur += df_adv_of(s_step[cur]);
-        tab[(u64)blockIdx.x * kEntries + tid] = (u16)((cur < kPTile ? cexit : cur) - kPTile);
+        tab[(u64)blockIdx.x * kEntries + e] = (u16)((cur < kPTile ? cexit : cur) - kPTile);
     }
     if (tid < 64) canon[(u64)blockIdx.x * 64 + tid] = s_C[tid];
 }
 
-__global__ __launch_bounds__(kMarkThreads) void k_df_mark2(const u16 *__restrict__ step, const u32 *__restrict__ M,
+__global__ __launch_bounds__(kMark2Threads) void k_df_mark2(const u16 *__restrict__ step, const u32 *__restrict__ M,
                                                            const u16 *__restrict__ ent, const u16 *__restrict__ tab,
                                                            const u64 *__restrict__ canon, u64 n, u32 *__restrict__ code,
                                                            u64 *__restrict__ bm)
@@ -961,9 +967,9 @@ __global__ __launch_bounds__(kMarkThreads) void k_df_mark2(const u16 *__restrict
     const u32 tid = threadIdx.x;
     const u64 t0 = (u64)blockIdx.x * kPTile;
     const u32 entry = ent[blockIdx.x];
-    df_stage_steps(step, n, t0, tid, kMarkThreads, s_step);
+    df_stage_steps(step, n, t0, tid, kMark2Threads, s_step);
     if (tid < 64) { s_C[tid] = canon[(u64)blockIdx.x * 64 + tid]; s_mk[tid] = 0; }
-    for (u32 k = tid; k < kPTile + 264; k += kMarkThreads) s_type[k] = 0;
+    for (u32 k = tid; k < kPTile + 264; k += kMark2Threads) s_type[k] = 0;
     __syncthreads();
     if (tid == 0) { // from the entry to the first position on the canonical orbit (or out of the tile)
         u32 cur = entry, mw = 64;
@@ -980,7 +986,7 @@ __global__ __launch_bounds__(kMarkThreads) void k_df_mark2(const u16 *__restrict
     if (tid < 64 && tid > s_mw) s_mk[tid] = s_C[tid]; // behind the meeting point: the canonical orbit
     __syncthreads();
     const u32 exitp = s_exitp;
-    for (u32 k = tid; k < kPTile; k += kMarkThreads) {
+    for (u32 k = tid; k < kPTile; k += kMark2Threads) {
         if (!((s_mk[k >> 6] >> (k & 63u)) & 1ull)) continue;
         const u32 s = s_step[k], adv = s & 511u, li = s >> 9;
         // (4: a step of the parse starts here -- with li > 0 the step's reference is a code start that is not one)
@@ -993,7 +999,7 @@ __global__ __launch_bounds__(kMarkThreads) void k_df_mark2(const u16 *__restrict
     }
     __syncthreads();
     // code words, and one bit per position for the block cuts (the 64 positions of a wave straddle two words)
-    for (u32 k0 = entry + (tid & ~63u); k0 < exitp; k0 += kMarkThreads) {
+    for (u32 k0 = entry + (tid & ~63u); k0 < exitp; k0 += kMark2Threads) {
         const u32 k = k0 + (tid & 63u);
         const u64 q = t0 + k;
         const bool ok = k < exitp && q < n;
@@ -1735,7 +1741,7 @@ int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *
     for (u32 l = nlevels - 1; l >= 1; --l)
         hipLaunchKernelGGL(k_df_resolve, dim3((counts[l] + 63) / 64), dim3(64), 0, st, tabs[l - 1], counts[l - 1], ents[l],
                            counts[l], ents[l - 1]);
-    if (canon) hipLaunchKernelGGL(k_df_mark2, dim3(counts[0]), dim3(kMarkThreads), 0, st, step, M, ents[0], tabs[0], canon, n, code, bm);
+    if (canon) hipLaunchKernelGGL(k_df_mark2, dim3(counts[0]), dim3(kMark2Threads), 0, st, step, M, ents[0], tabs[0], canon, n, code, bm);
     else hipLaunchKernelGGL(k_df_mark, dim3(counts[0]), dim3(kMarkThreads), 0, st, step, M, ents[0], n, code, bm);
     return 0;
 }
