@@ -1323,11 +1323,7 @@ __global__ __launch_bounds__(kBThreads) void k_df_block(const u8 *__restrict__ i
         for (u32 j = 0; j < 8; ++j) {
             const u64 q = q0 + (u64)j * kBThreads + tid;
             c[j] = q < b1 ? code[q] : 0u;
-        }
-#pragma unroll
-        for (u32 j = 0; j < 8; ++j) {
-            const u64 q = q0 + (u64)j * kBThreads + tid;
-            lit[j] = ((c[j] & (F_CODE | F_REF)) == F_CODE) ? in[q] : 0u;
+            lit[j] = q < b1 ? in[q] : 0u; // (beside the code word, not behind it: one round trip per batch)
         }
 #pragma unroll
         for (u32 j = 0; j < 8; ++j) {
@@ -1545,18 +1541,32 @@ __global__ __launch_bounds__(kEThreads) void k_df_emit(const u8 *__restrict__ in
     if (tid == 0) s_base = bi.bit_off + bi.hdr_bits;
     __syncthreads();
     const u32 lane = tid & 63u, wave = tid >> 6;
+    // 4 consecutive positions per thread: their code words and text bytes are loaded together (16 + 4 bytes, one
+    // round trip), and the next chunk's are on their way while this one is coded
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    typedef u32x4 __attribute__((aligned(4))) u32x4u;
+    auto fetch = [&](u64 q0, u32 (&cw)[4], u32 &tx) {
+        cw[0] = cw[1] = cw[2] = cw[3] = 0; tx = 0;
+        if (q0 + 4 <= b1) {
+            const u32x4 w = *reinterpret_cast<const u32x4u *>(code + q0);
+            cw[0] = w.x; cw[1] = w.y; cw[2] = w.z; cw[3] = w.w;
+            tx = *reinterpret_cast<const df_u32u *>(in + q0);
+        } else
+            for (u32 j = 0; j < 4 && q0 + j < b1; ++j) { cw[j] = code[q0 + j]; tx |= (u32)in[q0 + j] << (8 * j); }
+    };
+    u32 ncw[4], ntx;
+    fetch(b0 + (u64)tid * 4, ncw, ntx);
     for (u64 c0 = b0; c0 < b1; c0 += kEThreads * 4) {
-        // 4 consecutive positions per thread
         u64 v[4];
         u32 nb[4];
         u32 tot = 0;
-        const u64 q0 = c0 + (u64)tid * 4;
+        u32 cw[4] = {ncw[0], ncw[1], ncw[2], ncw[3]};
+        const u32 tx = ntx;
+        if (c0 + kEThreads * 4 < b1) fetch(c0 + kEThreads * 4 + (u64)tid * 4, ncw, ntx);
         for (u32 j = 0; j < 4; ++j) {
-            const u64 q = q0 + j;
             v[j] = 0; nb[j] = 0;
-            if (q >= b1) continue;
-            const u32 c = code[q];
-            if (!(c & F_CODE)) continue;
+            const u32 c = cw[j];
+            if (!(c & F_CODE)) continue; // (also every position at or behind b1: its word was not loaded)
             if (c & F_REF) {
                 u32 lc, leb, lev, dc, deb, dev;
                 len_code((c & 511u) - 3, lc, leb, lev);
@@ -1568,8 +1578,8 @@ __global__ __launch_bounds__(kEThreads) void k_df_emit(const u8 *__restrict__ in
                 x |= (u64)dev << nn; nn += deb;
                 v[j] = x; nb[j] = nn;
             } else {
-                const u32 s = in[q];
-                v[j] = s_sc[s]; nb[j] = s_sl[s];
+                const u32 sy = (tx >> (8 * j)) & 0xFFu;
+                v[j] = s_sc[sy]; nb[j] = s_sl[sy];
             }
             tot += nb[j];
         }
