@@ -1130,7 +1130,7 @@ __device__ void df_down_heap(u32 *buf, u32 nn, u32 len)
 
 // cano_huff_table.rs:58-151 ("reverse package merge"), weights x + y.  freq: k non-zero weights, out: k lengths.
 // scr: 3*k + 64 + 2*lim*row words, row >= 2k + 4.
-__device__ void df_gen_code_lm(const u32 *freq, u32 n, u32 lim, u32 *scr, u8 *out)
+__device__ __forceinline__ void df_gen_code_lm(const u32 *freq, u32 n, u32 lim, u32 *scr, u8 *out)
 {
     const u32 row = 2 * n + 4;
     u32 *map = scr, *sfreq = map + n, *c = sfreq + n, *misc = c + n;
@@ -1239,8 +1239,135 @@ __device__ u32 df_make_table(const u32 *freq, u32 nsym, u32 lim, u8 *out, u32 *b
     return last;
 }
 
+// The same, by a whole wave.  The heap procedure is a chain of dependent accesses to one small array (two sift-downs
+// of six or seven levels per merge, half a dozen reads per level): out of LDS that is 0.4 ms for the hundred symbols
+// of a literal/length table, and it is what a block's workgroup spends its time on.  Here the array lives in
+// registers -- element e in lane e & 63 of register e >> 6 -- and every access is a v_readlane / v_writelane at a
+// wave-uniform index: the control flow runs on the scalar unit, an access costs a few cycles instead of an LDS round
+// trip.  Same procedure, same order of every comparison, same lengths.  NR: registers (2 * nsym <= 64 * NR).
+template <u32 NR>
+struct DfWaveArr {
+    typedef u32 vec_t __attribute__((ext_vector_type(NR <= 1 ? 1 : (NR <= 4 ? 4 : 16))));
+    vec_t r;
+    // (a vector indexed with a wave-uniform value: the compiler addresses the register through M0 -- one move and
+    // one v_readlane per access instead of a chain of compares over the registers)
+    __device__ __forceinline__ u32 get(u32 x) const
+    {
+        const u32 word = NR <= 1 ? r[0] : r[x >> 6];
+        return (u32)__builtin_amdgcn_readlane((int)word, (int)(x & 63u));
+    }
+    __device__ __forceinline__ void set(u32 x, u32 val)
+    {
+        // (a compare and a select stand in for v_writelane: this compiler has no builtin for it)
+        const u32 lane = (u32)__builtin_amdgcn_mbcnt_hi(~0u, (u32)__builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (NR <= 1) r[0] = lane == (x & 63u) ? val : r[0];
+        else {
+            const u32 word = r[x >> 6];
+            r[x >> 6] = lane == (x & 63u) ? val : word;
+        }
+    }
+};
+
+template <u32 NR>
+__device__ __forceinline__ void df_down_heap_wave(DfWaveArr<NR> &a, u32 nn, u32 len)
+{
+    const u32 tmp = a.get(nn);
+    const u32 wt = a.get(tmp);
+    u32 leaf = (nn << 1) + 1;
+    while (leaf < len) {
+        u32 c = a.get(leaf), wc = a.get(c);
+        if (leaf + 1 < len) {
+            const u32 c2 = a.get(leaf + 1), wc2 = a.get(c2);
+            if (wc > wc2) { leaf += 1; c = c2; wc = wc2; }
+        }
+        if (wt < wc) break;
+        a.set(nn, c);
+        nn = leaf;
+        leaf = (nn << 1) + 1;
+    }
+    a.set(nn, tmp);
+}
+
+// all 64 lanes of a wave call this with the same arguments; the arrays are in LDS
+template <u32 NR>
+__device__ __forceinline__ u32 df_make_table_wave(const u32 *freq, u32 nsym, u32 lim, u8 *out, u32 *buf, u32 *w, u8 *tmp, u32 *lm_scr, u32 *lm,
+                                  u32 lane)
+{
+    const u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    u32 k = 0, last = 0;
+    for (u32 i0 = 0; i0 < nsym; i0 += 64) { // the non-zero counts, in symbol order
+        const u32 i = i0 + lane;
+        const u32 f = i < nsym ? freq[i] : 0u;
+        if (i < nsym) out[i] = 0;
+        const u64 nz = __ballot(f != 0);
+        if (f) w[k + (u32)__popcll(nz & lt)] = f;
+        if (nz) last = i0 + 64 - (u32)__builtin_clzll(nz);
+        k += (u32)__popcll(nz);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (k == 0) return 0;
+    if (k == 1) { if (lane == 0) tmp[0] = 1; } // gen_code :158-160
+    else {
+        const u32 n = k;
+        DfWaveArr<NR> a;
+#pragma unroll
+        for (u32 q = 0; q < NR; ++q) {
+            const u32 e = q * 64 + lane;
+            a.r[q] = e < n ? n + e : (e < 2 * n ? w[e - n] : 0u);
+        }
+#pragma unroll
+        for (u32 q = NR; q < (NR <= 1 ? 1u : (NR <= 4 ? 4u : 16u)); ++q) a.r[q] = 0;
+        for (u32 i = n >> 1; i-- > 0;) df_down_heap_wave(a, i, n); // create_heap :33-38 (len = 2n, s = n)
+        for (u32 i = n - 1; i >= 1; --i) {
+            const u32 m1 = a.get(0);
+            a.set(0, a.get(i));
+            df_down_heap_wave(a, 0, i);
+            const u32 m2 = a.get(0);
+            a.set(i, a.get(m1) + a.get(m2));
+            a.set(0, i);
+            a.set(m1, i);
+            a.set(m2, i);
+            df_down_heap_wave(a, 0, i);
+        }
+        a.set(1, 0);
+        for (u32 i = 2; i < n; ++i) a.set(i, a.get(a.get(i)) + 1);
+#pragma unroll
+        for (u32 q = 0; q < NR; ++q) {
+            const u32 e = q * 64 + lane;
+            if (e < 2 * n) buf[e] = a.r[q];
+        }
+        __builtin_amdgcn_wave_barrier();
+        bool too_long = false;
+        for (u32 i0 = 0; i0 < n; i0 += 64) {
+            const u32 i = i0 + lane;
+            u32 l = 0;
+            if (i < n) { l = buf[buf[i + n]] + 1; tmp[i] = (u8)l; }
+            if (__ballot(l > lim)) too_long = true;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (too_long) {
+            if (lane == 0) {
+                df_gen_code_lm(w, n, lim, lm_scr, tmp);
+                if (lm) atomicAdd(lm, 1u);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    k = 0;
+    for (u32 i0 = 0; i0 < nsym; i0 += 64) {
+        const u32 i = i0 + lane;
+        const u32 f = i < nsym ? freq[i] : 0u;
+        const u64 nz = __ballot(f != 0);
+        if (f) out[i] = tmp[k + (u32)__popcll(nz & lt)];
+        k += (u32)__popcll(nz);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return last;
+}
+
 // canonical codes, bit-reversed (huffman/mod.rs:16-63 with is_reverse)
-__device__ void df_make_codes(const u8 *len, u32 n, u16 *code)
+__device__ __forceinline__ void df_make_codes(const u8 *len, u32 n, u16 *code)
 {
     u32 cur = 0, last = 0;
     for (u32 l = 1; l <= 15; ++l)
@@ -1257,19 +1384,19 @@ struct LsbSink { // single lane, LSB first into 32-bit words
     u32 *w;
     u64 acc;
     u32 nacc, widx;
-    __device__ void put(u32 v, u32 nbits)
+    __device__ __forceinline__ void put(u32 v, u32 nbits)
     {
         if (!nbits) return;
         acc |= (u64)v << nacc;
         nacc += nbits;
         if (nacc >= 32) { w[widx++] = (u32)acc; acc >>= 32; nacc -= 32; }
     }
-    __device__ u32 bits() const { return widx * 32 + nacc; }
-    __device__ void finish() { if (nacc) w[widx] = (u32)acc; }
+    __device__ __forceinline__ u32 bits() const { return widx * 32 + nacc; }
+    __device__ __forceinline__ void finish() { if (nacc) w[widx] = (u32)acc; }
 };
 
 // enc_tab_to_freq (deflate/encoder.rs:318-376): run coding of one length table
-__device__ u32 df_tab_runs(const u8 *tab, u32 n, u8 *ls, u8 *le, u32 *freq)
+__device__ __forceinline__ u32 df_tab_runs(const u8 *tab, u32 n, u8 *ls, u8 *le, u32 *freq)
 {
     u32 k = 0, old = 255, len = 0;
     for (u32 i = 0; i <= n; ++i) {
@@ -1308,6 +1435,10 @@ __global__ __launch_bounds__(kBThreads) void k_df_block(const u8 *__restrict__ i
     __shared__ u32 s_hdr[kHdrWords];
     __shared__ u32 s_lm7[3 * 19 + 64 + 2 * 7 * (2 * 19 + 4)];
     __shared__ u32 s_btype;
+    __shared__ u32 s_lenfreq[19], s_rk[3], s_lm2;
+    __shared__ u8 s_lenenc[19], s_lenmap[19], s_lentab[19];
+    __shared__ u16 s_lcode[19];
+    static_assert(kBThreads >= 128, "a wave for each of the block's two tables");
     const u32 tid = threadIdx.x, k = blockIdx.x;
     const u32 nblocks = *nb_p;
     if (nblocks == 0xFFFFFFFFu || k >= nblocks) return;
@@ -1341,22 +1472,43 @@ __global__ __launch_bounds__(kBThreads) void k_df_block(const u8 *__restrict__ i
     if (tid == 0) s_sf[256] += 1; // init_block :274-279
     __syncthreads();
     u32 *lm_scr = lm_scratch + (size_t)k * kDfLmWords;
-    if (tid == 0) s_n[0] = df_make_table(s_sf, 286, 15, s_sl, s_buf[0], s_w[0], s_tmp[0], lm_scr, &s_lm);
-    if (tid == 64) s_n[1] = df_make_table(s_of, 30, 15, s_ol, s_buf[1], s_w[1], s_tmp[1], lm_scr + kDfLmTable, &s_lm);
+    // the two tables side by side, a wave each (the heap lives in the wave's registers: df_make_table_wave)
+    const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63u;
+    if (wave == 0) {
+        const u32 r = df_make_table_wave<9>(s_sf, 286, 15, s_sl, s_buf[0], s_w[0], s_tmp[0], lm_scr, &s_lm, lane);
+        if (lane == 0) s_n[0] = r;
+    } else if (wave == 1) {
+        const u32 r = df_make_table_wave<1>(s_of, 30, 15, s_ol, s_buf[1], s_w[1], s_tmp[1], lm_scr + kDfLmTable, &s_lm, lane);
+        if (lane == 0) s_n[1] = r;
+    }
+    __syncthreads();
+    // create_custom_huffman_table :395-452: the run coding of both tables (one lane), its code (the wave), the header
+    if (tid < 19) { s_lenfreq[tid] = 0; s_lenenc[tid] = 0; }
+    if (tid == 0) { s_lm2 = 0; }
+    __syncthreads();
+    if (tid == 0) {
+        s_rk[0] = df_tab_runs(s_sl, s_n[0], s_ls[0], s_le[0], s_lenfreq);
+        s_rk[1] = df_tab_runs(s_ol, s_n[1], s_ls[1], s_le[1], s_lenfreq);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const u32 r = df_make_table_wave<1>(s_lenfreq, 19, 7, s_lenenc, s_buf[0], s_w[0], s_tmp[0], s_lm7, &s_lm2, lane);
+        if (lane == 0) s_rk[2] = r;
+    }
     __syncthreads();
     if (tid == 0) {
         const u32 sym_n = s_n[0], off_n = s_n[1];
-        // create_custom_huffman_table :395-452
-        u32 lenfreq[19];
-        for (u32 i = 0; i < 19; ++i) lenfreq[i] = 0;
-        const u32 symk = df_tab_runs(s_sl, sym_n, s_ls[0], s_le[0], lenfreq);
-        const u32 offk = df_tab_runs(s_ol, off_n, s_ls[1], s_le[1], lenfreq);
-        u8 len_enc[19];
-        u32 *sb = s_buf[0], *sw = s_w[0];
-        u32 lm2 = 0;
-        const u32 len_enc_n = df_make_table(lenfreq, 19, 7, len_enc, sb, sw, s_tmp[0], s_lm7, &lm2);
-        const u32 len_map[19] = {3, 17, 15, 13, 11, 9, 7, 5, 4, 6, 8, 10, 12, 14, 16, 18, 0, 1, 2};
-        u8 len_tab[19];
+        const u32 symk = s_rk[0], offk = s_rk[1];
+        const u8 *len_enc = s_lenenc;
+        const u32 lm2 = s_lm2;
+        const u32 len_enc_n = s_rk[2];
+        // (small arrays with computed indices live in LDS: on the stack they cost the kernel a private segment)
+        u8 *len_map = s_lenmap, *len_tab = s_lentab;
+        { // {3, 17, 15, 13, 11, 9, 7, 5, 4, 6, 8, 10, 12, 14, 16, 18, 0, 1, 2}
+            const u64 m0 = 0x0507090B0D0F1103ull, m1 = 0x12100E0C0A080604ull;
+            for (u32 i = 0; i < 8; ++i) { len_map[i] = (u8)(m0 >> (8 * i)); len_map[8 + i] = (u8)(m1 >> (8 * i)); }
+            len_map[16] = 0; len_map[17] = 1; len_map[18] = 2;
+        }
         for (u32 i = 0; i < 19; ++i) len_tab[i] = 0;
         u32 len_count = 3;
         for (u32 i = 0; i < len_enc_n; ++i)
@@ -1365,10 +1517,11 @@ __global__ __launch_bounds__(kBThreads) void k_df_block(const u8 *__restrict__ i
         for (u32 i = 0; i < sym_n; ++i) if (s_sl[i]) hlit = i;
         hlit -= 256;
         for (u32 i = 0; i < off_n; ++i) if (s_ol[i]) hdist = i;
-        u16 lcode[19];
+        u16 *lcode = s_lcode;
         for (u32 i = 0; i < 19; ++i) lcode[i] = 0;
         df_make_codes(len_enc, len_enc_n, lcode);
-        LsbSink sk{s_hdr, 0, 0, 0};
+        LsbSink sk;
+        sk.w = s_hdr; sk.acc = 0; sk.nacc = 0; sk.widx = 0;
         sk.put(is_final ? 1u : 0u, 1);
         sk.put(2, 2);
         sk.put(hlit, 5);
