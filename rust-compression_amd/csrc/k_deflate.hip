@@ -1448,16 +1448,16 @@ __global__ __launch_bounds__(kBThreads) void k_df_block(const u8 *__restrict__ i
     if (tid < 32) s_of[tid] = 0;
     if (tid == 0) s_lm = 0;
     __syncthreads();
-    for (u64 q0 = b0; q0 < b1; q0 += kBThreads * 8) { // eight independent loads in flight per thread
-        u32 c[8], lit[8];
+    for (u64 q0 = b0; q0 < b1; q0 += kBThreads * 16) { // sixteen independent loads in flight per thread
+        u32 c[16], lit[16];
 #pragma unroll
-        for (u32 j = 0; j < 8; ++j) {
+        for (u32 j = 0; j < 16; ++j) {
             const u64 q = q0 + (u64)j * kBThreads + tid;
             c[j] = q < b1 ? code[q] : 0u;
             lit[j] = q < b1 ? in[q] : 0u; // (beside the code word, not behind it: one round trip per batch)
         }
 #pragma unroll
-        for (u32 j = 0; j < 8; ++j) {
+        for (u32 j = 0; j < 16; ++j) {
             if (!(c[j] & F_CODE)) continue;
             if (c[j] & F_REF) {
                 u32 lc, eb, ev, dc;
