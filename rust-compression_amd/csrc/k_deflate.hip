@@ -6,22 +6,25 @@
 //     192-214, 80-115), so the chain it walks from position p (search_dic :216-267) is "the earlier
 //     positions with the same hash, nearest first, while the summed distance is <= 0x8000, at most
 //     255 of them, stopping behind the first one that matches to the limit".  Sorting positions by
-//     hash (stable, two counting passes per 1 Mi-position chunk: k_df_shist / k_df_sscan /
-//     k_df_sscatter) puts every chain in one run; k_df_prev turns the run into the reference's
-//     `pos` array (distance to the previous member, 0 = none within the window).
+//     hash (stable, two counting passes per 512 Ki-position chunk: k_df_shist / k_df_sscan /
+//     k_df_sscatter) puts every chain in one run: the candidates of an entry are the entries in front of it.
 //   * The candidate kept is the first one with the greatest length (the comparison closure of
 //     deflate/encoder.rs:34-51 can only prefer a new candidate that is strictly longer, because a
-//     later candidate is always farther): k_df_match, one window of 32 KiB + tile staged in LDS.
+//     later candidate is always farther): k_df_match2 reads the candidates off the sorted order, a lane per
+//     entry, 16 text bytes per step out of LDS.  (Rounds 1 and 2 walked the chains: k_df_prev turned the runs into
+//     the reference's `pos` array, k_df_match walked it with a 32 KiB window staged in LDS; BZ_DF_MATCH=walk.)
 //   * LzssEncoder::encode (lzss/encoder.rs:132-184) looks at the matches of p, p+1, p+2 and
 //     advances by `len + lazy_index`: adv(p) is a function of p, the parse is the orbit of 0
 //     under p -> p + adv(p).  Orbits are found per 4096-position tile for every possible entry
 //     offset (an entry is < 260 past the tile start), composed 64 tiles at a time, resolved top
-//     down, and marked by pointer doubling (k_df_tile_tab / k_df_compose / k_df_resolve / k_df_mark).
+//     down, and marked: k_df_tile_orbit / k_df_compose / k_df_resolve / k_df_mark2 (every entry is followed
+//     until it lands on the tile's canonical orbit; rounds 1 and 2 doubled pointers twelve times:
+//     k_df_tile_tab / k_df_mark, BZ_DF_PARSE=doubling).
 //   * InflaterInner::next (deflate/encoder.rs:577-636) closes a block when the next code would
 //     take it past 0xFFFF bytes: the next block starts at the last code start <= start + 0xFFFF
 //     (k_df_cuts).  write_block (:454-547) then chooses stored / fixed / dynamic from the block's
 //     symbol counts: k_df_block replays make_table (huffman/cano_huff_table.rs, the serial heap
-//     procedure and the package-merge fallback, one lane per table) and the code-length run
+//     procedure -- in the registers of a wave -- and the package-merge fallback) and the code-length run
 //     coding (:318-452) exactly; k_df_emit writes the bits LSB first (bitio/writer.rs, Right).
 #include <cstdlib>
 #include <cstring>
