@@ -20,6 +20,7 @@ struct DfWorkspace {
     double t_stage[6] = {0, 0, 0, 0, 0, 0}; // chains, matches, parse, blocks, emit, total
     u64 stats[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // blocks, stored, fixed, dynamic, limited tables, stream bytes, dynamic w/o distances
     hipEvent_t ev[7] = {};
+    hipEvent_t evq[kCutPieces + 1] = {}; // the pieces of the block chain beside the marking kernel
     bool ev_ready = false;
     std::vector<DfBlock> h_blocks;
     std::vector<u64> h_bstart;
@@ -32,8 +33,10 @@ void df_workspace_free(DfWorkspace *w)
                      &w->bstart, &w->nb, &w->blocks, &w->lens, &w->hdr, &w->lm, &w->total, &w->stream, &w->asum, &w->bsum,
                      &w->crc};
     for (DevBuf *b : all) b->release();
-    if (w->ev_ready)
+    if (w->ev_ready) {
         for (hipEvent_t e : w->ev) (void)hipEventDestroy(e);
+        for (hipEvent_t e : w->evq) (void)hipEventDestroy(e);
+    }
     delete w;
 }
 
@@ -123,6 +126,7 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     hipStream_t st = g->st;
     if (!w->ev_ready) {
         for (hipEvent_t &e : w->ev) HIPCHK(hipEventCreate(&e));
+        for (hipEvent_t &e : w->evq) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         w->ev_ready = true;
     }
     // history in front of the segment: the last 32 KiB of (dictionary, then the stream so far)
@@ -213,12 +217,24 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
               : df_launch_match2(st, d_all, nall, w->vals_out.as<u32>(), Mall)) != 0)
         return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[2], st));
+    if (seg.skip > 2 || (seg.skip && seg.dl0)) return BZ_E_PARAM;
+    // BZ_DF_CUTS=after: the chain of block starts behind the marking kernel (rounds 1 and 2) instead of in pieces
+    // beside it on the engine's second stream
+    const char *cv = getenv("BZ_DF_CUTS");
+    const bool beside = n != 0 && !doubling && !(cv && strcmp(cv, "after") == 0); // (no tiles, no pieces)
+    DfPiecewiseCuts pc;
+    pc.st2 = g->st2;
+    for (u32 i = 0; i <= kCutPieces; ++i) pc.ev[i] = w->evq[i];
+    pc.bstart = w->bstart.as<u64>();
+    pc.nb = w->nb.as<u32>();
+    pc.cap = bcap; pc.dl0 = seg.dl0; pc.first = seg.skip;
+    pc.state = w->total.as<u64>() + 2; // (two spare words of the 64-byte buffer that takes the stream's bit count)
     if (df_launch_parse(st, M, n, step, tabs.data(), ents.data(), counts.data(), nlevels, code, w->bitmap.as<u64>(),
-                        doubling ? nullptr : w->canon.as<u64>()) != 0)
+                        doubling ? nullptr : w->canon.as<u64>(), beside ? &pc : nullptr) != 0)
         return BZ_E_UNEXPECTED;
     HIPCHK(hipEventRecord(w->ev[3], st));
-    if (seg.skip > 2 || (seg.skip && seg.dl0)) return BZ_E_PARAM;
-    if (df_launch_cuts(st, n, w->bitmap.as<u64>(), w->bstart.as<u64>(), w->nb.as<u32>(), bcap, seg.dl0, seg.skip) != 0) return BZ_E_UNEXPECTED;
+    if (!beside && df_launch_cuts(st, n, w->bitmap.as<u64>(), w->bstart.as<u64>(), w->nb.as<u32>(), bcap, seg.dl0, seg.skip) != 0)
+        return BZ_E_UNEXPECTED;
     u64 consumed = n;
     u32 next_skip = 0;
     if (seg.more) {

@@ -60,8 +60,20 @@ u32 df_chunks(u64 n); // sort chunks of an input of n bytes
 int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *v0, u32 *s, u16 *hs, u32 *hist, u32 *tbase, u32 *pe);
 int df_launch_match(hipStream_t st, const u8 *in, const u32 *pe, u64 n, u32 *M);
 int df_launch_match2(hipStream_t st, const u8 *in, u64 n, const u32 *s, u32 *M);
+// the block chain taken in pieces beside the marking of the tiles (df_launch_parse with canon): a second stream,
+// kCutPieces + 1 events, the arguments of df_launch_cuts and two words of device memory for the chain's state
+constexpr u32 kCutPieces = 4;
+struct DfPiecewiseCuts {
+    hipStream_t st2;
+    hipEvent_t ev[kCutPieces + 1];
+    u64 *bstart;
+    u32 *nb;
+    u32 cap, dl0, first;
+    u64 *state;
+};
+// pc != nullptr (needs canon): the block starts are made on the way (no df_launch_cuts afterwards)
 int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *tabs, u16 *const *ents, const u32 *counts,
-                    u32 nlevels, u32 *code, u64 *bm, u64 *canon);
+                    u32 nlevels, u32 *code, u64 *bm, u64 *canon, const DfPiecewiseCuts *pc);
 // dl0: decompress_len carried into the segment (0 unless it follows an Action::Flush); last_is_final: the
 // segment ends the stream (Finish) rather than being flushed.  `in` is the segment's first byte; the dl0 bytes
 // in front of it must be readable (a stored first block copies them).  The block chain (df_launch_cuts) is its

@@ -961,17 +961,18 @@ __global__ __launch_bounds__(kOrbThreads) void k_df_tile_orbit(const u16 *__rest
 __global__ __launch_bounds__(kMark2Threads) void k_df_mark2(const u16 *__restrict__ step, const u32 *__restrict__ M,
                                                            const u16 *__restrict__ ent, const u16 *__restrict__ tab,
                                                            const u64 *__restrict__ canon, u64 n, u32 *__restrict__ code,
-                                                           u64 *__restrict__ bm)
+                                                           u64 *__restrict__ bm, u32 tile0)
 {
     __shared__ __attribute__((aligned(16))) u16 s_step[kPTile];
     __shared__ u64 s_C[64], s_mk[64];
     __shared__ u8 s_type[kPTile + 264];
     __shared__ u32 s_exitp, s_mw;
     const u32 tid = threadIdx.x;
-    const u64 t0 = (u64)blockIdx.x * kPTile;
-    const u32 entry = ent[blockIdx.x];
+    const u32 tile = tile0 + blockIdx.x; // (the tiles are marked in pieces: the block chain runs beside the next piece)
+    const u64 t0 = (u64)tile * kPTile;
+    const u32 entry = ent[tile];
     df_stage_steps(step, n, t0, tid, kMark2Threads, s_step);
-    if (tid < 64) { s_C[tid] = canon[(u64)blockIdx.x * 64 + tid]; s_mk[tid] = 0; }
+    if (tid < 64) { s_C[tid] = canon[(u64)tile * 64 + tid]; s_mk[tid] = 0; }
     for (u32 k = tid; k < kPTile + 264; k += kMark2Threads) s_type[k] = 0;
     __syncthreads();
     if (tid == 0) { // from the entry to the first position on the canonical orbit (or out of the tile)
@@ -983,7 +984,7 @@ __global__ __launch_bounds__(kMark2Threads) void k_df_mark2(const u16 *__restric
             cur += df_adv_of(s_step[cur]);
         }
         s_mw = mw;
-        s_exitp = mw < 64 ? (u32)tab[(u64)blockIdx.x * kEntries] + kPTile : cur; // (entry offset 0 is on the canonical orbit)
+        s_exitp = mw < 64 ? (u32)tab[(u64)tile * kEntries] + kPTile : cur; // (entry offset 0 is on the canonical orbit)
     }
     __syncthreads();
     if (tid < 64 && tid > s_mw) s_mk[tid] = s_C[tid]; // behind the meeting point: the canonical orbit
@@ -1028,20 +1029,29 @@ constexpr u32 kCutWords = (257 * kCutGroup + 64) / 64 + 3;
 // bytes in front of the segment -- the chain starts at the (negative) position -dl0.
 // first: the first block starts at this code start (not 0 when a part of a long stream begins with the literals of a
 // step whose reference opens its first block; they went out with the part before).
+// The chain can be taken in pieces (round 3: beside the marking kernel, which runs over the tiles in pieces too):
+// a call goes on while the window's end b + 0xFFFF lies in front of `limit` -- the code-start bits in front of
+// `limit` are final --, keeps where it stands in state[0..1] (b, blocks so far) and picks up there when `resume`
+// is set; the call with limit >= n ends the chain.
 __global__ __launch_bounds__(256) void k_df_cuts(const u64 *__restrict__ bm, u64 n, u64 *__restrict__ bstart,
-                                                 u32 *__restrict__ nb_out, u32 cap, u32 dl0, u32 first)
+                                                 u32 *__restrict__ nb_out, u32 cap, u32 dl0, u32 first, u64 limit,
+                                                 u32 resume, u64 *__restrict__ state)
 {
     __shared__ u64 s_bm[kCutGroup][kCutWords];
     __shared__ i64 s_b;
     __shared__ u32 s_k, s_done;
     const u32 tid = threadIdx.x;
     const u64 nwords = (n + 63) / 64;
-    if (tid == 0) { s_b = (i64)first - (i64)dl0; s_k = 0; s_done = 0; if (cap) bstart[0] = first; }
+    if (tid == 0) {
+        if (resume) { s_b = (i64)state[0]; s_k = (u32)state[1]; s_done = (u32)(state[1] >> 32); }
+        else { s_b = (i64)first - (i64)dl0; s_k = 0; s_done = 0; if (cap) bstart[0] = first; }
+    }
     __syncthreads();
+    const u64 lim = limit < n ? limit : n;
     for (;;) {
         const i64 b = s_b;
         const u64 x = (u64)(b + (i64)kBlockMax); // >= 0: dl0 <= 0xFFFF
-        if (x >= n || s_done) break;
+        if (x >= lim || s_done) break;
         // every region padded to kCutWords words ending at its highest word: all loads of a group are in
         // flight together (one memory round trip per kCutGroup hops)
         constexpr u32 kPer = (kCutGroup * kCutWords + 255) / 256;
@@ -1065,7 +1075,7 @@ __global__ __launch_bounds__(256) void k_df_cuts(const u64 *__restrict__ bm, u64
             u32 k = s_k;
             for (u32 j = 0; j < kCutGroup; ++j) {
                 const u64 xj = (u64)(cur + (i64)kBlockMax);
-                if (xj >= n) break;
+                if (xj >= lim) break;
                 const i64 wlo = (i64)((x + (u64)j * kBlockMax) >> 6) - (i64)(kCutWords - 1); // word of s_bm[j][0]
                 i64 w = (i64)(xj >> 6) - wlo;
                 u64 m = s_bm[j][w] & (~0ull >> (63 - (u32)(xj & 63)));
@@ -1081,11 +1091,16 @@ __global__ __launch_bounds__(256) void k_df_cuts(const u64 *__restrict__ bm, u64
         __syncthreads();
     }
     if (tid == 0) {
-        const u32 k = s_k + 1; // blocks
-        if (s_done == 2) *nb_out = 0xFFFFFFFFu;
-        else {
-            if (k < cap + 1) bstart[k] = n;
-            *nb_out = k;
+        if (limit < n && s_done != 2) { // not the last piece: remember where the chain stands
+            state[0] = (u64)s_b;
+            state[1] = (u64)s_k | ((u64)s_done << 32);
+        } else {
+            const u32 k = s_k + 1; // blocks
+            if (s_done == 2) *nb_out = 0xFFFFFFFFu;
+            else {
+                if (k < cap + 1) bstart[k] = n;
+                *nb_out = k;
+            }
         }
     }
 }
@@ -1894,7 +1909,7 @@ int df_launch_match(hipStream_t st, const u8 *in, const u32 *pe, u64 n, u32 *M)
 // canon: counts[0] * 64 words for the tiles' canonical orbits (k_df_tile_orbit / k_df_mark2), or nullptr for the
 // doubling kernels of rounds 1 and 2 (k_df_tile_tab / k_df_mark)
 int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *tabs, u16 *const *ents, const u32 *counts,
-                    u32 nlevels, u32 *code, u64 *bm, u64 *canon)
+                    u32 nlevels, u32 *code, u64 *bm, u64 *canon, const DfPiecewiseCuts *pc)
 {
     if (!n) return 0;
     DFCHK(hipMemsetAsync(bm, 0, ((n + 63) / 64 + 2) * sizeof(u64), st));
@@ -1907,14 +1922,32 @@ int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *
     for (u32 l = nlevels - 1; l >= 1; --l)
         hipLaunchKernelGGL(k_df_resolve, dim3((counts[l] + 63) / 64), dim3(64), 0, st, tabs[l - 1], counts[l - 1], ents[l],
                            counts[l], ents[l - 1]);
-    if (canon) hipLaunchKernelGGL(k_df_mark2, dim3(counts[0]), dim3(kMark2Threads), 0, st, step, M, ents[0], tabs[0], canon, n, code, bm);
-    else hipLaunchKernelGGL(k_df_mark, dim3(counts[0]), dim3(kMarkThreads), 0, st, step, M, ents[0], n, code, bm);
+    if (!canon) hipLaunchKernelGGL(k_df_mark, dim3(counts[0]), dim3(kMarkThreads), 0, st, step, M, ents[0], n, code, bm);
+    else if (!pc) hipLaunchKernelGGL(k_df_mark2, dim3(counts[0]), dim3(kMark2Threads), 0, st, step, M, ents[0], tabs[0], canon, n, code, bm, 0u);
+    else {
+        // The tiles are marked in pieces, and the chain of block starts -- one workgroup, 16 385 dependent hops per GiB,
+        // 4 ms on its own -- runs on a second stream beside the marking of the NEXT piece: a piece of the chain goes
+        // as far as the bits of the pieces marked so far are final (k_df_cuts: limit).  Plain stream dependencies,
+        // nothing waits on the device for anything.
+        const u32 ntiles = counts[0], np = ntiles < kCutPieces * 64 ? 1u : kCutPieces;
+        for (u32 i = 0; i < np; ++i) {
+            const u32 lo = (u32)((u64)ntiles * i / np), hi = (u32)((u64)ntiles * (i + 1) / np);
+            hipLaunchKernelGGL(k_df_mark2, dim3(hi - lo), dim3(kMark2Threads), 0, st, step, M, ents[0], tabs[0], canon, n, code, bm, lo);
+            DFCHK(hipEventRecord(pc->ev[i], st));
+            DFCHK(hipStreamWaitEvent(pc->st2, pc->ev[i], 0));
+            const u64 limit = i + 1 == np ? ~0ull : (u64)hi * kPTile;
+            hipLaunchKernelGGL(k_df_cuts, dim3(1), dim3(256), 0, pc->st2, bm, n, pc->bstart, pc->nb, pc->cap, pc->dl0, pc->first, limit,
+                               i ? 1u : 0u, pc->state);
+        }
+        DFCHK(hipEventRecord(pc->ev[kCutPieces], pc->st2));
+        DFCHK(hipStreamWaitEvent(st, pc->ev[kCutPieces], 0));
+    }
     return 0;
 }
 
 int df_launch_cuts(hipStream_t st, u64 n, u64 *bm, u64 *bstart, u32 *nb, u32 cap, u32 dl0, u32 first)
 {
-    hipLaunchKernelGGL(k_df_cuts, dim3(1), dim3(256), 0, st, bm, n, bstart, nb, cap, dl0, first);
+    hipLaunchKernelGGL(k_df_cuts, dim3(1), dim3(256), 0, st, bm, n, bstart, nb, cap, dl0, first, ~0ull, 0u, (u64 *)nullptr);
     return 0;
 }
 

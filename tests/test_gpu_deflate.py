@@ -251,6 +251,24 @@ def test_match_kernels_on_long_and_tied_candidates(pkg, oracle, eng, name, data,
     monkeypatch.setenv("BZ_DF_MATCH", "walk")
     monkeypatch.setenv("BZ_DF_PARSE", "doubling")  # (and the parse by pointer doubling instead of canonical orbits)
     check(pkg, oracle, eng, data)
+    monkeypatch.delenv("BZ_DF_MATCH")
+    monkeypatch.delenv("BZ_DF_PARSE")
+    monkeypatch.setenv("BZ_DF_CUTS", "after")  # (the block chain behind the marking kernel instead of beside it)
+    check(pkg, oracle, eng, data)
+
+
+@pytest.mark.parametrize("n", [1 << 20, (1 << 20) + 4096 * 3 + 17, 3 * (1 << 20) + 1234])
+def test_block_chain_in_pieces(pkg, oracle, eng, n, monkeypatch):
+    """from 256 tiles on the block chain runs in four pieces beside the marking kernel (k_df_cuts resumes where the
+    bits are final): same blocks as the chain in one piece behind it"""
+    rnd = random.Random(n)
+    words = [bytes(rnd.choice(b"abcdefghijklmnop") for _ in range(rnd.randint(1, 7))) for _ in range(200)]
+    d = b" ".join(rnd.choice(words) for _ in range(n // 3))[:n]
+    d = d[:n // 2] + bytes(rnd.getrandbits(8) for _ in range(70000)) + d[n // 2 + 70000:]  # (stored blocks in the middle)
+    assert len(d) == n
+    got = check(pkg, oracle, eng, d)
+    monkeypatch.setenv("BZ_DF_CUTS", "after")
+    assert check(pkg, oracle, eng, d) == got
 
 
 def test_empty_inputs_in_containers(pkg, oracle):
