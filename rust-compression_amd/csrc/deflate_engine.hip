@@ -20,7 +20,7 @@ struct DfWorkspace {
     double t_stage[6] = {0, 0, 0, 0, 0, 0}; // chains, matches, parse, blocks, emit, total
     u64 stats[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // blocks, stored, fixed, dynamic, limited tables, stream bytes, dynamic w/o distances
     hipEvent_t ev[7] = {};
-    hipEvent_t evq[kCutPieces + 1] = {}; // the pieces of the block chain beside the marking kernel
+    hipEvent_t evq[2 * kCutPieces + 1] = {}; // the pieces of the block chain beside the marking kernel
     bool ev_ready = false;
     std::vector<DfBlock> h_blocks;
     std::vector<u64> h_bstart;
@@ -228,7 +228,13 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     pc.bstart = w->bstart.as<u64>();
     pc.nb = w->nb.as<u32>();
     pc.cap = bcap; pc.dl0 = seg.dl0; pc.first = seg.skip;
-    pc.state = w->total.as<u64>() + 2; // (two spare words of the 64-byte buffer that takes the stream's bit count)
+    pc.state = w->total.as<u64>() + 2; // (spare words of the 64-byte buffer that takes the stream's bit count)
+    // the blocks of a piece follow the chain's piece at once -- unless the host has to look at the chain first (a part
+    // of a long stream, a wrapper ending under Action::Run: it drops blocks at the end)
+    const bool blocks_follow = beside && !seg.more && !seg.run;
+    pc.kdone = blocks_follow ? w->total.as<u32>() + 8 : nullptr;
+    for (u32 i = 0; i < kCutPieces; ++i) pc.evc[i] = w->evq[kCutPieces + 1 + i];
+    if (beside) HIPCHK(hipMemsetAsync(w->total.p, 0, 64, st));
     if (df_launch_parse(st, M, n, step, tabs.data(), ents.data(), counts.data(), nlevels, code, w->bitmap.as<u64>(),
                         doubling ? nullptr : w->canon.as<u64>(), beside ? &pc : nullptr) != 0)
         return BZ_E_UNEXPECTED;
@@ -286,9 +292,18 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
         HIPCHK(hipMemcpyAsync(w->nb.p, &keep, 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st)); // (`keep` lives on this stack frame)
     }
-    if (df_launch_blocks(st, d_in, code, w->bstart.as<u64>(), w->nb.as<u32>(), bcap, w->blocks.as<DfBlock>(),
-                         w->lens.as<u8>(), w->hdr.as<u32>(), w->lm.as<u32>(), w->total.as<u64>(), seg.dl0,
-                         (seg.final && !seg.more && !seg.run) ? 1u : 0u, seg.bit0) != 0)
+    if (blocks_follow) {
+        const u32 np = df_cut_pieces(ntiles);
+        for (u32 i = 0; i < np; ++i) {
+            HIPCHK(hipStreamWaitEvent(st, pc.evc[i], 0));
+            if (df_launch_blocks_piece(st, d_in, code, w->bstart.as<u64>(), w->nb.as<u32>(), bcap, w->blocks.as<DfBlock>(), w->lens.as<u8>(),
+                                       w->hdr.as<u32>(), w->lm.as<u32>(), seg.dl0, seg.final ? 1u : 0u, pc.kdone + i, i + 1 == np ? 1u : 0u) != 0)
+                return BZ_E_UNEXPECTED;
+        }
+        if (df_launch_block_offsets(st, w->blocks.as<DfBlock>(), w->nb.as<u32>(), w->total.as<u64>(), seg.bit0) != 0) return BZ_E_UNEXPECTED;
+    } else if (df_launch_blocks(st, d_in, code, w->bstart.as<u64>(), w->nb.as<u32>(), bcap, w->blocks.as<DfBlock>(),
+                                w->lens.as<u8>(), w->hdr.as<u32>(), w->lm.as<u32>(), w->total.as<u64>(), seg.dl0,
+                                (seg.final && !seg.more && !seg.run) ? 1u : 0u, seg.bit0) != 0)
         return BZ_E_UNEXPECTED;
     if (seg.bit0) HIPCHK(hipMemcpyAsync(w->stream.p, &seg.carry_byte, 1, hipMemcpyHostToDevice, st)); // (the stream was cleared above)
     HIPCHK(hipEventRecord(w->ev[4], st));

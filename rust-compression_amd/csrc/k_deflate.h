@@ -70,7 +70,16 @@ struct DfPiecewiseCuts {
     u32 *nb;
     u32 cap, dl0, first;
     u64 *state;
+    // kdone != nullptr: piece i of the chain leaves the number of blocks it has closed in kdone[i + 1] (kdone[0] is
+    // 0) and records evc[i]; the caller launches the blocks of every piece behind its event and df_launch_parse does
+    // not make `st` wait for the chain
+    u32 *kdone;
+    hipEvent_t evc[kCutPieces];
 };
+u32 df_cut_pieces(u32 ntiles);
+int df_launch_blocks_piece(hipStream_t st, const u8 *in, const u32 *code, u64 *bstart, u32 *nb, u32 cap, DfBlock *blocks, u8 *lens,
+                           u32 *hdr, u32 *lm_scratch, u32 dl0, u32 last_is_final, const u32 *kr, u32 piece_last);
+int df_launch_block_offsets(hipStream_t st, DfBlock *blocks, const u32 *nb, u64 *total_bits, u32 bit0);
 // pc != nullptr (needs canon): the block starts are made on the way (no df_launch_cuts afterwards)
 int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *tabs, u16 *const *ents, const u32 *counts,
                     u32 nlevels, u32 *code, u64 *bm, u64 *canon, const DfPiecewiseCuts *pc);

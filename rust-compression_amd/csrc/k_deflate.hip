@@ -1035,7 +1035,7 @@ constexpr u32 kCutWords = (257 * kCutGroup + 64) / 64 + 3;
 // is set; the call with limit >= n ends the chain.
 __global__ __launch_bounds__(256) void k_df_cuts(const u64 *__restrict__ bm, u64 n, u64 *__restrict__ bstart,
                                                  u32 *__restrict__ nb_out, u32 cap, u32 dl0, u32 first, u64 limit,
-                                                 u32 resume, u64 *__restrict__ state)
+                                                 u32 resume, u64 *__restrict__ state, u32 *__restrict__ kdone)
 {
     __shared__ u64 s_bm[kCutGroup][kCutWords];
     __shared__ i64 s_b;
@@ -1094,6 +1094,7 @@ __global__ __launch_bounds__(256) void k_df_cuts(const u64 *__restrict__ bm, u64
         if (limit < n && s_done != 2) { // not the last piece: remember where the chain stands
             state[0] = (u64)s_b;
             state[1] = (u64)s_k | ((u64)s_done << 32);
+            if (kdone) *kdone = s_k; // blocks 0 .. s_k - 1 have both their ends: k_df_block can take them
         } else {
             const u32 k = s_k + 1; // blocks
             if (s_done == 2) *nb_out = 0xFFFFFFFFu;
@@ -1101,6 +1102,7 @@ __global__ __launch_bounds__(256) void k_df_cuts(const u64 *__restrict__ bm, u64
                 if (k < cap + 1) bstart[k] = n;
                 *nb_out = k;
             }
+            if (kdone) *kdone = s_done == 2 ? 0xFFFFFFFFu : k;
         }
     }
 }
@@ -1443,7 +1445,7 @@ __global__ __launch_bounds__(kBThreads) void k_df_block(const u8 *__restrict__ i
                                                         const u64 *__restrict__ bstart, const u32 *__restrict__ nb_p,
                                                         DfBlock *__restrict__ blocks, u8 *__restrict__ lens,
                                                         u32 *__restrict__ hdr, u32 *__restrict__ lm_scratch, u32 dl0,
-                                                        u32 last_is_final)
+                                                        u32 last_is_final, const u32 *__restrict__ kr, u32 piece_last)
 {
     __shared__ u32 s_sf[288], s_of[32];
     __shared__ u32 s_buf[2][2 * 288], s_w[2][288];
@@ -1458,8 +1460,17 @@ __global__ __launch_bounds__(kBThreads) void k_df_block(const u8 *__restrict__ i
     __shared__ u16 s_lcode[19];
     static_assert(kBThreads >= 128, "a wave for each of the block's two tables");
     const u32 tid = threadIdx.x, k = blockIdx.x;
-    const u32 nblocks = *nb_p;
-    if (nblocks == 0xFFFFFFFFu || k >= nblocks) return;
+    // kr: the blocks of this launch are kr[0] .. kr[1] - 1 (the chain of block starts is still running for the blocks
+    // behind them; only the last piece knows the number of blocks)
+    u32 nblocks;
+    if (kr) {
+        const u32 lo = kr[0], hi = kr[1];
+        if (hi == 0xFFFFFFFFu || k < lo || k >= hi) return;
+        nblocks = piece_last ? *nb_p : 0xFFFFFFFEu;
+    } else {
+        nblocks = *nb_p;
+        if (nblocks == 0xFFFFFFFFu || k >= nblocks) return;
+    }
     const u64 b0 = bstart[k], b1 = bstart[k + 1];
     const bool is_final = (k + 1 == nblocks) && last_is_final; // (a flushed segment ends with a non-final block)
     for (u32 i = tid; i < 288; i += kBThreads) s_sf[i] = 0;
@@ -1929,7 +1940,7 @@ int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *
         // 4 ms on its own -- runs on a second stream beside the marking of the NEXT piece: a piece of the chain goes
         // as far as the bits of the pieces marked so far are final (k_df_cuts: limit).  Plain stream dependencies,
         // nothing waits on the device for anything.
-        const u32 ntiles = counts[0], np = ntiles < kCutPieces * 64 ? 1u : kCutPieces;
+        const u32 ntiles = counts[0], np = df_cut_pieces(ntiles);
         for (u32 i = 0; i < np; ++i) {
             const u32 lo = (u32)((u64)ntiles * i / np), hi = (u32)((u64)ntiles * (i + 1) / np);
             hipLaunchKernelGGL(k_df_mark2, dim3(hi - lo), dim3(kMark2Threads), 0, st, step, M, ents[0], tabs[0], canon, n, code, bm, lo);
@@ -1937,17 +1948,36 @@ int df_launch_parse(hipStream_t st, const u32 *M, u64 n, u16 *step, u16 *const *
             DFCHK(hipStreamWaitEvent(pc->st2, pc->ev[i], 0));
             const u64 limit = i + 1 == np ? ~0ull : (u64)hi * kPTile;
             hipLaunchKernelGGL(k_df_cuts, dim3(1), dim3(256), 0, pc->st2, bm, n, pc->bstart, pc->nb, pc->cap, pc->dl0, pc->first, limit,
-                               i ? 1u : 0u, pc->state);
+                               i ? 1u : 0u, pc->state, pc->kdone ? pc->kdone + i + 1 : (u32 *)nullptr);
+            if (pc->kdone) DFCHK(hipEventRecord(pc->evc[i], pc->st2)); // (the caller lets the blocks of this piece follow)
         }
-        DFCHK(hipEventRecord(pc->ev[kCutPieces], pc->st2));
-        DFCHK(hipStreamWaitEvent(st, pc->ev[kCutPieces], 0));
+        if (!pc->kdone) {
+            DFCHK(hipEventRecord(pc->ev[kCutPieces], pc->st2));
+            DFCHK(hipStreamWaitEvent(st, pc->ev[kCutPieces], 0));
+        }
     }
     return 0;
 }
 
 int df_launch_cuts(hipStream_t st, u64 n, u64 *bm, u64 *bstart, u32 *nb, u32 cap, u32 dl0, u32 first)
 {
-    hipLaunchKernelGGL(k_df_cuts, dim3(1), dim3(256), 0, st, bm, n, bstart, nb, cap, dl0, first, ~0ull, 0u, (u64 *)nullptr);
+    hipLaunchKernelGGL(k_df_cuts, dim3(1), dim3(256), 0, st, bm, n, bstart, nb, cap, dl0, first, ~0ull, 0u, (u64 *)nullptr, (u32 *)nullptr);
+    return 0;
+}
+
+u32 df_cut_pieces(u32 ntiles) { return ntiles < kCutPieces * 64 ? 1u : kCutPieces; }
+
+// the blocks kr[0] .. kr[1] - 1 (their ends are known: a piece of the chain has passed them)
+int df_launch_blocks_piece(hipStream_t st, const u8 *in, const u32 *code, u64 *bstart, u32 *nb, u32 cap, DfBlock *blocks, u8 *lens,
+                           u32 *hdr, u32 *lm_scratch, u32 dl0, u32 last_is_final, const u32 *kr, u32 piece_last)
+{
+    hipLaunchKernelGGL(k_df_block, dim3(cap), dim3(kBThreads), 0, st, in, code, bstart, nb, blocks, lens, hdr, lm_scratch, dl0,
+                       last_is_final, kr, piece_last);
+    return 0;
+}
+int df_launch_block_offsets(hipStream_t st, DfBlock *blocks, const u32 *nb, u64 *total_bits, u32 bit0)
+{
+    hipLaunchKernelGGL(k_df_offsets, dim3(1), dim3(256), 0, st, blocks, nb, total_bits, bit0);
     return 0;
 }
 
@@ -1955,7 +1985,7 @@ int df_launch_blocks(hipStream_t st, const u8 *in, const u32 *code, u64 *bstart,
                      DfBlock *blocks, u8 *lens, u32 *hdr, u32 *lm_scratch, u64 *total_bits, u32 dl0, u32 last_is_final, u32 bit0)
 {
     hipLaunchKernelGGL(k_df_block, dim3(cap), dim3(kBThreads), 0, st, in, code, bstart, nb, blocks, lens, hdr, lm_scratch, dl0,
-                       last_is_final);
+                       last_is_final, (const u32 *)nullptr, 1u);
     hipLaunchKernelGGL(k_df_offsets, dim3(1), dim3(256), 0, st, blocks, nb, total_bits, bit0);
     return 0;
 }
