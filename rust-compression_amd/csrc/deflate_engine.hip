@@ -175,7 +175,7 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     if ((rc = w->lens.ensure((size_t)bcap * 320)) != BZ_OK) return rc;
     if ((rc = w->hdr.ensure((size_t)bcap * kHdrWords * 4)) != BZ_OK) return rc;
     if ((rc = w->lm.ensure((size_t)bcap * kDfLmWords * 4)) != BZ_OK) return rc;
-    if ((rc = w->total.ensure(64)) != BZ_OK) return rc;
+    if ((rc = w->total.ensure(128)) != BZ_OK) return rc; // the stream's bit count, the chain's state, its pieces' block counts
     const size_t bound = df_encode_bound(n);
     if ((rc = w->stream.ensure(bound + 64)) != BZ_OK) return rc;
     const u64 ntot = seg.prior + n; // bytes the container's checksums cover
@@ -234,7 +234,7 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
     const bool blocks_follow = beside && !seg.more && !seg.run;
     pc.kdone = blocks_follow ? w->total.as<u32>() + 8 : nullptr;
     for (u32 i = 0; i < kCutPieces; ++i) pc.evc[i] = w->evq[kCutPieces + 1 + i];
-    if (beside) HIPCHK(hipMemsetAsync(w->total.p, 0, 64, st));
+    if (beside) HIPCHK(hipMemsetAsync(w->total.p, 0, 128, st));
     if (df_launch_parse(st, M, n, step, tabs.data(), ents.data(), counts.data(), nlevels, code, w->bitmap.as<u64>(),
                         doubling ? nullptr : w->canon.as<u64>(), beside ? &pc : nullptr) != 0)
         return BZ_E_UNEXPECTED;
