@@ -1536,7 +1536,7 @@ BZO_EXPORT size_t bzo_decode_buffer(const uint8_t *in, size_t n, uint8_t *out, s
     size_t o = 0;
     int st = 0;
     for (;;) {
-        uint8_t b;
+        uint8_t b = 0;
         int rc = dec_next(&d, &b);
         if (rc == 0) break;
         if (rc < 0) { st = rc; break; }
