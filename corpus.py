@@ -113,6 +113,56 @@ def corpus_on_device(total_bytes, device, first_chapter=0):
     return out
 
 
+def chapters(ks, workers=8):
+    """{k: chapter(k)} for the chapter numbers `ks`, generated side by side in fresh processes (a chapter is ~3 s of
+    Python; spawned, not forked: the caller may have initialised a GPU)."""
+    ks = sorted(set(ks))
+    if len(ks) <= 1 or workers <= 1:
+        return {k: chapter(k) for k in ks}
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    with ProcessPoolExecutor(min(workers, len(ks)), mp_context=mp.get_context("spawn")) as ex:
+        return dict(zip(ks, ex.map(chapter, ks)))
+
+
+def corpus_numpy(total_bytes, first_chapter=0, workers=8):
+    """The corpus as one numpy uint8 array (no second copy: 8 GiB stay 8 GiB)."""
+    out = np.empty(total_bytes, dtype=np.uint8)
+    ngib = (total_bytes + (1 << 30) - 1) >> 30
+    chs = chapters([first_chapter + g for g in range(ngib)], workers)
+    for g in range(ngib):
+        ch = np.frombuffer(chs[first_chapter + g], dtype=np.uint8)
+        lo, hi = g << 30, min(total_bytes, (g + 1) << 30)
+        for p in range(lo, hi, len(ch)):
+            k = min(len(ch), hi - p)
+            out[p:p + k] = ch[:k]
+    return out
+
+
+def slice_chapters(off, nbytes, first_chapter=0):
+    """chapter numbers the corpus bytes [off, off + nbytes) are made of"""
+    if nbytes <= 0:
+        return []
+    return [first_chapter + g for g in range(off >> 30, ((off + nbytes - 1) >> 30) + 1)]
+
+
+def slice_on_device(off, nbytes, device, first_chapter=0, chs=None):
+    """Bytes [off, off + nbytes) of the corpus as a torch uint8 tensor on `device`, without the rest of it."""
+    import torch
+    parts = []
+    end = off + nbytes
+    for g in range(off >> 30, ((end - 1) >> 30) + 1 if nbytes else 0):
+        raw = chs[first_chapter + g] if chs is not None else chapter(first_chapter + g)
+        ch = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        lo, hi = max(off, g << 30), min(end, (g + 1) << 30)
+        first = (lo - (g << 30)) % ch.numel()
+        reps = (first + (hi - lo) + ch.numel() - 1) // ch.numel()
+        parts.append(ch.repeat(reps)[first:first + (hi - lo)])
+    out = (parts[0].clone() if len(parts) == 1 else torch.cat(parts)) if parts else torch.empty(0, dtype=torch.uint8, device=device)
+    torch.cuda.synchronize(device)
+    return out
+
+
 def stress_t2(total_bytes):
     """Stress variant T2: a 4 KiB paragraph repeated -- deep LCPs."""
     para = chapter(0, 1 << 16)[:4096]

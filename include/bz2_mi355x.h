@@ -252,6 +252,21 @@ int bz_gpu_encode_sharded(bz_gpu_engine *g, int level, const void *d_in, size_t 
                           void *d_gather, size_t gather_cap_words, void *d_out, size_t cap,
                           size_t *out_len);
 
+/* The same call for a rank that holds only a WINDOW of the input (a rank of a large job need not back the bytes it
+ * never reads): d_window[0 .. window_bytes) are the input bytes [window_off, window_off + window_bytes) of the n-byte
+ * input (d_window 16-byte aligned, window_off a multiple of 16).  The window must hold the rank's slab, the bytes of
+ * the block that straddles its left edge (from the start of their 4 KiB tile on) and 16 bytes behind the slab (or all
+ * there are): bz_shard_window returns one that always does -- the slab plus bz_shard_halo_bytes(level) in front (a
+ * level-9 block covers at most 899981 * 255 / 5 = 45.9 MB of input) and one tile behind.  A window that turns out
+ * too short (the cut handed over by the rank before lies in front of it) makes every rank return BZ_E_CAPACITY.
+ * bz_gpu_encode_sharded(g, level, d_in, n, ...) == bz_gpu_encode_sharded_window(g, level, d_in, 0, n, n, ...). */
+size_t bz_shard_halo_bytes(int level);
+int bz_shard_window(int level, size_t n, int rank, int world, uint64_t *window_off, size_t *window_bytes);
+int bz_gpu_encode_sharded_window(bz_gpu_engine *g, int level, const void *d_window, uint64_t window_off,
+                                 size_t window_bytes, size_t n, const bz_shard_comm *comm, void *d_packed,
+                                 size_t packed_cap_words, void *d_gather, size_t gather_cap_words,
+                                 void *d_out, size_t cap, size_t *out_len);
+
 /* A ready-made transport: the four callbacks over RCCL (xGMI inside a node).  These three entry points are
  * exported by a SECOND library, libbz2_mi355x_rccl.so (it links librccl; the codec library does not):
  * rank 0 draws an id and ships its BZ_RCCL_ID_BYTES bytes to the other ranks by any means; every rank then

@@ -28,7 +28,7 @@ from . import _build
 
 __all__ = ["Action", "CompressionError", "BZip2Error", "BZip2Encoder", "BZip2Decoder", "encode", "decode",
            "compress", "decompress", "GpuEngine", "release_cached_resources",
-           "build", "lib", "device_count", "encode_bound", "rccl_lib", "rccl_unique_id", "RcclComm"]
+           "build", "lib", "device_count", "encode_bound", "shard_window", "rccl_lib", "rccl_unique_id", "RcclComm"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -83,7 +83,7 @@ EXPORTS = [
     "bz_gpu_engine_create", "bz_gpu_engine_destroy", "bz_encode_bound", "bz_gpu_encode_device",
     "bz_gpu_partition", "bz_gpu_partition_slab_begin", "bz_gpu_partition_slab_count",
     "bz_gpu_partition_slab_finish", "bz_gpu_block_count", "bz_gpu_encode_blocks", "bz_gpu_assemble", "bz_gpu_encode_sharded",
-    "bz_shard_comm_selftest", "bz_gpu_last_timings",
+    "bz_shard_comm_selftest", "bz_gpu_last_timings", "bz_shard_halo_bytes", "bz_shard_window", "bz_gpu_encode_sharded_window",
     "bz_gpu_last_bwt_stats", "bz_gpu_last_bwt_rounds", "bz_gpu_profile_enable", "bz_gpu_profile_kernels", "bz_gpu_profile_get",
     "bz_gpu_debug_bwt", "bz_gpu_debug_code_lengths", "bz_gpu_debug_block_stats",
     "bz_gpu_decode_device", "bz_gpu_decode_device_sharded", "bz_gpu_last_decode_timings", "bz_gpu_last_decode_stats", "bz_decode_buffer",
@@ -166,6 +166,10 @@ def lib():
                                   C.c_uint, C.c_uint, C.c_uint32, u32p, vp, sz, szp,
                                   C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     L.bz_gpu_encode_sharded.argtypes = [vp, C.c_int, vp, sz, vp, vp, sz, vp, sz, vp, sz, szp]
+    L.bz_shard_halo_bytes.restype = sz
+    L.bz_shard_halo_bytes.argtypes = [C.c_int]
+    L.bz_shard_window.argtypes = [C.c_int, sz, C.c_int, C.c_int, u64p, szp]
+    L.bz_gpu_encode_sharded_window.argtypes = [vp, C.c_int, vp, C.c_uint64, sz, sz, vp, vp, sz, vp, sz, vp, sz, szp]
     L.bz_shard_comm_selftest.argtypes = [vp, C.c_int]
     L.bz_gpu_last_timings.argtypes = [vp, C.POINTER(C.c_double)]
     L.bz_gpu_last_bwt_stats.argtypes = [vp, u64p]
@@ -302,6 +306,14 @@ class RcclComm:
             self._p = C.c_void_p()
 
     __del__ = close
+
+
+def shard_window(level, n, rank, world):
+    """(offset, bytes) of the input a rank of bz_gpu_encode_sharded_window has to hold: its slab, the largest block's
+    worth of input in front of it and one tile behind (bz_shard_window)."""
+    off, nb = C.c_uint64(0), C.c_size_t(0)
+    _check(lib().bz_shard_window(level, n, rank, world, C.byref(off), C.byref(nb)))
+    return off.value, nb.value
 
 
 def device_count():
@@ -737,6 +749,17 @@ class GpuEngine:
                                            C.byref(out_len)))
         return out_len.value
 
+    def encode_sharded_window(self, level, d_window, window_off, window_bytes, n, comm, d_out, cap, packed=None, gather=None):
+        """encode_sharded for a rank that holds only the input bytes [window_off, window_off + window_bytes) of the
+        n-byte input at d_window (shard_window() says which bytes a rank needs)."""
+        _settle()
+        out_len = C.c_size_t(0)
+        pp, pw = packed if packed else (None, 0)
+        gp, gw = gather if gather else (None, 0)
+        _check(lib().bz_gpu_encode_sharded_window(self._h, level, d_window, window_off, window_bytes, n, C.byref(comm.struct),
+                                                  pp, pw, gp, gw, d_out, cap, C.byref(out_len)))
+        return out_len.value
+
     DEC_STAGES = ("scan_huffman", "mtf", "inverse_bwt", "rle1_crc", "total")
 
     def decode_device(self, d_in, n, d_out, cap):
@@ -840,7 +863,8 @@ class GpuEngine:
         unordered = [int(x) for x in r]
         while unordered and unordered[-1] == 0:
             unordered.pop()
-        return {"rounds": s[0], "resorted_elements": s[1], "batches": s[2], "unordered_after_round": unordered}
+        return {"rounds": s[0], "resorted_elements": s[1], "batches": s[2], "unordered_after_round": unordered,
+                "fused_fallbacks": s[3]}  # sorts of this engine that fell back to the three-kernel passes (it stays on them)
 
     def block_stats(self):
         n = C.c_size_t(0)

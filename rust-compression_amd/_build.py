@@ -1,4 +1,6 @@
 """Builds the HIP shared library (gfx950 only) in-tree: rust-compression_amd/libbz2_mi355x.so."""
+import contextlib
+import fcntl
 import os
 import subprocess
 import sys
@@ -13,6 +15,30 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-u
          "-D__HIP_PLATFORM_AMD__"] + os.environ.get("BZ_EXTRA_FLAGS", "").split()
 
 
+@contextlib.contextmanager
+def _build_lock():
+    """One builder at a time per checkout (ranks started together all find a stale library): an fcntl lock on a file
+    beside the sources; the others wait, find the library fresh and do nothing."""
+    with open(os.path.join(HERE, ".build.lock"), "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
+def _link(cmd, target):
+    """the linker writes a temporary name in the same directory; os.replace puts it in place whole (nobody ever
+    dlopens a half-written library)"""
+    tmp = "%s.tmp.%d" % (target, os.getpid())
+    try:
+        subprocess.check_call(cmd + ["-o", tmp])
+        os.replace(tmp, target)
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -21,6 +47,11 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False):
+    with _build_lock():
+        return _build_locked(force, verbose)
+
+
+def _build_locked(force, verbose):
     deps_h = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
@@ -45,8 +76,7 @@ def build(force=False, verbose=False):
     if failed:
         raise RuntimeError("HIP build failed")
     if force or procs or _stale(SO, objs):
-        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", SO] + objs
-        subprocess.check_call(cmd)
+        _link([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950"] + objs, SO)
     # (libbz2_mi355x_rccl.so is built on demand by rccl_lib() / build_rccl(): the codec library must load on hosts
     # without the RCCL headers or library)
     return SO
@@ -59,12 +89,13 @@ def build_rccl(force=False, verbose=False):
     """The RCCL transport (csrc/rccl_comm.hip) as its own library: only it links librccl."""
     src = os.path.join(CSRC, "rccl_comm.hip")
     hdr = os.path.join(CSRC, "..", "..", "include", "bz2_mi355x.h")
-    if not (force or _stale(RCCL_SO, [src, hdr])):
-        return RCCL_SO
-    cmd = [HIPCC] + FLAGS + ["-shared", src, "-o", RCCL_SO, "-L/opt/rocm/lib", "-lrccl"]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    with _build_lock():
+        if not (force or _stale(RCCL_SO, [src, hdr])):
+            return RCCL_SO
+        cmd = [HIPCC] + FLAGS + ["-shared", src, "-L/opt/rocm/lib", "-lrccl"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        _link(cmd, RCCL_SO)
     return RCCL_SO
 
 

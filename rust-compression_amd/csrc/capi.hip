@@ -111,6 +111,17 @@ static double now_ms()
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
+// The calling thread's current HIP device is the caller's business: the entry points below switch devices (lanes of a
+// multi-device context live on different GPUs) and put the caller's device back when they return.  Worker threads
+// keep their own.
+struct CallerDevice {
+    int dev = -1;
+    CallerDevice() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~CallerDevice() { if (dev >= 0) (void)hipSetDevice(dev); }
+    CallerDevice(const CallerDevice &) = delete;
+    CallerDevice &operator=(const CallerDevice &) = delete;
+};
+
 static std::mutex g_cache_mu;
 static std::vector<EncResources *> g_cache; // resources of destroyed contexts, ready for reuse
 
@@ -198,7 +209,7 @@ static int resources_get(const std::vector<int> &devices, EncResources **out)
 static void resources_put(EncResources *r)
 {
     if (!r) return;
-    static const bool no_cache = getenv("BZ_ENC_NO_CACHE") != nullptr;
+    static const bool no_cache = getenv("BZ_ENC_NO_CACHE") && atoi(getenv("BZ_ENC_NO_CACHE")) != 0;
     std::lock_guard<std::mutex> lk(g_cache_mu);
     if (!no_cache && g_cache.size() < 2) g_cache.push_back(r);
     else resources_free(r);
@@ -209,6 +220,7 @@ static void resources_put(EncResources *r)
 extern "C" void bz_release_cached_resources(void)
 {
     std::vector<EncResources *> all;
+    const CallerDevice caller_device;
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         all.swap(g_cache);
@@ -751,6 +763,7 @@ extern "C" void bz_enc_destroy(bz_enc *e)
 {
     if (!e) return;
     if (e->r) {
+        const CallerDevice caller_device;
         {
             std::lock_guard<std::mutex> lk(e->mu);
             e->stop = true;
@@ -812,6 +825,7 @@ extern "C" int bz_enc_write(bz_enc *e, const uint8_t *in, size_t n)
 {
     if (!e || (!in && n)) return BZ_E_PARAM;
     if (n == 0) return e->err;
+    const CallerDevice caller_device;
     int rc = ensure_started(e);
     if (rc != BZ_OK) return rc;
     EncResources *r = e->r;
@@ -862,6 +876,7 @@ extern "C" int bz_enc_write(bz_enc *e, const uint8_t *in, size_t n)
 extern "C" int bz_enc_end(bz_enc *e, int action)
 {
     if (!e || action < BZ_ACTION_RUN || action > BZ_ACTION_FINISH) return BZ_E_PARAM;
+    const CallerDevice caller_device;
     int rc = ensure_started(e);
     if (rc != BZ_OK) return rc;
     // (The chunk still being filled goes to the workers with the caller's Action WITHOUT waiting for the

@@ -601,8 +601,8 @@ static int encode_batch(bz_gpu_engine *g, u32 nb, const std::vector<BlockDesc> &
         static const bool fail_test = getenv("BZ_FUSED_ZLE_FAILTEST") != nullptr; // (tests: exercise the redo)
         if (hipMemcpy(tk, g->ztick.p, sizeof(tk), hipMemcpyDeviceToHost) != hipSuccess) return BZ_E_UNEXPECTED;
         bool bad = tk[8] != 0 || fail_test;
-        for (u32 x = 0; x < 8; ++x)
-            if (tk[x] < kTilesPerBlock * ((nb + 7u - x) / 8u)) bad = true;
+        for (u32 x = 0; x < 8; ++x) // (exactly its share of the launch's workgroups: fewer = tiles left out, more = tiles run twice)
+            if (tk[x] != kTilesPerBlock * (xcd_grid_y(nb) / 8u)) bad = true;
         if (bad) {
             fprintf(stderr, "bz2_mi355x: the one-launch ZLE stage misbehaved (tile tickets / look-back); stage redone with three kernels\n");
             g->zle_fused_broken = true;
@@ -793,10 +793,34 @@ struct ShardBlock {
     u32 crc, pad;
 };
 
-extern "C" int bz_gpu_encode_sharded(bz_gpu_engine *g, int level, const void *d_in, size_t n,
-                                     const bz_shard_comm *comm, void *d_packed, size_t packed_cap_words,
-                                     void *d_gather, size_t gather_cap_words, void *d_out, size_t cap,
-                                     size_t *out_len)
+// A level-`level` block covers at most (100000 level - 19) * 255 / 5 input bytes (a run of 255 equal bytes is five
+// RLE1 bytes, encoder.rs:676-690): what a rank may have to re-read in front of its slab, rounded up to whole tiles.
+extern "C" size_t bz_shard_halo_bytes(int level)
+{
+    if (level < 1 || level > 9) return 0;
+    const u64 most = ((u64)level * 100000u - 19u) * 51u;
+    return (size_t)((most + 2 * kRleTile - 1) / kRleTile * kRleTile);
+}
+
+extern "C" int bz_shard_window(int level, size_t n, int rank, int world, uint64_t *window_off, size_t *window_bytes)
+{
+    if (level < 1 || level > 9 || world < 1 || rank < 0 || rank >= world || !window_off || !window_bytes) return BZ_E_PARAM;
+    const u64 ntiles = ((u64)n + kRleTile - 1) / kRleTile;
+    const u64 t0 = ntiles * (u64)rank / (u64)world, t1 = ntiles * (u64)(rank + 1) / (u64)world;
+    const u64 begin = t0 * kRleTile, end = std::min<u64>((u64)n, t1 * kRleTile);
+    const u64 halo = bz_shard_halo_bytes(level);
+    const u64 lo = begin > halo ? begin - halo : 0;
+    const u64 hi = std::min<u64>((u64)n, end + kRleTile); // (the split looks one byte past a slab's end)
+    *window_off = lo;
+    *window_bytes = (size_t)(hi > lo ? hi - lo : 0);
+    return BZ_OK;
+}
+
+// win_lo / win_hi: the input bytes that really lie behind d_in (the whole input: 0, n).
+static int encode_sharded_impl(bz_gpu_engine *g, int level, const void *d_in, size_t n, u64 win_lo, u64 win_hi,
+                               const bz_shard_comm *comm, void *d_packed, size_t packed_cap_words,
+                               void *d_gather, size_t gather_cap_words, void *d_out, size_t cap,
+                               size_t *out_len)
 {
     if (!g || !comm || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world) return BZ_E_PARAM;
     if (level < 1 || level > 9) return BZ_E_PARAM;
@@ -806,10 +830,17 @@ extern "C" int bz_gpu_encode_sharded(bz_gpu_engine *g, int level, const void *d_
     const u64 ntiles = (n + kRleTile - 1) / kRleTile;
     const u64 t0 = ntiles * (u64)rank / (u64)world, t1 = ntiles * (u64)(rank + 1) / (u64)world;
     int rc = BZ_OK; // this rank's status; collectives go on regardless
+    {
+        // the window must hold the slab, a tile in front of it (the split looks at the byte before a slab) and the
+        // byte behind it; how far the first block reaches back is only known when the cut arrives (checked there)
+        const u64 begin = t0 * kRleTile, end = std::min<u64>((u64)n, t1 * kRleTile);
+        const u64 need_lo = begin >= kRleTile ? begin - kRleTile : 0, need_hi = std::min<u64>((u64)n, end + 16);
+        if (t1 > t0 && (win_lo > need_lo || win_hi < need_hi)) rc = BZ_E_PARAM;
+    }
 
     // 1. slab scan + the RLE1 phase at the left edge
     int64_t last = -1;
-    rc = bz_gpu_partition_slab_begin(g, level, d_in, n, t0, t1, &last);
+    if (rc == BZ_OK) rc = bz_gpu_partition_slab_begin(g, level, d_in, n, t0, t1, &last);
     std::vector<int64_t> lasts((size_t)world, -1);
     if (world > 1) {
         if (comm->allgather(comm->ctx, &last, 8, lasts.data()) != 0) return BZ_E_UNEXPECTED; // (the transport itself failed: nothing to wait for)
@@ -824,6 +855,12 @@ extern "C" int bz_gpu_encode_sharded(bz_gpu_engine *g, int level, const void *d_
     uint64_t hop[2] = {0, 0}; // {first input byte of the receiver's first block, sender's status}
     if (rank > 0 && comm->recv(comm->ctx, rank - 1, hop, sizeof(hop)) != 0) return BZ_E_UNEXPECTED;
     if (rc == BZ_OK && hop[1] != 0) rc = -(int)hop[1];
+    // (a window: the first block's bytes in front of the slab must lie inside it, from the start of their tile on)
+    if (rc == BZ_OK && t1 > t0 && hop[0] / kRleTile * kRleTile < win_lo) {
+        fprintf(stderr, "bz2_mi355x: rank %d: its first block starts at input byte %llu, in front of the window it was given (%llu); "
+                        "bz_shard_window sizes one that always holds it\n", rank, (unsigned long long)hop[0], (unsigned long long)win_lo);
+        rc = BZ_E_CAPACITY;
+    }
     size_t nb = 0;
     uint64_t next = hop[0];
     // (the cut goes to the next rank before this rank writes its image: the chain over the ranks is serial, and
@@ -920,6 +957,29 @@ extern "C" int bz_gpu_encode_sharded(bz_gpu_engine *g, int level, const void *d_
         }
     return bz_gpu_assemble(g, level, (size_t)total_blocks, d_gather, awoff.data(), ablen.data(), acrc.data(), 1, 1, 1, 0, 0, 0,
                            nullptr, d_out, cap, out_len, nullptr, nullptr);
+}
+
+extern "C" int bz_gpu_encode_sharded(bz_gpu_engine *g, int level, const void *d_in, size_t n,
+                                     const bz_shard_comm *comm, void *d_packed, size_t packed_cap_words,
+                                     void *d_gather, size_t gather_cap_words, void *d_out, size_t cap,
+                                     size_t *out_len)
+{
+    return encode_sharded_impl(g, level, d_in, n, 0, n, comm, d_packed, packed_cap_words, d_gather, gather_cap_words, d_out,
+                               cap, out_len);
+}
+
+// The same call for a rank that holds only a WINDOW of the input: d_window[0 .. window_bytes) are the input bytes
+// [window_off, window_off + window_bytes).  The kernels address the input by absolute position, so the window is
+// handed on as the base it would have inside the whole input (never dereferenced outside the window).
+extern "C" int bz_gpu_encode_sharded_window(bz_gpu_engine *g, int level, const void *d_window, uint64_t window_off,
+                                            size_t window_bytes, size_t n, const bz_shard_comm *comm, void *d_packed,
+                                            size_t packed_cap_words, void *d_gather, size_t gather_cap_words,
+                                            void *d_out, size_t cap, size_t *out_len)
+{
+    if ((window_off & 15u) || window_off > n || window_bytes > n - window_off) return BZ_E_PARAM;
+    const void *base = reinterpret_cast<const void *>(reinterpret_cast<uintptr_t>(d_window) - (uintptr_t)window_off);
+    return encode_sharded_impl(g, level, base, n, window_off, window_off + window_bytes, comm, d_packed, packed_cap_words,
+                               d_gather, gather_cap_words, d_out, cap, out_len);
 }
 
 // Exercises a transport (the four callbacks of a bz_shard_comm) with known patterns, shaped like the

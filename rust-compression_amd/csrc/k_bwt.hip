@@ -2372,8 +2372,13 @@ static bool fused_pass_ok(hipStream_t st, const BwtArgs &a, u32 epoch)
     if (hipMemcpyAsync(&gave_up, a.sort_err, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
     if (hipStreamSynchronize(st) != hipSuccess) return false;
     if (gave_up) return false;
+    // Every workgroup of the launch draws one ticket from the counter of the XCD it runs on, and the launch has
+    // kTilesPerBlock * xcd_grid_y(nb) workgroups dealt evenly to the eight XCDs: each counter must stand at EXACTLY
+    // that share.  Fewer: an XCD ran fewer workgroups than it has tiles (tiles left out).  More: tickets were drawn
+    // twice -- the counters were cleared while the pass ran, or two launches shared an epoch -- and tiles ran twice.
+    const u32 want = kTilesPerBlock * (xcd_grid_y(a.nb) / 8u);
     for (u32 x = 0; x < 8; ++x)
-        if (tk[x] < kTilesPerBlock * ((a.nb + 7u - x) / 8u)) return false;
+        if (tk[x] != want) return false;
     return true;
 }
 
@@ -2634,10 +2639,9 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
         static const bool late_fail_test = getenv("BZ_ONESWEEP_LATEFAILTEST") != nullptr; // (tests: exercise the redo)
         bool bad = gave_up != 0 || late_fail_test;
-        for (size_t i = 0; i < tk.size(); ++i) {
-            const u32 x = (u32)(i & 7u);
-            if (tk[i] < kTilesPerBlock * ((a.nb + 7u - x) / 8u)) bad = true;
-        }
+        const u32 want = kTilesPerBlock * (xcd_grid_y(a.nb) / 8u); // (exactly: see fused_pass_ok)
+        for (size_t i = 0; i < tk.size(); ++i)
+            if (tk[i] != want) bad = true;
         if (bad) {
             (void)hipMemsetAsync(a.sort_err, 0, 4, st);
             return -2;

@@ -1091,7 +1091,9 @@ __global__ __launch_bounds__(256) void k_df_cuts(const u64 *__restrict__ bm, u64
         __syncthreads();
     }
     if (tid == 0) {
-        if (limit < n && s_done != 2) { // not the last piece: remember where the chain stands
+        if (limit < n) { // not the last piece: remember where the chain stands
+            // (a piece that found the chain broken -- s_done == 2 -- says so in the state: the pieces behind it leave at
+            // once and the last one reports 0xFFFFFFFF; the blocks this piece had closed before stay with k_df_block)
             state[0] = (u64)s_b;
             state[1] = (u64)s_k | ((u64)s_done << 32);
             if (kdone) *kdone = s_k; // blocks 0 .. s_k - 1 have both their ends: k_df_block can take them

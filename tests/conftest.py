@@ -16,8 +16,9 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    """No test waits for ever: a GPU test that has not come back after 25 minutes fails with the stacks of all
-    threads (pytest-timeout, when it is installed) instead of holding the whole session.  (The bound is generous on
+    """No test waits for ever: when a GPU test has not come back after 25 minutes pytest-timeout (when it is
+    installed) dumps the stacks of all threads and ENDS the pytest process (method="thread": the test may be
+    blocked inside a C call, where a signal-based timeout would not be served) -- the session fails instead of hanging.  (The bound is generous on
     purpose: the one stall seen so far -- three times in some forty runs -- was the first `import torch` of a process
     on a fresh GPU box waiting for the image to page in, inside `importlib`'s stat calls.)"""
     if not config.pluginmanager.hasplugin("timeout"):
