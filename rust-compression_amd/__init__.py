@@ -79,7 +79,8 @@ def build(force=False):
 EXPORTS = [
     "bz_strerror", "bz_version", "bz_device_count",
     "bz_enc_create", "bz_enc_write", "bz_enc_end", "bz_enc_read", "bz_enc_pending", "bz_enc_destroy",
-    "bz_encode_buffer", "bz_free", "bz_enc_create_multi", "bz_encode_buffer_multi", "bz_release_cached_resources",
+    "bz_encode_buffer", "bz_free", "bz_enc_create_multi", "bz_enc_set_verify", "bz_enc_verify_stats",
+    "bz_gpu_engine_set_verify", "bz_gpu_verify_stats", "bz_encode_buffer_multi", "bz_release_cached_resources",
     "bz_gpu_engine_create", "bz_gpu_engine_destroy", "bz_encode_bound", "bz_gpu_encode_device",
     "bz_gpu_partition", "bz_gpu_partition_slab_begin", "bz_gpu_partition_slab_count",
     "bz_gpu_partition_slab_finish", "bz_gpu_block_count", "bz_gpu_encode_blocks", "bz_gpu_assemble", "bz_gpu_encode_sharded",
@@ -145,6 +146,10 @@ def lib():
     L.bz_encode_buffer.argtypes = [C.c_int, C.c_int, C.c_char_p, sz, C.POINTER(u8p), szp]
     L.bz_enc_create_multi.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int), C.c_int]
     L.bz_encode_buffer_multi.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_char_p, sz, C.POINTER(u8p), szp]
+    L.bz_enc_set_verify.argtypes = [vp, C.c_int]
+    L.bz_enc_verify_stats.argtypes = [vp, u64p]
+    L.bz_gpu_engine_set_verify.argtypes = [vp, C.c_int]
+    L.bz_gpu_verify_stats.argtypes = [vp, u64p]
     L.bz_release_cached_resources.restype = None
     L.bz_release_cached_resources.argtypes = []
     L.bz_free.restype = None
@@ -329,7 +334,7 @@ class BZip2Encoder:
 
     CHUNK = 1 << 20  # bytes pulled from the input iterator per refill
 
-    def __init__(self, level=9, device=0, devices=None):
+    def __init__(self, level=9, device=0, devices=None, verify=None):
         if level < 1 or level > 9:
             raise ValueError("invalid level")  # the reference panics (encoder.rs:59-61)
         self._h = C.c_void_p()
@@ -338,6 +343,8 @@ class BZip2Encoder:
         else:
             devs = (C.c_int * len(devices))(*devices)
             _check(lib().bz_enc_create_multi(C.byref(self._h), level, devs, len(devices)))
+        if verify is not None:
+            self.set_verify(verify)
         self._buf = (C.c_uint8 * 65536)()
         self._ready = b""
         self._pos = 0
@@ -346,6 +353,18 @@ class BZip2Encoder:
         if getattr(self, "_h", None) and _LIB is not None:
             _LIB.bz_enc_destroy(self._h)
             self._h = None
+
+    VERIFY_STATS = ("blocks_checked", "jobs_redone", "jobs_failed_again", "nanoseconds")
+
+    def set_verify(self, on=True):
+        """Self-check (bz_enc_set_verify): every job's blocks are decoded on the device and compared with their input
+        before their bytes can be read; a job that fails is encoded again without look-back passes."""
+        _check(lib().bz_enc_set_verify(self._h, int(bool(on))))
+
+    def verify_stats(self):
+        s = (C.c_uint64 * 4)()
+        _check(lib().bz_enc_verify_stats(self._h, s))
+        return dict(zip(self.VERIFY_STATS, [int(x) for x in s]))
 
     @classmethod
     def with_devices(cls, level, devices):
@@ -423,12 +442,16 @@ def release_cached_resources():
     lib().bz_release_cached_resources()
 
 
-def compress(data, level=9, device=0, devices=None):
-    """One-shot over host buffers (bz_encode_buffer; `devices`: bz_encode_buffer_multi over that list of GPUs)."""
+def compress(data, level=9, device=0, devices=None, verify=None):
+    """One-shot over host buffers (bz_encode_buffer; `devices`: bz_encode_buffer_multi over that list of GPUs).
+    verify=True: through a streaming context with the self-check on (the one-shot entry points take BZ_VERIFY=1
+    from the environment); the bytes are the same."""
     if level < 1 or level > 9:
         raise ValueError("invalid level")
     if not isinstance(data, (bytes, bytearray)):
         data = bytes(data)
+    if verify is not None:
+        return BZip2Encoder(level, device, devices, verify=verify).encode_all(data)
     buf = data if isinstance(data, bytes) else (C.c_char * len(data)).from_buffer(data)
     out = C.POINTER(C.c_uint8)()
     n = C.c_size_t(0)
@@ -680,6 +703,15 @@ class GpuEngine:
             self._h = None
 
     __del__ = close
+
+    def set_verify(self, on=True):
+        """Self-check of the device-resident calls (bz_gpu_engine_set_verify)."""
+        _check(lib().bz_gpu_engine_set_verify(self._h, int(bool(on))))
+
+    def verify_stats(self):
+        s = (C.c_uint64 * 4)()
+        _check(lib().bz_gpu_verify_stats(self._h, s))
+        return dict(zip(BZip2Encoder.VERIFY_STATS, [int(x) for x in s]))
 
     def encode_device(self, level, d_in, n, d_out, cap):
         _settle()

@@ -291,6 +291,8 @@ struct bz_enc {
     u64 queued = 0;              // jobs queued
     bool stop = false, drain_stop = false;
     int err = BZ_OK;             // sticky
+    bool verify = false;         // bz_enc_set_verify / BZ_VERIFY=1: every job's blocks are decoded and compared before they leave
+    u64 vstats[4] = {0, 0, 0, 0}; // (mu) blocks checked, jobs redone, redone jobs that failed again, ns spent checking
 };
 
 static int grow(void **p, size_t *cap, size_t want)
@@ -542,7 +544,15 @@ static int job_encode(bz_enc *e, int lane, JobState &js)
     int rc = grow(&ln.d_packed, &ln.d_packed_cap, cap_words * 4);
     if (rc != BZ_OK) return rc;
     size_t used = 0;
+    uint64_t v0[4] = {0, 0, 0, 0}, v1[4] = {0, 0, 0, 0};
+    (void)bz_gpu_engine_set_verify(ln.g, e->verify ? 1 : 0); // (a lane's engine may come from the cache: the switch is the context's)
+    (void)bz_gpu_verify_stats(ln.g, v0);
     rc = bz_gpu_encode_blocks(ln.g, 0, 1, ln.d_packed, cap_words, js.woff.data(), js.blen.data(), js.crc.data(), &used);
+    (void)bz_gpu_verify_stats(ln.g, v1);
+    if (e->verify) {
+        std::lock_guard<std::mutex> lk(e->mu);
+        for (int i = 0; i < 4; ++i) e->vstats[i] += v1[i] - v0[i];
+    }
     js.t2 = now_ms();
     return rc;
 }
@@ -753,7 +763,24 @@ extern "C" int bz_enc_create_multi(bz_enc **out, int level, const int *devices, 
     bz_enc *e = new bz_enc();
     e->level = level;
     e->devices.assign(devices, devices + n_devices);
+    e->verify = getenv("BZ_VERIFY") && atoi(getenv("BZ_VERIFY")) != 0;
     *out = e;
+    return BZ_OK;
+}
+
+extern "C" int bz_enc_set_verify(bz_enc *e, int on)
+{
+    if (!e) return BZ_E_PARAM;
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->verify = on != 0; // (jobs already handed to a lane keep the setting they started with)
+    return BZ_OK;
+}
+
+extern "C" int bz_enc_verify_stats(bz_enc *e, uint64_t out[4])
+{
+    if (!e || !out) return BZ_E_PARAM;
+    std::lock_guard<std::mutex> lk(e->mu);
+    for (int i = 0; i < 4; ++i) out[i] = e->vstats[i];
     return BZ_OK;
 }
 

@@ -709,6 +709,17 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
     return BZ_OK;
 }
 
+int dec_decode_for_verify(bz_gpu_engine *g, const uint8_t *d_in, uint64_t n, uint8_t *d_out, uint64_t cap,
+                          uint64_t *produced, int *verdict)
+{
+    Sink sink;
+    sink.d_out = d_out;
+    sink.cap = cap;
+    const int rc = decode_core(g, d_in, n, sink, verdict);
+    *produced = sink.produced;
+    return rc;
+}
+
 // ---- C ABI ------------------------------------------------------------------------------------------------
 extern "C" int bz_gpu_decode_device(bz_gpu_engine *g, const void *d_in, size_t n, void *d_out, size_t cap,
                                     size_t *out_len)

@@ -7,6 +7,7 @@
 #include "engine_state.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -155,6 +156,7 @@ extern "C" int bz_gpu_engine_create(bz_gpu_engine **out, int device, size_t max_
     bz_gpu_engine *g = new bz_gpu_engine();
     g->device = device;
     g->max_blocks = max_blocks_in_flight ? max_blocks_in_flight : 64;
+    g->verify = getenv("BZ_VERIFY") && atoi(getenv("BZ_VERIFY")) != 0;
     HIPCHK(hipStreamCreateWithFlags(&g->st, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&g->st2, hipStreamNonBlocking));
     HIPCHK(hipHostMalloc((void **)&g->h_active, 64, hipHostMallocDefault));
@@ -196,7 +198,7 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
                      &g->summ, &g->summ_len, &g->init_state, &g->rank8, &g->ztile_last, &g->ztile_cnt, &g->mtf,
                      &g->mtf_freq, &g->bout, &g->selector, &g->code_len, &g->group_bitoff, &g->lm_scratch, &g->hglen, &g->hpack, &g->hrfreq, &g->hlm,
                      &g->stream, &g->error_flag, &g->packlist, &g->packed, &g->gathered, &g->asmlist, &g->gh_tiles, &g->gbase, &g->tile_state,
-                     &g->tickets};
+                     &g->tickets, &g->vstream, &g->vout, &g->vseg, &g->vmis};
     for (DevBuf *b : all) b->release();
     dec_workspace_free(g->dec);
     df_workspace_free(g->df);
@@ -509,6 +511,8 @@ static HuffArgs make_huff_args(bz_gpu_engine *g, u32 nb, u32 o)
     return ha;
 }
 
+__global__ void k_test_bump(u32 *p, u32 n) { *p = (*p + 1u) % n; } // (fault injection for the self-check's tests)
+
 // symbols in use -> key geometry -> rotation sort.  Returns rounds (<0: error).
 static int sort_batch(bz_gpu_engine *g, const BwtArgs &ba, u32 *inuse_bits, u32 max_n, u64 total_n, u64 *sorted,
                       KernelProf *prof, u64 *round_active)
@@ -560,6 +564,11 @@ static int encode_batch(bz_gpu_engine *g, u32 nb, const std::vector<BlockDesc> &
             break;
         }
         launch_last_column(g->st, ba, g->L.as<u8>() + (size_t)o * kSlot, g->orig_ptr.as<u32>() + o, total_n, &g->prof);
+        // (tests) BZ_TEST_CORRUPT=1: a wrong origPtr for the batch's first block while the engine is on its fused passes --
+        // a stream that is well formed and decodes to other bytes; nothing but a check of the result can notice
+        static const bool corrupt_test = getenv("BZ_TEST_CORRUPT") && atoi(getenv("BZ_TEST_CORRUPT")) != 0;
+        if (corrupt_test && g->fused_state[0] == 0 && descs[o].n > 1)
+            hipLaunchKernelGGL(k_test_bump, dim3(1), dim3(1), 0, g->st, g->orig_ptr.as<u32>() + o, descs[o].n);
         span_end(g, sp);
         g->bwt_stats[0] = std::max<u64>(g->bwt_stats[0], (u64)rounds);
         g->bwt_stats[1] += sorted;
@@ -617,19 +626,12 @@ static int encode_batch(bz_gpu_engine *g, u32 nb, const std::vector<BlockDesc> &
 
 extern "C" size_t bz_gpu_block_count(const bz_gpu_engine *g) { return g ? g->h_blocks.size() : 0; }
 
-extern "C" int bz_gpu_encode_blocks(bz_gpu_engine *g, size_t first, size_t stride, void *d_packed,
-                                    size_t cap_words, uint64_t *h_word_off, uint64_t *h_bit_len,
-                                    uint32_t *h_crc, size_t *words_used)
+static int encode_blocks_once(bz_gpu_engine *g, const std::vector<size_t> &mine, void *d_packed, size_t cap_words,
+                              uint64_t *h_word_off, uint64_t *h_bit_len, uint32_t *h_crc, size_t *words_used)
 {
-    if (!g || stride == 0) return BZ_E_PARAM;
-    HIPCHK(hipSetDevice(g->device));
     if (words_used) *words_used = 0;
     g->h_out.clear();
     g->h_out_nblock.clear();
-    const size_t total = g->h_blocks.size();
-    std::vector<size_t> mine;
-    for (size_t b = first; b < total; b += stride) mine.push_back(b);
-    if (mine.empty()) return BZ_OK;
     int rc = ensure_workspace(g, mine.size());
     if (rc != BZ_OK) return rc;
     HIPCHK(hipMemsetAsync(g->error_flag.p, 0, 4, g->st));
@@ -683,6 +685,145 @@ extern "C" int bz_gpu_encode_blocks(bz_gpu_engine *g, size_t first, size_t strid
     spans_collect(g);
     HIPCHK(hipGetLastError());
     if (words_used) *words_used = (size_t)word_cursor;
+    return BZ_OK;
+}
+
+// ---- self-check: decode what was just encoded, on the same device, and compare it with the input ------------------
+// The reference encoder cannot write a stream that does not decode to its input; a GPU pipeline with look-back words,
+// tickets and stream-ordered clears can (round 3 saw one wrong stream in six from a clear on the wrong stream).  With
+// verify on, the bit strings of a call's blocks are framed as a stream of their own (header, blocks, trailer), decoded
+// by the decode path of this library (k_dec*.hip: header parse, Huffman, inverse MTF, inverse BWT, RLE1 undo, block
+// CRCs) and the bytes are compared with the input bytes the blocks cover.  A call whose check fails is encoded again
+// with the three-kernel radix passes and the three-kernel ZLE stage (no look-back anywhere) and checked again; if that
+// fails too the call returns BZ_E_UNEXPECTED: no byte of a stream that does not decode leaves the library.
+struct VerifySeg {
+    u64 in_off, out_off, len;
+};
+__global__ __launch_bounds__(256) void k_verify_compare(const u8 *__restrict__ in, const u8 *__restrict__ out,
+                                                        const VerifySeg *__restrict__ segs, u32 *__restrict__ mismatches)
+{
+    const VerifySeg sg = segs[blockIdx.y];
+    bool bad = false;
+    for (u64 i = ((u64)blockIdx.x * 256u + threadIdx.x) * 16u; i < sg.len; i += (u64)gridDim.x * 256u * 16u) {
+        const u64 k = sg.len - i < 16u ? sg.len - i : 16u;
+        if (k == 16u) {
+            uint4 a, b;
+            __builtin_memcpy(&a, in + sg.in_off + i, 16);
+            __builtin_memcpy(&b, out + sg.out_off + i, 16);
+            bad = bad || a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w;
+        } else {
+            for (u64 j = 0; j < k; ++j) bad = bad || in[sg.in_off + i + j] != out[sg.out_off + i + j];
+        }
+    }
+    if (__ballot(bad) && (threadIdx.x & 63u) == 0u) atomicAdd(mismatches, 1u);
+}
+
+// 0: the blocks decode to their input; 1: they do not; < 0: the check itself could not run (status)
+static int verify_blocks(bz_gpu_engine *g, const std::vector<size_t> &mine, const void *d_packed, const uint64_t *h_word_off,
+                         const uint64_t *h_bit_len, const uint32_t *h_crc)
+{
+    const size_t nb = mine.size();
+    u64 bits = 32 + 80 + 64, in_bytes = 0;
+    std::vector<VerifySeg> segs(nb);
+    for (size_t k = 0; k < nb; ++k) {
+        const BlockDesc &d = g->h_blocks[mine[k]];
+        bits += h_bit_len[k];
+        segs[k].in_off = d.in_off;
+        segs[k].out_off = in_bytes;
+        segs[k].len = d.in_end - d.in_off;
+        in_bytes += segs[k].len;
+    }
+    int rc;
+    const size_t zcap = (size_t)(bits / 8 + 64) & ~(size_t)3;
+    if ((rc = g->vstream.ensure(zcap + 64)) || (rc = g->vout.ensure((size_t)in_bytes + 64)) ||
+        (rc = g->vseg.ensure(nb * sizeof(VerifySeg))) || (rc = g->vmis.ensure(4)))
+        return rc;
+    size_t zlen = 0;
+    const double t4 = g->t_stage[4], t5 = g->t_stage[5]; // (the check's framing is not part of the call's stage times)
+    rc = bz_gpu_assemble(g, g->level, nb, d_packed, h_word_off, h_bit_len, h_crc, 1, 1, 1, 0, 0, 0, nullptr, g->vstream.p,
+                         zcap, &zlen, nullptr, nullptr);
+    g->t_stage[4] = t4;
+    g->t_stage[5] = t5;
+    if (rc != BZ_OK) return rc;
+    HIPCHK(hipMemsetAsync((u8 *)g->vstream.p + zlen, 0, 64, g->st)); // (the decoder's bit reader looks a few bytes ahead)
+    HIPCHK(hipStreamSynchronize(g->st));
+    uint64_t produced = 0;
+    int verdict = BZ_OK;
+    const bool prof_on = g->prof.on;
+    g->prof.on = false; // (the decode kernels of the check do not belong in the encode profile)
+    rc = dec_decode_for_verify(g, g->vstream.as<u8>(), zlen, g->vout.as<u8>(), in_bytes, &produced, &verdict);
+    g->prof.on = prof_on;
+    if (rc == BZ_E_CAPACITY) return 1; // (decodes to MORE than the input)
+    if (rc != BZ_OK) return rc;
+    if (verdict != BZ_OK || produced != in_bytes) return 1;
+    u32 max_len = 1;
+    for (const VerifySeg &sg : segs) max_len = std::max<u32>(max_len, (u32)std::min<u64>(sg.len, 0xFFFFFFFFu));
+    HIPCHK(hipMemcpyAsync(g->vseg.p, segs.data(), nb * sizeof(VerifySeg), hipMemcpyHostToDevice, g->st));
+    HIPCHK(hipMemsetAsync(g->vmis.p, 0, 4, g->st));
+    const u32 gx = std::min<u32>((max_len + 4095u) / 4096u, 4096u);
+    for (size_t k0 = 0; k0 < nb; k0 += 65535) { // (grid.y is a 16-bit number)
+        const u32 ny = (u32)std::min<size_t>(nb - k0, 65535);
+        hipLaunchKernelGGL(k_verify_compare, dim3(gx, ny), dim3(256), 0, g->st, g->d_in, g->vout.as<u8>(),
+                           g->vseg.as<VerifySeg>() + k0, g->vmis.as<u32>());
+    }
+    u32 mis = 0;
+    HIPCHK(hipMemcpyAsync(&mis, g->vmis.p, 4, hipMemcpyDeviceToHost, g->st));
+    HIPCHK(hipStreamSynchronize(g->st));
+    HIPCHK(hipGetLastError());
+    return mis ? 1 : 0;
+}
+
+extern "C" int bz_gpu_encode_blocks(bz_gpu_engine *g, size_t first, size_t stride, void *d_packed,
+                                    size_t cap_words, uint64_t *h_word_off, uint64_t *h_bit_len,
+                                    uint32_t *h_crc, size_t *words_used)
+{
+    if (!g || stride == 0) return BZ_E_PARAM;
+    HIPCHK(hipSetDevice(g->device));
+    if (words_used) *words_used = 0;
+    const size_t total = g->h_blocks.size();
+    std::vector<size_t> mine;
+    for (size_t b = first; b < total; b += stride) mine.push_back(b);
+    if (mine.empty()) {
+        g->h_out.clear();
+        g->h_out_nblock.clear();
+        return BZ_OK;
+    }
+    int rc = encode_blocks_once(g, mine, d_packed, cap_words, h_word_off, h_bit_len, h_crc, words_used);
+    if (rc != BZ_OK || !g->verify) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    int v = verify_blocks(g, mine, d_packed, h_word_off, h_bit_len, h_crc);
+    g->verify_stats[0] += mine.size();
+    if (v == 1) {
+        g->verify_stats[1] += 1;
+        fprintf(stderr, "bz2_mi355x: self-check: %zu blocks did not decode to their input; encoded again without look-back passes\n",
+                mine.size());
+        g->fused_state[0] = 1;      // the three-kernel radix passes ...
+        g->fused_state[1] += 1;
+        g->zle_fused_broken = true; // ... and the three-kernel ZLE stage, for the rest of this engine's life
+        rc = encode_blocks_once(g, mine, d_packed, cap_words, h_word_off, h_bit_len, h_crc, words_used);
+        if (rc == BZ_OK) v = verify_blocks(g, mine, d_packed, h_word_off, h_bit_len, h_crc);
+        if (rc == BZ_OK && v == 1) {
+            g->verify_stats[2] += 1;
+            fprintf(stderr, "bz2_mi355x: self-check failed again: the call returns an error, no stream is produced\n");
+            rc = BZ_E_UNEXPECTED;
+        }
+    }
+    if (rc == BZ_OK && v < 0) rc = v;
+    g->verify_stats[3] += (u64)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+extern "C" int bz_gpu_engine_set_verify(bz_gpu_engine *g, int on)
+{
+    if (!g) return BZ_E_PARAM;
+    g->verify = on != 0;
+    return BZ_OK;
+}
+
+extern "C" int bz_gpu_verify_stats(bz_gpu_engine *g, uint64_t out[4])
+{
+    if (!g || !out) return BZ_E_PARAM;
+    for (int i = 0; i < 4; ++i) out[i] = g->verify_stats[i];
     return BZ_OK;
 }
 

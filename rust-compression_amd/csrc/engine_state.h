@@ -11,6 +11,10 @@ using namespace bzgpu;
 
 struct DecWorkspace;
 void dec_workspace_free(DecWorkspace *w);
+// the decode path as the encoder's self-check uses it (dec_engine.hip): d_in[n] -> d_out (device memory, cap bytes);
+// returns an infrastructure status, the decoder's verdict in *verdict and the bytes it produced in *produced
+int dec_decode_for_verify(struct bz_gpu_engine *g, const uint8_t *d_in, uint64_t n, uint8_t *d_out, uint64_t cap,
+                          uint64_t *produced, int *verdict);
 struct DfWorkspace;
 void df_workspace_free(DfWorkspace *w);
 
@@ -93,6 +97,11 @@ struct bz_gpu_engine {
         hipEvent_t a, b;
     };
     std::vector<Span> spans;
+    // self-check (bz_gpu_engine_set_verify / BZ_VERIFY=1): the blocks of every bz_gpu_encode_blocks call are decoded on
+    // the device and compared with the input they cover before the call returns
+    bool verify = false;
+    u64 verify_stats[4] = {0, 0, 0, 0}; // since creation: blocks checked, calls redone, redone calls that failed again, ns
+    DevBuf vstream, vout, vseg, vmis;
     DecWorkspace *dec = nullptr; // decode workspace, created by the first decode call
     DfWorkspace *df = nullptr;   // Deflate encode workspace, created by the first df_gpu_encode_device call
 };

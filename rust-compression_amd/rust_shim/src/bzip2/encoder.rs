@@ -71,6 +71,21 @@ impl BZip2Encoder {
         Self { h, ready: Vec::new(), pos: 0, chunk: Vec::with_capacity(CHUNK) }
     }
 
+    /// Self-check (not in the reference, whose sequential code cannot write a stream that does not decode): every
+    /// job's blocks are decoded again on the device and compared with the input they cover before their bytes are
+    /// handed out (`bz_enc_set_verify`).  Returns `self` for chaining: `BZip2Encoder::new(9).verified(true)`.
+    pub fn verified(self, on: bool) -> Self {
+        unsafe { ffi::bz_enc_set_verify(self.h, on as i32) };
+        self
+    }
+
+    /// (blocks checked, jobs redone, redone jobs that failed again, nanoseconds spent checking)
+    pub fn verify_stats(&self) -> [u64; 4] {
+        let mut s = [0u64; 4];
+        unsafe { ffi::bz_enc_verify_stats(self.h, s.as_mut_ptr()) };
+        s
+    }
+
     fn refill(&mut self) -> Result<usize, CompressionError> {
         self.ready.resize(1 << 16, 0);
         let k = unsafe { bz_enc_read(self.h, self.ready.as_mut_ptr(), self.ready.len()) };

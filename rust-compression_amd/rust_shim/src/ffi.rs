@@ -28,6 +28,8 @@ extern "C" {
     pub fn bz_enc_read(e: *mut bz_enc, out: *mut u8, cap: usize) -> isize;
     pub fn bz_enc_pending(e: *const bz_enc) -> usize;
     pub fn bz_enc_destroy(e: *mut bz_enc);
+    pub fn bz_enc_set_verify(e: *mut bz_enc, on: i32) -> i32;
+    pub fn bz_enc_verify_stats(e: *mut bz_enc, out: *mut u64) -> i32;
 
     // section 3: BZip2Decoder (src/bzip2/decoder.rs:583-612)
     pub fn bz_dec_create(out: *mut *mut bz_dec, device: i32) -> i32;
