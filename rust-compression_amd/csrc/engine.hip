@@ -511,7 +511,17 @@ static HuffArgs make_huff_args(bz_gpu_engine *g, u32 nb, u32 o)
     return ha;
 }
 
-__global__ void k_test_bump(u32 *p, u32 n) { *p = (*p + 1u) % n; } // (fault injection for the self-check's tests)
+__global__ void k_test_bump(u32 *p, u32 n) { *p = (*p + 1u) % n; } // (fault injections for the self-check's tests)
+__global__ void k_test_swap(u8 *L, u32 n)
+{
+    for (u32 i = n / 2; i + 1 < n; ++i)
+        if (L[i] != L[i + 1]) {
+            const u8 t = L[i];
+            L[i] = L[i + 1];
+            L[i + 1] = t;
+            return;
+        }
+}
 
 // symbols in use -> key geometry -> rotation sort.  Returns rounds (<0: error).
 static int sort_batch(bz_gpu_engine *g, const BwtArgs &ba, u32 *inuse_bits, u32 max_n, u64 total_n, u64 *sorted,
@@ -569,6 +579,14 @@ static int encode_batch(bz_gpu_engine *g, u32 nb, const std::vector<BlockDesc> &
         static const bool corrupt_test = getenv("BZ_TEST_CORRUPT") && atoi(getenv("BZ_TEST_CORRUPT")) != 0;
         if (corrupt_test && g->fused_state[0] == 0 && descs[o].n > 1)
             hipLaunchKernelGGL(k_test_bump, dim3(1), dim3(1), 0, g->st, g->orig_ptr.as<u32>() + o, descs[o].n);
+        // (tests) BZ_TEST_LATE_CLEAR=1: the OUTCOME of round 3's fault -- a sorted order that is not the block's -- as two
+        // unequal neighbours of the last column swapped.  (The fault itself, stale look-back words under the first
+        // pass's epoch tag, was tried as an injection and is not replayed: tiles scattered to wrong offsets break the
+        // digit-count invariants the later passes index with, and the run ends in a GPU memory fault rather than in a
+        // wrong stream -- on the test box in two attempts of two.)
+        static const bool late_clear_test = getenv("BZ_TEST_LATE_CLEAR") && atoi(getenv("BZ_TEST_LATE_CLEAR")) != 0;
+        if (late_clear_test && g->fused_state[0] == 0 && descs[o].n > 1)
+            hipLaunchKernelGGL(k_test_swap, dim3(1), dim3(1), 0, g->st, g->L.as<u8>() + (size_t)o * kSlot, descs[o].n);
         span_end(g, sp);
         g->bwt_stats[0] = std::max<u64>(g->bwt_stats[0], (u64)rounds);
         g->bwt_stats[1] += sorted;

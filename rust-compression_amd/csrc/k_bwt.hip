@@ -2397,24 +2397,16 @@ static bool init_sort_fused(hipStream_t st, const BwtArgs &a, u64 total_n, Kerne
     hipLaunchKernelGGL(k_ghist_scan, dim3(a.nb), dim3(kSortThreads), 0, st, a, 3u, 1u << B0, 1u << B1, 1u << B2, 0u);
     if (prof) prof->end(st, p);
     // phase A: order by key(j); phase B: walk it, order by key(j - c) -> 2c symbols
-    // (tests) BZ_TEST_LATE_CLEAR=1 emulates round 3's fault -- look-back words that were not cleared in time: the words
-    // of the first pass hold "inclusive prefix 0" under that pass's epoch tag, as a recycled buffer would after a clear
-    // that lands late.  A tile that looks back before its predecessor has published takes the stale word: its elements go
-    // to the wrong places, and neither the ticket counters nor the look-back spins notice.  Only a check of the RESULT
-    // does (bz_gpu_engine_set_verify).
-    static const bool late_clear_test = getenv("BZ_TEST_LATE_CLEAR") && atoi(getenv("BZ_TEST_LATE_CLEAR")) != 0;
-    if (late_clear_test)
-        (void)hipMemsetD32Async((hipDeviceptr_t)a.tile_state, (int)((((*a.epoch + 1u) % kSortEpochs) << 22) | kLbIncl),
-                                (size_t)a.nb * kTilesPerBlock * kMaxBins, st);
-    fused_pass<SRC_TEXT, B0>(st, a, 0, 0, nullptr, nullptr, a.KA, a.VA, 0, total_n, prof);
-    if (!fused_pass_ok(st, a, *a.epoch)) return false;
-    // (tests) BZ_TEST_STALE_TICKETS=1: the ticket counters of the next pass already stand at a full launch's count (a
-    // counter that was not cleared): every workgroup of that pass draws a ticket beyond its XCD's tiles and leaves, no
-    // tile is sorted, and each counter ends at twice its share -- a ">= tiles" check is satisfied, "== share" is not.
+    // (tests) BZ_TEST_STALE_TICKETS=1: the ticket counters of the first pass already stand at a full launch's count (a
+    // counter that was not cleared): every workgroup draws a ticket beyond its XCD's tiles and leaves, no tile is
+    // sorted, and each counter ends at twice its share -- a ">= tiles" check is satisfied, "== share" is not.  (The
+    // first pass, because its check comes before anything reads what the pass wrote.)
     static const bool stale_tickets_test = getenv("BZ_TEST_STALE_TICKETS") && atoi(getenv("BZ_TEST_STALE_TICKETS")) != 0;
     if (stale_tickets_test && *a.epoch + 1u < kSortEpochs)
         (void)hipMemsetD32Async((hipDeviceptr_t)(a.tickets + (size_t)(*a.epoch + 1u) * 8u),
                                 (int)(kTilesPerBlock * (xcd_grid_y(a.nb) / 8u)), 8, st);
+    fused_pass<SRC_TEXT, B0>(st, a, 0, 0, nullptr, nullptr, a.KA, a.VA, 0, total_n, prof);
+    if (!fused_pass_ok(st, a, *a.epoch)) return false;
     fused_pass<SRC_PAIRS, B1>(st, a, B0, 0, a.KA, a.VA, a.KB, a.VB, 1, total_n, prof);
     const u32 *gate = nullptr;
     if (local_b) {
