@@ -117,6 +117,14 @@ void bz_enc_destroy(bz_enc *e);
 int bz_enc_set_verify(bz_enc *e, int on);
 int bz_enc_verify_stats(bz_enc *e, uint64_t out[4]);
 
+/* Where the time of a stream went (milliseconds, summed over its jobs; a diagnostic -- the bytes do not depend on it):
+ * [0] the caller's copies into pinned staging memory  [1] the caller waiting for a free staging buffer
+ * [2] SPLIT sections (compose + RLE1 + block cuts; serial from job to job)  [3] ENCODE (jobs side by side on the lanes)
+ * [4] ASSEMBLE sections (serial)  [5] downloads  [6] number of jobs  [7] workers waiting for their turn in the two serial
+ * sections.  bz_encode_buffer_last_phases: the same for the last one-shot call of the process. */
+int bz_enc_phase_stats(bz_enc *e, double out_ms[8]);
+int bz_encode_buffer_last_phases(double out_ms[8]);
+
 /* One-shot over host buffers:
  * `in.iter().cloned().encode(&mut BZip2Encoder::new(level), Action::Finish).collect()`.
  * *out is malloc'ed by the library; release with bz_free. */

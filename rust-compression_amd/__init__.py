@@ -27,7 +27,7 @@ import sys
 from . import _build
 
 __all__ = ["Action", "CompressionError", "BZip2Error", "BZip2Encoder", "BZip2Decoder", "encode", "decode",
-           "compress", "decompress", "GpuEngine", "release_cached_resources",
+           "compress", "decompress", "GpuEngine", "release_cached_resources", "last_call_phases",
            "build", "lib", "device_count", "encode_bound", "shard_window", "rccl_lib", "rccl_unique_id", "RcclComm"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -79,7 +79,7 @@ def build(force=False):
 EXPORTS = [
     "bz_strerror", "bz_version", "bz_device_count",
     "bz_enc_create", "bz_enc_write", "bz_enc_end", "bz_enc_read", "bz_enc_pending", "bz_enc_destroy",
-    "bz_encode_buffer", "bz_free", "bz_enc_create_multi", "bz_enc_set_verify", "bz_enc_verify_stats",
+    "bz_encode_buffer", "bz_free", "bz_enc_create_multi", "bz_enc_set_verify", "bz_enc_verify_stats", "bz_enc_phase_stats", "bz_encode_buffer_last_phases",
     "bz_gpu_engine_set_verify", "bz_gpu_verify_stats", "bz_encode_buffer_multi", "bz_release_cached_resources",
     "bz_gpu_engine_create", "bz_gpu_engine_destroy", "bz_encode_bound", "bz_gpu_encode_device",
     "bz_gpu_partition", "bz_gpu_partition_slab_begin", "bz_gpu_partition_slab_count",
@@ -146,6 +146,8 @@ def lib():
     L.bz_encode_buffer.argtypes = [C.c_int, C.c_int, C.c_char_p, sz, C.POINTER(u8p), szp]
     L.bz_enc_create_multi.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int), C.c_int]
     L.bz_encode_buffer_multi.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_char_p, sz, C.POINTER(u8p), szp]
+    L.bz_enc_phase_stats.argtypes = [vp, C.POINTER(C.c_double)]
+    L.bz_encode_buffer_last_phases.argtypes = [C.POINTER(C.c_double)]
     L.bz_enc_set_verify.argtypes = [vp, C.c_int]
     L.bz_enc_verify_stats.argtypes = [vp, u64p]
     L.bz_gpu_engine_set_verify.argtypes = [vp, C.c_int]
@@ -366,6 +368,12 @@ class BZip2Encoder:
         _check(lib().bz_enc_verify_stats(self._h, s))
         return dict(zip(self.VERIFY_STATS, [int(x) for x in s]))
 
+    def phase_stats(self):
+        """where the time of this stream went so far (bz_enc_phase_stats)"""
+        t = (C.c_double * 8)()
+        _check(lib().bz_enc_phase_stats(self._h, t))
+        return {k: (int(v) if k == "jobs" else round(v, 3)) for k, v in zip(PHASES, t)}
+
     @classmethod
     def with_devices(cls, level, devices):
         """The same encoder over several GPUs of this process (bz_enc_create_multi): chunks of the input go round
@@ -435,6 +443,17 @@ def encode(iterable, encoder, action):
         if b is None:
             return
         yield b
+
+
+PHASES = ("caller_copy_in_ms", "caller_wait_staging_ms", "split_serial_ms", "encode_ms", "assemble_serial_ms", "download_ms",
+          "jobs", "workers_wait_turn_ms")
+
+
+def last_call_phases():
+    """where the time of the last one-shot call (compress / bz_encode_buffer[_multi]) went (bz_encode_buffer_last_phases)"""
+    t = (C.c_double * 8)()
+    _check(lib().bz_encode_buffer_last_phases(t))
+    return {k: (int(v) if k == "jobs" else round(v, 3)) for k, v in zip(PHASES, t)}
 
 
 def release_cached_resources():

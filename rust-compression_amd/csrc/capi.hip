@@ -291,6 +291,10 @@ struct bz_enc {
     u64 queued = 0;              // jobs queued
     bool stop = false, drain_stop = false;
     int err = BZ_OK;             // sticky
+    // where the time of a stream went, in ms (mu): [0] caller's copies into pinned memory, [1] caller waiting for a free
+    // staging buffer, [2] SPLIT sections (serial from job to job), [3] ENCODE (side by side on the lanes), [4] ASSEMBLE
+    // sections (serial), [5] downloads, [6] jobs, [7] workers waiting for their turn in the two serial sections
+    double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool verify = false;         // bz_enc_set_verify / BZ_VERIFY=1: every job's blocks are decoded and compared before they leave
     u64 vstats[4] = {0, 0, 0, 0}; // (mu) blocks checked, jobs redone, redone jobs that failed again, ns spent checking
 };
@@ -630,11 +634,13 @@ static void worker_main(bz_enc *e, int lane)
         JobState js;
         int rc;
         // SPLIT, in job order
+        const double tw0 = now_ms();
         {
             std::unique_lock<std::mutex> lk(e->mu);
             e->cv.wait(lk, [&] { return e->split_done == j.seq; });
             rc = e->err;
         }
+        const double tw1 = now_ms();
         if (rc == BZ_OK) rc = job_split(e, j, lane, js);
         {
             std::lock_guard<std::mutex> lk(e->mu);
@@ -647,12 +653,15 @@ static void worker_main(bz_enc *e, int lane)
         // ENCODE, beside the other lanes'
         if (rc == BZ_OK) rc = job_encode(e, lane, js);
         // ASSEMBLE, in job order
+        const double tw2 = now_ms();
         {
             std::unique_lock<std::mutex> lk(e->mu);
             if (rc != BZ_OK && e->err == BZ_OK) e->err = rc;
             e->cv.wait(lk, [&] { return e->asm_done == j.seq; });
             if (rc == BZ_OK) rc = e->err;
         }
+        const double tw3 = now_ms();
+        js.t2 = tw3; // (the assembly section begins when its turn has come)
         if (rc == BZ_OK) rc = job_assemble(e, j, lane, js);
         js.t3 = now_ms();
         {
@@ -663,14 +672,23 @@ static void worker_main(bz_enc *e, int lane)
         e->cv.notify_all();
         // DOWNLOAD beside the next job's assembly; the drainer appends in job order
         if (rc == BZ_OK) rc = job_download(e, lane, js);
+        const double t4 = now_ms();
         if (enc_trace())
             fprintf(stderr, "bz_enc job %llu (lane %d, device %d): mode %d, %zu bytes, %zu blocks: split %.2f ms, encode %.2f ms, "
                             "assemble %.2f ms, download %.2f ms (at %.1f)\n",
                     (unsigned long long)j.seq, lane, e->r->lanes[(size_t)lane].device, j.mode, js.n_all, js.n_blocks, js.t1 - js.t0,
-                    js.t2 - js.t1, js.t3 - js.t2, now_ms() - js.t3, now_ms());
+                    tw2 - js.t1, js.t3 - tw3, t4 - js.t3, now_ms());
         {
             std::lock_guard<std::mutex> lk(e->mu);
             if (rc != BZ_OK && e->err == BZ_OK) e->err = rc;
+            if (!js.skipped && js.t1 > 0) {
+                e->phase_ms[2] += js.t1 - js.t0;
+                e->phase_ms[3] += tw2 - js.t1;
+                e->phase_ms[4] += js.t3 - tw3;
+                e->phase_ms[5] += t4 - js.t3;
+                e->phase_ms[7] += (tw1 - tw0) + (tw3 - tw2);
+            }
+            e->phase_ms[6] += 1;
             Drain d;
             d.lane = lane;
             d.bytes = rc == BZ_OK ? js.out_len : 0;
@@ -856,6 +874,7 @@ extern "C" int bz_enc_write(bz_enc *e, const uint8_t *in, size_t n)
     int rc = ensure_started(e);
     if (rc != BZ_OK) return rc;
     EncResources *r = e->r;
+    double t_copy = 0, t_wait = 0;
     while (n) {
         // (the first chunk of a stream is small -- 64 MiB at most: the GPU has work sooner, and a short stream
         // takes little pinned memory; the staging buffers grow with the chunks they hold)
@@ -865,13 +884,17 @@ extern "C" int bz_enc_write(bz_enc *e, const uint8_t *in, size_t n)
             // A full chunk goes to the worker when MORE input arrives (its complete blocks are encoded
             // while the caller goes on writing); the last chunk of a stream is left for bz_enc_end, which
             // sends it together with the caller's Action instead of paying a job for the tail block alone.
+            const double ts0 = now_ms();
             if ((rc = submit(e, BZ_ACTION_RUN, false)) != BZ_OK) return rc;
+            t_wait += now_ms() - ts0;
         }
         if (e->fill == 0 && r->h_lane[e->fill_slot] >= 0) {
             // the pinned buffer of this slot is free once its last upload has completed
+            const double ts0 = now_ms();
             const Lane &ul = r->lanes[(size_t)r->h_lane[e->fill_slot]];
             if (hipSetDevice(ul.device) != hipSuccess || hipEventSynchronize(ul.ev_up) != hipSuccess) return BZ_E_UNEXPECTED;
             r->h_lane[e->fill_slot] = -1;
+            t_wait += now_ms() - ts0;
         }
         if (e->fill + std::min(n, cap - e->fill) > r->h_cap[e->fill_slot]) {
             // room for what this call adds (short streams stay small), for a whole chunk once it is half full
@@ -891,13 +914,35 @@ extern "C" int bz_enc_write(bz_enc *e, const uint8_t *in, size_t n)
             r->h_cap[e->fill_slot] = want;
         }
         const size_t k = std::min(n, cap - e->fill);
+        const double tc0 = now_ms();
         copy_in(r->h_in[e->fill_slot] + e->fill, in, k, e->devices.size());
+        t_copy += now_ms() - tc0;
         e->fill += k;
         in += k;
         n -= k;
     }
     std::lock_guard<std::mutex> lk(e->mu);
+    e->phase_ms[0] += t_copy;
+    e->phase_ms[1] += t_wait;
     return e->err;
+}
+
+extern "C" int bz_enc_phase_stats(bz_enc *e, double out_ms[8])
+{
+    if (!e || !out_ms) return BZ_E_PARAM;
+    std::lock_guard<std::mutex> lk(e->mu);
+    for (int i = 0; i < 8; ++i) out_ms[i] = e->phase_ms[i];
+    return BZ_OK;
+}
+
+static std::mutex g_last_mu;
+static double g_last_phases[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+extern "C" int bz_encode_buffer_last_phases(double out_ms[8])
+{
+    if (!out_ms) return BZ_E_PARAM;
+    std::lock_guard<std::mutex> lk(g_last_mu);
+    for (int i = 0; i < 8; ++i) out_ms[i] = g_last_phases[i];
+    return BZ_OK;
 }
 
 extern "C" int bz_enc_end(bz_enc *e, int action)
@@ -1033,6 +1078,12 @@ extern "C" int bz_encode_buffer_multi(int level, const int *devices, int n_devic
             e->out = nullptr;
             e->out_len = e->out_cap = e->out_head = 0;
         }
+    }
+    {
+        double ph[8];
+        (void)bz_enc_phase_stats(e, ph);
+        std::lock_guard<std::mutex> lk(g_last_mu);
+        for (int i = 0; i < 8; ++i) g_last_phases[i] = ph[i];
     }
     bz_enc_destroy(e);
     return rc;

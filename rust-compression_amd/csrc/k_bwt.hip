@@ -2543,8 +2543,8 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         // tiles of the longest list of the coming round (its members are the rotations the last refinement left
         // unordered), and of the list that refinement ran on
         const u32 list_tiles_prev = list_tiles;
+        const u32 mx = *reinterpret_cast<const u32 *>(h_active + 1); // the most rotations any block is left with
         {
-            const u32 mx = *reinterpret_cast<const u32 *>(h_active + 1);
             list_tiles = (mx + kSortTile - 1) / kSortTile + 1u;
             if (list_tiles > kTilesPerBlock) list_tiles = kTilesPerBlock;
         }
@@ -2556,10 +2556,21 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         ++rounds;
         bool carried = false;
         (void)hipMemsetAsync(a.nonfinal, 0, a.nb * sizeof(u32), st);
-        // Most rotations still unordered after two rounds (4c symbols and more compared): deep repeats.  One period
-        // round (k_block_period) finishes the groups of a periodic block; what it cannot take goes on doubling.
-        static const bool want_period = !(getenv("BZ_PERIOD_ROUND") && atoi(getenv("BZ_PERIOD_ROUND")) == 0);
-        const bool per_round = want_period && !period_done && rounds >= 3 && m * 4 >= total_n * 3;
+        // SOME block with most of its rotations still unordered after a doubling round (4c symbols and more compared;
+        // text is down to 7 % by then): deep repeats.  One period round (k_block_period) finishes the groups of the
+        // blocks that have a linear period; what it cannot take goes on doubling, and blocks without a period pay a
+        // survivor round that leaves their groups as they are (O(their survivors)).  The test is per BLOCK (round 4;
+        // rounds 1-3 asked for three quarters of the whole BATCH, so a batch in which every third block was a deep
+        // repeat took seventeen full-width walk rounds for everybody -- the reference's SA-IS costs the same whatever
+        // the data, sais.rs:127-264): the largest per-block count against the largest block.  BZ_PERIOD_ROUND=batch
+        // restores the old trigger, =0 turns the round off.
+        static const int want_period = [] {
+            const char *e = getenv("BZ_PERIOD_ROUND");
+            return !e ? 1 : (e[0] == 'b' ? 2 : (atoi(e) != 0 ? 1 : 0));
+        }();
+        const bool deep = want_period == 2 ? (rounds >= 3 && m * 4 >= total_n * 3)
+                                           : (rounds >= 2 && ((u64)mx * 4 >= (u64)max_n * 3 || m * 4 >= total_n * 3));
+        const bool per_round = want_period != 0 && !period_done && deep;
         u8 *impure = a.ptext; // (the packed text is not read any more once the init is over)
         if (per_round) {
             period_done = true;

@@ -9,7 +9,8 @@ oracle/deflate_oracle.c; single thread, one serial stream each).
 
 Entries (key -> corpus):  bzip2_l9_text_<N>gib (N = 1, 2, 4, 8: corpus.corpus_bytes(N GiB), the stream of
 bench.py --gpus N), bzip2_l9_text_64mib, bzip2_l9_t2_1gib, deflate_text_1gib, deflate_text_64mib, deflate_text_2gib
-(raw Deflate; zlib / gzip wrap the same bits; 2 GiB: more than one call of the GPU path handles in one part)."""
+(raw Deflate; zlib / gzip wrap the same bits; 2 GiB: more than one call of the GPU path handles in one part);
+bzip2_l9_<random|dna|binary|mix|logs>_32mib: the first 32 MiB of the 256 MiB corpora of corpus.matrix_corpus."""
 import argparse
 import hashlib
 import json
@@ -23,7 +24,10 @@ sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tests", "golden", "corpus_hashes.json")
 
 KEYS = ["bzip2_l9_text_64mib", "deflate_text_64mib", "bzip2_l9_text_1gib", "deflate_text_1gib", "bzip2_l9_t2_1gib",
-        "bzip2_l9_text_2gib", "bzip2_l9_text_4gib", "bzip2_l9_text_8gib", "deflate_text_2gib"]
+        "bzip2_l9_text_2gib", "bzip2_l9_text_4gib", "bzip2_l9_text_8gib", "deflate_text_2gib",
+        # the corpus matrix of bench.py extra.corpora (corpus.MATRIX): the first 32 MiB of each 256 MiB corpus
+        "bzip2_l9_random_32mib", "bzip2_l9_dna_32mib", "bzip2_l9_binary_32mib", "bzip2_l9_mix_32mib", "bzip2_l9_logs_32mib"]
+MATRIX_BYTES = 256 << 20  # the corpora are generated at this size (their content depends on it) and cut
 
 
 def make(key):
@@ -34,7 +38,11 @@ def make(key):
     codec, rest = key.split("_", 1)
     size = rest.rsplit("_", 1)[1]
     n = int(size[:-3]) << (30 if size.endswith("gib") else 20)
-    data = corpus.stress_t2(n) if "_t2_" in key else corpus.corpus_bytes(n)
+    kind = rest.rsplit("_", 1)[0].split("_", 1)[1]
+    if kind in corpus.MATRIX:
+        data = bytes(corpus.matrix_corpus(kind, MATRIX_BYTES)[:n])
+    else:
+        data = corpus.stress_t2(n) if "_t2_" in key else corpus.corpus_bytes(n)
     if codec == "bzip2":
         out = oracle.encode(data, 9)
     else:

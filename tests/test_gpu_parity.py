@@ -532,3 +532,42 @@ def test_period_round_on_deep_repeats(pkg, oracle, eng):
     # and whole streams (several periodic blocks per stream) against the oracle
     for data, level in (((para(4096) * 400)[:1_500_000], 5), ((b"ab" * 300_000)[:555_555], 1)):
         assert pkg.compress(data, level) == oracle.encode(data, level)
+
+
+def test_period_round_in_mixed_batches(pkg, oracle):
+    """A batch in which every third block is a deep repeat (text, text, a 4 KiB paragraph repeated, ...): the period
+    round is triggered by the BLOCKS that need it (round 4; rounds 1-3 looked at the batch as a whole, which such a
+    batch never satisfied: seventeen full-width rounds for everybody).  Streams against the oracle's -- the text
+    blocks go through a period round that must leave them alone -- and the round count says the round did run.
+    Other mixes: one deep block among many, deep blocks of different periods, a deep block that has no linear
+    period (defect in the middle: it goes on doubling while the others are finished)."""
+    import torch
+    import corpus
+    rng = random.Random(5)
+
+    def para(k):
+        return bytes(rng.choice(b"abcdefgh \n") for _ in range(k))
+
+    text = corpus.chapter(2, 1_300_000)
+    blk = 99_981  # a level-1 block
+    deep = [(para(4096) * 30)[:blk], (para(777) * 140)[:blk], (para(30_011) * 5)[:blk]]
+    broken = bytearray((para(512) * 220)[:blk])
+    broken[50_000] ^= 1
+    mixes = {
+        "2:1": b"".join(text[i * 2 * blk:(i + 1) * 2 * blk] + deep[i % 3] for i in range(6)),
+        "one deep in twelve": text[:6 * blk] + deep[0] + text[6 * blk:11 * blk],
+        "deep with a defect": text[:2 * blk] + bytes(broken) + deep[1] + text[2 * blk:4 * blk],
+    }
+    eng = pkg.GpuEngine(0, 32)
+    try:
+        for name, data in mixes.items():
+            t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+            cap = (pkg.encode_bound(len(data)) + 15) & ~15
+            o = torch.empty(cap, dtype=torch.uint8, device="cuda")
+            k = eng.encode_device(1, t.data_ptr(), len(data), o.data_ptr(), cap)
+            assert bytes(o[:k].cpu().numpy()) == oracle.encode(data, 1), name
+            rounds = eng.bwt_stats()["rounds"]
+            # (a block with a defect in the middle has common prefixes of half its length: it doubles to the end)
+            assert rounds <= (18 if "defect" in name else 7), (name, rounds)
+    finally:
+        eng.close()
