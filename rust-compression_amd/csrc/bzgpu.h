@@ -275,8 +275,8 @@ struct BwtArgs {
     unsigned long long *active;      // [64] per-round count of non-final rotations in unfinished blocks
     u32 *maxnf;                      // [64] per round: the largest number of non-final rotations any block is left with
     u32 *per_k, *per_shift;          // [nb] periodic blocks: repetition count, least-rotation start
-    u32 *lin_p, *lin_sig;            // [nb] blocks with a linear period (k_block_period): the period (0: none), 1 / 2 =
-                                     //   rotations congruent modulo it are ordered by ascending / descending start
+    u32 *lin_p, *lin_sig;            // [nb] blocks with a period (k_period_find): the period (0: none), the anchors that
+                                     //   voted for it
     u32 *bin_cursor;                 // [nb][1024] rank words binned so far (k_group_apply -> k_rank_place)
     u32 *pb_gate;                    // [nb] != 0: phase B of the init by the global passes (0: k_phase_b_local did it)
     u32 *loc_stats;                  // [4] k_phase_b_local: segments, overflows, segments out of order, LDS passes

@@ -45,7 +45,7 @@ namespace bzgpu {
 enum { SRC_TEXT = 0, SRC_PAIRS = 1, SRC_MM = 2, SRC_WALK = 3, SRC_SURV = 4, SRC_LISTG = 5,
        SRC_TEXTK = 6, SRC_WALKK = 7, SRC_MMK = 8, // ..K: keys stored by the histogram kernel of the pass
        SRC_MMC = 9, // MM that also CARRIES the rank of rotation j+h along (k_radix_scatter_lb, first walk round)
-       SRC_PERJ = 10 }; // the survivors keyed by their own start (the period round, see k_block_period)
+       SRC_PERJ = 10 }; // the survivors keyed by their own start (the period round, see k_period_find)
 // sources whose sequence is the compacted list (length count[lb]) rather than all n positions
 template <int SRC> struct src_is_list {
     static constexpr bool value = (SRC == SRC_PAIRS || SRC == SRC_SURV || SRC == SRC_LISTG || SRC == SRC_PERJ);
@@ -88,6 +88,38 @@ __device__ __forceinline__ u64 newbits_lane_word(const u64 *__restrict__ bits, s
         else if (cnt - rowbase < 64u) m |= ~0ull << (cnt - rowbase);
     }
     return m;
+}
+
+// ---- the period round's tables (k_period_find / k_period_bits / k_period_next), per block, in the flag bytes' slot ----
+// For a block with period p (lin_p): mis = bitmap of the positions i with T[i] != T[(i + p) mod n], lt = bitmap of
+// T[i] < T[(i + p) mod n], nxt[w] = the first such position at or behind 64 w (+ n when the search wraps).
+constexpr u32 kPerWords = kSlot / 64u; // 14080 words of 64 positions
+__device__ __forceinline__ const u64 *per_mis(const BwtArgs &a, u32 lb) { return reinterpret_cast<const u64 *>(a.flags + (size_t)lb * kSlot); }
+__device__ __forceinline__ const u64 *per_lt(const BwtArgs &a, u32 lb) { return per_mis(a, lb) + kPerWords; }
+__device__ __forceinline__ const u32 *per_nxt(const BwtArgs &a, u32 lb) { return reinterpret_cast<const u32 *>(per_mis(a, lb) + 2u * kPerWords); }
+// Rotations i and i + p (both < n) agree until the first position m >= i (cyclic) where the block and the block
+// shifted by p differ, and there rotation i reads T[m], rotation i + p reads T[m + p].
+// per_first_mis: that m, in [i, i + n);  per_lt_at: T[m] < T[m + p], i.e. rot(i) < rot(i + p)
+__device__ __forceinline__ u32 per_first_mis(const BwtArgs &a, u32 lb, u32 i)
+{
+    const u32 w = i >> 6;
+    const u64 here = per_mis(a, lb)[w] & (~0ull << (i & 63u));
+    return here ? (w << 6) + (u32)__builtin_ctzll(here) : per_nxt(a, lb)[w + 1u];
+}
+__device__ __forceinline__ bool per_lt_at(const BwtArgs &a, u32 lb, u32 n, u32 m)
+{
+    if (m >= n) m -= n;
+    return (per_lt(a, lb)[m >> 6] >> (m & 63u)) & 1ull;
+}
+// The direction a survivor is keyed by in the period round: that of a pair it belongs to at the depth reached -- the
+// pair (j, j + p) if those two still agree on `depth` symbols (they are in one group then), else the pair (j - p, j):
+// the last member of a chain has no successor in its group, and what decides its own successor pair is not the chain's
+// business.
+__device__ __forceinline__ bool per_key_ascending(const BwtArgs &a, u32 lb, u32 n, u32 p, u32 depth, u32 j)
+{
+    const u32 m = per_first_mis(a, lb, j);
+    if ((j + p < n && m - j >= depth) || j < p) return per_lt_at(a, lb, n, m);
+    return per_lt_at(a, lb, n, per_first_mis(a, lb, j - p));
 }
 
 // Batched form: the 16 rows of one lane.  All primary loads are issued back to back (clamped
@@ -178,17 +210,19 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
             key[r] = a.R[base + t] & ~kFinalBit;
         }
     } else if (SRC == SRC_PERJ) {
-        // the period round: order the survivors by where they start -- ascending or descending, as the block's
-        // period decides (k_block_period)
-        const bool desc = a.lin_sig[lb] == 2u;
+        // the period round: order the survivors by where they start -- ascending or descending, as the first
+        // difference between the block and the block shifted by its period decides for each of them (per_ascending)
+        const u32 p = a.lin_p[lb]; // (hm: the depth reached, in symbols)
 #pragma unroll
         for (u32 r = 0; r < 16; ++r) {
             const u32 idx = first + r * 64u;
             const u32 c = idx < cnt ? idx : cnt - 1u;
             val[r] = ld_stream(Vin + base + c);
-            key[r] = desc ? (n - 1u - val[r]) : val[r];
             ok |= (idx < cnt ? 1u : 0u) << r;
         }
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r)
+            key[r] = (p != 0u && !per_key_ascending(a, lb, n, p, hm, val[r])) ? (n - 1u - val[r]) : val[r];
     } else if (SRC == SRC_LISTG) {
         // survivor round, second half: walk that order, key = the survivor's own group
 #pragma unroll
@@ -274,7 +308,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shif
     const u8 *text = a.rle + d.rle_off;
     const u8 *pt = a.ptext + (size_t)lb * kSlot;
     const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
-    const u32 hm = (SRC == SRC_MM || SRC == SRC_MMK || SRC == SRC_SURV) ? (((u32)ki.chars * 2u) << h) % n : 0u;
+    const u32 hm = (SRC == SRC_MM || SRC == SRC_MMK || SRC == SRC_SURV) ? (((u32)ki.chars * 2u) << h) % n
+                   : (SRC == SRC_PERJ ? (u32)((((u64)ki.chars * 2u) << h) < n ? (((u64)ki.chars * 2u) << h) : n) : 0u);
 
     for (u32 i = threadIdx.x; i < kHistCopies * NB; i += kSortThreads) (&s_hist[0][0])[i] = 0;
     __syncthreads();
@@ -287,7 +322,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shif
         for (u32 r = 0; r < 16; ++r)
             if ((ok >> r) & 1u) atomicAdd(&s_hist[l & (kHistCopies - 1)][(key[r] >> shift) & (NB - 1)], 1u);
         // keys that cost a gather to build are kept for the scatter kernel of the same pass
-        if ((SRC == SRC_TEXT || SRC == SRC_WALK || SRC == SRC_MM || SRC == SRC_SURV || SRC == SRC_LISTG) && Kstore) {
+        if ((SRC == SRC_TEXT || SRC == SRC_WALK || SRC == SRC_MM || SRC == SRC_SURV || SRC == SRC_LISTG || SRC == SRC_PERJ) && Kstore) {
             const size_t base = (size_t)lb * kSlot;
 #pragma unroll
             for (u32 r = 0; r < 16; ++r) {
@@ -1977,22 +2012,32 @@ __global__ __launch_bounds__(kSortThreads) void k_periodic_place(BwtArgs a)
     }
 }
 
-// ---- blocks with a LINEAR period: deep repeats without the doubling rounds ---------------------------------
-// A block that is a paragraph repeated (stress corpus T2: 4 KiB x 220) has common prefixes of almost its whole length,
-// and prefix doubling pays log2(n / 2c) = 17 full rounds for it.  If T[i] == T[i + p] for all i < n - p (p the
-// smallest such period, p not a divisor of n), rotations i and i + p agree until the later one runs over the end of
-// the block: at offset d = n - p - i + e rotation i reads T[n - p + e] and rotation i + p reads T[e], for EVERY i.
-// So with e* the first e in [0, p) where T[n - p + e] != T[e] (it exists: the period is primitive and n mod p != 0),
-// rot(i) < rot(i + p) for all i < n - p if T[n - p + e*] < T[e*], and rot(i) > rot(i + p) for all of them otherwise:
-// rotations whose starts are congruent modulo p are ordered by their starts, ascending or descending.  A group of
-// still-equal rotations that are all congruent modulo p is therefore finished by ONE sort by start -- the period
-// round of run_bwt_once -- instead of the rounds that are left; groups that mix residues go on doubling (their common
-// prefixes are short: they end inside the paragraph).  The reference (sais.rs:266-272) only fixes the ORDER, which
-// this is.  k_block_period finds p, checks it over the whole block and settles the direction; blocks without such a
-// period (lin_p = 0) take no harm from the round: their groups are left alone.
-__global__ __launch_bounds__(kSortThreads) void k_block_period(BwtArgs a)
+// ---- blocks with a PERIOD: deep repeats without the doubling rounds ---------------------------------------------------
+// A block that holds a stretch repeated at distance p -- a paragraph repeated (stress corpus T2: 4 KiB x 220), a file
+// that occurs twice, a record format -- has common prefixes as long as the stretch, and prefix doubling pays
+// log2(length / 2c) rounds for it (17 for T2).  The reference's SA-IS (sais.rs:127-264) costs the same whatever the data.
+// What makes such data cheap: rotations i and i + p agree exactly until the first position m >= i (cyclic) where the
+// block differs from itself shifted by p, and THERE rotation i reads T[m] and rotation i + p reads T[m + p].  So
+//     rot(i) < rot(i + p)  <=>  T[m(i)] < T[m(i) + p],   m(i) = min { m >= i : T[m] != T[m + p] }   (indices mod n),
+// whatever the depth the doubling has reached -- one bitmap of the mismatch positions and one of their directions
+// answer it for every i.  A group of still-equal rotations whose members, ordered by start, step by exactly p and agree on
+// the direction is therefore a chain whose order is its order by start (ascending or descending): the period round
+// sorts the survivors by (group, start or mirrored start) and makes every member of such a group a group of its own.
+// Groups that mix residues, skip a member, or mix directions are marked impure (k_period_mark) and go on doubling.
+// Rounds 2-3 knew one case of this -- a block that is periodic from its first byte to its last (one direction for the
+// whole block); a block with a few foreign bytes in front of the repeated paragraph (a block cut that does not fall on a
+// paragraph boundary: every real file) got no help.  Now the period is looked for at eight anchors inside the block, it
+// need not hold everywhere (half the block is enough), and the direction is per mismatch.  Only the ORDER is the
+// reference's business (sais.rs:266-272), and the comparison above is exact.
+//   k_period_find  one workgroup per block with most of its rotations unordered: the distance at which the 16 bytes at
+//                  an anchor recur, by vote over eight anchors; kept when the block agrees with itself shifted by it at
+//                  half of its positions or more, and not everywhere (a block periodic as a cycle has equal rotations:
+//                  k_periodic_place's case)
+//   k_period_bits  the two bitmaps;  k_period_next  first mismatch at or behind every 64-position word
+__global__ __launch_bounds__(kSortThreads) void k_period_find(BwtArgs a)
 {
-    __shared__ u32 s_best, s_bad, s_e;
+    constexpr u32 kAnchors = 8;
+    __shared__ u32 s_best, s_cand[kAnchors], s_agree;
     const u32 lb = blockIdx.x, tid = threadIdx.x;
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
@@ -2001,70 +2046,158 @@ __global__ __launch_bounds__(kSortThreads) void k_block_period(BwtArgs a)
         a.lin_p[lb] = 0;
         a.lin_sig[lb] = 0;
     }
-    if (n < 256u) return;
-    u64 h0, h1;
-    __builtin_memcpy(&h0, text, 8);
-    __builtin_memcpy(&h1, text + 8, 8);
-    u32 from = 1, p = 0;
-    for (u32 attempt = 0; attempt < 8u; ++attempt) { // (uniform)
-        if (tid == 0) {
-            s_best = 0xFFFFFFFFu;
-            s_bad = 0;
-        }
+    // (count2: the survivors of the last refinement, k_survivor_compact) only blocks that are deep in repeats
+    if (n < 256u || (u64)a.count2[lb] * 4u < (u64)n * 3u) return;
+    for (u32 k = 0; k < kAnchors; ++k) { // (uniform)
+        const u32 at = (u32)(((u64)n * (k + 1u)) / 20u); // 5 % .. 40 % of the block: room for periods beyond n / 2
+        u64 h0, h1;
+        __builtin_memcpy(&h0, text + at, 8);
+        __builtin_memcpy(&h1, text + at + 8, 8);
+        if (tid == 0) s_best = 0xFFFFFFFFu;
         __syncthreads();
-        // the smallest shift >= from under which the first 16 bytes recur
-        for (u32 q = from + tid; q <= n / 2u && q < s_best; q += kSortThreads) {
+        const u32 last = n - 16u - at; // the farthest shift that keeps the 16 bytes inside the block
+        for (u32 q = 1u + tid; q <= last && q < s_best; q += kSortThreads) {
             u64 x0, x1;
-            __builtin_memcpy(&x0, text + q, 8);
-            __builtin_memcpy(&x1, text + q + 8, 8);
+            __builtin_memcpy(&x0, text + at + q, 8);
+            __builtin_memcpy(&x1, text + at + q + 8, 8);
             if (x0 == h0 && x1 == h1) {
                 atomicMin(&s_best, q);
                 break;
             }
         }
         __syncthreads();
-        const u32 cand = s_best;
-        if (cand == 0xFFFFFFFFu) return;
-        // is it a period of the whole block?
-        const u32 len = n - cand;
-        for (u32 i = tid * 8u; i < len && !s_bad; i += kSortThreads * 8u) {
-            if (i + 8u <= len) {
-                u64 x, y;
-                __builtin_memcpy(&x, text + i, 8);
-                __builtin_memcpy(&y, text + i + cand, 8);
-                if (x != y) s_bad = 1;
-            } else {
-                for (u32 k = i; k < len; ++k)
-                    if (text[k] != text[k + cand]) s_bad = 1;
-            }
-        }
-        __syncthreads();
-        if (!s_bad) {
-            p = cand;
-            break;
-        }
-        from = cand + 1u;
+        if (tid == 0) s_cand[k] = s_best;
         __syncthreads();
     }
-    if (p == 0 || n % p == 0u) return; // (none found; or the block is periodic as a CYCLE: k_periodic_place's case)
-    if (tid == 0) s_e = 0xFFFFFFFFu;
-    __syncthreads();
-    for (u32 e = tid; e < p && e < s_e; e += kSortThreads)
-        if (text[n - p + e] != text[e]) {
-            atomicMin(&s_e, e);
-            break;
+    // the candidate under which the block agrees with itself at the most positions (an anchor inside a run of equal
+    // bytes answers "1", one inside a short inner repeat answers that repeat's distance: the whole block decides)
+    u32 p = 0, best = 0;
+    for (u32 k = 0; k < kAnchors; ++k) { // (uniform: every thread reads the same shared words)
+        const u32 c = s_cand[k];
+        bool seen = c == 0xFFFFFFFFu;
+        for (u32 j = 0; j < k; ++j) seen = seen || s_cand[j] == c;
+        if (seen) continue;
+        if (tid == 0) s_agree = 0;
+        __syncthreads();
+        u32 mine = 0;
+        for (u32 i = tid * 8u; i < n; i += kSortThreads * 8u) {
+            if (i + 8u + c <= n) {
+                u64 x, y;
+                __builtin_memcpy(&x, text + i, 8);
+                __builtin_memcpy(&y, text + i + c, 8);
+                const u64 z = x ^ y; // bytes that agree are zero bytes
+                mine += 8u - (u32)__popcll(((z | (z >> 1) | (z >> 2) | (z >> 3) | (z >> 4) | (z >> 5) | (z >> 6) | (z >> 7)) & 0x0101010101010101ull));
+            } else {
+                for (u32 q = i; q < i + 8u && q < n; ++q) {
+                    const u32 t = q + c;
+                    mine += text[q] == text[t >= n ? t - n : t] ? 1u : 0u;
+                }
+            }
         }
-    __syncthreads();
-    if (tid == 0 && s_e != 0xFFFFFFFFu) {
+        mine = wave_sum(mine);
+        if ((tid & 63u) == 0) atomicAdd(&s_agree, mine);
+        __syncthreads();
+        const u32 agree = s_agree;
+        if (agree < n && (agree > best || (agree == best && c < p))) { // (agree == n: periodic as a cycle -- equal rotations)
+            best = agree;
+            p = c;
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && p != 0u && (u64)best * 2u >= n) {
         a.lin_p[lb] = p;
-        a.lin_sig[lb] = text[n - p + s_e] < text[s_e] ? 1u : 2u; // 1: ascending starts, 2: descending
+        a.lin_sig[lb] = (u32)(((u64)best * 1000u) / n); // (for the trace: agreement in permille)
     }
 }
 
-// the period round's list, ordered by (group, start): a group that holds two neighbours of different residues modulo
-// the period is marked impure (one byte per group head)
-__global__ __launch_bounds__(kSortThreads) void k_period_mark(BwtArgs a, const u32 *__restrict__ K, const u32 *__restrict__ V,
-                                                               u8 *__restrict__ impure)
+__global__ __launch_bounds__(kSortThreads) void k_period_bits(BwtArgs a)
+{
+    u32 tile, lb;
+    xcd_remap(gridDim.x, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    const u32 p = a.lin_p[lb];
+    if (p == 0u) return;
+    const BlockDesc d = a.blocks[lb];
+    const u32 n = d.n;
+    const u32 start = tile * kSortTile;
+    if (start >= n) return;
+    const u8 *__restrict__ text = a.rle + d.rle_off;
+    u64 *mis = const_cast<u64 *>(per_mis(a, lb)), *lt = const_cast<u64 *>(per_lt(a, lb));
+    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 i = start + w * 1024u + r * 64u + l;
+        bool m = false, less = false;
+        if (i < n) {
+            const u32 t = i + p;
+            const u8 x = text[i], y = text[t >= n ? t - n : t];
+            m = x != y;
+            less = x < y;
+        }
+        const u64 bm = __ballot(m), bl = __ballot(less);
+        if (l == 0 && start + w * 1024u + r * 64u < n) {
+            mis[(start + w * 1024u + r * 64u) >> 6] = bm;
+            lt[(start + w * 1024u + r * 64u) >> 6] = bl;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kSortThreads) void k_period_next(BwtArgs a)
+{
+    __shared__ u32 s_first[kSortThreads];
+    const u32 lb = blockIdx.x, tid = threadIdx.x;
+    if (a.lin_p[lb] == 0u) return;
+    const u32 n = a.blocks[lb].n;
+    const u32 nw = (n + 63u) >> 6;
+    const u64 *mis = per_mis(a, lb);
+    u32 *nxt = const_cast<u32 *>(per_nxt(a, lb));
+    const u32 per = (nw + kSortThreads - 1u) / kSortThreads; // words per thread, consecutive
+    const u32 w0 = tid * per, w1 = w0 + per < nw ? w0 + per : nw;
+    u32 first = 0xFFFFFFFFu; // the first mismatch inside this thread's words
+    for (u32 w = w0; w < w1; ++w) {
+        const u64 m = mis[w];
+        if (m) {
+            first = (w << 6) + (u32)__builtin_ctzll(m);
+            break;
+        }
+    }
+    s_first[tid] = first;
+    __syncthreads();
+    // the first mismatch behind this thread's words (threads above it, then -- wrapping -- the block's first one + n)
+    u32 behind = 0xFFFFFFFFu;
+    for (u32 t = tid + 1u; t < kSortThreads; ++t)
+        if (s_first[t] != 0xFFFFFFFFu) {
+            behind = s_first[t];
+            break;
+        }
+    if (behind == 0xFFFFFFFFu)
+        for (u32 t = 0; t < kSortThreads; ++t)
+            if (s_first[t] != 0xFFFFFFFFu) {
+                behind = s_first[t] + n;
+                break;
+            }
+    u32 run = behind;
+    for (u32 w = w1; w > w0;) {
+        --w;
+        const u64 m = mis[w];
+        if (m) run = (w << 6) + (u32)__builtin_ctzll(m);
+        nxt[w] = run;
+    }
+    if (tid == 0) { // (the word behind the last one: the wrap)
+        u32 f = 0xFFFFFFFFu;
+        for (u32 t = 0; t < kSortThreads; ++t)
+            if (s_first[t] != 0xFFFFFFFFu) {
+                f = s_first[t];
+                break;
+            }
+        nxt[nw] = f + n;
+    }
+}
+
+// the period round's list, ordered by (group, start or mirrored start): a group in which two neighbours do not step by
+// exactly the period, or disagree about the direction, is marked impure (one byte per group head)
+__global__ __launch_bounds__(kSortThreads) void k_period_mark(BwtArgs a, u32 step, const u32 *__restrict__ K,
+                                                               const u32 *__restrict__ V, u8 *__restrict__ impure)
 {
     u32 tile, lb;
     xcd_remap(gridDim.x, a.nb, tile, lb);
@@ -2073,11 +2206,19 @@ __global__ __launch_bounds__(kSortThreads) void k_period_mark(BwtArgs a, const u
     const u32 start = tile * kSortTile;
     const u32 p = a.lin_p[lb];
     if (start >= cnt || p == 0u) return;
+    const u32 n = a.blocks[lb].n;
+    const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
+    const u64 d64 = ((u64)ki.chars * 2u) << step;
+    const u32 depth = d64 < n ? (u32)d64 : n;
     const size_t base = (size_t)lb * kSlot;
     for (u32 idx = start + threadIdx.x; idx < cnt && idx < start + kSortTile; idx += kSortThreads) {
         if (idx == 0) continue;
         const u32 g = K[base + idx], gp = K[base + idx - 1];
-        if (g == gp && (V[base + idx] % p) != (V[base + idx - 1] % p)) impure[base + g] = 1;
+        if (g != gp) continue;
+        const u32 v = V[base + idx], vp = V[base + idx - 1];
+        const bool asc = per_key_ascending(a, lb, n, p, depth, v), ascp = per_key_ascending(a, lb, n, p, depth, vp);
+        const bool chain = asc == ascp && (asc ? v == vp + p : vp == v + p);
+        if (!chain) impure[base + g] = 1;
     }
 }
 
@@ -2324,7 +2465,7 @@ static void radix_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const
     else if (SRC == SRC_MM && Ktmp)
         hipLaunchKernelGGL((k_radix_scatter<SRC_MMK, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Ktmp,
                            Vin, Kout, Vout);
-    else if ((SRC == SRC_SURV || SRC == SRC_LISTG) && Ktmp) // the gathered ranks were kept: a plain pair list now
+    else if ((SRC == SRC_SURV || SRC == SRC_LISTG || SRC == SRC_PERJ) && Ktmp) // the gathered keys were kept: a plain pair list now
         hipLaunchKernelGGL((k_radix_scatter<SRC_PAIRS, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Ktmp,
                            Vin, Kout, Vout);
     else
@@ -2557,7 +2698,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         bool carried = false;
         (void)hipMemsetAsync(a.nonfinal, 0, a.nb * sizeof(u32), st);
         // SOME block with most of its rotations still unordered after a doubling round (4c symbols and more compared;
-        // text is down to 7 % by then): deep repeats.  One period round (k_block_period) finishes the groups of the
+        // text is down to 7 % by then): deep repeats.  One period round (k_period_find ...) finishes the groups of the
         // blocks that have a linear period; what it cannot take goes on doubling, and blocks without a period pay a
         // survivor round that leaves their groups as they are (O(their survivors)).  The test is per BLOCK (round 4;
         // rounds 1-3 asked for three quarters of the whole BATCH, so a batch in which every third block was a deep
@@ -2571,20 +2712,29 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         const bool deep = want_period == 2 ? (rounds >= 3 && m * 4 >= total_n * 3)
                                            : (rounds >= 2 && ((u64)mx * 4 >= (u64)max_n * 3 || m * 4 >= total_n * 3));
         const bool per_round = want_period != 0 && !period_done && deep;
+        static const bool bwt_trace = getenv("BZ_BWT_TRACE") != nullptr;
+        if (bwt_trace)
+            fprintf(stderr, "bz2_mi355x: sort round %d (h = %llu): %llu of %llu rotations unordered, at most %u in one block (of %u)%s\n",
+                    rounds, (unsigned long long)(2u * min_chars) << step, (unsigned long long)m, (unsigned long long)total_n, mx,
+                    max_n, per_round ? ": period round" : (m * 4 < total_n ? ": survivor form" : ": walk form"));
         u8 *impure = a.ptext; // (the packed text is not read any more once the init is over)
         if (per_round) {
             period_done = true;
-            hipLaunchKernelGGL(k_block_period, dim3(a.nb), dim3(kSortThreads), 0, st, a);
             (void)hipMemsetAsync(impure, 0, (size_t)a.nb * kSlot, st);
             hipLaunchKernelGGL(k_survivor_compact, grid_prev, dim3(kSortThreads), 0, st, a, lastV, fV);
             hipLaunchKernelGGL(k_copy_counts, dim3((a.nb + 255) / 256), dim3(256), 0, st, a.count, a.count2, a.nb);
-            radix_pass<SRC_PERJ, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, nullptr, list_tiles);
+            // the blocks' periods and the two bitmaps that order rotation i against rotation i + p (in the flag bytes'
+            // slot, which nothing uses before this round's k_group_flags)
+            hipLaunchKernelGGL(k_period_find, dim3(a.nb), dim3(kSortThreads), 0, st, a);
+            hipLaunchKernelGGL(k_period_bits, grid, dim3(kSortThreads), 0, st, a);
+            hipLaunchKernelGGL(k_period_next, dim3(a.nb), dim3(kSortThreads), 0, st, a);
+            radix_pass<SRC_PERJ, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK, list_tiles);
             radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof, nullptr, list_tiles);
             radix_pass<SRC_LISTG, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK, list_tiles);
             radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof, nullptr, list_tiles);
             u32 *t = cK; cK = fK; fK = t;
             t = cV; cV = fV; fV = t;
-            hipLaunchKernelGGL(k_period_mark, grid_list, dim3(kSortThreads), 0, st, a, cK, cV, impure);
+            hipLaunchKernelGGL(k_period_mark, grid_list, dim3(kSortThreads), 0, st, a, step, cK, cV, impure);
         } else if (m * 4 < total_n) {
             // few survivors: compact them (list order = sorted by group), order them by the rank
             // of rotation j+h (2 passes), then stably by their own group (2 passes): O(m) work
@@ -2639,6 +2789,18 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         p = prof ? prof->begin(st, KID_RANK_PLACE, m * 8) : -1;
         hipLaunchKernelGGL(k_rank_place, grid, dim3(kSortThreads), 0, st, a, fK);
         if (prof) prof->end(st, p);
+        if (per_round && bwt_trace) {
+            std::vector<u32> lp(a.nb), ls(a.nb), nf(a.nb), cn(a.nb);
+            (void)hipMemcpyAsync(lp.data(), a.lin_p, a.nb * 4, hipMemcpyDeviceToHost, st);
+            (void)hipMemcpyAsync(ls.data(), a.lin_sig, a.nb * 4, hipMemcpyDeviceToHost, st);
+            (void)hipMemcpyAsync(nf.data(), a.nonfinal, a.nb * 4, hipMemcpyDeviceToHost, st);
+            (void)hipMemcpyAsync(cn.data(), a.count, a.nb * 4, hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+            for (u32 b = 0; b < a.nb; ++b)
+                if (lp[b] || nf[b] * 2u > max_n)
+                    fprintf(stderr, "  block %u: period %u (the block agrees with itself shifted by it at %u permille of its positions), list %u, %u rotations left unordered\n", b, lp[b],
+                            ls[b], cn[b], nf[b]);
+        }
         lastV = cV;
         if (!per_round) ++step;
     }
