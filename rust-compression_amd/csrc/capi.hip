@@ -15,7 +15,18 @@
 // pads mid-stream, an empty write_block still rotates the combined CRC (:237-238) and repeats
 // the "BZh" header while block_no == 1 (:245).
 #include "../../include/bz2_mi355x.h"
+#ifdef BZ_HOST_PIPELINE_TEST
+// tests/host_stub: this file alone, compiled by a host compiler under ThreadSanitizer / AddressSanitizer against a stub
+// engine, with the HIP calls below served by a host shim whose streams are threads (tests/test_host_pipeline_sanitize.py)
+#include "hip_shim.h"
+namespace bzgpu {
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+} // namespace bzgpu
+#else
 #include "bzgpu.h"
+#endif
 
 #include <algorithm>
 #include <chrono>
@@ -127,6 +138,10 @@ static std::vector<EncResources *> g_cache; // resources of destroyed contexts, 
 
 static size_t enc_chunk_bytes()
 {
+#ifdef BZ_HOST_PIPELINE_TEST
+    if (const char *b = getenv("BZ_ENC_CHUNK_BYTES")) // (sanitizer runs: small chunks, many jobs; read at every call)
+        return (size_t)std::max(4096L, atol(b));
+#endif
     static const size_t v = [] {
         const char *s = getenv("BZ_ENC_CHUNK_MIB");
         long mib = s ? atol(s) : 384;
@@ -179,6 +194,10 @@ static int resources_get(const std::vector<int> &devices, EncResources **out)
     // blocks in flight: a chunk of level-9 text is chunk / 0.9 MB blocks (lower levels and run-heavy
     // inputs take several batches)
     r->engine_blocks = r->chunk / 800000 + 16;
+    if (const char *e = getenv("BZ_ENC_MAX_BLOCKS")) { // blocks in flight per lane (a job with more runs in several batches)
+        const long v = atol(e);
+        if (v >= 8 && (size_t)v < r->engine_blocks) r->engine_blocks = (size_t)v;
+    }
     r->lanes.resize(2 * devices.size());
     bool ok = true;
     for (size_t l = 0; l < r->lanes.size() && ok; ++l) { // (engines and buffers come with the jobs: job_split, grow)
@@ -892,6 +911,12 @@ extern "C" int bz_enc_write(bz_enc *e, const uint8_t *in, size_t n)
             // the pinned buffer of this slot is free once its last upload has completed
             const double ts0 = now_ms();
             const Lane &ul = r->lanes[(size_t)r->h_lane[e->fill_slot]];
+#ifdef BZ_HOST_PIPELINE_TEST
+            // (the sanitizer run's own check: BZ_TEST_HOST_RACE=1 drops this wait, and ThreadSanitizer must then report
+            // the caller's copy into a pinned buffer racing with the upload that still reads it)
+            if (getenv("BZ_TEST_HOST_RACE")) r->h_lane[e->fill_slot] = -1;
+            else
+#endif
             if (hipSetDevice(ul.device) != hipSuccess || hipEventSynchronize(ul.ev_up) != hipSuccess) return BZ_E_UNEXPECTED;
             r->h_lane[e->fill_slot] = -1;
             t_wait += now_ms() - ts0;
