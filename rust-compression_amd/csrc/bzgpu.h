@@ -105,6 +105,17 @@ template <class T> __device__ __forceinline__ void st_stream(T *p, T v)
 // ---- wave64 primitives -------------------------------------------------------
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
 
+// The value of the lane below (lane 0: 0) and of a lane known when the kernel is compiled, without the LDS crossbar:
+// __shfl_up(v, 1) / __shfl(v, k) compile to ds_bpermute_b32 plus the arithmetic of its byte address -- an LDS
+// instruction and four or five vector ones --, a DPP move shifted by one lane across the whole wave (wave_shr:1) and a
+// v_readlane_b32 are one instruction each.
+__device__ __forceinline__ u32 wave_shr1(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ u32 wave_lane(u32 v, u32 lane_uniform) { return (u32)__builtin_amdgcn_readlane((int)v, (int)lane_uniform); }
+__device__ __forceinline__ u64 wave_lane64(u64 v, u32 lane_uniform)
+{
+    return ((u64)wave_lane((u32)(v >> 32), lane_uniform) << 32) | wave_lane((u32)v, lane_uniform);
+}
+
 __device__ __forceinline__ u32 wave_incl_sum(u32 v)
 {
     const u32 l = lane_id();

@@ -62,7 +62,9 @@ extern "C" const char *bz_strerror(int code)
 extern "C" const char *bz_version(void) { return "bz2_mi355x 0.1 (gfx950)"; }
 
 // ---- the pipeline behind a context -------------------------------------------------------------
-// Host bytes reach the GPUs in CHUNKS (BZ_ENC_CHUNK_MIB, default 384 MiB, the first one of a stream 64 MiB: a
+// Host bytes reach the GPUs in CHUNKS (BZ_ENC_CHUNK_MIB, default 192 MiB since round 4 -- half the device and pinned
+// memory of 384 MiB for one per cent of the warm rate, and a first call that allocates half as much --, the first one of
+// a stream 64 MiB, BZ_ENC_FIRST_MIB: a
 // large batch keeps the latency-bound stages -- one workgroup per block in the Huffman stage -- a small share
 // of a job; measured on 1 GiB with one lane: 64 MiB chunks 4.6 GB/s host to host, 128 MiB 5.9, 256 MiB 6.5)
 // through two pinned staging buffers: bz_enc_write copies the caller's bytes into the pinned buffer being
@@ -144,7 +146,20 @@ static size_t enc_chunk_bytes()
 #endif
     static const size_t v = [] {
         const char *s = getenv("BZ_ENC_CHUNK_MIB");
-        long mib = s ? atol(s) : 384;
+        long mib = s ? atol(s) : 192;
+        if (mib < 1) mib = 1;
+        if (mib > 1024) mib = 1024;
+        return (size_t)mib << 20;
+    }();
+    return v;
+}
+
+// the first chunk of a stream is small: the GPU has work sooner, and a short stream takes little pinned memory
+static size_t enc_first_chunk_bytes()
+{
+    static const size_t v = [] {
+        const char *s = getenv("BZ_ENC_FIRST_MIB");
+        long mib = s ? atol(s) : 64;
         if (mib < 1) mib = 1;
         if (mib > 1024) mib = 1024;
         return (size_t)mib << 20;
@@ -898,7 +913,7 @@ extern "C" int bz_enc_write(bz_enc *e, const uint8_t *in, size_t n)
         // (the first chunk of a stream is small -- 64 MiB at most: the GPU has work sooner, and a short stream
         // takes little pinned memory; the staging buffers grow with the chunks they hold)
         const size_t later = e->chunk_bytes ? e->chunk_bytes : r->chunk;
-        const size_t cap = e->chunks_filled == 0 ? std::min(later, (size_t)64 << 20) : later;
+        const size_t cap = e->chunks_filled == 0 ? std::min(later, enc_first_chunk_bytes()) : later;
         if (e->fill == cap) {
             // A full chunk goes to the worker when MORE input arrives (its complete blocks are encoded
             // while the caller goes on writing); the last chunk of a stream is left for bz_enc_end, which
@@ -1067,7 +1082,7 @@ extern "C" int bz_encode_buffer_multi(int level, const int *devices, int n_devic
         // of the GPUs idle (1 GiB on one device in 64 + 384 + 384 + 192 MiB: the last 22 ms).  With several devices the
         // chunks get smaller rather than leave lanes without a job, down to 32 MiB (a job of 40 blocks still fills a
         // device's 256 CUs in the sort, and the per-job latencies of the tail stages run side by side).
-        const size_t most = enc_chunk_bytes(), first = std::min(most, (size_t)64 << 20);
+        const size_t most = enc_chunk_bytes(), first = std::min(most, enc_first_chunk_bytes());
         const size_t lanes = 2 * (size_t)n_devices, least = std::min(most, (size_t)32 << 20);
         if (in_len > first + most || (n_devices > 1 && in_len > first + 2 * least)) {
             const size_t rest = in_len - first;

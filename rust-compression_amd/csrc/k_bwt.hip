@@ -45,10 +45,12 @@ namespace bzgpu {
 enum { SRC_TEXT = 0, SRC_PAIRS = 1, SRC_MM = 2, SRC_WALK = 3, SRC_SURV = 4, SRC_LISTG = 5,
        SRC_TEXTK = 6, SRC_WALKK = 7, SRC_MMK = 8, // ..K: keys stored by the histogram kernel of the pass
        SRC_MMC = 9, // MM that also CARRIES the rank of rotation j+h along (k_radix_scatter_lb, first walk round)
-       SRC_PERJ = 10 }; // the survivors keyed by their own start (the period round, see k_period_find)
+       SRC_PERJ = 10,   // the survivors keyed by their own start (the period round, see k_period_find)
+       SRC_PACKED = 11 }; // one word per element: the digits still to be sorted by above bit 20, the rotation below (round 4:
+                          // the pass in front of the last one of phase A writes these, the last one reads them)
 // sources whose sequence is the compacted list (length count[lb]) rather than all n positions
 template <int SRC> struct src_is_list {
-    static constexpr bool value = (SRC == SRC_PAIRS || SRC == SRC_SURV || SRC == SRC_LISTG || SRC == SRC_PERJ);
+    static constexpr bool value = (SRC == SRC_PAIRS || SRC == SRC_SURV || SRC == SRC_LISTG || SRC == SRC_PERJ || SRC == SRC_PACKED);
 };
 
 // per-block key geometry, produced by k_key_params
@@ -192,6 +194,15 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
             const u32 c = idx < cnt ? idx : cnt - 1u;
             key[r] = ld_stream(Kin + base + c);
             val[r] = ld_stream(Vin + base + c);
+            ok |= (idx < cnt ? 1u : 0u) << r;
+        }
+    } else if (SRC == SRC_PACKED) {
+#pragma unroll
+        for (u32 r = 0; r < 16; ++r) {
+            const u32 idx = first + r * 64u;
+            const u32 c = idx < cnt ? idx : cnt - 1u;
+            key[r] = ld_stream(Vin + base + c); // (the digit is taken with shift 20; the rotation rides in the low bits)
+            val[r] = key[r] & 0xFFFFFu;
             ok |= (idx < cnt ? 1u : 0u) << r;
         }
     } else if (SRC == SRC_SURV) {
@@ -635,7 +646,9 @@ __global__ __launch_bounds__(kSortThreads) void k_ghist_scan(BwtArgs a, u32 ndig
 // the scatter of a fused pass; dpos selects the digit position inside gbase
 // WRITE_K = false: the keys are not stored (the pass that ends phase A of the init: phase B re-builds its
 // keys from the block and only walks the order)
-template <int SRC, int BITS, bool WRITE_K = true>
+// PACK_OUT: the element leaves as ONE word, (key >> (shift + BITS)) << 20 | rotation: the digits this pass and the
+// passes before it have used up are not needed again (4 bytes written instead of 8; the next pass is <SRC_PACKED>)
+template <int SRC, int BITS, bool WRITE_K = true, bool PACK_OUT = false>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h,
                                                                     const u32 *__restrict__ Kin,
                                                                     const u32 *__restrict__ Vin,
@@ -704,7 +717,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
 #pragma unroll
         for (u32 r = 0; r < 16; ++r) {
             const u32 rowbase = start + w * 1024u + r * 64u;
-            const u64 mnew = __shfl(myword, r, 64);
+            const u64 mnew = wave_lane64(myword, r);
             const u64 q = mnew & le_mask;
             const u32 head = q ? rowbase + 63u - (u32)__clzll(q) : (wl >= 0 ? (u32)wl : 0xFFFFFu);
             key[r] = (key[r] & (0xFFFFFu | kFinalBit)) | ((head & 0xFFFu) << 20);
@@ -832,17 +845,22 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
         if (lpos[r] != 0xFFFFFFFFu) s_buf[lpos[r]] = key[r];
     __syncthreads();
     u32 dst[16];
+    u32 hi[16]; // (PACK_OUT) the digits above this pass's, already in place for the packed word
 #pragma unroll
     for (u32 k = 0; k < 16; ++k) {
         const u32 i = k * kSortThreads + threadIdx.x;
         dst[k] = 0xFFFFFFFFu;
+        hi[k] = 0;
         if (i < total) {
             const u32 kk = s_buf[i];
             const u32 dg = (kk >> shift) & (NB - 1);
             dst[k] = s_base[dg] + (i - (u32)s_tpre[dg]);
-            if (WRITE_K) Kout[base + dst[k]] = kk;
+            if (SRC == SRC_PACKED) Vout[base + dst[k]] = kk & 0xFFFFFu; // (the rotation came with the digit: one staging round)
+            else if (PACK_OUT) hi[k] = (kk >> (shift + BITS)) << 20;
+            else if (WRITE_K) Kout[base + dst[k]] = kk;
         }
     }
+    if (SRC == SRC_PACKED) return;
     __syncthreads();
 #pragma unroll
     for (u32 r = 0; r < 16; ++r)
@@ -851,7 +869,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
 #pragma unroll
     for (u32 k = 0; k < 16; ++k) {
         const u32 i = k * kSortThreads + threadIdx.x;
-        if (i < total) Vout[base + dst[k]] = s_buf[i];
+        if (i < total) Vout[base + dst[k]] = PACK_OUT ? (hi[k] | s_buf[i]) : s_buf[i];
     }
 }
 
@@ -1225,11 +1243,11 @@ __global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 ste
     for (u32 r = 0; r < 16; ++r) {
         const u32 idx = first + r * 64u;
         const bool ok = idx < cnt;
-        u32 pg = __shfl_up(g[r], 1, 64), p1 = __shfl_up(s1[r], 1, 64), p2 = __shfl_up(s2[r], 1, 64);
+        u32 pg = wave_shr1(g[r]), p1 = wave_shr1(s1[r]), p2 = wave_shr1(s2[r]);
         // lane 0: the previous element is lane 63 of the previous row (or the pre-loaded one)
-        const u32 qg = (r == 0) ? pg0 : __shfl(g[(r + 15) & 15], 63, 64);
-        const u32 q1 = (r == 0) ? ps10 : __shfl(s1[(r + 15) & 15], 63, 64);
-        const u32 q2 = (r == 0) ? ps20 : __shfl(s2[(r + 15) & 15], 63, 64);
+        const u32 qg = (r == 0) ? pg0 : wave_lane(g[(r + 15) & 15], 63);
+        const u32 q1 = (r == 0) ? ps10 : wave_lane(s1[(r + 15) & 15], 63);
+        const u32 q2 = (r == 0) ? ps20 : wave_lane(s2[(r + 15) & 15], 63);
         if (l == 0) {
             pg = qg;
             p1 = q1;
@@ -1403,7 +1421,7 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
                 if (nf) atomicAdd(&s_gh[0][nf_head & 1023u], 1u);
                 const u32 lead = (u32)__ffsll((long long)mnf) - 1u;
                 const u32 hi = (nf_head >> 10) & 1023u;
-                const u32 hi0 = __shfl(hi, lead, 64);
+                const u32 hi0 = wave_lane(hi, lead); // (lead: first set bit of a ballot, the same in every lane)
                 const u64 same = __ballot(nf && hi == hi0);
                 if (same == mnf) {
                     if (l == lead) atomicAdd(&s_gh[1][hi0], (u32)__popcll(mnf));
@@ -1516,12 +1534,21 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
     __shared__ int s_carry_old, s_carry_new;
     __shared__ int s_wold[NW], s_wnew[NW];
     __shared__ u32 s_nonfinal, s_ticket;
-    __shared__ u32 s_gh[2][1024];
+    // LDS: 53.4 KB, so that THREE workgroups share a CU (rounds 1-3: 62.5 KB, two).  The staging buffer of the last phase
+    // holds, until that phase begins, the counters of the phases before it -- the digit counts of the next walk round
+    // (s_gh) and the per-bin counts of the rank words (s_bcnt) -- and what the last phase needs of them is moved to two
+    // small arrays (s_bpre, s_bdst) in front of the barrier that ends their life.
     __shared__ u32 s_stage[kSortTile];
     __shared__ u16 s_binof[kSortTile];
-    __shared__ u32 s_bcnt[1024];
     __shared__ u16 s_bpre[1024];
+    __shared__ u16 s_bdst[1024]; // a bin's cursor inside its 1024-word region (the region's start follows from the bin)
     __shared__ u32 s_wsum[NW];
+    u32 (*s_gh)[1024] = reinterpret_cast<u32 (*)[1024]>(s_stage);          // [2][1024], words 0 .. 2047
+    u32 *s_bcnt = s_stage + 2048;                                          // [1024],    words 2048 .. 3071
+#if defined(BZ_REFINE_TWO_PER_CU) // (A/B: the LDS footprint of rounds 1-3, two workgroups per CU)
+    __shared__ u32 s_pad[2600];
+    if (threadIdx.x == 0) s_pad[blockIdx.x % 2600u] = 0;
+#endif
 #ifdef BZ_REFINE_TIMING
     u64 t_prev = __builtin_readcyclecounter();
 #endif
@@ -1545,8 +1572,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
     const u8 *pt = a.ptext + (size_t)lb * kSlot;
     const size_t base = (size_t)lb * kSlot;
     if (INIT && a.pb_gate[lb] == 0u) K = a.KA; // phase B was done in LDS: phase A's keys are the list's keys
-    for (u32 i = threadIdx.x; i < 2048u; i += kSortThreads) (&s_gh[0][0])[i] = 0;
-    for (u32 i = threadIdx.x; i < 1024u; i += kSortThreads) s_bcnt[i] = 0;
+    for (u32 i = threadIdx.x; i < 3072u; i += kSortThreads) s_stage[i] = 0; // (s_gh and s_bcnt)
     if (threadIdx.x == 0) s_nonfinal = 0;
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
     const u32 wbase = start + w * 1024u;
@@ -1609,10 +1635,10 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
     for (u32 r = 0; r < 16; ++r) {
         const u32 idx = first + r * 64u;
         const bool ok = idx < cnt;
-        u32 pg = __shfl_up(gk[r], 1, 64), p1 = __shfl_up(s1[r], 1, 64), p2 = __shfl_up(s2[r], 1, 64);
-        const u32 qg = (r == 0) ? pg0 : __shfl(gk[(r + 15) & 15], 63, 64);
-        const u32 q1 = (r == 0) ? ps10 : __shfl(s1[(r + 15) & 15], 63, 64);
-        const u32 q2 = (r == 0) ? ps20 : __shfl(s2[(r + 15) & 15], 63, 64);
+        u32 pg = wave_shr1(gk[r]), p1 = wave_shr1(s1[r]), p2 = wave_shr1(s2[r]);
+        const u32 qg = (r == 0) ? pg0 : wave_lane(gk[(r + 15) & 15], 63);
+        const u32 q1 = (r == 0) ? ps10 : wave_lane(s1[(r + 15) & 15], 63);
+        const u32 q2 = (r == 0) ? ps20 : wave_lane(s2[(r + 15) & 15], 63);
         if (l == 0) {
             pg = qg;
             p1 = q1;
@@ -1631,7 +1657,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
     // does the element behind the wave's span start a new group?  (lane 63 holds both sides)
     bool next_after = true;
     if (need_next) next_after = (gk[15] != ng0) || (s1[15] != ns10) || (s2[15] != ns20);
-    next_after = __shfl((u32)next_after, 63, 64) != 0u;
+    next_after = wave_lane((u32)next_after, 63) != 0u;
     if (l == 0) {
         s_wold[w] = INIT ? 0 : wl_old;
         s_wnew[w] = wl_new;
@@ -1755,7 +1781,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
                 }
                 const u32 lead = (u32)__ffsll((long long)mnf) - 1u;
                 const u32 hi = (nf_head >> 10) & 1023u;
-                const u32 hi0 = __shfl(hi, lead, 64);
+                const u32 hi0 = wave_lane(hi, lead); // (lead: first set bit of a ballot, the same in every lane)
                 const u64 same = __ballot(nf && hi == hi0);
                 if (same == mnf) {
                     if (l == lead) atomicAdd(&s_gh[1][hi0], (u32)__popcll(mnf));
@@ -1802,10 +1828,10 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
         const u32 ex = carry + inc - mine;
         s_bpre[b0] = (u16)ex;
         s_bpre[b0 + 1] = (u16)(ex + c0);
-        s_bcnt[b0] = (b0 << kRankBinShift) + g0;
-        s_bcnt[b0 + 1] = ((b0 + 1u) << kRankBinShift) + g1;
+        s_bdst[b0] = (u16)g0; // (< 1024: a rotation occurs once, a bin never holds more than its 1024 words)
+        s_bdst[b0 + 1] = (u16)g1;
     }
-    __syncthreads();
+    __syncthreads(); // (s_gh and s_bcnt are dead from here on: their words become the staging buffer)
     RF_T(5);
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
@@ -1823,7 +1849,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
         const u32 i = k * kSortThreads + threadIdx.x;
         if (i < total) {
             const u32 bin = s_binof[i];
-            W[base + s_bcnt[bin] + (i - (u32)s_bpre[bin])] = s_stage[i];
+            W[base + (bin << kRankBinShift) + (u32)s_bdst[bin] + (i - (u32)s_bpre[bin])] = s_stage[i];
         }
     }
     RF_T(6);
@@ -1927,7 +1953,7 @@ __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, co
     {
         const u64 myword = newbits_lane_word(a.newbits, base, wbase, cnt, l, true);
 #pragma unroll
-        for (u32 r = 0; r < 17; ++r) mn[r] = __shfl(myword, r, 64);
+        for (u32 r = 0; r < 17; ++r) mn[r] = wave_lane64(myword, r);
     }
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
@@ -2487,17 +2513,17 @@ static u32 next_epoch(hipStream_t st, const BwtArgs &a)
     return e;
 }
 
-template <int SRC, int BITS, bool WRITE_K = true>
+template <int SRC, int BITS, bool WRITE_K = true, bool PACK_OUT = false>
 static void fused_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const u32 *Kin, const u32 *Vin, u32 *Kout,
                        u32 *Vout, u32 dpos, u64 elems, KernelProf *prof, u64 out_elems = ~0ull,
                        const u32 *gate = nullptr)
 {
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
-    const u64 rd = (SRC == SRC_TEXTK) ? 4 : ((SRC == SRC_TEXT) ? 1 : ((SRC == SRC_WALK) ? 5 : (SRC == SRC_MMC ? 9 : 8)));
+    const u64 rd = (SRC == SRC_TEXTK || SRC == SRC_PACKED) ? 4 : ((SRC == SRC_TEXT) ? 1 : ((SRC == SRC_WALK) ? 5 : (SRC == SRC_MMC ? 9 : 8)));
     const u32 e = next_epoch(st, a);
     if (out_elems == ~0ull) out_elems = elems;
-    const int p = prof ? prof->begin(st, KID_RADIX_SCATTER_LB, elems * rd + out_elems * (WRITE_K ? 8 : 4)) : -1;
-    hipLaunchKernelGGL((k_radix_scatter_lb<SRC, BITS, WRITE_K>), grid, dim3(kSortThreads), 0, st, a, shift, h, Kin, Vin, Kout, Vout,
+    const int p = prof ? prof->begin(st, KID_RADIX_SCATTER_LB, elems * rd + out_elems * ((WRITE_K && !PACK_OUT) ? 8 : 4)) : -1;
+    hipLaunchKernelGGL((k_radix_scatter_lb<SRC, BITS, WRITE_K, PACK_OUT>), grid, dim3(kSortThreads), 0, st, a, shift, h, Kin, Vin, Kout, Vout,
                        dpos, e, gate);
     if (prof) prof->end(st, p);
 }
@@ -2548,7 +2574,13 @@ static bool init_sort_fused(hipStream_t st, const BwtArgs &a, u64 total_n, Kerne
                                 (int)(kTilesPerBlock * (xcd_grid_y(a.nb) / 8u)), 8, st);
     fused_pass<SRC_TEXT, B0>(st, a, 0, 0, nullptr, nullptr, a.KA, a.VA, 0, total_n, prof);
     if (!fused_pass_ok(st, a, *a.epoch)) return false;
-    fused_pass<SRC_PAIRS, B1>(st, a, B0, 0, a.KA, a.VA, a.KB, a.VB, 1, total_n, prof);
+    // (round 4) the middle pass of phase A writes ONE word per element -- the last digit above bit 20, the rotation below:
+    // the first two digits are used up, and 10 + 20 bits fit a word -- and the last pass reads that word: 8 of the 32
+    // bytes the two passes moved per element, and one of the last pass's two trips through LDS.  BZ_PACKED_PASS=0: as before.
+    static const bool want_packed = !(getenv("BZ_PACKED_PASS") && atoi(getenv("BZ_PACKED_PASS")) == 0);
+    const bool packed = want_packed && !local_b;
+    if (packed) fused_pass<SRC_PAIRS, B1, true, true>(st, a, B0, 0, a.KA, a.VA, nullptr, a.VB, 1, total_n, prof);
+    else fused_pass<SRC_PAIRS, B1>(st, a, B0, 0, a.KA, a.VA, a.KB, a.VB, 1, total_n, prof);
     const u32 *gate = nullptr;
     if (local_b) {
         // phase B inside LDS (k_phase_b_local): phase A keeps its keys, the groups are ordered segment by segment;
@@ -2561,7 +2593,8 @@ static bool init_sort_fused(hipStream_t st, const BwtArgs &a, u64 total_n, Kerne
         gate = a.pb_gate;
     } else {
         (void)hipMemsetAsync(a.pb_gate, 1, a.nb * sizeof(u32), st); // every block: keys in KB, order by the passes
-        fused_pass<SRC_PAIRS, B2, false>(st, a, B0 + B1, 0, a.KB, a.VB, a.KA, a.VA, 2, total_n, prof); // (order only)
+        if (packed) fused_pass<SRC_PACKED, B2, false>(st, a, 20, 0, nullptr, a.VB, nullptr, a.VA, 2, total_n, prof); // (order only)
+        else fused_pass<SRC_PAIRS, B2, false>(st, a, B0 + B1, 0, a.KB, a.VB, a.KA, a.VA, 2, total_n, prof); // (order only)
     }
     fused_pass<SRC_WALK, B0>(st, a, 0, 0, a.KA, a.VA, a.KB, a.VB, 0, total_n, prof, ~0ull, gate);
     fused_pass<SRC_PAIRS, B1>(st, a, B0, 0, a.KB, a.VB, a.KA, a.VA, 1, total_n, prof, ~0ull, gate);
