@@ -124,6 +124,13 @@ __device__ __forceinline__ bool per_key_ascending(const BwtArgs &a, u32 lb, u32 
     return per_lt_at(a, lb, n, per_first_mis(a, lb, j - p));
 }
 
+// k_pair_compare's verdicts (the period round's groups of two), one byte per list position (0: not ordered here, 2: the smaller member, 3: the greater one), in the
+// digit counts' slot of the block, which only the fused walk rounds use
+__device__ __forceinline__ u8 *pair_bytes(const BwtArgs &a, u32 lb)
+{
+    return reinterpret_cast<u8 *>(a.gh_tiles + (size_t)lb * kTilesPerBlock * 3 * kMaxBins);
+}
+
 // Batched form: the 16 rows of one lane.  All primary loads are issued back to back (clamped
 // index instead of a branch), then all dependent gathers, so a wave keeps 16-32 memory
 // operations in flight instead of one -- these kernels are latency-bound otherwise.
@@ -224,16 +231,21 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
         // the period round: order the survivors by where they start -- ascending or descending, as the first
         // difference between the block and the block shifted by its period decides for each of them (per_ascending)
         const u32 p = a.lin_p[lb]; // (hm: the depth reached, in symbols)
+        const u8 *pb8 = a.gh_tiles ? pair_bytes(a, lb) : nullptr;
+        u32 pairv[16];
 #pragma unroll
         for (u32 r = 0; r < 16; ++r) {
             const u32 idx = first + r * 64u;
             const u32 c = idx < cnt ? idx : cnt - 1u;
             val[r] = ld_stream(Vin + base + c);
+            pairv[r] = pb8 ? pb8[c] : 0u;
             ok |= (idx < cnt ? 1u : 0u) << r;
         }
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r)
-            key[r] = (p != 0u && !per_key_ascending(a, lb, n, p, hm, val[r])) ? (n - 1u - val[r]) : val[r];
+        for (u32 r = 0; r < 16; ++r) {
+            if (pairv[r]) key[r] = pairv[r] & 1u; // a group of two, ordered by k_pair_compare
+            else key[r] = (p != 0u && !per_key_ascending(a, lb, n, p, hm, val[r])) ? (n - 1u - val[r]) : val[r];
+        }
     } else if (SRC == SRC_LISTG) {
         // survivor round, second half: walk that order, key = the survivor's own group
 #pragma unroll
@@ -1224,14 +1236,18 @@ __global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 ste
             if (need_prev) ps20 = pkey(pt, pj, ki.bits, ki.chars);
         } else if (impure) {
             const bool per = a.lin_p[lb] != 0u;
+            // every member of a group the round has put in order becomes a group of its own: a chain of the block's
+            // period (impure 0 in a block that has one) or a group of two ordered by comparison (impure 2)
 #pragma unroll
             for (u32 r = 0; r < 16; ++r) {
                 const u32 jr = jj[r] >= hm ? jj[r] - hm : jj[r] + n - hm; // (the rotation itself)
-                s1[r] = (per && impure[base + g[r]] == 0) ? jr + 1u : 0u;
+                const u32 im = impure[base + g[r]];
+                s1[r] = (im == 2u || (per && im == 0u)) ? jr + 1u : 0u;
             }
             if (need_prev) {
                 const u32 jr = pj >= hm ? pj - hm : pj + n - hm;
-                ps10 = (per && impure[base + pg0] == 0) ? jr + 1u : 0u;
+                const u32 im = impure[base + pg0];
+                ps10 = (im == 2u || (per && im == 0u)) ? jr + 1u : 0u;
             }
         } else {
 #pragma unroll
@@ -2220,6 +2236,75 @@ __global__ __launch_bounds__(kSortThreads) void k_period_next(BwtArgs a)
     }
 }
 
+// ---- groups of TWO: ordered by comparing the two rotations themselves ---------------------------------------------------
+// Data that holds a stretch twice (a file and its copy inside one block; the corpus "binary": the reference's fixtures
+// tiled with a byte changed every 4 KiB) leaves, after the first rounds, almost every rotation in a group of two whose
+// members agree for kilobytes: eight more doubling rounds over the whole block to find out what one look at the two
+// texts tells -- they are 0.9 MB, they sit in the L2.  In the period round (the round that runs when some block is
+// deep in repeats) a lane takes every group of exactly two members of the survivor list, compares the two rotations
+// from the depth reached on, sixteen bytes a step (cyclic; at most kPairCap bytes, then it gives up and the group goes
+// on doubling), and leaves the verdict in a byte per list position (pair_bytes).  SRC_PERJ keys such members by it, k_period_mark leaves their group alone (impure = 2) and the
+// refinement makes both final.  The comparison is the definition of the order (sais.rs:266-272 fixes nothing else).
+constexpr u32 kPairCap = 1u << 16;
+__global__ __launch_bounds__(kSortThreads) void k_pair_compare(BwtArgs a, u32 step, const u32 *__restrict__ V, u8 *__restrict__ impure)
+{
+    u32 tile, lb;
+    xcd_remap(gridDim.x, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    const BlockDesc d = a.blocks[lb];
+    const u32 n = d.n;
+    const u32 cnt = a.count[lb];
+    const u32 start = tile * kSortTile;
+    if (start >= cnt || n < 64u || (u64)cnt * 4u < (u64)n * 3u) return; // (only blocks that are deep in repeats)
+    const u8 *__restrict__ text = a.rle + d.rle_off;
+    const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
+    const u64 d64 = ((u64)ki.chars * 2u) << step;
+    const u32 depth = d64 < n ? (u32)d64 : n;
+    const size_t base = (size_t)lb * kSlot;
+    for (u32 idx = start + threadIdx.x; idx + 1u < cnt && idx < start + kSortTile; idx += kSortThreads) {
+        const u32 va = V[base + idx] & 0xFFFFFu, vb = V[base + idx + 1u] & 0xFFFFFu;
+        const u32 g = a.R[base + va] & ~kFinalBit;
+        if ((a.R[base + vb] & ~kFinalBit) != g) continue;
+        if (idx > 0 && (a.R[base + (V[base + idx - 1u] & 0xFFFFFu)] & ~kFinalBit) == g) continue;   // not the group's first
+        if (idx + 2u < cnt && (a.R[base + (V[base + idx + 2u] & 0xFFFFFu)] & ~kFinalBit) == g) continue; // three or more
+        // the first difference behind the `depth` symbols the two are known to share
+        u32 pa = va + depth, pb = vb + depth;
+        pa = pa >= n ? pa - n : pa;
+        pb = pb >= n ? pb - n : pb;
+        int verdict = 0; // -1: a < b, +1: a > b, 0: undecided
+        for (u32 done = 0; done < kPairCap && done + depth < n && verdict == 0;) {
+            const u32 room = n - (pa > pb ? pa : pb); // bytes before the first of the two wraps
+            if (room >= 16u) {
+                u64 x0, x1, y0, y1;
+                __builtin_memcpy(&x0, text + pa, 8);
+                __builtin_memcpy(&x1, text + pa + 8, 8);
+                __builtin_memcpy(&y0, text + pb, 8);
+                __builtin_memcpy(&y1, text + pb + 8, 8);
+                if (x0 != y0) verdict = __builtin_bswap64(x0) < __builtin_bswap64(y0) ? -1 : 1;
+                else if (x1 != y1) verdict = __builtin_bswap64(x1) < __builtin_bswap64(y1) ? -1 : 1;
+                pa += 16u;
+                pb += 16u;
+                done += 16u;
+            } else { // (near the block's end: byte by byte across the wrap)
+                for (u32 k = 0; k < 16u && verdict == 0; ++k) {
+                    const u8 x = text[pa], y = text[pb];
+                    if (x != y) verdict = x < y ? -1 : 1;
+                    pa = pa + 1u == n ? 0u : pa + 1u;
+                    pb = pb + 1u == n ? 0u : pb + 1u;
+                }
+                done += 16u;
+            }
+            if (pa >= n) pa -= n;
+            if (pb >= n) pb -= n;
+        }
+        if (verdict == 0) continue; // (equal as far as looked: a periodic block, or a repeat longer than the cap)
+        u8 *pb8 = pair_bytes(a, lb);
+        pb8[idx] = verdict > 0 ? 3 : 2;
+        pb8[idx + 1u] = verdict < 0 ? 3 : 2;
+        impure[base + g] = 2;
+    }
+}
+
 // the period round's list, ordered by (group, start or mirrored start): a group in which two neighbours do not step by
 // exactly the period, or disagree about the direction, is marked impure (one byte per group head)
 __global__ __launch_bounds__(kSortThreads) void k_period_mark(BwtArgs a, u32 step, const u32 *__restrict__ K,
@@ -2240,7 +2325,7 @@ __global__ __launch_bounds__(kSortThreads) void k_period_mark(BwtArgs a, u32 ste
     for (u32 idx = start + threadIdx.x; idx < cnt && idx < start + kSortTile; idx += kSortThreads) {
         if (idx == 0) continue;
         const u32 g = K[base + idx], gp = K[base + idx - 1];
-        if (g != gp) continue;
+        if (g != gp || impure[base + g] == 2) continue; // (2: a group of two that k_pair_compare has ordered)
         const u32 v = V[base + idx], vp = V[base + idx - 1];
         const bool asc = per_key_ascending(a, lb, n, p, depth, v), ascp = per_key_ascending(a, lb, n, p, depth, vp);
         const bool chain = asc == ascp && (asc ? v == vp + p : vp == v + p);
@@ -2758,6 +2843,15 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             hipLaunchKernelGGL(k_copy_counts, dim3((a.nb + 255) / 256), dim3(256), 0, st, a.count, a.count2, a.nb);
             // the blocks' periods and the two bitmaps that order rotation i against rotation i + p (in the flag bytes'
             // slot, which nothing uses before this round's k_group_flags)
+            // (OFF unless BZ_PAIR_COMPARE=1 -- measured in round 4 on the corpus it was written for, 256 MiB of the
+            // reference's binary fixtures tiled: 42 M groups of two whose members agree for 2-4 KB; one lane per group
+            // reads 270 GB out of the L2 and takes 70 ms, the eight doubling rounds it replaces for a third of the
+            // rotations take 25: 2.43 GB/s without it, 0.89 with it.  Same streams either way.)
+            static const bool want_pairs = getenv("BZ_PAIR_COMPARE") && atoi(getenv("BZ_PAIR_COMPARE")) != 0;
+            if (a.gh_tiles) { // (the verdict bytes live in the fused passes' digit counts: no fused passes, no pair round)
+                (void)hipMemset2DAsync(a.gh_tiles, (size_t)kTilesPerBlock * 3 * kMaxBins * 4, 0, (size_t)list_tiles * kSortTile, a.nb, st);
+                if (want_pairs) hipLaunchKernelGGL(k_pair_compare, grid_list, dim3(kSortThreads), 0, st, a, step, fV, impure);
+            }
             hipLaunchKernelGGL(k_period_find, dim3(a.nb), dim3(kSortThreads), 0, st, a);
             hipLaunchKernelGGL(k_period_bits, grid, dim3(kSortThreads), 0, st, a);
             hipLaunchKernelGGL(k_period_next, dim3(a.nb), dim3(kSortThreads), 0, st, a);
