@@ -2068,17 +2068,17 @@ __global__ __launch_bounds__(kSortThreads) void k_periodic_place(BwtArgs a)
 // Groups that mix residues, skip a member, or mix directions are marked impure (k_period_mark) and go on doubling.
 // Rounds 2-3 knew one case of this -- a block that is periodic from its first byte to its last (one direction for the
 // whole block); a block with a few foreign bytes in front of the repeated paragraph (a block cut that does not fall on a
-// paragraph boundary: every real file) got no help.  Now the period is looked for at eight anchors inside the block, it
+// paragraph boundary: every real file) got no help.  Now the period is looked for at four anchors inside the block, it
 // need not hold everywhere (half the block is enough), and the direction is per mismatch.  Only the ORDER is the
 // reference's business (sais.rs:266-272), and the comparison above is exact.
 //   k_period_find  one workgroup per block with most of its rotations unordered: the distance at which the 16 bytes at
-//                  an anchor recur, by vote over eight anchors; kept when the block agrees with itself shifted by it at
+//                  an anchor recur (four anchors; the candidate with the widest agreement wins); kept when the block agrees with itself shifted by it at
 //                  half of its positions or more, and not everywhere (a block periodic as a cycle has equal rotations:
 //                  k_periodic_place's case)
 //   k_period_bits  the two bitmaps;  k_period_next  first mismatch at or behind every 64-position word
 __global__ __launch_bounds__(kSortThreads) void k_period_find(BwtArgs a)
 {
-    constexpr u32 kAnchors = 8;
+    constexpr u32 kAnchors = 4;
     __shared__ u32 s_best, s_cand[kAnchors], s_agree;
     const u32 lb = blockIdx.x, tid = threadIdx.x;
     const BlockDesc d = a.blocks[lb];
@@ -2091,21 +2091,37 @@ __global__ __launch_bounds__(kSortThreads) void k_period_find(BwtArgs a)
     // (count2: the survivors of the last refinement, k_survivor_compact) only blocks that are deep in repeats
     if (n < 256u || (u64)a.count2[lb] * 4u < (u64)n * 3u) return;
     for (u32 k = 0; k < kAnchors; ++k) { // (uniform)
-        const u32 at = (u32)(((u64)n * (k + 1u)) / 20u); // 5 % .. 40 % of the block: room for periods beyond n / 2
+        const u32 at = (u32)(((u64)n * (k + 1u)) / 10u); // 10 % .. 40 % of the block: room for periods beyond n / 2
         u64 h0, h1;
         __builtin_memcpy(&h0, text + at, 8);
         __builtin_memcpy(&h1, text + at + 8, 8);
         if (tid == 0) s_best = 0xFFFFFFFFu;
         __syncthreads();
         const u32 last = n - 16u - at; // the farthest shift that keeps the 16 bytes inside the block
-        for (u32 q = 1u + tid; q <= last && q < s_best; q += kSortThreads) {
-            u64 x0, x1;
-            __builtin_memcpy(&x0, text + at + q, 8);
-            __builtin_memcpy(&x1, text + at + q + 8, 8);
-            if (x0 == h0 && x1 == h1) {
-                atomicMin(&s_best, q);
-                break;
+        // (four shifts per thread and trip, their loads in flight together; the second half of the 16 bytes is only
+        // looked at where the first agrees: a block without a period reads 8 bytes per shift and anchor, not 16)
+        for (u32 q0 = 1u + tid; q0 <= last && q0 < s_best; q0 += 4u * kSortThreads) {
+            u64 x[4];
+#pragma unroll
+            for (u32 u = 0; u < 4u; ++u) {
+                const u32 q = q0 + u * kSortThreads;
+                x[u] = ~h0;
+                if (q <= last) __builtin_memcpy(&x[u], text + at + q, 8);
             }
+            bool hit = false;
+#pragma unroll
+            for (u32 u = 0; u < 4u; ++u) {
+                if (!hit && x[u] == h0) {
+                    const u32 q = q0 + u * kSortThreads;
+                    u64 x1;
+                    __builtin_memcpy(&x1, text + at + q + 8, 8);
+                    if (x1 == h1) {
+                        atomicMin(&s_best, q);
+                        hit = true;
+                    }
+                }
+            }
+            if (hit) break;
         }
         __syncthreads();
         if (tid == 0) s_cand[k] = s_best;

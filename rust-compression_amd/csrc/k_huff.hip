@@ -195,6 +195,79 @@ __device__ int heap_code_lengths(const u32 *rfreq, u32 alpha, u32 *buf, u8 *out)
     return too_long; // 1: the caller must redo the table with gen_code_lm (:190-194)
 }
 
+// The same procedure by a whole WAVE with the heap in its registers (WaveArr, bzgpu.h): the procedure is a chain of
+// dependent accesses -- one lane per table paid an LDS round trip for each (0.8 ms per pass for a 258-symbol table,
+// 12 ms per 256 MiB of binary data in k_huff_tables).  Statement for statement heap_code_lengths above (the reference's
+// cano_huff_table.rs:14-38, :153-196 on the weights of encoder.rs:641-651); `buf` (2 n words of LDS) takes the finished
+// array for the last two loops, which are gathers.  All 64 lanes call it with the same arguments.
+template <u32 NR>
+__device__ __forceinline__ void down_heap_wave(WaveArr<NR> &a, u32 nn, u32 len)
+{
+    const u32 tmp = a.get(nn);
+    const u32 wt = a.get(tmp);
+    u32 leaf = (nn << 1) + 1;
+    while (leaf < len) {
+        u32 c = a.get(leaf), wc = a.get(c);
+        if (leaf + 1 < len) {
+            const u32 c2 = a.get(leaf + 1), wc2 = a.get(c2);
+            if (wc > wc2) { leaf += 1; c = c2; wc = wc2; }
+        }
+        if (wt < wc) break;
+        a.set(nn, c);
+        nn = leaf;
+        leaf = (nn << 1) + 1;
+    }
+    a.set(nn, tmp);
+}
+template <u32 NR>
+__device__ int heap_code_lengths_wave(const u32 *rfreq, u32 n, u32 *buf, u8 *out, u32 lane)
+{
+    WaveArr<NR> a;
+#pragma unroll
+    for (u32 q = 0; q < (NR <= 1 ? 1u : (NR <= 4 ? 4u : 16u)); ++q) {
+        const u32 e = q * 64u + lane;
+        u32 v = 0;
+        if (e < n) v = n + e;
+        else if (e < 2u * n) {
+            const u32 f = rfreq[e - n];
+            v = (f > 1u ? f : 1u) << 8; // encoder.rs:642-645
+        }
+        a.r[q] = v;
+    }
+    for (u32 i = n >> 1; i-- > 0;) down_heap_wave(a, i, n); // create_heap, :33-38
+    for (u32 i = n - 1; i >= 1; --i) { // :168-178
+        const u32 m1 = a.get(0);
+        a.set(0, a.get(i));
+        down_heap_wave(a, 0, i);
+        const u32 m2 = a.get(0);
+        a.set(i, weight_add(a.get(m1), a.get(m2)));
+        a.set(0, i);
+        a.set(m1, i);
+        a.set(m2, i);
+        down_heap_wave(a, 0, i);
+    }
+    a.set(1, 0); // :181-184
+    for (u32 i = 2; i < n; ++i) a.set(i, a.get(a.get(i)) + 1);
+#pragma unroll
+    for (u32 q = 0; q < (NR <= 1 ? 1u : (NR <= 4 ? 4u : 16u)); ++q) {
+        const u32 e = q * 64u + lane;
+        if (e < 2u * n) buf[e] = a.r[q];
+    }
+    __builtin_amdgcn_wave_barrier();
+    bool too_long = false;
+    for (u32 i0 = 0; i0 < n; i0 += 64u) { // :186-188
+        const u32 i = i0 + lane;
+        u32 l = 0;
+        if (i < n) {
+            l = buf[buf[i + n]] + 1;
+            out[i] = (u8)l;
+        }
+        if (__ballot(l > kLim)) too_long = true;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return too_long ? 1 : 0; // 1: the caller must redo the table with the package-merge (:190-194)
+}
+
 // length-limited redo from the weights; scr/row as for gen_code_lm, the weights go to scr's tail
 __device__ void lm_code_lengths(const u32 *rfreq, u32 n, u32 *scr, u32 scr_words, u32 row, u8 *out)
 {
@@ -819,8 +892,15 @@ __device__ __forceinline__ u32 huff_group_num(u32 mtf_count) // encoder.rs:370-3
 // (:112), and so is every package behind the last leaf (the loop ends with the leaves, :125).  Ranks are binary
 // searches, one element per lane.  The stable sort (:64-70) is a rank sort.  The bookkeeping between the levels
 // (take_package, :40-55, :129-141) runs level by level, the items of a level side by side.  Same scratch layout as gen_code_lm; the packages of a level are
-// kept in its own val row (dead once the level below exists).  All 64 lanes of ONE wave call it; the workgroup
-// is that wave.
+// kept in its own val row (dead once the level below exists).  All 64 lanes of ONE wave call it (the other waves of
+// the workgroup, if any, take no part).
+// (the lanes of ONE wave hand values to each other through LDS: a fence and a scheduling barrier, not a workgroup
+// barrier -- k_huff_tables calls this from one of its six waves)
+__device__ __forceinline__ void lm_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
 __device__ void lm_code_lengths_wave(const u32 *rfreq, u32 n, u32 *scr, u32 scr_words, u32 row, u8 *out, u32 lane)
 {
     const u32 lim = kLim;
@@ -836,7 +916,7 @@ __device__ void lm_code_lengths_wave(const u32 *rfreq, u32 n, u32 *scr, u32 scr_
         const u32 f = rfreq[i];
         w[i] = (f > 1u ? f : 1u) << 8;
     }
-    __syncthreads();
+    lm_wave_sync();
     // stable sort by weight, descending (:64-70), as ranks
     for (u32 i = lane; i < n; i += 64u) {
         const u32 f = w[i];
@@ -865,11 +945,11 @@ __device__ void lm_code_lengths_wave(const u32 *rfreq, u32 n, u32 *scr, u32 scr_
         for (u32 j = 1; j < lim; ++j)
             if (max_elem[j] > 2 * max_elem[j - 1] + b[j]) max_elem[j] = 2 * max_elem[j - 1] + b[j];
     }
-    __syncthreads();
+    lm_wave_sync();
     for (u32 j = 0; j < lim; ++j)           // :97-98 (zero initialised vectors)
         for (u32 t = lane; t < max_elem[j]; t += 64u) { val[j * row + t] = 0; ty[j * row + t] = 0; }
     for (u32 i = lane; i < n; i += 64u) c[i] = lim; // :99
-    __syncthreads();
+    lm_wave_sync();
     for (u32 t = lane; t < n && t < max_elem[lim - 1]; t += 64u) { // :101-104
         val[(lim - 1) * row + t] = sfreq[t];
         ty[(lim - 1) * row + t] = t;
@@ -878,7 +958,7 @@ __device__ void lm_code_lengths_wave(const u32 *rfreq, u32 n, u32 *scr, u32 scr_
         c[0] -= 1;
         cur[lim - 1] += 1;
     }
-    __syncthreads();
+    lm_wave_sync();
     const u32 last_leaf = sfreq[n - 1];
     for (u32 j = lim - 1; j > 0;) {         // :112-142
         const u32 next0 = cur[j], me = max_elem[j], cap = max_elem[j - 1];
@@ -888,10 +968,10 @@ __device__ void lm_code_lengths_wave(const u32 *rfreq, u32 n, u32 *scr, u32 scr_
             const u32 k = k0 + lane;
             u32 pk = 0;
             if (k < K) pk = weight_add(vj[next0 + 2u * k], vj[next0 + 2u * k + 1u]);
-            __syncthreads();
+            lm_wave_sync();
             if (k < K) vj[k] = pk; // (writes [k0, k0 + 64) lie in front of every later read, at >= next0 + 2 (k0 + 64))
         }
-        __syncthreads();
+        lm_wave_sync();
         for (u32 k = lane; k < K; k += 64u) {
             const u32 pk = vj[k];
             if (pk > last_leaf) {            // (a package behind the last leaf is never placed, :125)
@@ -922,10 +1002,10 @@ __device__ void lm_code_lengths_wave(const u32 *rfreq, u32 n, u32 *scr, u32 scr_
                 dt[pos] = i;
             }
         }
-        __syncthreads();
+        lm_wave_sync();
         j -= 1;
         if (lane == 0) cur[j] = 0;
-        __syncthreads();
+        lm_wave_sync();
         if (b[j] == 1) { // (uniform)
             // take_package(ty, c, cur, j) (:40-55), level by level instead of depth first: it takes the next item of
             // level j; an item that is a package takes the next two of the level below, and so on.  Which items a
@@ -946,16 +1026,16 @@ __device__ void lm_code_lengths_wave(const u32 *rfreq, u32 n, u32 *scr, u32 scr_
                     }
                     npk += (u32)__popcll(__ballot(isp));
                 }
-                __syncthreads();
+                lm_wave_sync();
                 if (lane == 0) cur[li] = c0 + need;
                 need = 2u * npk;
-                __syncthreads();
+                lm_wave_sync();
             }
         }
-        __syncthreads();
+        lm_wave_sync();
     }
     for (u32 i = lane; i < n; i += 64u) out[map[i]] = (u8)c[i]; // :144-150
-    __syncthreads();
+    lm_wave_sync();
 }
 
 // staging for any workgroup size (stage_symbols assumes its batch fits the 512-thread kernel's registers)
@@ -981,7 +1061,18 @@ __device__ __forceinline__ void stage_symbols_n(u32 *s_sym, const u16 *__restric
     }
 }
 
-__global__ __launch_bounds__(64) void k_huff_tables(HuffArgs a, u32 iter)
+// -DBZ_HUFF_HEAP_WAVE: a wave per table with the heap in its registers (heap_code_lengths_wave) instead of a lane per
+// table with the heap in LDS.  Measured in round 4 and NOT the default: the Huffman stage of the 1 GiB text corpus
+// takes 5.3 ms with it against 4.3 (38-symbol tables: six waves per block instead of one, 1189 blocks no longer
+// resident at once), 13.8 against 13.2 per 256 MiB of 258-symbol binary data, 6.6 against 5.7 of random bytes -- the
+// register array's writes are a compare and a select over up to sixteen registers, and that costs what the LDS round
+// trips did.  (The Deflate block kernel, where the same device pays, has 286-symbol tables and no LDS to spare.)
+#ifdef BZ_HUFF_HEAP_WAVE
+constexpr u32 kTabThreads = 6 * 64; // a wave per table
+#else
+constexpr u32 kTabThreads = 64;
+#endif
+__global__ __launch_bounds__(kTabThreads) void k_huff_tables(HuffArgs a, u32 iter)
 {
     __shared__ u8 s_len[6][kMaxAlpha + 6];
     __shared__ u32 s_rfreq[6][kMaxAlpha];
@@ -989,7 +1080,7 @@ __global__ __launch_bounds__(64) void k_huff_tables(HuffArgs a, u32 iter)
     __shared__ u32 s_need[6];
     __shared__ u32 s_lmcount;
     static_assert(kTabArena >= 6 * (2 * kMaxAlpha + 4), "the heap work arrays fit the arena");
-    const u32 lb = blockIdx.x, lane = threadIdx.x;
+    const u32 lb = blockIdx.x, tid = threadIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const BlockOut &bo = a.out[lb];
     const u32 mtf_count = bo.mtf_count;
     const u32 alpha = bo.in_use_count + 2; // encoder.rs:367
@@ -997,12 +1088,12 @@ __global__ __launch_bounds__(64) void k_huff_tables(HuffArgs a, u32 iter)
     const u32 *mtf_freq = a.mtf_freq + (size_t)lb * kMaxAlpha;
     u32 *rfreq = a.rfreq + (size_t)lb * 6 * kMaxAlpha;
     u8 *glen = a.glen + (size_t)lb * 6 * (kMaxAlpha + 6);
-    const bool tab_lane = lane < group_num;
-    const u32 tb = lane;
-    if (lane == 0) s_lmcount = 0;
+    const bool tab_lane = tid < group_num; // (the single-lane paths: one lane per table)
+    const u32 tb = tid;
+    if (tid == 0) s_lmcount = 0;
     if (iter == 0) {
         // initial tables, encoder.rs:379-426 (see k_huffman)
-        if (lane == 0) {
+        if (tid == 0) {
             u32 rem = mtf_count;
             int gs = 0;
             for (u32 k = 0; k < group_num; ++k) {
@@ -1025,16 +1116,29 @@ __global__ __launch_bounds__(64) void k_huff_tables(HuffArgs a, u32 iter)
             }
             a.hlm[lb] = 0;
         }
-        for (u32 i = lane; i < 6 * kMaxAlpha; i += 64u) rfreq[i] = 0;
+        for (u32 i = tid; i < 6 * kMaxAlpha; i += kTabThreads) rfreq[i] = 0;
         __syncthreads();
     } else {
         // the counts of the sweep come in, and are cleared for the next one
-        for (u32 i = lane; i < 6 * kMaxAlpha; i += 64u) {
+        for (u32 i = tid; i < 6 * kMaxAlpha; i += kTabThreads) {
             (&s_rfreq[0][0])[i] = rfreq[i];
             rfreq[i] = 0;
         }
         __syncthreads();
+        // the heap procedure: one lane per table, the heap in LDS (-DBZ_HUFF_HEAP_WAVE: wave w builds table w, the heap
+        // in its registers)
+#ifndef BZ_HUFF_HEAP_WAVE
         if (tab_lane) s_need[tb] = (u32)heap_code_lengths(s_rfreq[tb], alpha, s_arena + tb * (2 * kMaxAlpha + 4), s_len[tb]);
+#else
+        if (wv < group_num) { // (uniform per wave)
+            u32 *buf = s_arena + wv * (2 * kMaxAlpha + 4);
+            int need;
+            if (2u * alpha <= 64u) need = heap_code_lengths_wave<1>(s_rfreq[wv], alpha, buf, s_len[wv], lane);
+            else if (2u * alpha <= 256u) need = heap_code_lengths_wave<4>(s_rfreq[wv], alpha, buf, s_len[wv], lane);
+            else need = heap_code_lengths_wave<16>(s_rfreq[wv], alpha, buf, s_len[wv], lane);
+            if (lane == 0) s_need[wv] = (u32)need;
+        }
+#endif
         __syncthreads();
         // tables whose longest code exceeds 17 bits: package-merge, one lane each, as many tables at a time as fit
         // the arena, side by side in global memory when not even one does
@@ -1049,11 +1153,13 @@ __global__ __launch_bounds__(64) void k_huff_tables(HuffArgs a, u32 iter)
         (void)my_rank;
         if (any) { // uniform
             if (slots) {
-                // one table after the other, each by the whole wave (lm_code_lengths_wave)
-                for (u32 t = 0; t < group_num; ++t) {
-                    if (s_need[t]) { // uniform
-                        lm_code_lengths_wave(s_rfreq[t], alpha, s_arena, need, row, s_len[t], lane);
-                        if (lane == 0) s_lmcount += 1;
+                // one table after the other, each by one whole wave (lm_code_lengths_wave): wave 0
+                if (wv == 0) {
+                    for (u32 t = 0; t < group_num; ++t) {
+                        if (s_need[t]) { // uniform
+                            lm_code_lengths_wave(s_rfreq[t], alpha, s_arena, need, row, s_len[t], lane);
+                            if (lane == 0) s_lmcount += 1;
+                        }
                     }
                 }
                 __syncthreads();
@@ -1067,14 +1173,14 @@ __global__ __launch_bounds__(64) void k_huff_tables(HuffArgs a, u32 iter)
         }
     }
     // lengths and the packed form the sweeps add up
-    for (u32 i = lane; i < 6 * (kMaxAlpha + 6); i += 64u) glen[i] = (&s_len[0][0])[i];
+    for (u32 i = tid; i < 6 * (kMaxAlpha + 6); i += kTabThreads) glen[i] = (&s_len[0][0])[i];
     unsigned long long *pack = a.pack + (size_t)lb * kMaxAlpha;
-    for (u32 i = lane; i < alpha; i += 64u) {
+    for (u32 i = tid; i < alpha; i += kTabThreads) {
         unsigned long long p = 0;
         for (u32 t = 0; t < group_num; ++t) p |= (unsigned long long)s_len[t][i] << (10 * t);
         pack[i] = p;
     }
-    if (lane == 0 && s_lmcount) a.hlm[lb] += s_lmcount;
+    if (tid == 0 && s_lmcount) a.hlm[lb] += s_lmcount;
 }
 
 __global__ __launch_bounds__(kSweepThreads) void k_huff_sweep(HuffArgs a)
@@ -1443,10 +1549,10 @@ void launch_huffman(hipStream_t st, const HuffArgs &a)
     static const bool split = !(getenv("BZ_HUFF_SPLIT") && atoi(getenv("BZ_HUFF_SPLIT")) == 0);
     if (split) {
         const dim3 sweep_grid(kSweepTilesX, a.nb);
-        hipLaunchKernelGGL(k_huff_tables, dim3(a.nb), dim3(64), 0, st, a, 0u);
+        hipLaunchKernelGGL(k_huff_tables, dim3(a.nb), dim3(kTabThreads), 0, st, a, 0u);
         for (u32 iter = 1; iter <= 4; ++iter) { // BZ_N_ITERS, encoder.rs:294,433
             hipLaunchKernelGGL(k_huff_sweep, sweep_grid, dim3(kSweepThreads), 0, st, a);
-            hipLaunchKernelGGL(k_huff_tables, dim3(a.nb), dim3(64), 0, st, a, iter);
+            hipLaunchKernelGGL(k_huff_tables, dim3(a.nb), dim3(kTabThreads), 0, st, a, iter);
         }
         hipLaunchKernelGGL(k_huff_gbits, sweep_grid, dim3(kSweepThreads), 0, st, a);
         hipLaunchKernelGGL(k_huff_header, dim3(a.nb), dim3(kHuffThreads), 0, st, a);
