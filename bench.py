@@ -281,6 +281,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     kprof = eng.kernel_profile()
+    shard_t = eng.shard_timings() if multi else None
     stages = eng.timings()
     bstats = eng.bwt_stats()
     nblocks_rank = len(eng.block_stats())
@@ -293,6 +294,11 @@ def main():
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt = float(tmax.item())
         nblocks = int(tsum.item())
+        # the serial chain across the ranks: every rank's link (cut arrives -> own cut handed on), last timed step
+        links = [torch.zeros(4, dtype=torch.float64, device=wire) for _ in range(world)]
+        dist.all_gather(links, torch.tensor([shard_t[k] for k in ("wait_for_cut_ms", "chain_link_ms", "gather_ms", "assemble_ms")],
+                                            dtype=torch.float64, device=wire))
+        shard_all = [[round(float(x), 3) for x in t.tolist()] for t in links]
     else:
         nblocks = nblocks_rank
 
@@ -354,6 +360,14 @@ def main():
             "stream_sha256": sha,
             "checks": checks,
         }
+        if world > 1:
+            chain = [t[1] for t in shard_all[:-1]]  # (the last rank hands nothing on)
+            result["shard_chain"] = {"chain_ms_per_link": round(sum(chain) / len(chain), 3), "links_ms": chain,
+                                     "last_rank_waited_ms": shard_all[-1][0], "gather_ms_rank0": shard_all[0][2],
+                                     "assemble_ms_rank0": shard_all[0][3],
+                                     "note": "a link = from the arrival of the cut handed over by the rank before to the hand-on of "
+                                             "this rank's own (left halo, tile offsets, the cut chain over its slab); the links "
+                                             "are the one serial thing across the ranks"}
         if not args.no_cpu_baseline:
             # cpu_baseline leg: the oracle (a C restatement of the reference algorithm, 1 thread like the
             # reference) on a bounded sample of the same corpus; its output doubles as a parity check.

@@ -73,8 +73,8 @@ extern "C" const char *bz_version(void) { return "bz2_mi355x 0.1 (gfx950)"; }
 // the chunk's job will run on and hands the chunk to that lane's worker thread.
 //
 // A context drives one or several devices (bz_enc_create_multi): every entry of the caller's device list gets
-// TWO lanes (an engine with its own streams and buffers each), lane l lives on devices[l mod n_devices], and job
-// q runs on lane q mod (2 n_devices) -- consecutive jobs go to different devices, and the latency-bound tail of
+// THREE lanes (BZ_ENC_LANES; an engine with its own streams and buffers each), lane l lives on devices[l mod n_devices],
+// and job q runs on lane q mod (3 n_devices) -- consecutive jobs go to different devices, and the latency-bound tail of
 // one job's encode (Huffman: one workgroup per block) runs beside the bandwidth-bound sort of the job that
 // shares its device.  A job puts the unconsumed tail of the previous job's input (it lies in the previous lane's
 // buffer: a device-to-device copy, across xGMI with hipMemcpyPeerAsync when the lanes sit on different devices)
@@ -167,6 +167,20 @@ static size_t enc_first_chunk_bytes()
     return v;
 }
 
+// lanes per entry of a context's device list (BZ_ENC_LANES, 2 .. 8; consecutive jobs must run on different lanes: the
+// tail of a job's input is handed from lane to lane).  Default 3 since round 4: the latency-bound tails of two jobs
+// beside the sort of a third -- measured on 1 GiB, one device, warm bz_encode_buffer calls: 2 lanes 103.3 ms, 3 lanes
+// 98.1 ms (10.9 GB/s, 0.88 of the HBM-resident rate), 4 lanes 101.3 ms.
+static size_t enc_lanes_per_device()
+{
+    static const size_t v = [] {
+        const char *s = getenv("BZ_ENC_LANES");
+        const long k = s ? atol(s) : 3;
+        return (size_t)(k < 2 ? 2 : (k > 8 ? 8 : k));
+    }();
+    return v;
+}
+
 static void resources_free(EncResources *r)
 {
     if (!r) return;
@@ -213,7 +227,7 @@ static int resources_get(const std::vector<int> &devices, EncResources **out)
         const long v = atol(e);
         if (v >= 8 && (size_t)v < r->engine_blocks) r->engine_blocks = (size_t)v;
     }
-    r->lanes.resize(2 * devices.size());
+    r->lanes.resize(enc_lanes_per_device() * devices.size());
     bool ok = true;
     for (size_t l = 0; l < r->lanes.size() && ok; ++l) { // (engines and buffers come with the jobs: job_split, grow)
         Lane &ln = r->lanes[l];
@@ -1083,15 +1097,16 @@ extern "C" int bz_encode_buffer_multi(int level, const int *devices, int n_devic
         // chunks get smaller rather than leave lanes without a job, down to 32 MiB (a job of 40 blocks still fills a
         // device's 256 CUs in the sort, and the per-job latencies of the tail stages run side by side).
         const size_t most = enc_chunk_bytes(), first = std::min(most, enc_first_chunk_bytes());
-        const size_t lanes = 2 * (size_t)n_devices, least = std::min(most, (size_t)32 << 20);
+        const size_t lanes = enc_lanes_per_device() * (size_t)n_devices, least = std::min(most, (size_t)32 << 20);
         if (in_len > first + most || (n_devices > 1 && in_len > first + 2 * least)) {
             const size_t rest = in_len - first;
             size_t k = (rest + most - 1) / most;
-            k += k & 1u;
+            const size_t per = enc_lanes_per_device();
+            k = (k + per - 1) / per * per; // (a whole number of rounds over one device's lanes)
             if (n_devices > 1) {
                 const size_t k0 = k;
                 k = (k + lanes - 1) / lanes * lanes;
-                while (k > k0 && rest / k < least) k -= 2;
+                while (k > k0 && rest / k < least) k -= per;
             }
             e->chunk_bytes = (((rest + k - 1) / k) + 4095) & ~(size_t)4095;
         }

@@ -1011,8 +1011,14 @@ static int encode_sharded_impl(bz_gpu_engine *g, int level, const void *d_in, si
     if (rc == BZ_OK) rc = bz_gpu_partition_slab_count(g, carry);
 
     // 2. the cut chain
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+    for (double &t : g->shard_ms) t = 0;
+    const clk::time_point t_wait = clk::now();
     uint64_t hop[2] = {0, 0}; // {first input byte of the receiver's first block, sender's status}
     if (rank > 0 && comm->recv(comm->ctx, rank - 1, hop, sizeof(hop)) != 0) return BZ_E_UNEXPECTED;
+    g->shard_ms[0] = ms_since(t_wait);
+    const clk::time_point t_link = clk::now(); // this rank's link of the serial chain: from the hop's arrival to the hand-on
     if (rc == BZ_OK && hop[1] != 0) rc = -(int)hop[1];
     // (a window: the first block's bytes in front of the slab must lie inside it, from the start of their tile on)
     if (rc == BZ_OK && t1 > t0 && hop[0] / kRleTile * kRleTile < win_lo) {
@@ -1030,6 +1036,7 @@ static int encode_sharded_impl(bz_gpu_engine *g, int level, const void *d_in, si
         uint64_t out_hop[2] = {next, (uint64_t)(rc == BZ_OK ? 0 : -rc)};
         if (comm->send(comm->ctx, rank + 1, out_hop, sizeof(out_hop)) != 0) return BZ_E_UNEXPECTED;
     }
+    g->shard_ms[1] = ms_since(t_link);
     if (rc == BZ_OK) rc = slab_image(g, sc);
     else if (sc.span >= 0) { span_end(g, sc.span); spans_collect(g); }
 
@@ -1100,9 +1107,12 @@ static int encode_sharded_impl(bz_gpu_engine *g, int level, const void *d_in, si
         rlen[(size_t)r] = heads[(size_t)r].words * 4;
         cursor += heads[(size_t)r].words;
     }
+    const clk::time_point t_gather = clk::now();
     if (comm->gatherv(comm->ctx, d_packed, (size_t)used * 4, rank == 0 ? d_gather : nullptr, roff.data(), rlen.data()) != 0)
         return BZ_E_UNEXPECTED;
+    g->shard_ms[2] = ms_since(t_gather);
     if (rank != 0) return BZ_OK;
+    const clk::time_point t_asm = clk::now();
 
     std::vector<uint64_t> awoff((size_t)total_blocks + 1), ablen((size_t)total_blocks + 1);
     std::vector<uint32_t> acrc((size_t)total_blocks + 1);
@@ -1114,8 +1124,17 @@ static int encode_sharded_impl(bz_gpu_engine *g, int level, const void *d_in, si
             ablen[q] = m.bit_len;
             acrc[q] = m.crc;
         }
-    return bz_gpu_assemble(g, level, (size_t)total_blocks, d_gather, awoff.data(), ablen.data(), acrc.data(), 1, 1, 1, 0, 0, 0,
-                           nullptr, d_out, cap, out_len, nullptr, nullptr);
+    const int arc = bz_gpu_assemble(g, level, (size_t)total_blocks, d_gather, awoff.data(), ablen.data(), acrc.data(), 1, 1, 1, 0, 0,
+                                    0, nullptr, d_out, cap, out_len, nullptr, nullptr);
+    g->shard_ms[3] = ms_since(t_asm);
+    return arc;
+}
+
+extern "C" int bz_gpu_last_shard_timings(bz_gpu_engine *g, double out_ms[4])
+{
+    if (!g || !out_ms) return BZ_E_PARAM;
+    for (int i = 0; i < 4; ++i) out_ms[i] = g->shard_ms[i];
+    return BZ_OK;
 }
 
 extern "C" int bz_gpu_encode_sharded(bz_gpu_engine *g, int level, const void *d_in, size_t n,

@@ -88,6 +88,7 @@ struct bz_gpu_engine {
     std::vector<u32> h_out_nblock;
     double t_stage[6] = {0, 0, 0, 0, 0, 0};
     KernelProf prof;
+    double shard_ms[4] = {0, 0, 0, 0}; // last bz_gpu_encode_sharded: wait for the hop, hop -> hand-on, gather, assembly
     u64 bwt_stats[4] = {0, 0, 0, 0};
     u64 round_active[64] = {};
 

@@ -175,10 +175,10 @@ print("RESULT " + json.dumps({"rc": rc, "bytes": outn.value, "sha": sha, "second
 
 def test_one_process_eight_device_entries_at_config_size():
     """The drop-in surface at the size of configs[2]: ONE 8 GiB host buffer through bz_encode_buffer_multi with the
-    device list [0] * 8 (sixteen lanes on the box's one GPU) == the oracle's golden.  A fresh process: the lanes'
-    workspaces (sixteen engines) are this test's alone; chunks of 192 MiB keep them at ~8 GB each."""
+    device list [0] * 8 (sixteen lanes on the box's one GPU: two per entry here, so that sixteen workspaces of ~8 GB
+    share the one GPU with room to spare) == the oracle's golden.  A fresh process: the engines are this test's alone."""
     gold = _golden("bzip2_l9_text_8gib")
-    env = dict(os.environ, BZ_ENC_CHUNK_MIB="192")
+    env = dict(os.environ, BZ_ENC_CHUNK_MIB="192", BZ_ENC_LANES="2")
     out = subprocess.run([sys.executable, "-c", _MULTI % {"root": ROOT, "gib": 8, "lanes": 8}], env=env, capture_output=True,
                          text=True, timeout=1400)
     assert out.returncode == 0, out.stderr[-3000:]

@@ -165,6 +165,9 @@ def test_bench_two_ranks_line_is_self_sufficient():
     assert line["roofline"]["pipeline_8d"]["frac"] > 0 and line["roofline"]["frac"] > 0
     assert line["step_ms"]["n"] == 2 and line["step_ms"]["min"] <= line["step_ms"]["median"]
     assert line["config"]["ranks"]["world"] == 2
+    assert line["shard_chain"]["chain_ms_per_link"] > 0 and len(line["shard_chain"]["links_ms"]) == 1
+    assert line["end_to_end"]["calls_ms"]["n"] == 3 and line["end_to_end"]["phases_ms_of_the_median_call"]["jobs"] >= 1
+    assert line["value_end_to_end"] == line["end_to_end"]["bz_encode_buffer_multi"]
     assert line["end_to_end"]["devices"] == [0, 0] and line["end_to_end"]["bz_encode_buffer_multi"] > 0
     assert line["extra"]["decode"]["round_trip_equals_input_on_every_rank"] is True
     assert all(line["checks"].values()), line["checks"]
