@@ -76,9 +76,9 @@ int bz_enc_create(bz_enc **out, int level, int device);
 /* The same encoder over SEVERAL devices of one process (SURVEY.md 8(b) "Surface"; in the shims
  * `BZip2Encoder::with_devices(level, &[0, 1, ..])`, still src/bzip2/encoder.rs:58-72 for the caller, who drives it
  * through the unchanged Encoder::next of src/traits/encoder.rs:41-79).  Every entry of `devices` (HIP ordinals; an
- * ordinal may be listed more than once) gets three LANES (BZ_ENC_LANES in the environment: 2 .. 8) -- an engine with its
+ * ordinal may be listed more than once) gets two LANES (BZ_ENC_LANES in the environment: 2 .. 8) -- an engine with its
  * own streams and buffers each; the input is cut into chunks (BZ_ENC_CHUNK_MIB, default 192), chunk q is uploaded to and
- * encoded on lane q mod (3 n_devices), the unconsumed tail of a
+ * encoded on lane q mod (2 n_devices), the unconsumed tail of a
  * chunk's input crosses to the next lane's device (hipMemcpyPeerAsync: xGMI between the GPUs of a node), and the
  * block bit strings are concatenated in chunk order with the BitWriter carry, the combined CRC and "a block has
  * been written" handed from chunk to chunk on the host.  The bytes are those of bz_enc_create for any device list
@@ -137,7 +137,7 @@ int bz_encode_buffer_multi(int level, const int *devices, int n_devices, const u
                            uint8_t **out, size_t *out_len);
 void bz_free(void *p);
 /* Contexts and one-shot calls park their engines (batch workspace: about 31.5 MB of HBM per block of the largest
- * chunk seen, i.e. up to ~8 GB per lane with the default 192 MiB chunks, three lanes per listed device), device staging
+ * chunk seen, i.e. up to ~8 GB per lane with the default 192 MiB chunks, two lanes per listed device), device staging
  * buffers and 2 x BZ_ENC_CHUNK_MIB of pinned host memory in a per-process cache (two device lists at most) when they
  * end, so that the next one does not pay hipMalloc / hipHostMalloc again (fresh device memory costs about 40 ms per
  * GiB on this platform: the FIRST 1 GiB call of a process takes 0.3-0.6 s, a later one 0.1 s).  This call releases what

@@ -73,8 +73,8 @@ extern "C" const char *bz_version(void) { return "bz2_mi355x 0.1 (gfx950)"; }
 // the chunk's job will run on and hands the chunk to that lane's worker thread.
 //
 // A context drives one or several devices (bz_enc_create_multi): every entry of the caller's device list gets
-// THREE lanes (BZ_ENC_LANES; an engine with its own streams and buffers each), lane l lives on devices[l mod n_devices],
-// and job q runs on lane q mod (3 n_devices) -- consecutive jobs go to different devices, and the latency-bound tail of
+// TWO lanes (BZ_ENC_LANES; an engine with its own streams and buffers each), lane l lives on devices[l mod n_devices],
+// and job q runs on lane q mod (2 n_devices) -- consecutive jobs go to different devices, and the latency-bound tail of
 // one job's encode (Huffman: one workgroup per block) runs beside the bandwidth-bound sort of the job that
 // shares its device.  A job puts the unconsumed tail of the previous job's input (it lies in the previous lane's
 // buffer: a device-to-device copy, across xGMI with hipMemcpyPeerAsync when the lanes sit on different devices)
@@ -168,14 +168,16 @@ static size_t enc_first_chunk_bytes()
 }
 
 // lanes per entry of a context's device list (BZ_ENC_LANES, 2 .. 8; consecutive jobs must run on different lanes: the
-// tail of a job's input is handed from lane to lane).  Default 3 since round 4: the latency-bound tails of two jobs
-// beside the sort of a third -- measured on 1 GiB, one device, warm bz_encode_buffer calls: 2 lanes 103.3 ms, 3 lanes
-// 98.1 ms (10.9 GB/s, 0.88 of the HBM-resident rate), 4 lanes 101.3 ms.
+// tail of a job's input is handed from lane to lane).  Default 2: the latency-bound tail of one job beside the sort of
+// another.  Measured in round 4 on 1 GiB, one device, warm bz_encode_buffer calls: 2 lanes 103.3 ms, 3 lanes 98.1 ms
+// in a process of its own and 102.6 ms inside bench.py (the split sections queue behind two other lanes' sorts: 62 ms
+// summed over the jobs instead of 20), 4 lanes 101.3 ms -- and a third lane is a third workspace: the first call of a
+// process took 1.26 s with three lanes against 0.36 s with two.
 static size_t enc_lanes_per_device()
 {
     static const size_t v = [] {
         const char *s = getenv("BZ_ENC_LANES");
-        const long k = s ? atol(s) : 3;
+        const long k = s ? atol(s) : 2;
         return (size_t)(k < 2 ? 2 : (k > 8 ? 8 : k));
     }();
     return v;
