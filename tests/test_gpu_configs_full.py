@@ -62,6 +62,8 @@ def _worker(rank, world, port, shm_path, q):
         chs = {k: corpus.chapter(k) for k in corpus.slice_chapters(off, nbytes)}
         d_win = corpus.slice_on_device(off, nbytes, dev, chs=chs)
         eng = pkg.GpuEngine(0, BLOCKS_IN_FLIGHT)
+        if world == 2:
+            eng.set_verify(True)  # (the self-check on the sharded path at size: every rank decodes and compares its own blocks)
         comm = sharded.TorchComm(rank, world, dev)
         cap = ((pkg.encode_bound(n) + 15) & ~15) if rank == 0 else 16
         d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
@@ -69,6 +71,7 @@ def _worker(rank, world, port, shm_path, q):
         k = eng.encode_sharded_window(9, d_win.data_ptr(), off, nbytes, n, comm, d_out.data_ptr(), cap)
         res["errors"] = list(comm.errors)
         res["fallbacks"] = eng.bwt_stats()["fused_fallbacks"]
+        res["verify"] = eng.verify_stats()
         zlen = torch.tensor([k], dtype=torch.int64)
         if rank == 0:
             stream = d_out[:k].cpu().numpy()
@@ -143,6 +146,8 @@ def test_sharded_encode_and_decode_at_config_size(world, tmp_path):
     assert [r["errors"] for r in got] == [[]] * world
     assert got[0]["bytes"] == gold["bytes"] and got[0]["sha"] == gold["sha256"]
     assert [r["fallbacks"] for r in got] == [0] * world
+    if world == 2:
+        assert all(r["verify"]["blocks_checked"] > 1000 and r["verify"]["jobs_redone"] == 0 for r in got), [r["verify"] for r in got]
     n = world << 30
     covered = 0
     for r in got:

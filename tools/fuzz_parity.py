@@ -19,8 +19,28 @@ flavour = sys.argv[3] if len(sys.argv) > 3 else "small"   # small | big | stream
 rng = random.Random(seed)
 
 
+def gen_copies():
+    """round 4: what the period round is about -- a stretch repeated at some distance, with foreign bytes in front and
+    behind, a few changed bytes, two different stretches in one block, distances beyond half a block"""
+    k = rng.choice([2, 4, 16, 64, 256])
+    n = rng.choice([30000, 99981, 120000, 250000])
+    out = bytearray(bytes(rng.randrange(k) for _ in range(rng.choice([0, 1, 3, 50, 5000]))))
+    for _ in range(rng.choice([1, 1, 2])):
+        L = rng.choice([2, 7, 100, 3000, 4096, 40000, 60000, 90000])
+        base = bytes(rng.randrange(k) for _ in range(L))
+        reps = max(2, min(n // L, rng.choice([2, 3, 30, 1000])))
+        piece = bytearray(base * reps + base[:rng.randrange(L)])
+        for _ in range(rng.choice([0, 0, 1, 2, 5])):
+            piece[rng.randrange(len(piece))] ^= 1 + rng.randrange(3)
+        out += piece
+        out += bytes(rng.randrange(k) for _ in range(rng.choice([0, 0, 2, 700])))
+    return bytes(out[:n + rng.randrange(0, 5)])
+
+
 def gen():
-    kind = rng.randrange(8)
+    kind = rng.randrange(10)
+    if kind >= 8:
+        return gen_copies()
     n = rng.choice([0, 1, 2, 3, 5, 17, 255, 256, 257, 1000, 4096, 50000, 99980, 99981, 99982, 100010, 150000, 250000])
     n = max(0, n + rng.randrange(-3, 4)) if n > 10 else n
     k = rng.choice([1, 2, 3, 4, 8, 16, 64, 200, 256])
