@@ -140,7 +140,7 @@ void bz_free(void *p);
  * chunk seen, i.e. up to ~8 GB per lane with the default 192 MiB chunks, two lanes per listed device), device staging
  * buffers and 2 x BZ_ENC_CHUNK_MIB of pinned host memory in a per-process cache (two device lists at most) when they
  * end, so that the next one does not pay hipMalloc / hipHostMalloc again (fresh device memory costs about 40 ms per
- * GiB on this platform: the FIRST 1 GiB call of a process takes 0.3-0.6 s, a later one 0.1 s).  This call releases what
+ * GiB on this platform: the FIRST 1 GiB call of a process takes 0.35 s, a later one 0.1 s).  This call releases what
  * is parked; BZ_ENC_NO_CACHE=1 in the environment turns the cache off. */
 void bz_release_cached_resources(void);
 
@@ -160,6 +160,10 @@ typedef struct bz_gpu_engine bz_gpu_engine;
  * block); inputs with more blocks are processed in several batches. */
 int bz_gpu_engine_create(bz_gpu_engine **out, int device, size_t max_blocks_in_flight);
 void bz_gpu_engine_destroy(bz_gpu_engine *g);
+/* The batch workspace (about 31.5 MB per block in flight) is made by the first call that needs it and grows with the
+ * largest call seen; a caller who knows the size of the calls to come reserves it once (fresh device memory costs about
+ * 40 ms per GiB here: growing means freeing and paying again). */
+int bz_gpu_engine_reserve(bz_gpu_engine *g, size_t blocks);
 
 /* The self-check of section 1 for the device-resident calls: the blocks of every bz_gpu_encode_blocks (and so of
  * bz_gpu_encode_device / bz_gpu_encode_sharded on each rank) are decoded on the device and compared with the input they

@@ -325,6 +325,7 @@ struct bz_enc {
     size_t fill = 0;
     u64 chunks_filled = 0;       // chunks handed over so far
     size_t chunk_bytes = 0;      // 0: the resources' chunk size; a one-shot call knows its length and balances them
+    size_t reserve_blocks = 0;   // a one-shot call whose lanes will each see several jobs: their workspace is made once, at that size
     // Chain state 1 (handed from a job's SPLIT phase to the next job's): the unconsumed input lies in
     // lanes[tail_lane].d_buf, `tail_len` bytes at offset `tail_off`; finish_seen: a Finish job has been split
     int tail_lane = 0;
@@ -532,6 +533,10 @@ static int job_split(bz_enc *e, const EncJob &j, int lane, JobState &js)
     }
     if (!ln.g) { // a lane's engine is created when the lane gets its first job
         const int rc = bz_gpu_engine_create(&ln.g, ln.device, r->engine_blocks);
+        if (rc != BZ_OK) return rc;
+    }
+    if (e->reserve_blocks && j.seq < (u64)e->n_lanes) { // (the lane's first job of a one-shot call that has more for it)
+        const int rc = bz_gpu_engine_reserve(ln.g, e->reserve_blocks);
         if (rc != BZ_OK) return rc;
     }
     js.t0 = now_ms();
@@ -1111,6 +1116,10 @@ extern "C" int bz_encode_buffer_multi(int level, const int *devices, int n_devic
                 while (k > k0 && rest / k < least) k -= per;
             }
             e->chunk_bytes = (((rest + k - 1) / k) + 4095) & ~(size_t)4095;
+            // every lane gets a job of that size sooner or later (the first lane's first job is the small first chunk):
+            // its workspace is made for it at once -- level-9 text is ~0.9 MB a block; run-heavy or low-level inputs make
+            // more blocks and grow the workspace as before
+            if (k + 1 > lanes) e->reserve_blocks = e->chunk_bytes / 880000 + 4;
         }
     }
     if (in_len) rc = bz_enc_write(e, in, in_len);

@@ -53,6 +53,7 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
     (void)hipStreamDestroy(g->st);
     delete g;
 }
+extern "C" int bz_gpu_engine_reserve(bz_gpu_engine *g, size_t) { return g ? BZ_OK : BZ_E_PARAM; }
 extern "C" int bz_gpu_engine_set_verify(bz_gpu_engine *g, int on)
 {
     if (!g) return BZ_E_PARAM;
