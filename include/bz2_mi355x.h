@@ -249,8 +249,9 @@ int bz_gpu_assemble(bz_gpu_engine *g, int level, size_t n_blocks,
 
 /* ---- the whole stream over several GPUs (BASELINE.json configs[2]) ----------------
  * One process (one engine) per GPU; every rank calls bz_gpu_encode_sharded with the same level and n.
- * Rank r splits its SLAB of the input -- an equal share of the 4 KiB tiles, [ntiles*r/world,
- * ntiles*(r+1)/world) -- with the three _slab_ calls above, encodes the blocks that END in its slab
+ * Rank r splits its SLAB of the input -- a contiguous range of the 4 KiB tiles, bz_shard_slab_tiles: nearly equal
+ * shares, shrinking a little from rank to rank (BZ_SHARD_SKEW, default 0.02) because rank r starts its blocks r links of
+ * the cut chain later than rank 0 -- with the three _slab_ calls above, encodes the blocks that END in its slab
  * (stream order == rank order) and the block bit strings are gathered to rank 0, which assembles the
  * serial stream (bz_gpu_assemble).  d_in is addressed as the whole input, but a rank only reads its
  * slab and, in front of it, the input bytes of the block that straddles its left edge (a level-9
@@ -292,6 +293,7 @@ int bz_gpu_encode_sharded(bz_gpu_engine *g, int level, const void *d_in, size_t 
  * level-9 block covers at most 899981 * 255 / 5 = 45.9 MB of input) and one tile behind.  A window that turns out
  * too short (the cut handed over by the rank before lies in front of it) makes every rank return BZ_E_CAPACITY.
  * bz_gpu_encode_sharded(g, level, d_in, n, ...) == bz_gpu_encode_sharded_window(g, level, d_in, 0, n, n, ...). */
+int bz_shard_slab_tiles(size_t n, int rank, int world, uint64_t *tile0, uint64_t *tile1); /* the rank's tiles [tile0, tile1) */
 size_t bz_shard_halo_bytes(int level);
 int bz_shard_window(int level, size_t n, int rank, int world, uint64_t *window_off, size_t *window_bytes);
 int bz_gpu_encode_sharded_window(bz_gpu_engine *g, int level, const void *d_window, uint64_t window_off,

@@ -84,7 +84,7 @@ EXPORTS = [
     "bz_gpu_engine_create", "bz_gpu_engine_destroy", "bz_gpu_engine_reserve", "bz_encode_bound", "bz_gpu_encode_device",
     "bz_gpu_partition", "bz_gpu_partition_slab_begin", "bz_gpu_partition_slab_count",
     "bz_gpu_partition_slab_finish", "bz_gpu_block_count", "bz_gpu_encode_blocks", "bz_gpu_assemble", "bz_gpu_encode_sharded",
-    "bz_shard_comm_selftest", "bz_gpu_last_timings", "bz_shard_halo_bytes", "bz_shard_window", "bz_gpu_encode_sharded_window", "bz_gpu_last_shard_timings",
+    "bz_shard_comm_selftest", "bz_gpu_last_timings", "bz_shard_halo_bytes", "bz_shard_window", "bz_shard_slab_tiles", "bz_gpu_encode_sharded_window", "bz_gpu_last_shard_timings",
     "bz_gpu_last_bwt_stats", "bz_gpu_last_bwt_rounds", "bz_gpu_profile_enable", "bz_gpu_profile_kernels", "bz_gpu_profile_get",
     "bz_gpu_debug_bwt", "bz_gpu_debug_code_lengths", "bz_gpu_debug_block_stats",
     "bz_gpu_decode_device", "bz_gpu_decode_device_sharded", "bz_gpu_last_decode_timings", "bz_gpu_last_decode_stats", "bz_decode_buffer",
@@ -177,6 +177,7 @@ def lib():
     L.bz_shard_halo_bytes.restype = sz
     L.bz_shard_halo_bytes.argtypes = [C.c_int]
     L.bz_shard_window.argtypes = [C.c_int, sz, C.c_int, C.c_int, u64p, szp]
+    L.bz_shard_slab_tiles.argtypes = [sz, C.c_int, C.c_int, u64p, u64p]
     L.bz_gpu_encode_sharded_window.argtypes = [vp, C.c_int, vp, C.c_uint64, sz, sz, vp, vp, sz, vp, sz, vp, sz, szp]
     L.bz_gpu_last_shard_timings.argtypes = [vp, C.POINTER(C.c_double)]
     L.bz_shard_comm_selftest.argtypes = [vp, C.c_int]

@@ -963,6 +963,42 @@ struct ShardBlock {
     u32 crc, pad;
 };
 
+// Which tiles a rank owns.  The cut chain makes rank r start its blocks r links later than rank 0 (a link: ~2 ms per GiB
+// of slab against ~85 ms for the slab's blocks), and the step ends with the LAST rank: slabs that shrink a little from
+// rank to rank -- weights 1 + skew ((world - 1) / 2 - r), which sum to world -- let all ranks finish together instead
+// (at N = 8 and skew = link / slab time = 0.02: the last rank's 14 ms of waiting become 7 ms for everybody).  The bytes
+// of the stream do not depend on the split.  BZ_SHARD_SKEW in the environment (0 = equal slabs; default 0.02; every rank
+// of a job must see the same value).
+static double shard_skew()
+{
+    static const double v = [] {
+        const char *e = getenv("BZ_SHARD_SKEW");
+        double s = e ? atof(e) : 0.02;
+        if (!(s >= 0.0)) s = 0.0;
+        if (s > 0.2) s = 0.2;
+        return s;
+    }();
+    return v;
+}
+static u64 shard_tile_begin(u64 ntiles, int rank, int world)
+{
+    if (rank <= 0) return 0;
+    if (rank >= world) return ntiles;
+    const double r = rank, w = world, s = shard_skew();
+    const double share = (r + s * (r * (w - 1.0) / 2.0 - r * (r - 1.0) / 2.0)) / w; // sum of the weights of ranks < r, over world
+    u64 t = (u64)((double)ntiles * share + 0.5);
+    return t > ntiles ? ntiles : t;
+}
+extern "C" int bz_shard_slab_tiles(size_t n, int rank, int world, uint64_t *tile0, uint64_t *tile1)
+{
+    if (world < 1 || rank < 0 || rank >= world || !tile0 || !tile1) return BZ_E_PARAM;
+    const u64 ntiles = ((u64)n + kRleTile - 1) / kRleTile;
+    *tile0 = shard_tile_begin(ntiles, rank, world);
+    *tile1 = shard_tile_begin(ntiles, rank + 1, world);
+    if (*tile1 < *tile0) *tile1 = *tile0;
+    return BZ_OK;
+}
+
 // A level-`level` block covers at most (100000 level - 19) * 255 / 5 input bytes (a run of 255 equal bytes is five
 // RLE1 bytes, encoder.rs:676-690): what a rank may have to re-read in front of its slab, rounded up to whole tiles.
 extern "C" size_t bz_shard_halo_bytes(int level)
@@ -976,7 +1012,7 @@ extern "C" int bz_shard_window(int level, size_t n, int rank, int world, uint64_
 {
     if (level < 1 || level > 9 || world < 1 || rank < 0 || rank >= world || !window_off || !window_bytes) return BZ_E_PARAM;
     const u64 ntiles = ((u64)n + kRleTile - 1) / kRleTile;
-    const u64 t0 = ntiles * (u64)rank / (u64)world, t1 = ntiles * (u64)(rank + 1) / (u64)world;
+    const u64 t0 = shard_tile_begin(ntiles, rank, world), t1 = std::max(t0, shard_tile_begin(ntiles, rank + 1, world));
     const u64 begin = t0 * kRleTile, end = std::min<u64>((u64)n, t1 * kRleTile);
     const u64 halo = bz_shard_halo_bytes(level);
     const u64 lo = begin > halo ? begin - halo : 0;
@@ -998,7 +1034,7 @@ static int encode_sharded_impl(bz_gpu_engine *g, int level, const void *d_in, si
     const int rank = comm->rank, world = comm->world;
     if (world > 1 && (!comm->allgather || !comm->send || !comm->recv || !comm->gatherv)) return BZ_E_PARAM;
     const u64 ntiles = (n + kRleTile - 1) / kRleTile;
-    const u64 t0 = ntiles * (u64)rank / (u64)world, t1 = ntiles * (u64)(rank + 1) / (u64)world;
+    const u64 t0 = shard_tile_begin(ntiles, rank, world), t1 = std::max(t0, shard_tile_begin(ntiles, rank + 1, world));
     int rc = BZ_OK; // this rank's status; collectives go on regardless
     {
         // the window must hold the slab, a tile in front of it (the split looks at the byte before a slab) and the

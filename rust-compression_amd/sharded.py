@@ -37,9 +37,15 @@ class ShardComm(C.Structure):
 
 
 def slab_tiles(n, rank, world):
-    """Tile range [t0, t1) of `rank`: equal shares of the ceil(n / 4096) tiles (the library's split)."""
-    ntiles = (n + TILE - 1) // TILE
-    return ntiles * rank // world, ntiles * (rank + 1) // world
+    """Tile range [t0, t1) of `rank` (bz_shard_slab_tiles: the library's split -- nearly equal shares of the
+    ceil(n / 4096) tiles, shrinking a little from rank to rank to make up for the cut chain, BZ_SHARD_SKEW)."""
+    import importlib
+    lib = importlib.import_module(__package__).lib()
+    t0, t1 = C.c_uint64(0), C.c_uint64(0)
+    rc = lib.bz_shard_slab_tiles(n, rank, world, C.byref(t0), C.byref(t1))
+    if rc != 0:
+        raise ValueError("bz_shard_slab_tiles: status %d" % rc)
+    return t0.value, t1.value
 
 
 class _DevBytes:
