@@ -350,6 +350,7 @@ struct MtfArgs {
     u32 *zstate;             // [nb][kTilesPerBlock][4] look-back words of k_zle_fused
     u32 *ztick;              // [16] its tile tickets per XCD, [8]: a look-back gave up
     u32 fused_zle;           // 1: k_zle_fused; 0: k_zle_last + k_zle_emit<false> + k_zle_emit<true>
+    u32 walk_above;          // blocks with more symbols in use than this take the list walk (k_mtf_ranks): 256 = none, 96 = rounds 1-3
     u16 *mtf;                // [nb][kMtfStride] output symbols
     u32 *mtf_freq;           // [nb][kMaxAlpha]
     BlockOut *out;           // [nb]

@@ -491,6 +491,8 @@ static MtfArgs make_mtf_args(bz_gpu_engine *g, u32 nb, u32 o, u32 total_nb)
     ma.ztick = g->ztick.as<u32>();
     static const bool want_fused_zle = !(getenv("BZ_FUSED_ZLE") && atoi(getenv("BZ_FUSED_ZLE")) == 0);
     ma.fused_zle = (want_fused_zle && !g->zle_fused_broken && o == 0 && nb == total_nb) ? 1u : 0u; // (one sub-batch: one set of tickets)
+    static const bool want_walk = getenv("BZ_MTF_WALK") && atoi(getenv("BZ_MTF_WALK")) != 0;
+    ma.walk_above = want_walk ? 96u : 256u;
     ma.mtf = g->mtf.as<u16>() + (size_t)o * kMtfStride;
     ma.mtf_freq = g->mtf_freq.as<u32>() + (size_t)o * kMaxAlpha;
     ma.out = g->bout.as<BlockOut>() + o;

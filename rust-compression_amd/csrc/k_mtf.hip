@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void k_mtf_ranks(MtfArgs a)
     const u32 n = a.blocks[lb].n;
     const u32 chunk0 = blockIdx.x * 256u;
     if (chunk0 * kMtfChunk >= n) return;
-    if (popc8(a.inuse_bits + lb * 8) <= kMtfSmallAlpha) return; // k_mtf_ranks_small takes those blocks
+    if (popc8(a.inuse_bits + lb * 8) <= a.walk_above) return; // k_mtf_ranks_small takes those blocks
     const u32 nchunks = (n + kMtfChunk - 1) / kMtfChunk;
     // cooperative, coalesced load of up to 256 start lists (64 dwords each)
     {
@@ -379,19 +379,25 @@ __device__ __forceinline__ short2_t as_short2(u32 v)
     __builtin_memcpy(&r, &v, 4);
     return r;
 }
-__global__ __launch_bounds__(256) void k_mtf_ranks_small(MtfArgs a)
+// Round 4: the same for LARGE alphabets (97 .. 256 symbols in use) with 128 lanes per workgroup -- 128 pairs x 128
+// lanes x 4 B = 64 KB of LDS.  The list walk of k_mtf_ranks is a chain of dependent LDS read-modify-writes, as long as
+// the symbol's rank and, in a wave, as long as the LARGEST rank among its lanes: 19.5 ms per 256 MiB of random bytes,
+// 3.4 ms for ONE 98 KB block of the reference's sample1 (193 lanes with 512 symbols each, 6.7 us per symbol).  The
+// compares are independent reads that the LDS pipelines: its bandwidth, not its latency, is what they cost.
+// LANES chunks per workgroup, at most 2 * PAIRS symbols; the instance takes the blocks with ALPHA_LO < alpha <= 2 * PAIRS.
+template <u32 PAIRS, u32 LANES, u32 ALPHA_LO>
+__global__ __launch_bounds__(LANES) void k_mtf_ranks_small(MtfArgs a)
 {
-    __shared__ u32 s_last[kMtfSmallPairs * 256];
+    __shared__ u32 s_last[PAIRS * LANES];
     __shared__ u8 s_code[256];
     const u32 lb = blockIdx.y;
     const u32 n = a.blocks[lb].n;
-    const u32 chunk0 = blockIdx.x * 256u;
+    const u32 chunk0 = blockIdx.x * LANES;
     if (chunk0 * kMtfChunk >= n) return;
     const u32 *bits = a.inuse_bits + lb * 8;
     const u32 alpha = popc8(bits);
-    if (alpha > kMtfSmallAlpha) return;
-    {
-        const u32 v = threadIdx.x; // byte value -> code (rank among the bytes in use)
+    if (alpha > 2u * PAIRS || alpha <= ALPHA_LO) return;
+    for (u32 v = threadIdx.x; v < 256u; v += LANES) { // byte value -> code (rank among the bytes in use)
         u32 before = 0;
         for (u32 q = 0; q < (v >> 5); ++q) before += __popc(bits[q]);
         before += __popc(bits[v >> 5] & ((1u << (v & 31u)) - 1u));
@@ -404,16 +410,16 @@ __global__ __launch_bounds__(256) void k_mtf_ranks_small(MtfArgs a)
     const u32 end = (beg + kMtfChunk < n) ? beg + kMtfChunk : n;
     const u32 npairs = (alpha + 1u) >> 1;
     u32 *my = s_last + threadIdx.x;
-    for (u32 q = 0; q < npairs; ++q) my[q * 256u] = 0x80008000u; // both halves: -32768 = never seen
+    for (u32 q = 0; q < npairs; ++q) my[q * LANES] = 0x80008000u; // both halves: -32768 = never seen
     {
         // start list -> times -1, -2, ...
         const u8 *st = a.init_state + ((size_t)lb * kMaxMtfChunks + chunk) * 256u;
         for (u32 q = 0; q < alpha; ++q) {
             const u32 c = s_code[st[q]];
             const u32 t = (u32)(0xFFFFu - q) & 0xFFFFu; // (i16)(-1 - q)
-            u32 wd = my[(c >> 1) * 256u];
+            u32 wd = my[(c >> 1) * LANES];
             wd = (c & 1u) ? ((wd & 0x0000FFFFu) | (t << 16)) : ((wd & 0xFFFF0000u) | t);
-            my[(c >> 1) * 256u] = wd;
+            my[(c >> 1) * LANES] = wd;
         }
     }
     const u8 *L = a.L + (size_t)lb * kSlot;
@@ -442,20 +448,20 @@ __global__ __launch_bounds__(256) void k_mtf_ranks_small(MtfArgs a)
             u32 rank = 0;
             if (p0 + k < end) {
                 const u32 c = s_code[(wv[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
-                const u32 wc = my[(c >> 1) * 256u];
+                const u32 wc = my[(c >> 1) * LANES];
                 const u32 lsu = (c & 1u) ? (wc >> 16) : (wc & 0xFFFFu);
                 // both halves of a table word against the symbol's own time in packed 16-bit arithmetic:
                 // ls - t saturates (a never-seen -32768 must not wrap), its sign says t > ls
                 const short2_t ls2 = as_short2(lsu | (lsu << 16));
                 short2_t acc = {0, 0};
                 for (u32 q = 0; q < npairs; ++q) {
-                    const short2_t wd = as_short2(my[q * 256u]);
+                    const short2_t wd = as_short2(my[q * LANES]);
                     const short2_t neg = __builtin_elementwise_sub_sat(ls2, wd) >> (short2_t){15, 15}; // -1 where t > ls
                     acc -= neg;
                 }
                 rank = (u32)(int)acc.x + (u32)(int)acc.y;
                 const u32 t = (v * 16u + k) & 0xFFFFu; // time inside the chunk, 0..kMtfChunk-1
-                my[(c >> 1) * 256u] = (c & 1u) ? ((wc & 0x0000FFFFu) | (t << 16)) : ((wc & 0xFFFF0000u) | t);
+                my[(c >> 1) * LANES] = (c & 1u) ? ((wc & 0x0000FFFFu) | (t << 16)) : ((wc & 0xFFFF0000u) | t);
             }
             ov[k >> 2] |= rank << ((k & 3) * 8);
         }
@@ -858,8 +864,13 @@ void launch_mtf(hipStream_t st, const MtfArgs &a)
         hipLaunchKernelGGL(k_mtf_group_starts, dim3(a.nb), dim3(64), 0, st, a);
         hipLaunchKernelGGL(k_mtf_chunk_starts, dim3(kMtfGroups, a.nb), dim3(256), 0, st, a);
     }
-    hipLaunchKernelGGL(k_mtf_ranks_small, dim3(kChunkWGs, a.nb), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_mtf_ranks, dim3(kChunkWGs, a.nb), dim3(256), 0, st, a);
+    // ranks: the compare form for every alphabet (<= 96 symbols: 256 chunks per workgroup; more: 128); BZ_MTF_WALK=1 keeps
+    // the list walk for the large ones (rounds 1-3)
+    hipLaunchKernelGGL((k_mtf_ranks_small<kMtfSmallPairs, 256, 0>), dim3(kChunkWGs, a.nb), dim3(256), 0, st, a);
+    if (a.walk_above >= 256u)
+        hipLaunchKernelGGL((k_mtf_ranks_small<128, 128, kMtfSmallAlpha>), dim3((kMaxMtfChunks + 127) / 128, a.nb), dim3(128), 0, st, a);
+    else
+        hipLaunchKernelGGL(k_mtf_ranks, dim3(kChunkWGs, a.nb), dim3(256), 0, st, a);
     if (a.fused_zle) {
         (void)hipMemsetAsync(a.zstate, 0, (size_t)a.nb * kTilesPerBlock * 16, st);
         (void)hipMemsetAsync(a.ztick, 0, 64, st);
