@@ -195,6 +195,71 @@ __device__ int heap_code_lengths(const u32 *rfreq, u32 alpha, u32 *buf, u8 *out)
     return too_long; // 1: the caller must redo the table with gen_code_lm (:190-194)
 }
 
+// The same procedure with the WEIGHT kept beside the node in every heap entry (round 4).  A node's weight is fixed when
+// the node is made and never changes while it is in the heap, so an entry can be the 64-bit word weight << 32 | node: a
+// sift step then compares its two children after ONE LDS round trip (two adjacent 8-byte reads) instead of two (the
+// children's node numbers, then their weights) -- and the procedure is nothing but dependent round trips.  The
+// comparisons are the reference's, on the same values, in the same order (cano_huff_table.rs:14-38, :153-196): `>`
+// between the children, `<` against the sifted entry.  What the reference keeps in the same array besides the heap --
+// the parent of every node, later its depth -- lives in a u16 array (`par`); node weights need no home of their own (an
+// extracted entry carries its).  arena: 3 n words, 8-byte aligned.  Same lengths as heap_code_lengths (the probe
+// kernel runs both on every probed table).
+__device__ __forceinline__ void down_heap_w(u64 *H, u32 nn, u32 len)
+{
+    const u64 tmp = H[nn];
+    const u32 wt = (u32)(tmp >> 32);
+    u32 leaf = (nn << 1) + 1;
+    while (leaf < len) {
+        u64 c = H[leaf];
+        if (leaf + 1 < len) {
+            const u64 c2 = H[leaf + 1];
+            if ((u32)(c >> 32) > (u32)(c2 >> 32)) {
+                leaf += 1;
+                c = c2;
+            }
+        }
+        if (wt < (u32)(c >> 32)) break;
+        H[nn] = c;
+        nn = leaf;
+        leaf = (nn << 1) + 1;
+    }
+    H[nn] = tmp;
+}
+__device__ int heap_code_lengths_w(const u32 *rfreq, u32 alpha, u32 *arena, u8 *out)
+{
+    const u32 n = alpha;
+    if (n == 1) {
+        out[0] = 1;
+        return 0;
+    }
+    u64 *H = reinterpret_cast<u64 *>(arena);          // [n]
+    u16 *par = reinterpret_cast<u16 *>(arena + 2 * n); // [2 n]
+    for (u32 i = 0; i < n; ++i) {
+        const u32 f = rfreq[i];
+        H[i] = ((u64)((f > 1u ? f : 1u) << 8) << 32) | (u64)(n + i); // encoder.rs:642-645
+    }
+    for (u32 i = n >> 1; i-- > 0;) down_heap_w(H, i, n); // create_heap, :33-38
+    for (u32 i = n - 1; i >= 1; --i) { // :168-178
+        const u64 m1 = H[0];
+        H[0] = H[i];
+        down_heap_w(H, 0, i);
+        const u64 m2 = H[0];
+        H[0] = ((u64)weight_add((u32)(m1 >> 32), (u32)(m2 >> 32)) << 32) | (u64)i;
+        par[(u32)m1] = (u16)i;
+        par[(u32)m2] = (u16)i;
+        down_heap_w(H, 0, i);
+    }
+    par[1] = 0; // :181-184
+    for (u32 i = 2; i < n; ++i) par[i] = (u16)(par[par[i]] + 1u);
+    int too_long = 0;
+    for (u32 i = 0; i < n; ++i) { // :186-188
+        const u32 l = (u32)par[par[i + n]] + 1u;
+        out[i] = (u8)l;
+        if (l > kLim) too_long = 1;
+    }
+    return too_long;
+}
+
 // The same procedure by a whole WAVE with the heap in its registers (WaveArr, bzgpu.h): the procedure is a chain of
 // dependent accesses -- one lane per table paid an LDS round trip for each (0.8 ms per pass for a 258-symbol table,
 // 12 ms per 256 MiB of binary data in k_huff_tables).  Statement for statement heap_code_lengths above (the reference's
@@ -869,7 +934,7 @@ constexpr u32 kSweepTilesX = 12;    // workgroups per block (each loops over its
 // dead by then -- the package-merge scratch of as many tables at a time as fit (one of up to 40 symbols: text; larger
 // alphabets use global memory).  With the other arrays 24.6 KB per workgroup: six workgroups share a CU and every
 // block of a 1 GiB batch is resident at once (at 40 KB it took two rounds of 0.6 ms each, four times over).
-constexpr u32 kTabArena = 4200;
+constexpr u32 kTabArena = 6 * (3 * kMaxAlpha + 4); // 4668 words: six tables' heap entries (u64) and parents (u16)
 
 __device__ __forceinline__ u32 huff_group_num(u32 mtf_count) // encoder.rs:370-376
 {
@@ -1076,10 +1141,10 @@ __global__ __launch_bounds__(kTabThreads) void k_huff_tables(HuffArgs a, u32 ite
 {
     __shared__ u8 s_len[6][kMaxAlpha + 6];
     __shared__ u32 s_rfreq[6][kMaxAlpha];
-    __shared__ u32 s_arena[kTabArena];
+    __shared__ __attribute__((aligned(16))) u32 s_arena[kTabArena];
     __shared__ u32 s_need[6];
     __shared__ u32 s_lmcount;
-    static_assert(kTabArena >= 6 * (2 * kMaxAlpha + 4), "the heap work arrays fit the arena");
+    static_assert(kTabArena >= 6 * (3 * kMaxAlpha + 4) && (3 * kMaxAlpha + 4) % 2 == 0, "the heap work arrays fit the arena, 8-byte aligned");
     const u32 lb = blockIdx.x, tid = threadIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const BlockOut &bo = a.out[lb];
     const u32 mtf_count = bo.mtf_count;
@@ -1128,7 +1193,7 @@ __global__ __launch_bounds__(kTabThreads) void k_huff_tables(HuffArgs a, u32 ite
         // the heap procedure: one lane per table, the heap in LDS (-DBZ_HUFF_HEAP_WAVE: wave w builds table w, the heap
         // in its registers)
 #ifndef BZ_HUFF_HEAP_WAVE
-        if (tab_lane) s_need[tb] = (u32)heap_code_lengths(s_rfreq[tb], alpha, s_arena + tb * (2 * kMaxAlpha + 4), s_len[tb]);
+        if (tab_lane) s_need[tb] = (u32)heap_code_lengths_w(s_rfreq[tb], alpha, s_arena + tb * (3 * kMaxAlpha + 4), s_len[tb]);
 #else
         if (wv < group_num) { // (uniform per wave)
             u32 *buf = s_arena + wv * (2 * kMaxAlpha + 4);
@@ -1568,12 +1633,19 @@ void launch_huffman(hipStream_t st, const HuffArgs &a)
 __global__ void k_probe_code_lengths(const u32 *freq, u32 alpha, u8 *out, u32 *lm_scr, int *lm_flag)
 {
     __shared__ u32 s_buf[2 * kMaxAlpha + 4];
+    __shared__ __attribute__((aligned(16))) u32 s_arena_w[3 * kMaxAlpha + 4];
     __shared__ u32 s_f[kMaxAlpha];
     __shared__ u8 s_o[kMaxAlpha + 6], s_o2[kMaxAlpha + 6];
-    __shared__ int s_lm;
+    __shared__ int s_lm, s_bad;
     if (threadIdx.x == 0) {
         for (u32 i = 0; i < alpha; ++i) s_f[i] = freq[i];
         const int lm = heap_code_lengths(s_f, alpha, s_buf, s_o);
+        {   // (the form k_huff_tables uses must give the same lengths and the same verdict)
+            const int lm2 = heap_code_lengths_w(s_f, alpha, s_arena_w, s_o2);
+            s_bad = lm2 != lm ? 1 : 0;
+            for (u32 i = 0; i < alpha; ++i)
+                if (s_o2[i] != s_o[i]) s_bad = 1;
+        }
         if (lm) lm_code_lengths(s_f, alpha, lm_scr, kLmWords, kLmRow, s_o);
         *lm_flag = lm;
         s_lm = lm;
@@ -1588,7 +1660,7 @@ __global__ void k_probe_code_lengths(const u32 *freq, u32 alpha, u8 *out, u32 *l
     }
     __syncthreads();
     if (threadIdx.x == 0)
-        for (u32 i = 0; i < alpha; ++i) out[i] = s_o[i];
+        for (u32 i = 0; i < alpha; ++i) out[i] = s_bad ? (u8)0xFE : s_o[i]; // (0xFE: the two heap forms disagree)
 }
 
 void launch_probe_code_lengths(hipStream_t st, const u32 *d_freq, u32 alpha, u8 *d_out, u32 *lm_scr,
