@@ -1229,10 +1229,26 @@ __global__ __launch_bounds__(kTabThreads) void k_huff_tables(HuffArgs a, u32 ite
                 }
                 __syncthreads();
             } else {
+                // (large alphabets: the scratch of a table does not fit the arena -- it lies in global memory; the WAVE
+                // builds the tables one after the other there too.  Rounds 1-3 gave each table a single lane here:
+                // 12 of the 13 ms the Huffman stage took per 256 MiB of 258-symbol binary data.  BZ_HUFF_LM_LANE at build
+                // time keeps that form.)
+#ifdef BZ_HUFF_LM_LANE
                 if (tab_lane && s_need[tb]) {
                     lm_code_lengths(s_rfreq[tb], alpha, a.lm_scratch + ((size_t)lb * 6 + tb) * kLmWords, kLmWords, kLmRow, s_len[tb]);
                     atomicAdd(&s_lmcount, 1u);
                 }
+#else
+                if (wv == 0) {
+                    for (u32 t = 0; t < group_num; ++t) {
+                        if (s_need[t]) { // uniform
+                            lm_code_lengths_wave(s_rfreq[t], alpha, a.lm_scratch + ((size_t)lb * 6 + t) * kLmWords, kLmWords, kLmRow,
+                                                 s_len[t], lane);
+                            if (lane == 0) s_lmcount += 1;
+                        }
+                    }
+                }
+#endif
                 __syncthreads();
             }
         }
