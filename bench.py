@@ -808,6 +808,10 @@ def extras(result, args, pkg, eng, torch, dev, d_in, n, d_out, out_len, golden, 
     result["extra"]["corpora"] = corpora_leg(pkg, eng, torch, dev, args, d_out, golden, corpus, checks, result["value"])
     dog_beat("corpus matrix")
 
+    # ---- a link of the cut chain between ranks, measured on a GPU that does nothing else
+    result["extra"]["shard_link_replay"] = shard_link_replay_leg(pkg, eng, torch, dev, args, corpus, d_out, checks)
+    dog_beat("shard link replay")
+
 
 _COLD = r"""
 import ctypes, hashlib, importlib, json, sys, time
@@ -923,6 +927,40 @@ def small_inputs_leg(pkg, oracle, args, h_in, checks, device):
                     "gpu_call_us_min": round(ts[0] * 1e6, 1), "oracle_us": round(odt * 1e6, 1),
                     "gpu_over_oracle": round(ts[len(ts) // 2] / odt, 3)})
     checks["small_inputs_equal_oracle"] = bool(same)
+    return out
+
+
+def shard_link_replay_leg(pkg, eng, torch, dev, args, corpus, d_out, checks):
+    """The ranks of a 2-rank and of an 8-rank job (mib_per_gpu each) played one after the other on this GPU by
+    sharded.ReplayComm: every rank sees exactly what the ranks in front of it would have sent, so its cuts, its block
+    records and its timings are the real job's, taken on an idle GPU.  Per rank: ms from the call's entry until it is
+    ready for the cut of the rank in front (scan, counts, offsets, image and cut tables: no rank waits for another
+    there), and the LINK -- from the hop's arrival to the hand-on -- which is all that is serial across the ranks."""
+    sharded = importlib.import_module("rust-compression_amd.sharded")
+    out = {"note": "ranks replayed one at a time on one idle GPU; link = hop in -> hop out (cuts_ms: the table look-ups and their "
+                   "copy back alone); before_the_cut_ms runs on all ranks at once in a real job"}
+    per = args.mib_per_gpu << 20
+    for world in (2, 8):
+        n = world * per
+        hist, ranks, blocks = {}, [], 0
+        for rank in range(world):
+            off, nbytes = pkg.shard_window(args.level, n, rank, world)
+            d_win = corpus.slice_on_device(off, nbytes, dev)
+            cap = d_out.numel() if rank == 0 else 16
+            for _ in range(2):  # (warm, then the one that counts: buffers sized, same hop replayed)
+                comm = sharded.ReplayComm(rank, world, dev, hist)
+                eng.encode_sharded_window(args.level, d_win.data_ptr(), off, nbytes, n, comm, d_out.data_ptr(), cap)
+                assert not comm.errors, comm.errors
+            ph = eng.shard_phases()
+            blocks += len(eng.block_stats())
+            ranks.append({"rank": rank, "link_ms": ph["chain_link_ms"], "cuts_ms": ph["cuts_ms"],
+                          "before_the_cut_ms": ph["before_the_cut_ms"], "call_ms": ph["call_ms"]})
+            del d_win
+        cs = eng.cut_stats()
+        links = [r["link_ms"] for r in ranks[:-1]]
+        out["world_%d" % world] = {"input_gib": n >> 30, "blocks": blocks, "chain_ms_per_link": round(sum(links) / len(links), 3),
+                                   "max_link_ms": max(links), "ranks": ranks}
+        checks["replay_world_%d_cuts_from_tables" % world] = bool(cs["fell_back"] == 0 and cs["from_tables"] > 0)
     return out
 
 

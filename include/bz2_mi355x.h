@@ -250,10 +250,14 @@ int bz_gpu_assemble(bz_gpu_engine *g, int level, size_t n_blocks,
 /* ---- the whole stream over several GPUs (BASELINE.json configs[2]) ----------------
  * One process (one engine) per GPU; every rank calls bz_gpu_encode_sharded with the same level and n.
  * Rank r splits its SLAB of the input -- a contiguous range of the 4 KiB tiles, bz_shard_slab_tiles: nearly equal
- * shares, shrinking a little from rank to rank (BZ_SHARD_SKEW, default 0.02) because rank r starts its blocks r links of
- * the cut chain later than rank 0 -- with the three _slab_ calls above, encodes the blocks that END in its slab
+ * shares, shrinking a little from rank to rank (BZ_SHARD_SKEW) because rank r starts its blocks r links of
+ * the cut chain later than rank 0 --, encodes the blocks that END in its slab
  * (stream order == rank order) and the block bit strings are gathered to rank 0, which assembles the
- * serial stream (bz_gpu_assemble).  d_in is addressed as the whole input, but a rank only reads its
+ * serial stream (bz_gpu_assemble).  The cuts (encoder.rs:692) are the only serial dependency between the slabs, and a
+ * rank prepares its link of that chain before the cut of the rank in front arrives: with the slabs' image sizes
+ * all-gathered every rank knows where its slab lies in the RLE1 image of the whole input, the k-th block of the whole
+ * input can only start at one of 4 k + 1 offsets of that image, and the rank resolves the cut behind every such start
+ * inside its slab in parallel (tables; bz_gpu_cut_stats).  The link itself is then about a hundred table look-ups.  d_in is addressed as the whole input, but a rank only reads its
  * slab and, in front of it, the input bytes of the block that straddles its left edge (a level-9
  * block covers at most 900000 * 255 / 5 = 45.9 MB of input), so the rest need not be backed by memory.
  * The transport is the caller's: RCCL (ncclAllGather / ncclSend / ncclRecv over xGMI), MPI or
@@ -261,7 +265,7 @@ int bz_gpu_assemble(bz_gpu_engine *g, int level, size_t n_blocks,
  * every exchange; a rank-local error is carried in the exchanged status words and returned by ALL
  * ranks (no rank is left waiting in a collective).
  *   allgather(ctx, send, bytes, recv)   HOST memory: `bytes` bytes of every rank, in rank order, into recv
- *   send(ctx, dst, buf, bytes) / recv(ctx, src, buf, bytes)   HOST memory, 16 bytes along the cut chain
+ *   send(ctx, dst, buf, bytes) / recv(ctx, src, buf, bytes)   HOST memory, 32 bytes along the cut chain
  *   gatherv(ctx, d_send, send_bytes, d_recv, recv_off, recv_bytes)   DEVICE memory: rank r's send_bytes
  *       bytes land at d_recv + recv_off[r] on rank 0 (recv_bytes[r] == that rank's send_bytes; the
  *       two arrays are valid on every rank, d_recv only on rank 0; rank 0's own part included).  The transfer
@@ -288,8 +292,8 @@ int bz_gpu_encode_sharded(bz_gpu_engine *g, int level, const void *d_in, size_t 
 /* The same call for a rank that holds only a WINDOW of the input (a rank of a large job need not back the bytes it
  * never reads): d_window[0 .. window_bytes) are the input bytes [window_off, window_off + window_bytes) of the n-byte
  * input (d_window 16-byte aligned, window_off a multiple of 16).  The window must hold the rank's slab, the bytes of
- * the block that straddles its left edge (from the start of their 4 KiB tile on) and 16 bytes behind the slab (or all
- * there are): bz_shard_window returns one that always does -- the slab plus bz_shard_halo_bytes(level) in front (a
+ * the block that straddles its left edge (from the start of their 4 KiB tile on) and the 4 KiB tile behind the slab (or
+ * all there is): bz_shard_window returns one that always does -- the slab plus bz_shard_halo_bytes(level) in front (a
  * level-9 block covers at most 899981 * 255 / 5 = 45.9 MB of input) and one tile behind.  A window that turns out
  * too short (the cut handed over by the rank before lies in front of it) makes every rank return BZ_E_CAPACITY.
  * bz_gpu_encode_sharded(g, level, d_in, n, ...) == bz_gpu_encode_sharded_window(g, level, d_in, 0, n, n, ...). */
@@ -306,6 +310,10 @@ int bz_gpu_encode_sharded_window(bz_gpu_engine *g, int level, const void *d_wind
  * cut -- its LINK of the one serial chain across the ranks (left halo, tile offsets, the cut chain over its slab)
  * [2] the gather of the bit strings  [3] the assembly (rank 0). */
 int bz_gpu_last_shard_timings(bz_gpu_engine *g, double out_ms[4]);
+/* The same four and: [4] entry -> ready for the cut of the rank in front (scan, counts, the slab's image offsets, its
+ * image and the cut tables under way: nothing of it waits for another rank's cuts), [5] the cuts themselves once the
+ * hop is there (table look-ups, or the chain kernel), [6] unused, [7] the whole call. */
+int bz_gpu_last_shard_phases(bz_gpu_engine *g, double out_ms[8]);
 
 /* A ready-made transport: the four callbacks over RCCL (xGMI inside a node).  These three entry points are
  * exported by a SECOND library, libbz2_mi355x_rccl.so (it links librccl; the codec library does not):
@@ -338,6 +346,10 @@ int bz_gpu_last_timings(bz_gpu_engine *g, double out_seconds[6]);
  * this engine since its creation that fell back from the fused radix passes to the three-kernel passes (a
  * look-back gave up or tile tickets were not handed out evenly: the engine then stays on the three-kernel passes) */
 int bz_gpu_last_bwt_stats(bz_gpu_engine *g, uint64_t out[4]);
+/* The block cuts (encoder.rs:692), since the engine's creation: [0] partitions whose cuts came from the tables of
+ * candidate cuts (every cut a block start can lead to, resolved in parallel; BZ_CUT_TABLES=0 turns them off),
+ * [1] partitions that took the chain kernel instead although the tables were asked (never seen). */
+int bz_gpu_cut_stats(bz_gpu_engine *g, uint64_t out[2]);
 /* rotations still unordered after the initial 4-byte sort (out[0]) and after each doubling
  * round (out[1..]), summed over the blocks of the last encode */
 int bz_gpu_last_bwt_rounds(bz_gpu_engine *g, uint64_t out[64]);

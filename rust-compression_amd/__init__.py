@@ -84,8 +84,8 @@ EXPORTS = [
     "bz_gpu_engine_create", "bz_gpu_engine_destroy", "bz_gpu_engine_reserve", "bz_encode_bound", "bz_gpu_encode_device",
     "bz_gpu_partition", "bz_gpu_partition_slab_begin", "bz_gpu_partition_slab_count",
     "bz_gpu_partition_slab_finish", "bz_gpu_block_count", "bz_gpu_encode_blocks", "bz_gpu_assemble", "bz_gpu_encode_sharded",
-    "bz_shard_comm_selftest", "bz_gpu_last_timings", "bz_shard_halo_bytes", "bz_shard_window", "bz_shard_slab_tiles", "bz_gpu_encode_sharded_window", "bz_gpu_last_shard_timings",
-    "bz_gpu_last_bwt_stats", "bz_gpu_last_bwt_rounds", "bz_gpu_profile_enable", "bz_gpu_profile_kernels", "bz_gpu_profile_get",
+    "bz_shard_comm_selftest", "bz_gpu_last_timings", "bz_shard_halo_bytes", "bz_shard_window", "bz_shard_slab_tiles", "bz_gpu_encode_sharded_window", "bz_gpu_last_shard_timings", "bz_gpu_last_shard_phases",
+    "bz_gpu_last_bwt_stats", "bz_gpu_cut_stats", "bz_gpu_last_bwt_rounds", "bz_gpu_profile_enable", "bz_gpu_profile_kernels", "bz_gpu_profile_get",
     "bz_gpu_debug_bwt", "bz_gpu_debug_code_lengths", "bz_gpu_debug_block_stats",
     "bz_gpu_decode_device", "bz_gpu_decode_device_sharded", "bz_gpu_last_decode_timings", "bz_gpu_last_decode_stats", "bz_decode_buffer",
     "bz_dec_create", "bz_dec_write", "bz_dec_end", "bz_dec_read", "bz_dec_pending", "bz_dec_destroy",
@@ -180,10 +180,12 @@ def lib():
     L.bz_shard_slab_tiles.argtypes = [sz, C.c_int, C.c_int, u64p, u64p]
     L.bz_gpu_encode_sharded_window.argtypes = [vp, C.c_int, vp, C.c_uint64, sz, sz, vp, vp, sz, vp, sz, vp, sz, szp]
     L.bz_gpu_last_shard_timings.argtypes = [vp, C.POINTER(C.c_double)]
+    L.bz_gpu_last_shard_phases.argtypes = [vp, C.POINTER(C.c_double)]
     L.bz_shard_comm_selftest.argtypes = [vp, C.c_int]
     L.bz_gpu_last_timings.argtypes = [vp, C.POINTER(C.c_double)]
     L.bz_gpu_last_bwt_stats.argtypes = [vp, u64p]
     L.bz_gpu_last_bwt_rounds.argtypes = [vp, u64p]
+    L.bz_gpu_cut_stats.argtypes = [vp, u64p]
     L.bz_gpu_profile_enable.argtypes = [vp, C.c_int]
     L.bz_gpu_profile_kernels.argtypes = [vp]
     L.bz_gpu_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), u64p, C.POINTER(C.c_double), u64p]
@@ -820,6 +822,14 @@ class GpuEngine:
         _check(lib().bz_gpu_last_shard_timings(self._h, t))
         return dict(zip(("wait_for_cut_ms", "chain_link_ms", "gather_ms", "assemble_ms"), [round(x, 3) for x in t]))
 
+    def shard_phases(self):
+        """shard_timings() and: entry -> ready for the cut (nothing of it waits for another rank's cuts), the cuts alone
+        once the hop is there, the whole call"""
+        t = (C.c_double * 8)()
+        _check(lib().bz_gpu_last_shard_phases(self._h, t))
+        return dict(zip(("wait_for_cut_ms", "chain_link_ms", "gather_ms", "assemble_ms", "before_the_cut_ms", "cuts_ms", "_", "call_ms"),
+                        [round(x, 3) for x in t]))
+
     DEC_STAGES = ("scan_huffman", "mtf", "inverse_bwt", "rle1_crc", "total")
 
     def decode_device(self, d_in, n, d_out, cap):
@@ -914,6 +924,12 @@ class GpuEngine:
             _check(lib().bz_gpu_profile_get(self._h, i, C.byref(name), C.byref(n), C.byref(s), C.byref(b)))
             out[name.value.decode()] = {"launches": n.value, "seconds": s.value, "bytes": b.value}
         return out
+
+    def cut_stats(self):
+        """Partitions of this engine whose block cuts came from the candidate tables / that fell back to the chain kernel."""
+        s = (C.c_uint64 * 2)()
+        _check(lib().bz_gpu_cut_stats(self._h, s))
+        return {"from_tables": int(s[0]), "fell_back": int(s[1])}
 
     def bwt_stats(self):
         s = (C.c_uint64 * 4)()

@@ -291,6 +291,23 @@ struct RleBuffers {
     u64 *scan_part;   // [ntiles / 1024 + 2] workgroup totals of the tile scans
 };
 
+// the cuts from tables (k_rle1.hip, "kernels H"); offsets are those of the image of the WHOLE input
+struct CutPlan {
+    u64 L;          // bytes a block holds before the chunk that closes it (100000 level - 19)
+    u64 g_base;     // image offset of the first byte of tile tb (tile_off is relative to it)
+    u64 own_hi;     // g_base + tile_off[t1]: the targets in (g_base, own_hi] are answered here
+    u64 j_lo, j_hi; // the steps (= blocks of the whole input) with such targets
+    u64 tb, t1;     // the tiles of the range
+    u64 t_last;     // last tile whose bytes may be read (t1: there is a tile behind the range; else t1 - 1)
+};
+struct CutBuffers {
+    u64 *step_t0; // [steps] first tile of a step's targets
+    u32 *step_nt; // [steps] tiles of the step
+    u64 *step_w0; // [steps + 1] exclusive sum of step_nt
+    u32 *tab;     // the steps' tables
+    u16 *comp;    // sixteen steps composed
+};
+
 struct BwtArgs {
     const u8 *rle;
     const BlockDesc *blocks; // descriptors of the batch's blocks
@@ -512,10 +529,18 @@ void launch_rle_scan(hipStream_t st, const u8 *d_in, u64 n, u64 t0, u64 t1, u64 
                      const u32 *xp16, const RleBuffers &rb);
 void launch_rle_count(hipStream_t st, const u8 *d_in, u64 n, u64 t0, u64 t1, u64 in_begin, i64 init_carry,
                       const RleBuffers &rb, i64 *d_out_last);
-void launch_rle_prefix(hipStream_t st, u64 tb, u64 t1, const RleBuffers &rb);
+void launch_rle_prefix(hipStream_t st, u64 tb, u64 t1, const RleBuffers &rb, bool write_end = true);
 void launch_rle_cuts(hipStream_t st, const u8 *d_in, u64 n, u64 tb, u64 t1, u64 in_begin, const RleBuffers &rb,
                      u32 block_max_len, int emit_tail, BlockDesc *d_blocks, u32 max_blocks);
 void launch_rle_image(hipStream_t st, const u8 *d_in, u64 n, u64 tb, u64 t1, u64 in_begin, const RleBuffers &rb, u8 *d_rle);
+u64 cut_table_entries(const CutPlan &pl);
+void cut_groups(const CutPlan &pl, u64 *g_lo, u64 *g_hi, u64 *entries);
+u32 cut_seg_cap();
+void launch_cut_steps(hipStream_t st, const CutPlan &pl, const RleBuffers &rb, const CutBuffers &cb);
+void launch_cut_tables(hipStream_t st, const CutPlan &pl, const u8 *d_in, u64 n_lim, const RleBuffers &rb, const CutBuffers &cb,
+                       u64 work_total);
+void launch_cut_select(hipStream_t st, const CutPlan &pl, u64 j0, u64 s0, u64 start_in, u64 n, long long rle_bias, int emit_tail,
+                       const RleBuffers &rb, const CutBuffers &cb, BlockDesc *d_blocks, u32 max_blocks);
 void launch_block_crc(hipStream_t st, const u8 *d_in, const BlockDesc *d_blocks, u32 nblocks,
                       const u32 *crc_tab, const u32 *xp2, const u32 *tile_crc, u32 *d_crc);
 void launch_block_symbols(hipStream_t st, const BwtArgs &a, u32 *inuse_bits, u8 *sym_code, u8 *keyinfo);

@@ -202,7 +202,8 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
     (void)hipSetDevice(g->device);
     (void)hipStreamSynchronize(g->st);
     (void)hipStreamSynchronize(g->st2);
-    DevBuf *all[] = {&g->crc_tab, &g->xp16, &g->xp2, &g->tile_last, &g->carry_in, &g->tile_crc, &g->tile_count,
+    DevBuf *all[] = {&g->cut_step_t0, &g->cut_step_nt, &g->cut_step_w0, &g->cut_tab, &g->cut_comp,
+                     &g->crc_tab, &g->xp16, &g->xp2, &g->tile_last, &g->carry_in, &g->tile_crc, &g->tile_count,
                      &g->tile_off, &g->sub_off, &g->sub_rs, &g->scal, &g->scan_part, &g->rle, &g->blocks_all, &g->crc_all, &g->lblocks, &g->lcrc, &g->SA,
                      &g->R, &g->KA, &g->VA, &g->KB, &g->VB, &g->tile_hist, &g->count, &g->flags, &g->tlo, &g->tln,
                      &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->lin_p, &g->lin_sig, &g->bin_cursor, &g->pb_gate, &g->newbits, &g->bin_base, &g->sym_code, &g->keyinfo, &g->count2, &g->tile_nf, &g->L, &g->orig_ptr, &g->inuse_bits,
@@ -291,7 +292,10 @@ extern "C" int bz_gpu_partition_slab_count(bz_gpu_engine *g, int64_t carry_run)
     if (g->slab_t1 <= g->slab_t0) return BZ_OK;
     const RleBuffers rb = rle_buffers(g);
     const int sp = span_begin(g, 0);
-    launch_rle_count(g->st, g->d_in, g->n_in, g->slab_t0, g->slab_t1, 0, carry_run, rb, nullptr);
+    // (the run start live at the first byte BEHIND the slab goes to carry_in[slab_t1]: the cut tables look at that tile)
+    const u64 ntiles = (g->n_in + kRleTile - 1) / kRleTile;
+    launch_rle_count(g->st, g->d_in, g->n_in, g->slab_t0, g->slab_t1, 0, carry_run, rb,
+                     g->slab_t1 < ntiles ? rb.carry_in + g->slab_t1 : nullptr);
     span_end(g, sp);
     HIPCHK(hipGetLastError());
     return BZ_OK;
@@ -307,6 +311,86 @@ struct SlabCuts {
     int span = -1;
     bool pending = false, image_done = false;
 };
+static bool cut_tables_enabled()
+{
+    static const bool on = [] {
+        const char *e = getenv("BZ_CUT_TABLES");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+static CutBuffers cut_buffers(bz_gpu_engine *g)
+{
+    CutBuffers cb;
+    cb.step_t0 = g->cut_step_t0.as<u64>();
+    cb.step_nt = g->cut_step_nt.as<u32>();
+    cb.step_w0 = g->cut_step_w0.as<u64>();
+    cb.tab = g->cut_tab.as<u32>();
+    cb.comp = g->cut_comp.as<u16>();
+    return cb;
+}
+// Fills the cut tables for the targets inside the range [tb, t1) whose image is `total` bytes and begins at offset
+// g_base of the whole input's image (tile_off relative to tb must be there).  g->cut_ready says whether they will
+// answer: not when the switch is off or the range is beyond what the tables are sized for (the chain kernel then).
+// One host synchronisation (the number of workgroups of the table kernel).
+static int cut_tables_prepare(bz_gpu_engine *g, u64 g_base, u64 total, u64 tb, u64 t1)
+{
+    g->cut_ready = false;
+    if (!cut_tables_enabled()) return BZ_OK;
+    const u64 ntiles = (g->n_in + kRleTile - 1) / kRleTile;
+    CutPlan pl;
+    pl.L = (u64)g->level * 100000u - 19u; // encoder.rs:186
+    pl.g_base = g_base;
+    pl.own_hi = g_base + total;
+    pl.tb = tb;
+    pl.t1 = t1;
+    pl.t_last = t1 < ntiles ? t1 : (t1 > tb ? t1 - 1 : tb);
+    pl.j_lo = g_base < pl.L ? 0 : (g_base - pl.L) / (pl.L + 4u) + 1u; // smallest j with (j + 1) L + 4 j > g_base
+    const bool none = t1 <= tb || pl.own_hi < pl.L || pl.own_hi / pl.L - 1u < pl.j_lo;
+    if (none) {
+        pl.j_lo = 1;
+        pl.j_hi = 0;
+    } else {
+        pl.j_hi = pl.own_hi / pl.L - 1u; // largest j with (j + 1) L <= own_hi
+    }
+    const u64 nsteps = none ? 0 : pl.j_hi - pl.j_lo + 1u;
+    const u64 entries = cut_table_entries(pl);
+    if (nsteps / 16u + 64u >= cut_seg_cap() || entries > (1ull << 30)) return BZ_OK; // (beyond 58 GB behind one start)
+    u64 g_lo, g_hi, centries;
+    cut_groups(pl, &g_lo, &g_hi, &centries);
+    int rc;
+    if ((rc = g->cut_step_t0.ensure((nsteps + 1) * 8)) || (rc = g->cut_step_nt.ensure((nsteps + 1) * 4)) ||
+        (rc = g->cut_step_w0.ensure((nsteps + 2) * 8)) || (rc = g->cut_tab.ensure((entries + 1) * 4)) ||
+        (rc = g->cut_comp.ensure((centries + 1) * 2)))
+        return rc;
+    g->cut_plan = pl;
+    if (nsteps) {
+        const RleBuffers rb = rle_buffers(g);
+        const CutBuffers cb = cut_buffers(g);
+        launch_cut_steps(g->st, pl, rb, cb);
+        u64 work = 0;
+        HIPCHK(hipMemcpyAsync(&work, cb.step_w0 + nsteps, 8, hipMemcpyDeviceToHost, g->st));
+        HIPCHK(hipStreamSynchronize(g->st));
+        if (work >= (1ull << 31)) return BZ_OK;
+        const u64 n_lim = std::min<u64>(g->n_in, (pl.t_last + 1u) * (u64)kRleTile);
+        launch_cut_tables(g->st, pl, g->d_in, n_lim, rb, cb, work);
+    }
+    g->cut_ready = true;
+    return BZ_OK;
+}
+// The chain from block j0 at image offset s0 / input byte start_in; the image of the range begins at g->rle + rle_at.
+// res: blocks, consumed, tail flag, image offset and number of the block behind the last one cut here.
+static int cut_tables_select(bz_gpu_engine *g, u64 j0, u64 s0, u64 start_in, u64 rle_at, int emit_tail, u32 max_blocks,
+                             u64 res[5])
+{
+    const RleBuffers rb = rle_buffers(g);
+    launch_cut_select(g->st, g->cut_plan, j0, s0, start_in, g->n_in, (long long)rle_at - (long long)g->cut_plan.g_base, emit_tail, rb,
+                      cut_buffers(g), g->blocks_all.as<BlockDesc>(), max_blocks);
+    HIPCHK(hipMemcpyAsync(res, rb.cut_result, 5 * sizeof(u64), hipMemcpyDeviceToHost, g->st));
+    HIPCHK(hipStreamSynchronize(g->st));
+    return BZ_OK;
+}
+
 // image_beside: the image is written on g->st while the cut chain runs on g->st2 (nobody waits for the cut)
 static int slab_cuts(bz_gpu_engine *g, uint64_t start_in, int is_last, bool image_beside, SlabCuts &sc, size_t *n_blocks,
                      uint64_t *next_in, int *tail_block)
@@ -344,17 +428,39 @@ static int slab_cuts(bz_gpu_engine *g, uint64_t start_in, int is_last, bool imag
     // (262 144 workgroups per GiB) goes to g->st2, whose first launch after a pause comes ~100 us later -- the order
     // that lets the chain's workgroup in first (the other way round it took 3.2 ms instead of 1.8 in two runs of
     // three).  g->st waits for the image before it goes on.
-    launch_rle_cuts(g->st, g->d_in, n, tb, t1, start_in, rb, block_max_len, is_last ? 1 : 0,
-                    g->blocks_all.as<BlockDesc>(), (u32)max_blocks);
+    // From the first byte of the input every cut is one of 4 j + 1 known candidates: the tables (k_rle1.hip, "kernels
+    // H") answer them all at once; the chain kernel is what a caller with a start_in of its own gets, and the fallback.
+    const bool tables = start_in == 0 && t0 == 0 && cut_tables_enabled();
     if (image_beside) {
         if (!g->ev_aux) HIPCHK(hipEventCreateWithFlags(&g->ev_aux, hipEventDisableTiming));
-        launch_rle_image(g->st2, g->d_in, n, tb, t1, start_in, rb, g->rle.as<u8>());
-        HIPCHK(hipEventRecord(g->ev_aux, g->st2));
-        sc.image_done = true;
+        if (tables) { // (the table kernels are small launches: the image goes first and they run beside it)
+            launch_rle_image(g->st2, g->d_in, n, tb, t1, start_in, rb, g->rle.as<u8>());
+            HIPCHK(hipEventRecord(g->ev_aux, g->st2));
+            sc.image_done = true;
+        }
     }
-    u64 res[3] = {0, 0, 0};
-    HIPCHK(hipMemcpyAsync(res, rb.cut_result, sizeof(res), hipMemcpyDeviceToHost, g->st));
-    HIPCHK(hipStreamSynchronize(g->st));
+    u64 res[5] = {~0ull, 0, 0, 0, 0};
+    if (tables) {
+        if ((rc = cut_tables_prepare(g, 0, total, tb, t1)) != BZ_OK) return rc;
+        if (g->cut_ready && (rc = cut_tables_select(g, 0, 0, 0, 0, is_last ? 1 : 0, (u32)max_blocks, res)) != BZ_OK) return rc;
+        if (res[0] == ~0ull) {
+            if (g->cut_ready) fprintf(stderr, "bz2_mi355x: the cut tables did not answer a target; the chain kernel takes over\n");
+            ++g->cut_stats[1];
+        } else {
+            ++g->cut_stats[0];
+        }
+    }
+    if (res[0] == ~0ull) {
+        launch_rle_cuts(g->st, g->d_in, n, tb, t1, start_in, rb, block_max_len, is_last ? 1 : 0,
+                        g->blocks_all.as<BlockDesc>(), (u32)max_blocks);
+        if (image_beside && !sc.image_done) {
+            launch_rle_image(g->st2, g->d_in, n, tb, t1, start_in, rb, g->rle.as<u8>());
+            HIPCHK(hipEventRecord(g->ev_aux, g->st2));
+            sc.image_done = true;
+        }
+        HIPCHK(hipMemcpyAsync(res, rb.cut_result, 3 * sizeof(u64), hipMemcpyDeviceToHost, g->st));
+        HIPCHK(hipStreamSynchronize(g->st));
+    }
     if (image_beside) HIPCHK(hipStreamWaitEvent(g->st, g->ev_aux, 0));
     const size_t nb = (size_t)res[0];
     if (nb > max_blocks) return BZ_E_UNEXPECTED;
@@ -387,6 +493,127 @@ static int slab_image(bz_gpu_engine *g, SlabCuts &sc)
     spans_collect(g);
     HIPCHK(hipGetLastError());
     return BZ_OK;
+}
+
+// ---- a rank of a sharded job: what does not depend on the rank in front of it happens before that rank's cut arrives --
+// The slab's image offsets and its image do not depend on where the first block begins (RLE1 is a function of the input
+// alone: the run start live at the slab's first byte came with the all-gather), and with the slab's offset in the image
+// of the WHOLE input (an all-gather of the slabs' totals) neither do the cuts: the tables answer every target inside the
+// slab.  What is left for the link of the serial chain is k_cut_select.  The bytes of the first block that lie in front
+// of the slab (the halo) are coded after the cut has been handed on, into the room in front of the slab's image.
+struct SlabSpec {
+    u64 total = 0;    // bytes of the slab's image
+    u64 g_base = 0;   // its offset in the image of the whole input
+    u64 halo_cap = 0; // room in front of it in g->rle
+    bool image_done = false;
+    u64 h_halo_total = 0, want_halo_total = 0;
+};
+static int slab_spec_total(bz_gpu_engine *g, SlabSpec &sp)
+{
+    sp = SlabSpec();
+    if (g->n_in == 0) return BZ_OK;
+    HIPCHK(hipSetDevice(g->device));
+    const RleBuffers rb = rle_buffers(g);
+    const int span = span_begin(g, 0);
+    launch_rle_prefix(g->st, g->slab_t0, g->slab_t1, rb);
+    HIPCHK(hipMemcpyAsync(&sp.total, rb.total, 8, hipMemcpyDeviceToHost, g->st));
+    span_end(g, span);
+    HIPCHK(hipStreamSynchronize(g->st));
+    return BZ_OK;
+}
+static int slab_spec_tables(bz_gpu_engine *g, SlabSpec &sp, u64 g_base)
+{
+    sp.g_base = g_base;
+    g->cut_ready = false;
+    if (g->n_in == 0) return BZ_OK;
+    const u64 L = (u64)g->level * 100000u - 19u;
+    sp.halo_cap = g_base ? (L + 8u + 255u) / 256u * 256u : 0u;
+    const size_t max_blocks = (size_t)((sp.total + L + 4u) / L + 2u);
+    int rc;
+    if ((rc = g->rle.ensure(sp.halo_cap + sp.total + 256)) || (rc = g->blocks_all.ensure(max_blocks * sizeof(BlockDesc))) ||
+        (rc = g->crc_all.ensure(max_blocks * 4)))
+        return rc;
+    const RleBuffers rb = rle_buffers(g);
+    const int span = span_begin(g, 0);
+    if (!g->ev_aux) HIPCHK(hipEventCreateWithFlags(&g->ev_aux, hipEventDisableTiming));
+    launch_rle_image(g->st2, g->d_in, g->n_in, g->slab_t0, g->slab_t1, 0, rb, g->rle.as<u8>() + sp.halo_cap);
+    HIPCHK(hipEventRecord(g->ev_aux, g->st2));
+    sp.image_done = true;
+    rc = cut_tables_prepare(g, g_base, sp.total, g->slab_t0, g->slab_t1);
+    span_end(g, span);
+    return rc;
+}
+// start_in / s0 / j0: first input byte, image offset and number (in the whole input) of this rank's first block
+static int slab_spec_select(bz_gpu_engine *g, SlabSpec &sp, u64 start_in, u64 s0, u64 j0, int is_last, SlabCuts &sc,
+                            size_t *n_blocks, u64 *next_in, u64 *s_next, u64 *j_next)
+{
+    sc = SlabCuts();
+    *n_blocks = 0;
+    *next_in = start_in;
+    *s_next = s0;
+    *j_next = j0;
+    if (g->n_in == 0) return BZ_OK;
+    const u64 t0 = g->slab_t0;
+    if (start_in > t0 * (u64)kRleTile || s0 > sp.g_base) return BZ_E_PARAM;
+    const u64 L = (u64)g->level * 100000u - 19u;
+    const u64 D = sp.g_base - s0; // bytes of the first block's image in front of the slab
+    if (D > sp.halo_cap) return BZ_E_UNEXPECTED;
+    const size_t max_blocks = (size_t)((sp.total + L + 4u) / L + 2u);
+    u64 res[5] = {~0ull, 0, 0, 0, 0};
+    int rc;
+    if (g->cut_ready) {
+        if ((rc = cut_tables_select(g, j0, s0, start_in, sp.halo_cap, is_last, (u32)max_blocks, res)) != BZ_OK) return rc;
+        if (res[0] == ~0ull) fprintf(stderr, "bz2_mi355x: the cut tables did not answer a target; the chain kernel takes over\n");
+    }
+    if (res[0] == ~0ull) {
+        // the chain kernel: offsets relative to the first block's first tile, the image written again from there
+        if (cut_tables_enabled()) ++g->cut_stats[1];
+        HIPCHK(hipStreamWaitEvent(g->st, g->ev_aux, 0));
+        sp.image_done = false;
+        int tail = 0;
+        if ((rc = slab_cuts(g, start_in, is_last, false, sc, n_blocks, next_in, &tail)) != BZ_OK) return rc;
+        std::vector<BlockDesc> hb(*n_blocks);
+        if (*n_blocks) HIPCHK(hipMemcpy(hb.data(), g->blocks_all.p, *n_blocks * sizeof(BlockDesc), hipMemcpyDeviceToHost));
+        const size_t closed = *n_blocks - (tail ? 1 : 0);
+        for (size_t k = 0; k < closed; ++k) *s_next += hb[k].n;
+        *j_next = j0 + closed;
+        return BZ_OK;
+    }
+    ++g->cut_stats[0];
+    if (res[0] > max_blocks) return BZ_E_UNEXPECTED;
+    sc.tb = std::min<u64>(start_in / kRleTile, t0);
+    sc.start_in = start_in;
+    sc.nb = (size_t)res[0];
+    sc.pending = true;
+    sc.image_done = true;
+    sc.span = -1;
+    *n_blocks = sc.nb;
+    *next_in = sc.nb || is_last ? res[1] : start_in;
+    *s_next = res[3];
+    *j_next = res[4];
+    sp.want_halo_total = D;
+    return BZ_OK;
+}
+// the halo's image, then block CRCs and the host copies of the records (slab_image)
+static int slab_spec_finish(bz_gpu_engine *g, SlabSpec &sp, SlabCuts &sc)
+{
+    if (!sc.pending) return BZ_OK;
+    if (!sp.image_done) return slab_image(g, sc); // (the chain kernel's layout)
+    const RleBuffers rb = rle_buffers(g);
+    const u64 t0 = g->slab_t0;
+    sc.span = span_begin(g, 0);
+    sp.h_halo_total = sp.want_halo_total;
+    if (sc.tb < t0) {
+        // left halo: the tail of the previous slab(s) that belongs to this rank's first block, coded afresh from the
+        // cut (RLE1 restarted at a cut is RLE1 continued); it ends where the slab's image begins
+        launch_rle_scan(g->st, g->d_in, g->n_in, sc.tb, t0, sc.start_in, g->crc_tab.as<u32>(), g->xp16.as<u32>(), rb);
+        launch_rle_count(g->st, g->d_in, g->n_in, sc.tb, t0, sc.start_in, -1, rb, nullptr);
+        launch_rle_prefix(g->st, sc.tb, t0, rb, false);
+        HIPCHK(hipMemcpyAsync(&sp.h_halo_total, rb.total, 8, hipMemcpyDeviceToHost, g->st)); // (checked by the caller once the stream has been waited for)
+        launch_rle_image(g->st, g->d_in, g->n_in, sc.tb, t0, sc.start_in, rb, g->rle.as<u8>() + sp.halo_cap - sp.want_halo_total);
+    }
+    HIPCHK(hipStreamWaitEvent(g->st, g->ev_aux, 0)); // the slab's image (st2)
+    return slab_image(g, sc);
 }
 
 extern "C" int bz_gpu_partition_slab_finish(bz_gpu_engine *g, uint64_t start_in, int is_last, size_t *n_blocks,
@@ -1025,7 +1252,7 @@ extern "C" int bz_shard_window(int level, size_t n, int rank, int world, uint64_
 }
 
 // win_lo / win_hi: the input bytes that really lie behind d_in (the whole input: 0, n).
-static int encode_sharded_impl(bz_gpu_engine *g, int level, const void *d_in, size_t n, u64 win_lo, u64 win_hi,
+static int encode_sharded_impl2(bz_gpu_engine *g, int level, const void *d_in, size_t n, u64 win_lo, u64 win_hi,
                                const bz_shard_comm *comm, void *d_packed, size_t packed_cap_words,
                                void *d_gather, size_t gather_cap_words, void *d_out, size_t cap,
                                size_t *out_len)
@@ -1035,14 +1262,19 @@ static int encode_sharded_impl(bz_gpu_engine *g, int level, const void *d_in, si
     if (out_len) *out_len = 0;
     const int rank = comm->rank, world = comm->world;
     if (world > 1 && (!comm->allgather || !comm->send || !comm->recv || !comm->gatherv)) return BZ_E_PARAM;
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+    const clk::time_point t_entry = clk::now();
+    for (double &t : g->shard_ms) t = 0;
     const u64 ntiles = (n + kRleTile - 1) / kRleTile;
     const u64 t0 = shard_tile_begin(ntiles, rank, world), t1 = std::max(t0, shard_tile_begin(ntiles, rank + 1, world));
     int rc = BZ_OK; // this rank's status; collectives go on regardless
     {
         // the window must hold the slab, a tile in front of it (the split looks at the byte before a slab) and the
-        // byte behind it; how far the first block reaches back is only known when the cut arrives (checked there)
+        // tile behind it (a chunk that begins in the slab ends there); how far the first block reaches back is only
+        // known when the cut arrives (checked there)
         const u64 begin = t0 * kRleTile, end = std::min<u64>((u64)n, t1 * kRleTile);
-        const u64 need_lo = begin >= kRleTile ? begin - kRleTile : 0, need_hi = std::min<u64>((u64)n, end + 16);
+        const u64 need_lo = begin >= kRleTile ? begin - kRleTile : 0, need_hi = std::min<u64>((u64)n, end + kRleTile);
         if (t1 > t0 && (win_lo > need_lo || win_hi < need_hi)) rc = BZ_E_PARAM;
     }
 
@@ -1059,12 +1291,24 @@ static int encode_sharded_impl(bz_gpu_engine *g, int level, const void *d_in, si
     for (int r = 0; r < rank; ++r) carry = std::max(carry, lasts[(size_t)r]);
     if (rc == BZ_OK) rc = bz_gpu_partition_slab_count(g, carry);
 
-    // 2. the cut chain
-    using clk = std::chrono::steady_clock;
-    auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
-    for (double &t : g->shard_ms) t = 0;
+    // 2. where the slab's image lies in the image of the whole input; then its own image and the tables of its cuts
+    SlabSpec sp;
+    std::vector<uint64_t> totals((size_t)world, 0);
+    if (world > 1) {
+        if (rc == BZ_OK) rc = slab_spec_total(g, sp);
+        uint64_t mine_total = rc == BZ_OK ? sp.total : 0;
+        if (comm->allgather(comm->ctx, &mine_total, 8, totals.data()) != 0) return BZ_E_UNEXPECTED;
+        u64 g_base = 0;
+        for (int r = 0; r < rank; ++r) g_base += totals[(size_t)r];
+        if (rc == BZ_OK) rc = slab_spec_tables(g, sp, g_base);
+    }
+
+    // 3. the cut chain
+    g->shard_ms[4] = ms_since(t_entry);
     const clk::time_point t_wait = clk::now();
-    uint64_t hop[2] = {0, 0}; // {first input byte of the receiver's first block, sender's status}
+    // {first input byte of the receiver's first block, sender's status, the block's offset in the image of the whole
+    // input, its number}
+    uint64_t hop[4] = {0, 0, 0, 0};
     if (rank > 0 && comm->recv(comm->ctx, rank - 1, hop, sizeof(hop)) != 0) return BZ_E_UNEXPECTED;
     g->shard_ms[0] = ms_since(t_wait);
     const clk::time_point t_link = clk::now(); // this rank's link of the serial chain: from the hop's arrival to the hand-on
@@ -1080,13 +1324,19 @@ static int encode_sharded_impl(bz_gpu_engine *g, int level, const void *d_in, si
     // (the cut goes to the next rank before this rank writes its image: the chain over the ranks is serial, and
     // only the cuts are part of it)
     SlabCuts sc;
-    if (rc == BZ_OK) rc = slab_cuts(g, hop[0], rank == world - 1, world == 1, sc, &nb, &next, nullptr);
+    uint64_t s_next = hop[2], j_next = hop[3];
+    if (rc == BZ_OK) {
+        const clk::time_point t_sel = clk::now();
+        if (world == 1) rc = slab_cuts(g, hop[0], 1, true, sc, &nb, &next, nullptr);
+        else rc = slab_spec_select(g, sp, hop[0], hop[2], hop[3], rank == world - 1, sc, &nb, &next, &s_next, &j_next);
+        g->shard_ms[5] = ms_since(t_sel);
+    }
     if (rank < world - 1) {
-        uint64_t out_hop[2] = {next, (uint64_t)(rc == BZ_OK ? 0 : -rc)};
+        uint64_t out_hop[4] = {next, (uint64_t)(rc == BZ_OK ? 0 : -rc), s_next, j_next};
         if (comm->send(comm->ctx, rank + 1, out_hop, sizeof(out_hop)) != 0) return BZ_E_UNEXPECTED;
     }
     g->shard_ms[1] = ms_since(t_link);
-    if (rc == BZ_OK) rc = slab_image(g, sc);
+    if (rc == BZ_OK) rc = world == 1 ? slab_image(g, sc) : slab_spec_finish(g, sp, sc);
     else if (sc.span >= 0) { span_end(g, sc.span); spans_collect(g); }
 
     // this rank's blocks (the sort starts as soon as its own cuts are known)
@@ -1101,6 +1351,14 @@ static int encode_sharded_impl(bz_gpu_engine *g, int level, const void *d_in, si
         }
         if (rc == BZ_OK)
             rc = bz_gpu_encode_blocks(g, 0, 1, d_packed, packed_cap_words, woff.data(), blen.data(), crc.data(), &used);
+    }
+    if (rc == BZ_OK && sp.h_halo_total != sp.want_halo_total) {
+        if (hipStreamSynchronize(g->st) != hipSuccess || sp.h_halo_total != sp.want_halo_total) {
+            fprintf(stderr, "bz2_mi355x: rank %d: the image of its first block's bytes in front of the slab has %llu bytes, the "
+                            "offsets of the whole input's image say %llu\n", rank, (unsigned long long)sp.h_halo_total,
+                    (unsigned long long)sp.want_halo_total);
+            rc = BZ_E_UNEXPECTED;
+        }
     }
     if (world == 1) {
         if (rc != BZ_OK) return rc;
@@ -1179,10 +1437,28 @@ static int encode_sharded_impl(bz_gpu_engine *g, int level, const void *d_in, si
     return arc;
 }
 
+static int encode_sharded_impl(bz_gpu_engine *g, int level, const void *d_in, size_t n, u64 win_lo, u64 win_hi,
+                               const bz_shard_comm *comm, void *d_packed, size_t packed_cap_words,
+                               void *d_gather, size_t gather_cap_words, void *d_out, size_t cap,
+                               size_t *out_len)
+{
+    const std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    const int rc = encode_sharded_impl2(g, level, d_in, n, win_lo, win_hi, comm, d_packed, packed_cap_words, d_gather,
+                                        gather_cap_words, d_out, cap, out_len);
+    if (g) g->shard_ms[7] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+    return rc;
+}
+
 extern "C" int bz_gpu_last_shard_timings(bz_gpu_engine *g, double out_ms[4])
 {
     if (!g || !out_ms) return BZ_E_PARAM;
     for (int i = 0; i < 4; ++i) out_ms[i] = g->shard_ms[i];
+    return BZ_OK;
+}
+extern "C" int bz_gpu_last_shard_phases(bz_gpu_engine *g, double out_ms[8])
+{
+    if (!g || !out_ms) return BZ_E_PARAM;
+    for (int i = 0; i < 8; ++i) out_ms[i] = g->shard_ms[i];
     return BZ_OK;
 }
 
@@ -1286,6 +1562,14 @@ extern "C" int bz_gpu_last_bwt_stats(bz_gpu_engine *g, uint64_t out[4])
     if (!g) return BZ_E_PARAM;
     for (int i = 0; i < 3; ++i) out[i] = g->bwt_stats[i];
     out[3] = g->fused_state[1]; // sorts of this engine (since its creation) that fell back to the three-kernel passes
+    return BZ_OK;
+}
+
+extern "C" int bz_gpu_cut_stats(bz_gpu_engine *g, uint64_t out[2])
+{
+    if (!g || !out) return BZ_E_PARAM;
+    out[0] = g->cut_stats[0];
+    out[1] = g->cut_stats[1];
     return BZ_OK;
 }
 

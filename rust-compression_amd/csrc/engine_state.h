@@ -64,6 +64,11 @@ struct bz_gpu_engine {
     DevBuf crc_tab, xp16, xp2;
     // partition state (sized by the input)
     DevBuf tile_last, carry_in, tile_crc, tile_count, tile_off, sub_off, sub_rs, scal, scan_part, rle, blocks_all, crc_all;
+    // the cuts from tables (k_rle1.hip "kernels H")
+    DevBuf cut_step_t0, cut_step_nt, cut_step_w0, cut_tab, cut_comp;
+    CutPlan cut_plan = {};
+    bool cut_ready = false;       // the tables of the current range are filled (or being filled on st)
+    u64 cut_stats[2] = {0, 0};    // since creation: partitions cut from tables, partitions that fell back to the chain kernel
     std::vector<BlockDesc> h_blocks;
     std::vector<u32> h_crc;
     const u8 *d_in = nullptr;
@@ -88,7 +93,10 @@ struct bz_gpu_engine {
     std::vector<u32> h_out_nblock;
     double t_stage[6] = {0, 0, 0, 0, 0, 0};
     KernelProf prof;
-    double shard_ms[4] = {0, 0, 0, 0}; // last bz_gpu_encode_sharded: wait for the hop, hop -> hand-on, gather, assembly
+    // last bz_gpu_encode_sharded: wait for the hop, hop -> hand-on, gather, assembly; entry -> ready for the hop (scan,
+    // counts, the slab's image offsets, its image and the cut tables under way), the chain kernel or table look-ups alone,
+    // the whole call
+    double shard_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     u64 bwt_stats[4] = {0, 0, 0, 0};
     u64 round_active[64] = {};
 

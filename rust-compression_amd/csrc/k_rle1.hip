@@ -654,6 +654,248 @@ __global__ __launch_bounds__(CT) void k_rle_cuts(const u8 *__restrict__ in, u64 
     }
 }
 
+// ---- kernels H: the cuts from tables (no chain of launches-worth of latency, and nothing to wait for) ------
+// Block j of the whole input starts at image offset S_j, and S_j lies in [j L, j (L + 4)] (a block holds L ... L + 4
+// bytes), so the step S_j -> S_{j+1} -- "the end of the first chunk that ends at or behind the TARGET S_j + L" -- has
+// only 4 j + 1 possible arguments.  All of them are resolved in parallel, position by position: a chunk that ends at
+// image offset c_e and holds `em` bytes answers every target in (c_e - em, c_e].  A table entry is
+//     (c_e - target)  [3 bits: 0 .. 4]   |   (input position behind the chunk - first byte of the step's first tile) << 3
+// and the real chain is then one look-up per block -- or one per SIXTEEN blocks through the composed table
+// (`k_cut_compose`).  Offsets are those of the image of the WHOLE input (g_base = offset of the range's first byte:
+// a rank of a sharded job knows it from an all-gather of the slabs' totals) and so is j: a rank fills the tables for
+// the targets inside its slab, (g_base, own_hi], BEFORE the cut of the rank in front of it arrives, and what is left
+// of its link of the chain is `k_cut_select`: about a hundred dependent loads.  0xFFFFFFFF = a target of another rank.
+__host__ __device__ __forceinline__ u64 cut_tbase(u64 j_lo, u64 j) // entries of the steps j_lo ... j - 1
+{
+    return 2u * (j * (j - 1u) - j_lo * (j_lo - 1u)) + (j - j_lo);
+}
+__host__ __device__ __forceinline__ u64 cut_cbase(u64 g_lo, u64 g) // composed entries of the groups g_lo ... g - 1
+{
+    return 32u * (g * (g - 1u) - g_lo * (g_lo - 1u)) + (g - g_lo);
+}
+
+// largest t in [lo, hi] with off[t] < v (off[lo] < v is given)
+__device__ __forceinline__ u64 cut_last_below(const u64 *__restrict__ off, u64 lo, u64 hi, u64 v)
+{
+    while (lo < hi) {
+        const u64 mid = (lo + hi + 1) >> 1;
+        if (off[mid] < v) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// one thread per step: the tiles that hold the chunk ends of its targets
+__global__ __launch_bounds__(256) void k_cut_steps(CutPlan pl, const u64 *__restrict__ tile_off, u64 *__restrict__ step_t0,
+                                                    u32 *__restrict__ step_nt)
+{
+    const u64 gid = (u64)blockIdx.x * 256u + threadIdx.x;
+    const u64 j = pl.j_lo + gid;
+    if (j > pl.j_hi) return;
+    const u64 lb = (j + 1u) * pl.L;
+    const u64 w_lo = lb > pl.g_base + 1u ? lb : pl.g_base + 1u;
+    const u64 w_hi = lb + 4u * j < pl.own_hi ? lb + 4u * j : pl.own_hi;
+    u64 ta = pl.tb;
+    u32 nt = 0;
+    if (w_lo <= w_hi) {
+        ta = cut_last_below(tile_off, pl.tb, pl.t1, w_lo - pl.g_base);
+        u64 te = cut_last_below(tile_off, ta, pl.t1, w_hi - pl.g_base) + 1u; // (a chunk may end in the tile behind)
+        if (te > pl.t_last) te = pl.t_last;
+        if (ta > pl.t_last) ta = pl.t_last;
+        nt = (u32)(te - ta + 1u);
+    }
+    step_t0[gid] = ta;
+    step_nt[gid] = nt;
+}
+
+// exclusive sum of step_nt -> step_w0[0 .. nsteps], one workgroup
+__global__ __launch_bounds__(1024) void k_cut_steps_scan(const u32 *__restrict__ step_nt, u64 nsteps, u64 *__restrict__ step_w0)
+{
+    __shared__ u64 sh[16];
+    u64 run = 0;
+    for (u64 b0 = 0; b0 < nsteps; b0 += 1024u) {
+        const u64 b = b0 + threadIdx.x;
+        const u64 v = b < nsteps ? (u64)step_nt[b] : 0u;
+        u64 total;
+        const u64 ex = wg_excl<false>(v, sh, total);
+        if (b < nsteps) step_w0[b] = run + ex;
+        run += total;
+    }
+    if (threadIdx.x == 0) step_w0[nsteps] = run;
+}
+
+// one workgroup per (step, tile): the RLE1 evaluation of k_rle_count, and every chunk end answers its targets
+__global__ __launch_bounds__(RT) void k_cut_table(CutPlan pl, const u8 *__restrict__ in, u64 n_lim,
+                                                   const i64 *__restrict__ carry_in, const u64 *__restrict__ tile_off,
+                                                   const u64 *__restrict__ step_t0, const u64 *__restrict__ step_w0,
+                                                   u64 nsteps, u32 *__restrict__ tab)
+{
+    __shared__ i64 s_m[RT / 64 + 1];
+    __shared__ u32 s_s[RT / 64];
+    // the step this workgroup belongs to: last gid with step_w0[gid] <= blockIdx.x
+    u64 lo = 0, hi = nsteps - 1u;
+    while (lo < hi) {
+        const u64 mid = (lo + hi + 1) >> 1;
+        if (step_w0[mid] <= (u64)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const u64 gid = lo, j = pl.j_lo + gid;
+    const u64 t_first = step_t0[gid];
+    const u64 tile = t_first + ((u64)blockIdx.x - step_w0[gid]);
+    const u64 lb = (j + 1u) * pl.L;
+    const u64 w_lo = lb > pl.g_base + 1u ? lb : pl.g_base + 1u;
+    const u64 w_hi = lb + 4u * j < pl.own_hi ? lb + 4u * j : pl.own_hi;
+    const u64 in_ref = t_first * (u64)kRleTile;
+    u32 *__restrict__ row = tab + cut_tbase(pl.j_lo, j);
+
+    Seg s;
+    load_seg(in, n_lim, tile, s, 0);
+    const i64 rs = seg_run_start(s, carry_in[tile], s_m);
+    u8 e[16], cph[16];
+    const u32 cnt = eval_seg(s, rs, e, cph);
+    u32 tot;
+    const u32 ex = block_excl_sum(cnt, s_s, tot);
+    u64 cum = pl.g_base + tile_off[tile] + ex;
+    if (cum + cnt < w_lo || cum > w_hi + 4u) return; // none of this segment's chunk ends answers a target of the step
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k) {
+        if (k < s.valid && k >= s.skip) {
+            cum += e[k];
+            const int nbyte = (k + 1 < s.valid) ? (int)s.b[k + 1 < 16 ? k + 1 : 15] : s.next;
+            if (nbyte != (int)s.b[k] || cph[k] == 254u) {
+                const u32 c = cph[k];
+                const u64 em = c < 3u ? c + 1u : 5u;
+                const u64 t_lo = cum - em + 1u > w_lo ? cum - em + 1u : w_lo;
+                const u64 t_hi = cum < w_hi ? cum : w_hi;
+                const u32 rel = (u32)(s.p0 + k + 1u - in_ref) << 3;
+                for (u64 T = t_lo; T <= t_hi; ++T) row[T - lb] = (u32)(cum - T) | rel;
+            }
+        }
+    }
+}
+
+// sixteen steps in one: comp[g][i] = how far a block start with index i at step 16 g has drifted sixteen steps on
+// (0xFFFF: one of them leaves this rank's targets)
+__global__ __launch_bounds__(256) void k_cut_compose(CutPlan pl, u64 g_lo, const u32 *__restrict__ tab, u16 *__restrict__ comp)
+{
+    const u64 g = g_lo + blockIdx.y;
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    const u64 j0 = g * 16u;
+    if (i > 4u * j0) return;
+    u64 idx = i;
+    bool ok = true;
+    for (u32 q = 0; q < 16u; ++q) {
+        const u32 en = tab[cut_tbase(pl.j_lo, j0 + q) + idx];
+        if (en == 0xFFFFFFFFu) {
+            ok = false;
+            break;
+        }
+        idx += en & 7u;
+    }
+    comp[cut_cbase(g_lo, g) + i] = ok ? (u16)(idx - i) : (u16)0xFFFFu;
+}
+
+// The chain itself: from block j0 with image offset s0 (its first input byte: start_in).  Thread 0 follows the
+// composed tables and notes where every stretch begins; the threads then walk the stretches and write the records.
+// res[0] blocks (~0: the tables did not answer an owned target -- never seen; the caller falls back to k_rle_cuts),
+// res[1] input bytes consumed, res[2] tail flag, res[3] image offset and res[4] number of the next rank's first block.
+constexpr u32 kCutSegCap = 4096;
+__global__ __launch_bounds__(256) void k_cut_select(CutPlan pl, u64 j0, u64 s0, u64 start_in, u64 g_lo, u64 g_hi, u64 n,
+                                                    long long rle_bias, int emit_tail, const u32 *__restrict__ tab,
+                                                    const u16 *__restrict__ comp, const u64 *__restrict__ step_t0,
+                                                    BlockDesc *__restrict__ blocks, u32 max_blocks, u64 *__restrict__ res)
+{
+    __shared__ u32 sg_j[kCutSegCap]; // relative to j0
+    __shared__ u32 sg_idx[kCutSegCap];
+    __shared__ u8 sg_n[kCutSegCap];
+    __shared__ u64 s_stop[3]; // j, idx at the stop; 1 if the tables failed
+    __shared__ u32 s_nseg;
+    if (threadIdx.x == 0) {
+        u64 j = j0, idx = s0 - j0 * pl.L;
+        u32 ns = 0;
+        u64 bad = (s0 < j0 * pl.L || idx > 4u * j0) ? 1u : 0u;
+        while (!bad) {
+            if ((j + 1u) * pl.L + idx > pl.own_hi) break; // the target lies behind this rank's image
+            if (j > pl.j_hi || j < pl.j_lo || ns >= kCutSegCap) {
+                bad = 1;
+                break;
+            }
+            if ((j & 15u) == 0 && g_hi >= g_lo && (j >> 4) >= g_lo && (j >> 4) <= g_hi) {
+                const u16 c = comp[cut_cbase(g_lo, j >> 4) + idx];
+                if (c != 0xFFFFu) {
+                    sg_j[ns] = (u32)(j - j0);
+                    sg_idx[ns] = (u32)idx;
+                    sg_n[ns] = 16;
+                    ++ns;
+                    idx += c;
+                    j += 16u;
+                    continue;
+                }
+            }
+            const u32 en = tab[cut_tbase(pl.j_lo, j) + idx];
+            if (en == 0xFFFFFFFFu) {
+                bad = 1; // an owned target without an answer
+                break;
+            }
+            sg_j[ns] = (u32)(j - j0);
+            sg_idx[ns] = (u32)idx;
+            sg_n[ns] = 1;
+            ++ns;
+            idx += en & 7u;
+            j += 1u;
+        }
+        s_stop[0] = j;
+        s_stop[1] = idx;
+        s_stop[2] = bad;
+        s_nseg = ns;
+    }
+    __syncthreads();
+    const u64 j_stop = s_stop[0], s_end = j_stop * pl.L + s_stop[1];
+    const u32 ns = s_nseg;
+    const u64 nb = j_stop - j0;
+    const bool tail = emit_tail && !s_stop[2] && pl.own_hi > s_end;
+    if (s_stop[2]) {
+        if (threadIdx.x == 0) {
+            res[0] = ~0ull;
+            res[1] = start_in;
+            res[2] = 0;
+            res[3] = s0;
+            res[4] = j0;
+        }
+        return;
+    }
+    for (u32 q = threadIdx.x; q < ns; q += 256u) {
+        u64 j = j0 + sg_j[q], idx = sg_idx[q];
+        for (u32 w = 0; w < sg_n[q]; ++w, ++j) {
+            const u32 en = tab[cut_tbase(pl.j_lo, j) + idx];
+            const u64 cut_in = step_t0[j - pl.j_lo] * (u64)kRleTile + (u64)(en >> 3);
+            const u64 k = j - j0;
+            if (k < max_blocks) {
+                blocks[k].rle_off = (u64)((long long)(j * pl.L + idx) + rle_bias);
+                blocks[k].in_end = cut_in;
+                blocks[k].n = (u32)(pl.L + (en & 7u));
+                blocks[k].pad = 0;
+                if (k == 0) blocks[k].in_off = start_in;
+            }
+            if (k + 1u < max_blocks) blocks[k + 1u].in_off = cut_in;
+            if (j + 1u == j_stop) res[1] = tail ? n : cut_in;
+            idx += en & 7u;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (nb == 0) res[1] = tail ? n : start_in;
+        if (tail && nb < max_blocks) {
+            blocks[nb].rle_off = (u64)((long long)s_end + rle_bias);
+            if (nb == 0) blocks[nb].in_off = start_in;
+            blocks[nb].in_end = n;
+            blocks[nb].n = (u32)(pl.own_hi - s_end);
+            blocks[nb].pad = 0;
+        }
+        res[0] = nb + (tail ? 1u : 0u);
+        res[2] = tail ? 1u : 0u;
+        res[3] = s_end;
+        res[4] = j_stop;
+    }
+}
+
 // ---- kernel G: block CRC from tile CRCs -------------------------------------------
 __global__ __launch_bounds__(RT) void k_block_crc(const u8 *__restrict__ in,
                                                    const BlockDesc *__restrict__ blocks,
@@ -759,15 +1001,16 @@ void launch_rle_count(hipStream_t st, const u8 *d_in, u64 n, u64 t0, u64 t1, u64
                        rb.tile_count, rb.sub_off, rb.sub_rs);
 }
 
-void launch_rle_prefix(hipStream_t st, u64 tb, u64 t1, const RleBuffers &rb)
+void launch_rle_prefix(hipStream_t st, u64 tb, u64 t1, const RleBuffers &rb, bool write_end)
 {
-    // tile_off[tb] = 0 ... tile_off[t1] = total (offsets are relative to the range)
+    // tile_off[tb] = 0 ... tile_off[t1] = total (offsets are relative to the range); write_end = false leaves
+    // tile_off[t1] alone (it is the first offset of a range that has its own)
     if (t1 <= tb) {
         (void)hipMemsetAsync(rb.total, 0, 8, st);
-        (void)hipMemsetAsync(rb.tile_off + tb, 0, 8, st);
+        if (write_end) (void)hipMemsetAsync(rb.tile_off + tb, 0, 8, st);
         return;
     }
-    tiles_scan<false>(st, rb.tile_count, rb.tile_off, tb, t1, rb.scan_part, 0ull, rb.total, rb.tile_off + t1);
+    tiles_scan<false>(st, rb.tile_count, rb.tile_off, tb, t1, rb.scan_part, 0ull, rb.total, write_end ? rb.tile_off + t1 : nullptr);
 }
 
 // The chain of cuts is one workgroup that reads the input and the tile tables, not the image: the two are
@@ -788,6 +1031,53 @@ void launch_rle_image(hipStream_t st, const u8 *d_in, u64 n, u64 tb, u64 t1, u64
     if (t1 <= tb) return;
     hipLaunchKernelGGL(k_rle_scatter, dim3((u32)(t1 - tb)), dim3(RT), 0, st, d_in, n, tb, in_begin, rb.carry_in,
                        rb.tile_off, d_rle);
+}
+
+// The cuts from tables, in three steps (see "kernels H"): the steps' tiles (the caller reads step_w0[nsteps], the number
+// of workgroups of the table kernel), the tables, the chain.
+u64 cut_table_entries(const CutPlan &pl) { return pl.j_hi >= pl.j_lo ? cut_tbase(pl.j_lo, pl.j_hi + 1u) : 0u; }
+void cut_groups(const CutPlan &pl, u64 *g_lo, u64 *g_hi, u64 *entries)
+{
+    // groups of sixteen steps that lie inside [j_lo, j_hi]; *g_hi < *g_lo: none
+    *g_lo = (pl.j_lo + 15u) / 16u;
+    *g_hi = *g_lo;
+    *entries = 0;
+    if (pl.j_hi < pl.j_lo || pl.j_hi + 1u < (*g_lo + 1u) * 16u) {
+        *g_lo = 1;
+        *g_hi = 0;
+        return;
+    }
+    *g_hi = (pl.j_hi + 1u) / 16u - 1u;
+    *entries = cut_cbase(*g_lo, *g_hi + 1u);
+}
+u32 cut_seg_cap() { return kCutSegCap; }
+void launch_cut_steps(hipStream_t st, const CutPlan &pl, const RleBuffers &rb, const CutBuffers &cb)
+{
+    const u64 nsteps = pl.j_hi - pl.j_lo + 1u;
+    hipLaunchKernelGGL(k_cut_steps, dim3((u32)((nsteps + 255u) / 256u)), dim3(256), 0, st, pl, rb.tile_off, cb.step_t0, cb.step_nt);
+    hipLaunchKernelGGL(k_cut_steps_scan, dim3(1), dim3(1024), 0, st, cb.step_nt, nsteps, cb.step_w0);
+}
+void launch_cut_tables(hipStream_t st, const CutPlan &pl, const u8 *d_in, u64 n_lim, const RleBuffers &rb, const CutBuffers &cb,
+                       u64 work_total)
+{
+    const u64 nsteps = pl.j_hi - pl.j_lo + 1u;
+    (void)hipMemsetAsync(cb.tab, 0xFF, cut_table_entries(pl) * 4u, st);
+    if (work_total)
+        hipLaunchKernelGGL(k_cut_table, dim3((u32)work_total), dim3(RT), 0, st, pl, d_in, n_lim, rb.carry_in, rb.tile_off, cb.step_t0,
+                           cb.step_w0, nsteps, cb.tab);
+    u64 g_lo, g_hi, ce;
+    cut_groups(pl, &g_lo, &g_hi, &ce);
+    if (g_hi >= g_lo)
+        hipLaunchKernelGGL(k_cut_compose, dim3((u32)((4u * 16u * g_hi + 256u) / 256u), (u32)(g_hi - g_lo + 1u)), dim3(256), 0, st, pl,
+                           g_lo, cb.tab, cb.comp);
+}
+void launch_cut_select(hipStream_t st, const CutPlan &pl, u64 j0, u64 s0, u64 start_in, u64 n, long long rle_bias, int emit_tail,
+                       const RleBuffers &rb, const CutBuffers &cb, BlockDesc *d_blocks, u32 max_blocks)
+{
+    u64 g_lo, g_hi, ce;
+    cut_groups(pl, &g_lo, &g_hi, &ce);
+    hipLaunchKernelGGL(k_cut_select, dim3(1), dim3(256), 0, st, pl, j0, s0, start_in, g_lo, g_hi, n, rle_bias, emit_tail, cb.tab,
+                       cb.comp, cb.step_t0, d_blocks, max_blocks, rb.cut_result);
 }
 
 void launch_block_crc(hipStream_t st, const u8 *d_in, const BlockDesc *d_blocks, u32 nblocks,

@@ -170,6 +170,51 @@ class TorchComm:
         return self._guard(run)
 
 
+class ReplayComm(TorchComm):
+    """One rank of a `world`-rank job played BY ITSELF, the ranks one after the other in one process (rank 0 first):
+    what the ranks in front contributed to the exchanges is replayed from `history` (a dict shared by the ranks of
+    one replay), the ranks behind contribute zeros.  The cuts, the block records and the timings of a rank are those of
+    the real job -- they depend on the ranks in front only --, measured on a GPU that does nothing else (ranks that
+    share one GPU as processes wait for each other's kernels, which says nothing about a link of the chain); the
+    STREAM rank 0 assembles is not the job's (it holds rank 0's blocks only).  bench.py's `shard_link_replay`."""
+
+    def __init__(self, rank, world, device, history):
+        self.rank, self.world, self.group = rank, world, None
+        self.device, self.wire = device, torch.device("cpu")
+        self._tensors, self.errors, self.history, self._n_ag = {}, [], history, 0
+        self._cbs = (ALLGATHER_FN(self._allgather), SEND_FN(self._send), RECV_FN(self._recv), GATHERV_FN(self._gatherv))
+        self.struct = ShardComm(None, rank, world, *self._cbs)
+
+    def _allgather(self, _ctx, send, nbytes, recv):
+        def run():
+            k, self._n_ag = self._n_ag, self._n_ag + 1
+            mine = bytes(self._host_bytes(send, nbytes).numpy())
+            seen = self.history.setdefault(("allgather", k), {})
+            seen[self.rank] = mine
+            out = b"".join(seen.get(r, bytes(nbytes)) for r in range(self.world))
+            (C.c_uint8 * len(out)).from_address(recv)[:] = out
+        return self._guard(run)
+
+    def _send(self, _ctx, dst, buf, nbytes):
+        def run():
+            self.history[("hop", dst)] = bytes(self._host_bytes(buf, nbytes).numpy())
+        return self._guard(run)
+
+    def _recv(self, _ctx, src, buf, nbytes):
+        def run():
+            data = self.history[("hop", self.rank)]
+            assert len(data) == nbytes
+            (C.c_uint8 * nbytes).from_address(buf)[:] = data
+        return self._guard(run)
+
+    def _gatherv(self, _ctx, d_send, send_bytes, d_recv, recv_off, recv_bytes):
+        def run():
+            if self.rank == 0 and send_bytes:
+                self._buffer(d_recv, int(recv_off[0]) + send_bytes)[int(recv_off[0]):].copy_(self._buffer(d_send, send_bytes))
+            torch.cuda.synchronize(self.device)
+        return self._guard(run)
+
+
 def allgather_bytes(rank, world, dev):
     """The one collective of the sharded decode (bz_gpu_decode_device_sharded): returns a function
     send: bytes -> concatenation of every rank's bytes in rank order, over torch.distributed (RCCL

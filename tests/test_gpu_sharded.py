@@ -37,13 +37,18 @@ def _input(kind):
         return _text(300_000, 7) + runs + _text(260_000, 8) + b"z" * 70_000 + _text(100_001, 9), 1
     if kind == "text9":
         return _text(5_000_000, 3), 9
+    if kind == "runs":  # long runs: a level-1 block covers megabytes of input, more than some slabs hold
+        rng = random.Random(5)
+        runs = b"".join(bytes([rng.randrange(2)]) * rng.choice([1, 2, 3, 4, 5, 254, 255, 256, 700, 3000]) for _ in range(9000))
+        return runs + _text(150_000, 4) + runs[:1_000_000], 1
     if kind == "tiny":
         return b"abc" * 1000, 9      # fewer blocks than ranks: some ranks own none
     raise KeyError(kind)
 
 
-def _worker(rank, world, port, kind, q):
+def _worker(rank, world, port, kind, tables, q):
     sys.path.insert(0, ROOT)
+    os.environ["BZ_CUT_TABLES"] = "1" if tables else "0"  # (read by the library once, at its first partition)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -76,20 +81,23 @@ def _worker(rank, world, port, kind, q):
         if rank == 0:
             ks = eng.encode_device(level, d_in.data_ptr(), n, d_out.data_ptr(), cap)
             single = bytes(d_out[:ks].cpu().numpy())
-        q.put((rank, out1, out2, single, list(comm.errors)))
+        q.put((rank, out1, out2, single, list(comm.errors), eng.cut_stats()))
         eng.close()
     finally:
         dist.barrier()
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,kind", [(2, "mixed"), (3, "mixed"), (2, "text9"), (4, "tiny")])
-def test_sharded_encode_in_real_processes(oracle, world, kind):
+@pytest.mark.parametrize("world,kind,tables", [(2, "mixed", 1), (3, "mixed", 1), (2, "text9", 1), (4, "tiny", 1), (3, "runs", 1),
+                                               (4, "runs", 1), (3, "mixed", 0), (3, "runs", 0)])
+def test_sharded_encode_in_real_processes(oracle, world, kind, tables):
+    """tables = 1: every rank's cuts come from its tables of candidate cuts, filled before the cut of the rank in front
+    arrives (k_rle1.hip "kernels H"); 0: from the chain kernel, started when it arrives (BZ_CUT_TABLES=0)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, tables, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=600) for _ in range(world))
@@ -102,6 +110,9 @@ def test_sharded_encode_in_real_processes(oracle, world, kind):
     assert got[0][1] == want and got[0][2] == want and got[0][3] == want
     for r in range(1, world):
         assert got[r][1] == b"" and got[r][2] == b""
+    for r in range(world):
+        st = got[r][5]
+        assert st["fell_back"] == 0 and (st["from_tables"] >= 2 if tables else st["from_tables"] == 0), (r, st)
 
 
 def test_rccl_transport_library_single_rank(pkg, oracle):
