@@ -366,8 +366,10 @@ def main():
                                      "last_rank_waited_ms": shard_all[-1][0], "gather_ms_rank0": shard_all[0][2],
                                      "assemble_ms_rank0": shard_all[0][3],
                                      "note": "a link = from the arrival of the cut handed over by the rank before to the hand-on of "
-                                             "this rank's own (left halo, tile offsets, the cut chain over its slab); the links "
-                                             "are the one serial thing across the ranks"}
+                                             "this rank's own: the look-ups in the tables of candidate cuts the rank filled while it "
+                                             "waited (BZ_CUT_TABLES=0: left halo, tile offsets and the chain kernel); the links are the one "
+                                             "serial thing across the ranks.  Ranks that SHARE a GPU wait for each other's kernels "
+                                             "here: extra.shard_link_replay of the one-GPU line has the link on an idle GPU"}
         if not args.no_cpu_baseline:
             # cpu_baseline leg: the oracle (a C restatement of the reference algorithm, 1 thread like the
             # reference) on a bounded sample of the same corpus; its output doubles as a parity check.

@@ -1202,7 +1202,7 @@ static double shard_skew()
 {
     static const double v = [] {
         const char *e = getenv("BZ_SHARD_SKEW");
-        double s = e ? atof(e) : 0.02;
+        double s = e ? atof(e) : 0.004; // (a link is 0.1-0.3 ms of look-ups + the transport's hop against ~85 ms per GiB slab)
         if (!(s >= 0.0)) s = 0.0;
         if (s > 0.2) s = 0.2;
         return s;
