@@ -751,42 +751,84 @@ __global__ __launch_bounds__(64) void k_dec_walk_meta(DecArgs a)
 // Walk 1: every segment (sample node -> next sample node) is walked once.  The bytes it passes are
 // kept in the segment's scratch row (dword stores, kSegCap bytes); its length and successor go to
 // the sample arrays.  The node reached after kSegCap steps is remembered for the few long segments.
+// the cache policy of the chase's load (experiments: -DBZ_DEC_WALK_LOAD=1 nt, 2 sc1, 3 sc0 sc1, 4 nt sc0 sc1, 5 sc0)
+#ifndef BZ_DEC_WALK_LOAD
+#define BZ_DEC_WALK_LOAD 0
+#endif
+__device__ __forceinline__ u32 walk_load(const u32 *p)
+{
+#if BZ_DEC_WALK_LOAD == 0
+    return *p;
+#else
+    u32 r;
+#if BZ_DEC_WALK_LOAD == 1
+    asm volatile("global_load_dword %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+#elif BZ_DEC_WALK_LOAD == 2
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+#elif BZ_DEC_WALK_LOAD == 3
+    asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+#elif BZ_DEC_WALK_LOAD == 4
+    asm volatile("global_load_dword %0, %1, off sc0 sc1 nt\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+#else
+    asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+#endif
+    return r;
+#endif
+}
+
+#ifndef BZ_DEC_WALK_GROUP
+#define BZ_DEC_WALK_GROUP 1
+#endif
+constexpr u32 kWalkGroup = BZ_DEC_WALK_GROUP;                          // consecutive sample nodes a lane takes at a time
+constexpr u32 kWalkItems = (kDecSamples + kWalkGroup - 1u) / kWalkGroup; // items per block
 __global__ __launch_bounds__(256) void k_dec_walk_lengths(DecArgs a)
 {
     // blocks are dealt to the XCDs (workgroup i runs on XCD i % 8): a block's T vector is walked by
     // one XCD only and stays in that XCD's 4 MiB L2
     // (reading XCC_ID instead gives the same assignment and the same time: checked in round 2)
     const u32 xcd = blockIdx.x & 7u;
-    const u32 total = ((a.nb + 7u - xcd) / 8u) * kDecSamples;
+    const u32 total = ((a.nb + 7u - xcd) / 8u) * kWalkItems;
     u32 *ctr = a.work_ctr + xcd * 16u;
     bool have = false;
     u32 cur = 0, len = 0, n = 0, p0 = 0, slot = 0, acc = 0;
+    u32 sid = 0, sid_end = 0, lb = 0; // the lane's item: sample nodes [sid, sid_end) of block lb
     const u32 *T = nullptr;
     u8 *row = nullptr;
     bool dry = false;
+    // the next sample node of the lane's item that starts a segment
+    auto next_segment = [&]() {
+        while (sid < sid_end) {
+            const u32 node = (sid == kDecSamples - 1u) ? p0 : sid * kDecSampleStep;
+            // (p0's segment belongs to the start sample)
+            if (sid == kDecSamples - 1u || (node < n && node != p0)) {
+                slot = lb * kDecSamples + sid;
+                cur = node;
+                len = 0;
+                acc = 0;
+                row = a.seg_buf + (size_t)slot * kSegCap;
+                have = true;
+                ++sid;
+                return;
+            }
+            ++sid;
+        }
+    };
     while (true) {
         const u64 idle = __ballot(!have);
         if ((!dry && (u32)__popcll(idle) >= kWalkRefill) || idle == ~0ull) {
             u32 id, first_id;
             const bool got = take_item(ctr, total, !have, id, first_id);
             if (got) {
-                const u32 q = id / kDecSamples, sid = id - q * kDecSamples;
-                const u32 lb = q * 8u + xcd;
-                slot = lb * kDecSamples + sid;
+                const u32 q = id / kWalkItems, grp = id - q * kWalkItems;
+                lb = q * 8u + xcd;
                 const uint4 m = a.walk_meta[lb];
                 if (m.x) {
                     n = m.x;
                     T = a.T + (size_t)lb * kSlot;
                     p0 = m.y;
-                    const u32 node = (sid == kDecSamples - 1u) ? p0 : sid * kDecSampleStep;
-                    // (p0's segment belongs to the start sample)
-                    if (sid == kDecSamples - 1u || (node < n && node != p0)) {
-                        cur = node;
-                        len = 0;
-                        acc = 0;
-                        row = a.seg_buf + (size_t)slot * kSegCap;
-                        have = true;
-                    }
+                    sid = grp * kWalkGroup;
+                    sid_end = sid + kWalkGroup < kDecSamples ? sid + kWalkGroup : kDecSamples;
+                    next_segment();
                 }
             }
             if (first_id + (u32)__popcll(idle) >= total) dry = true; // the last items are handed out
@@ -798,7 +840,7 @@ __global__ __launch_bounds__(256) void k_dec_walk_lengths(DecArgs a)
 #pragma unroll 1
         for (u32 s = 0; s < kWalkBurst; ++s) {
             if (have) {
-                const u32 v = T[cur]; // tt[pos]: the byte in the low 8 bits, the next position above (decoder.rs:533-536)
+                const u32 v = walk_load(T + cur); // tt[pos]: the byte in the low 8 bits, the next position above (decoder.rs:533-536)
                 cur = v >> 8;
                 if (len < kSegCap) {
                     acc |= (v & 0xFFu) << (8u * (len & 3u));
@@ -818,6 +860,7 @@ __global__ __launch_bounds__(256) void k_dec_walk_lengths(DecArgs a)
                     a.samp_next[slot] = nid;
                     a.samp_len[slot] = len;
                     have = false;
+                    next_segment(); // (the other sample nodes of the lane's item: no trip to the counter)
                 }
             }
         }
