@@ -175,8 +175,10 @@ class ReplayComm(TorchComm):
     what the ranks in front contributed to the exchanges is replayed from `history` (a dict shared by the ranks of
     one replay), the ranks behind contribute zeros.  The cuts, the block records and the timings of a rank are those of
     the real job -- they depend on the ranks in front only --, measured on a GPU that does nothing else (ranks that
-    share one GPU as processes wait for each other's kernels, which says nothing about a link of the chain); the
-    STREAM rank 0 assembles is not the job's (it holds rank 0's blocks only).  bench.py's `shard_link_replay`."""
+    share one GPU as processes wait for each other's kernels, which says nothing about a link of the chain).  The
+    stream rank 0 assembles in that pass holds rank 0's blocks only; the ranks' bit strings are kept, though, and rank
+    0 played a SECOND time with the same history sees everything every rank contributed and assembles the job's
+    stream (`replay_job`).  bench.py's `shard_link_replay`, tools/fuzz_sharded.py."""
 
     def __init__(self, rank, world, device, history):
         self.rank, self.world, self.group = rank, world, None
@@ -191,7 +193,9 @@ class ReplayComm(TorchComm):
             mine = bytes(self._host_bytes(send, nbytes).numpy())
             seen = self.history.setdefault(("allgather", k), {})
             seen[self.rank] = mine
-            out = b"".join(seen.get(r, bytes(nbytes)) for r in range(self.world))
+            # (the per-block records are padded to the largest block count a rank KNOWS of, which grows from rank to
+            # rank in a replay: a recorded piece is cut or zero-padded to this call's size -- the padding is zeros anyway)
+            out = b"".join(seen.get(r, b"")[:nbytes].ljust(nbytes, b"\0") for r in range(self.world))
             (C.c_uint8 * len(out)).from_address(recv)[:] = out
         return self._guard(run)
 
@@ -209,10 +213,43 @@ class ReplayComm(TorchComm):
 
     def _gatherv(self, _ctx, d_send, send_bytes, d_recv, recv_off, recv_bytes):
         def run():
-            if self.rank == 0 and send_bytes:
-                self._buffer(d_recv, int(recv_off[0]) + send_bytes)[int(recv_off[0]):].copy_(self._buffer(d_send, send_bytes))
+            torch.cuda.synchronize(self.device)
+            mine = self._buffer(d_send, send_bytes)
+            if self.rank != 0:
+                self.history[("packed", self.rank)] = mine.clone()
+                return
+            for r in range(self.world):
+                part = mine if r == 0 else self.history.get(("packed", r))
+                k = int(recv_bytes[r])
+                if part is None or k == 0:
+                    continue  # (first pass: the ranks behind have not run yet and announced nothing)
+                assert part.numel() == k, (r, part.numel(), k)
+                self._buffer(d_recv, int(recv_off[r]) + k)[int(recv_off[r]):].copy_(part)
             torch.cuda.synchronize(self.device)
         return self._guard(run)
+
+
+def replay_job(eng, level, data_dev, n, world, d_out, cap, windows=True):
+    """A `world`-rank bz_gpu_encode_sharded job on ONE engine and one GPU, rank by rank (ReplayComm), then rank 0 again
+    with everything the ranks contributed: returns the length of the job's stream in d_out (a uint8 tensor of `cap`
+    bytes) and the per-rank shard phases.  data_dev: the n input bytes on the device (16-byte aligned).  windows: each rank
+    gets only its window of the input (bz_shard_window), copied to a buffer of its own."""
+    import importlib
+    pkg = importlib.import_module("rust-compression_amd")
+    hist, phases = {}, []
+    k = 0
+    for rank in list(range(world)) + [0]:
+        comm = ReplayComm(rank, world, data_dev.device, hist)
+        if windows:
+            off, nbytes = pkg.shard_window(level, n, rank, world)
+            win = torch.empty(nbytes + 16, dtype=torch.uint8, device=data_dev.device)[:nbytes]
+            win.copy_(data_dev[off:off + nbytes])
+            k = eng.encode_sharded_window(level, win.data_ptr(), off, nbytes, n, comm, d_out.data_ptr(), cap if rank == 0 else 16)
+        else:
+            k = eng.encode_sharded(level, data_dev.data_ptr(), n, comm, d_out.data_ptr(), cap if rank == 0 else 16)
+        assert not comm.errors, comm.errors
+        phases.append(eng.shard_phases())
+    return k, phases
 
 
 def allgather_bytes(rank, world, dev):

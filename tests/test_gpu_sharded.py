@@ -115,6 +115,16 @@ def test_sharded_encode_in_real_processes(oracle, world, kind, tables):
         assert st["fell_back"] == 0 and (st["from_tables"] >= 2 if tables else st["from_tables"] == 0), (r, st)
 
 
+def test_replayed_jobs_fuzz():
+    """tools/fuzz_sharded.py for 25 s: 2-8 rank jobs played rank by rank on the one GPU (sharded.replay_job), windows and
+    whole inputs, long runs, slabs smaller than a block; every stream == the oracle's, every cut from the tables."""
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_sharded.py"), "25", "5"], capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "fuzz_sharded ok" in p.stdout
+
+
 def test_rccl_transport_library_single_rank(pkg, oracle):
     """libbz2_mi355x_rccl.so (the callbacks over RCCL, implemented in C): a one-rank communicator on the test
     box's one GPU goes through the library's transport self-test (all-gather, the variable-length gather of
