@@ -870,11 +870,11 @@ __global__ __launch_bounds__(256) void k_dec_walk_lengths(DecArgs a)
 // order of the samples along the chain: one wave per block, the chain itself in LDS
 __global__ __launch_bounds__(64) void k_dec_rank_samples(DecArgs a)
 {
-    // 16-bit copies of the segment lengths (the rare longer one is fetched from memory): 29 KB of LDS
-    // per block instead of 43, so that all blocks of a 1 GiB file are resident at once
-    __shared__ u16 s_len[kDecSamples];
-    __shared__ u16 s_next[kDecSamples];
-    __shared__ u32 s_seen[(kDecSamples + 31) / 32];
+    // one word per sample: the segment's length (16 bits; the rare longer one is fetched from memory) and its
+    // successor, so that a hop of the serial chain is ONE dependent LDS read (rounds 1-3: three -- length, successor
+    // and a "seen" bit; 2.0 ms per GiB for 7000 hops per block).  28 KB of LDS per block: all blocks of a 1 GiB file
+    // are resident at once.
+    __shared__ u32 s_hop[kDecSamples];
     const u32 lb = blockIdx.x, l = threadIdx.x;
     if (a.err[lb]) return;
     const u32 n = a.tt_len[lb];
@@ -883,26 +883,27 @@ __global__ __launch_bounds__(64) void k_dec_rank_samples(DecArgs a)
         const bool live = (i == kDecSamples - 1u) || (i * kDecSampleStep < n);
         const u32 nx = live ? a.samp_next[base + i] : 0xFFFFFFFFu;
         const u32 ln = live ? a.samp_len[base + i] : 0u;
-        s_next[i] = nx < kDecSamples ? (u16)nx : (u16)0xFFFFu;
-        s_len[i] = ln < 0xFFFFu ? (u16)ln : (u16)0xFFFFu;
+        s_hop[i] = (nx < kDecSamples ? nx : 0xFFFFu) << 16 | (ln < 0xFFFFu ? ln : 0xFFFFu);
         a.samp_off[base + i] = 0xFFFFFFFFu;
     }
-    for (u32 i = l; i < (kDecSamples + 31) / 32; i += 64) s_seen[i] = 0;
     __threadfence();
     __syncthreads();
     if (l == 0) {
-        u32 s = kDecSamples - 1u, o = 0, cyc = n;
+        // T is a permutation: the first sample the chain comes back to is the one it started from (a periodic block's
+        // chain closes before n steps, decoder.rs:527-542 reads on around it)
+        const u32 start = kDecSamples - 1u;
+        u32 s = start, o = 0, cyc = n;
         while (o < n) {
-            if ((s_seen[s >> 5] >> (s & 31u)) & 1u) { // back at a visited sample: the chain closes before n steps
-                cyc = o;
+            a.samp_off[base + s] = o;
+            const u32 w = s_hop[s];
+            const u32 ln = w & 0xFFFFu;
+            o += (ln == 0xFFFFu) ? a.samp_len[base + s] : ln;
+            s = w >> 16;
+            if (s == 0xFFFFu) break;
+            if (s == start) {
+                if (o < n) cyc = o;
                 break;
             }
-            s_seen[s >> 5] |= 1u << (s & 31u);
-            a.samp_off[base + s] = o;
-            const u32 ln = s_len[s];
-            o += (ln == 0xFFFFu) ? a.samp_len[base + s] : ln;
-            s = s_next[s];
-            if (s >= kDecSamples) break;
         }
         a.cycle_len[lb] = cyc;
     }
