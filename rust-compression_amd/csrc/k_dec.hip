@@ -871,9 +871,11 @@ __global__ __launch_bounds__(256) void k_dec_walk_lengths(DecArgs a)
 __global__ __launch_bounds__(64) void k_dec_rank_samples(DecArgs a)
 {
     // one word per sample: the segment's length (16 bits; the rare longer one is fetched from memory) and its
-    // successor, so that a hop of the serial chain is ONE dependent LDS read (rounds 1-3: three -- length, successor
-    // and a "seen" bit; 2.0 ms per GiB for 7000 hops per block).  28 KB of LDS per block: all blocks of a 1 GiB file
-    // are resident at once.
+    // successor (15 bits), so that a hop of the serial chain is ONE dependent LDS read (rounds 1-3: three -- length,
+    // successor and a "seen" bit -- and a global store; 2.0 ms per GiB for 7000 hops per block); the offsets replace the
+    // words as the chain passes and leave together at the end.  28 KB of LDS per block: all blocks of a 1 GiB file are
+    // resident at once.
+    static_assert(kDecSamples < 0x7FFFu, "a sample's successor must fit 15 bits");
     __shared__ u32 s_hop[kDecSamples];
     const u32 lb = blockIdx.x, l = threadIdx.x;
     if (a.err[lb]) return;
@@ -883,10 +885,8 @@ __global__ __launch_bounds__(64) void k_dec_rank_samples(DecArgs a)
         const bool live = (i == kDecSamples - 1u) || (i * kDecSampleStep < n);
         const u32 nx = live ? a.samp_next[base + i] : 0xFFFFFFFFu;
         const u32 ln = live ? a.samp_len[base + i] : 0u;
-        s_hop[i] = (nx < kDecSamples ? nx : 0xFFFFu) << 16 | (ln < 0xFFFFu ? ln : 0xFFFFu);
-        a.samp_off[base + i] = 0xFFFFFFFFu;
+        s_hop[i] = (nx < kDecSamples ? nx : 0x7FFFu) << 16 | (ln < 0xFFFFu ? ln : 0xFFFFu);
     }
-    __threadfence();
     __syncthreads();
     if (l == 0) {
         // T is a permutation: the first sample the chain comes back to is the one it started from (a periodic block's
@@ -894,18 +894,23 @@ __global__ __launch_bounds__(64) void k_dec_rank_samples(DecArgs a)
         const u32 start = kDecSamples - 1u;
         u32 s = start, o = 0, cyc = n;
         while (o < n) {
-            a.samp_off[base + s] = o;
             const u32 w = s_hop[s];
+            s_hop[s] = 0x80000000u | o; // (a sample is visited once: its word now holds its offset, bit 31 = visited)
             const u32 ln = w & 0xFFFFu;
             o += (ln == 0xFFFFu) ? a.samp_len[base + s] : ln;
             s = w >> 16;
-            if (s == 0xFFFFu) break;
+            if (s == 0x7FFFu) break;
             if (s == start) {
                 if (o < n) cyc = o;
                 break;
             }
         }
         a.cycle_len[lb] = cyc;
+    }
+    __syncthreads();
+    for (u32 i = l; i < kDecSamples; i += 64) {
+        const u32 w = s_hop[i];
+        a.samp_off[base + i] = (w & 0x80000000u) ? (w & 0x7FFFFFFFu) : 0xFFFFFFFFu;
     }
 }
 
