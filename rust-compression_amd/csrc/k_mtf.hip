@@ -22,6 +22,9 @@
 namespace bzgpu {
 
 constexpr u32 kChunkWGs = (kMaxMtfChunks + 255) / 256;
+#ifndef BZ_MTF_HEADS
+#define BZ_MTF_HEADS 0 // 1: k_mtf_ranks_small ranks the heads of runs only (measured slower: profiles/r04_negatives.md)
+#endif
 constexpr u32 kMtfSmallAlpha = 96;                     // blocks with at most this many symbols use k_mtf_ranks_small // 14 workgroups of 256 chunks
 
 __device__ __forceinline__ u32 popc8(const u32 *b)
@@ -424,6 +427,82 @@ __global__ __launch_bounds__(LANES) void k_mtf_ranks_small(MtfArgs a)
     }
     const u8 *L = a.L + (size_t)lb * kSlot;
     u8 *R8 = a.rank8 + (size_t)lb * kSlot;
+#if BZ_MTF_HEADS
+    // (-DBZ_MTF_HEADS=1, measured slower -- MTF + ZLE stage 9.0 ms per GiB against 7.0: the walk over the head bits is a
+    // serial loop with a three-deep chain of dependent LDS reads per head, the form below is unrolled over register bytes)
+    // A lane's chunk is 512 consecutive bytes, read 64 bytes at a time (four 16-byte loads issued together).  Only
+    // the HEAD of a run of equal bytes costs a rank: the bytes behind it are at the front of the list (rank 0), and
+    // moving a symbol's time forward inside its own run changes no later rank (nothing else is seen in between).
+    // In the last column of text more than half of the bytes continue a run, but a wave pays for a step if ONE of its
+    // lanes needs it: so a lane gathers the head bits of its 64 bytes first and walks those -- the wave takes the
+    // LONGEST of 64 walks (about 40 of 64 steps on text) instead of all 64.  The bytes and their ranks pass through a
+    // 64-byte row per lane in LDS, indexed by the head's position.
+    __shared__ uint4 s_io[4][LANES];
+    u32 prevb = 0x100u; // no byte in front of the chunk's first: it is a head
+    for (u32 v4 = 0; v4 < kMtfChunk / 64u; ++v4) {
+        if (beg + v4 * 64u >= end) break;
+        uint4 q4[4];
+#pragma unroll
+        for (u32 u = 0; u < 4; ++u) {
+            const u32 pl = beg + v4 * 64u + u * 16u;
+            q4[u] = (pl < end) ? *reinterpret_cast<const uint4 *>(L + pl) : make_uint4(0, 0, 0, 0); // (slots are padded)
+        }
+        u64 heads = 0;
+#pragma unroll
+        for (u32 u = 0; u < 4; ++u) {
+            s_io[u][threadIdx.x] = q4[u];
+            const u32 wv[4] = {q4[u].x, q4[u].y, q4[u].z, q4[u].w};
+#pragma unroll
+            for (u32 w = 0; w < 4; ++w) {
+                // bytes that differ from the byte in front of them: x = word ^ (word shifted up by a byte, the last byte
+                // of the word before it shifted in); a byte of x is non-zero <=> head
+                const u32 x = wv[w] ^ ((wv[w] << 8) | (prevb & 0xFFu));
+                u32 y = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+                if (prevb > 0xFFu) y |= 0x80u;
+                prevb = wv[w] >> 24;
+                heads |= (u64)((((y >> 7) * 0x00204081u) >> 21) & 0xFu) << (u * 16u + w * 4u);
+            }
+        }
+        const u32 left = end - (beg + v4 * 64u); // bytes of the chunk from this piece on (>= 1)
+        if (left < 64u) heads &= (1ull << left) - 1ull;
+        const u64 heads0 = heads;
+        // a head's rank takes the place of its byte in the row; what is no head leaves as 0
+        const u8 *mine_in = reinterpret_cast<const u8 *>(&s_io[0][0]);
+        while (heads) {
+            const u32 k = (u32)__builtin_ctzll(heads);
+            heads &= heads - 1ull;
+            const u32 at = ((k >> 4) * LANES + threadIdx.x) * 16u + (k & 15u);
+            const u32 c = s_code[mine_in[at]];
+            const u32 wc = my[(c >> 1) * LANES];
+            const u32 lsu = (c & 1u) ? (wc >> 16) : (wc & 0xFFFFu);
+            // both halves of a table word against the symbol's own time in packed 16-bit arithmetic:
+            // ls - t saturates (a never-seen -32768 must not wrap), its sign says t > ls
+            const short2_t ls2 = as_short2(lsu | (lsu << 16));
+            short2_t acc = {0, 0};
+            for (u32 q = 0; q < npairs; ++q) {
+                const short2_t wd = as_short2(my[q * LANES]);
+                const short2_t neg = __builtin_elementwise_sub_sat(ls2, wd) >> (short2_t){15, 15}; // -1 where t > ls
+                acc -= neg;
+            }
+            const u32 rank = (u32)(int)acc.x + (u32)(int)acc.y;
+            const u32 t = (v4 * 64u + k) & 0xFFFFu; // time inside the chunk, 0..kMtfChunk-1
+            my[(c >> 1) * LANES] = (c & 1u) ? ((wc & 0x0000FFFFu) | (t << 16)) : ((wc & 0xFFFF0000u) | t);
+            reinterpret_cast<u8 *>(&s_io[0][0])[at] = (u8)rank;
+        }
+#pragma unroll
+        for (u32 u = 0; u < 4; ++u) {
+            const u32 p0 = beg + v4 * 64u + u * 16u;
+            if (p0 >= end) break;
+            const uint4 r = s_io[u][threadIdx.x];
+            const u32 hb = (u32)(heads0 >> (u * 16u)) & 0xFFFFu;
+            // four head bits -> four byte masks
+            const u32 m0 = (((hb & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu, m1 = ((((hb >> 4) & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
+            const u32 m2 = ((((hb >> 8) & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu, m3 = (((hb >> 12) * 0x00204081u) & 0x01010101u) * 0xFFu;
+            *reinterpret_cast<uint4 *>(R8 + p0) = make_uint4(r.x & m0, r.y & m1, r.z & m2, r.w & m3);
+        }
+    }
+}
+#else
     // A lane's chunk is 512 consecutive bytes: it is read 64 bytes at a time (four 16-byte loads issued
     // together, the ranks stored the same way), so a line is fetched once and used while it is there;
     // 16 bytes per visit meant eight visits per 128-byte line with 64 other lanes' lines in between
@@ -469,6 +548,7 @@ __global__ __launch_bounds__(LANES) void k_mtf_ranks_small(MtfArgs a)
       }
     }
 }
+#endif
 
 // ---- ZLE helpers ----------------------------------------------------------------------------
 struct ZSeg {
