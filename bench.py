@@ -666,7 +666,7 @@ def extras(result, args, pkg, eng, torch, dev, d_in, n, d_out, out_len, golden, 
         if gk in golden:
             checks["deflate_sha_equals_oracle_golden"] = bool(golden[gk]["sha256"] == dsha and golden[gk]["bytes"] == st["k"])
         # dominant kernel: the match finder; 9 algorithmic bytes per position (sorted position in, text, match word
-        # out: DESIGN.md section 11)
+        # out: DESIGN_deflate.md)
         ach = 9.0 * n / dft["matches"] / 1e9 if dft["matches"] > 0 else 0.0
         df = {"metric": "Deflate (Inflater) encode MB/s (input bytes, HBM-resident in and out)",
               "value": round(n / fdt / 1e6, 2), "unit": "MB/s", "ms_per_step": round(fdt * 1e3, 3), "steps": 2,
@@ -675,7 +675,7 @@ def extras(result, args, pkg, eng, torch, dev, d_in, n, d_out, out_len, golden, 
               "roofline": {"bound": "hbm", "kernel": "k_df_match2", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
                            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": pmc_df.get("k_df_match2"),
                            "avg_launch_ms": round(dft["matches"] * 1e3, 3), "algorithmic_bytes_per_launch": 9 * n,
-                           "note": "VALU-issue-bound, not HBM-bound (DESIGN.md section 11)"}}
+                           "note": "VALU-issue-bound, not HBM-bound (DESIGN_deflate.md)"}}
         if not args.no_cpu_baseline:
             smp = min(16 << 20, n)
             sample = bytes(d_in[:smp].cpu().numpy())

@@ -6,7 +6,7 @@ A "step" is one pass of the path (hash chains -> matches -> parse -> blocks + Hu
 emission) over the synthetic corpus, input and stream resident in HBM.  Prints ONE JSON line.
 N > 1 (python -m torch.distributed.run --nproc-per-node N ... bench_deflate.py --gpus N): replicas only --
 one 32 KiB window and one bit string run through a whole input, so the path does not shard inside a
-stream; every rank encodes its own GiB as its own stream, the only collective is the
+stream (DESIGN_deflate.md); every rank encodes its own GiB as its own stream, the only collective is the
 barrier / max of the timing.
 """
 import argparse
@@ -113,7 +113,7 @@ def main():
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "launches": 1,
                      "avg_launch_ms": round(match_s * 1e3, 3), "algorithmic_bytes_per_launch": alg,
                      "note": "60 G candidate pairs per GiB at 16-17 vector instructions per 64 of them: bound by vector "
-                             "instruction issue, not HBM (DESIGN.md section 11)"},
+                             "instruction issue, not HBM (DESIGN_deflate.md)"},
         "kernel_seconds_last_step": {k: round(v, 5) for k, v in stages.items()},
         "deflate_stats": stats,
         "checks": {"head_inflates_to_input": bool(ok)},
