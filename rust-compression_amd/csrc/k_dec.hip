@@ -125,7 +125,10 @@ constexpr u32 kOutBuf = 1024;    // staged output symbols
 // ---- D1: header + Huffman decode of one candidate -------------------------------------------------------
 // One workgroup of four waves per candidate.  Thread 0 parses the header; all threads build the
 // decode tables; the symbols are then found 256 candidate code starts at a time (below).
-constexpr u32 kD1Threads = 256;
+#ifndef BZ_D1_THREADS
+#define BZ_D1_THREADS 256
+#endif
+constexpr u32 kD1Threads = BZ_D1_THREADS; // threads = candidate code starts per round
 __global__ __launch_bounds__(kD1Threads) void k_dec_block(const u8 *__restrict__ in, u64 nbytes,
                                                    const DecCand *__restrict__ cands, u32 ncand,
                                                    DecBlockInfo *__restrict__ info, u16 *__restrict__ sym_out,
@@ -325,12 +328,12 @@ __global__ __launch_bounds__(kD1Threads) void k_dec_block(const u8 *__restrict__
     if (l < 6) s_j[l][kD1Threads] = (u16)kD1Threads; // outside stays outside
     while (true) {
         const u64 wb = pos >> 5;
-        s_ring[(wb + l) & (kRingWords - 1)] = bc.load(wb + l);
+        for (u32 q = l; q < kRingWords; q += kD1Threads) s_ring[(wb + q) & (kRingWords - 1)] = bc.load(wb + q);
         __syncthreads();
         BZ_T(2)
         u32 nout = 0;
         const u64 wend = (wb + kRingWords) * 32ull; // first bit not staged
-        while (nout + 65u <= kOutBuf && pos + 352ull <= wend) {
+        while (nout + 65u <= kOutBuf && pos + (u64)(kD1Threads + 96u) <= wend) { // (a candidate reads 64 bits from its start)
             if (krem == 0) {
                 if (g >= n_selectors) { // group_no > n_selectors (:381-383)
                     state = 2;
