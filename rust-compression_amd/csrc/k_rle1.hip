@@ -364,7 +364,7 @@ __global__ __launch_bounds__(RT) void k_rle_scatter(const u8 *__restrict__ in, u
 {
     __shared__ i64 s_m[RT / 64 + 1];
     __shared__ u32 s_s[RT / 64];
-    __shared__ u8 s_out[2 * kRleTile];
+    __shared__ __attribute__((aligned(16))) u8 s_out[2 * kRleTile + 32];
     const u64 tile = t0 + blockIdx.x;
     Seg s;
     load_seg(in, n, tile, s, in_begin);
@@ -372,7 +372,12 @@ __global__ __launch_bounds__(RT) void k_rle_scatter(const u8 *__restrict__ in, u
     u8 e[16], cph[16];
     const u32 cnt = eval_seg(s, rs, e, cph);
     u32 tot;
-    u32 o = block_excl_sum(cnt, s_s, tot);
+    // The tile's bytes are staged at the offset their destination has inside a 16-byte line, so that the copy out is
+    // aligned 16-byte stores of aligned 16-byte LDS reads (rounds 1-4a: one BYTE per lane and store instruction, sixteen
+    // store instructions per thread); only the ragged first and last line go out byte by byte.
+    u8 *dst = rle + tile_off[tile];
+    const u32 a0 = (u32)(reinterpret_cast<uintptr_t>(dst) & 15u);
+    u32 o = a0 + block_excl_sum(cnt, s_s, tot);
 #pragma unroll
     for (u32 k = 0; k < 16; ++k) {
         if (e[k]) {
@@ -381,8 +386,17 @@ __global__ __launch_bounds__(RT) void k_rle_scatter(const u8 *__restrict__ in, u
         }
     }
     __syncthreads();
-    u8 *dst = rle + tile_off[tile];
-    for (u32 i = threadIdx.x; i < tot; i += RT) dst[i] = s_out[i];
+    u8 *line0 = dst - a0; // 16-byte aligned
+    const u32 end = a0 + tot, nlines = (end + 15u) >> 4;
+    for (u32 j = threadIdx.x; j < nlines; j += RT) {
+        const u32 lo = j * 16u;
+        if (lo >= a0 && lo + 16u <= end) {
+            *reinterpret_cast<uint4 *>(line0 + lo) = *reinterpret_cast<const uint4 *>(s_out + lo);
+        } else {
+            const u32 b0 = lo > a0 ? lo : a0, b1 = lo + 16u < end ? lo + 16u : end;
+            for (u32 b = b0; b < b1; ++b) line0[b] = s_out[b];
+        }
+    }
 }
 
 // ---- kernel F: the chain of block cuts (one workgroup) -------------------------------------
