@@ -29,6 +29,7 @@ typedef uint64_t u64;
 #endif
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -316,6 +317,7 @@ struct bz_enc {
     bool finish_submitted = false; // ... and the caller's copy: a Finish job has been handed over
     bool oneshot = false;          // bz_encode_buffer: the output queue is read only at the end
     bool reserve_stop = false;     // (out_mu) tells reserve_output to give up
+    std::atomic<int> out_waiters{0}; // threads that want out_mu for an append or a read: reserve_output stands back for them
     bool any_block = false;      // block_no > 1               (encoder.rs:168,179)
     u32 combined_crc = 0;        // encoder.rs:167
     unsigned carry_bits = 0;     // BitWriter.counter          (writer.rs:167)
@@ -441,8 +443,12 @@ static int out_append_locked(bz_enc *e, const u8 *p, size_t n)
 // works (in slices, under the queue's lock: an append may move the buffer in between).
 static void reserve_output(bz_enc *e, size_t expect)
 {
-    constexpr size_t kSlice = (size_t)8 << 20;
+    // (1 MiB under the lock at a time, and none while the drainer waits for it: a std::mutex is not fair, and a helper
+    // that takes it again at once kept the drainer -- and with it the lanes' downloads -- out until ALL of the room
+    // was touched: 40 ms of a 1 GiB call, 120 ms of a 4 GiB one)
+    constexpr size_t kSlice = (size_t)1 << 20;
     for (size_t pos = 0; pos < expect; pos += kSlice) {
+        while (e->out_waiters.load(std::memory_order_acquire) > 0) std::this_thread::sleep_for(std::chrono::microseconds(20));
         std::lock_guard<std::mutex> lk(e->out_mu);
         if (e->reserve_stop) return;
         if (e->out_cap < expect) {
@@ -471,7 +477,9 @@ static void drainer_main(bz_enc *e)
         }
         int rc = BZ_OK;
         if (d.bytes) {
+            e->out_waiters.fetch_add(1, std::memory_order_acq_rel);
             std::lock_guard<std::mutex> lk(e->out_mu);
+            e->out_waiters.fetch_sub(1, std::memory_order_acq_rel);
             rc = out_append_locked(e, e->r->lanes[(size_t)d.lane].h_out, d.bytes);
         }
         {
