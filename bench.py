@@ -26,6 +26,7 @@ timeout, and the extras behind the headline have their own deadline after which 
 without them.
 """
 import argparse
+import ctypes
 import bz2
 import hashlib
 import importlib
@@ -510,7 +511,6 @@ def end_to_end_buffer(pkg, level, devices, h_in, n, want_sha, checks, hbm_value,
     pinned staging, device buffers: its time is first_call_s), then `repeats` timed ones -- median / min / max, the
     per-phase times of the median call (bz_encode_buffer_last_phases); every stream is compared with the device
     stream's SHA-256."""
-    import ctypes
     L = pkg.lib()
     src = ctypes.cast(h_in.ctypes.data, ctypes.c_char_p)
     devs = (ctypes.c_int * len(devices))(*devices)
@@ -646,7 +646,28 @@ def extras(result, args, pkg, eng, torch, dev, d_in, n, d_out, out_len, golden, 
         kk, vv = eng.decode_device(d_s.data_ptr(), ks, d_dec.data_ptr(), n + 64)
         checks["decode_equals_oracle_on_cpu_sample"] = bool(v == 0 and vv == 0 and kk == len(back) and
                                                             bytes(d_dec[:kk].cpu().numpy()) == back)
-    del d_dec
+    # the same stream host buffer -> host buffer (bz_decode_buffer: pageable caller memory, H2D / D2H inside the clock)
+    z_host = d_out[:out_len].cpu().numpy()
+    L = pkg.lib()
+    calls, e2e_ok = [], True
+    for rep in range(6):
+        dp, dn = ctypes.POINTER(ctypes.c_uint8)(), ctypes.c_size_t(0)
+        c0 = time.perf_counter()
+        rc = L.bz_decode_buffer(dev.index or 0, ctypes.cast(z_host.ctypes.data, ctypes.c_char_p), int(out_len), ctypes.byref(dp), ctypes.byref(dn))
+        calls.append(time.perf_counter() - c0)
+        e2e_ok = e2e_ok and rc == 0 and dn.value == n
+        if rep == 0 and e2e_ok:
+            back = torch.frombuffer((ctypes.c_uint8 * n).from_address(ctypes.addressof(dp.contents)), dtype=torch.uint8)
+            e2e_ok = bool(torch.equal(back.to(dev), d_in[:n]))
+            del back
+        L.bz_free(dp)
+    checks["decode_host_to_host_equals_input"] = bool(e2e_ok)
+    st5 = step_stats(calls[1:])
+    dec["end_to_end"] = {"bz_decode_buffer": round(n / (st5["median"] * 1e-3) / 1e6, 2), "unit": "MB/s (decoded bytes)", "calls_ms": st5,
+                         "first_call_s": round(calls[0], 4),
+                         "fraction_of_hbm_resident_rate": round(n / (st5["median"] * 1e-3) / 1e6 / dec["value"], 3),
+                         "note": "host buffer in -> host buffer out, pageable caller memory, median of 5 calls behind one untimed call"}
+    del d_dec, z_host
 
     # ---- Deflate (BASELINE.json configs[4]: Inflater on the same corpus, HBM -> HBM); one call takes < 2 GiB
     result["extra"] = {"decode": dec}
@@ -709,7 +730,6 @@ def extras(result, args, pkg, eng, torch, dev, d_in, n, d_out, out_len, golden, 
     del d_t2
 
     # ---- end to end: host buffer -> host buffer through the C ABI (PCIe both ways inside the clock)
-    import ctypes
     import numpy as np
     h_in = d_in.cpu().numpy()  # pageable caller memory
     e2e = end_to_end_buffer(pkg, args.level, [dev.index], h_in, n, result["stream_sha256"], checks, result["value"])
@@ -903,7 +923,6 @@ def cold_start_leg(h_in, n, level, device, want_sha, checks):
 def small_inputs_leg(pkg, oracle, args, h_in, checks, device):
     """One warm bz_encode_buffer call on small inputs (median of 11), the oracle on the same bytes beside it:
     the reference's sample1 (98 KB, one block), one level-9 block of the corpus, ten blocks."""
-    import ctypes
     L = pkg.lib()
     gold = os.path.join(ROOT, "tests", "golden", "sample1.ref")
     cases = [("sample1.ref (data/sample1.ref, 98 696 B, 1 block)", open(gold, "rb").read())] if os.path.exists(gold) else []

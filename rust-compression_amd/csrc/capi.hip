@@ -26,6 +26,7 @@ typedef uint64_t u64;
 } // namespace bzgpu
 #else
 #include "bzgpu.h"
+void dec_release_cached(); // dec_engine.hip: the engines bz_decode_buffer keeps between calls
 #endif
 
 #include <algorithm>
@@ -277,6 +278,9 @@ extern "C" void bz_release_cached_resources(void)
         all.swap(g_cache);
     }
     for (EncResources *r : all) resources_free(r);
+#ifndef BZ_HOST_PIPELINE_TEST
+    dec_release_cached(); // (the engines bz_decode_buffer keeps)
+#endif
 }
 
 struct EncJob {

@@ -11,6 +11,10 @@
 // is only noticed after that block's bytes were handed out, decoder.rs:189-201).
 #include "engine_state.h"
 
+#include <mutex>
+#include <sys/mman.h>
+#include <utility>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -106,11 +110,55 @@ struct DevBits {
 };
 
 // where decoded bytes go
+// Decoded bytes on the host: a plain growable buffer (no value initialisation -- a std::vector's resize() writes every
+// byte before the copy from the device does), in 2 MiB-aligned memory that asks for huge pages: the first touch of a
+// GiB of fresh 4 KiB pages costs 0.2 s, more than its decode.  free() takes it (bz_free).
+struct HostBuf {
+    u8 *p = nullptr;
+    size_t len = 0, cap = 0;
+    int reserve(size_t need)
+    {
+        if (need <= cap) return BZ_OK;
+        size_t want = std::max(need, cap + cap / 2 + 4096);
+        void *q = nullptr;
+        if (want >= ((size_t)4 << 20)) {
+            want = (want + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+            if (posix_memalign(&q, (size_t)2 << 20, want) != 0) q = nullptr;
+            if (q) (void)madvise(q, want, MADV_HUGEPAGE);
+        } else {
+            q = malloc(want);
+        }
+        if (!q) return BZ_E_NOMEM;
+        if (len) memcpy(q, p, len);
+        free(p);
+        p = static_cast<u8 *>(q);
+        cap = want;
+        return BZ_OK;
+    }
+    void drop_front(size_t k)
+    {
+        if (k >= len) {
+            len = 0;
+            return;
+        }
+        memmove(p, p + k, len - k);
+        len -= k;
+    }
+    u8 *release() // the caller owns the bytes now
+    {
+        u8 *q = p;
+        p = nullptr;
+        len = cap = 0;
+        return q;
+    }
+    ~HostBuf() { free(p); }
+};
+
 struct Sink {
     u8 *d_out = nullptr; // device destination (device API) or nullptr
     u64 cap = 0;
     bool dry = false;    // sizes only
-    std::vector<u8> *host = nullptr; // host destination (one-shot over host buffers)
+    HostBuf *host = nullptr; // host destination (one-shot over host buffers, the streaming context)
     DevBuf *staging = nullptr;
     u64 produced = 0;
 };
@@ -636,9 +684,11 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                     }
                 }
                 if (sink.host) {
-                    const size_t old = sink.host->size();
-                    sink.host->resize(old + valid);
-                    if (valid) HIPDEC(hipMemcpy(sink.host->data() + old, dst, valid, hipMemcpyDeviceToHost));
+                    const size_t old = sink.host->len;
+                    const int hrc = sink.host->reserve(old + valid);
+                    if (hrc != BZ_OK) return hrc;
+                    if (valid) HIPDEC(hipMemcpy(sink.host->p + old, dst, valid, hipMemcpyDeviceToHost));
+                    sink.host->len = old + valid;
                 }
                 sink.produced += valid;
                 } // shard_rc == BZ_OK
@@ -799,38 +849,84 @@ extern "C" int bz_gpu_last_decode_stats(bz_gpu_engine *g, uint64_t out[4])
     return BZ_OK;
 }
 
+// One engine per device is kept between one-shot calls (its decode workspace -- 13 MB per block in flight -- and the
+// buffer for the compressed bytes cost more to make than a GiB costs to decode); bz_release_cached_resources frees them.
+namespace {
+std::mutex g_dec_cache_mu;
+std::vector<std::pair<int, bz_gpu_engine *>> g_dec_cache;
+bz_gpu_engine *dec_cache_take(int device)
+{
+    std::lock_guard<std::mutex> lk(g_dec_cache_mu);
+    for (size_t i = 0; i < g_dec_cache.size(); ++i)
+        if (g_dec_cache[i].first == device) {
+            bz_gpu_engine *g = g_dec_cache[i].second;
+            g_dec_cache.erase(g_dec_cache.begin() + (ptrdiff_t)i);
+            return g;
+        }
+    return nullptr;
+}
+void dec_cache_put(int device, bz_gpu_engine *g)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_dec_cache_mu);
+        bool have = false;
+        for (const auto &e : g_dec_cache) have = have || e.first == device;
+        if (!have) {
+            g_dec_cache.emplace_back(device, g);
+            return;
+        }
+    }
+    bz_gpu_engine_destroy(g); // (two calls side by side on one device: the second engine is not kept)
+}
+} // namespace
+void dec_release_cached()
+{
+    std::vector<std::pair<int, bz_gpu_engine *>> all;
+    {
+        std::lock_guard<std::mutex> lk(g_dec_cache_mu);
+        all.swap(g_dec_cache);
+    }
+    for (auto &e : all) {
+        (void)hipSetDevice(e.first);
+        bz_gpu_engine_destroy(e.second);
+    }
+}
+
 extern "C" int bz_decode_buffer(int device, const uint8_t *in, size_t in_len, uint8_t **out, size_t *out_len)
 {
     if (!out || !out_len || (!in && in_len)) return BZ_E_PARAM;
     *out = nullptr;
     *out_len = 0;
-    bz_gpu_engine *g = nullptr;
-    int rc = bz_gpu_engine_create(&g, device, 0);
+    int caller_device = -1;
+    (void)hipGetDevice(&caller_device); // (put back on return: ADVICE r3, the same rule as the encoder's entry points)
+    bz_gpu_engine *g = dec_cache_take(device);
+    int rc = g ? BZ_OK : bz_gpu_engine_create(&g, device, 0);
     if (rc != BZ_OK) return rc;
-    void *d_in = nullptr;
-    std::vector<u8> host;
+    HostBuf host;
     int verdict = BZ_OK;
-    rc = BZ_E_NOMEM;
-    if (hipMalloc(&d_in, in_len + 64) == hipSuccess) {
+    rc = hipSetDevice(device) == hipSuccess ? g->dec_in.ensure(in_len + 64) : BZ_E_UNEXPECTED;
+    if (rc == BZ_OK) {
         rc = BZ_E_UNEXPECTED;
-        if (hipMemset(d_in, 0, in_len + 64) == hipSuccess &&
-            (!in_len || hipMemcpy(d_in, in, in_len, hipMemcpyHostToDevice) == hipSuccess)) {
+        // (the 64 bytes behind the stream are read as zeros by the bit readers)
+        if (hipMemsetAsync(static_cast<u8 *>(g->dec_in.p) + in_len, 0, 64, g->st) == hipSuccess &&
+            (!in_len || hipMemcpyAsync(g->dec_in.p, in, in_len, hipMemcpyHostToDevice, g->st) == hipSuccess) &&
+            hipStreamSynchronize(g->st) == hipSuccess) {
             if (!g->dec) g->dec = new DecWorkspace();
             Sink sink;
             sink.host = &host;
             sink.staging = &g->dec->staging;
-            rc = decode_core(g, static_cast<const u8 *>(d_in), in_len, sink, &verdict);
+            rc = decode_core(g, static_cast<const u8 *>(g->dec_in.p), in_len, sink, &verdict);
         }
     }
-    if (d_in) (void)hipFree(d_in);
-    bz_gpu_engine_destroy(g);
+    if (rc == BZ_OK) dec_cache_put(device, g);
+    else bz_gpu_engine_destroy(g); // (an engine that met an infrastructure error is not kept)
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
     if (rc != BZ_OK) return rc;
     // the bytes in front of an error are handed over too, as the reference's iterator yields them
-    uint8_t *h = (uint8_t *)malloc(host.size() ? host.size() : 1);
+    *out_len = host.len;
+    uint8_t *h = host.len ? host.release() : (uint8_t *)malloc(1);
     if (!h) return BZ_E_NOMEM;
-    if (!host.empty()) memcpy(h, host.data(), host.size());
     *out = h;
-    *out_len = host.size();
     return verdict;
 }
 
@@ -847,7 +943,7 @@ struct bz_dec {
     bz_gpu_engine *g = nullptr;
     std::vector<u8> in;  // compressed bytes from the next record on
     Resume rs;
-    std::vector<u8> out; // decoded bytes not yet handed out
+    HostBuf out;         // decoded bytes not yet handed out
     size_t out_pos = 0;
     DevBuf d_in;
     size_t chunk = (size_t)256 << 20;
@@ -866,7 +962,7 @@ static int dec_drain(bz_dec *d, bool final)
         }
     }
     if (d->out_pos) { // drop what has been read
-        d->out.erase(d->out.begin(), d->out.begin() + (ptrdiff_t)d->out_pos);
+        d->out.drop_front(d->out_pos);
         d->out_pos = 0;
     }
     const size_t n = d->in.size();
@@ -940,15 +1036,15 @@ extern "C" int bz_dec_end(bz_dec *d)
 extern "C" long bz_dec_read(bz_dec *d, uint8_t *out, size_t cap)
 {
     if (!d || (!out && cap)) return BZ_E_PARAM;
-    const size_t left = d->out.size() - d->out_pos;
+    const size_t left = d->out.len - d->out_pos;
     if (left == 0) return d->done ? (long)d->verdict : 0; // verdict (0 = clean end) once it is final, else "nothing yet"
     const size_t k = left < cap ? left : cap;
-    memcpy(out, d->out.data() + d->out_pos, k);
+    memcpy(out, d->out.p + d->out_pos, k);
     d->out_pos += k;
     return (long)k;
 }
 
-extern "C" size_t bz_dec_pending(const bz_dec *d) { return d ? d->out.size() - d->out_pos : 0; }
+extern "C" size_t bz_dec_pending(const bz_dec *d) { return d ? d->out.len - d->out_pos : 0; }
 
 extern "C" void bz_dec_destroy(bz_dec *d)
 {
