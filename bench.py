@@ -707,6 +707,25 @@ def extras(result, args, pkg, eng, torch, dev, d_in, n, d_out, out_len, golden, 
             checks["deflate_equals_oracle_on_cpu_sample"] = bool(bytes(d_df[:ks].cpu().numpy()) == ref)
             df["cpu_baseline"] = {"value": round(smp / cdt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
                                   "sample": "first %d MiB of the corpus, oracle/deflate_oracle.c (C restatement of Inflater)" % (smp >> 20)}
+        # the same host buffer -> host buffer (df_encode_buffer)
+        h_df = d_in[:n].cpu().numpy()
+        calls, df_ok = [], True
+        for rep in range(4):
+            dp, dn = ctypes.POINTER(ctypes.c_uint8)(), ctypes.c_size_t(0)
+            c0 = time.perf_counter()
+            rc = pkg.lib().df_encode_buffer(pkg.DEFLATE, dev.index or 0, ctypes.cast(h_df.ctypes.data, ctypes.c_char_p), n, ctypes.byref(dp),
+                                            ctypes.byref(dn))
+            calls.append(time.perf_counter() - c0)
+            df_ok = df_ok and rc == 0 and dn.value == st["k"]
+            if rep == 0 and df_ok:
+                df_ok = hashlib.sha256(memoryview((ctypes.c_uint8 * dn.value).from_address(ctypes.addressof(dp.contents)))).hexdigest() == dsha
+            pkg.lib().bz_free(dp)
+        checks["deflate_host_to_host_equals_device_stream"] = bool(df_ok)
+        st3 = step_stats(calls[1:])
+        df["end_to_end"] = {"df_encode_buffer": round(n / (st3["median"] * 1e-3) / 1e6, 2), "unit": "MB/s", "calls_ms": st3,
+                            "first_call_s": round(calls[0], 4), "fraction_of_hbm_resident_rate": round(n / (st3["median"] * 1e-3) / 1e6 / df["value"], 3),
+                            "note": "host buffer in -> host buffer out, pageable caller memory, median of 3 calls behind one untimed call"}
+        del h_df
         result["extra"]["deflate"] = df
         del d_df
 

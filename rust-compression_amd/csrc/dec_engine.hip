@@ -854,6 +854,7 @@ extern "C" int bz_gpu_last_decode_stats(bz_gpu_engine *g, uint64_t out[4])
 namespace {
 std::mutex g_dec_cache_mu;
 std::vector<std::pair<int, bz_gpu_engine *>> g_dec_cache;
+} // namespace
 bz_gpu_engine *dec_cache_take(int device)
 {
     std::lock_guard<std::mutex> lk(g_dec_cache_mu);
@@ -878,7 +879,6 @@ void dec_cache_put(int device, bz_gpu_engine *g)
     }
     bz_gpu_engine_destroy(g); // (two calls side by side on one device: the second engine is not kept)
 }
-} // namespace
 void dec_release_cached()
 {
     std::vector<std::pair<int, bz_gpu_engine *>> all;

@@ -579,31 +579,37 @@ extern "C" int df_encode_buffer_dict(int kind, int device, const uint8_t *in, si
     if (!out || !out_len || (!in && in_len) || kind < 0 || kind > 2 || (!dict && dict_len)) return BZ_E_PARAM;
     *out = nullptr;
     *out_len = 0;
-    bz_gpu_engine *g = nullptr;
-    int rc = bz_gpu_engine_create(&g, device, 1);
+    // (an engine per device is kept between one-shot calls, with its workspace and the two buffers below:
+    // bz_release_cached_resources frees it)
+    int caller_device = -1;
+    (void)hipGetDevice(&caller_device);
+    bz_gpu_engine *g = dec_cache_take(device);
+    int rc = g ? BZ_OK : bz_gpu_engine_create(&g, device, 1);
     if (rc != BZ_OK) return rc;
-    void *d_in = nullptr, *d_out = nullptr;
     const size_t cap = df_encode_bound(in_len) + 8;
     uint8_t *h = nullptr;
     size_t n_out = 0;
-    rc = BZ_E_NOMEM;
-    if (hipMalloc(&d_in, in_len + 64) != hipSuccess) goto done;
-    if (hipMalloc(&d_out, cap) != hipSuccess) goto done;
-    rc = BZ_E_UNEXPECTED;
-    if (in_len && hipMemcpy(d_in, in, in_len, hipMemcpyHostToDevice) != hipSuccess) goto done;
-    rc = df_gpu_encode_device_dict(g, kind, d_in, in_len, dict, dict_len, d_out, cap, &n_out);
-    if (rc != BZ_OK) goto done;
-    h = (uint8_t *)malloc(n_out ? n_out : 1);
-    if (!h) { rc = BZ_E_NOMEM; goto done; }
-    if (hipMemcpy(h, d_out, n_out, hipMemcpyDeviceToHost) != hipSuccess) { free(h); rc = BZ_E_UNEXPECTED; goto done; }
+    rc = hipSetDevice(device) == hipSuccess ? BZ_OK : BZ_E_UNEXPECTED;
+    if (rc == BZ_OK) rc = g->dec_in.ensure(in_len + 64);
+    if (rc == BZ_OK) rc = g->oneshot_out.ensure(cap);
+    if (rc == BZ_OK && in_len && hipMemcpy(g->dec_in.p, in, in_len, hipMemcpyHostToDevice) != hipSuccess) rc = BZ_E_UNEXPECTED;
+    if (rc == BZ_OK) rc = df_gpu_encode_device_dict(g, kind, g->dec_in.p, in_len, dict, dict_len, g->oneshot_out.p, cap, &n_out);
+    if (rc == BZ_OK) {
+        h = (uint8_t *)malloc(n_out ? n_out : 1);
+        if (!h) rc = BZ_E_NOMEM;
+        else if (hipMemcpy(h, g->oneshot_out.p, n_out, hipMemcpyDeviceToHost) != hipSuccess) {
+            free(h);
+            h = nullptr;
+            rc = BZ_E_UNEXPECTED;
+        }
+    }
+    if (rc == BZ_OK) dec_cache_put(device, g);
+    else bz_gpu_engine_destroy(g); // (an engine that met an error is not kept)
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
+    if (rc != BZ_OK) return rc;
     *out = h;
     *out_len = n_out;
-    rc = BZ_OK;
-done:
-    if (d_in) (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
-    bz_gpu_engine_destroy(g);
-    return rc;
+    return BZ_OK;
 }
 
 // ---- streaming context: the Encoder::next contract of Inflater / ZlibEncoder / GZipEncoder ----------------

@@ -202,7 +202,7 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
     (void)hipSetDevice(g->device);
     (void)hipStreamSynchronize(g->st);
     (void)hipStreamSynchronize(g->st2);
-    DevBuf *all[] = {&g->dec_in, &g->cut_step_t0, &g->cut_step_nt, &g->cut_step_w0, &g->cut_tab, &g->cut_comp,
+    DevBuf *all[] = {&g->dec_in, &g->oneshot_out, &g->cut_step_t0, &g->cut_step_nt, &g->cut_step_w0, &g->cut_tab, &g->cut_comp,
                      &g->crc_tab, &g->xp16, &g->xp2, &g->tile_last, &g->carry_in, &g->tile_crc, &g->tile_count,
                      &g->tile_off, &g->sub_off, &g->sub_rs, &g->scal, &g->scan_part, &g->rle, &g->blocks_all, &g->crc_all, &g->lblocks, &g->lcrc, &g->SA,
                      &g->R, &g->KA, &g->VA, &g->KB, &g->VB, &g->tile_hist, &g->count, &g->flags, &g->tlo, &g->tln,

@@ -15,7 +15,11 @@ void dec_workspace_free(DecWorkspace *w);
 // returns an infrastructure status, the decoder's verdict in *verdict and the bytes it produced in *produced
 int dec_decode_for_verify(struct bz_gpu_engine *g, const uint8_t *d_in, uint64_t n, uint8_t *d_out, uint64_t cap,
                           uint64_t *produced, int *verdict);
-void dec_release_cached(); // the engines bz_decode_buffer keeps between calls (bz_release_cached_resources)
+// the engines the one-shot calls over host buffers keep between calls (bz_decode_buffer, df_encode_buffer; one per
+// device; bz_release_cached_resources frees them)
+struct bz_gpu_engine *dec_cache_take(int device);
+void dec_cache_put(int device, struct bz_gpu_engine *g);
+void dec_release_cached();
 struct DfWorkspace;
 void df_workspace_free(DfWorkspace *w);
 
@@ -113,7 +117,7 @@ struct bz_gpu_engine {
     u64 verify_stats[4] = {0, 0, 0, 0}; // since creation: blocks checked, calls redone, redone calls that failed again, ns
     DevBuf vstream, vout, vseg, vmis;
     DecWorkspace *dec = nullptr; // decode workspace, created by the first decode call
-    DevBuf dec_in;               // bz_decode_buffer: the compressed bytes on the device (kept with the cached engine)
+    DevBuf dec_in, oneshot_out;  // bz_decode_buffer / df_encode_buffer: the caller's bytes on the device and the result (kept with the cached engine)
     DfWorkspace *df = nullptr;   // Deflate encode workspace, created by the first df_gpu_encode_device call
 };
 
