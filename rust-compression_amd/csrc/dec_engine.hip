@@ -954,8 +954,9 @@ struct bz_dec {
 static int dec_drain(bz_dec *d, bool final)
 {
     if (d->done) return d->verdict;
-    if (!d->g) {
-        const int rc = bz_gpu_engine_create(&d->g, d->device, 0);
+    if (!d->g) { // (an engine kept by an earlier one-shot call or context, with its workspace, or a new one)
+        d->g = dec_cache_take(d->device);
+        const int rc = d->g ? BZ_OK : bz_gpu_engine_create(&d->g, d->device, 0);
         if (rc != BZ_OK) {
             d->done = true;
             return d->verdict = rc;
@@ -966,8 +967,9 @@ static int dec_drain(bz_dec *d, bool final)
         d->out_pos = 0;
     }
     const size_t n = d->in.size();
-    int rc = d->d_in.ensure(n + 64);
-    if (rc == BZ_OK && hipMemset(d->d_in.p, 0, n + 64) != hipSuccess) rc = BZ_E_UNEXPECTED;
+    int rc = hipSetDevice(d->device) == hipSuccess ? d->d_in.ensure(n + 64) : BZ_E_UNEXPECTED;
+    // (the 64 bytes behind the input are read as zeros by the bit readers)
+    if (rc == BZ_OK && hipMemset(static_cast<u8 *>(d->d_in.p) + n, 0, 64) != hipSuccess) rc = BZ_E_UNEXPECTED;
     if (rc == BZ_OK && n && hipMemcpy(d->d_in.p, d->in.data(), n, hipMemcpyHostToDevice) != hipSuccess) rc = BZ_E_UNEXPECTED;
     int verdict = BZ_OK;
     if (rc == BZ_OK) {
@@ -1049,8 +1051,16 @@ extern "C" size_t bz_dec_pending(const bz_dec *d) { return d ? d->out.len - d->o
 extern "C" void bz_dec_destroy(bz_dec *d)
 {
     if (!d) return;
+    int caller_device = -1;
+    (void)hipGetDevice(&caller_device);
     if (d->g) (void)hipSetDevice(d->device);
     d->d_in.release();
-    if (d->g) bz_gpu_engine_destroy(d->g);
+    if (d->g) { // (kept for the next context or one-shot call unless the context met an infrastructure error)
+        const bool data_verdict = d->verdict == BZ_OK || d->verdict == BZ_E_DATA || d->verdict == BZ_E_MAGIC_FIRST || d->verdict == BZ_E_MAGIC ||
+                                  d->verdict == BZ_E_EOF;
+        if (data_verdict) dec_cache_put(d->device, d->g);
+        else bz_gpu_engine_destroy(d->g);
+    }
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
     delete d;
 }
