@@ -141,7 +141,9 @@ void bz_free(void *p);
  * buffers and 2 x BZ_ENC_CHUNK_MIB of pinned host memory in a per-process cache (two device lists at most) when they
  * end, so that the next one does not pay hipMalloc / hipHostMalloc again (fresh device memory costs about 40 ms per
  * GiB on this platform: the FIRST 1 GiB call of a process takes 0.35 s, a later one 0.1 s).  This call releases what
- * is parked; BZ_ENC_NO_CACHE=1 in the environment turns the cache off. */
+ * is parked; BZ_ENC_NO_CACHE=1 in the environment turns the cache off.  The decode and Deflate entry points over host
+ * buffers (bz_decode_buffer, bz_dec_*, df_encode_buffer, df_enc_*) park ONE engine per device the same way (its decode
+ * workspace: about 13 MB of HBM per block of the largest stream seen): released here too. */
 void bz_release_cached_resources(void);
 
 /* ========================================================================
@@ -421,7 +423,9 @@ int bz_gpu_last_decode_stats(bz_gpu_engine *g, uint64_t out[4]);
 
 /* One-shot over host buffers: `in.iter().cloned().decode(&mut BZip2Decoder::new())`
  * collected until None or the first Err.  *out (malloc'ed, release with
- * bz_free) holds the bytes yielded before the verdict, also when that is an error. */
+ * bz_free) holds the bytes yielded before the verdict, also when that is an error.
+ * 1 GiB of decoded bytes in 0.11 s (9.4 GB/s) from the second call of a process on: the engine and its workspace are
+ * kept between calls (bz_release_cached_resources), the bytes land once, in huge-page-backed memory. */
 int bz_decode_buffer(int device, const uint8_t *in, size_t in_len,
                      uint8_t **out, size_t *out_len);
 

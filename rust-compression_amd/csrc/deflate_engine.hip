@@ -657,7 +657,7 @@ extern "C" void df_enc_destroy(df_enc *e)
         (void)hipSetDevice(e->device);
         e->d_data.release();
         e->d_out.release();
-        bz_gpu_engine_destroy(e->g);
+        dec_cache_put(e->device, e->g); // (kept, with its workspace, for the next context or one-shot call on the device)
     }
     delete e;
 }
@@ -690,7 +690,10 @@ extern "C" int df_enc_end(df_enc *e, int action)
     // the iterator handed over; afterwards the encoder yields None and leaves its caller's iterator alone.
     const bool ends_container = e->kind != 0;
     int rc;
-    if (!e->g && (rc = bz_gpu_engine_create(&e->g, e->device, 0)) != BZ_OK) return rc;
+    if (!e->g) {
+        e->g = dec_cache_take(e->device);
+        if (!e->g && (rc = bz_gpu_engine_create(&e->g, e->device, 0)) != BZ_OK) return rc;
+    }
     HIPCHK(hipSetDevice(e->device));
     const size_t add = e->in.size();
     if (e->total + add + 64 > e->d_data.cap) { // grow, keeping the stream so far
