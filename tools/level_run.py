@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""HBM-resident encode and decode at every level (run on the GPU box): tools/level_run.py [MiB] [levels]"""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import corpus
+pkg = importlib.import_module("rust-compression_amd")
+mib = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+levels = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 5, 9]
+dev = torch.device("cuda", 0)
+d_in = corpus.corpus_on_device(mib << 20, dev)
+n = d_in.numel()
+cap = (pkg.encode_bound(n) + 15) & ~15
+d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+d_dec = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+for lv in levels:
+    eng = pkg.GpuEngine(0, min(n // (lv * 90000) + 8, 1400))
+    k = eng.encode_device(lv, d_in.data_ptr(), n, d_out.data_ptr(), cap)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        k = eng.encode_device(lv, d_in.data_ptr(), n, d_out.data_ptr(), cap)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    st = eng.timings()
+    bs = eng.bwt_stats()
+    eng.decode_device(d_out.data_ptr(), k, d_dec.data_ptr(), n + 64)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        kk, v = eng.decode_device(d_out.data_ptr(), k, d_dec.data_ptr(), n + 64)
+    torch.cuda.synchronize()
+    ddt = (time.perf_counter() - t0) / 3
+    ok = v == 0 and kk == n and bool(torch.equal(d_dec[:n], d_in))
+    print("level %d: encode %.1f ms = %.0f MB/s (%d blocks, %d batches, ratio %.3f, stages %s); decode %.1f ms = %.0f MB/s ok %s" % (
+        lv, dt * 1e3, n / dt / 1e6, len(eng.block_stats()), bs["batches"], k / n, {a: round(b * 1e3, 1) for a, b in st.items()}, ddt * 1e3, n / ddt / 1e6, ok), flush=True)
+    eng.close()
