@@ -312,6 +312,7 @@ struct BwtArgs {
     const u8 *rle;
     const BlockDesc *blocks; // descriptors of the batch's blocks
     u32 nb;
+    u32 tiles;               // tiles per block a launch of the sort covers (run_bwt: what the largest block needs)
     u32 *SA, *R, *KA, *VA, *KB, *VB; // [nb * kSlot]
     u32 *tile_hist;                  // [nb][kTilesPerBlock][kMaxBins]
     u32 *bin_base;                   // [nb][kMaxBins]

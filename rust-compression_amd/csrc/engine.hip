@@ -656,6 +656,7 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
     x.rle = g->rle.as<u8>();
     x.blocks = g->lblocks.as<BlockDesc>() + o;
     x.nb = nb;
+    x.tiles = kTilesPerBlock;
     x.SA = g->SA.as<u32>() + s;
     x.R = g->R.as<u32>() + s;
     x.KA = g->KA.as<u32>() + s;

@@ -684,13 +684,13 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
     // tiles; the host checks that every counter reached its total and falls back to the three-kernel
     // passes if a dispatch ever does it differently.
     const u32 xcd = (u32)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u; // XCC_ID, bits 3:0
-    const u32 my_tiles = kTilesPerBlock * ((a.nb + 7u - xcd) / 8u);
+    const u32 my_tiles = a.tiles * ((a.nb + 7u - xcd) / 8u); // (a.tiles: tiles per block the launch covers)
     if (threadIdx.x == 0) s_ticket = atomicAdd(&a.tickets[(size_t)epoch * 8u + xcd], 1u);
     __syncthreads();
     const u32 slot = s_ticket;
     if (slot >= my_tiles) return;
-    const u32 b8 = slot / kTilesPerBlock;
-    const u32 tile = slot - b8 * kTilesPerBlock;
+    const u32 b8 = slot / a.tiles;
+    const u32 tile = slot - b8 * a.tiles;
     const u32 lb = b8 * 8u + xcd;
     if (gate && gate[lb] == 0u) return; // (phase B of the init: the block was ordered inside LDS)
     const BlockDesc d = a.blocks[lb];
@@ -1569,13 +1569,13 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
     u64 t_prev = __builtin_readcyclecounter();
 #endif
     const u32 xcd = (u32)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u; // XCC_ID (see k_radix_scatter_lb)
-    const u32 my_tiles = kTilesPerBlock * ((a.nb + 7u - xcd) / 8u);
+    const u32 my_tiles = a.tiles * ((a.nb + 7u - xcd) / 8u); // (a.tiles: tiles per block the launch covers)
     if (threadIdx.x == 0) s_ticket = atomicAdd(&a.tickets[(size_t)epoch * 8u + xcd], 1u);
     __syncthreads();
     const u32 slot = s_ticket;
     if (slot >= my_tiles) return;
-    const u32 b8 = slot / kTilesPerBlock;
-    const u32 tile = slot - b8 * kTilesPerBlock;
+    const u32 b8 = slot / a.tiles;
+    const u32 tile = slot - b8 * a.tiles;
     const u32 lb = b8 * 8u + xcd;
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
@@ -2619,7 +2619,7 @@ static void fused_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const
                        u32 *Vout, u32 dpos, u64 elems, KernelProf *prof, u64 out_elems = ~0ull,
                        const u32 *gate = nullptr)
 {
-    const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
+    const dim3 grid(a.tiles, xcd_grid_y(a.nb));
     const u64 rd = (SRC == SRC_TEXTK || SRC == SRC_PACKED) ? 4 : ((SRC == SRC_TEXT) ? 1 : ((SRC == SRC_WALK) ? 5 : (SRC == SRC_MMC ? 9 : 8)));
     const u32 e = next_epoch(st, a);
     if (out_elems == ~0ull) out_elems = elems;
@@ -2641,10 +2641,10 @@ static bool fused_pass_ok(hipStream_t st, const BwtArgs &a, u32 epoch)
     if (hipStreamSynchronize(st) != hipSuccess) return false;
     if (gave_up) return false;
     // Every workgroup of the launch draws one ticket from the counter of the XCD it runs on, and the launch has
-    // kTilesPerBlock * xcd_grid_y(nb) workgroups dealt evenly to the eight XCDs: each counter must stand at EXACTLY
+    // a.tiles * xcd_grid_y(nb) workgroups dealt evenly to the eight XCDs: each counter must stand at EXACTLY
     // that share.  Fewer: an XCD ran fewer workgroups than it has tiles (tiles left out).  More: tickets were drawn
     // twice -- the counters were cleared while the pass ran, or two launches shared an epoch -- and tiles ran twice.
-    const u32 want = kTilesPerBlock * (xcd_grid_y(a.nb) / 8u);
+    const u32 want = a.tiles * (xcd_grid_y(a.nb) / 8u);
     for (u32 x = 0; x < 8; ++x)
         if (tk[x] != want) return false;
     return true;
@@ -2655,7 +2655,7 @@ static bool fused_pass_ok(hipStream_t st, const BwtArgs &a, u32 epoch)
 template <int B0, int B1, int B2>
 static bool init_sort_fused(hipStream_t st, const BwtArgs &a, u64 total_n, KernelProf *prof, bool local_b)
 {
-    const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
+    const dim3 grid(a.tiles, xcd_grid_y(a.nb));
     // the digit counts of key(j), once: both init phases sort the same multiset of keys
     // (the keys are not kept: with the packed text a key costs one load, less than a stored key's write and read)
     int p = prof ? prof->begin(st, KID_GHIST_TEXT, total_n * 1) : -1;
@@ -2672,7 +2672,7 @@ static bool init_sort_fused(hipStream_t st, const BwtArgs &a, u64 total_n, Kerne
     static const bool stale_tickets_test = getenv("BZ_TEST_STALE_TICKETS") && atoi(getenv("BZ_TEST_STALE_TICKETS")) != 0;
     if (stale_tickets_test && *a.epoch + 1u < kSortEpochs)
         (void)hipMemsetD32Async((hipDeviceptr_t)(a.tickets + (size_t)(*a.epoch + 1u) * 8u),
-                                (int)(kTilesPerBlock * (xcd_grid_y(a.nb) / 8u)), 8, st);
+                                (int)(a.tiles * (xcd_grid_y(a.nb) / 8u)), 8, st);
     fused_pass<SRC_TEXT, B0>(st, a, 0, 0, nullptr, nullptr, a.KA, a.VA, 0, total_n, prof);
     if (!fused_pass_ok(st, a, *a.epoch)) return false;
     // (round 4) the middle pass of phase A writes ONE word per element -- the last digit above bit 20, the rotation below:
@@ -2744,7 +2744,12 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
 {
     BwtArgs a = a_in;
     if (!allow_fused || a.fused_state[0]) a.fused = 0;
-    const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
+    // A launch covers the tiles the batch's LARGEST block needs, not a level-9 block's 110: at level 1 (100 KB blocks,
+    // 13 tiles) seven of eight workgroups of every launch had nothing to do (BZ_FULL_GRID=1: as before).  Array strides
+    // stay kTilesPerBlock.
+    static const bool full_grid = getenv("BZ_FULL_GRID") && atoi(getenv("BZ_FULL_GRID")) != 0;
+    a.tiles = full_grid ? kTilesPerBlock : std::min<u32>(kTilesPerBlock, std::max<u32>(1u, (max_n + kSortTile - 1u) / kSortTile));
+    const dim3 grid(a.tiles, xcd_grid_y(a.nb));
     (void)hipMemsetAsync(a.active, 0, 64 * sizeof(unsigned long long), st);
     (void)hipMemsetAsync(a.maxnf, 0, 64 * sizeof(u32), st);
     (void)hipMemsetAsync(a.nonfinal, 0, a.nb * sizeof(u32), st);
@@ -2807,7 +2812,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
     int rounds = 0;
     u32 slot = 0;
     bool period_done = false;
-    u32 list_tiles = kTilesPerBlock; // (the first refinement ran on all of SA)
+    u32 list_tiles = a.tiles; // (the first refinement ran on all of SA)
     while (true) {
         if (hipMemcpyAsync(h_active, a.active + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, st) !=
                 hipSuccess ||
@@ -2963,7 +2968,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
         static const bool late_fail_test = getenv("BZ_ONESWEEP_LATEFAILTEST") != nullptr; // (tests: exercise the redo)
         bool bad = gave_up != 0 || late_fail_test;
-        const u32 want = kTilesPerBlock * (xcd_grid_y(a.nb) / 8u); // (exactly: see fused_pass_ok)
+        const u32 want = a.tiles * (xcd_grid_y(a.nb) / 8u); // (exactly: see fused_pass_ok)
         for (size_t i = 0; i < tk.size(); ++i)
             if (tk[i] != want) bad = true;
         if (bad) {
