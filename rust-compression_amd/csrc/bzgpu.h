@@ -357,6 +357,7 @@ constexpr u32 kMtfStride = kSlot + 64;
 struct MtfArgs {
     const BlockDesc *blocks;
     u32 nb;
+    u32 tiles;               // tiles of kSortTile bytes per block the ZLE launches cover (what the largest block needs)
     const u8 *L;             // [nb * kSlot] last column (raw bytes)
     const u32 *inuse_bits;   // [nb][8]
     u8 *summ;                // [nb][kMaxMtfChunks][256] recency lists

@@ -707,6 +707,7 @@ static MtfArgs make_mtf_args(bz_gpu_engine *g, u32 nb, u32 o, u32 total_nb)
     const size_t s = (size_t)o * kSlot, t = (size_t)o * kTilesPerBlock, c = (size_t)o * kMaxMtfChunks;
     ma.blocks = g->lblocks.as<BlockDesc>() + o;
     ma.nb = nb;
+    ma.tiles = kTilesPerBlock; // (encode_batch: what the batch's largest block needs)
     ma.L = g->L.as<u8>() + s;
     ma.inuse_bits = g->inuse_bits.as<u32>() + (size_t)o * 8;
     ma.summ = g->summ.as<u8>() + c * 256;
@@ -795,6 +796,7 @@ static int encode_batch(bz_gpu_engine *g, u32 nb, const std::vector<BlockDesc> &
     std::vector<hipEvent_t> evs;
     int rc = BZ_OK;
     bool used_fused_zle = false;
+    u32 zle_tiles = kTilesPerBlock; // tiles per block the one-launch ZLE stage covered (one sub-batch: see make_mtf_args)
     for (u32 q = 0; q < parts && rc == BZ_OK; ++q) {
         const u32 o = (u32)(((u64)nb * q) / parts), o1 = (u32)(((u64)nb * (q + 1)) / parts);
         const u32 nbq = o1 - o;
@@ -841,7 +843,10 @@ static int encode_batch(bz_gpu_engine *g, u32 nb, const std::vector<BlockDesc> &
         (void)hipEventRecord(ev, g->st);
         (void)hipStreamWaitEvent(g->st2, ev, 0);
 
-        const MtfArgs ma = make_mtf_args(g, nbq, o, nb);
+        MtfArgs ma = make_mtf_args(g, nbq, o, nb);
+        static const bool full_grid = getenv("BZ_FULL_GRID") && atoi(getenv("BZ_FULL_GRID")) != 0;
+        if (!full_grid) ma.tiles = std::min<u32>(kTilesPerBlock, std::max<u32>(1u, (max_n + kSortTile - 1u) / kSortTile));
+        zle_tiles = ma.tiles;
         used_fused_zle = used_fused_zle || ma.fused_zle;
         sp = span_begin(g, 2, g->st2);
         launch_mtf(g->st2, ma);
@@ -870,7 +875,7 @@ static int encode_batch(bz_gpu_engine *g, u32 nb, const std::vector<BlockDesc> &
         if (hipMemcpy(tk, g->ztick.p, sizeof(tk), hipMemcpyDeviceToHost) != hipSuccess) return BZ_E_UNEXPECTED;
         bool bad = tk[8] != 0 || fail_test;
         for (u32 x = 0; x < 8; ++x) // (exactly its share of the launch's workgroups: fewer = tiles left out, more = tiles run twice)
-            if (tk[x] != kTilesPerBlock * (xcd_grid_y(nb) / 8u)) bad = true;
+            if (tk[x] != zle_tiles * (xcd_grid_y(nb) / 8u)) bad = true;
         if (bad) {
             fprintf(stderr, "bz2_mi355x: the one-launch ZLE stage misbehaved (tile tickets / look-back); stage redone with three kernels\n");
             g->zle_fused_broken = true;

@@ -773,13 +773,13 @@ __global__ __launch_bounds__(kSortThreads) void k_zle_fused(MtfArgs a)
     __shared__ u32 s_base, s_ticket;
     __shared__ u16 s_out[kSortTile + 64];
     const u32 xcd = (u32)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u; // XCC_ID
-    const u32 my_tiles = kTilesPerBlock * ((a.nb + 7u - xcd) / 8u);
+    const u32 my_tiles = a.tiles * ((a.nb + 7u - xcd) / 8u); // (a.tiles: tiles per block the launch covers)
     if (threadIdx.x == 0) s_ticket = atomicAdd(&a.ztick[xcd], 1u);
     __syncthreads();
     const u32 slot = s_ticket;
     if (slot >= my_tiles) return;
-    const u32 b8 = slot / kTilesPerBlock;
-    const u32 tile = slot - b8 * kTilesPerBlock;
+    const u32 b8 = slot / a.tiles;
+    const u32 tile = slot - b8 * a.tiles;
     const u32 lb = b8 * 8u + xcd;
     const u32 n = a.blocks[lb].n;
     if (tile * kSortTile >= n) return; // (tiles beyond the block publish nothing; nobody looks back at them)
@@ -954,10 +954,10 @@ void launch_mtf(hipStream_t st, const MtfArgs &a)
     if (a.fused_zle) {
         (void)hipMemsetAsync(a.zstate, 0, (size_t)a.nb * kTilesPerBlock * 16, st);
         (void)hipMemsetAsync(a.ztick, 0, 64, st);
-        hipLaunchKernelGGL(k_zle_fused, dim3(kTilesPerBlock, xcd_grid_y(a.nb)), dim3(kSortThreads), 0, st, a);
+        hipLaunchKernelGGL(k_zle_fused, dim3(a.tiles, xcd_grid_y(a.nb)), dim3(kSortThreads), 0, st, a);
         return;
     }
-    const dim3 grid(kTilesPerBlock, a.nb);
+    const dim3 grid(a.tiles, a.nb);
     hipLaunchKernelGGL(k_zle_last, grid, dim3(kSortThreads), 0, st, a);
     hipLaunchKernelGGL((k_zle_emit<false>), grid, dim3(kSortThreads), 0, st, a);
     hipLaunchKernelGGL((k_zle_emit<true>), grid, dim3(kSortThreads), 0, st, a);
