@@ -33,6 +33,8 @@ for lv in levels:
     torch.cuda.synchronize()
     ddt = (time.perf_counter() - t0) / 3
     ok = v == 0 and kk == n and bool(torch.equal(d_dec[:n], d_in))
+    dst = {a: round(b * 1e3, 1) for a, b in eng.decode_timings().items()}
+    print("level %d: decode stages %s" % (lv, dst))
     print("level %d: encode %.1f ms = %.0f MB/s (%d blocks, %d batches, ratio %.3f, stages %s); decode %.1f ms = %.0f MB/s ok %s" % (
         lv, dt * 1e3, n / dt / 1e6, len(eng.block_stats()), bs["batches"], k / n, {a: round(b * 1e3, 1) for a, b in st.items()}, ddt * 1e3, n / ddt / 1e6, ok), flush=True)
     eng.close()
