@@ -20,7 +20,7 @@ def main():
         for it in range(3):
             outp, outn = ctypes.POINTER(ctypes.c_uint8)(), ctypes.c_size_t(0)
             t0 = time.perf_counter()
-            rc = L.bz_encode_buffer_multi(9, devs, len(devices), ctypes.cast(h.ctypes.data, ctypes.c_char_p), n, ctypes.byref(outp), ctypes.byref(outn))
+            rc = L.bz_encode_buffer_multi(int(os.environ.get("BZ_LEVEL", "9")), devs, len(devices), ctypes.cast(h.ctypes.data, ctypes.c_char_p), n, ctypes.byref(outp), ctypes.byref(outn))
             dt = time.perf_counter() - t0
             assert rc == 0, rc
             L.bz_free(outp)
