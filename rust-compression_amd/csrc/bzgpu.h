@@ -442,6 +442,9 @@ constexpr u32 kDecSubs = kSlot / 64;                           // 64-byte RLE1-u
 struct KernelProf;
 struct DecArgs {
     u32 nb;
+    // launch shapes that follow the batch (a level-1 block is a ninth of a level-9 one): 8192-byte tiles of the T-vector
+    // sort and workgroups of 256 x 64-byte sub-tiles of the RLE1 undo per block
+    u32 tiles, sub_wgs;
     const u32 *slot;              // [nb] candidate slot (index into info / sym) of each true block, stream order
     const DecBlockInfo *info;     // [slots]
     const u16 *sym;               // [slots][kMtfStride] Huffman symbols

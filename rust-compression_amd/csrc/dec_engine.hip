@@ -565,6 +565,15 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             w->stats[1] += nb;
             DecArgs a;
             a.nb = nb;
+            {
+                // The launches of the T-vector sort and of the RLE1 undo follow the batch's largest block (bytes from the
+                // stream's level); small gain, low levels only (level 1: 64.3 -> 63 ms per GiB).
+                u32 max_bytes = 1;
+                for (u32 i = 0; i < nb; ++i) max_bytes = std::max(max_bytes, bmax[i]);
+                static const bool full_grid = getenv("BZ_FULL_GRID") && atoi(getenv("BZ_FULL_GRID")) != 0;
+                a.tiles = full_grid ? kTilesPerBlock : std::min<u32>(kTilesPerBlock, (max_bytes + kSortTile - 1) / kSortTile);
+                a.sub_wgs = full_grid ? (kDecSubs + 255) / 256 : std::min<u32>((kDecSubs + 255) / 256, ((max_bytes + 63) / 64 + 255) / 256);
+            }
             a.slot = w->slot.as<u32>();
             a.info = w->info.as<DecBlockInfo>();
             a.sym = w->sym.as<u16>();

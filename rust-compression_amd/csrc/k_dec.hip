@@ -1236,7 +1236,7 @@ __global__ __launch_bounds__(kSortThreads) void k_dec_thist(DecArgs a)
     // column is mostly runs, and single adds to one LDS word serialise
     __shared__ u32 s_hist[4][256];
     u32 tile, lb;
-    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu || a.err[lb]) return;
     const u32 n = a.tt_len[lb];
     const u32 start = tile * kSortTile;
@@ -1303,7 +1303,7 @@ __global__ __launch_bounds__(kSortThreads) void k_dec_tscatter(DecArgs a)
     __shared__ u16 s_cnt[NW][256];
     __shared__ u32 s_wsum[4];
     u32 tile, lb;
-    xcd_remap(kTilesPerBlock, a.nb, tile, lb);
+    xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu || a.err[lb]) return;
     const u32 n = a.tt_len[lb];
     const u32 start = tile * kSortTile;
@@ -1475,6 +1475,9 @@ void launch_dec_blocks(hipStream_t st, const u8 *in, u64 nbytes, const DecCand *
 void launch_dec_mtf(hipStream_t st, const DecArgs &a, KernelProf *prof, int *rec)
 {
     *rec = prof ? prof->begin(st, KID_DEC_MTF, 0) : -1;
+    // (the chunk kernels keep the launch of a full slot, 14 workgroups per block, most of which leave at once: launched
+    // with just the workgroups the chunks need the stage is SLOWER -- level 9: 9.5 ms per GiB against 8.3, level 1: 30.0
+    // against 17.1 --, with one workgroup per CU twice as slow; profiles/r04_off_default_configs.md)
     const u32 cw = (kMaxMtfChunks + 255) / 256;
     hipLaunchKernelGGL(k_dec_chunk_perm, dim3(cw, a.nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dec_compose, dim3(a.nb), dim3(64), 0, st, a);
@@ -1487,7 +1490,7 @@ void launch_dec_mtf(hipStream_t st, const DecArgs &a, KernelProf *prof, int *rec
 void launch_dec_walks(hipStream_t st, const DecArgs &a, u32 walk_wgs, hipStream_t st2, hipEvent_t ev_a, hipEvent_t ev_b,
                       KernelProf *prof, int rec[4])
 {
-    const dim3 tiles(kTilesPerBlock, xcd_grid_y(a.nb));
+    const dim3 tiles(a.tiles, xcd_grid_y(a.nb));
     rec[0] = prof ? prof->begin(st, KID_DEC_TSORT, 0) : -1;
     hipLaunchKernelGGL(k_dec_thist, tiles, dim3(kSortThreads), 0, st, a);
     hipLaunchKernelGGL(k_dec_tscan, dim3(a.nb), dim3(256), 0, st, a);
@@ -1510,14 +1513,14 @@ void launch_dec_walks(hipStream_t st, const DecArgs &a, u32 walk_wgs, hipStream_
     hipLaunchKernelGGL(k_dec_fixups, dim3(a.nb), dim3(256), 0, st, a);
     if (prof) prof->end(st, rec[2]);
     rec[3] = prof ? prof->begin(st, KID_DEC_RLE, 0) : -1;
-    hipLaunchKernelGGL(k_dec_rle_sub, dim3((kDecSubs + 255) / 256, a.nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_dec_rle_sub, dim3(a.sub_wgs, a.nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dec_rle_chain, dim3(a.nb), dim3(1024), 0, st, a);
     if (prof) prof->end(st, rec[3]);
 }
 
 void launch_dec_expand(hipStream_t st, const DecArgs &a, const u64 *out_base, u8 *out)
 {
-    hipLaunchKernelGGL(k_dec_rle_expand, dim3((kDecSubs + 255) / 256, a.nb), dim3(256), 0, st, a, out_base, out);
+    hipLaunchKernelGGL(k_dec_rle_expand, dim3(a.sub_wgs, a.nb), dim3(256), 0, st, a, out_base, out);
 }
 
 void launch_dec_crc(hipStream_t st, const DecArgs &a, const u64 *out_base, const u8 *out, u32 max_out_len,
