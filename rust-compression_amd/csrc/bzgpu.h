@@ -475,6 +475,7 @@ void launch_dec_scan(hipStream_t st, const u8 *in, u64 nbytes, DecCand *cands, u
 void launch_dec_blocks(hipStream_t st, const u8 *in, u64 nbytes, const DecCand *cands, u32 ncand, DecBlockInfo *info,
                        u16 *sym, u8 *sel_scratch);
 void launch_dec_mtf(hipStream_t st, const DecArgs &a, KernelProf *prof, int *rec);
+void launch_dec_gather_windows(hipStream_t st, const u8 *in, u64 nbytes, const u64 *bases, u32 nw, u8 *out);
 void launch_dec_walks(hipStream_t st, const DecArgs &a, u32 walk_wgs, hipStream_t st2, hipEvent_t ev_a, hipEvent_t ev_b,
                       KernelProf *prof, int rec[4]);
 void launch_dec_expand(hipStream_t st, const DecArgs &a, const u64 *out_base, u8 *out);

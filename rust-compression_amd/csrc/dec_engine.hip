@@ -27,6 +27,7 @@ constexpr u32 kForcedSlots = 16; // blocks per batch that start without a full 4
 
 struct DecWorkspace {
     size_t slots = 0;
+    DevBuf win_base, win_bytes; // the chain's windows behind the blocks' ends (see DevBits)
     DevBuf cands, count, info, sym, sel, slot, nbmax, perm, chunk_emit, tt_len, err, L, T, X, samp_next, samp_len,
         samp_off, cycle_len, sub_trans, sub_off, sub_state, work_ctr, walk_meta, seg_buf, seg_cont, long_list, out_len, thist, tbase, crc, out_base, staging, cand_all;
     hipEvent_t ev_a = nullptr, ev_b = nullptr; // fork / join of the second walk
@@ -37,7 +38,7 @@ struct DecWorkspace {
 void dec_workspace_free(DecWorkspace *w)
 {
     if (!w) return;
-    DevBuf *all[] = {&w->cands, &w->count, &w->info, &w->sym, &w->sel, &w->slot, &w->nbmax, &w->perm,
+    DevBuf *all[] = {&w->win_base, &w->win_bytes, &w->cands, &w->count, &w->info, &w->sym, &w->sel, &w->slot, &w->nbmax, &w->perm,
                      &w->chunk_emit, &w->tt_len, &w->err, &w->L, &w->T, &w->X, &w->samp_next, &w->samp_len,
                      &w->samp_off, &w->cycle_len, &w->sub_trans, &w->sub_off, &w->sub_state, &w->work_ctr, &w->walk_meta, &w->seg_buf, &w->seg_cont, &w->long_list, &w->out_len, &w->thist, &w->tbase,
                      &w->crc, &w->out_base, &w->staging, &w->cand_all};
@@ -81,9 +82,23 @@ struct DevBits {
     u64 base = ~0ull; // byte offset of buf[0]
     u64 len = 0;
     bool failed = false;
+    // 64-byte windows fetched ahead in ONE copy (the bytes behind every block of a batch: a stream's trailer and the
+    // next stream's header lie there; a file of many short streams -- pbzip2, lbzip2 -- otherwise costs a synchronous
+    // 64-byte copy per stream, 14 us each): sorted window bases and the windows' bytes
+    std::vector<u64> pre_base;
+    std::vector<u8> pre_bytes;
     u32 byte_at(u64 i)
     {
         if (i >= nbytes) return 0;
+        if (!(base != ~0ull && i >= base && i < base + len) && !pre_base.empty()) {
+            // the last window that starts at or in front of byte i
+            size_t lo = 0, hi = pre_base.size();
+            while (lo < hi) {
+                const size_t mid = (lo + hi) >> 1;
+                if (pre_base[mid] <= i) lo = mid + 1; else hi = mid;
+            }
+            if (lo > 0 && i < pre_base[lo - 1] + 64u) return pre_bytes[(lo - 1) * 64u + (size_t)(i - pre_base[lo - 1])];
+        }
         if (base == ~0ull || i < base || i >= base + len) {
             base = i & ~(u64)15;
             len = (nbytes - base < sizeof(buf)) ? nbytes - base : sizeof(buf);
@@ -362,6 +377,29 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             HIPDEC(hipMemcpyAsync(d1_host, w->info.p, (size_t)d1_count * sizeof(DecBlockInfo), hipMemcpyDeviceToHost, st));
             HIPDEC(hipStreamSynchronize(st));
             stage_time(0);
+            // the 64 bytes behind every candidate's end, in one copy: what the chain below reads at stream ends
+            {
+                std::vector<u64> bases;
+                bases.reserve(d1_count);
+                for (u32 i = 0; i < d1_count; ++i) {
+                    const u64 b = (d1_host[i].end_bit >> 3) & ~(u64)15;
+                    if (b < n && (bases.empty() || bases.back() != b)) bases.push_back(b);
+                }
+                std::sort(bases.begin(), bases.end());
+                bases.erase(std::unique(bases.begin(), bases.end()), bases.end());
+                rd.pre_base.clear();
+                rd.pre_bytes.clear();
+                if (bases.size() >= 4) { // (a handful of streams: the copies on demand are as cheap)
+                    int prc;
+                    if ((prc = w->win_base.ensure(bases.size() * 8)) || (prc = w->win_bytes.ensure(bases.size() * 64))) return prc;
+                    HIPDEC(hipMemcpyAsync(w->win_base.p, bases.data(), bases.size() * 8, hipMemcpyHostToDevice, st));
+                    launch_dec_gather_windows(st, d_in, n, w->win_base.as<u64>(), (u32)bases.size(), w->win_bytes.as<u8>());
+                    rd.pre_bytes.resize(bases.size() * 64);
+                    HIPDEC(hipMemcpyAsync(rd.pre_bytes.data(), w->win_bytes.p, bases.size() * 64, hipMemcpyDeviceToHost, st));
+                    HIPDEC(hipStreamSynchronize(st));
+                    rd.pre_base.swap(bases);
+                }
+            }
         }
         if (d1_rec >= 0) { // algorithmic bytes of D1: the compressed bits of its candidates + 2 B per symbol
             u64 by = 0;

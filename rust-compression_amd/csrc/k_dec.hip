@@ -1472,6 +1472,30 @@ void launch_dec_blocks(hipStream_t st, const u8 *in, u64 nbytes, const DecCand *
     hipLaunchKernelGGL(k_dec_block, dim3(ncand), dim3(kD1Threads), 0, st, in, nbytes, cands, ncand, info, sym, sel_scratch);
 }
 
+// 64-byte windows of the input at the given (16-byte aligned) offsets, zeros behind the end of the input: what the host's
+// record chain reads at stream ends, fetched for a whole batch at once
+__global__ __launch_bounds__(256) void k_dec_gather_windows(const u8 *__restrict__ in, u64 nbytes, const u64 *__restrict__ bases, u32 nw,
+                                                            u8 *__restrict__ out)
+{
+    const u32 i = blockIdx.x * 256u + threadIdx.x; // one thread per 16-byte piece
+    if (i >= nw * 4u) return;
+    const u64 p = bases[i >> 2] + (u64)(i & 3u) * 16u;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (p + 16 <= nbytes) { // (the input is read as 32-bit words everywhere: no more alignment is asked of it)
+        const u32 *w = reinterpret_cast<const u32 *>(in + p);
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+    } else if (p < nbytes) {
+        u32 t[4] = {0, 0, 0, 0};
+        for (u64 b = p; b < nbytes; ++b) t[(b - p) >> 2] |= (u32)in[b] << (8u * ((b - p) & 3u));
+        v = make_uint4(t[0], t[1], t[2], t[3]);
+    }
+    reinterpret_cast<uint4 *>(out)[i] = v;
+}
+void launch_dec_gather_windows(hipStream_t st, const u8 *in, u64 nbytes, const u64 *bases, u32 nw, u8 *out)
+{
+    if (nw) hipLaunchKernelGGL(k_dec_gather_windows, dim3((nw * 4u + 255u) / 256u), dim3(256), 0, st, in, nbytes, bases, nw, out);
+}
+
 void launch_dec_mtf(hipStream_t st, const DecArgs &a, KernelProf *prof, int *rec)
 {
     *rec = prof ? prof->begin(st, KID_DEC_MTF, 0) : -1;
