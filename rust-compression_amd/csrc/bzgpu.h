@@ -445,6 +445,7 @@ struct DecArgs {
     // launch shapes that follow the batch (a level-1 block is a ninth of a level-9 one): 8192-byte tiles of the T-vector
     // sort and workgroups of 256 x 64-byte sub-tiles of the RLE1 undo per block
     u32 tiles, sub_wgs;
+    u32 cw;                       // workgroups of 256 MTF chunks per block the chunk kernels are launched with
     const u32 *slot;              // [nb] candidate slot (index into info / sym) of each true block, stream order
     const DecBlockInfo *info;     // [slots]
     const u16 *sym;               // [slots][kMtfStride] Huffman symbols

@@ -606,9 +606,19 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             {
                 // The launches of the T-vector sort and of the RLE1 undo follow the batch's largest block (bytes from the
                 // stream's level); small gain, low levels only (level 1: 64.3 -> 63 ms per GiB).
-                u32 max_bytes = 1;
-                for (u32 i = 0; i < nb; ++i) max_bytes = std::max(max_bytes, bmax[i]);
+                u32 max_bytes = 1, max_nsym = 1;
+                for (u32 i = 0; i < nb; ++i) {
+                    max_bytes = std::max(max_bytes, bmax[i]);
+                    max_nsym = std::max(max_nsym, hslot[bslot[i]].nsym);
+                }
                 static const bool full_grid = getenv("BZ_FULL_GRID") && atoi(getenv("BZ_FULL_GRID")) != 0;
+                // The chunk kernels: the workgroups the largest block's chunks need, made ODD.  Workgroups go round the eight
+                // XCDs and, inside an XCD, round its four shader engines: with FEW filled workgroups per block at a stride
+                // that shares a factor with 4 (level 1: one filled workgroup per block, the other 13 of a full slot's 14
+                // idle) the filled ones met on half or a quarter of the shader engines -- MTF stage of 1 GiB at level 1:
+                // 15.3 ms with 1 workgroup per block, 30 with 2, 59 with 4, 17 with 3 or 7, 32 with 14, 123 with 56.
+                const u32 cw_full = (kMaxMtfChunks + 255) / 256, chunks = (max_nsym + kMtfChunk - 1) / kMtfChunk;
+                a.cw = full_grid ? cw_full : (std::min<u32>(cw_full, std::max<u32>(1u, (chunks + 255) / 256)) | 1u);
                 a.tiles = full_grid ? kTilesPerBlock : std::min<u32>(kTilesPerBlock, (max_bytes + kSortTile - 1) / kSortTile);
                 a.sub_wgs = full_grid ? (kDecSubs + 255) / 256 : std::min<u32>((kDecSubs + 255) / 256, ((max_bytes + 63) / 64 + 255) / 256);
             }

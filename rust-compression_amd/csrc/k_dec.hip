@@ -532,10 +532,15 @@ __device__ __forceinline__ u32 imtf_pop(u32 &w0, u32 &w1, u32 *list, u32 r)
 __global__ __launch_bounds__(256) void k_dec_chunk_perm(DecArgs a)
 {
     __shared__ u32 s_list[256 * 65];
-    const u32 lb = blockIdx.y;
+    // (all workgroups of a block on one XCD, blocks dealt round-robin: with the block as grid.y the XCD of a block's
+    // FILLED workgroups was (workgroups per block x block) mod 8 -- a launch with an even number of workgroups per block,
+    // most of them idle, put the work on half, a quarter or one of the eight XCDs)
+    u32 wgx, lb;
+    xcd_remap(gridDim.x, a.nb, wgx, lb);
+    if (lb == 0xFFFFFFFFu) return;
     const u32 sl = a.slot[lb];
     const u32 nsym = a.info[sl].nsym;
-    const u32 chunk = blockIdx.x * 256u + threadIdx.x;
+    const u32 chunk = wgx * 256u + threadIdx.x;
     const u32 beg = chunk * kMtfChunk;
     if (beg >= nsym) return;
     const u32 end = (beg + kMtfChunk < nsym) ? beg + kMtfChunk : nsym;
@@ -631,11 +636,13 @@ __global__ __launch_bounds__(64) void k_dec_compose(DecArgs a)
 __global__ __launch_bounds__(256) void k_dec_chunk_emit(DecArgs a)
 {
     __shared__ u32 s_list[256 * 65];
-    const u32 lb = blockIdx.y;
+    u32 wgx, lb;
+    xcd_remap(gridDim.x, a.nb, wgx, lb); // (see k_dec_chunk_perm)
+    if (lb == 0xFFFFFFFFu) return;
     if (a.err[lb]) return;
     const u32 sl = a.slot[lb];
     const u32 nsym = a.info[sl].nsym;
-    const u32 chunk0 = blockIdx.x * 256u;
+    const u32 chunk0 = wgx * 256u;
     if (chunk0 * kMtfChunk >= nsym) return;
     const u32 nchunks = (nsym + kMtfChunk - 1) / kMtfChunk;
     {
@@ -1502,10 +1509,12 @@ void launch_dec_mtf(hipStream_t st, const DecArgs &a, KernelProf *prof, int *rec
     // (the chunk kernels keep the launch of a full slot, 14 workgroups per block, most of which leave at once: launched
     // with just the workgroups the chunks need the stage is SLOWER -- level 9: 9.5 ms per GiB against 8.3, level 1: 30.0
     // against 17.1 --, with one workgroup per CU twice as slow; profiles/r04_off_default_configs.md)
-    const u32 cw = (kMaxMtfChunks + 255) / 256;
-    hipLaunchKernelGGL(k_dec_chunk_perm, dim3(cw, a.nb), dim3(256), 0, st, a);
+    static const u32 cw_env = getenv("BZ_DEC_CW") ? (u32)atoi(getenv("BZ_DEC_CW")) : 0u; // (experiments: workgroups per block; too few = blocks cut short)
+    const u32 cw = cw_env ? cw_env : a.cw; // (odd: see dec_engine.hip)
+    const dim3 cgrid(cw, xcd_grid_y(a.nb));
+    hipLaunchKernelGGL(k_dec_chunk_perm, cgrid, dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dec_compose, dim3(a.nb), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(k_dec_chunk_emit, dim3(cw, a.nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_dec_chunk_emit, cgrid, dim3(256), 0, st, a);
     if (prof) prof->end(st, *rec);
 }
 
