@@ -929,7 +929,10 @@ __global__ __launch_bounds__(256) void k_emit_payload(HuffArgs a)
 // The tables travel between the kernels as lengths (glen), as 6 x 10-bit packed lengths per symbol (pack) and
 // as counts (rfreq).  BZ_HUFF_SPLIT=0 selects k_huffman.
 constexpr u32 kSweepThreads = 256;  // groups per sweep step
-constexpr u32 kSweepTilesX = 12;    // workgroups per block (each loops over its share of the group tiles)
+#ifndef BZ_SWEEP_TILES_X
+#define BZ_SWEEP_TILES_X 11 // odd: workgroups go round the XCDs and, inside one, round its four shader engines -- with 12 per
+#endif                      // block and three of them filled (level 1) the filled ones met on a part of the chip: 2.4 -> 2.0 ms per 256 MiB
+constexpr u32 kSweepTilesX = BZ_SWEEP_TILES_X; // workgroups per block (each loops over its share of the group tiles)
 // k_huff_tables' scratch arena in LDS: the heap procedure's work arrays (6 x (2 * 258 + 4) words), then -- they are
 // dead by then -- the package-merge scratch of as many tables at a time as fit (one of up to 40 symbols: text; larger
 // alphabets use global memory).  With the other arrays 24.6 KB per workgroup: six workgroups share a CU and every
