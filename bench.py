@@ -64,6 +64,9 @@ def parse_args():
                     help="seconds without progress after which a rank gives up with exit status 5")
     ap.add_argument("--extras-timeout", type=float, default=600.0,
                     help="N > 1: seconds the legs behind the headline may take before rank 0 prints the headline without them")
+    ap.add_argument("--preflight-timeout", type=float, default=240.0,
+                    help="N > 1: seconds the checks in front of the timed steps may take (transport self-test over the real "
+                         "communicator, peer copies between the devices) before rank 0 prints a line that says where they stood")
     ap.add_argument("--share-gpu", action="store_true",
                     help="ranks share the visible GPUs (rank r -> device r mod count) and talk over gloo: lets "
                          "the N > 1 path run on a box with fewer GPUs than ranks (not a scaling measurement)")
@@ -161,6 +164,86 @@ def load_json(*path):
         return json.load(open(p))
     except (OSError, ValueError):
         return {}
+
+
+def preflight(args, torch, dist, ctl, pkg, comm, rank, world, ndev, share, native, wire, dog, config_stub):
+    """N > 1, before anything is timed: the first contact with a multi-GPU node must be DIAGNOSABLE (VERDICT r4 item 6 --
+    RCCL with more than one rank and peer copies between two devices have only ever run in one-GPU emulation here).
+      (1) the communicator counts N ranks (ncclCommCount for the library's transport; a sum of ones over the process group
+          -- on the devices when the backend is nccl -- for torch.distributed's);
+      (2) bz_shard_comm_selftest over the REAL communicator with device buffers: the exchanges of bz_gpu_encode_sharded
+          (all-gather, the rank-to-rank chain, the variable-length gather) with known patterns, verdict shared by all ranks;
+      (3) rank 0: one hipMemcpyPeerAsync round trip per neighbour pair of the devices the end-to-end leg will drive
+          (bz_peer_copy_selftest; its failure only skips that leg -- the sharded path does not use peer copies).
+    A failure of (1) or (2), or no answer within --preflight-timeout, ends the run: rank 0 prints ONE JSON line with
+    "preflight" saying which stage and which ranks, every rank leaves with status 4 (a plain exit of a process that has
+    touched the GPU -- nothing is re-executed)."""
+    import threading
+    rec = {"backend": dist.get_backend(), "transport": "library RCCL" if native else "torch.distributed", "world": world,
+           "devices_visible": ndev, "ranks_share_gpus": bool(share), "stage": "start"}
+
+    def line(status):
+        out = dict(config_stub)
+        out.update({"value": None, "preflight": dict(rec, status=status)})
+        return json.dumps(out)
+
+    def expired():
+        if rank == 0:
+            print(line("no answer within %.0f s in stage '%s'" % (args.preflight_timeout, rec["stage"])), flush=True)
+        sys.stderr.write("bench.py: rank %d: preflight stood in stage '%s' for %.0f s: giving up\n" % (rank, rec["stage"], args.preflight_timeout))
+        sys.stderr.flush()
+        os._exit(4)
+    timer = threading.Timer(args.preflight_timeout, expired)
+    timer.daemon = True
+    timer.start()
+    mine = {"rank": rank, "errors": []}
+    try:
+        rec["stage"] = "communicator count"
+        if native:
+            mine["comm_count"] = int(comm.count())
+        else:
+            one = torch.ones(1, dtype=torch.int64, device=wire)
+            dist.all_reduce(one)
+            if wire.type == "cuda":
+                torch.cuda.synchronize()
+            mine["comm_count"] = int(one.item())
+        dog.beat("preflight: communicator count")
+        rec["stage"] = "transport self-test"
+        mine["selftest_status"] = int(pkg.lib().bz_shard_comm_selftest(ctypes.byref(comm.struct), 0))
+        mine["errors"] += [repr(e) for e in getattr(comm, "errors", [])]
+        if os.environ.get("BZ_BENCH_PREFLIGHT_FAIL") == str(rank):  # (tests: this rank's transport reports an error)
+            mine["errors"].append("injected by BZ_BENCH_PREFLIGHT_FAIL")
+        dog.beat("preflight: transport self-test")
+    except Exception as e:  # noqa: BLE001 -- reported in the line, whatever it is
+        mine["errors"].append(repr(e))
+    if rank == 0:
+        rec["stage"] = "peer copies"
+        devices = [r % ndev for r in range(world)] if share else list(range(world))
+        peer = (ctypes.c_int * world)()
+        ms = (ctypes.c_double * world)()
+        try:
+            prc = int(pkg.lib().bz_peer_copy_selftest((ctypes.c_int * world)(*devices), world, 1 << 20, peer, ms))
+        except Exception as e:  # noqa: BLE001
+            prc = -1
+            mine["errors"].append(repr(e))
+        rec["peer_copies"] = {"devices": devices, "status": prc, "peer_access": list(peer), "round_trip_ms": [round(x, 3) for x in ms],
+                              "note": "devices[i] -> devices[i + 1 mod N] and back, 1 MiB; peer_access 1: direct (xGMI), 0: through "
+                                      "the host, -1: both on one device"}
+        dog.beat("preflight: peer copies")
+    rec["stage"] = "verdicts"
+    every = [None] * world
+    dist.all_gather_object(every, mine, group=ctl)
+    timer.cancel()
+    rec["ranks"] = every
+    bad = [m["rank"] for m in every if m.get("comm_count") != world or m.get("selftest_status") != 0 or m["errors"]]
+    rec["stage"] = "done"
+    if bad:
+        if rank == 0:
+            print(line("FAILED on rank(s) %s" % bad), flush=True)
+        dist.barrier(group=ctl)
+        sys.exit(4)
+    rec["status"] = "ok"
+    return rec
 
 
 ENC_KERNELS = ("k_radix_hist", "k_radix_scan", "k_radix_scatter", "k_group_flags", "k_group_apply", "k_last_column",
@@ -262,6 +345,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    wire = torch.device("cpu") if (share or native or world == 1) else dev
+    pre = None
+    if world > 1:
+        pre = preflight(args, torch, dist, ctl, pkg, comm, rank, world, ndev, share, native, wire, dog,
+                        {"metric": "BZip2 level-%d encode MB/s" % args.level, "unit": "MB/s", "n_gpus": world, "steps": args.steps,
+                         "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "data": "synthetic"})
     die_at = os.environ.get("BZ_BENCH_DIE")  # tests: "<rank>:<step>" -- that rank dies in front of that timed step
     die_rank, die_step = (int(x) for x in die_at.split(":")) if die_at else (-1, -1)
     dog.beat("corpus and buffers ready")
@@ -287,7 +376,6 @@ def main():
     bstats = eng.bwt_stats()
     nblocks_rank = len(eng.block_stats())
     eng.profile(False)
-    wire = torch.device("cpu") if (share or native or world == 1) else dev
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=wire)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -337,7 +425,8 @@ def main():
         result = {
             "metric": "BZip2 level-%d encode MB/s (input bytes, HBM-resident in and out: the kernels' rate; value_end_to_end is "
                       "host buffer to host buffer at the C ABI)" % args.level,
-            "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 2), "value_is": "hbm_resident", "value_hbm_resident": round(value, 2),
+            "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "step_ms": step_stats(step_times),
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/u32", "data": "synthetic",
@@ -351,7 +440,9 @@ def main():
                        if multi else "one engine, one GPU",
                        "out_bytes": out_len, "ratio": round(out_len / n, 4),
                        "ranks": {"world": world, "backend": (dist.get_backend() if world > 1 else None),
-                                 "rccl_comm_count": (comm.count() if (multi and native) else None)}},
+                                 "rccl_comm_count": (comm.count() if (multi and native) else (pre["ranks"][0]["comm_count"] if pre else None)),
+                                 "rccl_comm_count_source": ("ncclCommCount" if (multi and native) else
+                                                            ("sum of ones over the %s process group" % dist.get_backend() if pre else None))}},
             "roofline": roofline,
             "kernel_seconds_last_step_rank0": {k: round(v, 5) for k, v in stages.items()},
             "bwt": bstats,
@@ -361,6 +452,8 @@ def main():
             "stream_sha256": sha,
             "checks": checks,
         }
+        if pre is not None:
+            result["preflight"] = pre
         if world > 1:
             chain = [t[1] for t in shard_all[:-1]]  # (the last rank hands nothing on)
             result["shard_chain"] = {"chain_ms_per_link": round(sum(chain) / len(chain), 3), "links_ms": chain,
@@ -445,7 +538,9 @@ def main():
         # bz_encode_buffer_multi == BZip2Encoder::with_devices, host buffer -> host buffer, H2D / D2H and the xGMI
         # hand-over of chunk tails inside the clock; the other ranks wait on the host (gloo), their GPUs idle
         leg["name"] = "end to end over all devices"
-        if rank == 0:
+        if rank == 0 and pre["peer_copies"]["status"] != 0:
+            result["end_to_end"] = {"skipped": "preflight: the peer copies between the devices failed (preflight.peer_copies)"}
+        elif rank == 0:
             devices = [r % ndev for r in range(world)] if share else list(range(world))
             try:
                 import numpy as np

@@ -145,6 +145,13 @@ void bz_free(void *p);
  * buffers (bz_decode_buffer, bz_dec_*, df_encode_buffer, df_enc_*) park ONE engine per device the same way (its decode
  * workspace: about 13 MB of HBM per block of the largest stream seen): released here too. */
 void bz_release_cached_resources(void);
+/* Diagnostic for hosts with several devices (no reference counterpart: the reference has no devices).  What a context
+ * over `devices` does when a job's unconsumed tail changes device -- hipMemcpyPeerAsync, across xGMI where peer access
+ * can be enabled, through the host where not -- done once per neighbour pair devices[i] -> devices[i + 1 mod n] with
+ * `bytes` (1 ... 2^30) of a known pattern, there and back, compared on the host.  peer_access[i] (may be NULL): 1 direct
+ * access enabled, 0 not offered, -1 both on one device (nothing copied); out_ms[i] (may be NULL): the round trip's wall
+ * time, -1 if the pair failed.  BZ_OK when every pair's bytes came back intact; a failing pair is named on stderr. */
+int bz_peer_copy_selftest(const int *devices, int n_devices, size_t bytes, int *peer_access, double *out_ms);
 
 /* ========================================================================
  * 2. Device-resident engine (what bz_enc drives; also the bench / multi-GPU

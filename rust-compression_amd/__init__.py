@@ -80,7 +80,7 @@ EXPORTS = [
     "bz_strerror", "bz_version", "bz_device_count",
     "bz_enc_create", "bz_enc_write", "bz_enc_end", "bz_enc_read", "bz_enc_pending", "bz_enc_destroy",
     "bz_encode_buffer", "bz_free", "bz_enc_create_multi", "bz_enc_set_verify", "bz_enc_verify_stats", "bz_enc_phase_stats", "bz_encode_buffer_last_phases",
-    "bz_gpu_engine_set_verify", "bz_gpu_verify_stats", "bz_encode_buffer_multi", "bz_release_cached_resources",
+    "bz_gpu_engine_set_verify", "bz_gpu_verify_stats", "bz_encode_buffer_multi", "bz_release_cached_resources", "bz_peer_copy_selftest",
     "bz_gpu_engine_create", "bz_gpu_engine_destroy", "bz_gpu_engine_reserve", "bz_encode_bound", "bz_gpu_encode_device",
     "bz_gpu_partition", "bz_gpu_partition_slab_begin", "bz_gpu_partition_slab_count",
     "bz_gpu_partition_slab_finish", "bz_gpu_block_count", "bz_gpu_encode_blocks", "bz_gpu_assemble", "bz_gpu_encode_sharded",
@@ -154,6 +154,7 @@ def lib():
     L.bz_gpu_verify_stats.argtypes = [vp, u64p]
     L.bz_release_cached_resources.restype = None
     L.bz_release_cached_resources.argtypes = []
+    L.bz_peer_copy_selftest.argtypes = [C.POINTER(C.c_int), C.c_int, sz, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.bz_free.restype = None
     L.bz_free.argtypes = [vp]
     L.bz_gpu_engine_create.argtypes = [C.POINTER(vp), C.c_int, sz]

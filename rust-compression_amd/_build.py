@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libbz2_mi355x.so")
 SOURCES = ["k_rle1.hip", "k_bwt.hip", "k_mtf.hip", "k_huff.hip", "k_emit.hip", "k_dec.hip", "k_deflate.hip", "engine.hip", "dec_engine.hip", "deflate_engine.hip", "capi.hip"]
-HEADERS = ["bzgpu.h", "engine_state.h", "bz2_rnums.h", "k_deflate.h", os.path.join("..", "..", "include", "bz2_mi355x.h")]
+HEADERS = ["bzgpu.h", "engine_state.h", "copy_pool.h", "bz2_rnums.h", "k_deflate.h", os.path.join("..", "..", "include", "bz2_mi355x.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function",
          "-D__HIP_PLATFORM_AMD__"] + os.environ.get("BZ_EXTRA_FLAGS", "").split()

@@ -295,10 +295,12 @@ struct RleBuffers {
 struct CutPlan {
     u64 L;          // bytes a block holds before the chunk that closes it (100000 level - 19)
     u64 g_base;     // image offset of the first byte of tile tb (tile_off is relative to it)
-    u64 own_hi;     // g_base + tile_off[t1]: the targets in (g_base, own_hi] are answered here
+    u64 own_hi;     // g_base + tile_off[t1]: a target is answered here if the chunk that closes its block ENDS in (g_base, own_hi]
+    u64 w_min;      // smallest such target: g_base - 3 (a chunk that ends at g_base + 1 holds up to five bytes), 1 for g_base < 4
     u64 j_lo, j_hi; // the steps (= blocks of the whole input) with such targets
     u64 tb, t1;     // the tiles of the range
     u64 t_last;     // last tile whose bytes may be read (t1: there is a tile behind the range; else t1 - 1)
+    u64 t_eval;     // last tile whose chunk ends answer targets (t1 - 1: a chunk that ends behind the range is the next rank's)
 };
 struct CutBuffers {
     u64 *step_t0; // [steps] first tile of a step's targets

@@ -269,6 +269,94 @@ static void resources_put(EncResources *r)
 
 // What a finished context leaves behind for the next one -- engines with their batch workspace (about 31.5 MB per
 // block of the largest job seen), device staging buffers, 2 x chunk of pinned host memory -- is released here.
+// ---- diagnostic for hosts with several devices -------------------------------------------------------------------------
+// What a context over `devices` does between consecutive lanes when a job's unconsumed tail changes device
+// (job_split: hipMemcpyPeerAsync, across xGMI where peer access can be enabled, through the host where not), done once
+// per neighbour pair devices[i] -> devices[i + 1 mod n] with a known pattern, there and back, and compared on the host.
+// peer_access[i]: 1 direct access enabled, 0 not offered (the copy goes through the host), -1 both lanes on one device
+// (nothing copied); out_ms[i]: the round trip's wall time, -1 if the pair failed.  BZ_OK when every pair's bytes came
+// back intact; the first HIP error is printed with the pair it belongs to.  No reference counterpart (the reference has
+// no devices); bench.py's preflight and INTEGRATION.md use it to make a first contact with a multi-GPU host diagnosable.
+extern "C" int bz_peer_copy_selftest(const int *devices, int n_devices, size_t bytes, int *peer_access, double *out_ms)
+{
+    if (!devices || n_devices < 1 || bytes == 0 || bytes > ((size_t)1 << 30)) return BZ_E_PARAM;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BZ_E_NOGPU;
+    for (int i = 0; i < n_devices; ++i)
+        if (devices[i] < 0 || devices[i] >= ndev) return BZ_E_PARAM;
+    int caller_device = -1;
+    (void)hipGetDevice(&caller_device);
+    std::vector<uint8_t> pat(bytes), back(bytes);
+    for (size_t i = 0; i < bytes; ++i) pat[i] = (uint8_t)(i * 131u + (i >> 8) * 7u + 5u);
+    int rc = BZ_OK;
+    for (int i = 0; i < n_devices; ++i) {
+        const int a = devices[i], b = devices[(i + 1) % n_devices];
+        if (peer_access) peer_access[i] = -1;
+        if (out_ms) out_ms[i] = 0.0;
+        if (a == b) continue;
+        int can_ab = 0, can_ba = 0;
+        (void)hipDeviceCanAccessPeer(&can_ab, a, b);
+        (void)hipDeviceCanAccessPeer(&can_ba, b, a);
+        if (can_ab && hipSetDevice(a) == hipSuccess) (void)hipDeviceEnablePeerAccess(b, 0);
+        if (can_ba && hipSetDevice(b) == hipSuccess) (void)hipDeviceEnablePeerAccess(a, 0);
+        (void)hipGetLastError(); // (already enabled: not an error worth keeping)
+        if (peer_access) peer_access[i] = (can_ab && can_ba) ? 1 : 0;
+        void *da = nullptr, *db = nullptr, *da2 = nullptr;
+        hipStream_t sa = nullptr, sb = nullptr;
+        hipError_t he = hipSuccess;
+        const char *what = "hipSetDevice";
+        const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        do {
+            if ((he = hipSetDevice(a)) != hipSuccess) break;
+            what = "hipMalloc";
+            if ((he = hipMalloc(&da, bytes)) != hipSuccess || (he = hipMalloc(&da2, bytes)) != hipSuccess) break;
+            what = "hipStreamCreate";
+            if ((he = hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)) != hipSuccess) break;
+            what = "hipMemcpy (host to device)";
+            if ((he = hipMemcpy(da, pat.data(), bytes, hipMemcpyHostToDevice)) != hipSuccess) break;
+            if ((he = hipMemset(da2, 0, bytes)) != hipSuccess) break;
+            what = "hipSetDevice";
+            if ((he = hipSetDevice(b)) != hipSuccess) break;
+            what = "hipMalloc";
+            if ((he = hipMalloc(&db, bytes)) != hipSuccess) break;
+            what = "hipStreamCreate";
+            if ((he = hipStreamCreateWithFlags(&sb, hipStreamNonBlocking)) != hipSuccess) break;
+            // there: on a stream of the RECEIVING device, as job_split queues it (the lane that takes the tail owns the copy)
+            what = "hipMemcpyPeerAsync (there)";
+            if ((he = hipMemcpyPeerAsync(db, b, da, a, bytes, sb)) != hipSuccess) break;
+            if ((he = hipStreamSynchronize(sb)) != hipSuccess) break;
+            what = "hipMemcpyPeerAsync (back)";
+            if ((he = hipSetDevice(a)) != hipSuccess) break;
+            if ((he = hipMemcpyPeerAsync(da2, a, db, b, bytes, sa)) != hipSuccess) break;
+            if ((he = hipStreamSynchronize(sa)) != hipSuccess) break;
+            what = "hipMemcpy (device to host)";
+            if ((he = hipMemcpy(back.data(), da2, bytes, hipMemcpyDeviceToHost)) != hipSuccess) break;
+        } while (false);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        bool ok = he == hipSuccess;
+        if (!ok) {
+            fprintf(stderr, "bz2_mi355x: peer copy self-test, devices %d -> %d: %s failed: %s\n", a, b, what, hipGetErrorString(he));
+            (void)hipGetLastError();
+        } else if (memcmp(back.data(), pat.data(), bytes) != 0) {
+            fprintf(stderr, "bz2_mi355x: peer copy self-test, devices %d -> %d -> %d: the bytes came back changed\n", a, b, a);
+            ok = false;
+        }
+        if (sa && hipSetDevice(a) == hipSuccess) (void)hipStreamDestroy(sa);
+        if (hipSetDevice(a) == hipSuccess) {
+            if (da) (void)hipFree(da);
+            if (da2) (void)hipFree(da2);
+        }
+        if (hipSetDevice(b) == hipSuccess) {
+            if (sb) (void)hipStreamDestroy(sb);
+            if (db) (void)hipFree(db);
+        }
+        if (out_ms) out_ms[i] = ok ? ms : -1.0;
+        if (!ok) rc = BZ_E_UNEXPECTED;
+    }
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
+    return rc;
+}
+
 extern "C" void bz_release_cached_resources(void)
 {
     std::vector<EncResources *> all;
@@ -512,7 +600,7 @@ struct JobState {
     size_t n_all = 0, n_eff = 0, n_blocks = 0, consumed = 0;
     size_t out_len = 0;
     int tail = 0;
-    bool skipped = false; // input after Finish
+    int mode = BZ_ACTION_RUN; // the job's Action as EncoderInner sees it: behind a Finish, flush() and finish() do nothing any more
     std::vector<uint64_t> woff, blen;
     std::vector<uint32_t> crc;
     double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
@@ -531,18 +619,12 @@ static int job_split(bz_enc *e, const EncJob &j, int lane, JobState &js)
 {
     EncResources *r = e->r;
     Lane &ln = r->lanes[(size_t)lane];
-    if (e->finish_seen) {
-        // Input that arrives after Finish is not encoded.  (The reference keeps collecting it, EncoderInner::next
-        // has no `finished` test, encoder.rs:671-697, and would write further blocks BEHIND the trailer once
-        // another 900 KB have come in; flush() and finish() do nothing any more, :718-739.  Such output is no
-        // .bz2 stream; the corner is not mirrored -- documented in INTEGRATION.md.)
-        js.skipped = true;
-        if (j.n) {
-            if (hipEventSynchronize(ln.ev_up) != hipSuccess) return BZ_E_UNEXPECTED;
-            chunk_composed(e, lane);
-        }
-        return BZ_OK;
-    }
+    // Input that arrives after Finish goes on being collected as the reference does it: EncoderInner::next has no
+    // `finished` test (encoder.rs:671-697), so a block is written -- BEHIND the trailer, without a header unless no block
+    // has been written yet -- whenever another 100000 * level - 19 bytes have come together, while flush() and finish()
+    // do nothing any more (:718-739): every later job is a Run job, whatever the caller's Action.  (Such output is no
+    // .bz2 stream; it is what the reference yields, tests/test_gpu_parity.py::test_streaming_write_after_finish.)
+    js.mode = e->finish_seen ? BZ_ACTION_RUN : j.mode;
     if (!ln.g) { // a lane's engine is created when the lane gets its first job
         const int rc = bz_gpu_engine_create(&ln.g, ln.device, r->engine_blocks);
         if (rc != BZ_OK) return rc;
@@ -580,31 +662,31 @@ static int job_split(bz_enc *e, const EncJob &j, int lane, JobState &js)
     }
     js.n_eff = js.n_all;
     int rc;
-    if (j.mode != BZ_ACTION_FINISH && (rc = pending_chunk_start(js.d, js.n_all, j.n, j.tail_run, &js.n_eff)) != BZ_OK)
+    if (js.mode != BZ_ACTION_FINISH && (rc = pending_chunk_start(js.d, js.n_all, j.n, j.tail_run, &js.n_eff)) != BZ_OK)
         return rc;
     if (js.n_eff > 0) {
-        rc = bz_gpu_partition(ln.g, e->level, js.d, js.n_eff, j.mode, &js.n_blocks, &js.consumed, &js.tail);
+        rc = bz_gpu_partition(ln.g, e->level, js.d, js.n_eff, js.mode, &js.n_blocks, &js.consumed, &js.tail);
         if (rc != BZ_OK) return rc;
     }
     js.t1 = now_ms();
     // the bytes that went into blocks; what is left is the next job's tail
     size_t drop;
-    if (j.mode == BZ_ACTION_RUN) drop = js.n_blocks ? js.consumed : 0;
-    else if (j.mode == BZ_ACTION_FLUSH) drop = js.n_eff;
+    if (js.mode == BZ_ACTION_RUN) drop = js.n_blocks ? js.consumed : 0;
+    else if (js.mode == BZ_ACTION_FLUSH) drop = js.n_eff;
     else drop = js.n_all;
     if (js.n_all) { // (a job without any input leaves the tail where it is)
         e->tail_lane = lane;
         e->tail_off = drop;
         e->tail_len = js.n_all - drop;
     }
-    if (j.mode == BZ_ACTION_FINISH) e->finish_seen = true;
+    if (js.mode == BZ_ACTION_FINISH) e->finish_seen = true;
     return BZ_OK;
 }
 
 static int job_encode(bz_enc *e, int lane, JobState &js)
 {
     Lane &ln = e->r->lanes[(size_t)lane];
-    if (js.skipped || js.n_blocks == 0) {
+    if (js.n_blocks == 0) {
         js.t2 = now_ms();
         return BZ_OK;
     }
@@ -631,9 +713,9 @@ static int job_encode(bz_enc *e, int lane, JobState &js)
 static int job_assemble(bz_enc *e, const EncJob &j, int lane, JobState &js)
 {
     Lane &ln = e->r->lanes[(size_t)lane];
-    const int mode = j.mode;
+    (void)j;
+    const int mode = js.mode;
     const size_t n_blocks = js.n_blocks;
-    if (js.skipped) return BZ_OK;
     if (mode == BZ_ACTION_RUN && n_blocks == 0) return BZ_OK; // no write_block call happened
 
     // The flush()/finish() call itself sees an empty block_buf when every byte went into
@@ -748,7 +830,7 @@ static void worker_main(bz_enc *e, int lane)
         {
             std::lock_guard<std::mutex> lk(e->mu);
             if (rc != BZ_OK && e->err == BZ_OK) e->err = rc;
-            if (!js.skipped && js.t1 > 0) {
+            if (js.t1 > 0) {
                 e->phase_ms[2] += js.t1 - js.t0;
                 e->phase_ms[3] += tw2 - js.t1;
                 e->phase_ms[4] += js.t3 - tw3;
@@ -1029,7 +1111,9 @@ extern "C" int bz_enc_end(bz_enc *e, int action)
     // copy of EncoderInner.finished, which a worker sets only when the Finish job is assembled.  A job
     // that is waited for has every earlier job in front of it done, too: assembly is in job order.)
     // blocks the reference would already have emitted while it was consuming the input
-    if (!e->finish_submitted && action == BZ_ACTION_RUN) {
+    // (behind a Finish every Action is a Run for EncoderInner: flush() and finish() do nothing, but the bytes the iterator
+    // yielded have gone through EncoderInner::next -- encoder.rs:80-85 -- and the blocks they completed come out)
+    if (action == BZ_ACTION_RUN ? !e->finish_submitted || e->fill : e->finish_submitted && e->fill) {
         if ((rc = submit(e, BZ_ACTION_RUN, true)) != BZ_OK) return rc;
     }
     for (;;) {

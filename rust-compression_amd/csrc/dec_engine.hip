@@ -10,9 +10,13 @@
 // all blocks in front of the failing record are produced, then the error (a block CRC mismatch
 // is only noticed after that block's bytes were handed out, decoder.rs:189-201).
 #include "engine_state.h"
+#include "copy_pool.h"
 
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <sys/mman.h>
+#include <thread>
 #include <utility>
 
 #include <algorithm>
@@ -29,7 +33,7 @@ struct DecWorkspace {
     size_t slots = 0;
     DevBuf win_base, win_bytes; // the chain's windows behind the blocks' ends (see DevBits)
     DevBuf cands, count, info, sym, sel, slot, nbmax, perm, chunk_emit, tt_len, err, L, T, X, samp_next, samp_len,
-        samp_off, cycle_len, sub_trans, sub_off, sub_state, work_ctr, walk_meta, seg_buf, seg_cont, long_list, out_len, thist, tbase, crc, out_base, staging, cand_all;
+        samp_off, cycle_len, sub_trans, sub_off, sub_state, work_ctr, walk_meta, seg_buf, seg_cont, long_list, out_len, thist, tbase, crc, out_base, staging, staging2, cand_all;
     hipEvent_t ev_a = nullptr, ev_b = nullptr; // fork / join of the second walk
     double t_stage[5] = {0, 0, 0, 0, 0};
     u64 stats[4] = {0, 0, 0, 0}; // candidates, blocks, streams, forced blocks
@@ -41,7 +45,7 @@ void dec_workspace_free(DecWorkspace *w)
     DevBuf *all[] = {&w->win_base, &w->win_bytes, &w->cands, &w->count, &w->info, &w->sym, &w->sel, &w->slot, &w->nbmax, &w->perm,
                      &w->chunk_emit, &w->tt_len, &w->err, &w->L, &w->T, &w->X, &w->samp_next, &w->samp_len,
                      &w->samp_off, &w->cycle_len, &w->sub_trans, &w->sub_off, &w->sub_state, &w->work_ctr, &w->walk_meta, &w->seg_buf, &w->seg_cont, &w->long_list, &w->out_len, &w->thist, &w->tbase,
-                     &w->crc, &w->out_base, &w->staging, &w->cand_all};
+                     &w->crc, &w->out_base, &w->staging, &w->staging2, &w->cand_all};
     for (DevBuf *b : all) b->release();
     if (w->ev_a) (void)hipEventDestroy(w->ev_a);
     if (w->ev_b) (void)hipEventDestroy(w->ev_b);
@@ -174,7 +178,8 @@ struct Sink {
     u64 cap = 0;
     bool dry = false;    // sizes only
     HostBuf *host = nullptr; // host destination (one-shot over host buffers, the streaming context)
-    DevBuf *staging = nullptr;
+    DevBuf *staging[2] = {nullptr, nullptr}; // ... through these, batch by batch in turn
+    CopyPool *pool = nullptr; // ... copied by these threads while the next batch's kernels run (nullptr: one hipMemcpy per batch)
     u64 produced = 0;
 };
 
@@ -309,6 +314,20 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
         c1 = nc * (size_t)(sh->rank + 1) / (size_t)sh->world;
         B = (u32)std::max<size_t>(c1 - c0, 1);
     }
+    if (sink.host && sink.pool && !sh) {
+        // Host destination: smaller batches, so that the copy of batch k to the caller's memory (sink.pool's threads)
+        // runs beside the kernels of batch k + 1 -- with one batch per GiB the download stood behind the whole decode
+        // (118 ms per GiB host to host against 48 ms of kernels).
+        u32 hb = 320;
+        if (const char *e = getenv("BZ_DEC_HOST_BATCH")) {
+            const long v = atol(e);
+            if (v >= 1 && v <= 65536) hb = (u32)v;
+        }
+        // (equal batches: 1189 blocks are 4 x 298, not 3 x 320 + 229)
+        const size_t nbat = (nc + hb - 1) / hb;
+        if (nbat > 1) hb = (u32)((nc + nbat - 1) / nbat);
+        if (hb < B) B = hb;
+    }
     if (nc < B) B = (u32)(nc ? nc : 1);
     const u32 B_want = B;
     {
@@ -357,6 +376,18 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
     u32 next_head = 0, next_bits = 0;
     size_t ci = 0;
     bool finished = false;
+    // host destination: the copies out of the two staging buffers (see Sink); whatever way this function is left, the
+    // copies in flight are over when it returns (the staging buffers and the caller's buffer outlive them)
+    struct PoolGuard {
+        CopyPool *p;
+        ~PoolGuard()
+        {
+            if (p) p->wait_all();
+        }
+    } pool_guard{sink.host ? sink.pool : nullptr};
+    u32 batch_no = 0;
+    size_t stage_ticket[2] = {0, 0};
+    bool stage_busy[2] = {false, false};
 
     while (!finished) {
         // ---- D1 over the next batch of candidates
@@ -702,9 +733,14 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             } else if (good) {
                 u8 *dst = nullptr;
                 if (sink.host) {
-                    const int rc = sink.staging->ensure(bytes + 64);
+                    const u32 sb = batch_no & 1u;
+                    if (stage_busy[sb]) { // the copy of the batch before the last one reads this buffer
+                        sink.pool->wait(stage_ticket[sb]);
+                        stage_busy[sb] = false;
+                    }
+                    const int rc = sink.staging[sb]->ensure(bytes + 64);
                     if (rc) return rc;
-                    dst = sink.staging->as<u8>();
+                    dst = sink.staging[sb]->as<u8>();
                 } else {
                     if (sink.produced + bytes > sink.cap) {
                         if (!sh) return BZ_E_CAPACITY;
@@ -742,10 +778,28 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                 }
                 if (sink.host) {
                     const size_t old = sink.host->len;
-                    const int hrc = sink.host->reserve(old + valid);
-                    if (hrc != BZ_OK) return hrc;
-                    if (valid) HIPDEC(hipMemcpy(sink.host->p + old, dst, valid, hipMemcpyDeviceToHost));
-                    sink.host->len = old + valid;
+                    if (old + valid > sink.host->cap) {
+                        // room for the rest of the file too, going by this batch's bytes per block (growing moves the
+                        // buffer: copies in flight are waited for, and every growth copies what is there)
+                        if (sink.pool) sink.pool->wait_all();
+                        stage_busy[0] = stage_busy[1] = false;
+                        size_t want = old + valid;
+                        const size_t rest = nc > ci ? nc - ci : 0; // candidates behind this batch
+                        if (rest && keep) want += (size_t)((double)valid / (double)keep * (double)rest * 1.02) + ((size_t)1 << 20);
+                        const int hrc = sink.host->reserve(want);
+                        if (hrc != BZ_OK) return hrc;
+                    }
+                    if (valid) {
+                        if (sink.pool) {
+                            const u32 sb = batch_no & 1u;
+                            stage_ticket[sb] = sink.pool->submit(sink.host->p + old, dst, valid, hipMemcpyDeviceToHost);
+                            stage_busy[sb] = true;
+                        } else {
+                            HIPDEC(hipMemcpy(sink.host->p + old, dst, valid, hipMemcpyDeviceToHost));
+                        }
+                    }
+                    sink.host->len = old + valid; // (bytes whose copies may still be in flight: settled before this function returns)
+                    batch_no += 1;
                 }
                 sink.produced += valid;
                 } // shard_rc == BZ_OK
@@ -804,6 +858,10 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             w->stats[2] = stream_no;
             finished = true;
         }
+    }
+    if (sink.host && sink.pool) {
+        sink.pool->wait_all();
+        if (sink.pool->failed()) return BZ_E_UNEXPECTED;
     }
     if (prof) prof->collect();
     if (rs) {
@@ -963,15 +1021,29 @@ extern "C" int bz_decode_buffer(int device, const uint8_t *in, size_t in_len, ui
     int verdict = BZ_OK;
     rc = hipSetDevice(device) == hipSuccess ? g->dec_in.ensure(in_len + 64) : BZ_E_UNEXPECTED;
     if (rc == BZ_OK) {
+        // Both copies of the call on a few threads (copy_pool.h): the upload in slices side by side, the decoded bytes batch
+        // by batch beside the kernels of the next batch.  BZ_DEC_OVERLAP=0: one hipMemcpy each way, one batch (rounds 1-4).
+        static const bool overlap = !(getenv("BZ_DEC_OVERLAP") && atoi(getenv("BZ_DEC_OVERLAP")) == 0);
+        CopyPool pool(device);
         rc = BZ_E_UNEXPECTED;
         // (the 64 bytes behind the stream are read as zeros by the bit readers)
-        if (hipMemsetAsync(static_cast<u8 *>(g->dec_in.p) + in_len, 0, 64, g->st) == hipSuccess &&
-            (!in_len || hipMemcpyAsync(g->dec_in.p, in, in_len, hipMemcpyHostToDevice, g->st) == hipSuccess) &&
-            hipStreamSynchronize(g->st) == hipSuccess) {
+        bool up = hipMemsetAsync(static_cast<u8 *>(g->dec_in.p) + in_len, 0, 64, g->st) == hipSuccess;
+        if (up && in_len) {
+            if (overlap && in_len >= ((size_t)16 << 20)) {
+                pool.submit(g->dec_in.p, in, in_len, hipMemcpyHostToDevice);
+                pool.wait_all();
+                up = !pool.failed();
+            } else {
+                up = hipMemcpyAsync(g->dec_in.p, in, in_len, hipMemcpyHostToDevice, g->st) == hipSuccess;
+            }
+        }
+        if (up && hipStreamSynchronize(g->st) == hipSuccess) {
             if (!g->dec) g->dec = new DecWorkspace();
             Sink sink;
             sink.host = &host;
-            sink.staging = &g->dec->staging;
+            sink.staging[0] = &g->dec->staging;
+            sink.staging[1] = &g->dec->staging2;
+            sink.pool = overlap ? &pool : nullptr;
             rc = decode_core(g, static_cast<const u8 *>(g->dec_in.p), in_len, sink, &verdict);
         }
     }
@@ -988,68 +1060,131 @@ extern "C" int bz_decode_buffer(int device, const uint8_t *in, size_t in_len, ui
 }
 
 // ---- streaming mirror of BZip2Decoder (decoder.rs:583-612) ------------------------------------------------
-// The reference pulls input bytes on demand and yields output bytes one by one.  Here compressed
-// bytes are collected (bz_dec_write); whenever BZ_DEC_CHUNK bytes (default 256 MiB) have come in,
-// and when the input ends (bz_dec_end), the records that are wholly there are decoded and their
-// bytes queued (bz_dec_read).  The chain's state (bit position, stream number, level, combined
-// CRC) is carried between the calls, the bytes from the first undecided record on are kept.  An
-// error, if any, is reported after the bytes in front of it -- the same sequence of items the
-// reference's iterator produces; memory is bounded by the chunk, not by the file.
+// The reference pulls input bytes on demand and yields output bytes one by one.  Here compressed bytes are collected
+// (bz_dec_write); whenever BZ_DEC_CHUNK bytes (default 32 MiB) have come in, and when the input ends (bz_dec_end), they go
+// to the context's WORKER thread, which decodes the records that are wholly there and queues their bytes (bz_dec_read)
+// -- while the caller goes on writing and reading: the caller's copies (compressed bytes in, decoded bytes out: a GiB of
+// them is 0.1 s of one core) run beside the upload, the kernels and the download of the next chunk instead of in a row
+// with them (rounds 1-4 decoded inside bz_dec_write: 4.2 GB/s for what the kernels do at 22).  The chain's state (bit
+// position, stream number, level, combined CRC) is carried from chunk to chunk, the bytes from the first undecided
+// record on are kept.  An error, if any, is reported after the bytes in front of it -- the same sequence of items the
+// reference's iterator produces; memory is bounded by the chunks in flight (two at most wait for the worker), not by
+// the file.
+namespace {
+struct DecJob {
+    std::vector<u8> bytes;
+    bool final = false;
+};
+struct DecSeg { // decoded bytes of one chunk, handed out from `pos` on
+    HostBuf buf;
+    size_t pos = 0;
+};
+} // namespace
 struct bz_dec {
     int device = 0;
     bz_gpu_engine *g = nullptr;
-    std::vector<u8> in;  // compressed bytes from the next record on
-    Resume rs;
-    HostBuf out;         // decoded bytes not yet handed out
-    size_t out_pos = 0;
-    DevBuf d_in;
-    size_t chunk = (size_t)256 << 20;
-    bool ended = false, done = false; // done: the verdict is final (error, or clean end)
+    size_t chunk = (size_t)32 << 20;
+    // the caller's side
+    std::vector<u8> in; // compressed bytes not yet handed to the worker
+    bool ended = false;
+    // shared (mu)
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<DecJob> jobs;
+    std::deque<DecSeg *> outq;
+    size_t out_bytes = 0;                // queued and not yet read
+    u64 submitted = 0, processed = 0;    // jobs
+    bool stop = false;
+    bool done = false;                   // the verdict is final (error, or clean end): later input is ignored
     int verdict = BZ_OK;
+    // the worker's side
+    std::thread worker;
+    std::vector<u8> work; // compressed bytes from the next record on
+    Resume rs;
+    DevBuf d_in;
+    CopyPool *pool = nullptr;
 };
 
-static int dec_drain(bz_dec *d, bool final)
+// the worker: one chunk (everything not yet decided + the new bytes)
+static void dec_process(bz_dec *d, DecJob &j)
 {
-    if (d->done) return d->verdict;
+    auto finish = [&](int v) {
+        std::lock_guard<std::mutex> lk(d->mu);
+        d->done = true;
+        d->verdict = v;
+    };
     if (!d->g) { // (an engine kept by an earlier one-shot call or context, with its workspace, or a new one)
         d->g = dec_cache_take(d->device);
         const int rc = d->g ? BZ_OK : bz_gpu_engine_create(&d->g, d->device, 0);
-        if (rc != BZ_OK) {
-            d->done = true;
-            return d->verdict = rc;
-        }
+        if (rc != BZ_OK) return finish(rc);
     }
-    if (d->out_pos) { // drop what has been read
-        d->out.drop_front(d->out_pos);
-        d->out_pos = 0;
-    }
-    const size_t n = d->in.size();
+    if (d->work.empty()) d->work.swap(j.bytes);
+    else d->work.insert(d->work.end(), j.bytes.begin(), j.bytes.end());
+    const size_t n = d->work.size();
     int rc = hipSetDevice(d->device) == hipSuccess ? d->d_in.ensure(n + 64) : BZ_E_UNEXPECTED;
     // (the 64 bytes behind the input are read as zeros by the bit readers)
     if (rc == BZ_OK && hipMemset(static_cast<u8 *>(d->d_in.p) + n, 0, 64) != hipSuccess) rc = BZ_E_UNEXPECTED;
-    if (rc == BZ_OK && n && hipMemcpy(d->d_in.p, d->in.data(), n, hipMemcpyHostToDevice) != hipSuccess) rc = BZ_E_UNEXPECTED;
+    if (rc == BZ_OK && n) {
+        if (d->pool && n >= ((size_t)16 << 20)) {
+            d->pool->submit(d->d_in.p, d->work.data(), n, hipMemcpyHostToDevice);
+            d->pool->wait_all();
+            if (d->pool->failed()) rc = BZ_E_UNEXPECTED;
+        } else if (hipMemcpy(d->d_in.p, d->work.data(), n, hipMemcpyHostToDevice) != hipSuccess) {
+            rc = BZ_E_UNEXPECTED;
+        }
+    }
     int verdict = BZ_OK;
+    DecSeg *seg = new DecSeg();
     if (rc == BZ_OK) {
         if (!d->g->dec) d->g->dec = new DecWorkspace();
         Sink sink;
-        sink.host = &d->out;
-        sink.staging = &d->g->dec->staging;
-        d->rs.final = final;
+        sink.host = &seg->buf;
+        sink.staging[0] = &d->g->dec->staging;
+        sink.staging[1] = &d->g->dec->staging2;
+        sink.pool = d->pool;
+        d->rs.final = j.final;
         rc = decode_core(d->g, d->d_in.as<u8>(), n, sink, &verdict, nullptr, &d->rs);
     }
-    if (rc != BZ_OK || verdict != BZ_OK) {
-        d->done = true;
-        return d->verdict = (rc != BZ_OK ? rc : verdict);
+    // the bytes in front of an error are handed over too, as the reference's iterator yields them
+    if (rc == BZ_OK && seg->buf.len) {
+        std::lock_guard<std::mutex> lk(d->mu);
+        d->out_bytes += seg->buf.len;
+        d->outq.push_back(seg);
+    } else {
+        delete seg;
     }
+    if (rc != BZ_OK || verdict != BZ_OK) return finish(rc != BZ_OK ? rc : verdict);
     if (d->rs.stopped) { // keep the input from the undecided record on
         const size_t used = (size_t)(d->rs.pos >> 3);
-        d->in.erase(d->in.begin(), d->in.begin() + (ptrdiff_t)used);
+        d->work.erase(d->work.begin(), d->work.begin() + (ptrdiff_t)used);
         d->rs.pos &= 7u;
-        return BZ_OK;
+        return;
     }
-    d->in.clear();
-    d->done = true; // the file ended cleanly
-    return d->verdict = BZ_OK;
+    d->work.clear();
+    finish(BZ_OK); // the file ended cleanly
+}
+
+static void dec_worker(bz_dec *d)
+{
+    for (;;) {
+        DecJob j;
+        bool skip;
+        {
+            std::unique_lock<std::mutex> lk(d->mu);
+            d->cv.wait(lk, [&] { return d->stop || !d->jobs.empty(); });
+            if (d->jobs.empty()) return;
+            j = std::move(d->jobs.front());
+            d->jobs.pop_front();
+            skip = d->done; // (an error is waiting behind the queued bytes; further input is ignored)
+        }
+        d->cv.notify_all(); // (a writer may be waiting for room in the queue)
+        if (!skip) dec_process(d, j);
+        {
+            std::lock_guard<std::mutex> lk(d->mu);
+            d->processed += 1;
+        }
+        d->cv.notify_all();
+    }
 }
 
 extern "C" int bz_dec_create(bz_dec **out, int device)
@@ -1065,19 +1200,60 @@ extern "C" int bz_dec_create(bz_dec **out, int device)
         const long long v = atoll(e);
         if (v >= 1) d->chunk = (size_t)v;
     }
+    static const bool overlap = !(getenv("BZ_DEC_OVERLAP") && atoi(getenv("BZ_DEC_OVERLAP")) == 0);
+    if (overlap) d->pool = new CopyPool(device);
     *out = d;
     return BZ_OK;
+}
+
+// hands what has been written to the worker (final: the input iterator has ended)
+static void dec_submit(bz_dec *d, bool final)
+{
+    DecJob j;
+    j.bytes.swap(d->in);
+    j.final = final;
+    // A small chunk (less than 4 MiB: short files, and every test that sets a small BZ_DEC_CHUNK to look at the moments
+    // bytes and errors come out) is decoded before this call returns, as in rounds 1-4: handing it over would only delay
+    // its bytes by a thread switch.  A large one is decoded beside the caller.
+    const bool wait = j.bytes.size() < ((size_t)4 << 20);
+    u64 ticket;
+    {
+        std::unique_lock<std::mutex> lk(d->mu);
+        if (!d->worker.joinable()) d->worker = std::thread(dec_worker, d);
+        d->cv.wait(lk, [&] { return d->jobs.size() < 2; }); // (two chunks wait at most: memory is bounded by the chunk)
+        d->jobs.push_back(std::move(j));
+        ticket = ++d->submitted;
+    }
+    d->cv.notify_all();
+    if (wait) {
+        std::unique_lock<std::mutex> lk(d->mu);
+        d->cv.wait(lk, [&] { return d->processed >= ticket; });
+    }
 }
 
 extern "C" int bz_dec_write(bz_dec *d, const uint8_t *data, size_t n)
 {
     if (!d || (!data && n)) return BZ_E_PARAM;
     if (d->ended) return BZ_E_UNEXPECTED;
-    if (d->done) return BZ_OK; // (an error is waiting behind the queued bytes; further input is ignored)
-    d->in.insert(d->in.end(), data, data + n);
-    if (d->in.size() >= d->chunk) {
-        const int rc = dec_drain(d, false);
-        if (rc != BZ_OK && rc != BZ_E_DATA && rc != BZ_E_MAGIC_FIRST && rc != BZ_E_MAGIC) return rc; // infrastructure
+    {
+        std::lock_guard<std::mutex> lk(d->mu);
+        if (d->done) { // (an error is waiting behind the queued bytes; further input is ignored -- unless it is the library's own)
+            const int v = d->verdict;
+            return (v == BZ_OK || v == BZ_E_DATA || v == BZ_E_MAGIC_FIRST || v == BZ_E_MAGIC || v == BZ_E_EOF) ? BZ_OK : v;
+        }
+    }
+    // A chunk goes to the worker once BZ_DEC_CHUNK bytes are there; a large write is cut at that size, but never into
+    // pieces of less than 1 MiB (a tiny BZ_DEC_CHUNK -- the tests' way to stop the decoder in mid-record -- hands over what
+    // a call brought, as rounds 1-4 did, not thousands of jobs).
+    const size_t gran = std::max(d->chunk, (size_t)1 << 20);
+    while (n) {
+        const size_t room = d->in.size() < gran ? gran - d->in.size() : 0;
+        const size_t k = room ? std::min(n, room) : n;
+        if (d->in.size() + k > d->in.capacity()) d->in.reserve(std::max(d->in.size() + k, std::min(gran, 2 * d->in.capacity())));
+        d->in.insert(d->in.end(), data, data + k);
+        data += k;
+        n -= k;
+        if (d->in.size() >= d->chunk && (d->in.size() >= gran || n == 0)) dec_submit(d, false);
     }
     return BZ_OK;
 }
@@ -1087,29 +1263,59 @@ extern "C" int bz_dec_end(bz_dec *d)
     if (!d) return BZ_E_PARAM;
     if (!d->ended) {
         d->ended = true;
-        (void)dec_drain(d, true);
+        dec_submit(d, true);
     }
+    std::unique_lock<std::mutex> lk(d->mu);
+    d->cv.wait(lk, [&] { return d->processed >= d->submitted; });
     return d->verdict;
 }
 
 extern "C" long bz_dec_read(bz_dec *d, uint8_t *out, size_t cap)
 {
     if (!d || (!out && cap)) return BZ_E_PARAM;
-    const size_t left = d->out.len - d->out_pos;
-    if (left == 0) return d->done ? (long)d->verdict : 0; // verdict (0 = clean end) once it is final, else "nothing yet"
+    DecSeg *seg = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(d->mu);
+        if (d->outq.empty()) // verdict (0 = clean end) once it is final and every chunk handed over has been looked at, else "nothing yet"
+            return (d->done && d->processed >= d->submitted) ? (long)d->verdict : 0;
+        seg = d->outq.front(); // (only this thread takes segments off the queue)
+    }
+    const size_t left = seg->buf.len - seg->pos;
     const size_t k = left < cap ? left : cap;
-    memcpy(out, d->out.p + d->out_pos, k);
-    d->out_pos += k;
+    memcpy(out, seg->buf.p + seg->pos, k);
+    seg->pos += k;
+    {
+        std::lock_guard<std::mutex> lk(d->mu);
+        d->out_bytes -= k;
+        if (seg->pos == seg->buf.len) d->outq.pop_front();
+        else seg = nullptr;
+    }
+    delete seg;
     return (long)k;
 }
 
-extern "C" size_t bz_dec_pending(const bz_dec *d) { return d ? d->out.len - d->out_pos : 0; }
+extern "C" size_t bz_dec_pending(const bz_dec *d)
+{
+    if (!d) return 0;
+    bz_dec *m = const_cast<bz_dec *>(d);
+    std::lock_guard<std::mutex> lk(m->mu);
+    return d->out_bytes;
+}
 
 extern "C" void bz_dec_destroy(bz_dec *d)
 {
     if (!d) return;
     int caller_device = -1;
     (void)hipGetDevice(&caller_device);
+    {
+        std::lock_guard<std::mutex> lk(d->mu);
+        d->stop = true;
+        d->jobs.clear(); // (chunks that wait are dropped; the one being decoded is finished)
+    }
+    d->cv.notify_all();
+    if (d->worker.joinable()) d->worker.join();
+    delete d->pool;
+    for (DecSeg *sg : d->outq) delete sg;
     if (d->g) (void)hipSetDevice(d->device);
     d->d_in.release();
     if (d->g) { // (kept for the next context or one-shot call unless the context met an infrastructure error)

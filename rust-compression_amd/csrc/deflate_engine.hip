@@ -10,6 +10,9 @@
 #include <vector>
 
 #include "engine_state.h"
+#include "copy_pool.h"
+
+#include <functional>
 #include "k_deflate.h"
 
 using namespace dfgpu;
@@ -448,11 +451,29 @@ static u64 df_part_bytes()
     return v;
 }
 
+// The one-shot call over host buffers runs its parts beside its own copies (df_encode_buffer_dict): a part may start once
+// its bytes have been uploaded (need_input: "bytes [0, upto) of the segment must be on the device"), and its bytes of the
+// stream leave for the host while the next part is encoded (part_done: "stream bytes [off, off + len) are final").
+struct DfPartHooks {
+    u64 part_bytes = 0; // 0: BZ_DF_PART_MIB
+    std::function<int(u64 upto)> need_input;
+    std::function<void(size_t off, size_t len)> part_done;
+};
+
 static int df_encode_parts(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, const u8 *dict, size_t dict_len, u8 *d_out,
-                           size_t cap, size_t *out_len, const DfSeg &seg0 = DfSeg(), u32 *dl_out = nullptr)
+                           size_t cap, size_t *out_len, const DfSeg &seg0 = DfSeg(), u32 *dl_out = nullptr,
+                           const DfPartHooks *hooks = nullptr)
 {
-    const u64 part = df_part_bytes();
-    if (n <= part + kPartGuard) return df_encode_core(g, kind, d_in, n, dict, dict_len, d_out, cap, out_len, seg0, dl_out);
+    const u64 part = hooks && hooks->part_bytes ? hooks->part_bytes : df_part_bytes();
+    if (n <= part + kPartGuard) {
+        if (hooks && hooks->need_input) {
+            const int irc = hooks->need_input(n);
+            if (irc != BZ_OK) return irc;
+        }
+        const int rc = df_encode_core(g, kind, d_in, n, dict, dict_len, d_out, cap, out_len, seg0, dl_out);
+        if (rc == BZ_OK && hooks && hooks->part_done) hooks->part_done(0, *out_len);
+        return rc;
+    }
     u64 pos = 0;
     size_t written = 0;
     DfSeg seg = seg0;
@@ -471,9 +492,14 @@ static int df_encode_parts(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, co
         seg.accumulate_stats = k > 0;
         size_t got = 0;
         DfPartOut po;
+        if (hooks && hooks->need_input) {
+            const int irc = hooks->need_input(std::min<u64>(n, pos + len + 64));
+            if (irc != BZ_OK) return irc;
+        }
         const int rc = df_encode_core(g, kind, d_in + pos, len, dict, dict_len, d_out ? d_out + written : nullptr,
                                       d_out ? cap - written : 0, &got, seg, last ? dl_out : nullptr, &po);
         if (rc != BZ_OK) return rc;
+        if (hooks && hooks->part_done && d_out) hooks->part_done(written, got);
         static const bool trace = getenv("BZ_DF_TRACE") != nullptr;
         if (trace)
             fprintf(stderr, "bz2_mi355x: deflate part %u: input [%llu, +%llu) of %llu, kept %llu bytes of it, %zu stream bytes, "
@@ -592,6 +618,53 @@ extern "C" int df_encode_buffer_dict(int kind, int device, const uint8_t *in, si
     rc = hipSetDevice(device) == hipSuccess ? BZ_OK : BZ_E_UNEXPECTED;
     if (rc == BZ_OK) rc = g->dec_in.ensure(in_len + 64);
     if (rc == BZ_OK) rc = g->oneshot_out.ensure(cap);
+    // Large inputs: the call's two copies run beside its kernels (copy_pool.h).  The input goes up in 8 MiB slices on a
+    // few threads, in order; the encode runs in parts of BZ_DF_BUFFER_PART_MIB (default 128 MiB -- the bytes do not depend
+    // on the parts, tests/test_gpu_deflate.py::test_many_part_seams_equal_oracle_golden), each as soon as its bytes have
+    // arrived, and a part's bytes of the stream leave for the caller's buffer while the next part is encoded.  Rounds 1-4
+    // uploaded everything, encoded, downloaded: 110 ms per GiB for 66 ms of kernels.
+    // BZ_DF_OVERLAP=0 restores that.
+    static const bool overlap = !(getenv("BZ_DF_OVERLAP") && atoi(getenv("BZ_DF_OVERLAP")) == 0);
+    if (rc == BZ_OK && overlap && in_len >= ((size_t)64 << 20)) {
+        static const u64 part_bytes = [] {
+            const char *e = getenv("BZ_DF_BUFFER_PART_MIB");
+            long mib = e ? atol(e) : 128;
+            if (mib < 1) mib = 1;
+            if (mib > 1536) mib = 1536;
+            return (u64)mib << 20;
+        }();
+        h = (uint8_t *)malloc(cap); // (pages are only touched where stream bytes land; shrunk to the stream below)
+        if (!h) rc = BZ_E_NOMEM;
+        if (rc == BZ_OK) {
+            CopyPool pool(device);
+            const size_t S = CopyPool::slice_bytes();
+            std::vector<size_t> up;
+            for (size_t off = 0; off < in_len; off += S)
+                up.push_back(pool.submit(static_cast<u8 *>(g->dec_in.p) + off, in + off, std::min(S, in_len - off), hipMemcpyHostToDevice));
+            size_t waited = 0;
+            DfPartHooks hooks;
+            hooks.part_bytes = std::min<u64>(part_bytes, df_part_bytes());
+            hooks.need_input = [&](u64 upto) {
+                const size_t want = (size_t)std::min<u64>((upto + S - 1) / S, up.size());
+                for (; waited < want; ++waited) pool.wait(up[waited]);
+                return pool.failed() ? BZ_E_UNEXPECTED : BZ_OK;
+            };
+            hooks.part_done = [&](size_t off, size_t len) {
+                if (len) pool.submit(h + off, static_cast<const u8 *>(g->oneshot_out.p) + off, len, hipMemcpyDeviceToHost);
+            };
+            rc = df_encode_parts(g, kind, static_cast<const u8 *>(g->dec_in.p), in_len, dict, dict_len, static_cast<u8 *>(g->oneshot_out.p), cap,
+                                 &n_out);
+            pool.wait_all();
+            if (rc == BZ_OK && pool.failed()) rc = BZ_E_UNEXPECTED;
+        }
+        if (rc == BZ_OK) {
+            uint8_t *h2 = (uint8_t *)realloc(h, n_out ? n_out : 1);
+            if (h2) h = h2;
+        } else {
+            free(h);
+            h = nullptr;
+        }
+    } else {
     if (rc == BZ_OK && in_len && hipMemcpy(g->dec_in.p, in, in_len, hipMemcpyHostToDevice) != hipSuccess) rc = BZ_E_UNEXPECTED;
     if (rc == BZ_OK) rc = df_gpu_encode_device_dict(g, kind, g->dec_in.p, in_len, dict, dict_len, g->oneshot_out.p, cap, &n_out);
     if (rc == BZ_OK) {
@@ -602,6 +675,7 @@ extern "C" int df_encode_buffer_dict(int kind, int device, const uint8_t *in, si
             h = nullptr;
             rc = BZ_E_UNEXPECTED;
         }
+    }
     }
     if (rc == BZ_OK) dec_cache_put(device, g);
     else bz_gpu_engine_destroy(g); // (an engine that met an error is not kept)
@@ -628,6 +702,7 @@ struct df_enc {
     size_t encoded = 0; // ... of which segments have been written for
     uint32_t dl = 0;    // InflaterInner.decompress_len behind the last segment (deflate/encoder.rs:267)
     bool wrote_head = false;
+    int last_status = BZ_OK; // of the last df_enc_end: an engine that met an infrastructure error is not parked for others
 };
 
 extern "C" int df_enc_create(df_enc **out, int kind, int device)
@@ -654,10 +729,17 @@ extern "C" void df_enc_destroy(df_enc *e)
 {
     if (!e) return;
     if (e->g) {
+        int caller_device = -1;
+        (void)hipGetDevice(&caller_device);
         (void)hipSetDevice(e->device);
         e->d_data.release();
         e->d_out.release();
-        dec_cache_put(e->device, e->g); // (kept, with its workspace, for the next context or one-shot call on the device)
+        // kept, with its workspace, for the next context or one-shot call on the device -- unless the context met an
+        // infrastructure error (a sticky HIP error, a half-grown workspace): bz_decode_buffer, df_encode_buffer and
+        // bz_dec_destroy do the same
+        if (e->last_status == BZ_OK) dec_cache_put(e->device, e->g);
+        else bz_gpu_engine_destroy(e->g);
+        if (caller_device >= 0) (void)hipSetDevice(caller_device);
     }
     delete e;
 }
@@ -679,9 +761,19 @@ extern "C" int df_enc_write(df_enc *e, const uint8_t *in, size_t n)
 // decompress_len carry over.  Action::Finish: the last segment, final bit set, container trailer.
 // The zlib / gzip wrappers end their container at the first None they see, whatever the action
 // (zlib/encoder.rs:131-151): see `ends_container` below.
+static int df_enc_end_impl(df_enc *e, int action);
 extern "C" int df_enc_end(df_enc *e, int action)
 {
     if (!e || action < 0 || action > 2) return BZ_E_PARAM;
+    int caller_device = -1;
+    (void)hipGetDevice(&caller_device);
+    const int rc = df_enc_end_impl(e, action);
+    e->last_status = rc;
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
+    return rc;
+}
+static int df_enc_end_impl(df_enc *e, int action)
+{
     if (action == 0 && e->kind == 0) return BZ_OK;
     if (e->finished) return BZ_OK; // flush() / finish() behind the final block do nothing (:636-660)
     // zlib / gzip: the container ends at the first None of the inner Inflater whatever the Action

@@ -345,7 +345,9 @@ static int cut_tables_prepare(bz_gpu_engine *g, u64 g_base, u64 total, u64 tb, u
     pl.tb = tb;
     pl.t1 = t1;
     pl.t_last = t1 < ntiles ? t1 : (t1 > tb ? t1 - 1 : tb);
-    pl.j_lo = g_base < pl.L ? 0 : (g_base - pl.L) / (pl.L + 4u) + 1u; // smallest j with (j + 1) L + 4 j > g_base
+    pl.t_eval = t1 > tb ? t1 - 1 : tb;
+    pl.w_min = g_base >= 4u ? g_base - 3u : 1u;
+    pl.j_lo = pl.w_min - 1u < pl.L ? 0 : (pl.w_min - 1u - pl.L) / (pl.L + 4u) + 1u; // smallest j with (j + 1) L + 4 j >= w_min
     const bool none = t1 <= tb || pl.own_hi < pl.L || pl.own_hi / pl.L - 1u < pl.j_lo;
     if (none) {
         pl.j_lo = 1;
@@ -355,14 +357,17 @@ static int cut_tables_prepare(bz_gpu_engine *g, u64 g_base, u64 total, u64 tb, u
     }
     const u64 nsteps = none ? 0 : pl.j_hi - pl.j_lo + 1u;
     const u64 entries = cut_table_entries(pl);
-    if (nsteps / 16u + 64u >= cut_seg_cap() || entries > (1ull << 30)) return BZ_OK; // (beyond 58 GB behind one start)
+    // The tables grow with the SQUARE of the number of blocks behind one start (2 N^2 entries): beyond 2^26 entries
+    // (256 MB; 5 800 blocks = 5 GiB at level 9, 0.55 GiB at level 1) the chain kernel's ~4 ms per GiB are cheaper than
+    // the room and the clearing, and so they are when the room cannot be had.
+    if (nsteps / 16u + 64u >= cut_seg_cap() || entries > (1ull << 26)) return BZ_OK;
     u64 g_lo, g_hi, centries;
     cut_groups(pl, &g_lo, &g_hi, &centries);
-    int rc;
-    if ((rc = g->cut_step_t0.ensure((nsteps + 1) * 8)) || (rc = g->cut_step_nt.ensure((nsteps + 1) * 4)) ||
-        (rc = g->cut_step_w0.ensure((nsteps + 2) * 8)) || (rc = g->cut_tab.ensure((entries + 1) * 4)) ||
-        (rc = g->cut_comp.ensure((centries + 1) * 2)))
-        return rc;
+    if (g->cut_step_t0.ensure((nsteps + 1) * 8) || g->cut_step_nt.ensure((nsteps + 1) * 4) || g->cut_step_w0.ensure((nsteps + 2) * 8) ||
+        g->cut_tab.ensure((entries + 1) * 4) || g->cut_comp.ensure((centries + 1) * 2)) {
+        (void)hipGetLastError(); // (an allocation that failed is not an error of the encode: the chain kernel needs none of it)
+        return BZ_OK;
+    }
     g->cut_plan = pl;
     if (nsteps) {
         const RleBuffers rb = rle_buffers(g);
@@ -506,7 +511,7 @@ struct SlabSpec {
     u64 g_base = 0;   // its offset in the image of the whole input
     u64 halo_cap = 0; // room in front of it in g->rle
     bool image_done = false;
-    u64 h_halo_total = 0, want_halo_total = 0;
+    u64 want_halo_total = 0; // (what was found: g->h_halo_total)
 };
 static int slab_spec_total(bz_gpu_engine *g, SlabSpec &sp)
 {
@@ -602,14 +607,14 @@ static int slab_spec_finish(bz_gpu_engine *g, SlabSpec &sp, SlabCuts &sc)
     const RleBuffers rb = rle_buffers(g);
     const u64 t0 = g->slab_t0;
     sc.span = span_begin(g, 0);
-    sp.h_halo_total = sp.want_halo_total;
+    g->h_halo_total = sp.want_halo_total;
     if (sc.tb < t0) {
         // left halo: the tail of the previous slab(s) that belongs to this rank's first block, coded afresh from the
         // cut (RLE1 restarted at a cut is RLE1 continued); it ends where the slab's image begins
         launch_rle_scan(g->st, g->d_in, g->n_in, sc.tb, t0, sc.start_in, g->crc_tab.as<u32>(), g->xp16.as<u32>(), rb);
         launch_rle_count(g->st, g->d_in, g->n_in, sc.tb, t0, sc.start_in, -1, rb, nullptr);
         launch_rle_prefix(g->st, sc.tb, t0, rb, false);
-        HIPCHK(hipMemcpyAsync(&sp.h_halo_total, rb.total, 8, hipMemcpyDeviceToHost, g->st)); // (checked by the caller once the stream has been waited for)
+        HIPCHK(hipMemcpyAsync(&g->h_halo_total, rb.total, 8, hipMemcpyDeviceToHost, g->st)); // (checked by the caller once the stream has been waited for)
         launch_rle_image(g->st, g->d_in, g->n_in, sc.tb, t0, sc.start_in, rb, g->rle.as<u8>() + sp.halo_cap - sp.want_halo_total);
     }
     HIPCHK(hipStreamWaitEvent(g->st, g->ev_aux, 0)); // the slab's image (st2)
@@ -1202,8 +1207,9 @@ struct ShardBlock {
 // of slab against ~85 ms for the slab's blocks), and the step ends with the LAST rank: slabs that shrink a little from
 // rank to rank -- weights 1 + skew ((world - 1) / 2 - r), which sum to world -- let all ranks finish together instead
 // (at N = 8 and skew = link / slab time = 0.02: the last rank's 14 ms of waiting become 7 ms for everybody).  The bytes
-// of the stream do not depend on the split.  BZ_SHARD_SKEW in the environment (0 = equal slabs; default 0.02; every rank
-// of a job must see the same value).
+// of the stream do not depend on the split.  BZ_SHARD_SKEW in the environment (0 = equal slabs; default 0.004 -- with the
+// cut tables a link is 0.1-0.3 ms, not the 2 ms of the chain kernel the 0.02 above was worked out for; every rank of a job
+// must see the same value).
 static double shard_skew()
 {
     static const double v = [] {
@@ -1358,10 +1364,10 @@ static int encode_sharded_impl2(bz_gpu_engine *g, int level, const void *d_in, s
         if (rc == BZ_OK)
             rc = bz_gpu_encode_blocks(g, 0, 1, d_packed, packed_cap_words, woff.data(), blen.data(), crc.data(), &used);
     }
-    if (rc == BZ_OK && sp.h_halo_total != sp.want_halo_total) {
-        if (hipStreamSynchronize(g->st) != hipSuccess || sp.h_halo_total != sp.want_halo_total) {
+    if (rc == BZ_OK && world > 1 && g->h_halo_total != sp.want_halo_total) {
+        if (hipStreamSynchronize(g->st) != hipSuccess || g->h_halo_total != sp.want_halo_total) {
             fprintf(stderr, "bz2_mi355x: rank %d: the image of its first block's bytes in front of the slab has %llu bytes, the "
-                            "offsets of the whole input's image say %llu\n", rank, (unsigned long long)sp.h_halo_total,
+                            "offsets of the whole input's image say %llu\n", rank, (unsigned long long)g->h_halo_total,
                     (unsigned long long)sp.want_halo_total);
             rc = BZ_E_UNEXPECTED;
         }

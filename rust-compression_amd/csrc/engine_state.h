@@ -73,6 +73,8 @@ struct bz_gpu_engine {
     DevBuf cut_step_t0, cut_step_nt, cut_step_w0, cut_tab, cut_comp;
     CutPlan cut_plan = {};
     bool cut_ready = false;       // the tables of the current range are filled (or being filled on st)
+    u64 h_halo_total = 0;         // sharded job: the image bytes a rank found in front of its slab (a D2H copy queued on st lands here:
+                                  // the engine outlives every return path of the call, a stack frame does not)
     u64 cut_stats[2] = {0, 0};    // since creation: partitions cut from tables, partitions that fell back to the chain kernel
     std::vector<BlockDesc> h_blocks;
     std::vector<u32> h_crc;

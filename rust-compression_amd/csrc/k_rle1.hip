@@ -437,10 +437,10 @@ __global__ __launch_bounds__(CT) void k_rle_cuts(const u8 *__restrict__ in, u64 
     u64 s_rle = 0, s_in = in_begin;
     u64 cur_tile = t_begin; // tile_off[cur_tile] < every later target
     u32 nb = 0;
-    bool broken = false;
+    bool broken = false, ended = false; // ended: the next target's chunk ends behind the range (see phase 2b)
     u32 nsw = CSW_SMALL; // sweeps per window in this round
 
-    while (!broken) {
+    while (!broken && !ended) {
         if (M < s_rle + L || M == s_rle) break; // no chunk end reaches the limit any more
         // ---- phase 1: this wave's window ------------------------------------------------
         const u64 T_lo = s_rle + (u64)(w + 1) * L; // smallest possible target of step w
@@ -601,6 +601,11 @@ __global__ __launch_bounds__(CT) void k_rle_cuts(const u8 *__restrict__ in, u64 
                 if (ok) {
                     r_rle = base_off + acc;
                     r_in = in0 + (u64)seg * 16u + k + 1u;
+                    // A chunk that BEGINS in the range and ends behind it (a run across the edge of a slab: its count
+                    // byte belongs to the run's last input byte, so the range's image ends in mid-chunk) closes no
+                    // block of this range: the block it would close begins here and is the next rank's first one
+                    // (that rank codes the bytes in front of its slab afresh, from this block's start).
+                    if (r_rle > M) r_rle = CUT_END;
                 }
             }
             s_res_rle[w][l] = r_rle;
@@ -620,7 +625,10 @@ __global__ __launch_bounds__(CT) void k_rle_cuts(const u8 *__restrict__ in, u64 
                 break;
             }
             const u64 r = s_res_rle[q][idx];
-            if (r == CUT_END) break;
+            if (r == CUT_END) {
+                ended = true;
+                break;
+            }
             if (r == CUT_OUT) {
                 if (q == 0) {
                     if (nsw == CSW_BIG) broken = true; // 12 KiB always hold step 0
@@ -706,15 +714,16 @@ __global__ __launch_bounds__(256) void k_cut_steps(CutPlan pl, const u64 *__rest
     const u64 j = pl.j_lo + gid;
     if (j > pl.j_hi) return;
     const u64 lb = (j + 1u) * pl.L;
-    const u64 w_lo = lb > pl.g_base + 1u ? lb : pl.g_base + 1u;
+    const u64 w_lo = lb > pl.w_min ? lb : pl.w_min;
     const u64 w_hi = lb + 4u * j < pl.own_hi ? lb + 4u * j : pl.own_hi;
     u64 ta = pl.tb;
     u32 nt = 0;
     if (w_lo <= w_hi) {
-        ta = cut_last_below(tile_off, pl.tb, pl.t1, w_lo - pl.g_base);
-        u64 te = cut_last_below(tile_off, ta, pl.t1, w_hi - pl.g_base) + 1u; // (a chunk may end in the tile behind)
-        if (te > pl.t_last) te = pl.t_last;
-        if (ta > pl.t_last) ta = pl.t_last;
+        // (targets at or below g_base: the chunk that answers them began in front of the range and ends in its first tiles)
+        if (w_lo > pl.g_base) ta = cut_last_below(tile_off, pl.tb, pl.t1, w_lo - pl.g_base);
+        u64 te = (w_hi > pl.g_base ? cut_last_below(tile_off, ta, pl.t1, w_hi - pl.g_base) : ta) + 1u; // (a chunk may end in the tile behind)
+        if (te > pl.t_eval) te = pl.t_eval;
+        if (ta > pl.t_eval) ta = pl.t_eval;
         nt = (u32)(te - ta + 1u);
     }
     step_t0[gid] = ta;
@@ -755,7 +764,7 @@ __global__ __launch_bounds__(RT) void k_cut_table(CutPlan pl, const u8 *__restri
     const u64 t_first = step_t0[gid];
     const u64 tile = t_first + ((u64)blockIdx.x - step_w0[gid]);
     const u64 lb = (j + 1u) * pl.L;
-    const u64 w_lo = lb > pl.g_base + 1u ? lb : pl.g_base + 1u;
+    const u64 w_lo = lb > pl.w_min ? lb : pl.w_min;
     const u64 w_hi = lb + 4u * j < pl.own_hi ? lb + 4u * j : pl.own_hi;
     const u64 in_ref = t_first * (u64)kRleTile;
     u32 *__restrict__ row = tab + cut_tbase(pl.j_lo, j);
@@ -827,9 +836,17 @@ __global__ __launch_bounds__(256) void k_cut_select(CutPlan pl, u64 j0, u64 s0, 
         u32 ns = 0;
         u64 bad = (s0 < j0 * pl.L || idx > 4u * j0) ? 1u : 0u;
         while (!bad) {
-            if ((j + 1u) * pl.L + idx > pl.own_hi) break; // the target lies behind this rank's image
-            if (j > pl.j_hi || j < pl.j_lo || ns >= kCutSegCap) {
+            const u64 target = (j + 1u) * pl.L + idx;
+            if (target > pl.own_hi) break; // the target lies behind this rank's image
+            if (ns >= kCutSegCap) {
                 bad = 1;
+                break;
+            }
+            // A target among the last four bytes of this rank's image may belong to a chunk that ends BEHIND the image (a
+            // run across the edge of the slab: its count byte is the next slab's): such a chunk is evaluated by the next
+            // rank (w_min), the block it closes is that rank's first one, and the chain of this rank stops here.
+            if (j > pl.j_hi || j < pl.j_lo) {
+                if (target + 4u <= pl.own_hi) bad = 1;
                 break;
             }
             if ((j & 15u) == 0 && g_hi >= g_lo && (j >> 4) >= g_lo && (j >> 4) <= g_hi) {
@@ -846,7 +863,7 @@ __global__ __launch_bounds__(256) void k_cut_select(CutPlan pl, u64 j0, u64 s0, 
             }
             const u32 en = tab[cut_tbase(pl.j_lo, j) + idx];
             if (en == 0xFFFFFFFFu) {
-                bad = 1; // an owned target without an answer
+                if (target + 4u <= pl.own_hi) bad = 1; // an owned target without an answer (else: the next rank's, see above)
                 break;
             }
             sg_j[ns] = (u32)(j - j0);

@@ -10,7 +10,8 @@ oracle/deflate_oracle.c; single thread, one serial stream each).
 Entries (key -> corpus):  bzip2_l9_text_<N>gib (N = 1, 2, 4, 8: corpus.corpus_bytes(N GiB), the stream of
 bench.py --gpus N), bzip2_l9_text_64mib, bzip2_l9_t2_1gib, deflate_text_1gib, deflate_text_64mib, deflate_text_2gib
 (raw Deflate; zlib / gzip wrap the same bits; 2 GiB: more than one call of the GPU path handles in one part);
-bzip2_l9_<random|dna|binary|mix|logs>_32mib: the first 32 MiB of the 256 MiB corpora of corpus.matrix_corpus."""
+bzip2_l9_<random|dna|binary|mix|logs>_32mib: the first 32 MiB of the 256 MiB corpora of corpus.matrix_corpus;
+bzip2_l1_text_256mib, bzip2_l5_text_256mib: levels 1 and 5 on the first 256 MiB of the text corpus."""
 import argparse
 import hashlib
 import json
@@ -25,6 +26,8 @@ OUT = os.path.join(ROOT, "tests", "golden", "corpus_hashes.json")
 
 KEYS = ["bzip2_l9_text_64mib", "deflate_text_64mib", "bzip2_l9_text_1gib", "deflate_text_1gib", "bzip2_l9_t2_1gib",
         "bzip2_l9_text_2gib", "bzip2_l9_text_4gib", "bzip2_l9_text_8gib", "deflate_text_2gib",
+        # levels other than 9 at size (round 5): 256 MiB of the text corpus at levels 1 and 5 (2 685 and 537 blocks)
+        "bzip2_l1_text_256mib", "bzip2_l5_text_256mib",
         # the corpus matrix of bench.py extra.corpora (corpus.MATRIX): the first 32 MiB of each 256 MiB corpus
         "bzip2_l9_random_32mib", "bzip2_l9_dna_32mib", "bzip2_l9_binary_32mib", "bzip2_l9_mix_32mib", "bzip2_l9_logs_32mib"]
 MATRIX_BYTES = 256 << 20  # the corpora are generated at this size (their content depends on it) and cut
@@ -44,7 +47,7 @@ def make(key):
     else:
         data = corpus.stress_t2(n) if "_t2_" in key else corpus.corpus_bytes(n)
     if codec == "bzip2":
-        out = oracle.encode(data, 9)
+        out = oracle.encode(data, int(rest.split("_", 1)[0][1:]))  # (bzip2_l<level>_...)
     else:
         out = oracle.deflate_encode(data, 0)
     return key, {"sha256": hashlib.sha256(out).hexdigest(), "bytes": len(out), "input_bytes": n,

@@ -121,6 +121,7 @@ inline hipError_t hipMemcpyPeerAsync(void *dst, int, const void *src, int, size_
 {
     return hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s);
 }
+inline hipError_t hipMemset(void *dst, int v, size_t n) { memset(dst, v, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t s)
 {
     if (!s) { memset(dst, v, n); return hipSuccess; }

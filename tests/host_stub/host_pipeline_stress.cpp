@@ -234,6 +234,17 @@ int main(int argc, char **argv)
         for (int r : res) bad |= r;
         if (bad) fprintf(stderr, "streams side by side: a stream differs from its reference\n");
     }
+    if (!bad) { // the multi-device diagnostic (bench.py's preflight): neighbour pairs of a device list, one of them on one device
+        const int devs[4] = {0, 1, 1, 3};
+        int peer[4] = {9, 9, 9, 9};
+        double ms[4] = {-2, -2, -2, -2};
+        const int rc = bz_peer_copy_selftest(devs, 4, 100000, peer, ms);
+        if (rc != BZ_OK || peer[0] != 1 || peer[1] != -1 || peer[2] != 1 || peer[3] != 1 || ms[0] < 0 || ms[1] != 0.0 || ms[3] < 0 ||
+            bz_peer_copy_selftest(devs, 0, 1, nullptr, nullptr) != BZ_E_PARAM || bz_peer_copy_selftest(nullptr, 2, 1, nullptr, nullptr) != BZ_E_PARAM) {
+            fprintf(stderr, "bz_peer_copy_selftest: rc %d, peer %d %d %d %d\n", rc, peer[0], peer[1], peer[2], peer[3]);
+            bad = 1;
+        }
+    }
     bz_release_cached_resources();
     printf(bad ? "FAILED\n" : "ok\n");
     return bad;

@@ -192,3 +192,34 @@ def test_one_process_eight_device_entries_at_config_size():
     res = json.loads(line[0][7:])
     assert res["rc"] == 0
     assert res["bytes"] == gold["bytes"] and res["sha"] == gold["sha256"], res
+
+
+@pytest.mark.parametrize("key,level,kind", [("bzip2_l9_t2_1gib", 9, "t2"), ("bzip2_l1_text_256mib", 1, "text"),
+                                            ("bzip2_l5_text_256mib", 5, "text")])
+def test_single_gpu_goldens_at_size(key, level, kind):
+    """the 1 GiB deep-repeat corpus T2 (the period round at size: 220 copies of a 4 KiB paragraph per
+    block) and levels other than 9 at size (256 MiB of text at level 1 = 2 685 blocks in three batches, level 5 = 537) --
+    the device-resident encode's stream carries the SHA-256 and length of the ORACLE's stream for the same bytes
+    (tests/golden/make_corpus_hashes.py; block sizes: /root/reference/src/bzip2/encoder.rs:186), and decodes back."""
+    import torch
+    import corpus
+    pkg = importlib.import_module("rust-compression_amd")
+    g = _golden(key)
+    n = g["input_bytes"]
+    dev = torch.device("cuda", 0)
+    if kind == "t2":
+        d_in = torch.frombuffer(bytearray(corpus.t2_slice(0, n)), dtype=torch.uint8).to(dev)
+    else:
+        d_in = corpus.slice_on_device(0, n, dev)
+    assert hashlib.sha256(memoryview(d_in.cpu().numpy())).hexdigest() == g["input_sha256"]
+    eng = pkg.GpuEngine(0, 1400)
+    cap = (pkg.encode_bound(n) + 15) & ~15
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    k = eng.encode_device(level, d_in.data_ptr(), n, d_out.data_ptr(), cap)
+    assert k == g["bytes"]
+    assert hashlib.sha256(memoryview(d_out[:k].cpu().numpy())).hexdigest() == g["sha256"]
+    assert eng.bwt_stats()["fused_fallbacks"] == 0
+    d_back = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    m, verdict = eng.decode_device(d_out.data_ptr(), k, d_back.data_ptr(), n + 64)[:2]
+    assert (m, verdict) == (n, 0) and torch.equal(d_back[:n], d_in)
+    eng.close()

@@ -190,6 +190,40 @@ def test_streaming_flush_sequences(pkg, oracle):
         assert enc.encode_all(b"", pkg.Action.FINISH) == ora.encode_iter(b"", oracle.ACTION_FINISH)
 
 
+def test_streaming_write_after_finish(pkg, oracle):
+    """Input written BEHIND Action::Finish (encoder.rs:80-85 + :671-697: EncoderInner::next has no `finished` test): the
+    reference goes on collecting it and writes further blocks behind the trailer whenever a block has come together, while
+    flush() and finish() do nothing any more (:718-739).  Byte for byte against the oracle's BZip2Encoder mirror, call by
+    call: Finish -> too little for a block -> more (a block comes out, byte-aligned, without a header) -> Flush (the pad
+    byte of the bit writer only) -> Run -> Finish twice; and a stream whose FIRST call is an empty Finish (the header is
+    written again in front of the first block: block_no is still 1)."""
+    d = (sample(1) + sample(2)) * 3
+    plan = [(d[:150000], 2), (d[150000:200000], 2), (d[200000:420000], 2), (b"", 1), (d[:300000], 0), (b"", 2), (b"", 2)]
+    enc, ora = pkg.BZip2Encoder(1), oracle.Encoder(1)
+    sizes = []
+    for piece, act in plan:
+        got, want = enc.encode_all(piece, pkg.Action(act)), ora.encode_iter(piece, act)
+        assert got == want, (len(piece), act, len(got), len(want))
+        sizes.append(len(got))
+    assert sizes[1] == 0 and sizes[2] > 1000 and sizes[3] == 1 and sizes[4] > 1000 and sizes[6] == 0, sizes
+    enc, ora = pkg.BZip2Encoder(1), oracle.Encoder(1)
+    assert enc.encode_all(b"", pkg.Action.FINISH) == ora.encode_iter(b"", oracle.ACTION_FINISH)
+    got, want = enc.encode_all(d[:250000], pkg.Action.FINISH), ora.encode_iter(d[:250000], oracle.ACTION_FINISH)
+    assert got == want and got[:4] == b"BZh1" and len(got) > 1000
+    # pieces that cross the pipeline's chunking: 2.5 MB behind a Finish at level 9, in three writes and one Run
+    rng = random.Random(12)
+    enc, ora = pkg.BZip2Encoder(9), oracle.Encoder(9)
+    big = _text(2_500_000, 5)
+    assert enc.encode_all(big[:1000], pkg.Action.FINISH) == ora.encode_iter(big[:1000], oracle.ACTION_FINISH)
+    pos = 1000
+    while pos < len(big):
+        k = rng.choice([1, 70000, 900000, 1200000])
+        act = rng.choice([0, 1, 2])
+        piece = big[pos:pos + k]
+        pos += len(piece)
+        assert enc.encode_all(piece, pkg.Action(act)) == ora.encode_iter(piece, act), (pos, act)
+
+
 def test_flush_on_fresh_encoder(pkg, oracle):
     enc = pkg.BZip2Encoder(9)
     ora = oracle.Encoder(9)

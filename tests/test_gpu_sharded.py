@@ -125,6 +125,19 @@ def test_replayed_jobs_fuzz():
     assert "fuzz_sharded ok" in p.stdout
 
 
+@pytest.mark.parametrize("tables", [True, False])
+def test_run_across_a_slab_edge_closes_the_next_ranks_block(tables):
+    """tools/shard_edge_replay.py: slab edges 1, 2, 3, 4 and more bytes into the 255-byte chunk that closes a block (a run's
+    count byte belongs to its last input byte, so the slab's image ends in mid-chunk): the block is the next rank's first
+    one; streams == oracle with the cut tables and with the chain kernel (every rank returned BZ_E_PARAM)."""
+    import subprocess
+    env = dict(os.environ, BZ_CUT_TABLES="1" if tables else "0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_edge_replay.py")], capture_output=True, text=True, timeout=900,
+                       env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "shard_edge_replay ok" in p.stdout
+
+
 def test_rccl_transport_library_single_rank(pkg, oracle):
     """libbz2_mi355x_rccl.so (the callbacks over RCCL, implemented in C): a one-rank communicator on the test
     box's one GPU goes through the library's transport self-test (all-gather, the variable-length gather of
@@ -185,7 +198,15 @@ def test_bench_two_ranks_line_is_self_sufficient():
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] == 1
     assert line["roofline"]["pipeline_8d"]["frac"] > 0 and line["roofline"]["frac"] > 0
     assert line["step_ms"]["n"] == 2 and line["step_ms"]["min"] <= line["step_ms"]["median"]
-    assert line["config"]["ranks"]["world"] == 2
+    assert line["config"]["ranks"]["world"] == 2 and line["config"]["ranks"]["rccl_comm_count"] == 2
+    assert line["value_is"] == "hbm_resident" and line["value_hbm_resident"] == line["value"]
+    # the preflight in front of the timed steps: communicator count, the library's transport self-test over
+    # the real communicator with device buffers, one peer round trip per neighbour pair of the end-to-end leg's devices
+    pre = line["preflight"]
+    assert pre["status"] == "ok" and pre["world"] == 2 and pre["backend"] == "gloo"
+    assert [r["rank"] for r in pre["ranks"]] == [0, 1]
+    assert all(r["comm_count"] == 2 and r["selftest_status"] == 0 and r["errors"] == [] for r in pre["ranks"])
+    assert pre["peer_copies"]["status"] == 0 and pre["peer_copies"]["devices"] == [0, 0] and pre["peer_copies"]["peer_access"] == [-1, -1]
     assert line["shard_chain"]["chain_ms_per_link"] > 0 and len(line["shard_chain"]["links_ms"]) == 1
     assert line["end_to_end"]["calls_ms"]["n"] == 3 and line["end_to_end"]["phases_ms_of_the_median_call"]["jobs"] >= 1
     assert line["value_end_to_end"] == line["end_to_end"]["bz_encode_buffer_multi"]
@@ -195,6 +216,21 @@ def test_bench_two_ranks_line_is_self_sufficient():
     for k in ("stream_sha_equals_oracle_golden", "gpu_equals_oracle_on_cpu_sample", "decode_sharded_round_trip",
               "end_to_end_buffer_equals_device_stream"):
         assert k in line["checks"], k
+
+
+def test_bench_preflight_failure_prints_a_line_and_leaves():
+    """The transport self-test of the preflight fails on rank 1 (BZ_BENCH_PREFLIGHT_FAIL=1: that rank reports an error of
+    its transport): rank 0 prints ONE line whose "preflight" names the rank, no step is timed, every rank leaves with 4."""
+    import json
+    outs = _bench_ranks(2, ["--steps", "1", "--warmup", "0", "--mib-per-gpu", "32", "--no-extras", "--no-cpu-baseline",
+                            "--hang-timeout", "120"], {"BZ_BENCH_PREFLIGHT_FAIL": "1"}, 300)
+    assert [o[0] for o in outs] == [4, 4], outs[0][2][-1500:] + outs[1][2][-1500:]
+    lines0 = [x for x in outs[0][1].splitlines() if x.startswith("{")]
+    assert len(lines0) == 1
+    line = json.loads(lines0[0])
+    assert line["value"] is None and line["n_gpus"] == 2
+    assert line["preflight"]["status"] == "FAILED on rank(s) [1]"
+    assert line["preflight"]["ranks"][1]["errors"] and line["preflight"]["ranks"][0]["errors"] == []
 
 
 def test_bench_rank_death_does_not_hang_the_others():
