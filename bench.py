@@ -762,6 +762,47 @@ def extras(result, args, pkg, eng, torch, dev, d_in, n, d_out, out_len, golden, 
                          "first_call_s": round(calls[0], 4),
                          "fraction_of_hbm_resident_rate": round(n / (st5["median"] * 1e-3) / 1e6 / dec["value"], 3),
                          "note": "host buffer in -> host buffer out, pageable caller memory, median of 5 calls behind one untimed call"}
+    # the streaming context (bz_dec_write / bz_dec_end / bz_dec_read through raw pointers: the loop a Rust or C host runs):
+    # the stream written in 1 MiB pieces, the decoded bytes read in 4 MiB pieces as they come
+    wr, rd = L.bz_dec_write, L.bz_dec_read
+    saved_w, saved_r, saved_rr = wr.argtypes, rd.argtypes, rd.restype
+    wr.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    rd.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    rd.restype = ctypes.c_long
+    zbase = z_host.ctypes.data
+    sink4 = (ctypes.c_uint8 * (4 << 20))()
+    s_calls, s_ok = [], True
+    for rep in range(4):
+        hd = ctypes.c_void_p()
+        c0 = time.perf_counter()
+        s_ok = s_ok and L.bz_dec_create(ctypes.byref(hd), dev.index or 0) == 0
+        got = 0
+        crc = 0
+        for i in range(0, int(out_len), 1 << 20):
+            s_ok = s_ok and wr(hd, zbase + i, min(1 << 20, int(out_len) - i)) == 0
+            while True:
+                k = rd(hd, sink4, len(sink4))
+                if k <= 0:
+                    break
+                got += k
+        rc_end = L.bz_dec_end(hd)
+        last = 0
+        while True:
+            k = rd(hd, sink4, len(sink4))
+            if k <= 0:
+                last = k
+                break
+            got += k
+        s_calls.append(time.perf_counter() - c0)
+        L.bz_dec_destroy(hd)
+        s_ok = s_ok and rc_end == 0 and last == 0 and got == n
+    wr.argtypes, rd.argtypes, rd.restype = saved_w, saved_r, saved_rr
+    checks["decode_streaming_context_yields_every_byte"] = bool(s_ok)
+    ss = step_stats(s_calls[1:])
+    dec["end_to_end"]["bz_dec_write_read"] = round(n / (ss["median"] * 1e-3) / 1e6, 2)
+    dec["end_to_end"]["streaming_calls_ms"] = ss
+    dec["end_to_end"]["streaming_note"] = ("bz_dec_write in 1 MiB pieces, bz_dec_read in 4 MiB pieces between the writes and behind bz_dec_end; "
+                                           "median of 3 streams behind one untimed one")
     del d_dec, z_host
 
     # ---- Deflate (BASELINE.json configs[4]: Inflater on the same corpus, HBM -> HBM); one call takes < 2 GiB

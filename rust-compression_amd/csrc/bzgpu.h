@@ -21,6 +21,7 @@ constexpr u32 kSortThreads = 512;
 constexpr u32 kTilesPerBlock = 110;         // ceil(900000 / 8192)
 constexpr u32 kSlot = kTilesPerBlock * kSortTile; // 901120: per-block stride of the u32 work arrays
 constexpr u32 kMaxBins = 2048;              // 11-bit digits for the initial 32-bit key sort
+constexpr u32 kPerK = 8;                    // distances per block the period round orders copies by (round 5: one before)
 constexpr u32 kGSize = 50;                  // BZ_G_SIZE, src/bzip2/mod.rs:20
 constexpr u32 kMaxSelectors = 18002;        // BZ_MAX_SELECTORS, src/bzip2/encoder.rs:295
 constexpr u32 kMaxAlpha = 258;
@@ -100,6 +101,24 @@ template <class T> __device__ __forceinline__ void st_stream(T *p, T v)
 #else
     *p = v;
 #endif
+}
+
+// The same for element `idx` of an array whose start is wave-uniform, with the byte offset kept in 32 bits (idx < 2^30):
+// the access is then `global_load_dword v, v_off, s[base:base+1]` -- one shift for the address instead of a 64-bit shift
+// and a 64-bit add, one address register instead of two, and rows a constant distance apart share the register (the
+// distance goes into the instruction's immediate offset).
+__device__ __forceinline__ u32 ld_stream_at(const u32 *base_uniform, u32 idx)
+{
+    return ld_stream(reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(base_uniform) + (size_t)(u32)(idx << 2)));
+}
+__device__ __forceinline__ void st_stream_at(u32 *base_uniform, u32 idx, u32 v)
+{
+    st_stream(reinterpret_cast<u32 *>(reinterpret_cast<char *>(base_uniform) + (size_t)(u32)(idx << 2)), v);
+}
+
+__device__ __forceinline__ void st_plain_at(u32 *base_uniform, u32 idx, u32 v)
+{
+    *reinterpret_cast<u32 *>(reinterpret_cast<char *>(base_uniform) + (size_t)(u32)(idx << 2)) = v;
 }
 
 // ---- wave64 primitives -------------------------------------------------------
@@ -245,6 +264,17 @@ __device__ __forceinline__ uint4 ld_sc1_x4(const u32 *p)
     return make_uint4(r.x, r.y, r.z, r.w);
 }
 
+// the same load WITHOUT the wait, for several words asked for together (ld_x4_wait_all before the first use of any of
+// them: the compiler does not know that the registers are filled late)
+__device__ __forceinline__ void ld_sc1_x4_issue(const u32 *p, u32x4_t &r)
+{
+#ifndef BZ_LB_SC1
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(r) : "v"(p) : "memory");
+#else
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r) : "v"(p) : "memory");
+#endif
+}
+__device__ __forceinline__ void ld_x4_wait_all() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
 
 // ---- CRC-32/BZIP2 arithmetic in GF(2)[x] / 0x104C11DB7 ------------------------
 constexpr u32 kCrcPoly = 0x04C11DB7u;
@@ -329,8 +359,9 @@ struct BwtArgs {
     unsigned long long *active;      // [64] per-round count of non-final rotations in unfinished blocks
     u32 *maxnf;                      // [64] per round: the largest number of non-final rotations any block is left with
     u32 *per_k, *per_shift;          // [nb] periodic blocks: repetition count, least-rotation start
-    u32 *lin_p, *lin_sig;            // [nb] blocks with a period (k_period_find): the period (0: none), the anchors that
-                                     //   voted for it
+    u32 *lin_p, *lin_sig;            // [nb][kPerK] blocks deep in repeats (k_period_find): the distances at which they agree
+                                     //   with themselves, widest agreement first (0: none / no more), and that agreement
+                                     //   in permille of the block
     u32 *bin_cursor;                 // [nb][1024] rank words binned so far (k_group_apply -> k_rank_place)
     u32 *pb_gate;                    // [nb] != 0: phase B of the init by the global passes (0: k_phase_b_local did it)
     u32 *loc_stats;                  // [4] k_phase_b_local: segments, overflows, segments out of order, LDS passes
@@ -347,6 +378,8 @@ struct BwtArgs {
     u32 *tickets;                    // [kSortEpochs][8] tile tickets per pass and XCD
     u32 *sort_err;                   // [1] a look-back that gave up
     u32 *epoch;                      // host: the engine's pass counter (1 .. kSortEpochs-1)
+    u32 per_pairs;                   // != 0: BZ_PAIR_COMPARE=1 -- the period round orders groups of two by comparing them; the
+                                     //   verdict bytes then take the digit-count slot and the period tables the flag bytes'
     u32 *fused_state;                // host, per engine: [0] != 0: the fused passes misbehaved once and stay off for
                                      //   this engine, [1] sorts that fell back to the three-kernel passes
     u32 *tile_state_all;             // host: whole look-back buffer (cleared when the counter wraps)

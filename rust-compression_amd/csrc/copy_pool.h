@@ -1,36 +1,44 @@
-// copy_pool.h -- copies between PAGEABLE caller memory and the device on several threads, beside the kernels.
+// copy_pool.h -- copies between PAGEABLE caller memory and the device BESIDE the kernels.
 //
 // The entry points over host buffers (bz_decode_buffer, bz_dec_*, df_encode_buffer) hand the library plain malloc'ed
-// memory.  One hipMemcpy of such memory runs on the calling thread: the runtime pins the pages (fresh output pages are
-// first faulted in and zeroed by the kernel -- a GiB of them costs more than its decode) and the caller waits.  Here a
-// copy is cut into slices that a few threads take from a queue, each with a stream of its own: the page work of the
-// slices runs side by side, and the thread that launches kernels goes on with the next batch meanwhile (a job is
-// waited for by ticket before its device buffer is reused; everything is waited for before a call returns).
-// BZ_COPY_THREADS in the environment (default 4, 1 ... 16).  Threads start with the first job and end with the pool.
+// memory, and a hipMemcpy of such memory occupies the thread that calls it.  What the copies cost on an MI355X host
+// (tools/ubench/hostcopy.hip, profiles/r05_host_copies.md):
+//   * host -> device from touched pageable memory: 50 GB/s from ONE thread (1 GiB in 21 ms); slices on several threads
+//     are SLOWER (4 threads: 35 ms, 8 threads: 46-55 ms -- the runtime serialises them and adds its overhead per call);
+//   * device -> host into touched pageable memory: 19 ms per GiB from one thread (as fast as into pinned memory);
+//     into FRESH memory 43-51 ms (huge pages) -- the kernel zeroes every page at its first touch, 39 ms per GiB on one
+//     thread, but 6 ms on eight; slices on several threads: 80-120 ms.
+// So: ONE thread per direction issues the copies, in order, slice by slice (a slice is what a caller can wait for), and
+// a copy into fresh memory is preceded by a first touch of its pages on BZ_COPY_THREADS threads (default 8).  The thread
+// that launches kernels goes on with the next batch or part meanwhile; a job is waited for by ticket before its device
+// buffer is reused, everything before a call returns.  Threads start with the first job and end with the pool.
 #pragma once
 #include "engine_state.h"
 
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
 
 struct CopyPool {
-    struct Slice {
+    struct Job {
         void *dst;
         const void *src;
         size_t n;
         hipMemcpyKind kind;
+        bool fresh; // (device -> host) the destination's pages have not been touched yet
         size_t ticket;
+        std::function<void(bool)> on_done; // (optional) called on the copying thread when the bytes have landed (or the copy failed)
     };
     int device = 0;
-    std::vector<std::thread> threads;
+    std::thread io[2]; // [0] host -> device, [1] device -> host
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<Slice> q;
-    std::vector<size_t> left; // per ticket - base: slices not yet done
-    size_t base = 0;          // tickets below it are done and forgotten
+    std::deque<Job> q[2];
+    std::vector<char> done; // per ticket - base
+    size_t base = 0;        // tickets below it are done and forgotten
     bool stop = false, failed_ = false;
 
     explicit CopyPool(int dev) : device(dev) {}
@@ -43,68 +51,85 @@ struct CopyPool {
             stop = true;
         }
         cv.notify_all();
-        for (auto &t : threads) t.join();
+        for (auto &t : io)
+            if (t.joinable()) t.join();
     }
-    static unsigned thread_count()
+    static unsigned touch_threads()
     {
         static const unsigned n = [] {
             const char *e = getenv("BZ_COPY_THREADS");
-            long v = e ? atol(e) : 4;
+            long v = e ? atol(e) : 8;
             if (v < 1) v = 1;
-            if (v > 16) v = 16;
+            if (v > 32) v = 32;
             return (unsigned)v;
         }();
         return n;
     }
-    static size_t slice_bytes() { return (size_t)8 << 20; }
+    static size_t slice_bytes() { return (size_t)32 << 20; }
 
-    void run()
+    // first touch of [p, p + n): one write per 4 KiB page (a huge page is faulted in by its first one), on several threads
+    static void touch(void *p, size_t n)
+    {
+        const unsigned nt = n >= ((size_t)8 << 20) ? touch_threads() : 1u;
+        const size_t per = ((n / nt) + 4095) & ~(size_t)4095;
+        auto body = [=](unsigned t) {
+            volatile char *c = static_cast<volatile char *>(p);
+            const size_t lo = (size_t)t * per, hi = std::min(n, lo + per);
+            for (size_t o = lo; o < hi; o += 4096) c[o] = 0;
+            if (hi > lo) c[hi - 1] = 0;
+        };
+        if (nt == 1) return body(0);
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(body, t);
+        body(0);
+        for (auto &x : th) x.join();
+    }
+
+    void run(int dir)
     {
         hipStream_t st = nullptr;
         bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
         for (;;) {
-            Slice s;
+            Job j;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return stop || !q.empty(); });
-                if (q.empty()) break; // stop, and nothing left
-                s = q.front();
-                q.pop_front();
+                cv.wait(lk, [&] { return stop || !q[dir].empty(); });
+                if (q[dir].empty()) break; // stop, and nothing left
+                j = std::move(q[dir].front());
+                q[dir].pop_front();
             }
-            const bool done = ok && hipMemcpyAsync(s.dst, s.src, s.n, s.kind, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+            if (j.fresh) touch(j.dst, j.n);
+            const bool good = ok && (j.n == 0 || (hipMemcpyAsync(j.dst, j.src, j.n, j.kind, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess));
+            if (j.on_done) j.on_done(good);
             {
                 std::lock_guard<std::mutex> lk(mu);
-                if (!done) failed_ = true;
-                left[s.ticket - base] -= 1;
+                if (!good) failed_ = true;
+                done[j.ticket - base] = 1;
             }
             cv.notify_all();
         }
         if (st) (void)hipStreamDestroy(st);
     }
 
-    // queues dst[0, n) <- src[0, n); returns the job's ticket
-    size_t submit(void *dst, const void *src, size_t n, hipMemcpyKind kind)
+    // queues dst[0, n) <- src[0, n) as ONE job (callers that want to wait for parts of a copy submit the parts); returns its ticket
+    size_t submit(void *dst, const void *src, size_t n, hipMemcpyKind kind, bool fresh = false, std::function<void(bool)> on_done = nullptr)
     {
+        const int dir = kind == hipMemcpyHostToDevice ? 0 : 1;
         size_t ticket;
         {
             std::lock_guard<std::mutex> lk(mu);
-            ticket = base + left.size();
-            const size_t per = slice_bytes();
-            const size_t k = (n + per - 1) / per;
-            left.push_back(k);
-            for (size_t i = 0; i < k; ++i) {
-                Slice s;
-                s.dst = static_cast<u8 *>(dst) + i * per;
-                s.src = static_cast<const u8 *>(src) + i * per;
-                s.n = (i + 1 == k) ? n - i * per : per;
-                s.kind = kind;
-                s.ticket = ticket;
-                q.push_back(s);
-            }
-            if (threads.empty() && k) {
-                const unsigned nt = (unsigned)std::min<size_t>(thread_count(), 16);
-                for (unsigned t = 0; t < nt; ++t) threads.emplace_back([this] { run(); });
-            }
+            ticket = base + done.size();
+            done.push_back(0);
+            Job j;
+            j.dst = dst;
+            j.src = src;
+            j.n = n;
+            j.kind = kind;
+            j.fresh = fresh && dir == 1;
+            j.ticket = ticket;
+            j.on_done = std::move(on_done);
+            q[dir].push_back(std::move(j));
+            if (!io[dir].joinable()) io[dir] = std::thread([this, dir] { run(dir); });
         }
         cv.notify_all();
         return ticket;
@@ -112,18 +137,18 @@ struct CopyPool {
     void wait(size_t ticket)
     {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return ticket < base || ticket - base >= left.size() || left[ticket - base] == 0; });
+        cv.wait(lk, [&] { return ticket < base || ticket - base >= done.size() || done[ticket - base]; });
     }
     void wait_all()
     {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] {
-            for (size_t v : left)
-                if (v) return false;
+            for (char v : done)
+                if (!v) return false;
             return true;
         });
-        base += left.size(); // (a long-lived pool does not grow a list for ever)
-        left.clear();
+        base += done.size(); // (a long-lived pool does not grow a list for ever)
+        done.clear();
     }
     bool failed()
     {

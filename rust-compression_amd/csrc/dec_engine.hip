@@ -12,8 +12,10 @@
 #include "engine_state.h"
 #include "copy_pool.h"
 
+#include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <sys/mman.h>
 #include <thread>
@@ -28,6 +30,16 @@ namespace {
 constexpr u32 kForcedSlots = 16; // blocks per batch that start without a full 48-bit magic
 
 } // namespace
+
+static bool dec_trace()
+{
+    static const bool on = getenv("BZ_DEC_TRACE") != nullptr;
+    return on;
+}
+static double dec_now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 struct DecWorkspace {
     size_t slots = 0;
@@ -177,10 +189,17 @@ struct Sink {
     u8 *d_out = nullptr; // device destination (device API) or nullptr
     u64 cap = 0;
     bool dry = false;    // sizes only
-    HostBuf *host = nullptr; // host destination (one-shot over host buffers, the streaming context)
-    DevBuf *staging[2] = {nullptr, nullptr}; // ... through these, batch by batch in turn
-    CopyPool *pool = nullptr; // ... copied by these threads while the next batch's kernels run (nullptr: one hipMemcpy per batch)
+    HostBuf *host = nullptr; // host destination, one growing buffer (the one-shot call over host buffers)
+    // host destination, a buffer of its own for every sub-batch (the streaming context: its reader takes the bytes of a
+    // sub-batch while the next one is rebuilt): seg_alloc(n) -> n bytes of fresh memory or nullptr, seg_done(p, n, ok) when
+    // the bytes have landed there -- on the copying thread -- or the copy failed
+    std::function<u8 *(size_t)> seg_alloc;
+    std::function<bool(u8 *)> seg_fresh; // (optional) are the pages of this buffer untouched?  (default: yes)
+    std::function<void(u8 *, size_t, bool)> seg_done;
+    DevBuf *staging[2] = {nullptr, nullptr}; // ... through these, sub-batch by sub-batch in turn
+    CopyPool *pool = nullptr; // ... copied by its thread while the next sub-batch's kernels run (nullptr: one hipMemcpy per batch)
     u64 produced = 0;
+    bool to_host() const { return host != nullptr || (bool)seg_alloc; }
 };
 
 } // namespace
@@ -314,20 +333,6 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
         c1 = nc * (size_t)(sh->rank + 1) / (size_t)sh->world;
         B = (u32)std::max<size_t>(c1 - c0, 1);
     }
-    if (sink.host && sink.pool && !sh) {
-        // Host destination: smaller batches, so that the copy of batch k to the caller's memory (sink.pool's threads)
-        // runs beside the kernels of batch k + 1 -- with one batch per GiB the download stood behind the whole decode
-        // (118 ms per GiB host to host against 48 ms of kernels).
-        u32 hb = 320;
-        if (const char *e = getenv("BZ_DEC_HOST_BATCH")) {
-            const long v = atol(e);
-            if (v >= 1 && v <= 65536) hb = (u32)v;
-        }
-        // (equal batches: 1189 blocks are 4 x 298, not 3 x 320 + 229)
-        const size_t nbat = (nc + hb - 1) / hb;
-        if (nbat > 1) hb = (u32)((nc + nbat - 1) / nbat);
-        if (hb < B) B = hb;
-    }
     if (nc < B) B = (u32)(nc ? nc : 1);
     const u32 B_want = B;
     {
@@ -384,7 +389,7 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
         {
             if (p) p->wait_all();
         }
-    } pool_guard{sink.host ? sink.pool : nullptr};
+    } pool_guard{sink.to_host() ? sink.pool : nullptr};
     u32 batch_no = 0;
     size_t stage_ticket[2] = {0, 0};
     bool stage_busy[2] = {false, false};
@@ -629,9 +634,29 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
         int shard_rc = BZ_OK;   // an infrastructure error of this rank, told to the others
 
         // ---- D2..D4 for the true blocks of the batch
-        const u32 nb = (u32)bslot.size();
-        if (nb) {
-            w->stats[1] += nb;
+        // Host destination: the blocks are rebuilt in SUB-BATCHES, so that the copy of sub-batch k to the caller's memory
+        // (sink.pool's thread) runs beside the kernels of sub-batch k + 1 -- with everything in one go the download stood
+        // behind the whole decode (118 ms per GiB host to host against 48 ms of kernels).  D1 stays one
+        // launch over the whole batch: it takes the time of ONE block's Huffman decode however many blocks there are
+        // (11 ms; four batches of 300 blocks paid it four times: measured, profiles/r05_host_copies.md).
+        const u32 nb_all = (u32)bslot.size();
+        u32 sub_max = nb_all;
+        if (sink.to_host() && sink.pool && !sh && nb_all) {
+            u32 hb = 320;
+            if (const char *e = getenv("BZ_DEC_HOST_BATCH")) {
+                const long v = atol(e);
+                if (v >= 1 && v <= 65536) hb = (u32)v;
+            }
+            const u32 nbat = (nb_all + hb - 1) / hb; // (equal sub-batches: 1189 blocks are 4 x 298, not 3 x 320 + 229)
+            sub_max = (nb_all + nbat - 1) / nbat;
+        }
+        if (nb_all) {
+            w->stats[1] += nb_all;
+            HIPDEC(hipMemcpyAsync(w->slot.p, bslot.data(), (size_t)nb_all * 4, hipMemcpyHostToDevice, st));
+            HIPDEC(hipMemcpyAsync(w->nbmax.p, bmax.data(), (size_t)nb_all * 4, hipMemcpyHostToDevice, st));
+        }
+        for (u32 s0 = 0; s0 < nb_all && !finished && local_fail == ~0ull && shard_rc == BZ_OK; s0 += sub_max) {
+            const u32 nb = std::min(sub_max, nb_all - s0);
             DecArgs a;
             a.nb = nb;
             {
@@ -639,8 +664,8 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                 // stream's level); small gain, low levels only (level 1: 64.3 -> 63 ms per GiB).
                 u32 max_bytes = 1, max_nsym = 1;
                 for (u32 i = 0; i < nb; ++i) {
-                    max_bytes = std::max(max_bytes, bmax[i]);
-                    max_nsym = std::max(max_nsym, hslot[bslot[i]].nsym);
+                    max_bytes = std::max(max_bytes, bmax[s0 + i]);
+                    max_nsym = std::max(max_nsym, hslot[bslot[s0 + i]].nsym);
                 }
                 static const bool full_grid = getenv("BZ_FULL_GRID") && atoi(getenv("BZ_FULL_GRID")) != 0;
                 // The chunk kernels: the workgroups the largest block's chunks need, made ODD.  Workgroups go round the eight
@@ -653,10 +678,10 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                 a.tiles = full_grid ? kTilesPerBlock : std::min<u32>(kTilesPerBlock, (max_bytes + kSortTile - 1) / kSortTile);
                 a.sub_wgs = full_grid ? (kDecSubs + 255) / 256 : std::min<u32>((kDecSubs + 255) / 256, ((max_bytes + 63) / 64 + 255) / 256);
             }
-            a.slot = w->slot.as<u32>();
+            a.slot = w->slot.as<u32>() + s0;
             a.info = w->info.as<DecBlockInfo>();
             a.sym = w->sym.as<u16>();
-            a.nblock_max = w->nbmax.as<u32>();
+            a.nblock_max = w->nbmax.as<u32>() + s0;
             a.perm = w->perm.as<u8>();
             a.chunk_emit = w->chunk_emit.as<u32>();
             a.tt_len = w->tt_len.as<u32>();
@@ -680,8 +705,6 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             a.thist = w->thist.as<u32>();
             a.tbase = w->tbase.as<u32>();
             a.crc = w->crc.as<u32>();
-            HIPDEC(hipMemcpyAsync(w->slot.p, bslot.data(), (size_t)nb * 4, hipMemcpyHostToDevice, st));
-            HIPDEC(hipMemcpyAsync(w->nbmax.p, bmax.data(), (size_t)nb * 4, hipMemcpyHostToDevice, st));
             HIPDEC(hipMemsetAsync(w->err.p, 0, (size_t)nb * 4, st));
             HIPDEC(hipMemsetAsync(w->out_len.p, 0, (size_t)nb * 4, st));
             HIPDEC(hipEventRecord(ev[0], st));
@@ -702,7 +725,7 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             if (prof) { // algorithmic bytes per stage, now that symbol counts and block lengths are known
                 u64 nsym = 0, ntt = 0;
                 for (u32 i = 0; i < nb; ++i) {
-                    nsym += hslot[bslot[i]].nsym;
+                    nsym += hslot[bslot[s0 + i]].nsym;
                     ntt += h_err[i] ? 0 : h_tt[i];
                 }
                 prof->set_bytes(mtf_rec, nsym * 4 + ntt);    // symbols read twice (2 B), column written
@@ -732,7 +755,7 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                 sink.produced += bytes;
             } else if (good) {
                 u8 *dst = nullptr;
-                if (sink.host) {
+                if (sink.to_host()) {
                     const u32 sb = batch_no & 1u;
                     if (stage_busy[sb]) { // the copy of the batch before the last one reads this buffer
                         sink.pool->wait(stage_ticket[sb]);
@@ -769,14 +792,36 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                 stage_time(3);
                 u64 valid = bytes;
                 for (u32 i = 0; i < good; ++i) {
-                    if (~h_crc[i] != bcrc[i]) { // decoder.rs:189-198: noticed after the block's bytes went out
+                    if (~h_crc[i] != bcrc[s0 + i]) { // decoder.rs:189-198: noticed after the block's bytes went out
                         crc_bad = true;
                         keep = i + 1;
                         valid = h_base[i] + h_len[i];
                         break;
                     }
                 }
-                if (sink.host) {
+                if (sink.seg_alloc) {
+                    if (valid) {
+                        u8 *hp = sink.seg_alloc((size_t)valid);
+                        if (!hp) return BZ_E_NOMEM;
+                        if (sink.pool) {
+                            const u32 sb = batch_no & 1u;
+                            auto done_cb = sink.seg_done;
+                            const size_t vb = (size_t)valid;
+                            const bool fresh = sink.seg_fresh ? sink.seg_fresh(hp) : true;
+                            stage_ticket[sb] = sink.pool->submit(hp, dst, vb, hipMemcpyDeviceToHost, fresh, [done_cb, hp, vb](bool ok) { done_cb(hp, vb, ok); });
+                            stage_busy[sb] = true;
+                        } else {
+                            const bool ok = hipMemcpy(hp, dst, valid, hipMemcpyDeviceToHost) == hipSuccess;
+                            sink.seg_done(hp, (size_t)valid, ok);
+                            if (!ok) return BZ_E_UNEXPECTED;
+                        }
+                    }
+                    if (dec_trace())
+                        fprintf(stderr, "bz decode sub-batch %u: %u blocks, %llu bytes; stages so far D0+D1 %.2f, MTF %.2f, walks %.2f, expand+CRC %.2f ms (at %.1f)\n",
+                                batch_no, nb, (unsigned long long)valid, w->t_stage[0] * 1e3, w->t_stage[1] * 1e3, w->t_stage[2] * 1e3,
+                                w->t_stage[3] * 1e3, dec_now_ms());
+                    batch_no += 1;
+                } else if (sink.host) {
                     const size_t old = sink.host->len;
                     if (old + valid > sink.host->cap) {
                         // room for the rest of the file too, going by this batch's bytes per block (growing moves the
@@ -784,7 +829,7 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                         if (sink.pool) sink.pool->wait_all();
                         stage_busy[0] = stage_busy[1] = false;
                         size_t want = old + valid;
-                        const size_t rest = nc > ci ? nc - ci : 0; // candidates behind this batch
+                        const size_t rest = (size_t)(nb_all - s0 - nb) + (nc > ci ? nc - ci : 0); // blocks and candidates behind this sub-batch
                         if (rest && keep) want += (size_t)((double)valid / (double)keep * (double)rest * 1.02) + ((size_t)1 << 20);
                         const int hrc = sink.host->reserve(want);
                         if (hrc != BZ_OK) return hrc;
@@ -792,26 +837,30 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                     if (valid) {
                         if (sink.pool) {
                             const u32 sb = batch_no & 1u;
-                            stage_ticket[sb] = sink.pool->submit(sink.host->p + old, dst, valid, hipMemcpyDeviceToHost);
+                            stage_ticket[sb] = sink.pool->submit(sink.host->p + old, dst, valid, hipMemcpyDeviceToHost, true); // (fresh pages: touched first, on several threads)
                             stage_busy[sb] = true;
                         } else {
                             HIPDEC(hipMemcpy(sink.host->p + old, dst, valid, hipMemcpyDeviceToHost));
                         }
                     }
                     sink.host->len = old + valid; // (bytes whose copies may still be in flight: settled before this function returns)
+                    if (dec_trace())
+                        fprintf(stderr, "bz decode batch %u: %u blocks, %llu bytes; stages so far D0+D1 %.2f, MTF %.2f, walks %.2f, expand+CRC %.2f ms (at %.1f)\n",
+                                batch_no, nb, (unsigned long long)valid, w->t_stage[0] * 1e3, w->t_stage[1] * 1e3, w->t_stage[2] * 1e3,
+                                w->t_stage[3] * 1e3, dec_now_ms());
                     batch_no += 1;
                 }
                 sink.produced += valid;
                 } // shard_rc == BZ_OK
             }
-            if (crc_bad) local_fail = keep - 1;
-            else if (good < nb) local_fail = good;
+            if (crc_bad) local_fail = s0 + keep - 1;
+            else if (good < nb) local_fail = s0 + good;
             if (!sh && (crc_bad || good < nb)) {
                 *verdict = BZ_E_DATA;
                 finished = true;
-                continue;
             }
         }
+        if (finished) continue;
         if (sh) {
             // settle the verdict and the place of every slice
             std::vector<ShardSum> sums((size_t)sh->world);
@@ -859,7 +908,7 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
             finished = true;
         }
     }
-    if (sink.host && sink.pool) {
+    if (sink.to_host() && sink.pool) {
         sink.pool->wait_all();
         if (sink.pool->failed()) return BZ_E_UNEXPECTED;
     }
@@ -1012,6 +1061,7 @@ extern "C" int bz_decode_buffer(int device, const uint8_t *in, size_t in_len, ui
     if (!out || !out_len || (!in && in_len)) return BZ_E_PARAM;
     *out = nullptr;
     *out_len = 0;
+    const double t_enter = dec_now_ms();
     int caller_device = -1;
     (void)hipGetDevice(&caller_device); // (put back on return: ADVICE r3, the same rule as the encoder's entry points)
     bz_gpu_engine *g = dec_cache_take(device);
@@ -1021,23 +1071,17 @@ extern "C" int bz_decode_buffer(int device, const uint8_t *in, size_t in_len, ui
     int verdict = BZ_OK;
     rc = hipSetDevice(device) == hipSuccess ? g->dec_in.ensure(in_len + 64) : BZ_E_UNEXPECTED;
     if (rc == BZ_OK) {
-        // Both copies of the call on a few threads (copy_pool.h): the upload in slices side by side, the decoded bytes batch
-        // by batch beside the kernels of the next batch.  BZ_DEC_OVERLAP=0: one hipMemcpy each way, one batch (rounds 1-4).
+        // The decoded bytes leave batch by batch beside the kernels of the next batch (copy_pool.h: one copying thread, the
+        // fresh pages of the caller's buffer touched on several threads in front of it); the compressed bytes go up in one
+        // hipMemcpy as before (50 GB/s from pageable memory: 226 MB in 6 ms).  BZ_DEC_OVERLAP=0: one batch, one hipMemcpy
+        // behind it (rounds 1-4).
         static const bool overlap = !(getenv("BZ_DEC_OVERLAP") && atoi(getenv("BZ_DEC_OVERLAP")) == 0);
         CopyPool pool(device);
         rc = BZ_E_UNEXPECTED;
         // (the 64 bytes behind the stream are read as zeros by the bit readers)
-        bool up = hipMemsetAsync(static_cast<u8 *>(g->dec_in.p) + in_len, 0, 64, g->st) == hipSuccess;
-        if (up && in_len) {
-            if (overlap && in_len >= ((size_t)16 << 20)) {
-                pool.submit(g->dec_in.p, in, in_len, hipMemcpyHostToDevice);
-                pool.wait_all();
-                up = !pool.failed();
-            } else {
-                up = hipMemcpyAsync(g->dec_in.p, in, in_len, hipMemcpyHostToDevice, g->st) == hipSuccess;
-            }
-        }
-        if (up && hipStreamSynchronize(g->st) == hipSuccess) {
+        if (hipMemsetAsync(static_cast<u8 *>(g->dec_in.p) + in_len, 0, 64, g->st) == hipSuccess &&
+            (!in_len || hipMemcpyAsync(g->dec_in.p, in, in_len, hipMemcpyHostToDevice, g->st) == hipSuccess) &&
+            hipStreamSynchronize(g->st) == hipSuccess) {
             if (!g->dec) g->dec = new DecWorkspace();
             Sink sink;
             sink.host = &host;
@@ -1047,6 +1091,7 @@ extern "C" int bz_decode_buffer(int device, const uint8_t *in, size_t in_len, ui
             rc = decode_core(g, static_cast<const u8 *>(g->dec_in.p), in_len, sink, &verdict);
         }
     }
+    if (dec_trace()) fprintf(stderr, "bz_decode_buffer: %zu -> %zu bytes, rc %d, done at %.1f (entered at %.1f)\n", in_len, host.len, rc, dec_now_ms(), t_enter);
     if (rc == BZ_OK) dec_cache_put(device, g);
     else bz_gpu_engine_destroy(g); // (an engine that met an infrastructure error is not kept)
     if (caller_device >= 0) (void)hipSetDevice(caller_device);
@@ -1061,45 +1106,59 @@ extern "C" int bz_decode_buffer(int device, const uint8_t *in, size_t in_len, ui
 
 // ---- streaming mirror of BZip2Decoder (decoder.rs:583-612) ------------------------------------------------
 // The reference pulls input bytes on demand and yields output bytes one by one.  Here compressed bytes are collected
-// (bz_dec_write); whenever BZ_DEC_CHUNK bytes (default 32 MiB) have come in, and when the input ends (bz_dec_end), they go
-// to the context's WORKER thread, which decodes the records that are wholly there and queues their bytes (bz_dec_read)
+// (bz_dec_write); whenever BZ_DEC_CHUNK bytes (default 128 MiB; the first chunks of a stream 16 and 48 MiB, so that the GPU
+// has work early) have come in, and when the input ends (bz_dec_end), they go to the context's WORKER thread, which decodes the
+// records that are wholly there and queues their bytes (bz_dec_read), sub-batch by sub-batch as they land in host memory
 // -- while the caller goes on writing and reading: the caller's copies (compressed bytes in, decoded bytes out: a GiB of
-// them is 0.1 s of one core) run beside the upload, the kernels and the download of the next chunk instead of in a row
-// with them (rounds 1-4 decoded inside bz_dec_write: 4.2 GB/s for what the kernels do at 22).  The chain's state (bit
-// position, stream number, level, combined CRC) is carried from chunk to chunk, the bytes from the first undecided
-// record on are kept.  An error, if any, is reported after the bytes in front of it -- the same sequence of items the
-// reference's iterator produces; memory is bounded by the chunks in flight (two at most wait for the worker), not by
-// the file.
+// them is 0.1 s of one core) run beside the upload, the kernels and the download instead of in a row with them (rounds
+// 1-4 decoded inside bz_dec_write: 4.2 GB/s for what the kernels do at 22).  The chain's state (bit position, stream
+// number, level, combined CRC) is carried from chunk to chunk, the bytes from the first undecided record on are kept.
+// An error, if any, is reported after the bytes in front of it -- the same sequence of items the reference's iterator
+// produces; memory is bounded by the chunks in flight (two at most wait for the worker), not by the file.
+// bz_dec_end says "the input iterator has ended" and returns at once (with the verdict if it is already final);
+// behind it bz_dec_read WAITS for the next bytes or the final verdict instead of answering "nothing yet" -- a consumer
+// reads the head of the file while its tail is still being decoded.
 namespace {
 struct DecJob {
     std::vector<u8> bytes;
     bool final = false;
 };
-struct DecSeg { // decoded bytes of one chunk, handed out from `pos` on
-    HostBuf buf;
-    size_t pos = 0;
+struct DecSeg { // decoded bytes of one sub-batch, handed out from `pos` on
+    u8 *p = nullptr;
+    size_t len = 0, pos = 0, cap = 0;
+    bool landed = false; // the copy from the device is over (segments are queued in order when they are allocated)
+    bool fresh = true;   // its pages have not been touched yet
+    ~DecSeg() { free(p); }
 };
 } // namespace
 struct bz_dec {
     int device = 0;
     bz_gpu_engine *g = nullptr;
-    size_t chunk = (size_t)32 << 20;
+    size_t chunk = (size_t)128 << 20, first_chunk = (size_t)16 << 20;
     // the caller's side
     std::vector<u8> in; // compressed bytes not yet handed to the worker
     bool ended = false;
+    u64 chunks_sent = 0;
     // shared (mu)
     std::mutex mu;
     std::condition_variable cv;
     std::deque<DecJob> jobs;
     std::deque<DecSeg *> outq;
-    size_t out_bytes = 0;                // queued and not yet read
+    // Buffers that have been read (decoded bytes) or uploaded (compressed bytes) are kept for the sub-batches and chunks
+    // to come instead of being freed: memory the runtime has had registered for a copy is expensive to give back while
+    // kernels run (the unmapping invalidates the registration and stalls the process' queues -- chunks took 50-60 ms
+    // instead of 30 when every segment was freed behind its reader, profiles/r05_host_copies.md), and a buffer that
+    // comes back has its pages touched already.  At most four of each are kept.
+    std::vector<DecSeg *> spare_segs;
+    std::vector<std::vector<u8>> spare_bytes;
+    size_t out_bytes = 0;                // landed and not yet read
     u64 submitted = 0, processed = 0;    // jobs
     bool stop = false;
     bool done = false;                   // the verdict is final (error, or clean end): later input is ignored
     int verdict = BZ_OK;
     // the worker's side
     std::thread worker;
-    std::vector<u8> work; // compressed bytes from the next record on
+    std::vector<u8> carry; // compressed bytes from the next record on (what the last chunk left undecided)
     Resume rs;
     DevBuf d_in;
     CopyPool *pool = nullptr;
@@ -1118,49 +1177,101 @@ static void dec_process(bz_dec *d, DecJob &j)
         const int rc = d->g ? BZ_OK : bz_gpu_engine_create(&d->g, d->device, 0);
         if (rc != BZ_OK) return finish(rc);
     }
-    if (d->work.empty()) d->work.swap(j.bytes);
-    else d->work.insert(d->work.end(), j.bytes.begin(), j.bytes.end());
-    const size_t n = d->work.size();
-    int rc = hipSetDevice(d->device) == hipSuccess ? d->d_in.ensure(n + 64) : BZ_E_UNEXPECTED;
+    const double t0 = dec_now_ms();
+    // the device holds [carry | new bytes]: two uploads, no copy of the chunk on the host; room for a whole chunk and a
+    // block's worth of carry from the start, so that the buffer is made once
+    const size_t nc = d->carry.size(), nn = j.bytes.size(), n = nc + nn;
+    int rc = hipSetDevice(d->device) == hipSuccess ? d->d_in.ensure(std::max(n, d->chunk + ((size_t)4 << 20)) + 64) : BZ_E_UNEXPECTED;
     // (the 64 bytes behind the input are read as zeros by the bit readers)
-    if (rc == BZ_OK && hipMemset(static_cast<u8 *>(d->d_in.p) + n, 0, 64) != hipSuccess) rc = BZ_E_UNEXPECTED;
-    if (rc == BZ_OK && n) {
-        if (d->pool && n >= ((size_t)16 << 20)) {
-            d->pool->submit(d->d_in.p, d->work.data(), n, hipMemcpyHostToDevice);
-            d->pool->wait_all();
-            if (d->pool->failed()) rc = BZ_E_UNEXPECTED;
-        } else if (hipMemcpy(d->d_in.p, d->work.data(), n, hipMemcpyHostToDevice) != hipSuccess) {
-            rc = BZ_E_UNEXPECTED;
-        }
-    }
+    if (rc == BZ_OK && hipMemsetAsync(static_cast<u8 *>(d->d_in.p) + n, 0, 64, d->g->st) != hipSuccess) rc = BZ_E_UNEXPECTED;
+    if (rc == BZ_OK && nc && hipMemcpyAsync(d->d_in.p, d->carry.data(), nc, hipMemcpyHostToDevice, d->g->st) != hipSuccess) rc = BZ_E_UNEXPECTED;
+    if (rc == BZ_OK && nn && hipMemcpyAsync(static_cast<u8 *>(d->d_in.p) + nc, j.bytes.data(), nn, hipMemcpyHostToDevice, d->g->st) != hipSuccess)
+        rc = BZ_E_UNEXPECTED;
+    if (rc == BZ_OK && hipStreamSynchronize(d->g->st) != hipSuccess) rc = BZ_E_UNEXPECTED;
+    const double t1 = dec_now_ms();
     int verdict = BZ_OK;
-    DecSeg *seg = new DecSeg();
+    size_t produced = 0;
     if (rc == BZ_OK) {
         if (!d->g->dec) d->g->dec = new DecWorkspace();
         Sink sink;
-        sink.host = &seg->buf;
+        // a buffer of its own for every sub-batch, queued at once (the order of the queue is the order of the file) and
+        // handed to the reader when its bytes have landed
+        sink.seg_alloc = [d](size_t k) -> u8 * {
+            DecSeg *sg = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(d->mu);
+                size_t best = ~(size_t)0;
+                for (size_t i = 0; i < d->spare_segs.size(); ++i)
+                    if (d->spare_segs[i]->cap >= k && (best == ~(size_t)0 || d->spare_segs[i]->cap < d->spare_segs[best]->cap)) best = i;
+                if (best != ~(size_t)0) {
+                    sg = d->spare_segs[best];
+                    d->spare_segs.erase(d->spare_segs.begin() + (ptrdiff_t)best);
+                }
+            }
+            if (!sg) {
+                void *q = nullptr;
+                const size_t want = (k + k / 16 + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1); // (sub-batches of a file differ by a per cent or two)
+                if (posix_memalign(&q, (size_t)2 << 20, want) != 0) return nullptr;
+                (void)madvise(q, want, MADV_HUGEPAGE);
+                sg = new DecSeg();
+                sg->p = static_cast<u8 *>(q);
+                sg->cap = want;
+            }
+            sg->len = k;
+            sg->pos = 0;
+            sg->landed = false;
+            std::lock_guard<std::mutex> lk(d->mu);
+            d->outq.push_back(sg);
+            return sg->p;
+        };
+        sink.seg_fresh = [d](u8 *p8) {
+            std::lock_guard<std::mutex> lk(d->mu);
+            for (DecSeg *sg : d->outq)
+                if (sg->p == p8) {
+                    const bool f = sg->fresh;
+                    sg->fresh = false;
+                    return f;
+                }
+            return true;
+        };
+        sink.seg_done = [d](u8 *p8, size_t k, bool ok) {
+            {
+                std::lock_guard<std::mutex> lk(d->mu);
+                for (DecSeg *sg : d->outq)
+                    if (sg->p == p8) {
+                        sg->landed = true; // (a failed copy ends the context with an error: its bytes are never read as data)
+                        if (ok) d->out_bytes += k;
+                        else sg->len = sg->pos;
+                    }
+            }
+            d->cv.notify_all();
+        };
         sink.staging[0] = &d->g->dec->staging;
         sink.staging[1] = &d->g->dec->staging2;
         sink.pool = d->pool;
         d->rs.final = j.final;
         rc = decode_core(d->g, d->d_in.as<u8>(), n, sink, &verdict, nullptr, &d->rs);
+        produced = (size_t)sink.produced;
     }
-    // the bytes in front of an error are handed over too, as the reference's iterator yields them
-    if (rc == BZ_OK && seg->buf.len) {
-        std::lock_guard<std::mutex> lk(d->mu);
-        d->out_bytes += seg->buf.len;
-        d->outq.push_back(seg);
-    } else {
-        delete seg;
-    }
+    if (dec_trace())
+        fprintf(stderr, "bz_dec chunk: %zu + %zu compressed bytes (final %d): upload %.2f ms, decode %.2f ms -> %zu bytes, rc %d verdict %d (at %.1f)\n",
+                nc, nn, (int)j.final, t1 - t0, dec_now_ms() - t1, produced, rc, verdict, dec_now_ms());
+    // (the bytes in front of an error have been handed over too, as the reference's iterator yields them)
     if (rc != BZ_OK || verdict != BZ_OK) return finish(rc != BZ_OK ? rc : verdict);
     if (d->rs.stopped) { // keep the input from the undecided record on
         const size_t used = (size_t)(d->rs.pos >> 3);
-        d->work.erase(d->work.begin(), d->work.begin() + (ptrdiff_t)used);
+        std::vector<u8> keep;
+        if (used < nc) {
+            keep.assign(d->carry.begin() + (ptrdiff_t)used, d->carry.end());
+            keep.insert(keep.end(), j.bytes.begin(), j.bytes.end());
+        } else {
+            keep.assign(j.bytes.begin() + (ptrdiff_t)(used - nc), j.bytes.end());
+        }
+        d->carry.swap(keep);
         d->rs.pos &= 7u;
         return;
     }
-    d->work.clear();
+    d->carry.clear();
     finish(BZ_OK); // the file ended cleanly
 }
 
@@ -1182,6 +1293,10 @@ static void dec_worker(bz_dec *d)
         {
             std::lock_guard<std::mutex> lk(d->mu);
             d->processed += 1;
+            if (j.bytes.capacity() >= ((size_t)4 << 20) && d->spare_bytes.size() < 4) { // (kept for the writer, see spare_segs)
+                j.bytes.clear();
+                d->spare_bytes.push_back(std::move(j.bytes));
+            }
         }
         d->cv.notify_all();
     }
@@ -1198,7 +1313,11 @@ extern "C" int bz_dec_create(bz_dec **out, int device)
     d->device = device;
     if (const char *e = getenv("BZ_DEC_CHUNK")) {
         const long long v = atoll(e);
-        if (v >= 1) d->chunk = (size_t)v;
+        if (v >= 1) d->chunk = d->first_chunk = (size_t)v;
+    }
+    if (const char *e = getenv("BZ_DEC_FIRST_CHUNK")) {
+        const long long v = atoll(e);
+        if (v >= 1) d->first_chunk = (size_t)v;
     }
     static const bool overlap = !(getenv("BZ_DEC_OVERLAP") && atoi(getenv("BZ_DEC_OVERLAP")) == 0);
     if (overlap) d->pool = new CopyPool(device);
@@ -1212,6 +1331,7 @@ static void dec_submit(bz_dec *d, bool final)
     DecJob j;
     j.bytes.swap(d->in);
     j.final = final;
+    d->chunks_sent += 1;
     // A small chunk (less than 4 MiB: short files, and every test that sets a small BZ_DEC_CHUNK to look at the moments
     // bytes and errors come out) is decoded before this call returns, as in rounds 1-4: handing it over would only delay
     // its bytes by a thread switch.  A large one is decoded beside the caller.
@@ -1245,15 +1365,30 @@ extern "C" int bz_dec_write(bz_dec *d, const uint8_t *data, size_t n)
     // A chunk goes to the worker once BZ_DEC_CHUNK bytes are there; a large write is cut at that size, but never into
     // pieces of less than 1 MiB (a tiny BZ_DEC_CHUNK -- the tests' way to stop the decoder in mid-record -- hands over what
     // a call brought, as rounds 1-4 did, not thousands of jobs).
-    const size_t gran = std::max(d->chunk, (size_t)1 << 20);
     while (n) {
+        // (16, 48, 128, 128 ... MiB: the worker has a chunk as soon as 16 MiB are there, and the Huffman stage -- 11 ms per
+        // chunk whatever its size: the latency of one block -- is paid four times per GiB of output, not eight)
+        size_t chunk = d->chunk;
+        if (d->chunks_sent < 4) {
+            size_t c = d->first_chunk;
+            for (u64 q = 0; q < d->chunks_sent && c < d->chunk; ++q) c *= 3;
+            chunk = std::min(c, d->chunk);
+        }
+        const size_t gran = std::max(chunk, (size_t)1 << 20);
         const size_t room = d->in.size() < gran ? gran - d->in.size() : 0;
         const size_t k = room ? std::min(n, room) : n;
-        if (d->in.size() + k > d->in.capacity()) d->in.reserve(std::max(d->in.size() + k, std::min(gran, 2 * d->in.capacity())));
+        if (d->in.empty() && d->in.capacity() < gran && gran >= ((size_t)4 << 20)) { // (a buffer an earlier chunk went up from, if one has come back)
+            std::lock_guard<std::mutex> lk(d->mu);
+            if (!d->spare_bytes.empty()) {
+                d->in.swap(d->spare_bytes.back());
+                d->spare_bytes.pop_back();
+            }
+        }
+        if (d->in.size() + k > d->in.capacity()) d->in.reserve(std::max(d->in.size() + k, std::min(gran, std::max((size_t)65536, 2 * d->in.capacity()))));
         d->in.insert(d->in.end(), data, data + k);
         data += k;
         n -= k;
-        if (d->in.size() >= d->chunk && (d->in.size() >= gran || n == 0)) dec_submit(d, false);
+        if (d->in.size() >= chunk && (d->in.size() >= gran || n == 0)) dec_submit(d, false);
     }
     return BZ_OK;
 }
@@ -1265,9 +1400,8 @@ extern "C" int bz_dec_end(bz_dec *d)
         d->ended = true;
         dec_submit(d, true);
     }
-    std::unique_lock<std::mutex> lk(d->mu);
-    d->cv.wait(lk, [&] { return d->processed >= d->submitted; });
-    return d->verdict;
+    std::lock_guard<std::mutex> lk(d->mu);
+    return d->done ? d->verdict : BZ_OK; // (not final yet: the verdict follows the last byte out of bz_dec_read, which waits for it now)
 }
 
 extern "C" long bz_dec_read(bz_dec *d, uint8_t *out, size_t cap)
@@ -1275,22 +1409,31 @@ extern "C" long bz_dec_read(bz_dec *d, uint8_t *out, size_t cap)
     if (!d || (!out && cap)) return BZ_E_PARAM;
     DecSeg *seg = nullptr;
     {
-        std::lock_guard<std::mutex> lk(d->mu);
-        if (d->outq.empty()) // verdict (0 = clean end) once it is final and every chunk handed over has been looked at, else "nothing yet"
-            return (d->done && d->processed >= d->submitted) ? (long)d->verdict : 0;
-        seg = d->outq.front(); // (only this thread takes segments off the queue)
+        std::unique_lock<std::mutex> lk(d->mu);
+        for (;;) {
+            while (!d->outq.empty() && d->outq.front()->landed && d->outq.front()->pos == d->outq.front()->len) { // (read, or lost)
+                if (d->spare_segs.size() < 4) d->spare_segs.push_back(d->outq.front());
+                else delete d->outq.front();
+                d->outq.pop_front();
+            }
+            if (!d->outq.empty() && d->outq.front()->landed) break;
+            const bool idle = d->processed >= d->submitted; // (a chunk that has been looked at has all its segments landed)
+            // the verdict (0 = clean end) once it is final and every chunk handed over has been looked at
+            if (d->outq.empty() && d->done && idle) return (long)d->verdict;
+            // "nothing yet" while more input may come; behind the end of the input the next bytes or the verdict are waited for
+            if (!d->ended || (d->outq.empty() && idle)) return 0;
+            d->cv.wait(lk);
+        }
+        seg = d->outq.front(); // (only this thread takes segments off the queue; the worker appends behind it)
     }
-    const size_t left = seg->buf.len - seg->pos;
+    const size_t left = seg->len - seg->pos;
     const size_t k = left < cap ? left : cap;
-    memcpy(out, seg->buf.p + seg->pos, k);
-    seg->pos += k;
+    memcpy(out, seg->p + seg->pos, k);
     {
         std::lock_guard<std::mutex> lk(d->mu);
+        seg->pos += k;
         d->out_bytes -= k;
-        if (seg->pos == seg->buf.len) d->outq.pop_front();
-        else seg = nullptr;
     }
-    delete seg;
     return (long)k;
 }
 
@@ -1316,6 +1459,7 @@ extern "C" void bz_dec_destroy(bz_dec *d)
     if (d->worker.joinable()) d->worker.join();
     delete d->pool;
     for (DecSeg *sg : d->outq) delete sg;
+    for (DecSeg *sg : d->spare_segs) delete sg;
     if (d->g) (void)hipSetDevice(d->device);
     d->d_in.release();
     if (d->g) { // (kept for the next context or one-shot call unless the context met an infrastructure error)

@@ -618,13 +618,14 @@ extern "C" int df_encode_buffer_dict(int kind, int device, const uint8_t *in, si
     rc = hipSetDevice(device) == hipSuccess ? BZ_OK : BZ_E_UNEXPECTED;
     if (rc == BZ_OK) rc = g->dec_in.ensure(in_len + 64);
     if (rc == BZ_OK) rc = g->oneshot_out.ensure(cap);
-    // Large inputs: the call's two copies run beside its kernels (copy_pool.h).  The input goes up in 8 MiB slices on a
-    // few threads, in order; the encode runs in parts of BZ_DF_BUFFER_PART_MIB (default 128 MiB -- the bytes do not depend
+    // Large inputs: the call's two copies run beside its kernels (copy_pool.h).  The input goes up in 32 MiB slices from one
+    // thread, in order; the encode runs in parts of BZ_DF_BUFFER_PART_MIB (default 128 MiB -- the bytes do not depend
     // on the parts, tests/test_gpu_deflate.py::test_many_part_seams_equal_oracle_golden), each as soon as its bytes have
     // arrived, and a part's bytes of the stream leave for the caller's buffer while the next part is encoded.  Rounds 1-4
     // uploaded everything, encoded, downloaded: 110 ms per GiB for 66 ms of kernels.
     // BZ_DF_OVERLAP=0 restores that.
-    static const bool overlap = !(getenv("BZ_DF_OVERLAP") && atoi(getenv("BZ_DF_OVERLAP")) == 0);
+    // (bits, for A/B runs: 1 the upload beside the parts, 2 the downloads beside the parts; 4 alone: parts, but the copies as before)
+    static const int overlap = getenv("BZ_DF_OVERLAP") ? atoi(getenv("BZ_DF_OVERLAP")) : 3;
     if (rc == BZ_OK && overlap && in_len >= ((size_t)64 << 20)) {
         static const u64 part_bytes = [] {
             const char *e = getenv("BZ_DF_BUFFER_PART_MIB");
@@ -645,15 +646,17 @@ extern "C" int df_encode_buffer_dict(int kind, int device, const uint8_t *in, si
             DfPartHooks hooks;
             hooks.part_bytes = std::min<u64>(part_bytes, df_part_bytes());
             hooks.need_input = [&](u64 upto) {
+                if (!(overlap & 1)) upto = in_len;
                 const size_t want = (size_t)std::min<u64>((upto + S - 1) / S, up.size());
                 for (; waited < want; ++waited) pool.wait(up[waited]);
                 return pool.failed() ? BZ_E_UNEXPECTED : BZ_OK;
             };
             hooks.part_done = [&](size_t off, size_t len) {
-                if (len) pool.submit(h + off, static_cast<const u8 *>(g->oneshot_out.p) + off, len, hipMemcpyDeviceToHost);
+                if (len && (overlap & 2)) pool.submit(h + off, static_cast<const u8 *>(g->oneshot_out.p) + off, len, hipMemcpyDeviceToHost, true);
             };
             rc = df_encode_parts(g, kind, static_cast<const u8 *>(g->dec_in.p), in_len, dict, dict_len, static_cast<u8 *>(g->oneshot_out.p), cap,
-                                 &n_out);
+                                 &n_out, DfSeg(), nullptr, &hooks);
+            if (rc == BZ_OK && !(overlap & 2) && n_out) pool.submit(h, g->oneshot_out.p, n_out, hipMemcpyDeviceToHost, true);
             pool.wait_all();
             if (rc == BZ_OK && pool.failed()) rc = BZ_E_UNEXPECTED;
         }

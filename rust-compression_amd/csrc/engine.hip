@@ -84,8 +84,8 @@ static int ensure_workspace(bz_gpu_engine *g, size_t need_blocks)
     ENS(active, 64 * 8 + 64 * 4);
     ENS(per_k, nb * 4);
     ENS(per_shift, nb * 4);
-    ENS(lin_p, nb * 4);
-    ENS(lin_sig, nb * 4);
+    ENS(lin_p, nb * (size_t)4 * kPerK);
+    ENS(lin_sig, nb * (size_t)4 * kPerK);
     ENS(bin_cursor, nb * (size_t)1024 * 4);
     ENS(pb_gate, nb * (size_t)4 + 256); // (+ loc_stats behind the gates)
     // (cleared ON THE ENGINE'S STREAM: a memset on the null stream is not ordered against work on a non-blocking stream,
@@ -682,8 +682,8 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
     x.maxnf = reinterpret_cast<u32 *>(g->active.as<unsigned long long>() + 64);
     x.per_k = g->per_k.as<u32>() + o;
     x.per_shift = g->per_shift.as<u32>() + o;
-    x.lin_p = g->lin_p.as<u32>() + o;
-    x.lin_sig = g->lin_sig.as<u32>() + o;
+    x.lin_p = g->lin_p.as<u32>() + (size_t)o * kPerK;
+    x.lin_sig = g->lin_sig.as<u32>() + (size_t)o * kPerK;
     x.bin_cursor = g->bin_cursor.as<u32>() + (size_t)o * 1024;
     x.pb_gate = g->pb_gate.as<u32>() + o;
     x.loc_stats = g->pb_gate.as<u32>() + g->ws_blocks; // (behind the gates)
@@ -703,6 +703,8 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
     x.tile_state_bytes = g->tile_state.cap;
     static const u32 want_fused = (getenv("BZ_ONESWEEP") && atoi(getenv("BZ_ONESWEEP")) == 0) ? 0u : 1u;
     x.fused = want_fused;
+    static const u32 want_pairs = (getenv("BZ_PAIR_COMPARE") && atoi(getenv("BZ_PAIR_COMPARE")) != 0) ? 1u : 0u;
+    x.per_pairs = want_pairs;
     return x;
 }
 

@@ -92,36 +92,60 @@ __device__ __forceinline__ u64 newbits_lane_word(const u64 *__restrict__ bits, s
     return m;
 }
 
-// ---- the period round's tables (k_period_find / k_period_bits / k_period_next), per block, in the flag bytes' slot ----
-// For a block with period p (lin_p): mis = bitmap of the positions i with T[i] != T[(i + p) mod n], lt = bitmap of
-// T[i] < T[(i + p) mod n], nxt[w] = the first such position at or behind 64 w (+ n when the search wraps).
+// ---- the period round's tables (k_period_find / k_period_bits / k_period_next), per block and listed distance ----
+// For a block that agrees with itself at distance p (lin_p[lb][i], i < kPerK): mis = bitmap of the positions x with
+// T[x] != T[(x + p) mod n], lt = bitmap of T[x] < T[(x + p) mod n], nxt[w] = the first such position at or behind 64 w
+// (+ n when the search wraps).  One set is 281 608 bytes; the sets of a block live in its digit-count slot
+// (gh_tiles: 2.7 MB per block, which only the fused walk rounds use -- room for eight) or, without the fused passes or
+// with the pair comparison on (its verdict bytes live there), in the flag bytes' slot (room for three).
 constexpr u32 kPerWords = kSlot / 64u; // 14080 words of 64 positions
-__device__ __forceinline__ const u64 *per_mis(const BwtArgs &a, u32 lb) { return reinterpret_cast<const u64 *>(a.flags + (size_t)lb * kSlot); }
-__device__ __forceinline__ const u64 *per_lt(const BwtArgs &a, u32 lb) { return per_mis(a, lb) + kPerWords; }
-__device__ __forceinline__ const u32 *per_nxt(const BwtArgs &a, u32 lb) { return reinterpret_cast<const u32 *>(per_mis(a, lb) + 2u * kPerWords); }
-// Rotations i and i + p (both < n) agree until the first position m >= i (cyclic) where the block and the block
-// shifted by p differ, and there rotation i reads T[m], rotation i + p reads T[m + p].
-// per_first_mis: that m, in [i, i + n);  per_lt_at: T[m] < T[m + p], i.e. rot(i) < rot(i + p)
-__device__ __forceinline__ u32 per_first_mis(const BwtArgs &a, u32 lb, u32 i)
+constexpr u32 kPerSetBytes = 2u * kPerWords * 8u + ((kPerWords + 1u) * 4u + 7u) / 8u * 8u;
+static_assert((size_t)kPerK * kPerSetBytes <= (size_t)kTilesPerBlock * 3 * kMaxBins * 4, "the period tables do not fit the digit-count slot");
+__host__ __device__ __forceinline__ bool per_in_counts(const BwtArgs &a) { return a.gh_tiles != nullptr && !a.per_pairs; }
+__host__ __device__ __forceinline__ u32 per_kmax(const BwtArgs &a) { return per_in_counts(a) ? kPerK : (kSlot / kPerSetBytes < kPerK ? kSlot / kPerSetBytes : kPerK); }
+__device__ __forceinline__ const u8 *per_set(const BwtArgs &a, u32 lb, u32 i)
 {
-    const u32 w = i >> 6;
-    const u64 here = per_mis(a, lb)[w] & (~0ull << (i & 63u));
-    return here ? (w << 6) + (u32)__builtin_ctzll(here) : per_nxt(a, lb)[w + 1u];
+    const u8 *base = per_in_counts(a) ? reinterpret_cast<const u8 *>(a.gh_tiles + (size_t)lb * kTilesPerBlock * 3 * kMaxBins)
+                                      : a.flags + (size_t)lb * kSlot;
+    return base + (size_t)i * kPerSetBytes;
 }
-__device__ __forceinline__ bool per_lt_at(const BwtArgs &a, u32 lb, u32 n, u32 m)
+__device__ __forceinline__ const u64 *per_mis(const BwtArgs &a, u32 lb, u32 i) { return reinterpret_cast<const u64 *>(per_set(a, lb, i)); }
+__device__ __forceinline__ const u64 *per_lt(const BwtArgs &a, u32 lb, u32 i) { return per_mis(a, lb, i) + kPerWords; }
+__device__ __forceinline__ const u32 *per_nxt(const BwtArgs &a, u32 lb, u32 i) { return reinterpret_cast<const u32 *>(per_mis(a, lb, i) + 2u * kPerWords); }
+// Rotations x and x + p (both < n) agree until the first position m >= x (cyclic) where the block and the block
+// shifted by p differ, and there rotation x reads T[m], rotation x + p reads T[m + p].
+// per_first_mis: that m, in [x, x + n);  per_lt_at: T[m] < T[m + p], i.e. rot(x) < rot(x + p)
+__device__ __forceinline__ u32 per_first_mis(const BwtArgs &a, u32 lb, u32 i, u32 x)
+{
+    const u32 w = x >> 6;
+    const u64 here = per_mis(a, lb, i)[w] & (~0ull << (x & 63u));
+    return here ? (w << 6) + (u32)__builtin_ctzll(here) : per_nxt(a, lb, i)[w + 1u];
+}
+__device__ __forceinline__ bool per_lt_at(const BwtArgs &a, u32 lb, u32 i, u32 n, u32 m)
 {
     if (m >= n) m -= n;
-    return (per_lt(a, lb)[m >> 6] >> (m & 63u)) & 1ull;
+    return (per_lt(a, lb, i)[m >> 6] >> (m & 63u)) & 1ull;
 }
-// The direction a survivor is keyed by in the period round: that of a pair it belongs to at the depth reached -- the
-// pair (j, j + p) if those two still agree on `depth` symbols (they are in one group then), else the pair (j - p, j):
-// the last member of a chain has no successor in its group, and what decides its own successor pair is not the chain's
-// business.
-__device__ __forceinline__ bool per_key_ascending(const BwtArgs &a, u32 lb, u32 n, u32 p, u32 depth, u32 j)
+// The direction a survivor is keyed by in the period round (ascending: by its start, descending: by its mirrored
+// start): that of a pair it belongs to at the depth reached -- for the first listed distance p under which it has a
+// mate in its group, the pair (j, j + p) if those two still agree on `depth` symbols, else the pair (j - p, j) if THOSE
+// do.  A heuristic only: k_period_mark checks every pair of neighbours of the sorted list exactly.
+__device__ __forceinline__ bool per_key_ascending(const BwtArgs &a, u32 lb, u32 n, u32 depth, u32 j)
 {
-    const u32 m = per_first_mis(a, lb, j);
-    if ((j + p < n && m - j >= depth) || j < p) return per_lt_at(a, lb, n, m);
-    return per_lt_at(a, lb, n, per_first_mis(a, lb, j - p));
+    const u32 kmax = per_kmax(a);
+    for (u32 i = 0; i < kmax; ++i) {
+        const u32 p = a.lin_p[(size_t)lb * kPerK + i];
+        if (p == 0u) break;
+        if (j + p < n) {
+            const u32 m = per_first_mis(a, lb, i, j);
+            if (m - j >= depth) return per_lt_at(a, lb, i, n, m);
+        }
+        if (j >= p) {
+            const u32 m = per_first_mis(a, lb, i, j - p);
+            if (m - (j - p) >= depth) return per_lt_at(a, lb, i, n, m);
+        }
+    }
+    return true;
 }
 
 // k_pair_compare's verdicts (the period round's groups of two), one byte per list position (0: not ordered here, 2: the smaller member, 3: the greater one), in the
@@ -195,23 +219,27 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
             ok |= (idx < cnt ? 1u : 0u) << r;
         }
     } else if (SRC == SRC_PAIRS) {
+        // Streamed lists: no index is clamped (a row beyond the list still lies inside the block's slot -- 110 tiles of
+        // 8192 are exactly kSlot -- and takes no part), so the sixteen rows of a lane are ONE address register and sixteen
+        // immediate offsets, and the participation mask is "the first k rows" (round 5; before: a compare, a select, a
+        // 64-bit shift and two 64-bit adds per row and array).
+        const u32 *kp = Kin + base, *vp = Vin + base;
 #pragma unroll
         for (u32 r = 0; r < 16; ++r) {
-            const u32 idx = first + r * 64u;
-            const u32 c = idx < cnt ? idx : cnt - 1u;
-            key[r] = ld_stream(Kin + base + c);
-            val[r] = ld_stream(Vin + base + c);
-            ok |= (idx < cnt ? 1u : 0u) << r;
+            key[r] = ld_stream_at(kp, first + r * 64u);
+            val[r] = ld_stream_at(vp, first + r * 64u);
         }
+        const u32 rows = first < cnt ? (cnt - first + 63u) >> 6 : 0u;
+        ok = rows >= 16u ? 0xFFFFu : (1u << rows) - 1u;
     } else if (SRC == SRC_PACKED) {
+        const u32 *vp = Vin + base;
 #pragma unroll
         for (u32 r = 0; r < 16; ++r) {
-            const u32 idx = first + r * 64u;
-            const u32 c = idx < cnt ? idx : cnt - 1u;
-            key[r] = ld_stream(Vin + base + c); // (the digit is taken with shift 20; the rotation rides in the low bits)
+            key[r] = ld_stream_at(vp, first + r * 64u); // (the digit is taken with shift 20; the rotation rides in the low bits)
             val[r] = key[r] & 0xFFFFFu;
-            ok |= (idx < cnt ? 1u : 0u) << r;
         }
+        const u32 rows = first < cnt ? (cnt - first + 63u) >> 6 : 0u;
+        ok = rows >= 16u ? 0xFFFFu : (1u << rows) - 1u;
     } else if (SRC == SRC_SURV) {
         // survivor round, first half: order the survivors by the rank of rotation j+h
 #pragma unroll
@@ -230,8 +258,8 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
     } else if (SRC == SRC_PERJ) {
         // the period round: order the survivors by where they start -- ascending or descending, as the first
         // difference between the block and the block shifted by its period decides for each of them (per_ascending)
-        const u32 p = a.lin_p[lb]; // (hm: the depth reached, in symbols)
-        const u8 *pb8 = a.gh_tiles ? pair_bytes(a, lb) : nullptr;
+        const u32 p = a.lin_p[(size_t)lb * kPerK]; // (hm: the depth reached, in symbols; 0: the block has no listed distance)
+        const u8 *pb8 = (a.gh_tiles && a.per_pairs) ? pair_bytes(a, lb) : nullptr;
         u32 pairv[16];
 #pragma unroll
         for (u32 r = 0; r < 16; ++r) {
@@ -244,7 +272,7 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
 #pragma unroll
         for (u32 r = 0; r < 16; ++r) {
             if (pairv[r]) key[r] = pairv[r] & 1u; // a group of two, ordered by k_pair_compare
-            else key[r] = (p != 0u && !per_key_ascending(a, lb, n, p, hm, val[r])) ? (n - 1u - val[r]) : val[r];
+            else key[r] = (p != 0u && !per_key_ascending(a, lb, n, hm, val[r])) ? (n - 1u - val[r]) : val[r];
         }
     } else if (SRC == SRC_LISTG) {
         // survivor round, second half: walk that order, key = the survivor's own group
@@ -660,8 +688,31 @@ __global__ __launch_bounds__(kSortThreads) void k_ghist_scan(BwtArgs a, u32 ndig
 // keys from the block and only walks the order)
 // PACK_OUT: the element leaves as ONE word, (key >> (shift + BITS)) << 20 | rotation: the digits this pass and the
 // passes before it have used up are not needed again (4 bytes written instead of 8; the next pass is <SRC_PACKED>)
+// (-DBZ_SCATTER_WAVES_PER_EU=6: the compiler is told to fit three workgroups per CU -- 80 registers, a few of them
+// spilled -- instead of the two that 95 registers allow; an A/B switch, profiles/r05_sort_negatives.md)
+#ifndef BZ_SCATTER_LATE_LB
+#define BZ_SCATTER_LATE_LB 1
+#endif
+#ifndef BZ_LB_WINDOW
+#define BZ_LB_WINDOW 1
+#endif
+#ifdef BZ_SCATTER_WAVES_PER_EU
+#define BZ_SCATTER_BOUNDS __launch_bounds__(kSortThreads, BZ_SCATTER_WAVES_PER_EU)
+#else
+#define BZ_SCATTER_BOUNDS __launch_bounds__(kSortThreads)
+#endif
+// -DBZ_SCATTER_TIMING: cycles (>> 6) per phase of a tile, summed over the tiles of all launches into loc_stats[32 + 8 * c + k]
+// (c = 0: the streamed sources PAIRS / PACKED, c = 1: the sources that gather -- TEXT, WALK, MM, MMC; a barrier at every
+// mark; BZ_LOCAL_TRACE=1 prints them): 0 ticket + set-up + counters cleared, 1 rows fetched and ranked, 2 counts over the
+// waves + scan over the digits, 3 look-back, 4 places + keys staged, 5 keys read back and stored, 6 values staged,
+// 7 values read back and stored
+#ifdef BZ_SCATTER_TIMING
+#define SC_T(k) do { __syncthreads(); const u64 t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&a.loc_stats[32 + ((SRC == SRC_PAIRS || SRC == SRC_PACKED) ? 0 : 8) + (k)], (u32)((t_ - t_prev) >> 6)); t_prev = t_; } while (0)
+#else
+#define SC_T(k) do { } while (0)
+#endif
 template <int SRC, int BITS, bool WRITE_K = true, bool PACK_OUT = false>
-__global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h,
+__global__ BZ_SCATTER_BOUNDS void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h,
                                                                     const u32 *__restrict__ Kin,
                                                                     const u32 *__restrict__ Vin,
                                                                     u32 *__restrict__ Kout, u32 *__restrict__ Vout,
@@ -672,7 +723,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
     constexpr u32 NW = kSortThreads / 64;
     __shared__ u32 s_buf[kSortTile];
     __shared__ u32 s_base[NB];
-    __shared__ u16 s_tpre[NB];
+    __shared__ u16 s_tpre[NB]; // (only between the scan over the digits and the look-back: see s_base below)
     __shared__ u32 s_wsum[NW];
     __shared__ u32 s_total;
     __shared__ u32 s_ticket;
@@ -683,6 +734,9 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
     // round-robin (observed: XCC_ID == linear id % 8), so every XCD gets as many workgroups as it has
     // tiles; the host checks that every counter reached its total and falls back to the three-kernel
     // passes if a dispatch ever does it differently.
+#ifdef BZ_SCATTER_TIMING
+    u64 t_prev = __builtin_readcyclecounter();
+#endif
     const u32 xcd = (u32)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u; // XCC_ID, bits 3:0
     const u32 my_tiles = a.tiles * ((a.nb + 7u - xcd) / 8u); // (a.tiles: tiles per block the launch covers)
     if (threadIdx.x == 0) s_ticket = atomicAdd(&a.tickets[(size_t)epoch * 8u + xcd], 1u);
@@ -705,6 +759,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
     const size_t base = (size_t)lb * kSlot;
     for (u32 i = threadIdx.x; i < NW * NB / 2; i += kSortThreads) s_buf[i] = 0;
     __syncthreads();
+    SC_T(0);
 
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
     const u64 lt_mask = (l == 0) ? 0ull : (~0ull >> (64 - l));
@@ -745,76 +800,35 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
         rnk[r] = rank_in_wave<BITS>(my_cnt, dg, ok, l, lt_mask);
     }
     __syncthreads();
+    SC_T(1);
     constexpr u32 PER = NB / kSortThreads; // digits per thread (2 or 4), consecutive
     u32 tot[PER];
     u32 mine = 0;
-#pragma unroll
-    for (u32 q = 0; q < PER; ++q) {
-        const u32 dg = threadIdx.x * PER + q;
-        u32 run = 0;
-#pragma unroll
-        for (u32 k = 0; k < NW; ++k) {
-            const u32 c = s_cnt[k * NB + dg];
-            s_cnt[k * NB + dg] = (u16)run;
-            run += c;
-        }
-        tot[q] = run;
-        mine += run;
-    }
-    // this tile's digit counts go out, the predecessors' come in: four digits per 16-byte word group
-    // (one sc1 store / load moves 16 bytes for the price of 4, MI355X_MICROARCH.md)
-#pragma unroll
-    for (u32 q = 0; q < PER; ++q) s_base[threadIdx.x * PER + q] = tot[q];
-    __syncthreads();
-    if (threadIdx.x < NB / 4u) {
-        const u32 d0 = threadIdx.x * 4u;
-        u32 *mystate = a.tile_state + ((size_t)lb * kTilesPerBlock + tile) * kMaxBins + d0;
-        const u32 etag = epoch << 22;
-        const u32 t4[4] = {s_base[d0], s_base[d0 + 1], s_base[d0 + 2], s_base[d0 + 3]};
-        const u32 f0 = etag | (tile ? kLbAgg : kLbIncl);
-        st_sc1_x4(mystate, make_uint4(f0 | t4[0], f0 | t4[1], f0 | t4[2], f0 | t4[3]));
-        u32 excl[4] = {0, 0, 0, 0};
-        if (tile) {
-            u32 open = 0xFu; // digits whose sum has not met an inclusive prefix yet
-            u32 spins = 0;
-            for (u32 p = tile; p > 0 && open;) {
-                --p;
-                const u32 *src = a.tile_state + ((size_t)lb * kTilesPerBlock + p) * kMaxBins + d0;
-                uint4 v = ld_sc1_x4(src);
-                while (true) {
-                    const u32 x[4] = {v.x, v.y, v.z, v.w};
-                    bool ready = true;
-#pragma unroll
-                    for (u32 k = 0; k < 4; ++k)
-                        if ((x[k] >> 22) != epoch || (x[k] & kLbFlagMask) == 0u) ready = false;
-                    if (ready) break; // (the four words of a group are written by one store)
-                    if (lb_give_up(spins, a.sort_err, kLbSpinMax)) {
-                        atomicExch(a.sort_err, 1u);
-                        v = make_uint4(etag | kLbIncl, etag | kLbIncl, etag | kLbIncl, etag | kLbIncl);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                    v = ld_sc1_x4(src);
-                }
-                const u32 x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (u32 k = 0; k < 4; ++k) {
-                    if ((open >> k) & 1u) {
-                        excl[k] += x[k] & kLbValMask;
-                        if ((x[k] & kLbFlagMask) == kLbIncl) open &= ~(1u << k);
-                    }
-                }
-            }
-            const u32 fi = etag | kLbIncl;
-            st_sc1_x4(mystate, make_uint4(fi | (excl[0] + t4[0]), fi | (excl[1] + t4[1]), fi | (excl[2] + t4[2]),
-                                          fi | (excl[3] + t4[3])));
-        }
-        const u32 *gb = a.gbase + ((size_t)lb * 3 + dpos) * kMaxBins + d0;
-#pragma unroll
-        for (u32 k = 0; k < 4; ++k) s_base[d0 + k] = gb[k] + excl[k];
-    }
-    // exclusive scan of the totals over digits (digit order == thread order)
+    // Round 5: the per-wave counts of a thread's digits stay in its registers (two u16 per register) until the scan over
+    // the digits has said where each digit begins in the tile; the counters then take (tile offset of the digit +
+    // elements of the waves in front) in ONE write, and an element's place in the staging buffer is one look-up
+    // (my_cnt[dg] + rank) instead of two (s_tpre[dg] + my_cnt[dg] + rank).  Likewise s_base ends up as (global base -
+    // tile offset): the destination of staged element i is s_base[dg] + i.  Two LDS reads and two adds less per element
+    // and trip (r04_scatter_counters.md: the pass is held by its vector and LDS instructions, not by bytes).  The scan
+    // over the digits comes BEFORE the look-back now, so that the counts are out of the registers while a tile waits
+    // for its predecessors.
     {
+        u32 cw[NW][PER / 2];
+#pragma unroll
+        for (u32 q = 0; q < PER; ++q) {
+            const u32 dg = threadIdx.x * PER + q;
+            u32 run = 0;
+#pragma unroll
+            for (u32 k = 0; k < NW; ++k) {
+                const u32 c = s_cnt[k * NB + dg];
+                if (q & 1u) cw[k][q >> 1] |= c << 16;
+                else cw[k][q >> 1] = c;
+                run += c;
+            }
+            tot[q] = run;
+            mine += run;
+        }
+        // exclusive scan of the totals over digits (digit order == thread order)
         const u32 inc = wave_incl_sum(mine);
         if (l == 63) s_wsum[w] = inc;
         __syncthreads();
@@ -826,17 +840,134 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
         u32 ex = carry + inc - mine;
 #pragma unroll
         for (u32 q = 0; q < PER; ++q) {
-            s_tpre[threadIdx.x * PER + q] = (u16)ex;
+            const u32 dg = threadIdx.x * PER + q;
+            u32 run = ex; // (<= 8192: fits the u16 counters)
+#pragma unroll
+            for (u32 k = 0; k < NW; ++k) {
+                s_cnt[k * NB + dg] = (u16)run;
+                run += (q & 1u) ? (cw[k][q >> 1] >> 16) : (cw[k][q >> 1] & 0xFFFFu);
+            }
+            s_tpre[dg] = (u16)ex;
+            s_base[dg] = tot[q]; // (this tile's digit counts: what the look-back publishes)
             ex += tot[q];
         }
         if (threadIdx.x == 0) s_total = total;
     }
     __syncthreads();
+    SC_T(2);
+    // this tile's digit counts go out, the predecessors' come in: four digits per 16-byte word group
+    // (one sc1 store / load moves 16 bytes for the price of 4, MI355X_MICROARCH.md)
+    // Round 5 (BZ_SCATTER_LATE_LB, default on): the counts go out HERE, but the walk over the predecessors' words waits
+    // until the tile's keys have been staged and read back -- the in-kernel phase timers (-DBZ_SCATTER_TIMING,
+    // profiles/r05_sort_negatives.md) put 30-35 % of a tile's time into a look-back that began the moment the counts
+    // were out: consecutive tickets start together, so a tile's predecessor publishes when the tile does, and four of
+    // the eight waves waited at the barrier behind the walk.  The staging in between is work the tile has to do anyway.
+    const u32 lb_d0 = threadIdx.x * 4u;
+    u32 *lb_mystate = a.tile_state + ((size_t)lb * kTilesPerBlock + tile) * kMaxBins + lb_d0;
+    const u32 etag = epoch << 22;
+    u32 t4[4] = {0, 0, 0, 0};
+    if (threadIdx.x < NB / 4u) {
+#pragma unroll
+        for (u32 k = 0; k < 4; ++k) t4[k] = s_base[lb_d0 + k];
+        const u32 f0 = etag | (tile ? kLbAgg : kLbIncl);
+        st_sc1_x4(lb_mystate, make_uint4(f0 | t4[0], f0 | t4[1], f0 | t4[2], f0 | t4[3]));
+    }
+    auto lookback_walk = [&]() {
+        if (threadIdx.x >= NB / 4u) return;
+        const u32 d0 = lb_d0;
+        u32 excl[4] = {0, 0, 0, 0};
+        if (tile) {
+            u32 open = 0xFu; // digits whose sum has not met an inclusive prefix yet
+            u32 spins = 0;
+#ifdef BZ_SCATTER_TIMING
+            u32 hops = 0, spins0 = 0;
+#endif
+            // The words of BZ_LB_WINDOW predecessors are asked for together (a tile walks back over five predecessors on
+            // average before it meets an inclusive prefix -- measured, profiles/r05_sort_negatives.md -- and every hop of
+            // a one-by-one walk is a round trip to the L2); they are then taken in order, nearest first.
+            for (u32 p = tile; p > 0 && open;) {
+                const u32 win = p < (u32)BZ_LB_WINDOW ? p : (u32)BZ_LB_WINDOW;
+                uint4 vw[BZ_LB_WINDOW];
+#if BZ_LB_WINDOW > 1
+                {
+                    u32x4_t rw[BZ_LB_WINDOW];
+#pragma unroll
+                    for (u32 j = 0; j < (u32)BZ_LB_WINDOW; ++j) { // (beyond the block's first tile: the first tile's words again -- no branch between the loads)
+                        const u32 q = j < win ? p - 1u - j : 0u;
+                        ld_sc1_x4_issue(a.tile_state + ((size_t)lb * kTilesPerBlock + q) * kMaxBins + d0, rw[j]);
+                    }
+                    ld_x4_wait_all();
+#pragma unroll
+                    for (u32 j = 0; j < (u32)BZ_LB_WINDOW; ++j) vw[j] = make_uint4(rw[j].x, rw[j].y, rw[j].z, rw[j].w);
+                }
+#else
+                vw[0] = ld_sc1_x4(a.tile_state + ((size_t)lb * kTilesPerBlock + (p - 1u)) * kMaxBins + d0);
+#endif
+#pragma unroll
+                for (u32 j = 0; j < (u32)BZ_LB_WINDOW; ++j) {
+                    if (j >= win || !open) break;
+                    const u32 *src = a.tile_state + ((size_t)lb * kTilesPerBlock + (p - 1u - j)) * kMaxBins + d0;
+                    uint4 v = vw[j];
+#ifdef BZ_SCATTER_TIMING
+                    ++hops;
+#endif
+                    while (true) {
+                        const u32 x[4] = {v.x, v.y, v.z, v.w};
+                        bool ready = true;
+#pragma unroll
+                        for (u32 k = 0; k < 4; ++k)
+                            if ((x[k] >> 22) != epoch || (x[k] & kLbFlagMask) == 0u) ready = false;
+                        if (ready) break; // (the four words of a group are written by one store)
+                        if (lb_give_up(spins, a.sort_err, kLbSpinMax)) {
+                            atomicExch(a.sort_err, 1u);
+                            v = make_uint4(etag | kLbIncl, etag | kLbIncl, etag | kLbIncl, etag | kLbIncl);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                        v = ld_sc1_x4(src);
+#ifdef BZ_SCATTER_TIMING
+                        ++spins0;
+#endif
+                    }
+                    const u32 x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (u32 k = 0; k < 4; ++k) {
+                        if ((open >> k) & 1u) {
+                            excl[k] += x[k] & kLbValMask;
+                            if ((x[k] & kLbFlagMask) == kLbIncl) open &= ~(1u << k);
+                        }
+                    }
+                }
+                p -= win;
+            }
+#ifdef BZ_SCATTER_TIMING
+            if (threadIdx.x == 0) { // (thread 0's digit group: hops walked, loads repeated while a word was not there yet, tiles)
+                atomicAdd(&a.loc_stats[48], hops);
+                atomicAdd(&a.loc_stats[49], spins0);
+                atomicAdd(&a.loc_stats[50], 1u);
+                atomicMax(&a.loc_stats[51], hops);
+            }
+#endif
+            const u32 fi = etag | kLbIncl;
+            st_sc1_x4(lb_mystate, make_uint4(fi | (excl[0] + t4[0]), fi | (excl[1] + t4[1]), fi | (excl[2] + t4[2]),
+                                             fi | (excl[3] + t4[3])));
+        }
+        const u32 *gb = a.gbase + ((size_t)lb * 3 + dpos) * kMaxBins + d0;
+#pragma unroll
+        for (u32 k = 0; k < 4; ++k) s_base[d0 + k] = gb[k] + excl[k] - (u32)s_tpre[d0 + k];
+    };
+#if !BZ_SCATTER_LATE_LB
+    lookback_walk();
+#endif
+#if !BZ_SCATTER_LATE_LB
+    __syncthreads();
+    SC_T(3);
+#endif
     u32 lpos[16];
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
         const u32 dg = (key[r] >> shift) & (NB - 1);
-        lpos[r] = (rnk[r] != 0xFFFFFFFFu) ? (u32)s_tpre[dg] + (u32)my_cnt[dg] + rnk[r] : 0xFFFFFFFFu;
+        lpos[r] = (rnk[r] != 0xFFFFFFFFu) ? (u32)my_cnt[dg] + rnk[r] : 0xFFFFFFFFu;
     }
     const u32 total = s_total;
     __syncthreads(); // counters are dead from here on: the buffer becomes the staging area
@@ -856,33 +987,52 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lb(BwtArgs a, u3
     for (u32 r = 0; r < 16; ++r)
         if (lpos[r] != 0xFFFFFFFFu) s_buf[lpos[r]] = key[r];
     __syncthreads();
+    SC_T(4);
     u32 dst[16];
     u32 hi[16]; // (PACK_OUT) the digits above this pass's, already in place for the packed word
+#if BZ_SCATTER_LATE_LB
+    u32 kks[16];
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k) {
+        const u32 i = k * kSortThreads + threadIdx.x;
+        kks[k] = i < total ? s_buf[i] : 0u;
+    }
+    lookback_walk();
+    __syncthreads();
+    SC_T(3);
+#endif
 #pragma unroll
     for (u32 k = 0; k < 16; ++k) {
         const u32 i = k * kSortThreads + threadIdx.x;
         dst[k] = 0xFFFFFFFFu;
         hi[k] = 0;
         if (i < total) {
+#if BZ_SCATTER_LATE_LB
+            const u32 kk = kks[k];
+#else
             const u32 kk = s_buf[i];
+#endif
             const u32 dg = (kk >> shift) & (NB - 1);
-            dst[k] = s_base[dg] + (i - (u32)s_tpre[dg]);
-            if (SRC == SRC_PACKED) Vout[base + dst[k]] = kk & 0xFFFFFu; // (the rotation came with the digit: one staging round)
+            dst[k] = s_base[dg] + i;
+            if (SRC == SRC_PACKED) st_plain_at(Vout + base, dst[k], kk & 0xFFFFFu); // (the rotation came with the digit: one staging round)
             else if (PACK_OUT) hi[k] = (kk >> (shift + BITS)) << 20;
-            else if (WRITE_K) Kout[base + dst[k]] = kk;
+            else if (WRITE_K) st_plain_at(Kout + base, dst[k], kk);
         }
     }
+    SC_T(5);
     if (SRC == SRC_PACKED) return;
     __syncthreads();
 #pragma unroll
     for (u32 r = 0; r < 16; ++r)
         if (lpos[r] != 0xFFFFFFFFu) s_buf[lpos[r]] = val[r];
     __syncthreads();
+    SC_T(6);
 #pragma unroll
     for (u32 k = 0; k < 16; ++k) {
         const u32 i = k * kSortThreads + threadIdx.x;
-        if (i < total) Vout[base + dst[k]] = PACK_OUT ? (hi[k] | s_buf[i]) : s_buf[i];
+        if (i < total) st_plain_at(Vout + base, dst[k], PACK_OUT ? (hi[k] | s_buf[i]) : s_buf[i]);
     }
+    SC_T(7);
 }
 
 // ---- phase B of the init inside LDS ----------------------------------------------------------------
@@ -1235,7 +1385,7 @@ __global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 ste
             for (u32 r = 0; r < 16; ++r) s2[r] = pkey(pt, jj[r], ki.bits, ki.chars);
             if (need_prev) ps20 = pkey(pt, pj, ki.bits, ki.chars);
         } else if (impure) {
-            const bool per = a.lin_p[lb] != 0u;
+            const bool per = a.lin_p[(size_t)lb * kPerK] != 0u;
             // every member of a group the round has put in order becomes a group of its own: a chain of the block's
             // period (impure 0 in a block that has one) or a group of two ordered by comparison (impure 2)
 #pragma unroll
@@ -2078,20 +2228,24 @@ __global__ __launch_bounds__(kSortThreads) void k_periodic_place(BwtArgs a)
 //   k_period_bits  the two bitmaps;  k_period_next  first mismatch at or behind every 64-position word
 __global__ __launch_bounds__(kSortThreads) void k_period_find(BwtArgs a)
 {
-    constexpr u32 kAnchors = 4;
-    __shared__ u32 s_best, s_cand[kAnchors], s_agree;
+    constexpr u32 kAnchors = 32;
+    __shared__ u32 s_best, s_cand[kAnchors], s_agree[kAnchors];
     const u32 lb = blockIdx.x, tid = threadIdx.x;
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
     const u8 *__restrict__ text = a.rle + d.rle_off;
-    if (tid == 0) {
-        a.lin_p[lb] = 0;
-        a.lin_sig[lb] = 0;
+    if (tid < kPerK) {
+        a.lin_p[(size_t)lb * kPerK + tid] = 0;
+        a.lin_sig[(size_t)lb * kPerK + tid] = 0;
     }
     // (count2: the survivors of the last refinement, k_survivor_compact) only blocks that are deep in repeats
     if (n < 256u || (u64)a.count2[lb] * 4u < (u64)n * 3u) return;
+    // Round 5: up to kPerK distances per block instead of one.  Data whose copies DRIFT (a file and an edited copy of it,
+    // a tar of similar files; the corpus "binary": RLE1 turns a changed byte into a shift) agrees with itself at five to
+    // seven distances per block, none of them over half of it: thirty-two anchors over the first half of the block each
+    // name the distance at which their 16 bytes recur first, and the candidates with the widest agreement are listed.
     for (u32 k = 0; k < kAnchors; ++k) { // (uniform)
-        const u32 at = (u32)(((u64)n * (k + 1u)) / 10u); // 10 % .. 40 % of the block: room for periods beyond n / 2
+        const u32 at = (u32)(((u64)n * (k + 1u)) / (2u * (kAnchors + 1u))); // 1.5 % .. 48.5 % of the block: room for distances beyond n / 2
         u64 h0, h1;
         __builtin_memcpy(&h0, text + at, 8);
         __builtin_memcpy(&h1, text + at + 8, 8);
@@ -2099,7 +2253,7 @@ __global__ __launch_bounds__(kSortThreads) void k_period_find(BwtArgs a)
         __syncthreads();
         const u32 last = n - 16u - at; // the farthest shift that keeps the 16 bytes inside the block
         // (four shifts per thread and trip, their loads in flight together; the second half of the 16 bytes is only
-        // looked at where the first agrees: a block without a period reads 8 bytes per shift and anchor, not 16)
+        // looked at where the first agrees: a block without a repeat reads 8 bytes per shift and anchor, not 16)
         for (u32 q0 = 1u + tid; q0 <= last && q0 < s_best; q0 += 4u * kSortThreads) {
             u64 x[4];
 #pragma unroll
@@ -2127,16 +2281,15 @@ __global__ __launch_bounds__(kSortThreads) void k_period_find(BwtArgs a)
         if (tid == 0) s_cand[k] = s_best;
         __syncthreads();
     }
-    // the candidate under which the block agrees with itself at the most positions (an anchor inside a run of equal
-    // bytes answers "1", one inside a short inner repeat answers that repeat's distance: the whole block decides)
-    u32 p = 0, best = 0;
+    // how widely the block agrees with itself under every distinct candidate (an anchor inside a run of equal bytes
+    // answers "1", one inside a short inner repeat answers that repeat's distance: the whole block decides)
     for (u32 k = 0; k < kAnchors; ++k) { // (uniform: every thread reads the same shared words)
         const u32 c = s_cand[k];
         bool seen = c == 0xFFFFFFFFu;
         for (u32 j = 0; j < k; ++j) seen = seen || s_cand[j] == c;
-        if (seen) continue;
-        if (tid == 0) s_agree = 0;
+        if (tid == 0) s_agree[k] = 0;
         __syncthreads();
+        if (seen) continue;
         u32 mine = 0;
         for (u32 i = tid * 8u; i < n; i += kSortThreads * 8u) {
             if (i + 8u + c <= n) {
@@ -2153,18 +2306,32 @@ __global__ __launch_bounds__(kSortThreads) void k_period_find(BwtArgs a)
             }
         }
         mine = wave_sum(mine);
-        if ((tid & 63u) == 0) atomicAdd(&s_agree, mine);
-        __syncthreads();
-        const u32 agree = s_agree;
-        if (agree < n && (agree > best || (agree == best && c < p))) { // (agree == n: periodic as a cycle -- equal rotations)
-            best = agree;
-            p = c;
-        }
+        if ((tid & 63u) == 0) atomicAdd(&s_agree[k], mine);
         __syncthreads();
     }
-    if (tid == 0 && p != 0u && (u64)best * 2u >= n) {
-        a.lin_p[lb] = p;
-        a.lin_sig[lb] = (u32)(((u64)best * 1000u) / n); // (for the trace: agreement in permille)
+    // the list: widest agreement first (ties: the shorter distance); a distance is worth its tables when the block agrees
+    // with itself under it at a sixteenth of its positions or more -- and not everywhere (periodic as a cycle: equal
+    // rotations, k_periodic_place's case)
+    if (tid == 0) {
+        const u32 kmax = per_kmax(a);
+        u32 listed = 0;
+        for (u32 round = 0; round < kmax; ++round) {
+            u32 bi = 0xFFFFFFFFu, best = 0, bp = 0;
+            for (u32 k = 0; k < kAnchors; ++k) {
+                const u32 c = s_cand[k], ag = s_agree[k];
+                if (c == 0xFFFFFFFFu || ag == 0u || ag >= n) continue;
+                if (ag > best || (ag == best && c < bp)) {
+                    best = ag;
+                    bp = c;
+                    bi = k;
+                }
+            }
+            if (bi == 0xFFFFFFFFu || (u64)best * 16u < n) break;
+            a.lin_p[(size_t)lb * kPerK + listed] = bp;
+            a.lin_sig[(size_t)lb * kPerK + listed] = (u32)(((u64)best * 1000u) / n); // (for the trace: agreement in permille)
+            ++listed;
+            s_agree[bi] = 0; // taken
+        }
     }
 }
 
@@ -2173,42 +2340,47 @@ __global__ __launch_bounds__(kSortThreads) void k_period_bits(BwtArgs a)
     u32 tile, lb;
     xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
-    const u32 p = a.lin_p[lb];
-    if (p == 0u) return;
+    if (a.lin_p[(size_t)lb * kPerK] == 0u) return;
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
     const u32 start = tile * kSortTile;
     if (start >= n) return;
     const u8 *__restrict__ text = a.rle + d.rle_off;
-    u64 *mis = const_cast<u64 *>(per_mis(a, lb)), *lt = const_cast<u64 *>(per_lt(a, lb));
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const u32 kmax = per_kmax(a);
+    for (u32 pi = 0; pi < kmax; ++pi) { // (uniform)
+        const u32 p = a.lin_p[(size_t)lb * kPerK + pi];
+        if (p == 0u) break;
+        u64 *mis = const_cast<u64 *>(per_mis(a, lb, pi)), *lt = const_cast<u64 *>(per_lt(a, lb, pi));
 #pragma unroll
-    for (u32 r = 0; r < 16; ++r) {
-        const u32 i = start + w * 1024u + r * 64u + l;
-        bool m = false, less = false;
-        if (i < n) {
-            const u32 t = i + p;
-            const u8 x = text[i], y = text[t >= n ? t - n : t];
-            m = x != y;
-            less = x < y;
-        }
-        const u64 bm = __ballot(m), bl = __ballot(less);
-        if (l == 0 && start + w * 1024u + r * 64u < n) {
-            mis[(start + w * 1024u + r * 64u) >> 6] = bm;
-            lt[(start + w * 1024u + r * 64u) >> 6] = bl;
+        for (u32 r = 0; r < 16; ++r) {
+            const u32 i = start + w * 1024u + r * 64u + l;
+            bool m = false, less = false;
+            if (i < n) {
+                const u32 t = i + p;
+                const u8 x = text[i], y = text[t >= n ? t - n : t];
+                m = x != y;
+                less = x < y;
+            }
+            const u64 bm = __ballot(m), bl = __ballot(less);
+            if (l == 0 && start + w * 1024u + r * 64u < n) {
+                mis[(start + w * 1024u + r * 64u) >> 6] = bm;
+                lt[(start + w * 1024u + r * 64u) >> 6] = bl;
+            }
         }
     }
 }
 
+// one workgroup per (block, listed distance)
 __global__ __launch_bounds__(kSortThreads) void k_period_next(BwtArgs a)
 {
     __shared__ u32 s_first[kSortThreads];
-    const u32 lb = blockIdx.x, tid = threadIdx.x;
-    if (a.lin_p[lb] == 0u) return;
+    const u32 lb = blockIdx.x, pi = blockIdx.y, tid = threadIdx.x;
+    if (pi >= per_kmax(a) || a.lin_p[(size_t)lb * kPerK + pi] == 0u) return;
     const u32 n = a.blocks[lb].n;
     const u32 nw = (n + 63u) >> 6;
-    const u64 *mis = per_mis(a, lb);
-    u32 *nxt = const_cast<u32 *>(per_nxt(a, lb));
+    const u64 *mis = per_mis(a, lb, pi);
+    u32 *nxt = const_cast<u32 *>(per_nxt(a, lb, pi));
     const u32 per = (nw + kSortThreads - 1u) / kSortThreads; // words per thread, consecutive
     const u32 w0 = tid * per, w1 = w0 + per < nw ? w0 + per : nw;
     u32 first = 0xFFFFFFFFu; // the first mismatch inside this thread's words
@@ -2321,8 +2493,11 @@ __global__ __launch_bounds__(kSortThreads) void k_pair_compare(BwtArgs a, u32 st
     }
 }
 
-// the period round's list, ordered by (group, start or mirrored start): a group in which two neighbours do not step by
-// exactly the period, or disagree about the direction, is marked impure (one byte per group head)
+// the period round's list, ordered by (group, start or mirrored start): every pair of neighbours inside a group must lie
+// a LISTED distance apart and stand in the order the first difference behind them gives (rot(lo) < rot(lo + p) <=>
+// T[m] < T[m + p] at the first m >= lo where the block and the block shifted by p differ: exact, whatever depth the
+// doubling has reached); a group with a pair that does not is marked impure (one byte per group head) and goes on
+// doubling.  The pairs of a group are checked one by one, so a group that passes is in its true order.
 __global__ __launch_bounds__(kSortThreads) void k_period_mark(BwtArgs a, u32 step, const u32 *__restrict__ K,
                                                                const u32 *__restrict__ V, u8 *__restrict__ impure)
 {
@@ -2331,20 +2506,26 @@ __global__ __launch_bounds__(kSortThreads) void k_period_mark(BwtArgs a, u32 ste
     if (lb == 0xFFFFFFFFu) return;
     const u32 cnt = a.count[lb];
     const u32 start = tile * kSortTile;
-    const u32 p = a.lin_p[lb];
-    if (start >= cnt || p == 0u) return;
+    if (start >= cnt || a.lin_p[(size_t)lb * kPerK] == 0u) return;
     const u32 n = a.blocks[lb].n;
-    const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
-    const u64 d64 = ((u64)ki.chars * 2u) << step;
-    const u32 depth = d64 < n ? (u32)d64 : n;
+    const u32 kmax = per_kmax(a);
+    (void)step;
     const size_t base = (size_t)lb * kSlot;
     for (u32 idx = start + threadIdx.x; idx < cnt && idx < start + kSortTile; idx += kSortThreads) {
         if (idx == 0) continue;
         const u32 g = K[base + idx], gp = K[base + idx - 1];
         if (g != gp || impure[base + g] == 2) continue; // (2: a group of two that k_pair_compare has ordered)
         const u32 v = V[base + idx], vp = V[base + idx - 1];
-        const bool asc = per_key_ascending(a, lb, n, p, depth, v), ascp = per_key_ascending(a, lb, n, p, depth, vp);
-        const bool chain = asc == ascp && (asc ? v == vp + p : vp == v + p);
+        const u32 lo = v < vp ? v : vp, dist = v < vp ? vp - v : v - vp;
+        bool chain = false;
+        for (u32 i = 0; i < kmax; ++i) {
+            const u32 p = a.lin_p[(size_t)lb * kPerK + i];
+            if (p == 0u) break;
+            if (p != dist) continue;
+            const bool lo_first = per_lt_at(a, lb, i, n, per_first_mis(a, lb, i, lo)); // rot(lo) < rot(lo + p)
+            chain = lo_first == (vp == lo); // the list has vp in front of v
+            break;
+        }
         if (!chain) impure[base + g] = 1;
     }
 }
@@ -2869,13 +3050,13 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             // reads 270 GB out of the L2 and takes 70 ms, the eight doubling rounds it replaces for a third of the
             // rotations take 25: 2.43 GB/s without it, 0.89 with it.  Same streams either way.)
             static const bool want_pairs = getenv("BZ_PAIR_COMPARE") && atoi(getenv("BZ_PAIR_COMPARE")) != 0;
-            if (a.gh_tiles) { // (the verdict bytes live in the fused passes' digit counts: no fused passes, no pair round)
+            if (a.gh_tiles && want_pairs) { // (the verdict bytes live in the fused passes' digit counts: no fused passes, no pair round)
                 (void)hipMemset2DAsync(a.gh_tiles, (size_t)kTilesPerBlock * 3 * kMaxBins * 4, 0, (size_t)list_tiles * kSortTile, a.nb, st);
-                if (want_pairs) hipLaunchKernelGGL(k_pair_compare, grid_list, dim3(kSortThreads), 0, st, a, step, fV, impure);
+                hipLaunchKernelGGL(k_pair_compare, grid_list, dim3(kSortThreads), 0, st, a, step, fV, impure);
             }
             hipLaunchKernelGGL(k_period_find, dim3(a.nb), dim3(kSortThreads), 0, st, a);
             hipLaunchKernelGGL(k_period_bits, grid, dim3(kSortThreads), 0, st, a);
-            hipLaunchKernelGGL(k_period_next, dim3(a.nb), dim3(kSortThreads), 0, st, a);
+            hipLaunchKernelGGL(k_period_next, dim3(a.nb, per_kmax(a)), dim3(kSortThreads), 0, st, a);
             radix_pass<SRC_PERJ, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK, list_tiles);
             radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof, nullptr, list_tiles);
             radix_pass<SRC_LISTG, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK, list_tiles);
@@ -2938,16 +3119,18 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         hipLaunchKernelGGL(k_rank_place, grid, dim3(kSortThreads), 0, st, a, fK);
         if (prof) prof->end(st, p);
         if (per_round && bwt_trace) {
-            std::vector<u32> lp(a.nb), ls(a.nb), nf(a.nb), cn(a.nb);
-            (void)hipMemcpyAsync(lp.data(), a.lin_p, a.nb * 4, hipMemcpyDeviceToHost, st);
-            (void)hipMemcpyAsync(ls.data(), a.lin_sig, a.nb * 4, hipMemcpyDeviceToHost, st);
+            std::vector<u32> lp((size_t)a.nb * kPerK), ls((size_t)a.nb * kPerK), nf(a.nb), cn(a.nb);
+            (void)hipMemcpyAsync(lp.data(), a.lin_p, (size_t)a.nb * kPerK * 4, hipMemcpyDeviceToHost, st);
+            (void)hipMemcpyAsync(ls.data(), a.lin_sig, (size_t)a.nb * kPerK * 4, hipMemcpyDeviceToHost, st);
             (void)hipMemcpyAsync(nf.data(), a.nonfinal, a.nb * 4, hipMemcpyDeviceToHost, st);
             (void)hipMemcpyAsync(cn.data(), a.count, a.nb * 4, hipMemcpyDeviceToHost, st);
             (void)hipStreamSynchronize(st);
             for (u32 b = 0; b < a.nb; ++b)
-                if (lp[b] || nf[b] * 2u > max_n)
-                    fprintf(stderr, "  block %u: period %u (the block agrees with itself shifted by it at %u permille of its positions), list %u, %u rotations left unordered\n", b, lp[b],
-                            ls[b], cn[b], nf[b]);
+                if (lp[(size_t)b * kPerK] || nf[b] * 2u > max_n) {
+                    fprintf(stderr, "  block %u: distances (agreement in permille of the block)", b);
+                    for (u32 i = 0; i < kPerK && lp[(size_t)b * kPerK + i]; ++i) fprintf(stderr, " %u (%u)", lp[(size_t)b * kPerK + i], ls[(size_t)b * kPerK + i]);
+                    fprintf(stderr, "; list %u, %u rotations left unordered\n", cn[b], nf[b]);
+                }
         }
         lastV = cV;
         if (!per_round) ++step;
@@ -2989,6 +3172,21 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
                         "of this batch by the global passes\n", ls[0], ls[1], ls[2], ls[3], ng, a.nb);
 #ifdef BZ_LOC_TIMERS
         fprintf(stderr, "  cycles/16 per phase (bounds, load, fill, passes, out): %u %u %u %u %u\n", ls[4], ls[5], ls[6], ls[7], ls[8]);
+#endif
+#ifdef BZ_SCATTER_TIMING
+        {
+            u32 rt[16] = {};
+            (void)hipMemcpy(rt, a.loc_stats + 32, sizeof(rt), hipMemcpyDeviceToHost);
+            fprintf(stderr, "  k_radix_scatter_lb cycles/64 per phase (set-up, fetch+rank, scans, look-back, stage K, store K, stage V, store V): "
+                            "streamed sources %u %u %u %u %u %u %u %u; gathering sources %u %u %u %u %u %u %u %u\n", rt[0], rt[1], rt[2], rt[3],
+                    rt[4], rt[5], rt[6], rt[7], rt[8], rt[9], rt[10], rt[11], rt[12], rt[13], rt[14], rt[15]);
+            (void)hipMemset(a.loc_stats + 32, 0, sizeof(rt));
+            u32 lk[4] = {};
+            (void)hipMemcpy(lk, a.loc_stats + 48, sizeof(lk), hipMemcpyDeviceToHost);
+            fprintf(stderr, "  look-back of thread 0's digits: %u tiles, %u hops (%.2f per tile, most %u), %u repeated loads (%.2f per tile)\n", lk[2], lk[0],
+                    lk[2] ? (double)lk[0] / lk[2] : 0.0, lk[3], lk[1], lk[2] ? (double)lk[1] / lk[2] : 0.0);
+            (void)hipMemset(a.loc_stats + 48, 0, sizeof(lk));
+        }
 #endif
 #ifdef BZ_REFINE_TIMING
         {

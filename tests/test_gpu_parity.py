@@ -568,6 +568,52 @@ def test_period_round_on_deep_repeats(pkg, oracle, eng):
         assert pkg.compress(data, level) == oracle.encode(data, level)
 
 
+def test_period_round_on_drifting_copies(pkg, oracle, eng):
+    """Copies that DRIFT (round 5): a stretch and edited copies of it inside one block -- a few bytes
+    inserted or dropped between the copies, so that the block agrees with itself at SEVERAL distances and at none of them
+    over half of its length (a tar of similar files; bench.py's corpus "binary").  The period round lists up to eight
+    distances per block (k_period_find), keys every survivor by a pair it belongs to at one of them and checks every pair
+    of neighbours of the sorted list against the first difference behind it (k_period_mark) -- the comparison that
+    /root/reference/src/suffix_array/sais.rs:266-272 defines, so the ORDER is the oracle's: rotation order of whole
+    blocks, the rounds it took, and whole streams."""
+    rng = random.Random(505)
+    alpha = b"etaoinshrdlu ,.\n"
+
+    def stretch(k):
+        return bytes(rng.choice(alpha) for _ in range(k))
+
+    def edited(b, every):
+        out, pos = bytearray(), 0
+        while pos < len(b):
+            k = min(len(b) - pos, every + rng.randrange(-every // 4, every // 4))
+            out += b[pos:pos + k]
+            pos += k
+            r = rng.randrange(4)
+            if r == 0:
+                out += bytes([rng.choice(alpha)])            # a byte inserted: the distance to the copy grows
+            elif r == 1:
+                pos += 1                                     # a byte dropped: it shrinks
+            elif r == 2 and out:
+                out[-1] = rng.choice(b"XYZ")                 # a byte changed: the pair is decided here
+        return bytes(out)
+
+    base = stretch(30_000)
+    blocks = [
+        (base + edited(base, 3000) + edited(base, 3000))[:99_000],        # three copies, two to four distances
+        (stretch(5000) + base + stretch(77) + edited(base, 1500))[:70_000],  # foreign bytes in front and between
+        (base[:20_000] + edited(base[:20_000], 500) + edited(base[:20_000], 700) + edited(base[:20_000], 900))[:82_000],
+        edited(base * 3, 4096)[:95_000],                                  # the bench corpus' shape: a byte per 4 KiB
+    ]
+    for i, blk in enumerate(blocks):
+        assert eng.debug_bwt(blk) == oracle.bwt(blk), (i, len(blk))
+    eng.debug_bwt(blocks[3])
+    with_round = eng.bwt_stats()["rounds"]
+    assert with_round <= 8, with_round  # (doubling alone: log2(4096 / 10) + 2 rounds and more)
+    big = edited(stretch(400_000) * 5, 4096)
+    for data, level in ((big[:1_900_000], 9), (b"".join(blocks), 1)):
+        assert pkg.compress(data, level) == oracle.encode(data, level)
+
+
 def test_period_round_in_mixed_batches(pkg, oracle):
     """A batch in which every third block is a deep repeat (text, text, a 4 KiB paragraph repeated, ...): the period
     round is triggered by the BLOCKS that need it (round 4; rounds 1-3 looked at the batch as a whole, which such a
