@@ -442,8 +442,8 @@ int bz_decode_buffer(int device, const uint8_t *in, size_t in_len,
  * > 0 bytes copied; 0 = nothing ready yet; once the verdict is final and
  * nothing is left, the verdict -- 0 = `None`, negative = the `Err` item).
  * Decoding is incremental and runs BESIDE the caller, on a thread of the
- * context: whenever BZ_DEC_CHUNK bytes (environment; default 128 MiB, the first
- * chunks of a stream 16 and 48 MiB) have been written, the records that are wholly
+ * context: whenever BZ_DEC_CHUNK bytes (environment; default 64 MiB, the first
+ * chunk of a stream 16 MiB) have been written, the records that are wholly
  * there are decoded and their bytes queued as they land in host memory, and the
  * chain state (bit position, stream number, level, combined CRC) is carried to
  * the next chunk; chunks of less than 4 MiB are decoded before bz_dec_write

@@ -1106,8 +1106,8 @@ extern "C" int bz_decode_buffer(int device, const uint8_t *in, size_t in_len, ui
 
 // ---- streaming mirror of BZip2Decoder (decoder.rs:583-612) ------------------------------------------------
 // The reference pulls input bytes on demand and yields output bytes one by one.  Here compressed bytes are collected
-// (bz_dec_write); whenever BZ_DEC_CHUNK bytes (default 128 MiB; the first chunks of a stream 16 and 48 MiB, so that the GPU
-// has work early) have come in, and when the input ends (bz_dec_end), they go to the context's WORKER thread, which decodes the
+// (bz_dec_write); whenever BZ_DEC_CHUNK bytes (default 64 MiB; the first chunk of a stream 16 MiB, so that the GPU has work
+// early) have come in, and when the input ends (bz_dec_end), they go to the context's WORKER thread, which decodes the
 // records that are wholly there and queues their bytes (bz_dec_read), sub-batch by sub-batch as they land in host memory
 // -- while the caller goes on writing and reading: the caller's copies (compressed bytes in, decoded bytes out: a GiB of
 // them is 0.1 s of one core) run beside the upload, the kernels and the download instead of in a row with them (rounds
@@ -1134,7 +1134,7 @@ struct DecSeg { // decoded bytes of one sub-batch, handed out from `pos` on
 struct bz_dec {
     int device = 0;
     bz_gpu_engine *g = nullptr;
-    size_t chunk = (size_t)128 << 20, first_chunk = (size_t)16 << 20;
+    size_t chunk = (size_t)64 << 20, first_chunk = (size_t)16 << 20;
     // the caller's side
     std::vector<u8> in; // compressed bytes not yet handed to the worker
     bool ended = false;
@@ -1366,14 +1366,10 @@ extern "C" int bz_dec_write(bz_dec *d, const uint8_t *data, size_t n)
     // pieces of less than 1 MiB (a tiny BZ_DEC_CHUNK -- the tests' way to stop the decoder in mid-record -- hands over what
     // a call brought, as rounds 1-4 did, not thousands of jobs).
     while (n) {
-        // (16, 48, 128, 128 ... MiB: the worker has a chunk as soon as 16 MiB are there, and the Huffman stage -- 11 ms per
-        // chunk whatever its size: the latency of one block -- is paid four times per GiB of output, not eight)
-        size_t chunk = d->chunk;
-        if (d->chunks_sent < 4) {
-            size_t c = d->first_chunk;
-            for (u64 q = 0; q < d->chunks_sent && c < d->chunk; ++q) c *= 3;
-            chunk = std::min(c, d->chunk);
-        }
+        // (measured on 1 GiB of text, 226 MB compressed: chunks of 16 + 64 + 64 + ... MiB 142 ms, of 16 + 48 + 128 + ... 150-156 ms,
+        // of 16 + 128 + ... 169-197 ms -- a chunk must have arrived whole before its Huffman stage can begin, and that stage
+        // is 11 ms per chunk whatever the chunk holds)
+        const size_t chunk = d->chunks_sent == 0 ? d->first_chunk : d->chunk;
         const size_t gran = std::max(chunk, (size_t)1 << 20);
         const size_t room = d->in.size() < gran ? gran - d->in.size() : 0;
         const size_t k = room ? std::min(n, room) : n;

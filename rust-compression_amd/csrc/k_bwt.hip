@@ -159,16 +159,16 @@ __device__ __forceinline__ u8 *pair_bytes(const BwtArgs &a, u32 lb)
 // index instead of a branch), then all dependent gathers, so a wave keeps 16-32 memory
 // operations in flight instead of one -- these kernels are latency-bound otherwise.
 // first = index of the lane's row-0 element; rows are 64 apart.  Returns the participation mask.
-template <int SRC>
+template <int SRC, int ROWS = 16>
 __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__restrict__ pt, u32 n, u32 hm,
                                           const u32 *__restrict__ Kin, const u32 *__restrict__ Vin, u32 first,
-                                          u32 cnt, KeyInfo ki, u32 (&key)[16], u32 (&val)[16])
+                                          u32 cnt, KeyInfo ki, u32 (&key)[ROWS], u32 (&val)[ROWS])
 {
     const size_t base = (size_t)lb * kSlot;
     u32 ok = 0;
     if (SRC == SRC_TEXT) {
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) {
+        for (u32 r = 0; r < (u32)ROWS; ++r) {
             const u32 idx = first + r * 64u;
             const u32 c = idx < cnt ? idx : cnt - 1u;
             key[r] = pkey(pt, c, ki.bits, ki.chars);
@@ -179,7 +179,7 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
         // phase B of the init: walk the key order of phase A, step back `chars` symbols
         const u32 cm = ki.chars % n;
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) {
+        for (u32 r = 0; r < (u32)ROWS; ++r) {
             const u32 idx = first + r * 64u;
             const u32 c = idx < cnt ? idx : cnt - 1u;
             const u32 s = ld_stream(Vin + base + c);
@@ -187,10 +187,10 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
             ok |= (idx < cnt ? 1u : 0u) << r;
         }
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) key[r] = pkey(pt, val[r], ki.bits, ki.chars);
+        for (u32 r = 0; r < (u32)ROWS; ++r) key[r] = pkey(pt, val[r], ki.bits, ki.chars);
     } else if (SRC == SRC_TEXTK) {
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) {
+        for (u32 r = 0; r < (u32)ROWS; ++r) {
             const u32 idx = first + r * 64u;
             const u32 c = idx < cnt ? idx : cnt - 1u;
             key[r] = ld_stream(Kin + base + c);
@@ -199,7 +199,7 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
         }
     } else if (SRC == SRC_MMK) {
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) {
+        for (u32 r = 0; r < (u32)ROWS; ++r) {
             const u32 idx = first + r * 64u;
             const u32 c = idx < cnt ? idx : cnt - 1u;
             key[r] = ld_stream(Kin + base + c);
@@ -210,7 +210,7 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
     } else if (SRC == SRC_WALKK) {
         const u32 cm = ki.chars % n;
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) {
+        for (u32 r = 0; r < (u32)ROWS; ++r) {
             const u32 idx = first + r * 64u;
             const u32 c = idx < cnt ? idx : cnt - 1u;
             key[r] = ld_stream(Kin + base + c);
@@ -225,32 +225,32 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
         // 64-bit shift and two 64-bit adds per row and array).
         const u32 *kp = Kin + base, *vp = Vin + base;
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) {
+        for (u32 r = 0; r < (u32)ROWS; ++r) {
             key[r] = ld_stream_at(kp, first + r * 64u);
             val[r] = ld_stream_at(vp, first + r * 64u);
         }
         const u32 rows = first < cnt ? (cnt - first + 63u) >> 6 : 0u;
-        ok = rows >= 16u ? 0xFFFFu : (1u << rows) - 1u;
+        ok = rows >= (u32)ROWS ? ((1u << ROWS) - 1u) : (1u << rows) - 1u;
     } else if (SRC == SRC_PACKED) {
         const u32 *vp = Vin + base;
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) {
+        for (u32 r = 0; r < (u32)ROWS; ++r) {
             key[r] = ld_stream_at(vp, first + r * 64u); // (the digit is taken with shift 20; the rotation rides in the low bits)
             val[r] = key[r] & 0xFFFFFu;
         }
         const u32 rows = first < cnt ? (cnt - first + 63u) >> 6 : 0u;
-        ok = rows >= 16u ? 0xFFFFu : (1u << rows) - 1u;
+        ok = rows >= (u32)ROWS ? ((1u << ROWS) - 1u) : (1u << rows) - 1u;
     } else if (SRC == SRC_SURV) {
         // survivor round, first half: order the survivors by the rank of rotation j+h
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) {
+        for (u32 r = 0; r < (u32)ROWS; ++r) {
             const u32 idx = first + r * 64u;
             const u32 c = idx < cnt ? idx : cnt - 1u;
             val[r] = ld_stream(Vin + base + c);
             ok |= (idx < cnt ? 1u : 0u) << r;
         }
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) {
+        for (u32 r = 0; r < (u32)ROWS; ++r) {
             u32 t = val[r] + hm;
             t = t >= n ? t - n : t;
             key[r] = a.R[base + t] & ~kFinalBit;
@@ -260,9 +260,9 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
         // difference between the block and the block shifted by its period decides for each of them (per_ascending)
         const u32 p = a.lin_p[(size_t)lb * kPerK]; // (hm: the depth reached, in symbols; 0: the block has no listed distance)
         const u8 *pb8 = (a.gh_tiles && a.per_pairs) ? pair_bytes(a, lb) : nullptr;
-        u32 pairv[16];
+        u32 pairv[ROWS];
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) {
+        for (u32 r = 0; r < (u32)ROWS; ++r) {
             const u32 idx = first + r * 64u;
             const u32 c = idx < cnt ? idx : cnt - 1u;
             val[r] = ld_stream(Vin + base + c);
@@ -270,33 +270,33 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
             ok |= (idx < cnt ? 1u : 0u) << r;
         }
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) {
+        for (u32 r = 0; r < (u32)ROWS; ++r) {
             if (pairv[r]) key[r] = pairv[r] & 1u; // a group of two, ordered by k_pair_compare
             else key[r] = (p != 0u && !per_key_ascending(a, lb, n, hm, val[r])) ? (n - 1u - val[r]) : val[r];
         }
     } else if (SRC == SRC_LISTG) {
         // survivor round, second half: walk that order, key = the survivor's own group
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) {
+        for (u32 r = 0; r < (u32)ROWS; ++r) {
             const u32 idx = first + r * 64u;
             const u32 c = idx < cnt ? idx : cnt - 1u;
             val[r] = ld_stream(Vin + base + c);
             ok |= (idx < cnt ? 1u : 0u) << r;
         }
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) key[r] = a.R[base + val[r]];
+        for (u32 r = 0; r < (u32)ROWS; ++r) key[r] = a.R[base + val[r]];
     } else {
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) {
+        for (u32 r = 0; r < (u32)ROWS; ++r) {
             const u32 idx = first + r * 64u;
             const u32 c = idx < cnt ? idx : cnt - 1u;
             const u32 s = ld_stream(a.SA + base + c);
             val[r] = (s >= hm) ? s - hm : s + n - hm;
         }
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) key[r] = a.R[base + val[r]];
+        for (u32 r = 0; r < (u32)ROWS; ++r) key[r] = a.R[base + val[r]];
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) {
+        for (u32 r = 0; r < (u32)ROWS; ++r) {
             const u32 idx = first + r * 64u;
             ok |= ((idx < cnt && !(key[r] & kFinalBit)) ? 1u : 0u) << r;
         }
@@ -696,10 +696,19 @@ __global__ __launch_bounds__(kSortThreads) void k_ghist_scan(BwtArgs a, u32 ndig
 #ifndef BZ_LB_WINDOW
 #define BZ_LB_WINDOW 1
 #endif
+#ifndef BZ_SCATTER_STATIC
+#define BZ_SCATTER_STATIC 0
+#endif
 #ifdef BZ_SCATTER_WAVES_PER_EU
-#define BZ_SCATTER_BOUNDS __launch_bounds__(kSortThreads, BZ_SCATTER_WAVES_PER_EU)
+#define BZ_SCATTER_WAVES_ARG , BZ_SCATTER_WAVES_PER_EU
 #else
-#define BZ_SCATTER_BOUNDS __launch_bounds__(kSortThreads)
+#define BZ_SCATTER_WAVES_ARG
+#endif
+// rows per lane of a tile: 16 (512 threads, rounds 1-5) or 8 (1024 threads: the same 8192-element tile on sixteen waves --
+// half the registers per lane; an A/B switch, profiles/r05_sort_negatives.md).  11-bit digits keep 16: their counters
+// (waves x 2048 x 2 bytes) have to fit the staging buffer they share.
+#ifndef BZ_SCATTER_ROWS
+#define BZ_SCATTER_ROWS 16
 #endif
 // -DBZ_SCATTER_TIMING: cycles (>> 6) per phase of a tile, summed over the tiles of all launches into loc_stats[32 + 8 * c + k]
 // (c = 0: the streamed sources PAIRS / PACKED, c = 1: the sources that gather -- TEXT, WALK, MM, MMC; a barrier at every
@@ -711,8 +720,8 @@ __global__ __launch_bounds__(kSortThreads) void k_ghist_scan(BwtArgs a, u32 ndig
 #else
 #define SC_T(k) do { } while (0)
 #endif
-template <int SRC, int BITS, bool WRITE_K = true, bool PACK_OUT = false>
-__global__ BZ_SCATTER_BOUNDS void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h,
+template <int SRC, int BITS, bool WRITE_K = true, bool PACK_OUT = false, int ROWS = (BITS > 10 ? 16 : BZ_SCATTER_ROWS)>
+__global__ __launch_bounds__(kSortTile / ROWS BZ_SCATTER_WAVES_ARG) void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h,
                                                                     const u32 *__restrict__ Kin,
                                                                     const u32 *__restrict__ Vin,
                                                                     u32 *__restrict__ Kout, u32 *__restrict__ Vout,
@@ -720,7 +729,9 @@ __global__ BZ_SCATTER_BOUNDS void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h
                                                                     const u32 *__restrict__ gate)
 {
     constexpr u32 NB = 1u << BITS;
-    constexpr u32 NW = kSortThreads / 64;
+    constexpr u32 kT = kSortTile / ROWS; // threads: 512 with 16 rows per lane, 1024 with 8
+    constexpr u32 kRows = ROWS;
+    constexpr u32 NW = kT / 64;
     __shared__ u32 s_buf[kSortTile];
     __shared__ u32 s_base[NB];
     __shared__ u16 s_tpre[NB]; // (only between the scan over the digits and the look-back: see s_base below)
@@ -737,11 +748,26 @@ __global__ BZ_SCATTER_BOUNDS void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h
 #ifdef BZ_SCATTER_TIMING
     u64 t_prev = __builtin_readcyclecounter();
 #endif
+#if BZ_SCATTER_STATIC
+    // (A/B switch, profiles/r05_sort_negatives.md) the tile follows from the workgroup's number, as in the three-kernel
+    // passes (xcd_remap: workgroups are dealt to the XCDs round-robin and started in order); the counter of the XCD the
+    // workgroup REALLY runs on is still counted up -- without waiting for the answer -- so that the host's check of the
+    // counters catches a dispatch that deals differently, and the bounded spins catch one that starts out of order.
+    const u32 lid = blockIdx.x + gridDim.x * blockIdx.y;
+    const u32 xcd = lid & 7u;
+    const u32 slot = lid >> 3;
+    if (threadIdx.x == 0) {
+        const u32 real_xcd = (u32)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;
+        __hip_atomic_fetch_add(&a.tickets[(size_t)epoch * 8u + real_xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const u32 my_tiles = a.tiles * ((a.nb + 7u - xcd) / 8u);
+#else
     const u32 xcd = (u32)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u; // XCC_ID, bits 3:0
     const u32 my_tiles = a.tiles * ((a.nb + 7u - xcd) / 8u); // (a.tiles: tiles per block the launch covers)
     if (threadIdx.x == 0) s_ticket = atomicAdd(&a.tickets[(size_t)epoch * 8u + xcd], 1u);
     __syncthreads();
     const u32 slot = s_ticket;
+#endif
     if (slot >= my_tiles) return;
     const u32 b8 = slot / a.tiles;
     const u32 tile = slot - b8 * a.tiles;
@@ -757,17 +783,17 @@ __global__ BZ_SCATTER_BOUNDS void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h
     const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
     const u32 hm = (SRC == SRC_MM || SRC == SRC_MMC || SRC == SRC_MMK || SRC == SRC_SURV) ? (((u32)ki.chars * 2u) << h) % n : 0u;
     const size_t base = (size_t)lb * kSlot;
-    for (u32 i = threadIdx.x; i < NW * NB / 2; i += kSortThreads) s_buf[i] = 0;
+    for (u32 i = threadIdx.x; i < NW * NB / 2; i += kT) s_buf[i] = 0;
     __syncthreads();
     SC_T(0);
 
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
     const u64 lt_mask = (l == 0) ? 0ull : (~0ull >> (64 - l));
     u16 *my_cnt = s_cnt + w * NB;
-    u32 key[16], val[16];
-    u32 rnk[16]; // 0xFFFFFFFF = takes no part
+    u32 key[kRows], val[kRows];
+    u32 rnk[kRows]; // 0xFFFFFFFF = takes no part
     const u32 okmask =
-        fetch_rows<SRC>(a, lb, pt, n, hm, Kin, Vin, start + w * 1024u + l, cnt, ki, key, val);
+        fetch_rows<SRC, ROWS>(a, lb, pt, n, hm, Kin, Vin, start + w * (64u * kRows) + l, cnt, ki, key, val);
     // SRC_MMC (the walk round that follows the first refinement): the list this pass builds is refined by
     // (group of j, rank of rotation j+h), and the rotation j+h of the element walked at position i is SA[i]: its rank
     // is the head of the group position i lies in -- the last new-group start at or before i, which the first
@@ -780,10 +806,10 @@ __global__ BZ_SCATTER_BOUNDS void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h
     if (SRC == SRC_MMC) {
         int wl = -1;
         const u64 le_mask = (l == 63) ? ~0ull : ((2ull << l) - 1ull);
-        const u64 myword = newbits_lane_word(a.newbits, base, start + w * 1024u, cnt, l, false);
+        const u64 myword = newbits_lane_word(a.newbits, base, start + w * (64u * kRows), cnt, l, false);
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) {
-            const u32 rowbase = start + w * 1024u + r * 64u;
+        for (u32 r = 0; r < kRows; ++r) {
+            const u32 rowbase = start + w * (64u * kRows) + r * 64u;
             const u64 mnew = wave_lane64(myword, r);
             const u64 q = mnew & le_mask;
             const u32 head = q ? rowbase + 63u - (u32)__clzll(q) : (wl >= 0 ? (u32)wl : 0xFFFFFu);
@@ -794,14 +820,14 @@ __global__ BZ_SCATTER_BOUNDS void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h
         if (l == 0) s_wlast[w] = wl;
     }
 #pragma unroll
-    for (u32 r = 0; r < 16; ++r) {
+    for (u32 r = 0; r < kRows; ++r) {
         const bool ok = (okmask >> r) & 1u;
         const u32 dg = (key[r] >> shift) & (NB - 1);
         rnk[r] = rank_in_wave<BITS>(my_cnt, dg, ok, l, lt_mask);
     }
     __syncthreads();
     SC_T(1);
-    constexpr u32 PER = NB / kSortThreads; // digits per thread (2 or 4), consecutive
+    constexpr u32 PER = NB / kT; // digits per thread (1, 2 or 4), consecutive
     u32 tot[PER];
     u32 mine = 0;
     // Round 5: the per-wave counts of a thread's digits stay in its registers (two u16 per register) until the scan over
@@ -813,7 +839,7 @@ __global__ BZ_SCATTER_BOUNDS void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h
     // over the digits comes BEFORE the look-back now, so that the counts are out of the registers while a tile waits
     // for its predecessors.
     {
-        u32 cw[NW][PER / 2];
+        u32 cw[NW][(PER + 1) / 2];
 #pragma unroll
         for (u32 q = 0; q < PER; ++q) {
             const u32 dg = threadIdx.x * PER + q;
@@ -963,9 +989,9 @@ __global__ BZ_SCATTER_BOUNDS void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h
     __syncthreads();
     SC_T(3);
 #endif
-    u32 lpos[16];
+    u32 lpos[kRows];
 #pragma unroll
-    for (u32 r = 0; r < 16; ++r) {
+    for (u32 r = 0; r < kRows; ++r) {
         const u32 dg = (key[r] >> shift) & (NB - 1);
         lpos[r] = (rnk[r] != 0xFFFFFFFFu) ? (u32)my_cnt[dg] + rnk[r] : 0xFFFFFFFFu;
     }
@@ -976,7 +1002,7 @@ __global__ BZ_SCATTER_BOUNDS void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h
         for (u32 k = 0; k < w; ++k) carry = s_wlast[k] > carry ? s_wlast[k] : carry;
         const u32 ck = ((u32)carry & 0xFFFu) << 20, cv = ((u32)carry >> 12) << 20;
 #pragma unroll
-        for (u32 r = 0; r < 16; ++r) {
+        for (u32 r = 0; r < kRows; ++r) {
             if ((key[r] >> 20) == 0xFFFu && (val[r] >> 20) == 0xFFu) {
                 key[r] = (key[r] & 0xFFFFFu) | ck;
                 val[r] = (val[r] & 0xFFFFFu) | cv;
@@ -984,17 +1010,17 @@ __global__ BZ_SCATTER_BOUNDS void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h
         }
     }
 #pragma unroll
-    for (u32 r = 0; r < 16; ++r)
+    for (u32 r = 0; r < kRows; ++r)
         if (lpos[r] != 0xFFFFFFFFu) s_buf[lpos[r]] = key[r];
     __syncthreads();
     SC_T(4);
-    u32 dst[16];
-    u32 hi[16]; // (PACK_OUT) the digits above this pass's, already in place for the packed word
+    u32 dst[kRows];
+    u32 hi[kRows]; // (PACK_OUT) the digits above this pass's, already in place for the packed word
 #if BZ_SCATTER_LATE_LB
-    u32 kks[16];
+    u32 kks[kRows];
 #pragma unroll
-    for (u32 k = 0; k < 16; ++k) {
-        const u32 i = k * kSortThreads + threadIdx.x;
+    for (u32 k = 0; k < kRows; ++k) {
+        const u32 i = k * kT + threadIdx.x;
         kks[k] = i < total ? s_buf[i] : 0u;
     }
     lookback_walk();
@@ -1002,8 +1028,8 @@ __global__ BZ_SCATTER_BOUNDS void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h
     SC_T(3);
 #endif
 #pragma unroll
-    for (u32 k = 0; k < 16; ++k) {
-        const u32 i = k * kSortThreads + threadIdx.x;
+    for (u32 k = 0; k < kRows; ++k) {
+        const u32 i = k * kT + threadIdx.x;
         dst[k] = 0xFFFFFFFFu;
         hi[k] = 0;
         if (i < total) {
@@ -1023,13 +1049,13 @@ __global__ BZ_SCATTER_BOUNDS void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h
     if (SRC == SRC_PACKED) return;
     __syncthreads();
 #pragma unroll
-    for (u32 r = 0; r < 16; ++r)
+    for (u32 r = 0; r < kRows; ++r)
         if (lpos[r] != 0xFFFFFFFFu) s_buf[lpos[r]] = val[r];
     __syncthreads();
     SC_T(6);
 #pragma unroll
-    for (u32 k = 0; k < 16; ++k) {
-        const u32 i = k * kSortThreads + threadIdx.x;
+    for (u32 k = 0; k < kRows; ++k) {
+        const u32 i = k * kT + threadIdx.x;
         if (i < total) st_plain_at(Vout + base, dst[k], PACK_OUT ? (hi[k] | s_buf[i]) : s_buf[i]);
     }
     SC_T(7);
@@ -2805,8 +2831,8 @@ static void fused_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const
     const u32 e = next_epoch(st, a);
     if (out_elems == ~0ull) out_elems = elems;
     const int p = prof ? prof->begin(st, KID_RADIX_SCATTER_LB, elems * rd + out_elems * ((WRITE_K && !PACK_OUT) ? 8 : 4)) : -1;
-    hipLaunchKernelGGL((k_radix_scatter_lb<SRC, BITS, WRITE_K, PACK_OUT>), grid, dim3(kSortThreads), 0, st, a, shift, h, Kin, Vin, Kout, Vout,
-                       dpos, e, gate);
+    hipLaunchKernelGGL((k_radix_scatter_lb<SRC, BITS, WRITE_K, PACK_OUT>), grid, dim3(kSortTile / (BITS > 10 ? 16 : BZ_SCATTER_ROWS)), 0, st, a, shift, h, Kin,
+                       Vin, Kout, Vout, dpos, e, gate);
     if (prof) prof->end(st, p);
 }
 
