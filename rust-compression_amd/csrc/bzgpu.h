@@ -129,6 +129,7 @@ __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
 // instruction and four or five vector ones --, a DPP move shifted by one lane across the whole wave (wave_shr:1) and a
 // v_readlane_b32 are one instruction each.
 __device__ __forceinline__ u32 wave_shr1(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ u32 wave_shl1(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); } // the lane ABOVE's value (lane 63: 0)
 __device__ __forceinline__ u32 wave_lane(u32 v, u32 lane_uniform) { return (u32)__builtin_amdgcn_readlane((int)v, (int)lane_uniform); }
 __device__ __forceinline__ u64 wave_lane64(u64 v, u32 lane_uniform)
 {

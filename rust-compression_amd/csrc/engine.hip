@@ -703,7 +703,7 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
     x.tile_state_bytes = g->tile_state.cap;
     static const u32 want_fused = (getenv("BZ_ONESWEEP") && atoi(getenv("BZ_ONESWEEP")) == 0) ? 0u : 1u;
     x.fused = want_fused;
-    static const u32 want_pairs = (getenv("BZ_PAIR_COMPARE") && atoi(getenv("BZ_PAIR_COMPARE")) != 0) ? 1u : 0u;
+    static const u32 want_pairs = (getenv("BZ_PAIR_COMPARE") && atoi(getenv("BZ_PAIR_COMPARE")) == 0) ? 0u : 1u; // (round 5: on by default)
     x.per_pairs = want_pairs;
     return x;
 }

@@ -2106,8 +2106,13 @@ __global__ __launch_bounds__(kSortThreads) void k_rank_place(BwtArgs a, const u3
 // The list (V, flags) a round has just refined -> the rotations that are still not final, in the
 // same order (i.e. sorted by their new group head).  Used when few survive: the next round then
 // sorts the survivors explicitly instead of walking all of SA.
+// mate / midx != nullptr (the period round and the pair round): every group of exactly TWO survivors -- a new-group start, no
+// start behind it, a start behind that: read off the bitmap the compaction reads anyway -- leaves mate[smaller start] = larger
+// start and midx[smaller start] = its place in the compacted list | (the smaller start stands first) << 31 for k_pair_scan
+// (round 5: k_pair_list found the same pairs with four random gathers of the rank array per list entry, 13 ms per GiB).
 __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, const u32 *__restrict__ V,
-                                                                    u32 *__restrict__ VS)
+                                                                    u32 *__restrict__ VS, u32 *__restrict__ mate = nullptr,
+                                                                    u32 *__restrict__ midx = nullptr)
 {
     constexpr u32 NW = kSortThreads / 64;
     __shared__ u32 s_off, s_wsum[NW];
@@ -2166,7 +2171,25 @@ __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, co
     const u64 lt_mask = (l == 0) ? 0ull : (~0ull >> (64 - l));
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
-        if ((surv[r] >> l) & 1ull) VS[base + off + (u32)__popcll(surv[r] & lt_mask)] = jv[r];
+        const u32 at = off + (u32)__popcll(surv[r] & lt_mask);
+        if ((surv[r] >> l) & 1ull) VS[base + at] = jv[r];
+        if (mate) {
+            // first member of a group of two: a start here, none at the next element, one at the element behind that
+            const u32 idx = wbase + r * 64u + l;
+            const bool is_new = (mn[r] >> l) & 1ull;
+            const bool n1 = idx + 1u >= cnt ? true : (l < 63u ? (mn[r] >> (l + 1u)) & 1ull : mn[r + 1] & 1ull);
+            const bool n2 = idx + 2u >= cnt ? true : (l < 62u ? (mn[r] >> (l + 2u)) & 1ull : (mn[r + 1] >> (l - 62u)) & 1ull);
+            // the partner's rotation: the next lane's, the next row's lane 0, or -- behind the wave's span -- one load
+            u32 partner = (u32)__shfl_down((int)jv[r], 1, 64);
+            const u32 nextrow0 = r + 1 < 16 ? wave_lane(jv[(r + 1) & 15], 0) : 0u;
+            if (l == 63u) partner = r + 1 < 16 ? nextrow0 : (idx + 1u < cnt ? (ld_stream(V + base + idx + 1u) & 0xFFFFFu) : 0u);
+            if (idx + 1u < cnt && is_new && !n1 && n2) {
+                const u32 va = jv[r], vb = partner;
+                const u32 lo = va < vb ? va : vb, hi = va < vb ? vb : va;
+                mate[base + lo] = hi;
+                midx[base + lo] = at | (va == lo ? 0x80000000u : 0u);
+            }
+        }
         off += (u32)__popcll(surv[r]);
     }
 }
@@ -2280,7 +2303,10 @@ __global__ __launch_bounds__(kSortThreads) void k_period_find(BwtArgs a)
         const u32 last = n - 16u - at; // the farthest shift that keeps the 16 bytes inside the block
         // (four shifts per thread and trip, their loads in flight together; the second half of the 16 bytes is only
         // looked at where the first agrees: a block without a repeat reads 8 bytes per shift and anchor, not 16)
-        for (u32 q0 = 1u + tid; q0 <= last && q0 < s_best; q0 += 4u * kSortThreads) {
+        // (s_best is read through a volatile pointer: without it the compiler keeps the first value in a register, no thread
+        // ever sees a hit of another one, and every anchor costs a pass over the rest of the block -- rounds 3-4 and the first
+        // build of round 5: 33 ms per GiB of the stress corpus T2 with thirty-two anchors)
+        for (u32 q0 = 1u + tid; q0 <= last && q0 < *(volatile u32 *)&s_best; q0 += 4u * kSortThreads) {
             u64 x[4];
 #pragma unroll
             for (u32 u = 0; u < 4u; ++u) {
@@ -2307,34 +2333,94 @@ __global__ __launch_bounds__(kSortThreads) void k_period_find(BwtArgs a)
         if (tid == 0) s_cand[k] = s_best;
         __syncthreads();
     }
-    // how widely the block agrees with itself under every distinct candidate (an anchor inside a run of equal bytes
-    // answers "1", one inside a short inner repeat answers that repeat's distance: the whole block decides)
-    for (u32 k = 0; k < kAnchors; ++k) { // (uniform: every thread reads the same shared words)
-        const u32 c = s_cand[k];
-        bool seen = c == 0xFFFFFFFFu;
-        for (u32 j = 0; j < k; ++j) seen = seen || s_cand[j] == c;
+    // The candidates worth a look: the distinct ones, by the number of anchors that named them, a dozen at most (an anchor
+    // inside a run of equal bytes answers "1", one inside a short inner repeat answers that repeat's distance; text has such
+    // repeats everywhere, and every candidate looked at costs a pass over the block -- the first build of this kernel looked
+    // at all of them: 33 ms per GiB of the stress corpus T2, a fifth of its step).
+    constexpr u32 kLook = 12;
+    __shared__ u32 s_lookc[kLook], s_nlook;
+    if (tid == 0) {
+        u32 votes[kAnchors];
+        for (u32 k = 0; k < kAnchors; ++k) {
+            votes[k] = 0;
+            const u32 c = s_cand[k];
+            if (c == 0xFFFFFFFFu) continue;
+            bool first = true;
+            for (u32 j = 0; j < k; ++j) first = first && s_cand[j] != c;
+            if (!first) continue;
+            for (u32 j = k; j < kAnchors; ++j) votes[k] += s_cand[j] == c ? 1u : 0u;
+        }
+        u32 nl = 0;
+        for (; nl < kLook; ++nl) {
+            u32 bi = 0xFFFFFFFFu, bv = 0;
+            for (u32 k = 0; k < kAnchors; ++k)
+                if (votes[k] > bv || (votes[k] == bv && bv && s_cand[k] < s_cand[bi])) {
+                    bv = votes[k];
+                    bi = k;
+                }
+            if (bi == 0xFFFFFFFFu) break;
+            s_lookc[nl] = s_cand[bi];
+            votes[bi] = 0;
+        }
+        s_nlook = nl;
+    }
+    __syncthreads();
+    // how widely the block agrees with itself under each of them: on every fourth stripe of 4 KiB first (a ranking needs no
+    // more), on all of it when the sample agrees everywhere (periodic as a cycle or nearly so: that decides whether the
+    // distance is listed at all)
+    const u32 nlook = s_nlook;
+    for (u32 k = 0; k < kAnchors; ++k) { // (the agreement of candidate k goes to s_agree[k], k < nlook)
         if (tid == 0) s_agree[k] = 0;
-        __syncthreads();
-        if (seen) continue;
-        u32 mine = 0;
-        for (u32 i = tid * 8u; i < n; i += kSortThreads * 8u) {
-            if (i + 8u + c <= n) {
-                u64 x, y;
-                __builtin_memcpy(&x, text + i, 8);
-                __builtin_memcpy(&y, text + i + c, 8);
-                const u64 z = x ^ y; // bytes that agree are zero bytes
-                mine += 8u - (u32)__popcll(((z | (z >> 1) | (z >> 2) | (z >> 3) | (z >> 4) | (z >> 5) | (z >> 6) | (z >> 7)) & 0x0101010101010101ull));
-            } else {
-                for (u32 q = i; q < i + 8u && q < n; ++q) {
-                    const u32 t = q + c;
-                    mine += text[q] == text[t >= n ? t - n : t] ? 1u : 0u;
+    }
+    __syncthreads();
+    for (u32 k = 0; k < nlook; ++k) { // (uniform)
+        const u32 c = s_lookc[k];
+        for (u32 pass = 0; pass < 2u; ++pass) {
+            u32 mine = 0, seen = 0;
+            for (u32 i = tid * 8u; i < n; i += kSortThreads * 8u) {
+                if (pass == 0 && ((i / (kSortThreads * 8u)) & 3u) != 0u) continue; // every fourth stripe
+                if (i + 8u + c <= n) {
+                    u64 x, y;
+                    __builtin_memcpy(&x, text + i, 8);
+                    __builtin_memcpy(&y, text + i + c, 8);
+                    const u64 z = x ^ y; // bytes that agree are zero bytes
+                    mine += 8u - (u32)__popcll(((z | (z >> 1) | (z >> 2) | (z >> 3) | (z >> 4) | (z >> 5) | (z >> 6) | (z >> 7)) & 0x0101010101010101ull));
+                    seen += 8u;
+                } else {
+                    for (u32 q = i; q < i + 8u && q < n; ++q) {
+                        const u32 t = q + c;
+                        mine += text[q] == text[t >= n ? t - n : t] ? 1u : 0u;
+                        seen += 1u;
+                    }
                 }
             }
+            mine = wave_sum(mine);
+            seen = wave_sum(seen);
+            if (tid == 0) {
+                s_agree[k] = 0;
+                s_best = 0; // (borrowed: the positions looked at)
+            }
+            __syncthreads();
+            if ((tid & 63u) == 0) {
+                atomicAdd(&s_agree[k], mine);
+                atomicAdd(&s_best, seen);
+            }
+            __syncthreads();
+            const u32 ag = s_agree[k], sn = s_best;
+            __syncthreads();
+            if (pass == 0) {
+                if (ag != sn) { // the sample, scaled to the block
+                    if (tid == 0) s_agree[k] = (u32)(((u64)ag * n) / (sn ? sn : 1u));
+                    break;
+                }
+            }
+            // (pass 1: the exact count stands)
         }
-        mine = wave_sum(mine);
-        if ((tid & 63u) == 0) atomicAdd(&s_agree[k], mine);
         __syncthreads();
     }
+    if (tid == 0)
+        for (u32 k = 0; k < kAnchors; ++k) s_cand[k] = k < nlook ? s_lookc[k] : 0xFFFFFFFFu; // (the list below reads s_cand / s_agree)
+    __syncthreads();
     // the list: widest agreement first (ties: the shorter distance); a distance is worth its tables when the block agrees
     // with itself under it at a sixteenth of its positions or more -- and not everywhere (periodic as a cycle: equal
     // rotations, k_periodic_place's case)
@@ -2516,6 +2602,130 @@ __global__ __launch_bounds__(kSortThreads) void k_pair_compare(BwtArgs a, u32 st
         pb8[idx] = verdict > 0 ? 3 : 2;
         pb8[idx + 1u] = verdict < 0 ? 3 : 2;
         impure[base + g] = 2;
+    }
+}
+
+// ---- groups of TWO, round 5: one scan per STRETCH of pairs instead of one per pair -----------------------------------------
+// k_pair_compare above gives every group of two a lane that reads both rotations until they differ: 2-4 KB per pair on data
+// whose copies agree that far, 270 GB out of the L2 per 256 MiB, 70 ms.  But the pairs of a copied stretch share their
+// difference: pairs (x, x + d) and (x + 1, x + 1 + d) agree up to the SAME position m -- the first m at or behind the later
+// start + depth with T[m] != T[m + d] -- whatever d is and however many distances a block has (copies that DRIFT: every
+// changed byte that RLE1 turns into a shift starts a new d).  So:
+//   k_pair_list  every group of exactly two members of the survivor list (found as k_pair_compare finds them) leaves
+//                mate[lo] = hi and the place of the pair in the list, indexed by its smaller START;
+//   k_pair_scan  walks the block in TEXT order, a wave per 64 consecutive starts: the lanes whose pairs lie the same distance
+//                apart are resolved together -- the wave compares 512 bytes of T and of T shifted by d per step, eight per
+//                lane, until a difference turns up, and every pair whose known-equal prefix ends in front of it takes it
+//                (the pairs behind it go on from there).  One verdict byte per list position, as k_pair_compare writes them.
+// The comparison is the definition of the order (sais.rs:266-272 fixes nothing else); 14 K waves per block read ~2 KB each.
+constexpr u32 kPairNone = 0xFFFFFFFFu;
+__global__ __launch_bounds__(kSortThreads) void k_pair_list(BwtArgs a, const u32 *__restrict__ V, u32 *__restrict__ mate, u32 *__restrict__ midx)
+{
+    u32 tile, lb;
+    xcd_remap(gridDim.x, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    const u32 n = a.blocks[lb].n;
+    const u32 cnt = a.count[lb];
+    const u32 start = tile * kSortTile;
+    if (start >= cnt || n < 64u || (u64)cnt * 4u < (u64)n * 3u) return; // (only blocks that are deep in repeats)
+    const size_t base = (size_t)lb * kSlot;
+    for (u32 idx = start + threadIdx.x; idx + 1u < cnt && idx < start + kSortTile; idx += kSortThreads) {
+        const u32 va = V[base + idx] & 0xFFFFFu, vb = V[base + idx + 1u] & 0xFFFFFu;
+        const u32 g = a.R[base + va] & ~kFinalBit;
+        if ((a.R[base + vb] & ~kFinalBit) != g) continue;
+        if (idx > 0 && (a.R[base + (V[base + idx - 1u] & 0xFFFFFu)] & ~kFinalBit) == g) continue;   // not the group's first
+        if (idx + 2u < cnt && (a.R[base + (V[base + idx + 2u] & 0xFFFFFu)] & ~kFinalBit) == g) continue; // three or more
+        const u32 lo = va < vb ? va : vb, hi = va < vb ? vb : va;
+        mate[base + lo] = hi;
+        midx[base + lo] = idx | (va == lo ? 0x80000000u : 0u); // (bit 31: the smaller start stands first in the list)
+    }
+}
+
+__device__ __forceinline__ u64 pair_load8(const u8 *__restrict__ text, u32 n, u32 p) // eight bytes from p on, cyclic (p < n)
+{
+    u64 v;
+    if (p + 8u <= n) {
+        __builtin_memcpy(&v, text + p, 8);
+    } else {
+        v = 0;
+        for (u32 k = 0; k < 8u; ++k) {
+            const u32 q = p + k;
+            v |= (u64)text[q >= n ? q - n : q] << (8u * k);
+        }
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(kSortThreads) void k_pair_scan(BwtArgs a, u32 step, const u32 *__restrict__ mate, const u32 *__restrict__ midx,
+                                                             u8 *__restrict__ impure)
+{
+    u32 tile, lb;
+    xcd_remap(gridDim.x, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    const BlockDesc d = a.blocks[lb];
+    const u32 n = d.n;
+    const u32 start = tile * kSortTile;
+    if (start >= n || n < 64u) return;
+    const u8 *__restrict__ text = a.rle + d.rle_off;
+    const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
+    const u64 d64 = ((u64)ki.chars * 2u) << step;
+    const u32 depth = d64 < n ? (u32)d64 : n;
+    const size_t base = (size_t)lb * kSlot;
+    u8 *pb8 = pair_bytes(a, lb);
+    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    for (u32 r = 0; r < 16u; ++r) {
+        const u32 x = start + w * 1024u + r * 64u + l;
+        const u32 hi = x < n ? mate[base + x] : kPairNone;
+        const bool has = hi != kPairNone && hi > x && hi < n;
+        const u32 dist = has ? hi - x : 0u;
+        u64 todo = __ballot(has);
+        bool solved = false, lo_less = false;
+        for (u32 tries = 0; todo && tries < 8u; ++tries) {
+            const u32 L = (u32)__builtin_ctzll(todo);
+            const u32 dL = wave_lane(dist, L), xL = wave_lane(x, L);
+            u64 grp = __ballot(has && !solved && dist == dL) & todo; // (lane L is in it; its start is the group's smallest)
+            u32 s = xL + depth;                                      // where the leader's known-equal prefix ends
+            s = s >= n ? s - n : s;
+            u32 scanned = 0;
+            bool found = false;
+            while (scanned < kPairCap && scanned + depth < n) {
+                u32 pa = s + 8u * l;
+                pa = pa >= n ? pa - n : pa;
+                u32 pb = pa + dL;
+                pb = pb >= n ? pb - n : pb;
+                const u64 xa = pair_load8(text, n, pa), xb = pair_load8(text, n, pb);
+                const u64 df = xa ^ xb;
+                const u64 bm = __ballot(df != 0ull);
+                if (bm) {
+                    const u32 f = (u32)__builtin_ctzll(bm);
+                    const u64 dff = wave_lane64(df, f), xaf = wave_lane64(xa, f), xbf = wave_lane64(xb, f);
+                    const u32 byte = (u32)__builtin_ctzll(dff) >> 3;
+                    const u32 moff = scanned + 8u * f + byte; // the first difference, counted from the leader's start + depth
+                    const bool less = (u32)((xaf >> (8u * byte)) & 0xFFull) < (u32)((xbf >> (8u * byte)) & 0xFFull);
+                    // every pair of the group whose own known-equal prefix ends at or in front of the difference takes it
+                    const bool mine = ((grp >> l) & 1ull) && (x - xL) <= moff;
+                    if (mine) {
+                        solved = true;
+                        lo_less = less;
+                    }
+                    todo &= ~__ballot(mine);
+                    found = true;
+                    break;
+                }
+                s += 512u;
+                s = s >= n ? s - n : s;
+                scanned += 512u;
+            }
+            if (!found) todo &= ~grp; // (equal as far as looked: a periodic block, or a repeat longer than the cap -- they go on doubling)
+        }
+        if (solved) {
+            const u32 mi = midx[base + x];
+            const u32 idx0 = mi & 0x7FFFFFFFu;
+            const bool lo_first = (mi >> 31) != 0u;
+            pb8[idx0 + (lo_first ? 0u : 1u)] = lo_less ? 2 : 3; // the smaller start's entry
+            pb8[idx0 + (lo_first ? 1u : 0u)] = lo_less ? 3 : 2;
+            impure[base + (a.R[base + x] & ~kFinalBit)] = 2;
+        }
     }
 }
 
@@ -3018,7 +3228,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
     u32 step = 0; // this round compares at depth h = 2c << step
     int rounds = 0;
     u32 slot = 0;
-    bool period_done = false;
+    bool period_done = false, pair_done = false;
     u32 list_tiles = a.tiles; // (the first refinement ran on all of SA)
     while (true) {
         if (hipMemcpyAsync(h_active, a.active + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, st) !=
@@ -3055,41 +3265,65 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             const char *e = getenv("BZ_PERIOD_ROUND");
             return !e ? 1 : (e[0] == 'b' ? 2 : (atoi(e) != 0 ? 1 : 0));
         }();
+        // (round 5: a batch that is unordered to the last rotation behind the init -- 63 of 64: a paragraph repeated; text
+        // stands at 56 % there, the corpus "binary" at 96 % -- takes the period round at once instead of behind a full-width
+        // walk round that orders nothing.  Only when the WHOLE batch looks like that: a period round in front of the walk
+        // round costs the blocks that do not need it four passes over their survivors and the carried ranks of that round,
+        // and at 8-12 symbols most groups of data that merely holds a stretch twice are still a mixture of both copies'
+        // neighbourhoods: binary loses 2 % with the round at h = 8 instead of 16.)
         const bool deep = want_period == 2 ? (rounds >= 3 && m * 4 >= total_n * 3)
-                                           : (rounds >= 2 && ((u64)mx * 4 >= (u64)max_n * 3 || m * 4 >= total_n * 3));
+                                           : ((rounds >= 2 && ((u64)mx * 4 >= (u64)max_n * 3 || m * 4 >= total_n * 3)) ||
+                                              (rounds == 1 && m * 64 >= total_n * 63));
         const bool per_round = want_period != 0 && !period_done && deep;
+        // A PAIR round (round 5): behind the period round, once, when half of the rotations are still unordered at a depth of 32
+        // symbols and more -- data that holds a stretch twice (the corpus "binary") leaves almost every rotation in a group of
+        // two by then, whose members agree for kilobytes: k_pair_scan orders them in one go, whatever the distances between the
+        // copies, instead of the eight doubling rounds they would take.  At the depth of the period round (8-16 symbols) most
+        // groups are still larger than two.
+        const bool pair_round = want_period != 0 && !per_round && period_done && !pair_done && a.gh_tiles && a.per_pairs &&
+                                ((u64)(2u * min_chars) << step) >= 32u && m * 2 >= total_n;
         static const bool bwt_trace = getenv("BZ_BWT_TRACE") != nullptr;
         if (bwt_trace)
             fprintf(stderr, "bz2_mi355x: sort round %d (h = %llu): %llu of %llu rotations unordered, at most %u in one block (of %u)%s\n",
                     rounds, (unsigned long long)(2u * min_chars) << step, (unsigned long long)m, (unsigned long long)total_n, mx,
-                    max_n, per_round ? ": period round" : (m * 4 < total_n ? ": survivor form" : ": walk form"));
+                    max_n, per_round ? ": period round" : (pair_round ? ": pair round" : (m * 4 < total_n ? ": survivor form" : ": walk form")));
         u8 *impure = a.ptext; // (the packed text is not read any more once the init is over)
-        if (per_round) {
-            period_done = true;
+        if (per_round || pair_round) {
+            if (per_round) period_done = true;
+            else pair_done = true;
             (void)hipMemsetAsync(impure, 0, (size_t)a.nb * kSlot, st);
-            hipLaunchKernelGGL(k_survivor_compact, grid_prev, dim3(kSortThreads), 0, st, a, lastV, fV);
+            // Round 5: the groups of two are ordered by one scan per stretch of pairs (k_survivor_compact leaves the pairs,
+            // k_pair_scan orders them; BZ_PAIR_COMPARE=0 turns it off, =2 runs round 4's one-lane-per-pair kernel instead).
+            // mate / place of the pair: the two arrays of the list the last refinement ran on, which nothing reads between the
+            // compaction and the passes below -- unless the compaction reads that very list (lastV), then the free key array.
+            static const int pair_mode = getenv("BZ_PAIR_COMPARE") ? atoi(getenv("BZ_PAIR_COMPARE")) : 1;
+            const bool pairs = a.gh_tiles && a.per_pairs && pair_mode != 0; // (the verdict bytes live in the fused passes' digit counts: no fused passes, no pair round)
+            u32 *mate = (lastV == cK) ? fK : cK, *midx = (lastV == cV || lastV == cK) ? fK : cV;
+            if (mate == midx) midx = (lastV == cV) ? cK : cV;
+            const bool scan = pairs && pair_mode != 2;
+            if (scan) (void)hipMemsetAsync(mate, 0xFF, (size_t)a.nb * kSlot * 4, st);
+            hipLaunchKernelGGL(k_survivor_compact, grid_prev, dim3(kSortThreads), 0, st, a, lastV, fV, scan ? mate : nullptr, scan ? midx : nullptr);
             hipLaunchKernelGGL(k_copy_counts, dim3((a.nb + 255) / 256), dim3(256), 0, st, a.count, a.count2, a.nb);
-            // the blocks' periods and the two bitmaps that order rotation i against rotation i + p (in the flag bytes'
-            // slot, which nothing uses before this round's k_group_flags)
-            // (OFF unless BZ_PAIR_COMPARE=1 -- measured in round 4 on the corpus it was written for, 256 MiB of the
-            // reference's binary fixtures tiled: 42 M groups of two whose members agree for 2-4 KB; one lane per group
-            // reads 270 GB out of the L2 and takes 70 ms, the eight doubling rounds it replaces for a third of the
-            // rotations take 25: 2.43 GB/s without it, 0.89 with it.  Same streams either way.)
-            static const bool want_pairs = getenv("BZ_PAIR_COMPARE") && atoi(getenv("BZ_PAIR_COMPARE")) != 0;
-            if (a.gh_tiles && want_pairs) { // (the verdict bytes live in the fused passes' digit counts: no fused passes, no pair round)
+            if (pairs) {
                 (void)hipMemset2DAsync(a.gh_tiles, (size_t)kTilesPerBlock * 3 * kMaxBins * 4, 0, (size_t)list_tiles * kSortTile, a.nb, st);
-                hipLaunchKernelGGL(k_pair_compare, grid_list, dim3(kSortThreads), 0, st, a, step, fV, impure);
+                if (pair_mode == 2) hipLaunchKernelGGL(k_pair_compare, grid_list, dim3(kSortThreads), 0, st, a, step, fV, impure);
+                else hipLaunchKernelGGL(k_pair_scan, grid, dim3(kSortThreads), 0, st, a, step, mate, midx, impure);
             }
+            // the blocks' distances and the bitmaps that order rotation i against rotation i + p (in the flag bytes' slot, which
+            // nothing uses before this round's k_group_flags); the pair round lists none
+            if (!per_round) (void)hipMemsetAsync(a.lin_p, 0, (size_t)a.nb * kPerK * 4, st);
+            if (per_round) {
             hipLaunchKernelGGL(k_period_find, dim3(a.nb), dim3(kSortThreads), 0, st, a);
             hipLaunchKernelGGL(k_period_bits, grid, dim3(kSortThreads), 0, st, a);
             hipLaunchKernelGGL(k_period_next, dim3(a.nb, per_kmax(a)), dim3(kSortThreads), 0, st, a);
+            }
             radix_pass<SRC_PERJ, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK, list_tiles);
             radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof, nullptr, list_tiles);
             radix_pass<SRC_LISTG, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK, list_tiles);
             radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof, nullptr, list_tiles);
             u32 *t = cK; cK = fK; fK = t;
             t = cV; cV = fV; fV = t;
-            hipLaunchKernelGGL(k_period_mark, grid_list, dim3(kSortThreads), 0, st, a, step, cK, cV, impure);
+            if (per_round) hipLaunchKernelGGL(k_period_mark, grid_list, dim3(kSortThreads), 0, st, a, step, cK, cV, impure);
         } else if (m * 4 < total_n) {
             // few survivors: compact them (list order = sorted by group), order them by the rank
             // of rotation j+h (2 passes), then stably by their own group (2 passes): O(m) work
@@ -3120,7 +3354,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             }
         }
         (void)hipMemsetAsync(a.bin_cursor, 0, (size_t)a.nb * 1024 * sizeof(u32), st);
-        if (per_round) {
+        if (per_round || pair_round) {
             // (the comparison depth does not move: the next round doubles from where the last one stood)
             p = prof ? prof->begin(st, KID_GROUP_FLAGS, m * 13) : -1;
             hipLaunchKernelGGL((k_group_flags<false>), grid_list, dim3(kSortThreads), 0, st, a, step, cK, cV, impure);
@@ -3159,7 +3393,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
                 }
         }
         lastV = cV;
-        if (!per_round) ++step;
+        if (!per_round && !pair_round) ++step;
     }
     if (fused) {
         // a look-back that gave up (it never should) must not pass for a sorted block, and every pass
