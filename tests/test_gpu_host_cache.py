@@ -60,3 +60,63 @@ def test_decode_buffer_hands_out_memory_free_takes(pkg, oracle):
                 assert C.addressof(outp.contents) % (2 << 20) == 0
             L.bz_free(outp)
     pkg.release_cached_resources()
+
+
+def test_peer_copy_selftest_on_the_boxes_devices(pkg):
+    """bz_peer_copy_selftest (round 5; bench.py's preflight at N > 1): a list that names the one device twice copies
+    nothing (peer_access -1), bad arguments are refused, and the calling thread's current device is left as it was.  (Two
+    different devices need a second GPU: the driver's node; the pairs' arithmetic runs under the sanitizers against the HIP
+    shim, tests/host_stub/host_pipeline_stress.cpp.)"""
+    import ctypes as C
+    import torch
+    L = pkg.lib()
+    torch.cuda.set_device(0)
+    devs = (C.c_int * 2)(0, 0)
+    peer = (C.c_int * 2)(9, 9)
+    ms = (C.c_double * 2)(-2.0, -2.0)
+    assert L.bz_peer_copy_selftest(devs, 2, 1 << 20, peer, ms) == 0
+    assert list(peer) == [-1, -1] and list(ms) == [0.0, 0.0]
+    assert L.bz_peer_copy_selftest(devs, 0, 1 << 20, None, None) == pkg.BZ_E_PARAM
+    assert L.bz_peer_copy_selftest((C.c_int * 1)(77), 1, 1 << 20, None, None) == pkg.BZ_E_PARAM
+    assert L.bz_peer_copy_selftest(devs, 2, 0, None, None) == pkg.BZ_E_PARAM
+    n = torch.cuda.device_count()
+    if n >= 2:  # (a multi-GPU box: the real thing, a round trip per neighbour pair)
+        devs = (C.c_int * n)(*range(n))
+        peer = (C.c_int * n)()
+        ms = (C.c_double * n)()
+        assert L.bz_peer_copy_selftest(devs, n, 1 << 20, peer, ms) == 0
+        assert all(p in (0, 1) for p in peer) and all(t > 0 for t in ms)
+    assert torch.cuda.current_device() == 0
+
+
+def test_streaming_decoder_reads_behind_the_end_wait_for_the_worker(pkg, oracle):
+    """Round 5: bz_dec_end returns at once and bz_dec_read waits behind it.  A stream large enough for the worker thread
+    (chunks of 4 MiB and more are decoded beside the caller): written in one piece, ended, then read in small pieces until
+    the verdict -- every byte, then 0; a corrupted copy: the bytes in front of the error, then the error
+    (/root/reference/src/bzip2/decoder.rs:583-612: the iterator yields exactly that sequence)."""
+    import bz2
+    import ctypes as C
+    data = _text(30_000_000, 11)
+    z = bz2.compress(data, 9)
+    assert len(z) > (5 << 20)
+    L = pkg.lib()
+    for corrupt in (False, True):
+        zz = bytearray(z)
+        if corrupt:
+            zz[len(zz) * 3 // 4] ^= 0x55
+        want, verdict = oracle.decode(bytes(zz))
+        h = C.c_void_p()
+        assert L.bz_dec_create(C.byref(h), 0) == 0
+        assert L.bz_dec_write(h, bytes(zz), len(zz)) == 0
+        rc_end = L.bz_dec_end(h)
+        assert rc_end in (0, verdict)
+        buf = (C.c_uint8 * (3 << 20))()
+        got = bytearray()
+        while True:
+            k = L.bz_dec_read(h, buf, len(buf))
+            if k <= 0:
+                break
+            got += bytes(buf[:k])
+        L.bz_dec_destroy(h)
+        assert k == verdict and bytes(got) == want, (corrupt, k, verdict, len(got), len(want))
+        assert (verdict == 0) == (not corrupt)
