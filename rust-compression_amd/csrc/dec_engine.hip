@@ -185,6 +185,18 @@ struct HostBuf {
     ~HostBuf() { free(p); }
 };
 
+// Incremental decode (the streaming context): the chain's state between two calls, and whether
+// more input may follow.  A call that is not the last one stops in front of the first record it
+// cannot be sure about (not wholly inside the bytes it has, or failing -- which near the end of a
+// buffer may just mean "cut off"); the caller keeps the input from `pos` on and calls again.
+struct Resume {
+    u64 pos = 0; // bit position of the next record (in: inside the buffer handed in; out: likewise)
+    u32 stream_no = 1, level = 0, combined = 0;
+    bool need_header = true;
+    bool final = true;    // no more input will come
+    bool stopped = false; // out: stopped in front of an unsure record, nothing wrong so far
+};
+
 struct Sink {
     u8 *d_out = nullptr; // device destination (device API) or nullptr
     u64 cap = 0;
@@ -200,6 +212,13 @@ struct Sink {
     CopyPool *pool = nullptr; // ... copied by its thread while the next sub-batch's kernels run (nullptr: one hipMemcpy per batch)
     u64 produced = 0;
     bool to_host() const { return host != nullptr || (bool)seg_alloc; }
+    // (the streaming context's two lanes, see bz_dec) chain_final(state): the record chain of this call has been walked to
+    // its end -- `state` is what the next call starts from -- and only the rebuilding of its blocks is left: the next chunk's
+    // scan and Huffman stage may begin beside it.  before_output(): called once in front of the first block that is rebuilt;
+    // waits until the chunk in front has handed out all its bytes; false = give up (an error in front, or the context ends).
+    std::function<void(const Resume &)> chain_final;
+    std::function<bool()> before_output;
+    bool aborted = false;
 };
 
 } // namespace
@@ -231,17 +250,6 @@ struct ShardSum { // one rank's result
     u64 fail_ord;   // ordinal (in stream order) of its first failing block, ~0 if none
     u64 first_ord;  // ordinal of its first block (~0: it owns none)
     u64 pad;
-};
-// Incremental decode (the streaming context): the chain's state between two calls, and whether
-// more input may follow.  A call that is not the last one stops in front of the first record it
-// cannot be sure about (not wholly inside the bytes it has, or failing -- which near the end of a
-// buffer may just mean "cut off"); the caller keeps the input from `pos` on and calls again.
-struct Resume {
-    u64 pos = 0; // bit position of the next record (in: inside the buffer handed in; out: likewise)
-    u32 stream_no = 1, level = 0, combined = 0;
-    bool need_header = true;
-    bool final = true;    // no more input will come
-    bool stopped = false; // out: stopped in front of an unsure record, nothing wrong so far
 };
 struct Shard {
     int rank = 0, world = 1;
@@ -391,6 +399,7 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
         }
     } pool_guard{sink.to_host() ? sink.pool : nullptr};
     u32 batch_no = 0;
+    bool chain_told = false, out_open = false;
     size_t stage_ticket[2] = {0, 0};
     bool stage_busy[2] = {false, false};
 
@@ -614,6 +623,24 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
         }
         if (rd.failed) return BZ_E_UNEXPECTED;
         ci = cj;
+        if (term != 0 && sink.chain_final && !chain_told) {
+            chain_told = true;
+            Resume fin;
+            fin.stopped = term == 2;
+            fin.pos = term == 2 ? rec_pos : pos;
+            fin.combined = term == 2 ? rec_combined : combined;
+            fin.stream_no = term == 2 ? rec_stream_no : stream_no;
+            fin.need_header = term == 2 ? rec_need_header : need_header;
+            fin.level = level;
+            sink.chain_final(fin);
+        }
+        if (sink.before_output && !out_open) {
+            out_open = true;
+            if (!sink.before_output()) {
+                sink.aborted = true;
+                return BZ_OK;
+            }
+        }
         u64 my_first_ord = ~0ull; // stream ordinal of this rank's first block
         const u64 n_true = bslot.size();
         if (sh) {
@@ -1013,12 +1040,13 @@ extern "C" int bz_gpu_last_decode_stats(bz_gpu_engine *g, uint64_t out[4])
     return BZ_OK;
 }
 
-// One engine per device is kept between one-shot calls (its decode workspace -- 13 MB per block in flight -- and the
+// Two engines per device are kept between one-shot calls and contexts (its decode workspace -- 13 MB per block in flight -- and the
 // buffer for the compressed bytes cost more to make than a GiB costs to decode); bz_release_cached_resources frees them.
 namespace {
 std::mutex g_dec_cache_mu;
 std::vector<std::pair<int, bz_gpu_engine *>> g_dec_cache;
 } // namespace
+static void dec_spare_bufs_clear();
 bz_gpu_engine *dec_cache_take(int device)
 {
     std::lock_guard<std::mutex> lk(g_dec_cache_mu);
@@ -1034,14 +1062,14 @@ void dec_cache_put(int device, bz_gpu_engine *g)
 {
     {
         std::lock_guard<std::mutex> lk(g_dec_cache_mu);
-        bool have = false;
-        for (const auto &e : g_dec_cache) have = have || e.first == device;
-        if (!have) {
+        size_t have = 0;
+        for (const auto &e : g_dec_cache) have += e.first == device ? 1 : 0;
+        if (have < 2) { // (two: the lanes of a streaming context)
             g_dec_cache.emplace_back(device, g);
             return;
         }
     }
-    bz_gpu_engine_destroy(g); // (two calls side by side on one device: the second engine is not kept)
+    bz_gpu_engine_destroy(g); // (more calls side by side on one device: their engines are not kept)
 }
 void dec_release_cached()
 {
@@ -1054,6 +1082,7 @@ void dec_release_cached()
         (void)hipSetDevice(e.first);
         bz_gpu_engine_destroy(e.second);
     }
+    dec_spare_bufs_clear();
 }
 
 extern "C" int bz_decode_buffer(int device, const uint8_t *in, size_t in_len, uint8_t **out, size_t *out_len)
@@ -1119,8 +1148,65 @@ extern "C" int bz_decode_buffer(int device, const uint8_t *in, size_t in_len, ui
 // behind it bz_dec_read WAITS for the next bytes or the final verdict instead of answering "nothing yet" -- a consumer
 // reads the head of the file while its tail is still being decoded.
 namespace {
+// Compressed bytes on their way to a lane: plain memory without value initialisation, 2 MiB-aligned and asking for huge
+// pages from 4 MiB on (a chunk is written once and uploaded once: what its buffer costs is the first touch of its pages
+// -- a malloc'ed std::vector that doubled its way to 64 MiB took the writer 25 ms per chunk, a third of a second per GiB).
+struct ByteBuf {
+    u8 *p = nullptr;
+    size_t len = 0, cap = 0;
+    ByteBuf() = default;
+    ByteBuf(const ByteBuf &) = delete;
+    ByteBuf &operator=(const ByteBuf &) = delete;
+    ByteBuf(ByteBuf &&o) noexcept : p(o.p), len(o.len), cap(o.cap) { o.p = nullptr, o.len = o.cap = 0; }
+    ByteBuf &operator=(ByteBuf &&o) noexcept
+    {
+        if (this != &o) {
+            free(p);
+            p = o.p, len = o.len, cap = o.cap;
+            o.p = nullptr, o.len = o.cap = 0;
+        }
+        return *this;
+    }
+    ~ByteBuf() { free(p); }
+    size_t size() const { return len; }
+    bool empty() const { return len == 0; }
+    size_t capacity() const { return cap; }
+    const u8 *data() const { return p; }
+    void clear() { len = 0; }
+    void swap(ByteBuf &o)
+    {
+        std::swap(p, o.p);
+        std::swap(len, o.len);
+        std::swap(cap, o.cap);
+    }
+    bool reserve(size_t want)
+    {
+        if (want <= cap) return true;
+        void *q = nullptr;
+        if (want >= ((size_t)4 << 20)) {
+            want = (want + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+            if (posix_memalign(&q, (size_t)2 << 20, want) != 0) q = nullptr;
+            if (q) (void)madvise(q, want, MADV_HUGEPAGE);
+        } else {
+            q = malloc(want);
+        }
+        if (!q) return false;
+        if (len) memcpy(q, p, len);
+        free(p);
+        p = static_cast<u8 *>(q);
+        cap = want;
+        return true;
+    }
+    bool append(const u8 *src, size_t k)
+    {
+        if (len + k > cap && !reserve(len + k)) return false;
+        memcpy(p + len, src, k);
+        len += k;
+        return true;
+    }
+};
 struct DecJob {
-    std::vector<u8> bytes;
+    ByteBuf bytes;
     bool final = false;
 };
 struct DecSeg { // decoded bytes of one sub-batch, handed out from `pos` on
@@ -1131,12 +1217,42 @@ struct DecSeg { // decoded bytes of one sub-batch, handed out from `pos` on
     ~DecSeg() { free(p); }
 };
 } // namespace
+// Chunk buffers of contexts that have ended, kept for the next context (up to four, 64 MiB each by default: their pages
+// are touched already); bz_release_cached_resources frees them with the engines.
+static std::mutex g_dec_spare_mu;
+static std::vector<ByteBuf> g_dec_spare_bufs;
+static void dec_spare_bufs_clear()
+{
+    std::vector<ByteBuf> all;
+    {
+        std::lock_guard<std::mutex> lk(g_dec_spare_mu);
+        all.swap(g_dec_spare_bufs);
+    }
+}
+static void dec_spare_buf_take(ByteBuf &into, size_t want)
+{
+    std::lock_guard<std::mutex> lk(g_dec_spare_mu);
+    for (size_t i = 0; i < g_dec_spare_bufs.size(); ++i)
+        if (g_dec_spare_bufs[i].capacity() >= want) {
+            into.swap(g_dec_spare_bufs[i]);
+            into.clear();
+            g_dec_spare_bufs.erase(g_dec_spare_bufs.begin() + (ptrdiff_t)i);
+            return;
+        }
+}
+static void dec_spare_buf_put(ByteBuf &b)
+{
+    if (b.capacity() < ((size_t)4 << 20) || b.capacity() > ((size_t)256 << 20)) return;
+    std::lock_guard<std::mutex> lk(g_dec_spare_mu);
+    if (g_dec_spare_bufs.size() >= 4) return;
+    b.clear();
+    g_dec_spare_bufs.push_back(std::move(b));
+}
 struct bz_dec {
     int device = 0;
-    bz_gpu_engine *g = nullptr;
     size_t chunk = (size_t)64 << 20, first_chunk = (size_t)16 << 20;
     // the caller's side
-    std::vector<u8> in; // compressed bytes not yet handed to the worker
+    ByteBuf in; // compressed bytes not yet handed to the worker
     bool ended = false;
     u64 chunks_sent = 0;
     // shared (mu)
@@ -1150,49 +1266,82 @@ struct bz_dec {
     // instead of 30 when every segment was freed behind its reader, profiles/r05_host_copies.md), and a buffer that
     // comes back has its pages touched already.  At most four of each are kept.
     std::vector<DecSeg *> spare_segs;
-    std::vector<std::vector<u8>> spare_bytes;
+    std::vector<ByteBuf> spare_bytes;
     size_t out_bytes = 0;                // landed and not yet read
     u64 submitted = 0, processed = 0;    // jobs
     bool stop = false;
     bool done = false;                   // the verdict is final (error, or clean end): later input is ignored
     int verdict = BZ_OK;
-    // the worker's side
-    std::thread worker;
+    // the workers' side.  TWO lanes (an engine, an input buffer and a thread each) take the chunks in turn: a chunk's
+    // record chain is known once its Huffman stage (D1: 11 ms whatever the chunk holds) is over, and from there on the
+    // next chunk's upload, scan and D1 run on the other lane beside the rebuilding (D2..D4) of this one's blocks.  The
+    // chain -- carry, rs -- belongs to the lane whose job number is `chain_turn`; decoded bytes are handed out by the lane
+    // whose job number is `out_turn` (a lane whose chain is walked waits there for the chunk in front to finish, and
+    // gives up if that one ended with an error).  BZ_DEC_LANES=1: one lane (round 5's first form: D1 of a chunk behind
+    // D4 of the one in front).
+    struct Lane {
+        bz_gpu_engine *g = nullptr;
+        DevBuf d_in;
+        std::thread th;
+    } lane[2];
+    int n_lanes = 2;
+    u64 taken = 0, chain_turn = 0, out_turn = 0; // job numbers (mu)
     std::vector<u8> carry; // compressed bytes from the next record on (what the last chunk left undecided)
     Resume rs;
-    DevBuf d_in;
     CopyPool *pool = nullptr;
 };
 
-// the worker: one chunk (everything not yet decided + the new bytes)
-static void dec_process(bz_dec *d, DecJob &j)
+// a lane: one chunk (everything not yet decided + the new bytes); `no` is the chunk's job number
+static void dec_process(bz_dec *d, bz_dec::Lane &ln, DecJob &j, u64 no)
 {
+    bool chain_mine = true; // (this lane holds the chain until the hook below or the end of this function passes it on)
+    auto pass_chain = [&] {
+        if (!chain_mine) return;
+        chain_mine = false;
+        {
+            std::lock_guard<std::mutex> lk(d->mu);
+            d->chain_turn = no + 1;
+        }
+        d->cv.notify_all();
+    };
     auto finish = [&](int v) {
         std::lock_guard<std::mutex> lk(d->mu);
+        if (d->done) return;
         d->done = true;
         d->verdict = v;
     };
-    if (!d->g) { // (an engine kept by an earlier one-shot call or context, with its workspace, or a new one)
-        d->g = dec_cache_take(d->device);
-        const int rc = d->g ? BZ_OK : bz_gpu_engine_create(&d->g, d->device, 0);
-        if (rc != BZ_OK) return finish(rc);
+    auto wait_out_turn = [&]() -> bool { // false: the chunk in front ended the context (an error), or the context is being destroyed
+        std::unique_lock<std::mutex> lk(d->mu);
+        d->cv.wait(lk, [&] { return d->out_turn == no || d->stop; });
+        return d->out_turn == no && !d->done;
+    };
+    if (!ln.g) { // (an engine kept by an earlier one-shot call or context, with its workspace, or a new one)
+        ln.g = dec_cache_take(d->device);
+        const int rc = ln.g ? BZ_OK : bz_gpu_engine_create(&ln.g, d->device, 0);
+        if (rc != BZ_OK) {
+            pass_chain();
+            if (wait_out_turn()) finish(rc);
+            return;
+        }
     }
     const double t0 = dec_now_ms();
     // the device holds [carry | new bytes]: two uploads, no copy of the chunk on the host; room for a whole chunk and a
     // block's worth of carry from the start, so that the buffer is made once
     const size_t nc = d->carry.size(), nn = j.bytes.size(), n = nc + nn;
-    int rc = hipSetDevice(d->device) == hipSuccess ? d->d_in.ensure(std::max(n, d->chunk + ((size_t)4 << 20)) + 64) : BZ_E_UNEXPECTED;
+    int rc = hipSetDevice(d->device) == hipSuccess ? ln.d_in.ensure(std::max(n, d->chunk + ((size_t)4 << 20)) + 64) : BZ_E_UNEXPECTED;
     // (the 64 bytes behind the input are read as zeros by the bit readers)
-    if (rc == BZ_OK && hipMemsetAsync(static_cast<u8 *>(d->d_in.p) + n, 0, 64, d->g->st) != hipSuccess) rc = BZ_E_UNEXPECTED;
-    if (rc == BZ_OK && nc && hipMemcpyAsync(d->d_in.p, d->carry.data(), nc, hipMemcpyHostToDevice, d->g->st) != hipSuccess) rc = BZ_E_UNEXPECTED;
-    if (rc == BZ_OK && nn && hipMemcpyAsync(static_cast<u8 *>(d->d_in.p) + nc, j.bytes.data(), nn, hipMemcpyHostToDevice, d->g->st) != hipSuccess)
+    if (rc == BZ_OK && hipMemsetAsync(static_cast<u8 *>(ln.d_in.p) + n, 0, 64, ln.g->st) != hipSuccess) rc = BZ_E_UNEXPECTED;
+    if (rc == BZ_OK && nc && hipMemcpyAsync(ln.d_in.p, d->carry.data(), nc, hipMemcpyHostToDevice, ln.g->st) != hipSuccess) rc = BZ_E_UNEXPECTED;
+    if (rc == BZ_OK && nn && hipMemcpyAsync(static_cast<u8 *>(ln.d_in.p) + nc, j.bytes.data(), nn, hipMemcpyHostToDevice, ln.g->st) != hipSuccess)
         rc = BZ_E_UNEXPECTED;
-    if (rc == BZ_OK && hipStreamSynchronize(d->g->st) != hipSuccess) rc = BZ_E_UNEXPECTED;
+    if (rc == BZ_OK && hipStreamSynchronize(ln.g->st) != hipSuccess) rc = BZ_E_UNEXPECTED;
     const double t1 = dec_now_ms();
     int verdict = BZ_OK;
     size_t produced = 0;
+    bool stopped = false, aborted = false;
+    double t_chain = 0, t_out = 0;
     if (rc == BZ_OK) {
-        if (!d->g->dec) d->g->dec = new DecWorkspace();
+        if (!ln.g->dec) ln.g->dec = new DecWorkspace();
         Sink sink;
         // a buffer of its own for every sub-batch, queued at once (the order of the queue is the order of the file) and
         // handed to the reader when its bytes have landed
@@ -1246,52 +1395,80 @@ static void dec_process(bz_dec *d, DecJob &j)
             }
             d->cv.notify_all();
         };
-        sink.staging[0] = &d->g->dec->staging;
-        sink.staging[1] = &d->g->dec->staging2;
+        // the chain is walked: the state and the bytes the next chunk starts from, and the chain goes to the other lane
+        sink.chain_final = [&](const Resume &fin) {
+            stopped = fin.stopped;
+            if (fin.stopped) { // keep the input from the undecided record on
+                const size_t used = (size_t)(fin.pos >> 3);
+                std::vector<u8> keep;
+                if (used < nc) {
+                    keep.assign(d->carry.begin() + (ptrdiff_t)used, d->carry.end());
+                    keep.insert(keep.end(), j.bytes.data(), j.bytes.data() + nn);
+                } else {
+                    keep.assign(j.bytes.data() + (used - nc), j.bytes.data() + nn);
+                }
+                d->carry.swap(keep);
+            } else {
+                d->carry.clear();
+            }
+            d->rs = fin;
+            d->rs.pos &= 7u;
+            t_chain = dec_now_ms();
+            pass_chain();
+        };
+        sink.before_output = [&]() -> bool {
+            const bool go = wait_out_turn();
+            t_out = dec_now_ms();
+            return go;
+        };
+        sink.staging[0] = &ln.g->dec->staging;
+        sink.staging[1] = &ln.g->dec->staging2;
         sink.pool = d->pool;
-        d->rs.final = j.final;
-        rc = decode_core(d->g, d->d_in.as<u8>(), n, sink, &verdict, nullptr, &d->rs);
+        Resume rs = d->rs; // (a copy: d->rs is the next chunk's from chain_final on)
+        rs.final = j.final;
+        rc = decode_core(ln.g, ln.d_in.as<u8>(), n, sink, &verdict, nullptr, &rs);
         produced = (size_t)sink.produced;
+        aborted = sink.aborted;
+        if (chain_mine) stopped = rs.stopped; // (left before the chain's end: an error of the library's own)
     }
+    pass_chain();
     if (dec_trace())
-        fprintf(stderr, "bz_dec chunk: %zu + %zu compressed bytes (final %d): upload %.2f ms, decode %.2f ms -> %zu bytes, rc %d verdict %d (at %.1f)\n",
-                nc, nn, (int)j.final, t1 - t0, dec_now_ms() - t1, produced, rc, verdict, dec_now_ms());
+        fprintf(stderr, "bz_dec chunk %llu: %zu + %zu compressed bytes (final %d): upload %.2f ms, chain known after %.2f, waited for its turn %.2f, decode %.2f ms -> %zu bytes, rc %d verdict %d%s (at %.1f)\n",
+                (unsigned long long)no, nc, nn, (int)j.final, t1 - t0, t_chain ? t_chain - t1 : 0.0, t_out && t_chain ? t_out - t_chain : 0.0, dec_now_ms() - t1,
+                produced, rc, verdict, aborted ? " GIVEN UP" : "", dec_now_ms());
+    if (aborted) return;
     // (the bytes in front of an error have been handed over too, as the reference's iterator yields them)
-    if (rc != BZ_OK || verdict != BZ_OK) return finish(rc != BZ_OK ? rc : verdict);
-    if (d->rs.stopped) { // keep the input from the undecided record on
-        const size_t used = (size_t)(d->rs.pos >> 3);
-        std::vector<u8> keep;
-        if (used < nc) {
-            keep.assign(d->carry.begin() + (ptrdiff_t)used, d->carry.end());
-            keep.insert(keep.end(), j.bytes.begin(), j.bytes.end());
-        } else {
-            keep.assign(j.bytes.begin() + (ptrdiff_t)(used - nc), j.bytes.end());
-        }
-        d->carry.swap(keep);
-        d->rs.pos &= 7u;
+    if (rc != BZ_OK || verdict != BZ_OK) {
+        if (wait_out_turn()) finish(rc != BZ_OK ? rc : verdict); // (an error in front of the first block: its turn has not been waited for yet)
         return;
     }
-    d->carry.clear();
-    finish(BZ_OK); // the file ended cleanly
+    if (!stopped) finish(BZ_OK); // the file ended cleanly
 }
 
-static void dec_worker(bz_dec *d)
+static void dec_worker(bz_dec *d, int li)
 {
+    bz_dec::Lane &ln = d->lane[li];
     for (;;) {
         DecJob j;
         bool skip;
+        u64 no;
         {
             std::unique_lock<std::mutex> lk(d->mu);
-            d->cv.wait(lk, [&] { return d->stop || !d->jobs.empty(); });
-            if (d->jobs.empty()) return;
+            d->cv.wait(lk, [&] { return d->stop || (!d->jobs.empty() && d->chain_turn == d->taken); });
+            if (d->jobs.empty() || d->chain_turn != d->taken) return; // (stop)
             j = std::move(d->jobs.front());
             d->jobs.pop_front();
+            no = d->taken++;
             skip = d->done; // (an error is waiting behind the queued bytes; further input is ignored)
         }
         d->cv.notify_all(); // (a writer may be waiting for room in the queue)
-        if (!skip) dec_process(d, j);
+        if (!skip) dec_process(d, ln, j, no);
         {
-            std::lock_guard<std::mutex> lk(d->mu);
+            std::unique_lock<std::mutex> lk(d->mu);
+            if (d->chain_turn == no) d->chain_turn = no + 1; // (a skipped chunk)
+            d->cv.notify_all();
+            d->cv.wait(lk, [&] { return d->out_turn == no || d->stop; }); // chunks are done in their order
+            if (d->out_turn == no) d->out_turn = no + 1;
             d->processed += 1;
             if (j.bytes.capacity() >= ((size_t)4 << 20) && d->spare_bytes.size() < 4) { // (kept for the writer, see spare_segs)
                 j.bytes.clear();
@@ -1321,6 +1498,8 @@ extern "C" int bz_dec_create(bz_dec **out, int device)
     }
     static const bool overlap = !(getenv("BZ_DEC_OVERLAP") && atoi(getenv("BZ_DEC_OVERLAP")) == 0);
     if (overlap) d->pool = new CopyPool(device);
+    if (const char *e = getenv("BZ_DEC_LANES")) d->n_lanes = atoi(e) == 1 ? 1 : 2;
+    if (!overlap) d->n_lanes = 1;
     *out = d;
     return BZ_OK;
 }
@@ -1339,7 +1518,8 @@ static void dec_submit(bz_dec *d, bool final)
     u64 ticket;
     {
         std::unique_lock<std::mutex> lk(d->mu);
-        if (!d->worker.joinable()) d->worker = std::thread(dec_worker, d);
+        for (int i = 0; i < d->n_lanes; ++i)
+            if (!d->lane[i].th.joinable() && (i == 0 || d->chunks_sent > 1)) d->lane[i].th = std::thread(dec_worker, d, i); // (the second lane with the second chunk)
         d->cv.wait(lk, [&] { return d->jobs.size() < 2; }); // (two chunks wait at most: memory is bounded by the chunk)
         d->jobs.push_back(std::move(j));
         ticket = ++d->submitted;
@@ -1374,14 +1554,22 @@ extern "C" int bz_dec_write(bz_dec *d, const uint8_t *data, size_t n)
         const size_t room = d->in.size() < gran ? gran - d->in.size() : 0;
         const size_t k = room ? std::min(n, room) : n;
         if (d->in.empty() && d->in.capacity() < gran && gran >= ((size_t)4 << 20)) { // (a buffer an earlier chunk went up from, if one has come back)
-            std::lock_guard<std::mutex> lk(d->mu);
-            if (!d->spare_bytes.empty()) {
-                d->in.swap(d->spare_bytes.back());
-                d->spare_bytes.pop_back();
+            {
+                std::lock_guard<std::mutex> lk(d->mu);
+                if (!d->spare_bytes.empty()) {
+                    d->in.swap(d->spare_bytes.back());
+                    d->spare_bytes.pop_back();
+                }
             }
+            if (d->in.capacity() < gran) dec_spare_buf_take(d->in, gran); // (or one an earlier context left behind)
         }
-        if (d->in.size() + k > d->in.capacity()) d->in.reserve(std::max(d->in.size() + k, std::min(gran, std::max((size_t)65536, 2 * d->in.capacity()))));
-        d->in.insert(d->in.end(), data, data + k);
+        // room for the whole chunk as soon as the file is not a tiny one (untouched pages cost nothing)
+        if (d->in.size() + k > d->in.capacity()) {
+            const size_t need = d->in.size() + k;
+            const size_t want = need >= ((size_t)1 << 20) ? std::max(need, gran) : std::max(need, std::max((size_t)65536, 2 * d->in.capacity()));
+            if (!d->in.reserve(want)) return BZ_E_NOMEM;
+        }
+        (void)d->in.append(data, k);
         data += k;
         n -= k;
         if (d->in.size() >= chunk && (d->in.size() >= gran || n == 0)) dec_submit(d, false);
@@ -1452,17 +1640,22 @@ extern "C" void bz_dec_destroy(bz_dec *d)
         d->jobs.clear(); // (chunks that wait are dropped; the one being decoded is finished)
     }
     d->cv.notify_all();
-    if (d->worker.joinable()) d->worker.join();
+    for (auto &ln : d->lane)
+        if (ln.th.joinable()) ln.th.join();
+    for (ByteBuf &b : d->spare_bytes) dec_spare_buf_put(b);
+    dec_spare_buf_put(d->in);
     delete d->pool;
     for (DecSeg *sg : d->outq) delete sg;
     for (DecSeg *sg : d->spare_segs) delete sg;
-    if (d->g) (void)hipSetDevice(d->device);
-    d->d_in.release();
-    if (d->g) { // (kept for the next context or one-shot call unless the context met an infrastructure error)
+    for (auto &ln : d->lane) {
+        if (!ln.g) continue;
+        (void)hipSetDevice(d->device);
+        ln.d_in.release();
+        // (kept for the next context or one-shot call unless the context met an infrastructure error)
         const bool data_verdict = d->verdict == BZ_OK || d->verdict == BZ_E_DATA || d->verdict == BZ_E_MAGIC_FIRST || d->verdict == BZ_E_MAGIC ||
                                   d->verdict == BZ_E_EOF;
-        if (data_verdict) dec_cache_put(d->device, d->g);
-        else bz_gpu_engine_destroy(d->g);
+        if (data_verdict) dec_cache_put(d->device, ln.g);
+        else bz_gpu_engine_destroy(ln.g);
     }
     if (caller_device >= 0) (void)hipSetDevice(caller_device);
     delete d;
