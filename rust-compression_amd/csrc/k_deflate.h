@@ -56,6 +56,17 @@ struct DfBlock {
     u64 bit_off;   // where it starts in the stream
 };
 
+// what a part of a long stream tells the host when its kernels are over (k_df_part_keep, k_df_part_tail)
+struct DfPartRes {
+    u64 consumed;    // where the next part starts
+    u64 last_bstart; // start of the last block written
+    u32 skip, err, nb_all, end_byte;
+    u32 st[5];       // blocks stored / fixed / dynamic, limited tables, dynamic blocks without distances
+    u32 pad[3];
+};
+int df_launch_part_keep(hipStream_t st, const u64 *bstart, u32 *nb, u32 bcap, const u32 *code, u64 n, u64 guard, DfPartRes *res);
+int df_launch_part_tail(hipStream_t st, const DfBlock *blocks, const u64 *bstart, const u32 *nb, const u64 *total_bits, const u8 *stream, DfPartRes *res);
+
 u32 df_chunks(u64 n); // sort chunks of an input of n bytes
 int df_launch_chains(hipStream_t st, const u8 *in, u64 n, u32 *v0, u32 *s, u16 *hs, u32 *hist, u32 *tbase, u32 *pe);
 int df_launch_match(hipStream_t st, const u8 *in, const u32 *pe, u64 n, u32 *M);

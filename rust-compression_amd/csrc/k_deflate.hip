@@ -2006,4 +2006,86 @@ int df_launch_sums(hipStream_t st, const u8 *in, u64 n, u64 *asum, u64 *bsum, u3
     return 0;
 }
 
+// ---- what the host used to look at between the stages of a PART of a long stream (deflate_engine.hip) ---------------------
+// A part that is not the last one keeps the blocks that START at or before n - guard and hands the next part the STEP of
+// the parse that holds the first block left out.  Rounds 1-4 read the block starts and three code words back in the middle
+// of the part's kernels (four round trips with the GPU idle; behind the copying thread of a host-buffer call each of them
+// took a fraction of a millisecond); the decision is three comparisons.
+__global__ __launch_bounds__(256) void k_df_part_keep(const u64 *__restrict__ bstart, u32 *__restrict__ nb, u32 bcap,
+                                                        const u32 *__restrict__ code, u64 n, u64 guard, DfPartRes *__restrict__ res)
+{
+    __shared__ u32 s_keep;
+    const u32 nb_all = *nb;
+    if (threadIdx.x == 0) s_keep = 0;
+    __syncthreads();
+    const bool bad = nb_all == 0xFFFFFFFFu || nb_all > bcap || n <= guard;
+    if (!bad) {
+        u32 best = 0; // (block starts ascend: the blocks kept are a prefix)
+        for (u32 k = threadIdx.x; k < nb_all; k += blockDim.x)
+            if (bstart[k] + guard <= n) best = k + 1u;
+        if (best) atomicMax(&s_keep, best);
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const u32 keep = s_keep;
+    u32 err = bad ? 1u : 0u;
+    if (!err && (keep == 0u || keep >= nb_all)) err = 2u; // (a part is much longer than the guard)
+    u64 bcut = 0;
+    u32 skip = 0;
+    if (!err) {
+        bcut = bstart[keep];
+        if (bcut < 2) err = 3u;
+    }
+    if (!err) { // the step of the parse that emitted the code at bcut: at most two literals in front of it
+        const u32 c0 = code[bcut - 2], c1 = code[bcut - 1], c2 = code[bcut];
+        skip = (c2 & F_STEP) ? 0u : ((c1 & F_STEP) ? 1u : 2u);
+        const u32 cs = skip == 0u ? c2 : (skip == 1u ? c1 : c0);
+        if (!(cs & F_STEP) || !(c2 & F_CODE)) err = 4u;
+    }
+    res->nb_all = nb_all;
+    res->err = err;
+    res->skip = skip;
+    res->consumed = bcut - skip;
+    *nb = err ? 0u : keep; // (an error: the kernels behind this one find nothing to do, the host reports it)
+}
+
+// behind the emission: the partly filled byte a part hands on, where the last block starts, what kinds of blocks there were
+__global__ __launch_bounds__(256) void k_df_part_tail(const DfBlock *__restrict__ blocks, const u64 *__restrict__ bstart, const u32 *__restrict__ nb,
+                                                        const u64 *__restrict__ total_bits, const u8 *__restrict__ stream, DfPartRes *__restrict__ res)
+{
+    __shared__ u32 s_st[6];
+    if (threadIdx.x < 6) s_st[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 n = *nb;
+    if (n != 0xFFFFFFFFu) {
+        u32 c[6] = {0, 0, 0, 0, 0, 0};
+        for (u32 k = threadIdx.x; k < n; k += blockDim.x) {
+            const DfBlock b = blocks[k];
+            c[b.btype < 3u ? b.btype : 0u] += 1u;
+            c[3] += b.lm & 0xFFu;
+            c[4] += (b.lm >> 8) & 1u;
+        }
+#pragma unroll
+        for (u32 i = 0; i < 5; ++i)
+            if (c[i]) atomicAdd(&s_st[i], c[i]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) res->st[threadIdx.x] = s_st[threadIdx.x];
+    if (threadIdx.x == 0) {
+        res->last_bstart = (n && n != 0xFFFFFFFFu) ? bstart[n - 1u] : 0ull;
+        res->end_byte = stream[*total_bits >> 3];
+    }
+}
+
+int df_launch_part_keep(hipStream_t st, const u64 *bstart, u32 *nb, u32 bcap, const u32 *code, u64 n, u64 guard, DfPartRes *res)
+{
+    hipLaunchKernelGGL(k_df_part_keep, dim3(1), dim3(256), 0, st, bstart, nb, bcap, code, n, guard, res);
+    return 0;
+}
+int df_launch_part_tail(hipStream_t st, const DfBlock *blocks, const u64 *bstart, const u32 *nb, const u64 *total_bits, const u8 *stream, DfPartRes *res)
+{
+    hipLaunchKernelGGL(k_df_part_tail, dim3(1), dim3(256), 0, st, blocks, bstart, nb, total_bits, stream, res);
+    return 0;
+}
+
 } // namespace dfgpu

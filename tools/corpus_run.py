@@ -10,7 +10,8 @@ pkg = importlib.import_module("rust-compression_amd")
 name = sys.argv[1]
 mib = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-h = corpus.matrix_corpus(name, 256 << 20)[:mib << 20] if name in corpus.MATRIX else None
+import numpy as np
+h = corpus.matrix_corpus(name, 256 << 20)[:mib << 20] if name in corpus.MATRIX else (np.frombuffer(corpus.stress_t2(mib << 20), dtype=np.uint8).copy() if name == "t2" else None)
 t = torch.from_numpy(h).cuda() if h is not None else corpus.corpus_on_device(mib << 20, torch.device("cuda", 0))
 n = t.numel()
 eng = pkg.GpuEngine(0, 400)
@@ -25,3 +26,11 @@ torch.cuda.synchronize()
 dt = (time.time() - t0) / steps
 print("%s %d MiB: %.2f ms = %.0f MB/s, %d rounds, stages %s" % (name, mib, dt * 1e3, n / dt / 1e6, eng.bwt_stats()["rounds"],
                                                                {a: round(b * 1e3, 2) for a, b in eng.timings().items()}))
+if os.environ.get("KPROF"):
+    eng.profile(True)
+    eng.encode_device(9, t.data_ptr(), n, o.data_ptr(), cap)
+    torch.cuda.synchronize()
+    kp = eng.kernel_profile()
+    for k, v in sorted(kp.items(), key=lambda kv: -kv[1]["seconds"])[:25]:
+        print("  %-28s %5d launches %8.3f ms" % (k, v["launches"], v["seconds"] * 1e3))
+    print("  unordered after round:", eng.bwt_stats()["unordered_after_round"])
