@@ -120,3 +120,73 @@ def test_streaming_decoder_reads_behind_the_end_wait_for_the_worker(pkg, oracle)
         L.bz_dec_destroy(h)
         assert k == verdict and bytes(got) == want, (corrupt, k, verdict, len(got), len(want))
         assert (verdict == 0) == (not corrupt)
+
+
+def _stream_through(L, zz, piece=1 << 20, read_cap=3 << 20, read_between=True):
+    """the loop a host runs: write in pieces, read what has come between the writes, end, read to the verdict"""
+    import ctypes as C
+    h = C.c_void_p()
+    assert L.bz_dec_create(C.byref(h), 0) == 0
+    buf = (C.c_uint8 * read_cap)()
+    got = bytearray()
+    zb = bytes(zz)
+    for i in range(0, len(zb), piece):
+        assert L.bz_dec_write(h, zb[i:i + piece], len(zb[i:i + piece])) == 0
+        while read_between:
+            k = L.bz_dec_read(h, buf, len(buf))
+            if k <= 0:
+                break
+            got += bytes(buf[:k])
+    L.bz_dec_end(h)
+    while True:
+        k = L.bz_dec_read(h, buf, len(buf))
+        if k <= 0:
+            break
+        got += bytes(buf[:k])
+    L.bz_dec_destroy(h)
+    return bytes(got), k
+
+
+def test_streaming_decoder_two_lanes(pkg, oracle, monkeypatch):
+    """Round 5: chunks of 4 MiB and more go to the context's two lanes -- the next chunk's scan and Huffman stage run
+    beside the rebuilding of this chunk's blocks, a lane whose chunk in front ends with an error gives up before it hands
+    out a byte.  Several chunks per stream here (BZ_DEC_CHUNK = 4 MiB): a clean stream, two streams in one file with the
+    seam inside a chunk, a block corrupted in the second chunk (the third is in flight on the other lane by then), a
+    stream cut off in mid-block, a context destroyed with chunks still in flight: the bytes and the verdict of the oracle's
+    decoder every time (/root/reference/src/bzip2/decoder.rs:583-612: bytes in front of an error, then the error)."""
+    import ctypes as C
+    monkeypatch.setenv("BZ_DEC_CHUNK", str(4 << 20))
+    monkeypatch.setenv("BZ_DEC_FIRST_CHUNK", str(4 << 20))
+    data = _text(80_000_000, 21)
+    z = pkg.compress(data, 9)
+    assert len(z) > (14 << 20)  # four chunks at least
+    L = pkg.lib()
+    # clean, with and without reads between the writes; one lane gives the same
+    for between in (True, False):
+        got, verdict = _stream_through(L, z, read_between=between)
+        assert verdict == 0 and got == data
+    monkeypatch.setenv("BZ_DEC_LANES", "1")
+    got, verdict = _stream_through(L, z)
+    assert verdict == 0 and got == data
+    monkeypatch.delenv("BZ_DEC_LANES")
+    # two streams, the seam somewhere inside the third chunk
+    cut = 40_500_123
+    zz = pkg.compress(data[:cut], 9) + pkg.compress(data[cut:], 5)
+    got, verdict = _stream_through(L, zz)
+    assert verdict == 0 and got == data
+    # a block of the second chunk corrupted / the stream cut off inside the third chunk / junk behind the stream
+    for name, bad in (("flip", bytes(z[:6 << 20]) + bytes([z[6 << 20] ^ 0x41]) + bytes(z[(6 << 20) + 1:])),
+                      ("cut", bytes(z[:(9 << 20) + 12345])),
+                      ("junk", bytes(z) + b"\x00" * 5)):
+        want, st = oracle.decode(bad)
+        assert st != 0, name
+        for between in (True, False):
+            got, verdict = _stream_through(L, bad, read_between=between)
+            assert verdict == st and got == want, (name, between, verdict, st, len(got), len(want))
+    # a context that is dropped while its chunks are in flight (nothing read): no hang, the next context is fine
+    h = C.c_void_p()
+    assert L.bz_dec_create(C.byref(h), 0) == 0
+    assert L.bz_dec_write(h, bytes(z), len(z)) == 0
+    L.bz_dec_destroy(h)
+    got, verdict = _stream_through(L, z[:5 << 20] + z[5 << 20:])
+    assert verdict == 0 and got == data
