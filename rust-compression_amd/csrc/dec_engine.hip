@@ -1047,16 +1047,27 @@ std::mutex g_dec_cache_mu;
 std::vector<std::pair<int, bz_gpu_engine *>> g_dec_cache;
 } // namespace
 static void dec_spare_bufs_clear();
-bz_gpu_engine *dec_cache_take(int device)
+// prefer: 1 = an engine that has decoded before (it holds the decode workspace), 2 = one that has a Deflate workspace;
+// otherwise the engine that was put back last (two engines are kept since the streaming decoder has two lanes: taking the
+// OLDEST one made consecutive one-shot calls alternate between them, each paying for a workspace of its own)
+bz_gpu_engine *dec_cache_take(int device, int prefer)
 {
     std::lock_guard<std::mutex> lk(g_dec_cache_mu);
-    for (size_t i = 0; i < g_dec_cache.size(); ++i)
-        if (g_dec_cache[i].first == device) {
-            bz_gpu_engine *g = g_dec_cache[i].second;
-            g_dec_cache.erase(g_dec_cache.begin() + (ptrdiff_t)i);
-            return g;
+    size_t pick = ~(size_t)0;
+    for (size_t i = g_dec_cache.size(); i-- > 0;) {
+        if (g_dec_cache[i].first != device) continue;
+        const bz_gpu_engine *c = g_dec_cache[i].second;
+        const bool match = prefer == 1 ? c->dec != nullptr : (prefer == 2 ? c->df != nullptr : true);
+        if (pick == ~(size_t)0) pick = i; // (the newest one of the device)
+        if (match) {
+            pick = i;
+            break;
         }
-    return nullptr;
+    }
+    if (pick == ~(size_t)0) return nullptr;
+    bz_gpu_engine *g = g_dec_cache[pick].second;
+    g_dec_cache.erase(g_dec_cache.begin() + (ptrdiff_t)pick);
+    return g;
 }
 void dec_cache_put(int device, bz_gpu_engine *g)
 {
@@ -1093,7 +1104,7 @@ extern "C" int bz_decode_buffer(int device, const uint8_t *in, size_t in_len, ui
     const double t_enter = dec_now_ms();
     int caller_device = -1;
     (void)hipGetDevice(&caller_device); // (put back on return: ADVICE r3, the same rule as the encoder's entry points)
-    bz_gpu_engine *g = dec_cache_take(device);
+    bz_gpu_engine *g = dec_cache_take(device, 1);
     int rc = g ? BZ_OK : bz_gpu_engine_create(&g, device, 0);
     if (rc != BZ_OK) return rc;
     HostBuf host;
@@ -1316,7 +1327,7 @@ static void dec_process(bz_dec *d, bz_dec::Lane &ln, DecJob &j, u64 no)
         return d->out_turn == no && !d->done;
     };
     if (!ln.g) { // (an engine kept by an earlier one-shot call or context, with its workspace, or a new one)
-        ln.g = dec_cache_take(d->device);
+        ln.g = dec_cache_take(d->device, 1);
         const int rc = ln.g ? BZ_OK : bz_gpu_engine_create(&ln.g, d->device, 0);
         if (rc != BZ_OK) {
             pass_chain();

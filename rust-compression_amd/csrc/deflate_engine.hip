@@ -625,7 +625,7 @@ extern "C" int df_encode_buffer_dict(int kind, int device, const uint8_t *in, si
     int caller_device = -1;
     (void)hipGetDevice(&caller_device);
     if (getenv("BZ_DF_TRACE")) fprintf(stderr, "bz2_mi355x: df_encode_buffer entered at %.1f\n", df_now_ms());
-    bz_gpu_engine *g = dec_cache_take(device);
+    bz_gpu_engine *g = dec_cache_take(device, 2);
     int rc = g ? BZ_OK : bz_gpu_engine_create(&g, device, 1);
     if (rc != BZ_OK) return rc;
     const size_t cap = df_encode_bound(in_len) + 8;
@@ -821,7 +821,7 @@ static int df_enc_end_impl(df_enc *e, int action)
     const bool ends_container = e->kind != 0;
     int rc;
     if (!e->g) {
-        e->g = dec_cache_take(e->device);
+        e->g = dec_cache_take(e->device, 2);
         if (!e->g && (rc = bz_gpu_engine_create(&e->g, e->device, 0)) != BZ_OK) return rc;
     }
     HIPCHK(hipSetDevice(e->device));

@@ -17,7 +17,7 @@ int dec_decode_for_verify(struct bz_gpu_engine *g, const uint8_t *d_in, uint64_t
                           uint64_t *produced, int *verdict);
 // the engines the one-shot calls over host buffers keep between calls (bz_decode_buffer, df_encode_buffer; one per
 // device; bz_release_cached_resources frees them)
-struct bz_gpu_engine *dec_cache_take(int device);
+struct bz_gpu_engine *dec_cache_take(int device, int prefer = 0);
 void dec_cache_put(int device, struct bz_gpu_engine *g);
 void dec_release_cached();
 struct DfWorkspace;
