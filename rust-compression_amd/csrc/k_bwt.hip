@@ -2109,7 +2109,7 @@ __global__ __launch_bounds__(kSortThreads) void k_rank_place(BwtArgs a, const u3
 // mate / midx != nullptr (the period round and the pair round): every group of exactly TWO survivors -- a new-group start, no
 // start behind it, a start behind that: read off the bitmap the compaction reads anyway -- leaves mate[smaller start] = larger
 // start and midx[smaller start] = its place in the compacted list | (the smaller start stands first) << 31 for k_pair_scan
-// (round 5: k_pair_list found the same pairs with four random gathers of the rank array per list entry, 13 ms per GiB).
+// (a kernel of its own found the same pairs with four random gathers of the rank array per list entry: 13 ms per GiB).
 __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, const u32 *__restrict__ V,
                                                                     u32 *__restrict__ VS, u32 *__restrict__ mate = nullptr,
                                                                     u32 *__restrict__ midx = nullptr)
@@ -2611,36 +2611,14 @@ __global__ __launch_bounds__(kSortThreads) void k_pair_compare(BwtArgs a, u32 st
 // difference: pairs (x, x + d) and (x + 1, x + 1 + d) agree up to the SAME position m -- the first m at or behind the later
 // start + depth with T[m] != T[m + d] -- whatever d is and however many distances a block has (copies that DRIFT: every
 // changed byte that RLE1 turns into a shift starts a new d).  So:
-//   k_pair_list  every group of exactly two members of the survivor list (found as k_pair_compare finds them) leaves
-//                mate[lo] = hi and the place of the pair in the list, indexed by its smaller START;
+//   k_survivor_compact  every group of exactly two members of the survivor list (it sees the groups' starts in the bitmap it
+//                compacts by) leaves mate[lo] = hi and the place of the pair in the list, indexed by its smaller START;
 //   k_pair_scan  walks the block in TEXT order, a wave per 64 consecutive starts: the lanes whose pairs lie the same distance
 //                apart are resolved together -- the wave compares 512 bytes of T and of T shifted by d per step, eight per
 //                lane, until a difference turns up, and every pair whose known-equal prefix ends in front of it takes it
 //                (the pairs behind it go on from there).  One verdict byte per list position, as k_pair_compare writes them.
 // The comparison is the definition of the order (sais.rs:266-272 fixes nothing else); 14 K waves per block read ~2 KB each.
 constexpr u32 kPairNone = 0xFFFFFFFFu;
-__global__ __launch_bounds__(kSortThreads) void k_pair_list(BwtArgs a, const u32 *__restrict__ V, u32 *__restrict__ mate, u32 *__restrict__ midx)
-{
-    u32 tile, lb;
-    xcd_remap(gridDim.x, a.nb, tile, lb);
-    if (lb == 0xFFFFFFFFu) return;
-    const u32 n = a.blocks[lb].n;
-    const u32 cnt = a.count[lb];
-    const u32 start = tile * kSortTile;
-    if (start >= cnt || n < 64u || (u64)cnt * 4u < (u64)n * 3u) return; // (only blocks that are deep in repeats)
-    const size_t base = (size_t)lb * kSlot;
-    for (u32 idx = start + threadIdx.x; idx + 1u < cnt && idx < start + kSortTile; idx += kSortThreads) {
-        const u32 va = V[base + idx] & 0xFFFFFu, vb = V[base + idx + 1u] & 0xFFFFFu;
-        const u32 g = a.R[base + va] & ~kFinalBit;
-        if ((a.R[base + vb] & ~kFinalBit) != g) continue;
-        if (idx > 0 && (a.R[base + (V[base + idx - 1u] & 0xFFFFFu)] & ~kFinalBit) == g) continue;   // not the group's first
-        if (idx + 2u < cnt && (a.R[base + (V[base + idx + 2u] & 0xFFFFFu)] & ~kFinalBit) == g) continue; // three or more
-        const u32 lo = va < vb ? va : vb, hi = va < vb ? vb : va;
-        mate[base + lo] = hi;
-        midx[base + lo] = idx | (va == lo ? 0x80000000u : 0u); // (bit 31: the smaller start stands first in the list)
-    }
-}
-
 __device__ __forceinline__ u64 pair_load8(const u8 *__restrict__ text, u32 n, u32 p) // eight bytes from p on, cyclic (p < n)
 {
     u64 v;
