@@ -12,10 +12,10 @@ wgs = sys.argv[3].split(",") if len(sys.argv) > 3 else ["256"]
 dev = torch.device("cuda", 0)
 d_in = corpus.corpus_on_device(mib << 20, dev)
 n = d_in.numel()
-eng = pkg.GpuEngine(0, min(n // 800000 + 8, 1400))
+eng = pkg.GpuEngine(0, min(n // (90000 * int(os.environ.get('BZ_LEVEL', '9'))) + 64, 12000))
 cap = (pkg.encode_bound(n) + 15) & ~15
 d_z = torch.empty(cap, dtype=torch.uint8, device=dev)
-zn = eng.encode_device(9, d_in.data_ptr(), n, d_z.data_ptr(), cap)
+zn = eng.encode_device(int(os.environ.get('BZ_LEVEL', '9')), d_in.data_ptr(), n, d_z.data_ptr(), cap)
 d_out = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
 for v in wgs:
     os.environ["BZ_DEC_WALK_WGS"] = v
