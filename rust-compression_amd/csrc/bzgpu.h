@@ -376,6 +376,7 @@ struct BwtArgs {
     u32 *gh_tiles;                   // [nb][kTilesPerBlock][3][kMaxBins] per-tile digit counts of a whole phase
     u32 *gbase;                      // [nb][3][kMaxBins] digits smaller, per digit position
     u32 *tile_state;                 // [nb][kTilesPerBlock][kMaxBins] look-back words: epoch | flag | value
+    u32 *tile_state2;                // [nb][2 kTilesPerBlock][kMaxBins] the same for passes over half tiles (BZ_LB_SMALL_TILE), or nullptr
     u32 *tickets;                    // [kSortEpochs][8] tile tickets per pass and XCD
     u32 *sort_err;                   // [1] a look-back that gave up
     u32 *epoch;                      // host: the engine's pass counter (1 .. kSortEpochs-1)

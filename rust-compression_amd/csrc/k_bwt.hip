@@ -35,6 +35,7 @@
 //
 // Integer path: no MFMA.  Bound: HBM (streamed u32 arrays) + L2 gathers.
 #include "bzgpu.h"
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -720,8 +721,15 @@ __global__ __launch_bounds__(kSortThreads) void k_ghist_scan(BwtArgs a, u32 ndig
 #else
 #define SC_T(k) do { } while (0)
 #endif
-template <int SRC, int BITS, bool WRITE_K = true, bool PACK_OUT = false, int ROWS = (BITS > 10 ? 16 : BZ_SCATTER_ROWS)>
-__global__ __launch_bounds__(kSortTile / ROWS BZ_SCATTER_WAVES_ARG) void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h,
+// TILE: elements per tile -- kSortTile, or (-DBZ_LB_SMALL_TILE=1, an A/B switch: VERDICT r4 item 1 (a), "256 threads x 16 rows")
+// half of it for the streamed sources with 10-bit digits: four waves per workgroup behind each barrier instead of eight, five
+// workgroups per CU instead of two; twice the tickets and look-back words per element.  Its look-back words live in a
+// region of their own (tile_state2: twice the tiles per block).
+#ifndef BZ_LB_SMALL_TILE
+#define BZ_LB_SMALL_TILE 0
+#endif
+template <int SRC, int BITS, bool WRITE_K = true, bool PACK_OUT = false, int ROWS = (BITS > 10 ? 16 : BZ_SCATTER_ROWS), int TILE = (int)kSortTile>
+__global__ __launch_bounds__(TILE / ROWS BZ_SCATTER_WAVES_ARG) void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h,
                                                                     const u32 *__restrict__ Kin,
                                                                     const u32 *__restrict__ Vin,
                                                                     u32 *__restrict__ Kout, u32 *__restrict__ Vout,
@@ -729,10 +737,12 @@ __global__ __launch_bounds__(kSortTile / ROWS BZ_SCATTER_WAVES_ARG) void k_radix
                                                                     const u32 *__restrict__ gate)
 {
     constexpr u32 NB = 1u << BITS;
-    constexpr u32 kT = kSortTile / ROWS; // threads: 512 with 16 rows per lane, 1024 with 8
+    constexpr u32 kT = (u32)TILE / ROWS; // threads: 512 with 16 rows per lane, 1024 with 8 (256 for a half tile)
+    constexpr u32 kTileStride = kTilesPerBlock * (kSortTile / (u32)TILE); // tiles per block in the look-back words' array
+    u32 *const tstate = ((u32)TILE == kSortTile) ? a.tile_state : a.tile_state2;
     constexpr u32 kRows = ROWS;
     constexpr u32 NW = kT / 64;
-    __shared__ u32 s_buf[kSortTile];
+    __shared__ u32 s_buf[TILE];
     __shared__ u32 s_base[NB];
     __shared__ u16 s_tpre[NB]; // (only between the scan over the digits and the look-back: see s_base below)
     __shared__ u32 s_wsum[NW];
@@ -776,7 +786,7 @@ __global__ __launch_bounds__(kSortTile / ROWS BZ_SCATTER_WAVES_ARG) void k_radix
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
     const u32 cnt = src_is_list<SRC>::value ? a.count[lb] : n;
-    const u32 start = tile * kSortTile;
+    const u32 start = tile * (u32)TILE;
     if (start >= cnt) return;
     const u8 *text = a.rle + d.rle_off;
     const u8 *pt = a.ptext + (size_t)lb * kSlot;
@@ -889,7 +899,7 @@ __global__ __launch_bounds__(kSortTile / ROWS BZ_SCATTER_WAVES_ARG) void k_radix
     // were out: consecutive tickets start together, so a tile's predecessor publishes when the tile does, and four of
     // the eight waves waited at the barrier behind the walk.  The staging in between is work the tile has to do anyway.
     const u32 lb_d0 = threadIdx.x * 4u;
-    u32 *lb_mystate = a.tile_state + ((size_t)lb * kTilesPerBlock + tile) * kMaxBins + lb_d0;
+    u32 *lb_mystate = tstate + ((size_t)lb * kTileStride + tile) * kMaxBins + lb_d0;
     const u32 etag = epoch << 22;
     u32 t4[4] = {0, 0, 0, 0};
     if (threadIdx.x < NB / 4u) {
@@ -920,19 +930,19 @@ __global__ __launch_bounds__(kSortTile / ROWS BZ_SCATTER_WAVES_ARG) void k_radix
 #pragma unroll
                     for (u32 j = 0; j < (u32)BZ_LB_WINDOW; ++j) { // (beyond the block's first tile: the first tile's words again -- no branch between the loads)
                         const u32 q = j < win ? p - 1u - j : 0u;
-                        ld_sc1_x4_issue(a.tile_state + ((size_t)lb * kTilesPerBlock + q) * kMaxBins + d0, rw[j]);
+                        ld_sc1_x4_issue(tstate + ((size_t)lb * kTileStride + q) * kMaxBins + d0, rw[j]);
                     }
                     ld_x4_wait_all();
 #pragma unroll
                     for (u32 j = 0; j < (u32)BZ_LB_WINDOW; ++j) vw[j] = make_uint4(rw[j].x, rw[j].y, rw[j].z, rw[j].w);
                 }
 #else
-                vw[0] = ld_sc1_x4(a.tile_state + ((size_t)lb * kTilesPerBlock + (p - 1u)) * kMaxBins + d0);
+                vw[0] = ld_sc1_x4(tstate + ((size_t)lb * kTileStride + (p - 1u)) * kMaxBins + d0);
 #endif
 #pragma unroll
                 for (u32 j = 0; j < (u32)BZ_LB_WINDOW; ++j) {
                     if (j >= win || !open) break;
-                    const u32 *src = a.tile_state + ((size_t)lb * kTilesPerBlock + (p - 1u - j)) * kMaxBins + d0;
+                    const u32 *src = tstate + ((size_t)lb * kTileStride + (p - 1u - j)) * kMaxBins + d0;
                     uint4 v = vw[j];
 #ifdef BZ_SCATTER_TIMING
                     ++hops;
@@ -3009,6 +3019,8 @@ static u32 next_epoch(hipStream_t st, const BwtArgs &a)
     return e;
 }
 
+// (BZ_LB_SMALL_TILE) the epochs of the running sort whose launches had twice the tiles: their ticket counters end at twice the share
+static thread_local std::vector<u32> *tl_double_epochs = nullptr;
 template <int SRC, int BITS, bool WRITE_K = true, bool PACK_OUT = false>
 static void fused_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const u32 *Kin, const u32 *Vin, u32 *Kout,
                        u32 *Vout, u32 dpos, u64 elems, KernelProf *prof, u64 out_elems = ~0ull,
@@ -3019,8 +3031,17 @@ static void fused_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const
     const u32 e = next_epoch(st, a);
     if (out_elems == ~0ull) out_elems = elems;
     const int p = prof ? prof->begin(st, KID_RADIX_SCATTER_LB, elems * rd + out_elems * ((WRITE_K && !PACK_OUT) ? 8 : 4)) : -1;
-    hipLaunchKernelGGL((k_radix_scatter_lb<SRC, BITS, WRITE_K, PACK_OUT>), grid, dim3(kSortTile / (BITS > 10 ? 16 : BZ_SCATTER_ROWS)), 0, st, a, shift, h, Kin,
-                       Vin, Kout, Vout, dpos, e, gate);
+    constexpr bool small_tile = BZ_LB_SMALL_TILE != 0 && BITS == 10 && (SRC == SRC_PAIRS || SRC == SRC_PACKED);
+    if (small_tile && a.tile_state2) {
+        BwtArgs a2 = a; // (twice the tiles of half the size; the counters of this epoch end at twice the share)
+        a2.tiles = a.tiles * 2u;
+        if (tl_double_epochs) tl_double_epochs->push_back(e);
+        hipLaunchKernelGGL((k_radix_scatter_lb<SRC, BITS, WRITE_K, PACK_OUT, 16, (int)(kSortTile / 2)>), dim3(a2.tiles, xcd_grid_y(a.nb)), dim3(kSortTile / 2 / 16), 0, st,
+                           a2, shift, h, Kin, Vin, Kout, Vout, dpos, e, gate);
+    } else {
+        hipLaunchKernelGGL((k_radix_scatter_lb<SRC, BITS, WRITE_K, PACK_OUT>), grid, dim3(kSortTile / (BITS > 10 ? 16 : BZ_SCATTER_ROWS)), 0, st, a, shift, h, Kin,
+                           Vin, Kout, Vout, dpos, e, gate);
+    }
     if (prof) prof->end(st, p);
 }
 
@@ -3154,6 +3175,11 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
     // first pass is checked, and the three-kernel passes redo the sort from the block if it fails.
     bool fused = a.fused != 0;
     const u32 epoch_first = *a.epoch + 1u; // (fused) the passes of this call, for the coverage check below
+    std::vector<u32> double_epochs;
+    struct TlGuard {
+        TlGuard(std::vector<u32> *v) { tl_double_epochs = v; }
+        ~TlGuard() { tl_double_epochs = nullptr; }
+    } tl_guard(&double_epochs);
     if (fused) {
         // BZ_LOCAL_B=1: phase B of the init inside LDS (k_phase_b_local) for the blocks it can take.  Off by default:
         // measured on the 1 GiB text corpus it takes 37 ms against 15 ms for the three global passes it replaces
@@ -3260,11 +3286,14 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         // groups are still larger than two.
         const bool pair_round = want_period != 0 && !per_round && period_done && !pair_done && a.gh_tiles && a.per_pairs &&
                                 ((u64)(2u * min_chars) << step) >= 32u && m * 2 >= total_n;
+        // survivor form below this share of the rotations (BZ_SURV_SHARE=num/den, default 1/4: measured)
+        static const u64 surv_num = [] { const char *e = getenv("BZ_SURV_SHARE"); unsigned a = 1, b = 4; if (e && sscanf(e, "%u/%u", &a, &b) == 2 && a && b) return (u64)a; return (u64)1; }();
+        static const u64 surv_den = [] { const char *e = getenv("BZ_SURV_SHARE"); unsigned a = 1, b = 4; if (e && sscanf(e, "%u/%u", &a, &b) == 2 && a && b) return (u64)b; return (u64)4; }();
         static const bool bwt_trace = getenv("BZ_BWT_TRACE") != nullptr;
         if (bwt_trace)
             fprintf(stderr, "bz2_mi355x: sort round %d (h = %llu): %llu of %llu rotations unordered, at most %u in one block (of %u)%s\n",
                     rounds, (unsigned long long)(2u * min_chars) << step, (unsigned long long)m, (unsigned long long)total_n, mx,
-                    max_n, per_round ? ": period round" : (pair_round ? ": pair round" : (m * 4 < total_n ? ": survivor form" : ": walk form")));
+                    max_n, per_round ? ": period round" : (pair_round ? ": pair round" : (m * surv_den < total_n * surv_num ? ": survivor form" : ": walk form")));
         u8 *impure = a.ptext; // (the packed text is not read any more once the init is over)
         if (per_round || pair_round) {
             if (per_round) period_done = true;
@@ -3302,7 +3331,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             u32 *t = cK; cK = fK; fK = t;
             t = cV; cV = fV; fV = t;
             if (per_round) hipLaunchKernelGGL(k_period_mark, grid_list, dim3(kSortThreads), 0, st, a, step, cK, cV, impure);
-        } else if (m * 4 < total_n) {
+        } else if (m * surv_den < total_n * surv_num) {
             // few survivors: compact them (list order = sorted by group), order them by the rank
             // of rotation j+h (2 passes), then stably by their own group (2 passes): O(m) work
             hipLaunchKernelGGL(k_survivor_compact, grid_prev, dim3(kSortThreads), 0, st, a, lastV, fV);
@@ -3390,8 +3419,11 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         static const bool late_fail_test = getenv("BZ_ONESWEEP_LATEFAILTEST") != nullptr; // (tests: exercise the redo)
         bool bad = gave_up != 0 || late_fail_test;
         const u32 want = a.tiles * (xcd_grid_y(a.nb) / 8u); // (exactly: see fused_pass_ok)
-        for (size_t i = 0; i < tk.size(); ++i)
-            if (tk[i] != want) bad = true;
+        for (size_t i = 0; i < tk.size(); ++i) {
+            const u32 ep = epoch_first + (u32)(i / 8u);
+            const bool dbl = std::find(double_epochs.begin(), double_epochs.end(), ep) != double_epochs.end();
+            if (tk[i] != (dbl ? 2u * want : want)) bad = true;
+        }
         if (bad) {
             (void)hipMemsetAsync(a.sort_err, 0, 4, st);
             return -2;
