@@ -18,6 +18,9 @@ constexpr u32 kWave = 64;
 constexpr u32 kMaxBlockLen = 900000;        // 100000*level, >= n (n <= 100000*level - 19 + 4)
 constexpr u32 kSortTile = 8192;             // elements per radix tile: 8 waves x 16 rows x 64 lanes
 constexpr u32 kSortThreads = 512;
+#ifndef BZ_LB_SMALL_TILE // (an A/B build switch of the fused radix pass, k_bwt.hip; 1 = half tiles for the streamed sources)
+#define BZ_LB_SMALL_TILE 0
+#endif
 constexpr u32 kTilesPerBlock = 110;         // ceil(900000 / 8192)
 constexpr u32 kSlot = kTilesPerBlock * kSortTile; // 901120: per-block stride of the u32 work arrays
 constexpr u32 kMaxBins = 2048;              // 11-bit digits for the initial 32-bit key sort

@@ -119,7 +119,7 @@ static int ensure_workspace(bz_gpu_engine *g, size_t need_blocks)
     if (!(getenv("BZ_ONESWEEP") && atoi(getenv("BZ_ONESWEEP")) == 0)) { // buffers of the fused radix passes
         ENS(gh_tiles, nb * (size_t)kTilesPerBlock * 3 * kMaxBins * 4);
         ENS(gbase, nb * (size_t)3 * kMaxBins * 4);
-        ENS(tile_state, nb * (size_t)kTilesPerBlock * kMaxBins * 4 * 3); // (+ twice as much for passes over half tiles, tile_state2)
+        ENS(tile_state, nb * (size_t)kTilesPerBlock * kMaxBins * 4 * (BZ_LB_SMALL_TILE ? 3 : 1)); // (BZ_LB_SMALL_TILE: + twice as much for passes over half tiles, tile_state2)
         ENS(tickets, (size_t)kSortEpochs * 8 * 4 + 64);
         if (hipMemsetAsync(g->tile_state.p, 0, g->tile_state.cap, g->st) != hipSuccess ||
             hipMemsetAsync(g->tickets.p, 0, g->tickets.cap, g->st) != hipSuccess)
@@ -695,7 +695,7 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
     x.gh_tiles = g->gh_tiles.as<u32>() + t * 3 * kMaxBins;
     x.gbase = g->gbase.as<u32>() + (size_t)o * 3 * kMaxBins;
     x.tile_state = g->tile_state.as<u32>() + t * kMaxBins;
-    x.tile_state2 = g->tile_state.p ? g->tile_state.as<u32>() + ((size_t)g->ws_blocks * kTilesPerBlock + 2 * t) * kMaxBins : nullptr;
+    x.tile_state2 = (BZ_LB_SMALL_TILE && g->tile_state.p) ? g->tile_state.as<u32>() + ((size_t)g->ws_blocks * kTilesPerBlock + 2 * t) * kMaxBins : nullptr;
     x.tickets = g->tickets.as<u32>();
     x.sort_err = g->tickets.p ? g->tickets.as<u32>() + (size_t)kSortEpochs * 8 : nullptr; // (no fused passes: not allocated)
     x.epoch = &g->sort_epoch;

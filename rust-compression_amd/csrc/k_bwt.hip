@@ -725,9 +725,6 @@ __global__ __launch_bounds__(kSortThreads) void k_ghist_scan(BwtArgs a, u32 ndig
 // half of it for the streamed sources with 10-bit digits: four waves per workgroup behind each barrier instead of eight, five
 // workgroups per CU instead of two; twice the tickets and look-back words per element.  Its look-back words live in a
 // region of their own (tile_state2: twice the tiles per block).
-#ifndef BZ_LB_SMALL_TILE
-#define BZ_LB_SMALL_TILE 0
-#endif
 template <int SRC, int BITS, bool WRITE_K = true, bool PACK_OUT = false, int ROWS = (BITS > 10 ? 16 : BZ_SCATTER_ROWS), int TILE = (int)kSortTile>
 __global__ __launch_bounds__(TILE / ROWS BZ_SCATTER_WAVES_ARG) void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h,
                                                                     const u32 *__restrict__ Kin,
