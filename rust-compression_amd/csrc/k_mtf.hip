@@ -24,6 +24,20 @@ namespace bzgpu {
 constexpr u32 kChunkWGs = (kMaxMtfChunks + 255) / 256;
 #ifndef BZ_MTF_HEADS
 #define BZ_MTF_HEADS 0 // 1: k_mtf_ranks_small ranks the heads of runs only (measured slower: profiles/r04_negatives.md)
+#ifndef BZ_MTF_FENCE
+#define BZ_MTF_FENCE 0
+#endif
+#ifndef BZ_MTF_BLOCK
+#define BZ_MTF_BLOCK 32
+#endif
+#if BZ_MTF_FENCE
+#define BZ_MTF_SCHED_FENCE __builtin_amdgcn_sched_barrier(0)
+#else
+#define BZ_MTF_SCHED_FENCE do { } while (0)
+#endif
+#ifndef BZ_MTF_PIPELINED
+#define BZ_MTF_PIPELINED 1 // the compare loop of k_mtf_ranks_small with the next rows of the table in flight (0: the plain loop)
+#endif
 #endif
 constexpr u32 kMtfSmallAlpha = 96;                     // blocks with at most this many symbols use k_mtf_ranks_small // 14 workgroups of 256 chunks
 
@@ -413,7 +427,11 @@ __global__ __launch_bounds__(LANES) void k_mtf_ranks_small(MtfArgs a)
     const u32 end = (beg + kMtfChunk < n) ? beg + kMtfChunk : n;
     const u32 npairs = (alpha + 1u) >> 1;
     u32 *my = s_last + threadIdx.x;
-    for (u32 q = 0; q < npairs; ++q) my[q * LANES] = 0x80008000u; // both halves: -32768 = never seen
+    // (the compare loop below runs over blocks of 16 pairs: the rows behind the alphabet's last pair hold "never seen" too)
+    constexpr u32 kPB = BZ_MTF_BLOCK; // pairs per block of the pipelined compare loop (two blocks per trip)
+    static_assert(PAIRS % (2u * kPB) == 0 || PAIRS <= kMtfSmallPairs, "the compare loop takes the table two blocks at a time");
+    const u32 npairs16 = ((npairs + 2u * kPB - 1u) / (2u * kPB) * (2u * kPB)) < PAIRS ? ((npairs + 2u * kPB - 1u) / (2u * kPB) * (2u * kPB)) : PAIRS;
+    for (u32 q = 0; q < npairs16; ++q) my[q * LANES] = 0x80008000u; // both halves: -32768 = never seen
     {
         // start list -> times -1, -2, ...
         const u8 *st = a.init_state + ((size_t)lb * kMaxMtfChunks + chunk) * 256u;
@@ -533,6 +551,31 @@ __global__ __launch_bounds__(LANES) void k_mtf_ranks_small(MtfArgs a)
                 // ls - t saturates (a never-seen -32768 must not wrap), its sign says t > ls
                 const short2_t ls2 = as_short2(lsu | (lsu << 16));
                 short2_t acc = {0, 0};
+#if BZ_MTF_PIPELINED
+              if (PAIRS > kMtfSmallPairs) { // (<= 96 symbols: three workgroups per CU hide the wait already; measured slower with it: 2.02 -> 2.27 ms per 256 MiB of text)
+                // Round 5: the table rows of the NEXT eight pairs are on their way while the eight at hand are compared -- the
+                // compiler's loop asked for eight rows, waited for them and compared them, one wave per SIMD with nothing to hide
+                // the wait behind (64 KB of LDS per 128 lanes): 7.3 ms per 256 MiB of random bytes, 200 cycles per eight pairs of
+                // which 96 were arithmetic.
+                u32 ra[kPB], rb[kPB];
+#pragma unroll
+                for (u32 e = 0; e < kPB; ++e) ra[e] = my[e * LANES];
+                for (u32 q = 0; q < npairs16; q += 2u * kPB) {
+#pragma unroll
+                    for (u32 e = 0; e < kPB; ++e) rb[e] = my[(q + kPB + e) * LANES];
+                    BZ_MTF_SCHED_FENCE;
+#pragma unroll
+                    for (u32 e = 0; e < kPB; ++e) acc -= __builtin_elementwise_sub_sat(ls2, as_short2(ra[e])) >> (short2_t){15, 15};
+                    // (the last trip asks for the table's first rows again: never used)
+                    const u32 qn = (q + 2u * kPB < npairs16) ? q + 2u * kPB : 0u;
+#pragma unroll
+                    for (u32 e = 0; e < kPB; ++e) ra[e] = my[(qn + e) * LANES];
+                    BZ_MTF_SCHED_FENCE;
+#pragma unroll
+                    for (u32 e = 0; e < kPB; ++e) acc -= __builtin_elementwise_sub_sat(ls2, as_short2(rb[e])) >> (short2_t){15, 15};
+                }
+              } else
+#endif
                 for (u32 q = 0; q < npairs; ++q) {
                     const short2_t wd = as_short2(my[q * LANES]);
                     const short2_t neg = __builtin_elementwise_sub_sat(ls2, wd) >> (short2_t){15, 15}; // -1 where t > ls
