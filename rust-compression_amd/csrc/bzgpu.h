@@ -383,6 +383,8 @@ struct BwtArgs {
     u32 *tickets;                    // [kSortEpochs][8] tile tickets per pass and XCD
     u32 *sort_err;                   // [1] a look-back that gave up
     u32 *epoch;                      // host: the engine's pass counter (1 .. kSortEpochs-1)
+    u8 *per_aux;                     // [nb][2 kMtfStride] bytes (the MTF stage's symbol buffer, free during the sort): the period round's
+                                     // pair verdict bytes [kSlot] and group bytes [kSlot], one per position of the survivor list
     u32 per_pairs;                   // != 0: BZ_PAIR_COMPARE=1 -- the period round orders groups of two by comparing them; the
                                      //   verdict bytes then take the digit-count slot and the period tables the flag bytes'
     u32 *fused_state;                // host, per engine: [0] != 0: the fused passes misbehaved once and stay off for

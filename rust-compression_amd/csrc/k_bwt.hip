@@ -100,9 +100,10 @@ __device__ __forceinline__ u64 newbits_lane_word(const u64 *__restrict__ bits, s
 // (gh_tiles: 2.7 MB per block, which only the fused walk rounds use -- room for eight) or, without the fused passes or
 // with the pair comparison on (its verdict bytes live there), in the flag bytes' slot (room for three).
 constexpr u32 kPerWords = kSlot / 64u; // 14080 words of 64 positions
+constexpr u32 kPerGroupMax = 8;        // the largest group the period round ranks member by member
 constexpr u32 kPerSetBytes = 2u * kPerWords * 8u + ((kPerWords + 1u) * 4u + 7u) / 8u * 8u;
 static_assert((size_t)kPerK * kPerSetBytes <= (size_t)kTilesPerBlock * 3 * kMaxBins * 4, "the period tables do not fit the digit-count slot");
-__host__ __device__ __forceinline__ bool per_in_counts(const BwtArgs &a) { return a.gh_tiles != nullptr && !a.per_pairs; }
+__host__ __device__ __forceinline__ bool per_in_counts(const BwtArgs &a) { return a.gh_tiles != nullptr; }
 __host__ __device__ __forceinline__ u32 per_kmax(const BwtArgs &a) { return per_in_counts(a) ? kPerK : (kSlot / kPerSetBytes < kPerK ? kSlot / kPerSetBytes : kPerK); }
 __device__ __forceinline__ const u8 *per_set(const BwtArgs &a, u32 lb, u32 i)
 {
@@ -153,7 +154,13 @@ __device__ __forceinline__ bool per_key_ascending(const BwtArgs &a, u32 lb, u32 
 // digit counts' slot of the block, which only the fused walk rounds use
 __device__ __forceinline__ u8 *pair_bytes(const BwtArgs &a, u32 lb)
 {
-    return reinterpret_cast<u8 *>(a.gh_tiles + (size_t)lb * kTilesPerBlock * 3 * kMaxBins);
+    return a.per_aux + (size_t)lb * kMtfStride * 2u;
+}
+// (second half of round 5) a byte per list position for the members of SMALL groups: place inside the group | members << 4
+// (3 .. 15 members; 0: a larger group), left by k_survivor_compact, read by the period round's keys (fetch_rows<SRC_PERJ>)
+__device__ __forceinline__ u8 *group_bytes(const BwtArgs &a, u32 lb)
+{
+    return a.per_aux + (size_t)lb * kMtfStride * 2u + kSlot;
 }
 
 // Batched form: the 16 rows of one lane.  All primary loads are issued back to back (clamped
@@ -260,7 +267,7 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
         // the period round: order the survivors by where they start -- ascending or descending, as the first
         // difference between the block and the block shifted by its period decides for each of them (per_ascending)
         const u32 p = a.lin_p[(size_t)lb * kPerK]; // (hm: the depth reached, in symbols; 0: the block has no listed distance)
-        const u8 *pb8 = (a.gh_tiles && a.per_pairs) ? pair_bytes(a, lb) : nullptr;
+        const u8 *pb8 = (a.gh_tiles && a.per_aux && a.per_pairs) ? pair_bytes(a, lb) : nullptr;
         u32 pairv[ROWS];
 #pragma unroll
         for (u32 r = 0; r < (u32)ROWS; ++r) {
@@ -270,11 +277,77 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
             pairv[r] = pb8 ? pb8[c] : 0u;
             ok |= (idx < cnt ? 1u : 0u) << r;
         }
+        // (second half of round 5) a SMALL group -- 3 .. kPerGroupMax members, every pair of them a listed distance apart -- is
+        // keyed by the member's exact RANK inside it: rot(x) < rot(x + d) is one look at the tables of distance d, so a
+        // member counts the members below it.  The heuristic direction above orders a group of copies only when their
+        // order happens to be that of their starts (or the reverse); three copies are in mixed order half of the time (the
+        // corpus "binary": 43 % of its rotations sit in groups of three and four at 32 symbols).  k_period_mark checks the
+        // neighbours of the sorted list as before: a wrong rank costs a round, never a byte.
+        const u8 *gb8 = (pb8 && p != 0u) ? group_bytes(a, lb) : nullptr;
+        u32 lp[kPerK];
+        {
+            const u32 kmax = per_kmax(a);
+#pragma unroll
+            for (u32 i = 0; i < kPerK; ++i) lp[i] = (gb8 && i < kmax) ? a.lin_p[(size_t)lb * kPerK + i] : 0u;
+        }
 #pragma unroll
         for (u32 r = 0; r < (u32)ROWS; ++r) {
-            if (pairv[r]) key[r] = pairv[r] & 1u; // a group of two, ordered by k_pair_compare
-            else key[r] = (p != 0u && !per_key_ascending(a, lb, n, hm, val[r])) ? (n - 1u - val[r]) : val[r];
+            if (pairv[r]) {
+                key[r] = pairv[r] & 1u; // a group of two, ordered by k_pair_compare
+                continue;
+            }
+            key[r] = (p != 0u && !per_key_ascending(a, lb, n, hm, val[r])) ? (n - 1u - val[r]) : val[r];
+            if (!gb8) continue;
+            const u32 idx = first + r * 64u;
+            if (idx >= cnt) continue;
+            const u32 gi = gb8[idx];
+            const u32 sz = gi >> 4, off = gi & 15u;
+            if (sz < 3u || sz > kPerGroupMax || off >= sz || idx < off || idx - off + sz > cnt) continue;
+            const u32 g0 = idx - off;
+            const u32 j = val[r];
+            u32 mem[kPerGroupMax];
+#pragma unroll
+            for (u32 t = 0; t < kPerGroupMax; ++t) mem[t] = t < sz ? Vin[base + g0 + t] : 0u;
+            bool all = true;
+            u32 rank = 0;
+#pragma unroll
+            for (u32 t = 0; t < kPerGroupMax; ++t) {
+                if (t >= sz) break;
+#pragma unroll
+                for (u32 u = t + 1u; u < kPerGroupMax; ++u) {
+                    if (u >= sz) break;
+                    const u32 x = mem[t] < mem[u] ? mem[t] : mem[u], y = mem[t] < mem[u] ? mem[u] : mem[t];
+                    const u32 dd = y - x;
+                    u32 which = kPerK;
+#pragma unroll
+                    for (u32 i = 0; i < kPerK; ++i)
+                        if (lp[i] != 0u && lp[i] == dd) which = i;
+                    if (which == kPerK) {
+                        all = false;
+                    } else if (x == j || y == j) { // rot(x) < rot(y)?
+                        const bool lt = per_lt_at(a, lb, which, n, per_first_mis(a, lb, which, x));
+                        rank += (y == j) ? (lt ? 1u : 0u) : (lt ? 0u : 1u);
+                    }
+                }
+            }
+            if (all) key[r] = rank;
+#ifdef BZ_PERJ_DEBUG
+            atomicAdd(&a.loc_stats[60], 1u);
+            if (all) atomicAdd(&a.loc_stats[61], 1u);
+            atomicAdd(&a.loc_stats[62 + (sz < 9u ? sz - 3u : 5u)], 1u);
+#endif
         }
+#ifdef BZ_PERJ_DEBUG
+#pragma unroll
+        for (u32 r = 0; r < (u32)ROWS; ++r) {
+            const u32 idx = first + r * 64u;
+            if (idx < cnt) {
+                atomicAdd(&a.loc_stats[70], 1u);
+                if (pairv[r]) atomicAdd(&a.loc_stats[71], 1u);
+                if (gb8 && gb8[idx]) atomicAdd(&a.loc_stats[72], 1u);
+            }
+        }
+#endif
     } else if (SRC == SRC_LISTG) {
         // survivor round, second half: walk that order, key = the survivor's own group
 #pragma unroll
@@ -2159,6 +2232,9 @@ __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, co
 #pragma unroll
         for (u32 r = 0; r < 17; ++r) mn[r] = wave_lane64(myword, r);
     }
+    // (the period round) the starts of the 64 elements in front of the wave's span: a group may begin there
+    const u64 mn_prev = (mate && wbase >= 64u) ? a.newbits[(base + wbase - 64u) >> 6] : 0ull;
+    u8 *gb8 = mate ? group_bytes(a, lb) : nullptr;
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
         const u32 idx = wbase + r * 64u + l;
@@ -2180,6 +2256,15 @@ __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, co
     for (u32 r = 0; r < 16; ++r) {
         const u32 at = off + (u32)__popcll(surv[r] & lt_mask);
         if ((surv[r] >> l) & 1ull) VS[base + at] = jv[r];
+        if (mate && ((surv[r] >> l) & 1ull)) {
+            // place inside its group and the group's size, from the start bits around the element (groups of 3 .. 15)
+            const u64 cur = mn[r], prv = r ? mn[r - 1] : mn_prev, nxw = mn[r + 1];
+            const u64 lo = (l == 63u) ? cur : ((cur << (63u - l)) | (prv >> (l + 1u)));
+            const u64 hi = (l == 63u) ? nxw : ((cur >> (l + 1u)) | (nxw << (63u - l)));
+            const u32 back = lo ? (u32)__clzll(lo) : 64u, fwd = hi ? (u32)__builtin_ctzll(hi) + 1u : 65u;
+            const u32 size = back + fwd;
+            gb8[at] = (size >= 3u && size <= 15u) ? (u8)(back | (size << 4)) : (u8)0;
+        }
         if (mate) {
             // first member of a group of two: a start here, none at the next element, one at the element behind that
             const u32 idx = wbase + r * 64u + l;
@@ -2282,7 +2367,7 @@ __global__ __launch_bounds__(kSortThreads) void k_periodic_place(BwtArgs a)
 //                  half of its positions or more, and not everywhere (a block periodic as a cycle has equal rotations:
 //                  k_periodic_place's case)
 //   k_period_bits  the two bitmaps;  k_period_next  first mismatch at or behind every 64-position word
-__global__ __launch_bounds__(kSortThreads) void k_period_find(BwtArgs a)
+__global__ __launch_bounds__(kSortThreads) void k_period_find(BwtArgs a, u32 quarters)
 {
     constexpr u32 kAnchors = 32;
     __shared__ u32 s_best, s_cand[kAnchors], s_agree[kAnchors];
@@ -2295,7 +2380,7 @@ __global__ __launch_bounds__(kSortThreads) void k_period_find(BwtArgs a)
         a.lin_sig[(size_t)lb * kPerK + tid] = 0;
     }
     // (count2: the survivors of the last refinement, k_survivor_compact) only blocks that are deep in repeats
-    if (n < 256u || (u64)a.count2[lb] * 4u < (u64)n * 3u) return;
+    if (n < 256u || (u64)a.count2[lb] * 4u < (u64)n * quarters) return; // (the second period round: a quarter of the block)
     // Round 5: up to kPerK distances per block instead of one.  Data whose copies DRIFT (a file and an edited copy of it,
     // a tar of similar files; the corpus "binary": RLE1 turns a changed byte into a shift) agrees with itself at five to
     // seven distances per block, none of them over half of it: thirty-two anchors over the first half of the block each
@@ -3275,14 +3360,26 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         const bool deep = want_period == 2 ? (rounds >= 3 && m * 4 >= total_n * 3)
                                            : ((rounds >= 2 && ((u64)mx * 4 >= (u64)max_n * 3 || m * 4 >= total_n * 3)) ||
                                               (rounds == 1 && m * 64 >= total_n * 63));
-        const bool per_round = want_period != 0 && !period_done && deep;
+        // (second half of round 5) a SECOND period round where round 5's pair round stood -- behind the first one, once, when a third
+        // of the rotations are still unordered at 32 symbols and more: with tables, pairs AND the exact ranks inside groups of
+        // three to eight (fetch_rows<SRC_PERJ>).  At the first period round's depth (8-16 symbols) the groups of data that holds
+        // a stretch several times are still mixtures of the copies' neighbourhoods (the corpus "binary": ranks ordered 10 M of its
+        // 250 M rotations there); at 32 symbols 43 % of its rotations sit in groups of three and four copies.
+        // MEASURED AND OFF BY DEFAULT (BZ_PERIOD_SECOND=1 turns it on): on "binary" the second round finds 50 % of its list in
+        // groups of three to eight (40 % in groups of four) but only 0.2 % of those with every pair of members a LISTED distance
+        // apart -- four copies need six distances, the drift of the copies multiplies them, a block lists eight at most and
+        // finds them from anchors, not from the groups -- and costs 17 ms per 256 MiB: 93 -> 114 ms.  Without it the pair round
+        // runs as in the first half of the round.
+        static const bool want_second = getenv("BZ_PERIOD_SECOND") && atoi(getenv("BZ_PERIOD_SECOND")) != 0;
+        const bool second_stage = want_period != 0 && period_done && !pair_done && a.gh_tiles && a.per_aux && a.per_pairs &&
+                                  ((u64)(2u * min_chars) << step) >= 32u && m * (want_second ? 3 : 2) >= total_n;
+        const bool per_round = want_period != 0 && ((!period_done && deep) || (second_stage && want_second));
         // A PAIR round (round 5): behind the period round, once, when half of the rotations are still unordered at a depth of 32
         // symbols and more -- data that holds a stretch twice (the corpus "binary") leaves almost every rotation in a group of
         // two by then, whose members agree for kilobytes: k_pair_scan orders them in one go, whatever the distances between the
         // copies, instead of the eight doubling rounds they would take.  At the depth of the period round (8-16 symbols) most
         // groups are still larger than two.
-        const bool pair_round = want_period != 0 && !per_round && period_done && !pair_done && a.gh_tiles && a.per_pairs &&
-                                ((u64)(2u * min_chars) << step) >= 32u && m * 2 >= total_n;
+        const bool pair_round = !per_round && second_stage;
         // survivor form below this share of the rotations (BZ_SURV_SHARE=num/den, default 1/4: measured)
         static const u64 surv_num = [] { const char *e = getenv("BZ_SURV_SHARE"); unsigned a = 1, b = 4; if (e && sscanf(e, "%u/%u", &a, &b) == 2 && a && b) return (u64)a; return (u64)1; }();
         static const u64 surv_den = [] { const char *e = getenv("BZ_SURV_SHARE"); unsigned a = 1, b = 4; if (e && sscanf(e, "%u/%u", &a, &b) == 2 && a && b) return (u64)b; return (u64)4; }();
@@ -3293,6 +3390,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
                     max_n, per_round ? ": period round" : (pair_round ? ": pair round" : (m * surv_den < total_n * surv_num ? ": survivor form" : ": walk form")));
         u8 *impure = a.ptext; // (the packed text is not read any more once the init is over)
         if (per_round || pair_round) {
+            if (per_round && period_done) pair_done = true; // (the second period round takes the pair round's place)
             if (per_round) period_done = true;
             else pair_done = true;
             (void)hipMemsetAsync(impure, 0, (size_t)a.nb * kSlot, st);
@@ -3301,7 +3399,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             // mate / place of the pair: the two arrays of the list the last refinement ran on, which nothing reads between the
             // compaction and the passes below -- unless the compaction reads that very list (lastV), then the free key array.
             static const int pair_mode = getenv("BZ_PAIR_COMPARE") ? atoi(getenv("BZ_PAIR_COMPARE")) : 1;
-            const bool pairs = a.gh_tiles && a.per_pairs && pair_mode != 0; // (the verdict bytes live in the fused passes' digit counts: no fused passes, no pair round)
+            const bool pairs = a.gh_tiles && a.per_aux && a.per_pairs && pair_mode != 0; // (only with the fused passes: the three-kernel fallback keeps to round 4's period round)
             u32 *mate = (lastV == cK) ? fK : cK, *midx = (lastV == cV || lastV == cK) ? fK : cV;
             if (mate == midx) midx = (lastV == cV) ? cK : cV;
             const bool scan = pairs && pair_mode != 2;
@@ -3309,7 +3407,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             hipLaunchKernelGGL(k_survivor_compact, grid_prev, dim3(kSortThreads), 0, st, a, lastV, fV, scan ? mate : nullptr, scan ? midx : nullptr);
             hipLaunchKernelGGL(k_copy_counts, dim3((a.nb + 255) / 256), dim3(256), 0, st, a.count, a.count2, a.nb);
             if (pairs) {
-                (void)hipMemset2DAsync(a.gh_tiles, (size_t)kTilesPerBlock * 3 * kMaxBins * 4, 0, (size_t)list_tiles * kSortTile, a.nb, st);
+                (void)hipMemset2DAsync(a.per_aux, (size_t)kMtfStride * 2, 0, (size_t)list_tiles * kSortTile, a.nb, st);
                 if (pair_mode == 2) hipLaunchKernelGGL(k_pair_compare, grid_list, dim3(kSortThreads), 0, st, a, step, fV, impure);
                 else hipLaunchKernelGGL(k_pair_scan, grid, dim3(kSortThreads), 0, st, a, step, mate, midx, impure);
             }
@@ -3317,7 +3415,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             // nothing uses before this round's k_group_flags); the pair round lists none
             if (!per_round) (void)hipMemsetAsync(a.lin_p, 0, (size_t)a.nb * kPerK * 4, st);
             if (per_round) {
-            hipLaunchKernelGGL(k_period_find, dim3(a.nb), dim3(kSortThreads), 0, st, a);
+            hipLaunchKernelGGL(k_period_find, dim3(a.nb), dim3(kSortThreads), 0, st, a, second_stage ? 1u : 3u);
             hipLaunchKernelGGL(k_period_bits, grid, dim3(kSortThreads), 0, st, a);
             hipLaunchKernelGGL(k_period_next, dim3(a.nb, per_kmax(a)), dim3(kSortThreads), 0, st, a);
             }
@@ -3382,6 +3480,16 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         p = prof ? prof->begin(st, KID_RANK_PLACE, m * 8) : -1;
         hipLaunchKernelGGL(k_rank_place, grid, dim3(kSortThreads), 0, st, a, fK);
         if (prof) prof->end(st, p);
+#ifdef BZ_PERJ_DEBUG
+        if (per_round) {
+            u32 dbg[16] = {};
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(dbg, a.loc_stats + 60, sizeof(dbg), hipMemcpyDeviceToHost);
+            fprintf(stderr, "  period round keys: %u list entries (hist kernel only), %u in ordered pairs, %u with a group byte; %u in groups of 3..8 (sizes 3,4,5,6,7,8: %u %u %u %u %u %u), %u of them with every pair listed\n",
+                    dbg[10], dbg[11], dbg[12], dbg[0], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7], dbg[1]);
+            (void)hipMemset(a.loc_stats + 60, 0, sizeof(dbg));
+        }
+#endif
         if (per_round && bwt_trace) {
             std::vector<u32> lp((size_t)a.nb * kPerK), ls((size_t)a.nb * kPerK), nf(a.nb), cn(a.nb);
             (void)hipMemcpyAsync(lp.data(), a.lin_p, (size_t)a.nb * kPerK * 4, hipMemcpyDeviceToHost, st);
