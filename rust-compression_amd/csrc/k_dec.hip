@@ -122,9 +122,9 @@ constexpr u16 kLutLong = 0xFFFE, kLutBad = 0xFFFF;
 constexpr u32 kRingWords = 256;  // staged input window (words), power of two
 constexpr u32 kOutBuf = 1024;    // staged output symbols
 
-// ---- D1: header + Huffman decode of one candidate -------------------------------------------------------
-// One workgroup of four waves per candidate.  Thread 0 parses the header; all threads build the
-// decode tables; the symbols are then found 256 candidate code starts at a time (below).
+#ifndef BZ_D1_PAR_SEL
+#define BZ_D1_PAR_SEL 1 // the selectors of a block's header by all threads (0: by thread 0, one unary code per step)
+#endif
 #ifndef BZ_D1_SEL_LDS
 #define BZ_D1_SEL_LDS 1
 #endif
@@ -132,6 +132,163 @@ constexpr u32 kOutBuf = 1024;    // staged output symbols
 #define BZ_D1_THREADS 256
 #endif
 constexpr u32 kD1Threads = BZ_D1_THREADS; // threads = candidate code starts per round
+#if BZ_D1_PAR_SEL
+// ---- the selectors of a block's header by the whole workgroup ------------------------------------------------------------
+// n_selectors unary codes (j one bits and a zero, j < n_groups: the position in a move-to-front list of the tables,
+// decoder.rs:294-316).  Thread 0 took them one code per step: 18 002 dependent steps, 1.5 M of the 1.9 M cycles a header
+// costs, 0.8 ms of a block's 12.5.  Here:
+//   A  every thread takes 32 bits of the code string per trip: the zeros in them are code ends; a block scan of their
+//      number says which selectors they end, a block max-scan of the last zero's position says where the first of them
+//      began; j goes to sel[s].  A code with n_groups one bits (the reference gives up there) is noted with the smallest
+//      selector number -- also when its zero lies behind the n_selectors * n_groups bits looked at (then fewer zeros
+//      than selectors turn up, and the code behind the last zero is the one).
+//   B  the move-to-front of the j: "take position j to the front" is a permutation of POSITIONS whatever the list holds,
+//      so a thread composes the permutations of its stretch of selectors, an exclusive scan over the threads gives the
+//      list in front of each stretch, and the stretch is replayed from it (the values replace the j in sel[]).
+// out64[0] = (selector << 32 | first bit of its code, relative to p0) of the first bad code or ~0; out64[1] = the bit
+// behind the last selector, relative to p0.  scratch: 144 words of LDS.  All threads call it; it ends with a barrier.
+__device__ __forceinline__ u32 d1_perm_compose(u32 x, u32 y) // (x o y)[k] = x[y[k]]: y's move applied to the list x
+{
+    u32 r = 0;
+#pragma unroll
+    for (u32 k = 0; k < 6; ++k) {
+        const u32 yk = (y >> (4u * k)) & 15u;
+        r |= ((x >> (4u * yk)) & 15u) << (4u * k);
+    }
+    return r;
+}
+__device__ __forceinline__ u32 d1_move_front(u32 lst, u32 j, u32 &v)
+{
+    v = (lst >> (4u * j)) & 15u;
+    if (j) {
+        const u32 lowmask = (1u << (4u * j)) - 1u;
+        lst = (lst & ~((lowmask << 4) | 15u)) | ((lst & lowmask) << 4) | v;
+    }
+    return lst;
+}
+__device__ void d1_selectors(const BitCur &bc, u8 *__restrict__ sel, u64 p0, u32 nsel, u32 ng, u32 l, u32 *scratch, u64 *out64)
+{
+    constexpr u32 NW = kD1Threads / 64;
+    u32 *s_zsum = scratch;                 // [NW] zeros per wave
+    int *s_zmax = reinterpret_cast<int *>(scratch + 8);  // [NW] last zero per wave
+    u32 *s_pw = scratch + 16;              // [NW] permutation per wave
+    const u32 wv = l >> 6, ln = l & 63u;
+    if (l == 0) {
+        out64[0] = ~0ull;
+        out64[1] = 0ull;
+    }
+    __syncthreads();
+    // ---- A
+    const u32 maxbits = nsel * ng;
+    u32 zdone = 0;  // selectors ended so far
+    int lastz = -1; // the last zero so far (relative bit position)
+    for (u32 base = 0; base < maxbits && zdone < nsel; base += kD1Threads * 32u) {
+        const u64 bp = p0 + base + 32u * l;
+        const u64 wi = bp >> 5;
+        const u32 sh = (u32)bp & 31u;
+        const u32 hw = bc.load(wi), lw = bc.load(wi + 1);
+        const u32 word = sh ? ((hw << sh) | (lw >> (32u - sh))) : hw;
+        const u32 zm = ~word; // bit (31 - b) set: a zero at bit b of this thread's 32 (b = 0 first)
+        const u32 zc = (u32)__popc(zm);
+        const int myz = zm ? (int)(base + 32u * l + 31u - (u32)__builtin_ctz(zm)) : -1;
+        // scans over the wave, then over the waves
+        u32 zin = zc;
+        int zmx = myz;
+#pragma unroll
+        for (u32 d = 1; d < 64; d <<= 1) {
+            const u32 a = (u32)__shfl_up((int)zin, d, 64);
+            const int b = __shfl_up(zmx, d, 64);
+            if (ln >= d) {
+                zin += a;
+                zmx = b > zmx ? b : zmx;
+            }
+        }
+        if (ln == 63u) {
+            s_zsum[wv] = zin;
+            s_zmax[wv] = zmx;
+        }
+        __syncthreads();
+        u32 zbase = zdone, ztot = 0;
+        int pmax = lastz, tmax = lastz;
+        for (u32 k = 0; k < NW; ++k) {
+            if (k < wv) {
+                zbase += s_zsum[k];
+                pmax = s_zmax[k] > pmax ? s_zmax[k] : pmax;
+            }
+            ztot += s_zsum[k];
+            tmax = s_zmax[k] > tmax ? s_zmax[k] : tmax;
+        }
+        const int prevlane = __shfl_up(zmx, 1, 64); // (inclusive max of the lanes in front)
+        int prev = (ln ? (prevlane > pmax ? prevlane : pmax) : pmax);
+        u32 sidx = zbase + zin - zc;
+        u32 m = zm;
+        while (m && sidx < nsel) {
+            const u32 b = (u32)__builtin_clz(m);
+            const int pos = (int)(base + 32u * l + b);
+            const u32 j = (u32)(pos - prev - 1);
+            if (j >= ng) atomicMin(reinterpret_cast<unsigned long long *>(&out64[0]), ((unsigned long long)sidx << 32) | (u32)(prev + 1));
+            else sel[sidx] = (u8)j;
+            if (sidx + 1u == nsel) out64[1] = (u64)(pos + 1);
+            prev = pos;
+            ++sidx;
+            m &= ~(0x80000000u >> b);
+        }
+        zdone += ztot;
+        lastz = tmax;
+        __syncthreads(); // (the wave sums are written again in the next trip)
+    }
+    if (zdone < nsel && l == 0) // fewer zeros than selectors inside n_selectors * n_groups bits: the code behind the last zero is too long
+        atomicMin(reinterpret_cast<unsigned long long *>(&out64[0]), ((unsigned long long)zdone << 32) | (u32)(lastz + 1));
+    __syncthreads();
+    if (out64[0] != ~0ull) return; // (uniform: every thread reads the same word behind the barrier)
+    // ---- B
+    const u32 per = (((nsel + kD1Threads - 1u) / kD1Threads) + 15u) & ~15u; // selectors per thread, whole 16-byte groups
+    const u32 s0 = l * per, s1 = s0 + per < nsel ? s0 + per : nsel;
+    u32 P = 0x543210u;
+    for (u32 q = s0; q < s1; q += 16u) {
+        const uint4 v4 = *reinterpret_cast<const uint4 *>(sel + q);
+        const u32 wd[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (u32 k = 0; k < 16; ++k) {
+            if (q + k < s1) {
+                u32 v;
+                P = d1_move_front(P, (wd[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu, v);
+            }
+        }
+    }
+    u32 inc = P;
+#pragma unroll
+    for (u32 d = 1; d < 64; d <<= 1) {
+        const u32 o = (u32)__shfl_up((int)inc, d, 64);
+        if (ln >= d) inc = d1_perm_compose(o, inc);
+    }
+    if (ln == 63u) s_pw[wv] = inc;
+    __syncthreads();
+    u32 E = 0x543210u; // the list in front of this thread's stretch
+    for (u32 k = 0; k < wv; ++k) E = d1_perm_compose(E, s_pw[k]);
+    {
+        const u32 before = (u32)__shfl_up((int)inc, 1, 64);
+        if (ln) E = d1_perm_compose(E, before);
+    }
+    for (u32 q = s0; q < s1; q += 16u) {
+        const uint4 v4 = *reinterpret_cast<const uint4 *>(sel + q);
+        const u32 wd[4] = {v4.x, v4.y, v4.z, v4.w};
+        u32 od[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (u32 k = 0; k < 16; ++k) {
+            u32 v = 0;
+            if (q + k < s1) E = d1_move_front(E, (wd[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu, v);
+            od[k >> 2] |= v << ((k & 3u) * 8u);
+        }
+        *reinterpret_cast<uint4 *>(sel + q) = make_uint4(od[0], od[1], od[2], od[3]);
+    }
+    __syncthreads();
+}
+#endif
+
+// ---- D1: header + Huffman decode of one candidate -------------------------------------------------------
+// One workgroup of four waves per candidate.  Thread 0 parses the header; all threads build the
+// decode tables; the symbols are then found 256 candidate code starts at a time (below).
 __global__ __launch_bounds__(kD1Threads) void k_dec_block(const u8 *__restrict__ in, u64 nbytes,
                                                    const DecCand *__restrict__ cands, u32 ncand,
                                                    DecBlockInfo *__restrict__ info, u16 *__restrict__ sym_out,
@@ -148,6 +305,9 @@ __global__ __launch_bounds__(kD1Threads) void k_dec_block(const u8 *__restrict__
     __shared__ u16 s_j[6][kD1Threads + 4]; // s_j[k][i]: the code start 2^k symbols behind start i (256 = outside the window)
     __shared__ u16 s_e[kD1Threads];        // table entry of the code that would start at i
     __shared__ u32 s_ctl[4];               // symbols taken, bits consumed, stop reason
+#if BZ_D1_PAR_SEL
+    __shared__ u64 s_sel64[2];
+#endif
 #if BZ_D1_SEL_LDS
     __shared__ u8 s_sel[256];              // the selectors of the groups g .. g | 255
 #endif
@@ -208,6 +368,7 @@ __global__ __launch_bounds__(kD1Threads) void k_dec_block(const u8 *__restrict__
                 n_selectors = bc.read(15);
                 if (n_selectors < 1) status = BZ_DEC_E_DATA;            // :290-292
             }
+#if !BZ_D1_PAR_SEL
             if (!status) { // selectors: unary MTF positions (:294-316); a whole unary code per step
                 u32 lst = 0x543210u;
                 for (u32 s = 0; s < n_selectors; ++s) {
@@ -226,6 +387,36 @@ __global__ __launch_bounds__(kD1Threads) void k_dec_block(const u8 *__restrict__
                     sel[s] = (u8)v;
                 }
             }
+#else
+            // (the selectors are taken by all threads behind the barrier below; thread 0 goes on with the coding tables then)
+            s_hdr[0] = n_groups;
+            s_hdr[1] = alpha;
+            s_hdr[2] = n_selectors;
+            s_hdr[3] = status ? 1u : 0u;
+            s_pos = bc.pos();
+            if (status) {
+                bi.status = (u32)status;
+                bi.end_bit = bc.pos();
+                bi.nsym = 0;
+            }
+        }
+    }
+    __syncthreads();
+    if (s_hdr[3]) return;
+    d1_selectors(bc, sel, s_pos, s_hdr[2], s_hdr[0], l, &s_cnt[0][0], s_sel64);
+    // (s_sel64[0]: (selector << 32 | its first bit, relative) of the first selector with n_groups one bits, or ~0;
+    //  s_sel64[1]: the bit behind the last selector, relative)
+    if (l == 0) {
+        int status = 0;
+        const u32 n_groups = s_hdr[0], alpha = s_hdr[1];
+        if (s_sel64[0] != ~0ull) {
+            status = BZ_DEC_E_DATA; // the reference gives up at the n_groups-th one bit of a selector (:294-316)
+            bc.seek(s_pos + (s_sel64[0] & 0xFFFFFFFFull));
+        } else {
+            bc.seek(s_pos + s_sel64[1]);
+        }
+        {
+#endif
             if (!status) { // coding tables (:318-348); "10" = +1, "11" = -1, "0" = next symbol
                 for (u32 t = 0; t < n_groups && !status; ++t) {
                     u32 curr = bc.read(5);
@@ -248,9 +439,11 @@ __global__ __launch_bounds__(kD1Threads) void k_dec_block(const u8 *__restrict__
                     }
                 }
             }
+#if !BZ_D1_PAR_SEL
             s_hdr[0] = n_groups;
             s_hdr[1] = alpha;
             s_hdr[2] = n_selectors;
+#endif
             s_hdr[3] = status ? 1u : 0u;
             s_pos = bc.pos();
             if (status) {

@@ -447,3 +447,52 @@ def test_streaming_decoder_incremental_errors(pkg, oracle, monkeypatch):
             got += dec.decode_all(b"")
         got += ei.value.partial
         assert ei.value.code == st and bytes(got) == want
+
+
+def _selector_region(z, block_bit):
+    """(first bit, n_groups, n_selectors) of the selectors of the block whose magic starts at bit `block_bit`"""
+    def bits(pos, k):
+        v = 0
+        for i in range(k):
+            b = pos + i
+            v = (v << 1) | ((z[b >> 3] >> (7 - (b & 7))) & 1)
+        return v
+    p = block_bit + 48 + 32 + 1 + 24
+    used = bits(p, 16)
+    p += 16 + 16 * bin(used).count("1")
+    n_groups, n_sel = bits(p, 3), bits(p + 3, 15)
+    return p + 18, n_groups, n_sel
+
+
+def test_selector_codes_with_too_many_ones(pkg, oracle):
+    """Round 5: the selectors of a block's header are parsed by the whole workgroup (k_dec.hip d1_selectors): the zeros of
+    the code string are found 8192 bits per trip, a code with n_groups one bits is noted with the smallest selector number.
+    Streams whose selector region has such a code -- the first selector, one in the middle, the last one, a run of ones
+    that reaches far behind the region -- and clean ones whose region crosses several trips: the oracle's bytes and verdict
+    (/root/reference/src/bzip2/decoder.rs:294-316)."""
+    d = sample(1)[:98000] * 9 + bytes(range(256)) * 40
+    for level in (1, 9):
+        z = bytearray(bz2.compress(d, level))
+        first, ng, nsel = _selector_region(z, 32)  # the first block's magic sits behind the 4-byte stream header
+        assert 2 <= ng <= 6 and nsel >= 100
+        both(pkg, oracle, bytes(z))
+        # selector codes are at most ng bits long: ng ones at a code boundary make a bad code; find boundaries by walking
+        ends, p = [], first
+        for _ in range(nsel):
+            q = p
+            while (z[q >> 3] >> (7 - (q & 7))) & 1:
+                q += 1
+            ends.append((p, q))
+            p = q + 1
+        for which in (0, nsel // 2, nsel - 1):
+            bad = bytearray(z)
+            start = ends[which][0]
+            for b in range(start, start + ng):
+                bad[b >> 3] |= 1 << (7 - (b & 7))
+            got = both(pkg, oracle, bytes(bad))
+            assert got[1] == E_DATA or got[1] == 0  # (the oracle decides; a changed stream may still parse)
+        bad = bytearray(z)
+        start = ends[nsel // 3][0]
+        for b in range(start, start + 20000):  # a run of ones far longer than the region that is left
+            bad[b >> 3] |= 1 << (7 - (b & 7))
+        both(pkg, oracle, bytes(bad))
