@@ -283,7 +283,9 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
         // order happens to be that of their starts (or the reverse); three copies are in mixed order half of the time (the
         // corpus "binary": 43 % of its rotations sit in groups of three and four at 32 symbols).  k_period_mark checks the
         // neighbours of the sorted list as before: a wrong rank costs a round, never a byte.
-        const u8 *gb8 = (pb8 && p != 0u) ? group_bytes(a, lb) : nullptr;
+        // (a block without any small group -- a paragraph repeated has none -- skips the bytes: the compaction leaves a flag in
+        // the last byte of the block's slot of the round's "impure" marks, which the host clears in front of it)
+        const u8 *gb8 = (pb8 && p != 0u && a.ptext[base + kSlot - 1u]) ? group_bytes(a, lb) : nullptr;
         u32 lp[kPerK];
         {
             const u32 kmax = per_kmax(a);
@@ -2263,7 +2265,9 @@ __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, co
             const u64 hi = (l == 63u) ? nxw : ((cur >> (l + 1u)) | (nxw << (63u - l)));
             const u32 back = lo ? (u32)__clzll(lo) : 64u, fwd = hi ? (u32)__builtin_ctzll(hi) + 1u : 65u;
             const u32 size = back + fwd;
-            gb8[at] = (size >= 3u && size <= 15u) ? (u8)(back | (size << 4)) : (u8)0;
+            const bool small = size >= 3u && size <= 15u;
+            gb8[at] = small ? (u8)(back | (size << 4)) : (u8)0;
+            if (small && size <= kPerGroupMax) a.ptext[base + kSlot - 1u] = 1; // (read by the keys of the period round, see fetch_rows<SRC_PERJ>)
         }
         if (mate) {
             // first member of a group of two: a start here, none at the next element, one at the element behind that
