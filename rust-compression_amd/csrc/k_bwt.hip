@@ -2267,6 +2267,8 @@ __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, co
             const u32 size = back + fwd;
             const bool small = size >= 3u && size <= 15u;
             gb8[at] = small ? (u8)(back | (size << 4)) : (u8)0;
+            pair_bytes(a, lb)[at] = 0; // (k_pair_scan / k_pair_compare fill in the verdicts: no memset of the bytes on the host)
+            if (size == 2u) a.ptext[base + kSlot - 2u] = 1; // the block has groups of two: k_pair_scan looks at it
             if (small && size <= kPerGroupMax) a.ptext[base + kSlot - 1u] = 1; // (read by the keys of the period round, see fetch_rows<SRC_PERJ>)
         }
         if (mate) {
@@ -2740,11 +2742,12 @@ __global__ __launch_bounds__(kSortThreads) void k_pair_scan(BwtArgs a, u32 step,
     const u32 n = d.n;
     const u32 start = tile * kSortTile;
     if (start >= n || n < 64u) return;
+    const size_t base = (size_t)lb * kSlot;
+    if (impure[base + kSlot - 2u] == 0) return; // (k_survivor_compact found no group of two in this block)
     const u8 *__restrict__ text = a.rle + d.rle_off;
     const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
     const u64 d64 = ((u64)ki.chars * 2u) << step;
     const u32 depth = d64 < n ? (u32)d64 : n;
-    const size_t base = (size_t)lb * kSlot;
     u8 *pb8 = pair_bytes(a, lb);
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
     for (u32 r = 0; r < 16u; ++r) {
@@ -3411,7 +3414,8 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             hipLaunchKernelGGL(k_survivor_compact, grid_prev, dim3(kSortThreads), 0, st, a, lastV, fV, scan ? mate : nullptr, scan ? midx : nullptr);
             hipLaunchKernelGGL(k_copy_counts, dim3((a.nb + 255) / 256), dim3(256), 0, st, a.count, a.count2, a.nb);
             if (pairs) {
-                (void)hipMemset2DAsync(a.per_aux, (size_t)kMtfStride * 2, 0, (size_t)list_tiles * kSortTile, a.nb, st);
+                // (the verdict bytes of the list were cleared by k_survivor_compact, entry by entry -- unless round 4's kernel is asked for)
+                if (pair_mode == 2) (void)hipMemset2DAsync(a.per_aux, (size_t)kMtfStride * 2, 0, (size_t)list_tiles * kSortTile, a.nb, st);
                 if (pair_mode == 2) hipLaunchKernelGGL(k_pair_compare, grid_list, dim3(kSortThreads), 0, st, a, step, fV, impure);
                 else hipLaunchKernelGGL(k_pair_scan, grid, dim3(kSortThreads), 0, st, a, step, mate, midx, impure);
             }
