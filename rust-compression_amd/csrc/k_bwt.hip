@@ -2286,6 +2286,7 @@ __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, co
                 const u32 lo = va < vb ? va : vb, hi = va < vb ? vb : va;
                 mate[base + lo] = hi;
                 midx[base + lo] = at | (va == lo ? 0x80000000u : 0u);
+                atomicOr(reinterpret_cast<u32 *>(a.flags + base) + (lo >> 5), 1u << (lo & 31u));
             }
         }
         off += (u32)__popcll(surv[r]);
@@ -2752,7 +2753,8 @@ __global__ __launch_bounds__(kSortThreads) void k_pair_scan(BwtArgs a, u32 step,
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
     for (u32 r = 0; r < 16u; ++r) {
         const u32 x = start + w * 1024u + r * 64u + l;
-        const u32 hi = x < n ? mate[base + x] : kPairNone;
+        const bool has_mate = x < n && ((reinterpret_cast<const u32 *>(a.flags + base)[x >> 5] >> (x & 31u)) & 1u);
+        const u32 hi = has_mate ? mate[base + x] : kPairNone;
         const bool has = hi != kPairNone && hi > x && hi < n;
         const u32 dist = has ? hi - x : 0u;
         u64 todo = __ballot(has);
@@ -3410,7 +3412,9 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             u32 *mate = (lastV == cK) ? fK : cK, *midx = (lastV == cV || lastV == cK) ? fK : cV;
             if (mate == midx) midx = (lastV == cV) ? cK : cV;
             const bool scan = pairs && pair_mode != 2;
-            if (scan) (void)hipMemsetAsync(mate, 0xFF, (size_t)a.nb * kSlot * 4, st);
+            // (which starts have a mate: a bit per position in the flag bytes' slot -- free until this round's k_group_flags --,
+            // 1/32 of the bytes that clearing the mate array itself took)
+            if (scan) (void)hipMemset2DAsync(a.flags, kSlot, 0, kSlot / 8u, a.nb, st);
             hipLaunchKernelGGL(k_survivor_compact, grid_prev, dim3(kSortThreads), 0, st, a, lastV, fV, scan ? mate : nullptr, scan ? midx : nullptr);
             hipLaunchKernelGGL(k_copy_counts, dim3((a.nb + 255) / 256), dim3(256), 0, st, a.count, a.count2, a.nb);
             if (pairs) {
