@@ -883,6 +883,24 @@ def extras(result, args, pkg, eng, torch, dev, d_in, n, d_out, out_len, golden, 
     result["t2_stress"] = {"value": round(t2n / tdt / 1e6, 2), "unit": "MB/s", "mib": t2n >> 20,
                            "rounds": eng.bwt_stats()["rounds"], "out_bytes": res2["k"]}
     del d_t2
+    # ... and at the headline's size, in one batch like the headline (VERDICT r4 item 2 quotes T2 at 1 GiB): median of three
+    # steps behind one untimed one, the stream's SHA-256 against the oracle's golden for that corpus
+    if n >= (1 << 30) and args.level == 9:
+        t2g = 1 << 30
+        d_t2 = torch.frombuffer(bytearray(corpus.stress_t2(t2g)), dtype=torch.uint8).to(dev)
+        res3 = {}
+
+        def t2_big():
+            res3["k"] = eng.encode_device(9, d_t2.data_ptr(), t2g, d_out.data_ptr(), d_out.numel())
+        t2_big()
+        tds = sorted(timed(t2_big, 1, sync) for _ in range(3))
+        sha_t2 = hashlib.sha256(bytes(d_out[:res3["k"]].cpu().numpy())).hexdigest()
+        want_t2 = (load_json("tests", "golden", "corpus_hashes.json") or {}).get("bzip2_l9_t2_1gib")
+        want_t2 = want_t2.get("sha256") if isinstance(want_t2, dict) else want_t2
+        checks["t2_1gib_stream_equals_oracle_golden"] = bool(want_t2) and sha_t2 == want_t2
+        result["t2_stress"]["at_1gib"] = {"value": round(t2g / tds[1] / 1e6, 2), "unit": "MB/s", "ms_per_step": round(tds[1] * 1e3, 3),
+                                          "rounds": eng.bwt_stats()["rounds"], "out_bytes": res3["k"], "sha256": sha_t2}
+        del d_t2
 
     # ---- end to end: host buffer -> host buffer through the C ABI (PCIe both ways inside the clock)
     import numpy as np

@@ -158,9 +158,10 @@ __device__ __forceinline__ u8 *pair_bytes(const BwtArgs &a, u32 lb)
 }
 // (second half of round 5) a byte per list position for the members of SMALL groups: place inside the group | members << 4
 // (3 .. 15 members; 0: a larger group), left by k_survivor_compact, read by the period round's keys (fetch_rows<SRC_PERJ>)
+// (ONE byte per list position for both: 0 nothing, 2 / 3 a pair's verdict, >= 0x30 a member of a group of three and more)
 __device__ __forceinline__ u8 *group_bytes(const BwtArgs &a, u32 lb)
 {
-    return a.per_aux + (size_t)lb * kMtfStride * 2u + kSlot;
+    return a.per_aux + (size_t)lb * kMtfStride * 2u;
 }
 
 // Batched form: the 16 rows of one lane.  All primary loads are issued back to back (clamped
@@ -274,7 +275,7 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
             const u32 idx = first + r * 64u;
             const u32 c = idx < cnt ? idx : cnt - 1u;
             val[r] = ld_stream(Vin + base + c);
-            pairv[r] = pb8 ? pb8[c] : 0u;
+            pairv[r] = pb8 ? pb8[c] : 0u; // (2 / 3: a pair's verdict; >= 0x30: the byte of a small group's member)
             ok |= (idx < cnt ? 1u : 0u) << r;
         }
         // (second half of round 5) a SMALL group -- 3 .. kPerGroupMax members, every pair of them a listed distance apart -- is
@@ -294,7 +295,7 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
         }
 #pragma unroll
         for (u32 r = 0; r < (u32)ROWS; ++r) {
-            if (pairv[r]) {
+            if (pairv[r] == 2u || pairv[r] == 3u) {
                 key[r] = pairv[r] & 1u; // a group of two, ordered by k_pair_compare
                 continue;
             }
@@ -302,7 +303,7 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
             if (!gb8) continue;
             const u32 idx = first + r * 64u;
             if (idx >= cnt) continue;
-            const u32 gi = gb8[idx];
+            const u32 gi = pairv[r];
             const u32 sz = gi >> 4, off = gi & 15u;
             if (sz < 3u || sz > kPerGroupMax || off >= sz || idx < off || idx - off + sz > cnt) continue;
             const u32 g0 = idx - off;
@@ -2266,8 +2267,7 @@ __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, co
             const u32 back = lo ? (u32)__clzll(lo) : 64u, fwd = hi ? (u32)__builtin_ctzll(hi) + 1u : 65u;
             const u32 size = back + fwd;
             const bool small = size >= 3u && size <= 15u;
-            gb8[at] = small ? (u8)(back | (size << 4)) : (u8)0;
-            pair_bytes(a, lb)[at] = 0; // (k_pair_scan / k_pair_compare fill in the verdicts: no memset of the bytes on the host)
+            gb8[at] = small ? (u8)(back | (size << 4)) : (u8)0; // (k_pair_scan / k_pair_compare fill in the pairs' verdicts: no memset of the bytes on the host)
             if (size == 2u) a.ptext[base + kSlot - 2u] = 1; // the block has groups of two: k_pair_scan looks at it
             if (small && size <= kPerGroupMax) a.ptext[base + kSlot - 1u] = 1; // (read by the keys of the period round, see fetch_rows<SRC_PERJ>)
         }

@@ -14,7 +14,7 @@ import numpy as np
 h = corpus.matrix_corpus(name, 256 << 20)[:mib << 20] if name in corpus.MATRIX else (np.frombuffer(corpus.stress_t2(mib << 20), dtype=np.uint8).copy() if name == "t2" else None)
 t = torch.from_numpy(h).cuda() if h is not None else corpus.corpus_on_device(mib << 20, torch.device("cuda", 0))
 n = t.numel()
-eng = pkg.GpuEngine(0, 400)
+eng = pkg.GpuEngine(0, int(os.environ.get("BZ_ENGINE_BLOCKS", "400")))
 cap = (pkg.encode_bound(n) + 15) & ~15
 o = torch.empty(cap, dtype=torch.uint8, device="cuda")
 eng.encode_device(9, t.data_ptr(), n, o.data_ptr(), cap)
