@@ -385,6 +385,8 @@ struct BwtArgs {
     u32 *epoch;                      // host: the engine's pass counter (1 .. kSortEpochs-1)
     u8 *per_aux;                     // [nb][2 kMtfStride] bytes (the MTF stage's symbol buffer, free during the sort): the period round's
                                      // pair verdict bytes [kSlot] and group bytes [kSlot], one per position of the survivor list
+    u32 per_keyshift;                // the period round's start-based keys are shifted down by this (10 when every listed distance of the
+                                     // batch is at least 1024: the members of a group then differ above bit 10, ONE pass orders them)
     u32 per_pairs;                   // != 0: BZ_PAIR_COMPARE=1 -- the period round orders groups of two by comparing them; the
                                      //   verdict bytes then take the digit-count slot and the period tables the flag bytes'
     u32 *fused_state;                // host, per engine: [0] != 0: the fused passes misbehaved once and stay off for

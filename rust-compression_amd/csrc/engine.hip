@@ -706,6 +706,7 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
     x.fused = want_fused;
     static const u32 want_pairs = (getenv("BZ_PAIR_COMPARE") && atoi(getenv("BZ_PAIR_COMPARE")) == 0) ? 0u : 1u; // (round 5: on by default)
     x.per_pairs = want_pairs;
+    x.per_keyshift = 0;
     x.per_aux = reinterpret_cast<u8 *>(g->mtf.as<u16>() + (size_t)o * kMtfStride);
     return x;
 }

@@ -299,7 +299,7 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
                 key[r] = pairv[r] & 1u; // a group of two, ordered by k_pair_compare
                 continue;
             }
-            key[r] = (p != 0u && !per_key_ascending(a, lb, n, hm, val[r])) ? (n - 1u - val[r]) : val[r];
+            key[r] = ((p != 0u && !per_key_ascending(a, lb, n, hm, val[r])) ? (n - 1u - val[r]) : val[r]) >> a.per_keyshift;
             if (!gb8) continue;
             const u32 idx = first + r * 64u;
             if (idx >= cnt) continue;
@@ -3431,12 +3431,45 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             hipLaunchKernelGGL(k_period_bits, grid, dim3(kSortThreads), 0, st, a);
             hipLaunchKernelGGL(k_period_next, dim3(a.nb, per_kmax(a)), dim3(kSortThreads), 0, st, a);
             }
-            radix_pass<SRC_PERJ, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK, list_tiles);
-            radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof, nullptr, list_tiles);
-            radix_pass<SRC_LISTG, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK, list_tiles);
-            radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof, nullptr, list_tiles);
-            u32 *t = cK; cK = fK; fK = t;
-            t = cV; cV = fV; fV = t;
+            // The start-based keys are heuristic (k_period_mark decides): when every listed distance of the batch is 1024 and more
+            // -- a paragraph repeated every 4 KiB --, the members of a group differ above bit 10 and the keys go down by ten bits:
+            // ranks, pair verdicts and shifted starts all fit ONE digit, and the second pass over the key is left out (a pass over
+            // the whole list: 4.4 of T2's 119 ms per GiB).  BZ_PERIOD_ONE_PASS=0: two passes always.
+            static const bool want_one_pass = !(getenv("BZ_PERIOD_ONE_PASS") && atoi(getenv("BZ_PERIOD_ONE_PASS")) == 0);
+            bool one_pass = false;
+            if (per_round && want_one_pass) {
+                std::vector<u32> lp((size_t)a.nb * kPerK), ls((size_t)a.nb * kPerK);
+                if (hipMemcpyAsync(lp.data(), a.lin_p, lp.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipMemcpyAsync(ls.data(), a.lin_sig, ls.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+                    return -1;
+                one_pass = true;
+                u32 small = 0, smallest = 0xFFFFFFFFu;
+                // (a distance below 1024 that a fifth of its block agrees at; the ones that barely made the list -- a paragraph
+                // repeated lists a chance distance at 6 % in one block of forty -- only leave their few groups to the doubling)
+                for (size_t i = 0; i < lp.size(); ++i)
+                    if (lp[i] != 0u && lp[i] < 1024u && ls[i] >= 200u) {
+                        one_pass = false;
+                        small += 1;
+                        smallest = lp[i] < smallest ? lp[i] : smallest;
+                    }
+                if (bwt_trace) fprintf(stderr, "  period round: %s (%u distances below 1024 that a fifth of their block agrees at, the smallest %u)\n", one_pass ? "one pass over the keys" : "two passes over the keys", small, small ? smallest : 0u);
+            }
+            a.per_keyshift = one_pass ? 10u : 0u;
+            if (one_pass) {
+                radix_pass<SRC_PERJ, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK, list_tiles);
+                radix_pass<SRC_LISTG, 10>(st, a, 0, step, nullptr, cV, fK, cK, m, prof, fV, list_tiles); // (values cV -> cK, keys kept in fV)
+                radix_pass<SRC_PAIRS, 10>(st, a, 10, step, fK, cK, cV, fV, m, prof, nullptr, list_tiles); // (result: keys in cV, values in fV)
+                u32 *rk = cV, *rv = fV, *ok = fK, *ov = cK;
+                cK = rk; cV = rv; fK = ok; fV = ov;
+            } else {
+                radix_pass<SRC_PERJ, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK, list_tiles);
+                radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof, nullptr, list_tiles);
+                radix_pass<SRC_LISTG, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK, list_tiles);
+                radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof, nullptr, list_tiles);
+                u32 *t = cK; cK = fK; fK = t;
+                t = cV; cV = fV; fV = t;
+            }
+            a.per_keyshift = 0;
             if (per_round) hipLaunchKernelGGL(k_period_mark, grid_list, dim3(kSortThreads), 0, st, a, step, cK, cV, impure);
         } else if (m * surv_den < total_n * surv_num) {
             // few survivors: compact them (list order = sorted by group), order them by the rank
