@@ -87,7 +87,7 @@ static int ensure_workspace(bz_gpu_engine *g, size_t need_blocks)
     ENS(lin_p, nb * (size_t)4 * kPerK);
     ENS(lin_sig, nb * (size_t)4 * kPerK);
     ENS(bin_cursor, nb * (size_t)1024 * 4);
-    ENS(pb_gate, nb * (size_t)4 + 256); // (+ loc_stats behind the gates)
+    ENS(pb_gate, nb * (size_t)4 + 1024); // (+ loc_stats behind the gates: 256 words)
     // (cleared ON THE ENGINE'S STREAM: a memset on the null stream is not ordered against work on a non-blocking stream,
     // and it need not be over when the call returns)
     if (hipMemsetAsync(g->pb_gate.p, 0, g->pb_gate.cap, g->st) != hipSuccess) return BZ_E_UNEXPECTED;

@@ -1424,6 +1424,180 @@ __global__ __launch_bounds__(kLocThreads) void k_phase_b_local(BwtArgs a, const 
     }
 }
 
+// ---- a survivor round inside LDS ---------------------------------------------------------------------------------------
+// A survivor round orders the compacted list -- the rotations the last refinement left unordered, in the order of their
+// groups -- by (group, rank of rotation j + h): two passes by the rank, two by the group, each over the whole list through
+// HBM (k_radix_hist / k_radix_scan / k_radix_scatter x 4: 3.7 ms per GiB of text for its two survivor rounds).  But the
+// list IS in group order and its groups are small (text: 7 % of the rotations are left behind the first walk round, in
+// groups of two and three): a workgroup takes the groups that START inside one tile of the list -- at most kLocCap
+// elements -- into LDS as 64-bit words  group number inside the segment | rank of j + h (20 bits) | j (20 bits),  orders
+// them with k_phase_b_local's LSD passes that never leave LDS, and writes (group, j) out once.  Same rules as there: the
+// result is CHECKED (the ranking inside a wave relies on the order in which LDS serves the lanes of one atomic), and a
+// segment that does not fit (a group of more than kLocCap - kSortTile members) or fails the check raises a flag
+// (loc_stats[LOC_STAT_SURV_FAIL]): the host then sorts the round's list with the four global passes, as before.
+constexpr u32 LOC_STAT_SURV_FAIL = 80;
+__device__ __forceinline__ u32 first_group_start_list(const u32 *__restrict__ R, const u32 *__restrict__ Vb, u32 p0, u32 cnt, u32 limit)
+{
+    if (p0 == 0) return 0;
+    if (p0 >= cnt) return cnt;
+    const u32 l = threadIdx.x & 63u;
+    for (u32 q0 = p0; q0 < p0 + limit; q0 += 64u) {
+        if (q0 >= cnt) return cnt;
+        const u32 q = q0 + l;
+        bool b = false;
+        if (q < cnt) b = (R[Vb[q] & 0xFFFFFu] & ~kFinalBit) != (R[Vb[q - 1] & 0xFFFFFu] & ~kFinalBit);
+        const u64 m = __ballot(b);
+        if (m) return q0 + (u32)__ffsll((long long)m) - 1u;
+    }
+    return 0xFFFFFFFFu;
+}
+__global__ __launch_bounds__(kLocThreads) void k_surv_local(BwtArgs a, u32 step, const u32 *__restrict__ V, u32 *__restrict__ Kout,
+                                                             u32 *__restrict__ Vout)
+{
+    __shared__ u64 s_e[kLocCap];
+    __shared__ u32 s_cnt[kLocSets][kLocBins / 2]; // u16 counters, two to a word
+    __shared__ u16 s_tpre[kLocBins];
+    __shared__ u32 s_wsum[kLocSets];
+    __shared__ u32 s_seg[2];
+    __shared__ u32 s_bad;
+    u32 tile, lb;
+    xcd_remap(gridDim.x, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    const u32 n = a.blocks[lb].n;
+    const u32 cnt = a.count[lb];
+    const u32 start = tile * kSortTile;
+    if (start >= cnt) return;
+    const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
+    const u32 hm = (((u32)ki.chars * 2u) << step) % n;
+    const size_t base = (size_t)lb * kSlot;
+    const u32 *Rb = a.R + base, *Vl = V + base;
+    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    if (w == 0) {
+        const u32 s = first_group_start_list(Rb, Vl, start, cnt, kLocCap + 64u);
+        if (l == 0) s_seg[0] = s;
+    } else if (w == 1) {
+        const u32 s = first_group_start_list(Rb, Vl, start + kSortTile, cnt, kLocCap + 64u);
+        if (l == 0) s_seg[1] = s;
+    }
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    const u32 s0 = (u32)__builtin_amdgcn_readfirstlane((int)s_seg[0]), s1 = (u32)__builtin_amdgcn_readfirstlane((int)s_seg[1]);
+    if (s0 == 0xFFFFFFFFu || s1 == 0xFFFFFFFFu || (s1 > s0 && s1 - s0 > kLocCap)) {
+        if (threadIdx.x == 0) atomicAdd(&a.loc_stats[LOC_STAT_SURV_FAIL], 1u);
+        return;
+    }
+    if (s1 <= s0) return; // no group starts inside this tile
+    const u32 len = s1 - s0;
+    const u32 *Vb = Vl + s0;
+    const u32 wu = (u32)__builtin_amdgcn_readfirstlane((int)w);
+    const u32 posA = wu * 1024u, posB = kSortTile + wu * 1024u; // this wave's first position in either half
+    // ---- load: j, its group (a new one? bit 63 for now) and the rank of j + h
+    u32 gcount[2] = {0, 0};
+#pragma unroll 1
+    for (u32 half = 0; half < 2; ++half) {
+        const u32 pos0 = half ? posB : posA;
+        if (pos0 >= len) break;
+        u32 prev_last = 0;
+        if (l == 0 && pos0 > 0) prev_last = Rb[Vb[pos0 - 1u] & 0xFFFFFu] & ~kFinalBit;
+        const u32 rows = (len - pos0 + 63u) / 64u < 16u ? (len - pos0 + 63u) / 64u : 16u;
+        u32 tot = 0;
+#pragma unroll 4
+        for (u32 r = 0; r < rows; ++r) {
+            const u32 i = pos0 + r * 64u + l;
+            const u32 c = i < len ? i : len - 1u;
+            const u32 v = ld_stream(Vb + c) & 0xFFFFFu;
+            const u32 g = Rb[v] & ~kFinalBit;
+            u32 t = v + hm;
+            t = t >= n ? t - n : t;
+            const u32 k2 = Rb[t] & ~kFinalBit;
+            u32 pg = __shfl_up(g, 1, 64);
+            if (l == 0) pg = prev_last;
+            prev_last = __shfl(g, 63, 64);
+            const bool f = (i < len) && (i == 0 || g != pg);
+            if (i < len) s_e[i] = ((u64)(f ? 1u : 0u) << 63) | ((u64)k2 << 20) | (u64)v;
+            tot += (u32)__popcll(__ballot(f));
+        }
+        gcount[half] = tot;
+    }
+    if (l == 0) {
+        s_wsum[w] = gcount[0];
+        s_wsum[kLocWaves + w] = gcount[1];
+    }
+    __syncthreads();
+    u32 gcarryA = 0, gcarryB = 0, groups = 0;
+    for (u32 k = 0; k < kLocSets; ++k) {
+        const u32 c = s_wsum[k];
+        if (k < w) gcarryA += c;
+        if (k < kLocWaves + w) gcarryB += c;
+        groups += c;
+    }
+    const u64 le_mask = (l == 63) ? ~0ull : ((2ull << l) - 1ull);
+    constexpr u32 kbits = 20u;
+    const u32 gshift = 20u + kbits; // the group number sits right above the rank
+    const bool haveB = posB < len;  // (wave-uniform)
+    u64 eA[16], eB[16];
+    loc_fill(eA, s_e, posA, len, l, le_mask, gshift, gcarryA);
+    if (haveB) loc_fill(eB, s_e, posB, len, l, le_mask, gshift, gcarryB);
+    const u32 gbits = groups > 1u ? 32u - (u32)__builtin_clz(groups - 1u) : 0u;
+    const u32 npass = (kbits + gbits + kLocBits - 1u) / kLocBits;
+    u32 *cntA = s_cnt[w], *cntB = s_cnt[kLocWaves + w];
+    u16 *cnt16 = reinterpret_cast<u16 *>(&s_cnt[0][0]);
+#pragma unroll 1
+    for (u32 p = 0; p < npass; ++p) {
+        const u32 shift = 20u + p * kLocBits;
+        u32 rnkA[16], rnkB[16];
+        loc_rank(eA, rnkA, cntA, posA, len, l, shift);
+        if (haveB) loc_rank(eB, rnkB, cntB, posB, len, l, shift);
+        else {
+#pragma unroll
+            for (u32 q = 0; q < kLocBins / 2 / 64; ++q) cntB[q * 64u + l] = 0;
+        }
+        __syncthreads();
+        u32 tot;
+        {
+            const u32 dg = threadIdx.x; // (kLocThreads == kLocBins)
+            u32 run = 0;
+#pragma unroll
+            for (u32 k = 0; k < kLocSets; ++k) {
+                const u32 c = cnt16[k * kLocBins + dg];
+                cnt16[k * kLocBins + dg] = (u16)run;
+                run += c;
+            }
+            tot = run;
+        }
+        const u32 inc = wave_incl_sum(tot);
+        if (l == 63) s_wsum[w] = inc;
+        __syncthreads();
+        {
+            u32 carry = 0;
+            for (u32 k = 0; k < w; ++k) carry += s_wsum[k];
+            s_tpre[threadIdx.x] = (u16)(carry + inc - tot);
+        }
+        __syncthreads();
+        loc_move(eA, rnkA, cntA, s_tpre, s_e, posA, len, l, shift);
+        if (haveB) loc_move(eB, rnkB, cntB, s_tpre, s_e, posB, len, l, shift);
+        __syncthreads();
+        if (p + 1 < npass) {
+            loc_reload(eA, s_e, posA, len, l);
+            if (haveB) loc_reload(eB, s_e, posB, len, l);
+        }
+    }
+    // ---- out: (group, j) in the order found, checked
+    {
+        bool bad = false;
+        for (u32 i = threadIdx.x; i < len; i += kLocThreads) {
+            const u64 x = s_e[i];
+            if (i && (s_e[i - 1] >> 20) > (x >> 20)) bad = true;
+            const u32 v = (u32)x & 0xFFFFFu;
+            Vout[base + s0 + i] = v;
+            Kout[base + s0 + i] = Rb[v] & ~kFinalBit;
+        }
+        if (__ballot(bad) && l == 0) s_bad = 1u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_bad) atomicAdd(&a.loc_stats[LOC_STAT_SURV_FAIL], 1u);
+}
+
 // ---- group refinement, part 1: boundary flags over the sorted pair list ----------------
 // INIT: the list is all n rotations sorted by their first 2c symbols (one old group); K holds
 //       key(j) = symbols [0,c), the second half key(j+c) is re-read from the block (L2).
@@ -3324,6 +3498,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
     int rounds = 0;
     u32 slot = 0;
     bool period_done = false, pair_done = false;
+    bool surv_local_ok = true; // (no segment of a survivor round of this sort has overflowed LDS so far)
     u32 list_tiles = a.tiles; // (the first refinement ran on all of SA)
     while (true) {
         if (hipMemcpyAsync(h_active, a.active + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, st) !=
@@ -3476,6 +3651,23 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             // of rotation j+h (2 passes), then stably by their own group (2 passes): O(m) work
             hipLaunchKernelGGL(k_survivor_compact, grid_prev, dim3(kSortThreads), 0, st, a, lastV, fV);
             hipLaunchKernelGGL(k_copy_counts, dim3((a.nb + 255) / 256), dim3(256), 0, st, a.count, a.count2, a.nb);
+            // The list inside LDS, segment by segment (k_surv_local) -- unless BZ_SURV_LOCAL=0, or a segment of an earlier round
+            // of this sort did not fit: then, and when one of this round does not, the four global passes.
+            static const bool want_local_surv = !(getenv("BZ_SURV_LOCAL") && atoi(getenv("BZ_SURV_LOCAL")) == 0);
+            bool local_done = false;
+            // (only lists of less than an eighth of the rotations: text's are 7 % and 0.001 %; a list of 18 % -- the corpus "binary"
+            // behind its walk rounds -- still holds groups that do not fit, and the failed attempt costs 3 ms per 256 MiB)
+            if (want_local_surv && surv_local_ok && m * 8 < total_n) { // (cK, cV are free: the compaction above was the last reader of the old list)
+                u32 fails = 0;
+                (void)hipMemsetAsync(a.loc_stats + LOC_STAT_SURV_FAIL, 0, 4, st);
+                hipLaunchKernelGGL(k_surv_local, grid_list, dim3(kLocThreads), 0, st, a, step, fV, cK, cV);
+                if (hipMemcpyAsync(&fails, a.loc_stats + LOC_STAT_SURV_FAIL, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+                    return -1;
+                local_done = fails == 0;
+                if (!local_done) surv_local_ok = false;
+                if (bwt_trace) fprintf(stderr, "  survivor round inside LDS: %s\n", local_done ? "done" : "a segment did not fit or failed its check: the global passes");
+            }
+            if (!local_done) {
             // (the ranks a histogram kernel gathers are kept in the free key array for its scatter kernel: with few
             // survivors per block the rank arrays of the blocks in flight do not fit the L2, a gather costs a sector)
             radix_pass<SRC_SURV, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK, list_tiles);
@@ -3484,6 +3676,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof, nullptr, list_tiles);
             u32 *t = cK; cK = fK; fK = t;
             t = cV; cV = fV; fV = t;
+            }
         } else {
             // pass A walks all of SA (total_n), pass B and the refinement only the m survivors
             if (fused) {

@@ -15,7 +15,7 @@ LIB = os.path.join(ROOT, "rust-compression_amd", "libbz2_mi355x.so")
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 # kernels known to keep a few dwords on the stack (bytes); everything else must be 0
-ALLOWED = {"k_rle_cuts": 64, "k_phase_b_local": 16, "k_group_refine": 16, "k_huffman": 16}
+ALLOWED = {"k_rle_cuts": 64, "k_phase_b_local": 16, "k_surv_local": 16, "k_group_refine": 16, "k_huffman": 16}
 
 
 def code_objects(blob):
