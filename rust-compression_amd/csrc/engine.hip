@@ -363,7 +363,7 @@ static int cut_tables_prepare(bz_gpu_engine *g, u64 g_base, u64 total, u64 tb, u
     if (nsteps / 16u + 64u >= cut_seg_cap() || entries > (1ull << 26)) return BZ_OK;
     u64 g_lo, g_hi, centries;
     cut_groups(pl, &g_lo, &g_hi, &centries);
-    if (g->cut_step_t0.ensure((nsteps + 1) * 8) || g->cut_step_nt.ensure((nsteps + 1) * 4) || g->cut_step_w0.ensure((nsteps + 2) * 8) ||
+    if (g->cut_step_t0.ensure((nsteps + 1) * 8) || g->cut_step_nt.ensure((nsteps + 1) * 4) || g->cut_step_w0.ensure((nsteps + 2 + nsteps / 1024 + 4) * 8) ||
         g->cut_tab.ensure((entries + 1) * 4) || g->cut_comp.ensure((centries + 1) * 2)) {
         (void)hipGetLastError(); // (an allocation that failed is not an error of the encode: the chain kernel needs none of it)
         return BZ_OK;
