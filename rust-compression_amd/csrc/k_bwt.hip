@@ -41,6 +41,9 @@
 #include <cstdlib>
 #include <vector>
 
+#ifndef BZ_SYM_SPAN
+#define BZ_SYM_SPAN 8 // tiles per workgroup of k_block_symbols
+#endif
 namespace bzgpu {
 
 enum { SRC_TEXT = 0, SRC_PAIRS = 1, SRC_MM = 2, SRC_WALK = 3, SRC_SURV = 4, SRC_LISTG = 5,
@@ -3028,7 +3031,10 @@ __global__ __launch_bounds__(kSortThreads) void k_block_symbols(BwtArgs a, u32 *
     if (lb == 0xFFFFFFFFu) return;
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
-    const u32 start = tile * kSortTile;
+    // (eight tiles per workgroup: one tile is ONE 16-byte load per thread, and the reductions and atomics behind it cost more than
+    // the load -- 0.98 ms per GiB for a kernel that reads the image once)
+    constexpr u32 kSpan = (u32)BZ_SYM_SPAN * kSortTile;
+    const u32 start = tile * kSpan;
     if (start >= n) return;
     const u8 *text = a.rle + d.rle_off;
     const u8 *pt = a.ptext + (size_t)lb * kSlot;
@@ -3036,7 +3042,7 @@ __global__ __launch_bounds__(kSortThreads) void k_block_symbols(BwtArgs a, u32 *
     __syncthreads();
     // 16 bytes per load, from the 16-byte boundary in front of the tile (the image is padded at both ends of a block's
     // bytes by its neighbours or by the buffer's slack); four 64-bit sets, picked with selects
-    const u32 cnt = (n - start) < kSortTile ? (n - start) : kSortTile;
+    const u32 cnt = (n - start) < kSpan ? (n - start) : kSpan;
     const uintptr_t p0 = reinterpret_cast<uintptr_t>(text + start);
     const u32 lead = (u32)(p0 & 15u);
     const uint4 *src = reinterpret_cast<const uint4 *>(p0 - lead);
@@ -3389,7 +3395,7 @@ void launch_block_symbols(hipStream_t st, const BwtArgs &a, u32 *inuse_bits, u8 
 {
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
     (void)hipMemsetAsync(inuse_bits, 0, (size_t)a.nb * 8 * sizeof(u32), st);
-    hipLaunchKernelGGL(k_block_symbols, grid, dim3(kSortThreads), 0, st, a, inuse_bits);
+    hipLaunchKernelGGL(k_block_symbols, dim3((a.tiles + (u32)BZ_SYM_SPAN - 1u) / (u32)BZ_SYM_SPAN, xcd_grid_y(a.nb)), dim3(kSortThreads), 0, st, a, inuse_bits);
     hipLaunchKernelGGL(k_key_params, dim3(a.nb), dim3(256), 0, st, inuse_bits, sym_code, keyinfo);
     hipLaunchKernelGGL(k_pack_text, grid, dim3(kSortThreads), 0, st, a, a.ptext);
 }
