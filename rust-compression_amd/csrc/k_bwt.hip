@@ -41,10 +41,14 @@
 #include <cstdlib>
 #include <vector>
 
+#ifndef BZ_GH_SPAN
+#define BZ_GH_SPAN 8 // tiles per workgroup (and per entry of the digit counts) of k_ghist_text
+#endif
 #ifndef BZ_SYM_SPAN
 #define BZ_SYM_SPAN 8 // tiles per workgroup of k_block_symbols
 #endif
 namespace bzgpu {
+constexpr u32 kGhSpan = BZ_GH_SPAN;
 
 enum { SRC_TEXT = 0, SRC_PAIRS = 1, SRC_MM = 2, SRC_WALK = 3, SRC_SURV = 4, SRC_LISTG = 5,
        SRC_TEXTK = 6, SRC_WALKK = 7, SRC_MMK = 8, // ..K: keys stored by the histogram kernel of the pass
@@ -686,10 +690,12 @@ __global__ __launch_bounds__(kSortThreads) void k_ghist_text(BwtArgs a, u32 *__r
     u32 tile, lb;
     xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
+    // (kGhSpan tiles per workgroup and ONE set of counts for them: the counts of a tile are 12 KB for 8 KB of text, and
+    // k_ghist_scan read them all back -- 1.6 GB each way per GiB)
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
-    const u32 start = tile * kSortTile;
-    if (start >= n) return;
+    const u32 start0 = tile * kGhSpan * kSortTile;
+    if (start0 >= n) return;
     const u8 *text = a.rle + d.rle_off;
     const u8 *pt = a.ptext + (size_t)lb * kSlot;
     const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
@@ -698,20 +704,25 @@ __global__ __launch_bounds__(kSortThreads) void k_ghist_text(BwtArgs a, u32 *__r
     for (u32 i = threadIdx.x; i < 2 * NB2; i += kSortThreads) (&s_h2[0][0])[i] = 0;
     __syncthreads();
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
-    u32 key[16], val[16];
-    const u32 ok = fetch_rows<SRC_TEXT>(a, lb, pt, n, 0, nullptr, nullptr, start + w * 1024u + l, n, ki, key, val);
     const size_t base = (size_t)lb * kSlot;
+#pragma unroll 1
+    for (u32 sp = 0; sp < kGhSpan; ++sp) {
+        const u32 start = start0 + sp * kSortTile;
+        if (start >= n) break;
+        u32 key[16], val[16];
+        const u32 ok = fetch_rows<SRC_TEXT>(a, lb, pt, n, 0, nullptr, nullptr, start + w * 1024u + l, n, ki, key, val);
 #pragma unroll
-    for (u32 r = 0; r < 16; ++r) {
-        if ((ok >> r) & 1u) {
-            atomicAdd(&s_h0[l & 1u][key[r] & (NB0 - 1)], 1u);
-            atomicAdd(&s_h1[l & 1u][(key[r] >> B0) & (NB1 - 1)], 1u);
-            atomicAdd(&s_h2[l & 1u][(key[r] >> (B0 + B1)) & (NB2 - 1)], 1u);
-            if (Kstore) Kstore[base + start + w * 1024u + r * 64u + l] = key[r];
+        for (u32 r = 0; r < 16; ++r) {
+            if ((ok >> r) & 1u) {
+                atomicAdd(&s_h0[l & 1u][key[r] & (NB0 - 1)], 1u);
+                atomicAdd(&s_h1[l & 1u][(key[r] >> B0) & (NB1 - 1)], 1u);
+                atomicAdd(&s_h2[l & 1u][(key[r] >> (B0 + B1)) & (NB2 - 1)], 1u);
+                if (Kstore) Kstore[base + start + w * 1024u + r * 64u + l] = key[r];
+            }
         }
     }
     __syncthreads();
-    u32 *out = a.gh_tiles + ((size_t)lb * kTilesPerBlock + tile) * 3 * kMaxBins;
+    u32 *out = a.gh_tiles + ((size_t)lb * kTilesPerBlock + tile) * 3 * kMaxBins; // (entry `tile` holds the counts of kGhSpan tiles)
     for (u32 i = threadIdx.x; i < NB0; i += kSortThreads) out[i] = s_h0[0][i] + s_h0[1][i];
     for (u32 i = threadIdx.x; i < NB1; i += kSortThreads) out[kMaxBins + i] = s_h1[0][i] + s_h1[1][i];
     for (u32 i = threadIdx.x; i < NB2; i += kSortThreads) out[2 * kMaxBins + i] = s_h2[0][i] + s_h2[1][i];
@@ -721,13 +732,13 @@ __global__ __launch_bounds__(kSortThreads) void k_ghist_text(BwtArgs a, u32 *__r
 // ntiles_from_count: the tiles that hold counts are those of the list of length count[lb] (the
 // refinement that took them), else those of the block.  Sets count[lb] to the number of keys.
 __global__ __launch_bounds__(kSortThreads) void k_ghist_scan(BwtArgs a, u32 ndig, u32 nbins0, u32 nbins1, u32 nbins2,
-                                                             u32 ntiles_from_count)
+                                                             u32 ntiles_from_count, u32 span = 1u)
 {
     __shared__ u32 s_wsum[kSortThreads / 64];
     const u32 lb = blockIdx.x;
     const u32 n = a.blocks[lb].n;
     const u32 len = ntiles_from_count ? a.count[lb] : n;
-    const u32 ntiles = (len + kSortTile - 1) / kSortTile;
+    const u32 ntiles = ((len + kSortTile - 1) / kSortTile + span - 1u) / span; // (span: tiles per entry of the counts, k_ghist_text)
     const u32 *gt = a.gh_tiles + (size_t)lb * kTilesPerBlock * 3 * kMaxBins;
     u32 total0 = 0;
     for (u32 dpos = 0; dpos < ndig; ++dpos) {
@@ -3346,10 +3357,10 @@ static bool init_sort_fused(hipStream_t st, const BwtArgs &a, u64 total_n, Kerne
     // the digit counts of key(j), once: both init phases sort the same multiset of keys
     // (the keys are not kept: with the packed text a key costs one load, less than a stored key's write and read)
     int p = prof ? prof->begin(st, KID_GHIST_TEXT, total_n * 1) : -1;
-    hipLaunchKernelGGL((k_ghist_text<B0, B1, B2>), grid, dim3(kSortThreads), 0, st, a, (u32 *)nullptr);
+    hipLaunchKernelGGL((k_ghist_text<B0, B1, B2>), dim3((a.tiles + kGhSpan - 1u) / kGhSpan, xcd_grid_y(a.nb)), dim3(kSortThreads), 0, st, a, (u32 *)nullptr);
     if (prof) prof->end(st, p);
-    p = prof ? prof->begin(st, KID_GHIST_SCAN, (u64)a.nb * kTilesPerBlock * 3 * 1024 * 4) : -1;
-    hipLaunchKernelGGL(k_ghist_scan, dim3(a.nb), dim3(kSortThreads), 0, st, a, 3u, 1u << B0, 1u << B1, 1u << B2, 0u);
+    p = prof ? prof->begin(st, KID_GHIST_SCAN, (u64)a.nb * kTilesPerBlock * 3 * 1024 * 4 / kGhSpan) : -1;
+    hipLaunchKernelGGL(k_ghist_scan, dim3(a.nb), dim3(kSortThreads), 0, st, a, 3u, 1u << B0, 1u << B1, 1u << B2, 0u, kGhSpan);
     if (prof) prof->end(st, p);
     // phase A: order by key(j); phase B: walk it, order by key(j - c) -> 2c symbols
     // (tests) BZ_TEST_STALE_TICKETS=1: the ticket counters of the first pass already stand at a full launch's count (a
