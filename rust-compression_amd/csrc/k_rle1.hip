@@ -1087,9 +1087,11 @@ void launch_cut_steps(hipStream_t st, const CutPlan &pl, const RleBuffers &rb, c
     const u64 nsteps = pl.j_hi - pl.j_lo + 1u;
     if (nsteps == 0) return; // (cut_tables_prepare does not get here without steps)
     hipLaunchKernelGGL(k_cut_steps, dim3((u32)((nsteps + 255u) / 256u)), dim3(256), 0, st, pl, rb.tile_off, cb.step_t0, cb.step_nt);
-    // (the exclusive sum of the steps' tile counts: 2.8 M steps for the 1 189 blocks of a GiB.  One workgroup walking them
-    // 1024 at a time -- k_cut_steps_scan, rounds 4-5 -- took 1.5 ms with the rest of the chip idle; the three-kernel scan of
-    // the tile offsets does it in parallel.  The workgroup totals live behind step_w0's nsteps + 1 entries.)
+    // (the exclusive sum of the steps' tile counts, by the three-kernel scan of the tile offsets instead of one workgroup
+    // that walks the steps 1024 at a time (k_cut_steps_scan, rounds 4-5).  For the 1 189 blocks of a GiB there are about
+    // 1 200 steps and either form is microseconds of work; the kernel trace shows it at 1.5 ms only because it runs beside
+    // k_rle_scatter and waits for a CU -- nothing the step time sees.  The workgroup totals live behind step_w0's
+    // nsteps + 1 entries.)
     tiles_scan<false>(st, cb.step_nt, cb.step_w0, 0, nsteps, cb.step_w0 + nsteps + 2, 0ull, cb.step_w0 + nsteps, nullptr);
 }
 void launch_cut_tables(hipStream_t st, const CutPlan &pl, const u8 *d_in, u64 n_lim, const RleBuffers &rb, const CutBuffers &cb,
