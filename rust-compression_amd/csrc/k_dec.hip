@@ -1681,11 +1681,60 @@ __global__ __launch_bounds__(256) void k_dec_crc(DecArgs a, const u64 *__restric
 }
 
 // ---- launchers --------------------------------------------------------------------------------------------------
+// The same scan with FOUR byte positions per thread out of three aligned big-endian words (k_dec_scan loads seven single
+// bytes per position: 1.6 G byte loads for a 226 MB stream, 0.9 ms; round 5).  `in` must be 4-byte aligned.
+__global__ __launch_bounds__(256) void k_dec_scan4(const u8 *__restrict__ in, u64 nbytes, DecCand *__restrict__ cands,
+                                                    u32 cap, u32 *__restrict__ count)
+{
+    const u64 t = (u64)blockIdx.x * 256u + threadIdx.x;
+    const u64 p0 = t * 4u;
+    if (p0 >= nbytes) return;
+    const u32 *w = reinterpret_cast<const u32 *>(in);
+    const u64 nwords = (nbytes + 3u) / 4u;
+    const u32 r = (u32)(nbytes & 3u);
+    const u32 tail_mask = r ? ~(0xFFFFFFFFu >> (8u * r)) : 0xFFFFFFFFu;
+    u32 x[3];
+#pragma unroll
+    for (u32 k = 0; k < 3; ++k) {
+        const u64 i = t + k;
+        u32 v = 0;
+        if (i < nwords) {
+            v = __builtin_bswap32(w[i]);
+            if (i + 1 == nwords) v &= tail_mask;
+        }
+        x[k] = v;
+    }
+    const u64 hi = ((u64)x[0] << 32) | x[1];
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {
+        const u64 p = p0 + j;
+        if (p >= nbytes) break;
+        const u64 top = j ? ((hi << (8u * j)) | ((u64)x[2] >> (32u - 8u * j))) : hi; // the 64 bits from byte p on
+        const u64 wdw = top >> 8;                                                       // 56 of them
+#pragma unroll
+        for (u32 s = 0; s < 8; ++s) {
+            const u64 v = (wdw >> (8u - s)) & 0xFFFFFFFFFFFFull;
+            const u32 type = (v == kBlockMagic) ? 1u : (v == kEosMagic ? 2u : 0u);
+            if (type && p * 8 + s + 48 <= nbytes * 8) {
+                const u32 i = atomicAdd(count, 1u);
+                if (i < cap) {
+                    cands[i].bitpos = p * 8 + s;
+                    cands[i].type = type;
+                    cands[i].pad = 0;
+                }
+            }
+        }
+    }
+}
+
 void launch_dec_scan(hipStream_t st, const u8 *in, u64 nbytes, DecCand *cands, u32 cap, u32 *count)
 {
     (void)hipMemsetAsync(count, 0, 4, st);
     if (nbytes == 0) return;
-    hipLaunchKernelGGL(k_dec_scan, dim3((u32)((nbytes + 255) / 256)), dim3(256), 0, st, in, nbytes, cands, cap, count);
+    if ((reinterpret_cast<uintptr_t>(in) & 3u) == 0)
+        hipLaunchKernelGGL(k_dec_scan4, dim3((u32)(((nbytes + 3) / 4 + 255) / 256)), dim3(256), 0, st, in, nbytes, cands, cap, count);
+    else
+        hipLaunchKernelGGL(k_dec_scan, dim3((u32)((nbytes + 255) / 256)), dim3(256), 0, st, in, nbytes, cands, cap, count);
 }
 
 void launch_dec_blocks(hipStream_t st, const u8 *in, u64 nbytes, const DecCand *cands, u32 ncand, DecBlockInfo *info,
