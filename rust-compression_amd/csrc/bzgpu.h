@@ -383,12 +383,13 @@ struct BwtArgs {
     u32 *tickets;                    // [kSortEpochs][8] tile tickets per pass and XCD
     u32 *sort_err;                   // [1] a look-back that gave up
     u32 *epoch;                      // host: the engine's pass counter (1 .. kSortEpochs-1)
-    u8 *per_aux;                     // [nb][2 kMtfStride] bytes (the MTF stage's symbol buffer, free during the sort): the period round's
-                                     // pair verdict bytes [kSlot] and group bytes [kSlot], one per position of the survivor list
+    u8 *per_aux;                     // [nb][2 kMtfStride] bytes (the MTF stage's symbol buffer, free during the sort): a group byte and a
+                                     // link byte per position of the survivor list (k_survivor_compact, k_link_scan; k_bwt.hip)
     u32 per_keyshift;                // the period round's start-based keys are shifted down by this (10 when every listed distance of the
                                      // batch is at least 1024: the members of a group then differ above bit 10, ONE pass orders them)
-    u32 per_pairs;                   // != 0: BZ_PAIR_COMPARE=1 -- the period round orders groups of two by comparing them; the
-                                     //   verdict bytes then take the digit-count slot and the period tables the flag bytes'
+    u32 per_wide;                    // the period round under way sorts thirty-bit keys (per_ekey, k_bwt.hip)
+    u32 per_links;                   // != 0: small groups of survivors are ranked by direct comparison in the period round and in link
+                                     //   rounds behind it (BZ_LINK_ROUND=0: off)
     u32 *fused_state;                // host, per engine: [0] != 0: the fused passes misbehaved once and stay off for
                                      //   this engine, [1] sorts that fell back to the three-kernel passes
     u32 *tile_state_all;             // host: whole look-back buffer (cleared when the counter wraps)

@@ -704,9 +704,10 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
     x.tile_state_bytes = g->tile_state.cap;
     static const u32 want_fused = (getenv("BZ_ONESWEEP") && atoi(getenv("BZ_ONESWEEP")) == 0) ? 0u : 1u;
     x.fused = want_fused;
-    static const u32 want_pairs = (getenv("BZ_PAIR_COMPARE") && atoi(getenv("BZ_PAIR_COMPARE")) == 0) ? 0u : 1u; // (round 5: on by default)
-    x.per_pairs = want_pairs;
+    static const u32 want_links = (getenv("BZ_LINK_ROUND") && atoi(getenv("BZ_LINK_ROUND")) == 0) ? 0u : 1u;
+    x.per_links = want_links;
     x.per_keyshift = 0;
+    x.per_wide = 0;
     x.per_aux = reinterpret_cast<u8 *>(g->mtf.as<u16>() + (size_t)o * kMtfStride);
     return x;
 }

@@ -107,7 +107,6 @@ __device__ __forceinline__ u64 newbits_lane_word(const u64 *__restrict__ bits, s
 // (gh_tiles: 2.7 MB per block, which only the fused walk rounds use -- room for eight) or, without the fused passes or
 // with the pair comparison on (its verdict bytes live there), in the flag bytes' slot (room for three).
 constexpr u32 kPerWords = kSlot / 64u; // 14080 words of 64 positions
-constexpr u32 kPerGroupMax = 8;        // the largest group the period round ranks member by member
 constexpr u32 kPerSetBytes = 2u * kPerWords * 8u + ((kPerWords + 1u) * 4u + 7u) / 8u * 8u;
 static_assert((size_t)kPerK * kPerSetBytes <= (size_t)kTilesPerBlock * 3 * kMaxBins * 4, "the period tables do not fit the digit-count slot");
 __host__ __device__ __forceinline__ bool per_in_counts(const BwtArgs &a) { return a.gh_tiles != nullptr; }
@@ -157,18 +156,56 @@ __device__ __forceinline__ bool per_key_ascending(const BwtArgs &a, u32 lb, u32 
     return true;
 }
 
-// k_pair_compare's verdicts (the period round's groups of two), one byte per list position (0: not ordered here, 2: the smaller member, 3: the greater one), in the
-// digit counts' slot of the block, which only the fused walk rounds use
-__device__ __forceinline__ u8 *pair_bytes(const BwtArgs &a, u32 lb)
+// (round 6) STRETCHES with a short period.  A block that agrees with itself at a listed distance p NOT LARGER THAN THE DEPTH
+// REACHED holds stretches that repeat p bytes -- "ugh\n" thirty thousand times in libbzip2's sample3, cut into sixty
+// stretches by the changed bytes of the corpus "binary": four groups of 60 000 rotations each, a quarter of the block, whose
+// members agree for up to 7 KB.  The chain rule (neighbours a listed distance apart) orders such a group only when all its
+// members lie in ONE stretch.  But the order of ALL of them follows from where their stretches end: rotation x follows the
+// periodic pattern for e(x) = m(x) + p - x symbols (m(x): the first position at or behind x where the block differs from
+// itself shifted by p) and then reads T[m + p] where the pattern goes on with T[m].  Members of one group share `depth` >= p
+// symbols, so they follow the SAME pattern, and of two members with e(x) < e(y) the shorter one is the smaller iff its
+// deviation is downward (T[m + p] < T[m]) -- y still reads the pattern's symbol there.  So inside a group
+//     (down, e ascending, deviating byte) < (up, e descending, deviating byte)
+// is the true order of classes of members; members with the same class agree on e + 1 symbols and stay one group.  Exact,
+// no check needed (a member with e < depth shares its deviation with every other member of its group: one class).  The
+// key: up << 28 | (up ? 0xFFFFF - e : e) << 8 | byte -- thirty bits, three passes (a.per_wide; the host asks for them when
+// some block of the batch lists such a distance).  Whether a distance applies is a property of the GROUP (the first `depth`
+// symbols decide it), so all members of a group are keyed under the same distance: the first listed one that applies.
+__device__ __forceinline__ bool per_ekey(const BwtArgs &a, u32 lb, const u8 *__restrict__ text, u32 n, u32 depth, u32 x, u32 &key)
 {
-    return a.per_aux + (size_t)lb * kMtfStride * 2u;
+    const u32 kmax = per_kmax(a);
+    for (u32 i = 0; i < kmax; ++i) {
+        const u32 p = a.lin_p[(size_t)lb * kPerK + i];
+        if (p == 0u) break;
+        if (p > depth) continue;
+        const u32 m = per_first_mis(a, lb, i, x); // in [x, x + n)
+        const u32 e = m - x + p;
+        if (e < depth) continue;
+        u32 mp = (m >= n ? m - n : m) + p;
+        mp = mp >= n ? mp - n : mp;
+        const bool up = per_lt_at(a, lb, i, n, m);
+        const u32 ec = e < 0xFFFFFu ? e : 0xFFFFFu;
+        key = up ? ((1u << 28) | ((0xFFFFFu - ec) << 8) | (u32)text[mp]) : ((ec << 8) | (u32)text[mp]);
+        return true;
+    }
+    return false;
 }
-// (second half of round 5) a byte per list position for the members of SMALL groups: place inside the group | members << 4
-// (3 .. 15 members; 0: a larger group), left by k_survivor_compact, read by the period round's keys (fetch_rows<SRC_PERJ>)
-// (ONE byte per list position for both: 0 nothing, 2 / 3 a pair's verdict, >= 0x30 a member of a group of three and more)
+
+// (round 6) SMALL groups of the survivor list -- 2 .. kLinkMax members -- are ranked member by member from direct comparisons
+// of their rotations (k_link_scan), whatever the distances between the copies.  Two byte arrays per block, one byte per
+// position of the compacted list, in the MTF stage's symbol buffer (free during the sort):
+//   group_bytes  place inside the group | members << 4 (k_survivor_compact; 0: not a member of a small group); k_link_keys
+//                turns a ranked member's byte into 2 + rank and every other one into 0 for the period round's keys
+//   link_bytes   comparisons with the other members that are decided << 4 | members found smaller (k_link_scan, atomic adds)
+constexpr u32 kLinkMax = 8; // the largest group ranked member by member (two nibbles per member: counts up to 7)
+static_assert(kLinkMax == 8 && kMtfStride >= kSlot + 8, "link_rank reads a group's eight link bytes with one load");
 __device__ __forceinline__ u8 *group_bytes(const BwtArgs &a, u32 lb)
 {
     return a.per_aux + (size_t)lb * kMtfStride * 2u;
+}
+__device__ __forceinline__ u8 *link_bytes(const BwtArgs &a, u32 lb)
+{
+    return a.per_aux + (size_t)lb * kMtfStride * 2u + kMtfStride;
 }
 
 // Batched form: the 16 rows of one lane.  All primary loads are issued back to back (clamped
@@ -275,89 +312,25 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
         // the period round: order the survivors by where they start -- ascending or descending, as the first
         // difference between the block and the block shifted by its period decides for each of them (per_ascending)
         const u32 p = a.lin_p[(size_t)lb * kPerK]; // (hm: the depth reached, in symbols; 0: the block has no listed distance)
-        const u8 *pb8 = (a.gh_tiles && a.per_aux && a.per_pairs) ? pair_bytes(a, lb) : nullptr;
-        u32 pairv[ROWS];
+        // (round 6) a member of a SMALL group that k_link_scan has ranked is keyed by its exact rank inside the group
+        // (k_link_keys left 2 + rank in its byte); k_period_mark leaves such groups alone (impure = 2)
+        const u8 *gb8 = (a.per_aux && a.per_links) ? group_bytes(a, lb) : nullptr;
+        u32 gbv[ROWS];
 #pragma unroll
         for (u32 r = 0; r < (u32)ROWS; ++r) {
             const u32 idx = first + r * 64u;
             const u32 c = idx < cnt ? idx : cnt - 1u;
             val[r] = ld_stream(Vin + base + c);
-            pairv[r] = pb8 ? pb8[c] : 0u; // (2 / 3: a pair's verdict; >= 0x30: the byte of a small group's member)
+            gbv[r] = gb8 ? gb8[c] : 0u;
             ok |= (idx < cnt ? 1u : 0u) << r;
         }
-        // (second half of round 5) a SMALL group -- 3 .. kPerGroupMax members, every pair of them a listed distance apart -- is
-        // keyed by the member's exact RANK inside it: rot(x) < rot(x + d) is one look at the tables of distance d, so a
-        // member counts the members below it.  The heuristic direction above orders a group of copies only when their
-        // order happens to be that of their starts (or the reverse); three copies are in mixed order half of the time (the
-        // corpus "binary": 43 % of its rotations sit in groups of three and four at 32 symbols).  k_period_mark checks the
-        // neighbours of the sorted list as before: a wrong rank costs a round, never a byte.
-        // (a block without any small group -- a paragraph repeated has none -- skips the bytes: the compaction leaves a flag in
-        // the last byte of the block's slot of the round's "impure" marks, which the host clears in front of it)
-        const u8 *gb8 = (pb8 && p != 0u && a.ptext[base + kSlot - 1u]) ? group_bytes(a, lb) : nullptr;
-        u32 lp[kPerK];
-        {
-            const u32 kmax = per_kmax(a);
-#pragma unroll
-            for (u32 i = 0; i < kPerK; ++i) lp[i] = (gb8 && i < kmax) ? a.lin_p[(size_t)lb * kPerK + i] : 0u;
-        }
 #pragma unroll
         for (u32 r = 0; r < (u32)ROWS; ++r) {
-            if (pairv[r] == 2u || pairv[r] == 3u) {
-                key[r] = pairv[r] & 1u; // a group of two, ordered by k_pair_compare
-                continue;
-            }
-            key[r] = ((p != 0u && !per_key_ascending(a, lb, n, hm, val[r])) ? (n - 1u - val[r]) : val[r]) >> a.per_keyshift;
-            if (!gb8) continue;
-            const u32 idx = first + r * 64u;
-            if (idx >= cnt) continue;
-            const u32 gi = pairv[r];
-            const u32 sz = gi >> 4, off = gi & 15u;
-            if (sz < 3u || sz > kPerGroupMax || off >= sz || idx < off || idx - off + sz > cnt) continue;
-            const u32 g0 = idx - off;
-            const u32 j = val[r];
-            u32 mem[kPerGroupMax];
-#pragma unroll
-            for (u32 t = 0; t < kPerGroupMax; ++t) mem[t] = t < sz ? Vin[base + g0 + t] : 0u;
-            bool all = true;
-            u32 rank = 0;
-#pragma unroll
-            for (u32 t = 0; t < kPerGroupMax; ++t) {
-                if (t >= sz) break;
-#pragma unroll
-                for (u32 u = t + 1u; u < kPerGroupMax; ++u) {
-                    if (u >= sz) break;
-                    const u32 x = mem[t] < mem[u] ? mem[t] : mem[u], y = mem[t] < mem[u] ? mem[u] : mem[t];
-                    const u32 dd = y - x;
-                    u32 which = kPerK;
-#pragma unroll
-                    for (u32 i = 0; i < kPerK; ++i)
-                        if (lp[i] != 0u && lp[i] == dd) which = i;
-                    if (which == kPerK) {
-                        all = false;
-                    } else if (x == j || y == j) { // rot(x) < rot(y)?
-                        const bool lt = per_lt_at(a, lb, which, n, per_first_mis(a, lb, which, x));
-                        rank += (y == j) ? (lt ? 1u : 0u) : (lt ? 0u : 1u);
-                    }
-                }
-            }
-            if (all) key[r] = rank;
-#ifdef BZ_PERJ_DEBUG
-            atomicAdd(&a.loc_stats[60], 1u);
-            if (all) atomicAdd(&a.loc_stats[61], 1u);
-            atomicAdd(&a.loc_stats[62 + (sz < 9u ? sz - 3u : 5u)], 1u);
-#endif
+            u32 ek;
+            if (gbv[r] >= 2u && gbv[r] < 2u + kLinkMax) key[r] = gbv[r] - 2u;
+            else if (a.per_wide && p != 0u && per_ekey(a, lb, a.rle + a.blocks[lb].rle_off, n, hm, val[r], ek)) key[r] = ek;
+            else key[r] = ((p != 0u && !per_key_ascending(a, lb, n, hm, val[r])) ? (n - 1u - val[r]) : val[r]) >> a.per_keyshift;
         }
-#ifdef BZ_PERJ_DEBUG
-#pragma unroll
-        for (u32 r = 0; r < (u32)ROWS; ++r) {
-            const u32 idx = first + r * 64u;
-            if (idx < cnt) {
-                atomicAdd(&a.loc_stats[70], 1u);
-                if (pairv[r]) atomicAdd(&a.loc_stats[71], 1u);
-                if (gb8 && gb8[idx]) atomicAdd(&a.loc_stats[72], 1u);
-            }
-        }
-#endif
     } else if (SRC == SRC_LISTG) {
         // survivor round, second half: walk that order, key = the survivor's own group
 #pragma unroll
@@ -1683,18 +1656,24 @@ __global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 ste
             if (need_prev) ps20 = pkey(pt, pj, ki.bits, ki.chars);
         } else if (impure) {
             const bool per = a.lin_p[(size_t)lb * kPerK] != 0u;
+            const u64 d64 = ((u64)ki.chars * 2u) << step;
+            const u32 depth = d64 < n ? (u32)d64 : n;
             // every member of a group the round has put in order becomes a group of its own: a chain of the block's
-            // period (impure 0 in a block that has one) or a group of two ordered by comparison (impure 2)
+            // period (impure 0 in a block that has one) or a small group ranked by comparison (impure 2); a group of
+            // stretches with a short period (impure 1, per_ekey applies) splits into its classes, which the list holds
+            // in their true order
 #pragma unroll
             for (u32 r = 0; r < 16; ++r) {
                 const u32 jr = jj[r] >= hm ? jj[r] - hm : jj[r] + n - hm; // (the rotation itself)
                 const u32 im = impure[base + g[r]];
-                s1[r] = (im == 2u || (per && im == 0u)) ? jr + 1u : 0u;
+                u32 ek;
+                s1[r] = (im == 2u || (per && im == 0u)) ? jr + 1u : ((per && a.per_wide && per_ekey(a, lb, text, n, depth, jr, ek)) ? ek + 1u : 0u);
             }
             if (need_prev) {
                 const u32 jr = pj >= hm ? pj - hm : pj + n - hm;
                 const u32 im = impure[base + pg0];
-                ps10 = (im == 2u || (per && im == 0u)) ? jr + 1u : 0u;
+                u32 ek;
+                ps10 = (im == 2u || (per && im == 0u)) ? jr + 1u : ((per && a.per_wide && per_ekey(a, lb, text, n, depth, jr, ek)) ? ek + 1u : 0u);
             }
         } else {
 #pragma unroll
@@ -2377,13 +2356,12 @@ __global__ __launch_bounds__(kSortThreads) void k_rank_place(BwtArgs a, const u3
 // The list (V, flags) a round has just refined -> the rotations that are still not final, in the
 // same order (i.e. sorted by their new group head).  Used when few survive: the next round then
 // sorts the survivors explicitly instead of walking all of SA.
-// mate / midx != nullptr (the period round and the pair round): every group of exactly TWO survivors -- a new-group start, no
-// start behind it, a start behind that: read off the bitmap the compaction reads anyway -- leaves mate[smaller start] = larger
-// start and midx[smaller start] = its place in the compacted list | (the smaller start stands first) << 31 for k_pair_scan
-// (a kernel of its own found the same pairs with four random gathers of the rank array per list entry: 13 ms per GiB).
+// midx != nullptr (the period round and the link rounds): every member of a SMALL group of survivors (2 .. kLinkMax members:
+// the place inside the group and its size are read off the start bits the compaction reads anyway) leaves
+// midx[its start] = its place in the compacted list | place inside the group << 20 | members << 24 (the host cleared the
+// array: 0 = not such a member) and its group byte.
 __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, const u32 *__restrict__ V,
-                                                                    u32 *__restrict__ VS, u32 *__restrict__ mate = nullptr,
-                                                                    u32 *__restrict__ midx = nullptr)
+                                                                    u32 *__restrict__ VS, u32 *__restrict__ midx = nullptr)
 {
     constexpr u32 NW = kSortThreads / 64;
     __shared__ u32 s_off, s_wsum[NW];
@@ -2423,9 +2401,9 @@ __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, co
 #pragma unroll
         for (u32 r = 0; r < 17; ++r) mn[r] = wave_lane64(myword, r);
     }
-    // (the period round) the starts of the 64 elements in front of the wave's span: a group may begin there
-    const u64 mn_prev = (mate && wbase >= 64u) ? a.newbits[(base + wbase - 64u) >> 6] : 0ull;
-    u8 *gb8 = mate ? group_bytes(a, lb) : nullptr;
+    // (links) the starts of the 64 elements in front of the wave's span: a group may begin there
+    const u64 mn_prev = (midx && wbase >= 64u) ? a.newbits[(base + wbase - 64u) >> 6] : 0ull;
+    u8 *gb8 = midx ? group_bytes(a, lb) : nullptr;
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
         const u32 idx = wbase + r * 64u + l;
@@ -2443,42 +2421,28 @@ __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, co
     u32 off = s_off;
     for (u32 k = 0; k < w; ++k) off += s_wsum[k];
     const u64 lt_mask = (l == 0) ? 0ull : (~0ull >> (64 - l));
+    bool any_small = false;
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
         const u32 at = off + (u32)__popcll(surv[r] & lt_mask);
         if ((surv[r] >> l) & 1ull) VS[base + at] = jv[r];
-        if (mate && ((surv[r] >> l) & 1ull)) {
-            // place inside its group and the group's size, from the start bits around the element (groups of 3 .. 15)
+        if (midx && ((surv[r] >> l) & 1ull)) {
+            // place inside its group and the group's size, from the start bits around the element
             const u64 cur = mn[r], prv = r ? mn[r - 1] : mn_prev, nxw = mn[r + 1];
             const u64 lo = (l == 63u) ? cur : ((cur << (63u - l)) | (prv >> (l + 1u)));
             const u64 hi = (l == 63u) ? nxw : ((cur >> (l + 1u)) | (nxw << (63u - l)));
             const u32 back = lo ? (u32)__clzll(lo) : 64u, fwd = hi ? (u32)__builtin_ctzll(hi) + 1u : 65u;
             const u32 size = back + fwd;
-            const bool small = size >= 3u && size <= 15u;
-            gb8[at] = small ? (u8)(back | (size << 4)) : (u8)0; // (k_pair_scan / k_pair_compare fill in the pairs' verdicts: no memset of the bytes on the host)
-            if (size == 2u) a.ptext[base + kSlot - 2u] = 1; // the block has groups of two: k_pair_scan looks at it
-            if (small && size <= kPerGroupMax) a.ptext[base + kSlot - 1u] = 1; // (read by the keys of the period round, see fetch_rows<SRC_PERJ>)
-        }
-        if (mate) {
-            // first member of a group of two: a start here, none at the next element, one at the element behind that
-            const u32 idx = wbase + r * 64u + l;
-            const bool is_new = (mn[r] >> l) & 1ull;
-            const bool n1 = idx + 1u >= cnt ? true : (l < 63u ? (mn[r] >> (l + 1u)) & 1ull : mn[r + 1] & 1ull);
-            const bool n2 = idx + 2u >= cnt ? true : (l < 62u ? (mn[r] >> (l + 2u)) & 1ull : (mn[r + 1] >> (l - 62u)) & 1ull);
-            // the partner's rotation: the next lane's, the next row's lane 0, or -- behind the wave's span -- one load
-            u32 partner = (u32)__shfl_down((int)jv[r], 1, 64);
-            const u32 nextrow0 = r + 1 < 16 ? wave_lane(jv[(r + 1) & 15], 0) : 0u;
-            if (l == 63u) partner = r + 1 < 16 ? nextrow0 : (idx + 1u < cnt ? (ld_stream(V + base + idx + 1u) & 0xFFFFFu) : 0u);
-            if (idx + 1u < cnt && is_new && !n1 && n2) {
-                const u32 va = jv[r], vb = partner;
-                const u32 lo = va < vb ? va : vb, hi = va < vb ? vb : va;
-                mate[base + lo] = hi;
-                midx[base + lo] = at | (va == lo ? 0x80000000u : 0u);
-                atomicOr(reinterpret_cast<u32 *>(a.flags + base) + (lo >> 5), 1u << (lo & 31u));
+            const bool small = size >= 2u && size <= kLinkMax;
+            gb8[at] = small ? (u8)(back | (size << 4)) : (u8)0;
+            if (small) {
+                midx[base + jv[r]] = at | (back << 20) | (size << 24); // (never 0: the host cleared the array, 0 = no member)
+                any_small = true;
             }
         }
         off += (u32)__popcll(surv[r]);
     }
+    if (any_small) a.ptext[base + kSlot - 2u] = 1; // the block has small groups: k_link_scan and k_link_keys look at it
 }
 
 __global__ void k_copy_counts(u32 *__restrict__ dst, const u32 *__restrict__ src, u32 nb)
@@ -2564,7 +2528,7 @@ __global__ __launch_bounds__(kSortThreads) void k_periodic_place(BwtArgs a)
 //   k_period_bits  the two bitmaps;  k_period_next  first mismatch at or behind every 64-position word
 __global__ __launch_bounds__(kSortThreads) void k_period_find(BwtArgs a, u32 quarters)
 {
-    constexpr u32 kAnchors = 32;
+    constexpr u32 kLongAnchors = 32, kShortAnchors = 64, kShortMax = 64, kAnchors = kLongAnchors + kShortAnchors;
     __shared__ u32 s_best, s_cand[kAnchors], s_agree[kAnchors];
     const u32 lb = blockIdx.x, tid = threadIdx.x;
     const BlockDesc d = a.blocks[lb];
@@ -2575,19 +2539,29 @@ __global__ __launch_bounds__(kSortThreads) void k_period_find(BwtArgs a, u32 qua
         a.lin_sig[(size_t)lb * kPerK + tid] = 0;
     }
     // (count2: the survivors of the last refinement, k_survivor_compact) only blocks that are deep in repeats
-    if (n < 256u || (u64)a.count2[lb] * 4u < (u64)n * quarters) return; // (the second period round: a quarter of the block)
+    // (round 6: the SHORT distances are looked for in every block that has a sixteenth of its rotations left -- a block may
+    // hold one stretch of "ugh\n" x 13 000 and nothing else that repeats; the search costs one trip)
+    if (n < 256u || (u64)a.count2[lb] * 16u < (u64)n) return;
+    const bool deep_block = (u64)a.count2[lb] * 4u >= (u64)n * quarters;
     // Round 5: up to kPerK distances per block instead of one.  Data whose copies DRIFT (a file and an edited copy of it,
     // a tar of similar files; the corpus "binary": RLE1 turns a changed byte into a shift) agrees with itself at five to
     // seven distances per block, none of them over half of it: thirty-two anchors over the first half of the block each
     // name the distance at which their 16 bytes recur first, and the candidates with the widest agreement are listed.
-    for (u32 k = 0; k < kAnchors; ++k) { // (uniform)
-        const u32 at = (u32)(((u64)n * (k + 1u)) / (2u * (kAnchors + 1u))); // 1.5 % .. 48.5 % of the block: room for distances beyond n / 2
+    for (u32 k = 0; k < kLongAnchors; ++k) { // (uniform)
+        if (!deep_block) {
+            if (tid == 0) s_cand[k] = 0xFFFFFFFFu;
+            continue;
+        }
+        const u32 at = (u32)(((u64)n * (k + 1u)) / (2u * (kLongAnchors + 1u))); // 1.5 % .. 48.5 % of the block: room for distances beyond n / 2
         u64 h0, h1;
         __builtin_memcpy(&h0, text + at, 8);
         __builtin_memcpy(&h1, text + at + 8, 8);
         if (tid == 0) s_best = 0xFFFFFFFFu;
         __syncthreads();
-        const u32 last = n - 16u - at; // the farthest shift that keeps the 16 bytes inside the block
+        // the farthest shift that keeps the 16 bytes inside the block -- and (round 6) not beyond an eighth of it: stretches that far
+        // apart make groups of eight members at most, which k_link_scan ranks whatever their distances; the chains of a listed
+        // distance are for the groups of MANY copies (a paragraph repeated).  An anchor without a hit costs a pass over its range.
+        const u32 last = (n - 16u - at) < (n >> 3) ? (n - 16u - at) : (n >> 3);
         // (four shifts per thread and trip, their loads in flight together; the second half of the 16 bytes is only
         // looked at where the first agrees: a block without a repeat reads 8 bytes per shift and anchor, not 16)
         // (s_best is read through a volatile pointer: without it the compiler keeps the first value in a register, no thread
@@ -2620,6 +2594,25 @@ __global__ __launch_bounds__(kSortThreads) void k_period_find(BwtArgs a, u32 qua
         if (tid == 0) s_cand[k] = s_best;
         __syncthreads();
     }
+    // (round 6) SHORT distances -- stretches that repeat a few bytes ("ugh\n" x 30 000), whose groups per_ekey splits by where
+    // the stretches end -- are looked for all over the block, not only in its first half: sixty-four more anchors, shifts of
+    // 1 .. kShortMax only (one trip: a wave per anchor, a lane per shift).  Such a stretch may be a twentieth of the block.
+    for (u32 k = tid >> 6; k < kShortAnchors; k += kSortThreads / 64u) {
+        const u32 at = (u32)(((u64)n * (2u * k + 1u)) / (2u * kShortAnchors));
+        const u32 q = (tid & 63u) + 1u;
+        bool hit = false;
+        if (at + q + 16u <= n && q <= kShortMax) {
+            u64 h0, h1, x0, x1;
+            __builtin_memcpy(&h0, text + at, 8);
+            __builtin_memcpy(&h1, text + at + 8, 8);
+            __builtin_memcpy(&x0, text + at + q, 8);
+            __builtin_memcpy(&x1, text + at + q + 8, 8);
+            hit = x0 == h0 && x1 == h1;
+        }
+        const u64 hits = __ballot(hit);
+        if ((tid & 63u) == 0u) s_cand[kLongAnchors + k] = hits ? (u32)__builtin_ctzll(hits) + 1u : 0xFFFFFFFFu;
+    }
+    __syncthreads();
     // The candidates worth a look: the distinct ones, by the number of anchors that named them, a dozen at most (an anchor
     // inside a run of equal bytes answers "1", one inside a short inner repeat answers that repeat's distance; text has such
     // repeats everywhere, and every candidate looked at costs a pass over the block -- the first build of this kernel looked
@@ -2719,13 +2712,14 @@ __global__ __launch_bounds__(kSortThreads) void k_period_find(BwtArgs a, u32 qua
             for (u32 k = 0; k < kAnchors; ++k) {
                 const u32 c = s_cand[k], ag = s_agree[k];
                 if (c == 0xFFFFFFFFu || ag == 0u || ag >= n) continue;
+                if ((u64)ag * (c <= kShortMax ? 128u : 16u) < n) continue; // (a short period is worth its tables at a 128th of the block)
                 if (ag > best || (ag == best && c < bp)) {
                     best = ag;
                     bp = c;
                     bi = k;
                 }
             }
-            if (bi == 0xFFFFFFFFu || (u64)best * 16u < n) break;
+            if (bi == 0xFFFFFFFFu) break;
             a.lin_p[(size_t)lb * kPerK + listed] = bp;
             a.lin_sig[(size_t)lb * kPerK + listed] = (u32)(((u64)best * 1000u) / n); // (for the trace: agreement in permille)
             ++listed;
@@ -2823,90 +2817,33 @@ __global__ __launch_bounds__(kSortThreads) void k_period_next(BwtArgs a)
     }
 }
 
-// ---- groups of TWO: ordered by comparing the two rotations themselves ---------------------------------------------------
-// Data that holds a stretch twice (a file and its copy inside one block; the corpus "binary": the reference's fixtures
-// tiled with a byte changed every 4 KiB) leaves, after the first rounds, almost every rotation in a group of two whose
-// members agree for kilobytes: eight more doubling rounds over the whole block to find out what one look at the two
-// texts tells -- they are 0.9 MB, they sit in the L2.  In the period round (the round that runs when some block is
-// deep in repeats) a lane takes every group of exactly two members of the survivor list, compares the two rotations
-// from the depth reached on, sixteen bytes a step (cyclic; at most kPairCap bytes, then it gives up and the group goes
-// on doubling), and leaves the verdict in a byte per list position (pair_bytes).  SRC_PERJ keys such members by it, k_period_mark leaves their group alone (impure = 2) and the
-// refinement makes both final.  The comparison is the definition of the order (sais.rs:266-272 fixes nothing else).
-constexpr u32 kPairCap = 1u << 16;
-__global__ __launch_bounds__(kSortThreads) void k_pair_compare(BwtArgs a, u32 step, const u32 *__restrict__ V, u8 *__restrict__ impure)
-{
-    u32 tile, lb;
-    xcd_remap(gridDim.x, a.nb, tile, lb);
-    if (lb == 0xFFFFFFFFu) return;
-    const BlockDesc d = a.blocks[lb];
-    const u32 n = d.n;
-    const u32 cnt = a.count[lb];
-    const u32 start = tile * kSortTile;
-    if (start >= cnt || n < 64u || (u64)cnt * 4u < (u64)n * 3u) return; // (only blocks that are deep in repeats)
-    const u8 *__restrict__ text = a.rle + d.rle_off;
-    const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
-    const u64 d64 = ((u64)ki.chars * 2u) << step;
-    const u32 depth = d64 < n ? (u32)d64 : n;
-    const size_t base = (size_t)lb * kSlot;
-    for (u32 idx = start + threadIdx.x; idx + 1u < cnt && idx < start + kSortTile; idx += kSortThreads) {
-        const u32 va = V[base + idx] & 0xFFFFFu, vb = V[base + idx + 1u] & 0xFFFFFu;
-        const u32 g = a.R[base + va] & ~kFinalBit;
-        if ((a.R[base + vb] & ~kFinalBit) != g) continue;
-        if (idx > 0 && (a.R[base + (V[base + idx - 1u] & 0xFFFFFu)] & ~kFinalBit) == g) continue;   // not the group's first
-        if (idx + 2u < cnt && (a.R[base + (V[base + idx + 2u] & 0xFFFFFu)] & ~kFinalBit) == g) continue; // three or more
-        // the first difference behind the `depth` symbols the two are known to share
-        u32 pa = va + depth, pb = vb + depth;
-        pa = pa >= n ? pa - n : pa;
-        pb = pb >= n ? pb - n : pb;
-        int verdict = 0; // -1: a < b, +1: a > b, 0: undecided
-        for (u32 done = 0; done < kPairCap && done + depth < n && verdict == 0;) {
-            const u32 room = n - (pa > pb ? pa : pb); // bytes before the first of the two wraps
-            if (room >= 16u) {
-                u64 x0, x1, y0, y1;
-                __builtin_memcpy(&x0, text + pa, 8);
-                __builtin_memcpy(&x1, text + pa + 8, 8);
-                __builtin_memcpy(&y0, text + pb, 8);
-                __builtin_memcpy(&y1, text + pb + 8, 8);
-                if (x0 != y0) verdict = __builtin_bswap64(x0) < __builtin_bswap64(y0) ? -1 : 1;
-                else if (x1 != y1) verdict = __builtin_bswap64(x1) < __builtin_bswap64(y1) ? -1 : 1;
-                pa += 16u;
-                pb += 16u;
-                done += 16u;
-            } else { // (near the block's end: byte by byte across the wrap)
-                for (u32 k = 0; k < 16u && verdict == 0; ++k) {
-                    const u8 x = text[pa], y = text[pb];
-                    if (x != y) verdict = x < y ? -1 : 1;
-                    pa = pa + 1u == n ? 0u : pa + 1u;
-                    pb = pb + 1u == n ? 0u : pb + 1u;
-                }
-                done += 16u;
-            }
-            if (pa >= n) pa -= n;
-            if (pb >= n) pb -= n;
-        }
-        if (verdict == 0) continue; // (equal as far as looked: a periodic block, or a repeat longer than the cap)
-        u8 *pb8 = pair_bytes(a, lb);
-        pb8[idx] = verdict > 0 ? 3 : 2;
-        pb8[idx + 1u] = verdict < 0 ? 3 : 2;
-        impure[base + g] = 2;
-    }
-}
-
-// ---- groups of TWO, round 5: one scan per STRETCH of pairs instead of one per pair -----------------------------------------
-// k_pair_compare above gives every group of two a lane that reads both rotations until they differ: 2-4 KB per pair on data
-// whose copies agree that far, 270 GB out of the L2 per 256 MiB, 70 ms.  But the pairs of a copied stretch share their
-// difference: pairs (x, x + d) and (x + 1, x + 1 + d) agree up to the SAME position m -- the first m at or behind the later
-// start + depth with T[m] != T[m + d] -- whatever d is and however many distances a block has (copies that DRIFT: every
-// changed byte that RLE1 turns into a shift starts a new d).  So:
-//   k_survivor_compact  every group of exactly two members of the survivor list (it sees the groups' starts in the bitmap it
-//                compacts by) leaves mate[lo] = hi and the place of the pair in the list, indexed by its smaller START;
-//   k_pair_scan  walks the block in TEXT order, a wave per 64 consecutive starts: the lanes whose pairs lie the same distance
-//                apart are resolved together -- the wave compares 512 bytes of T and of T shifted by d per step, eight per
-//                lane, until a difference turns up, and every pair whose known-equal prefix ends in front of it takes it
-//                (the pairs behind it go on from there).  One verdict byte per list position, as k_pair_compare writes them.
-// The comparison is the definition of the order (sais.rs:266-272 fixes nothing else); 14 K waves per block read ~2 KB each.
-constexpr u32 kPairNone = 0xFFFFFFFFu;
-__device__ __forceinline__ u64 pair_load8(const u8 *__restrict__ text, u32 n, u32 p) // eight bytes from p on, cyclic (p < n)
+// ---- SMALL groups: ranked member by member from direct comparisons, one scan per STRETCH of copies ----------------------------
+// Data that holds a stretch several times (a file and edited copies of it, a tar of similar files; the corpus "binary": the
+// reference's fixtures tiled with a byte changed every 4 KiB, and the fixtures repeat inside themselves) leaves, after the
+// first rounds, almost every rotation in a group of two to four whose members agree for kilobytes: eight and more doubling
+// rounds over the whole block to find out what one look at the texts tells -- they are 0.9 MB, they sit in the L2.  And the
+// comparisons of a copied stretch are SHARED: rotations x and y = x + d agree up to the same position m as x + 1 and
+// y + 1 do -- the first m at or behind the later start + depth with T[m] != T[m + d] -- whatever d is and however many
+// distances a block has (copies that DRIFT: every changed byte that RLE1 turns into a shift starts a new d).  So:
+//   k_survivor_compact  every member of a group of 2 .. kLinkMax survivors leaves its place in the list under its START;
+//   k_link_scan  walks the block in TEXT order, a wave per 64 consecutive starts.  A lane whose start x is such a member
+//                reads its group and takes the members that start behind x one after the other, nearest first; the
+//                lanes whose partner lies the same distance away are resolved together -- the wave compares 512 bytes of
+//                T and of T shifted by d per step, eight per lane, until a difference turns up, and every lane whose
+//                known-equal prefix ends in front of it takes it (the lanes behind it go on from there).  EVERY pair of
+//                members is compared (by the member with the smaller start): a chain of neighbours in start order would
+//                do for most groups, but a copy with a changed byte between two that agree beyond it leaves the two
+//                undecided -- and that is exactly what drifting copies look like.  A decided comparison adds 1 to the
+//                "decided" nibble of both members' link bytes and 1 to the "members below" nibble of the greater one;
+//   k_link_keys  a group all of whose members have all their comparisons decided is ordered: member -> 2 + rank in its
+//                group byte (the period round's keys), impure[group] = 2 (k_period_mark leaves it alone, the refinement
+//                makes every member a group of its own);
+//   k_link_permute  the same for a LINK round (no period tables, no radix passes: the list is in group order already and
+//                a ranked member's place is the group's first place + its rank).
+// The comparison is the definition of the order (sais.rs:266-272 fixes nothing else); a group that is not decided (equal
+// rotations, more stretches in one row of starts than kLinkTries) goes on doubling.
+constexpr u32 kLinkTries = 8;      // stretches per row of 64 starts and partner
+__device__ __forceinline__ u64 link_load8(const u8 *__restrict__ text, u32 n, u32 p) // eight bytes from p on, cyclic (p < n)
 {
     u64 v;
     if (p + 8u <= n) {
@@ -2921,9 +2858,13 @@ __device__ __forceinline__ u64 pair_load8(const u8 *__restrict__ text, u32 n, u3
     return v;
 }
 
-__global__ __launch_bounds__(kSortThreads) void k_pair_scan(BwtArgs a, u32 step, const u32 *__restrict__ mate, const u32 *__restrict__ midx,
-                                                             u8 *__restrict__ impure)
+__global__ __launch_bounds__(kSortThreads) void k_link_scan(BwtArgs a, u32 step, const u32 *__restrict__ VS, const u32 *__restrict__ midx,
+                                                             const u8 *__restrict__ impure)
 {
+    // what the last scan of this wave found, per partner slot: {distance, leader's start, first difference (absolute, not
+    // wrapped), smaller start is the smaller rotation}.  The next row of 64 starts almost always lies inside the same
+    // stretch: its lanes take the verdict without a scan.
+    __shared__ u32 s_carry[kSortThreads / 64][kLinkMax][4];
     u32 tile, lb;
     xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
@@ -2932,67 +2873,189 @@ __global__ __launch_bounds__(kSortThreads) void k_pair_scan(BwtArgs a, u32 step,
     const u32 start = tile * kSortTile;
     if (start >= n || n < 64u) return;
     const size_t base = (size_t)lb * kSlot;
-    if (impure[base + kSlot - 2u] == 0) return; // (k_survivor_compact found no group of two in this block)
+    if (impure[base + kSlot - 2u] == 0) return; // (k_survivor_compact found no small group in this block)
     const u8 *__restrict__ text = a.rle + d.rle_off;
     const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
     const u64 d64 = ((u64)ki.chars * 2u) << step;
     const u32 depth = d64 < n ? (u32)d64 : n;
-    u8 *pb8 = pair_bytes(a, lb);
+    const u32 cnt = a.count[lb];
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    if (l < kLinkMax * 4u) (&s_carry[w][0][0])[l] = 0u; // (distance 0: no carry)
+    u32 mi[16];
+#pragma unroll
     for (u32 r = 0; r < 16u; ++r) {
         const u32 x = start + w * 1024u + r * 64u + l;
-        const bool has_mate = x < n && ((reinterpret_cast<const u32 *>(a.flags + base)[x >> 5] >> (x & 31u)) & 1u);
-        const u32 hi = has_mate ? mate[base + x] : kPairNone;
-        const bool has = hi != kPairNone && hi > x && hi < n;
-        const u32 dist = has ? hi - x : 0u;
-        u64 todo = __ballot(has);
-        bool solved = false, lo_less = false;
-        for (u32 tries = 0; todo && tries < 8u; ++tries) {
-            const u32 L = (u32)__builtin_ctzll(todo);
-            const u32 dL = wave_lane(dist, L), xL = wave_lane(x, L);
-            u64 grp = __ballot(has && !solved && dist == dL) & todo; // (lane L is in it; its start is the group's smallest)
-            u32 s = xL + depth;                                      // where the leader's known-equal prefix ends
-            s = s >= n ? s - n : s;
-            u32 scanned = 0;
-            bool found = false;
-            while (scanned < kPairCap && scanned + depth < n) {
-                u32 pa = s + 8u * l;
-                pa = pa >= n ? pa - n : pa;
-                u32 pb = pa + dL;
-                pb = pb >= n ? pb - n : pb;
-                const u64 xa = pair_load8(text, n, pa), xb = pair_load8(text, n, pb);
-                const u64 df = xa ^ xb;
-                const u64 bm = __ballot(df != 0ull);
-                if (bm) {
-                    const u32 f = (u32)__builtin_ctzll(bm);
-                    const u64 dff = wave_lane64(df, f), xaf = wave_lane64(xa, f), xbf = wave_lane64(xb, f);
-                    const u32 byte = (u32)__builtin_ctzll(dff) >> 3;
-                    const u32 moff = scanned + 8u * f + byte; // the first difference, counted from the leader's start + depth
-                    const bool less = (u32)((xaf >> (8u * byte)) & 0xFFull) < (u32)((xbf >> (8u * byte)) & 0xFFull);
-                    // every pair of the group whose own known-equal prefix ends at or in front of the difference takes it
-                    const bool mine = ((grp >> l) & 1ull) && (x - xL) <= moff;
-                    if (mine) {
-                        solved = true;
-                        lo_less = less;
-                    }
-                    todo &= ~__ballot(mine);
-                    found = true;
-                    break;
+        mi[r] = x < n ? ld_stream(midx + base + x) : 0u;
+    }
+#pragma unroll 1
+    for (u32 r = 0; r < 16u; ++r) {
+        const u32 x = start + w * 1024u + r * 64u + l;
+        u32 e = 0;
+#pragma unroll
+        for (u32 q = 0; q < 16u; ++q) e = q == r ? mi[q] : e; // (a register array under a loop that is not unrolled)
+        // the group of x: its place in the list, the members, and for each member behind x how many lie between
+        u32 idx = e & 0xFFFFFu, size = e >> 24;
+        const u32 off = (e >> 20) & 15u;
+        if (size < 2u || size > kLinkMax || off >= size || idx < off || idx - off + size > cnt) size = 0; // (0: no member of a small group)
+        if (!__ballot(size != 0u)) continue;
+        const u32 g0 = idx - off;
+        u32 mem[kLinkMax], slot[kLinkMax];
+        {
+            // (the members lie side by side in the list: two 16-byte loads instead of eight gathers; entries behind the
+            // group's last one are read and not used -- the list's array is kSlot words, so is the slack behind cnt)
+            uint4 m0 = make_uint4(0, 0, 0, 0), m1 = make_uint4(0, 0, 0, 0);
+            if (size) __builtin_memcpy(&m0, VS + base + g0, 16);
+            if (size > 4u) __builtin_memcpy(&m1, VS + base + g0 + 4u, 16);
+            mem[0] = m0.x; mem[1] = m0.y; mem[2] = m0.z; mem[3] = m0.w;
+            mem[4] = m1.x; mem[5] = m1.y; mem[6] = m1.z; mem[7] = m1.w;
+        }
+        // the other members, nearest in front first ... farthest behind last (by start): consecutive starts of a copied
+        // stretch meet the same distances in the same slots
+        u32 nothers = size ? size - 1u : 0u;
+#pragma unroll
+        for (u32 t = 0; t < kLinkMax; ++t) {
+            u32 c = 0;
+#pragma unroll
+            for (u32 u = 0; u < kLinkMax; ++u) c += (u < size && mem[u] != x && mem[u] < mem[t]) ? 1u : 0u;
+            slot[t] = (t < size && mem[t] != x && mem[t] < n) ? c : 0xFFFFFFFFu;
+        }
+        u32 own = 0; // comparisons decided << 4 | members found smaller
+#pragma unroll 1
+        for (u32 s = 0; s + 1u < kLinkMax; ++s) {
+            const bool has = s < nothers;
+            u64 todo = __ballot(has);
+            if (!todo) break; // (no lane has a partner left)
+            u32 y = x;
+#pragma unroll
+            for (u32 t = 0; t < kLinkMax; ++t)
+                if (slot[t] == s) y = mem[t];
+            const u32 dist = y >= x ? y - x : y + n - x; // (a partner in front: the distance the other way round the block)
+            bool solved = false, lo_less = false;
+            {
+                // inside the stretch the wave's last scan for this slot resolved?
+                const u32 cd = s_carry[w][s][0], cx = s_carry[w][s][1], cD = s_carry[w][s][2], cl = s_carry[w][s][3];
+                if (has && cd != 0u && dist == cd && x >= cx && x + depth <= cD) {
+                    solved = true;
+                    lo_less = cl != 0u;
                 }
-                s += 512u;
-                s = s >= n ? s - n : s;
-                scanned += 512u;
+                todo &= ~__ballot(solved);
             }
-            if (!found) todo &= ~grp; // (equal as far as looked: a periodic block, or a repeat longer than the cap -- they go on doubling)
+            for (u32 tries = 0; todo && tries < kLinkTries; ++tries) {
+                const u32 L = (u32)__builtin_ctzll(todo);
+                const u32 dL = wave_lane(dist, L), xL = wave_lane(x, L);
+                const u64 grp = __ballot(has && !solved && dist == dL) & todo; // (lane L is in it; its start is the group's smallest)
+                u32 sp = xL + depth;                                            // where the leader's known-equal prefix ends
+                sp = sp >= n ? sp - n : sp;
+                u32 scanned = 0;
+                bool found = false;
+                while (scanned + depth < n) { // (all the way: two members that agree to the end are equal rotations, a periodic block)
+                    u32 pa = sp + 8u * l;
+                    pa = pa >= n ? pa - n : pa;
+                    u32 pb = pa + dL;
+                    pb = pb >= n ? pb - n : pb;
+                    const u64 xa = link_load8(text, n, pa), xb = link_load8(text, n, pb);
+                    const u64 df = xa ^ xb;
+                    const u64 bm = __ballot(df != 0ull);
+                    if (bm) {
+                        const u32 f = (u32)__builtin_ctzll(bm);
+                        const u64 dff = wave_lane64(df, f), xaf = wave_lane64(xa, f), xbf = wave_lane64(xb, f);
+                        const u32 byte = (u32)__builtin_ctzll(dff) >> 3;
+                        const u32 moff = scanned + 8u * f + byte; // the first difference, counted from the leader's start + depth
+                        const bool less = (u32)((xaf >> (8u * byte)) & 0xFFull) < (u32)((xbf >> (8u * byte)) & 0xFFull);
+                        // every lane of the group whose own known-equal prefix ends at or in front of the difference takes it
+                        const bool mine = ((grp >> l) & 1ull) && (x - xL) <= moff;
+                        if (mine) {
+                            solved = true;
+                            lo_less = less;
+                        }
+                        todo &= ~__ballot(mine);
+                        found = true;
+                        if (l == 0) {
+                            s_carry[w][s][0] = dL;
+                            s_carry[w][s][1] = xL;
+                            s_carry[w][s][2] = xL + depth + moff;
+                            s_carry[w][s][3] = less ? 1u : 0u;
+                        }
+                        break;
+                    }
+                    sp += 512u;
+                    sp = sp >= n ? sp - n : sp;
+                    scanned += 512u;
+                }
+                if (!found) todo &= ~grp; // (equal rotations: a periodic block -- k_periodic_place's case)
+            }
+            if (solved && y != x) own += 0x10u + (lo_less ? 0u : 1u); // rot(x) > rot(y): one more member below x
         }
-        if (solved) {
-            const u32 mi = midx[base + x];
-            const u32 idx0 = mi & 0x7FFFFFFFu;
-            const bool lo_first = (mi >> 31) != 0u;
-            pb8[idx0 + (lo_first ? 0u : 1u)] = lo_less ? 2 : 3; // the smaller start's entry
-            pb8[idx0 + (lo_first ? 1u : 0u)] = lo_less ? 3 : 2;
-            impure[base + (a.R[base + x] & ~kFinalBit)] = 2;
-        }
+        // (every member makes all its comparisons itself -- both members of a pair scan it, and the scans are shared along the
+        // stretch --, so its byte is a plain store: the first build had the smaller start add to its partner's byte, 375 M byte
+        // atomics per 256 MiB of the corpus "binary", 7.6 of the kernel's 11.5 ms)
+        if (size) link_bytes(a, lb)[idx] = (u8)own;
+    }
+}
+
+// the rank of list entry idx inside its small group when every member of the group has all its comparisons decided
+// (g0: the group's first place in the list, first: idx is that place)
+__device__ __forceinline__ bool link_rank(const u8 *__restrict__ gb8, const u8 *__restrict__ lk8, u32 idx, u32 cnt, u32 &g0, u32 &rank, bool &first)
+{
+    const u32 gb = gb8[idx];
+    const u32 size = gb >> 4, off = gb & 15u;
+    if (size < 2u || size > kLinkMax || off >= size || idx < off || idx - off + size > cnt) return false;
+    g0 = idx - off;
+    first = off == 0u;
+    u64 lw; // (the members' bytes lie side by side: one unaligned load; the array has 64 bytes of slack behind the slot)
+    __builtin_memcpy(&lw, lk8 + g0, 8);
+    bool all = true;
+#pragma unroll
+    for (u32 t = 0; t < kLinkMax; ++t)
+        if (t < size) all = all && (u32)((lw >> (8u * t + 4u)) & 15ull) == size - 1u;
+    rank = (u32)(lw >> (8u * off)) & 15u;
+    return all && rank < size;
+}
+
+__global__ __launch_bounds__(kSortThreads) void k_link_keys(BwtArgs a, const u32 *__restrict__ VS, u8 *__restrict__ impure)
+{
+    u32 tile, lb;
+    xcd_remap(gridDim.x, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    const u32 cnt = a.count[lb];
+    const u32 start = tile * kSortTile;
+    const size_t base = (size_t)lb * kSlot;
+    if (start >= cnt || impure[base + kSlot - 2u] == 0) return; // (no small group: every group byte of the block's list is 0 already)
+    u8 *gb8 = group_bytes(a, lb);
+    const u8 *lk8 = link_bytes(a, lb);
+    for (u32 idx = start + threadIdx.x; idx < cnt && idx < start + kSortTile; idx += kSortThreads) {
+        u32 g0 = 0, rank = 0;
+        bool first = false;
+        const bool ranked = link_rank(gb8, lk8, idx, cnt, g0, rank, first);
+        if (ranked && first) impure[base + (a.R[base + VS[base + idx]] & ~kFinalBit)] = 2;
+        gb8[idx] = ranked ? (u8)(2u + rank) : (u8)0; // (each entry reads its own group byte only: nobody else's read is disturbed)
+    }
+}
+
+// a link round's list: the survivors in group order, the members of ranked groups in their order; keys = the group heads
+__global__ __launch_bounds__(kSortThreads) void k_link_permute(BwtArgs a, const u32 *__restrict__ VS, u32 *__restrict__ Kout, u32 *__restrict__ Vout,
+                                                                u8 *__restrict__ impure)
+{
+    u32 tile, lb;
+    xcd_remap(gridDim.x, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    const u32 cnt = a.count[lb];
+    const u32 start = tile * kSortTile;
+    const size_t base = (size_t)lb * kSlot;
+    if (start >= cnt) return;
+    const bool any = impure[base + kSlot - 2u] != 0;
+    const u8 *gb8 = group_bytes(a, lb);
+    const u8 *lk8 = link_bytes(a, lb);
+    for (u32 idx = start + threadIdx.x; idx < cnt && idx < start + kSortTile; idx += kSortThreads) {
+        const u32 x = VS[base + idx];
+        const u32 head = a.R[base + x] & ~kFinalBit;
+        u32 g0 = 0, rank = 0;
+        bool first = false;
+        const bool ranked = any && link_rank(gb8, lk8, idx, cnt, g0, rank, first);
+        if (ranked && first) impure[base + head] = 2;
+        const u32 at = ranked ? g0 + rank : idx;
+        Kout[base + at] = head;
+        Vout[base + at] = x;
     }
 }
 
@@ -3514,7 +3577,12 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
     u32 step = 0; // this round compares at depth h = 2c << step
     int rounds = 0;
     u32 slot = 0;
-    bool period_done = false, pair_done = false;
+    bool period_done = false;
+    // (round 6) link rounds: behind the period round, whenever a doubling round has just run and enough is left unordered --
+    // until one of them orders less than a quarter of what it was given (the groups that are left are large)
+    bool last_doubled = false, links_pay = true;
+    u64 link_m = 0; // what the last link round was given (0: the last round was none)
+    if (!(a.gh_tiles && a.per_aux)) a.per_links = 0; // (the bitmap of the small groups' starts lives where the period tables live without the fused passes' slot)
     bool surv_local_ok = true; // (no segment of a survivor round of this sort has overflowed LDS so far)
     u32 list_tiles = a.tiles; // (the first refinement ran on all of SA)
     while (true) {
@@ -3539,6 +3607,13 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         ++slot;
         ++rounds;
         bool carried = false;
+        u32 trace_worst = 0;
+        if (getenv("BZ_BWT_TRACE")) { // (which block holds the most: a.nonfinal still has the last refinement's counts)
+            std::vector<u32> nf(a.nb);
+            (void)hipMemcpyAsync(nf.data(), a.nonfinal, a.nb * 4, hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+            trace_worst = (u32)(std::max_element(nf.begin(), nf.end()) - nf.begin());
+        }
         (void)hipMemsetAsync(a.nonfinal, 0, a.nb * sizeof(u32), st);
         // SOME block with most of its rotations still unordered after a doubling round (4c symbols and more compared;
         // text is down to 7 % by then): deep repeats.  One period round (k_period_find ...) finishes the groups of the
@@ -3561,98 +3636,95 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         const bool deep = want_period == 2 ? (rounds >= 3 && m * 4 >= total_n * 3)
                                            : ((rounds >= 2 && ((u64)mx * 4 >= (u64)max_n * 3 || m * 4 >= total_n * 3)) ||
                                               (rounds == 1 && m * 64 >= total_n * 63));
-        // (second half of round 5) a SECOND period round where round 5's pair round stood -- behind the first one, once, when a third
-        // of the rotations are still unordered at 32 symbols and more: with tables, pairs AND the exact ranks inside groups of
-        // three to eight (fetch_rows<SRC_PERJ>).  At the first period round's depth (8-16 symbols) the groups of data that holds
-        // a stretch several times are still mixtures of the copies' neighbourhoods (the corpus "binary": ranks ordered 10 M of its
-        // 250 M rotations there); at 32 symbols 43 % of its rotations sit in groups of three and four copies.
-        // MEASURED AND OFF BY DEFAULT (BZ_PERIOD_SECOND=1 turns it on): on "binary" the second round finds 50 % of its list in
-        // groups of three to eight (40 % in groups of four) but only 0.2 % of those with every pair of members a LISTED distance
-        // apart -- four copies need six distances, the drift of the copies multiplies them, a block lists eight at most and
-        // finds them from anchors, not from the groups -- and costs 17 ms per 256 MiB: 93 -> 114 ms.  Without it the pair round
-        // runs as in the first half of the round.
-        static const bool want_second = getenv("BZ_PERIOD_SECOND") && atoi(getenv("BZ_PERIOD_SECOND")) != 0;
-        const bool second_stage = want_period != 0 && period_done && !pair_done && a.gh_tiles && a.per_aux && a.per_pairs &&
-                                  ((u64)(2u * min_chars) << step) >= 32u && m * (want_second ? 3 : 2) >= total_n;
-        const bool per_round = want_period != 0 && ((!period_done && deep) || (second_stage && want_second));
-        // A PAIR round (round 5): behind the period round, once, when half of the rotations are still unordered at a depth of 32
-        // symbols and more -- data that holds a stretch twice (the corpus "binary") leaves almost every rotation in a group of
-        // two by then, whose members agree for kilobytes: k_pair_scan orders them in one go, whatever the distances between the
-        // copies, instead of the eight doubling rounds they would take.  At the depth of the period round (8-16 symbols) most
-        // groups are still larger than two.
-        const bool pair_round = !per_round && second_stage;
+        const bool per_round = want_period != 0 && !period_done && deep;
+        // A LINK round (round 6; round 5 had a pair round at 32 symbols here): the small groups of the survivor list -- two to
+        // kLinkMax members -- ranked by direct comparison (k_link_scan), no tables, no radix passes.  Data that holds a stretch
+        // several times leaves most of its rotations in such groups once a doubling round or two have told the copies'
+        // neighbourhoods apart; their members agree for kilobytes, which is eight and more doubling rounds.  Taken whenever
+        // a doubling round has just run behind the period round (so: only batches that are deep in repeats) and a 256th of
+        // the rotations is still unordered, as long as the rounds pay.
+        if (link_m) {
+            if ((link_m - m) * 4 < link_m) links_pay = false;
+            link_m = 0;
+        }
+        const bool link_round = !per_round && a.per_links && period_done && last_doubled && links_pay && m * 256 >= total_n;
         // survivor form below this share of the rotations (BZ_SURV_SHARE=num/den, default 1/4: measured)
         static const u64 surv_num = [] { const char *e = getenv("BZ_SURV_SHARE"); unsigned a = 1, b = 4; if (e && sscanf(e, "%u/%u", &a, &b) == 2 && a && b) return (u64)a; return (u64)1; }();
         static const u64 surv_den = [] { const char *e = getenv("BZ_SURV_SHARE"); unsigned a = 1, b = 4; if (e && sscanf(e, "%u/%u", &a, &b) == 2 && a && b) return (u64)b; return (u64)4; }();
         static const bool bwt_trace = getenv("BZ_BWT_TRACE") != nullptr;
         if (bwt_trace)
-            fprintf(stderr, "bz2_mi355x: sort round %d (h = %llu): %llu of %llu rotations unordered, at most %u in one block (of %u)%s\n",
+            fprintf(stderr, "bz2_mi355x: sort round %d (h = %llu): %llu of %llu rotations unordered, at most %u in one block (block %u; of %u)%s\n",
                     rounds, (unsigned long long)(2u * min_chars) << step, (unsigned long long)m, (unsigned long long)total_n, mx,
-                    max_n, per_round ? ": period round" : (pair_round ? ": pair round" : (m * surv_den < total_n * surv_num ? ": survivor form" : ": walk form")));
+                    trace_worst, max_n, per_round ? ": period round" : (link_round ? ": link round" : (m * surv_den < total_n * surv_num ? ": survivor form" : ": walk form")));
         u8 *impure = a.ptext; // (the packed text is not read any more once the init is over)
-        if (per_round || pair_round) {
-            if (per_round && period_done) pair_done = true; // (the second period round takes the pair round's place)
+        last_doubled = !(per_round || link_round);
+        if (per_round || link_round) {
             if (per_round) period_done = true;
-            else pair_done = true;
+            else link_m = m;
             (void)hipMemsetAsync(impure, 0, (size_t)a.nb * kSlot, st);
-            // Round 5: the groups of two are ordered by one scan per stretch of pairs (k_survivor_compact leaves the pairs,
-            // k_pair_scan orders them; BZ_PAIR_COMPARE=0 turns it off, =2 runs round 4's one-lane-per-pair kernel instead).
-            // mate / place of the pair: the two arrays of the list the last refinement ran on, which nothing reads between the
-            // compaction and the passes below -- unless the compaction reads that very list (lastV), then the free key array.
-            static const int pair_mode = getenv("BZ_PAIR_COMPARE") ? atoi(getenv("BZ_PAIR_COMPARE")) : 1;
-            const bool pairs = a.gh_tiles && a.per_aux && a.per_pairs && pair_mode != 0; // (only with the fused passes: the three-kernel fallback keeps to round 4's period round)
-            u32 *mate = (lastV == cK) ? fK : cK, *midx = (lastV == cV || lastV == cK) ? fK : cV;
-            if (mate == midx) midx = (lastV == cV) ? cK : cV;
-            const bool scan = pairs && pair_mode != 2;
-            // (which starts have a mate: a bit per position in the flag bytes' slot -- free until this round's k_group_flags --,
-            // 1/32 of the bytes that clearing the mate array itself took)
-            if (scan) (void)hipMemset2DAsync(a.flags, kSlot, 0, kSlot / 8u, a.nb, st);
-            hipLaunchKernelGGL(k_survivor_compact, grid_prev, dim3(kSortThreads), 0, st, a, lastV, fV, scan ? mate : nullptr, scan ? midx : nullptr);
+            // The members of small groups leave their place in the compacted list under their start (midx: the keys of the
+            // list the last refinement ran on, which nothing reads any more) and a bit in a bitmap of such starts (the flag
+            // bytes' slot, free until this round's k_group_flags); k_link_scan ranks them, k_link_keys / k_link_permute
+            // take the groups that are decided.  BZ_LINK_ROUND=0: neither (the period round keeps its tables and chains).
+            const bool links = a.per_links != 0;
+            u32 *midx = cK;
+            if (links) (void)hipMemsetAsync(midx, 0, (size_t)a.nb * kSlot * sizeof(u32), st); // (0: the start is no member of a small group)
+            hipLaunchKernelGGL(k_survivor_compact, grid_prev, dim3(kSortThreads), 0, st, a, lastV, fV, links ? midx : nullptr);
             hipLaunchKernelGGL(k_copy_counts, dim3((a.nb + 255) / 256), dim3(256), 0, st, a.count, a.count2, a.nb);
-            if (pairs) {
-                // (the verdict bytes of the list were cleared by k_survivor_compact, entry by entry -- unless round 4's kernel is asked for)
-                if (pair_mode == 2) (void)hipMemset2DAsync(a.per_aux, (size_t)kMtfStride * 2, 0, (size_t)list_tiles * kSortTile, a.nb, st);
-                if (pair_mode == 2) hipLaunchKernelGGL(k_pair_compare, grid_list, dim3(kSortThreads), 0, st, a, step, fV, impure);
-                else hipLaunchKernelGGL(k_pair_scan, grid, dim3(kSortThreads), 0, st, a, step, mate, midx, impure);
-            }
-            // the blocks' distances and the bitmaps that order rotation i against rotation i + p (in the flag bytes' slot, which
-            // nothing uses before this round's k_group_flags); the pair round lists none
-            if (!per_round) (void)hipMemsetAsync(a.lin_p, 0, (size_t)a.nb * kPerK * 4, st);
-            if (per_round) {
-            hipLaunchKernelGGL(k_period_find, dim3(a.nb), dim3(kSortThreads), 0, st, a, second_stage ? 1u : 3u);
+            if (links) hipLaunchKernelGGL(k_link_scan, grid, dim3(kSortThreads), 0, st, a, step, fV, midx, impure);
+            if (link_round) {
+                // no tables, no passes: the list is in group order, a ranked member's place is its group's first + its rank
+                (void)hipMemsetAsync(a.lin_p, 0, (size_t)a.nb * kPerK * 4, st);
+                hipLaunchKernelGGL(k_link_permute, grid_list, dim3(kSortThreads), 0, st, a, fV, cK, cV, impure);
+            } else {
+            if (links) hipLaunchKernelGGL(k_link_keys, grid_list, dim3(kSortThreads), 0, st, a, fV, impure);
+            // the blocks' distances and the bitmaps that order rotation i against rotation i + p (in the digit counts' slot)
+            hipLaunchKernelGGL(k_period_find, dim3(a.nb), dim3(kSortThreads), 0, st, a, 3u);
             hipLaunchKernelGGL(k_period_bits, grid, dim3(kSortThreads), 0, st, a);
             hipLaunchKernelGGL(k_period_next, dim3(a.nb, per_kmax(a)), dim3(kSortThreads), 0, st, a);
-            }
             // The start-based keys are heuristic (k_period_mark decides): when every listed distance of the batch is 1024 and more
             // -- a paragraph repeated every 4 KiB --, the members of a group differ above bit 10 and the keys go down by ten bits:
             // ranks, pair verdicts and shifted starts all fit ONE digit, and the second pass over the key is left out (a pass over
             // the whole list: 4.4 of T2's 119 ms per GiB).  BZ_PERIOD_ONE_PASS=0: two passes always.
             static const bool want_one_pass = !(getenv("BZ_PERIOD_ONE_PASS") && atoi(getenv("BZ_PERIOD_ONE_PASS")) == 0);
-            bool one_pass = false;
-            if (per_round && want_one_pass) {
+            bool one_pass = false, wide = false;
+            {
                 std::vector<u32> lp((size_t)a.nb * kPerK), ls((size_t)a.nb * kPerK);
                 if (hipMemcpyAsync(lp.data(), a.lin_p, lp.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
                     hipMemcpyAsync(ls.data(), a.lin_sig, ls.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
                     return -1;
-                one_pass = true;
+                one_pass = want_one_pass;
                 u32 small = 0, smallest = 0xFFFFFFFFu;
                 // (a distance below 1024 that a fifth of its block agrees at; the ones that barely made the list -- a paragraph
                 // repeated lists a chance distance at 6 % in one block of forty -- only leave their few groups to the doubling)
-                for (size_t i = 0; i < lp.size(); ++i)
+                // (round 6) a distance that is not larger than the depth reached -- sixteen symbols per key at most -- means
+                // stretches with a short period, whose groups are split by where the stretches end (per_ekey): thirty-bit keys
+                const u64 depth_max = 16ull << step;
+                for (size_t i = 0; i < lp.size(); ++i) {
                     if (lp[i] != 0u && lp[i] < 1024u && ls[i] >= 200u) {
                         one_pass = false;
                         small += 1;
                         smallest = lp[i] < smallest ? lp[i] : smallest;
                     }
-                if (bwt_trace) fprintf(stderr, "  period round: %s (%u distances below 1024 that a fifth of their block agrees at, the smallest %u)\n", one_pass ? "one pass over the keys" : "two passes over the keys", small, small ? smallest : 0u);
+                    if (lp[i] != 0u && lp[i] <= depth_max) wide = true;
+                }
+                if (wide) one_pass = false;
+                if (bwt_trace) fprintf(stderr, "  period round: %s (%u distances below 1024 that a fifth of their block agrees at, the smallest %u)\n", wide ? "three passes over thirty-bit keys" : (one_pass ? "one pass over the keys" : "two passes over the keys"), small, small ? smallest : 0u);
             }
             a.per_keyshift = one_pass ? 10u : 0u;
+            a.per_wide = wide ? 1u : 0u;
             if (one_pass) {
                 radix_pass<SRC_PERJ, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK, list_tiles);
                 radix_pass<SRC_LISTG, 10>(st, a, 0, step, nullptr, cV, fK, cK, m, prof, fV, list_tiles); // (values cV -> cK, keys kept in fV)
                 radix_pass<SRC_PAIRS, 10>(st, a, 10, step, fK, cK, cV, fV, m, prof, nullptr, list_tiles); // (result: keys in cV, values in fV)
                 u32 *rk = cV, *rv = fV, *ok = fK, *ov = cK;
                 cK = rk; cV = rv; fK = ok; fV = ov;
+            } else if (wide) {
+                radix_pass<SRC_PERJ, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK, list_tiles);
+                radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof, nullptr, list_tiles);
+                radix_pass<SRC_PAIRS, 10>(st, a, 20, step, fK, fV, cK, cV, m, prof, nullptr, list_tiles);
+                radix_pass<SRC_LISTG, 10>(st, a, 0, step, nullptr, cV, fK, fV, m, prof, cK, list_tiles);
+                radix_pass<SRC_PAIRS, 10>(st, a, 10, step, fK, fV, cK, cV, m, prof, nullptr, list_tiles); // (the result is in cK, cV)
             } else {
                 radix_pass<SRC_PERJ, 10>(st, a, 0, step, nullptr, fV, cK, cV, m, prof, fK, list_tiles);
                 radix_pass<SRC_PAIRS, 10>(st, a, 10, step, cK, cV, fK, fV, m, prof, nullptr, list_tiles);
@@ -3662,7 +3734,8 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
                 t = cV; cV = fV; fV = t;
             }
             a.per_keyshift = 0;
-            if (per_round) hipLaunchKernelGGL(k_period_mark, grid_list, dim3(kSortThreads), 0, st, a, step, cK, cV, impure);
+            hipLaunchKernelGGL(k_period_mark, grid_list, dim3(kSortThreads), 0, st, a, step, cK, cV, impure);
+            }
         } else if (m * surv_den < total_n * surv_num) {
             // few survivors: compact them (list order = sorted by group), order them by the rank
             // of rotation j+h (2 passes), then stably by their own group (2 passes): O(m) work
@@ -3711,10 +3784,11 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             }
         }
         (void)hipMemsetAsync(a.bin_cursor, 0, (size_t)a.nb * 1024 * sizeof(u32), st);
-        if (per_round || pair_round) {
+        if (per_round || link_round) {
             // (the comparison depth does not move: the next round doubles from where the last one stood)
             p = prof ? prof->begin(st, KID_GROUP_FLAGS, m * 13) : -1;
             hipLaunchKernelGGL((k_group_flags<false>), grid_list, dim3(kSortThreads), 0, st, a, step, cK, cV, impure);
+            a.per_wide = 0;
             if (prof) prof->end(st, p);
             p = prof ? prof->begin(st, KID_GROUP_APPLY, m * 17) : -1;
             hipLaunchKernelGGL((k_group_apply<false>), grid_list, dim3(kSortThreads), 0, st, a, step, slot, cK, cV, fK);
@@ -3735,16 +3809,6 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         p = prof ? prof->begin(st, KID_RANK_PLACE, m * 8) : -1;
         hipLaunchKernelGGL(k_rank_place, grid, dim3(kSortThreads), 0, st, a, fK);
         if (prof) prof->end(st, p);
-#ifdef BZ_PERJ_DEBUG
-        if (per_round) {
-            u32 dbg[16] = {};
-            (void)hipStreamSynchronize(st);
-            (void)hipMemcpy(dbg, a.loc_stats + 60, sizeof(dbg), hipMemcpyDeviceToHost);
-            fprintf(stderr, "  period round keys: %u list entries (hist kernel only), %u in ordered pairs, %u with a group byte; %u in groups of 3..8 (sizes 3,4,5,6,7,8: %u %u %u %u %u %u), %u of them with every pair listed\n",
-                    dbg[10], dbg[11], dbg[12], dbg[0], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7], dbg[1]);
-            (void)hipMemset(a.loc_stats + 60, 0, sizeof(dbg));
-        }
-#endif
         if (per_round && bwt_trace) {
             std::vector<u32> lp((size_t)a.nb * kPerK), ls((size_t)a.nb * kPerK), nf(a.nb), cn(a.nb);
             (void)hipMemcpyAsync(lp.data(), a.lin_p, (size_t)a.nb * kPerK * 4, hipMemcpyDeviceToHost, st);
@@ -3760,7 +3824,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
                 }
         }
         lastV = cV;
-        if (!per_round && !pair_round) ++step;
+        if (!per_round && !link_round) ++step;
     }
     if (fused) {
         // a look-back that gave up (it never should) must not pass for a sorted block, and every pass

@@ -623,6 +623,77 @@ def test_period_round_on_drifting_copies(pkg, oracle, eng):
         assert pkg.compress(data, level) == oracle.encode(data, level)
 
 
+def test_link_rounds_on_copies_of_copies(pkg, oracle, eng):
+    """Round 6: SMALL groups of survivors -- two to eight members -- are ranked member by member from direct
+    comparisons of their rotations (k_link_scan: one scan per stretch of copies, whatever the distances; k_link_keys /
+    k_link_permute), in the period round and in link rounds behind it.  The shape it was built for: a stretch that occurs
+    four times in a block -- it repeats inside itself and the whole occurs twice --, every copy with a byte changed every few
+    KiB (bench.py's corpus "binary"): groups of four whose members stand in mixed order, a changed byte in a middle copy
+    between two that agree beyond it.  The comparison is what /root/reference/src/suffix_array/sais.rs:266-272 defines, so
+    the ORDER is the oracle's: rotation order of whole blocks, the rounds it took, whole streams, and the same streams with
+    the link rounds off."""
+    rng = random.Random(606)
+    alpha = bytes(range(33, 97))
+
+    def stretch(k):
+        return bytes(rng.choice(alpha) for _ in range(k))
+
+    def touched(b, every):
+        out = bytearray(b)
+        for pos in range(rng.randrange(every), len(out), every):
+            out[pos] = out[pos] ^ (1 + rng.randrange(7))
+        return bytes(out)
+
+    inner = stretch(9_000)
+    unit = inner + stretch(3_000) + touched(inner, 2048) + stretch(1_500)   # repeats inside itself
+    blocks = [
+        (touched(unit, 4096) + touched(unit, 4096) + touched(unit, 4096) + touched(unit, 4096))[:99_000],  # groups of 2, 4, 6, 8
+        (stretch(333) + touched(unit * 2, 1024) + stretch(7) + touched(unit * 2, 3000))[:97_000],
+        (touched(inner * 9, 4096) + stretch(100))[:82_000],                    # nine copies: groups beyond kLinkMax go on doubling
+        (touched(inner[:5000] * 3, 700) + b"q" * 3000 + touched(inner[:5000] * 3, 900) + (b"abcd" * 5000))[:70_000],  # runs and a short period beside copies
+        touched(stretch(20_000) * 2, 4096) * 2,                                # cyclic period of the WHOLE block: equal rotations stay undecided
+    ]
+    # stretches with a SHORT period cut by changed bytes ("ugh\n" x 30 000 in libbzip2's sample3): groups of thousands of
+    # rotations from many stretches, split by where their stretches end (per_ekey) -- deviations upward and downward, stretches
+    # of equal length, a stretch across the block's wrap, period 1, two different periods in one block
+    ugh = bytearray(b"ugh\n" * 12_000)
+    for pos in range(700, len(ugh), 1900):
+        ugh[pos] = (ugh[pos] + (1 if (pos // 1900) % 3 else 251)) & 255
+    for pos in (10_000, 20_000, 30_000):           # three stretches of the same length behind the same byte
+        ugh[pos] = ord("#")
+        ugh[pos + 1_204] = ord("#")
+    blocks.append(bytes(ugh[:40_000]) + stretch(5_000) + bytes(ugh[40_000:48_000]))
+    blocks.append(b"gh\n" + bytes(ugh[:30_000]) + stretch(2_000) + b"ab" * 9_000 + b"!" + b"ab" * 700 + stretch(50) + b"u")
+    blocks.append((b"z" * 3_000 + stretch(10) + b"z" * 2_999 + stretch(10) + b"z" * 3_000 + b"y" + touched(inner, 4096))[:40_000])
+    rounds = []
+    for i, blk in enumerate(blocks):
+        assert eng.debug_bwt(blk) == oracle.bwt(blk), (i, len(blk))
+        rounds.append(eng.bwt_stats()["rounds"])
+    assert rounds[0] <= 7 and rounds[1] <= 7, rounds  # (doubling alone: log2(4096 / 12) + 2 = 10 and more)
+    data = b"".join(blocks)
+    big = touched((unit * 80)[:1_850_000], 4096)
+    for d, level in ((big, 9), (data, 1), (data, 3)):
+        assert pkg.compress(d, level) == oracle.encode(d, level)
+    # the same streams with the link rounds off (the period round keeps its tables and chains): identical bytes
+    code = """
+import sys, importlib, hashlib
+sys.path.insert(0, %r)
+pkg = importlib.import_module("rust-compression_amd")
+d = open(sys.argv[1], "rb").read()
+print(hashlib.sha256(pkg.compress(d, 1)).hexdigest())
+""" % ROOT
+    import subprocess
+    import sys
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".bin") as f:
+        f.write(data)
+        f.flush()
+        out = subprocess.run([sys.executable, "-c", code, f.name], env=dict(os.environ, BZ_LINK_ROUND="0"), capture_output=True,
+                             text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == hashlib.sha256(oracle.encode(data, 1)).hexdigest()
+
+
 def test_period_round_in_mixed_batches(pkg, oracle):
     """A batch in which every third block is a deep repeat (text, text, a 4 KiB paragraph repeated, ...): the period
     round is triggered by the BLOCKS that need it (round 4; rounds 1-3 looked at the batch as a whole, which such a
