@@ -450,11 +450,19 @@ int bz_decode_buffer(int device, const uint8_t *in, size_t in_len,
  * there are decoded and their bytes queued as they land in host memory, and the
  * chain state (bit position, stream number, level, combined CRC) is carried to
  * the next chunk; chunks of less than 4 MiB are decoded before bz_dec_write
- * returns.  bz_dec_end hands over the rest and returns AT ONCE -- with the
- * verdict if it is already final, else BZ_OK -- and from then on bz_dec_read
- * WAITS for the next bytes or the final verdict instead of answering "nothing
- * yet": a consumer reads the head of the file while its tail is being decoded
- * (the verdict follows the last byte, as the reference's iterator yields it).
+ * returns.  bz_dec_end hands over the rest and does not wait for the decode --
+ * it returns the verdict if it is already final, else BZ_OK; like bz_dec_write
+ * it waits only while two chunks are already queued, and for a last chunk of
+ * less than 4 MiB, which is decoded inside the call -- and from then on
+ * bz_dec_read WAITS for the next bytes or the final verdict instead of
+ * answering "nothing yet" (a caller that polls between other work must not
+ * call it behind bz_dec_end until it can afford to block): a consumer reads the
+ * head of the file while its tail is being decoded (the verdict follows the
+ * last byte, as the reference's iterator yields it).  INPUT memory is bounded
+ * by the chunks in flight (three); decoded bytes wait in host segments until
+ * they are read, without a limit -- a caller that writes a whole file before
+ * its first read holds the whole decoded output (back-pressure on the worker
+ * would dead-lock exactly that caller: its writes wait for the worker).
  * The reference decodes lazily block by block -- same items, coarser moments.
  * 1 GiB written in 1 MiB pieces and read in 4 MiB pieces: see bench.py
  * extra.decode.end_to_end.streaming (rounds 1-4, which decoded inside

@@ -856,9 +856,20 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                         if (sink.pool) sink.pool->wait_all();
                         stage_busy[0] = stage_busy[1] = false;
                         size_t want = old + valid;
-                        const size_t rest = (size_t)(nb_all - s0 - nb) + (nc > ci ? nc - ci : 0); // blocks and candidates behind this sub-batch
-                        if (rest && keep) want += (size_t)((double)valid / (double)keep * (double)rest * 1.02) + ((size_t)1 << 20);
-                        const int hrc = sink.host->reserve(want);
+                        // blocks behind this sub-batch, and -- while the chain has not ended -- the candidates behind the batch,
+                        // but no more of them than the input left can hold (a block record is 80 bits and more; junk behind
+                        // a stream may hold magic patterns by the million, and a chain that has ended takes none of them)
+                        size_t rest = (size_t)(nb_all - s0 - nb);
+                        if (term == 0 && nc > ci) {
+                            const u64 bits_left = nbits > pos ? nbits - pos : 0ull;
+                            rest += std::min<size_t>(nc - ci, (size_t)(bits_left / 80ull));
+                        }
+                        if (rest && keep) {
+                            const double per_block = std::min((double)valid / (double)keep, 900000.0 * 1.25 + 64.0);
+                            want += (size_t)(per_block * (double)rest * 1.02) + ((size_t)1 << 20);
+                        }
+                        int hrc = sink.host->reserve(want);
+                        if (hrc != BZ_OK && want > old + valid) hrc = sink.host->reserve(old + valid); // (the guess was too much: what is needed now)
                         if (hrc != BZ_OK) return hrc;
                     }
                     if (valid) {

@@ -54,11 +54,12 @@ enum { SRC_TEXT = 0, SRC_PAIRS = 1, SRC_MM = 2, SRC_WALK = 3, SRC_SURV = 4, SRC_
        SRC_TEXTK = 6, SRC_WALKK = 7, SRC_MMK = 8, // ..K: keys stored by the histogram kernel of the pass
        SRC_MMC = 9, // MM that also CARRIES the rank of rotation j+h along (k_radix_scatter_lb, first walk round)
        SRC_PERJ = 10,   // the survivors keyed by their own start (the period round, see k_period_find)
-       SRC_PACKED = 11 }; // one word per element: the digits still to be sorted by above bit 20, the rotation below (round 4:
+       SRC_PACKED = 11,   // one word per element: the digits still to be sorted by above bit 20, the rotation below (round 4:
                           // the pass in front of the last one of phase A writes these, the last one reads them)
+       SRC_PERJK = 12 };  // PERJ's keys as its histogram kernel kept them (bit 31: the entry takes no part)
 // sources whose sequence is the compacted list (length count[lb]) rather than all n positions
 template <int SRC> struct src_is_list {
-    static constexpr bool value = (SRC == SRC_PAIRS || SRC == SRC_SURV || SRC == SRC_LISTG || SRC == SRC_PERJ || SRC == SRC_PACKED);
+    static constexpr bool value = (SRC == SRC_PAIRS || SRC == SRC_SURV || SRC == SRC_LISTG || SRC == SRC_PERJ || SRC == SRC_PERJK || SRC == SRC_PACKED);
 };
 
 // per-block key geometry, produced by k_key_params
@@ -194,9 +195,9 @@ __device__ __forceinline__ bool per_ekey(const BwtArgs &a, u32 lb, const u8 *__r
 // (round 6) SMALL groups of the survivor list -- 2 .. kLinkMax members -- are ranked member by member from direct comparisons
 // of their rotations (k_link_scan), whatever the distances between the copies.  Two byte arrays per block, one byte per
 // position of the compacted list, in the MTF stage's symbol buffer (free during the sort):
-//   group_bytes  place inside the group | members << 4 (k_survivor_compact; 0: not a member of a small group); k_link_keys
-//                turns a ranked member's byte into 2 + rank and every other one into 0 for the period round's keys
-//   link_bytes   comparisons with the other members that are decided << 4 | members found smaller (k_link_scan, atomic adds)
+//   group_bytes  place inside the group | members << 4 (k_survivor_compact; 0: not a member of a small group); k_link_finalize
+//                turns the byte of a member it has made final into 1 and every other one into 0
+//   link_bytes   comparisons with the other members that are decided << 4 | members found smaller (k_link_scan)
 constexpr u32 kLinkMax = 8; // the largest group ranked member by member (two nibbles per member: counts up to 7)
 static_assert(kLinkMax == 8 && kMtfStride >= kSlot + 8, "link_rank reads a group's eight link bytes with one load");
 __device__ __forceinline__ u8 *group_bytes(const BwtArgs &a, u32 lb)
@@ -312,8 +313,8 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
         // the period round: order the survivors by where they start -- ascending or descending, as the first
         // difference between the block and the block shifted by its period decides for each of them (per_ascending)
         const u32 p = a.lin_p[(size_t)lb * kPerK]; // (hm: the depth reached, in symbols; 0: the block has no listed distance)
-        // (round 6) a member of a SMALL group that k_link_scan has ranked is keyed by its exact rank inside the group
-        // (k_link_keys left 2 + rank in its byte); k_period_mark leaves such groups alone (impure = 2)
+        // (round 6) a member of a SMALL group that k_link_scan has ranked is final already (k_link_finalize left 1 in its
+        // group byte): it takes no part, the pass compacts the list (the keys it keeps carry bit 31 for such entries)
         const u8 *gb8 = (a.per_aux && a.per_links) ? group_bytes(a, lb) : nullptr;
         u32 gbv[ROWS];
 #pragma unroll
@@ -322,14 +323,24 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
             const u32 c = idx < cnt ? idx : cnt - 1u;
             val[r] = ld_stream(Vin + base + c);
             gbv[r] = gb8 ? gb8[c] : 0u;
-            ok |= (idx < cnt ? 1u : 0u) << r;
+            ok |= ((idx < cnt && gbv[r] != 1u) ? 1u : 0u) << r;
         }
 #pragma unroll
         for (u32 r = 0; r < (u32)ROWS; ++r) {
             u32 ek;
-            if (gbv[r] >= 2u && gbv[r] < 2u + kLinkMax) key[r] = gbv[r] - 2u;
+            if (gbv[r] == 1u) key[r] = 0x80000000u;
             else if (a.per_wide && p != 0u && per_ekey(a, lb, a.rle + a.blocks[lb].rle_off, n, hm, val[r], ek)) key[r] = ek;
             else key[r] = ((p != 0u && !per_key_ascending(a, lb, n, hm, val[r])) ? (n - 1u - val[r]) : val[r]) >> a.per_keyshift;
+        }
+    } else if (SRC == SRC_PERJK) {
+        const u32 *kp = Kin + base, *vp = Vin + base;
+#pragma unroll
+        for (u32 r = 0; r < (u32)ROWS; ++r) {
+            const u32 idx = first + r * 64u;
+            const u32 c = idx < cnt ? idx : cnt - 1u;
+            key[r] = ld_stream(kp + c);
+            val[r] = ld_stream(vp + c);
+            ok |= ((idx < cnt && !(key[r] >> 31)) ? 1u : 0u) << r;
         }
     } else if (SRC == SRC_LISTG) {
         // survivor round, second half: walk that order, key = the survivor's own group
@@ -410,7 +421,9 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(BwtArgs a, u32 shif
     if (lb == 0xFFFFFFFFu) return;
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
-    const u32 cnt = src_is_list<SRC>::value ? a.count[lb] : n;
+    // (the period round's first pass compacts: its input is the whole survivor list, count2; its scan leaves the length of what
+    // takes part in count)
+    const u32 cnt = (SRC == SRC_PERJ || SRC == SRC_PERJK) ? a.count2[lb] : (src_is_list<SRC>::value ? a.count[lb] : n);
     const u32 start = tile * kSortTile;
     if (start >= cnt) return;
     const u8 *text = a.rle + d.rle_off;
@@ -460,7 +473,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scan(BwtArgs a)
     __shared__ u32 s_wsum[kSortThreads / 64];
     const u32 lb = blockIdx.x;
     const u32 n = a.blocks[lb].n;
-    const u32 cnt = src_is_list<SRC>::value ? a.count[lb] : n;
+    const u32 cnt = (SRC == SRC_PERJ || SRC == SRC_PERJK) ? a.count2[lb] : (src_is_list<SRC>::value ? a.count[lb] : n);
     const u32 ntiles = (cnt + kSortTile - 1) / kSortTile;
     u32 *hist = a.tile_hist + (size_t)lb * kTilesPerBlock * kMaxBins;
     u32 *bin_base = a.bin_base + (size_t)lb * kMaxBins;
@@ -506,7 +519,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scan(BwtArgs a)
         if (dgt < NB) bin_base[dgt] = base;
         base += tot[q];
     }
-    if (!src_is_list<SRC>::value && threadIdx.x == 0) a.count[lb] = total; // list length for the next passes
+    if ((!src_is_list<SRC>::value || SRC == SRC_PERJ) && threadIdx.x == 0) a.count[lb] = total; // list length for the next passes
 }
 
 // ---- radix pass, part 3: stable scatter -----------------------------------------------
@@ -537,7 +550,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(BwtArgs a, u32 s
     if (lb == 0xFFFFFFFFu) return;
     const BlockDesc d = a.blocks[lb];
     const u32 n = d.n;
-    const u32 cnt = src_is_list<SRC>::value ? a.count[lb] : n;
+    const u32 cnt = (SRC == SRC_PERJ || SRC == SRC_PERJK) ? a.count2[lb] : (src_is_list<SRC>::value ? a.count[lb] : n);
     const u32 start = tile * kSortTile;
     if (start >= cnt) return;
     const u8 *text = a.rle + d.rle_off;
@@ -2360,11 +2373,13 @@ __global__ __launch_bounds__(kSortThreads) void k_rank_place(BwtArgs a, const u3
 // the place inside the group and its size are read off the start bits the compaction reads anyway) leaves
 // midx[its start] = its place in the compacted list | place inside the group << 20 | members << 24 (the host cleared the
 // array: 0 = not such a member) and its group byte.
+// dense_only (the period round): only in blocks whose list holds a quarter of the block and more -- k_link_scan walks a block
+// in text order, which costs a text block with 2 % of its rotations left more than the doubling round it saves.
 __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, const u32 *__restrict__ V,
-                                                                    u32 *__restrict__ VS, u32 *__restrict__ midx = nullptr)
+                                                                    u32 *__restrict__ VS, u32 *__restrict__ midx = nullptr, u32 dense_only = 0)
 {
     constexpr u32 NW = kSortThreads / 64;
-    __shared__ u32 s_off, s_wsum[NW];
+    __shared__ u32 s_off, s_wsum[NW], s_total;
     u32 tile, lb;
     xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
@@ -2380,9 +2395,12 @@ __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, co
     if (a.tile_nf[lb * kTilesPerBlock + tile] == 0) return;
     const size_t base = (size_t)lb * kSlot;
     if (threadIdx.x == 0) {
-        u32 off = 0;
+        u32 off = 0, tot = 0;
         for (u32 t = 0; t < tile; ++t) off += a.tile_nf[lb * kTilesPerBlock + t];
+        if (midx && dense_only)
+            for (u32 t = 0; t < ntiles; ++t) tot += a.tile_nf[lb * kTilesPerBlock + t];
         s_off = off;
+        s_total = tot;
     }
     const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
     const u32 wbase = start + w * 1024u;
@@ -2422,6 +2440,11 @@ __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, co
     for (u32 k = 0; k < w; ++k) off += s_wsum[k];
     const u64 lt_mask = (l == 0) ? 0ull : (~0ull >> (64 - l));
     bool any_small = false;
+    // (a sparse list: its groups go on doubling -- their group bytes are cleared all the same, the period round's keys look at them)
+    // (a block of less than 64 bytes -- the two bytes behind a cut -- has no small groups either: k_link_scan does not look at it,
+    // and a group byte without a link byte written in this round would be read with a stale one: fuzz cases of round 6,
+    // tests/golden/fuzz_r6_*.bin)
+    const bool sparse = midx && ((dense_only && (u64)s_total * 4u < (u64)a.blocks[lb].n) || a.blocks[lb].n < 64u);
 #pragma unroll
     for (u32 r = 0; r < 16; ++r) {
         const u32 at = off + (u32)__popcll(surv[r] & lt_mask);
@@ -2433,7 +2456,7 @@ __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, co
             const u64 hi = (l == 63u) ? nxw : ((cur >> (l + 1u)) | (nxw << (63u - l)));
             const u32 back = lo ? (u32)__clzll(lo) : 64u, fwd = hi ? (u32)__builtin_ctzll(hi) + 1u : 65u;
             const u32 size = back + fwd;
-            const bool small = size >= 2u && size <= kLinkMax;
+            const bool small = size >= 2u && size <= kLinkMax && !sparse;
             gb8[at] = small ? (u8)(back | (size << 4)) : (u8)0;
             if (small) {
                 midx[base + jv[r]] = at | (back << 20) | (size << 24); // (never 0: the host cleared the array, 0 = no member)
@@ -2442,7 +2465,7 @@ __global__ __launch_bounds__(kSortThreads) void k_survivor_compact(BwtArgs a, co
         }
         off += (u32)__popcll(surv[r]);
     }
-    if (any_small) a.ptext[base + kSlot - 2u] = 1; // the block has small groups: k_link_scan and k_link_keys look at it
+    if (any_small) a.ptext[base + kSlot - 2u] = 1; // the block has small groups: k_link_scan and k_link_finalize look at it
 }
 
 __global__ void k_copy_counts(u32 *__restrict__ dst, const u32 *__restrict__ src, u32 nb)
@@ -2619,8 +2642,8 @@ __global__ __launch_bounds__(kSortThreads) void k_period_find(BwtArgs a, u32 qua
     // at all of them: 33 ms per GiB of the stress corpus T2, a fifth of its step).
     constexpr u32 kLook = 12;
     __shared__ u32 s_lookc[kLook], s_nlook;
+    __shared__ u32 votes[kAnchors];
     if (tid == 0) {
-        u32 votes[kAnchors];
         for (u32 k = 0; k < kAnchors; ++k) {
             votes[k] = 0;
             const u32 c = s_cand[k];
@@ -2835,14 +2858,12 @@ __global__ __launch_bounds__(kSortThreads) void k_period_next(BwtArgs a)
 //                do for most groups, but a copy with a changed byte between two that agree beyond it leaves the two
 //                undecided -- and that is exactly what drifting copies look like.  A decided comparison adds 1 to the
 //                "decided" nibble of both members' link bytes and 1 to the "members below" nibble of the greater one;
-//   k_link_keys  a group all of whose members have all their comparisons decided is ordered: member -> 2 + rank in its
-//                group byte (the period round's keys), impure[group] = 2 (k_period_mark leaves it alone, the refinement
-//                makes every member a group of its own);
-//   k_link_permute  the same for a LINK round (no period tables, no radix passes: the list is in group order already and
-//                a ranked member's place is the group's first place + its rank).
+//   k_link_finalize  a group all of whose members have all their comparisons decided is ordered, and its members are final
+//                at once (SA, last column, rank word); the period round's passes and the link round's k_link_compact run
+//                on what is left.
 // The comparison is the definition of the order (sais.rs:266-272 fixes nothing else); a group that is not decided (equal
 // rotations, more stretches in one row of starts than kLinkTries) goes on doubling.
-constexpr u32 kLinkTries = 8;      // stretches per row of 64 starts and partner
+constexpr u32 kLinkTries = 8;      // stretches per row of 64 starts and partner that the whole wave scans
 __device__ __forceinline__ u64 link_load8(const u8 *__restrict__ text, u32 n, u32 p) // eight bytes from p on, cyclic (p < n)
 {
     u64 v;
@@ -2940,6 +2961,29 @@ __global__ __launch_bounds__(kSortThreads) void k_link_scan(BwtArgs a, u32 step,
                 }
                 todo &= ~__ballot(solved);
             }
+            if (todo) {
+                // a look of its own for every lane first: sixteen bytes behind the depth reached.  Rows whose lanes all have
+                // partners somewhere else (text: short repeats all over the block) are no stretch of one copy, a scan by the
+                // whole wave resolves one lane of them; copies that agree for kilobytes pay two loads for nothing.
+                if (has && !solved && depth + 16u < n) {
+                    u32 pa = x + depth, pb = y + depth;
+                    pa = pa >= n ? pa - n : pa;
+                    pb = pb >= n ? pb - n : pb;
+                    u32 pa8 = pa + 8u, pb8 = pb + 8u;
+                    pa8 = pa8 >= n ? pa8 - n : pa8;
+                    pb8 = pb8 >= n ? pb8 - n : pb8;
+                    const u64 xa = link_load8(text, n, pa), xb = link_load8(text, n, pb);
+                    const u64 xa8 = link_load8(text, n, pa8), xb8 = link_load8(text, n, pb8);
+                    const u64 df = xa != xb ? xa ^ xb : xa8 ^ xb8;
+                    if (df) {
+                        const u32 byte = (u32)__builtin_ctzll(df) >> 3;
+                        const u64 ua = xa != xb ? xa : xa8, ub = xa != xb ? xb : xb8;
+                        solved = true;
+                        lo_less = (u32)((ua >> (8u * byte)) & 0xFFull) < (u32)((ub >> (8u * byte)) & 0xFFull);
+                    }
+                }
+                todo &= ~__ballot(solved);
+            }
             for (u32 tries = 0; todo && tries < kLinkTries; ++tries) {
                 const u32 L = (u32)__builtin_ctzll(todo);
                 const u32 dL = wave_lane(dist, L), xL = wave_lane(x, L);
@@ -2949,11 +2993,15 @@ __global__ __launch_bounds__(kSortThreads) void k_link_scan(BwtArgs a, u32 step,
                 u32 scanned = 0;
                 bool found = false;
                 while (scanned + depth < n) { // (all the way: two members that agree to the end are equal rotations, a periodic block)
-                    u32 pa = sp + 8u * l;
+                    // (a lane whose eight bytes begin a whole turn behind the leader's start and more has nothing new to look at --
+                    // and in a block shorter than the 512 bytes of a step its position would wrap twice: a periodic block
+                    // of 72 bytes came out in the wrong order, tests/golden/fuzz_r6_links_2414.bin)
+                    const bool in_turn = scanned + 8u * l + depth < n;
+                    u32 pa = sp + (in_turn ? 8u * l : 0u);
                     pa = pa >= n ? pa - n : pa;
                     u32 pb = pa + dL;
                     pb = pb >= n ? pb - n : pb;
-                    const u64 xa = link_load8(text, n, pa), xb = link_load8(text, n, pb);
+                    const u64 xa = link_load8(text, n, pa), xb = in_turn ? link_load8(text, n, pb) : xa;
                     const u64 df = xa ^ xb;
                     const u64 bm = __ballot(df != 0ull);
                     if (bm) {
@@ -3012,30 +3060,16 @@ __device__ __forceinline__ bool link_rank(const u8 *__restrict__ gb8, const u8 *
     return all && rank < size;
 }
 
-__global__ __launch_bounds__(kSortThreads) void k_link_keys(BwtArgs a, const u32 *__restrict__ VS, u8 *__restrict__ impure)
+// A group all of whose members have all their comparisons decided is ORDERED, and its members are final at once: member x
+// stands at the group's first place in SA + its rank.  What k_group_apply does for a rotation that becomes final is done
+// right here -- SA, the last column, origPtr, the rank word (a 4-byte store at random: they are a few per group, and the
+// rotations leave the list for good) -- and the entry's group byte becomes 1: the period round's passes and the link round's
+// compaction leave it out, so everything behind this kernel runs on what is LEFT (a third of the list on the corpus
+// "binary", where the passes, the flags and the apply kernel over the whole list were 14 of the round's 30 ms).
+// tile_nf[tile] = entries of the tile that stay (for k_link_compact).
+__global__ __launch_bounds__(kSortThreads) void k_link_finalize(BwtArgs a, const u32 *__restrict__ VS, const u8 *__restrict__ impure)
 {
-    u32 tile, lb;
-    xcd_remap(gridDim.x, a.nb, tile, lb);
-    if (lb == 0xFFFFFFFFu) return;
-    const u32 cnt = a.count[lb];
-    const u32 start = tile * kSortTile;
-    const size_t base = (size_t)lb * kSlot;
-    if (start >= cnt || impure[base + kSlot - 2u] == 0) return; // (no small group: every group byte of the block's list is 0 already)
-    u8 *gb8 = group_bytes(a, lb);
-    const u8 *lk8 = link_bytes(a, lb);
-    for (u32 idx = start + threadIdx.x; idx < cnt && idx < start + kSortTile; idx += kSortThreads) {
-        u32 g0 = 0, rank = 0;
-        bool first = false;
-        const bool ranked = link_rank(gb8, lk8, idx, cnt, g0, rank, first);
-        if (ranked && first) impure[base + (a.R[base + VS[base + idx]] & ~kFinalBit)] = 2;
-        gb8[idx] = ranked ? (u8)(2u + rank) : (u8)0; // (each entry reads its own group byte only: nobody else's read is disturbed)
-    }
-}
-
-// a link round's list: the survivors in group order, the members of ranked groups in their order; keys = the group heads
-__global__ __launch_bounds__(kSortThreads) void k_link_permute(BwtArgs a, const u32 *__restrict__ VS, u32 *__restrict__ Kout, u32 *__restrict__ Vout,
-                                                                u8 *__restrict__ impure)
-{
+    __shared__ u32 s_stay;
     u32 tile, lb;
     xcd_remap(gridDim.x, a.nb, tile, lb);
     if (lb == 0xFFFFFFFFu) return;
@@ -3043,19 +3077,100 @@ __global__ __launch_bounds__(kSortThreads) void k_link_permute(BwtArgs a, const 
     const u32 start = tile * kSortTile;
     const size_t base = (size_t)lb * kSlot;
     if (start >= cnt) return;
-    const bool any = impure[base + kSlot - 2u] != 0;
-    const u8 *gb8 = group_bytes(a, lb);
+    const u32 here = cnt - start < kSortTile ? cnt - start : kSortTile;
+    if (impure[base + kSlot - 2u] == 0) { // (no small group: every group byte of the block's list is 0 already, everything stays)
+        if (threadIdx.x == 0) a.tile_nf[lb * kTilesPerBlock + tile] = here;
+        return;
+    }
+    if (threadIdx.x == 0) s_stay = 0;
+    __syncthreads();
+    const BlockDesc d = a.blocks[lb];
+    const u32 n = d.n;
+    const u8 *__restrict__ text = a.rle + d.rle_off;
+    u8 *gb8 = group_bytes(a, lb);
     const u8 *lk8 = link_bytes(a, lb);
+    u32 stay = 0;
     for (u32 idx = start + threadIdx.x; idx < cnt && idx < start + kSortTile; idx += kSortThreads) {
-        const u32 x = VS[base + idx];
-        const u32 head = a.R[base + x] & ~kFinalBit;
         u32 g0 = 0, rank = 0;
         bool first = false;
-        const bool ranked = any && link_rank(gb8, lk8, idx, cnt, g0, rank, first);
-        if (ranked && first) impure[base + head] = 2;
-        const u32 at = ranked ? g0 + rank : idx;
-        Kout[base + at] = head;
-        Vout[base + at] = x;
+        const bool ranked = link_rank(gb8, lk8, idx, cnt, g0, rank, first);
+        // (the group's first place in SA is the rank of any of its members: the entry that stands first in the list looks it up,
+        // the others take it from that lane when it belongs to the same wave)
+        const u32 x = VS[base + idx];
+        const u32 off = idx - g0;
+        const bool same_wave = ranked && off <= (threadIdx.x & 63u);
+        u32 head = (ranked && !same_wave) || (ranked && first) ? (a.R[base + x] & ~kFinalBit) : 0u;
+        {
+            const u32 from = __shfl(head, (int)((threadIdx.x & 63u) - (same_wave ? off : 0u)), 64);
+            if (same_wave && !first) head = from;
+        }
+        if (ranked) {
+            const u32 pos = head + rank;
+            a.SA[base + pos] = x;
+            a.L[base + pos] = text[x ? x - 1u : n - 1u];
+            if (x == 0) a.orig_ptr[lb] = pos;
+            a.R[base + x] = pos | kFinalBit;
+        } else {
+            stay += 1;
+        }
+        gb8[idx] = ranked ? (u8)1 : (u8)0; // (each entry reads its own group byte only: nobody else's read is disturbed)
+    }
+    stay = wave_sum(stay);
+    if ((threadIdx.x & 63u) == 0 && stay) atomicAdd(&s_stay, stay);
+    __syncthreads();
+    if (threadIdx.x == 0) a.tile_nf[lb * kTilesPerBlock + tile] = s_stay;
+}
+
+// a link round's list: what k_link_finalize left, in list (= group) order; keys = the group heads
+__global__ __launch_bounds__(kSortThreads) void k_link_compact(BwtArgs a, const u32 *__restrict__ VS, u32 *__restrict__ Kout, u32 *__restrict__ Vout)
+{
+    constexpr u32 NW = kSortThreads / 64;
+    __shared__ u32 s_off, s_wsum[NW];
+    u32 tile, lb;
+    xcd_remap(gridDim.x, a.nb, tile, lb);
+    if (lb == 0xFFFFFFFFu) return;
+    const u32 cnt = a.count2[lb]; // (the whole survivor list; count becomes what is left)
+    const u32 start = tile * kSortTile;
+    const u32 ntiles = (cnt + kSortTile - 1) / kSortTile;
+    if (tile == 0 && threadIdx.x == 0) {
+        u32 tot = 0;
+        for (u32 t = 0; t < ntiles; ++t) tot += a.tile_nf[lb * kTilesPerBlock + t];
+        a.count[lb] = tot;
+    }
+    if (start >= cnt) return;
+    const size_t base = (size_t)lb * kSlot;
+    if (threadIdx.x == 0) {
+        u32 off = 0;
+        for (u32 t = 0; t < tile; ++t) off += a.tile_nf[lb * kTilesPerBlock + t];
+        s_off = off;
+    }
+    const u8 *gb8 = group_bytes(a, lb);
+    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const u32 wbase = start + w * 1024u;
+    u64 keep[16];
+    u32 xv[16];
+    u32 wcount = 0;
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 idx = wbase + r * 64u + l;
+        const u32 c = idx < cnt ? idx : cnt - 1u;
+        xv[r] = ld_stream(VS + base + c);
+        keep[r] = __ballot(idx < cnt && gb8[c] != 1u);
+        wcount += (u32)__popcll(keep[r]);
+    }
+    if (l == 0) s_wsum[w] = wcount;
+    __syncthreads();
+    u32 off = s_off;
+    for (u32 k = 0; k < w; ++k) off += s_wsum[k];
+    const u64 lt_mask = (l == 0) ? 0ull : (~0ull >> (64 - l));
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        if ((keep[r] >> l) & 1ull) {
+            const u32 at = off + (u32)__popcll(keep[r] & lt_mask);
+            Kout[base + at] = a.R[base + xv[r]] & ~kFinalBit;
+            Vout[base + at] = xv[r];
+        }
+        off += (u32)__popcll(keep[r]);
     }
 }
 
@@ -3077,22 +3192,70 @@ __global__ __launch_bounds__(kSortThreads) void k_period_mark(BwtArgs a, u32 ste
     const u32 kmax = per_kmax(a);
     (void)step;
     const size_t base = (size_t)lb * kSlot;
-    for (u32 idx = start + threadIdx.x; idx < cnt && idx < start + kSortTile; idx += kSortThreads) {
-        if (idx == 0) continue;
-        const u32 g = K[base + idx], gp = K[base + idx - 1];
-        if (g != gp || impure[base + g] == 2) continue; // (2: a group of two that k_pair_compare has ordered)
-        const u32 v = V[base + idx], vp = V[base + idx - 1];
-        const u32 lo = v < vp ? v : vp, dist = v < vp ? vp - v : v - vp;
-        bool chain = false;
-        for (u32 i = 0; i < kmax; ++i) {
-            const u32 p = a.lin_p[(size_t)lb * kPerK + i];
-            if (p == 0u) break;
-            if (p != dist) continue;
-            const bool lo_first = per_lt_at(a, lb, i, n, per_first_mis(a, lb, i, lo)); // rot(lo) < rot(lo + p)
-            chain = lo_first == (vp == lo); // the list has vp in front of v
-            break;
+    u32 lp[kPerK];
+#pragma unroll
+    for (u32 i = 0; i < kPerK; ++i) lp[i] = i < kmax ? a.lin_p[(size_t)lb * kPerK + i] : 0u;
+    // (round 6) the sixteen rows of a lane together, every phase's loads in flight at once (the kernel took an entry at a
+    // time: a chain of five dependent loads each, 11 ms per GiB of the stress corpus T2 -- a tenth of its step)
+    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const u32 first = start + w * 1024u + l;
+    u32 g[16], v[16];
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 idx = first + r * 64u;
+        const u32 c = idx < cnt ? idx : cnt - 1u;
+        g[r] = ld_stream(K + base + c);
+        v[r] = ld_stream(V + base + c);
+    }
+    u32 pg0 = 0, pv0 = 0;
+    if (l == 0 && first > 0 && first < cnt) {
+        pg0 = K[base + first - 1];
+        pv0 = V[base + first - 1];
+    }
+    u32 lo[16], wh[16];
+    u32 act = 0, vp_lo = 0; // per row: the pair is checked against the tables; the element in front is the pair's smaller start
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        const u32 idx = first + r * 64u;
+        u32 pg = wave_shr1(g[r]), pv = wave_shr1(v[r]);
+        const u32 qg = (r == 0) ? pg0 : wave_lane(g[(r + 15) & 15], 63);
+        const u32 qv = (r == 0) ? pv0 : wave_lane(v[(r + 15) & 15], 63);
+        if (l == 0) {
+            pg = qg;
+            pv = qv;
         }
-        if (!chain) impure[base + g] = 1;
+        lo[r] = v[r] < pv ? v[r] : pv;
+        wh[r] = kPerK;
+        if (idx < cnt && idx > 0 && g[r] == pg) {
+            const u32 dist = v[r] < pv ? pv - v[r] : v[r] - pv;
+#pragma unroll
+            for (u32 i = 0; i < kPerK; ++i)
+                if (lp[i] != 0u && lp[i] == dist) wh[r] = i;
+            if (wh[r] == kPerK) impure[base + g[r]] = 1; // (no listed distance apart)
+            else {
+                act |= 1u << r;
+                vp_lo |= (pv == lo[r] ? 1u : 0u) << r;
+            }
+        }
+    }
+    u64 here[16];
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) here[r] = ((act >> r) & 1u) ? (per_mis(a, lb, wh[r])[lo[r] >> 6] & (~0ull << (lo[r] & 63u))) : 1ull;
+    u32 m[16];
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r)
+        m[r] = here[r] ? ((lo[r] >> 6) << 6) + (u32)__builtin_ctzll(here[r]) : per_nxt(a, lb, wh[r])[(lo[r] >> 6) + 1u];
+    u64 ltw[16];
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        if (m[r] >= n) m[r] -= n;
+        ltw[r] = ((act >> r) & 1u) ? per_lt(a, lb, wh[r])[m[r] >> 6] : 0ull;
+    }
+#pragma unroll
+    for (u32 r = 0; r < 16; ++r) {
+        if (!((act >> r) & 1u)) continue;
+        const bool lo_first = (ltw[r] >> (m[r] & 63u)) & 1ull;   // rot(lo) < rot(lo + p)
+        if (lo_first != (((vp_lo >> r) & 1u) != 0u)) impure[base + g[r]] = 1; // (the list has the element in front first)
     }
 }
 
@@ -3342,7 +3505,10 @@ static void radix_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const
     else if (SRC == SRC_MM && Ktmp)
         hipLaunchKernelGGL((k_radix_scatter<SRC_MMK, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Ktmp,
                            Vin, Kout, Vout);
-    else if ((SRC == SRC_SURV || SRC == SRC_LISTG || SRC == SRC_PERJ) && Ktmp) // the gathered keys were kept: a plain pair list now
+    else if (SRC == SRC_PERJ && Ktmp) // (bit 31 of a kept key: a member of a ranked group, final already)
+        hipLaunchKernelGGL((k_radix_scatter<SRC_PERJK, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Ktmp,
+                           Vin, Kout, Vout);
+    else if ((SRC == SRC_SURV || SRC == SRC_LISTG) && Ktmp) // the gathered keys were kept: a plain pair list now
         hipLaunchKernelGGL((k_radix_scatter<SRC_PAIRS, BITS>), grid, dim3(kSortThreads), 0, st, a, shift, h, Ktmp,
                            Vin, Kout, Vout);
     else
@@ -3582,7 +3748,8 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
     // until one of them orders less than a quarter of what it was given (the groups that are left are large)
     bool last_doubled = false, links_pay = true;
     u64 link_m = 0; // what the last link round was given (0: the last round was none)
-    if (!(a.gh_tiles && a.per_aux)) a.per_links = 0; // (the bitmap of the small groups' starts lives where the period tables live without the fused passes' slot)
+    if (!(a.gh_tiles && a.per_aux)) a.per_links = 0; // (only with the fused passes' workspace: the period tables then live in the digit counts' slot)
+    const u32 links_on = a.per_links;
     bool surv_local_ok = true; // (no segment of a survivor round of this sort has overflowed LDS so far)
     u32 list_tiles = a.tiles; // (the first refinement ran on all of SA)
     while (true) {
@@ -3647,7 +3814,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             if ((link_m - m) * 4 < link_m) links_pay = false;
             link_m = 0;
         }
-        const bool link_round = !per_round && a.per_links && period_done && last_doubled && links_pay && m * 256 >= total_n;
+        const bool link_round = !per_round && links_on && period_done && last_doubled && links_pay && m * 256 >= total_n;
         // survivor form below this share of the rotations (BZ_SURV_SHARE=num/den, default 1/4: measured)
         static const u64 surv_num = [] { const char *e = getenv("BZ_SURV_SHARE"); unsigned a = 1, b = 4; if (e && sscanf(e, "%u/%u", &a, &b) == 2 && a && b) return (u64)a; return (u64)1; }();
         static const u64 surv_den = [] { const char *e = getenv("BZ_SURV_SHARE"); unsigned a = 1, b = 4; if (e && sscanf(e, "%u/%u", &a, &b) == 2 && a && b) return (u64)b; return (u64)4; }();
@@ -3663,21 +3830,24 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             else link_m = m;
             (void)hipMemsetAsync(impure, 0, (size_t)a.nb * kSlot, st);
             // The members of small groups leave their place in the compacted list under their start (midx: the keys of the
-            // list the last refinement ran on, which nothing reads any more) and a bit in a bitmap of such starts (the flag
-            // bytes' slot, free until this round's k_group_flags); k_link_scan ranks them, k_link_keys / k_link_permute
-            // take the groups that are decided.  BZ_LINK_ROUND=0: neither (the period round keeps its tables and chains).
-            const bool links = a.per_links != 0;
+            // list the last refinement ran on, which nothing reads any more); k_link_scan ranks them, k_link_finalize makes
+            // the members of decided groups final, and the rest of the round runs on what is left.  BZ_LINK_ROUND=0: none
+            // of it (the period round keeps its tables and chains).
+            // (a period round taken at once -- the batch unordered to the last rotation behind the init: a paragraph repeated --
+            // meets groups of hundreds, none of eight: clearing midx and the compaction's extra work cost 2 % of such a batch)
+            const bool links = links_on != 0 && !(per_round && rounds == 1);
+            a.per_links = links ? 1u : 0u; // (the round's kernels look at the group bytes only when the round has written them)
             u32 *midx = cK;
             if (links) (void)hipMemsetAsync(midx, 0, (size_t)a.nb * kSlot * sizeof(u32), st); // (0: the start is no member of a small group)
-            hipLaunchKernelGGL(k_survivor_compact, grid_prev, dim3(kSortThreads), 0, st, a, lastV, fV, links ? midx : nullptr);
+            hipLaunchKernelGGL(k_survivor_compact, grid_prev, dim3(kSortThreads), 0, st, a, lastV, fV, links ? midx : nullptr, per_round ? 1u : 0u);
             hipLaunchKernelGGL(k_copy_counts, dim3((a.nb + 255) / 256), dim3(256), 0, st, a.count, a.count2, a.nb);
             if (links) hipLaunchKernelGGL(k_link_scan, grid, dim3(kSortThreads), 0, st, a, step, fV, midx, impure);
+            if (links) hipLaunchKernelGGL(k_link_finalize, grid_list, dim3(kSortThreads), 0, st, a, fV, impure);
             if (link_round) {
-                // no tables, no passes: the list is in group order, a ranked member's place is its group's first + its rank
+                // no tables, no passes: what the ranked groups leave behind, in list order (count2: the whole list, count: the rest)
                 (void)hipMemsetAsync(a.lin_p, 0, (size_t)a.nb * kPerK * 4, st);
-                hipLaunchKernelGGL(k_link_permute, grid_list, dim3(kSortThreads), 0, st, a, fV, cK, cV, impure);
+                hipLaunchKernelGGL(k_link_compact, grid_list, dim3(kSortThreads), 0, st, a, fV, cK, cV);
             } else {
-            if (links) hipLaunchKernelGGL(k_link_keys, grid_list, dim3(kSortThreads), 0, st, a, fV, impure);
             // the blocks' distances and the bitmaps that order rotation i against rotation i + p (in the digit counts' slot)
             hipLaunchKernelGGL(k_period_find, dim3(a.nb), dim3(kSortThreads), 0, st, a, 3u);
             hipLaunchKernelGGL(k_period_bits, grid, dim3(kSortThreads), 0, st, a);
@@ -3789,6 +3959,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             p = prof ? prof->begin(st, KID_GROUP_FLAGS, m * 13) : -1;
             hipLaunchKernelGGL((k_group_flags<false>), grid_list, dim3(kSortThreads), 0, st, a, step, cK, cV, impure);
             a.per_wide = 0;
+            a.per_links = links_on;
             if (prof) prof->end(st, p);
             p = prof ? prof->begin(st, KID_GROUP_APPLY, m * 17) : -1;
             hipLaunchKernelGGL((k_group_apply<false>), grid_list, dim3(kSortThreads), 0, st, a, step, slot, cK, cV, fK);

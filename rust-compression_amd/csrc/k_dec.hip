@@ -1692,15 +1692,17 @@ __global__ __launch_bounds__(256) void k_dec_scan4(const u8 *__restrict__ in, u6
     const u32 *w = reinterpret_cast<const u32 *>(in);
     const u64 nwords = (nbytes + 3u) / 4u;
     const u32 r = (u32)(nbytes & 3u);
-    const u32 tail_mask = r ? ~(0xFFFFFFFFu >> (8u * r)) : 0xFFFFFFFFu;
     u32 x[3];
 #pragma unroll
     for (u32 k = 0; k < 3; ++k) {
         const u64 i = t + k;
         u32 v = 0;
-        if (i < nwords) {
+        if (i + 1 == nwords && r) {
+            // (the last, partial word byte by byte: a caller's buffer of exactly nbytes ends here -- bz_gpu_decode_device may be
+            // handed a sub-range of a larger allocation or the last bytes of one)
+            for (u32 b = 0; b < r; ++b) v |= (u32)in[i * 4u + b] << (24u - 8u * b);
+        } else if (i < nwords) {
             v = __builtin_bswap32(w[i]);
-            if (i + 1 == nwords) v &= tail_mask;
         }
         x[k] = v;
     }

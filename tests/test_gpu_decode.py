@@ -213,6 +213,21 @@ def test_false_magic_inside_payload(pkg, oracle):
     both(pkg, oracle, z + b"BZh9" + magic * 20)
 
 
+def test_junk_tail_full_of_block_magics(pkg, oracle):
+    """a valid stream followed by megabytes that hold the 48-bit block magic by the hundred thousand.
+    The candidates behind the chain's end must not be priced as blocks when the host buffer grows (rounds 5's estimate asked
+    for terabytes and returned BZ_E_NOMEM, dropping every byte decoded): the bytes of the valid stream come out, then the
+    reference's verdict (bzip2/decoder.rs:163-581: the next record's magic is wrong)."""
+    import corpus
+    magic = bytes.fromhex("314159265359")
+    d = corpus.chapter(3, 2_500_000)
+    z = bz2.compress(d, 9)
+    junk = (magic + b"\x00\x11") * 400_000  # 3.2 MB, 400 000 candidates
+    for tail in (junk, b"BZh9" + junk):
+        out, st = both(pkg, oracle, z + tail, cap=4_000_000)
+        assert out == d and st != 0
+
+
 # ---- device API ------------------------------------------------------------------------------------------
 def test_decode_device_api(pkg, oracle, eng):
     import torch

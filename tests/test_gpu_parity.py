@@ -694,6 +694,19 @@ print(hashlib.sha256(pkg.compress(d, 1)).hexdigest())
     assert out.stdout.strip().splitlines()[-1] == hashlib.sha256(oracle.encode(data, 1)).hexdigest()
 
 
+@pytest.mark.parametrize("name", ["fuzz_r6_links_880.bin", "fuzz_r6_small_1522.bin", "fuzz_r6_links_2414.bin"])
+def test_fuzz_cases_of_round_6(pkg, oracle, name):
+    """Two inputs tools/fuzz_parity.py found against the first build of the link rounds: a level-1 block of copies and,
+    behind the cut, a block of one or two bytes in the same batch -- its group of two equal rotations was taken for a small
+    group, k_link_scan leaves such blocks alone, and the stale link byte of an earlier batch ranked it; and a PERIODIC block
+    of 72 bytes behind the cut, whose equal rotations the scan of a 512-byte step compared beyond the block's end."""
+    with open(os.path.join(GOLDEN, name), "rb") as f:
+        d = f.read()
+    for level in (1, 9):
+        assert pkg.compress(d, level) == oracle.encode(d, level), (name, level)
+    assert pkg.compress(d + d[:3], 1) == oracle.encode(d + d[:3], 1)
+
+
 def test_period_round_in_mixed_batches(pkg, oracle):
     """A batch in which every third block is a deep repeat (text, text, a 4 KiB paragraph repeated, ...): the period
     round is triggered by the BLOCKS that need it (round 4; rounds 1-3 looked at the batch as a whole, which such a

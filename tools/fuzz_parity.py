@@ -10,8 +10,16 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-pkg = importlib.import_module("rust-compression_amd")
 from oracle import oracle
+if os.environ.get("FUZZ_REPLAY"):
+    # FUZZ_REPLAY=<case>: no GPU -- the oracle stands in for the library, the input of that case is written to
+    # /tmp/fuzz_case.bin (the generators draw from one seeded stream: a failing case of a GPU run is found again here)
+    class _Stub:
+        compress = staticmethod(lambda d, lvl: oracle.encode(d, lvl))
+        decompress = staticmethod(lambda z: oracle.decode(z, max(1 << 20, 300 * len(z) + 1024)))
+    pkg = _Stub()
+else:
+    pkg = importlib.import_module("rust-compression_amd")
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -37,8 +45,44 @@ def gen_copies():
     return bytes(out[:n + rng.randrange(0, 5)])
 
 
+def gen_links():
+    """round 6: what the link rounds and the split of short-period stretches are about -- a unit that repeats inside itself,
+    copied two to ten times with a byte changed every few hundred to few thousand bytes (groups of 2 .. 8 and beyond, in mixed
+    order, a changed byte in a middle copy), and stretches that repeat 1 .. 9 bytes, cut by changed bytes (up- and downward)"""
+    k = rng.choice([4, 16, 64, 200])
+    n = rng.choice([30000, 99981, 120000, 250000])
+
+    def rnd(m):
+        return bytes(rng.randrange(k) for _ in range(m))
+
+    def touched(b, every):
+        b = bytearray(b)
+        for pos in range(rng.randrange(every), len(b), every):
+            b[pos] = (b[pos] + rng.choice([1, 2, 255, 128])) & 255
+        return bytes(b)
+
+    out = bytearray(rnd(rng.choice([0, 1, 3, 500])))
+    while len(out) < n:
+        what = rng.randrange(3)
+        if what == 0:
+            inner = rnd(rng.choice([100, 1000, 5000]))
+            unit = inner + rnd(rng.choice([0, 50, 2000])) + touched(inner, rng.choice([64, 700, 4096]))
+            for _ in range(rng.choice([2, 3, 4, 10])):
+                out += touched(unit, rng.choice([300, 2048, 4096]))
+        elif what == 1:
+            p = rnd(rng.choice([1, 2, 4, 5, 9]))
+            out += touched(p * rng.choice([200, 3000, 20000]), rng.choice([97, 1900, 4096]))
+        else:
+            out += rnd(rng.choice([10, 3000]))
+    return bytes(out[:n + rng.randrange(0, 5)])
+
+
 def gen():
-    kind = rng.randrange(10)
+    if os.environ.get("FUZZ_ONLY") == "links":
+        return gen_links()
+    kind = rng.randrange(12)
+    if kind >= 10:
+        return gen_links()
     if kind >= 8:
         return gen_copies()
     n = rng.choice([0, 1, 2, 3, 5, 17, 255, 256, 257, 1000, 4096, 50000, 99980, 99981, 99982, 100010, 150000, 250000])
@@ -247,6 +291,10 @@ while time.time() - t0 < budget:
     d = gen_case()
     lvl = rng.choice([1, 1, 1, 2, 9]) if flavour == "small" else rng.choice([9, 9, 5])
     cases += 1
+    if os.environ.get("FUZZ_REPLAY") and cases == int(os.environ["FUZZ_REPLAY"]):
+        open("/tmp/fuzz_case.bin", "wb").write(d)
+        print("case", cases, "len", len(d), "level", lvl, "written to /tmp/fuzz_case.bin")
+        sys.exit(0)
     if os.environ.get("FUZZ_VERBOSE"):
         print("case", cases, "len", len(d), "level", lvl, "t %.1f" % (time.time() - t0), flush=True)
     want = oracle.encode(d, lvl)
