@@ -141,7 +141,7 @@ void bz_free(void *p);
  * buffers and 2 x BZ_ENC_CHUNK_MIB of pinned host memory in a per-process cache (two device lists at most) when they
  * end, so that the next one does not pay hipMalloc / hipHostMalloc again (fresh device memory costs about 40 ms per
  * GiB on this platform: the FIRST 1 GiB call of a process takes 0.35 s, a later one 0.1 s).  This call releases what
- * is parked; BZ_ENC_NO_CACHE=1 in the environment turns the cache off.  The decode and Deflate entry points over host
+ * is parked (call it between contexts to run without the cache).  The decode and Deflate entry points over host
  * buffers (bz_decode_buffer, bz_dec_*, df_encode_buffer, df_enc_*) park up to TWO engines per device the same way (the
  * lanes of a streaming decoder; a decode workspace is about 13 MB of HBM per block of the largest stream seen; a call
  * takes an engine that holds its kind of workspace, else the one parked last), and bz_dec_* contexts leave up to four of

@@ -18,9 +18,6 @@ constexpr u32 kWave = 64;
 constexpr u32 kMaxBlockLen = 900000;        // 100000*level, >= n (n <= 100000*level - 19 + 4)
 constexpr u32 kSortTile = 8192;             // elements per radix tile: 8 waves x 16 rows x 64 lanes
 constexpr u32 kSortThreads = 512;
-#ifndef BZ_LB_SMALL_TILE // (an A/B build switch of the fused radix pass, k_bwt.hip; 1 = half tiles for the streamed sources)
-#define BZ_LB_SMALL_TILE 0
-#endif
 constexpr u32 kTilesPerBlock = 110;         // ceil(900000 / 8192)
 constexpr u32 kSlot = kTilesPerBlock * kSortTile; // 901120: per-block stride of the u32 work arrays
 constexpr u32 kMaxBins = 2048;              // 11-bit digits for the initial 32-bit key sort
@@ -29,10 +26,7 @@ constexpr u32 kGSize = 50;                  // BZ_G_SIZE, src/bzip2/mod.rs:20
 constexpr u32 kMaxSelectors = 18002;        // BZ_MAX_SELECTORS, src/bzip2/encoder.rs:295
 constexpr u32 kMaxAlpha = 258;
 constexpr u32 kRleTile = 4096;              // input bytes per RLE1/CRC tile (256 threads x 16 B)
-#ifndef BZ_MTF_CHUNK
-#define BZ_MTF_CHUNK 512
-#endif
-constexpr u32 kMtfChunk = BZ_MTF_CHUNK;     // symbols per serial MTF chunk (one lane each)
+constexpr u32 kMtfChunk = 512;     // symbols per serial MTF chunk (one lane each)
 constexpr u32 kMaxMtfChunks = (kMaxBlockLen + kMtfChunk - 1) / kMtfChunk; // 3516
 // words reserved per block bit string: header (<= ~27k bits) + 900001 symbols x 17 bits (+ slack)
 constexpr u32 kStreamWords = 480000;        // 1.92 MB
@@ -85,25 +79,14 @@ struct BlockOut {
 // ---- streaming access hints -----------------------------------------------------
 // Arrays that are swept once per kernel (sorted pair lists, SA as the walk source) are loaded
 // non-temporally so they do not push the block's rank array (3.6 MB, gathered at random) out of the
-// XCD's 4 MiB L2.  -DBZ_USE_NT=0 turns the hint off (A/B switch).
-#ifndef BZ_USE_NT
-#define BZ_USE_NT 1
-#endif
+// XCD's 4 MiB L2 (+2.4 % of the step, measured in round 2).
 template <class T> __device__ __forceinline__ T ld_stream(const T *p)
 {
-#if BZ_USE_NT
     return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
 }
 template <class T> __device__ __forceinline__ void st_stream(T *p, T v)
 {
-#if BZ_USE_NT
     __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
 }
 
 // The same for element `idx` of an array whose start is wave-uniform, with the byte offset kept in 32 bits (idx < 2^30):
@@ -242,8 +225,8 @@ __device__ __forceinline__ bool lb_give_up(u32 &spins, const u32 *sort_err, u32 
 // 16-byte accesses that the other compute units OF THE SAME XCD observe: plain stores are written
 // through to the XCD's L2 and stay there, `nt` loads bypass the L1 and are served by that L2
 // (MI355X_MICROARCH.md).  Producer and consumer of a look-back word always share an XCD (tickets are
-// taken from the counter of the XCD a workgroup runs on).  -DBZ_LB_SC1 selects accesses that are
-// coherent across XCDs instead (sc1; 2-3x the latency, and such stores drop the L2 line).  A 16-byte
+// taken from the counter of the XCD a workgroup runs on).  (Accesses that are coherent across XCDs -- sc1 -- have 2-3x
+// the latency, and such stores drop the L2 line: the first build used them and won 2.5 % where this one wins 7.)  A 16-byte
 // granule written by one store is seen whole.
 typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_sc1_x4(u32 *p, uint4 v)
@@ -251,20 +234,12 @@ __device__ __forceinline__ void st_sc1_x4(u32 *p, uint4 v)
     const u32x4_t r = {v.x, v.y, v.z, v.w};
     // (s_nop: a store of more than 8 bytes reads its data registers a cycle late; the compiler's hazard
     // recogniser does not look inside inline assembly)
-    #ifndef BZ_LB_SC1
     asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(r) : "memory");
-#else
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(r) : "memory");
-#endif
 }
 __device__ __forceinline__ uint4 ld_sc1_x4(const u32 *p)
 {
     u32x4_t r;
-    #ifndef BZ_LB_SC1
     asm volatile("global_load_dwordx4 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
-#else
-    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
-#endif
     return make_uint4(r.x, r.y, r.z, r.w);
 }
 
@@ -272,11 +247,7 @@ __device__ __forceinline__ uint4 ld_sc1_x4(const u32 *p)
 // them: the compiler does not know that the registers are filled late)
 __device__ __forceinline__ void ld_sc1_x4_issue(const u32 *p, u32x4_t &r)
 {
-#ifndef BZ_LB_SC1
     asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(r) : "v"(p) : "memory");
-#else
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r) : "v"(p) : "memory");
-#endif
 }
 __device__ __forceinline__ void ld_x4_wait_all() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
 
@@ -367,8 +338,8 @@ struct BwtArgs {
                                      //   with themselves, widest agreement first (0: none / no more), and that agreement
                                      //   in permille of the block
     u32 *bin_cursor;                 // [nb][1024] rank words binned so far (k_group_apply -> k_rank_place)
-    u32 *pb_gate;                    // [nb] != 0: phase B of the init by the global passes (0: k_phase_b_local did it)
-    u32 *loc_stats;                  // [4] k_phase_b_local: segments, overflows, segments out of order, LDS passes
+    u32 *pb_gate;                    // [nb] != 0: phase B of the init by the global passes (always, since round 6: the LDS form is gone)
+    u32 *loc_stats;                  // [64] k_surv_local's counters (LOC_STAT_*), the phase timers of the instrumented builds
     u8 *L;                           // [nb * kSlot] last column, written as rotations become final
     u32 *orig_ptr;                   // [nb] position of rotation 0 in the sorted order
     u8 *ptext;                       // [nb * kSlot] the blocks' symbols packed for pkey() (k_pack_text); borrowed: the
@@ -379,7 +350,6 @@ struct BwtArgs {
     u32 *gh_tiles;                   // [nb][kTilesPerBlock][3][kMaxBins] per-tile digit counts of a whole phase
     u32 *gbase;                      // [nb][3][kMaxBins] digits smaller, per digit position
     u32 *tile_state;                 // [nb][kTilesPerBlock][kMaxBins] look-back words: epoch | flag | value
-    u32 *tile_state2;                // [nb][2 kTilesPerBlock][kMaxBins] the same for passes over half tiles (BZ_LB_SMALL_TILE), or nullptr
     u32 *tickets;                    // [kSortEpochs][8] tile tickets per pass and XCD
     u32 *sort_err;                   // [1] a look-back that gave up
     u32 *epoch;                      // host: the engine's pass counter (1 .. kSortEpochs-1)
@@ -414,7 +384,6 @@ struct MtfArgs {
     u32 *zstate;             // [nb][kTilesPerBlock][4] look-back words of k_zle_fused
     u32 *ztick;              // [16] its tile tickets per XCD, [8]: a look-back gave up
     u32 fused_zle;           // 1: k_zle_fused; 0: k_zle_last + k_zle_emit<false> + k_zle_emit<true>
-    u32 walk_above;          // blocks with more symbols in use than this take the list walk (k_mtf_ranks): 256 = none, 96 = rounds 1-3
     u16 *mtf;                // [nb][kMtfStride] output symbols
     u32 *mtf_freq;           // [nb][kMaxAlpha]
     BlockOut *out;           // [nb]
@@ -477,10 +446,7 @@ struct DecBlockInfo {
     u8 seq2unseq[256];
 };
 
-#ifndef BZ_DEC_SAMPLE_STEP
-#define BZ_DEC_SAMPLE_STEP 128
-#endif
-constexpr u32 kDecSampleStep = BZ_DEC_SAMPLE_STEP;             // every n-th T slot is a sample node
+constexpr u32 kDecSampleStep = 128;             // every n-th T slot is a sample node
 constexpr u32 kDecSamples = kMaxBlockLen / kDecSampleStep + 3; // sample nodes per block (the last one = the start node)
 constexpr u32 kSegCap = 4 * kDecSampleStep;                    // scratch bytes per segment (mean length = the step)
 constexpr u32 kDecSubs = kSlot / 64;                           // 64-byte RLE1-undo sub-tiles per block
@@ -599,7 +565,6 @@ void launch_block_symbols(hipStream_t st, const BwtArgs &a, u32 *inuse_bits, u8 
 int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned long long *h_active,
             u64 *sorted_elems, KernelProf *prof, u64 *round_active /*[64] or null*/, bool wide_keys,
             u32 min_chars);
-void launch_last_column(hipStream_t st, const BwtArgs &a, u8 *L, u32 *orig_ptr, u64 total_n, KernelProf *prof);
 void launch_mtf(hipStream_t st, const MtfArgs &a);
 void launch_huffman(hipStream_t st, const HuffArgs &a);
 void launch_probe_code_lengths(hipStream_t st, const u32 *d_freq, u32 alpha, u8 *d_out, u32 *lm_scr,

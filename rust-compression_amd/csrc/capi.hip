@@ -66,7 +66,7 @@ extern "C" const char *bz_version(void) { return "bz2_mi355x 0.1 (gfx950)"; }
 // ---- the pipeline behind a context -------------------------------------------------------------
 // Host bytes reach the GPUs in CHUNKS (BZ_ENC_CHUNK_MIB, default 192 MiB since round 4 -- half the device and pinned
 // memory of 384 MiB for one per cent of the warm rate, and a first call that allocates half as much --, the first one of
-// a stream 64 MiB, BZ_ENC_FIRST_MIB: a
+// a stream 64 MiB: a
 // large batch keeps the latency-bound stages -- one workgroup per block in the Huffman stage -- a small share
 // of a job; measured on 1 GiB with one lane: 64 MiB chunks 4.6 GB/s host to host, 128 MiB 5.9, 256 MiB 6.5)
 // through two pinned staging buffers: bz_enc_write copies the caller's bytes into the pinned buffer being
@@ -156,18 +156,9 @@ static size_t enc_chunk_bytes()
     return v;
 }
 
-// the first chunk of a stream is small: the GPU has work sooner, and a short stream takes little pinned memory
-static size_t enc_first_chunk_bytes()
-{
-    static const size_t v = [] {
-        const char *s = getenv("BZ_ENC_FIRST_MIB");
-        long mib = s ? atol(s) : 64;
-        if (mib < 1) mib = 1;
-        if (mib > 1024) mib = 1024;
-        return (size_t)mib << 20;
-    }();
-    return v;
-}
+// the first chunk of a stream is small: the GPU has work sooner, and a short stream takes little pinned memory (16 ... 192 MiB
+// measured in round 4, two- and three-step ramps and geometric job sizes in round 6: flat, profiles/r06_e2e_schedule.md)
+static size_t enc_first_chunk_bytes() { return (size_t)64 << 20; }
 
 // lanes per entry of a context's device list (BZ_ENC_LANES, 2 .. 8; consecutive jobs must run on different lanes: the
 // tail of a job's input is handed from lane to lane).  Default 2: the latency-bound tail of one job beside the sort of
@@ -227,10 +218,6 @@ static int resources_get(const std::vector<int> &devices, EncResources **out)
     // blocks in flight: a chunk of level-9 text is chunk / 0.9 MB blocks (lower levels and run-heavy
     // inputs take several batches)
     r->engine_blocks = r->chunk / 800000 + 16;
-    if (const char *e = getenv("BZ_ENC_MAX_BLOCKS")) { // blocks in flight per lane (a job with more runs in several batches)
-        const long v = atol(e);
-        if (v >= 8 && (size_t)v < r->engine_blocks) r->engine_blocks = (size_t)v;
-    }
     r->lanes.resize(enc_lanes_per_device() * devices.size());
     bool ok = true;
     for (size_t l = 0; l < r->lanes.size() && ok; ++l) { // (engines and buffers come with the jobs: job_split, grow)
@@ -261,9 +248,8 @@ static int resources_get(const std::vector<int> &devices, EncResources **out)
 static void resources_put(EncResources *r)
 {
     if (!r) return;
-    static const bool no_cache = getenv("BZ_ENC_NO_CACHE") && atoi(getenv("BZ_ENC_NO_CACHE")) != 0;
     std::lock_guard<std::mutex> lk(g_cache_mu);
-    if (!no_cache && g_cache.size() < 2) g_cache.push_back(r);
+    if (g_cache.size() < 2) g_cache.push_back(r);
     else resources_free(r);
 }
 
@@ -993,13 +979,8 @@ static void copy_in(u8 *dst, const u8 *src, size_t n, size_t n_devices)
         return;
     }
     const unsigned hw = std::thread::hardware_concurrency();
-    static const long per_dev = [] {
-        const char *s = getenv("BZ_ENC_COPY_THREADS"); // copy threads per device of the context
-        const long v = s ? atol(s) : 0;
-        return v > 0 && v <= 64 ? v : 0L;
-    }();
-    size_t nt = per_dev ? (size_t)per_dev : (hw >= 8 ? 4 : (hw >= 4 ? 2 : 1));
-    if (n_devices > 1 || per_dev) nt = std::min<size_t>(nt * n_devices, std::max<size_t>(hw / 2, 1));
+    size_t nt = hw >= 8 ? 4 : (hw >= 4 ? 2 : 1);
+    if (n_devices > 1) nt = std::min<size_t>(nt * n_devices, std::max<size_t>(hw / 2, 1));
     nt = std::min(nt, n / ((size_t)1 << 20));
     if (nt <= 1) {
         memcpy(dst, src, n);

@@ -9,7 +9,7 @@
 //     into FRESH memory 43-51 ms (huge pages) -- the kernel zeroes every page at its first touch, 39 ms per GiB on one
 //     thread, but 6 ms on eight; slices on several threads: 80-120 ms.
 // So: ONE thread per direction issues the copies, in order, slice by slice (a slice is what a caller can wait for), and
-// a copy into fresh memory is preceded by a first touch of its pages on BZ_COPY_THREADS threads (default 8).  The thread
+// a copy into fresh memory is preceded by a first touch of its pages on eight threads.  The thread
 // that launches kernels goes on with the next batch or part meanwhile; a job is waited for by ticket before its device
 // buffer is reused, everything before a call returns.  Threads start with the first job and end with the pool.
 #pragma once
@@ -56,14 +56,7 @@ struct CopyPool {
     }
     static unsigned touch_threads()
     {
-        static const unsigned n = [] {
-            const char *e = getenv("BZ_COPY_THREADS");
-            long v = e ? atol(e) : 8;
-            if (v < 1) v = 1;
-            if (v > 32) v = 32;
-            return (unsigned)v;
-        }();
-        return n;
+        return 8u; // (eight threads touch a gigabyte of fresh pages in 6 ms; more are not faster: profiles/r05_host_copies.md)
     }
     static size_t slice_bytes() { return (size_t)32 << 20; }
 

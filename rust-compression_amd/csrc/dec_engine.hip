@@ -330,11 +330,7 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
         const long v = atol(e);
         if (v >= 1 && v <= 65536) B = (u32)v;
     }
-    u32 walk_wgs = 256; // persistent walker workgroups (bounds the window of blocks being walked)
-    if (const char *e = getenv("BZ_DEC_WALK_WGS")) {
-        const long v = atol(e);
-        if (v >= 1 && v <= 65536) walk_wgs = (u32)v;
-    }
+    const u32 walk_wgs = 256; // persistent walker workgroups (bounds the window of blocks being walked; 128 ... 1024 measured: profiles/r04_decode_walk_schedule.md)
     size_t c0 = 0, c1 = nc; // this rank's candidates
     if (sh) {
         c0 = nc * (size_t)sh->rank / (size_t)sh->world;
@@ -669,11 +665,7 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
         const u32 nb_all = (u32)bslot.size();
         u32 sub_max = nb_all;
         if (sink.to_host() && sink.pool && !sh && nb_all) {
-            u32 hb = 320;
-            if (const char *e = getenv("BZ_DEC_HOST_BATCH")) {
-                const long v = atol(e);
-                if (v >= 1 && v <= 65536) hb = (u32)v;
-            }
+            const u32 hb = 320;
             const u32 nbat = (nb_all + hb - 1) / hb; // (equal sub-batches: 1189 blocks are 4 x 298, not 3 x 320 + 229)
             sub_max = (nb_all + nbat - 1) / nbat;
         }
@@ -694,16 +686,15 @@ static int decode_core(bz_gpu_engine *g, const u8 *d_in, u64 n, Sink &sink, int 
                     max_bytes = std::max(max_bytes, bmax[s0 + i]);
                     max_nsym = std::max(max_nsym, hslot[bslot[s0 + i]].nsym);
                 }
-                static const bool full_grid = getenv("BZ_FULL_GRID") && atoi(getenv("BZ_FULL_GRID")) != 0;
                 // The chunk kernels: the workgroups the largest block's chunks need, made ODD.  Workgroups go round the eight
                 // XCDs and, inside an XCD, round its four shader engines: with FEW filled workgroups per block at a stride
                 // that shares a factor with 4 (level 1: one filled workgroup per block, the other 13 of a full slot's 14
                 // idle) the filled ones met on half or a quarter of the shader engines -- MTF stage of 1 GiB at level 1:
                 // 15.3 ms with 1 workgroup per block, 30 with 2, 59 with 4, 17 with 3 or 7, 32 with 14, 123 with 56.
                 const u32 cw_full = (kMaxMtfChunks + 255) / 256, chunks = (max_nsym + kMtfChunk - 1) / kMtfChunk;
-                a.cw = full_grid ? cw_full : (std::min<u32>(cw_full, std::max<u32>(1u, (chunks + 255) / 256)) | 1u);
-                a.tiles = full_grid ? kTilesPerBlock : std::min<u32>(kTilesPerBlock, (max_bytes + kSortTile - 1) / kSortTile);
-                a.sub_wgs = full_grid ? (kDecSubs + 255) / 256 : std::min<u32>((kDecSubs + 255) / 256, ((max_bytes + 63) / 64 + 255) / 256);
+                a.cw = std::min<u32>(cw_full, std::max<u32>(1u, (chunks + 255) / 256)) | 1u;
+                a.tiles = std::min<u32>(kTilesPerBlock, (max_bytes + kSortTile - 1) / kSortTile);
+                a.sub_wgs = std::min<u32>((kDecSubs + 255) / 256, ((max_bytes + 63) / 64 + 255) / 256);
             }
             a.slot = w->slot.as<u32>() + s0;
             a.info = w->info.as<DecBlockInfo>();
@@ -1124,9 +1115,7 @@ extern "C" int bz_decode_buffer(int device, const uint8_t *in, size_t in_len, ui
     if (rc == BZ_OK) {
         // The decoded bytes leave batch by batch beside the kernels of the next batch (copy_pool.h: one copying thread, the
         // fresh pages of the caller's buffer touched on several threads in front of it); the compressed bytes go up in one
-        // hipMemcpy as before (50 GB/s from pageable memory: 226 MB in 6 ms).  BZ_DEC_OVERLAP=0: one batch, one hipMemcpy
-        // behind it (rounds 1-4).
-        static const bool overlap = !(getenv("BZ_DEC_OVERLAP") && atoi(getenv("BZ_DEC_OVERLAP")) == 0);
+        // hipMemcpy as before (50 GB/s from pageable memory: 226 MB in 6 ms).  (Rounds 1-4: one batch, one hipMemcpy behind it.)
         CopyPool pool(device);
         rc = BZ_E_UNEXPECTED;
         // (the 64 bytes behind the stream are read as zeros by the bit readers)
@@ -1138,7 +1127,7 @@ extern "C" int bz_decode_buffer(int device, const uint8_t *in, size_t in_len, ui
             sink.host = &host;
             sink.staging[0] = &g->dec->staging;
             sink.staging[1] = &g->dec->staging2;
-            sink.pool = overlap ? &pool : nullptr;
+            sink.pool = &pool;
             rc = decode_core(g, static_cast<const u8 *>(g->dec_in.p), in_len, sink, &verdict);
         }
     }
@@ -1518,10 +1507,8 @@ extern "C" int bz_dec_create(bz_dec **out, int device)
         const long long v = atoll(e);
         if (v >= 1) d->first_chunk = (size_t)v;
     }
-    static const bool overlap = !(getenv("BZ_DEC_OVERLAP") && atoi(getenv("BZ_DEC_OVERLAP")) == 0);
-    if (overlap) d->pool = new CopyPool(device);
+    d->pool = new CopyPool(device);
     if (const char *e = getenv("BZ_DEC_LANES")) d->n_lanes = atoi(e) == 1 ? 1 : 2;
-    if (!overlap) d->n_lanes = 1;
     *out = d;
     return BZ_OK;
 }

@@ -437,6 +437,11 @@ static int df_encode_core(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, con
 // left out (a code start: the lazy parse from a code start does not depend on what came before,
 // lzss/encoder.rs:132-184), with the 32 KiB in front of it as history and in the middle of the byte its
 // predecessor ended in.  The bytes are those of one pass over the whole segment.
+static bool df_trace()
+{
+    static const bool on = getenv("BZ_DF_TRACE") != nullptr; // (diagnostics: a line per part and per one-shot call)
+    return on;
+}
 static double df_now_ms()
 {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -507,8 +512,7 @@ static int df_encode_parts(bz_gpu_engine *g, int kind, const u8 *d_in, u64 n, co
                                       d_out ? cap - written : 0, &got, seg, last ? dl_out : nullptr, &po);
         if (rc != BZ_OK) return rc;
         if (hooks && hooks->part_done && d_out) hooks->part_done(written, got);
-        static const bool trace = getenv("BZ_DF_TRACE") != nullptr;
-        if (trace)
+        if (df_trace())
             fprintf(stderr, "bz2_mi355x: deflate part %u: input [%llu, +%llu) of %llu, kept %llu bytes of it, %zu stream bytes, "
                             "%u bits handed on, %llu blocks; waited for its input %.2f ms, call %.2f ms of which kernels %.2f (at %.1f)\n", k, (unsigned long long)pos, (unsigned long long)len,
                     (unsigned long long)n, (unsigned long long)(last ? len : po.consumed), got, last ? 0u : po.end_bits,
@@ -624,7 +628,7 @@ extern "C" int df_encode_buffer_dict(int kind, int device, const uint8_t *in, si
     // bz_release_cached_resources frees it)
     int caller_device = -1;
     (void)hipGetDevice(&caller_device);
-    if (getenv("BZ_DF_TRACE")) fprintf(stderr, "bz2_mi355x: df_encode_buffer entered at %.1f\n", df_now_ms());
+    if (df_trace()) fprintf(stderr, "bz2_mi355x: df_encode_buffer entered at %.1f\n", df_now_ms());
     bz_gpu_engine *g = dec_cache_take(device, 2);
     int rc = g ? BZ_OK : bz_gpu_engine_create(&g, device, 1);
     if (rc != BZ_OK) return rc;
@@ -635,32 +639,16 @@ extern "C" int df_encode_buffer_dict(int kind, int device, const uint8_t *in, si
     if (rc == BZ_OK) rc = g->dec_in.ensure(in_len + 64);
     if (rc == BZ_OK) rc = g->oneshot_out.ensure(cap);
     // Large inputs: the call's two copies run beside its kernels (copy_pool.h).  The input goes up in 32 MiB slices from one
-    // thread, in order; the encode runs in parts of BZ_DF_BUFFER_PART_MIB (default 128 MiB -- the bytes do not depend
+    // thread, in order; the encode runs in parts (the bytes do not depend
     // on the parts, tests/test_gpu_deflate.py::test_many_part_seams_equal_oracle_golden), each as soon as its bytes have
     // arrived, and a part's bytes of the stream leave for the caller's buffer while the next part is encoded.  Rounds 1-4
     // uploaded everything, encoded, downloaded: 110 ms per GiB for 66 ms of kernels.
-    // BZ_DF_OVERLAP=0 restores that.
-    // (bits, for A/B runs: 1 the upload beside the parts, 2 the downloads beside the parts; 4 alone: parts, but the copies as before)
-    static const int overlap = getenv("BZ_DF_OVERLAP") ? atoi(getenv("BZ_DF_OVERLAP")) : 3;
-    if (rc == BZ_OK && overlap && in_len >= ((size_t)64 << 20)) {
+    if (rc == BZ_OK && in_len >= ((size_t)64 << 20)) {
         // Parts: a short first one (64 MiB: the kernels start 1.5 ms into the upload), then 256 MiB each -- a part's kernels cost
         // 1.4 ms more than its share of one pass (the block chain of a part stands behind its marking, every launch has its tail),
         // and the upload (50 GB/s) is 300 MiB ahead when the first part is over.  Eight parts of 128 MiB: 77 ms of kernels per
-        // GiB instead of 66.  BZ_DF_BUFFER_PART_MIB / BZ_DF_BUFFER_FIRST_MIB set them.
-        static const u64 part_bytes = [] {
-            const char *e = getenv("BZ_DF_BUFFER_PART_MIB");
-            long mib = e ? atol(e) : 256;
-            if (mib < 1) mib = 1;
-            if (mib > 1536) mib = 1536;
-            return (u64)mib << 20;
-        }();
-        static const u64 first_bytes = [] {
-            const char *e = getenv("BZ_DF_BUFFER_FIRST_MIB");
-            long mib = e ? atol(e) : (getenv("BZ_DF_BUFFER_PART_MIB") ? 1536 : 64);
-            if (mib < 1) mib = 1;
-            if (mib > 1536) mib = 1536;
-            return (u64)mib << 20;
-        }();
+        // GiB instead of 66 (profiles/r05_host_copies.md).
+        const u64 part_bytes = (u64)256 << 20, first_bytes = (u64)64 << 20;
         // the caller's buffer: 2 MiB-aligned memory that asks for huge pages (its pages are touched where stream bytes land, on
         // several threads, in front of each copy: 44 MB of 4 KiB pages took 5 ms, the last part's stood behind the call)
         {
@@ -682,20 +670,18 @@ extern "C" int df_encode_buffer_dict(int kind, int device, const uint8_t *in, si
             hooks.part_bytes = std::min<u64>(part_bytes, df_part_bytes());
             hooks.first_part_bytes = first_bytes;
             hooks.need_input = [&](u64 upto) {
-                if (!(overlap & 1)) upto = in_len;
                 const size_t want = (size_t)std::min<u64>((upto + S - 1) / S, up.size());
                 for (; waited < want; ++waited) pool.wait(up[waited]);
                 return pool.failed() ? BZ_E_UNEXPECTED : BZ_OK;
             };
             hooks.part_done = [&](size_t off, size_t len) {
-                if (len && (overlap & 2)) pool.submit(h + off, static_cast<const u8 *>(g->oneshot_out.p) + off, len, hipMemcpyDeviceToHost, true);
+                if (len) pool.submit(h + off, static_cast<const u8 *>(g->oneshot_out.p) + off, len, hipMemcpyDeviceToHost, true);
             };
             rc = df_encode_parts(g, kind, static_cast<const u8 *>(g->dec_in.p), in_len, dict, dict_len, static_cast<u8 *>(g->oneshot_out.p), cap,
                                  &n_out, DfSeg(), nullptr, &hooks);
-            if (rc == BZ_OK && !(overlap & 2) && n_out) pool.submit(h, g->oneshot_out.p, n_out, hipMemcpyDeviceToHost, true);
             const double t_parts = df_now_ms();
             pool.wait_all();
-            if (getenv("BZ_DF_TRACE")) fprintf(stderr, "bz2_mi355x: df_encode_buffer: parts over at %.1f, copies over at %.1f\n", t_parts, df_now_ms());
+            if (df_trace()) fprintf(stderr, "bz2_mi355x: df_encode_buffer: parts over at %.1f, copies over at %.1f\n", t_parts, df_now_ms());
             if (rc == BZ_OK && pool.failed()) rc = BZ_E_UNEXPECTED;
         }
         if (rc != BZ_OK) { // (the buffer is not shrunk to the stream: the pages behind it were never touched)

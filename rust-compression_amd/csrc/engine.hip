@@ -46,6 +46,13 @@ static void spans_collect(bz_gpu_engine *g)
 // The batch workspace holds `ws_blocks` blocks in flight: as many as the call at hand needs (up to
 // max_blocks, the batch size), grown when a later call needs more -- a context that only ever sees small
 // inputs does not take 31.5 MB x max_blocks of HBM.
+// BZ_ONESWEEP=0: the three-kernel radix passes from the start (tests/test_gpu_parity.py::test_radix_pass_flavours_agree)
+static bool fused_wanted()
+{
+    static const bool on = !(getenv("BZ_ONESWEEP") && atoi(getenv("BZ_ONESWEEP")) == 0);
+    return on;
+}
+
 static int ensure_workspace(bz_gpu_engine *g, size_t need_blocks)
 {
     if (need_blocks > g->max_blocks) need_blocks = g->max_blocks;
@@ -116,10 +123,10 @@ static int ensure_workspace(bz_gpu_engine *g, size_t need_blocks)
     ENS(stream, nb * (size_t)kStreamWords * 4);
     ENS(error_flag, 4);
     ENS(packlist, nb * sizeof(PackBlock));
-    if (!(getenv("BZ_ONESWEEP") && atoi(getenv("BZ_ONESWEEP")) == 0)) { // buffers of the fused radix passes
+    if (fused_wanted()) { // buffers of the fused radix passes
         ENS(gh_tiles, nb * (size_t)kTilesPerBlock * 3 * kMaxBins * 4);
         ENS(gbase, nb * (size_t)3 * kMaxBins * 4);
-        ENS(tile_state, nb * (size_t)kTilesPerBlock * kMaxBins * 4 * (BZ_LB_SMALL_TILE ? 3 : 1)); // (BZ_LB_SMALL_TILE: + twice as much for passes over half tiles, tile_state2)
+        ENS(tile_state, nb * (size_t)kTilesPerBlock * kMaxBins * 4);
         ENS(tickets, (size_t)kSortEpochs * 8 * 4 + 64);
         if (hipMemsetAsync(g->tile_state.p, 0, g->tile_state.cap, g->st) != hipSuccess ||
             hipMemsetAsync(g->tickets.p, 0, g->tickets.cap, g->st) != hipSuccess)
@@ -695,15 +702,13 @@ static BwtArgs make_bwt_args(bz_gpu_engine *g, u32 nb, u32 o = 0)
     x.gh_tiles = g->gh_tiles.as<u32>() + t * 3 * kMaxBins;
     x.gbase = g->gbase.as<u32>() + (size_t)o * 3 * kMaxBins;
     x.tile_state = g->tile_state.as<u32>() + t * kMaxBins;
-    x.tile_state2 = (BZ_LB_SMALL_TILE && g->tile_state.p) ? g->tile_state.as<u32>() + ((size_t)g->ws_blocks * kTilesPerBlock + 2 * t) * kMaxBins : nullptr;
     x.tickets = g->tickets.as<u32>();
     x.sort_err = g->tickets.p ? g->tickets.as<u32>() + (size_t)kSortEpochs * 8 : nullptr; // (no fused passes: not allocated)
     x.epoch = &g->sort_epoch;
     x.fused_state = g->fused_state;
     x.tile_state_all = g->tile_state.as<u32>();
     x.tile_state_bytes = g->tile_state.cap;
-    static const u32 want_fused = (getenv("BZ_ONESWEEP") && atoi(getenv("BZ_ONESWEEP")) == 0) ? 0u : 1u;
-    x.fused = want_fused;
+    x.fused = fused_wanted() ? 1u : 0u;
     static const u32 want_links = (getenv("BZ_LINK_ROUND") && atoi(getenv("BZ_LINK_ROUND")) == 0) ? 0u : 1u;
     x.per_links = want_links;
     x.per_keyshift = 0;
@@ -731,8 +736,6 @@ static MtfArgs make_mtf_args(bz_gpu_engine *g, u32 nb, u32 o, u32 total_nb)
     ma.ztick = g->ztick.as<u32>();
     static const bool want_fused_zle = !(getenv("BZ_FUSED_ZLE") && atoi(getenv("BZ_FUSED_ZLE")) == 0);
     ma.fused_zle = (want_fused_zle && !g->zle_fused_broken && o == 0 && nb == total_nb) ? 1u : 0u; // (one sub-batch: one set of tickets)
-    static const bool want_walk = getenv("BZ_MTF_WALK") && atoi(getenv("BZ_MTF_WALK")) != 0;
-    ma.walk_above = want_walk ? 96u : 256u;
     ma.mtf = g->mtf.as<u16>() + (size_t)o * kMtfStride;
     ma.mtf_freq = g->mtf_freq.as<u32>() + (size_t)o * kMaxAlpha;
     ma.out = g->bout.as<BlockOut>() + o;
@@ -784,8 +787,7 @@ static int sort_batch(bz_gpu_engine *g, const BwtArgs &ba, u32 *inuse_bits, u32 
     std::vector<u8> ki((size_t)ba.nb * 4);
     if (hipMemcpyAsync(ki.data(), ba.keyinfo, ki.size(), hipMemcpyDeviceToHost, g->st) != hipSuccess) return -1;
     if (hipStreamSynchronize(g->st) != hipSuccess) return -1;
-    static const bool force_wide = getenv("BZ_FORCE_WIDE") != nullptr; // (experiment: 11+11+10-bit digits for every batch)
-    bool wide = force_wide;
+    bool wide = false;
     u32 min_chars = 8;
     for (u32 i = 0; i < ba.nb; ++i) {
         if (ki[(size_t)i * 4] >= 8) wide = true;
@@ -802,8 +804,7 @@ static int sort_batch(bz_gpu_engine *g, const BwtArgs &ba, u32 *inuse_bits, u32 
 // slots and bandwidth free.
 static int encode_batch(bz_gpu_engine *g, u32 nb, const std::vector<BlockDesc> &descs)
 {
-    static const u32 want_parts = getenv("BZ_PARTS") ? (u32)atoi(getenv("BZ_PARTS")) : 1u;
-    const u32 parts = (nb >= 64 && want_parts >= 1) ? want_parts : 1u;
+    const u32 parts = 1u; // (sub-batches -- the sort of q + 1 beside the tail stages of q -- were measured in rounds 1-2: a batch fills the chip better whole)
     std::vector<hipEvent_t> evs;
     int rc = BZ_OK;
     bool used_fused_zle = false;
@@ -827,7 +828,6 @@ static int encode_batch(bz_gpu_engine *g, u32 nb, const std::vector<BlockDesc> &
             rc = BZ_E_UNEXPECTED;
             break;
         }
-        launch_last_column(g->st, ba, g->L.as<u8>() + (size_t)o * kSlot, g->orig_ptr.as<u32>() + o, total_n, &g->prof);
         // (tests) BZ_TEST_CORRUPT=1: a wrong origPtr for the batch's first block while the engine is on its fused passes --
         // a stream that is well formed and decodes to other bytes; nothing but a check of the result can notice
         static const bool corrupt_test = getenv("BZ_TEST_CORRUPT") && atoi(getenv("BZ_TEST_CORRUPT")) != 0;
@@ -855,8 +855,7 @@ static int encode_batch(bz_gpu_engine *g, u32 nb, const std::vector<BlockDesc> &
         (void)hipStreamWaitEvent(g->st2, ev, 0);
 
         MtfArgs ma = make_mtf_args(g, nbq, o, nb);
-        static const bool full_grid = getenv("BZ_FULL_GRID") && atoi(getenv("BZ_FULL_GRID")) != 0;
-        if (!full_grid) ma.tiles = std::min<u32>(kTilesPerBlock, std::max<u32>(1u, (max_n + kSortTile - 1u) / kSortTile));
+        ma.tiles = std::min<u32>(kTilesPerBlock, std::max<u32>(1u, (max_n + kSortTile - 1u) / kSortTile));
         zle_tiles = ma.tiles;
         used_fused_zle = used_fused_zle || ma.fused_zle;
         sp = span_begin(g, 2, g->st2);

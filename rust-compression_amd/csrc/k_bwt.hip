@@ -41,14 +41,9 @@
 #include <cstdlib>
 #include <vector>
 
-#ifndef BZ_GH_SPAN
-#define BZ_GH_SPAN 8 // tiles per workgroup (and per entry of the digit counts) of k_ghist_text
-#endif
-#ifndef BZ_SYM_SPAN
-#define BZ_SYM_SPAN 8 // tiles per workgroup of k_block_symbols
-#endif
 namespace bzgpu {
-constexpr u32 kGhSpan = BZ_GH_SPAN;
+constexpr u32 kGhSpan = 8;  // tiles per workgroup (and per entry of the digit counts) of k_ghist_text
+constexpr u32 kSymSpan = 8; // tiles per workgroup of k_block_symbols
 
 enum { SRC_TEXT = 0, SRC_PAIRS = 1, SRC_MM = 2, SRC_WALK = 3, SRC_SURV = 4, SRC_LISTG = 5,
        SRC_TEXTK = 6, SRC_WALKK = 7, SRC_MMK = 8, // ..K: keys stored by the histogram kernel of the pass
@@ -376,23 +371,11 @@ __device__ __forceinline__ u32 fetch_rows(const BwtArgs &a, u32 lb, const u8 *__
 // ranked one after the other; `cnt` = this wave's u16 counters in LDS).  0xFFFFFFFF: takes no part.
 //  * match-any form: the lanes with the same digit are found with ballots, the lowest peers come first,
 //    the highest peer publishes the new count.
-//  * -DBZ_RANK_ATOMIC: one returning LDS atomic add per row on the 32-bit word that holds the digit's u16
-//    counter.  Lanes of one wave instruction that hit the same word are served in ascending lane order on
-//    gfx950 (tools/ubench/ldsorder.hip checks exactly this), so the returned values ARE the stable ranks.
+//    (one returning LDS atomic add per row instead was measured in round 3 and is slower: profiles/r01_r03_measured_and_dropped.md)
 template <int BITS>
 __device__ __forceinline__ u32 rank_in_wave(u16 *cnt, u32 dg, bool ok, u32 l, u64 lt_mask)
 {
     u32 rnk = 0xFFFFFFFFu;
-#ifdef BZ_RANK_ATOMIC
-    (void)l;
-    (void)lt_mask;
-    if (ok) {
-        const u32 sh = (dg & 1u) * 16u;
-        const u32 old = __hip_atomic_fetch_add(reinterpret_cast<u32 *>(cnt) + (dg >> 1), 1u << sh, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
-        rnk = (old >> sh) & 0xFFFFu;
-    }
-#else
     const u64 peers = wave_match_digit<BITS>(dg, ok);
     if (ok) {
         const u32 before = __popcll(peers & lt_mask);
@@ -400,7 +383,6 @@ __device__ __forceinline__ u32 rank_in_wave(u16 *cnt, u32 dg, bool ok, u32 l, u6
         rnk = c0 + before;
         if ((peers >> l) == 1ull) cnt[dg] = (u16)(c0 + before + 1u);
     }
-#endif
     return rnk;
 }
 
@@ -765,31 +747,11 @@ __global__ __launch_bounds__(kSortThreads) void k_ghist_scan(BwtArgs a, u32 ndig
 // keys from the block and only walks the order)
 // PACK_OUT: the element leaves as ONE word, (key >> (shift + BITS)) << 20 | rotation: the digits this pass and the
 // passes before it have used up are not needed again (4 bytes written instead of 8; the next pass is <SRC_PACKED>)
-// (-DBZ_SCATTER_WAVES_PER_EU=6: the compiler is told to fit three workgroups per CU -- 80 registers, a few of them
-// spilled -- instead of the two that 95 registers allow; an A/B switch, profiles/r05_sort_negatives.md)
-#ifndef BZ_SCATTER_LATE_LB
-#define BZ_SCATTER_LATE_LB 1
-#endif
-#ifndef BZ_LB_WINDOW
-#define BZ_LB_WINDOW 1
-#endif
-#ifndef BZ_SCATTER_STATIC
-#define BZ_SCATTER_STATIC 0
-#endif
-#ifdef BZ_SCATTER_WAVES_PER_EU
-#define BZ_SCATTER_WAVES_ARG , BZ_SCATTER_WAVES_PER_EU
-#else
-#define BZ_SCATTER_WAVES_ARG
-#endif
-// rows per lane of a tile: 16 (512 threads, rounds 1-5) or 8 (1024 threads: the same 8192-element tile on sixteen waves --
-// half the registers per lane; an A/B switch, profiles/r05_sort_negatives.md).  11-bit digits keep 16: their counters
-// (waves x 2048 x 2 bytes) have to fit the staging buffer they share.
-#ifndef BZ_SCATTER_ROWS
-#define BZ_SCATTER_ROWS 16
-#endif
+// (Tile shapes and occupancies that were measured and are not kept -- 1024 threads x 8 rows, 256 x 16, 512 x 12, forced
+// occupancies, look-back windows, tiles without tickets: profiles/r05_sort_negatives.md, profiles/r06_sort_negatives.md.)
 // -DBZ_SCATTER_TIMING: cycles (>> 6) per phase of a tile, summed over the tiles of all launches into loc_stats[32 + 8 * c + k]
 // (c = 0: the streamed sources PAIRS / PACKED, c = 1: the sources that gather -- TEXT, WALK, MM, MMC; a barrier at every
-// mark; BZ_LOCAL_TRACE=1 prints them): 0 ticket + set-up + counters cleared, 1 rows fetched and ranked, 2 counts over the
+// mark; the host prints them at the end of a sort): 0 ticket + set-up + counters cleared, 1 rows fetched and ranked, 2 counts over the
 // waves + scan over the digits, 3 look-back, 4 places + keys staged, 5 keys read back and stored, 6 values staged,
 // 7 values read back and stored
 #ifdef BZ_SCATTER_TIMING
@@ -797,12 +759,8 @@ __global__ __launch_bounds__(kSortThreads) void k_ghist_scan(BwtArgs a, u32 ndig
 #else
 #define SC_T(k) do { } while (0)
 #endif
-// TILE: elements per tile -- kSortTile, or (-DBZ_LB_SMALL_TILE=1, an A/B switch: VERDICT r4 item 1 (a), "256 threads x 16 rows")
-// half of it for the streamed sources with 10-bit digits: four waves per workgroup behind each barrier instead of eight, five
-// workgroups per CU instead of two; twice the tickets and look-back words per element.  Its look-back words live in a
-// region of their own (tile_state2: twice the tiles per block).
-template <int SRC, int BITS, bool WRITE_K = true, bool PACK_OUT = false, int ROWS = (BITS > 10 ? 16 : BZ_SCATTER_ROWS), int TILE = (int)kSortTile>
-__global__ __launch_bounds__(TILE / ROWS BZ_SCATTER_WAVES_ARG) void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h,
+template <int SRC, int BITS, bool WRITE_K = true, bool PACK_OUT = false, int ROWS = 16, int TILE = (int)kSortTile>
+__global__ __launch_bounds__(TILE / ROWS) void k_radix_scatter_lb(BwtArgs a, u32 shift, u32 h,
                                                                     const u32 *__restrict__ Kin,
                                                                     const u32 *__restrict__ Vin,
                                                                     u32 *__restrict__ Kout, u32 *__restrict__ Vout,
@@ -811,8 +769,9 @@ __global__ __launch_bounds__(TILE / ROWS BZ_SCATTER_WAVES_ARG) void k_radix_scat
 {
     constexpr u32 NB = 1u << BITS;
     constexpr u32 kT = (u32)TILE / ROWS; // threads: 512 with 16 rows per lane, 1024 with 8 (256 for a half tile)
-    constexpr u32 kTileStride = kTilesPerBlock * (kSortTile / (u32)TILE); // tiles per block in the look-back words' array
-    u32 *const tstate = ((u32)TILE == kSortTile) ? a.tile_state : a.tile_state2;
+    static_assert((u32)TILE == kSortTile, "the look-back words are laid out for tiles of kSortTile elements");
+    constexpr u32 kTileStride = kTilesPerBlock; // tiles per block in the look-back words' array
+    u32 *const tstate = a.tile_state;
     constexpr u32 kRows = ROWS;
     constexpr u32 NW = kT / 64;
     __shared__ u32 s_buf[TILE];
@@ -831,26 +790,11 @@ __global__ __launch_bounds__(TILE / ROWS BZ_SCATTER_WAVES_ARG) void k_radix_scat
 #ifdef BZ_SCATTER_TIMING
     u64 t_prev = __builtin_readcyclecounter();
 #endif
-#if BZ_SCATTER_STATIC
-    // (A/B switch, profiles/r05_sort_negatives.md) the tile follows from the workgroup's number, as in the three-kernel
-    // passes (xcd_remap: workgroups are dealt to the XCDs round-robin and started in order); the counter of the XCD the
-    // workgroup REALLY runs on is still counted up -- without waiting for the answer -- so that the host's check of the
-    // counters catches a dispatch that deals differently, and the bounded spins catch one that starts out of order.
-    const u32 lid = blockIdx.x + gridDim.x * blockIdx.y;
-    const u32 xcd = lid & 7u;
-    const u32 slot = lid >> 3;
-    if (threadIdx.x == 0) {
-        const u32 real_xcd = (u32)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;
-        __hip_atomic_fetch_add(&a.tickets[(size_t)epoch * 8u + real_xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const u32 my_tiles = a.tiles * ((a.nb + 7u - xcd) / 8u);
-#else
     const u32 xcd = (u32)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u; // XCC_ID, bits 3:0
     const u32 my_tiles = a.tiles * ((a.nb + 7u - xcd) / 8u); // (a.tiles: tiles per block the launch covers)
     if (threadIdx.x == 0) s_ticket = atomicAdd(&a.tickets[(size_t)epoch * 8u + xcd], 1u);
     __syncthreads();
     const u32 slot = s_ticket;
-#endif
     if (slot >= my_tiles) return;
     const u32 b8 = slot / a.tiles;
     const u32 tile = slot - b8 * a.tiles;
@@ -966,7 +910,7 @@ __global__ __launch_bounds__(TILE / ROWS BZ_SCATTER_WAVES_ARG) void k_radix_scat
     SC_T(2);
     // this tile's digit counts go out, the predecessors' come in: four digits per 16-byte word group
     // (one sc1 store / load moves 16 bytes for the price of 4, MI355X_MICROARCH.md)
-    // Round 5 (BZ_SCATTER_LATE_LB, default on): the counts go out HERE, but the walk over the predecessors' words waits
+    // Round 5: the counts go out HERE, but the walk over the predecessors' words waits
     // until the tile's keys have been staged and read back -- the in-kernel phase timers (-DBZ_SCATTER_TIMING,
     // profiles/r05_sort_negatives.md) put 30-35 % of a tile's time into a look-back that began the moment the counts
     // were out: consecutive tickets start together, so a tile's predecessor publishes when the tile does, and four of
@@ -991,63 +935,40 @@ __global__ __launch_bounds__(TILE / ROWS BZ_SCATTER_WAVES_ARG) void k_radix_scat
 #ifdef BZ_SCATTER_TIMING
             u32 hops = 0, spins0 = 0;
 #endif
-            // The words of BZ_LB_WINDOW predecessors are asked for together (a tile walks back over five predecessors on
-            // average before it meets an inclusive prefix -- measured, profiles/r05_sort_negatives.md -- and every hop of
-            // a one-by-one walk is a round trip to the L2); they are then taken in order, nearest first.
-            for (u32 p = tile; p > 0 && open;) {
-                const u32 win = p < (u32)BZ_LB_WINDOW ? p : (u32)BZ_LB_WINDOW;
-                uint4 vw[BZ_LB_WINDOW];
-#if BZ_LB_WINDOW > 1
-                {
-                    u32x4_t rw[BZ_LB_WINDOW];
-#pragma unroll
-                    for (u32 j = 0; j < (u32)BZ_LB_WINDOW; ++j) { // (beyond the block's first tile: the first tile's words again -- no branch between the loads)
-                        const u32 q = j < win ? p - 1u - j : 0u;
-                        ld_sc1_x4_issue(tstate + ((size_t)lb * kTileStride + q) * kMaxBins + d0, rw[j]);
-                    }
-                    ld_x4_wait_all();
-#pragma unroll
-                    for (u32 j = 0; j < (u32)BZ_LB_WINDOW; ++j) vw[j] = make_uint4(rw[j].x, rw[j].y, rw[j].z, rw[j].w);
-                }
-#else
-                vw[0] = ld_sc1_x4(tstate + ((size_t)lb * kTileStride + (p - 1u)) * kMaxBins + d0);
-#endif
-#pragma unroll
-                for (u32 j = 0; j < (u32)BZ_LB_WINDOW; ++j) {
-                    if (j >= win || !open) break;
-                    const u32 *src = tstate + ((size_t)lb * kTileStride + (p - 1u - j)) * kMaxBins + d0;
-                    uint4 v = vw[j];
+            // (Asking for the words of two to four predecessors at once -- a tile walks back over five on average before it
+            // meets an inclusive prefix -- was measured in round 5 and bought nothing: profiles/r05_sort_negatives.md.)
+            for (u32 p = tile; p > 0 && open; --p) {
+                const u32 *src = tstate + ((size_t)lb * kTileStride + (p - 1u)) * kMaxBins + d0;
+                uint4 v = ld_sc1_x4(src);
 #ifdef BZ_SCATTER_TIMING
-                    ++hops;
+                ++hops;
 #endif
-                    while (true) {
-                        const u32 x[4] = {v.x, v.y, v.z, v.w};
-                        bool ready = true;
-#pragma unroll
-                        for (u32 k = 0; k < 4; ++k)
-                            if ((x[k] >> 22) != epoch || (x[k] & kLbFlagMask) == 0u) ready = false;
-                        if (ready) break; // (the four words of a group are written by one store)
-                        if (lb_give_up(spins, a.sort_err, kLbSpinMax)) {
-                            atomicExch(a.sort_err, 1u);
-                            v = make_uint4(etag | kLbIncl, etag | kLbIncl, etag | kLbIncl, etag | kLbIncl);
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(2);
-                        v = ld_sc1_x4(src);
-#ifdef BZ_SCATTER_TIMING
-                        ++spins0;
-#endif
-                    }
+                while (true) {
                     const u32 x[4] = {v.x, v.y, v.z, v.w};
+                    bool ready = true;
 #pragma unroll
-                    for (u32 k = 0; k < 4; ++k) {
-                        if ((open >> k) & 1u) {
-                            excl[k] += x[k] & kLbValMask;
-                            if ((x[k] & kLbFlagMask) == kLbIncl) open &= ~(1u << k);
-                        }
+                    for (u32 k = 0; k < 4; ++k)
+                        if ((x[k] >> 22) != epoch || (x[k] & kLbFlagMask) == 0u) ready = false;
+                    if (ready) break; // (the four words of a group are written by one store)
+                    if (lb_give_up(spins, a.sort_err, kLbSpinMax)) {
+                        atomicExch(a.sort_err, 1u);
+                        v = make_uint4(etag | kLbIncl, etag | kLbIncl, etag | kLbIncl, etag | kLbIncl);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    v = ld_sc1_x4(src);
+#ifdef BZ_SCATTER_TIMING
+                    ++spins0;
+#endif
+                }
+                const u32 x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (u32 k = 0; k < 4; ++k) {
+                    if ((open >> k) & 1u) {
+                        excl[k] += x[k] & kLbValMask;
+                        if ((x[k] & kLbFlagMask) == kLbIncl) open &= ~(1u << k);
                     }
                 }
-                p -= win;
             }
 #ifdef BZ_SCATTER_TIMING
             if (threadIdx.x == 0) { // (thread 0's digit group: hops walked, loads repeated while a word was not there yet, tiles)
@@ -1065,13 +986,6 @@ __global__ __launch_bounds__(TILE / ROWS BZ_SCATTER_WAVES_ARG) void k_radix_scat
 #pragma unroll
         for (u32 k = 0; k < 4; ++k) s_base[d0 + k] = gb[k] + excl[k] - (u32)s_tpre[d0 + k];
     };
-#if !BZ_SCATTER_LATE_LB
-    lookback_walk();
-#endif
-#if !BZ_SCATTER_LATE_LB
-    __syncthreads();
-    SC_T(3);
-#endif
     u32 lpos[kRows];
 #pragma unroll
     for (u32 r = 0; r < kRows; ++r) {
@@ -1099,7 +1013,6 @@ __global__ __launch_bounds__(TILE / ROWS BZ_SCATTER_WAVES_ARG) void k_radix_scat
     SC_T(4);
     u32 dst[kRows];
     u32 hi[kRows]; // (PACK_OUT) the digits above this pass's, already in place for the packed word
-#if BZ_SCATTER_LATE_LB
     u32 kks[kRows];
 #pragma unroll
     for (u32 k = 0; k < kRows; ++k) {
@@ -1109,18 +1022,13 @@ __global__ __launch_bounds__(TILE / ROWS BZ_SCATTER_WAVES_ARG) void k_radix_scat
     lookback_walk();
     __syncthreads();
     SC_T(3);
-#endif
 #pragma unroll
     for (u32 k = 0; k < kRows; ++k) {
         const u32 i = k * kT + threadIdx.x;
         dst[k] = 0xFFFFFFFFu;
         hi[k] = 0;
         if (i < total) {
-#if BZ_SCATTER_LATE_LB
             const u32 kk = kks[k];
-#else
-            const u32 kk = s_buf[i];
-#endif
             const u32 dg = (kk >> shift) & (NB - 1);
             dst[k] = s_base[dg] + i;
             if (SRC == SRC_PACKED) st_plain_at(Vout + base, dst[k], kk & 0xFFFFFu); // (the rotation came with the digit: one staging round)
@@ -1156,7 +1064,7 @@ __global__ __launch_bounds__(TILE / ROWS BZ_SCATTER_WAVES_ARG) void k_radix_scat
 //     of one instruction that hit the same word are served in ascending lane order on gfx950
 //     (tools/ubench/ldsorder.hip).  The result is CHECKED: the words are compared with their neighbours when
 //     they are written out, and a block with a pair out of order is marked in a.pb_gate and sorted by the
-//     three global passes like a block that does not fit (-DBZ_LOC_MATCH: the ballot form, no such reliance).
+//     three global passes like a block that does not fit.
 //   * a block whose keys are wider than 30 bits, or with a segment of more than kLocCap elements (a group of
 //     more than kLocCap - kSortTile equal c-symbol prefixes can do that), is marked the same way: the global
 //     passes skip every block that is not marked.
@@ -1209,21 +1117,11 @@ __device__ __forceinline__ void loc_rank(const u64 (&e)[16], u32 (&rnk)[16], u32
     for (u32 r = 0; r < 16; ++r) {
         const u32 i = pos0 + r * 64u + l;
         const u32 dg = (u32)(e[r] >> shift) & (kLocBins - 1u);
-#ifdef BZ_LOC_MATCH
-        const u64 lt_mask = (l == 0) ? 0ull : (~0ull >> (64 - l));
-        const u64 peers = wave_match_digit<kLocBits>(dg, i < len);
-        u16 *c16 = reinterpret_cast<u16 *>(cnt);
-        const u32 before = (u32)__popcll(peers & lt_mask);
-        const u32 c0 = c16[dg];
-        rnk[r] = c0 + before;
-        if (i < len && (peers >> l) == 1ull) c16[dg] = (u16)(c0 + before + 1u);
-#else
         const u32 sh = (dg & 1u) * 16u;
         u32 old = 0;
         if (i < len)
             old = __hip_atomic_fetch_add(cnt + (dg >> 1), 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         rnk[r] = (old >> sh) & 0xFFFFu;
-#endif
     }
 }
 // loc_move: every word to its place in the order by the digit
@@ -1248,182 +1146,7 @@ __device__ __forceinline__ void loc_reload(u64 (&e)[16], const u64 *s_e, u32 pos
     }
 }
 
-#ifdef BZ_LOC_TIMERS
-#define LOC_T(k) do { __syncthreads(); const u64 t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&a.loc_stats[4 + (k)], (u32)((t_ - t_prev) >> 4)); t_prev = t_; } while (0)
-#else
 #define LOC_T(k) do { } while (0)
-#endif
-__global__ __launch_bounds__(kLocThreads) void k_phase_b_local(BwtArgs a, const u32 *__restrict__ K,
-                                                                const u32 *__restrict__ V)
-{
-#ifdef BZ_LOC_TIMERS
-    u64 t_prev = __builtin_readcyclecounter();
-#endif
-    __shared__ u64 s_e[kLocCap];
-    __shared__ u32 s_cnt[kLocSets][kLocBins / 2]; // u16 counters, two to a word
-    __shared__ u16 s_tpre[kLocBins];
-    __shared__ u32 s_wsum[kLocSets];
-    __shared__ u32 s_seg[2];
-    __shared__ u32 s_bad;
-    u32 tile, lb;
-    xcd_remap(gridDim.x, a.nb, tile, lb);
-    if (lb == 0xFFFFFFFFu) return;
-    const BlockDesc d = a.blocks[lb];
-    const u32 n = d.n;
-    const u32 start = tile * kSortTile;
-    if (start >= n) return;
-    const KeyInfo ki = reinterpret_cast<const KeyInfo *>(a.keyinfo)[lb];
-    const u32 kbits = (u32)ki.bits * (u32)ki.chars;
-    if (kbits > 30u) { // (all segments of the block see the same)
-        if (tile == 0 && threadIdx.x == 0) a.pb_gate[lb] = 1u;
-        return;
-    }
-    const size_t base = (size_t)lb * kSlot;
-    const u8 *text = a.rle + d.rle_off;
-    const u8 *pt = a.ptext + (size_t)lb * kSlot;
-    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
-    if (w == 0) {
-        const u32 s = first_group_start(K + base, start, n, kLocCap + 64u);
-        if (l == 0) s_seg[0] = s;
-    } else if (w == 1) {
-        const u32 s = first_group_start(K + base, start + kSortTile, n, kLocCap + 64u);
-        if (l == 0) s_seg[1] = s;
-    }
-    if (threadIdx.x == 0) s_bad = 0;
-    __syncthreads();
-    const u32 s0 = (u32)__builtin_amdgcn_readfirstlane((int)s_seg[0]), s1 = (u32)__builtin_amdgcn_readfirstlane((int)s_seg[1]);
-    if (s0 == 0xFFFFFFFFu || s1 == 0xFFFFFFFFu || (s1 > s0 && s1 - s0 > kLocCap)) {
-        if (threadIdx.x == 0) {
-            a.pb_gate[lb] = 1u;
-            atomicAdd(&a.loc_stats[LOC_STAT_OVERFLOW], 1u);
-        }
-        return;
-    }
-    if (s1 <= s0) return; // no group starts inside this tile
-    LOC_T(0);
-    const u32 len = s1 - s0;
-    const u32 cm = (u32)ki.chars % n;
-    const u32 *Kb = K + base + s0, *Vb = V + base + s0;
-    const u32 wu = (u32)__builtin_amdgcn_readfirstlane((int)w);
-    const u32 posA = wu * 1024u, posB = kSortTile + wu * 1024u; // this wave's first position in either half
-
-    // ---- load: the second-half keys and the group starts (bit 63, for now) go to LDS row by row
-    u32 gcount[2] = {0, 0};
-#pragma unroll 1
-    for (u32 half = 0; half < 2; ++half) {
-        const u32 pos0 = half ? posB : posA;
-        if (pos0 >= len) break;
-        u32 prev_last = 0;
-        if (l == 0 && pos0 > 0) prev_last = Kb[pos0 - 1u];
-        const u32 rows = (len - pos0 + 63u) / 64u < 16u ? (len - pos0 + 63u) / 64u : 16u;
-        u32 tot = 0;
-#pragma unroll 4
-        for (u32 r = 0; r < rows; ++r) {
-            const u32 i = pos0 + r * 64u + l;
-            const u32 c = i < len ? i : len - 1u;
-            const u32 kk = ld_stream(Kb + c);
-            const u32 v = ld_stream(Vb + c);
-            u32 pk = __shfl_up(kk, 1, 64);
-            if (l == 0) pk = prev_last;
-            prev_last = __shfl(kk, 63, 64);
-            const bool f = (i < len) && (i == 0 || kk != pk);
-            u32 t = v + cm;
-            t = t >= n ? t - n : t;
-            const u32 k2 = pkey(pt, t, ki.bits, ki.chars);
-            if (i < len) s_e[i] = ((u64)(f ? 1u : 0u) << 63) | ((u64)k2 << 20) | (u64)v;
-            tot += (u32)__popcll(__ballot(f));
-        }
-        gcount[half] = tot;
-    }
-    if (l == 0) {
-        s_wsum[w] = gcount[0];
-        s_wsum[kLocWaves + w] = gcount[1];
-    }
-    __syncthreads();
-    LOC_T(1);
-    u32 gcarryA = 0, gcarryB = 0, groups = 0;
-    for (u32 k = 0; k < kLocSets; ++k) {
-        const u32 c = s_wsum[k];
-        if (k < w) gcarryA += c;
-        if (k < kLocWaves + w) gcarryB += c;
-        groups += c;
-    }
-    const u64 le_mask = (l == 63) ? ~0ull : ((2ull << l) - 1ull);
-    const u32 gshift = 20u + kbits; // the group number sits right above key(j+c)
-    const bool haveB = posB < len;  // (wave-uniform)
-    u64 eA[16], eB[16];
-    loc_fill(eA, s_e, posA, len, l, le_mask, gshift, gcarryA);
-    if (haveB) loc_fill(eB, s_e, posB, len, l, le_mask, gshift, gcarryB);
-    const u32 gbits = groups > 1u ? 32u - (u32)__builtin_clz(groups - 1u) : 0u;
-    // digits of kLocBits bits from bit 20 up to the top bit of the group number; none when every group is a
-    // single rotation (nothing to order)
-    const u32 npass = (groups < len) ? (kbits + gbits + kLocBits - 1u) / kLocBits : 0u;
-    LOC_T(2);
-    u32 *cntA = s_cnt[w], *cntB = s_cnt[kLocWaves + w];
-    u16 *cnt16 = reinterpret_cast<u16 *>(&s_cnt[0][0]);
-#pragma unroll 1
-    for (u32 p = 0; p < npass; ++p) {
-        const u32 shift = 20u + p * kLocBits;
-        u32 rnkA[16], rnkB[16];
-        loc_rank(eA, rnkA, cntA, posA, len, l, shift);
-        if (haveB) loc_rank(eB, rnkB, cntB, posB, len, l, shift);
-        else {
-#pragma unroll
-            for (u32 q = 0; q < kLocBins / 2 / 64; ++q) cntB[q * 64u + l] = 0;
-        }
-        __syncthreads();
-        u32 tot;
-        {
-            const u32 dg = threadIdx.x; // (kLocThreads == kLocBins)
-            u32 run = 0;
-#pragma unroll
-            for (u32 k = 0; k < kLocSets; ++k) {
-                const u32 c = cnt16[k * kLocBins + dg];
-                cnt16[k * kLocBins + dg] = (u16)run;
-                run += c;
-            }
-            tot = run;
-        }
-        const u32 inc = wave_incl_sum(tot);
-        if (l == 63) s_wsum[w] = inc;
-        __syncthreads();
-        {
-            u32 carry = 0;
-            for (u32 k = 0; k < w; ++k) carry += s_wsum[k];
-            s_tpre[threadIdx.x] = (u16)(carry + inc - tot);
-        }
-        __syncthreads();
-        loc_move(eA, rnkA, cntA, s_tpre, s_e, posA, len, l, shift);
-        if (haveB) loc_move(eB, rnkB, cntB, s_tpre, s_e, posB, len, l, shift);
-        __syncthreads();
-        if (p + 1 < npass) {
-            loc_reload(eA, s_e, posA, len, l);
-            if (haveB) loc_reload(eB, s_e, posB, len, l);
-        }
-    }
-    LOC_T(3);
-    // ---- out: the order, checked (no pass: the words still sit where they were loaded, flag bits and all)
-    {
-        bool bad = false;
-        for (u32 i = threadIdx.x; i < len; i += kLocThreads) {
-            const u64 x = s_e[i];
-            if (npass && i && (s_e[i - 1] >> 20) > (x >> 20)) bad = true;
-            a.SA[base + s0 + i] = (u32)x & 0xFFFFFu;
-        }
-        if (__ballot(bad) && l == 0) s_bad = 1u;
-    }
-    __syncthreads();
-    LOC_T(4);
-    if (threadIdx.x == 0) {
-        atomicAdd(&a.loc_stats[LOC_STAT_SEGS], 1u);
-        atomicAdd(&a.loc_stats[LOC_STAT_PASSES], npass);
-        if (s_bad) {
-            a.pb_gate[lb] = 1u;
-            atomicAdd(&a.loc_stats[LOC_STAT_UNSORTED], 1u);
-        }
-    }
-}
-
 // ---- a survivor round inside LDS ---------------------------------------------------------------------------------------
 // A survivor round orders the compacted list -- the rotations the last refinement left unordered, in the order of their
 // groups -- by (group, rank of rotation j + h): two passes by the rank, two by the group, each over the whole list through
@@ -1746,10 +1469,7 @@ __global__ __launch_bounds__(kSortThreads) void k_group_flags(BwtArgs a, u32 ste
 // takes one bin (1024 ranks) per wave, puts the words in place in LDS and writes the rank array in
 // whole lines.  A word is (j & 1023) | head << 10 | final << 31; bin b owns the 1024 words behind
 // b * 1024 of the free key array (a rotation occurs once, so a bin cannot overflow).
-#ifndef BZ_RANK_BIN_SHIFT
-#define BZ_RANK_BIN_SHIFT 10
-#endif
-constexpr u32 kRankBinShift = BZ_RANK_BIN_SHIFT, kRankBins = kSlot >> kRankBinShift; // 880 bins of 1024 rotations
+constexpr u32 kRankBinShift = 10, kRankBins = kSlot >> kRankBinShift; // 880 bins of 1024 rotations
 constexpr u32 kRankBinSize = 1u << kRankBinShift, kRankBinMask = kRankBinSize - 1u;
 static_assert(kRankBinShift + 20u + 1u <= 32u, "j inside the bin, a 20-bit head and the final bit share a word");
 static_assert(kRankBins <= 1024 && (kRankBins << kRankBinShift) == kSlot, "bins tile the slot");
@@ -1972,7 +1692,7 @@ __global__ __launch_bounds__(kSortThreads) void k_group_apply(BwtArgs a, u32 nex
 // Used when the fused radix passes are (a.fused); BZ_FUSED_REFINE=0 keeps the two kernels everywhere.
 constexpr u32 kLbNone = 0xFFFFFu;
 // -DBZ_REFINE_TIMING: cycles (>> 4) per phase of a tile, summed over tiles into loc_stats[16 + 8 * INIT + k]
-// (a barrier at every mark; BZ_LOCAL_TRACE=1 prints them): 0 ticket + set-up, 1 list + secondary keys, 2 flags,
+// (a barrier at every mark; the host prints them at the end of a sort): 0 ticket + set-up, 1 list + secondary keys, 2 flags,
 // 3 look-back, 4 positions / rank words / last column, 5 counts out + bin offsets, 6 staging + rank words out
 #ifdef BZ_REFINE_TIMING
 #define RF_T(k) do { __syncthreads(); const u64 t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&a.loc_stats[16 + (INIT ? 8 : 0) + (k)], (u32)((t_ - t_prev) >> 4)); t_prev = t_; } while (0)
@@ -2000,10 +1720,6 @@ __global__ __launch_bounds__(kSortThreads, 4) void k_group_refine(BwtArgs a, u32
     __shared__ u32 s_wsum[NW];
     u32 (*s_gh)[1024] = reinterpret_cast<u32 (*)[1024]>(s_stage);          // [2][1024], words 0 .. 2047
     u32 *s_bcnt = s_stage + 2048;                                          // [1024],    words 2048 .. 3071
-#if defined(BZ_REFINE_TWO_PER_CU) // (A/B: the LDS footprint of rounds 1-3, two workgroups per CU)
-    __shared__ u32 s_pad[2600];
-    if (threadIdx.x == 0) s_pad[blockIdx.x % 2600u] = 0;
-#endif
 #ifdef BZ_REFINE_TIMING
     u64 t_prev = __builtin_readcyclecounter();
 #endif
@@ -3270,7 +2986,7 @@ __global__ __launch_bounds__(kSortThreads) void k_block_symbols(BwtArgs a, u32 *
     const u32 n = d.n;
     // (eight tiles per workgroup: one tile is ONE 16-byte load per thread, and the reductions and atomics behind it cost more than
     // the load -- 0.98 ms per GiB for a kernel that reads the image once)
-    constexpr u32 kSpan = (u32)BZ_SYM_SPAN * kSortTile;
+    constexpr u32 kSpan = kSymSpan * kSortTile;
     const u32 start = tile * kSpan;
     if (start >= n) return;
     const u8 *text = a.rle + d.rle_off;
@@ -3393,40 +3109,6 @@ __global__ __launch_bounds__(kSortThreads) void k_pack_text(BwtArgs a, u8 *__res
     for (u32 i = threadIdx.x; i < 256u * bits; i += kSortThreads) dst[i] = s_out[i];
 }
 
-// ---- last column, origPtr ---------------------------------------------------------------------------
-// L[i] = block[(SA[i]-1) mod n]  (src/bzip2/encoder.rs:331-338); origPtr = i with SA[i]==0 (:332-334)
-__global__ __launch_bounds__(kSortThreads) void k_last_column(BwtArgs a, u8 *__restrict__ L,
-                                                               u32 *__restrict__ orig_ptr)
-{
-    u32 tile, lb;
-    xcd_remap(gridDim.x, a.nb, tile, lb);
-    if (lb == 0xFFFFFFFFu) return;
-    const BlockDesc d = a.blocks[lb];
-    const u32 n = d.n;
-    const u32 start = tile * kSortTile;
-    if (start >= n) return;
-    const u8 *text = a.rle + d.rle_off;
-    const u8 *pt = a.ptext + (size_t)lb * kSlot;
-    const size_t base = (size_t)lb * kSlot;
-    u32 sv[16];
-#pragma unroll
-    for (u32 r = 0; r < 16; ++r) {
-        const u32 i = start + r * kSortThreads + threadIdx.x;
-        sv[r] = ld_stream(a.SA + base + (i < n ? i : n - 1u));
-    }
-    u8 cv[16];
-#pragma unroll
-    for (u32 r = 0; r < 16; ++r) cv[r] = text[sv[r] == 0 ? n - 1 : sv[r] - 1];
-#pragma unroll
-    for (u32 r = 0; r < 16; ++r) {
-        const u32 i = start + r * kSortThreads + threadIdx.x;
-        if (i < n) {
-            if (sv[r] == 0) orig_ptr[lb] = i;
-            L[base + i] = cv[r];
-        }
-    }
-}
-
 // ---- host side ------------------------------------------------------------------------------------
 int KernelProf::begin(hipStream_t st, int id, u64 nbytes)
 {
@@ -3530,8 +3212,6 @@ static u32 next_epoch(hipStream_t st, const BwtArgs &a)
     return e;
 }
 
-// (BZ_LB_SMALL_TILE) the epochs of the running sort whose launches had twice the tiles: their ticket counters end at twice the share
-static thread_local std::vector<u32> *tl_double_epochs = nullptr;
 template <int SRC, int BITS, bool WRITE_K = true, bool PACK_OUT = false>
 static void fused_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const u32 *Kin, const u32 *Vin, u32 *Kout,
                        u32 *Vout, u32 dpos, u64 elems, KernelProf *prof, u64 out_elems = ~0ull,
@@ -3542,17 +3222,7 @@ static void fused_pass(hipStream_t st, const BwtArgs &a, u32 shift, u32 h, const
     const u32 e = next_epoch(st, a);
     if (out_elems == ~0ull) out_elems = elems;
     const int p = prof ? prof->begin(st, KID_RADIX_SCATTER_LB, elems * rd + out_elems * ((WRITE_K && !PACK_OUT) ? 8 : 4)) : -1;
-    constexpr bool small_tile = BZ_LB_SMALL_TILE != 0 && BITS == 10 && (SRC == SRC_PAIRS || SRC == SRC_PACKED);
-    if (small_tile && a.tile_state2) {
-        BwtArgs a2 = a; // (twice the tiles of half the size; the counters of this epoch end at twice the share)
-        a2.tiles = a.tiles * 2u;
-        if (tl_double_epochs) tl_double_epochs->push_back(e);
-        hipLaunchKernelGGL((k_radix_scatter_lb<SRC, BITS, WRITE_K, PACK_OUT, 16, (int)(kSortTile / 2)>), dim3(a2.tiles, xcd_grid_y(a.nb)), dim3(kSortTile / 2 / 16), 0, st,
-                           a2, shift, h, Kin, Vin, Kout, Vout, dpos, e, gate);
-    } else {
-        hipLaunchKernelGGL((k_radix_scatter_lb<SRC, BITS, WRITE_K, PACK_OUT>), grid, dim3(kSortTile / (BITS > 10 ? 16 : BZ_SCATTER_ROWS)), 0, st, a, shift, h, Kin,
-                           Vin, Kout, Vout, dpos, e, gate);
-    }
+    hipLaunchKernelGGL((k_radix_scatter_lb<SRC, BITS, WRITE_K, PACK_OUT>), grid, dim3(kSortTile / 16), 0, st, a, shift, h, Kin, Vin, Kout, Vout, dpos, e, gate);
     if (prof) prof->end(st, p);
 }
 
@@ -3580,7 +3250,7 @@ static bool fused_pass_ok(hipStream_t st, const BwtArgs &a, u32 epoch)
 // false: the first pass did not behave (workgroups not dealt evenly to the XCDs, or a look-back gave
 // up); nothing of it is used then and the caller sorts with the three-kernel passes
 template <int B0, int B1, int B2>
-static bool init_sort_fused(hipStream_t st, const BwtArgs &a, u64 total_n, KernelProf *prof, bool local_b)
+static bool init_sort_fused(hipStream_t st, const BwtArgs &a, u64 total_n, KernelProf *prof)
 {
     const dim3 grid(a.tiles, xcd_grid_y(a.nb));
     // the digit counts of key(j), once: both init phases sort the same multiset of keys
@@ -3604,26 +3274,11 @@ static bool init_sort_fused(hipStream_t st, const BwtArgs &a, u64 total_n, Kerne
     if (!fused_pass_ok(st, a, *a.epoch)) return false;
     // (round 4) the middle pass of phase A writes ONE word per element -- the last digit above bit 20, the rotation below:
     // the first two digits are used up, and 10 + 20 bits fit a word -- and the last pass reads that word: 8 of the 32
-    // bytes the two passes moved per element, and one of the last pass's two trips through LDS.  BZ_PACKED_PASS=0: as before.
-    static const bool want_packed = !(getenv("BZ_PACKED_PASS") && atoi(getenv("BZ_PACKED_PASS")) == 0);
-    const bool packed = want_packed && !local_b;
-    if (packed) fused_pass<SRC_PAIRS, B1, true, true>(st, a, B0, 0, a.KA, a.VA, nullptr, a.VB, 1, total_n, prof);
-    else fused_pass<SRC_PAIRS, B1>(st, a, B0, 0, a.KA, a.VA, a.KB, a.VB, 1, total_n, prof);
+    // bytes the two passes moved per element, and one of the last pass's two trips through LDS.
+    fused_pass<SRC_PAIRS, B1, true, true>(st, a, B0, 0, a.KA, a.VA, nullptr, a.VB, 1, total_n, prof);
+    (void)hipMemsetAsync(a.pb_gate, 1, a.nb * sizeof(u32), st); // every block: keys in KB, order by the passes
+    fused_pass<SRC_PACKED, B2, false>(st, a, 20, 0, nullptr, a.VB, nullptr, a.VA, 2, total_n, prof); // (order only)
     const u32 *gate = nullptr;
-    if (local_b) {
-        // phase B inside LDS (k_phase_b_local): phase A keeps its keys, the groups are ordered segment by segment;
-        // the three passes below then only run for the blocks the kernel marked in pb_gate
-        fused_pass<SRC_PAIRS, B2>(st, a, B0 + B1, 0, a.KB, a.VB, a.KA, a.VA, 2, total_n, prof);
-        (void)hipMemsetAsync(a.pb_gate, 0, a.nb * sizeof(u32), st);
-        p = prof ? prof->begin(st, KID_PHASE_B_LOCAL, total_n * 17) : -1;
-        hipLaunchKernelGGL(k_phase_b_local, grid, dim3(kLocThreads), 0, st, a, a.KA, a.VA);
-        if (prof) prof->end(st, p);
-        gate = a.pb_gate;
-    } else {
-        (void)hipMemsetAsync(a.pb_gate, 1, a.nb * sizeof(u32), st); // every block: keys in KB, order by the passes
-        if (packed) fused_pass<SRC_PACKED, B2, false>(st, a, 20, 0, nullptr, a.VB, nullptr, a.VA, 2, total_n, prof); // (order only)
-        else fused_pass<SRC_PAIRS, B2, false>(st, a, B0 + B1, 0, a.KB, a.VB, a.KA, a.VA, 2, total_n, prof); // (order only)
-    }
     fused_pass<SRC_WALK, B0>(st, a, 0, 0, a.KA, a.VA, a.KB, a.VB, 0, total_n, prof, ~0ull, gate);
     fused_pass<SRC_PAIRS, B1>(st, a, B0, 0, a.KB, a.VB, a.KA, a.VA, 1, total_n, prof, ~0ull, gate);
     // the last pass puts the order straight into SA: the first refinement leaves every rotation where it is
@@ -3635,7 +3290,7 @@ void launch_block_symbols(hipStream_t st, const BwtArgs &a, u32 *inuse_bits, u8 
 {
     const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
     (void)hipMemsetAsync(inuse_bits, 0, (size_t)a.nb * 8 * sizeof(u32), st);
-    hipLaunchKernelGGL(k_block_symbols, dim3((a.tiles + (u32)BZ_SYM_SPAN - 1u) / (u32)BZ_SYM_SPAN, xcd_grid_y(a.nb)), dim3(kSortThreads), 0, st, a, inuse_bits);
+    hipLaunchKernelGGL(k_block_symbols, dim3((a.tiles + kSymSpan - 1u) / kSymSpan, xcd_grid_y(a.nb)), dim3(kSortThreads), 0, st, a, inuse_bits);
     hipLaunchKernelGGL(k_key_params, dim3(a.nb), dim3(256), 0, st, inuse_bits, sym_code, keyinfo);
     hipLaunchKernelGGL(k_pack_text, grid, dim3(kSortThreads), 0, st, a, a.ptext);
 }
@@ -3672,10 +3327,8 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
     BwtArgs a = a_in;
     if (!allow_fused || a.fused_state[0]) a.fused = 0;
     // A launch covers the tiles the batch's LARGEST block needs, not a level-9 block's 110: at level 1 (100 KB blocks,
-    // 13 tiles) seven of eight workgroups of every launch had nothing to do (BZ_FULL_GRID=1: as before).  Array strides
-    // stay kTilesPerBlock.
-    static const bool full_grid = getenv("BZ_FULL_GRID") && atoi(getenv("BZ_FULL_GRID")) != 0;
-    a.tiles = full_grid ? kTilesPerBlock : std::min<u32>(kTilesPerBlock, std::max<u32>(1u, (max_n + kSortTile - 1u) / kSortTile));
+    // 13 tiles) seven of eight workgroups of every launch had nothing to do.  Array strides stay kTilesPerBlock.
+    a.tiles = std::min<u32>(kTilesPerBlock, std::max<u32>(1u, (max_n + kSortTile - 1u) / kSortTile));
     const dim3 grid(a.tiles, xcd_grid_y(a.nb));
     (void)hipMemsetAsync(a.active, 0, 64 * sizeof(unsigned long long), st);
     (void)hipMemsetAsync(a.maxnf, 0, 64 * sizeof(u32), st);
@@ -3686,18 +3339,10 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
     // first pass is checked, and the three-kernel passes redo the sort from the block if it fails.
     bool fused = a.fused != 0;
     const u32 epoch_first = *a.epoch + 1u; // (fused) the passes of this call, for the coverage check below
-    std::vector<u32> double_epochs;
-    struct TlGuard {
-        TlGuard(std::vector<u32> *v) { tl_double_epochs = v; }
-        ~TlGuard() { tl_double_epochs = nullptr; }
-    } tl_guard(&double_epochs);
     if (fused) {
-        // BZ_LOCAL_B=1: phase B of the init inside LDS (k_phase_b_local) for the blocks it can take.  Off by default:
-        // measured on the 1 GiB text corpus it takes 37 ms against 15 ms for the three global passes it replaces
-        // ("phase B inside LDS").
-        static const bool want_local = getenv("BZ_LOCAL_B") && atoi(getenv("BZ_LOCAL_B")) != 0;
-        const bool ok = wide_keys ? init_sort_fused<11, 11, 10>(st, a, total_n, prof, want_local)
-                                  : init_sort_fused<10, 10, 10>(st, a, total_n, prof, want_local);
+        // (phase B of the init inside LDS was built in round 2 and took 37 ms per GiB of text against 15 ms for the three
+        // global passes it replaces: profiles/r02_phase_b_in_lds.md; its machinery lives on in k_surv_local)
+        const bool ok = wide_keys ? init_sort_fused<11, 11, 10>(st, a, total_n, prof) : init_sort_fused<10, 10, 10>(st, a, total_n, prof);
         if (!ok) {
             fprintf(stderr, "bz2_mi355x: fused radix passes disabled (tile tickets / look-back check failed)\n");
             a.fused_state[0] = 1;
@@ -3715,9 +3360,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
     // flags + apply in one pass (k_group_refine) whenever the fused radix passes are in use; BZ_FUSED_REFINE=0 keeps
     // the two kernels (A/B measurements, tests)
     static const bool want_refine = !(getenv("BZ_FUSED_REFINE") && atoi(getenv("BZ_FUSED_REFINE")) == 0);
-    static const bool local_b_on = getenv("BZ_LOCAL_B") && atoi(getenv("BZ_LOCAL_B")) != 0;
-    // (BZ_LOCAL_B=1: the first refinement reads phase A's keys from KA, the array its rank words go to: two kernels)
-    const bool refine = fused && want_refine && !local_b_on;
+    const bool refine = fused && want_refine;
     int p;
     (void)hipMemsetAsync(a.bin_cursor, 0, (size_t)a.nb * 1024 * sizeof(u32), st);
     if (refine) {
@@ -3775,7 +3418,8 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         ++rounds;
         bool carried = false;
         u32 trace_worst = 0;
-        if (getenv("BZ_BWT_TRACE")) { // (which block holds the most: a.nonfinal still has the last refinement's counts)
+        static const bool bwt_trace = getenv("BZ_BWT_TRACE") != nullptr;
+        if (bwt_trace) { // (which block holds the most: a.nonfinal still has the last refinement's counts)
             std::vector<u32> nf(a.nb);
             (void)hipMemcpyAsync(nf.data(), a.nonfinal, a.nb * 4, hipMemcpyDeviceToHost, st);
             (void)hipStreamSynchronize(st);
@@ -3815,10 +3459,8 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             link_m = 0;
         }
         const bool link_round = !per_round && links_on && period_done && last_doubled && links_pay && m * 256 >= total_n;
-        // survivor form below this share of the rotations (BZ_SURV_SHARE=num/den, default 1/4: measured)
-        static const u64 surv_num = [] { const char *e = getenv("BZ_SURV_SHARE"); unsigned a = 1, b = 4; if (e && sscanf(e, "%u/%u", &a, &b) == 2 && a && b) return (u64)a; return (u64)1; }();
-        static const u64 surv_den = [] { const char *e = getenv("BZ_SURV_SHARE"); unsigned a = 1, b = 4; if (e && sscanf(e, "%u/%u", &a, &b) == 2 && a && b) return (u64)b; return (u64)4; }();
-        static const bool bwt_trace = getenv("BZ_BWT_TRACE") != nullptr;
+        // survivor form below this share of the rotations (1/8 ... 1/2 measured in round 5: flat)
+        constexpr u64 surv_num = 1, surv_den = 4;
         if (bwt_trace)
             fprintf(stderr, "bz2_mi355x: sort round %d (h = %llu): %llu of %llu rotations unordered, at most %u in one block (block %u; of %u)%s\n",
                     rounds, (unsigned long long)(2u * min_chars) << step, (unsigned long long)m, (unsigned long long)total_n, mx,
@@ -3855,15 +3497,14 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             // The start-based keys are heuristic (k_period_mark decides): when every listed distance of the batch is 1024 and more
             // -- a paragraph repeated every 4 KiB --, the members of a group differ above bit 10 and the keys go down by ten bits:
             // ranks, pair verdicts and shifted starts all fit ONE digit, and the second pass over the key is left out (a pass over
-            // the whole list: 4.4 of T2's 119 ms per GiB).  BZ_PERIOD_ONE_PASS=0: two passes always.
-            static const bool want_one_pass = !(getenv("BZ_PERIOD_ONE_PASS") && atoi(getenv("BZ_PERIOD_ONE_PASS")) == 0);
+            // the whole list: 4.4 of T2's 119 ms per GiB).
             bool one_pass = false, wide = false;
             {
                 std::vector<u32> lp((size_t)a.nb * kPerK), ls((size_t)a.nb * kPerK);
                 if (hipMemcpyAsync(lp.data(), a.lin_p, lp.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
                     hipMemcpyAsync(ls.data(), a.lin_sig, ls.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
                     return -1;
-                one_pass = want_one_pass;
+                one_pass = true;
                 u32 small = 0, smallest = 0xFFFFFFFFu;
                 // (a distance below 1024 that a fifth of its block agrees at; the ones that barely made the list -- a paragraph
                 // repeated lists a chance distance at 6 % in one block of forty -- only leave their few groups to the doubling)
@@ -3911,13 +3552,12 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             // of rotation j+h (2 passes), then stably by their own group (2 passes): O(m) work
             hipLaunchKernelGGL(k_survivor_compact, grid_prev, dim3(kSortThreads), 0, st, a, lastV, fV);
             hipLaunchKernelGGL(k_copy_counts, dim3((a.nb + 255) / 256), dim3(256), 0, st, a.count, a.count2, a.nb);
-            // The list inside LDS, segment by segment (k_surv_local) -- unless BZ_SURV_LOCAL=0, or a segment of an earlier round
+            // The list inside LDS, segment by segment (k_surv_local) -- unless a segment of an earlier round
             // of this sort did not fit: then, and when one of this round does not, the four global passes.
-            static const bool want_local_surv = !(getenv("BZ_SURV_LOCAL") && atoi(getenv("BZ_SURV_LOCAL")) == 0);
             bool local_done = false;
             // (only lists of less than an eighth of the rotations: text's are 7 % and 0.001 %; a list of 18 % -- the corpus "binary"
             // behind its walk rounds -- still holds groups that do not fit, and the failed attempt costs 3 ms per 256 MiB)
-            if (want_local_surv && surv_local_ok && m * 8 < total_n) { // (cK, cV are free: the compaction above was the last reader of the old list)
+            if (surv_local_ok && m * 8 < total_n) { // (cK, cV are free: the compaction above was the last reader of the old list)
                 u32 fails = 0;
                 (void)hipMemsetAsync(a.loc_stats + LOC_STAT_SURV_FAIL, 0, 4, st);
                 hipLaunchKernelGGL(k_surv_local, grid_list, dim3(kLocThreads), 0, st, a, step, fV, cK, cV);
@@ -4013,31 +3653,16 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
         static const bool late_fail_test = getenv("BZ_ONESWEEP_LATEFAILTEST") != nullptr; // (tests: exercise the redo)
         bool bad = gave_up != 0 || late_fail_test;
-        const u32 want = a.tiles * (xcd_grid_y(a.nb) / 8u); // (exactly: see fused_pass_ok)
-        for (size_t i = 0; i < tk.size(); ++i) {
-            const u32 ep = epoch_first + (u32)(i / 8u);
-            const bool dbl = std::find(double_epochs.begin(), double_epochs.end(), ep) != double_epochs.end();
-            if (tk[i] != (dbl ? 2u * want : want)) bad = true;
-        }
+        for (size_t i = 0; i < tk.size(); ++i)
+            if (tk[i] != a.tiles * (xcd_grid_y(a.nb) / 8u)) bad = true; // (exactly: see fused_pass_ok)
         if (bad) {
             (void)hipMemsetAsync(a.sort_err, 0, 4, st);
             return -2;
         }
     }
-    static const bool local_trace = getenv("BZ_LOCAL_TRACE") != nullptr;
-    if (local_trace) {
-        u32 ls[12] = {};
-        std::vector<u32> gates(a.nb);
-        (void)hipMemcpyAsync(ls, a.loc_stats, sizeof(ls), hipMemcpyDeviceToHost, st);
-        (void)hipMemcpyAsync(gates.data(), a.pb_gate, a.nb * sizeof(u32), hipMemcpyDeviceToHost, st);
+#if defined(BZ_SCATTER_TIMING) || defined(BZ_REFINE_TIMING)
+    { // (the phase timers of the instrumented builds: tools/build_variant.sh <name> -DBZ_SCATTER_TIMING / -DBZ_REFINE_TIMING)
         (void)hipStreamSynchronize(st);
-        u32 ng = 0;
-        for (u32 g : gates) ng += g != 0;
-        fprintf(stderr, "bz2_mi355x: phase B in LDS: %u segments so far (%u too long, %u out of order, %u passes); %u of %u blocks "
-                        "of this batch by the global passes\n", ls[0], ls[1], ls[2], ls[3], ng, a.nb);
-#ifdef BZ_LOC_TIMERS
-        fprintf(stderr, "  cycles/16 per phase (bounds, load, fill, passes, out): %u %u %u %u %u\n", ls[4], ls[5], ls[6], ls[7], ls[8]);
-#endif
 #ifdef BZ_SCATTER_TIMING
         {
             u32 rt[16] = {};
@@ -4064,6 +3689,7 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         }
 #endif
     }
+#endif
     // periodic blocks: whatever is still non-final is a set of equal rotations
     (void)hipMemsetAsync(a.per_k, 0, a.nb * sizeof(u32), st);
     (void)hipMemsetAsync(a.per_shift, 0xFF, a.nb * sizeof(u32), st);
@@ -4093,18 +3719,6 @@ int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned l
         if (r == -2) r = -1;
     }
     return r;
-}
-
-void launch_last_column(hipStream_t st, const BwtArgs &a, u8 *L, u32 *orig_ptr, u64 total_n, KernelProf *prof)
-{
-    // The last column is written by k_group_apply / k_periodic_place when a rotation becomes final; the pass over
-    // SA is kept as a cross-check (BZ_LASTCOL_PASS=1 redoes the column from SA: same bytes).
-    static const bool redo = getenv("BZ_LASTCOL_PASS") && atoi(getenv("BZ_LASTCOL_PASS")) != 0;
-    if (!redo) return;
-    const dim3 grid(kTilesPerBlock, xcd_grid_y(a.nb));
-    const int p = prof ? prof->begin(st, KID_LAST_COLUMN, total_n * 6) : -1;
-    hipLaunchKernelGGL(k_last_column, grid, dim3(kSortThreads), 0, st, a, L, orig_ptr);
-    if (prof) prof->end(st, p);
 }
 
 } // namespace bzgpu

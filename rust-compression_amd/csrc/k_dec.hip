@@ -114,25 +114,12 @@ struct BitCur {
 // are resident at once (10 bits: 21 KB per block, 7 per CU, 1792 on the chip; 11 bits: 4 per CU --
 // the 1189 blocks of a 1 GiB file then run as two rounds, twice the time).  Longer codes take the
 // canonical walk.
-#ifndef BZ_DEC_LUT_BITS
-#define BZ_DEC_LUT_BITS 10
-#endif
-constexpr u32 kLutBits = BZ_DEC_LUT_BITS;
+constexpr u32 kLutBits = 10;
 constexpr u16 kLutLong = 0xFFFE, kLutBad = 0xFFFF;
 constexpr u32 kRingWords = 256;  // staged input window (words), power of two
 constexpr u32 kOutBuf = 1024;    // staged output symbols
 
-#ifndef BZ_D1_PAR_SEL
-#define BZ_D1_PAR_SEL 1 // the selectors of a block's header by all threads (0: by thread 0, one unary code per step)
-#endif
-#ifndef BZ_D1_SEL_LDS
-#define BZ_D1_SEL_LDS 1
-#endif
-#ifndef BZ_D1_THREADS
-#define BZ_D1_THREADS 256
-#endif
-constexpr u32 kD1Threads = BZ_D1_THREADS; // threads = candidate code starts per round
-#if BZ_D1_PAR_SEL
+constexpr u32 kD1Threads = 256; // threads = candidate code starts per round
 // ---- the selectors of a block's header by the whole workgroup ------------------------------------------------------------
 // n_selectors unary codes (j one bits and a zero, j < n_groups: the position in a move-to-front list of the tables,
 // decoder.rs:294-316).  Thread 0 took them one code per step: 18 002 dependent steps, 1.5 M of the 1.9 M cycles a header
@@ -284,7 +271,6 @@ __device__ void d1_selectors(const BitCur &bc, u8 *__restrict__ sel, u64 p0, u32
     }
     __syncthreads();
 }
-#endif
 
 // ---- D1: header + Huffman decode of one candidate -------------------------------------------------------
 // One workgroup of four waves per candidate.  Thread 0 parses the header; all threads build the
@@ -305,22 +291,12 @@ __global__ __launch_bounds__(kD1Threads) void k_dec_block(const u8 *__restrict__
     __shared__ u16 s_j[6][kD1Threads + 4]; // s_j[k][i]: the code start 2^k symbols behind start i (256 = outside the window)
     __shared__ u16 s_e[kD1Threads];        // table entry of the code that would start at i
     __shared__ u32 s_ctl[4];               // symbols taken, bits consumed, stop reason
-#if BZ_D1_PAR_SEL
     __shared__ u64 s_sel64[2];
-#endif
-#if BZ_D1_SEL_LDS
     __shared__ u8 s_sel[256];              // the selectors of the groups g .. g | 255
-#endif
     const u32 c = blockIdx.x;
     if (c >= ncand) return;
     const u32 l = threadIdx.x;
-#ifdef BZ_DEC_TIMING
-    u64 tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    u64 tq = clock64();
-#define BZ_T(i) { const u64 now_ = clock64(); tm[i] += now_ - tq; tq = now_; }
-#else
 #define BZ_T(i)
-#endif
     DecBlockInfo &bi = info[c];
     BitCur bc;
     bc.open(in, nbytes);
@@ -368,26 +344,6 @@ __global__ __launch_bounds__(kD1Threads) void k_dec_block(const u8 *__restrict__
                 n_selectors = bc.read(15);
                 if (n_selectors < 1) status = BZ_DEC_E_DATA;            // :290-292
             }
-#if !BZ_D1_PAR_SEL
-            if (!status) { // selectors: unary MTF positions (:294-316); a whole unary code per step
-                u32 lst = 0x543210u;
-                for (u32 s = 0; s < n_selectors; ++s) {
-                    bc.fill();
-                    const u32 j = (u32)__builtin_clz(~bc.peek(32) | 1u); // leading one bits (at most 31 counted)
-                    if (j >= n_groups) { // the reference gives up at the n_groups-th one bit
-                        status = BZ_DEC_E_DATA;
-                        break;
-                    }
-                    bc.skip(j + 1u);
-                    const u32 v = (lst >> (4u * j)) & 15u;
-                    if (j) {
-                        const u32 lowmask = (1u << (4u * j)) - 1u;
-                        lst = (lst & ~((lowmask << 4) | 15u)) | ((lst & lowmask) << 4) | v;
-                    }
-                    sel[s] = (u8)v;
-                }
-            }
-#else
             // (the selectors are taken by all threads behind the barrier below; thread 0 goes on with the coding tables then)
             s_hdr[0] = n_groups;
             s_hdr[1] = alpha;
@@ -416,7 +372,6 @@ __global__ __launch_bounds__(kD1Threads) void k_dec_block(const u8 *__restrict__
             bc.seek(s_pos + s_sel64[1]);
         }
         {
-#endif
             if (!status) { // coding tables (:318-348); "10" = +1, "11" = -1, "0" = next symbol
                 for (u32 t = 0; t < n_groups && !status; ++t) {
                     u32 curr = bc.read(5);
@@ -439,11 +394,6 @@ __global__ __launch_bounds__(kD1Threads) void k_dec_block(const u8 *__restrict__
                     }
                 }
             }
-#if !BZ_D1_PAR_SEL
-            s_hdr[0] = n_groups;
-            s_hdr[1] = alpha;
-            s_hdr[2] = n_selectors;
-#endif
             s_hdr[3] = status ? 1u : 0u;
             s_pos = bc.pos();
             if (status) {
@@ -522,15 +472,11 @@ __global__ __launch_bounds__(kD1Threads) void k_dec_block(const u8 *__restrict__
     u64 pos = s_pos;
     u32 flushed = 0;
     u32 g = 0, krem = 0, t = 0; // krem == 0: open the next group before the next symbol
-#if BZ_D1_SEL_LDS
     // Round 5: the selectors come through a 256-entry window in LDS (refilled by all threads every 256 groups) instead of one
     // global load per group issued a round ahead of its use (k_dec_block 12.74 -> 12.49 ms)
     for (u32 q = l; q < 256u; q += kD1Threads) s_sel[q] = sel[q < n_selectors ? q : 0u];
     __syncthreads();
     u32 t_next = s_sel[0];
-#else
-    u32 t_next = sel[0];        // (fetched one group ahead: the load's latency stays off the serial path)
-#endif
     u32 state = 0;              // 0 running, 1 end of block, 2 error
     if (l < 6) s_j[l][kD1Threads] = (u16)kD1Threads; // outside stays outside
     while (true) {
@@ -548,16 +494,12 @@ __global__ __launch_bounds__(kD1Threads) void k_dec_block(const u8 *__restrict__
                 }
                 t = t_next;
                 ++g;
-#if BZ_D1_SEL_LDS
                 if ((g & 255u) == 0u) { // (g, krem are the same in every thread: the barriers are met by all)
                     __syncthreads();
                     for (u32 q = l; q < 256u; q += kD1Threads) s_sel[q] = sel[g + q < n_selectors ? g + q : 0u];
                     __syncthreads();
                 }
                 t_next = s_sel[g & 255u];
-#else
-                t_next = sel[g < n_selectors ? g : 0u];
-#endif
                 krem = kGSize;
             }
             if (pos >= total_bits) { // peek returns no bits: Ok(None) -> DataError (:387-390)
@@ -679,11 +621,6 @@ __global__ __launch_bounds__(kD1Threads) void k_dec_block(const u8 *__restrict__
         for (u32 i = l; i < nout; i += kD1Threads) out[flushed + i] = s_out[i];
         flushed += nout;
         BZ_T(6)
-#ifdef BZ_DEC_TIMING
-        if (state && l == 0 && c == 7)
-            printf("D1 cycles: header %llu tables %llu refill %llu lookup %llu double %llu rank %llu flush %llu nsym %u\n",
-                   tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], flushed);
-#endif
         if (state) {
             if (l == 0) {
                 bi.status = state == 2 ? (u32)BZ_DEC_E_DATA : 0u;
@@ -977,35 +914,13 @@ __global__ __launch_bounds__(64) void k_dec_walk_meta(DecArgs a)
 // Walk 1: every segment (sample node -> next sample node) is walked once.  The bytes it passes are
 // kept in the segment's scratch row (dword stores, kSegCap bytes); its length and successor go to
 // the sample arrays.  The node reached after kSegCap steps is remembered for the few long segments.
-// the cache policy of the chase's load (experiments: -DBZ_DEC_WALK_LOAD=1 nt, 2 sc1, 3 sc0 sc1, 4 nt sc0 sc1, 5 sc0)
-#ifndef BZ_DEC_WALK_LOAD
-#define BZ_DEC_WALK_LOAD 0
-#endif
+// the chase's load: a plain one (nt / sc0 / sc1 variants were measured in round 3 and change nothing: profiles/r03_decode_walk_window.md)
 __device__ __forceinline__ u32 walk_load(const u32 *p)
 {
-#if BZ_DEC_WALK_LOAD == 0
     return *p;
-#else
-    u32 r;
-#if BZ_DEC_WALK_LOAD == 1
-    asm volatile("global_load_dword %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
-#elif BZ_DEC_WALK_LOAD == 2
-    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
-#elif BZ_DEC_WALK_LOAD == 3
-    asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
-#elif BZ_DEC_WALK_LOAD == 4
-    asm volatile("global_load_dword %0, %1, off sc0 sc1 nt\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
-#else
-    asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
-#endif
-    return r;
-#endif
 }
 
-#ifndef BZ_DEC_WALK_GROUP
-#define BZ_DEC_WALK_GROUP 1
-#endif
-constexpr u32 kWalkGroup = BZ_DEC_WALK_GROUP;                          // consecutive sample nodes a lane takes at a time
+constexpr u32 kWalkGroup = 1;                          // consecutive sample nodes a lane takes at a time
 constexpr u32 kWalkItems = (kDecSamples + kWalkGroup - 1u) / kWalkGroup; // items per block
 __global__ __launch_bounds__(256) void k_dec_walk_lengths(DecArgs a)
 {
@@ -1776,8 +1691,7 @@ void launch_dec_mtf(hipStream_t st, const DecArgs &a, KernelProf *prof, int *rec
     // (the chunk kernels keep the launch of a full slot, 14 workgroups per block, most of which leave at once: launched
     // with just the workgroups the chunks need the stage is SLOWER -- level 9: 9.5 ms per GiB against 8.3, level 1: 30.0
     // against 17.1 --, with one workgroup per CU twice as slow; profiles/r04_off_default_configs.md)
-    static const u32 cw_env = getenv("BZ_DEC_CW") ? (u32)atoi(getenv("BZ_DEC_CW")) : 0u; // (experiments: workgroups per block; too few = blocks cut short)
-    const u32 cw = cw_env ? cw_env : a.cw; // (odd: see dec_engine.hip)
+    const u32 cw = a.cw; // (odd: see dec_engine.hip)
     const dim3 cgrid(cw, xcd_grid_y(a.nb));
     hipLaunchKernelGGL(k_dec_chunk_perm, cgrid, dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dec_compose, dim3(a.nb), dim3(64), 0, st, a);

@@ -18,10 +18,7 @@
 
 namespace bzgpu {
 
-#ifndef BZ_HUFF_THREADS
-#define BZ_HUFF_THREADS 512
-#endif
-constexpr u32 kHuffThreads = BZ_HUFF_THREADS;
+constexpr u32 kHuffThreads = 512;
 
 // encoder.rs:647-650
 __device__ __forceinline__ u32 weight_add(u32 x, u32 y)
@@ -398,10 +395,7 @@ __device__ __forceinline__ void stage_symbols(u32 *s_sym, const u16 *__restrict_
     }
 }
 
-#ifndef BZ_HUFF_WAVES
-#define BZ_HUFF_WAVES 4
-#endif
-__global__ __launch_bounds__(kHuffThreads, BZ_HUFF_WAVES) void k_huffman(HuffArgs a) // (4 waves per SIMD = two workgroups per CU)
+__global__ __launch_bounds__(kHuffThreads, 4) void k_huffman(HuffArgs a) // (4 waves per SIMD = two workgroups per CU)
 {
     __shared__ u8 s_len[6][kMaxAlpha + 6];
     __shared__ u32 s_rfreq[6][kMaxAlpha];
@@ -418,13 +412,7 @@ __global__ __launch_bounds__(kHuffThreads, BZ_HUFF_WAVES) void k_huffman(HuffArg
 
     const u32 lb = blockIdx.x;
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-#ifdef BZ_HUFF_TIMING
-    u64 tm[6] = {0, 0, 0, 0, 0, 0};
-    u64 tq = clock64();
-#define BZ_HT(i) { const u64 now_ = clock64(); tm[i] += now_ - tq; tq = now_; }
-#else
 #define BZ_HT(i)
-#endif
     const u16 *mtf = a.mtf + (size_t)lb * a.mtf_stride;
     const u32 *mtf_freq = a.mtf_freq + (size_t)lb * kMaxAlpha;
     BlockOut &bo = a.out[lb];
@@ -858,10 +846,6 @@ __global__ __launch_bounds__(kHuffThreads, BZ_HUFF_WAVES) void k_huffman(HuffArg
         for (u32 w = w0 + tid; w < w1; w += kHuffThreads) stream[w] = 0;
     }
     BZ_HT(3)
-#ifdef BZ_HUFF_TIMING
-    if (tid == 0 && lb == 7)
-        printf("k_huffman cycles: sweeps(hist+barriers) %llu heaps %llu lm %llu tail %llu staging %llu cost-loop %llu\n", tm[0], tm[1], tm[2], tm[3], tm[4], tm[5]);
-#endif
 }
 
 // ---- payload: one lane per 50-symbol group (encoder.rs:609-629) ---------------------------
@@ -929,10 +913,7 @@ __global__ __launch_bounds__(256) void k_emit_payload(HuffArgs a)
 // The tables travel between the kernels as lengths (glen), as 6 x 10-bit packed lengths per symbol (pack) and
 // as counts (rfreq).  BZ_HUFF_SPLIT=0 selects k_huffman.
 constexpr u32 kSweepThreads = 256;  // groups per sweep step
-#ifndef BZ_SWEEP_TILES_X
-#define BZ_SWEEP_TILES_X 11 // odd: workgroups go round the XCDs and, inside one, round its four shader engines -- with 12 per
-#endif                      // block and three of them filled (level 1) the filled ones met on a part of the chip: 2.4 -> 2.0 ms per 256 MiB
-constexpr u32 kSweepTilesX = BZ_SWEEP_TILES_X; // workgroups per block (each loops over its share of the group tiles)
+constexpr u32 kSweepTilesX = 11; // workgroups per block (each loops over its share of the group tiles)
 // k_huff_tables' scratch arena in LDS: the heap procedure's work arrays (6 x (2 * 258 + 4) words), then -- they are
 // dead by then -- the package-merge scratch of as many tables at a time as fit (one of up to 40 symbols: text; larger
 // alphabets use global memory).  With the other arrays 24.6 KB per workgroup: six workgroups share a CU and every
@@ -1129,17 +1110,13 @@ __device__ __forceinline__ void stage_symbols_n(u32 *s_sym, const u16 *__restric
     }
 }
 
-// -DBZ_HUFF_HEAP_WAVE: a wave per table with the heap in its registers (heap_code_lengths_wave) instead of a lane per
-// table with the heap in LDS.  Measured in round 4 and NOT the default: the Huffman stage of the 1 GiB text corpus
+// (A wave per table with the heap in its registers instead of a lane per table with the heap in LDS was measured in
+// round 4, profiles/r04_negatives.md: the Huffman stage of the 1 GiB text corpus
 // takes 5.3 ms with it against 4.3 (38-symbol tables: six waves per block instead of one, 1189 blocks no longer
 // resident at once), 13.8 against 13.2 per 256 MiB of 258-symbol binary data, 6.6 against 5.7 of random bytes -- the
 // register array's writes are a compare and a select over up to sixteen registers, and that costs what the LDS round
-// trips did.  (The Deflate block kernel, where the same device pays, has 286-symbol tables and no LDS to spare.)
-#ifdef BZ_HUFF_HEAP_WAVE
-constexpr u32 kTabThreads = 6 * 64; // a wave per table
-#else
+// trips did.  The Deflate block kernel, where the same device pays, has 286-symbol tables and no LDS to spare.)
 constexpr u32 kTabThreads = 64;
-#endif
 __global__ __launch_bounds__(kTabThreads) void k_huff_tables(HuffArgs a, u32 iter)
 {
     __shared__ u8 s_len[6][kMaxAlpha + 6];
@@ -1193,20 +1170,8 @@ __global__ __launch_bounds__(kTabThreads) void k_huff_tables(HuffArgs a, u32 ite
             rfreq[i] = 0;
         }
         __syncthreads();
-        // the heap procedure: one lane per table, the heap in LDS (-DBZ_HUFF_HEAP_WAVE: wave w builds table w, the heap
-        // in its registers)
-#ifndef BZ_HUFF_HEAP_WAVE
+        // the heap procedure: one lane per table, the heap in LDS
         if (tab_lane) s_need[tb] = (u32)heap_code_lengths_w(s_rfreq[tb], alpha, s_arena + tb * (3 * kMaxAlpha + 4), s_len[tb]);
-#else
-        if (wv < group_num) { // (uniform per wave)
-            u32 *buf = s_arena + wv * (2 * kMaxAlpha + 4);
-            int need;
-            if (2u * alpha <= 64u) need = heap_code_lengths_wave<1>(s_rfreq[wv], alpha, buf, s_len[wv], lane);
-            else if (2u * alpha <= 256u) need = heap_code_lengths_wave<4>(s_rfreq[wv], alpha, buf, s_len[wv], lane);
-            else need = heap_code_lengths_wave<16>(s_rfreq[wv], alpha, buf, s_len[wv], lane);
-            if (lane == 0) s_need[wv] = (u32)need;
-        }
-#endif
         __syncthreads();
         // tables whose longest code exceeds 17 bits: package-merge, one lane each, as many tables at a time as fit
         // the arena, side by side in global memory when not even one does
@@ -1234,14 +1199,7 @@ __global__ __launch_bounds__(kTabThreads) void k_huff_tables(HuffArgs a, u32 ite
             } else {
                 // (large alphabets: the scratch of a table does not fit the arena -- it lies in global memory; the WAVE
                 // builds the tables one after the other there too.  Rounds 1-3 gave each table a single lane here:
-                // 12 of the 13 ms the Huffman stage took per 256 MiB of 258-symbol binary data.  BZ_HUFF_LM_LANE at build
-                // time keeps that form.)
-#ifdef BZ_HUFF_LM_LANE
-                if (tab_lane && s_need[tb]) {
-                    lm_code_lengths(s_rfreq[tb], alpha, a.lm_scratch + ((size_t)lb * 6 + tb) * kLmWords, kLmWords, kLmRow, s_len[tb]);
-                    atomicAdd(&s_lmcount, 1u);
-                }
-#else
+                // 12 of the 13 ms the Huffman stage took per 256 MiB of 258-symbol binary data.)
                 if (wv == 0) {
                     for (u32 t = 0; t < group_num; ++t) {
                         if (s_need[t]) { // uniform
@@ -1251,7 +1209,6 @@ __global__ __launch_bounds__(kTabThreads) void k_huff_tables(HuffArgs a, u32 ite
                         }
                     }
                 }
-#endif
                 __syncthreads();
             }
         }

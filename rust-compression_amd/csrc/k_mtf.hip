@@ -22,23 +22,6 @@
 namespace bzgpu {
 
 constexpr u32 kChunkWGs = (kMaxMtfChunks + 255) / 256;
-#ifndef BZ_MTF_HEADS
-#define BZ_MTF_HEADS 0 // 1: k_mtf_ranks_small ranks the heads of runs only (measured slower: profiles/r04_negatives.md)
-#ifndef BZ_MTF_FENCE
-#define BZ_MTF_FENCE 0
-#endif
-#ifndef BZ_MTF_BLOCK
-#define BZ_MTF_BLOCK 32
-#endif
-#if BZ_MTF_FENCE
-#define BZ_MTF_SCHED_FENCE __builtin_amdgcn_sched_barrier(0)
-#else
-#define BZ_MTF_SCHED_FENCE do { } while (0)
-#endif
-#ifndef BZ_MTF_PIPELINED
-#define BZ_MTF_PIPELINED 1 // the compare loop of k_mtf_ranks_small with the next rows of the table in flight (0: the plain loop)
-#endif
-#endif
 constexpr u32 kMtfSmallAlpha = 96;                     // blocks with at most this many symbols use k_mtf_ranks_small // 14 workgroups of 256 chunks
 
 __device__ __forceinline__ u32 popc8(const u32 *b)
@@ -97,83 +80,6 @@ __global__ __launch_bounds__(256) void k_mtf_summaries(MtfArgs a)
     a.summ_len[(size_t)lb * kMaxMtfChunks + chunk] = (u16)cnt;
 }
 
-// ---- M2: compose the reports; one wave per block --------------------------------------
-__global__ __launch_bounds__(64) void k_mtf_compose(MtfArgs a)
-{
-    __shared__ u8 s_state[256];
-    __shared__ u8 s_new[256];
-    __shared__ u8 s_mark[256];
-    const u32 lb = blockIdx.x;
-    const u32 n = a.blocks[lb].n;
-    const u32 l = threadIdx.x;
-    const u32 nchunks = (n + kMtfChunk - 1) / kMtfChunk;
-    const u32 *bits = a.inuse_bits + lb * 8;
-    // identity list: in-use byte values ascending
-    {
-        u32 before = 0;
-        for (u32 q = 0; q < (l * 4u) / 32u; ++q) before += __popc(bits[q]);
-        // entries for byte values 4l..4l+3
-        const u32 wd = bits[(l * 4u) >> 5];
-        const u32 sh = (l * 4u) & 31u;
-        before += __popc(wd & ((1u << sh) - 1u));
-        for (u32 k = 0; k < 4; ++k) {
-            s_state[l * 4 + k] = 0;
-        }
-        __syncthreads();
-        u32 pos = before;
-        for (u32 k = 0; k < 4; ++k)
-            if ((wd >> (sh + k)) & 1u) s_state[pos++] = (u8)(l * 4u + k);
-    }
-    __syncthreads();
-    const u32 alpha = popc8(bits);
-    u32 *st32 = reinterpret_cast<u32 *>(s_state);
-    // the report of chunk c + 1 is fetched while chunk c is folded in: the loop is a chain of
-    // barriers, a memory round trip inside every link would double its length
-    const size_t rep0 = (size_t)lb * kMaxMtfChunks;
-    u32 m_next = nchunks > 1 ? (u32)a.summ_len[rep0] : 0u;
-    u32 w_next = nchunks > 1 ? reinterpret_cast<const u32 *>(a.summ + rep0 * 256u)[l] : 0u;
-    for (u32 c = 0; c < nchunks; ++c) {
-        // the list chunk c starts from
-        u32 *dst = reinterpret_cast<u32 *>(a.init_state + ((size_t)lb * kMaxMtfChunks + c) * 256u);
-        dst[l] = st32[l];
-        if (c + 1 == nchunks) break;
-        const u32 m = m_next, w = w_next;
-        if (c + 2 < nchunks) {
-            m_next = a.summ_len[rep0 + c + 1];
-            w_next = reinterpret_cast<const u32 *>(a.summ + (rep0 + c + 1) * 256u)[l];
-        }
-        reinterpret_cast<u32 *>(s_mark)[l] = 0;
-        __syncthreads();
-#pragma unroll
-        for (u32 k = 0; k < 4; ++k) {
-            const u32 i = l * 4u + k;
-            if (i < m) {
-                const u8 v = (u8)(w >> (8u * k));
-                s_mark[v] = 1;
-                s_new[i] = v;
-            }
-        }
-        __syncthreads();
-        // stable compaction of the old entries that are not in the report
-        u32 keep[4], nk = 0;
-        u8 ev[4];
-#pragma unroll
-        for (u32 k = 0; k < 4; ++k) {
-            const u32 e = l * 4 + k;
-            ev[k] = s_state[e];
-            keep[k] = (e < alpha && !s_mark[ev[k]]) ? 1u : 0u;
-            nk += keep[k];
-        }
-        const u32 inc = wave_incl_sum(nk);
-        u32 pos = m + inc - nk;
-#pragma unroll
-        for (u32 k = 0; k < 4; ++k)
-            if (keep[k]) s_new[pos++] = ev[k];
-        __syncthreads();
-        st32[l] = reinterpret_cast<u32 *>(s_new)[l];
-        __syncthreads();
-    }
-}
 
 // ---- M2 in three short steps instead of one chain of 1758 links per block ---------------------------------------
 // A chunk's report R acts on the list as  list -> R ++ (list \ R)  (its symbols, most recent first, move to the
@@ -314,73 +220,6 @@ __global__ __launch_bounds__(256) void k_mtf_chunk_starts(MtfArgs a)
     }
 }
 
-// ---- M3: one lane per chunk replays its symbols ------------------------------------------
-__global__ __launch_bounds__(256) void k_mtf_ranks(MtfArgs a)
-{
-    __shared__ u32 s_list[256 * 65];
-    const u32 lb = blockIdx.y;
-    const u32 n = a.blocks[lb].n;
-    const u32 chunk0 = blockIdx.x * 256u;
-    if (chunk0 * kMtfChunk >= n) return;
-    if (popc8(a.inuse_bits + lb * 8) <= a.walk_above) return; // k_mtf_ranks_small takes those blocks
-    const u32 nchunks = (n + kMtfChunk - 1) / kMtfChunk;
-    // cooperative, coalesced load of up to 256 start lists (64 dwords each)
-    {
-        const u32 *src = reinterpret_cast<const u32 *>(a.init_state + ((size_t)lb * kMaxMtfChunks + chunk0) * 256u);
-        const u32 avail = (nchunks - chunk0 < 256u ? nchunks - chunk0 : 256u) * 64u;
-        for (u32 i = threadIdx.x; i < avail; i += 256u) s_list[(i >> 6) * 65u + (i & 63u)] = src[i];
-    }
-    __syncthreads();
-    const u32 chunk = chunk0 + threadIdx.x;
-    const u32 beg = chunk * kMtfChunk;
-    if (beg >= n) return;
-    const u32 end = (beg + kMtfChunk < n) ? beg + kMtfChunk : n;
-    u32 *list = s_list + threadIdx.x * 65u;
-    const u8 *L = a.L + (size_t)lb * kSlot;
-    u8 *R8 = a.rank8 + (size_t)lb * kSlot;
-    for (u32 v = 0; v < kMtfChunk / 16u; ++v) {
-        const u32 p0 = beg + v * 16u;
-        if (p0 >= end) break;
-        const uint4 q = *reinterpret_cast<const uint4 *>(L + p0);
-        const u32 wv[4] = {q.x, q.y, q.z, q.w};
-        u32 ov[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (u32 k = 0; k < 16; ++k) {
-            u32 rank = 0;
-            if (p0 + k < end) {
-                const u32 c = (wv[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-                u32 w = list[0];
-                if ((w & 0xFFu) != c) {
-                    const u32 rep = c * 0x01010101u;
-                    u32 carry = c, d = 0;
-                    while (true) {
-                        const u32 x = w ^ rep;
-                        const u32 z = (x - 0x01010101u) & ~x & 0x80808080u;
-                        if (z == 0) {
-                            list[d] = (w << 8) | carry;
-                            carry = w >> 24;
-                            ++d;
-                            if (d == 64u) { // symbol not in the list: impossible for in-use bytes
-                                rank = 0xFFu;
-                                break;
-                            }
-                            w = list[d];
-                            continue;
-                        }
-                        const u32 b = (u32)__builtin_ctz(z) >> 3;
-                        const u32 upto = (b == 3u) ? 0xFFFFFFFFu : ((1u << (8u * (b + 1u))) - 1u);
-                        const u32 lowm = upto >> 8;
-                        list[d] = (w & ~upto) | ((((w & lowm) << 8) | carry) & upto);
-                        rank = 4u * d + b;
-                        break;
-                    }
-                }
-            }
-            ov[k >> 2] |= rank << ((k & 3) * 8);
-        }
-        *reinterpret_cast<uint4 *>(R8 + p0) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
-    }
-}
 
 // ---- M3': the same for small alphabets, without the data-dependent list walk ------------------
 // rank(i) = number of symbols used more recently than symbol(i) = #{c : last[c] > last[sym(i)]},
@@ -428,7 +267,7 @@ __global__ __launch_bounds__(LANES) void k_mtf_ranks_small(MtfArgs a)
     const u32 npairs = (alpha + 1u) >> 1;
     u32 *my = s_last + threadIdx.x;
     // (the compare loop below runs over blocks of 16 pairs: the rows behind the alphabet's last pair hold "never seen" too)
-    constexpr u32 kPB = BZ_MTF_BLOCK; // pairs per block of the pipelined compare loop (two blocks per trip)
+    constexpr u32 kPB = 32; // pairs per block of the pipelined compare loop (two blocks per trip)
     static_assert(PAIRS % (2u * kPB) == 0 || PAIRS <= kMtfSmallPairs, "the compare loop takes the table two blocks at a time");
     const u32 npairs16 = ((npairs + 2u * kPB - 1u) / (2u * kPB) * (2u * kPB)) < PAIRS ? ((npairs + 2u * kPB - 1u) / (2u * kPB) * (2u * kPB)) : PAIRS;
     for (u32 q = 0; q < npairs16; ++q) my[q * LANES] = 0x80008000u; // both halves: -32768 = never seen
@@ -445,82 +284,6 @@ __global__ __launch_bounds__(LANES) void k_mtf_ranks_small(MtfArgs a)
     }
     const u8 *L = a.L + (size_t)lb * kSlot;
     u8 *R8 = a.rank8 + (size_t)lb * kSlot;
-#if BZ_MTF_HEADS
-    // (-DBZ_MTF_HEADS=1, measured slower -- MTF + ZLE stage 9.0 ms per GiB against 7.0: the walk over the head bits is a
-    // serial loop with a three-deep chain of dependent LDS reads per head, the form below is unrolled over register bytes)
-    // A lane's chunk is 512 consecutive bytes, read 64 bytes at a time (four 16-byte loads issued together).  Only
-    // the HEAD of a run of equal bytes costs a rank: the bytes behind it are at the front of the list (rank 0), and
-    // moving a symbol's time forward inside its own run changes no later rank (nothing else is seen in between).
-    // In the last column of text more than half of the bytes continue a run, but a wave pays for a step if ONE of its
-    // lanes needs it: so a lane gathers the head bits of its 64 bytes first and walks those -- the wave takes the
-    // LONGEST of 64 walks (about 40 of 64 steps on text) instead of all 64.  The bytes and their ranks pass through a
-    // 64-byte row per lane in LDS, indexed by the head's position.
-    __shared__ uint4 s_io[4][LANES];
-    u32 prevb = 0x100u; // no byte in front of the chunk's first: it is a head
-    for (u32 v4 = 0; v4 < kMtfChunk / 64u; ++v4) {
-        if (beg + v4 * 64u >= end) break;
-        uint4 q4[4];
-#pragma unroll
-        for (u32 u = 0; u < 4; ++u) {
-            const u32 pl = beg + v4 * 64u + u * 16u;
-            q4[u] = (pl < end) ? *reinterpret_cast<const uint4 *>(L + pl) : make_uint4(0, 0, 0, 0); // (slots are padded)
-        }
-        u64 heads = 0;
-#pragma unroll
-        for (u32 u = 0; u < 4; ++u) {
-            s_io[u][threadIdx.x] = q4[u];
-            const u32 wv[4] = {q4[u].x, q4[u].y, q4[u].z, q4[u].w};
-#pragma unroll
-            for (u32 w = 0; w < 4; ++w) {
-                // bytes that differ from the byte in front of them: x = word ^ (word shifted up by a byte, the last byte
-                // of the word before it shifted in); a byte of x is non-zero <=> head
-                const u32 x = wv[w] ^ ((wv[w] << 8) | (prevb & 0xFFu));
-                u32 y = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
-                if (prevb > 0xFFu) y |= 0x80u;
-                prevb = wv[w] >> 24;
-                heads |= (u64)((((y >> 7) * 0x00204081u) >> 21) & 0xFu) << (u * 16u + w * 4u);
-            }
-        }
-        const u32 left = end - (beg + v4 * 64u); // bytes of the chunk from this piece on (>= 1)
-        if (left < 64u) heads &= (1ull << left) - 1ull;
-        const u64 heads0 = heads;
-        // a head's rank takes the place of its byte in the row; what is no head leaves as 0
-        const u8 *mine_in = reinterpret_cast<const u8 *>(&s_io[0][0]);
-        while (heads) {
-            const u32 k = (u32)__builtin_ctzll(heads);
-            heads &= heads - 1ull;
-            const u32 at = ((k >> 4) * LANES + threadIdx.x) * 16u + (k & 15u);
-            const u32 c = s_code[mine_in[at]];
-            const u32 wc = my[(c >> 1) * LANES];
-            const u32 lsu = (c & 1u) ? (wc >> 16) : (wc & 0xFFFFu);
-            // both halves of a table word against the symbol's own time in packed 16-bit arithmetic:
-            // ls - t saturates (a never-seen -32768 must not wrap), its sign says t > ls
-            const short2_t ls2 = as_short2(lsu | (lsu << 16));
-            short2_t acc = {0, 0};
-            for (u32 q = 0; q < npairs; ++q) {
-                const short2_t wd = as_short2(my[q * LANES]);
-                const short2_t neg = __builtin_elementwise_sub_sat(ls2, wd) >> (short2_t){15, 15}; // -1 where t > ls
-                acc -= neg;
-            }
-            const u32 rank = (u32)(int)acc.x + (u32)(int)acc.y;
-            const u32 t = (v4 * 64u + k) & 0xFFFFu; // time inside the chunk, 0..kMtfChunk-1
-            my[(c >> 1) * LANES] = (c & 1u) ? ((wc & 0x0000FFFFu) | (t << 16)) : ((wc & 0xFFFF0000u) | t);
-            reinterpret_cast<u8 *>(&s_io[0][0])[at] = (u8)rank;
-        }
-#pragma unroll
-        for (u32 u = 0; u < 4; ++u) {
-            const u32 p0 = beg + v4 * 64u + u * 16u;
-            if (p0 >= end) break;
-            const uint4 r = s_io[u][threadIdx.x];
-            const u32 hb = (u32)(heads0 >> (u * 16u)) & 0xFFFFu;
-            // four head bits -> four byte masks
-            const u32 m0 = (((hb & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu, m1 = ((((hb >> 4) & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
-            const u32 m2 = ((((hb >> 8) & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu, m3 = (((hb >> 12) * 0x00204081u) & 0x01010101u) * 0xFFu;
-            *reinterpret_cast<uint4 *>(R8 + p0) = make_uint4(r.x & m0, r.y & m1, r.z & m2, r.w & m3);
-        }
-    }
-}
-#else
     // A lane's chunk is 512 consecutive bytes: it is read 64 bytes at a time (four 16-byte loads issued
     // together, the ranks stored the same way), so a line is fetched once and used while it is there;
     // 16 bytes per visit meant eight visits per 128-byte line with 64 other lanes' lines in between
@@ -551,7 +314,6 @@ __global__ __launch_bounds__(LANES) void k_mtf_ranks_small(MtfArgs a)
                 // ls - t saturates (a never-seen -32768 must not wrap), its sign says t > ls
                 const short2_t ls2 = as_short2(lsu | (lsu << 16));
                 short2_t acc = {0, 0};
-#if BZ_MTF_PIPELINED
               if (PAIRS > kMtfSmallPairs) { // (<= 96 symbols: three workgroups per CU hide the wait already; measured slower with it: 2.02 -> 2.27 ms per 256 MiB of text)
                 // Round 5: the table rows of the NEXT eight pairs are on their way while the eight at hand are compared -- the
                 // compiler's loop asked for eight rows, waited for them and compared them, one wave per SIMD with nothing to hide
@@ -563,19 +325,16 @@ __global__ __launch_bounds__(LANES) void k_mtf_ranks_small(MtfArgs a)
                 for (u32 q = 0; q < npairs16; q += 2u * kPB) {
 #pragma unroll
                     for (u32 e = 0; e < kPB; ++e) rb[e] = my[(q + kPB + e) * LANES];
-                    BZ_MTF_SCHED_FENCE;
 #pragma unroll
                     for (u32 e = 0; e < kPB; ++e) acc -= __builtin_elementwise_sub_sat(ls2, as_short2(ra[e])) >> (short2_t){15, 15};
                     // (the last trip asks for the table's first rows again: never used)
                     const u32 qn = (q + 2u * kPB < npairs16) ? q + 2u * kPB : 0u;
 #pragma unroll
                     for (u32 e = 0; e < kPB; ++e) ra[e] = my[(qn + e) * LANES];
-                    BZ_MTF_SCHED_FENCE;
 #pragma unroll
                     for (u32 e = 0; e < kPB; ++e) acc -= __builtin_elementwise_sub_sat(ls2, as_short2(rb[e])) >> (short2_t){15, 15};
                 }
               } else
-#endif
                 for (u32 q = 0; q < npairs; ++q) {
                     const short2_t wd = as_short2(my[q * LANES]);
                     const short2_t neg = __builtin_elementwise_sub_sat(ls2, wd) >> (short2_t){15, 15}; // -1 where t > ls
@@ -591,7 +350,6 @@ __global__ __launch_bounds__(LANES) void k_mtf_ranks_small(MtfArgs a)
       }
     }
 }
-#endif
 
 // ---- ZLE helpers ----------------------------------------------------------------------------
 struct ZSeg {
@@ -979,21 +737,13 @@ void launch_mtf(hipStream_t st, const MtfArgs &a)
 {
     (void)hipMemsetAsync(a.mtf_freq, 0, (size_t)a.nb * kMaxAlpha * sizeof(u32), st);
     hipLaunchKernelGGL(k_mtf_summaries, dim3(kChunkWGs, a.nb), dim3(256), 0, st, a);
-    static const bool serial_compose = getenv("BZ_MTF_COMPOSE_SERIAL") && atoi(getenv("BZ_MTF_COMPOSE_SERIAL")) != 0;
-    if (serial_compose) {
-        hipLaunchKernelGGL(k_mtf_compose, dim3(a.nb), dim3(64), 0, st, a);
-    } else {
-        hipLaunchKernelGGL(k_mtf_merge_groups, dim3(kMtfGroups, a.nb), dim3(64), 0, st, a);
-        hipLaunchKernelGGL(k_mtf_group_starts, dim3(a.nb), dim3(64), 0, st, a);
-        hipLaunchKernelGGL(k_mtf_chunk_starts, dim3(kMtfGroups, a.nb), dim3(256), 0, st, a);
-    }
-    // ranks: the compare form for every alphabet (<= 96 symbols: 256 chunks per workgroup; more: 128); BZ_MTF_WALK=1 keeps
-    // the list walk for the large ones (rounds 1-3)
+    hipLaunchKernelGGL(k_mtf_merge_groups, dim3(kMtfGroups, a.nb), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_mtf_group_starts, dim3(a.nb), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_mtf_chunk_starts, dim3(kMtfGroups, a.nb), dim3(256), 0, st, a);
+    // ranks: the compare form for every alphabet (<= 96 symbols: 256 chunks per workgroup; more: 128 -- the list walk of
+    // rounds 1-3 took 21.0 ms per 256 MiB of random bytes against 8.9: DESIGN.md section 4)
     hipLaunchKernelGGL((k_mtf_ranks_small<kMtfSmallPairs, 256, 0>), dim3(kChunkWGs, a.nb), dim3(256), 0, st, a);
-    if (a.walk_above >= 256u)
-        hipLaunchKernelGGL((k_mtf_ranks_small<128, 128, kMtfSmallAlpha>), dim3((kMaxMtfChunks + 127) / 128, a.nb), dim3(128), 0, st, a);
-    else
-        hipLaunchKernelGGL(k_mtf_ranks, dim3(kChunkWGs, a.nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_mtf_ranks_small<128, 128, kMtfSmallAlpha>), dim3((kMaxMtfChunks + 127) / 128, a.nb), dim3(128), 0, st, a);
     if (a.fused_zle) {
         (void)hipMemsetAsync(a.zstate, 0, (size_t)a.nb * kTilesPerBlock * 16, st);
         (void)hipMemsetAsync(a.ztick, 0, 64, st);

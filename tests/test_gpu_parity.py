@@ -382,36 +382,6 @@ def test_radix_pass_flavours_agree(oracle):
             assert "stage redone with three kernels" in out.stderr
 
 
-def test_phase_b_in_lds_flavour(oracle):
-    """BZ_LOCAL_B=1: the second half of the initial sort is done segment by segment inside LDS (k_phase_b_local)
-    for the blocks that fit; blocks with a group of equal prefixes too long for a segment (the runs of "ab"
-    below), or with more than 128 symbols, take the global passes in the same batch.  Same streams."""
-    import subprocess
-    import sys
-    code = (
-        "import importlib,sys,hashlib;sys.path.insert(0,%r);pkg=importlib.import_module('rust-compression_amd');"
-        "import corpus;t=corpus.corpus_bytes(1<<21);"
-        "d=t[:1200000]+b'ab'*150000+t[1200000:1500000]+bytes(range(256))*300+t[1500000:];"
-        "print(hashlib.sha256(pkg.compress(d,9)).hexdigest(), hashlib.sha256(pkg.compress(d,2)).hexdigest())" % ROOT)
-    import corpus
-    t = corpus.corpus_bytes(1 << 21)
-    d = t[:1200000] + b"ab" * 150000 + t[1200000:1500000] + bytes(range(256)) * 300 + t[1500000:]
-    want = "%s %s" % (hashlib.sha256(oracle.encode(d, 9)).hexdigest(), hashlib.sha256(oracle.encode(d, 2)).hexdigest())
-    e = dict(os.environ)
-    e.update({"BZ_LOCAL_B": "1", "BZ_LOCAL_TRACE": "1"})
-    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
-    assert out.stdout.strip().splitlines()[-1] == want, (out.stdout, out.stderr[-800:])
-    lines = [ln for ln in out.stderr.splitlines() if "phase B in LDS" in ln]
-    assert lines, out.stderr[-800:]
-    import re
-    seen = [tuple(int(x) for x in re.search(r"(\d+) segments so far \((\d+) too long, (\d+) out of order", ln).groups())
-            for ln in lines]
-    assert seen[-1][0] > 0 and seen[-1][1] > 0 and seen[-1][2] == 0, seen  # segments sorted, some refused, none unstable
-    gated = [tuple(int(x) for x in re.search(r"(\d+) of (\d+) blocks", ln).groups()) for ln in lines]
-    assert any(0 < g < nb for g, nb in gated), gated  # a batch with both kinds of block
-
-
 def test_pass_counter_wraps(pkg, oracle):
     """one engine, enough sorts for the fused passes' epoch tag (1023 values) to wrap several times"""
     import torch
@@ -705,6 +675,32 @@ def test_fuzz_cases_of_round_6(pkg, oracle, name):
     for level in (1, 9):
         assert pkg.compress(d, level) == oracle.encode(d, level), (name, level)
     assert pkg.compress(d + d[:3], 1) == oracle.encode(d + d[:3], 1)
+
+
+def test_trace_switches_change_no_byte(oracle):
+    """BZ_BWT_TRACE / BZ_ENC_TRACE / BZ_DEC_TRACE / BZ_DF_TRACE print timelines on stderr (sort rounds, jobs, chunks, parts) and
+    must leave every stream as it is: one process with all four on, a deep-repeat input (so that the period and link
+    rounds print), the host pipeline, the decoder and the Deflate path against the oracle."""
+    import subprocess
+    import sys
+    code = """
+import sys, importlib, random
+sys.path.insert(0, %r)
+pkg = importlib.import_module("rust-compression_amd")
+from oracle import oracle
+rng = random.Random(9)
+unit = bytes(rng.randrange(40) for _ in range(30000))
+d = (unit * 3 + bytes(rng.randrange(200) for _ in range(5000)) + unit)[:120000]
+z = pkg.compress(d, 1)
+assert z == oracle.encode(d, 1)
+assert pkg.decompress(z) == (d, 0)
+assert pkg.deflate_compress(d, pkg.ZLIB) == oracle.deflate_encode(d, pkg.ZLIB)
+print("ok")
+""" % ROOT
+    env = dict(os.environ, BZ_BWT_TRACE="1", BZ_ENC_TRACE="1", BZ_DEC_TRACE="1", BZ_DF_TRACE="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-500:] + out.stderr[-3000:]
+    assert "sort round" in out.stderr and "bz_enc job" in out.stderr
 
 
 def test_period_round_in_mixed_batches(pkg, oracle):

@@ -68,6 +68,33 @@ def test_split_helpers():
     assert all(spans[i][1] == spans[i + 1][0] for i in range(2))
 
 
+def test_shard_skew_switch_moves_the_slab_edges():
+    """BZ_SHARD_SKEW (read once per process): 0 = equal slabs; a larger value hands the ranks in front more tiles (they wait
+    for nobody's cuts).  Whatever the value the slabs tile the input in rank order -- the bytes of a sharded stream do not
+    depend on it (tests/test_gpu_sharded.py compares them with the oracle's)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = """
+import sys, importlib
+sys.path.insert(0, %r)
+sharded = importlib.import_module("rust-compression_amd.sharded")
+n, world = 1 << 30, 8
+spans = [sharded.slab_tiles(n, r, world) for r in range(world)]
+assert spans[0][0] == 0 and spans[-1][1] == (n + 4095) // 4096
+assert all(spans[i][1] == spans[i + 1][0] and spans[i][0] < spans[i][1] for i in range(world - 1))
+print(" ".join(str(b - a) for a, b in spans))
+""" % ROOT
+    sizes = {}
+    for skew in ("0", "0.05"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BZ_SHARD_SKEW=skew), capture_output=True, text=True,
+                             timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        sizes[skew] = [int(x) for x in out.stdout.split()]
+    assert max(sizes["0"]) - min(sizes["0"]) <= 1
+    assert sizes["0.05"][0] > sizes["0.05"][-1] + 100 and sum(sizes["0.05"]) == sum(sizes["0"])
+
+
 def test_shard_comm_parameter_checks():
     import ctypes
     pkg = importlib.import_module("rust-compression_amd")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """First and later bz_encode_buffer calls of a fresh process on the 1 GiB corpus read from a file:
-tools/cold_time.py <file> [calls]; BZ_ENC_MAX_BLOCKS / BZ_ENC_CHUNK_MIB / BZ_ENC_TRACE steer the library."""
+tools/cold_time.py <file> [calls]; BZ_ENC_CHUNK_MIB / BZ_ENC_TRACE steer the library."""
 import ctypes, importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,4 +17,4 @@ for i in range(calls):
     ts.append(time.perf_counter() - t0)
     L.bz_free(outp)
     assert rc == 0
-print("BZ_ENC_MAX_BLOCKS=%s: calls (ms): %s" % (os.environ.get("BZ_ENC_MAX_BLOCKS"), " ".join("%.1f" % (t * 1e3) for t in ts)), flush=True)
+print("BZ_ENC_CHUNK_MIB=%s: calls (ms): %s" % (os.environ.get("BZ_ENC_CHUNK_MIB"), " ".join("%.1f" % (t * 1e3) for t in ts)), flush=True)
