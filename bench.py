@@ -181,6 +181,11 @@ def preflight(args, torch, dist, ctl, pkg, comm, rank, world, ndev, share, nativ
     import threading
     rec = {"backend": dist.get_backend(), "transport": "library RCCL" if native else "torch.distributed", "world": world,
            "devices_visible": ndev, "ranks_share_gpus": bool(share), "stage": "start"}
+    try:  # (what is linked: the version string a maintainer asks for first when a collective misbehaves)
+        rec["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception as e:  # noqa: BLE001
+        rec["rccl_version"] = "unknown (%r)" % (e,)
+    rec["hip_version"] = getattr(torch.version, "hip", None)
 
     def line(status):
         out = dict(config_stub)
@@ -226,6 +231,11 @@ def preflight(args, torch, dist, ctl, pkg, comm, rank, world, ndev, share, nativ
         except Exception as e:  # noqa: BLE001
             prc = -1
             mine["errors"].append(repr(e))
+        # hipDeviceCanAccessPeer for ALL pairs of the visible devices (a query: no context is made on the other devices)
+        try:
+            rec["peer_access_matrix"] = [[1 if (i == j or torch.cuda.can_device_access_peer(i, j)) else 0 for j in range(ndev)] for i in range(ndev)]
+        except Exception as e:  # noqa: BLE001
+            rec["peer_access_matrix"] = "unavailable (%r)" % (e,)
         rec["peer_copies"] = {"devices": devices, "status": prc, "peer_access": list(peer), "round_trip_ms": [round(x, 3) for x in ms],
                               "note": "devices[i] -> devices[i + 1 mod N] and back, 1 MiB; peer_access 1: direct (xGMI), 0: through "
                                       "the host, -1: both on one device"}
@@ -376,7 +386,12 @@ def main():
     bstats = eng.bwt_stats()
     nblocks_rank = len(eng.block_stats())
     eng.profile(False)
+    rank_ms = None
     if world > 1:
+        # every rank's own clock over the timed steps (a straggler GPU shows in the one line the driver keeps)
+        mine_t = [torch.zeros(1, dtype=torch.float64, device=wire) for _ in range(world)]
+        dist.all_gather(mine_t, torch.tensor([dt], dtype=torch.float64, device=wire))
+        rank_ms = [round(float(t.item()) / args.steps * 1e3, 3) for t in mine_t]
         tmax = torch.tensor([dt], dtype=torch.float64, device=wire)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = torch.tensor([float(nblocks_rank)], dtype=torch.float64, device=wire)
@@ -428,6 +443,7 @@ def main():
             "value": round(value, 2), "value_is": "hbm_resident", "value_hbm_resident": round(value, 2),
             "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "step_ms": step_stats(step_times),
+            "ms_per_step_of_every_rank": rank_ms,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/u32", "data": "synthetic",
             "config": {"workload": ("%d MiB synthetic repeating-text corpus (16 MiB Zipf chapters), level %d, "

@@ -206,6 +206,11 @@ def test_bench_two_ranks_line_is_self_sufficient():
     assert pre["status"] == "ok" and pre["world"] == 2 and pre["backend"] == "gloo"
     assert [r["rank"] for r in pre["ranks"]] == [0, 1]
     assert all(r["comm_count"] == 2 and r["selftest_status"] == 0 and r["errors"] == [] for r in pre["ranks"])
+    # round 6: what is linked, who can reach whom, and every rank's own clock in the one line
+    assert pre["rccl_version"] and pre["hip_version"]
+    m = pre["peer_access_matrix"]
+    assert len(m) == pre["devices_visible"] and all(len(row) == len(m) and row[i] == 1 for i, row in enumerate(m))
+    assert len(line["ms_per_step_of_every_rank"]) == 2 and max(line["ms_per_step_of_every_rank"]) == line["ms_per_step"]
     assert pre["peer_copies"]["status"] == 0 and pre["peer_copies"]["devices"] == [0, 0] and pre["peer_copies"]["peer_access"] == [-1, -1]
     assert line["shard_chain"]["chain_ms_per_link"] > 0 and len(line["shard_chain"]["links_ms"]) == 1
     assert line["end_to_end"]["calls_ms"]["n"] == 3 and line["end_to_end"]["phases_ms_of_the_median_call"]["jobs"] >= 1
