@@ -188,20 +188,15 @@ __device__ __forceinline__ bool per_ekey(const BwtArgs &a, u32 lb, const u8 *__r
 }
 
 // (round 6) SMALL groups of the survivor list -- 2 .. kLinkMax members -- are ranked member by member from direct comparisons
-// of their rotations (k_link_scan), whatever the distances between the copies.  Two byte arrays per block, one byte per
-// position of the compacted list, in the MTF stage's symbol buffer (free during the sort):
+// of their rotations (k_link_scan), whatever the distances between the copies.  A byte per position of the compacted list,
+// in the MTF stage's symbol buffer (free during the sort):
 //   group_bytes  place inside the group | members << 4 (k_survivor_compact; 0: not a member of a small group); k_link_finalize
 //                turns the byte of a member it has made final into 1 and every other one into 0
-//   link_bytes   comparisons with the other members that are decided << 4 | members found smaller (k_link_scan)
-constexpr u32 kLinkMax = 8; // the largest group ranked member by member (two nibbles per member: counts up to 7)
-static_assert(kLinkMax == 8 && kMtfStride >= kSlot + 8, "link_rank reads a group's eight link bytes with one load");
+//   (the verdicts of the pairs: a word per list entry in the round's free key array, k_link_scan -> k_link_finalize)
+constexpr u32 kLinkMax = 8; // the largest group ranked member by member (a result word holds 7 + 7 bits; members are read 4 + 4)
 __device__ __forceinline__ u8 *group_bytes(const BwtArgs &a, u32 lb)
 {
     return a.per_aux + (size_t)lb * kMtfStride * 2u;
-}
-__device__ __forceinline__ u8 *link_bytes(const BwtArgs &a, u32 lb)
-{
-    return a.per_aux + (size_t)lb * kMtfStride * 2u + kMtfStride;
 }
 
 // Batched form: the 16 rows of one lane.  All primary loads are issued back to back (clamped
@@ -2596,7 +2591,7 @@ __device__ __forceinline__ u64 link_load8(const u8 *__restrict__ text, u32 n, u3
 }
 
 __global__ __launch_bounds__(kSortThreads) void k_link_scan(BwtArgs a, u32 step, const u32 *__restrict__ VS, const u32 *__restrict__ midx,
-                                                             const u8 *__restrict__ impure)
+                                                             const u8 *__restrict__ impure, u32 *__restrict__ RES)
 {
     // what the last scan of this wave found, per partner slot: {distance, leader's start, first difference (absolute, not
     // wrapped), smaller start is the smaller rotation}.  The next row of 64 starts almost always lies inside the same
@@ -2646,17 +2641,19 @@ __global__ __launch_bounds__(kSortThreads) void k_link_scan(BwtArgs a, u32 step,
             mem[0] = m0.x; mem[1] = m0.y; mem[2] = m0.z; mem[3] = m0.w;
             mem[4] = m1.x; mem[5] = m1.y; mem[6] = m1.z; mem[7] = m1.w;
         }
-        // the other members, nearest in front first ... farthest behind last (by start): consecutive starts of a copied
-        // stretch meet the same distances in the same slots
-        u32 nothers = size ? size - 1u : 0u;
+        // the members that start BEHIND x, nearest first (a pair is compared by its member with the smaller start; the other one
+        // reads the verdict in k_link_finalize): consecutive starts of a copied stretch meet the same distances in the same slots
+        u32 nothers = 0;
 #pragma unroll
         for (u32 t = 0; t < kLinkMax; ++t) {
             u32 c = 0;
 #pragma unroll
-            for (u32 u = 0; u < kLinkMax; ++u) c += (u < size && mem[u] != x && mem[u] < mem[t]) ? 1u : 0u;
-            slot[t] = (t < size && mem[t] != x && mem[t] < n) ? c : 0xFFFFFFFFu;
+            for (u32 u = 0; u < kLinkMax; ++u) c += (u < size && mem[u] > x && mem[u] < mem[t]) ? 1u : 0u;
+            const bool behind = t < size && mem[t] > x && mem[t] < n;
+            slot[t] = behind ? c : 0xFFFFFFFFu;
+            nothers += behind ? 1u : 0u;
         }
-        u32 own = 0; // comparisons decided << 4 | members found smaller
+        u32 own = 0; // bit s: the comparison with the s-th member behind x is decided; bit 8 + s: rot(x) is the smaller one
 #pragma unroll 1
         for (u32 s = 0; s + 1u < kLinkMax; ++s) {
             const bool has = s < nothers;
@@ -2666,7 +2663,7 @@ __global__ __launch_bounds__(kSortThreads) void k_link_scan(BwtArgs a, u32 step,
 #pragma unroll
             for (u32 t = 0; t < kLinkMax; ++t)
                 if (slot[t] == s) y = mem[t];
-            const u32 dist = y >= x ? y - x : y + n - x; // (a partner in front: the distance the other way round the block)
+            const u32 dist = y - x;
             bool solved = false, lo_less = false;
             {
                 // inside the stretch the wave's last scan for this slot resolved?
@@ -2680,7 +2677,9 @@ __global__ __launch_bounds__(kSortThreads) void k_link_scan(BwtArgs a, u32 step,
             if (todo) {
                 // a look of its own for every lane first: sixteen bytes behind the depth reached.  Rows whose lanes all have
                 // partners somewhere else (text: short repeats all over the block) are no stretch of one copy, a scan by the
-                // whole wave resolves one lane of them; copies that agree for kilobytes pay two loads for nothing.
+                // whole wave resolves one lane of them; copies that agree for kilobytes pay four loads for nothing.  (Leaving
+                // the look out in rows whose neighbouring lanes lie the same distance from their partners was measured:
+                // 7.2 -> 8.3 ms per 256 MiB of the corpus "binary" -- at sixteen symbols many of ITS pairs end within the look.)
                 if (has && !solved && depth + 16u < n) {
                     u32 pa = x + depth, pb = y + depth;
                     pa = pa >= n ? pa - n : pa;
@@ -2748,42 +2747,42 @@ __global__ __launch_bounds__(kSortThreads) void k_link_scan(BwtArgs a, u32 step,
                 }
                 if (!found) todo &= ~grp; // (equal rotations: a periodic block -- k_periodic_place's case)
             }
-            if (solved && y != x) own += 0x10u + (lo_less ? 0u : 1u); // rot(x) > rot(y): one more member below x
+            if (solved && y != x) own |= (1u << s) | (lo_less ? (0x100u << s) : 0u);
         }
-        // (every member makes all its comparisons itself -- both members of a pair scan it, and the scans are shared along the
-        // stretch --, so its byte is a plain store: the first build had the smaller start add to its partner's byte, 375 M byte
-        // atomics per 256 MiB of the corpus "binary", 7.6 of the kernel's 11.5 ms)
-        if (size) link_bytes(a, lb)[idx] = (u8)own;
+        // (every member writes its word, decided or not: k_link_finalize reads the words of a whole group.  The first build had
+        // the smaller start add to its partner's byte -- 375 M byte atomics per 256 MiB of the corpus "binary", 7.6 of the
+        // kernel's 11.5 ms; the second had both members of a pair scan it: twice the partners per lane, 8.2 ms.)
+        if (size) RES[base + idx] = own;
     }
 }
 
-// the rank of list entry idx inside its small group when every member of the group has all its comparisons decided
-// (g0: the group's first place in the list, first: idx is that place)
-__device__ __forceinline__ bool link_rank(const u8 *__restrict__ gb8, const u8 *__restrict__ lk8, u32 idx, u32 cnt, u32 &g0, u32 &rank, bool &first)
+// A group all of whose pairs are decided is ORDERED, and its members are final at once: member x stands at the group's first
+// place in SA + the number of members below it.  What k_group_apply does for a rotation that becomes final is done right
+// here -- SA, the last column, origPtr, the rank word (a 4-byte store at random: they are a few per group, and the
+// rotations leave the list for good) -- and the entry's group byte becomes 1: the period round's passes and the link
+// round's compaction leave it out, so everything behind this kernel runs on what is LEFT (a third of the list on the corpus
+// "binary", where the passes, the flags and the apply kernel over the whole list were 14 of the round's 30 ms).
+// A member reads the group's members and their result words (k_link_scan: the verdict of a pair lies with its smaller
+// start, under the number of members between the two), counts the members below it and says whether ITS pairs are all
+// decided; the group is decided when every member says so -- a ballot when the group's entries lie in one row of 64 list
+// entries (all but one group in twenty), else every pair is looked at.
+// tile_nf[tile] = entries of the tile that stay (for k_link_compact).
+__device__ __forceinline__ bool link_pair(const u32 (&m)[kLinkMax], const u32 (&res)[kLinkMax], u32 size, u32 ai, u32 bi, bool &a_less)
 {
-    const u32 gb = gb8[idx];
-    const u32 size = gb >> 4, off = gb & 15u;
-    if (size < 2u || size > kLinkMax || off >= size || idx < off || idx - off + size > cnt) return false;
-    g0 = idx - off;
-    first = off == 0u;
-    u64 lw; // (the members' bytes lie side by side: one unaligned load; the array has 64 bytes of slack behind the slot)
-    __builtin_memcpy(&lw, lk8 + g0, 8);
-    bool all = true;
+    // the pair (m[ai], m[bi]): decided?  a_less: rot(m[ai]) < rot(m[bi])
+    const bool a_lo = m[ai] < m[bi];
+    const u32 lo = a_lo ? m[ai] : m[bi], hi = a_lo ? m[bi] : m[ai];
+    const u32 r = a_lo ? res[ai] : res[bi];
+    u32 sl = 0;
 #pragma unroll
-    for (u32 t = 0; t < kLinkMax; ++t)
-        if (t < size) all = all && (u32)((lw >> (8u * t + 4u)) & 15ull) == size - 1u;
-    rank = (u32)(lw >> (8u * off)) & 15u;
-    return all && rank < size;
+    for (u32 u = 0; u < kLinkMax; ++u) sl += (u < size && m[u] > lo && m[u] < hi) ? 1u : 0u;
+    const bool lo_less = (r >> (8u + sl)) & 1u;
+    a_less = a_lo ? lo_less : !lo_less;
+    return (r >> sl) & 1u;
 }
 
-// A group all of whose members have all their comparisons decided is ORDERED, and its members are final at once: member x
-// stands at the group's first place in SA + its rank.  What k_group_apply does for a rotation that becomes final is done
-// right here -- SA, the last column, origPtr, the rank word (a 4-byte store at random: they are a few per group, and the
-// rotations leave the list for good) -- and the entry's group byte becomes 1: the period round's passes and the link round's
-// compaction leave it out, so everything behind this kernel runs on what is LEFT (a third of the list on the corpus
-// "binary", where the passes, the flags and the apply kernel over the whole list were 14 of the round's 30 ms).
-// tile_nf[tile] = entries of the tile that stay (for k_link_compact).
-__global__ __launch_bounds__(kSortThreads) void k_link_finalize(BwtArgs a, const u32 *__restrict__ VS, const u8 *__restrict__ impure)
+__global__ __launch_bounds__(kSortThreads) void k_link_finalize(BwtArgs a, const u32 *__restrict__ VS, const u8 *__restrict__ impure,
+                                                                 const u32 *__restrict__ RES)
 {
     __shared__ u32 s_stay;
     u32 tile, lb;
@@ -2804,20 +2803,81 @@ __global__ __launch_bounds__(kSortThreads) void k_link_finalize(BwtArgs a, const
     const u32 n = d.n;
     const u8 *__restrict__ text = a.rle + d.rle_off;
     u8 *gb8 = group_bytes(a, lb);
-    const u8 *lk8 = link_bytes(a, lb);
+    const u32 l = threadIdx.x & 63u;
     u32 stay = 0;
-    for (u32 idx = start + threadIdx.x; idx < cnt && idx < start + kSortTile; idx += kSortThreads) {
-        u32 g0 = 0, rank = 0;
-        bool first = false;
-        const bool ranked = link_rank(gb8, lk8, idx, cnt, g0, rank, first);
+    // (the trips of the loop are uniform for the workgroup -- the ballots below need every lane of a wave)
+    for (u32 i0 = start; i0 < start + kSortTile && i0 < cnt; i0 += kSortThreads) {
+        const u32 idx = i0 + threadIdx.x;
+        const bool live = idx < cnt;
+        const u32 gb = live ? gb8[idx] : 0u;
+        u32 size = gb >> 4;
+        const u32 off = gb & 15u;
+        if (size < 2u || size > kLinkMax || off >= size || idx < off || idx - off + size > cnt) size = 0;
+        const u32 g0 = idx - off;
+        u32 m[kLinkMax], res[kLinkMax];
+        {
+            uint4 m0 = make_uint4(0, 0, 0, 0), m1 = make_uint4(0, 0, 0, 0), r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0, 0);
+            if (size) {
+                __builtin_memcpy(&m0, VS + base + g0, 16);
+                __builtin_memcpy(&r0, RES + base + g0, 16);
+            }
+            if (size > 4u) {
+                __builtin_memcpy(&m1, VS + base + g0 + 4u, 16);
+                __builtin_memcpy(&r1, RES + base + g0 + 4u, 16);
+            }
+            m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
+            res[0] = r0.x; res[1] = r0.y; res[2] = r0.z; res[3] = r0.w; res[4] = r1.x; res[5] = r1.y; res[6] = r1.z; res[7] = r1.w;
+        }
+        // this member's pairs
+        u32 x = 0;
+#pragma unroll
+        for (u32 t = 0; t < kLinkMax; ++t) x = t == off ? m[t] : x;
+        u32 rmine = 0;
+#pragma unroll
+        for (u32 t = 0; t < kLinkMax; ++t) rmine = t == off ? res[t] : rmine;
+        bool own_ok = size != 0u;
+        u32 rank = 0;
+#pragma unroll
+        for (u32 t = 0; t < kLinkMax; ++t) {
+            if (t >= size || m[t] == x) continue;
+            // (the pair (x, m[t]) through link_pair's arithmetic, with x's own word at hand)
+            const bool x_lo = x < m[t];
+            const u32 lo = x_lo ? x : m[t], hi = x_lo ? m[t] : x;
+            const u32 r = x_lo ? rmine : res[t];
+            u32 sl = 0;
+#pragma unroll
+            for (u32 u = 0; u < kLinkMax; ++u) sl += (u < size && m[u] > lo && m[u] < hi) ? 1u : 0u;
+            const bool lo_less = (r >> (8u + sl)) & 1u;
+            own_ok = own_ok && ((r >> sl) & 1u);
+            rank += (x_lo ? !lo_less : lo_less) ? 1u : 0u; // the other member is the smaller rotation
+        }
+        // the group: every member's pairs decided
+        bool ranked;
+        {
+            const u64 okm = __ballot(own_ok);
+            const bool in_row = size != 0u && off <= l && l - off + size <= 64u;
+            const u64 want = (size >= 64u ? ~0ull : ((1ull << size) - 1ull)) << (in_row ? l - off : 0u);
+            ranked = in_row && (okm & want) == want;
+            if (size != 0u && !in_row && own_ok) { // (the group lies across two rows: every pair)
+                bool all = true;
+#pragma unroll
+                for (u32 p = 0; p < kLinkMax; ++p)
+#pragma unroll
+                    for (u32 q = p + 1u; q < kLinkMax; ++q) {
+                        if (q >= size) continue;
+                        bool dummy;
+                        all = all && link_pair(m, res, size, p, q, dummy);
+                    }
+                ranked = all;
+            }
+        }
         // (the group's first place in SA is the rank of any of its members: the entry that stands first in the list looks it up,
         // the others take it from that lane when it belongs to the same wave)
-        const u32 x = VS[base + idx];
-        const u32 off = idx - g0;
-        const bool same_wave = ranked && off <= (threadIdx.x & 63u);
-        u32 head = (ranked && !same_wave) || (ranked && first) ? (a.R[base + x] & ~kFinalBit) : 0u;
+        const bool first = off == 0u;
+        const bool same_wave = ranked && off <= l;
+        u32 head = (ranked && (!same_wave || first)) ? (a.R[base + x] & ~kFinalBit) : 0u;
         {
-            const u32 from = __shfl(head, (int)((threadIdx.x & 63u) - (same_wave ? off : 0u)), 64);
+            const u32 from = __shfl(head, (int)(l - (same_wave ? off : 0u)), 64);
             if (same_wave && !first) head = from;
         }
         if (ranked) {
@@ -2826,13 +2886,13 @@ __global__ __launch_bounds__(kSortThreads) void k_link_finalize(BwtArgs a, const
             a.L[base + pos] = text[x ? x - 1u : n - 1u];
             if (x == 0) a.orig_ptr[lb] = pos;
             a.R[base + x] = pos | kFinalBit;
-        } else {
+        } else if (live) {
             stay += 1;
         }
-        gb8[idx] = ranked ? (u8)1 : (u8)0; // (each entry reads its own group byte only: nobody else's read is disturbed)
+        if (live) gb8[idx] = ranked ? (u8)1 : (u8)0; // (each entry reads its own group byte only: nobody else's read is disturbed)
     }
     stay = wave_sum(stay);
-    if ((threadIdx.x & 63u) == 0 && stay) atomicAdd(&s_stay, stay);
+    if (l == 0 && stay) atomicAdd(&s_stay, stay);
     __syncthreads();
     if (threadIdx.x == 0) a.tile_nf[lb * kTilesPerBlock + tile] = s_stay;
 }
@@ -3483,8 +3543,9 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             if (links) (void)hipMemsetAsync(midx, 0, (size_t)a.nb * kSlot * sizeof(u32), st); // (0: the start is no member of a small group)
             hipLaunchKernelGGL(k_survivor_compact, grid_prev, dim3(kSortThreads), 0, st, a, lastV, fV, links ? midx : nullptr, per_round ? 1u : 0u);
             hipLaunchKernelGGL(k_copy_counts, dim3((a.nb + 255) / 256), dim3(256), 0, st, a.count, a.count2, a.nb);
-            if (links) hipLaunchKernelGGL(k_link_scan, grid, dim3(kSortThreads), 0, st, a, step, fV, midx, impure);
-            if (links) hipLaunchKernelGGL(k_link_finalize, grid_list, dim3(kSortThreads), 0, st, a, fV, impure);
+            // (the pairs' verdicts: a word per list entry in the free key array, which nothing else touches before the passes)
+            if (links) hipLaunchKernelGGL(k_link_scan, grid, dim3(kSortThreads), 0, st, a, step, fV, midx, impure, fK);
+            if (links) hipLaunchKernelGGL(k_link_finalize, grid_list, dim3(kSortThreads), 0, st, a, fV, impure, fK);
             if (link_round) {
                 // no tables, no passes: what the ranked groups leave behind, in list order (count2: the whole list, count: the rest)
                 (void)hipMemsetAsync(a.lin_p, 0, (size_t)a.nb * kPerK * 4, st);
