@@ -158,6 +158,17 @@ def roofline_of(kprof, names, pmc):
             "algorithmic_bytes_per_launch": d["bytes"] // d["launches"]}
 
 
+def kernel_sources_sha16():
+    """SHA-256 (16 hex digits) of the kernel sources -- what tools/summarize_prof.py stores beside the PMC traffic it condenses."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    hh = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(here, "rust-compression_amd", "csrc", "k_*.hip")) + [os.path.join(here, "rust-compression_amd", "csrc", "bzgpu.h")]):
+        with open(fn, "rb") as f:
+            hh.update(f.read())
+    return hh.hexdigest()[:16]
+
+
 def load_json(*path):
     p = os.path.join(ROOT, *path)
     try:
@@ -437,6 +448,8 @@ def main():
         if "__total_bytes_per_step" in pmc:
             roofline["hbm_traffic_bytes_per_input_byte"] = round(pmc["__total_bytes_per_step"] / pmc["__input_bytes"], 1)
             roofline["hbm_traffic_source"] = pmc.get("__source")
+            # (the counters are a committed file, not a measurement of this run: say whether it belongs to the kernels that ran)
+            roofline["hbm_traffic_is_of_these_kernels"] = bool(pmc.get("__kernel_sources_sha16") == kernel_sources_sha16())
         result = {
             "metric": "BZip2 level-%d encode MB/s (input bytes, HBM-resident in and out: the kernels' rate; value_end_to_end is "
                       "host buffer to host buffer at the C ABI)" % args.level,

@@ -69,6 +69,13 @@ if pmc:
     total = sum(d["FETCH_SIZE_KiB_x2"] + d["WRITE_SIZE_KiB"] for k, d in pmc.items() if k.startswith("k_")) * 1024
     traffic["__total_bytes_per_step"] = int(total)
     traffic["__source"] = tag + "_pmc.json"
+    # the kernel sources the counters belong to (run this right behind the profile, on the tree that was profiled):
+    # bench.py compares it with the tree it runs on and says in its line whether the committed traffic is that of its kernels
+    import hashlib
+    hh = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(root, "rust-compression_amd", "csrc", "k_*.hip")) + [os.path.join(root, "rust-compression_amd", "csrc", "bzgpu.h")]):
+        hh.update(open(fn, "rb").read())
+    traffic["__kernel_sources_sha16"] = hh.hexdigest()[:16]
     for f in ("bench_fetch.json",):
         pth = os.path.join(src, f)
         try:
