@@ -368,7 +368,8 @@ int bz_gpu_last_bwt_rounds(bz_gpu_engine *g, uint64_t out[64]);
 /* Per-kernel timing of the BWT kernels (HIP events around every launch, on the engine's
  * stream).  Enable, run encodes, then read: kernel name (all template instances of one
  * kernel are pooled), launches, summed duration, summed ALGORITHMIC bytes.
- * bz_gpu_profile_enable also clears the counters. */
+ * bz_gpu_profile_enable also clears the counters.  `on`: bit 0 the kernel timing, bit 1 the per-pass figures of
+ * bz_gpu_debug_block_sections (a few ballots per group in the Huffman sweeps: off by default). */
 int bz_gpu_profile_enable(bz_gpu_engine *g, int on);
 int bz_gpu_profile_kernels(bz_gpu_engine *g);
 int bz_gpu_profile_get(bz_gpu_engine *g, int idx, const char **name, uint64_t *launches,
@@ -388,6 +389,15 @@ int bz_gpu_debug_code_lengths(bz_gpu_engine *g, const uint32_t *h_freq, size_t a
  * nblock, crc, origPtr, mtf_count, in_use_count, group_num, n_selectors, max_len */
 int bz_gpu_debug_block_stats(bz_gpu_engine *g, uint32_t *h_stats, size_t cap_blocks,
                              size_t *n_blocks);
+/* ... and the figures behind the other two debug lines of write_blockdata
+ * (src/bzip2/encoder.rs:483-498 "pass k: size is .., grp uses are ..", :556-636
+ * "bits: mapping .., selectors .., code lengths .., codes .."): 32 x uint32 per
+ * block: [0..3] totc / 8 of the four refinement passes, [4 + 6 k + t] groups that
+ * chose table t in pass k, [28] bits of the mapping table, [29] of the
+ * selectors, [30] of the code lengths, [31] of the symbols.  The per-pass
+ * figures need bz_gpu_profile_enable(g, 2) in force during the encode (else 0). */
+int bz_gpu_debug_block_sections(bz_gpu_engine *g, uint32_t *h_sections, size_t cap_blocks,
+                                size_t *n_blocks);
 
 /* ========================================================================
  * 3. Decoder  ==  `BZip2Decoder`  (src/bzip2/decoder.rs:583-612; the work is

@@ -593,6 +593,10 @@ typedef struct {
     uint32_t nblock, block_crc, orig_ptr, mtf_count, in_use_count, group_num, n_selectors;
     uint32_t max_len, lm_tables; /* lm_tables: how many tables took gen_code_lm */
     uint64_t bits;
+    /* the figures of the two other debug lines of write_blockdata: "pass k: size is {totc / 8}, grp uses are {fave}"
+       (encoder.rs:483-498) and "bits: mapping .., selectors .., code lengths .., codes .." (:556-636) */
+    uint32_t pass_size[4], fave[4][6];
+    uint32_t bits_mapping, bits_selectors, bits_lengths, bits_codes;
 } bzo_block_stats;
 
 typedef struct {
@@ -769,6 +773,7 @@ static int write_blockdata(bzo_enc *e, bzo_block_stats *st)
         memset(rfreq, 0, sizeof(rfreq));
         n_selectors = 0;
         size_t gs = 0;
+        uint32_t totc = 0, fave[6] = {0, 0, 0, 0, 0, 0}; /* :435-438 */
         while (gs < mtf_count) {
             size_t ge = gs + BZ_G_SIZE < mtf_count ? gs + BZ_G_SIZE : mtf_count;
             /* len.iter().rev().map(cost).enumerate().min_by(): first minimum wins */
@@ -782,8 +787,14 @@ static int write_blockdata(bzo_enc *e, bzo_block_stats *st)
             }
             selector[n_selectors] = (uint8_t)bt;
             n_selectors += 1;
+            totc += bc;    /* :469 */
+            fave[bt] += 1; /* :470 */
             for (size_t i = gs; i < ge; i++) rfreq[bt][e->mtf_buffer[i]] += 1;
             gs = ge;
+        }
+        if (st) { /* the debug line :483-498 */
+            st->pass_size[iter] = totc / 8;
+            for (size_t t = 0; t < 6; t++) st->fave[iter][t] = fave[t];
         }
         /* len = rfreq.iter().rev().map(create_huffman), :504-508 */
         for (size_t k = 0; k < group_num; k++)
@@ -802,6 +813,7 @@ static int write_blockdata(bzo_enc *e, bzo_block_stats *st)
         bzo_canonical_codes(len[group_num - 1 - t], alpha_size, code[t]);
 
     /* mapping table, :527-565 */
+    const uint64_t z_map = e->num_z; /* :532 */
     {
         uint16_t in_use16 = 0;
         for (size_t i = 0; i < 16; i++) {
@@ -817,6 +829,7 @@ static int write_blockdata(bzo_enc *e, bzo_block_stats *st)
     }
 
     /* selectors, :567-574 */
+    const uint64_t z_sel = e->num_z; /* :568 */
     enc_write(e, (uint32_t)group_num, 3);
     enc_write(e, (uint32_t)n_selectors, 15);
     for (size_t i = 0; i < n_selectors; i++) {
@@ -826,6 +839,7 @@ static int write_blockdata(bzo_enc *e, bzo_block_stats *st)
     free(selector_mtf);
 
     /* coding tables, :583-601 */
+    const uint64_t z_len = e->num_z; /* :584 */
     uint32_t max_len = 0;
     for (size_t t = 0; t < group_num; t++) {
         const uint8_t *l = len[group_num - 1 - t];
@@ -841,6 +855,7 @@ static int write_blockdata(bzo_enc *e, bzo_block_stats *st)
     }
 
     /* block data, :609-629 */
+    const uint64_t z_cod = e->num_z; /* :610 */
     {
         size_t sel_ctr = 0, gs = 0;
         while (gs < mtf_count) {
@@ -862,6 +877,10 @@ static int write_blockdata(bzo_enc *e, bzo_block_stats *st)
         st->group_num = (uint32_t)group_num;
         st->n_selectors = (uint32_t)n_selectors;
         st->max_len = max_len;
+        st->bits_mapping = (uint32_t)(z_sel - z_map);
+        st->bits_selectors = (uint32_t)(z_len - z_sel);
+        st->bits_lengths = (uint32_t)(z_cod - z_len);
+        st->bits_codes = (uint32_t)(e->num_z - z_cod);
     }
     return 0;
 }

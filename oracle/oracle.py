@@ -19,10 +19,15 @@ class BlockStats(C.Structure):
         ("mtf_count", C.c_uint32), ("in_use_count", C.c_uint32), ("group_num", C.c_uint32),
         ("n_selectors", C.c_uint32), ("max_len", C.c_uint32), ("lm_tables", C.c_uint32),
         ("bits", C.c_uint64),
+        ("pass_size", C.c_uint32 * 4), ("fave", (C.c_uint32 * 6) * 4),
+        ("bits_mapping", C.c_uint32), ("bits_selectors", C.c_uint32), ("bits_lengths", C.c_uint32), ("bits_codes", C.c_uint32),
     ]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["pass_size"] = list(self.pass_size)
+        d["fave"] = [list(row) for row in self.fave]
+        return d
 
 
 PULL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)

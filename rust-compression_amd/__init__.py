@@ -86,7 +86,7 @@ EXPORTS = [
     "bz_gpu_partition_slab_finish", "bz_gpu_block_count", "bz_gpu_encode_blocks", "bz_gpu_assemble", "bz_gpu_encode_sharded",
     "bz_shard_comm_selftest", "bz_gpu_last_timings", "bz_shard_halo_bytes", "bz_shard_window", "bz_shard_slab_tiles", "bz_gpu_encode_sharded_window", "bz_gpu_last_shard_timings", "bz_gpu_last_shard_phases",
     "bz_gpu_last_bwt_stats", "bz_gpu_cut_stats", "bz_gpu_last_bwt_rounds", "bz_gpu_profile_enable", "bz_gpu_profile_kernels", "bz_gpu_profile_get",
-    "bz_gpu_debug_bwt", "bz_gpu_debug_code_lengths", "bz_gpu_debug_block_stats",
+    "bz_gpu_debug_bwt", "bz_gpu_debug_code_lengths", "bz_gpu_debug_block_stats", "bz_gpu_debug_block_sections",
     "bz_gpu_decode_device", "bz_gpu_decode_device_sharded", "bz_gpu_last_decode_timings", "bz_gpu_last_decode_stats", "bz_decode_buffer",
     "bz_dec_create", "bz_dec_write", "bz_dec_end", "bz_dec_read", "bz_dec_pending", "bz_dec_destroy",
     "df_encode_bound", "df_gpu_encode_device", "df_gpu_last_timings", "df_gpu_last_stats", "df_gpu_debug_codes",
@@ -193,6 +193,7 @@ def lib():
     L.bz_gpu_debug_bwt.argtypes = [vp, C.c_char_p, sz, u32p]
     L.bz_gpu_debug_code_lengths.argtypes = [vp, u32p, sz, u8p, C.POINTER(C.c_int)]
     L.bz_gpu_debug_block_stats.argtypes = [vp, u32p, sz, szp]
+    L.bz_gpu_debug_block_sections.argtypes = [vp, u32p, sz, szp]
     L.bz_gpu_decode_device.argtypes = [vp, vp, sz, vp, sz, szp]
     L.bz_gpu_decode_device_sharded.argtypes = [vp, vp, sz, vp, sz, C.c_int, C.c_int, ALLGATHER_FN, vp, szp, szp, szp]
     L.bz_gpu_last_decode_timings.argtypes = [vp, C.POINTER(C.c_double)]
@@ -955,6 +956,20 @@ class GpuEngine:
             d["max_len"] = buf[i * 8 + 7] & 0xFFFF
             d["lm_tables"] = buf[i * 8 + 7] >> 16
             out.append(d)
+        return out
+
+    def block_sections(self):
+        """Per block of the last encode: the figures of the reference's debug lines "pass k: size is .., grp uses are .." and
+        "bits: mapping .., selectors .., code lengths .., codes .." (src/bzip2/encoder.rs:483-498, :556-636)."""
+        n = C.c_size_t(0)
+        _check(lib().bz_gpu_debug_block_sections(self._h, None, 0, C.byref(n)))
+        buf = (C.c_uint32 * (32 * max(n.value, 1)))()
+        _check(lib().bz_gpu_debug_block_sections(self._h, buf, n.value, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            w = buf[i * 32:(i + 1) * 32]
+            out.append({"pass_size": list(w[0:4]), "fave": [list(w[4 + 6 * k:10 + 6 * k]) for k in range(4)],
+                        "bits_mapping": w[28], "bits_selectors": w[29], "bits_lengths": w[30], "bits_codes": w[31]})
         return out
 
     # stage probes

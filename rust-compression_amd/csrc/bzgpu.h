@@ -72,7 +72,7 @@ struct BlockOut {
     u32 max_len;
     u32 lm_tables;
     u32 header_bits;
-    u32 pad;
+    u32 pad;       // (k_huff_header) 16-byte ranges of the byte map in use | bits of the selectors' unary codes << 5
     u64 total_bits;
 };
 
@@ -412,6 +412,7 @@ struct HuffArgs {
     unsigned long long *pack; // [nb][kMaxAlpha] the same as 6 x 10 bits per symbol
     u32 *rfreq;            // [nb][6][kMaxAlpha] symbol counts per selected table of the sweep under way
     u32 *hlm;              // [nb] tables that took the length-limited path
+    u32 *pass_stats;       // [nb][4][8] per refinement pass: the groups' cost under their chosen tables (totc), groups per table (fave[6])
     u32 *stream;           // [nb][kStreamWords]  block bit string, logical MSB-first words
     BlockOut *out;         // [nb]
     u32 *error_flag;       // [1]

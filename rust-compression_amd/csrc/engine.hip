@@ -120,6 +120,7 @@ static int ensure_workspace(bz_gpu_engine *g, size_t need_blocks)
     ENS(hpack, nb * (size_t)kMaxAlpha * 8);
     ENS(hrfreq, nb * (size_t)6 * kMaxAlpha * 4);
     ENS(hlm, nb * 4);
+    ENS(hpass, nb * (size_t)32 * 4);
     ENS(stream, nb * (size_t)kStreamWords * 4);
     ENS(error_flag, 4);
     ENS(packlist, nb * sizeof(PackBlock));
@@ -215,7 +216,7 @@ extern "C" void bz_gpu_engine_destroy(bz_gpu_engine *g)
                      &g->R, &g->KA, &g->VA, &g->KB, &g->VB, &g->tile_hist, &g->count, &g->flags, &g->tlo, &g->tln,
                      &g->nonfinal, &g->active, &g->per_k, &g->per_shift, &g->lin_p, &g->lin_sig, &g->bin_cursor, &g->pb_gate, &g->newbits, &g->bin_base, &g->sym_code, &g->keyinfo, &g->count2, &g->tile_nf, &g->L, &g->orig_ptr, &g->inuse_bits,
                      &g->summ, &g->summ_len, &g->init_state, &g->rank8, &g->ztile_last, &g->ztile_cnt, &g->mtf,
-                     &g->mtf_freq, &g->bout, &g->selector, &g->code_len, &g->group_bitoff, &g->lm_scratch, &g->hglen, &g->hpack, &g->hrfreq, &g->hlm,
+                     &g->mtf_freq, &g->bout, &g->selector, &g->code_len, &g->group_bitoff, &g->lm_scratch, &g->hglen, &g->hpack, &g->hrfreq, &g->hlm, &g->hpass,
                      &g->stream, &g->error_flag, &g->packlist, &g->packed, &g->gathered, &g->asmlist, &g->gh_tiles, &g->gbase, &g->tile_state,
                      &g->tickets, &g->vstream, &g->vout, &g->vseg, &g->vmis};
     for (DevBuf *b : all) b->release();
@@ -761,6 +762,7 @@ static HuffArgs make_huff_args(bz_gpu_engine *g, u32 nb, u32 o)
     ha.pack = g->hpack.as<unsigned long long>() + (size_t)o * kMaxAlpha;
     ha.rfreq = g->hrfreq.as<u32>() + (size_t)o * 6 * kMaxAlpha;
     ha.hlm = g->hlm.as<u32>() + o;
+    ha.pass_stats = g->debug_figures ? g->hpass.as<u32>() + (size_t)o * 32 : nullptr; // (armed by bz_gpu_profile_enable(g, 2))
     ha.stream = g->stream.as<u32>() + (size_t)o * kStreamWords;
     ha.out = g->bout.as<BlockOut>() + o;
     ha.error_flag = g->error_flag.as<u32>();
@@ -906,6 +908,7 @@ static int encode_blocks_once(bz_gpu_engine *g, const std::vector<size_t> &mine,
     if (words_used) *words_used = 0;
     g->h_out.clear();
     g->h_out_nblock.clear();
+    g->h_out_pass.clear();
     int rc = ensure_workspace(g, mine.size());
     if (rc != BZ_OK) return rc;
     HIPCHK(hipMemsetAsync(g->error_flag.p, 0, 4, g->st));
@@ -931,7 +934,10 @@ static int encode_blocks_once(bz_gpu_engine *g, const std::vector<size_t> &mine,
         if (rc != BZ_OK) return rc;
         outs.resize(nb);
         u32 err = 0;
+        const size_t pass0 = g->h_out_pass.size();
+        g->h_out_pass.resize(pass0 + (size_t)nb * 32);
         HIPCHK(hipMemcpyAsync(outs.data(), g->bout.p, nb * sizeof(BlockOut), hipMemcpyDeviceToHost, g->st));
+        if (g->debug_figures) HIPCHK(hipMemcpyAsync(g->h_out_pass.data() + pass0, g->hpass.p, (size_t)nb * 32 * 4, hipMemcpyDeviceToHost, g->st));
         HIPCHK(hipMemcpyAsync(&err, g->error_flag.p, 4, hipMemcpyDeviceToHost, g->st));
         HIPCHK(hipStreamSynchronize(g->st));
         HIPCHK(hipGetLastError());
@@ -1060,6 +1066,7 @@ extern "C" int bz_gpu_encode_blocks(bz_gpu_engine *g, size_t first, size_t strid
     if (mine.empty()) {
         g->h_out.clear();
         g->h_out_nblock.clear();
+        g->h_out_pass.clear();
         return BZ_OK;
     }
     int rc = encode_blocks_once(g, mine, d_packed, cap_words, h_word_off, h_bit_len, h_crc, words_used);
@@ -1617,6 +1624,36 @@ extern "C" int bz_gpu_debug_block_stats(bz_gpu_engine *g, uint32_t *h_stats, siz
     return BZ_OK;
 }
 
+// The figures behind the reference's other two log::debug! lines of write_blockdata (src/bzip2/encoder.rs:483-498 "pass k: size
+// is .., grp uses are ..", :556-636 "bits: mapping .., selectors .., code lengths .., codes ..") for every block of the last
+// encode: 32 words per block -- [0..3] totc / 8 of the four refinement passes, [4 + 6 k + t] groups that chose table t in
+// pass k (fave), [28] bits of the mapping table, [29] of the selectors (3 + 15 + their unary codes), [30] of the code
+// lengths, [31] of the block's symbols.  The per-pass figures are collected only while bz_gpu_profile_enable(g, 2) is in force
+// (0.1 ms per GiB in k_huff_sweep and a copy per batch; off: they read 0) and not by the BZ_HUFF_SPLIT=0 flavour.
+extern "C" int bz_gpu_debug_block_sections(bz_gpu_engine *g, uint32_t *h_sections, size_t cap_blocks, size_t *n_blocks)
+{
+    if (!g) return BZ_E_PARAM;
+    const size_t nb = g->h_out.size();
+    if (n_blocks) *n_blocks = nb;
+    if (g->h_out_pass.size() < nb * 32) return nb ? BZ_E_UNEXPECTED : BZ_OK;
+    for (size_t i = 0; i < nb && i < cap_blocks; ++i) {
+        const BlockOut &o = g->h_out[i];
+        const uint32_t *ps = g->h_out_pass.data() + i * 32;
+        uint32_t *s = h_sections + i * 32;
+        for (int k = 0; k < 4; ++k) {
+            s[k] = ps[k * 8] / 8u;
+            for (int t = 0; t < 6; ++t) s[4 + 6 * k + t] = ps[k * 8 + 1 + t];
+        }
+        const uint32_t used_ranges = o.pad & 31u, sel_total = o.pad >> 5;
+        const uint32_t mapping = 16u + 16u * used_ranges, selectors = 3u + 15u + sel_total;
+        s[28] = mapping;
+        s[29] = selectors;
+        s[30] = o.header_bits - (48u + 32u + 1u + 24u) - mapping - selectors;
+        s[31] = (uint32_t)(o.total_bits - o.header_bits);
+    }
+    return BZ_OK;
+}
+
 extern "C" int bz_gpu_debug_bwt(bz_gpu_engine *g, const uint8_t *h_block, size_t n, uint32_t *h_sa)
 {
     if (!g || n == 0 || n > kMaxBlockLen) return BZ_E_PARAM;
@@ -1679,7 +1716,8 @@ extern "C" int bz_gpu_profile_enable(bz_gpu_engine *g, int on)
 {
     if (!g) return BZ_E_PARAM;
     g->prof.reset();
-    g->prof.on = on != 0;
+    g->prof.on = (on & 1) != 0;
+    g->debug_figures = (on & 2) != 0; // (the per-pass figures of bz_gpu_debug_block_sections: a few ballots per group in k_huff_sweep)
     return BZ_OK;
 }
 

@@ -85,7 +85,7 @@ struct bz_gpu_engine {
     // batch workspace (sized by max_blocks)
     DevBuf lblocks, lcrc, SA, R, KA, VA, KB, VB, tile_hist, count, flags, tlo, tln, nonfinal, active, per_k,
         per_shift, lin_p, lin_sig, bin_cursor, pb_gate, bin_base, newbits, sym_code, keyinfo, count2, tile_nf, L, orig_ptr, inuse_bits, summ, summ_len, init_state, rank8, ztile_last, ztile_cnt, zstate, ztick, mtf,
-        mtf_freq, bout, selector, code_len, group_bitoff, lm_scratch, hglen, hpack, hrfreq, hlm, stream, error_flag, packlist, gh_tiles, gbase,
+        mtf_freq, bout, selector, code_len, group_bitoff, lm_scratch, hglen, hpack, hrfreq, hlm, hpass, stream, error_flag, packlist, gh_tiles, gbase,
         tile_state, tickets;
     u32 sort_epoch = 0; // fused radix passes: tag of the current pass in tile_state / tickets
     bool zle_fused_broken = false; // the one-launch ZLE stage misbehaved on this engine once: it stays on the three kernels
@@ -98,6 +98,7 @@ struct bz_gpu_engine {
     // results of the last encode
     std::vector<BlockOut> h_out;
     std::vector<u32> h_out_nblock;
+    std::vector<u32> h_out_pass; // 32 words per block: k_huff_sweep's per-pass figures (bz_gpu_debug_block_sections)
     double t_stage[6] = {0, 0, 0, 0, 0, 0};
     KernelProf prof;
     // last bz_gpu_encode_sharded: wait for the hop, hop -> hand-on, gather, assembly; entry -> ready for the hop (scan,
@@ -116,6 +117,7 @@ struct bz_gpu_engine {
     // self-check (bz_gpu_engine_set_verify / BZ_VERIFY=1): the blocks of every bz_gpu_encode_blocks call are decoded on
     // the device and compared with the input they cover before the call returns
     bool verify = false;
+    bool debug_figures = false; // bz_gpu_profile_enable(g, 2 | ..): k_huff_sweep sums the per-pass figures of bz_gpu_debug_block_sections
     u64 verify_stats[4] = {0, 0, 0, 0}; // since creation: blocks checked, calls redone, redone calls that failed again, ns
     DevBuf vstream, vout, vseg, vmis;
     DecWorkspace *dec = nullptr; // decode workspace, created by the first decode call

@@ -828,6 +828,7 @@ __global__ __launch_bounds__(kHuffThreads, 4) void k_huffman(HuffArgs a) // (4 w
     }
     if (tid == 0) {
         bo.header_bits = hb;
+        bo.pad = used_ranges | (sel_total << 5); // (the sections of the header: bz_gpu_debug_block_sections)
         bo.total_bits = (u64)hb + payload_bits;
         bo.group_num = group_num;
         bo.n_selectors = n_selectors;
@@ -1224,9 +1225,12 @@ __global__ __launch_bounds__(kTabThreads) void k_huff_tables(HuffArgs a, u32 ite
     if (tid == 0 && s_lmcount) a.hlm[lb] += s_lmcount;
 }
 
-__global__ __launch_bounds__(kSweepThreads) void k_huff_sweep(HuffArgs a)
+// iter: the refinement pass (0 .. 3); its totc and fave (encoder.rs:435-470, the figures of the reference's
+// log::debug! line :483-498) are summed into a.pass_stats for bz_gpu_debug_block_sections
+__global__ __launch_bounds__(kSweepThreads) void k_huff_sweep(HuffArgs a, u32 iter)
 {
     __shared__ unsigned long long s_pack[kMaxAlpha];
+    __shared__ u32 s_pass[8];
     __shared__ u32 s_rfreq[6][kMaxAlpha];
     __shared__ u32 s_sym[kSweepThreads * kGSize / 2];
     const u32 lb = blockIdx.y, tid = threadIdx.x;
@@ -1240,11 +1244,13 @@ __global__ __launch_bounds__(kSweepThreads) void k_huff_sweep(HuffArgs a)
     const unsigned long long *pack = a.pack + (size_t)lb * kMaxAlpha;
     for (u32 i = tid; i < alpha; i += kSweepThreads) s_pack[i] = pack[i];
     for (u32 i = tid; i < 6 * kMaxAlpha; i += kSweepThreads) (&s_rfreq[0][0])[i] = 0;
+    if (tid < 8) s_pass[tid] = 0;
     for (u32 g0 = blockIdx.x * kSweepThreads; g0 < n_selectors; g0 += kSweepTilesX * kSweepThreads) {
         __syncthreads(); // (the staging area is free again; first trip: tables and counters are set)
         stage_symbols_n<kSweepThreads>(s_sym, mtf, g0, mtf_count);
         __syncthreads();
         const u32 g = g0 + tid;
+        u32 bt_mine = 0xFFFFFFFFu, bc_mine = 0; // (for the pass's figures: summed per wave below)
         if (g < n_selectors) {
             const u32 gs = g * kGSize;
             const u32 cnt = (gs + kGSize < mtf_count) ? kGSize : mtf_count - gs;
@@ -1282,6 +1288,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_huff_sweep(HuffArgs a)
                 }
             }
             selector[g] = (u8)bt;
+            bt_mine = bt;
+            bc_mine = bc;
             if (big) {
                 for (u32 i = 0; i < cnt; ++i) {
                     const u32 sy = (my[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
@@ -1294,6 +1302,17 @@ __global__ __launch_bounds__(kSweepThreads) void k_huff_sweep(HuffArgs a)
                 if (c) atomicAdd(&s_rfreq[bt][q], c);
             }
         }
+        if (a.pass_stats) { // totc += bc, fave[bt] += 1 (:469-470), a wave at a time: one LDS add per figure instead of one per group
+            const u32 wtot = wave_sum(bc_mine);
+            u32 mine = 0;
+#pragma unroll
+            for (u32 t = 0; t < 6; ++t) {
+                const u32 c = (u32)__popcll(__ballot(bt_mine == t));
+                mine = (tid & 63u) == t + 1u ? c : mine;
+            }
+            if ((tid & 63u) == 0u) mine = wtot;
+            if ((tid & 63u) < 7u && mine) atomicAdd(&s_pass[tid & 63u], mine);
+        }
     }
     __syncthreads();
     u32 *rfreq = a.rfreq + (size_t)lb * 6 * kMaxAlpha;
@@ -1301,6 +1320,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_huff_sweep(HuffArgs a)
         const u32 c = (&s_rfreq[0][0])[i];
         if (c) atomicAdd(&rfreq[i], c);
     }
+    if (a.pass_stats && tid < 7 && s_pass[tid]) atomicAdd(&a.pass_stats[((size_t)lb * 4 + iter) * 8 + tid], s_pass[tid]);
 }
 
 // payload bits of every group under the final tables (raw, not yet summed) -> group_bitoff
@@ -1567,6 +1587,7 @@ __global__ __launch_bounds__(kHuffThreads) void k_huff_header(HuffArgs a)
     }
     if (tid == 0) {
         bo.header_bits = hb;
+        bo.pad = used_ranges | (sel_total << 5); // (the sections of the header: bz_gpu_debug_block_sections)
         bo.total_bits = (u64)hb + payload_bits;
         bo.group_num = group_num;
         bo.n_selectors = n_selectors;
@@ -1588,11 +1609,12 @@ __global__ __launch_bounds__(kHuffThreads) void k_huff_header(HuffArgs a)
 void launch_huffman(hipStream_t st, const HuffArgs &a)
 {
     static const bool split = !(getenv("BZ_HUFF_SPLIT") && atoi(getenv("BZ_HUFF_SPLIT")) == 0);
+    if (a.pass_stats) (void)hipMemsetAsync(a.pass_stats, 0, (size_t)a.nb * 32 * sizeof(u32), st); // (BZ_HUFF_SPLIT=0: the figures stay 0)
     if (split) {
         const dim3 sweep_grid(kSweepTilesX, a.nb);
         hipLaunchKernelGGL(k_huff_tables, dim3(a.nb), dim3(kTabThreads), 0, st, a, 0u);
         for (u32 iter = 1; iter <= 4; ++iter) { // BZ_N_ITERS, encoder.rs:294,433
-            hipLaunchKernelGGL(k_huff_sweep, sweep_grid, dim3(kSweepThreads), 0, st, a);
+            hipLaunchKernelGGL(k_huff_sweep, sweep_grid, dim3(kSweepThreads), 0, st, a, iter - 1u);
             hipLaunchKernelGGL(k_huff_tables, dim3(a.nb), dim3(kTabThreads), 0, st, a, iter);
         }
         hipLaunchKernelGGL(k_huff_gbits, sweep_grid, dim3(kSweepThreads), 0, st, a);
