@@ -380,7 +380,10 @@ int bz_gpu_profile_get(bz_gpu_engine *g, int idx, const char **name, uint64_t *l
 /* Rotation order of ONE block (src/suffix_array/sais.rs:266 `bwt`). */
 int bz_gpu_debug_bwt(bz_gpu_engine *g, const uint8_t *h_block, size_t n, uint32_t *h_sa);
 /* Code lengths of one table (EncoderInner::create_huffman,
- * src/bzip2/encoder.rs:641-651) through the device code. */
+ * src/bzip2/encoder.rs:641-651) through the device code.  alpha <= 258 and a total of
+ * less than 2^20 occurrences (a block holds 900 001 symbols at most; the device's weights
+ * are 32-bit, the reference's usize: equal below 2^24 occurrences per package), else
+ * BZ_E_PARAM. */
 int bz_gpu_debug_code_lengths(bz_gpu_engine *g, const uint32_t *h_freq, size_t alpha,
                               uint8_t *h_len, int *took_length_limited_path);
 /* Per-block statistics of the last bz_gpu_encode_blocks / encode_device call,

@@ -1685,6 +1685,11 @@ extern "C" int bz_gpu_debug_code_lengths(bz_gpu_engine *g, const uint32_t *h_fre
                                          int *took_length_limited_path)
 {
     if (!g || alpha == 0 || alpha > kMaxAlpha) return BZ_E_PARAM;
+    {   // the domain of the device's 32-bit weights (k_huff.hip "DOMAIN"): what a block can hold, with room to spare
+        uint64_t total = 0;
+        for (size_t i = 0; i < alpha; ++i) total += h_freq[i] ? h_freq[i] : 1u;
+        if (total >= (1u << 20)) return BZ_E_PARAM;
+    }
     HIPCHK(hipSetDevice(g->device));
     DevBuf f, o, s, fl;
     int rc;

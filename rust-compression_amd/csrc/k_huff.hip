@@ -257,6 +257,182 @@ __device__ int heap_code_lengths_w(const u32 *rfreq, u32 alpha, u32 *arena, u8 *
     return too_long;
 }
 
+// The same procedure PIPELINED over eight lanes (round 6).  The main loop is 2 (n - 1) sift-downs from the root, each
+// up to log2(n) levels long, and each needs the root its predecessor left -- but only the root and the root's
+// children: a sift-down that has made its step at level t never touches levels <= t again.  So the next sift-down
+// starts two steps behind the one in front of it (its first step reads level 1, which the one in front finished one
+// step earlier) and follows it down the tree two levels apart: what a step reads (the children, one level below the
+// sift's place) and what the sifts in front of it write (their own places, two and more levels below) never meet.  A
+// lane per sift-down in flight, every lane one level per step; a new sift-down every second step instead of every
+// log2(n)-th.  The one other dependence: a "pop" takes the LAST entry of the heap for the root
+// (cano_huff_table.rs:169-171), and a sift-down in flight whose place is an ancestor of that entry (or the entry) may
+// yet move it: the pop waits a step (one start in five on a 258-symbol table).  create_heap (:33-38) runs level by
+// level: the sift-downs of one level work in disjoint subtrees.  Same comparisons on the same values as
+// heap_code_lengths_w, same array after every sift-down (the probe kernel runs all forms on every probed table).
+//
+// What a step costs is its INSTRUCTIONS, not its LDS round trip (a lone wave issues a vector instruction every four to
+// eight cycles: the first form, eight lanes per table and six tables in one wave, took 1 000 cycles a step for 120
+// instructions, as long as the one-lane form's three levels).  So: one WAVE per table -- what is the same for the
+// eight lanes (the loop's counters, the two smallest, whether to start a sift-down) is then the same for the wave
+// and lives in scalar registers behind scalar branches --, and the step's vector part is the level of a sift-down.
+// All 64 lanes of a wave call it with the same arguments (`on`: the wave has a table); lanes 0-7 carry the sift-downs.
+constexpr u32 kPipeLanes = 8;
+__device__ __forceinline__ void heap_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ int heap_code_lengths_pipe(const u32 *rfreq, u32 n_, u32 *arena, u8 *out, u32 lane, bool on_)
+{
+    // (the same in the 64 lanes, and the compiler is to know: the loop's counters then live in scalar registers)
+    const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)n_);
+    const bool on = __builtin_amdgcn_readfirstlane(on_ ? 1 : 0) != 0;
+    if (n == 1) {
+        if (on && lane == 0) out[0] = 1;
+        return 0;
+    }
+    u64 *H = reinterpret_cast<u64 *>(arena);           // [n]
+    u16 *par = reinterpret_cast<u16 *>(arena + 2 * n); // [2 n]
+#ifdef BZ_TAB_TIMING
+    const unsigned long long tt0 = wall_clock64(), tc0 = clock64();
+    u32 nsteps = 0;
+#endif
+    if (on)
+        for (u32 i = lane; i < n; i += 64u) {
+            const u32 f = rfreq[i];
+            H[i] = ((u64)((f > 1u ? f : 1u) << 8) << 32) | (u64)(n + i); // encoder.rs:642-645
+        }
+    heap_wave_sync();
+    const u32 half = n >> 1; // create_heap, :33-38: the nodes half - 1 .. 0, deepest level first
+    for (int L = 31 - (int)__clz(half); L >= 0; --L) {
+        const u32 first = (1u << L) - 1u;
+        u32 last = (2u << L) - 2u;
+        if (last > half - 1u) last = half - 1u;
+        if (on)
+            for (u32 i = first + lane; i <= last; i += 64u) down_heap_w(H, i, n);
+        heap_wave_sync();
+    }
+    // A step = ONE LDS round trip: the children of this lane's sift-down, the root and the last entry are read side by
+    // side (the root was written a step ago at the latest; the last entry is used only if no sift-down that was in
+    // flight when the step began can reach it), then the step's write.  The lanes of a wave run in lockstep and the
+    // LDS serves a wave's instructions in order: the scheduling barrier keeps the compiler from moving a step's reads
+    // above the write of the step before.  An entry is the pair (node, weight): the u64 weight << 32 | node of
+    // down_heap_w, read as two words.
+    const uint2 *Hr = reinterpret_cast<const uint2 *>(arena);
+    uint2 *Hw = reinterpret_cast<uint2 *>(arena);
+    bool active = false;                              // per lane: the sift-down, its place and level, the sifted entry
+    u32 nn = 0, lv = 0, len = 0, tw = 0, tn = 0;
+    bool done = !on;                                  // per wave
+    u32 i = n, typ = 0, since = 2, sidx = 0, m1w = 0, m1n = 0;
+#ifdef BZ_TAB_TIMING
+    const unsigned long long tt1 = wall_clock64();
+#endif
+    for (;;) {
+#ifdef BZ_TAB_TIMING
+        nsteps++;
+#endif
+        const u32 p = i - 1u; // the entry a pop would take (i >= 1); is this lane's place (level lv) above it?
+        const u32 lp = 31u - (u32)__clz(p + 1u);
+        const bool mine = active & (lp >= lv) & (((p + 1u) >> ((lp - lv) & 31u)) == nn + 1u);
+        const bool wait = __ballot(mine) != 0ull;
+        const u32 leaf = (nn << 1) + 1u;
+        const bool has = active & (leaf < len), has2 = active & (leaf + 1u < len);
+        uint2 c1 = Hr[has ? leaf : 0u], c2 = Hr[has2 ? leaf + 1u : 0u];
+        uint2 root = Hr[0], lastv = Hr[p];
+        asm volatile("" : "+v"(c1.x), "+v"(c1.y), "+v"(c2.x), "+v"(c2.y)); // (whole entries now, not the nodes in a second round trip)
+        const u32 rn = (u32)__builtin_amdgcn_readfirstlane((int)root.x), rw = (u32)__builtin_amdgcn_readfirstlane((int)root.y);
+        const u32 en = (u32)__builtin_amdgcn_readfirstlane((int)lastv.x), ew = (u32)__builtin_amdgcn_readfirstlane((int)lastv.y);
+        // one level of this lane's sift-down (down_heap_w's loop body, cano_huff_table.rs:18-27)
+        const u32 w2 = has2 ? c2.y : 0xFFFFFFFFu;
+        const bool pick2 = c1.y > w2;
+        const u32 sw = pick2 ? c2.y : c1.y, sn = pick2 ? c2.x : c1.x;
+        const bool stop = !has | (tw < sw);
+        if (active) Hw[nn] = stop ? make_uint2(tn, tw) : make_uint2(sn, sw);
+        nn = stop ? nn : leaf + (pick2 ? 1u : 0u);
+        lv += stop ? 0u : 1u;
+        active = active & !stop;
+        // the next sift-down of the table (scalar)
+        since += 1u;
+        if (!done && since >= 2u) {
+            const bool take = lane == (sidx & (kPipeLanes - 1u));
+            if (typ == 0u) { // :169-171  m1 = the root; the last entry takes its place
+                if (i < 2u) done = true;
+                else if (!wait) {
+                    i = p;
+                    m1w = rw;
+                    m1n = rn;
+                    active = active | take;
+                    nn = take ? 0u : nn;
+                    lv = take ? 0u : lv;
+                    len = take ? i : len;
+                    tw = take ? ew : tw;
+                    tn = take ? en : tn;
+                    sidx += 1u;
+                    since = 0;
+                    typ = 1u;
+                }
+            } else { // :172-177  m2 = the root; the new node takes its place
+                const u32 mw = weight_add(m1w, rw);
+                active = active | take;
+                nn = take ? 0u : nn;
+                lv = take ? 0u : lv;
+                len = take ? i : len;
+                tw = take ? mw : tw;
+                tn = take ? i : tn;
+                if (lane == 0) {
+                    par[m1n] = (u16)i;
+                    par[rn] = (u16)i;
+                }
+                sidx += 1u;
+                since = 0;
+                typ = 0u;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (done && __ballot(active) == 0ull) break;
+    }
+#ifdef BZ_TAB_TIMING
+    const unsigned long long tt2 = wall_clock64();
+#endif
+    heap_wave_sync();
+    // :181-184, the depth of every inner node (the root is node 1; a parent's number is smaller than its child's, so
+    // the reference walks the nodes upwards once).  Here by pointer jumping: Q[k] = hops << 16 | the node `hops` parents
+    // above k; a round adds what the node up there has reached so far (one word: read and written whole), and the
+    // root points at itself with 0 hops.  ceil(log2(depth)) rounds of the 64 lanes instead of n dependent round trips
+    // of one.  Q lies over the heap, which is dead.
+    u32 *Q = arena;
+    if (on)
+        for (u32 k = 1u + lane; k < n; k += 64u) Q[k] = k == 1u ? 1u : ((1u << 16) | (u32)par[k]);
+    heap_wave_sync();
+    for (;;) {
+        bool more = false;
+        if (on)
+            for (u32 k = 2u + lane; k < n; k += 64u) {
+                const u32 q = Q[k], up = Q[q & 0xFFFFu];
+                Q[k] = (((q >> 16) + (up >> 16)) << 16) | (up & 0xFFFFu);
+                more = more | ((up & 0xFFFFu) != 1u);
+            }
+        heap_wave_sync();
+        if (__ballot(more) == 0ull) break;
+    }
+    bool too_long = false;
+    if (on)
+        for (u32 k = lane; k < n; k += 64u) { // :186-188
+            const u32 l = (Q[par[k + n]] >> 16) + 1u;
+            out[k] = (u8)l;
+            if (l > kLim) too_long = true;
+        }
+    const bool any_long = __ballot(too_long) != 0ull;
+    heap_wave_sync();
+#ifdef BZ_TAB_TIMING
+    if (lane == 0 && blockIdx.x == 0) {
+        const unsigned long long tt3 = wall_clock64(), tc3 = clock64();
+        printf("heap n %u: create %llu, main %llu (%u steps), tail %llu  [x10 ns]; shader clocks %llu\n", n, tt1 - tt0, tt2 - tt1, nsteps, tt3 - tt2, tc3 - tc0);
+    }
+#endif
+    return any_long ? 1 : 0;
+}
+
 // The same procedure by a whole WAVE with the heap in its registers (WaveArr, bzgpu.h): the procedure is a chain of
 // dependent accesses -- one lane per table paid an LDS round trip for each (0.8 ms per pass for a 258-symbol table,
 // 12 ms per 256 MiB of binary data in k_huff_tables).  Statement for statement heap_code_lengths above (the reference's
@@ -944,6 +1120,10 @@ __device__ __forceinline__ u32 huff_group_num(u32 mtf_count) // encoder.rs:370-3
 // (take_package, :40-55, :129-141) runs level by level, the items of a level side by side.  Same scratch layout as gen_code_lm; the packages of a level are
 // kept in its own val row (dead once the level below exists).  All 64 lanes of ONE wave call it (the other waves of
 // the workgroup, if any, take no part).
+// DOMAIN: the weights are u32 here and usize in the reference (encoder.rs:641-651; the masks keep 24 bits of
+// occurrences per operand, the SUM keeps one more): equal as long as no package reaches 2^24 occurrences.  A package
+// of level j holds every leaf at most once per level below it: <= 16 x the table's total, and a block's total is
+// <= 900 001 + 258 -- 14.4 M < 16.7 M.  bz_gpu_debug_code_lengths refuses tables of 2^20 occurrences and more.
 // (the lanes of ONE wave hand values to each other through LDS: a fence and a scheduling barrier, not a workgroup
 // barrier -- k_huff_tables calls this from one of its six waves)
 __device__ __forceinline__ void lm_wave_sync()
@@ -1117,7 +1297,7 @@ __device__ __forceinline__ void stage_symbols_n(u32 *s_sym, const u16 *__restric
 // resident at once), 13.8 against 13.2 per 256 MiB of 258-symbol binary data, 6.6 against 5.7 of random bytes -- the
 // register array's writes are a compare and a select over up to sixteen registers, and that costs what the LDS round
 // trips did.  The Deflate block kernel, where the same device pays, has 286-symbol tables and no LDS to spare.)
-constexpr u32 kTabThreads = 64;
+constexpr u32 kTabThreads = 384; // six waves: one per table for the heap procedure
 __global__ __launch_bounds__(kTabThreads) void k_huff_tables(HuffArgs a, u32 iter)
 {
     __shared__ u8 s_len[6][kMaxAlpha + 6];
@@ -1171,8 +1351,13 @@ __global__ __launch_bounds__(kTabThreads) void k_huff_tables(HuffArgs a, u32 ite
             rfreq[i] = 0;
         }
         __syncthreads();
-        // the heap procedure: one lane per table, the heap in LDS
-        if (tab_lane) s_need[tb] = (u32)heap_code_lengths_w(s_rfreq[tb], alpha, s_arena + tb * (3 * kMaxAlpha + 4), s_len[tb]);
+        // the heap procedure: a wave per table, eight sift-downs in flight, the heap in LDS (heap_code_lengths_pipe)
+        {
+            const bool on = wv < group_num; // (uniform per wave)
+            const u32 gq = on ? wv : 0u;
+            const int lm = heap_code_lengths_pipe(s_rfreq[gq], alpha, s_arena + gq * (3 * kMaxAlpha + 4), s_len[gq], lane, on);
+            if (on && lane == 0) s_need[wv] = (u32)lm;
+        }
         __syncthreads();
         // tables whose longest code exceeds 17 bits: package-merge, one lane each, as many tables at a time as fit
         // the arena, side by side in global memory when not even one does
@@ -1199,16 +1384,13 @@ __global__ __launch_bounds__(kTabThreads) void k_huff_tables(HuffArgs a, u32 ite
                 __syncthreads();
             } else {
                 // (large alphabets: the scratch of a table does not fit the arena -- it lies in global memory; the WAVE
-                // builds the tables one after the other there too.  Rounds 1-3 gave each table a single lane here:
+                // builds a table there too.  Rounds 1-3 gave each table a single lane here:
                 // 12 of the 13 ms the Huffman stage took per 256 MiB of 258-symbol binary data.)
-                if (wv == 0) {
-                    for (u32 t = 0; t < group_num; ++t) {
-                        if (s_need[t]) { // uniform
-                            lm_code_lengths_wave(s_rfreq[t], alpha, a.lm_scratch + ((size_t)lb * 6 + t) * kLmWords, kLmWords, kLmRow,
-                                                 s_len[t], lane);
-                            if (lane == 0) s_lmcount += 1;
-                        }
-                    }
+                // (round 6: every table has scratch of its own there and a wave of its own here)
+                if (wv < group_num && s_need[wv]) { // uniform per wave
+                    lm_code_lengths_wave(s_rfreq[wv], alpha, a.lm_scratch + ((size_t)lb * 6 + wv) * kLmWords, kLmWords, kLmRow,
+                                         s_len[wv], lane);
+                    if (lane == 0) atomicAdd(&s_lmcount, 1u);
                 }
                 __syncthreads();
             }
@@ -1633,7 +1815,7 @@ __global__ void k_probe_code_lengths(const u32 *freq, u32 alpha, u8 *out, u32 *l
     __shared__ u32 s_buf[2 * kMaxAlpha + 4];
     __shared__ __attribute__((aligned(16))) u32 s_arena_w[3 * kMaxAlpha + 4];
     __shared__ u32 s_f[kMaxAlpha];
-    __shared__ u8 s_o[kMaxAlpha + 6], s_o2[kMaxAlpha + 6];
+    __shared__ u8 s_o[kMaxAlpha + 6], s_o2[kMaxAlpha + 6], s_o3[kMaxAlpha + 6];
     __shared__ int s_lm, s_bad;
     if (threadIdx.x == 0) {
         for (u32 i = 0; i < alpha; ++i) s_f[i] = freq[i];
@@ -1649,6 +1831,16 @@ __global__ void k_probe_code_lengths(const u32 *freq, u32 alpha, u8 *out, u32 *l
         s_lm = lm;
     }
     __syncthreads();
+    {   // the pipelined form (the one k_huff_tables uses), on the heap's own lengths: s_o3
+        const int lm3 = heap_code_lengths_pipe(s_f, alpha, s_arena_w, s_o3, threadIdx.x, true);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (lm3 != s_lm) s_bad = 1;
+            for (u32 i = 0; i < alpha; ++i)
+                if (s_o3[i] != s_o2[i]) s_bad = 1;
+        }
+        __syncthreads();
+    }
     if (s_lm) { // uniform
         lm_code_lengths_wave(s_f, alpha, lm_scr, kLmWords, kLmRow, s_o2, threadIdx.x);
         __syncthreads();
