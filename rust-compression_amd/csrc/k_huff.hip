@@ -331,17 +331,26 @@ __device__ int heap_code_lengths_pipe(const u32 *rfreq, u32 n_, u32 *arena, u8 *
 #ifdef BZ_TAB_TIMING
         nsteps++;
 #endif
-        const u32 p = i - 1u; // the entry a pop would take (i >= 1); is this lane's place (level lv) above it?
-        const u32 lp = 31u - (u32)__clz(p + 1u);
-        const bool mine = active & (lp >= lv) & (((p + 1u) >> ((lp - lv) & 31u)) == nn + 1u);
-        const bool wait = __ballot(mine) != 0ull;
+        const u32 p = i - 1u; // the entry a pop would take (i >= 1)
+        const bool start = !done && since >= 1u; // (scalar) this step may start a sift-down: it reads the root, and
+        bool wait = false;                       // for a pop the last entry -- if no lane's place (level lv) is above it
         const u32 leaf = (nn << 1) + 1u;
         const bool has = active & (leaf < len), has2 = active & (leaf + 1u < len);
         uint2 c1 = Hr[has ? leaf : 0u], c2 = Hr[has2 ? leaf + 1u : 0u];
-        uint2 root = Hr[0], lastv = Hr[p];
+        u32 rn = 0, rw = 0, en = 0, ew = 0;
+        if (start) {
+            const uint2 root = Hr[0], lastv = Hr[p];
+            if (typ == 0u) {
+                const u32 lp = 31u - (u32)__clz(p + 1u);
+                const bool mine = active & (lp >= lv) & (((p + 1u) >> ((lp - lv) & 31u)) == nn + 1u);
+                wait = __ballot(mine) != 0ull;
+            }
+            rn = (u32)__builtin_amdgcn_readfirstlane((int)root.x);
+            rw = (u32)__builtin_amdgcn_readfirstlane((int)root.y);
+            en = (u32)__builtin_amdgcn_readfirstlane((int)lastv.x);
+            ew = (u32)__builtin_amdgcn_readfirstlane((int)lastv.y);
+        }
         asm volatile("" : "+v"(c1.x), "+v"(c1.y), "+v"(c2.x), "+v"(c2.y)); // (whole entries now, not the nodes in a second round trip)
-        const u32 rn = (u32)__builtin_amdgcn_readfirstlane((int)root.x), rw = (u32)__builtin_amdgcn_readfirstlane((int)root.y);
-        const u32 en = (u32)__builtin_amdgcn_readfirstlane((int)lastv.x), ew = (u32)__builtin_amdgcn_readfirstlane((int)lastv.y);
         // one level of this lane's sift-down (down_heap_w's loop body, cano_huff_table.rs:18-27)
         const u32 w2 = has2 ? c2.y : 0xFFFFFFFFu;
         const bool pick2 = c1.y > w2;
@@ -1335,14 +1344,18 @@ __global__ __launch_bounds__(kTabThreads) void k_huff_tables(HuffArgs a, u32 ite
                     a_freq -= mtf_freq[ge];
                     ge -= 1;
                 }
-                u8 *l = s_len[group_num - 1 - k];
-                for (int i = 0; i < (int)alpha; ++i) l[i] = (i >= gs && i <= ge) ? 0 : 15; // :297-298
+                s_need[group_num - 1 - k] = (u32)gs | ((u32)(ge + 1) << 16); // the table's range [gs, ge]
                 rem -= a_freq;
                 gs = ge + 1;
             }
             a.hlm[lb] = 0;
         }
         for (u32 i = tid; i < 6 * kMaxAlpha; i += kTabThreads) rfreq[i] = 0;
+        __syncthreads();
+        for (u32 i = tid; i < group_num * alpha; i += kTabThreads) { // :297-298, all lanes
+            const u32 t = i / alpha, sym = i - t * alpha, rg = s_need[t];
+            s_len[t][sym] = (sym >= (rg & 0xFFFFu) && sym < (rg >> 16)) ? 0 : 15;
+        }
         __syncthreads();
     } else {
         // the counts of the sweep come in, and are cleared for the next one
