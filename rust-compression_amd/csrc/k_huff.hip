@@ -1306,7 +1306,15 @@ __device__ __forceinline__ void stage_symbols_n(u32 *s_sym, const u16 *__restric
 // resident at once), 13.8 against 13.2 per 256 MiB of 258-symbol binary data, 6.6 against 5.7 of random bytes -- the
 // register array's writes are a compare and a select over up to sixteen registers, and that costs what the LDS round
 // trips did.  The Deflate block kernel, where the same device pays, has 286-symbol tables and no LDS to spare.)
-constexpr u32 kTabThreads = 384; // six waves: one per table for the heap procedure
+// Two forms (round 6), same lengths (the probe kernel runs both heap forms on every probed table):
+//   kTabThreads = 384, six waves: a wave per table, the heap procedure pipelined (heap_code_lengths_pipe) -- a third
+//     of the serial form's time for a block alone (258 symbols: 375 us a launch against 560), four times its
+//     instructions in all;
+//   64, one wave: a lane per table (heap_code_lengths_w) -- for batches that fill the SIMDs with one wave per block
+//     (1189 blocks of text: 145 us a launch against 200 for the six-wave form).
+// launch_huffman takes the six-wave form while a batch's waves find SIMDs of their own (kTabPipeBlocks).
+constexpr u32 kTabPipeBlocks = 320; // 6 waves x 320 blocks: two per SIMD
+template <u32 kTabThreads>
 __global__ __launch_bounds__(kTabThreads) void k_huff_tables(HuffArgs a, u32 iter)
 {
     __shared__ u8 s_len[6][kMaxAlpha + 6];
@@ -1365,11 +1373,13 @@ __global__ __launch_bounds__(kTabThreads) void k_huff_tables(HuffArgs a, u32 ite
         }
         __syncthreads();
         // the heap procedure: a wave per table, eight sift-downs in flight, the heap in LDS (heap_code_lengths_pipe)
-        {
+        if constexpr (kTabThreads >= 384) {
             const bool on = wv < group_num; // (uniform per wave)
             const u32 gq = on ? wv : 0u;
             const int lm = heap_code_lengths_pipe(s_rfreq[gq], alpha, s_arena + gq * (3 * kMaxAlpha + 4), s_len[gq], lane, on);
             if (on && lane == 0) s_need[wv] = (u32)lm;
+        } else {
+            if (tab_lane) s_need[tb] = (u32)heap_code_lengths_w(s_rfreq[tb], alpha, s_arena + tb * (3 * kMaxAlpha + 4), s_len[tb]);
         }
         __syncthreads();
         // tables whose longest code exceeds 17 bits: package-merge, one lane each, as many tables at a time as fit
@@ -1400,10 +1410,12 @@ __global__ __launch_bounds__(kTabThreads) void k_huff_tables(HuffArgs a, u32 ite
                 // builds a table there too.  Rounds 1-3 gave each table a single lane here:
                 // 12 of the 13 ms the Huffman stage took per 256 MiB of 258-symbol binary data.)
                 // (round 6: every table has scratch of its own there and a wave of its own here)
-                if (wv < group_num && s_need[wv]) { // uniform per wave
-                    lm_code_lengths_wave(s_rfreq[wv], alpha, a.lm_scratch + ((size_t)lb * 6 + wv) * kLmWords, kLmWords, kLmRow,
-                                         s_len[wv], lane);
-                    if (lane == 0) atomicAdd(&s_lmcount, 1u);
+                for (u32 t = wv; t < group_num; t += kTabThreads / 64u) {
+                    if (s_need[t]) { // uniform per wave
+                        lm_code_lengths_wave(s_rfreq[t], alpha, a.lm_scratch + ((size_t)lb * 6 + t) * kLmWords, kLmWords, kLmRow,
+                                             s_len[t], lane);
+                        if (lane == 0) atomicAdd(&s_lmcount, 1u);
+                    }
                 }
                 __syncthreads();
             }
@@ -1807,10 +1819,15 @@ void launch_huffman(hipStream_t st, const HuffArgs &a)
     if (a.pass_stats) (void)hipMemsetAsync(a.pass_stats, 0, (size_t)a.nb * 32 * sizeof(u32), st); // (BZ_HUFF_SPLIT=0: the figures stay 0)
     if (split) {
         const dim3 sweep_grid(kSweepTilesX, a.nb);
-        hipLaunchKernelGGL(k_huff_tables, dim3(a.nb), dim3(kTabThreads), 0, st, a, 0u);
+        const bool pipe = a.nb <= kTabPipeBlocks;
+        auto tables = [&](u32 iter) {
+            if (pipe) hipLaunchKernelGGL(k_huff_tables<384>, dim3(a.nb), dim3(384), 0, st, a, iter);
+            else hipLaunchKernelGGL(k_huff_tables<64>, dim3(a.nb), dim3(64), 0, st, a, iter);
+        };
+        tables(0u);
         for (u32 iter = 1; iter <= 4; ++iter) { // BZ_N_ITERS, encoder.rs:294,433
             hipLaunchKernelGGL(k_huff_sweep, sweep_grid, dim3(kSweepThreads), 0, st, a, iter - 1u);
-            hipLaunchKernelGGL(k_huff_tables, dim3(a.nb), dim3(kTabThreads), 0, st, a, iter);
+            tables(iter);
         }
         hipLaunchKernelGGL(k_huff_gbits, sweep_grid, dim3(kSweepThreads), 0, st, a);
         hipLaunchKernelGGL(k_huff_header, dim3(a.nb), dim3(kHuffThreads), 0, st, a);

@@ -442,6 +442,32 @@ def test_pass_counter_wraps(pkg, oracle):
         e.close()
 
 
+def test_both_forms_of_the_table_kernel(pkg, oracle):
+    """k_huff_tables has two forms (k_huff.hip): a wave per table with the heap procedure pipelined for batches of up to
+    kTabPipeBlocks = 320 blocks, a lane per table for larger ones.  The same level-1 input -- text, 256-symbol blocks
+    (sample2 tiled), random bytes: 369 blocks -- through an engine that holds all of them in one batch and through one
+    that holds 64: the same stream, the oracle's (cano_huff_table.rs:153-196 for both).  (Tables that take the
+    length-limited path: text at level 9 -- the 2 MB of test_block_stats_match_oracle through the six-wave form, the
+    1 GiB golden of test_gpu_configs_full through the one-wave form.)"""
+    import torch
+    import corpus
+    rng = random.Random(77)
+    d = corpus.chapter(3, 18_000_000) + (sample(2) * 80)[:16_000_000] + bytes(rng.randrange(256) for _ in range(3_000_000))
+    want = oracle.encode(d, 1)
+    tin = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+    cap = (pkg.encode_bound(len(d)) + 15) & ~15
+    tout = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    for blocks in (1024, 64):
+        e = pkg.GpuEngine(0, blocks)
+        try:
+            n = e.encode_device(1, tin.data_ptr(), len(d), tout.data_ptr(), cap)
+            got = bytes(tout[:n].cpu().numpy())
+            assert len(e.block_stats()) > 320
+        finally:
+            e.close()
+        assert got == want, blocks
+
+
 def test_streaming_across_chunk_boundaries(oracle):
     """The host pipeline with 1 MiB chunks (BZ_ENC_CHUNK_MIB=1, read once per process): many chunks per
     stream, block tails carried from chunk to chunk on the device, runs that cover whole chunks (the
