@@ -567,6 +567,17 @@ int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned l
             u64 *sorted_elems, KernelProf *prof, u64 *round_active /*[64] or null*/, bool wide_keys,
             u32 min_chars);
 void launch_mtf(hipStream_t st, const MtfArgs &a);
+bool env_verify(); // BZ_VERIFY=1: the self-check for every context and engine of the process (k_emit.hip)
+// a few bytes for the host between launches (k_emit.hip): up to four device ranges, 0 = they are there and the stream's
+// earlier work is done
+struct MailSeg {
+    void *h;
+    const void *d;
+    size_t n;
+};
+int mail_fetch(hipStream_t st, const MailSeg *segs, int nseg);
+// a few bytes from the host in front of the next launch (up to 1 KB as a kernel argument, more by hipMemcpyAsync); 0 = queued
+int mail_poke(hipStream_t st, void *d_dst, const void *h_src, size_t n);
 void launch_huffman(hipStream_t st, const HuffArgs &a);
 void launch_probe_code_lengths(hipStream_t st, const u32 *d_freq, u32 alpha, u8 *d_out, u32 *lm_scr,
                                int *d_flag);

@@ -916,7 +916,7 @@ extern "C" int bz_enc_create_multi(bz_enc **out, int level, const int *devices, 
     bz_enc *e = new bz_enc();
     e->level = level;
     e->devices.assign(devices, devices + n_devices);
-    e->verify = getenv("BZ_VERIFY") && atoi(getenv("BZ_VERIFY")) != 0;
+    e->verify = bzgpu::env_verify();
     *out = e;
     return BZ_OK;
 }

@@ -14,6 +14,13 @@
 #include <vector>
 
 
+// a few bytes for the host and the stream's earlier work done (mail_fetch, k_emit.hip)
+#define MAILCHK(st, ...)                                                             \
+    do {                                                                             \
+        const MailSeg mail_segs_[] = {__VA_ARGS__};                                  \
+        if (mail_fetch((st), mail_segs_, (int)(sizeof(mail_segs_) / sizeof(mail_segs_[0]))) != 0) return BZ_E_UNEXPECTED; \
+    } while (0)
+
 static int span_begin(bz_gpu_engine *g, int stage, hipStream_t st = nullptr)
 {
     bz_gpu_engine::Span s;
@@ -164,7 +171,7 @@ extern "C" int bz_gpu_engine_create(bz_gpu_engine **out, int device, size_t max_
     bz_gpu_engine *g = new bz_gpu_engine();
     g->device = device;
     g->max_blocks = max_blocks_in_flight ? max_blocks_in_flight : 64;
-    g->verify = getenv("BZ_VERIFY") && atoi(getenv("BZ_VERIFY")) != 0;
+    g->verify = bzgpu::env_verify();
     HIPCHK(hipStreamCreateWithFlags(&g->st, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&g->st2, hipStreamNonBlocking));
     HIPCHK(hipHostMalloc((void **)&g->h_active, 64, hipHostMallocDefault));
@@ -282,9 +289,8 @@ extern "C" int bz_gpu_partition_slab_begin(bz_gpu_engine *g, int level, const vo
     if (tile1 > tile0) {
         launch_slab_last(g->st, rb, tile0, tile1, d_last);
         i64 last = -1;
-        HIPCHK(hipMemcpyAsync(&last, d_last, 8, hipMemcpyDeviceToHost, g->st));
         span_end(g, sp);
-        HIPCHK(hipStreamSynchronize(g->st));
+        MAILCHK(g->st, {&last, d_last, 8});
         if (slab_last_start) *slab_last_start = last;
     } else {
         span_end(g, sp);
@@ -382,8 +388,7 @@ static int cut_tables_prepare(bz_gpu_engine *g, u64 g_base, u64 total, u64 tb, u
         const CutBuffers cb = cut_buffers(g);
         launch_cut_steps(g->st, pl, rb, cb);
         u64 work = 0;
-        HIPCHK(hipMemcpyAsync(&work, cb.step_w0 + nsteps, 8, hipMemcpyDeviceToHost, g->st));
-        HIPCHK(hipStreamSynchronize(g->st));
+        MAILCHK(g->st, {&work, cb.step_w0 + nsteps, 8});
         if (work >= (1ull << 31)) return BZ_OK;
         const u64 n_lim = std::min<u64>(g->n_in, (pl.t_last + 1u) * (u64)kRleTile);
         launch_cut_tables(g->st, pl, g->d_in, n_lim, rb, cb, work);
@@ -399,8 +404,7 @@ static int cut_tables_select(bz_gpu_engine *g, u64 j0, u64 s0, u64 start_in, u64
     const RleBuffers rb = rle_buffers(g);
     launch_cut_select(g->st, g->cut_plan, j0, s0, start_in, g->n_in, (long long)rle_at - (long long)g->cut_plan.g_base, emit_tail, rb,
                       cut_buffers(g), g->blocks_all.as<BlockDesc>(), max_blocks);
-    HIPCHK(hipMemcpyAsync(res, rb.cut_result, 5 * sizeof(u64), hipMemcpyDeviceToHost, g->st));
-    HIPCHK(hipStreamSynchronize(g->st));
+    MAILCHK(g->st, {res, rb.cut_result, 5 * sizeof(u64)});
     return BZ_OK;
 }
 
@@ -430,8 +434,7 @@ static int slab_cuts(bz_gpu_engine *g, uint64_t start_in, int is_last, bool imag
     }
     launch_rle_prefix(g->st, tb, t1, rb);
     u64 total = 0;
-    HIPCHK(hipMemcpyAsync(&total, rb.total, 8, hipMemcpyDeviceToHost, g->st));
-    HIPCHK(hipStreamSynchronize(g->st));
+    MAILCHK(g->st, {&total, rb.total, 8});
     const size_t max_blocks = (size_t)(total / block_max_len + 2);
     int rc;
     if ((rc = g->rle.ensure(total + 256)) || (rc = g->blocks_all.ensure(max_blocks * sizeof(BlockDesc))) ||
@@ -471,8 +474,7 @@ static int slab_cuts(bz_gpu_engine *g, uint64_t start_in, int is_last, bool imag
             HIPCHK(hipEventRecord(g->ev_aux, g->st2));
             sc.image_done = true;
         }
-        HIPCHK(hipMemcpyAsync(res, rb.cut_result, 3 * sizeof(u64), hipMemcpyDeviceToHost, g->st));
-        HIPCHK(hipStreamSynchronize(g->st));
+        MAILCHK(g->st, {res, rb.cut_result, 3 * sizeof(u64)});
     }
     if (image_beside) HIPCHK(hipStreamWaitEvent(g->st, g->ev_aux, 0));
     const size_t nb = (size_t)res[0];
@@ -498,11 +500,9 @@ static int slab_image(bz_gpu_engine *g, SlabCuts &sc)
     if (nb) {
         launch_block_crc(g->st, g->d_in, g->blocks_all.as<BlockDesc>(), (u32)nb, g->crc_tab.as<u32>(),
                          g->xp2.as<u32>(), g->tile_crc.as<u32>(), g->crc_all.as<u32>());
-        HIPCHK(hipMemcpyAsync(g->h_blocks.data(), g->blocks_all.p, nb * sizeof(BlockDesc), hipMemcpyDeviceToHost,
-                              g->st));
-        HIPCHK(hipMemcpyAsync(g->h_crc.data(), g->crc_all.p, nb * 4, hipMemcpyDeviceToHost, g->st));
     }
     span_end(g, sc.span);
+    if (nb) MAILCHK(g->st, {g->h_blocks.data(), g->blocks_all.p, nb * sizeof(BlockDesc)}, {g->h_crc.data(), g->crc_all.p, nb * 4});
     spans_collect(g);
     HIPCHK(hipGetLastError());
     return BZ_OK;
@@ -529,9 +529,8 @@ static int slab_spec_total(bz_gpu_engine *g, SlabSpec &sp)
     const RleBuffers rb = rle_buffers(g);
     const int span = span_begin(g, 0);
     launch_rle_prefix(g->st, g->slab_t0, g->slab_t1, rb);
-    HIPCHK(hipMemcpyAsync(&sp.total, rb.total, 8, hipMemcpyDeviceToHost, g->st));
     span_end(g, span);
-    HIPCHK(hipStreamSynchronize(g->st));
+    MAILCHK(g->st, {&sp.total, rb.total, 8});
     return BZ_OK;
 }
 static int slab_spec_tables(bz_gpu_engine *g, SlabSpec &sp, u64 g_base)
@@ -787,8 +786,10 @@ static int sort_batch(bz_gpu_engine *g, const BwtArgs &ba, u32 *inuse_bits, u32 
 {
     launch_block_symbols(g->st, ba, inuse_bits, const_cast<u8 *>(ba.sym_code), const_cast<u8 *>(ba.keyinfo));
     std::vector<u8> ki((size_t)ba.nb * 4);
-    if (hipMemcpyAsync(ki.data(), ba.keyinfo, ki.size(), hipMemcpyDeviceToHost, g->st) != hipSuccess) return -1;
-    if (hipStreamSynchronize(g->st) != hipSuccess) return -1;
+    {
+        const MailSeg sg = {ki.data(), ba.keyinfo, ki.size()};
+        if (mail_fetch(g->st, &sg, 1) != 0) return -1;
+    }
     bool wide = false;
     u32 min_chars = 8;
     for (u32 i = 0; i < ba.nb; ++i) {
@@ -877,14 +878,18 @@ static int encode_batch(bz_gpu_engine *g, u32 nb, const std::vector<BlockDesc> &
     } else {
         (void)hipStreamSynchronize(g->st2);
     }
-    (void)hipStreamSynchronize(g->st);
+    u32 tk[9] = {};
+    if (rc == BZ_OK && used_fused_zle) { // (the tickets of the ZLE stage come with the wait for the batch)
+        const MailSeg sg = {tk, g->ztick.p, sizeof(tk)};
+        if (mail_fetch(g->st, &sg, 1) != 0) return BZ_E_UNEXPECTED;
+    } else {
+        (void)hipStreamSynchronize(g->st);
+    }
     for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
     if (rc == BZ_OK && used_fused_zle) {
         // did the one-launch ZLE stage hand out every tile on every XCD, and did no look-back give up?  If not (it never
         // has), the MTF / ZLE and Huffman stages run again with the three ZLE kernels, and the engine stays on them.
-        u32 tk[9] = {};
         static const bool fail_test = getenv("BZ_FUSED_ZLE_FAILTEST") != nullptr; // (tests: exercise the redo)
-        if (hipMemcpy(tk, g->ztick.p, sizeof(tk), hipMemcpyDeviceToHost) != hipSuccess) return BZ_E_UNEXPECTED;
         bool bad = tk[8] != 0 || fail_test;
         for (u32 x = 0; x < 8; ++x) // (exactly its share of the launch's workgroups: fewer = tiles left out, more = tiles run twice)
             if (tk[x] != zle_tiles * (xcd_grid_y(nb) / 8u)) bad = true;
@@ -927,19 +932,17 @@ static int encode_blocks_once(bz_gpu_engine *g, const std::vector<size_t> &mine,
             crcs[i] = g->h_crc[mine[k0 + i]];
             if (descs[i].n > kMaxBlockLen) return BZ_E_UNEXPECTED;
         }
-        HIPCHK(hipMemcpyAsync(g->lblocks.p, descs.data(), nb * sizeof(BlockDesc), hipMemcpyHostToDevice, g->st));
-        HIPCHK(hipMemcpyAsync(g->lcrc.p, crcs.data(), nb * 4, hipMemcpyHostToDevice, g->st));
-        HIPCHK(hipStreamSynchronize(g->st)); // descs/crcs are reused by the next batch
+        if (mail_poke(g->st, g->lblocks.p, descs.data(), nb * sizeof(BlockDesc)) || mail_poke(g->st, g->lcrc.p, crcs.data(), nb * 4)) return BZ_E_UNEXPECTED;
+        const bool last_batch = k0 + nb == mine.size();
+        if (!last_batch) HIPCHK(hipStreamSynchronize(g->st)); // descs/crcs are reused by the next batch (the last one's live until the call's final wait)
         rc = encode_batch(g, nb, descs);
         if (rc != BZ_OK) return rc;
         outs.resize(nb);
         u32 err = 0;
         const size_t pass0 = g->h_out_pass.size();
         g->h_out_pass.resize(pass0 + (size_t)nb * 32);
-        HIPCHK(hipMemcpyAsync(outs.data(), g->bout.p, nb * sizeof(BlockOut), hipMemcpyDeviceToHost, g->st));
         if (g->debug_figures) HIPCHK(hipMemcpyAsync(g->h_out_pass.data() + pass0, g->hpass.p, (size_t)nb * 32 * 4, hipMemcpyDeviceToHost, g->st));
-        HIPCHK(hipMemcpyAsync(&err, g->error_flag.p, 4, hipMemcpyDeviceToHost, g->st));
-        HIPCHK(hipStreamSynchronize(g->st));
+        MAILCHK(g->st, {outs.data(), g->bout.p, nb * sizeof(BlockOut)}, {&err, g->error_flag.p, 4});
         HIPCHK(hipGetLastError());
         if (err) return BZ_E_UNEXPECTED;
         pbs.resize(nb);
@@ -957,10 +960,10 @@ static int encode_blocks_once(bz_gpu_engine *g, const std::vector<size_t> &mine,
         }
         if (word_cursor > cap_words) return BZ_E_CAPACITY;
         const int sp = span_begin(g, 4);
-        HIPCHK(hipMemcpyAsync(g->packlist.p, pbs.data(), nb * sizeof(PackBlock), hipMemcpyHostToDevice, g->st));
+        if (mail_poke(g->st, g->packlist.p, pbs.data(), nb * sizeof(PackBlock))) return BZ_E_UNEXPECTED;
         launch_pack(g->st, g->stream.as<u32>(), g->packlist.as<PackBlock>(), nb, (u32 *)d_packed);
         span_end(g, sp);
-        HIPCHK(hipStreamSynchronize(g->st)); // pbs reused
+        if (!last_batch) HIPCHK(hipStreamSynchronize(g->st)); // pbs reused
     }
     spans_collect(g);
     HIPCHK(hipGetLastError());
@@ -1140,7 +1143,7 @@ extern "C" int bz_gpu_assemble(bz_gpu_engine *g, int level, size_t n_blocks, con
     if (n_blocks) {
         int rc = g->asmlist.ensure(n_blocks * sizeof(AsmBlock));
         if (rc != BZ_OK) return rc;
-        HIPCHK(hipMemcpyAsync(g->asmlist.p, ab.data(), n_blocks * sizeof(AsmBlock), hipMemcpyHostToDevice, g->st));
+        if (mail_poke(g->st, g->asmlist.p, ab.data(), n_blocks * sizeof(AsmBlock))) return BZ_E_UNEXPECTED;
         launch_assemble(g->st, (const u32 *)d_packed, g->asmlist.as<AsmBlock>(), (u32)n_blocks, max_words,
                         (u32 *)d_out);
     }
@@ -1157,8 +1160,7 @@ extern "C" int bz_gpu_assemble(bz_gpu_engine *g, int level, size_t n_blocks, con
         ocb = (unsigned)(total_bits & 7u);
         if (ocb) {
             u8 last = 0;
-            HIPCHK(hipMemcpyAsync(&last, (const u8 *)d_out + bytes, 1, hipMemcpyDeviceToHost, g->st));
-            HIPCHK(hipStreamSynchronize(g->st));
+            MAILCHK(g->st, {&last, (const u8 *)d_out + bytes, 1});
             ocy = last & (0xFFu << (8 - ocb));
         }
     }

@@ -3293,9 +3293,10 @@ static bool fused_pass_ok(hipStream_t st, const BwtArgs &a, u32 epoch)
     static const bool fail_test = getenv("BZ_ONESWEEP_FAILTEST") != nullptr; // (tests: exercise the fallback)
     if (fail_test) return false;
     u32 tk[8], gave_up = 0;
-    if (hipMemcpyAsync(tk, a.tickets + (size_t)epoch * 8u, sizeof(tk), hipMemcpyDeviceToHost, st) != hipSuccess) return false;
-    if (hipMemcpyAsync(&gave_up, a.sort_err, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
-    if (hipStreamSynchronize(st) != hipSuccess) return false;
+    {
+        const MailSeg sg[2] = {{tk, a.tickets + (size_t)epoch * 8u, sizeof(tk)}, {&gave_up, a.sort_err, 4}};
+        if (mail_fetch(st, sg, 2) != 0) return false;
+    }
     if (gave_up) return false;
     // Every workgroup of the launch draws one ticket from the counter of the XCD it runs on, and the launch has
     // a.tiles * xcd_grid_y(nb) workgroups dealt evenly to the eight XCDs: each counter must stand at EXACTLY
@@ -3456,11 +3457,10 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
     bool surv_local_ok = true; // (no segment of a survivor round of this sort has overflowed LDS so far)
     u32 list_tiles = a.tiles; // (the first refinement ran on all of SA)
     while (true) {
-        if (hipMemcpyAsync(h_active, a.active + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, st) !=
-                hipSuccess ||
-            hipMemcpyAsync(h_active + 1, a.maxnf + slot, sizeof(u32), hipMemcpyDeviceToHost, st) != hipSuccess)
-            return -1;
-        if (hipStreamSynchronize(st) != hipSuccess) return -1;
+        {
+            const MailSeg sg[2] = {{h_active, a.active + slot, sizeof(unsigned long long)}, {h_active + 1, a.maxnf + slot, sizeof(u32)}};
+            if (mail_fetch(st, sg, 2) != 0) return -1;
+        }
         const u64 m = *h_active; // rotations still to be ordered (in unfinished blocks)
         // tiles of the longest list of the coming round (its members are the rotations the last refinement left
         // unordered), and of the list that refinement ran on
@@ -3562,9 +3562,10 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
             bool one_pass = false, wide = false;
             {
                 std::vector<u32> lp((size_t)a.nb * kPerK), ls((size_t)a.nb * kPerK);
-                if (hipMemcpyAsync(lp.data(), a.lin_p, lp.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                    hipMemcpyAsync(ls.data(), a.lin_sig, ls.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-                    return -1;
+                {
+                    const MailSeg sg[2] = {{lp.data(), a.lin_p, lp.size() * 4}, {ls.data(), a.lin_sig, ls.size() * 4}};
+                    if (mail_fetch(st, sg, 2) != 0) return -1;
+                }
                 one_pass = true;
                 u32 small = 0, smallest = 0xFFFFFFFFu;
                 // (a distance below 1024 that a fifth of its block agrees at; the ones that barely made the list -- a paragraph
@@ -3622,8 +3623,10 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
                 u32 fails = 0;
                 (void)hipMemsetAsync(a.loc_stats + LOC_STAT_SURV_FAIL, 0, 4, st);
                 hipLaunchKernelGGL(k_surv_local, grid_list, dim3(kLocThreads), 0, st, a, step, fV, cK, cV);
-                if (hipMemcpyAsync(&fails, a.loc_stats + LOC_STAT_SURV_FAIL, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-                    return -1;
+                {
+                    const MailSeg sg = {&fails, a.loc_stats + LOC_STAT_SURV_FAIL, 4};
+                    if (mail_fetch(st, &sg, 1) != 0) return -1;
+                }
                 local_done = fails == 0;
                 if (!local_done) surv_local_ok = false;
                 if (bwt_trace) fprintf(stderr, "  survivor round inside LDS: %s\n", local_done ? "done" : "a segment did not fit or failed its check: the global passes");
@@ -3704,14 +3707,12 @@ static int run_bwt_once(hipStream_t st, const BwtArgs &a_in, u32 max_n, u64 tota
         u32 gave_up = 0;
         std::vector<u32> tk;
         const u32 epoch_last = *a.epoch;
-        if (hipMemcpyAsync(&gave_up, a.sort_err, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
-        if (epoch_last >= epoch_first) { // (no wrap of the pass counter in between)
+        if (epoch_last >= epoch_first) // (no wrap of the pass counter in between)
             tk.resize((size_t)(epoch_last - epoch_first + 1u) * 8u);
-            if (hipMemcpyAsync(tk.data(), a.tickets + (size_t)epoch_first * 8u, tk.size() * 4, hipMemcpyDeviceToHost, st) !=
-                hipSuccess)
-                return -1;
+        {
+            const MailSeg sg[2] = {{&gave_up, a.sort_err, 4}, {tk.data(), a.tickets + (size_t)epoch_first * 8u, tk.size() * 4}};
+            if (mail_fetch(st, sg, tk.empty() ? 1 : 2) != 0) return -1;
         }
-        if (hipStreamSynchronize(st) != hipSuccess) return -1;
         static const bool late_fail_test = getenv("BZ_ONESWEEP_LATEFAILTEST") != nullptr; // (tests: exercise the redo)
         bool bad = gave_up != 0 || late_fail_test;
         for (size_t i = 0; i < tk.size(); ++i)

@@ -771,6 +771,33 @@ print("ok")
     assert "sort round" in out.stderr and "bz_enc job" in out.stderr
 
 
+def test_mailbox_off_changes_no_byte(oracle):
+    """BZ_MAILBOX=0: the host's small reads between launches (block counts, a sort round's survivors, bit counts; mail_fetch,
+    k_emit.hip) and its small writes (mail_poke) go through hipMemcpyAsync + hipStreamSynchronize as in rounds 1-5 instead of
+    the per-stream mailbox in host-mapped memory: same streams either way -- one block, several batches, a deep-repeat block
+    with its period and link rounds, levels 1 and 9."""
+    import subprocess
+    import sys
+    code = """
+import sys, importlib, random
+sys.path.insert(0, %r)
+pkg = importlib.import_module("rust-compression_amd")
+from oracle import oracle
+rng = random.Random(19)
+unit = bytes(rng.randrange(40) for _ in range(30000))
+cases = [(unit * 3 + bytes(rng.randrange(200) for _ in range(5000)) + unit)[:120000], b"", b"x", bytes(rng.randrange(256) for _ in range(350000)),
+         open(%r, "rb").read()]
+for d in cases:
+    for level in (1, 9):
+        assert pkg.compress(d, level) == oracle.encode(d, level), (len(d), level)
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests", "golden", "sample1.ref"))
+    for val in ("0", "1"):
+        env = dict(os.environ, BZ_MAILBOX=val)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and out.stdout.strip().endswith("ok"), val + out.stdout[-500:] + out.stderr[-3000:]
+
+
 def test_period_round_in_mixed_batches(pkg, oracle):
     """A batch in which every third block is a deep repeat (text, text, a 4 KiB paragraph repeated, ...): the period
     round is triggered by the BLOCKS that need it (round 4; rounds 1-3 looked at the batch as a whole, which such a
