@@ -567,7 +567,7 @@ int run_bwt(hipStream_t st, const BwtArgs &a, u32 max_n, u64 total_n, unsigned l
             u64 *sorted_elems, KernelProf *prof, u64 *round_active /*[64] or null*/, bool wide_keys,
             u32 min_chars);
 void launch_mtf(hipStream_t st, const MtfArgs &a);
-bool env_verify(); // BZ_VERIFY=1: the self-check for every context and engine of the process (k_emit.hip)
+inline bool env_verify() { return getenv("BZ_VERIFY") && atoi(getenv("BZ_VERIFY")) != 0; } // the self-check for every context and engine of the process
 // a few bytes for the host between launches (k_emit.hip): up to four device ranges, 0 = they are there and the stream's
 // earlier work is done
 struct MailSeg {

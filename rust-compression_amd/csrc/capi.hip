@@ -23,6 +23,7 @@ namespace bzgpu {
 typedef uint8_t u8;
 typedef uint32_t u32;
 typedef uint64_t u64;
+inline bool env_verify() { return false; } // (bzgpu.h: BZ_VERIFY; the stub engine has no self-check)
 } // namespace bzgpu
 #else
 #include "bzgpu.h"

@@ -157,10 +157,6 @@ __global__ __launch_bounds__(256) void k_poke(u8 *dst, PokeBytes pb, u32 n)
         for (u32 b = i * 4u; b < n && b < i * 4u + 4u; ++b) dst[b] = (u8)(pb.w[i] >> (8u * (b & 3u)));
     }
 }
-bool env_verify()
-{
-    return getenv("BZ_VERIFY") && atoi(getenv("BZ_VERIFY")) != 0;
-}
 static bool mailbox_off() // BZ_MAILBOX=0 (tests): hipMemcpyAsync + hipStreamSynchronize as in rounds 1-5, same bytes
 {
     static const bool off = getenv("BZ_MAILBOX") && atoi(getenv("BZ_MAILBOX")) == 0;
@@ -235,6 +231,9 @@ int mail_fetch(hipStream_t st, const MailSeg *segs, int nseg)
     const auto t0 = std::chrono::steady_clock::now();
     u32 spins = 0;
     while (__atomic_load_n(m->hseq, __ATOMIC_ACQUIRE) != s) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause(); // (the sibling hardware thread may be the caller's copy thread)
+#endif
         if ((++spins & 0x3FFFFu) == 0) { // every ~ms: a stream that has failed or gone idle without the word will never raise it
             const hipError_t q = hipStreamQuery(st);
             if (q != hipSuccess && q != hipErrorNotReady) return -1;
