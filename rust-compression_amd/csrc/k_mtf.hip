@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256) void k_mtf_chunk_starts(MtfArgs a)
 // stay in step (the list walk above costs each step the LARGEST rank among its lanes).  The table
 // lives in LDS as [pair of symbols][lane] 2 x i16: conflict-free, 48 KiB for <= 96 symbols.
 constexpr u32 kMtfSmallPairs = kMtfSmallAlpha / 2;
+constexpr u32 kMtfSubBlocks = 16; // batches of up to this many blocks: SUB = 8 (k_mtf_ranks_small)
 typedef short short2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ short2_t as_short2(u32 v)
 {
@@ -241,14 +242,19 @@ __device__ __forceinline__ short2_t as_short2(u32 v)
 // 3.4 ms for ONE 98 KB block of the reference's sample1 (193 lanes with 512 symbols each, 6.7 us per symbol).  The
 // compares are independent reads that the LDS pipelines: its bandwidth, not its latency, is what they cost.
 // LANES chunks per workgroup, at most 2 * PAIRS symbols; the instance takes the blocks with ALPHA_LO < alpha <= 2 * PAIRS.
-template <u32 PAIRS, u32 LANES, u32 ALPHA_LO>
+// SUB (round 6: a few blocks alone -- one 98 KB block of 256 symbols is 193 chunks, 0.6 ms of 512 dependent symbols on
+// four waves): SUB neighbouring lanes share a chunk, each compares every SUB-th pair of the table and the partial counts
+// are added across the lanes (the lanes of a chunk sit in one wave: they run in lockstep, the LDS serves them in order).
+template <u32 PAIRS, u32 LANES, u32 ALPHA_LO, u32 SUB = 1>
 __global__ __launch_bounds__(LANES) void k_mtf_ranks_small(MtfArgs a)
 {
-    __shared__ u32 s_last[PAIRS * LANES];
+    constexpr u32 CL = LANES / SUB; // chunks per workgroup = columns of the table
+    __shared__ u32 s_last[PAIRS * CL];
     __shared__ u8 s_code[256];
     const u32 lb = blockIdx.y;
     const u32 n = a.blocks[lb].n;
-    const u32 chunk0 = blockIdx.x * LANES;
+    const u32 chunk0 = blockIdx.x * CL;
+    const u32 sub = threadIdx.x % SUB;
     if (chunk0 * kMtfChunk >= n) return;
     const u32 *bits = a.inuse_bits + lb * 8;
     const u32 alpha = popc8(bits);
@@ -260,27 +266,35 @@ __global__ __launch_bounds__(LANES) void k_mtf_ranks_small(MtfArgs a)
         s_code[v] = (u8)before;
     }
     __syncthreads();
-    const u32 chunk = chunk0 + threadIdx.x;
+    const u32 chunk = chunk0 + threadIdx.x / SUB;
     const u32 beg = chunk * kMtfChunk;
     if (beg >= n) return;
     const u32 end = (beg + kMtfChunk < n) ? beg + kMtfChunk : n;
     const u32 npairs = (alpha + 1u) >> 1;
-    u32 *my = s_last + threadIdx.x;
+    u32 *my = s_last + threadIdx.x / SUB;
     // (the compare loop below runs over blocks of 16 pairs: the rows behind the alphabet's last pair hold "never seen" too)
     constexpr u32 kPB = 32; // pairs per block of the pipelined compare loop (two blocks per trip)
     static_assert(PAIRS % (2u * kPB) == 0 || PAIRS <= kMtfSmallPairs, "the compare loop takes the table two blocks at a time");
     const u32 npairs16 = ((npairs + 2u * kPB - 1u) / (2u * kPB) * (2u * kPB)) < PAIRS ? ((npairs + 2u * kPB - 1u) / (2u * kPB) * (2u * kPB)) : PAIRS;
-    for (u32 q = 0; q < npairs16; ++q) my[q * LANES] = 0x80008000u; // both halves: -32768 = never seen
-    {
+    for (u32 q = sub; q < (SUB > 1 ? PAIRS : npairs16); q += SUB) my[q * CL] = 0x80008000u; // both halves: -32768 = never seen
+    if (SUB > 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (sub == 0) {
         // start list -> times -1, -2, ...
         const u8 *st = a.init_state + ((size_t)lb * kMaxMtfChunks + chunk) * 256u;
         for (u32 q = 0; q < alpha; ++q) {
             const u32 c = s_code[st[q]];
             const u32 t = (u32)(0xFFFFu - q) & 0xFFFFu; // (i16)(-1 - q)
-            u32 wd = my[(c >> 1) * LANES];
+            u32 wd = my[(c >> 1) * CL];
             wd = (c & 1u) ? ((wd & 0x0000FFFFu) | (t << 16)) : ((wd & 0xFFFF0000u) | t);
-            my[(c >> 1) * LANES] = wd;
+            my[(c >> 1) * CL] = wd;
         }
+    }
+    if (SUB > 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
     }
     const u8 *L = a.L + (size_t)lb * kSlot;
     u8 *R8 = a.rank8 + (size_t)lb * kSlot;
@@ -308,45 +322,57 @@ __global__ __launch_bounds__(LANES) void k_mtf_ranks_small(MtfArgs a)
             u32 rank = 0;
             if (p0 + k < end) {
                 const u32 c = s_code[(wv[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
-                const u32 wc = my[(c >> 1) * LANES];
+                const u32 wc = my[(c >> 1) * CL];
                 const u32 lsu = (c & 1u) ? (wc >> 16) : (wc & 0xFFFFu);
                 // both halves of a table word against the symbol's own time in packed 16-bit arithmetic:
                 // ls - t saturates (a never-seen -32768 must not wrap), its sign says t > ls
                 const short2_t ls2 = as_short2(lsu | (lsu << 16));
                 short2_t acc = {0, 0};
-              if (PAIRS > kMtfSmallPairs) { // (<= 96 symbols: three workgroups per CU hide the wait already; measured slower with it: 2.02 -> 2.27 ms per 256 MiB of text)
+              if (SUB == 1 && PAIRS > kMtfSmallPairs) { // (<= 96 symbols: three workgroups per CU hide the wait already; measured slower with it: 2.02 -> 2.27 ms per 256 MiB of text)
                 // Round 5: the table rows of the NEXT eight pairs are on their way while the eight at hand are compared -- the
                 // compiler's loop asked for eight rows, waited for them and compared them, one wave per SIMD with nothing to hide
                 // the wait behind (64 KB of LDS per 128 lanes): 7.3 ms per 256 MiB of random bytes, 200 cycles per eight pairs of
                 // which 96 were arithmetic.
                 u32 ra[kPB], rb[kPB];
 #pragma unroll
-                for (u32 e = 0; e < kPB; ++e) ra[e] = my[e * LANES];
+                for (u32 e = 0; e < kPB; ++e) ra[e] = my[e * CL];
                 for (u32 q = 0; q < npairs16; q += 2u * kPB) {
 #pragma unroll
-                    for (u32 e = 0; e < kPB; ++e) rb[e] = my[(q + kPB + e) * LANES];
+                    for (u32 e = 0; e < kPB; ++e) rb[e] = my[(q + kPB + e) * CL];
 #pragma unroll
                     for (u32 e = 0; e < kPB; ++e) acc -= __builtin_elementwise_sub_sat(ls2, as_short2(ra[e])) >> (short2_t){15, 15};
                     // (the last trip asks for the table's first rows again: never used)
                     const u32 qn = (q + 2u * kPB < npairs16) ? q + 2u * kPB : 0u;
 #pragma unroll
-                    for (u32 e = 0; e < kPB; ++e) ra[e] = my[(qn + e) * LANES];
+                    for (u32 e = 0; e < kPB; ++e) ra[e] = my[(qn + e) * CL];
 #pragma unroll
                     for (u32 e = 0; e < kPB; ++e) acc -= __builtin_elementwise_sub_sat(ls2, as_short2(rb[e])) >> (short2_t){15, 15};
                 }
+              } else if (SUB > 1) { // this lane's PAIRS / SUB rows, all asked for at once (a loop that waits for each row is 820 us
+                // for sample1's block, the one-lane form 600)
+                constexpr u32 PER = PAIRS / SUB;
+                u32 ra[PER];
+#pragma unroll
+                for (u32 e = 0; e < PER; ++e) ra[e] = my[(sub * PER + e) * CL];
+#pragma unroll
+                for (u32 e = 0; e < PER; ++e) acc -= __builtin_elementwise_sub_sat(ls2, as_short2(ra[e])) >> (short2_t){15, 15};
               } else
                 for (u32 q = 0; q < npairs; ++q) {
-                    const short2_t wd = as_short2(my[q * LANES]);
+                    const short2_t wd = as_short2(my[q * CL]);
                     const short2_t neg = __builtin_elementwise_sub_sat(ls2, wd) >> (short2_t){15, 15}; // -1 where t > ls
                     acc -= neg;
                 }
                 rank = (u32)(int)acc.x + (u32)(int)acc.y;
+                if (SUB > 1) { // the chunk's lanes add up what each counted
+#pragma unroll
+                    for (u32 d = 1; d < SUB; d <<= 1) rank += (u32)__shfl_xor((int)rank, (int)d, 64);
+                }
                 const u32 t = (v * 16u + k) & 0xFFFFu; // time inside the chunk, 0..kMtfChunk-1
-                my[(c >> 1) * LANES] = (c & 1u) ? ((wc & 0x0000FFFFu) | (t << 16)) : ((wc & 0xFFFF0000u) | t);
+                if (sub == 0) my[(c >> 1) * CL] = (c & 1u) ? ((wc & 0x0000FFFFu) | (t << 16)) : ((wc & 0xFFFF0000u) | t);
             }
             ov[k >> 2] |= rank << ((k & 3) * 8);
         }
-        *reinterpret_cast<uint4 *>(R8 + p0) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+        if (sub == 0) *reinterpret_cast<uint4 *>(R8 + p0) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
       }
     }
 }
@@ -742,8 +768,13 @@ void launch_mtf(hipStream_t st, const MtfArgs &a)
     hipLaunchKernelGGL(k_mtf_chunk_starts, dim3(kMtfGroups, a.nb), dim3(256), 0, st, a);
     // ranks: the compare form for every alphabet (<= 96 symbols: 256 chunks per workgroup; more: 128 -- the list walk of
     // rounds 1-3 took 21.0 ms per 256 MiB of random bytes against 8.9: DESIGN.md section 4)
-    hipLaunchKernelGGL((k_mtf_ranks_small<kMtfSmallPairs, 256, 0>), dim3(kChunkWGs, a.nb), dim3(256), 0, st, a);
-    hipLaunchKernelGGL((k_mtf_ranks_small<128, 128, kMtfSmallAlpha>), dim3((kMaxMtfChunks + 127) / 128, a.nb), dim3(128), 0, st, a);
+    if (a.nb <= kMtfSubBlocks) { // a few blocks alone: eight lanes per chunk (one 98 KB block of 256 symbols: 600 -> 224 us; SUB = 4: 263)
+        hipLaunchKernelGGL((k_mtf_ranks_small<kMtfSmallPairs, 256, 0, 8>), dim3((kMaxMtfChunks + 31) / 32, a.nb), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_mtf_ranks_small<128, 128, kMtfSmallAlpha, 8>), dim3((kMaxMtfChunks + 15) / 16, a.nb), dim3(128), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((k_mtf_ranks_small<kMtfSmallPairs, 256, 0>), dim3(kChunkWGs, a.nb), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_mtf_ranks_small<128, 128, kMtfSmallAlpha>), dim3((kMaxMtfChunks + 127) / 128, a.nb), dim3(128), 0, st, a);
+    }
     if (a.fused_zle) {
         (void)hipMemsetAsync(a.zstate, 0, (size_t)a.nb * kTilesPerBlock * 16, st);
         (void)hipMemsetAsync(a.ztick, 0, 64, st);
