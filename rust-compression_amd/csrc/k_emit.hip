@@ -187,7 +187,7 @@ static Mailbox *mailbox_of(hipStream_t st)
     if (it != boxes.end()) return it->second;
     Mailbox *m = new Mailbox;
     void *p = nullptr;
-    if (hipHostMalloc(&p, kMailCap + 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+    if (hipHostMalloc(&p, kMailCap + 64, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) {
         delete m;
         return nullptr;
     }
